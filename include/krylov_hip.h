@@ -1,0 +1,223 @@
+/*
+ * krylov_hip.h -- C ABI of libkrylov_hip.so: the MI355X (gfx950) Krylov `expand!` hot path
+ * behind KrylovKit.jl's eigsolve / linsolve / svdsolve.
+ *
+ * KrylovKit has no FFI registry; its extension seam is Julia multiple dispatch on the vector
+ * type T of OrthonormalBasis{T} and on the operator.  Each entry point below
+ * names the reference method (file:line under /root/reference) that a `HipVec`-specialised
+ * Julia method would forward to with `ccall((:kk_xxx, "libkrylov_hip"), Cint, (...), ...)`;
+ * the bindings are spelled out in INTEGRATION.md / julia/KrylovKitHIP.jl.
+ *
+ * Conventions (modelled on the reference's only real FFI, the LAPACK ccalls in
+ * src/dense/linalg.jl:428-454): caller-owned host buffers passed by pointer, every function
+ * returns an int status (0 = OK, <0 = error; text via kk_last_error()), dimension errors are
+ * reported before any work is queued (the shim turns KK_ERR_DIM into DimensionMismatch).
+ *
+ * Data model.  All scalars are IEEE binary64 (the north-star dtype); complex is out of scope.
+ *   - A *basis* is one contiguous HBM slab of `capacity` columns, column-major, leading
+ *     dimension ld >= n (ld is a multiple of 512 rows and ld/512 is odd so that equal row
+ *     offsets in different columns do not alias onto the same HBM channel; rows n..ld-1 of every
+ *     column are kept zero by every kernel).  A "vector" is (basis, column index).  This replaces
+ *     OrthonormalBasis{T} = Vector{T} of separately allocated vectors (src/orthonormal.jl:26-54):
+ *     push!/pop!/resize! become host-side integer bookkeeping.
+ *   - Calls that return a host scalar are synchronous on return.  All other calls are
+ *     stream-ordered on the context's HIP stream (kk_ctx_set_stream lets the caller share
+ *     torch's / RCCL's stream so collectives interleave without host syncs).
+ *   - One context = one GPU = one calling thread at a time (the reference's threaded kernels
+ *     are fork-join inside one call, src/orthonormal.jl:95-105; no concurrent entry).
+ *   - Column indices, counts: int (0-based).  Row counts: int64_t.
+ */
+#ifndef KRYLOV_HIP_H
+#define KRYLOV_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KK_VERSION 100 /* 0.1.0 */
+
+/* status codes */
+#define KK_OK 0
+#define KK_ERR_INVALID (-1)     /* bad handle / argument */
+#define KK_ERR_DIM (-2)         /* DimensionMismatch (src/orthonormal.jl:93,140,296) */
+#define KK_ERR_HIP (-3)         /* HIP runtime failure, see kk_last_error() */
+#define KK_ERR_NOMEM (-4)
+#define KK_ERR_ZERO_NORM (-5)   /* "initial vector should not have norm zero" (factorizations/lanczos.jl:184) */
+#define KK_ERR_UNSUPPORTED (-6)
+#define KK_ERR_NO_DEVICE (-7)   /* no gfx950 device visible: the product never falls back to CPU */
+
+typedef struct kk_ctx_s* kk_ctx;
+typedef struct kk_basis_s* kk_basis;
+typedef struct kk_op_s* kk_op;
+
+/* Orthogonalizer hierarchy, src/algorithms.jl:17-80.  eta is only read for the *IR variants
+ * (default 1/sqrt(2), algorithms.jl:66,80). */
+typedef enum {
+    KK_CGS = 0,   /* ClassicalGramSchmidt   */
+    KK_MGS = 1,   /* ModifiedGramSchmidt    */
+    KK_CGS2 = 2,  /* ClassicalGramSchmidt2  */
+    KK_MGS2 = 3,  /* ModifiedGramSchmidt2 (KrylovDefaults.orth, algorithms.jl:556) */
+    KK_CGSIR = 4, /* ClassicalGramSchmidtIR */
+    KK_MGSIR = 5  /* ModifiedGramSchmidtIR  */
+} kk_orth_t;
+
+/* How the MGS family is executed on the device (kk_ctx_set_option("mgs_mode", v)):
+ *   0 = strict:   one fused axpy+dot kernel per basis vector, sequential as in
+ *                 src/orthonormal.jl:417-421 (32 N bytes / vector).
+ *   1 = lowsync:  algebraically identical MGS coefficients from ONE projection pass plus a
+ *                 triangular solve with the strictly-lower Gram matrix of the basis, maintained
+ *                 incrementally (16 N bytes / vector).  Default. */
+
+/* ---------------------------------------------------------------- library / context */
+int kk_version(void);
+const char* kk_last_error(void);
+int kk_device_count(int* count);
+int kk_ctx_create(int device, kk_ctx* out);
+int kk_ctx_destroy(kk_ctx ctx);
+int kk_ctx_set_stream(kk_ctx ctx, void* hip_stream); /* NULL -> the context's own stream */
+int kk_ctx_get_stream(kk_ctx ctx, void** hip_stream);
+int kk_ctx_sync(kk_ctx ctx);
+int kk_ctx_set_option(kk_ctx ctx, const char* key, double value);
+int kk_ctx_get_option(kk_ctx ctx, const char* key, double* value);
+/* elapsed GPU milliseconds between two HIP events recorded on the context stream (bench.py) */
+int kk_ctx_timer_start(kk_ctx ctx);
+int kk_ctx_timer_stop(kk_ctx ctx, double* ms);
+/* per-kernel-class HIP-event timing (roofline leg of bench.py): when enabled every launch of
+ * the named class is bracketed by events; totals are read back with kk_ctx_prof_get. */
+int kk_ctx_prof_enable(kk_ctx ctx, int on);
+int kk_ctx_prof_reset(kk_ctx ctx);
+int kk_ctx_prof_get(kk_ctx ctx, const char* kernel_class, double* total_ms, int64_t* launches);
+
+/* ---------------------------------------------------------------- basis slab
+ * replaces OrthonormalBasis{T} (src/orthonormal.jl:26-54) and the residual / work vectors of
+ * the factorizations (factorizations/lanczos.jl:31-37, arnoldi.jl:31-36, gkl.jl:31-38). */
+int kk_basis_create(kk_ctx ctx, int64_t n, int capacity, kk_basis* out);
+int kk_basis_free(kk_basis b);
+int kk_basis_info(kk_basis b, int64_t* n, int64_t* ld, int* capacity, void** device_ptr);
+int kk_basis_upload(kk_basis b, int col, const double* host);   /* x0 in  (eigsolve/eigsolve.jl:195-201) */
+int kk_basis_download(kk_basis b, int col, double* host);       /* Ritz vectors out (eigsolve/lanczos.jl:131-133) */
+/* same with device pointers (n contiguous doubles, e.g. a torch tensor's data_ptr) */
+int kk_basis_upload_device(kk_basis b, int col, const void* dptr);
+int kk_basis_download_device(kk_basis b, int col, void* dptr);
+
+/* ---------------------------------------------------------------- L1 vector verbs
+ * VectorInterface.jl verbs as the reference calls them: the un-fused
+ * fallback so that ANY KrylovKit algorithm runs on a HipVec. */
+int kk_vec_dot(kk_basis bx, int cx, kk_basis by, int cy, double* out);             /* inner(x,y) */
+int kk_vec_nrm2(kk_basis bx, int cx, double* out);                                 /* norm(x) */
+int kk_vec_axpby(kk_basis by, int cy, kk_basis bx, int cx, double a, double b);    /* add!!(y,x,a,b): y = b*y + a*x */
+int kk_vec_scal(kk_basis bx, int cx, double a);                                    /* scale!!(x,a) */
+int kk_vec_copy_scal(kk_basis by, int cy, kk_basis bx, int cx, double a);          /* scale!!(y,x,a) / scale(x,a) */
+int kk_vec_zero(kk_basis bx, int cx);                                              /* zerovector!! */
+int kk_vec_fill_random(kk_basis bx, int cx, uint64_t seed);                        /* rand! for x0 (uniform [0,1), counter-based, independent of launch shape) */
+
+/* ---------------------------------------------------------------- operators (src/apply.jl:1-19)
+ * kk_csc_create takes Julia's SparseMatrixCSC{Float64,Int64} arrays as they are
+ * (index_base = 1); kk_csr_create takes CSR with int64 row pointers and int32 columns.
+ * flags: bit0 = matrix is symmetric (A' * x uses A). */
+#define KK_OP_SYMMETRIC 1
+int kk_csr_create(kk_ctx ctx, int64_t nrows, int64_t ncols, int64_t nnz, const int64_t* rowptr,
+                  const int32_t* colind, const double* val, int index_base, int flags, kk_op* out);
+int kk_csc_create(kk_ctx ctx, int64_t nrows, int64_t ncols, int64_t nnz, const int64_t* colptr,
+                  const int64_t* rowval, const double* nzval, int index_base, int flags, kk_op* out);
+int kk_op_free(kk_op op);
+int kk_op_info(kk_op op, int64_t* nrows, int64_t* ncols, int64_t* nnz, int* format /*0=ELL,1=CSR*/,
+               int64_t* device_bytes);
+/* Row-sharded operators (one process per GPU): column indices >= n_local address a ghost
+ * buffer of n_ghost doubles the caller fills before each apply (halo rows / all-gathered x). */
+int kk_op_set_ghost(kk_op op, int64_t n_local_cols, int64_t n_ghost);
+int kk_op_ghost_ptr(kk_op op, int transpose, void** device_ptr);
+/* y = A*x (transpose=0: apply / apply_normal, apply.jl:1,14) or A'*x (apply_adjoint, apply.jl:15) */
+int kk_spmv(kk_op op, int transpose, kk_basis bx, int cx, kk_basis by, int cy);
+/* affine form apply(op, x, a0, a1) = a0*x + a1*A*x (apply.jl:4-11) */
+int kk_spmv_affine(kk_op op, kk_basis bx, int cx, kk_basis by, int cy, double a0, double a1);
+/* gather x[idx[i]] -> out[i] on device (packing halo/ghost send buffers) */
+int kk_gather(kk_basis bx, int cx, const int64_t* device_idx, int64_t count, void* device_out);
+
+/* ---------------------------------------------------------------- L2 basis operations
+ * (src/orthonormal.jl).  The basis vectors addressed are columns c0 .. c0+m-1 of `b`. */
+/* project!!  y[j] = beta*y[j] + alpha*inner(b[c0+j], x)   (orthonormal.jl:88-118) */
+int kk_project(kk_basis b, int c0, int m, kk_basis bx, int cx, double alpha, double beta, double* y);
+/* unproject!! y = beta*y + alpha*sum_j b[c0+j]*x[j]        (orthonormal.jl:132-196); also
+ * Base.:*(b, x) (orthonormal.jl:57-60) and the GMRES x-update (linsolve/gmres.jl:105-108). */
+int kk_unproject(kk_basis by, int cy, kk_basis b, int c0, int m, const double* x, double alpha, double beta);
+/* rank1update! b[c0+j] = beta*b[c0+j] + alpha*y*conj(x[j]) (orthonormal.jl:210-275) */
+int kk_rank1update(kk_basis b, int c0, int m, kk_basis by, int cy, const double* x, double alpha, double beta);
+/* basistransform! b[c0+j] <- sum_i b[c0+i]*U[i,j], i<m, j<n; U column-major, ldu >= m
+ * (orthonormal.jl:291-354); columns c0+n .. c0+m-1 keep their old contents. */
+int kk_basistransform(kk_basis b, int c0, int m, int n, const double* U, int ldu);
+/* rmul!(b, G::Givens): (q1,q2) <- (c*q1 - s*q2, s*q1 + c*q2)   (dense/givens.jl:12-36) */
+int kk_givens_rmul(kk_basis b, int i1, int i2, double c, double s);
+/* rmul!(b, H::Householder) over columns c0..c0+m-1 (dense/reflector.jl:143-154):
+ * w = sum_j b[c0+j]*v[j]; b[c0+j] -= beta*w*v[j].  One fused kernel (row-local). */
+int kk_householder_rmul(kk_basis b, int c0, int m, const double* v, double beta);
+/* orthogonalize!!(w, b, x, alg) (orthonormal.jl:378-452): w <- w - sum_j x[j] b[c0+j].
+ * x (m doubles, host) receives the coefficients, *nrm (optional) the norm of the result
+ * (it is a by-product of the last pass), *npasses the number of passes over the basis. */
+int kk_orthogonalize(kk_basis b, int c0, int m, kk_basis bw, int cw, kk_orth_t alg, double eta,
+                     double* x, double* nrm, int* npasses);
+/* orthonormalize!! (orthonormal.jl:522-527): as above, then w <- w/nrm. */
+int kk_orthonormalize(kk_basis b, int c0, int m, kk_basis bw, int cw, kk_orth_t alg, double eta,
+                      double* x, double* nrm, int* npasses);
+/* orthogonalize!!(v, q, alg) vector-vs-vector variants (orthonormal.jl:455-489) */
+int kk_orthogonalize_vec(kk_basis bq, int cq, kk_basis bw, int cw, kk_orth_t alg, double eta,
+                         double* s, double* nrm);
+/* Gram-matrix bookkeeping for mgs_mode=1: tell the library that columns c0.. of `b` changed
+ * other than through the fused expands (basistransform, upload, ...). */
+int kk_basis_invalidate_gram(kk_basis b);
+
+/* ---------------------------------------------------------------- L3 fused expand! steps
+ * One call = one `expand!` = one operator application (the reference's `numops` unit,
+ * eigsolve/lanczos.jl:79).  One host synchronisation at the end (alpha, beta, h are needed on
+ * the host every iteration: eigsolve/lanczos.jl:34-45, linsolve/gmres.jl:55); the *IR variants
+ * add one per extra pass because the loop condition lives on the host side of the reference too.
+ */
+
+/* Lanczos expand! (factorizations/lanczos.jl:250-272) + lanczosrecurrence (:295-376).
+ * On entry columns c0..c0+k-1 hold V and column c0+k holds the residual r with |r| = beta_old.
+ * On return column c0+k holds v_{k+1} = r/beta_old and column c0+k+1 the new residual.
+ * For keepvecs=false (only CGS/MGS, lanczos.jl:140-142) pass k = min(k,1): only V[end-1] is read. */
+int kk_lanczos_expand(kk_op op, kk_basis b, int c0, int k, kk_orth_t orth, double eta,
+                      double beta_old, double* alpha, double* beta, int* npasses);
+/* Lanczos initialize (factorizations/lanczos.jl:180-222): column c0 holds x0 on entry; on
+ * return column c0 = v1, column c0+1 = r. */
+int kk_lanczos_initialize(kk_op op, kk_basis b, int c0, kk_orth_t orth, double eta,
+                          double* alpha, double* beta);
+
+/* Arnoldi expand! (factorizations/arnoldi.jl:199-219) + arnoldirecurrence!! (:239-245).
+ * Columns as for Lanczos.  h receives the k+1 new Hessenberg entries H[1:k+1, k+1]
+ * (the packed column, dense/packedhessenberg.jl:32-48); *beta = |r|. */
+int kk_arnoldi_expand(kk_op op, kk_basis b, int c0, int k, kk_orth_t orth, double eta,
+                      double beta_old, double* h, double* beta, int* npasses);
+/* Arnoldi initialize (arnoldi.jl:135-175); identical arithmetic to the Lanczos one. */
+int kk_arnoldi_initialize(kk_op op, kk_basis b, int c0, kk_orth_t orth, double eta,
+                          double* alpha, double* beta);
+
+/* GKL expand! (factorizations/gkl.jl:246-269) + gklrecurrence (:294-404).
+ * U-basis bu: columns 0..k-1 = U, column k = r (|r| = beta_old).  V-basis bv: columns 0..k-1 = V.
+ * On return bu column k = u_{k+1}, bu column k+1 = new r, bv column k = v_{k+1}. */
+int kk_gkl_expand(kk_op op, kk_basis bu, kk_basis bv, int k, kk_orth_t orth, double eta,
+                  double beta_old, double* alpha, double* beta, int* npasses_v, int* npasses_u);
+/* GKL initialize (gkl.jl:183-215): bu column 0 holds u0 on entry. */
+int kk_gkl_initialize(kk_op op, kk_basis bu, kk_basis bv, double* alpha, double* beta);
+
+/* ---------------------------------------------------------------- split-phase pieces for
+ * row-sharded (multi-GPU) runs: partial coefficients stay on the device so the caller can
+ * all-reduce them in place (RCCL on the same stream) between the two halves of a pass.
+ * The scalar workspace is one contiguous device array of kk_ws_size() doubles. */
+int kk_ws_ptr(kk_ctx ctx, void** device_ptr, int64_t* count);
+/* ws[off+j] = sum over local rows of b[c0+j][row]*x[row]  (j<m) */
+int kk_project_dev(kk_basis b, int c0, int m, kk_basis bx, int cx, int64_t ws_off);
+/* y <- y - sum_j ws[off+j] b[c0+j];  ws[nrm_off .. +2] = local |y|^2, its sqrt, 1/sqrt (if nrm_off >= 0) */
+int kk_unproject_dev(kk_basis by, int cy, kk_basis b, int c0, int m, int64_t ws_off, int64_t nrm_off);
+int kk_dot_dev(kk_basis bx, int cx, kk_basis by, int cy, int64_t ws_off);          /* ws[off] = local <x,y> */
+int kk_axpy_dev(kk_basis by, int cy, kk_basis bx, int cx, int64_t ws_off, double sign); /* y += sign*ws[off]*x */
+int kk_ws_read(kk_ctx ctx, int64_t off, int64_t count, double* host);              /* sync */
+int kk_ws_write(kk_ctx ctx, int64_t off, int64_t count, const double* host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KRYLOV_HIP_H */

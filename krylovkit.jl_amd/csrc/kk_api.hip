@@ -1,0 +1,1323 @@
+// C ABI of libkrylov_hip.so (see include/krylov_hip.h): contexts, basis slabs, sparse operators,
+// the L1/L2 verbs and the fused L3 expand! steps.  Host-side C++ only orchestrates kernel
+// launches on one HIP stream; there is NO CPU compute fallback anywhere in this file.
+#include "kk_internal.h"
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+
+static thread_local std::string g_last_error;
+
+void kk_set_error(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+}
+int kk_hip_fail(hipError_t e, const char* what, const char* file, int line) {
+    kk_set_error("HIP error %d (%s) in %s at %s:%d", (int)e, hipGetErrorString(e), what, file, line);
+    return KK_ERR_HIP;
+}
+
+static const double KK_EPS = std::numeric_limits<double>::epsilon();
+
+// ------------------------------------------------------------------------------------------
+// library / context
+// ------------------------------------------------------------------------------------------
+extern "C" int kk_version(void) { return KK_VERSION; }
+extern "C" const char* kk_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" int kk_device_count(int* count) {
+    KK_CHECK(count, KK_ERR_INVALID, "kk_device_count: null pointer");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        n = 0;
+    }
+    *count = n;
+    return KK_OK;
+}
+
+extern "C" int kk_ctx_create(int device, kk_ctx* out) {
+    KK_CHECK(out, KK_ERR_INVALID, "kk_ctx_create: null out");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        kk_set_error("kk_ctx_create: no HIP device visible; libkrylov_hip has no CPU fallback");
+        return KK_ERR_NO_DEVICE;
+    }
+    KK_CHECK(device >= 0 && device < n, KK_ERR_INVALID, "kk_ctx_create: device %d out of range [0,%d)", device, n);
+    KK_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    KK_HIP(hipGetDeviceProperties(&prop, device));
+    kk_ctx c = new kk_ctx_s();
+    c->device = device;
+    c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    KK_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    KK_HIP(hipMalloc(&c->ws, WS_TOTAL * sizeof(double)));
+    KK_HIP(hipMemset(c->ws, 0, WS_TOTAL * sizeof(double)));
+    KK_HIP(hipMalloc(&c->partials, (size_t)(2 * KK_MAX_M + 8) * KK_MAX_BLOCKS * sizeof(double)));
+    KK_HIP(hipHostMalloc(&c->h_pin, 4 * WS_TOTAL * sizeof(double), hipHostMallocDefault));
+    KK_HIP(hipHostMalloc(&c->h_U, (size_t)KK_MAX_M * KK_MAX_M * sizeof(double), hipHostMallocDefault));
+    KK_HIP(hipEventCreate(&c->t0));
+    KK_HIP(hipEventCreate(&c->t1));
+    const char* env = getenv("KK_BLOCKS_PER_CU");
+    if (env && atoi(env) > 0) c->blocks_per_cu = atoi(env);
+    env = getenv("KK_MGS_MODE");
+    if (env) c->mgs_mode = atoi(env);
+    *out = c;
+    return KK_OK;
+}
+
+extern "C" int kk_ctx_destroy(kk_ctx c) {
+    if (!c) return KK_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& p : c->prof_pending) { c->event_pool.push_back(p.second.first); c->event_pool.push_back(p.second.second); }
+    for (auto e : c->event_pool) (void)hipEventDestroy(e);
+    (void)hipEventDestroy(c->t0);
+    (void)hipEventDestroy(c->t1);
+    (void)hipFree(c->ws);
+    (void)hipFree(c->partials);
+    (void)hipHostFree(c->h_pin);
+    (void)hipHostFree(c->h_U);
+    (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return KK_OK;
+}
+
+extern "C" int kk_ctx_set_stream(kk_ctx c, void* s) {
+    KK_CHECK(c, KK_ERR_INVALID, "null ctx");
+    KK_HIP(hipStreamSynchronize(c->stream));
+    c->stream = s ? (hipStream_t)s : c->own_stream;
+    return KK_OK;
+}
+extern "C" int kk_ctx_get_stream(kk_ctx c, void** s) {
+    KK_CHECK(c && s, KK_ERR_INVALID, "null arg");
+    *s = (void*)c->stream;
+    return KK_OK;
+}
+extern "C" int kk_ctx_sync(kk_ctx c) {
+    KK_CHECK(c, KK_ERR_INVALID, "null ctx");
+    KK_HIP(hipStreamSynchronize(c->stream));
+    return KK_OK;
+}
+extern "C" int kk_ctx_set_option(kk_ctx c, const char* key, double value) {
+    KK_CHECK(c && key, KK_ERR_INVALID, "null arg");
+    if (!strcmp(key, "blocks_per_cu")) {
+        KK_CHECK(value >= 1 && value * c->num_cus <= KK_MAX_BLOCKS, KK_ERR_INVALID, "blocks_per_cu out of range");
+        c->blocks_per_cu = (int)value;
+    } else if (!strcmp(key, "mgs_mode")) {
+        KK_CHECK(value == 0 || value == 1, KK_ERR_INVALID, "mgs_mode must be 0 (strict) or 1 (lowsync)");
+        c->mgs_mode = (int)value;
+    } else {
+        kk_set_error("unknown option '%s'", key);
+        return KK_ERR_INVALID;
+    }
+    return KK_OK;
+}
+extern "C" int kk_ctx_get_option(kk_ctx c, const char* key, double* value) {
+    KK_CHECK(c && key && value, KK_ERR_INVALID, "null arg");
+    if (!strcmp(key, "blocks_per_cu")) *value = c->blocks_per_cu;
+    else if (!strcmp(key, "mgs_mode")) *value = c->mgs_mode;
+    else if (!strcmp(key, "num_cus")) *value = c->num_cus;
+    else {
+        kk_set_error("unknown option '%s'", key);
+        return KK_ERR_INVALID;
+    }
+    return KK_OK;
+}
+extern "C" int kk_ctx_timer_start(kk_ctx c) {
+    KK_CHECK(c, KK_ERR_INVALID, "null ctx");
+    KK_HIP(hipEventRecord(c->t0, c->stream));
+    return KK_OK;
+}
+extern "C" int kk_ctx_timer_stop(kk_ctx c, double* ms) {
+    KK_CHECK(c && ms, KK_ERR_INVALID, "null arg");
+    KK_HIP(hipEventRecord(c->t1, c->stream));
+    KK_HIP(hipEventSynchronize(c->t1));
+    float f = 0;
+    KK_HIP(hipEventElapsedTime(&f, c->t0, c->t1));
+    *ms = f;
+    return KK_OK;
+}
+
+// ---- per-kernel-class event profiling
+static hipEvent_t prof_event(kk_ctx c) {
+    if (!c->event_pool.empty()) {
+        hipEvent_t e = c->event_pool.back();
+        c->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+static void prof_resolve(kk_ctx c) {
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& p : c->prof_pending) {
+        float f = 0;
+        if (hipEventElapsedTime(&f, p.second.first, p.second.second) == hipSuccess) {
+            auto& e = c->prof_tab[p.first];
+            e.ms += f;
+            e.launches += 1;
+        }
+        c->event_pool.push_back(p.second.first);
+        c->event_pool.push_back(p.second.second);
+    }
+    c->prof_pending.clear();
+}
+void kk_prof_begin(kk_ctx c, const char* cls) {
+    hipEvent_t a = prof_event(c), b = prof_event(c);
+    (void)hipEventRecord(a, c->stream);
+    c->prof_pending.push_back({cls, {a, b}});
+}
+void kk_prof_end(kk_ctx c) {
+    if (c->prof_pending.empty()) return;
+    (void)hipEventRecord(c->prof_pending.back().second.second, c->stream);
+    if (c->prof_pending.size() > 8192) prof_resolve(c);
+}
+extern "C" int kk_ctx_prof_enable(kk_ctx c, int on) {
+    KK_CHECK(c, KK_ERR_INVALID, "null ctx");
+    if (!on && c->prof) prof_resolve(c);
+    c->prof = on != 0;
+    return KK_OK;
+}
+extern "C" int kk_ctx_prof_reset(kk_ctx c) {
+    KK_CHECK(c, KK_ERR_INVALID, "null ctx");
+    prof_resolve(c);
+    c->prof_tab.clear();
+    return KK_OK;
+}
+extern "C" int kk_ctx_prof_get(kk_ctx c, const char* cls, double* total_ms, int64_t* launches) {
+    KK_CHECK(c && cls, KK_ERR_INVALID, "null arg");
+    prof_resolve(c);
+    auto it = c->prof_tab.find(cls);
+    if (total_ms) *total_ms = it == c->prof_tab.end() ? 0.0 : it->second.ms;
+    if (launches) *launches = it == c->prof_tab.end() ? 0 : it->second.launches;
+    return KK_OK;
+}
+
+kk_part kk_partition(kk_ctx c, int64_t ld) {
+    const int64_t nsub = ld / KK_SUB;
+    int64_t target = (int64_t)c->num_cus * c->blocks_per_cu;
+    if (target > KK_MAX_BLOCKS) target = KK_MAX_BLOCKS;
+    if (target < 1) target = 1;
+    const int64_t spb = std::max<int64_t>(1, (nsub + target - 1) / target);
+    kk_part p;
+    p.rpb = spb * KK_SUB;
+    p.nblk = (int)std::max<int64_t>(1, (nsub + spb - 1) / spb);
+    return p;
+}
+
+// D2H fetch of `count` workspace doubles starting at `off` into pinned slot `slot` (queued; no sync)
+static int ws_fetch_async(kk_ctx c, int64_t off, int64_t count, int slot) {
+    KK_HIP(hipMemcpyAsync(c->h_pin + (int64_t)slot * WS_TOTAL + off, c->ws + off, count * sizeof(double),
+                          hipMemcpyDeviceToHost, c->stream));
+    return KK_OK;
+}
+static inline const double* pin(kk_ctx c, int64_t off, int slot = 0) { return c->h_pin + (int64_t)slot * WS_TOTAL + off; }
+static int stream_sync(kk_ctx c) {
+    KK_HIP(hipStreamSynchronize(c->stream));
+    return KK_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// basis slab
+// ------------------------------------------------------------------------------------------
+extern "C" int kk_basis_create(kk_ctx c, int64_t n, int capacity, kk_basis* out) {
+    KK_CHECK(c && out, KK_ERR_INVALID, "kk_basis_create: null arg");
+    KK_CHECK(n > 0 && capacity > 0, KK_ERR_INVALID, "kk_basis_create: n=%lld capacity=%d", (long long)n, capacity);
+    KK_HIP(hipSetDevice(c->device));
+    int64_t ld = (n + KK_SUB - 1) / KK_SUB * KK_SUB;
+    if (((ld / KK_SUB) & 1) == 0) ld += KK_SUB;  // odd number of 4 KiB row chunks per column: no channel aliasing
+    kk_basis b = new kk_basis_s();
+    b->ctx = c; b->n = n; b->ld = ld; b->cap = capacity;
+    size_t bytes = (size_t)ld * capacity * sizeof(double);
+    hipError_t e = hipMalloc(&b->d, bytes);
+    if (e != hipSuccess) {
+        delete b;
+        kk_set_error("kk_basis_create: hipMalloc of %zu bytes failed: %s", bytes, hipGetErrorString(e));
+        return KK_ERR_NOMEM;
+    }
+    KK_HIP(hipMemsetAsync(b->d, 0, bytes, c->stream));
+    *out = b;
+    return KK_OK;
+}
+extern "C" int kk_basis_free(kk_basis b) {
+    if (!b) return KK_OK;
+    (void)hipStreamSynchronize(b->ctx->stream);
+    (void)hipFree(b->d);
+    delete b;
+    return KK_OK;
+}
+extern "C" int kk_basis_info(kk_basis b, int64_t* n, int64_t* ld, int* capacity, void** dptr) {
+    KK_CHECK(b, KK_ERR_INVALID, "null basis");
+    if (n) *n = b->n;
+    if (ld) *ld = b->ld;
+    if (capacity) *capacity = b->cap;
+    if (dptr) *dptr = b->d;
+    return KK_OK;
+}
+#define CHECK_COL(b, c) KK_CHECK((b) && (c) >= 0 && (c) < (b)->cap, KK_ERR_INVALID, "%s: column %d out of range", __func__, (c))
+static inline void gram_touch(kk_basis b, int col) {
+    if (col < b->gram_rows) b->gram_rows = col;
+}
+extern "C" int kk_basis_invalidate_gram(kk_basis b) {
+    KK_CHECK(b, KK_ERR_INVALID, "null basis");
+    b->gram_rows = 0;
+    return KK_OK;
+}
+extern "C" int kk_basis_upload(kk_basis b, int col, const double* host) {
+    CHECK_COL(b, col);
+    KK_CHECK(host, KK_ERR_INVALID, "null host pointer");
+    gram_touch(b, col);
+    KK_HIP(hipMemcpyAsync(b->col(col), host, b->n * sizeof(double), hipMemcpyHostToDevice, b->ctx->stream));
+    return stream_sync(b->ctx);
+}
+extern "C" int kk_basis_download(kk_basis b, int col, double* host) {
+    CHECK_COL(b, col);
+    KK_CHECK(host, KK_ERR_INVALID, "null host pointer");
+    KK_HIP(hipMemcpyAsync(host, b->col(col), b->n * sizeof(double), hipMemcpyDeviceToHost, b->ctx->stream));
+    return stream_sync(b->ctx);
+}
+extern "C" int kk_basis_upload_device(kk_basis b, int col, const void* dptr) {
+    CHECK_COL(b, col);
+    gram_touch(b, col);
+    KK_HIP(hipMemcpyAsync(b->col(col), dptr, b->n * sizeof(double), hipMemcpyDeviceToDevice, b->ctx->stream));
+    return KK_OK;
+}
+extern "C" int kk_basis_download_device(kk_basis b, int col, void* dptr) {
+    CHECK_COL(b, col);
+    KK_HIP(hipMemcpyAsync(dptr, b->col(col), b->n * sizeof(double), hipMemcpyDeviceToDevice, b->ctx->stream));
+    return KK_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// L1 verbs
+// ------------------------------------------------------------------------------------------
+#define CHECK_SAME(bx, by) KK_CHECK((bx)->ctx == (by)->ctx && (bx)->n == (by)->n && (bx)->ld == (by)->ld, KK_ERR_DIM, "%s: vector length mismatch (%lld vs %lld)", __func__, (long long)(bx)->n, (long long)(by)->n)
+
+extern "C" int kk_vec_dot(kk_basis bx, int cx, kk_basis by, int cy, double* out) {
+    CHECK_COL(bx, cx); CHECK_COL(by, cy); CHECK_SAME(bx, by);
+    KK_CHECK(out, KK_ERR_INVALID, "null out");
+    kk_ctx c = bx->ctx;
+    KK_TRY(kk_launch_dot(c, bx->col(cx), by->col(cy), bx->ld, WS_SCAL + SC_DOT));
+    KK_TRY(ws_fetch_async(c, WS_SCAL + SC_DOT, 1, 0));
+    KK_TRY(stream_sync(c));
+    *out = *pin(c, WS_SCAL + SC_DOT);
+    return KK_OK;
+}
+extern "C" int kk_vec_nrm2(kk_basis bx, int cx, double* out) {
+    CHECK_COL(bx, cx);
+    KK_CHECK(out, KK_ERR_INVALID, "null out");
+    kk_ctx c = bx->ctx;
+    KK_TRY(kk_launch_nrm2(c, bx->col(cx), bx->ld, WS_SCAL + SC_NRM2));
+    KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2, 2, 0));
+    KK_TRY(stream_sync(c));
+    *out = pin(c, WS_SCAL + SC_NRM2)[1];
+    return KK_OK;
+}
+extern "C" int kk_vec_axpby(kk_basis by, int cy, kk_basis bx, int cx, double a, double b) {
+    CHECK_COL(bx, cx); CHECK_COL(by, cy); CHECK_SAME(bx, by);
+    gram_touch(by, cy);
+    return kk_launch_axpby(by->ctx, by->col(cy), bx->col(cx), by->ld, a, b, nullptr, 1.0, 0);
+}
+extern "C" int kk_vec_scal(kk_basis bx, int cx, double a) {
+    CHECK_COL(bx, cx);
+    gram_touch(bx, cx);
+    return kk_launch_scal(bx->ctx, bx->col(cx), bx->ld, a, nullptr);
+}
+extern "C" int kk_vec_copy_scal(kk_basis by, int cy, kk_basis bx, int cx, double a) {
+    CHECK_COL(bx, cx); CHECK_COL(by, cy); CHECK_SAME(bx, by);
+    gram_touch(by, cy);
+    return kk_launch_copy_scal(by->ctx, by->col(cy), bx->col(cx), by->ld, a);
+}
+extern "C" int kk_vec_zero(kk_basis bx, int cx) {
+    CHECK_COL(bx, cx);
+    gram_touch(bx, cx);
+    KK_HIP(hipMemsetAsync(bx->col(cx), 0, bx->ld * sizeof(double), bx->ctx->stream));
+    return KK_OK;
+}
+extern "C" int kk_vec_fill_random(kk_basis bx, int cx, uint64_t seed) {
+    CHECK_COL(bx, cx);
+    gram_touch(bx, cx);
+    return kk_launch_fill_random(bx->ctx, bx->col(cx), bx->n, seed);
+}
+
+// ------------------------------------------------------------------------------------------
+// operators
+// ------------------------------------------------------------------------------------------
+static void free_sparse(kk_sparse_dev& M) {
+    (void)hipFree(M.ell_col); (void)hipFree(M.ell_val);
+    (void)hipFree(M.rowptr); (void)hipFree(M.colind); (void)hipFree(M.val);
+    (void)hipFree(M.ghost);
+    M = kk_sparse_dev();
+}
+
+static int upload_sparse(kk_ctx c, const kk_host_csr& h, kk_sparse_dev& M) {
+    const int64_t nrows = h.nrows, nnz = h.rowptr[nrows];
+    M.nrows = nrows; M.ncols = h.ncols; M.nnz = nnz;
+    KK_CHECK(nnz < (int64_t)1 << 31, KK_ERR_UNSUPPORTED, "nnz >= 2^31 not supported (int32 row pointers on device)");
+    KK_CHECK(h.ncols < (int64_t)1 << 31 && nrows < (int64_t)1 << 31, KK_ERR_UNSUPPORTED, "dimension >= 2^31 not supported");
+    int64_t maxw = 0;
+    for (int64_t i = 0; i < nrows; ++i) maxw = std::max(maxw, h.rowptr[i + 1] - h.rowptr[i]);
+    const bool force_csr = getenv("KK_SPMV_FORMAT") && !strcmp(getenv("KK_SPMV_FORMAT"), "csr");
+    const bool force_ell = getenv("KK_SPMV_FORMAT") && !strcmp(getenv("KK_SPMV_FORMAT"), "ell");
+    const bool ell = !force_csr && (force_ell || (maxw <= 64 && (double)maxw * nrows <= 1.25 * (double)nnz + 4096));
+    if (ell) {
+        M.format = 0;
+        M.width = (int)std::max<int64_t>(maxw, 1);
+        M.ell_ld = (nrows + 63) / 64 * 64;
+        std::vector<int32_t> ec((size_t)M.ell_ld * M.width, 0);
+        std::vector<double> ev((size_t)M.ell_ld * M.width, 0.0);
+        for (int64_t i = 0; i < nrows; ++i) {
+            int k = 0;
+            for (int64_t p = h.rowptr[i]; p < h.rowptr[i + 1]; ++p, ++k) {
+                ec[(size_t)k * M.ell_ld + i] = h.col[p];
+                ev[(size_t)k * M.ell_ld + i] = h.val[p];
+            }
+        }
+        KK_HIP(hipMalloc(&M.ell_col, ec.size() * sizeof(int32_t)));
+        KK_HIP(hipMalloc(&M.ell_val, ev.size() * sizeof(double)));
+        KK_HIP(hipMemcpy(M.ell_col, ec.data(), ec.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        KK_HIP(hipMemcpy(M.ell_val, ev.data(), ev.size() * sizeof(double), hipMemcpyHostToDevice));
+        M.bytes = ec.size() * 4 + ev.size() * 8;
+    } else {
+        M.format = 1;
+        std::vector<int32_t> rp(nrows + 1);
+        for (int64_t i = 0; i <= nrows; ++i) rp[i] = (int32_t)h.rowptr[i];
+        KK_HIP(hipMalloc(&M.rowptr, (nrows + 1) * sizeof(int32_t)));
+        KK_HIP(hipMalloc(&M.colind, std::max<int64_t>(nnz, 1) * sizeof(int32_t)));
+        KK_HIP(hipMalloc(&M.val, std::max<int64_t>(nnz, 1) * sizeof(double)));
+        KK_HIP(hipMemcpy(M.rowptr, rp.data(), (nrows + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
+        KK_HIP(hipMemcpy(M.colind, h.col.data(), nnz * sizeof(int32_t), hipMemcpyHostToDevice));
+        KK_HIP(hipMemcpy(M.val, h.val.data(), nnz * sizeof(double), hipMemcpyHostToDevice));
+        const double avg = nrows ? (double)nnz / nrows : 1;
+        int L = 2;
+        while (L * 2 <= avg && L < 64) L *= 2;
+        M.lanes_per_row = L;
+        M.bytes = (nrows + 1) * 4 + nnz * 12;
+    }
+    return KK_OK;
+}
+
+static void transpose_csr(const kk_host_csr& a, kk_host_csr& t) {
+    t.nrows = a.ncols; t.ncols = a.nrows;
+    const int64_t nnz = a.rowptr[a.nrows];
+    t.rowptr.assign(t.nrows + 1, 0);
+    t.col.resize(nnz); t.val.resize(nnz);
+    for (int64_t p = 0; p < nnz; ++p) t.rowptr[a.col[p] + 1]++;
+    for (int64_t i = 0; i < t.nrows; ++i) t.rowptr[i + 1] += t.rowptr[i];
+    std::vector<int64_t> cur(t.rowptr.begin(), t.rowptr.end() - 1);
+    for (int64_t i = 0; i < a.nrows; ++i)
+        for (int64_t p = a.rowptr[i]; p < a.rowptr[i + 1]; ++p) {
+            const int64_t q = cur[a.col[p]]++;
+            t.col[q] = (int32_t)i;
+            t.val[q] = a.val[p];
+        }
+}
+
+extern "C" int kk_csr_create(kk_ctx c, int64_t nrows, int64_t ncols, int64_t nnz, const int64_t* rowptr,
+                             const int32_t* colind, const double* val, int index_base, int flags, kk_op* out) {
+    KK_CHECK(c && out && rowptr && (nnz == 0 || (colind && val)), KK_ERR_INVALID, "kk_csr_create: null arg");
+    KK_CHECK(nrows > 0 && ncols > 0 && nnz >= 0, KK_ERR_INVALID, "kk_csr_create: bad dimensions");
+    KK_CHECK(index_base == 0 || index_base == 1, KK_ERR_INVALID, "index_base must be 0 or 1");
+    KK_CHECK(rowptr[nrows] - index_base == nnz, KK_ERR_DIM, "kk_csr_create: rowptr[nrows] != nnz");
+    KK_HIP(hipSetDevice(c->device));
+    kk_op op = new kk_op_s();
+    op->ctx = c; op->nrows = nrows; op->ncols = ncols; op->nnz = nnz; op->flags = flags;
+    kk_host_csr& h = op->hA;
+    h.nrows = nrows; h.ncols = ncols;
+    h.rowptr.resize(nrows + 1);
+    for (int64_t i = 0; i <= nrows; ++i) h.rowptr[i] = rowptr[i] - index_base;
+    h.col.resize(nnz); h.val.assign(val, val + nnz);
+    for (int64_t p = 0; p < nnz; ++p) {
+        const int64_t cc = (int64_t)colind[p] - index_base;
+        if (cc < 0 || cc >= ncols) {
+            delete op;
+            kk_set_error("kk_csr_create: column index %lld out of range at entry %lld", (long long)cc, (long long)p);
+            return KK_ERR_DIM;
+        }
+        h.col[p] = (int32_t)cc;
+    }
+    int s = upload_sparse(c, h, op->A);
+    if (s != KK_OK) { free_sparse(op->A); delete op; return s; }
+    if (flags & KK_OP_SYMMETRIC) { kk_host_csr().rowptr.swap(h.rowptr); h.col.clear(); h.col.shrink_to_fit(); h.val.clear(); h.val.shrink_to_fit(); }
+    *out = op;
+    return KK_OK;
+}
+
+extern "C" int kk_csc_create(kk_ctx c, int64_t nrows, int64_t ncols, int64_t nnz, const int64_t* colptr,
+                             const int64_t* rowval, const double* nzval, int index_base, int flags, kk_op* out) {
+    KK_CHECK(c && out && colptr && (nnz == 0 || (rowval && nzval)), KK_ERR_INVALID, "kk_csc_create: null arg");
+    KK_CHECK(nrows > 0 && ncols > 0 && nnz >= 0, KK_ERR_INVALID, "kk_csc_create: bad dimensions");
+    KK_CHECK(index_base == 0 || index_base == 1, KK_ERR_INVALID, "index_base must be 0 or 1");
+    KK_CHECK(colptr[ncols] - index_base == nnz, KK_ERR_DIM, "kk_csc_create: colptr[ncols] != nnz");
+    KK_HIP(hipSetDevice(c->device));
+    // the CSC arrays of A are the CSR arrays of A'
+    kk_host_csr ht;
+    ht.nrows = ncols; ht.ncols = nrows;
+    ht.rowptr.resize(ncols + 1);
+    for (int64_t i = 0; i <= ncols; ++i) ht.rowptr[i] = colptr[i] - index_base;
+    ht.col.resize(nnz); ht.val.assign(nzval, nzval + nnz);
+    for (int64_t p = 0; p < nnz; ++p) {
+        const int64_t r = rowval[p] - index_base;
+        if (r < 0 || r >= nrows) {
+            kk_set_error("kk_csc_create: row index %lld out of range at entry %lld", (long long)r, (long long)p);
+            return KK_ERR_DIM;
+        }
+        ht.col[p] = (int32_t)r;
+    }
+    kk_op op = new kk_op_s();
+    op->ctx = c; op->nrows = nrows; op->ncols = ncols; op->nnz = nnz; op->flags = flags;
+    int s;
+    if (flags & KK_OP_SYMMETRIC) {
+        s = upload_sparse(c, ht, op->A);  // A == A'
+    } else {
+        transpose_csr(ht, op->hA);
+        s = upload_sparse(c, op->hA, op->A);
+        if (s == KK_OK) {
+            s = upload_sparse(c, ht, op->At);
+            op->have_At = (s == KK_OK);
+            kk_host_csr().rowptr.swap(op->hA.rowptr); op->hA.col.clear(); op->hA.val.clear();
+        }
+    }
+    if (s != KK_OK) { free_sparse(op->A); free_sparse(op->At); delete op; return s; }
+    *out = op;
+    return KK_OK;
+}
+
+extern "C" int kk_op_free(kk_op op) {
+    if (!op) return KK_OK;
+    (void)hipStreamSynchronize(op->ctx->stream);
+    free_sparse(op->A);
+    free_sparse(op->At);
+    delete op;
+    return KK_OK;
+}
+
+extern "C" int kk_op_info(kk_op op, int64_t* nrows, int64_t* ncols, int64_t* nnz, int* format, int64_t* bytes) {
+    KK_CHECK(op, KK_ERR_INVALID, "null op");
+    if (nrows) *nrows = op->nrows;
+    if (ncols) *ncols = op->ncols;
+    if (nnz) *nnz = op->nnz;
+    if (format) *format = op->A.format;
+    if (bytes) *bytes = op->A.bytes + op->At.bytes;
+    return KK_OK;
+}
+
+extern "C" int kk_op_set_ghost(kk_op op, int64_t n_local_cols, int64_t n_ghost) {
+    KK_CHECK(op, KK_ERR_INVALID, "null op");
+    KK_CHECK(n_local_cols >= 0 && n_ghost >= 0 && n_local_cols + n_ghost == op->ncols, KK_ERR_DIM,
+             "kk_op_set_ghost: n_local (%lld) + n_ghost (%lld) != ncols (%lld)", (long long)n_local_cols,
+             (long long)n_ghost, (long long)op->ncols);
+    (void)hipFree(op->A.ghost);
+    op->A.ghost = nullptr;
+    op->A.n_local = n_local_cols;
+    op->A.n_ghost = n_ghost;
+    if (n_ghost > 0) KK_HIP(hipMalloc(&op->A.ghost, n_ghost * sizeof(double)));
+    return KK_OK;
+}
+extern "C" int kk_op_ghost_ptr(kk_op op, int transpose, void** dptr) {
+    KK_CHECK(op && dptr, KK_ERR_INVALID, "null arg");
+    KK_CHECK(!transpose, KK_ERR_UNSUPPORTED, "ghost columns are only supported for the non-transposed apply");
+    *dptr = op->A.ghost;
+    return KK_OK;
+}
+
+static int get_matrix(kk_op op, int transpose, const kk_sparse_dev** M) {
+    if (!transpose || (op->flags & KK_OP_SYMMETRIC)) {
+        *M = &op->A;
+        return KK_OK;
+    }
+    if (!op->have_At) {
+        KK_CHECK(!op->hA.rowptr.empty(), KK_ERR_INVALID, "transpose requested but host copy is gone");
+        kk_host_csr ht;
+        transpose_csr(op->hA, ht);
+        KK_TRY(upload_sparse(op->ctx, ht, op->At));
+        op->have_At = true;
+        kk_host_csr().rowptr.swap(op->hA.rowptr); op->hA.col.clear(); op->hA.col.shrink_to_fit(); op->hA.val.clear(); op->hA.val.shrink_to_fit();
+    }
+    *M = &op->At;
+    return KK_OK;
+}
+
+// dimension check of y = op(A) x ; with ghosts the x-vector holds the local columns only
+static int check_apply(kk_op op, int transpose, kk_basis bx, kk_basis by) {
+    const int64_t in = transpose ? op->nrows : (op->A.n_ghost > 0 ? op->A.n_local : op->ncols);
+    const int64_t outn = transpose ? op->ncols : op->nrows;
+    KK_CHECK(bx->n == in && by->n == outn, KK_ERR_DIM, "apply: operator is %lldx%lld%s, x has %lld rows, y has %lld rows",
+             (long long)op->nrows, (long long)op->ncols, transpose ? " (adjoint)" : "", (long long)bx->n, (long long)by->n);
+    KK_CHECK(bx->ctx == op->ctx && by->ctx == op->ctx, KK_ERR_INVALID, "apply: objects belong to different contexts");
+    return KK_OK;
+}
+
+extern "C" int kk_spmv(kk_op op, int transpose, kk_basis bx, int cx, kk_basis by, int cy) {
+    KK_CHECK(op, KK_ERR_INVALID, "null op");
+    CHECK_COL(bx, cx); CHECK_COL(by, cy);
+    KK_TRY(check_apply(op, transpose, bx, by));
+    KK_CHECK(!(bx == by && cx == cy), KK_ERR_INVALID, "kk_spmv: x and y must differ");
+    const kk_sparse_dev* M;
+    KK_TRY(get_matrix(op, transpose, &M));
+    gram_touch(by, cy);
+    kk_spmv_fuse f;
+    return kk_launch_spmv(op->ctx, *M, bx->col(cx), by->col(cy), by->ld, f);
+}
+
+extern "C" int kk_spmv_affine(kk_op op, kk_basis bx, int cx, kk_basis by, int cy, double a0, double a1) {
+    KK_CHECK(op, KK_ERR_INVALID, "null op");
+    CHECK_COL(bx, cx); CHECK_COL(by, cy);
+    KK_TRY(check_apply(op, 0, bx, by));
+    KK_CHECK(op->nrows == op->ncols || op->A.n_ghost > 0, KK_ERR_DIM, "affine apply needs a square operator");
+    KK_CHECK(!(bx == by && cx == cy), KK_ERR_INVALID, "kk_spmv_affine: x and y must differ");
+    gram_touch(by, cy);
+    kk_spmv_fuse f;
+    f.a0 = a0; f.a1 = a1;
+    return kk_launch_spmv(op->ctx, op->A, bx->col(cx), by->col(cy), by->ld, f);
+}
+
+extern "C" int kk_gather(kk_basis bx, int cx, const int64_t* device_idx, int64_t count, void* device_out) {
+    CHECK_COL(bx, cx);
+    return kk_launch_gather(bx->ctx, bx->col(cx), device_idx, count, (double*)device_out);
+}
+
+// ------------------------------------------------------------------------------------------
+// L2 basis operations
+// ------------------------------------------------------------------------------------------
+#define CHECK_RANGE(b, c0, m) KK_CHECK((b) && (c0) >= 0 && (m) >= 0 && (c0) + (m) <= (b)->cap && (m) <= KK_MAX_M, KK_ERR_INVALID, "%s: column range [%d,%d) invalid (capacity %d, max %d per call)", __func__, (c0), (c0) + (m), (b) ? (b)->cap : 0, KK_MAX_M)
+
+extern "C" int kk_project(kk_basis b, int c0, int m, kk_basis bx, int cx, double alpha, double beta, double* y) {
+    CHECK_RANGE(b, c0, m); CHECK_COL(bx, cx); CHECK_SAME(b, bx);
+    KK_CHECK(y || m == 0, KK_ERR_INVALID, "null y");
+    if (m == 0) return KK_OK;
+    kk_ctx c = b->ctx;
+    KK_TRY(kk_launch_project(c, b->col(c0), b->ld, m, bx->col(cx), nullptr, nullptr, nullptr, WS_S, WS_G));
+    KK_TRY(ws_fetch_async(c, WS_S, m, 0));
+    KK_TRY(stream_sync(c));
+    const double* s = pin(c, WS_S);
+    for (int j = 0; j < m; ++j) y[j] = (beta == 0.0) ? alpha * s[j] : beta * y[j] + alpha * s[j];
+    return KK_OK;
+}
+
+extern "C" int kk_unproject(kk_basis by, int cy, kk_basis b, int c0, int m, const double* x, double alpha, double beta) {
+    CHECK_RANGE(b, c0, m); CHECK_COL(by, cy); CHECK_SAME(b, by);
+    KK_CHECK(x || m == 0, KK_ERR_INVALID, "null x");
+    KK_CHECK(!(by == b && cy >= c0 && cy < c0 + m), KK_ERR_INVALID, "kk_unproject: y aliases a basis column");
+    gram_touch(by, cy);
+    kk_coef ch;
+    memset(&ch, 0, sizeof(ch));
+    for (int j = 0; j < m; ++j) ch.v[j] = x[j];
+    return kk_launch_unproject(b->ctx, b->col(c0), b->ld, m, by->col(cy), by->col(cy), &ch, nullptr, alpha, beta, -1,
+                               nullptr, -1);
+}
+
+extern "C" int kk_rank1update(kk_basis b, int c0, int m, kk_basis by, int cy, const double* x, double alpha, double beta) {
+    CHECK_RANGE(b, c0, m); CHECK_COL(by, cy); CHECK_SAME(b, by);
+    KK_CHECK(x || m == 0, KK_ERR_INVALID, "null x");
+    KK_CHECK(!(by == b && cy >= c0 && cy < c0 + m), KK_ERR_INVALID, "kk_rank1update: y aliases a basis column");
+    if (m == 0) return KK_OK;
+    gram_touch(b, c0);
+    kk_coef ch;
+    memset(&ch, 0, sizeof(ch));
+    for (int j = 0; j < m; ++j) ch.v[j] = x[j];
+    return kk_launch_rank1(b->ctx, b->col(c0), b->ld, m, by->col(cy), &ch, alpha, beta);
+}
+
+extern "C" int kk_basistransform(kk_basis b, int c0, int m, int n, const double* U, int ldu) {
+    CHECK_RANGE(b, c0, m);
+    KK_CHECK(U && n >= 0 && n <= m && ldu >= m, KK_ERR_DIM, "kk_basistransform: U must be m x n with n <= m, ldu >= m");
+    if (n == 0 || m == 0) return KK_OK;
+    kk_ctx c = b->ctx;
+    gram_touch(b, c0);
+    // pack U (m x n, leading dimension m) into the pinned staging area, then into device scratch
+    KK_TRY(stream_sync(c));
+    double* hp = c->h_U;  // pinned KK_MAX_M x KK_MAX_M staging
+    for (int j = 0; j < n; ++j) memcpy(hp + (size_t)j * m, U + (size_t)j * ldu, m * sizeof(double));
+    double* dU = c->partials;  // reuse the partial-sum buffer as U scratch (>= 2 MiB)
+    KK_HIP(hipMemcpyAsync(dU, hp, (size_t)m * n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    return kk_launch_basistransform(c, b->col(c0), b->ld, m, n, dU);
+}
+
+extern "C" int kk_givens_rmul(kk_basis b, int i1, int i2, double cc, double s) {
+    CHECK_COL(b, i1); CHECK_COL(b, i2);
+    KK_CHECK(i1 != i2, KK_ERR_INVALID, "kk_givens_rmul: i1 == i2");
+    gram_touch(b, std::min(i1, i2));
+    return kk_launch_givens(b->ctx, b->col(i1), b->col(i2), b->ld, cc, s);
+}
+
+extern "C" int kk_householder_rmul(kk_basis b, int c0, int m, const double* v, double beta) {
+    CHECK_RANGE(b, c0, m);
+    KK_CHECK(v || m == 0, KK_ERR_INVALID, "null v");
+    if (m == 0 || beta == 0.0) return KK_OK;  // iszero(beta) && return b  (reflector.jl:147)
+    gram_touch(b, c0);
+    kk_coef ch;
+    memset(&ch, 0, sizeof(ch));
+    for (int j = 0; j < m; ++j) ch.v[j] = v[j];
+    return kk_launch_householder(b->ctx, b->col(c0), b->ld, m, &ch, beta);
+}
+
+// ---- Gram rows for the low-synchronisation MGS -------------------------------------------
+// gram(i, j) = <b_i, b_j>, j < i, stored at b->gram[i*cap + j]; rows [0, gram_rows) valid.
+static int gram_ensure(kk_basis b, int upto /* exclusive */) {
+    kk_ctx c = b->ctx;
+    if (b->gram.empty()) b->gram.assign((size_t)b->cap * b->cap, 0.0);
+    if (b->gram_rows < 1) b->gram_rows = 1;  // row 0 has no strictly-lower entries
+    for (int i = b->gram_rows; i < upto; ++i) {
+        for (int j0 = 0; j0 < i; j0 += KK_MAX_M) {
+            const int mm = std::min(KK_MAX_M, i - j0);
+            KK_TRY(kk_launch_project(c, b->col(j0), b->ld, mm, b->col(i), nullptr, nullptr, nullptr, WS_G, WS_G));
+            KK_TRY(ws_fetch_async(c, WS_G, mm, 1));
+            KK_TRY(stream_sync(c));
+            memcpy(&b->gram[(size_t)i * b->cap + j0], pin(c, WS_G, 1), mm * sizeof(double));
+        }
+        b->gram_rows = i + 1;
+    }
+    return KK_OK;
+}
+// solve (I + L) s = p in place, L = strictly lower Gram block of columns [c0, c0+m)
+static void gram_solve(kk_basis b, int c0, int m, double* p) {
+    for (int i = 1; i < m; ++i) {
+        const double* row = &b->gram[(size_t)(c0 + i) * b->cap + c0];
+        double t = p[i];
+        for (int j = 0; j < i; ++j) t -= row[j] * p[j];
+        p[i] = t;
+    }
+}
+
+// ---- one orthogonalisation pass; coefficient results land in pinned slot `slot` ------------
+// CGS pass:  s = V'w ; w -= V s ; optional |w| (orthonormal.jl:378-384)
+static int pass_cgs(kk_ctx c, const double* V, int64_t ld, int m, double* w, bool want_norm, int slot) {
+    KK_TRY(kk_launch_project(c, V, ld, m, w, nullptr, nullptr, nullptr, WS_S, WS_G));
+    KK_TRY(ws_fetch_async(c, WS_S, m, slot));
+    KK_TRY(kk_launch_unproject(c, V, ld, m, w, w, nullptr, c->ws + WS_S, -1.0, 1.0, -1, nullptr,
+                               want_norm ? WS_SCAL + SC_NRM2 : -1));
+    if (want_norm) KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2, 2, slot));
+    return KK_OK;
+}
+// strict MGS sweep (orthonormal.jl:414-423): `carry` = pending axpy (q, &s) left over from a
+// previous sweep whose last subtraction is fused into this sweep's first dot.
+static int pass_mgs_strict(kk_ctx c, const double* V, int64_t ld, int m, double* w, int64_t ws_s, bool want_norm,
+                           int slot, const double* carry_q, const double* carry_s, bool leave_carry) {
+    const double* qp = carry_q;
+    const double* sp = carry_s;
+    for (int j = 0; j < m; ++j) {
+        const double* q = V + (int64_t)j * ld;
+        KK_TRY(kk_launch_mgs_step(c, w, ld, qp, sp, q, ws_s + j, -1));
+        qp = q;
+        sp = c->ws + ws_s + j;
+    }
+    if (!leave_carry) {
+        KK_TRY(kk_launch_mgs_step(c, w, ld, qp, sp, nullptr, -1, want_norm ? WS_SCAL + SC_NRM2 : -1));
+        if (want_norm) KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2, 2, slot));
+    }
+    KK_TRY(ws_fetch_async(c, ws_s, m, slot));
+    return KK_OK;
+}
+// low-sync MGS sweep: p = V'w (one pass), s = (I+L)^-1 p on the host, w -= V s.
+static int pass_mgs_lowsync(kk_basis b, int c0, int m, double* w, double* s_out, bool want_norm, int slot) {
+    kk_ctx c = b->ctx;
+    KK_TRY(gram_ensure(b, c0 + m));
+    KK_TRY(kk_launch_project(c, b->col(c0), b->ld, m, w, nullptr, nullptr, nullptr, WS_S, WS_G));
+    KK_TRY(ws_fetch_async(c, WS_S, m, slot));
+    KK_TRY(stream_sync(c));
+    kk_coef ch;
+    memset(&ch, 0, sizeof(ch));
+    memcpy(ch.v, pin(c, WS_S, slot), m * sizeof(double));
+    gram_solve(b, c0, m, ch.v);
+    memcpy(s_out, ch.v, m * sizeof(double));
+    KK_TRY(kk_launch_unproject(c, b->col(c0), b->ld, m, w, w, &ch, nullptr, -1.0, 1.0, -1, nullptr,
+                               want_norm ? WS_SCAL + SC_NRM2 : -1));
+    if (want_norm) KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2, 2, slot));
+    return KK_OK;
+}
+
+// orthogonalize!!(w, b[c0:c0+m), x, alg) -- all six algorithms (orthonormal.jl:378-452).
+// On return x[0..m) holds the accumulated coefficients; *nrm = |w| if want_norm.
+static int orth_run(kk_basis b, int c0, int m, double* w, kk_orth_t alg, double eta, double* x, double* nrm,
+                    int* npasses, bool want_norm) {
+    kk_ctx c = b->ctx;
+    const double* V = b->col(c0);
+    const int64_t ld = b->ld;
+    int passes = 0;
+    double nn = 0;
+    if (m == 0) {
+        if (want_norm || alg == KK_CGSIR || alg == KK_MGSIR) {
+            KK_TRY(kk_launch_nrm2(c, w, ld, WS_SCAL + SC_NRM2));
+            KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2, 2, 0));
+            KK_TRY(stream_sync(c));
+            nn = pin(c, WS_SCAL + SC_NRM2)[1];
+        }
+        if (nrm) *nrm = nn;
+        if (npasses) *npasses = 0;
+        return KK_OK;
+    }
+    const bool lowsync = c->mgs_mode == 1;
+    std::vector<double> tmp(m);
+    switch (alg) {
+        case KK_CGS: {
+            KK_TRY(pass_cgs(c, V, ld, m, w, want_norm, 0));
+            KK_TRY(stream_sync(c));
+            memcpy(x, pin(c, WS_S, 0), m * sizeof(double));
+            nn = pin(c, WS_SCAL + SC_NRM2, 0)[1];
+            passes = 1;
+        } break;
+        case KK_CGS2: {  // :394-399
+            KK_TRY(pass_cgs(c, V, ld, m, w, false, 0));
+            KK_TRY(pass_cgs(c, V, ld, m, w, want_norm, 1));
+            KK_TRY(stream_sync(c));
+            for (int j = 0; j < m; ++j) x[j] = pin(c, WS_S, 0)[j] + pin(c, WS_S, 1)[j];
+            nn = pin(c, WS_SCAL + SC_NRM2, 1)[1];
+            passes = 2;
+        } break;
+        case KK_CGSIR: {  // :400-412
+            KK_TRY(kk_launch_nrm2(c, w, ld, WS_SCAL + SC_NRM2B));
+            KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2B, 2, 1));
+            KK_TRY(pass_cgs(c, V, ld, m, w, true, 0));
+            KK_TRY(stream_sync(c));
+            double nold = pin(c, WS_SCAL + SC_NRM2B, 1)[1];
+            memcpy(x, pin(c, WS_S, 0), m * sizeof(double));
+            nn = pin(c, WS_SCAL + SC_NRM2, 0)[1];
+            passes = 1;
+            while (KK_EPS < nn && nn < eta * nold) {
+                nold = nn;
+                KK_TRY(pass_cgs(c, V, ld, m, w, true, 0));
+                KK_TRY(stream_sync(c));
+                for (int j = 0; j < m; ++j) x[j] += pin(c, WS_S, 0)[j];
+                nn = pin(c, WS_SCAL + SC_NRM2, 0)[1];
+                ++passes;
+            }
+        } break;
+        case KK_MGS: {
+            if (lowsync) {
+                KK_TRY(pass_mgs_lowsync(b, c0, m, w, x, want_norm, 0));
+                KK_TRY(stream_sync(c));
+            } else {
+                KK_TRY(pass_mgs_strict(c, V, ld, m, w, WS_S, want_norm, 0, nullptr, nullptr, false));
+                KK_TRY(stream_sync(c));
+                memcpy(x, pin(c, WS_S, 0), m * sizeof(double));
+            }
+            nn = pin(c, WS_SCAL + SC_NRM2, 0)[1];
+            passes = 1;
+        } break;
+        case KK_MGS2: {  // :434-439
+            if (lowsync) {
+                KK_TRY(pass_mgs_lowsync(b, c0, m, w, x, false, 0));
+                KK_TRY(pass_mgs_lowsync(b, c0, m, w, tmp.data(), want_norm, 0));
+                KK_TRY(stream_sync(c));
+                for (int j = 0; j < m; ++j) x[j] += tmp[j];
+            } else {
+                // the last axpy of sweep 1 is fused with the first dot of sweep 2
+                KK_TRY(pass_mgs_strict(c, V, ld, m, w, WS_S, false, 0, nullptr, nullptr, true));
+                KK_TRY(pass_mgs_strict(c, V, ld, m, w, WS_G, want_norm, 0, V + (int64_t)(m - 1) * ld,
+                                       c->ws + WS_S + m - 1, false));
+                KK_TRY(stream_sync(c));
+                for (int j = 0; j < m; ++j) x[j] = pin(c, WS_S, 0)[j] + pin(c, WS_G, 0)[j];
+            }
+            nn = pin(c, WS_SCAL + SC_NRM2, 0)[1];
+            passes = 2;
+        } break;
+        case KK_MGSIR: {  // :440-452
+            KK_TRY(kk_launch_nrm2(c, w, ld, WS_SCAL + SC_NRM2B));
+            KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2B, 2, 1));
+            if (lowsync) KK_TRY(pass_mgs_lowsync(b, c0, m, w, x, true, 0));
+            else KK_TRY(pass_mgs_strict(c, V, ld, m, w, WS_S, true, 0, nullptr, nullptr, false));
+            KK_TRY(stream_sync(c));
+            double nold = pin(c, WS_SCAL + SC_NRM2B, 1)[1];
+            if (!lowsync) memcpy(x, pin(c, WS_S, 0), m * sizeof(double));
+            nn = pin(c, WS_SCAL + SC_NRM2, 0)[1];
+            passes = 1;
+            while (KK_EPS < nn && nn < eta * nold) {
+                nold = nn;
+                if (lowsync) KK_TRY(pass_mgs_lowsync(b, c0, m, w, tmp.data(), true, 0));
+                else KK_TRY(pass_mgs_strict(c, V, ld, m, w, WS_S, true, 0, nullptr, nullptr, false));
+                KK_TRY(stream_sync(c));
+                for (int j = 0; j < m; ++j) x[j] += lowsync ? tmp[j] : pin(c, WS_S, 0)[j];
+                nn = pin(c, WS_SCAL + SC_NRM2, 0)[1];
+                ++passes;
+            }
+        } break;
+        default:
+            kk_set_error("unknown orthogonalizer %d", (int)alg);
+            return KK_ERR_INVALID;
+    }
+    if (nrm) *nrm = nn;
+    if (npasses) *npasses = passes;
+    return KK_OK;
+}
+
+extern "C" int kk_orthogonalize(kk_basis b, int c0, int m, kk_basis bw, int cw, kk_orth_t alg, double eta, double* x,
+                                double* nrm, int* npasses) {
+    CHECK_RANGE(b, c0, m); CHECK_COL(bw, cw); CHECK_SAME(b, bw);
+    KK_CHECK(x || m == 0, KK_ERR_INVALID, "null x");
+    KK_CHECK(!(bw == b && cw >= c0 && cw < c0 + m), KK_ERR_INVALID, "kk_orthogonalize: w aliases a basis column");
+    gram_touch(bw, cw);
+    return orth_run(b, c0, m, bw->col(cw), alg, eta, x, nrm, npasses, nrm != nullptr);
+}
+
+extern "C" int kk_orthonormalize(kk_basis b, int c0, int m, kk_basis bw, int cw, kk_orth_t alg, double eta, double* x,
+                                 double* nrm, int* npasses) {
+    CHECK_RANGE(b, c0, m); CHECK_COL(bw, cw); CHECK_SAME(b, bw);
+    KK_CHECK(x || m == 0, KK_ERR_INVALID, "null x");
+    KK_CHECK(!(bw == b && cw >= c0 && cw < c0 + m), KK_ERR_INVALID, "kk_orthonormalize: w aliases a basis column");
+    gram_touch(bw, cw);
+    double nn = 0;
+    KK_TRY(orth_run(b, c0, m, bw->col(cw), alg, eta, x, &nn, npasses, true));
+    if (nrm) *nrm = nn;
+    return kk_launch_scal(b->ctx, bw->col(cw), bw->ld, 1.0 / nn, nullptr);  // scale!!(v, inv(beta))  :525
+}
+
+// _orthogonalize!!(v, q, alg) (orthonormal.jl:455-489)
+static int orth_vec_run(kk_ctx c, const double* q, double* w, int64_t ld, kk_orth_t alg, double eta, double* s_out,
+                        double* nrm, bool want_norm) {
+    double s = 0, nn = 0;
+    if (alg == KK_CGS || alg == KK_MGS) {
+        KK_TRY(kk_launch_mgs_step(c, w, ld, nullptr, nullptr, q, WS_S, -1));
+        KK_TRY(kk_launch_mgs_step(c, w, ld, q, c->ws + WS_S, nullptr, -1, want_norm ? WS_SCAL + SC_NRM2 : -1));
+        KK_TRY(ws_fetch_async(c, WS_S, 1, 0));
+        if (want_norm) KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2, 2, 0));
+        KK_TRY(stream_sync(c));
+        s = pin(c, WS_S)[0];
+        nn = pin(c, WS_SCAL + SC_NRM2)[1];
+    } else if (alg == KK_CGS2 || alg == KK_MGS2) {
+        KK_TRY(kk_launch_mgs_step(c, w, ld, nullptr, nullptr, q, WS_S, -1));
+        KK_TRY(kk_launch_mgs_step(c, w, ld, q, c->ws + WS_S, q, WS_S + 1, -1));
+        KK_TRY(kk_launch_mgs_step(c, w, ld, q, c->ws + WS_S + 1, nullptr, -1, want_norm ? WS_SCAL + SC_NRM2 : -1));
+        KK_TRY(ws_fetch_async(c, WS_S, 2, 0));
+        if (want_norm) KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2, 2, 0));
+        KK_TRY(stream_sync(c));
+        s = pin(c, WS_S)[0] + pin(c, WS_S)[1];
+        nn = pin(c, WS_SCAL + SC_NRM2)[1];
+    } else {
+        KK_TRY(kk_launch_nrm2(c, w, ld, WS_SCAL + SC_NRM2B));
+        KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2B, 2, 1));
+        KK_TRY(kk_launch_mgs_step(c, w, ld, nullptr, nullptr, q, WS_S, -1));
+        KK_TRY(kk_launch_mgs_step(c, w, ld, q, c->ws + WS_S, nullptr, -1, WS_SCAL + SC_NRM2));
+        KK_TRY(ws_fetch_async(c, WS_S, 1, 0));
+        KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2, 2, 0));
+        KK_TRY(stream_sync(c));
+        double nold = pin(c, WS_SCAL + SC_NRM2B, 1)[1];
+        s = pin(c, WS_S)[0];
+        nn = pin(c, WS_SCAL + SC_NRM2)[1];
+        while (KK_EPS < nn && nn < eta * nold) {
+            nold = nn;
+            KK_TRY(kk_launch_mgs_step(c, w, ld, nullptr, nullptr, q, WS_S, -1));
+            KK_TRY(kk_launch_mgs_step(c, w, ld, q, c->ws + WS_S, nullptr, -1, WS_SCAL + SC_NRM2));
+            KK_TRY(ws_fetch_async(c, WS_S, 1, 0));
+            KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2, 2, 0));
+            KK_TRY(stream_sync(c));
+            s += pin(c, WS_S)[0];
+            nn = pin(c, WS_SCAL + SC_NRM2)[1];
+        }
+    }
+    if (s_out) *s_out = s;
+    if (nrm) *nrm = nn;
+    return KK_OK;
+}
+
+extern "C" int kk_orthogonalize_vec(kk_basis bq, int cq, kk_basis bw, int cw, kk_orth_t alg, double eta, double* s,
+                                    double* nrm) {
+    CHECK_COL(bq, cq); CHECK_COL(bw, cw); CHECK_SAME(bq, bw);
+    KK_CHECK(!(bq == bw && cq == cw), KK_ERR_INVALID, "kk_orthogonalize_vec: q and w must differ");
+    gram_touch(bw, cw);
+    return orth_vec_run(bq->ctx, bq->col(cq), bw->col(cw), bw->ld, alg, eta, s, nrm, nrm != nullptr);
+}
+
+// ------------------------------------------------------------------------------------------
+// L3 fused expand! steps
+// ------------------------------------------------------------------------------------------
+static int check_square_op(kk_op op, kk_basis b) {
+    KK_CHECK(op && b, KK_ERR_INVALID, "null arg");
+    KK_CHECK(op->ctx == b->ctx, KK_ERR_INVALID, "operator and basis belong to different contexts");
+    const int64_t in = op->A.n_ghost > 0 ? op->A.n_local : op->ncols;
+    KK_CHECK(op->nrows == b->n && in == b->n, KK_ERR_DIM, "operator is %lldx%lld but vectors have %lld rows",
+             (long long)op->nrows, (long long)op->ncols, (long long)b->n);
+    return KK_OK;
+}
+
+// initialize (factorizations/lanczos.jl:180-222 == arnoldi.jl:135-175): col c0 = x0 -> v ; col c0+1 = r
+static int krylov_initialize(kk_op op, kk_basis b, int c0, kk_orth_t orth, double eta, double* alpha, double* beta) {
+    KK_TRY(check_square_op(op, b));
+    KK_CHECK(c0 >= 0 && c0 + 2 <= b->cap, KK_ERR_INVALID, "initialize: need columns %d..%d", c0, c0 + 1);
+    KK_CHECK(alpha && beta, KK_ERR_INVALID, "null output");
+    kk_ctx c = b->ctx;
+    double* x0 = b->col(c0);
+    double* r = b->col(c0 + 1);
+    gram_touch(b, c0);
+    // beta0 = norm(x0); Ax0 = A x0 with fused <x0, Ax0>
+    KK_TRY(kk_launch_nrm2(c, x0, b->ld, WS_SCAL + SC_NRM2));
+    kk_spmv_fuse f;
+    f.dot_mode = 1; f.dot_slot = SC_ALPHA0;
+    KK_TRY(kk_launch_spmv(c, op->A, x0, r, b->ld, f));
+    KK_TRY(ws_fetch_async(c, WS_SCAL, 16, 0));
+    KK_TRY(stream_sync(c));
+    const double beta0 = pin(c, WS_SCAL + SC_NRM)[0];
+    if (beta0 == 0.0) {
+        kk_set_error("initial vector should not have norm zero");
+        return KK_ERR_ZERO_NORM;
+    }
+    double a = pin(c, WS_SCAL + SC_ALPHA0)[0] / (beta0 * beta0);
+    KK_TRY(kk_launch_scal(c, x0, b->ld, 1.0 / beta0, nullptr));   // v = x0/beta0      :190
+    KK_TRY(kk_launch_scal(c, r, b->ld, 1.0 / beta0, nullptr));    // r = Ax0/beta0     :194
+    const bool ir = (orth == KK_CGSIR || orth == KK_MGSIR);
+    double beta_old = 0;
+    if (ir) {
+        KK_TRY(kk_launch_nrm2(c, r, b->ld, WS_SCAL + SC_NRM2B));  // beta_old = norm(r) :196
+        KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2B, 2, 1));
+    }
+    // r -= alpha v ; beta = norm(r)
+    KK_TRY(kk_launch_axpby(c, r, x0, b->ld, -a, 1.0, nullptr, 1.0, 0));
+    KK_TRY(kk_launch_nrm2(c, r, b->ld, WS_SCAL + SC_NRM2));
+    KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2, 2, 0));
+    KK_TRY(stream_sync(c));
+    double bt = pin(c, WS_SCAL + SC_NRM2)[1];
+    if (ir) beta_old = pin(c, WS_SCAL + SC_NRM2B, 1)[1];
+    auto correct = [&]() -> int {  // dalpha = <v,r>; alpha += dalpha; r -= dalpha v; beta = |r|   :201-204
+        KK_TRY(kk_launch_mgs_step(c, r, b->ld, nullptr, nullptr, x0, WS_S, -1));
+        KK_TRY(kk_launch_mgs_step(c, r, b->ld, x0, c->ws + WS_S, nullptr, -1, WS_SCAL + SC_NRM2));
+        KK_TRY(ws_fetch_async(c, WS_S, 1, 0));
+        KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2, 2, 0));
+        KK_TRY(stream_sync(c));
+        a += pin(c, WS_S)[0];
+        bt = pin(c, WS_SCAL + SC_NRM2)[1];
+        return KK_OK;
+    };
+    if (orth == KK_CGS2 || orth == KK_MGS2) {
+        KK_TRY(correct());
+    } else if (ir) {
+        while (KK_EPS < bt && bt < eta * beta_old) {
+            beta_old = bt;
+            KK_TRY(correct());
+        }
+    }
+    *alpha = a;
+    *beta = bt;
+    return KK_OK;
+}
+
+extern "C" int kk_lanczos_initialize(kk_op op, kk_basis b, int c0, kk_orth_t orth, double eta, double* alpha,
+                                     double* beta) {
+    return krylov_initialize(op, b, c0, orth, eta, alpha, beta);
+}
+extern "C" int kk_arnoldi_initialize(kk_op op, kk_basis b, int c0, kk_orth_t orth, double eta, double* alpha,
+                                     double* beta) {
+    return krylov_initialize(op, b, c0, orth, eta, alpha, beta);
+}
+
+extern "C" int kk_lanczos_expand(kk_op op, kk_basis b, int c0, int k, kk_orth_t orth, double eta, double beta_old,
+                                 double* alpha, double* beta, int* npasses) {
+    KK_TRY(check_square_op(op, b));
+    KK_CHECK(k >= 1 && c0 >= 0 && c0 + k + 2 <= b->cap && k + 1 <= KK_MAX_M, KK_ERR_INVALID,
+             "kk_lanczos_expand: need k >= 1 and columns %d..%d within capacity %d", c0, c0 + k + 1, b->cap);
+    KK_CHECK(alpha && beta, KK_ERR_INVALID, "null output");
+    KK_CHECK(beta_old != 0.0, KK_ERR_ZERO_NORM, "kk_lanczos_expand: residual norm is zero");
+    kk_ctx c = b->ctx;
+    const int64_t ld = b->ld;
+    const int m = k + 1;                  // basis size after the push
+    double* V = b->col(c0);
+    double* v = b->col(c0 + k);           // holds r on entry
+    const double* vprev = b->col(c0 + k - 1);
+    double* w = b->col(c0 + k + 1);
+    gram_touch(b, c0 + k);
+    int passes = 0;
+    // V = push!(V, scale!!(r, 1/beta_old))   lanczos.jl:257
+    KK_TRY(kk_launch_scal(c, v, ld, 1.0 / beta_old, nullptr));
+    // w = A v - beta_old v_prev with the fused alpha dot   lanczos.jl:297-299 / 306-308
+    kk_spmv_fuse f;
+    f.vprev = vprev; f.bprev = beta_old;
+    const bool cgs_order = (orth == KK_CGS || orth == KK_CGS2 || orth == KK_CGSIR);
+    f.dot_mode = cgs_order ? 1 : 2;
+    f.dot_slot = SC_ALPHA0;
+    KK_TRY(kk_launch_spmv(c, op->A, v, w, ld, f));
+    const double* a0_dev = c->ws + WS_SCAL + SC_ALPHA0;
+    double a = 0, bt = 0;
+    const bool lowsync = c->mgs_mode == 1;
+    if (orth == KK_CGS || orth == KK_MGS || orth == KK_CGSIR || orth == KK_MGSIR) {
+        // w -= alpha v ; beta = |w|
+        KK_TRY(kk_launch_mgs_step(c, w, ld, v, a0_dev, nullptr, -1, WS_SCAL + SC_NRM2));
+        KK_TRY(ws_fetch_async(c, WS_SCAL, 4, 0));
+        KK_TRY(stream_sync(c));
+        a = pin(c, WS_SCAL + SC_ALPHA0)[0];
+        bt = pin(c, WS_SCAL + SC_NRM)[0];
+        if (orth == KK_CGSIR || orth == KK_MGSIR) {  // lanczos.jl:346-354 / 363-374
+            const double ab2 = a * a + beta_old * beta_old;
+            double nold = std::sqrt(bt * bt + ab2);
+            std::vector<double> s(m);
+            while (KK_EPS < bt && bt < eta * nold) {
+                nold = bt;
+                double nn = 0;
+                int p1 = 0;
+                KK_TRY(orth_run(b, c0, m, w, orth == KK_CGSIR ? KK_CGS : KK_MGS, eta, s.data(), &nn, &p1, true));
+                a += s[m - 1];
+                bt = nn;
+                ++passes;
+            }
+        }
+    } else if (orth == KK_CGS2 || (orth == KK_MGS2 && lowsync)) {
+        // one projection pass with "w -= alpha0 v" folded in (read V twice in total):
+        //   s = V'(w - alpha0 v) ; w <- w - V (s + alpha0 e_m) ; beta = |w|     lanczos.jl:318-322 / 329-336
+        if (orth == KK_MGS2) KK_TRY(gram_ensure(b, c0 + m));
+        KK_TRY(kk_launch_project(c, V, ld, m, w, v, a0_dev, nullptr, WS_S, WS_G));
+        if (orth == KK_CGS2) {
+            KK_TRY(kk_launch_unproject(c, V, ld, m, w, w, nullptr, c->ws + WS_S, -1.0, 1.0, m - 1, a0_dev,
+                                       WS_SCAL + SC_NRM2));
+            KK_TRY(ws_fetch_async(c, WS_S, m, 0));
+            KK_TRY(ws_fetch_async(c, WS_SCAL, 4, 0));
+            KK_TRY(stream_sync(c));
+            a = pin(c, WS_SCAL + SC_ALPHA0)[0] + pin(c, WS_S)[m - 1];
+        } else {
+            KK_TRY(ws_fetch_async(c, WS_S, m, 0));
+            KK_TRY(ws_fetch_async(c, WS_SCAL, 1, 0));
+            KK_TRY(stream_sync(c));
+            kk_coef ch;
+            memset(&ch, 0, sizeof(ch));
+            memcpy(ch.v, pin(c, WS_S), m * sizeof(double));
+            gram_solve(b, c0, m, ch.v);
+            const double a0 = pin(c, WS_SCAL + SC_ALPHA0)[0];
+            a = a0 + ch.v[m - 1];
+            ch.v[m - 1] += a0;
+            KK_TRY(kk_launch_unproject(c, V, ld, m, w, w, &ch, nullptr, -1.0, 1.0, -1, nullptr, WS_SCAL + SC_NRM2));
+            KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2, 2, 0));
+            KK_TRY(stream_sync(c));
+        }
+        bt = pin(c, WS_SCAL + SC_NRM)[0];
+        passes = 1;
+    } else if (orth == KK_MGS2) {
+        // strict: w -= alpha0 v fused with the first dot of the sweep   lanczos.jl:329-334
+        KK_TRY(pass_mgs_strict(c, V, ld, m, w, WS_S, true, 0, v, a0_dev, false));
+        KK_TRY(ws_fetch_async(c, WS_SCAL, 1, 0));
+        KK_TRY(stream_sync(c));
+        a = pin(c, WS_SCAL + SC_ALPHA0)[0] + pin(c, WS_S)[m - 1];
+        bt = pin(c, WS_SCAL + SC_NRM2)[1];
+        passes = 1;
+    } else {
+        kk_set_error("unknown orthogonalizer %d", (int)orth);
+        return KK_ERR_INVALID;
+    }
+    *alpha = a;
+    *beta = bt;
+    if (npasses) *npasses = passes;
+    return KK_OK;
+}
+
+extern "C" int kk_arnoldi_expand(kk_op op, kk_basis b, int c0, int k, kk_orth_t orth, double eta, double beta_old,
+                                 double* h, double* beta, int* npasses) {
+    KK_TRY(check_square_op(op, b));
+    KK_CHECK(k >= 1 && c0 >= 0 && c0 + k + 2 <= b->cap && k + 1 <= KK_MAX_M, KK_ERR_INVALID,
+             "kk_arnoldi_expand: need k >= 1 and columns %d..%d within capacity %d", c0, c0 + k + 1, b->cap);
+    KK_CHECK(h && beta, KK_ERR_INVALID, "null output");
+    KK_CHECK(beta_old != 0.0, KK_ERR_ZERO_NORM, "kk_arnoldi_expand: residual norm is zero");
+    kk_ctx c = b->ctx;
+    const int m = k + 1;
+    double* v = b->col(c0 + k);
+    double* w = b->col(c0 + k + 1);
+    gram_touch(b, c0 + k);
+    KK_TRY(kk_launch_scal(c, v, b->ld, 1.0 / beta_old, nullptr));  // push!(V, scale(r, 1/beta))   arnoldi.jl:209
+    kk_spmv_fuse f;
+    KK_TRY(kk_launch_spmv(c, op->A, v, w, b->ld, f));               // w = apply(operator, last(V))  :242
+    return orth_run(b, c0, m, w, orth, eta, h, beta, npasses, true);  // orthogonalize!! + norm      :243-244
+}
+
+// ---- GKL ----------------------------------------------------------------------------------
+static int check_gkl(kk_op op, kk_basis bu, kk_basis bv) {
+    KK_CHECK(op && bu && bv, KK_ERR_INVALID, "null arg");
+    KK_CHECK(op->ctx == bu->ctx && op->ctx == bv->ctx, KK_ERR_INVALID, "objects belong to different contexts");
+    KK_CHECK(op->nrows == bu->n && op->ncols == bv->n, KK_ERR_DIM,
+             "GKL: operator is %lldx%lld, U vectors have %lld rows, V vectors %lld", (long long)op->nrows,
+             (long long)op->ncols, (long long)bu->n, (long long)bv->n);
+    KK_CHECK(op->A.n_ghost == 0, KK_ERR_UNSUPPORTED, "GKL on ghosted (row-sharded) operators goes through the split-phase API");
+    return KK_OK;
+}
+
+extern "C" int kk_gkl_initialize(kk_op op, kk_basis bu, kk_basis bv, double* alpha, double* beta) {
+    KK_TRY(check_gkl(op, bu, bv));
+    KK_CHECK(bu->cap >= 2 && bv->cap >= 1, KK_ERR_INVALID, "GKL initialize: capacity too small");
+    KK_CHECK(alpha && beta, KK_ERR_INVALID, "null output");
+    kk_ctx c = bu->ctx;
+    const kk_sparse_dev* At;
+    KK_TRY(get_matrix(op, 1, &At));
+    double* u0 = bu->col(0);
+    double* v0 = bv->col(0);
+    double* r = bu->col(1);
+    gram_touch(bu, 0); gram_touch(bv, 0);
+    // beta0 = |u0| ; v0 = A' u0 (with |v0|^2) ; Av0 = A v0 (with <u0, A v0> computed separately)
+    KK_TRY(kk_launch_nrm2(c, u0, bu->ld, WS_SCAL + SC_NRM2B));
+    kk_spmv_fuse f1;
+    f1.nrm_slot = SC_NRM2;
+    KK_TRY(kk_launch_spmv(c, *At, u0, v0, bv->ld, f1));
+    kk_spmv_fuse f2;
+    KK_TRY(kk_launch_spmv(c, op->A, v0, r, bu->ld, f2));
+    KK_TRY(kk_launch_dot(c, u0, r, bu->ld, WS_SCAL + SC_DOT));
+    KK_TRY(ws_fetch_async(c, WS_SCAL, 16, 0));
+    KK_TRY(stream_sync(c));
+    const double beta0 = pin(c, WS_SCAL + SC_NRMB)[0];
+    if (beta0 == 0.0) {
+        kk_set_error("initial vector should not have norm zero");
+        return KK_ERR_ZERO_NORM;
+    }
+    const double a = pin(c, WS_SCAL + SC_NRM)[0] / beta0;                 // alpha = |v0|/beta0   gkl.jl:189
+    const double a2 = pin(c, WS_SCAL + SC_DOT)[0] / (beta0 * beta0);      // alpha^2 check        :191-192
+    if (!(std::fabs(a2 - a * a) <= std::sqrt(KK_EPS) * std::max(std::fabs(a2), a * a))) {
+        kk_set_error("operator and its adjoint are not compatible");
+        return KK_ERR_INVALID;
+    }
+    KK_TRY(kk_launch_scal(c, u0, bu->ld, 1.0 / beta0, nullptr));          // u = u0/beta0
+    KK_TRY(kk_launch_scal(c, v0, bv->ld, 1.0 / (a * beta0), nullptr));    // v = v0/(alpha beta0)
+    // r = Av0/(alpha beta0) - alpha u
+    KK_TRY(kk_launch_axpby(c, r, u0, bu->ld, -a, 1.0 / (a * beta0), nullptr, 1.0, 0));
+    KK_TRY(kk_launch_nrm2(c, r, bu->ld, WS_SCAL + SC_NRM2));
+    KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2, 2, 0));
+    KK_TRY(stream_sync(c));
+    *alpha = a;
+    *beta = pin(c, WS_SCAL + SC_NRM)[0];
+    return KK_OK;
+}
+
+extern "C" int kk_gkl_expand(kk_op op, kk_basis bu, kk_basis bv, int k, kk_orth_t orth, double eta, double beta_old,
+                             double* alpha, double* beta, int* npasses_v, int* npasses_u) {
+    KK_TRY(check_gkl(op, bu, bv));
+    KK_CHECK(k >= 1 && k + 2 <= bu->cap && k + 1 <= bv->cap && k + 1 <= KK_MAX_M, KK_ERR_INVALID,
+             "kk_gkl_expand: k=%d does not fit capacities %d / %d", k, bu->cap, bv->cap);
+    KK_CHECK(alpha && beta, KK_ERR_INVALID, "null output");
+    KK_CHECK(beta_old != 0.0, KK_ERR_ZERO_NORM, "kk_gkl_expand: residual norm is zero");
+    kk_ctx c = bu->ctx;
+    const kk_sparse_dev* At;
+    KK_TRY(get_matrix(op, 1, &At));
+    double* u = bu->col(k);            // holds r on entry
+    double* v = bv->col(k);
+    double* r = bu->col(k + 1);
+    const double* vlast = bv->col(k - 1);
+    gram_touch(bu, k); gram_touch(bv, k);
+    int pv = 0, pu = 0;
+    double a = 0, bt = 0;
+    std::vector<double> tmp(k + 1);
+    // U = push!(U, scale!!(r, 1/beta_old))   gkl.jl:254
+    KK_TRY(kk_launch_scal(c, u, bu->ld, 1.0 / beta_old, nullptr));
+    // v = A'u - beta_old V[end]  (fused), alpha = |v| fused when no sweep follows
+    kk_spmv_fuse f1;
+    f1.vprev = vlast; f1.bprev = beta_old;
+    const bool v_sweep = (orth == KK_MGS2 || orth == KK_CGSIR || orth == KK_MGSIR);
+    f1.nrm_slot = SC_NRM2;
+    KK_TRY(kk_launch_spmv(c, *At, u, v, bv->ld, f1));
+    if (orth == KK_MGS2) {  // gkl.jl:330-336
+        double nn = 0;
+        KK_TRY(orth_run(bv, 0, k, v, KK_MGS, eta, tmp.data(), &nn, nullptr, true));
+        a = nn;
+        pv = 1;
+        // publish alpha / 1/alpha on the device for the next kernels
+        double hv[3] = {a * a, a, 1.0 / a};
+        KK_HIP(hipMemcpyAsync(c->ws + WS_SCAL + SC_NRM2, hv, sizeof(hv), hipMemcpyHostToDevice, c->stream));
+        KK_TRY(stream_sync(c));
+    } else if (orth == KK_CGSIR || orth == KK_MGSIR) {  // gkl.jl:353-360 / 380-389
+        KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2, 2, 0));
+        KK_TRY(stream_sync(c));
+        a = pin(c, WS_SCAL + SC_NRM)[0];
+        double nold = std::sqrt(a * a + beta_old * beta_old);
+        while ((orth == KK_CGSIR || KK_EPS < a) && a < eta * nold) {
+            nold = a;
+            double nn = 0;
+            KK_TRY(orth_run(bv, 0, k, v, orth == KK_CGSIR ? KK_CGS : KK_MGS, eta, tmp.data(), &nn, nullptr, true));
+            a = nn;
+            ++pv;
+            if (a == 0.0) break;
+        }
+        double hv[3] = {a * a, a, 1.0 / a};
+        KK_HIP(hipMemcpyAsync(c->ws + WS_SCAL + SC_NRM2, hv, sizeof(hv), hipMemcpyHostToDevice, c->stream));
+        KK_TRY(stream_sync(c));
+    }
+    (void)v_sweep;
+    const double* alpha_dev = c->ws + WS_SCAL + SC_NRM;
+    const double* inva_dev = c->ws + WS_SCAL + SC_INVNRM;
+    // v = scale!!(v, inv(alpha))
+    KK_TRY(kk_launch_scal(c, v, bv->ld, 0.0, inva_dev));
+    // r = A v - alpha u (fused), beta = |r| fused when no sweep follows
+    kk_spmv_fuse f2;
+    f2.vprev = u; f2.bprev_dev = alpha_dev;
+    f2.nrm_slot = SC_NRM2B;
+    KK_TRY(kk_launch_spmv(c, op->A, v, r, bu->ld, f2));
+    if (orth == KK_CGS || orth == KK_MGS) {
+        KK_TRY(ws_fetch_async(c, WS_SCAL, 16, 0));
+        KK_TRY(stream_sync(c));
+        a = pin(c, WS_SCAL + SC_NRM)[0];
+        bt = pin(c, WS_SCAL + SC_NRMB)[0];
+    } else if (orth == KK_CGS2 || orth == KK_MGS2) {  // gkl.jl:319-321 / 341-344
+        KK_TRY(ws_fetch_async(c, WS_SCAL, 16, 2));
+        double nn = 0;
+        KK_TRY(orth_run(bu, 0, k + 1, r, orth == KK_CGS2 ? KK_CGS : KK_MGS, eta, tmp.data(), &nn, nullptr, true));
+        a = pin(c, WS_SCAL + SC_NRM, 2)[0];
+        bt = nn;
+        pu = 1;
+    } else {  // IR: gkl.jl:364-370 / 394-401
+        KK_TRY(ws_fetch_async(c, WS_SCAL, 16, 0));
+        KK_TRY(stream_sync(c));
+        a = pin(c, WS_SCAL + SC_NRM)[0];
+        bt = pin(c, WS_SCAL + SC_NRMB)[0];
+        double nold = std::sqrt(a * a + bt * bt);
+        while (KK_EPS < bt && bt < eta * nold) {
+            nold = bt;
+            double nn = 0;
+            KK_TRY(orth_run(bu, 0, k + 1, r, orth == KK_CGSIR ? KK_CGS : KK_MGS, eta, tmp.data(), &nn, nullptr, true));
+            bt = nn;
+            ++pu;
+        }
+    }
+    *alpha = a;
+    *beta = bt;
+    if (npasses_v) *npasses_v = pv;
+    if (npasses_u) *npasses_u = pu;
+    return KK_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// split-phase API (row-sharded multi-GPU runs)
+// ------------------------------------------------------------------------------------------
+extern "C" int kk_ws_ptr(kk_ctx c, void** dptr, int64_t* count) {
+    KK_CHECK(c, KK_ERR_INVALID, "null ctx");
+    if (dptr) *dptr = c->ws + WS_USER;
+    if (count) *count = KK_WS_USER;
+    return KK_OK;
+}
+#define CHECK_WS(off, cnt) KK_CHECK((off) >= 0 && (off) + (cnt) <= KK_WS_USER, KK_ERR_INVALID, "%s: workspace range [%lld,%lld) out of bounds", __func__, (long long)(off), (long long)((off) + (cnt)))
+
+extern "C" int kk_project_dev(kk_basis b, int c0, int m, kk_basis bx, int cx, int64_t ws_off) {
+    CHECK_RANGE(b, c0, m); CHECK_COL(bx, cx); CHECK_SAME(b, bx); CHECK_WS(ws_off, m);
+    if (m == 0) return KK_OK;
+    return kk_launch_project(b->ctx, b->col(c0), b->ld, m, bx->col(cx), nullptr, nullptr, nullptr, WS_USER + ws_off, WS_G);
+}
+extern "C" int kk_unproject_dev(kk_basis by, int cy, kk_basis b, int c0, int m, int64_t ws_off, int64_t nrm_off) {
+    CHECK_RANGE(b, c0, m); CHECK_COL(by, cy); CHECK_SAME(b, by); CHECK_WS(ws_off, m);
+    if (nrm_off >= 0) CHECK_WS(nrm_off, 3);
+    KK_CHECK(!(by == b && cy >= c0 && cy < c0 + m), KK_ERR_INVALID, "kk_unproject_dev: y aliases a basis column");
+    gram_touch(by, cy);
+    return kk_launch_unproject(b->ctx, b->col(c0), b->ld, m, by->col(cy), by->col(cy), nullptr,
+                               b->ctx->ws + WS_USER + ws_off, -1.0, 1.0, -1, nullptr,
+                               nrm_off >= 0 ? WS_USER + nrm_off : -1);
+}
+extern "C" int kk_dot_dev(kk_basis bx, int cx, kk_basis by, int cy, int64_t ws_off) {
+    CHECK_COL(bx, cx); CHECK_COL(by, cy); CHECK_SAME(bx, by); CHECK_WS(ws_off, 1);
+    return kk_launch_dot(bx->ctx, bx->col(cx), by->col(cy), bx->ld, (int)(WS_USER + ws_off));
+}
+extern "C" int kk_axpy_dev(kk_basis by, int cy, kk_basis bx, int cx, int64_t ws_off, double sign) {
+    CHECK_COL(bx, cx); CHECK_COL(by, cy); CHECK_SAME(bx, by); CHECK_WS(ws_off, 1);
+    gram_touch(by, cy);
+    return kk_launch_axpby(by->ctx, by->col(cy), bx->col(cx), by->ld, 0.0, 1.0, by->ctx->ws + WS_USER + ws_off, sign, 1);
+}
+extern "C" int kk_ws_read(kk_ctx c, int64_t off, int64_t count, double* host) {
+    KK_CHECK(c && host, KK_ERR_INVALID, "null arg");
+    CHECK_WS(off, count);
+    KK_HIP(hipMemcpyAsync(host, c->ws + WS_USER + off, count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    return stream_sync(c);
+}
+extern "C" int kk_ws_write(kk_ctx c, int64_t off, int64_t count, const double* host) {
+    KK_CHECK(c && host, KK_ERR_INVALID, "null arg");
+    CHECK_WS(off, count);
+    KK_HIP(hipMemcpyAsync(c->ws + WS_USER + off, host, count * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    return stream_sync(c);
+}

@@ -1,0 +1,184 @@
+// Internal declarations shared by the .hip translation units of libkrylov_hip.so.
+// gfx950 (CDNA4) only: wave64, 256 CUs in 8 XCDs, HBM3E-bound streaming kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include <map>
+#include "../../include/krylov_hip.h"
+
+#define KK_MAX_M 256          // max basis vectors touched by one project/unproject call
+#define KK_MAX_BLOCKS 4096    // max thread blocks of a reducing kernel (partials row stride)
+#define KK_TPB 256            // threads per block of every streaming kernel (4 waves)
+#define KK_SUB 512            // rows covered by one block sub-step: 256 threads x 2 rows (16 B/lane)
+#define KK_RG 4               // sub-steps per row group (8 rows per thread in registers)
+
+// scalar workspace layout (doubles)
+#define WS_S 0                // coefficients of the current pass            [KK_MAX_M]
+#define WS_G (WS_S + KK_MAX_M)      // second right-hand side (Gram row)     [KK_MAX_M]
+#define WS_X (WS_G + KK_MAX_M)      // accumulated coefficients              [KK_MAX_M]
+#define WS_SCAL (WS_X + KK_MAX_M)   // named scalars                         [64]
+#define WS_USER (WS_SCAL + 64)      // split-phase API area                  [KK_WS_USER]
+#define KK_WS_USER 4096
+#define WS_TOTAL (WS_USER + KK_WS_USER)
+// a finalize with_sqrt writes three consecutive slots: sum, sqrt(sum), 1/sqrt(sum)
+enum { SC_ALPHA0 = 0, SC_NRM2 = 1, SC_NRM = 2, SC_INVNRM = 3, SC_DOT = 4, SC_TMP0 = 5, SC_TMP1 = 6, SC_TMP2 = 7,
+       SC_NRM2B = 8, SC_NRMB = 9, SC_INVNRMB = 10, SC_DOTB = 11 };
+
+void kk_set_error(const char* fmt, ...);
+int kk_hip_fail(hipError_t e, const char* what, const char* file, int line);
+#define KK_HIP(call)                                                        \
+    do {                                                                    \
+        hipError_t _e = (call);                                             \
+        if (_e != hipSuccess) return kk_hip_fail(_e, #call, __FILE__, __LINE__); \
+    } while (0)
+#define KK_CHECK(cond, code, ...)                 \
+    do {                                          \
+        if (!(cond)) {                            \
+            kk_set_error(__VA_ARGS__);            \
+            return (code);                        \
+        }                                         \
+    } while (0)
+#define KK_TRY(call)                \
+    do {                            \
+        int _s = (call);            \
+        if (_s != KK_OK) return _s; \
+    } while (0)
+
+struct kk_prof_entry {
+    double ms = 0;
+    int64_t launches = 0;
+};
+
+struct kk_ctx_s {
+    int device = 0;
+    int num_cus = 256;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    double* ws = nullptr;        // device scalar workspace [WS_TOTAL]
+    double* partials = nullptr;  // device partial sums [(2*KK_MAX_M + 8) * KK_MAX_BLOCKS]
+    double* h_pin = nullptr;     // pinned host staging [4][WS_TOTAL]
+    double* h_U = nullptr;       // pinned staging for basistransform's U [KK_MAX_M^2]
+    int blocks_per_cu = 8;
+    int mgs_mode = 1;
+    int fuse_passes = 1;         // fuse unproject(pass i) with project(pass i+1)
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    bool prof = false;
+    std::map<std::string, kk_prof_entry> prof_tab;
+    std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> prof_pending;
+    std::vector<hipEvent_t> event_pool;
+};
+
+struct kk_basis_s {
+    kk_ctx ctx = nullptr;
+    int64_t n = 0, ld = 0;
+    int cap = 0;
+    double* d = nullptr;
+    // Gram bookkeeping for mgs_mode=1: gram[i*cap + j] = <b_i, b_j> for j < i < gram_rows
+    std::vector<double> gram;
+    int gram_c0 = 0;    // first column the Gram rows refer to
+    int gram_rows = 0;  // rows [0, gram_rows) of the strictly-lower Gram matrix are valid
+    inline double* col(int c) const { return d + (int64_t)c * ld; }
+};
+
+struct kk_sparse_dev {  // one direction (A or A') on the device
+    int format = -1;    // 0 = ELL (column-major, padded), 1 = CSR
+    int64_t nrows = 0, ncols = 0, nnz = 0;
+    // ELL
+    int width = 0;
+    int64_t ell_ld = 0;
+    int32_t* ell_col = nullptr;
+    double* ell_val = nullptr;
+    // CSR
+    int32_t* rowptr = nullptr;
+    int32_t* colind = nullptr;
+    double* val = nullptr;
+    int lanes_per_row = 4;
+    // ghost columns (row-sharded operators)
+    int64_t n_local = -1, n_ghost = 0;
+    double* ghost = nullptr;
+    int64_t bytes = 0;
+};
+
+struct kk_host_csr {
+    int64_t nrows = 0, ncols = 0;
+    std::vector<int64_t> rowptr;
+    std::vector<int32_t> col;
+    std::vector<double> val;
+};
+
+struct kk_op_s {
+    kk_ctx ctx = nullptr;
+    int64_t nrows = 0, ncols = 0, nnz = 0;
+    int flags = 0;
+    kk_sparse_dev A, At;
+    kk_host_csr hA;  // kept until A' has been built (or never needed)
+    bool have_At = false;
+    int64_t n_local_cols = -1, n_ghost = 0;
+};
+
+// ---- launch helpers (kk_api.hip)
+struct kk_part {  // static even row partition of [0, ld) over nblk blocks
+    int nblk;
+    int64_t rpb;  // rows per block, multiple of KK_SUB
+};
+kk_part kk_partition(kk_ctx ctx, int64_t ld);
+void kk_prof_begin(kk_ctx ctx, const char* cls);
+void kk_prof_end(kk_ctx ctx);
+struct kk_prof_scope {
+    kk_ctx c;
+    kk_prof_scope(kk_ctx ctx, const char* cls) : c(ctx) {
+        if (c->prof) kk_prof_begin(c, cls);
+    }
+    ~kk_prof_scope() {
+        if (c->prof) kk_prof_end(c);
+    }
+};
+
+// ---- kernels launchers (kk_kernels.hip)
+// coefficient vector passed by value in the kernarg segment (no H2D copy, scalar loads)
+struct kk_coef {
+    double v[KK_MAX_M];
+};
+
+// epilogue / fusion description of an SpMV launch
+struct kk_spmv_fuse {
+    double a1 = 1.0;                 // y = a1*(A x)*xscale + a0*x - bprev*vprev
+    double a0 = 0.0;
+    const double* xscale_dev = nullptr;  // optional device scalar multiplying x (e.g. 1/alpha)
+    const double* vprev = nullptr;   // optional vector subtracted with weight bprev
+    double bprev = 0.0;
+    const double* bprev_dev = nullptr;   // if set: weight = *bprev_dev (device scalar)
+    int dot_mode = 0;                // 0 none, 1 = <x, A x> before subtracting vprev (CGS order,
+                                     // lanczos.jl:298), 2 = <x, y> after (MGS order, lanczos.jl:308)
+    int dot_slot = SC_ALPHA0;        // ws scalar receiving the dot
+    int nrm_slot = -1;               // ws scalar receiving |y|^2 (and sqrt at slot+1, 1/sqrt at +... see finalize)
+};
+
+int kk_launch_spmv(kk_ctx ctx, const kk_sparse_dev& M, const double* x, double* y, int64_t ld_y_rows,
+                   const kk_spmv_fuse& f);
+int kk_launch_dot(kk_ctx ctx, const double* x, const double* y, int64_t ld, int slot_ws_off);
+int kk_launch_nrm2(kk_ctx ctx, const double* x, int64_t ld, int slot_ws_off);  // writes nrm2, sqrt at +1, 1/sqrt at +3
+int kk_launch_axpby(kk_ctx ctx, double* y, const double* x, int64_t ld, double a, double b,
+                    const double* a_dev, double a_dev_sign, int a_dev_mode);
+int kk_launch_scal(kk_ctx ctx, double* x, int64_t ld, double a, const double* a_dev);
+int kk_launch_copy_scal(kk_ctx ctx, double* y, const double* x, int64_t ld, double a);
+int kk_launch_fill_random(kk_ctx ctx, double* x, int64_t n, uint64_t seed);
+int kk_launch_gather(kk_ctx ctx, const double* x, const int64_t* idx, int64_t count, double* out);
+// s = V' * (w - pre_a * pre_vec);  optional second rhs g = V' * rhs2
+int kk_launch_project(kk_ctx ctx, const double* V, int64_t ld, int m, const double* w,
+                      const double* pre_vec, const double* pre_a_dev, const double* rhs2,
+                      int64_t ws_s_off, int64_t ws_g_off);
+// w_out = beta*w_in + alpha * sum_j coef[j] V_j ; coef from kernarg (coef_host) or device (coef_dev)
+// extra: coefficient add_idx gets += *add_dev ; optional |w_out|^2 -> ws[nrm_off] (+sqrt, 1/sqrt)
+int kk_launch_unproject(kk_ctx ctx, const double* V, int64_t ld, int m, const double* w_in, double* w_out,
+                        const kk_coef* coef_host, const double* coef_dev, double alpha, double beta,
+                        int add_idx, const double* add_dev, int64_t nrm_off);
+int kk_launch_mgs_step(kk_ctx ctx, double* w, int64_t ld, const double* q_prev, const double* s_prev_dev,
+                       const double* q_next, int64_t ws_dot_off, int64_t ws_nrm_off);
+int kk_launch_basistransform(kk_ctx ctx, double* V, int64_t ld, int m, int n, const double* U_dev);
+int kk_launch_givens(kk_ctx ctx, double* q1, double* q2, int64_t ld, double c, double s);
+int kk_launch_householder(kk_ctx ctx, double* V, int64_t ld, int m, const kk_coef* v, double beta);
+int kk_launch_rank1(kk_ctx ctx, double* V, int64_t ld, int m, const double* y, const kk_coef* x, double alpha,
+                    double beta);

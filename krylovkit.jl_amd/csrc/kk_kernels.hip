@@ -1,0 +1,846 @@
+// Hand-written gfx950 (CDNA4, wave64) kernels of the Krylov expand! hot path.
+//
+// Every kernel here is HBM-bandwidth bound (<= 0.25 flop/byte).  Common design:
+//   * 256-thread blocks (4 waves), every lane moves 16 B per load (global_load_dwordx4),
+//     a wave instruction covers 1 KiB contiguous -> fully coalesced column streams.
+//   * static even row partition: block b owns rows [b*rpb, (b+1)*rpb), rpb a multiple of 512,
+//     so all blocks carry the same byte count and reductions are summed in a fixed order
+//     (bitwise reproducible run to run).
+//   * reductions: per-lane FMA chains -> DPP butterfly inside each row of 16 lanes ->
+//     v_readlane across the 4 rows -> LDS across the 4 waves -> one partial per block in
+//     HBM -> tiny finalize kernel.  No atomics.
+//   * rows n..ld-1 of every column are zero and stay zero, so no kernel needs a row bound check.
+#include "kk_internal.h"
+
+typedef double2 d2;
+__device__ __forceinline__ int64_t imin(int64_t a, int64_t b) { return a < b ? a : b; }
+
+__device__ __forceinline__ d2 ld2(const double* p) { return *reinterpret_cast<const d2*>(p); }
+__device__ __forceinline__ void st2(double* p, d2 v) { *reinterpret_cast<d2*>(p) = v; }
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_d(double v, int l) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+// Sum over the 64 lanes of a wave; result is wave-uniform (same bits in every lane).
+__device__ __forceinline__ double wave_sum(double v) {
+#ifndef KK_NO_DPP
+    v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);  // row_half_mirror
+    v += dpp_mov<0x140>(v);  // row_mirror  -> every lane holds the sum of its row of 16
+    double r0 = readlane_d(v, 0), r1 = readlane_d(v, 16), r2 = readlane_d(v, 32), r3 = readlane_d(v, 48);
+    return (r0 + r1) + (r2 + r3);
+#else
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+#endif
+}
+// Sum over the 32-lane half a lane belongs to (DPP row ops + one cross-row readlane pair).
+__device__ __forceinline__ double block_sum(double v, double* sm /* >= 4 doubles */) {
+    v = wave_sum(v);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) sm[wave] = v;
+    __syncthreads();
+    double t = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+    __syncthreads();
+    return t;
+}
+
+// ------------------------------------------------------------------------------------------
+// BLAS-1 verbs
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(KK_TPB) void k_dot(const double* __restrict__ x, const double* __restrict__ y,
+                                                int64_t ld, int64_t rpb, double* __restrict__ part) {
+    __shared__ double sm[4];
+    const int64_t r0 = (int64_t)blockIdx.x * rpb, r1 = imin(r0 + rpb, ld);
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    int64_t r = r0 + threadIdx.x * 2;
+    for (; r + 3 * KK_SUB < r1; r += 4 * KK_SUB) {
+        d2 x0 = ld2(x + r), x1 = ld2(x + r + KK_SUB), x2 = ld2(x + r + 2 * KK_SUB), x3 = ld2(x + r + 3 * KK_SUB);
+        d2 y0 = ld2(y + r), y1 = ld2(y + r + KK_SUB), y2 = ld2(y + r + 2 * KK_SUB), y3 = ld2(y + r + 3 * KK_SUB);
+        a0 = fma(x0.x, y0.x, a0); a0 = fma(x0.y, y0.y, a0);
+        a1 = fma(x1.x, y1.x, a1); a1 = fma(x1.y, y1.y, a1);
+        a2 = fma(x2.x, y2.x, a2); a2 = fma(x2.y, y2.y, a2);
+        a3 = fma(x3.x, y3.x, a3); a3 = fma(x3.y, y3.y, a3);
+    }
+    for (; r < r1; r += KK_SUB) {
+        d2 x0 = ld2(x + r), y0 = ld2(y + r);
+        a0 = fma(x0.x, y0.x, a0); a0 = fma(x0.y, y0.y, a0);
+    }
+    double t = block_sum((a0 + a1) + (a2 + a3), sm);
+    if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+
+// out[0] = sum(part[0..n)), out[1] = sqrt, out[2] = 1/sqrt   (single block)
+__global__ __launch_bounds__(KK_TPB) void k_finalize_scalar(const double* __restrict__ part, int n,
+                                                            double* __restrict__ out, int with_sqrt) {
+    __shared__ double sm[4];
+    double a = 0;
+    for (int i = threadIdx.x; i < n; i += KK_TPB) a += part[i];
+    double t = block_sum(a, sm);
+    if (threadIdx.x == 0) {
+        out[0] = t;
+        if (with_sqrt) {
+            double s = sqrt(t);
+            out[1] = s;
+            out[2] = 1.0 / s;
+        }
+    }
+}
+
+// y = b*y + a*x ; a = a_host, or a_sign * (*a_dev) [mode 1], or a_sign / (*a_dev) [mode 2]
+template <bool BZERO>
+__global__ __launch_bounds__(KK_TPB) void k_axpby(double* __restrict__ y, const double* __restrict__ x, int64_t ld,
+                                                  int64_t rpb, double a, double b, const double* __restrict__ a_dev,
+                                                  double a_sign, int a_mode) {
+    if (a_dev) a = (a_mode == 2) ? a_sign / *a_dev : a_sign * *a_dev;
+    const int64_t r0 = (int64_t)blockIdx.x * rpb, r1 = imin(r0 + rpb, ld);
+    for (int64_t r = r0 + threadIdx.x * 2; r < r1; r += KK_SUB) {
+        d2 xv = ld2(x + r), yv;
+        if (BZERO) {
+            yv.x = a * xv.x; yv.y = a * xv.y;
+        } else {
+            yv = ld2(y + r);
+            yv.x = fma(a, xv.x, b * yv.x); yv.y = fma(a, xv.y, b * yv.y);
+        }
+        st2(y + r, yv);
+    }
+}
+
+__global__ __launch_bounds__(KK_TPB) void k_scal(double* __restrict__ x, int64_t ld, int64_t rpb, double a,
+                                                 const double* __restrict__ a_dev) {
+    if (a_dev) a = *a_dev;
+    const int64_t r0 = (int64_t)blockIdx.x * rpb, r1 = imin(r0 + rpb, ld);
+    for (int64_t r = r0 + threadIdx.x * 2; r < r1; r += KK_SUB) {
+        d2 v = ld2(x + r);
+        v.x *= a; v.y *= a;
+        st2(x + r, v);
+    }
+}
+
+// counter-based uniform [0,1): splitmix64 of (seed, row) -> 53-bit mantissa. Independent of grid.
+__global__ __launch_bounds__(KK_TPB) void k_fill_random(double* __restrict__ x, int64_t n, uint64_t seed) {
+    for (int64_t i = (int64_t)blockIdx.x * KK_TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * KK_TPB) {
+        uint64_t z = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(i + 1);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z = z ^ (z >> 31);
+        x[i] = (double)(z >> 11) * (1.0 / 9007199254740992.0);
+    }
+}
+
+__global__ __launch_bounds__(KK_TPB) void k_gather(const double* __restrict__ x, const int64_t* __restrict__ idx,
+                                                   int64_t count, double* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * KK_TPB + threadIdx.x; i < count; i += (int64_t)gridDim.x * KK_TPB)
+        out[i] = x[idx[i]];
+}
+
+// ------------------------------------------------------------------------------------------
+// project: s[j] = <V_j, w'>, j < m, with w' = w - a*pre (optional) and an optional second
+// right-hand side g[j] = <V_j, rhs2>.  V is read exactly once (8 m N bytes), w once.
+// Lane-distributed accumulators: lane l of every wave owns columns l, 64+l, 128+l, 192+l.
+// ------------------------------------------------------------------------------------------
+template <bool PRE, bool RHS2, bool FULL>
+__device__ __forceinline__ void proj_batch(const double* __restrict__ Vc, int64_t ld, int ncol, int nsub, const d2 (&wv)[KK_RG],
+                                           const d2 (&gv)[KK_RG], int lane, int jj, double& acc, double& acc2) {
+    d2 x[4][KK_RG];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+        for (int k = 0; k < KK_RG; ++k) {
+            if (FULL || (c < ncol && k < nsub))
+                x[c][k] = ld2(Vc + (int64_t)c * ld + k * KK_SUB);
+            else
+                x[c][k] = d2{0.0, 0.0};
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        double t = 0;
+#pragma unroll
+        for (int k = 0; k < KK_RG; ++k) {
+            t = fma(x[c][k].x, wv[k].x, t);
+            t = fma(x[c][k].y, wv[k].y, t);
+        }
+        double tot = wave_sum(t);
+        acc += (lane == jj + c) ? tot : 0.0;
+        if (RHS2) {
+            double t2 = 0;
+#pragma unroll
+            for (int k = 0; k < KK_RG; ++k) {
+                t2 = fma(x[c][k].x, gv[k].x, t2);
+                t2 = fma(x[c][k].y, gv[k].y, t2);
+            }
+            double tot2 = wave_sum(t2);
+            acc2 += (lane == jj + c) ? tot2 : 0.0;
+        }
+    }
+}
+
+template <bool PRE, bool RHS2>
+__global__ __launch_bounds__(KK_TPB) void k_project(const double* __restrict__ V, int64_t ld, int m,
+                                                    const double* __restrict__ w, const double* __restrict__ pre_vec,
+                                                    const double* __restrict__ pre_a, const double* __restrict__ rhs2,
+                                                    int64_t rpb, double* __restrict__ part) {
+    __shared__ double sm[(RHS2 ? 2 : 1) * 4 * KK_MAX_M];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t r0 = (int64_t)blockIdx.x * rpb, r1 = imin(r0 + rpb, ld);
+    double acc[4] = {0, 0, 0, 0}, acc2[4] = {0, 0, 0, 0};
+    double a = 0;
+    if (PRE) a = *pre_a;
+    for (int64_t rg = r0; rg < r1; rg += KK_SUB * KK_RG) {
+        const int nsub = (int)imin((int64_t)KK_RG, (r1 - rg) / KK_SUB);
+        const int64_t off = rg + tid * 2;
+        d2 wv[KK_RG], gv[KK_RG];
+#pragma unroll
+        for (int k = 0; k < KK_RG; ++k) {
+            if (k < nsub) {
+                wv[k] = ld2(w + off + k * KK_SUB);
+                if (PRE) {
+                    d2 p = ld2(pre_vec + off + k * KK_SUB);
+                    wv[k].x = fma(-a, p.x, wv[k].x);
+                    wv[k].y = fma(-a, p.y, wv[k].y);
+                }
+                if (RHS2) gv[k] = ld2(rhs2 + off + k * KK_SUB);
+                else gv[k] = d2{0.0, 0.0};
+            } else {
+                wv[k] = d2{0.0, 0.0};
+                gv[k] = d2{0.0, 0.0};
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int jq = q * 64;
+            if (jq < m) {
+                const int jn = min(64, m - jq);
+                const double* Vq = V + (int64_t)jq * ld + off;
+                int jj = 0;
+                if (nsub == KK_RG) {
+                    for (; jj + 4 <= jn; jj += 4)
+                        proj_batch<PRE, RHS2, true>(Vq + (int64_t)jj * ld, ld, 4, KK_RG, wv, gv, lane, jj, acc[q], acc2[q]);
+                }
+                for (; jj < jn; jj += 4)
+                    proj_batch<PRE, RHS2, false>(Vq + (int64_t)jj * ld, ld, min(4, jn - jj), nsub, wv, gv, lane, jj, acc[q], acc2[q]);
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (q * 64 < m) {
+            sm[wave * KK_MAX_M + q * 64 + lane] = acc[q];
+            if (RHS2) sm[4 * KK_MAX_M + wave * KK_MAX_M + q * 64 + lane] = acc2[q];
+        }
+    }
+    __syncthreads();
+    if (tid < m) {
+        double t = (sm[tid] + sm[KK_MAX_M + tid]) + (sm[2 * KK_MAX_M + tid] + sm[3 * KK_MAX_M + tid]);
+        part[(int64_t)tid * KK_MAX_BLOCKS + blockIdx.x] = t;
+        if (RHS2) {
+            const double* s2 = sm + 4 * KK_MAX_M;
+            double t2 = (s2[tid] + s2[KK_MAX_M + tid]) + (s2[2 * KK_MAX_M + tid] + s2[3 * KK_MAX_M + tid]);
+            part[(int64_t)(KK_MAX_M + tid) * KK_MAX_BLOCKS + blockIdx.x] = t2;
+        }
+    }
+}
+
+// one wave per output value: ws_a[j] = sum_b part[j][b]; second segment (rows KK_MAX_M + j) -> ws_b[j]
+__global__ __launch_bounds__(KK_TPB) void k_finalize_project(const double* __restrict__ part, int nblk, int m,
+                                                             double* __restrict__ ws_a, double* __restrict__ ws_b) {
+    const int lane = threadIdx.x & 63;
+    const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int total = ws_b ? 2 * m : m;
+    if (v >= total) return;
+    const int row = (v < m) ? v : KK_MAX_M + (v - m);
+    const double* p = part + (int64_t)row * KK_MAX_BLOCKS;
+    double a = 0;
+    for (int b = lane; b < nblk; b += 64) a += p[b];
+    a = wave_sum(a);
+    if (lane == 0) {
+        if (v < m) ws_a[v] = a;
+        else ws_b[v - m] = a;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// unproject: w_out = beta*w_in + alpha * sum_j c[j] V_j, with optional fused |w_out|^2.
+// Coefficients come from the kernarg segment (host vector, scalar loads) or from device memory;
+// coefficient add_idx may get a device scalar added (folds the Lanczos "w -= alpha v" into the pass).
+// ------------------------------------------------------------------------------------------
+template <bool NORM, bool BZERO>
+__global__ __launch_bounds__(KK_TPB) void k_unproject(const double* __restrict__ V, int64_t ld, int m,
+                                                      const double* w_in, double* w_out,
+                                                      kk_coef ch, const double* __restrict__ coef_dev, double alpha,
+                                                      double beta, int add_idx, const double* __restrict__ add_dev,
+                                                      int64_t rpb, double* __restrict__ part) {
+    __shared__ double sc[KK_MAX_M];
+    __shared__ double sm[4];
+    const int tid = threadIdx.x;
+    if (tid < m) {
+        double c = coef_dev ? coef_dev[tid] : ch.v[tid];
+        if (tid == add_idx) c += *add_dev;
+        sc[tid] = alpha * c;
+    }
+    __syncthreads();
+    const int64_t r0 = (int64_t)blockIdx.x * rpb, r1 = imin(r0 + rpb, ld);
+    double nacc = 0;
+    for (int64_t rg = r0; rg < r1; rg += KK_SUB * KK_RG) {
+        const int nsub = (int)imin((int64_t)KK_RG, (r1 - rg) / KK_SUB);
+        const int64_t off = rg + tid * 2;
+        d2 wv[KK_RG];
+#pragma unroll
+        for (int k = 0; k < KK_RG; ++k) {
+            if (!BZERO && k < nsub) {
+                wv[k] = ld2(w_in + off + k * KK_SUB);
+                wv[k].x *= beta; wv[k].y *= beta;
+            } else {
+                wv[k] = d2{0.0, 0.0};
+            }
+        }
+        const double* Vo = V + off;
+        int j = 0;
+        if (nsub == KK_RG) {
+            for (; j + 4 <= m; j += 4) {
+                d2 x[4][KK_RG];
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int k = 0; k < KK_RG; ++k) x[c][k] = ld2(Vo + (int64_t)(j + c) * ld + k * KK_SUB);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const double s = sc[j + c];
+#pragma unroll
+                    for (int k = 0; k < KK_RG; ++k) {
+                        wv[k].x = fma(s, x[c][k].x, wv[k].x);
+                        wv[k].y = fma(s, x[c][k].y, wv[k].y);
+                    }
+                }
+            }
+        }
+        for (; j < m; ++j) {
+            const double s = sc[j];
+#pragma unroll
+            for (int k = 0; k < KK_RG; ++k) {
+                if (k < nsub) {
+                    d2 x = ld2(Vo + (int64_t)j * ld + k * KK_SUB);
+                    wv[k].x = fma(s, x.x, wv[k].x);
+                    wv[k].y = fma(s, x.y, wv[k].y);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < KK_RG; ++k) {
+            if (k < nsub) {
+                st2(w_out + off + k * KK_SUB, wv[k]);
+                if (NORM) {
+                    nacc = fma(wv[k].x, wv[k].x, nacc);
+                    nacc = fma(wv[k].y, wv[k].y, nacc);
+                }
+            }
+        }
+    }
+    if (NORM) {
+        double t = block_sum(nacc, sm);
+        if (tid == 0) part[blockIdx.x] = t;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// strict modified Gram-Schmidt step (src/orthonormal.jl:417-421), fused across the j boundary:
+//   w -= s_prev * q_prev   (axpy of step j-1, skipped if q_prev == nullptr)
+//   partial <q_next, w>    (dot of step j, skipped if q_next == nullptr)
+//   partial |w|^2          (when NORM)
+// 32 N bytes per basis vector instead of 40 N for separate dot + axpy.
+// ------------------------------------------------------------------------------------------
+template <bool NORM>
+__global__ __launch_bounds__(KK_TPB) void k_mgs_step(double* __restrict__ w, int64_t ld, int64_t rpb,
+                                                     const double* __restrict__ q_prev,
+                                                     const double* __restrict__ s_prev, const double* __restrict__ q_next,
+                                                     double* __restrict__ part_dot, double* __restrict__ part_nrm) {
+    __shared__ double sm[4];
+    const double s = q_prev ? *s_prev : 0.0;
+    const int64_t r0 = (int64_t)blockIdx.x * rpb, r1 = imin(r0 + rpb, ld);
+    double a0 = 0, a1 = 0, n0 = 0;
+    int64_t r = r0 + threadIdx.x * 2;
+    for (; r + KK_SUB < r1; r += 2 * KK_SUB) {
+        d2 w0 = ld2(w + r), w1 = ld2(w + r + KK_SUB);
+        if (q_prev) {
+            d2 p0 = ld2(q_prev + r), p1 = ld2(q_prev + r + KK_SUB);
+            w0.x = fma(-s, p0.x, w0.x); w0.y = fma(-s, p0.y, w0.y);
+            w1.x = fma(-s, p1.x, w1.x); w1.y = fma(-s, p1.y, w1.y);
+            st2(w + r, w0); st2(w + r + KK_SUB, w1);
+        }
+        if (q_next) {
+            d2 q0 = ld2(q_next + r), q1 = ld2(q_next + r + KK_SUB);
+            a0 = fma(q0.x, w0.x, a0); a0 = fma(q0.y, w0.y, a0);
+            a1 = fma(q1.x, w1.x, a1); a1 = fma(q1.y, w1.y, a1);
+        }
+        if (NORM) {
+            n0 = fma(w0.x, w0.x, n0); n0 = fma(w0.y, w0.y, n0);
+            n0 = fma(w1.x, w1.x, n0); n0 = fma(w1.y, w1.y, n0);
+        }
+    }
+    for (; r < r1; r += KK_SUB) {
+        d2 w0 = ld2(w + r);
+        if (q_prev) {
+            d2 p0 = ld2(q_prev + r);
+            w0.x = fma(-s, p0.x, w0.x); w0.y = fma(-s, p0.y, w0.y);
+            st2(w + r, w0);
+        }
+        if (q_next) {
+            d2 q0 = ld2(q_next + r);
+            a0 = fma(q0.x, w0.x, a0); a0 = fma(q0.y, w0.y, a0);
+        }
+        if (NORM) { n0 = fma(w0.x, w0.x, n0); n0 = fma(w0.y, w0.y, n0); }
+    }
+    if (q_next) {
+        double t = block_sum(a0 + a1, sm);
+        if (threadIdx.x == 0) part_dot[blockIdx.x] = t;
+    }
+    if (NORM) {
+        double t = block_sum(n0, sm);
+        if (threadIdx.x == 0) part_nrm[blockIdx.x] = t;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// SpMV.  ELL (column-major, padded to `width`) with 2 rows per lane for regular matrices
+// (stencils); CSR with L lanes per row (L = 64 is row-per-wavefront) otherwise.
+// Fused epilogue (Lanczos three-term tail, lanczos.jl:297-310):
+//   ax  = xs * sum_k val*x[col]            (xs: optional device scalar, e.g. 1/alpha in GKL)
+//   y   = a1*ax + a0*x[row] - bprev*vprev[row]
+//   dot = <x, ax> (mode 1)  or <x, y> (mode 2)    nrm2 = |y|^2
+// Column indices >= n_local address the ghost buffer (row-sharded operators).
+// ------------------------------------------------------------------------------------------
+struct spmv_epi {
+    double a1, a0, bprev;
+    const double* xs_dev;
+    const double* bprev_dev;
+    const double* vprev;
+    int dot_mode;
+    int want_nrm;
+    int64_t n_local;  // < 0: no ghost
+    const double* ghost;
+};
+
+__device__ __forceinline__ double xload(const double* __restrict__ x, const spmv_epi& e, int c) {
+    if (e.n_local >= 0 && c >= e.n_local) return e.ghost[c - e.n_local];
+    return x[c];
+}
+
+__global__ __launch_bounds__(KK_TPB) void k_spmv_ell(const int32_t* __restrict__ ecol, const double* __restrict__ eval,
+                                                     int64_t ell_ld, int width, int64_t nrows,
+                                                     const double* __restrict__ x, double* __restrict__ y, spmv_epi e,
+                                                     int nb_logical, double* __restrict__ part_dot,
+                                                     double* __restrict__ part_nrm) {
+    __shared__ double sm[4];
+    // XCD banding: block b runs on XCD b & 7 and walks the band [xcd*per, (xcd+1)*per) of logical
+    // 512-row chunks with stride nbx, so the blocks resident on one XCD sweep a contiguous row
+    // window together and stencil neighbours (+-nx rows) are L2 hits of the same XCD.
+    const int per = (nb_logical + 7) >> 3;
+    const int nbx = gridDim.x >> 3;
+    const int xcd = blockIdx.x & 7;
+    double dacc = 0, nacc = 0;
+    const double xs = e.xs_dev ? *e.xs_dev : 1.0;
+    const double bp = e.vprev ? (e.bprev_dev ? *e.bprev_dev : e.bprev) : 0.0;
+    for (int c = blockIdx.x >> 3; c < per; c += nbx) {
+        const int lb = xcd * per + c;
+        if (lb >= nb_logical) break;
+        const int64_t row = ((int64_t)lb * KK_TPB + threadIdx.x) * 2;
+        if (row < nrows) {  // ell_ld is even and >= nrows; pad entries have val 0, col 0
+            double s0 = 0, s1 = 0;
+            const int32_t* cp = ecol + row;
+            const double* vp = eval + row;
+            for (int k = 0; k < width; ++k) {
+                const int2 cc = *reinterpret_cast<const int2*>(cp + (int64_t)k * ell_ld);
+                const d2 v = ld2(vp + (int64_t)k * ell_ld);
+                s0 = fma(v.x, xload(x, e, cc.x), s0);
+                s1 = fma(v.y, xload(x, e, cc.y), s1);
+            }
+            s0 *= xs; s1 *= xs;
+            d2 out{e.a1 * s0, e.a1 * s1};
+            d2 xv{0.0, 0.0};
+            if (e.a0 != 0.0 || e.dot_mode) {
+                xv = ld2(x + row);
+                xv.x *= xs; xv.y *= xs;
+            }
+            if (e.a0 != 0.0) { out.x = fma(e.a0, xv.x, out.x); out.y = fma(e.a0, xv.y, out.y); }
+            if (e.dot_mode == 1) { dacc = fma(xv.x, out.x, dacc); dacc = fma(xv.y, out.y, dacc); }
+            if (e.vprev) {
+                const d2 p = ld2(e.vprev + row);
+                out.x = fma(-bp, p.x, out.x); out.y = fma(-bp, p.y, out.y);
+            }
+            if (row + 1 >= nrows) out.y = 0.0;  // odd nrows: keep the pad row zero
+            if (e.dot_mode == 2) { dacc = fma(xv.x, out.x, dacc); dacc = fma(xv.y, out.y, dacc); }
+            if (e.want_nrm) { nacc = fma(out.x, out.x, nacc); nacc = fma(out.y, out.y, nacc); }
+            st2(y + row, out);
+        }
+    }
+    if (e.dot_mode) {
+        double t = block_sum(dacc, sm);
+        if (threadIdx.x == 0) part_dot[blockIdx.x] = t;
+    }
+    if (e.want_nrm) {
+        double t = block_sum(nacc, sm);
+        if (threadIdx.x == 0) part_nrm[blockIdx.x] = t;
+    }
+}
+
+template <int L>
+__global__ __launch_bounds__(KK_TPB) void k_spmv_csr(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind,
+                                                     const double* __restrict__ val, int64_t nrows,
+                                                     const double* __restrict__ x, double* __restrict__ y, spmv_epi e,
+                                                     double* __restrict__ part_dot, double* __restrict__ part_nrm) {
+    __shared__ double sm[4];
+    constexpr int RPB = KK_TPB / L;  // rows per block iteration
+    const int sub = threadIdx.x % L, rl = threadIdx.x / L;
+    double dacc = 0, nacc = 0;
+    const double xs = e.xs_dev ? *e.xs_dev : 1.0;
+    for (int64_t row = (int64_t)blockIdx.x * RPB + rl; row < nrows; row += (int64_t)gridDim.x * RPB) {
+        const int b = rowptr[row], en = rowptr[row + 1];
+        double s = 0;
+        for (int k = b + sub; k < en; k += L) s = fma(val[k], xload(x, e, colind[k]), s);
+#pragma unroll
+        for (int o = L / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, L);
+        if (sub == 0) {
+            s *= xs;
+            double out = e.a1 * s;
+            double xv = 0;
+            if (e.a0 != 0.0 || e.dot_mode) xv = x[row] * xs;
+            if (e.a0 != 0.0) out = fma(e.a0, xv, out);
+            if (e.dot_mode == 1) dacc = fma(xv, out, dacc);
+            if (e.vprev) {
+                const double bp = e.bprev_dev ? *e.bprev_dev : e.bprev;
+                out = fma(-bp, e.vprev[row], out);
+            }
+            if (e.dot_mode == 2) dacc = fma(xv, out, dacc);
+            if (e.want_nrm) nacc = fma(out, out, nacc);
+            y[row] = out;
+        }
+    }
+    if (e.dot_mode) {
+        double t = block_sum(dacc, sm);
+        if (threadIdx.x == 0) part_dot[blockIdx.x] = t;
+    }
+    if (e.want_nrm) {
+        double t = block_sum(nacc, sm);
+        if (threadIdx.x == 0) part_nrm[blockIdx.x] = t;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// restart-time kernels (per restart, not per iteration)
+// ------------------------------------------------------------------------------------------
+// basistransform! (orthonormal.jl:291-354): V[:, 0:n] <- V[:, 0:m] * U (m x n, column-major in
+// device memory).  Row-local, so it is done in place: a block stages a 64-row x m tile in LDS,
+// then each thread produces outputs for (row, 4 columns at a time).
+#define BT_ROWS 64
+__global__ __launch_bounds__(KK_TPB) void k_basistransform(double* __restrict__ V, int64_t ld, int m, int n,
+                                                           const double* __restrict__ U) {
+    extern __shared__ __attribute__((aligned(16))) double tile[];  // [m][BT_ROWS + 1]
+    const int tid = threadIdx.x;
+    const int TS = BT_ROWS + 1;
+    for (int64_t rb = (int64_t)blockIdx.x * BT_ROWS; rb < ld; rb += (int64_t)gridDim.x * BT_ROWS) {
+        for (int idx = tid; idx < m * BT_ROWS; idx += KK_TPB) {
+            const int i = idx / BT_ROWS, r = idx % BT_ROWS;
+            tile[i * TS + r] = V[(int64_t)i * ld + rb + r];
+        }
+        __syncthreads();
+        const int r = tid % BT_ROWS, jg = tid / BT_ROWS;  // 4 column groups
+        for (int j = jg; j < n; j += 4) {
+            const double* Uj = U + (int64_t)j * m;
+            double a = 0;
+            for (int i = 0; i < m; ++i) a = fma(tile[i * TS + r], Uj[i], a);
+            V[(int64_t)j * ld + rb + r] = a;
+        }
+        __syncthreads();
+    }
+}
+
+// rmul!(b, G::Givens) (dense/givens.jl:20-36): (q1,q2) <- (c q1 - s q2, s q1 + c q2)
+__global__ __launch_bounds__(KK_TPB) void k_givens(double* __restrict__ q1, double* __restrict__ q2, int64_t ld,
+                                                   int64_t rpb, double c, double s) {
+    const int64_t r0 = (int64_t)blockIdx.x * rpb, r1 = imin(r0 + rpb, ld);
+    for (int64_t r = r0 + threadIdx.x * 2; r < r1; r += KK_SUB) {
+        d2 a = ld2(q1 + r), b = ld2(q2 + r), o1, o2;
+        o1.x = c * a.x - s * b.x; o1.y = c * a.y - s * b.y;
+        o2.x = s * a.x + c * b.x; o2.y = s * a.y + c * b.y;
+        st2(q1 + r, o1); st2(q2 + r, o2);
+    }
+}
+
+// rmul!(b, H::Householder) (dense/reflector.jl:143-154), row-local and fused:
+//   t = sum_j V[row,j] v[j];  V[row,j] -= beta * t * v[j]
+// two sweeps over the m columns of the row tile; the second sweep hits L2.
+__global__ __launch_bounds__(KK_TPB) void k_householder(double* __restrict__ V, int64_t ld, int m, kk_coef hv,
+                                                        double beta, int64_t rpb) {
+    const int64_t r0 = (int64_t)blockIdx.x * rpb, r1 = imin(r0 + rpb, ld);
+    for (int64_t r = r0 + threadIdx.x * 2; r < r1; r += KK_SUB) {
+        d2 t{0.0, 0.0};
+        for (int j = 0; j < m; ++j) {
+            const d2 x = ld2(V + (int64_t)j * ld + r);
+            t.x = fma(x.x, hv.v[j], t.x); t.y = fma(x.y, hv.v[j], t.y);
+        }
+        t.x *= beta; t.y *= beta;
+        for (int j = 0; j < m; ++j) {
+            d2 x = ld2(V + (int64_t)j * ld + r);
+            x.x = fma(-t.x, hv.v[j], x.x); x.y = fma(-t.y, hv.v[j], x.y);
+            st2(V + (int64_t)j * ld + r, x);
+        }
+    }
+}
+
+// rank1update! (orthonormal.jl:210-275): V_j = beta*V_j + alpha * y * x[j]
+__global__ __launch_bounds__(KK_TPB) void k_rank1(double* __restrict__ V, int64_t ld, int m,
+                                                  const double* __restrict__ y, kk_coef xc, double alpha, double beta,
+                                                  int64_t rpb) {
+    const int64_t r0 = (int64_t)blockIdx.x * rpb, r1 = imin(r0 + rpb, ld);
+    for (int64_t r = r0 + threadIdx.x * 2; r < r1; r += KK_SUB) {
+        const d2 yv = ld2(y + r);
+        for (int j = 0; j < m; ++j) {
+            const double a = alpha * xc.v[j];
+            d2 x;
+            if (beta == 0.0) { x.x = a * yv.x; x.y = a * yv.y; }
+            else {
+                x = ld2(V + (int64_t)j * ld + r);
+                x.x = fma(a, yv.x, beta * x.x); x.y = fma(a, yv.y, beta * x.y);
+            }
+            st2(V + (int64_t)j * ld + r, x);
+        }
+    }
+}
+
+// ==========================================================================================
+// host-side launchers
+// ==========================================================================================
+static inline double* part_row(kk_ctx ctx, int row) { return ctx->partials + (int64_t)row * KK_MAX_BLOCKS; }
+#define PART_SCAL_A (2 * KK_MAX_M)      // partial rows used by scalar reductions
+#define PART_SCAL_B (2 * KK_MAX_M + 1)
+
+static int finalize_scalar(kk_ctx ctx, int part_row_idx, int n, int64_t ws_off, bool with_sqrt) {
+    hipLaunchKernelGGL(k_finalize_scalar, dim3(1), dim3(KK_TPB), 0, ctx->stream, part_row(ctx, part_row_idx), n,
+                       ctx->ws + ws_off, with_sqrt ? 1 : 0);
+    KK_HIP(hipGetLastError());
+    return KK_OK;
+}
+
+int kk_launch_dot(kk_ctx ctx, const double* x, const double* y, int64_t ld, int slot_ws_off) {
+    kk_part p = kk_partition(ctx, ld);
+    {
+        kk_prof_scope ps(ctx, "k_dot");
+        hipLaunchKernelGGL(k_dot, dim3(p.nblk), dim3(KK_TPB), 0, ctx->stream, x, y, ld, p.rpb, part_row(ctx, PART_SCAL_A));
+    }
+    KK_HIP(hipGetLastError());
+    return finalize_scalar(ctx, PART_SCAL_A, p.nblk, slot_ws_off, false);
+}
+
+int kk_launch_nrm2(kk_ctx ctx, const double* x, int64_t ld, int slot_ws_off) {
+    kk_part p = kk_partition(ctx, ld);
+    {
+        kk_prof_scope ps(ctx, "k_dot");
+        hipLaunchKernelGGL(k_dot, dim3(p.nblk), dim3(KK_TPB), 0, ctx->stream, x, x, ld, p.rpb, part_row(ctx, PART_SCAL_A));
+    }
+    KK_HIP(hipGetLastError());
+    return finalize_scalar(ctx, PART_SCAL_A, p.nblk, slot_ws_off, true);
+}
+
+int kk_launch_axpby(kk_ctx ctx, double* y, const double* x, int64_t ld, double a, double b, const double* a_dev,
+                    double a_dev_sign, int a_dev_mode) {
+    kk_prof_scope ps(ctx, "k_axpby");
+    kk_part p = kk_partition(ctx, ld);
+    if (b == 0.0)
+        hipLaunchKernelGGL(k_axpby<true>, dim3(p.nblk), dim3(KK_TPB), 0, ctx->stream, y, x, ld, p.rpb, a, b, a_dev,
+                           a_dev_sign, a_dev_mode);
+    else
+        hipLaunchKernelGGL(k_axpby<false>, dim3(p.nblk), dim3(KK_TPB), 0, ctx->stream, y, x, ld, p.rpb, a, b, a_dev,
+                           a_dev_sign, a_dev_mode);
+    KK_HIP(hipGetLastError());
+    return KK_OK;
+}
+
+int kk_launch_scal(kk_ctx ctx, double* x, int64_t ld, double a, const double* a_dev) {
+    kk_prof_scope ps(ctx, "k_scal");
+    kk_part p = kk_partition(ctx, ld);
+    hipLaunchKernelGGL(k_scal, dim3(p.nblk), dim3(KK_TPB), 0, ctx->stream, x, ld, p.rpb, a, a_dev);
+    KK_HIP(hipGetLastError());
+    return KK_OK;
+}
+
+int kk_launch_copy_scal(kk_ctx ctx, double* y, const double* x, int64_t ld, double a) {
+    return kk_launch_axpby(ctx, y, x, ld, a, 0.0, nullptr, 1.0, 0);
+}
+
+int kk_launch_fill_random(kk_ctx ctx, double* x, int64_t n, uint64_t seed) {
+    kk_prof_scope ps(ctx, "k_fill_random");
+    int nb = (int)std::min<int64_t>((n + KK_TPB - 1) / KK_TPB, 4096);
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(k_fill_random, dim3(nb), dim3(KK_TPB), 0, ctx->stream, x, n, seed);
+    KK_HIP(hipGetLastError());
+    return KK_OK;
+}
+
+int kk_launch_gather(kk_ctx ctx, const double* x, const int64_t* idx, int64_t count, double* out) {
+    kk_prof_scope ps(ctx, "k_gather");
+    if (count <= 0) return KK_OK;
+    int nb = (int)std::min<int64_t>((count + KK_TPB - 1) / KK_TPB, 4096);
+    hipLaunchKernelGGL(k_gather, dim3(nb), dim3(KK_TPB), 0, ctx->stream, x, idx, count, out);
+    KK_HIP(hipGetLastError());
+    return KK_OK;
+}
+
+int kk_launch_project(kk_ctx ctx, const double* V, int64_t ld, int m, const double* w, const double* pre_vec,
+                      const double* pre_a_dev, const double* rhs2, int64_t ws_s_off, int64_t ws_g_off) {
+    kk_part p = kk_partition(ctx, ld);
+    dim3 g(p.nblk), b(KK_TPB);
+    double* part = ctx->partials;
+    kk_prof_scope* ps = new kk_prof_scope(ctx, "k_project");
+    if (pre_vec && rhs2)
+        hipLaunchKernelGGL((k_project<true, true>), g, b, 0, ctx->stream, V, ld, m, w, pre_vec, pre_a_dev, rhs2, p.rpb, part);
+    else if (pre_vec)
+        hipLaunchKernelGGL((k_project<true, false>), g, b, 0, ctx->stream, V, ld, m, w, pre_vec, pre_a_dev, rhs2, p.rpb, part);
+    else if (rhs2)
+        hipLaunchKernelGGL((k_project<false, true>), g, b, 0, ctx->stream, V, ld, m, w, pre_vec, pre_a_dev, rhs2, p.rpb, part);
+    else
+        hipLaunchKernelGGL((k_project<false, false>), g, b, 0, ctx->stream, V, ld, m, w, pre_vec, pre_a_dev, rhs2, p.rpb, part);
+    delete ps;
+    KK_HIP(hipGetLastError());
+    const int total = rhs2 ? 2 * m : m;
+    hipLaunchKernelGGL(k_finalize_project, dim3((total + 3) / 4), dim3(KK_TPB), 0, ctx->stream, part, p.nblk, m,
+                       ctx->ws + ws_s_off, rhs2 ? ctx->ws + ws_g_off : (double*)nullptr);
+    KK_HIP(hipGetLastError());
+    return KK_OK;
+}
+
+int kk_launch_unproject(kk_ctx ctx, const double* V, int64_t ld, int m, const double* w_in, double* w_out,
+                        const kk_coef* coef_host, const double* coef_dev, double alpha, double beta, int add_idx,
+                        const double* add_dev, int64_t nrm_off) {
+    kk_part p = kk_partition(ctx, ld);
+    dim3 g(p.nblk), b(KK_TPB);
+    static const kk_coef zero_coef = {};
+    const kk_coef& ch = coef_host ? *coef_host : zero_coef;
+    double* part = part_row(ctx, PART_SCAL_A);
+    const bool norm = nrm_off >= 0, bzero = (beta == 0.0);
+    kk_prof_scope* ps = new kk_prof_scope(ctx, "k_unproject");
+    if (norm && bzero)
+        hipLaunchKernelGGL((k_unproject<true, true>), g, b, 0, ctx->stream, V, ld, m, w_in, w_out, ch, coef_dev, alpha, beta, add_idx, add_dev, p.rpb, part);
+    else if (norm)
+        hipLaunchKernelGGL((k_unproject<true, false>), g, b, 0, ctx->stream, V, ld, m, w_in, w_out, ch, coef_dev, alpha, beta, add_idx, add_dev, p.rpb, part);
+    else if (bzero)
+        hipLaunchKernelGGL((k_unproject<false, true>), g, b, 0, ctx->stream, V, ld, m, w_in, w_out, ch, coef_dev, alpha, beta, add_idx, add_dev, p.rpb, part);
+    else
+        hipLaunchKernelGGL((k_unproject<false, false>), g, b, 0, ctx->stream, V, ld, m, w_in, w_out, ch, coef_dev, alpha, beta, add_idx, add_dev, p.rpb, part);
+    delete ps;
+    KK_HIP(hipGetLastError());
+    if (norm) return finalize_scalar(ctx, PART_SCAL_A, p.nblk, nrm_off, true);
+    return KK_OK;
+}
+
+int kk_launch_mgs_step(kk_ctx ctx, double* w, int64_t ld, const double* q_prev, const double* s_prev_dev,
+                       const double* q_next, int64_t ws_dot_off, int64_t ws_nrm_off) {
+    kk_part p = kk_partition(ctx, ld);
+    dim3 g(p.nblk), b(KK_TPB);
+    double* pd = part_row(ctx, PART_SCAL_A);
+    double* pn = part_row(ctx, PART_SCAL_B);
+    kk_prof_scope* ps = new kk_prof_scope(ctx, "k_mgs_step");
+    if (ws_nrm_off >= 0)
+        hipLaunchKernelGGL((k_mgs_step<true>), g, b, 0, ctx->stream, w, ld, p.rpb, q_prev, s_prev_dev, q_next, pd, pn);
+    else
+        hipLaunchKernelGGL((k_mgs_step<false>), g, b, 0, ctx->stream, w, ld, p.rpb, q_prev, s_prev_dev, q_next, pd, pn);
+    delete ps;
+    KK_HIP(hipGetLastError());
+    if (q_next) KK_TRY(finalize_scalar(ctx, PART_SCAL_A, p.nblk, ws_dot_off, false));
+    if (ws_nrm_off >= 0) KK_TRY(finalize_scalar(ctx, PART_SCAL_B, p.nblk, ws_nrm_off, true));
+    return KK_OK;
+}
+
+int kk_launch_spmv(kk_ctx ctx, const kk_sparse_dev& M, const double* x, double* y, int64_t ld_y_rows,
+                   const kk_spmv_fuse& f) {
+    (void)ld_y_rows;
+    spmv_epi e;
+    e.a1 = f.a1; e.a0 = f.a0; e.bprev = f.bprev;
+    e.xs_dev = f.xscale_dev; e.bprev_dev = f.bprev_dev; e.vprev = f.vprev;
+    e.dot_mode = f.dot_mode; e.want_nrm = f.nrm_slot >= 0 ? 1 : 0;
+    e.n_local = M.n_ghost > 0 ? M.n_local : -1;
+    e.ghost = M.ghost;
+    double* pd = part_row(ctx, PART_SCAL_A);
+    double* pn = part_row(ctx, PART_SCAL_B);
+    int nblk = 0;
+    kk_prof_scope* ps = new kk_prof_scope(ctx, M.format == 0 ? "k_spmv_ell" : "k_spmv_csr");
+    if (M.format == 0) {
+        const int nb_logical = (int)((M.nrows + 2 * KK_TPB - 1) / (2 * KK_TPB));
+        const int per = (nb_logical + 7) / 8;
+        const int nbx = std::min(per, KK_MAX_BLOCKS / 8);
+        nblk = nbx * 8;
+        hipLaunchKernelGGL(k_spmv_ell, dim3(nblk), dim3(KK_TPB), 0, ctx->stream, M.ell_col, M.ell_val, M.ell_ld, M.width,
+                           M.nrows, x, y, e, nb_logical, pd, pn);
+    } else {
+        const int L = M.lanes_per_row;
+        const int rpb = KK_TPB / L;
+        int64_t want = (M.nrows + rpb - 1) / rpb;
+        nblk = (int)std::min<int64_t>(want, (int64_t)ctx->num_cus * 16);
+        if (nblk < 1) nblk = 1;
+        dim3 g(nblk), b(KK_TPB);
+#define CSR_CASE(LL) case LL: hipLaunchKernelGGL((k_spmv_csr<LL>), g, b, 0, ctx->stream, M.rowptr, M.colind, M.val, M.nrows, x, y, e, pd, pn); break;
+        switch (L) {
+            CSR_CASE(2) CSR_CASE(4) CSR_CASE(8) CSR_CASE(16) CSR_CASE(32) CSR_CASE(64)
+            default: delete ps; kk_set_error("bad lanes_per_row %d", L); return KK_ERR_INVALID;
+        }
+#undef CSR_CASE
+    }
+    delete ps;
+    KK_HIP(hipGetLastError());
+    if (nblk > KK_MAX_BLOCKS && (f.dot_mode || f.nrm_slot >= 0)) {
+        kk_set_error("spmv grid %d exceeds partial buffer", nblk);
+        return KK_ERR_INVALID;
+    }
+    if (f.dot_mode) KK_TRY(finalize_scalar(ctx, PART_SCAL_A, nblk, WS_SCAL + f.dot_slot, false));
+    if (f.nrm_slot >= 0) KK_TRY(finalize_scalar(ctx, PART_SCAL_B, nblk, WS_SCAL + f.nrm_slot, true));
+    return KK_OK;
+}
+
+int kk_launch_basistransform(kk_ctx ctx, double* V, int64_t ld, int m, int n, const double* U_dev) {
+    kk_prof_scope ps(ctx, "k_basistransform");
+    const size_t shm = (size_t)m * (BT_ROWS + 1) * sizeof(double);
+    int nb = (int)std::min<int64_t>(ld / BT_ROWS, (int64_t)ctx->num_cus * 8);
+    if (nb < 1) nb = 1;
+    if (shm > 64 * 1024) {
+        KK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_basistransform),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    }
+    hipLaunchKernelGGL(k_basistransform, dim3(nb), dim3(KK_TPB), shm, ctx->stream, V, ld, m, n, U_dev);
+    KK_HIP(hipGetLastError());
+    return KK_OK;
+}
+
+int kk_launch_givens(kk_ctx ctx, double* q1, double* q2, int64_t ld, double c, double s) {
+    kk_prof_scope ps(ctx, "k_givens");
+    kk_part p = kk_partition(ctx, ld);
+    hipLaunchKernelGGL(k_givens, dim3(p.nblk), dim3(KK_TPB), 0, ctx->stream, q1, q2, ld, p.rpb, c, s);
+    KK_HIP(hipGetLastError());
+    return KK_OK;
+}
+
+int kk_launch_householder(kk_ctx ctx, double* V, int64_t ld, int m, const kk_coef* v, double beta) {
+    kk_prof_scope ps(ctx, "k_householder");
+    kk_part p = kk_partition(ctx, ld);
+    hipLaunchKernelGGL(k_householder, dim3(p.nblk), dim3(KK_TPB), 0, ctx->stream, V, ld, m, *v, beta, p.rpb);
+    KK_HIP(hipGetLastError());
+    return KK_OK;
+}
+
+int kk_launch_rank1(kk_ctx ctx, double* V, int64_t ld, int m, const double* y, const kk_coef* x, double alpha,
+                    double beta) {
+    kk_prof_scope ps(ctx, "k_rank1");
+    kk_part p = kk_partition(ctx, ld);
+    hipLaunchKernelGGL(k_rank1, dim3(p.nblk), dim3(KK_TPB), 0, ctx->stream, V, ld, m, y, *x, alpha, beta, p.rpb);
+    KK_HIP(hipGetLastError());
+    return KK_OK;
+}

@@ -1,0 +1,332 @@
+"""eigsolve / linsolve / svdsolve drivers: the reference's host control flow
+(src/eigsolve/lanczos.jl, src/linsolve/gmres.jl, src/eigsolve/svdsolve.jl) re-stated over the
+device factorizations.  In a Julia deployment these loops are KrylovKit's own, unchanged (they
+only touch the L1/L2/L3 surface that KrylovKitHIP.jl overloads -- INTEGRATION.md); this Python
+mirror exists because the image has no Julia toolchain, and issues the identical call sequence
+into libkrylov_hip.so.  Small dense work (k x k) is done on the host exactly as in the reference.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import List, Optional
+
+import numpy as np
+
+from . import dense
+from .core import DeviceBasis, HipVec, KrylovDefaults, Orthogonalizer, SparseOperator
+from .factorizations import (ArnoldiIterator, GKLIterator, LanczosIterator, _as_operator, expand_, initialize,
+                             initialize_, shrink_)
+
+
+@dataclass
+class ConvergenceInfo:  # KrylovKit.jl:212-218
+    converged: int
+    residual: object
+    normres: object
+    numiter: int
+    numops: int
+
+
+# -------------------------------------------------------------------- algorithm structs
+@dataclass
+class Lanczos:  # algorithms.jl:110-127
+    orth: Orthogonalizer = KrylovDefaults.orth
+    krylovdim: int = KrylovDefaults.krylovdim
+    maxiter: int = KrylovDefaults.maxiter
+    tol: float = KrylovDefaults.tol
+    eager: bool = False
+    verbosity: int = 0
+
+
+@dataclass
+class GMRES:  # algorithms.jl:373-390
+    orth: Orthogonalizer = KrylovDefaults.orth
+    maxiter: int = KrylovDefaults.maxiter
+    krylovdim: int = KrylovDefaults.krylovdim
+    tol: float = KrylovDefaults.tol
+    verbosity: int = 0
+
+
+@dataclass
+class GKL:  # algorithms.jl:200-217
+    orth: Orthogonalizer = KrylovDefaults.orth
+    krylovdim: int = KrylovDefaults.krylovdim
+    maxiter: int = KrylovDefaults.maxiter
+    tol: float = KrylovDefaults.tol
+    eager: bool = False
+    verbosity: int = 0
+
+
+# -------------------------------------------------------------------- eigsolve (Lanczos)
+def eigsolve(A, x0, howmany: int = 1, which: str = "LM", alg: Optional[Lanczos] = None, *, return_device: bool = False,
+             **kw):
+    """eigsolve(A, x0, howmany, which, alg::Lanczos) (src/eigsolve/lanczos.jl:1-155).
+
+    A: SparseOperator or scipy.sparse matrix (must be symmetric).  Returns
+    (values, vectors, ConvergenceInfo); vectors are numpy arrays unless return_device."""
+    alg = alg or Lanczos(**kw)
+    krylovdim, maxiter = alg.krylovdim, alg.maxiter
+    if howmany > krylovdim:
+        raise ValueError(f"krylov dimension {krylovdim} too small to compute {howmany} eigenvalues")
+    op = _as_operator(A)
+    it = LanczosIterator(op, x0, alg.orth, True, capacity=krylovdim + 2)
+    fact = initialize(it)
+    numops = 1
+    numiter = 1
+    tol = alg.tol
+    HH = np.zeros((krylovdim + 1, krylovdim))
+    converged = 0
+    D = U = f = None
+    while True:
+        beta = fact.normres
+        K = len(fact)
+        if K == krylovdim or beta <= tol or (alg.eager and K >= howmany):  # :45
+            a, b = fact.rayleighquotient()
+            if K == 1:
+                D = np.array([a[0]])
+                U = np.ones((1, 1))
+                f = np.array([beta])
+                converged = int(beta <= tol)
+            else:
+                D, U = dense.tridiageigh(a, b)  # :59
+                p = dense.sortperm(D, which)
+                D, U = D[p], np.array(U[:, p])
+                f = U[K - 1, :] * beta  # :61
+                converged = 0
+                while converged < K and abs(f[converged]) <= tol:
+                    converged += 1
+            if converged >= howmany or beta <= tol:
+                break
+        if K < krylovdim:  # :77-79
+            fact = expand_(it, fact)
+            numops += 1
+        else:  # thick restart :80-116
+            if numiter == maxiter:
+                break
+            keep = (3 * krylovdim + 2 * converged) // 5
+            H = HH[: keep + 1, :keep]
+            H[:] = 0.0
+            for j in range(keep):
+                H[j, j] = D[j]
+                H[keep, j] = f[j]
+            for j in range(keep, 0, -1):  # :94-101
+                hb, hv, nu = dense.householder(H[j, :j], j - 1)
+                H[j, j - 1] = nu
+                H[j, : j - 1] = 0.0
+                rr = np.arange(j)
+                dense.lmul_householder(hb, hv, rr, H)
+                dense.rmul_householder(H, hb, hv, rr, slice(0, j))
+                dense.rmul_householder(U, hb, hv, rr)
+            for j in range(keep):
+                fact.alphas[j] = H[j, j]
+                fact.betas[j] = H[j + 1, j]
+            B = fact.basis()
+            B.basistransform(U[:, :keep])  # :109
+            HipVec(B, keep).scale_from_(fact.r, 1.0 / beta)  # B[keep+1] = scale!!(r, 1/beta)  :111
+            fact = shrink_(fact, keep)  # :114
+            numiter += 1
+    hm = howmany
+    if converged > howmany:
+        hm = converged
+    elif len(D) < howmany:
+        hm = len(D)
+    values = D[:hm]
+    Vc = U[:, :hm]
+    B = fact.basis()
+    K = len(fact)
+    out = DeviceBasis(B.n, max(hm, 1), op.ctx)
+    for i in range(hm):  # vectors = [B*v for v in cols(V)]   :131-133
+        B.times(Vc[:, i], HipVec(out, i), 0, K)
+    out.length = hm
+    normres = np.abs(f[:hm])
+    info = ConvergenceInfo(converged, None, normres, numiter, numops)
+    if return_device:
+        return values, out, info
+    vectors = [out.download(i) for i in range(hm)]
+    info.residual = [fact.r.get() * Vc[-1, i] for i in range(hm)]  # :134-136
+    return values, vectors, info
+
+
+# -------------------------------------------------------------------- linsolve (GMRES)
+def linsolve(A, b, x0=None, alg: Optional[GMRES] = None, a0: float = 0.0, a1: float = 1.0, *, atol: Optional[float] = None,
+             rtol: Optional[float] = None, return_device: bool = False, **kw):
+    """linsolve(operator, b, x0, alg::GMRES, a0, a1) (src/linsolve/gmres.jl:1-151), with the
+    tolerance handling of the front-end (`tol = max(atol, rtol*norm(b))`, linsolve/linsolve.jl:135-140)."""
+    op = _as_operator(A)
+    ctx = op.ctx
+    n = op.shape[0]
+    b = np.asarray(b, dtype=np.float64)
+    alg = alg or GMRES(**{k: v for k, v in kw.items() if k in ("orth", "maxiter", "krylovdim", "tol", "verbosity")})
+    if atol is not None or rtol is not None:
+        alg = GMRES(alg.orth, alg.maxiter, alg.krylovdim, max(atol or 0.0, (rtol or 0.0) * float(np.linalg.norm(b))))
+    krylovdim, maxiter, tol = alg.krylovdim, alg.maxiter, alg.tol
+    # work vectors: 0 = b, 1 = x, 2 = r, 3 = tmp
+    W = DeviceBasis(n, 4, ctx)
+    vb, vx, vr, vt = HipVec(W, 0), HipVec(W, 1), HipVec(W, 2), HipVec(W, 3)
+    vb.set(b)
+    if x0 is None:
+        vx.zero_()
+    else:
+        vx.set(np.asarray(x0, dtype=np.float64))
+    # r = b - a0 x0 - a1 A x0   :3-12
+    op.apply(vx, vt)
+    vr.scale_from_(vb, 1.0)
+    if a0 != 0:
+        vr.add_(vx, -a0)
+    vr.add_(vt, -a1)
+    beta = vr.norm()
+    if beta < tol:
+        x = W if return_device else vx.get()
+        return x, ConvergenceInfo(1, vr.get(), beta, 0, 1)
+    y = np.zeros(krylovdim + 1)
+    gs: List[Optional[tuple]] = [None] * krylovdim
+    R = np.zeros((krylovdim, krylovdim))
+    numiter = 0
+    numops = 1
+    it = ArnoldiIterator(op, vr, alg.orth, capacity=krylovdim + 2)
+    fact = initialize(it)
+    numops += 1
+    while True:
+        numiter += 1
+        y[0] = beta
+        k = 1
+        H = fact.rayleighquotient()
+        R[0, 0] = a0 + a1 * H[0, 0]
+        c, s, R[0, 0] = dense.givens(R[0, 0], a1 * fact.normres)
+        gs[0] = (0, 1, c, s)
+        y[1] = 0.0
+        y[0], y[1] = c * y[0] + s * y[1], -s * y[0] + c * y[1]
+        beta = abs(y[1])
+        while R[k - 1, k - 1] != 0 and beta > tol and len(fact) < krylovdim:  # :55
+            fact = expand_(it, fact)
+            numops += 1
+            k = len(fact)
+            # new Hessenberg column straight from the packed storage
+            base = ((k * k + k - 2) >> 1)
+            hcol = fact.H[base: base + k]
+            for i in range(k - 1):
+                R[i, k - 1] = a1 * hcol[i]
+            R[k - 1, k - 1] = a0 + a1 * hcol[k - 1]
+            Rk = R[:, k - 1]
+            for i in range(k - 1):  # :72-75
+                i1, i2, c, s = gs[i]
+                Rk[i1], Rk[i2] = c * Rk[i1] + s * Rk[i2], -s * Rk[i1] + c * Rk[i2]
+            if math.hypot(R[k - 1, k - 1], a1 * fact.normres) < tol:  # :78-85
+                c, s, y[k] = dense.givens(0.0, y[k - 1])
+                gs[k - 1] = (k, k - 1, c, s)
+                y[k - 1] = 0.0
+                R[k - 1, k - 1] = 0.0
+            else:
+                c, s, R[k - 1, k - 1] = dense.givens(R[k - 1, k - 1], a1 * fact.normres)
+                gs[k - 1] = (k - 1, k, c, s)
+                y[k] = 0.0
+                y[k - 1], y[k] = c * y[k - 1] + s * y[k], -s * y[k - 1] + c * y[k]
+            beta = abs(y[k])
+        kk = k - 1 if (R[k - 1, k - 1] == 0 and y[k - 1] == 0) else k  # :98-102
+        dense.ldiv_upper(R, y, kk)
+        V = fact.basis()
+        V.unproject(vx, y[:k], 0, k, 1.0, 1.0)  # x += sum V[i] y[i]   :105-108
+        if beta > tol and numiter < maxiter:  # :110-117
+            fact.r.scale_(1.0 / fact.normres)  # push!(V, scale!!(w, 1/normres))
+            V.length = k + 1
+            for i in range(k):
+                i1, i2, c, s = gs[i]
+                V.rmul_givens(i1, i2, c, -s)  # rmul!(V, gs[i]')
+            vr.scale_from_(HipVec(V, k), y[k])  # r = scale!!(r, V[k+1], y[k+1])
+            V.length = k
+        else:  # :119-132
+            vr.scale_from_(vb, 1.0)
+            op.apply_affine(vx, vt, a0, a1)
+            vr.add_(vt, -1.0)
+            numops += 1
+            beta = vr.norm()
+            if beta < tol:
+                x = W if return_device else vx.get()
+                return x, ConvergenceInfo(1, vr.get(), beta, numiter, numops)
+        if numiter >= maxiter:
+            x = W if return_device else vx.get()
+            return x, ConvergenceInfo(0, vr.get(), beta, numiter, numops)
+        it = ArnoldiIterator(op, vr, alg.orth, capacity=krylovdim + 2)  # :147-148
+        fact = initialize_(it, fact)
+
+
+# -------------------------------------------------------------------- svdsolve (GKL)
+def svdsolve(A, x0, howmany: int = 1, which: str = "LR", alg: Optional[GKL] = None, **kw):
+    """svdsolve(A, x0, howmany, which, alg::GKL) (src/eigsolve/svdsolve.jl:144-314)."""
+    alg = alg or GKL(**kw)
+    krylovdim, maxiter, tol = alg.krylovdim, alg.maxiter, alg.tol
+    if howmany > krylovdim:
+        raise ValueError(f"krylov dimension {krylovdim} too small to compute {howmany} singular values")
+    op = _as_operator(A)
+    numiter = 1
+    it = GKLIterator(op, x0, alg.orth, capacity=krylovdim + 2)
+    fact = initialize(it)
+    numops = 2
+    HH = np.zeros((krylovdim + 1, krylovdim))
+    converged = 0
+    P = Q = f = S = None
+    while True:
+        beta = fact.normres
+        K = len(fact)
+        if K == krylovdim or beta <= tol or (alg.eager and K >= howmany):
+            P, S, Q = dense.bidiagsvd(fact.rayleighquotient())  # :198
+            if which == "SR":
+                P, S, Q = P[:, ::-1], S[::-1], Q[::-1, :]
+            elif which != "LR":
+                raise ValueError(f"invalid specification of which singular values to target: which = {which}")
+            f = Q.T[K - 1, :] * beta  # :208
+            converged = 0
+            while converged < K and abs(f[converged]) < tol:
+                converged += 1
+            if converged >= howmany or beta <= tol:
+                break
+        if K < krylovdim:
+            fact = expand_(it, fact)
+            numops += 2
+        else:
+            if numiter == maxiter:
+                break
+            keep = (3 * krylovdim + 2 * converged) // 5
+            U, V = fact.basis("U"), fact.basis("V")
+            U.basistransform(np.ascontiguousarray(P[:, :keep]))       # :233
+            V.basistransform(np.ascontiguousarray(Q.T[:, :keep]))     # :240
+            HipVec(U, keep).scale_from_(fact.r, 1.0 / fact.normres)   # U[keep+1] = scale!!(r, 1/normres)  :249
+            H = HH[: keep + 1, :keep]
+            H[:] = 0.0
+            for j in range(keep):
+                H[j, j] = S[j]
+                H[keep, j] = f[j]
+            for j in range(keep, 0, -1):  # :257-269
+                hb, hv, nu = dense.householder(H[j, :j], j - 1)
+                H[j, j - 1] = nu
+                H[j, : j - 1] = 0.0
+                rr = np.arange(j)
+                dense.rmul_householder(H, hb, hv, rr, slice(0, j))
+                V.rmul_householder(hb, hv, 0, j)  # rmul!(V, h')
+                hb, hv, nu = dense.householder(H[:j, j - 1], j - 1)
+                H[j - 1, j - 1] = nu
+                H[: j - 1, j - 1] = 0.0
+                dense.lmul_householder(hb, hv, rr, H[:, : j - 1])
+                U.rmul_householder(hb, hv, 0, j)  # rmul!(U, h')
+            for j in range(keep):
+                fact.alphas[j] = H[j, j]
+                fact.betas[j] = H[j + 1, j]
+            fact = shrink_(fact, keep)
+            numiter += 1
+    if converged > howmany:
+        howmany = converged
+    values = S[:howmany]
+    Pv, Qv = P[:, :howmany], Q[:howmany, :]
+    K = len(fact)
+    U, V = fact.basis("U"), fact.basis("V")
+    outU = DeviceBasis(U.n, max(howmany, 1), op.ctx)
+    outV = DeviceBasis(V.n, max(howmany, 1), op.ctx)
+    left, right = [], []
+    for i in range(howmany):
+        U.times(Pv[:, i], HipVec(outU, i), 0, K)
+        V.times(Qv[i, :], HipVec(outV, i), 0, K)
+        left.append(outU.download(i))
+        right.append(outV.download(i))
+    normres = np.abs(f[:howmany])
+    return values, left, right, ConvergenceInfo(converged, None, normres, numiter, numops)

@@ -1,0 +1,1148 @@
+"""CPU oracle: NumPy/SciPy (float64) restatement of KrylovKit.jl's Krylov `expand!` path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing in the shipped product (`krylovkit.jl_amd/`) may import
+this module; only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg use
+it, and only as the checker.
+
+PARITY STATUS: **bit-level parity unpinned** -- the reference is Julia and no `julia` binary
+exists in this image, its test inputs come from Julia's seeded RNG, and every comparison in the
+reference test-suite is tolerance based (`test/testsetup.jl:14`).  The oracle is therefore pinned
+against what the reference's tests *do* pin: the per-`expand!` invariants of
+`test/factorize.jl:140-148,185-193,285-296`, the orthogonaliser identities of
+`test/linalg.jl:4-25`, dense LAPACK spectra (`test/eigsolve.jl:74,122-123`,
+`test/svdsolve.jl:14,89`, `test/linsolve.jl:135,230`) and the two known-answer fixtures
+(toric code: four eigenvalues at -16, `test/eigsolve.jl:471-549`; issue #143 71x71 matrix,
+`test/issues.jl:39-129`).  See tests/test_oracle_*.py.
+
+Every function cites the reference file:line (relative to /root/reference) it restates.  The
+arithmetic that is NOT in the reference tree (VectorInterface.jl compat 0.5/0.6 -- unpinned, no
+Manifest; Julia stdlib LinearAlgebra / SparseArrays) is restated from the call sites' semantics
+(SURVEY.md Appendix B): inner = conj-linear dot, norm = 2-norm, add!!(y,x,a,b) = b*y + a*x.
+
+Indices are 0-based here; comments give the Julia 1-based line they mirror.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import numpy as np
+import scipy.linalg as sla
+import scipy.sparse as sp
+
+EPS = np.finfo(np.float64).eps
+
+
+# --------------------------------------------------------------------------------------
+# Orthogonalizers -- src/algorithms.jl:17-80
+# --------------------------------------------------------------------------------------
+@dataclass(frozen=True)
+class Orthogonalizer:
+    name: str
+    eta: float = 1.0 / math.sqrt(2.0)  # DGKS default, algorithms.jl:66,80
+
+
+CGS = Orthogonalizer("cgs")
+MGS = Orthogonalizer("mgs")
+CGS2 = Orthogonalizer("cgs2")
+MGS2 = Orthogonalizer("mgs2")
+
+
+def CGSIR(eta: float = 1.0 / math.sqrt(2.0)) -> Orthogonalizer:
+    return Orthogonalizer("cgsir", eta)
+
+
+def MGSIR(eta: float = 1.0 / math.sqrt(2.0)) -> Orthogonalizer:
+    return Orthogonalizer("mgsir", eta)
+
+
+ALL_ORTHS = (CGS, MGS, CGS2, MGS2, CGSIR(), MGSIR())
+
+
+# --------------------------------------------------------------------------------------
+# L1 vector verbs (VectorInterface.jl semantics) on float64 ndarrays
+# --------------------------------------------------------------------------------------
+def inner(x: np.ndarray, y: np.ndarray) -> float:
+    return float(np.dot(x, y))  # real case of conj-linear <x,y>
+
+
+def norm(x: np.ndarray) -> float:
+    return float(np.linalg.norm(x))
+
+
+def add(y: np.ndarray, x: np.ndarray, a: float = 1.0, b: float = 1.0) -> np.ndarray:
+    """add!!(y, x, a, b): y <- b*y + a*x, in place, returns y."""
+    if b != 1.0:
+        y *= b
+    y += a * x
+    return y
+
+
+def scale(x: np.ndarray, a: float) -> np.ndarray:
+    return x * a  # fresh vector
+
+
+def scale_(y: np.ndarray, a: float) -> np.ndarray:
+    y *= a
+    return y
+
+
+# --------------------------------------------------------------------------------------
+# Operator protocol -- src/apply.jl:1-19
+# --------------------------------------------------------------------------------------
+def apply(op, x: np.ndarray) -> np.ndarray:
+    """apply(A::AbstractMatrix, x) = A*x ; apply(f, x) = f(x)   (apply.jl:1-2)"""
+    if callable(op):
+        return np.asarray(op(x), dtype=np.float64)
+    return np.asarray(op @ x, dtype=np.float64).ravel()
+
+
+def apply_normal(op, x):
+    """apply.jl:14,16: matrix -> A*x ; tuple (f, fadj) -> f(x)"""
+    if isinstance(op, tuple):
+        return np.asarray(op[0](x), dtype=np.float64)
+    return apply(op, x)
+
+
+def apply_adjoint(op, x):
+    """apply.jl:15,17: matrix -> A'*x ; tuple (f, fadj) -> fadj(x)"""
+    if isinstance(op, tuple):
+        return np.asarray(op[1](x), dtype=np.float64)
+    return np.asarray(op.T @ x, dtype=np.float64).ravel()
+
+
+# --------------------------------------------------------------------------------------
+# OrthonormalBasis helpers -- src/orthonormal.jl.  A basis is a python list of ndarrays.
+# --------------------------------------------------------------------------------------
+def project(b: Sequence[np.ndarray], x: np.ndarray, y: Optional[np.ndarray] = None,
+            alpha: float = 1.0, beta: float = 0.0, r: Optional[Sequence[int]] = None) -> np.ndarray:
+    """project!! (orthonormal.jl:88-118): y[j] = beta*y[j] + alpha*inner(b[r[j]], x)."""
+    r = range(len(b)) if r is None else r
+    if y is None:
+        y = np.zeros(len(r))
+    for j, rj in enumerate(r):
+        if beta == 0:
+            y[j] = alpha * inner(b[rj], x)
+        else:
+            y[j] = beta * y[j] + alpha * inner(b[rj], x)
+    return y
+
+
+def unproject(y: np.ndarray, b: Sequence[np.ndarray], x: Sequence[float],
+              alpha: float = 1.0, beta: float = 0.0, r: Optional[Sequence[int]] = None) -> np.ndarray:
+    """unproject!! generic path (orthonormal.jl:132-150): y = beta*y + alpha*sum b[r[i]]*x[i]."""
+    r = range(len(b)) if r is None else r
+    if beta == 0:
+        y[:] = 0.0
+    elif beta != 1:
+        y *= beta
+    for i, ri in enumerate(r):
+        y = add(y, b[ri], alpha * x[i])
+    return y
+
+
+def basis_times(b: Sequence[np.ndarray], x: Sequence[float]) -> np.ndarray:
+    """Base.:*(b::OrthonormalBasis, x) (orthonormal.jl:57-60)."""
+    return unproject(np.zeros_like(b[0]), b, x)
+
+
+def rank1update(b: List[np.ndarray], y: np.ndarray, x: Sequence[float],
+                alpha: float = 1.0, beta: float = 1.0, r: Optional[Sequence[int]] = None):
+    """rank1update! (orthonormal.jl:210-229): b[r[i]] = beta*b[r[i]] + alpha*y*conj(x[i])."""
+    r = range(len(b)) if r is None else r
+    for i, ri in enumerate(r):
+        if beta == 1:
+            b[ri] = add(b[ri], y, alpha * x[i])
+        elif beta == 0:
+            b[ri] = y * (alpha * x[i])
+        else:
+            b[ri] = add(b[ri], y, alpha * x[i], beta)
+    return b
+
+
+def basistransform(b: List[np.ndarray], U: np.ndarray) -> List[np.ndarray]:
+    """basistransform! (orthonormal.jl:291-321): b[j] <- sum_i b[i]*U[i,j]; old vectors dropped
+    for j < n, vectors j >= n are left untouched (the reference only overwrites b[1:n], :316-318)."""
+    m, n = U.shape
+    assert m == len(b)
+    b2 = []
+    for j in range(n):
+        v = b[0] * U[0, j]  # scale!!(b2[j], b[1], U[1,j])  :310
+        for i in range(1, m):
+            v = add(v, b[i], U[i, j])  # :312
+        b2.append(v)
+    for j in range(n):
+        b[j] = b2[j]
+    return b
+
+
+def givens_rmul(b: List[np.ndarray], i1: int, i2: int, c: float, s: float):
+    """rmul!(b::OrthonormalBasis, G::Givens) generic path (dense/givens.jl:30-36), real case:
+    q1' = c*q1 - s*q2 ; q2' = s*q1 + c*q2."""
+    q1, q2 = b[i1], b[i2]
+    q1n = c * q1 - s * q2
+    q2n = s * q1 + c * q2
+    b[i1], b[i2] = q1n, q2n
+    return b
+
+
+def householder_rmul(b: List[np.ndarray], beta: float, v: Sequence[float], r: Sequence[int]):
+    """rmul!(b::OrthonormalBasis, H::Householder) (dense/reflector.jl:143-154):
+    w = sum_{i in r} b[i] v[i]; b[i] <- b[i] - beta*w*conj(v[i])."""
+    if beta == 0:
+        return b
+    w = unproject(np.zeros_like(b[r[0]]), b, v, 1.0, 0.0, r)
+    return rank1update(b, w, v, -beta, 1.0, r)
+
+
+# --------------------------------------------------------------------------------------
+# orthogonalize!! family -- src/orthonormal.jl:370-527
+# --------------------------------------------------------------------------------------
+def _cgs(v, b, x):  # :378-384
+    x = project(b, v, x)
+    v = unproject(v, b, x, -1.0, 1.0)
+    return v, x
+
+
+def _recgs(v, b, x):  # reorthogonalize!! CGS :385-393
+    s = project(b, v, np.empty_like(x))
+    v = unproject(v, b, s, -1.0, 1.0)
+    x += s
+    return v, x
+
+
+def _mgs(v, b, x):  # :414-423
+    for i, q in enumerate(b):
+        s = inner(q, v)
+        v = add(v, q, -s)
+        x[i] = s
+    return v, x
+
+
+def _remgs(v, b, x):  # :424-433
+    for i, q in enumerate(b):
+        s = inner(q, v)
+        v = add(v, q, -s)
+        x[i] += s
+    return v, x
+
+
+def orthogonalize(v: np.ndarray, b: Sequence[np.ndarray], alg: Orthogonalizer,
+                  x: Optional[np.ndarray] = None, stats: Optional[dict] = None):
+    """orthogonalize!!(v, b, x, alg) (orthonormal.jl:372-452). Mutates v, returns (v, x).
+    `stats['passes']` (optional) counts full passes over the basis (for byte accounting)."""
+    if x is None:
+        x = np.empty(len(b))
+    passes = 1
+    n = alg.name
+    if n == "cgs":
+        v, x = _cgs(v, b, x)
+    elif n == "cgs2":  # :394-399
+        v, x = _cgs(v, b, x)
+        v, x = _recgs(v, b, x)
+        passes = 2
+    elif n == "cgsir":  # :400-412
+        nold = norm(v)
+        v, x = _cgs(v, b, x)
+        nnew = norm(v)
+        while EPS < nnew < alg.eta * nold:
+            nold = nnew
+            v, x = _recgs(v, b, x)
+            nnew = norm(v)
+            passes += 1
+    elif n == "mgs":
+        v, x = _mgs(v, b, x)
+    elif n == "mgs2":  # :434-439
+        v, x = _mgs(v, b, x)
+        v, x = _remgs(v, b, x)
+        passes = 2
+    elif n == "mgsir":  # :440-452
+        nold = norm(v)
+        v, x = _mgs(v, b, x)
+        nnew = norm(v)
+        while EPS < nnew < alg.eta * nold:
+            nold = nnew
+            v, x = _remgs(v, b, x)
+            nnew = norm(v)
+            passes += 1
+    else:
+        raise ValueError(n)
+    if stats is not None:
+        stats["passes"] = stats.get("passes", 0) + passes
+    return v, x
+
+
+def orthogonalize_vec(v: np.ndarray, q: np.ndarray, alg: Orthogonalizer):
+    """_orthogonalize!!(v, q, alg) vector-vs-vector variants (orthonormal.jl:455-489)."""
+    n = alg.name
+    if n in ("cgs", "mgs"):  # :458-464
+        s = inner(q, v)
+        v = add(v, q, -s)
+        return v, s
+    if n in ("cgs2", "mgs2"):  # :465-473
+        s = inner(q, v)
+        v = add(v, q, -s)
+        ds = inner(q, v)
+        v = add(v, q, -ds)
+        return v, s + ds
+    # IR :474-489
+    nold = norm(v)
+    s = inner(q, v)
+    v = add(v, q, -s)
+    nnew = norm(v)
+    while EPS < nnew < alg.eta * nold:
+        nold = nnew
+        ds = inner(q, v)
+        v = add(v, q, -ds)
+        s += ds
+        nnew = norm(v)
+    return v, s
+
+
+def orthonormalize(v, b, alg, x=None):
+    """orthonormalize!! (orthonormal.jl:522-527): returns (v/|v|, beta, x)."""
+    v, x = orthogonalize(v, b, alg, x)
+    beta = norm(v)
+    v = scale_(v, 1.0 / beta)
+    return v, beta, x
+
+
+# --------------------------------------------------------------------------------------
+# Lanczos factorization -- src/factorizations/lanczos.jl
+# --------------------------------------------------------------------------------------
+@dataclass
+class LanczosFactorization:  # lanczos.jl:31-37
+    k: int
+    V: List[np.ndarray]
+    alphas: List[float]
+    betas: List[float]
+    r: np.ndarray
+
+    def __len__(self):
+        return self.k
+
+    @property
+    def normres(self):
+        return self.betas[-1]
+
+    def rayleighquotient(self):
+        """SymTridiagonal(alphas, betas) (lanczos.jl:44-46) -> (diag, offdiag[:k-1])."""
+        return np.array(self.alphas[: self.k]), np.array(self.betas[: self.k - 1])
+
+
+@dataclass
+class LanczosIterator:  # lanczos.jl:129-153
+    operator: object
+    x0: np.ndarray
+    orth: Orthogonalizer = MGS2
+    keepvecs: bool = True
+
+    def __post_init__(self):
+        if not self.keepvecs and self.orth.name not in ("cgs", "mgs"):
+            raise ValueError("Cannot use reorthogonalization without keeping all Krylov vectors")
+
+
+def lanczos_initialize(it: LanczosIterator) -> LanczosFactorization:
+    """initialize(iter::LanczosIterator) (lanczos.jl:180-222)."""
+    x0 = it.x0
+    beta0 = norm(x0)
+    if beta0 == 0:
+        raise ValueError("initial vector should not have norm zero")
+    Ax0 = apply(it.operator, x0)
+    alpha = inner(x0, Ax0) / (beta0 * beta0)
+    v = x0 * (1.0 / beta0)  # add!!(scale(Ax0, 0), x0, 1/beta0)  :190
+    r = scale_(Ax0, 1.0 / beta0)  # :194
+    beta_old = norm(r)
+    r = add(r, v, -alpha)
+    beta = norm(r)
+    n = it.orth.name
+    if n in ("cgs2", "mgs2"):  # :200-204
+        dalpha = inner(v, r)
+        alpha += dalpha
+        r = add(r, v, -dalpha)
+        beta = norm(r)
+    elif n in ("cgsir", "mgsir"):  # :205-213
+        while EPS < beta < it.orth.eta * beta_old:
+            beta_old = beta
+            dalpha = inner(v, r)
+            alpha += dalpha
+            r = add(r, v, -dalpha)
+            beta = norm(r)
+    return LanczosFactorization(1, [v], [alpha], [beta], r)
+
+
+def lanczos_initialize_(it: LanczosIterator, st: LanczosFactorization) -> LanczosFactorization:
+    """initialize!(iter, state) (lanczos.jl:223-249)."""
+    V = st.V
+    while len(V) > 1:
+        V.pop()
+    st.alphas.clear()
+    st.betas.clear()
+    V[0] = it.x0 * (1.0 / norm(it.x0))
+    w = apply(it.operator, V[0])
+    r, alpha = orthogonalize_vec(w, V[0], it.orth)
+    beta = norm(r)
+    st.k = 1
+    st.alphas.append(alpha)
+    st.betas.append(beta)
+    st.r = r
+    return st
+
+
+def lanczosrecurrence(operator, V: List[np.ndarray], beta: float, orth: Orthogonalizer,
+                      stats: Optional[dict] = None):
+    """The six lanczosrecurrence methods (lanczos.jl:295-376). Returns (w, alpha, beta)."""
+    n = orth.name
+    v = V[-1]
+    w = apply(operator, v)
+    passes = 0
+    if n == "cgs":  # :295-303
+        alpha = inner(v, w)
+        w = add(w, V[-2], -beta)
+        w = add(w, v, -alpha)
+        beta = norm(w)
+    elif n == "mgs":  # :304-312
+        w = add(w, V[-2], -beta)
+        alpha = inner(v, w)
+        w = add(w, v, -alpha)
+        beta = norm(w)
+    elif n == "cgs2":  # :313-324
+        alpha = inner(v, w)
+        w = add(w, V[-2], -beta)
+        w = add(w, v, -alpha)
+        w, s = orthogonalize(w, V, CGS)
+        alpha += s[-1]
+        beta = norm(w)
+        passes = 1
+    elif n == "mgs2":  # :325-338
+        w = add(w, V[-2], -beta)
+        w, alpha = orthogonalize_vec(w, v, MGS)
+        s = alpha
+        for q in V:
+            w, s = orthogonalize_vec(w, q, MGS)
+        alpha += s
+        beta = norm(w)
+        passes = 1
+    elif n == "cgsir":  # :339-356
+        alpha = inner(v, w)
+        w = add(w, V[-2], -beta)
+        w = add(w, v, -alpha)
+        ab2 = alpha * alpha + beta * beta
+        beta = norm(w)
+        nold = math.sqrt(beta * beta + ab2)
+        while EPS < beta < orth.eta * nold:
+            nold = beta
+            w, s = orthogonalize(w, V, CGS)
+            alpha += s[-1]
+            beta = norm(w)
+            passes += 1
+    elif n == "mgsir":  # :357-376
+        w = add(w, V[-2], -beta)
+        w, alpha = orthogonalize_vec(w, v, MGS)
+        ab2 = alpha * alpha + beta * beta
+        beta = norm(w)
+        nold = math.sqrt(beta * beta + ab2)
+        while EPS < beta < orth.eta * nold:
+            nold = beta
+            s = 0.0
+            for q in V:
+                w, s = orthogonalize_vec(w, q, MGS)
+            alpha += s
+            beta = norm(w)
+            passes += 1
+    else:
+        raise ValueError(n)
+    if stats is not None:
+        stats["passes"] = stats.get("passes", 0) + passes
+    return w, alpha, beta
+
+
+def lanczos_expand(it: LanczosIterator, st: LanczosFactorization,
+                   stats: Optional[dict] = None) -> LanczosFactorization:
+    """expand!(iter::LanczosIterator, state) (lanczos.jl:250-272)."""
+    beta_old = st.normres
+    st.V.append(scale_(st.r, 1.0 / beta_old))  # :257
+    r, alpha, beta = lanczosrecurrence(it.operator, st.V, beta_old, it.orth, stats)  # :258
+    st.alphas.append(alpha)
+    st.betas.append(beta)
+    if not it.keepvecs:
+        st.V.pop(0)  # :264
+    st.k += 1
+    st.r = r
+    return st
+
+
+def lanczos_shrink(st: LanczosFactorization, k: int) -> LanczosFactorization:
+    """shrink!(state::LanczosFactorization, k) (lanczos.jl:273-291)."""
+    assert len(st) == len(st.V)
+    if len(st) <= k:
+        return st
+    V = st.V
+    while len(V) > k + 1:
+        V.pop()
+    r = V.pop()
+    del st.alphas[k:]
+    del st.betas[k:]
+    st.k = k
+    st.r = scale_(r, st.normres)
+    return st
+
+
+# --------------------------------------------------------------------------------------
+# Arnoldi factorization -- src/factorizations/arnoldi.jl, dense/packedhessenberg.jl
+# --------------------------------------------------------------------------------------
+def packed_index(i: int, j: int) -> int:
+    """0-based offset of H[i,j] (1-based i<=j+1) in packed storage (packedhessenberg.jl:32-39):
+    data[((j*j + j - 2) >> 1) + i]  (1-based)  ->  minus one for 0-based."""
+    return ((j * j + j - 2) >> 1) + i - 1
+
+
+@dataclass
+class ArnoldiFactorization:  # arnoldi.jl:31-36
+    k: int
+    V: List[np.ndarray]
+    H: List[float]  # packed Hessenberg
+    r: np.ndarray
+
+    def __len__(self):
+        return self.k
+
+    @property
+    def normres(self):
+        return abs(self.H[-1])  # arnoldi.jl:50
+
+    def rayleighquotient(self) -> np.ndarray:
+        """Dense k x k upper Hessenberg view of the packed data (arnoldi.jl:46-48)."""
+        k = self.k
+        Hd = np.zeros((k, k))
+        for j in range(1, k + 1):
+            for i in range(1, min(j + 1, k) + 1):
+                Hd[i - 1, j - 1] = self.H[packed_index(i, j)]
+        return Hd
+
+
+@dataclass
+class ArnoldiIterator:  # arnoldi.jl:98-106
+    operator: object
+    x0: np.ndarray
+    orth: Orthogonalizer = MGS2
+
+
+def arnoldi_initialize(it: ArnoldiIterator) -> ArnoldiFactorization:
+    """initialize(iter::ArnoldiIterator) (arnoldi.jl:135-175)."""
+    x0 = it.x0
+    beta0 = norm(x0)
+    if beta0 == 0:
+        raise ValueError("initial vector should not have norm zero")
+    Ax0 = apply(it.operator, x0)
+    alpha = inner(x0, Ax0) / (beta0 * beta0)
+    v = x0 * (1.0 / beta0)
+    r = scale_(Ax0, 1.0 / beta0)
+    beta_old = norm(r)
+    r = add(r, v, -alpha)
+    beta = norm(r)
+    n = it.orth.name
+    if n in ("cgs2", "mgs2"):
+        dalpha = inner(v, r)
+        alpha += dalpha
+        r = add(r, v, -dalpha)
+        beta = norm(r)
+    elif n in ("cgsir", "mgsir"):
+        while EPS < beta < it.orth.eta * beta_old:
+            beta_old = beta
+            dalpha = inner(v, r)
+            alpha += dalpha
+            r = add(r, v, -dalpha)
+            beta = norm(r)
+    return ArnoldiFactorization(1, [v], [alpha, beta], r)
+
+
+def arnoldi_initialize_(it: ArnoldiIterator, st: ArnoldiFactorization) -> ArnoldiFactorization:
+    """initialize!(iter, state) (arnoldi.jl:176-198)."""
+    V = st.V
+    while len(V) > 1:
+        V.pop()
+    st.H.clear()
+    V[0] = it.x0 * (1.0 / norm(it.x0))
+    w = apply(it.operator, V[0])
+    r, alpha = orthogonalize_vec(w, V[0], it.orth)
+    beta = norm(r)
+    st.k = 1
+    st.H.extend([alpha, beta])
+    st.r = r
+    return st
+
+
+def arnoldi_expand(it: ArnoldiIterator, st: ArnoldiFactorization,
+                   stats: Optional[dict] = None) -> ArnoldiFactorization:
+    """expand!(iter::ArnoldiIterator, state) (arnoldi.jl:199-219) with
+    arnoldirecurrence!! (arnoldi.jl:239-245)."""
+    st.k += 1
+    k = st.k
+    beta = st.normres
+    st.V.append(scale(st.r, 1.0 / beta))  # :209 (non-mutating)
+    w = apply(it.operator, st.V[-1])  # :242
+    h = np.empty(k)
+    r, h = orthogonalize(w, st.V, it.orth, h, stats)  # :243
+    beta = norm(r)  # :244
+    st.H.extend(float(t) for t in h)
+    st.H.append(beta)  # :213
+    st.r = r
+    return st
+
+
+def arnoldi_shrink(st: ArnoldiFactorization, k: int) -> ArnoldiFactorization:
+    """shrink!(state::ArnoldiFactorization, k) (arnoldi.jl:220-236)."""
+    if len(st) <= k:
+        return st
+    V = st.V
+    while len(V) > k + 1:
+        V.pop()
+    r = V.pop()
+    del st.H[(k * k + 3 * k) >> 1:]
+    st.k = k
+    st.r = scale_(r, st.normres)
+    return st
+
+
+# --------------------------------------------------------------------------------------
+# GKL factorization -- src/factorizations/gkl.jl
+# --------------------------------------------------------------------------------------
+@dataclass
+class GKLFactorization:  # gkl.jl:31-38
+    k: int
+    U: List[np.ndarray]
+    V: List[np.ndarray]
+    alphas: List[float]
+    betas: List[float]
+    r: np.ndarray
+
+    def __len__(self):
+        return self.k
+
+    @property
+    def normres(self):
+        return self.betas[-1]
+
+
+@dataclass
+class GKLIterator:  # gkl.jl:137-152
+    operator: object
+    u0: np.ndarray
+    orth: Orthogonalizer = MGS2
+
+
+def gkl_initialize(it: GKLIterator) -> GKLFactorization:
+    """initialize(iter::GKLIterator) (gkl.jl:183-215)."""
+    u0 = it.u0
+    beta0 = norm(u0)
+    if beta0 == 0:
+        raise ValueError("initial vector should not have norm zero")
+    v0 = apply_adjoint(it.operator, u0)
+    alpha = norm(v0) / beta0
+    Av0 = apply_normal(it.operator, v0)
+    alpha2 = inner(u0, Av0) / beta0 ** 2
+    if not np.isclose(alpha2, alpha * alpha, rtol=math.sqrt(EPS)):  # `≈`  :192
+        raise ValueError("operator and its adjoint are not compatible")
+    u = scale(u0, 1.0 / beta0)
+    v = scale(v0, 1.0 / (alpha * beta0))
+    r = scale_(Av0, 1.0 / (alpha * beta0))
+    r = add(r, u, -alpha)
+    beta = norm(r)
+    return GKLFactorization(1, [u], [v], [alpha], [beta], r)
+
+
+def gklrecurrence(operator, U, V, beta, orth: Orthogonalizer, stats: Optional[dict] = None):
+    """The gklrecurrence methods (gkl.jl:294-404). Returns (v, r, alpha, beta)."""
+    n = orth.name
+    u = U[-1]
+    v = apply_adjoint(operator, u)
+    v = add(v, V[-1], -beta)
+    pv = pu = 0
+    if n in ("cgs", "mgs"):  # :294-307
+        alpha = norm(v)
+        v = scale_(v, 1.0 / alpha)
+        r = apply_normal(operator, v)
+        r = add(r, u, -alpha)
+        beta = norm(r)
+    elif n == "cgs2":  # :308-323
+        alpha = norm(v)
+        v = scale_(v, 1.0 / alpha)
+        r = apply_normal(operator, v)
+        r = add(r, u, -alpha)
+        r, _ = orthogonalize(r, U, CGS)
+        beta = norm(r)
+        pu = 1
+    elif n == "mgs2":  # :324-346
+        for q in V:
+            v, _ = orthogonalize_vec(v, q, MGS)
+        alpha = norm(v)
+        v = scale_(v, 1.0 / alpha)
+        r = apply_normal(operator, v)
+        r = add(r, u, -alpha)
+        for q in U:
+            r, _ = orthogonalize_vec(r, q, MGS)
+        beta = norm(r)
+        pv = pu = 1
+    elif n == "cgsir":  # :347-373
+        alpha = norm(v)
+        nold = math.sqrt(alpha * alpha + beta * beta)
+        while alpha < orth.eta * nold:  # note: no eps guard in the reference  :355
+            nold = alpha
+            v, _ = orthogonalize(v, V, CGS)
+            alpha = norm(v)
+            pv += 1
+        v = scale_(v, 1.0 / alpha)
+        r = apply_normal(operator, v)
+        r = add(r, u, -alpha)
+        beta = norm(r)
+        nold = math.sqrt(alpha * alpha + beta * beta)
+        while EPS < beta < orth.eta * nold:
+            nold = beta
+            r, _ = orthogonalize(r, U, CGS)
+            beta = norm(r)
+            pu += 1
+    elif n == "mgsir":  # :374-404
+        alpha = norm(v)
+        nold = math.sqrt(alpha * alpha + beta * beta)
+        while EPS < alpha < orth.eta * nold:
+            nold = alpha
+            for q in V:
+                v, _ = orthogonalize_vec(v, q, MGS)
+            alpha = norm(v)
+            pv += 1
+        v = scale_(v, 1.0 / alpha)
+        r = apply_normal(operator, v)
+        r = add(r, u, -alpha)
+        beta = norm(r)
+        nold = math.sqrt(alpha * alpha + beta * beta)
+        while EPS < beta < orth.eta * nold:
+            nold = beta
+            for q in U:
+                r, _ = orthogonalize_vec(r, q, MGS)
+            beta = norm(r)
+            pu += 1
+    else:
+        raise ValueError(n)
+    if stats is not None:
+        stats["passes_v"] = stats.get("passes_v", 0) + pv
+        stats["passes_u"] = stats.get("passes_u", 0) + pu
+    return v, r, alpha, beta
+
+
+def gkl_expand(it: GKLIterator, st: GKLFactorization, stats: Optional[dict] = None):
+    """expand!(iter::GKLIterator, state) (gkl.jl:246-269)."""
+    beta_old = st.normres
+    st.U.append(scale_(st.r, 1.0 / beta_old))
+    v, r, alpha, beta = gklrecurrence(it.operator, st.U, st.V, beta_old, it.orth, stats)
+    st.V.append(v)
+    st.alphas.append(alpha)
+    st.betas.append(beta)
+    st.k += 1
+    st.r = r
+    return st
+
+
+def gkl_shrink(st: GKLFactorization, k: int):
+    """shrink!(state::GKLFactorization, k) (gkl.jl:270-291)."""
+    assert len(st) == len(st.V)
+    if len(st) <= k:
+        return st
+    U, V = st.U, st.V
+    while len(V) > k + 1:
+        U.pop()
+        V.pop()
+    V.pop()
+    r = U.pop()
+    del st.alphas[k:]
+    del st.betas[k:]
+    st.k = k
+    st.r = scale_(r, st.normres)
+    return st
+
+
+# --------------------------------------------------------------------------------------
+# Small dense helpers -- src/dense/*.jl, Julia LinearAlgebra.givens
+# --------------------------------------------------------------------------------------
+def householder_vec(x: np.ndarray, i: int):
+    """_householder!(v, i) (dense/reflector.jl:40-69), real case. `i` 0-based.
+    Returns (beta, v, nu) with v[i] = 1 such that (I - beta v v') x = nu e_i, nu = |x| >= 0."""
+    v = np.array(x, dtype=np.float64)
+    sigma = float(np.dot(v[:i], v[:i]) + np.dot(v[i + 1:], v[i + 1:]))
+    vi = v[i]
+    nu = math.sqrt(vi * vi + sigma)
+    if sigma == 0 and vi == nu:
+        beta = 0.0
+    else:
+        if vi < 0:
+            vi = vi - nu
+        else:
+            vi = (-sigma) / (vi + nu)  # ((vi - conj(vi))*nu - sigma)/(conj(vi)+nu), real
+        v[:i] /= vi
+        v[i + 1:] /= vi
+        v[i] = 1.0
+        beta = -vi / nu
+    return beta, v, nu
+
+
+def householder_lmul(beta, v, r, A: np.ndarray):
+    """lmul!(H, A) (dense/reflector.jl:89-112): A[r,:] -= beta * v (v' A[r,:])."""
+    if beta == 0:
+        return A
+    mu = beta * (v @ A[r, :])
+    A[r, :] -= np.outer(v, mu)
+    return A
+
+
+def householder_rmul_mat(A: np.ndarray, beta, v, r, rows=None):
+    """rmul!(A, H) (dense/reflector.jl:113-142): A[rows,r] -= (A[rows,r] v) beta v'.
+    For H' (adjoint) beta -> conj(beta): identical in the real case."""
+    if beta == 0:
+        return A
+    rows = slice(None) if rows is None else rows
+    w = A[rows, r] @ v
+    A[rows, r] -= np.outer(w, beta * v)
+    return A
+
+
+def givens(f: float, g: float):
+    """LinearAlgebra.givensAlgorithm (LAPACK dlartg semantics), real case: returns (c, s, r)
+    with [c s; -s c] [f; g] = [r; 0]."""
+    if g == 0:
+        return 1.0, 0.0, f
+    if f == 0:
+        return 0.0, 1.0, g
+    r = math.hypot(f, g)
+    c, s = f / r, g / r
+    if abs(f) > abs(g) and c < 0:
+        c, s, r = -c, -s, -r
+    return c, s, r
+
+
+def eigsort_key(which: str):
+    """eigsort (eigsolve/eigsolve.jl:334-355), real spectrum."""
+    if which == "LM":
+        return (lambda d: np.abs(d)), True
+    if which == "LR":
+        return (lambda d: d), True
+    if which == "SR":
+        return (lambda d: d), False
+    raise ValueError(f"invalid specification of which eigenvalues to target: which = {which}")
+
+
+def sortperm(D: np.ndarray, which: str) -> np.ndarray:
+    by, rev = eigsort_key(which)
+    key = by(np.asarray(D))
+    # Julia's sortperm is stable; rev=true keeps stability w.r.t. reversed comparison
+    return np.argsort(-key if rev else key, kind="stable")
+
+
+def tridiageigh(alphas: np.ndarray, betas: np.ndarray):
+    """tridiageigh! -> LAPACK stegr (dense/linalg.jl:109-116,396-458): ascending eigenvalues."""
+    if len(alphas) == 1:
+        return np.array([alphas[0]]), np.ones((1, 1))
+    return sla.eigh_tridiagonal(alphas, betas, lapack_driver="stemr")
+
+
+# --------------------------------------------------------------------------------------
+# Drivers
+# --------------------------------------------------------------------------------------
+@dataclass
+class ConvergenceInfo:  # KrylovKit.jl:212-218
+    converged: int
+    residual: object
+    normres: object
+    numiter: int
+    numops: int
+
+
+def eigsolve_lanczos(A, x0: np.ndarray, howmany: int = 1, which: str = "LM", *, krylovdim: int = 30,
+                     maxiter: int = 100, tol: float = 1e-12, orth: Orthogonalizer = MGS2,
+                     eager: bool = False, trace: Optional[list] = None):
+    """eigsolve(A, x0, howmany, which, alg::Lanczos) (eigsolve/lanczos.jl:1-155)."""
+    if howmany > krylovdim:
+        raise ValueError("krylov dimension too small")
+    it = LanczosIterator(A, np.array(x0, dtype=np.float64), orth)
+    fact = lanczos_initialize(it)
+    numops = 1
+    numiter = 1
+    HH = np.zeros((krylovdim + 1, krylovdim))
+    converged = 0
+    D = U = f = None
+    while True:
+        beta = fact.normres
+        K = len(fact)
+        if K == krylovdim or beta <= tol or (eager and K >= howmany):  # :45
+            a, b = fact.rayleighquotient()
+            if K == 1:
+                D = np.array([a[0]])
+                U = np.ones((1, 1))
+                f = np.array([beta])
+                converged = int(beta <= tol)
+            else:
+                D, U = tridiageigh(a, b)
+                p = sortperm(D, which)
+                D, U = D[p], U[:, p]
+                f = U[K - 1, :] * beta  # :61
+                converged = 0
+                while converged < K and abs(f[converged]) <= tol:
+                    converged += 1
+            if trace is not None:
+                trace.append((numiter, K, D.copy(), np.abs(f)))
+            if converged >= howmany or beta <= tol:
+                break
+        if K < krylovdim:  # :77-79
+            fact = lanczos_expand(it, fact)
+            numops += 1
+        else:  # :80-116
+            if numiter == maxiter:
+                break
+            keep = (3 * krylovdim + 2 * converged) // 5
+            H = HH[: keep + 1, :keep]
+            H[:] = 0.0
+            for j in range(keep):
+                H[j, j] = D[j]
+                H[keep, j] = f[j]
+            U = np.array(U)
+            for j in range(keep, 0, -1):  # j = keep:-1:1 (1-based)  :94-101
+                hb, hv, nu = householder_vec(H[j, :j], j - 1)  # householder(H, j+1, 1:j, j)
+                H[j, j - 1] = nu
+                H[j, : j - 1] = 0.0
+                rr = np.arange(j)
+                householder_lmul(hb, hv, rr, H)
+                householder_rmul_mat(H, hb, hv, rr, rows=slice(0, j))
+                householder_rmul_mat(U, hb, hv, rr)
+            for j in range(keep):
+                fact.alphas[j] = H[j, j]
+                fact.betas[j] = H[j + 1, j]
+            B = fact.V
+            B = basistransform(B, U[:, :keep])  # :109
+            r = fact.r
+            B[keep] = scale_(r, 1.0 / beta)  # :111
+            fact = lanczos_shrink(fact, keep)
+            numiter += 1
+    hm = howmany
+    if converged > howmany:
+        hm = converged
+    elif len(D) < howmany:
+        hm = len(D)
+    values = D[:hm]
+    Vc = U[:, :hm]
+    vectors = [basis_times(fact.V, Vc[:, i]) for i in range(hm)]
+    residuals = [scale(fact.r, Vc[-1, i]) for i in range(hm)]
+    normres = np.abs(f[:hm])
+    return values, vectors, ConvergenceInfo(converged, residuals, normres, numiter, numops)
+
+
+def gmres(operator, b: np.ndarray, x0: Optional[np.ndarray] = None, a0: float = 0.0, a1: float = 1.0, *,
+          krylovdim: int = 30, maxiter: int = 100, tol: float = 1e-12,
+          orth: Orthogonalizer = MGS2, trace: Optional[list] = None):
+    """linsolve(operator, b, x0, alg::GMRES, a0, a1) (linsolve/gmres.jl:1-151).
+    `tol` is the absolute tolerance (the front-end computes max(atol, rtol*|b|),
+    linsolve/linsolve.jl:135-140)."""
+    b = np.asarray(b, dtype=np.float64)
+    x0 = np.zeros_like(b) if x0 is None else np.asarray(x0, dtype=np.float64)
+    y0 = apply(operator, x0)
+    r = scale(b, 1.0)
+    if a0 != 0:
+        r = add(r, x0, -a0)
+    r = add(r, y0, -a1)
+    x = x0.copy()
+    beta = norm(r)
+    if beta < tol:
+        return x, ConvergenceInfo(1, r, beta, 0, 1)
+    y = np.zeros(krylovdim + 1)
+    gs = [None] * krylovdim
+    R = np.zeros((krylovdim, krylovdim))
+    numiter = 0
+    numops = 1
+    it = ArnoldiIterator(operator, r, orth)
+    fact = arnoldi_initialize(it)
+    numops += 1
+    while True:
+        numiter += 1
+        y[0] = beta
+        k = 1
+        H = fact.rayleighquotient()
+        R[0, 0] = a0 + a1 * H[0, 0]
+        c, s, R[0, 0] = givens(R[0, 0], a1 * fact.normres)
+        gs[0] = (0, 1, c, s)  # Givens(i1, i2, c, s), 0-based
+        y[1] = 0.0
+        y[0], y[1] = c * y[0] + s * y[1], -s * y[0] + c * y[1]
+        beta = abs(y[1])
+        while R[k - 1, k - 1] != 0 and beta > tol and len(fact) < krylovdim:  # :55
+            fact = arnoldi_expand(it, fact)
+            numops += 1
+            k = len(fact)
+            H = fact.rayleighquotient()
+            for i in range(k - 1):
+                R[i, k - 1] = a1 * H[i, k - 1]
+            R[k - 1, k - 1] = a0 + a1 * H[k - 1, k - 1]
+            Rk = R[:, k - 1]
+            for i in range(k - 1):  # apply old Givens: lmul!(gs[i], Rk)  :72-75
+                i1, i2, c, s = gs[i]
+                Rk[i1], Rk[i2] = c * Rk[i1] + s * Rk[i2], -s * Rk[i1] + c * Rk[i2]
+            if math.hypot(R[k - 1, k - 1], a1 * fact.normres) < tol:  # :78-85
+                c, s, y[k] = givens(0.0, y[k - 1])  # givens(0, y[k], k+1, k): i1=k+1, i2=k
+                gs[k - 1] = (k, k - 1, c, s)
+                y[k - 1] = 0.0
+                R[k - 1, k - 1] = 0.0
+            else:
+                c, s, R[k - 1, k - 1] = givens(R[k - 1, k - 1], a1 * fact.normres)
+                gs[k - 1] = (k - 1, k, c, s)
+                y[k] = 0.0
+                y[k - 1], y[k] = c * y[k - 1] + s * y[k], -s * y[k - 1] + c * y[k]
+            beta = abs(y[k])
+            if trace is not None:
+                trace.append((numiter, k, beta))
+        # triangular solve :98-102 (ldiv!, dense/linalg.jl:96-106)
+        kk = k - 1 if (R[k - 1, k - 1] == 0 and y[k - 1] == 0) else k
+        for j in range(kk - 1, -1, -1):
+            y[j] = y[j] / R[j, j]
+            y[:j] -= R[:j, j] * y[j]
+        V = fact.V
+        for i in range(k):  # :105-108
+            x = add(x, V[i], y[i])
+        if beta > tol and numiter < maxiter:  # :110-117
+            w = fact.r
+            V.append(scale_(w, 1.0 / fact.normres))
+            for i in range(k):
+                i1, i2, c, s = gs[i]
+                givens_rmul(V, i1, i2, c, -s)  # rmul!(V, gs[i]')  adjoint: s -> -s
+            r = V[k] * y[k]
+        else:  # :119-132
+            r = scale(b, 1.0)
+            Ax = apply(operator, x)
+            r = add(r, a0 * x + a1 * Ax, -1.0)
+            numops += 1
+            beta = norm(r)
+            if beta < tol:
+                return x, ConvergenceInfo(1, r, beta, numiter, numops)
+        if numiter >= maxiter:
+            return x, ConvergenceInfo(0, r, beta, numiter, numops)
+        it = ArnoldiIterator(operator, r, orth)
+        fact = arnoldi_initialize_(it, fact)
+
+
+def svdsolve_gkl(A, x0: np.ndarray, howmany: int = 1, which: str = "LR", *, krylovdim: int = 30,
+                 maxiter: int = 100, tol: float = 1e-12, orth: Orthogonalizer = MGS2,
+                 eager: bool = False):
+    """svdsolve(A, x0, howmany, which, alg::GKL) (eigsolve/svdsolve.jl:144-314)."""
+    if howmany > krylovdim:
+        raise ValueError("krylov dimension too small")
+    numiter = 1
+    it = GKLIterator(A, np.array(x0, dtype=np.float64), orth)
+    fact = gkl_initialize(it)
+    numops = 2
+    HH = np.zeros((krylovdim + 1, krylovdim))
+    converged = 0
+    P = Q = f = S = None
+    while True:
+        beta = fact.normres
+        K = len(fact)
+        if K == krylovdim or beta <= tol or (eager and K >= howmany):
+            # rayleighquotient: lower Bidiagonal(alphas, betas[:K-1])  gkl.jl:50-55
+            Bm = np.diag(np.array(fact.alphas[:K]))
+            if K > 1:
+                Bm += np.diag(np.array(fact.betas[: K - 1]), -1)
+            P, S, Q = np.linalg.svd(Bm)  # B = P*diag(S)*Q ; descending S  (bidiagsvd!, linalg.jl:123-130)
+            if which == "SR":
+                P = P[:, ::-1]
+                S = S[::-1]
+                Q = Q[::-1, :]
+            elif which != "LR":
+                raise ValueError(which)
+            f = Q.T[K - 1, :] * beta  # mul!(f, view(Q', K, :), beta)  :208
+            converged = 0
+            while converged < K and abs(f[converged]) < tol:
+                converged += 1
+            if converged >= howmany or beta <= tol:
+                break
+        if K < krylovdim:
+            fact = gkl_expand(it, fact)
+            numops += 2
+        else:
+            if numiter == maxiter:
+                break
+            keep = (3 * krylovdim + 2 * converged) // 5
+            U = fact.U
+            basistransform(U, P[:, :keep])  # :233
+            V = fact.V
+            basistransform(V, Q.T[:, :keep])  # :240
+            r = fact.r
+            U[keep] = scale_(r, 1.0 / fact.normres)  # :249
+            H = HH[: keep + 1, :keep]
+            H[:] = 0.0
+            for j in range(keep):
+                H[j, j] = S[j]
+                H[keep, j] = f[j]
+            for j in range(keep, 0, -1):  # :257-269
+                hb, hv, nu = householder_vec(H[j, :j], j - 1)  # householder(H, j+1, 1:j, j)
+                H[j, j - 1] = nu
+                H[j, : j - 1] = 0.0
+                rr = np.arange(j)
+                householder_rmul_mat(H, hb, hv, rr, rows=slice(0, j))
+                householder_rmul(V, hb, hv, rr)  # rmul!(V, h')
+                hb, hv, nu = householder_vec(H[:j, j - 1], j - 1)  # householder(H, 1:j, j, j)
+                H[j - 1, j - 1] = nu
+                H[: j - 1, j - 1] = 0.0
+                householder_lmul(hb, hv, rr, H[:, : j - 1])
+                householder_rmul(U, hb, hv, rr)  # rmul!(U, h')
+            for j in range(keep):
+                fact.alphas[j] = H[j, j]
+                fact.betas[j] = H[j + 1, j]
+            fact = gkl_shrink(fact, keep)
+            numiter += 1
+    if converged > howmany:
+        howmany = converged
+    values = S[:howmany]
+    Pv = P[:, :howmany]
+    Qv = Q[:howmany, :]
+    left = [basis_times(fact.U, Pv[:, i]) for i in range(howmany)]
+    right = [basis_times(fact.V, Qv[i, :]) for i in range(howmany)]
+    residuals = [scale(fact.r, Qv[i, -1]) for i in range(howmany)]
+    normres = np.abs(f[:howmany])
+    return values, left, right, ConvergenceInfo(converged, residuals, normres, numiter, numops)
+
+
+# --------------------------------------------------------------------------------------
+# Synthetic operators of SURVEY.md §8(d) (shared by tests and bench; pure functions of shape/seed)
+# --------------------------------------------------------------------------------------
+def laplacian_2d(nx: int, ny: int, shift_diag: Optional[np.ndarray] = None) -> sp.csr_matrix:
+    """5-point Dirichlet Laplacian on an nx x ny grid, diag 4, off-diag -1 (cfg 2).
+    Row index = ix + nx*iy."""
+    ex, ey = np.ones(nx), np.ones(ny)
+    Tx = sp.diags([-ex[:-1], 2 * ex, -ex[:-1]], [-1, 0, 1])
+    Ty = sp.diags([-ey[:-1], 2 * ey, -ey[:-1]], [-1, 0, 1])
+    A = sp.kron(sp.identity(ny), Tx) + sp.kron(Ty, sp.identity(nx))
+    if shift_diag is not None:
+        A = A + sp.diags(shift_diag)
+    return sp.csr_matrix(A)
+
+
+def laplacian_2d_eigs(nx: int, ny: int) -> np.ndarray:
+    i = np.arange(1, nx + 1)
+    j = np.arange(1, ny + 1)
+    lx = 2 - 2 * np.cos(i * np.pi / (nx + 1))
+    ly = 2 - 2 * np.cos(j * np.pi / (ny + 1))
+    return np.sort((lx[:, None] + ly[None, :]).ravel())
+
+
+def convection_diffusion_2d(nx: int, ny: int, px: float = 0.5, py: float = 0.25) -> sp.csr_matrix:
+    """Nonsymmetric 5-point convection-diffusion (cfg 3), central differences, cell Peclet
+    numbers px, py: stencil  W=-(1+px) E=-(1-px) S=-(1+py) N=-(1-py) C=4."""
+    ex, ey = np.ones(nx), np.ones(ny)
+    Tx = sp.diags([-(1 + px) * ex[:-1], 2 * ex, -(1 - px) * ex[:-1]], [-1, 0, 1])
+    Ty = sp.diags([-(1 + py) * ey[:-1], 2 * ey, -(1 - py) * ey[:-1]], [-1, 0, 1])
+    return sp.csr_matrix(sp.kron(sp.identity(ny), Tx) + sp.kron(Ty, sp.identity(nx)))
+
+
+def sparse_random(nrows: int, ncols: int, nnz_per_row: int, seed: int) -> sp.csr_matrix:
+    """cfg 4: random sparse rectangular, duplicates summed."""
+    rng = np.random.default_rng(seed)
+    cols = rng.integers(0, ncols, size=(nrows, nnz_per_row))
+    vals = rng.standard_normal((nrows, nnz_per_row))
+    rows = np.repeat(np.arange(nrows), nnz_per_row)
+    A = sp.coo_matrix((vals.ravel(), (rows, cols.ravel())), shape=(nrows, ncols))
+    return sp.csr_matrix(A)

@@ -1,0 +1,397 @@
+"""GPU parity tests proper: the HIP path (through the C ABI of libkrylov_hip.so) against the CPU
+oracle on the same seeded inputs.  Float64 tolerances: coefficients / norms 1e-12 relative,
+Ritz values 1e-10 relative (BASELINE.json north_star), orthogonality 1e-12."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-12
+
+
+def orth_pairs(kk, ko):
+    return [
+        (kk.ClassicalGramSchmidt(), ko.CGS), (kk.ModifiedGramSchmidt(), ko.MGS),
+        (kk.ClassicalGramSchmidt2(), ko.CGS2), (kk.ModifiedGramSchmidt2(), ko.MGS2),
+        (kk.ClassicalGramSchmidtIR(0.75), ko.CGSIR(0.75)), (kk.ModifiedGramSchmidtIR(0.75), ko.MGSIR(0.75)),
+    ]
+
+
+def relerr(a, b):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300))) if a.size else 0.0
+
+
+@pytest.mark.parametrize("n", [1, 2, 7, 511, 512, 513, 1000, 4097, 100003])
+def test_l1_verbs(kk, ctx, n):
+    rng = np.random.default_rng(n)
+    x, y = rng.standard_normal(n), rng.standard_normal(n)
+    B = kk.DeviceBasis(n, 3, ctx)
+    vx, vy, vz = B[0].set(x), B[1].set(y), B[2]
+    assert abs(vx.inner(vy) - x @ y) <= 1e-13 * np.linalg.norm(x) * np.linalg.norm(y) + 1e-300
+    assert abs(vx.norm() - np.linalg.norm(x)) <= 1e-14 * np.linalg.norm(x)
+    vy.add_(vx, 0.3, -1.7)
+    np.testing.assert_allclose(vy.get(), -1.7 * y + 0.3 * x, rtol=1e-15, atol=1e-15)
+    vz.scale_from_(vx, 2.5)
+    np.testing.assert_allclose(vz.get(), 2.5 * x, rtol=1e-15)
+    vz.scale_(-0.5)
+    np.testing.assert_allclose(vz.get(), -1.25 * x, rtol=1e-15)
+    vz.zero_()
+    assert np.all(vz.get() == 0)
+    # pad rows stay zero: norm of a freshly random-filled column only sees n entries
+    vz.rand_(42)
+    z = vz.get()
+    assert z.min() >= 0 and z.max() < 1 and abs(vz.norm() - np.linalg.norm(z)) <= 1e-13 * np.linalg.norm(z)
+    vz2 = kk.DeviceBasis(n, 1, ctx)[0].rand_(42)
+    assert np.array_equal(vz2.get(), z)  # counter-based: reproducible
+
+
+@pytest.mark.parametrize("n,m", [(5, 1), (300, 3), (1000, 4), (5000, 17), (70000, 64), (33333, 65), (20000, 130)])
+def test_project_unproject(kk, ko, ctx, n, m):
+    rng = np.random.default_rng(n + m)
+    V = rng.standard_normal((n, m))
+    w = rng.standard_normal(n)
+    B = kk.DeviceBasis(n, m + 2, ctx)
+    for j in range(m):
+        B.upload(j, V[:, j])
+    B.length = m
+    vw = B[m].set(w)
+    y = B.project(vw)
+    ref = V.T @ w
+    assert np.max(np.abs(y - ref)) <= 1e-13 * np.linalg.norm(w) * np.sqrt(n)
+    y0 = rng.standard_normal(m)
+    y2 = B.project(vw, alpha=0.5, beta=2.0, y=y0.copy())
+    np.testing.assert_allclose(y2, 2.0 * y0 + 0.5 * ref, rtol=1e-12, atol=1e-12)
+    # sub-range
+    if m > 2:
+        y3 = B.project(vw, c0=1, m=m - 2)
+        np.testing.assert_allclose(y3, ref[1:m - 1], rtol=1e-11, atol=1e-11)
+    x = rng.standard_normal(m)
+    out = B[m + 1].set(w)
+    B.unproject(out, x, alpha=-1.0, beta=1.0)
+    np.testing.assert_allclose(out.get(), w - V @ x, rtol=1e-12, atol=1e-12)
+    B.unproject(out, x, alpha=2.0, beta=0.0)
+    np.testing.assert_allclose(out.get(), 2.0 * (V @ x), rtol=1e-12, atol=1e-12)
+    with pytest.raises(kk.DimensionMismatch):
+        B.project(vw, y=np.zeros(m + 1))
+    with pytest.raises(kk.DimensionMismatch):
+        B.unproject(out, np.zeros(m + 1))
+
+
+@pytest.mark.parametrize("mgs_mode", [0, 1])
+@pytest.mark.parametrize("n,m", [(10, 4), (100, 30), (5000, 61), (40000, 100)])
+def test_orthogonalize_all_algs(kk, ko, ctx, n, m, mgs_mode):
+    """test/linalg.jl:4-25 identities + coefficient parity with the oracle."""
+    ctx.set_option("mgs_mode", mgs_mode)
+    rng = np.random.default_rng(1000 + n + m)
+    Q, _ = np.linalg.qr(rng.standard_normal((n, min(m, n - 1))))
+    m = Q.shape[1]
+    # a vector with a large component inside span(Q) so that IR variants take a second pass
+    w0 = Q @ rng.standard_normal(m) * 50 + rng.standard_normal(n) * 1e-3
+    for dev, ref in orth_pairs(kk, ko):
+        B = kk.DeviceBasis(n, m + 1, ctx)
+        for j in range(m):
+            B.upload(j, Q[:, j])
+        B.length = m
+        vw = B[m].set(w0)
+        x, nrm, passes = B.orthogonalize(vw, dev)
+        wr, xr = ko.orthogonalize(w0.copy(), [Q[:, j].copy() for j in range(m)], ref)
+        assert relerr(x, xr) < 1e-9, (dev.name, relerr(x, xr))
+        wd = vw.get()
+        assert abs(nrm - np.linalg.norm(wd)) <= 1e-12 * np.linalg.norm(wd)
+        # norm([r, norm(x)]) ~ norm(a)   (test/linalg.jl:12)
+        assert abs(np.hypot(nrm, np.linalg.norm(x)) - np.linalg.norm(w0)) <= 1e-10 * np.linalg.norm(w0)
+        if dev.is_reorth:
+            assert np.max(np.abs(Q.T @ wd)) <= 1e-12 * np.linalg.norm(w0)
+            np.testing.assert_allclose(wd, wr, rtol=0, atol=1e-11 * np.linalg.norm(w0))
+        # orthonormalize!!
+        vw.set(w0)
+        x2, beta, _ = B.orthonormalize(vw, dev)
+        assert abs(vw.norm() - 1) < 1e-13 and abs(beta - nrm) <= 1e-12 * nrm
+    ctx.set_option("mgs_mode", 1)
+
+
+def test_orthogonalize_vec(kk, ko, ctx):
+    rng = np.random.default_rng(5)
+    n = 3000
+    q = rng.standard_normal(n)
+    q /= np.linalg.norm(q)
+    w0 = 30 * q + rng.standard_normal(n) * 1e-2
+    for dev, ref in orth_pairs(kk, ko):
+        B = kk.DeviceBasis(n, 2, ctx)
+        vq, vw = B[0].set(q), B[1].set(w0)
+        s, nrm = vw.orthogonalize_against_(vq, dev)
+        wr, sr = ko.orthogonalize_vec(w0.copy(), q, ref)
+        assert abs(s - sr) <= 1e-13 * abs(sr)
+        np.testing.assert_allclose(vw.get(), wr, rtol=0, atol=1e-13 * np.linalg.norm(w0))
+        assert abs(nrm - np.linalg.norm(wr)) <= 1e-11 * np.linalg.norm(wr)
+
+
+def _mats(ko):
+    rng = np.random.default_rng(9)
+    A1 = ko.laplacian_2d(37, 23)                       # ELL, symmetric
+    A2 = ko.convection_diffusion_2d(41, 17)            # ELL, nonsymmetric
+    A3 = ko.sparse_random(700, 300, 9, 11)             # rectangular
+    d = rng.integers(0, 60, size=500)                  # very ragged rows -> CSR path
+    rows = np.repeat(np.arange(500), d)
+    A4 = sp.csr_matrix((rng.standard_normal(rows.size), (rows, rng.integers(0, 500, rows.size))), shape=(500, 500))
+    A5 = sp.csr_matrix(([1.5], ([0], [0])), shape=(3, 3))  # empty rows
+    return [A1, A2, A3, A4, A5]
+
+
+@pytest.mark.parametrize("via_csc", [False, True])
+def test_spmv_formats(kk, ko, ctx, via_csc):
+    rng = np.random.default_rng(3)
+    for A in _mats(ko):
+        op = kk.SparseOperator(A, ctx, via_csc=via_csc)
+        nr, nc = A.shape
+        X, Y = kk.DeviceBasis(nc, 2, ctx), kk.DeviceBasis(nr, 2, ctx)
+        x, u = rng.standard_normal(nc), rng.standard_normal(nr)
+        op.apply(X[0].set(x), Y[0])
+        scale = np.abs(A) @ np.abs(x) + 1e-300
+        assert np.max(np.abs(Y[0].get() - A @ x) / scale) < 1e-14
+        op.apply_adjoint(Y[1].set(u), X[1])
+        scale = np.abs(A.T) @ np.abs(u) + 1e-300
+        assert np.max(np.abs(X[1].get() - A.T @ u) / scale) < 1e-14
+        if nr == nc:
+            op.apply_affine(X[0], Y[0], 0.7, -1.3)
+            np.testing.assert_allclose(Y[0].get(), 0.7 * x - 1.3 * (A @ x), rtol=1e-12, atol=1e-12)
+        with pytest.raises(kk.DimensionMismatch):
+            op.apply(kk.DeviceBasis(nc + 1, 1, ctx)[0], Y[0])
+
+
+def test_csr_forced(kk, ko, ctx, monkeypatch):
+    monkeypatch.setenv("KK_SPMV_FORMAT", "csr")
+    A = ko.laplacian_2d(50, 40)
+    op = kk.SparseOperator(A, ctx)
+    assert op.info()["format"] == "CSR"
+    x = np.random.default_rng(1).standard_normal(A.shape[1])
+    X = kk.DeviceBasis(A.shape[0], 2, ctx)
+    op.apply(X[0].set(x), X[1])
+    np.testing.assert_allclose(X[1].get(), A @ x, rtol=1e-13, atol=1e-13)
+
+
+@pytest.mark.parametrize("mgs_mode", [0, 1])
+def test_lanczos_factorization(kk, ko, ctx, mgs_mode):
+    """test/factorize.jl:140-148 invariants after every expand! + (alpha, beta) parity with the oracle."""
+    ctx.set_option("mgs_mode", mgs_mode)
+    nx, ny = 40, 30
+    n = nx * ny
+    A = ko.laplacian_2d(nx, ny, shift_diag=10 * np.linspace(0, 1, n) ** 2)
+    x0 = np.random.default_rng(3).random(n)
+    steps = 25
+    for dev, ref in orth_pairs(kk, ko):
+        it = kk.LanczosIterator(kk.SparseOperator(A, ctx, symmetric=True), x0, dev, capacity=steps + 3)
+        fact = kk.initialize(it)
+        oit = ko.LanczosIterator(A, x0.copy(), ref)
+        ofact = ko.lanczos_initialize(oit)
+        for _ in range(steps):
+            fact = kk.expand_(it, fact)
+            ofact = ko.lanczos_expand(oit, ofact)
+            k = len(fact)
+            V = fact.V.to_numpy()
+            r = fact.r.get()
+            T = np.diag(fact.alphas) + np.diag(fact.betas[:-1], 1) + np.diag(fact.betas[:-1], -1)
+            ek = np.zeros(k); ek[-1] = 1
+            assert abs(np.linalg.norm(r) - fact.normres) <= 1e-12 * max(1, fact.normres)
+            assert np.max(np.abs(A @ V - V @ T - np.outer(r, ek))) < 1e-11
+            if dev.is_reorth:
+                assert np.max(np.abs(V.T @ V - np.eye(k))) < 1e-12
+        tol = 1e-10 if dev.is_reorth else 1e-6  # plain CGS/MGS Lanczos loses orthogonality: trajectories drift
+        assert relerr(fact.alphas, ofact.alphas) < tol, dev.name
+        assert relerr(fact.betas, ofact.betas) < tol, dev.name
+        # shrink! (lanczos.jl:273-291)
+        fact = kk.shrink_(fact, 10)
+        ofact = ko.lanczos_shrink(ofact, 10)
+        assert len(fact) == 10 and len(fact.V) == 10
+        np.testing.assert_allclose(fact.r.get(), ofact.r, rtol=0, atol=1e-6 if not dev.is_reorth else 1e-10)
+    ctx.set_option("mgs_mode", 1)
+
+
+def test_lanczos_keepvecs_false(kk, ko, ctx):
+    n = 900
+    A = ko.laplacian_2d(30, 30)
+    x0 = np.random.default_rng(8).random(n)
+    for dev, ref in orth_pairs(kk, ko)[:2]:
+        it = kk.LanczosIterator(kk.SparseOperator(A, ctx, symmetric=True), x0, dev, keepvecs=False, capacity=6)
+        fact = kk.initialize(it)
+        oit = ko.LanczosIterator(A, x0.copy(), ref, keepvecs=False)
+        ofact = ko.lanczos_initialize(oit)
+        for _ in range(12):
+            fact = kk.expand_(it, fact)
+            ofact = ko.lanczos_expand(oit, ofact)
+        assert len(fact.V) == 1 and len(ofact.V) == 1
+        assert relerr(fact.alphas, ofact.alphas) < 1e-9 and relerr(fact.betas, ofact.betas) < 1e-9
+    with pytest.raises(ValueError):
+        kk.LanczosIterator(None, x0, kk.ModifiedGramSchmidt2(), keepvecs=False)
+
+
+@pytest.mark.parametrize("mgs_mode", [0, 1])
+def test_arnoldi_factorization(kk, ko, ctx, mgs_mode):
+    """test/factorize.jl:185-193: V'V = I, A V = V H + r e', norm(r) = beta, after every expand!."""
+    ctx.set_option("mgs_mode", mgs_mode)
+    A = ko.convection_diffusion_2d(30, 20)
+    n = A.shape[0]
+    x0 = np.random.default_rng(4).random(n)
+    steps = 20
+    for dev, ref in orth_pairs(kk, ko):
+        it = kk.ArnoldiIterator(kk.SparseOperator(A, ctx), x0, dev, capacity=steps + 3)
+        fact = kk.initialize(it)
+        oit = ko.ArnoldiIterator(A, x0.copy(), ref)
+        ofact = ko.arnoldi_initialize(oit)
+        for _ in range(steps):
+            fact = kk.expand_(it, fact)
+            ofact = ko.arnoldi_expand(oit, ofact)
+        k = len(fact)
+        V, r, H = fact.V.to_numpy(), fact.r.get(), fact.rayleighquotient()
+        ek = np.zeros(k); ek[-1] = 1
+        assert np.max(np.abs(A @ V - V @ H - np.outer(r, ek))) < 1e-11
+        assert abs(np.linalg.norm(r) - fact.normres) < 1e-12
+        assert np.max(np.abs(V.T @ V - np.eye(k))) < (1e-12 if dev.is_reorth else 1e-8)
+        assert relerr(fact.H, ofact.H) < (1e-8 if dev.is_reorth else 1e-5) or \
+            np.max(np.abs(np.array(fact.H) - np.array(ofact.H))) < 1e-10
+        fact = kk.shrink_(fact, 7)
+        ofact = ko.arnoldi_shrink(ofact, 7)
+        assert len(fact.H) == len(ofact.H) and len(fact.V) == 7
+    ctx.set_option("mgs_mode", 1)
+
+
+@pytest.mark.parametrize("mgs_mode", [0, 1])
+def test_gkl_factorization(kk, ko, ctx, mgs_mode):
+    """test/factorize.jl:285-296: A V = U B + r e', A'U = V B', U'U = I, V'V = I."""
+    ctx.set_option("mgs_mode", mgs_mode)
+    A = ko.sparse_random(600, 250, 8, 21)
+    u0 = np.random.default_rng(6).random(600)
+    steps = 15
+    for dev, ref in orth_pairs(kk, ko):
+        it = kk.GKLIterator(kk.SparseOperator(A, ctx), u0, dev, capacity=steps + 3)
+        fact = kk.initialize(it)
+        oit = ko.GKLIterator(A, u0.copy(), ref)
+        ofact = ko.gkl_initialize(oit)
+        for _ in range(steps):
+            fact = kk.expand_(it, fact)
+            ofact = ko.gkl_expand(oit, ofact)
+        k = len(fact)
+        U, V, r, B = fact.U.to_numpy(), fact.V.to_numpy(), fact.r.get(), fact.rayleighquotient()
+        ek = np.zeros(k); ek[-1] = 1
+        assert np.max(np.abs(A @ V - U @ B - np.outer(r, ek))) < 1e-11
+        assert np.max(np.abs(A.T @ U - V @ B.T)) < 1e-10
+        if dev.name in ("mgs2", "cgsir", "mgsir"):
+            assert np.max(np.abs(U.T @ U - np.eye(k))) < 1e-12
+            assert np.max(np.abs(V.T @ V - np.eye(k))) < 1e-12
+        tol = 1e-10 if dev.is_reorth else 1e-6
+        assert relerr(fact.alphas, ofact.alphas) < tol and relerr(fact.betas, ofact.betas) < tol
+        fact = kk.shrink_(fact, 5)
+        assert len(fact.U) == 5 and len(fact.V) == 5
+    ctx.set_option("mgs_mode", 1)
+
+
+def test_restart_kernels(kk, ko, ctx):
+    """test/linalg.jl:27-44: Givens / Householder on a basis agree with dense rmul!; basistransform!."""
+    rng = np.random.default_rng(12)
+    n, m = 3001, 23
+    V = rng.standard_normal((n, m))
+    B = kk.DeviceBasis(n, m + 1, ctx)
+    for j in range(m):
+        B.upload(j, V[:, j])
+    B.length = m
+    c, s = np.cos(0.3), np.sin(0.3)
+    B.rmul_givens(2, 5, c, s)
+    Vr = V.copy()
+    Vr[:, 2], Vr[:, 5] = c * V[:, 2] - s * V[:, 5], s * V[:, 2] + c * V[:, 5]
+    np.testing.assert_allclose(B.to_numpy(), Vr, rtol=1e-14, atol=1e-14)
+    hv = rng.standard_normal(9); hv[3] = 1.0
+    beta = 2.0 / (hv @ hv)
+    B.rmul_householder(beta, hv, 4, 9)
+    w = Vr[:, 4:13] @ hv
+    Vr[:, 4:13] -= np.outer(w, beta * hv)
+    np.testing.assert_allclose(B.to_numpy(), Vr, rtol=1e-13, atol=1e-12)
+    U, _ = np.linalg.qr(rng.standard_normal((m, m)))
+    keep = 14
+    B.basistransform(U[:, :keep])
+    Vt = Vr.copy()
+    Vt[:, :keep] = Vr @ U[:, :keep]
+    np.testing.assert_allclose(B.to_numpy(), Vt, rtol=1e-12, atol=1e-12)
+    y = B[m].set(rng.standard_normal(n))
+    x = rng.standard_normal(5)
+    B.rank1update(y, x, c0=3, m=5, alpha=0.5, beta=1.0)
+    Vt[:, 3:8] += 0.5 * np.outer(y.get(), x)
+    np.testing.assert_allclose(B.to_numpy(), Vt, rtol=1e-12, atol=1e-12)
+    with pytest.raises(kk.DimensionMismatch):
+        B.basistransform(U[:5, :3])
+
+
+@pytest.mark.parametrize("which", ["LM", "SR", "LR"])
+def test_eigsolve_lanczos(kk, ko, ctx, which):
+    """test/eigsolve.jl:74,122-123: values vs dense eigvals, residual identity; counts equal the oracle's."""
+    nx, ny = 24, 18
+    n = nx * ny
+    A = ko.laplacian_2d(nx, ny, shift_diag=10 * np.linspace(0, 1, n) ** 2)
+    ev = np.linalg.eigvalsh(A.toarray())
+    x0 = np.random.default_rng(2).random(n)
+    for dev, ref in orth_pairs(kk, ko)[2:]:
+        vals, vecs, info = kk.eigsolve(kk.SparseOperator(A, ctx, symmetric=True), x0, 4, which,
+                                       krylovdim=30, maxiter=200, tol=1e-11, orth=dev)
+        ovals, ovecs, oinfo = ko.eigsolve_lanczos(A, x0, 4, which, krylovdim=30, maxiter=200, tol=1e-11, orth=ref)
+        assert info.converged >= 4
+        key = {"LM": lambda d: -np.abs(d), "SR": lambda d: d, "LR": lambda d: -d}[which]
+        expect = ev[np.argsort(key(ev), kind="stable")][: len(vals)]
+        assert relerr(vals, expect) < 1e-10
+        assert relerr(vals[:4], ovals[:4]) < 1e-10
+        assert (info.numiter, info.numops) == (oinfo.numiter, oinfo.numops)
+        for lam, v in zip(vals, vecs):
+            assert np.linalg.norm(A @ v - lam * v) < 1e-9
+        Vm = np.stack(vecs, 1)
+        assert np.max(np.abs(Vm.T @ Vm - np.eye(len(vecs)))) < 1e-10
+
+
+def test_linsolve_gmres(kk, ko, ctx):
+    """test/linsolve.jl:135,230: b ~ (a0 + a1 A) x; numops / numiter equal the oracle's (BASELINE north_star)."""
+    A = ko.convection_diffusion_2d(40, 25)
+    n = A.shape[0]
+    b = np.random.default_rng(4).random(n)
+    for a0, a1 in ((0.0, 1.0), (0.3, 0.9)):
+        for dev, ref in orth_pairs(kk, ko):
+            tol = 1e-10 * np.linalg.norm(b)
+            x, info = kk.linsolve(kk.SparseOperator(A, ctx), b, None, kk.GMRES(dev, 20, 25, tol), a0, a1)
+            xo, oinfo = ko.gmres(A, b, None, a0, a1, krylovdim=25, maxiter=20, tol=tol, orth=ref)
+            assert info.converged == 1 and oinfo.converged == 1
+            assert (info.numiter, info.numops) == (oinfo.numiter, oinfo.numops), dev.name
+            assert abs(info.normres - oinfo.normres) <= 1e-6 * tol + 1e-10 * oinfo.normres + 1e-14
+            assert np.linalg.norm(a0 * x + a1 * (A @ x) - b) <= 1.01 * tol
+            np.testing.assert_allclose(x, xo, rtol=0, atol=1e-8 * np.linalg.norm(xo))
+    # started from the solution: numops == 1 (test/linsolve.jl:167)
+    xs = np.random.default_rng(1).random(n)
+    x, info = kk.linsolve(kk.SparseOperator(A, ctx), A @ xs, xs, kk.GMRES(tol=1e-8))
+    assert info.numops == 1 and info.converged == 1
+
+
+def test_svdsolve_gkl(kk, ko, ctx):
+    """test/svdsolve.jl:14,61-63,89: S ~ svdvals, U'U = I, A V ~ U S, A'U ~ V S."""
+    A = ko.sparse_random(400, 180, 10, 31)
+    sv = np.linalg.svd(A.toarray(), compute_uv=False)
+    u0 = np.random.default_rng(6).random(400)
+    for dev, ref in orth_pairs(kk, ko)[2:]:
+        S, L, R, info = kk.svdsolve(kk.SparseOperator(A, ctx), u0, 5, "LR", krylovdim=20, maxiter=100, tol=1e-10, orth=dev)
+        So, Lo, Ro, oinfo = ko.svdsolve_gkl(A, u0, 5, "LR", krylovdim=20, maxiter=100, tol=1e-10, orth=ref)
+        assert info.converged >= 5
+        assert relerr(S[:5], sv[:5]) < 1e-10 and relerr(S[:5], So[:5]) < 1e-10
+        assert (info.numiter, info.numops) == (oinfo.numiter, oinfo.numops)
+        Lm, Rm = np.stack(L, 1), np.stack(R, 1)
+        assert np.max(np.abs(Lm.T @ Lm - np.eye(len(S)))) < 1e-10
+        assert np.max(np.abs(A @ Rm - Lm * S)) < 1e-8
+        assert np.max(np.abs(A.T @ Lm - Rm * S)) < 1e-8
+
+
+def test_error_behaviour(kk, ctx):
+    B = kk.DeviceBasis(10, 3, ctx)
+    with pytest.raises(kk.KrylovHipError):
+        B.upload(5, np.zeros(10))
+    with pytest.raises(kk.DimensionMismatch):
+        B.upload(0, np.zeros(11))
+    A = sp.identity(10, format="csr")
+    it = kk.LanczosIterator(kk.SparseOperator(A, ctx, symmetric=True), np.zeros(10), kk.ModifiedGramSchmidt2(), capacity=4)
+    with pytest.raises(kk.KrylovHipError) as e:
+        kk.initialize(it)
+    assert "norm zero" in str(e.value)
