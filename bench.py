@@ -1,0 +1,253 @@
+#!/usr/bin/env python
+"""bench.py -- BASELINE.json's metric on MI355X: Lanczos iterations/s (+ achieved HBM GB/s) for
+eigsolve(Lanczos) on the 10M-row 5-point Laplacian (SparseMatrixCSC), krylovdim = 100.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL)
+
+One *step* = one full Krylov sweep of the hot path: `initialize` + 99 `expand!` calls
+(basis size m = 2..100), i.e. 99 Lanczos iterations (1 iteration = 1 expand! = 1 operator
+application, the reference's `numops` unit).  value = 99*K / elapsed  [iterations/s], inputs
+resident in HBM before the timed region.  N > 1 is WEAK scaling: every rank owns 10M rows of a
+(4000 x 2500*N)-grid Laplacian, basis row-sharded, 2 RCCL all-reduces + 1 halo exchange per
+iteration; value = iterations/s of the whole job (every iteration advances all 10M*N rows).
+
+Extra objects: "roofline" (dominant kernel, HIP events recorded on the kernels' stream inside
+the timed region) and "cpu_baseline" (the C twin of the oracle timed on the host cores, rank 0,
+N = 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import scipy.sparse as sp
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT / "krylovkit.jl_amd"))
+
+NX, NY = 4000, 2500          # configs[1]: 10M-row 5-point Laplacian
+KRYLOVDIM = 100
+HBM_PEAK_GBPS = 8000.0       # MI355X HBM3E spec (MI355X_MICROARCH.md)
+
+
+def laplacian_rows(nx: int, ny_total: int, y0: int, y1: int) -> sp.csr_matrix:
+    """Rows [y0*nx, y1*nx) of the 5-point Dirichlet Laplacian on an nx x ny_total grid
+    (diag 4, off-diag -1), global column indices.  SURVEY.md 8(d) cfg 2."""
+    n_glob = nx * ny_total
+    r = np.arange(y0 * nx, y1 * nx, dtype=np.int64)
+    ix = r % nx
+    cols = [r, r - 1, r + 1, r - nx, r + nx]
+    vals = [np.full(r.size, 4.0)] + [np.full(r.size, -1.0)] * 4
+    ok = [np.ones(r.size, bool), ix > 0, ix < nx - 1, r - nx >= 0, r + nx < n_glob]
+    rows = np.concatenate([(r - y0 * nx)[m] for m in ok])
+    cc = np.concatenate([c[m] for c, m in zip(cols, ok)])
+    vv = np.concatenate([v[m] for v, m in zip(vals, ok)])
+    return sp.csr_matrix((vv, (rows, cc)), shape=(r.size, n_glob))
+
+
+def algorithmic_bytes_sweep(n_rows: int, krylovdim: int) -> float:
+    """(176 + 16 m) N bytes per expand at basis size m, m = 2..krylovdim."""
+    return float(sum((176 + 16 * m) * n_rows for m in range(2, krylovdim + 1)))
+
+
+def cpu_baseline(orth_code: int, budget_rows: int = 1_000_000):
+    """Time oracle/libcpu_ref.so (C twin of the oracle = the reference's un-fused CPU path) on a
+    bounded sample: the full 99-expand sweep on a 4000 x 250 grid (1/10 of the rows)."""
+    lib_path = ROOT / "oracle" / "libcpu_ref.so"
+    if not lib_path.exists():
+        return None
+    lib = C.CDLL(str(lib_path))
+    dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int64)
+    lib.kkref_lanczos.argtypes = [C.c_int64, ip, ip, dp, dp, C.c_int, C.c_int, C.c_double, C.c_int, dp, dp,
+                                  C.POINTER(C.c_int), dp]
+    lib.kkref_lanczos.restype = C.c_int
+    ny = budget_rows // NX
+    n = NX * ny
+    A = laplacian_rows(NX, ny, 0, ny).tocsc()
+    A.sort_indices()
+    colptr = np.ascontiguousarray(A.indptr, dtype=np.int64) + 1   # Julia SparseMatrixCSC{Float64,Int64}
+    rowval = np.ascontiguousarray(A.indices, dtype=np.int64) + 1
+    nz = np.ascontiguousarray(A.data)
+    x0 = np.random.default_rng(3).random(n)
+    steps = KRYLOVDIM - 1
+    al, be = np.zeros(steps + 1), np.zeros(steps + 1)
+    passes = C.c_int()
+    cores = os.cpu_count() or 1
+    t0 = time.perf_counter()
+    rc = lib.kkref_lanczos(n, colptr.ctypes.data_as(ip), rowval.ctypes.data_as(ip), nz.ctypes.data_as(dp),
+                           x0.ctypes.data_as(dp), steps, orth_code, 0.0, cores, al.ctypes.data_as(dp),
+                           be.ctypes.data_as(dp), C.byref(passes), None)
+    dt = time.perf_counter() - t0
+    if rc != 0:
+        return None
+    scale = n / float(NX * NY)
+    return {
+        "value": round(steps / dt * scale, 4), "unit": "it/s", "cores": cores, "kind": "port",
+        "sample": f"full {steps}-expand sweep (initialize included) on a {NX}x{ny} grid = {n} rows "
+                  f"({dt:.2f} s measured); rate scaled by {scale:g} to the 10M-row workload (the path is linear in N); "
+                  "oracle/cpu_ref.c: un-fused BLAS-1 passes (OpenMP) + serial Int64 CSC SpMV as the reference issues them",
+        "hbm_equiv_GBps": round(algorithmic_bytes_sweep(n, KRYLOVDIM) / dt / 1e9, 2),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--orth", default=os.environ.get("KK_BENCH_ORTH", "mgs2"), choices=["cgs2", "mgs2"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ny", type=int, default=NY, help="grid rows per GPU (default 2500 -> 10M rows per GPU)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+
+    import krylovkit_hip as kk
+
+    orth = kk.Orthogonalizer(args.orth)
+    n_local = NX * args.ny
+    K, W = args.steps, args.warmup
+    sweep_its = KRYLOVDIM - 1
+
+    use_dist = world > 1 or bool(os.environ.get("KK_BENCH_FORCE_DIST"))   # FORCE_DIST: exercise the sharded path on 1 GPU
+    if not use_dist:
+        ctx = kk.default_context()
+        A = laplacian_rows(NX, args.ny, 0, args.ny)
+        op = kk.SparseOperator(A, ctx, symmetric=True, via_csc=True)   # handed over as Julia's SparseMatrixCSC
+        del A
+        V = kk.DeviceBasis(n_local, KRYLOVDIM + 2, ctx)
+        x0 = kk.DeviceBasis(n_local, 1, ctx)
+        x0[0].rand_(3)                                                 # x0 = rand!(similar(A, T, n)), resident in HBM
+        it = kk.LanczosIterator(op, x0[0], orth, capacity=KRYLOVDIM + 2)
+
+        def sweep():
+            fact = kk.initialize(it, V)
+            for _ in range(sweep_its):
+                fact = kk.expand_(it, fact)
+            return fact
+
+        sync, barrier = ctx.sync, (lambda: None)
+        parallelism = "single GPU"
+    else:
+        import torch
+        import torch.distributed as dist
+        from krylovkit_hip import dist as kd
+
+        torch.cuda.set_device(local_rank)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        be = kd.HipBackend(local_rank)
+        ctx = be.ctx
+        part = kd.Partition.even(NX * args.ny * world, world, rank, align=NX)
+        A = laplacian_rows(NX, args.ny * world, rank * args.ny, (rank + 1) * args.ny)
+        dop = kd.DistSparseOperator(A, part, be)
+        del A
+        V = be.make_basis(n_local, KRYLOVDIM + 2)
+        xb = be.make_basis(n_local, 1)
+        xb[0].rand_(3 + rank)
+        it = kd.DistLanczosIterator(dop, (xb, 0), orth, capacity=KRYLOVDIM + 2)   # start vector resident in HBM
+
+        def sweep():
+            fact = it.initialize(V)
+            for _ in range(sweep_its):
+                fact = it.expand(fact)
+            return fact
+
+        def sync():
+            torch.cuda.synchronize()
+
+        def barrier():
+            dist.barrier()
+
+        parallelism = f"basis row-sharded over {world} GPUs (10M rows each), RCCL all-reduce x2 + halo P2P per iteration"
+
+    for _ in range(W):
+        sweep()
+    barrier(); sync()
+    ctx.prof_reset()
+    ctx.prof_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(K):
+        fact = sweep()
+    barrier(); sync()
+    elapsed = time.perf_counter() - t0
+    ctx.prof_enable(False)
+    if use_dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---------------- roofline of the dominant kernel (HIP events on the kernels' stream)
+    classes = {}
+    for name in ("k_project", "k_unproject", "k_spmv_ell", "k_spmv_csr", "k_scal", "k_mgs_step", "k_dot", "k_axpby"):
+        ms, n = ctx.prof_get(name)
+        if n:
+            classes[name] = (ms, n)
+    dom = max(classes, key=lambda k: classes[k][0]) if classes else None
+    roofline = None
+    if dom in ("k_project", "k_unproject"):
+        ms, n = classes[dom]
+        # one launch per expand at basis size m = 2..100: project moves (8m + 8) N algorithmic bytes
+        # (V once + w), unproject (8m + 16) N (V once + w read/write); their sum is pass(m) = (16m + 24) N.
+        extra = 8 if dom == "k_project" else 16
+        per_sweep = sum((8 * m + extra) * n_local for m in range(2, KRYLOVDIM + 1))
+        launches_per_sweep = KRYLOVDIM - 1
+        bytes_per_launch = per_sweep / launches_per_sweep
+        avg_ms = ms / n
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        tf = ROOT / "profiles" / "traffic.json"
+        if tf.exists():
+            try:
+                traffic = json.loads(tf.read_text()).get(dom)
+            except Exception:
+                traffic = None
+        roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                    "launches": int(n), "avg_launch_ms": round(avg_ms, 5),
+                    "algorithmic_bytes_per_launch": round(bytes_per_launch),
+                    "all_kernels_ms": {k: round(v[0], 3) for k, v in classes.items()}}
+
+    if rank == 0:
+        its = sweep_its * K
+        value = its / elapsed
+        alg = algorithmic_bytes_sweep(n_local * world, KRYLOVDIM) * K
+        out = {
+            "metric": "lanczos_iterations_per_second", "value": round(value, 3), "unit": "it/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(elapsed / K * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {
+                "workload": f"eigsolve(Lanczos) expand! sweep: {NX}x{args.ny * world} 5-point Laplacian "
+                            f"({n_local * world} rows, SparseMatrixCSC handed over via kk_csc_create), krylovdim={KRYLOVDIM}, "
+                            f"1 step = initialize + {sweep_its} expand! (m=2..{KRYLOVDIM})",
+                "orth": {"cgs2": "ClassicalGramSchmidt2", "mgs2": "ModifiedGramSchmidt2 (reference default; low-sync form)"}[args.orth],
+                "rows_per_gpu": n_local, "parallelism": parallelism,
+            },
+            "hbm_algorithmic_GBps": round(alg / elapsed / 1e9, 1),
+            "hbm_algorithmic_frac_of_peak_per_gpu": round(alg / elapsed / 1e9 / (HBM_PEAK_GBPS * world), 4),
+            "last_alpha": fact.alphas[-1], "last_beta": fact.betas[-1],
+            "roofline": roofline,
+        }
+        if world == 1 and not use_dist and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(orth.code)
+        print(json.dumps(out), flush=True)
+    if use_dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

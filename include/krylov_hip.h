@@ -125,10 +125,10 @@ int kk_csc_create(kk_ctx ctx, int64_t nrows, int64_t ncols, int64_t nnz, const i
 int kk_op_free(kk_op op);
 int kk_op_info(kk_op op, int64_t* nrows, int64_t* ncols, int64_t* nnz, int* format /*0=ELL,1=CSR*/,
                int64_t* device_bytes);
-/* Row-sharded operators (one process per GPU): column indices >= n_local address a ghost
- * buffer of n_ghost doubles the caller fills before each apply (halo rows / all-gathered x). */
-int kk_op_set_ghost(kk_op op, int64_t n_local_cols, int64_t n_ghost);
-int kk_op_ghost_ptr(kk_op op, int transpose, void** device_ptr);
+/* Row-sharded operators (one process per GPU): column indices >= n_local_cols address a
+ * caller-owned device buffer of n_ghost doubles that the caller fills before each apply
+ * (halo rows / all-gathered x); ncols of the operator must equal n_local_cols + n_ghost. */
+int kk_op_set_ghost(kk_op op, int64_t n_local_cols, int64_t n_ghost, void* device_ghost);
 /* y = A*x (transpose=0: apply / apply_normal, apply.jl:1,14) or A'*x (apply_adjoint, apply.jl:15) */
 int kk_spmv(kk_op op, int transpose, kk_basis bx, int cx, kk_basis by, int cy);
 /* affine form apply(op, x, a0, a1) = a0*x + a1*A*x (apply.jl:4-11) */
@@ -204,18 +204,27 @@ int kk_gkl_expand(kk_op op, kk_basis bu, kk_basis bv, int k, kk_orth_t orth, dou
 int kk_gkl_initialize(kk_op op, kk_basis bu, kk_basis bv, double* alpha, double* beta);
 
 /* ---------------------------------------------------------------- split-phase pieces for
- * row-sharded (multi-GPU) runs: partial coefficients stay on the device so the caller can
- * all-reduce them in place (RCCL on the same stream) between the two halves of a pass.
- * The scalar workspace is one contiguous device array of kk_ws_size() doubles. */
-int kk_ws_ptr(kk_ctx ctx, void** device_ptr, int64_t* count);
-/* ws[off+j] = sum over local rows of b[c0+j][row]*x[row]  (j<m) */
-int kk_project_dev(kk_basis b, int c0, int m, kk_basis bx, int cx, int64_t ws_off);
-/* y <- y - sum_j ws[off+j] b[c0+j];  ws[nrm_off .. +2] = local |y|^2, its sqrt, 1/sqrt (if nrm_off >= 0) */
-int kk_unproject_dev(kk_basis by, int cy, kk_basis b, int c0, int m, int64_t ws_off, int64_t nrm_off);
-int kk_dot_dev(kk_basis bx, int cx, kk_basis by, int cy, int64_t ws_off);          /* ws[off] = local <x,y> */
-int kk_axpy_dev(kk_basis by, int cy, kk_basis bx, int cx, int64_t ws_off, double sign); /* y += sign*ws[off]*x */
-int kk_ws_read(kk_ctx ctx, int64_t off, int64_t count, double* host);              /* sync */
-int kk_ws_write(kk_ctx ctx, int64_t off, int64_t count, const double* host);
+ * row-sharded (one process per GPU) runs.  Every inner-product-type result is a LOCAL partial
+ * written to a CALLER-OWNED device buffer (e.g. a torch tensor), so the caller can all-reduce
+ * it in place with RCCL on the same stream between the two halves of a pass.
+ * Nothing here synchronises the host. */
+/* w = A v - beta_old v_prev (col_prev < 0: no subtraction);
+ * dev_dot[0] = local <v, A v> (dot_mode 1, lanczos.jl:298) or local <v, w> (dot_mode 2, :308); 0: none */
+int kk_apply_fused_dev(kk_op op, kk_basis b, int col_v, int col_prev, int col_w, double beta_old, int dot_mode,
+                       void* dev_dot);
+/* dev_out[j] = local <b[c0+j], x>, j < m; with a second right-hand side (col_rhs2 >= 0, same
+ * basis as x) dev_out[m+j] = local <b[c0+j], rhs2>: the Gram row of the newest vector rides along. */
+int kk_project_dev(kk_basis b, int c0, int m, kk_basis bx, int cx, int col_rhs2, void* dev_out);
+/* y = beta*y + alpha*sum_j coef[j] b[c0+j] (coef on the host, passed in the kernarg segment);
+ * dev_nrm (optional, 3 doubles) = local |y|^2, its sqrt, 1/sqrt */
+int kk_unproject_dev(kk_basis by, int cy, kk_basis b, int c0, int m, const double* coef, double alpha, double beta,
+                     void* dev_nrm);
+int kk_dot_dev(kk_basis bx, int cx, kk_basis by, int cy, void* dev_out);      /* dev_out[0] = local <x,y> */
+int kk_nrm2_dev(kk_basis bx, int cx, void* dev_out3);                          /* local |x|^2, sqrt, 1/sqrt */
+/* y += sign * dev_a[0] * x   (device scalar, e.g. an all-reduced coefficient) */
+int kk_axpy_dev(kk_basis by, int cy, kk_basis bx, int cx, const void* dev_a, double sign);
+/* x *= 1/sqrt(dev_nrm2[0])   (normalise by an all-reduced squared norm, no host round trip) */
+int kk_scal_rsqrt_dev(kk_basis bx, int cx, const void* dev_nrm2);
 
 #ifdef __cplusplus
 }

@@ -25,6 +25,8 @@ int kk_hip_fail(hipError_t e, const char* what, const char* file, int line) {
 }
 
 static const double KK_EPS = std::numeric_limits<double>::epsilon();
+#define WSP(c, off) ((c)->ws + (off))
+#define SCP(c, slot) ((c)->ws + WS_SCAL + (slot))
 
 // ------------------------------------------------------------------------------------------
 // library / context
@@ -309,7 +311,7 @@ extern "C" int kk_vec_dot(kk_basis bx, int cx, kk_basis by, int cy, double* out)
     CHECK_COL(bx, cx); CHECK_COL(by, cy); CHECK_SAME(bx, by);
     KK_CHECK(out, KK_ERR_INVALID, "null out");
     kk_ctx c = bx->ctx;
-    KK_TRY(kk_launch_dot(c, bx->col(cx), by->col(cy), bx->ld, WS_SCAL + SC_DOT));
+    KK_TRY(kk_launch_dot(c, bx->col(cx), by->col(cy), bx->ld, SCP(c, SC_DOT)));
     KK_TRY(ws_fetch_async(c, WS_SCAL + SC_DOT, 1, 0));
     KK_TRY(stream_sync(c));
     *out = *pin(c, WS_SCAL + SC_DOT);
@@ -319,7 +321,7 @@ extern "C" int kk_vec_nrm2(kk_basis bx, int cx, double* out) {
     CHECK_COL(bx, cx);
     KK_CHECK(out, KK_ERR_INVALID, "null out");
     kk_ctx c = bx->ctx;
-    KK_TRY(kk_launch_nrm2(c, bx->col(cx), bx->ld, WS_SCAL + SC_NRM2));
+    KK_TRY(kk_launch_nrm2(c, bx->col(cx), bx->ld, SCP(c, SC_NRM2)));
     KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2, 2, 0));
     KK_TRY(stream_sync(c));
     *out = pin(c, WS_SCAL + SC_NRM2)[1];
@@ -358,7 +360,6 @@ extern "C" int kk_vec_fill_random(kk_basis bx, int cx, uint64_t seed) {
 static void free_sparse(kk_sparse_dev& M) {
     (void)hipFree(M.ell_col); (void)hipFree(M.ell_val);
     (void)hipFree(M.rowptr); (void)hipFree(M.colind); (void)hipFree(M.val);
-    (void)hipFree(M.ghost);
     M = kk_sparse_dev();
 }
 
@@ -514,22 +515,15 @@ extern "C" int kk_op_info(kk_op op, int64_t* nrows, int64_t* ncols, int64_t* nnz
     return KK_OK;
 }
 
-extern "C" int kk_op_set_ghost(kk_op op, int64_t n_local_cols, int64_t n_ghost) {
+extern "C" int kk_op_set_ghost(kk_op op, int64_t n_local_cols, int64_t n_ghost, void* device_ghost) {
     KK_CHECK(op, KK_ERR_INVALID, "null op");
     KK_CHECK(n_local_cols >= 0 && n_ghost >= 0 && n_local_cols + n_ghost == op->ncols, KK_ERR_DIM,
              "kk_op_set_ghost: n_local (%lld) + n_ghost (%lld) != ncols (%lld)", (long long)n_local_cols,
              (long long)n_ghost, (long long)op->ncols);
-    (void)hipFree(op->A.ghost);
-    op->A.ghost = nullptr;
+    KK_CHECK(n_ghost == 0 || device_ghost, KK_ERR_INVALID, "kk_op_set_ghost: null ghost buffer");
     op->A.n_local = n_local_cols;
     op->A.n_ghost = n_ghost;
-    if (n_ghost > 0) KK_HIP(hipMalloc(&op->A.ghost, n_ghost * sizeof(double)));
-    return KK_OK;
-}
-extern "C" int kk_op_ghost_ptr(kk_op op, int transpose, void** dptr) {
-    KK_CHECK(op && dptr, KK_ERR_INVALID, "null arg");
-    KK_CHECK(!transpose, KK_ERR_UNSUPPORTED, "ghost columns are only supported for the non-transposed apply");
-    *dptr = op->A.ghost;
+    op->A.ghost = (double*)device_ghost;  // caller-owned
     return KK_OK;
 }
 
@@ -599,7 +593,7 @@ extern "C" int kk_project(kk_basis b, int c0, int m, kk_basis bx, int cx, double
     KK_CHECK(y || m == 0, KK_ERR_INVALID, "null y");
     if (m == 0) return KK_OK;
     kk_ctx c = b->ctx;
-    KK_TRY(kk_launch_project(c, b->col(c0), b->ld, m, bx->col(cx), nullptr, nullptr, nullptr, WS_S, WS_G));
+    KK_TRY(kk_launch_project(c, b->col(c0), b->ld, m, bx->col(cx), nullptr, nullptr, nullptr, WSP(c, WS_S), WSP(c, WS_G)));
     KK_TRY(ws_fetch_async(c, WS_S, m, 0));
     KK_TRY(stream_sync(c));
     const double* s = pin(c, WS_S);
@@ -616,7 +610,7 @@ extern "C" int kk_unproject(kk_basis by, int cy, kk_basis b, int c0, int m, cons
     memset(&ch, 0, sizeof(ch));
     for (int j = 0; j < m; ++j) ch.v[j] = x[j];
     return kk_launch_unproject(b->ctx, b->col(c0), b->ld, m, by->col(cy), by->col(cy), &ch, nullptr, alpha, beta, -1,
-                               nullptr, -1);
+                               nullptr, nullptr);
 }
 
 extern "C" int kk_rank1update(kk_basis b, int c0, int m, kk_basis by, int cy, const double* x, double alpha, double beta) {
@@ -673,7 +667,7 @@ static int gram_ensure(kk_basis b, int upto /* exclusive */) {
     for (int i = b->gram_rows; i < upto; ++i) {
         for (int j0 = 0; j0 < i; j0 += KK_MAX_M) {
             const int mm = std::min(KK_MAX_M, i - j0);
-            KK_TRY(kk_launch_project(c, b->col(j0), b->ld, mm, b->col(i), nullptr, nullptr, nullptr, WS_G, WS_G));
+            KK_TRY(kk_launch_project(c, b->col(j0), b->ld, mm, b->col(i), nullptr, nullptr, nullptr, WSP(c, WS_G), WSP(c, WS_G)));
             KK_TRY(ws_fetch_async(c, WS_G, mm, 1));
             KK_TRY(stream_sync(c));
             memcpy(&b->gram[(size_t)i * b->cap + j0], pin(c, WS_G, 1), mm * sizeof(double));
@@ -695,10 +689,10 @@ static void gram_solve(kk_basis b, int c0, int m, double* p) {
 // ---- one orthogonalisation pass; coefficient results land in pinned slot `slot` ------------
 // CGS pass:  s = V'w ; w -= V s ; optional |w| (orthonormal.jl:378-384)
 static int pass_cgs(kk_ctx c, const double* V, int64_t ld, int m, double* w, bool want_norm, int slot) {
-    KK_TRY(kk_launch_project(c, V, ld, m, w, nullptr, nullptr, nullptr, WS_S, WS_G));
+    KK_TRY(kk_launch_project(c, V, ld, m, w, nullptr, nullptr, nullptr, WSP(c, WS_S), WSP(c, WS_G)));
     KK_TRY(ws_fetch_async(c, WS_S, m, slot));
     KK_TRY(kk_launch_unproject(c, V, ld, m, w, w, nullptr, c->ws + WS_S, -1.0, 1.0, -1, nullptr,
-                               want_norm ? WS_SCAL + SC_NRM2 : -1));
+                               want_norm ? SCP(c, SC_NRM2) : nullptr));
     if (want_norm) KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2, 2, slot));
     return KK_OK;
 }
@@ -710,31 +704,48 @@ static int pass_mgs_strict(kk_ctx c, const double* V, int64_t ld, int m, double*
     const double* sp = carry_s;
     for (int j = 0; j < m; ++j) {
         const double* q = V + (int64_t)j * ld;
-        KK_TRY(kk_launch_mgs_step(c, w, ld, qp, sp, q, ws_s + j, -1));
+        KK_TRY(kk_launch_mgs_step(c, w, ld, qp, sp, q, WSP(c, ws_s + j), nullptr));
         qp = q;
         sp = c->ws + ws_s + j;
     }
     if (!leave_carry) {
-        KK_TRY(kk_launch_mgs_step(c, w, ld, qp, sp, nullptr, -1, want_norm ? WS_SCAL + SC_NRM2 : -1));
+        KK_TRY(kk_launch_mgs_step(c, w, ld, qp, sp, nullptr, nullptr, want_norm ? SCP(c, SC_NRM2) : nullptr));
         if (want_norm) KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2, 2, slot));
     }
     KK_TRY(ws_fetch_async(c, ws_s, m, slot));
     return KK_OK;
 }
+// Projection for the low-sync MGS: p = V'(w - a*pre) into pinned slot `slot` (synchronised on
+// return).  The Gram row of the newest basis vector (column c0+m-1) rides along as a second
+// right-hand side of the same kernel when it is the only row missing -- no extra pass over V.
+static int lowsync_project(kk_basis b, int c0, int m, const double* w, const double* pre_vec, const double* pre_a,
+                           int slot) {
+    kk_ctx c = b->ctx;
+    KK_TRY(gram_ensure(b, c0 + m - 1));
+    const int newest = c0 + m - 1;
+    const bool ride = (b->gram_rows == newest && newest > 0 && c0 == 0);
+    if (!ride) KK_TRY(gram_ensure(b, c0 + m));
+    KK_TRY(kk_launch_project(c, b->col(c0), b->ld, m, w, pre_vec, pre_a, ride ? b->col(newest) : nullptr, WSP(c, WS_S), WSP(c, WS_G)));
+    KK_TRY(ws_fetch_async(c, WS_S, m, slot));
+    if (ride) KK_TRY(ws_fetch_async(c, WS_G, m, slot));
+    KK_TRY(stream_sync(c));
+    if (ride) {
+        memcpy(&b->gram[(size_t)newest * b->cap], pin(c, WS_G, slot), (m - 1) * sizeof(double));
+        b->gram_rows = newest + 1;
+    }
+    return KK_OK;
+}
 // low-sync MGS sweep: p = V'w (one pass), s = (I+L)^-1 p on the host, w -= V s.
 static int pass_mgs_lowsync(kk_basis b, int c0, int m, double* w, double* s_out, bool want_norm, int slot) {
     kk_ctx c = b->ctx;
-    KK_TRY(gram_ensure(b, c0 + m));
-    KK_TRY(kk_launch_project(c, b->col(c0), b->ld, m, w, nullptr, nullptr, nullptr, WS_S, WS_G));
-    KK_TRY(ws_fetch_async(c, WS_S, m, slot));
-    KK_TRY(stream_sync(c));
+    KK_TRY(lowsync_project(b, c0, m, w, nullptr, nullptr, slot));
     kk_coef ch;
     memset(&ch, 0, sizeof(ch));
     memcpy(ch.v, pin(c, WS_S, slot), m * sizeof(double));
     gram_solve(b, c0, m, ch.v);
     memcpy(s_out, ch.v, m * sizeof(double));
     KK_TRY(kk_launch_unproject(c, b->col(c0), b->ld, m, w, w, &ch, nullptr, -1.0, 1.0, -1, nullptr,
-                               want_norm ? WS_SCAL + SC_NRM2 : -1));
+                               want_norm ? SCP(c, SC_NRM2) : nullptr));
     if (want_norm) KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2, 2, slot));
     return KK_OK;
 }
@@ -750,7 +761,7 @@ static int orth_run(kk_basis b, int c0, int m, double* w, kk_orth_t alg, double 
     double nn = 0;
     if (m == 0) {
         if (want_norm || alg == KK_CGSIR || alg == KK_MGSIR) {
-            KK_TRY(kk_launch_nrm2(c, w, ld, WS_SCAL + SC_NRM2));
+            KK_TRY(kk_launch_nrm2(c, w, ld, SCP(c, SC_NRM2)));
             KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2, 2, 0));
             KK_TRY(stream_sync(c));
             nn = pin(c, WS_SCAL + SC_NRM2)[1];
@@ -759,7 +770,7 @@ static int orth_run(kk_basis b, int c0, int m, double* w, kk_orth_t alg, double 
         if (npasses) *npasses = 0;
         return KK_OK;
     }
-    const bool lowsync = c->mgs_mode == 1;
+    const bool lowsync = c->mgs_mode == 1 && c0 == 0;
     std::vector<double> tmp(m);
     switch (alg) {
         case KK_CGS: {
@@ -778,7 +789,7 @@ static int orth_run(kk_basis b, int c0, int m, double* w, kk_orth_t alg, double 
             passes = 2;
         } break;
         case KK_CGSIR: {  // :400-412
-            KK_TRY(kk_launch_nrm2(c, w, ld, WS_SCAL + SC_NRM2B));
+            KK_TRY(kk_launch_nrm2(c, w, ld, SCP(c, SC_NRM2B)));
             KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2B, 2, 1));
             KK_TRY(pass_cgs(c, V, ld, m, w, true, 0));
             KK_TRY(stream_sync(c));
@@ -825,7 +836,7 @@ static int orth_run(kk_basis b, int c0, int m, double* w, kk_orth_t alg, double 
             passes = 2;
         } break;
         case KK_MGSIR: {  // :440-452
-            KK_TRY(kk_launch_nrm2(c, w, ld, WS_SCAL + SC_NRM2B));
+            KK_TRY(kk_launch_nrm2(c, w, ld, SCP(c, SC_NRM2B)));
             KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2B, 2, 1));
             if (lowsync) KK_TRY(pass_mgs_lowsync(b, c0, m, w, x, true, 0));
             else KK_TRY(pass_mgs_strict(c, V, ld, m, w, WS_S, true, 0, nullptr, nullptr, false));
@@ -879,27 +890,27 @@ static int orth_vec_run(kk_ctx c, const double* q, double* w, int64_t ld, kk_ort
                         double* nrm, bool want_norm) {
     double s = 0, nn = 0;
     if (alg == KK_CGS || alg == KK_MGS) {
-        KK_TRY(kk_launch_mgs_step(c, w, ld, nullptr, nullptr, q, WS_S, -1));
-        KK_TRY(kk_launch_mgs_step(c, w, ld, q, c->ws + WS_S, nullptr, -1, want_norm ? WS_SCAL + SC_NRM2 : -1));
+        KK_TRY(kk_launch_mgs_step(c, w, ld, nullptr, nullptr, q, WSP(c, WS_S), nullptr));
+        KK_TRY(kk_launch_mgs_step(c, w, ld, q, c->ws + WS_S, nullptr, nullptr, want_norm ? SCP(c, SC_NRM2) : nullptr));
         KK_TRY(ws_fetch_async(c, WS_S, 1, 0));
         if (want_norm) KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2, 2, 0));
         KK_TRY(stream_sync(c));
         s = pin(c, WS_S)[0];
         nn = pin(c, WS_SCAL + SC_NRM2)[1];
     } else if (alg == KK_CGS2 || alg == KK_MGS2) {
-        KK_TRY(kk_launch_mgs_step(c, w, ld, nullptr, nullptr, q, WS_S, -1));
-        KK_TRY(kk_launch_mgs_step(c, w, ld, q, c->ws + WS_S, q, WS_S + 1, -1));
-        KK_TRY(kk_launch_mgs_step(c, w, ld, q, c->ws + WS_S + 1, nullptr, -1, want_norm ? WS_SCAL + SC_NRM2 : -1));
+        KK_TRY(kk_launch_mgs_step(c, w, ld, nullptr, nullptr, q, WSP(c, WS_S), nullptr));
+        KK_TRY(kk_launch_mgs_step(c, w, ld, q, c->ws + WS_S, q, WSP(c, WS_S + 1), nullptr));
+        KK_TRY(kk_launch_mgs_step(c, w, ld, q, c->ws + WS_S + 1, nullptr, nullptr, want_norm ? SCP(c, SC_NRM2) : nullptr));
         KK_TRY(ws_fetch_async(c, WS_S, 2, 0));
         if (want_norm) KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2, 2, 0));
         KK_TRY(stream_sync(c));
         s = pin(c, WS_S)[0] + pin(c, WS_S)[1];
         nn = pin(c, WS_SCAL + SC_NRM2)[1];
     } else {
-        KK_TRY(kk_launch_nrm2(c, w, ld, WS_SCAL + SC_NRM2B));
+        KK_TRY(kk_launch_nrm2(c, w, ld, SCP(c, SC_NRM2B)));
         KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2B, 2, 1));
-        KK_TRY(kk_launch_mgs_step(c, w, ld, nullptr, nullptr, q, WS_S, -1));
-        KK_TRY(kk_launch_mgs_step(c, w, ld, q, c->ws + WS_S, nullptr, -1, WS_SCAL + SC_NRM2));
+        KK_TRY(kk_launch_mgs_step(c, w, ld, nullptr, nullptr, q, WSP(c, WS_S), nullptr));
+        KK_TRY(kk_launch_mgs_step(c, w, ld, q, c->ws + WS_S, nullptr, nullptr, SCP(c, SC_NRM2)));
         KK_TRY(ws_fetch_async(c, WS_S, 1, 0));
         KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2, 2, 0));
         KK_TRY(stream_sync(c));
@@ -908,8 +919,8 @@ static int orth_vec_run(kk_ctx c, const double* q, double* w, int64_t ld, kk_ort
         nn = pin(c, WS_SCAL + SC_NRM2)[1];
         while (KK_EPS < nn && nn < eta * nold) {
             nold = nn;
-            KK_TRY(kk_launch_mgs_step(c, w, ld, nullptr, nullptr, q, WS_S, -1));
-            KK_TRY(kk_launch_mgs_step(c, w, ld, q, c->ws + WS_S, nullptr, -1, WS_SCAL + SC_NRM2));
+            KK_TRY(kk_launch_mgs_step(c, w, ld, nullptr, nullptr, q, WSP(c, WS_S), nullptr));
+            KK_TRY(kk_launch_mgs_step(c, w, ld, q, c->ws + WS_S, nullptr, nullptr, SCP(c, SC_NRM2)));
             KK_TRY(ws_fetch_async(c, WS_S, 1, 0));
             KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2, 2, 0));
             KK_TRY(stream_sync(c));
@@ -952,9 +963,9 @@ static int krylov_initialize(kk_op op, kk_basis b, int c0, kk_orth_t orth, doubl
     double* r = b->col(c0 + 1);
     gram_touch(b, c0);
     // beta0 = norm(x0); Ax0 = A x0 with fused <x0, Ax0>
-    KK_TRY(kk_launch_nrm2(c, x0, b->ld, WS_SCAL + SC_NRM2));
+    KK_TRY(kk_launch_nrm2(c, x0, b->ld, SCP(c, SC_NRM2)));
     kk_spmv_fuse f;
-    f.dot_mode = 1; f.dot_slot = SC_ALPHA0;
+    f.dot_mode = 1; f.dot_out = SCP(c, SC_ALPHA0);
     KK_TRY(kk_launch_spmv(c, op->A, x0, r, b->ld, f));
     KK_TRY(ws_fetch_async(c, WS_SCAL, 16, 0));
     KK_TRY(stream_sync(c));
@@ -969,19 +980,19 @@ static int krylov_initialize(kk_op op, kk_basis b, int c0, kk_orth_t orth, doubl
     const bool ir = (orth == KK_CGSIR || orth == KK_MGSIR);
     double beta_old = 0;
     if (ir) {
-        KK_TRY(kk_launch_nrm2(c, r, b->ld, WS_SCAL + SC_NRM2B));  // beta_old = norm(r) :196
+        KK_TRY(kk_launch_nrm2(c, r, b->ld, SCP(c, SC_NRM2B)));  // beta_old = norm(r) :196
         KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2B, 2, 1));
     }
     // r -= alpha v ; beta = norm(r)
     KK_TRY(kk_launch_axpby(c, r, x0, b->ld, -a, 1.0, nullptr, 1.0, 0));
-    KK_TRY(kk_launch_nrm2(c, r, b->ld, WS_SCAL + SC_NRM2));
+    KK_TRY(kk_launch_nrm2(c, r, b->ld, SCP(c, SC_NRM2)));
     KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2, 2, 0));
     KK_TRY(stream_sync(c));
     double bt = pin(c, WS_SCAL + SC_NRM2)[1];
     if (ir) beta_old = pin(c, WS_SCAL + SC_NRM2B, 1)[1];
     auto correct = [&]() -> int {  // dalpha = <v,r>; alpha += dalpha; r -= dalpha v; beta = |r|   :201-204
-        KK_TRY(kk_launch_mgs_step(c, r, b->ld, nullptr, nullptr, x0, WS_S, -1));
-        KK_TRY(kk_launch_mgs_step(c, r, b->ld, x0, c->ws + WS_S, nullptr, -1, WS_SCAL + SC_NRM2));
+        KK_TRY(kk_launch_mgs_step(c, r, b->ld, nullptr, nullptr, x0, WSP(c, WS_S), nullptr));
+        KK_TRY(kk_launch_mgs_step(c, r, b->ld, x0, c->ws + WS_S, nullptr, nullptr, SCP(c, SC_NRM2)));
         KK_TRY(ws_fetch_async(c, WS_S, 1, 0));
         KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2, 2, 0));
         KK_TRY(stream_sync(c));
@@ -1034,14 +1045,14 @@ extern "C" int kk_lanczos_expand(kk_op op, kk_basis b, int c0, int k, kk_orth_t 
     f.vprev = vprev; f.bprev = beta_old;
     const bool cgs_order = (orth == KK_CGS || orth == KK_CGS2 || orth == KK_CGSIR);
     f.dot_mode = cgs_order ? 1 : 2;
-    f.dot_slot = SC_ALPHA0;
+    f.dot_out = SCP(c, SC_ALPHA0);
     KK_TRY(kk_launch_spmv(c, op->A, v, w, ld, f));
     const double* a0_dev = c->ws + WS_SCAL + SC_ALPHA0;
     double a = 0, bt = 0;
     const bool lowsync = c->mgs_mode == 1;
     if (orth == KK_CGS || orth == KK_MGS || orth == KK_CGSIR || orth == KK_MGSIR) {
         // w -= alpha v ; beta = |w|
-        KK_TRY(kk_launch_mgs_step(c, w, ld, v, a0_dev, nullptr, -1, WS_SCAL + SC_NRM2));
+        KK_TRY(kk_launch_mgs_step(c, w, ld, v, a0_dev, nullptr, nullptr, SCP(c, SC_NRM2)));
         KK_TRY(ws_fetch_async(c, WS_SCAL, 4, 0));
         KK_TRY(stream_sync(c));
         a = pin(c, WS_SCAL + SC_ALPHA0)[0];
@@ -1060,22 +1071,20 @@ extern "C" int kk_lanczos_expand(kk_op op, kk_basis b, int c0, int k, kk_orth_t 
                 ++passes;
             }
         }
-    } else if (orth == KK_CGS2 || (orth == KK_MGS2 && lowsync)) {
+    } else if (orth == KK_CGS2 || (orth == KK_MGS2 && lowsync && c0 == 0)) {
         // one projection pass with "w -= alpha0 v" folded in (read V twice in total):
         //   s = V'(w - alpha0 v) ; w <- w - V (s + alpha0 e_m) ; beta = |w|     lanczos.jl:318-322 / 329-336
-        if (orth == KK_MGS2) KK_TRY(gram_ensure(b, c0 + m));
-        KK_TRY(kk_launch_project(c, V, ld, m, w, v, a0_dev, nullptr, WS_S, WS_G));
         if (orth == KK_CGS2) {
+            KK_TRY(kk_launch_project(c, V, ld, m, w, v, a0_dev, nullptr, WSP(c, WS_S), WSP(c, WS_G)));
             KK_TRY(kk_launch_unproject(c, V, ld, m, w, w, nullptr, c->ws + WS_S, -1.0, 1.0, m - 1, a0_dev,
-                                       WS_SCAL + SC_NRM2));
+                                       SCP(c, SC_NRM2)));
             KK_TRY(ws_fetch_async(c, WS_S, m, 0));
             KK_TRY(ws_fetch_async(c, WS_SCAL, 4, 0));
             KK_TRY(stream_sync(c));
             a = pin(c, WS_SCAL + SC_ALPHA0)[0] + pin(c, WS_S)[m - 1];
         } else {
-            KK_TRY(ws_fetch_async(c, WS_S, m, 0));
             KK_TRY(ws_fetch_async(c, WS_SCAL, 1, 0));
-            KK_TRY(stream_sync(c));
+            KK_TRY(lowsync_project(b, c0, m, w, v, a0_dev, 0));
             kk_coef ch;
             memset(&ch, 0, sizeof(ch));
             memcpy(ch.v, pin(c, WS_S), m * sizeof(double));
@@ -1083,7 +1092,7 @@ extern "C" int kk_lanczos_expand(kk_op op, kk_basis b, int c0, int k, kk_orth_t 
             const double a0 = pin(c, WS_SCAL + SC_ALPHA0)[0];
             a = a0 + ch.v[m - 1];
             ch.v[m - 1] += a0;
-            KK_TRY(kk_launch_unproject(c, V, ld, m, w, w, &ch, nullptr, -1.0, 1.0, -1, nullptr, WS_SCAL + SC_NRM2));
+            KK_TRY(kk_launch_unproject(c, V, ld, m, w, w, &ch, nullptr, -1.0, 1.0, -1, nullptr, SCP(c, SC_NRM2)));
             KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2, 2, 0));
             KK_TRY(stream_sync(c));
         }
@@ -1148,13 +1157,13 @@ extern "C" int kk_gkl_initialize(kk_op op, kk_basis bu, kk_basis bv, double* alp
     double* r = bu->col(1);
     gram_touch(bu, 0); gram_touch(bv, 0);
     // beta0 = |u0| ; v0 = A' u0 (with |v0|^2) ; Av0 = A v0 (with <u0, A v0> computed separately)
-    KK_TRY(kk_launch_nrm2(c, u0, bu->ld, WS_SCAL + SC_NRM2B));
+    KK_TRY(kk_launch_nrm2(c, u0, bu->ld, SCP(c, SC_NRM2B)));
     kk_spmv_fuse f1;
-    f1.nrm_slot = SC_NRM2;
+    f1.nrm_out = SCP(c, SC_NRM2);
     KK_TRY(kk_launch_spmv(c, *At, u0, v0, bv->ld, f1));
     kk_spmv_fuse f2;
     KK_TRY(kk_launch_spmv(c, op->A, v0, r, bu->ld, f2));
-    KK_TRY(kk_launch_dot(c, u0, r, bu->ld, WS_SCAL + SC_DOT));
+    KK_TRY(kk_launch_dot(c, u0, r, bu->ld, SCP(c, SC_DOT)));
     KK_TRY(ws_fetch_async(c, WS_SCAL, 16, 0));
     KK_TRY(stream_sync(c));
     const double beta0 = pin(c, WS_SCAL + SC_NRMB)[0];
@@ -1172,7 +1181,7 @@ extern "C" int kk_gkl_initialize(kk_op op, kk_basis bu, kk_basis bv, double* alp
     KK_TRY(kk_launch_scal(c, v0, bv->ld, 1.0 / (a * beta0), nullptr));    // v = v0/(alpha beta0)
     // r = Av0/(alpha beta0) - alpha u
     KK_TRY(kk_launch_axpby(c, r, u0, bu->ld, -a, 1.0 / (a * beta0), nullptr, 1.0, 0));
-    KK_TRY(kk_launch_nrm2(c, r, bu->ld, WS_SCAL + SC_NRM2));
+    KK_TRY(kk_launch_nrm2(c, r, bu->ld, SCP(c, SC_NRM2)));
     KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2, 2, 0));
     KK_TRY(stream_sync(c));
     *alpha = a;
@@ -1204,7 +1213,7 @@ extern "C" int kk_gkl_expand(kk_op op, kk_basis bu, kk_basis bv, int k, kk_orth_
     kk_spmv_fuse f1;
     f1.vprev = vlast; f1.bprev = beta_old;
     const bool v_sweep = (orth == KK_MGS2 || orth == KK_CGSIR || orth == KK_MGSIR);
-    f1.nrm_slot = SC_NRM2;
+    f1.nrm_out = SCP(c, SC_NRM2);
     KK_TRY(kk_launch_spmv(c, *At, u, v, bv->ld, f1));
     if (orth == KK_MGS2) {  // gkl.jl:330-336
         double nn = 0;
@@ -1240,7 +1249,7 @@ extern "C" int kk_gkl_expand(kk_op op, kk_basis bu, kk_basis bv, int k, kk_orth_
     // r = A v - alpha u (fused), beta = |r| fused when no sweep follows
     kk_spmv_fuse f2;
     f2.vprev = u; f2.bprev_dev = alpha_dev;
-    f2.nrm_slot = SC_NRM2B;
+    f2.nrm_out = SCP(c, SC_NRM2B);
     KK_TRY(kk_launch_spmv(c, op->A, v, r, bu->ld, f2));
     if (orth == KK_CGS || orth == KK_MGS) {
         KK_TRY(ws_fetch_async(c, WS_SCAL, 16, 0));
@@ -1276,48 +1285,61 @@ extern "C" int kk_gkl_expand(kk_op op, kk_basis bu, kk_basis bv, int k, kk_orth_
 }
 
 // ------------------------------------------------------------------------------------------
-// split-phase API (row-sharded multi-GPU runs)
+// split-phase API (row-sharded multi-GPU runs): local partials into caller-owned device buffers
 // ------------------------------------------------------------------------------------------
-extern "C" int kk_ws_ptr(kk_ctx c, void** dptr, int64_t* count) {
-    KK_CHECK(c, KK_ERR_INVALID, "null ctx");
-    if (dptr) *dptr = c->ws + WS_USER;
-    if (count) *count = KK_WS_USER;
-    return KK_OK;
+extern "C" int kk_apply_fused_dev(kk_op op, kk_basis b, int col_v, int col_prev, int col_w, double beta_old,
+                                  int dot_mode, void* dev_dot) {
+    KK_TRY(check_square_op(op, b));
+    CHECK_COL(b, col_v); CHECK_COL(b, col_w);
+    KK_CHECK(col_prev < b->cap && col_v != col_w, KK_ERR_INVALID, "kk_apply_fused_dev: bad columns");
+    KK_CHECK(dot_mode == 0 || dev_dot, KK_ERR_INVALID, "kk_apply_fused_dev: dot requested without output buffer");
+    gram_touch(b, col_w);
+    kk_spmv_fuse f;
+    if (col_prev >= 0) { f.vprev = b->col(col_prev); f.bprev = beta_old; }
+    f.dot_mode = dot_mode;
+    f.dot_out = (double*)dev_dot;
+    return kk_launch_spmv(op->ctx, op->A, b->col(col_v), b->col(col_w), b->ld, f);
 }
-#define CHECK_WS(off, cnt) KK_CHECK((off) >= 0 && (off) + (cnt) <= KK_WS_USER, KK_ERR_INVALID, "%s: workspace range [%lld,%lld) out of bounds", __func__, (long long)(off), (long long)((off) + (cnt)))
-
-extern "C" int kk_project_dev(kk_basis b, int c0, int m, kk_basis bx, int cx, int64_t ws_off) {
-    CHECK_RANGE(b, c0, m); CHECK_COL(bx, cx); CHECK_SAME(b, bx); CHECK_WS(ws_off, m);
+extern "C" int kk_project_dev(kk_basis b, int c0, int m, kk_basis bx, int cx, int col_rhs2, void* dev_out) {
+    CHECK_RANGE(b, c0, m); CHECK_COL(bx, cx); CHECK_SAME(b, bx);
+    KK_CHECK(dev_out || m == 0, KK_ERR_INVALID, "null output");
+    KK_CHECK(col_rhs2 < bx->cap, KK_ERR_INVALID, "kk_project_dev: rhs2 column out of range");
     if (m == 0) return KK_OK;
-    return kk_launch_project(b->ctx, b->col(c0), b->ld, m, bx->col(cx), nullptr, nullptr, nullptr, WS_USER + ws_off, WS_G);
+    double* o = (double*)dev_out;
+    return kk_launch_project(b->ctx, b->col(c0), b->ld, m, bx->col(cx), nullptr, nullptr,
+                             col_rhs2 >= 0 ? bx->col(col_rhs2) : nullptr, o, o + m);
 }
-extern "C" int kk_unproject_dev(kk_basis by, int cy, kk_basis b, int c0, int m, int64_t ws_off, int64_t nrm_off) {
-    CHECK_RANGE(b, c0, m); CHECK_COL(by, cy); CHECK_SAME(b, by); CHECK_WS(ws_off, m);
-    if (nrm_off >= 0) CHECK_WS(nrm_off, 3);
+extern "C" int kk_unproject_dev(kk_basis by, int cy, kk_basis b, int c0, int m, const double* coef, double alpha,
+                                double beta, void* dev_nrm) {
+    CHECK_RANGE(b, c0, m); CHECK_COL(by, cy); CHECK_SAME(b, by);
+    KK_CHECK(coef || m == 0, KK_ERR_INVALID, "null coef");
     KK_CHECK(!(by == b && cy >= c0 && cy < c0 + m), KK_ERR_INVALID, "kk_unproject_dev: y aliases a basis column");
     gram_touch(by, cy);
-    return kk_launch_unproject(b->ctx, b->col(c0), b->ld, m, by->col(cy), by->col(cy), nullptr,
-                               b->ctx->ws + WS_USER + ws_off, -1.0, 1.0, -1, nullptr,
-                               nrm_off >= 0 ? WS_USER + nrm_off : -1);
+    kk_coef ch;
+    memset(&ch, 0, sizeof(ch));
+    for (int j = 0; j < m; ++j) ch.v[j] = coef[j];
+    return kk_launch_unproject(b->ctx, b->col(c0), b->ld, m, by->col(cy), by->col(cy), &ch, nullptr, alpha, beta, -1,
+                               nullptr, (double*)dev_nrm);
 }
-extern "C" int kk_dot_dev(kk_basis bx, int cx, kk_basis by, int cy, int64_t ws_off) {
-    CHECK_COL(bx, cx); CHECK_COL(by, cy); CHECK_SAME(bx, by); CHECK_WS(ws_off, 1);
-    return kk_launch_dot(bx->ctx, bx->col(cx), by->col(cy), bx->ld, (int)(WS_USER + ws_off));
+extern "C" int kk_dot_dev(kk_basis bx, int cx, kk_basis by, int cy, void* dev_out) {
+    CHECK_COL(bx, cx); CHECK_COL(by, cy); CHECK_SAME(bx, by);
+    KK_CHECK(dev_out, KK_ERR_INVALID, "null output");
+    return kk_launch_dot(bx->ctx, bx->col(cx), by->col(cy), bx->ld, (double*)dev_out);
 }
-extern "C" int kk_axpy_dev(kk_basis by, int cy, kk_basis bx, int cx, int64_t ws_off, double sign) {
-    CHECK_COL(bx, cx); CHECK_COL(by, cy); CHECK_SAME(bx, by); CHECK_WS(ws_off, 1);
+extern "C" int kk_nrm2_dev(kk_basis bx, int cx, void* dev_out3) {
+    CHECK_COL(bx, cx);
+    KK_CHECK(dev_out3, KK_ERR_INVALID, "null output");
+    return kk_launch_nrm2(bx->ctx, bx->col(cx), bx->ld, (double*)dev_out3);
+}
+extern "C" int kk_axpy_dev(kk_basis by, int cy, kk_basis bx, int cx, const void* dev_a, double sign) {
+    CHECK_COL(bx, cx); CHECK_COL(by, cy); CHECK_SAME(bx, by);
+    KK_CHECK(dev_a, KK_ERR_INVALID, "null scalar");
     gram_touch(by, cy);
-    return kk_launch_axpby(by->ctx, by->col(cy), bx->col(cx), by->ld, 0.0, 1.0, by->ctx->ws + WS_USER + ws_off, sign, 1);
+    return kk_launch_axpby(by->ctx, by->col(cy), bx->col(cx), by->ld, 0.0, 1.0, (const double*)dev_a, sign, 1);
 }
-extern "C" int kk_ws_read(kk_ctx c, int64_t off, int64_t count, double* host) {
-    KK_CHECK(c && host, KK_ERR_INVALID, "null arg");
-    CHECK_WS(off, count);
-    KK_HIP(hipMemcpyAsync(host, c->ws + WS_USER + off, count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    return stream_sync(c);
-}
-extern "C" int kk_ws_write(kk_ctx c, int64_t off, int64_t count, const double* host) {
-    KK_CHECK(c && host, KK_ERR_INVALID, "null arg");
-    CHECK_WS(off, count);
-    KK_HIP(hipMemcpyAsync(c->ws + WS_USER + off, host, count * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    return stream_sync(c);
+extern "C" int kk_scal_rsqrt_dev(kk_basis bx, int cx, const void* dev_nrm2) {
+    CHECK_COL(bx, cx);
+    KK_CHECK(dev_nrm2, KK_ERR_INVALID, "null scalar");
+    gram_touch(bx, cx);
+    return kk_launch_scal(bx->ctx, bx->col(cx), bx->ld, 0.0, (const double*)dev_nrm2, 1);
 }

@@ -152,31 +152,31 @@ struct kk_spmv_fuse {
     const double* bprev_dev = nullptr;   // if set: weight = *bprev_dev (device scalar)
     int dot_mode = 0;                // 0 none, 1 = <x, A x> before subtracting vprev (CGS order,
                                      // lanczos.jl:298), 2 = <x, y> after (MGS order, lanczos.jl:308)
-    int dot_slot = SC_ALPHA0;        // ws scalar receiving the dot
-    int nrm_slot = -1;               // ws scalar receiving |y|^2 (and sqrt at slot+1, 1/sqrt at +... see finalize)
+    double* dot_out = nullptr;       // device scalar receiving the dot (required when dot_mode != 0)
+    double* nrm_out = nullptr;       // optional: device triple receiving |y|^2, sqrt, 1/sqrt
 };
 
 int kk_launch_spmv(kk_ctx ctx, const kk_sparse_dev& M, const double* x, double* y, int64_t ld_y_rows,
                    const kk_spmv_fuse& f);
-int kk_launch_dot(kk_ctx ctx, const double* x, const double* y, int64_t ld, int slot_ws_off);
-int kk_launch_nrm2(kk_ctx ctx, const double* x, int64_t ld, int slot_ws_off);  // writes nrm2, sqrt at +1, 1/sqrt at +3
+int kk_launch_dot(kk_ctx ctx, const double* x, const double* y, int64_t ld, double* out);
+int kk_launch_nrm2(kk_ctx ctx, const double* x, int64_t ld, double* out3);  // out3 = {|x|^2, |x|, 1/|x|}
 int kk_launch_axpby(kk_ctx ctx, double* y, const double* x, int64_t ld, double a, double b,
                     const double* a_dev, double a_dev_sign, int a_dev_mode);
-int kk_launch_scal(kk_ctx ctx, double* x, int64_t ld, double a, const double* a_dev);
+int kk_launch_scal(kk_ctx ctx, double* x, int64_t ld, double a, const double* a_dev, int rsqrt_mode = 0);
 int kk_launch_copy_scal(kk_ctx ctx, double* y, const double* x, int64_t ld, double a);
 int kk_launch_fill_random(kk_ctx ctx, double* x, int64_t n, uint64_t seed);
 int kk_launch_gather(kk_ctx ctx, const double* x, const int64_t* idx, int64_t count, double* out);
 // s = V' * (w - pre_a * pre_vec);  optional second rhs g = V' * rhs2
 int kk_launch_project(kk_ctx ctx, const double* V, int64_t ld, int m, const double* w,
                       const double* pre_vec, const double* pre_a_dev, const double* rhs2,
-                      int64_t ws_s_off, int64_t ws_g_off);
+                      double* out_s, double* out_g);
 // w_out = beta*w_in + alpha * sum_j coef[j] V_j ; coef from kernarg (coef_host) or device (coef_dev)
 // extra: coefficient add_idx gets += *add_dev ; optional |w_out|^2 -> ws[nrm_off] (+sqrt, 1/sqrt)
 int kk_launch_unproject(kk_ctx ctx, const double* V, int64_t ld, int m, const double* w_in, double* w_out,
                         const kk_coef* coef_host, const double* coef_dev, double alpha, double beta,
-                        int add_idx, const double* add_dev, int64_t nrm_off);
+                        int add_idx, const double* add_dev, double* nrm_out3);
 int kk_launch_mgs_step(kk_ctx ctx, double* w, int64_t ld, const double* q_prev, const double* s_prev_dev,
-                       const double* q_next, int64_t ws_dot_off, int64_t ws_nrm_off);
+                       const double* q_next, double* dot_out, double* nrm_out3);
 int kk_launch_basistransform(kk_ctx ctx, double* V, int64_t ld, int m, int n, const double* U_dev);
 int kk_launch_givens(kk_ctx ctx, double* q1, double* q2, int64_t ld, double c, double s);
 int kk_launch_householder(kk_ctx ctx, double* V, int64_t ld, int m, const kk_coef* v, double beta);

@@ -117,8 +117,8 @@ __global__ __launch_bounds__(KK_TPB) void k_axpby(double* __restrict__ y, const 
 }
 
 __global__ __launch_bounds__(KK_TPB) void k_scal(double* __restrict__ x, int64_t ld, int64_t rpb, double a,
-                                                 const double* __restrict__ a_dev) {
-    if (a_dev) a = *a_dev;
+                                                 const double* __restrict__ a_dev, int rsqrt_mode) {
+    if (a_dev) a = rsqrt_mode ? 1.0 / sqrt(*a_dev) : *a_dev;
     const int64_t r0 = (int64_t)blockIdx.x * rpb, r1 = imin(r0 + rpb, ld);
     for (int64_t r = r0 + threadIdx.x * 2; r < r1; r += KK_SUB) {
         d2 v = ld2(x + r);
@@ -625,31 +625,31 @@ static inline double* part_row(kk_ctx ctx, int row) { return ctx->partials + (in
 #define PART_SCAL_A (2 * KK_MAX_M)      // partial rows used by scalar reductions
 #define PART_SCAL_B (2 * KK_MAX_M + 1)
 
-static int finalize_scalar(kk_ctx ctx, int part_row_idx, int n, int64_t ws_off, bool with_sqrt) {
+static int finalize_scalar(kk_ctx ctx, int part_row_idx, int n, double* out, bool with_sqrt) {
     hipLaunchKernelGGL(k_finalize_scalar, dim3(1), dim3(KK_TPB), 0, ctx->stream, part_row(ctx, part_row_idx), n,
-                       ctx->ws + ws_off, with_sqrt ? 1 : 0);
+                       out, with_sqrt ? 1 : 0);
     KK_HIP(hipGetLastError());
     return KK_OK;
 }
 
-int kk_launch_dot(kk_ctx ctx, const double* x, const double* y, int64_t ld, int slot_ws_off) {
+int kk_launch_dot(kk_ctx ctx, const double* x, const double* y, int64_t ld, double* out) {
     kk_part p = kk_partition(ctx, ld);
     {
         kk_prof_scope ps(ctx, "k_dot");
         hipLaunchKernelGGL(k_dot, dim3(p.nblk), dim3(KK_TPB), 0, ctx->stream, x, y, ld, p.rpb, part_row(ctx, PART_SCAL_A));
     }
     KK_HIP(hipGetLastError());
-    return finalize_scalar(ctx, PART_SCAL_A, p.nblk, slot_ws_off, false);
+    return finalize_scalar(ctx, PART_SCAL_A, p.nblk, out, false);
 }
 
-int kk_launch_nrm2(kk_ctx ctx, const double* x, int64_t ld, int slot_ws_off) {
+int kk_launch_nrm2(kk_ctx ctx, const double* x, int64_t ld, double* out3) {
     kk_part p = kk_partition(ctx, ld);
     {
         kk_prof_scope ps(ctx, "k_dot");
         hipLaunchKernelGGL(k_dot, dim3(p.nblk), dim3(KK_TPB), 0, ctx->stream, x, x, ld, p.rpb, part_row(ctx, PART_SCAL_A));
     }
     KK_HIP(hipGetLastError());
-    return finalize_scalar(ctx, PART_SCAL_A, p.nblk, slot_ws_off, true);
+    return finalize_scalar(ctx, PART_SCAL_A, p.nblk, out3, true);
 }
 
 int kk_launch_axpby(kk_ctx ctx, double* y, const double* x, int64_t ld, double a, double b, const double* a_dev,
@@ -666,10 +666,10 @@ int kk_launch_axpby(kk_ctx ctx, double* y, const double* x, int64_t ld, double a
     return KK_OK;
 }
 
-int kk_launch_scal(kk_ctx ctx, double* x, int64_t ld, double a, const double* a_dev) {
+int kk_launch_scal(kk_ctx ctx, double* x, int64_t ld, double a, const double* a_dev, int rsqrt_mode) {
     kk_prof_scope ps(ctx, "k_scal");
     kk_part p = kk_partition(ctx, ld);
-    hipLaunchKernelGGL(k_scal, dim3(p.nblk), dim3(KK_TPB), 0, ctx->stream, x, ld, p.rpb, a, a_dev);
+    hipLaunchKernelGGL(k_scal, dim3(p.nblk), dim3(KK_TPB), 0, ctx->stream, x, ld, p.rpb, a, a_dev, rsqrt_mode);
     KK_HIP(hipGetLastError());
     return KK_OK;
 }
@@ -697,7 +697,7 @@ int kk_launch_gather(kk_ctx ctx, const double* x, const int64_t* idx, int64_t co
 }
 
 int kk_launch_project(kk_ctx ctx, const double* V, int64_t ld, int m, const double* w, const double* pre_vec,
-                      const double* pre_a_dev, const double* rhs2, int64_t ws_s_off, int64_t ws_g_off) {
+                      const double* pre_a_dev, const double* rhs2, double* out_s, double* out_g) {
     kk_part p = kk_partition(ctx, ld);
     dim3 g(p.nblk), b(KK_TPB);
     double* part = ctx->partials;
@@ -714,20 +714,20 @@ int kk_launch_project(kk_ctx ctx, const double* V, int64_t ld, int m, const doub
     KK_HIP(hipGetLastError());
     const int total = rhs2 ? 2 * m : m;
     hipLaunchKernelGGL(k_finalize_project, dim3((total + 3) / 4), dim3(KK_TPB), 0, ctx->stream, part, p.nblk, m,
-                       ctx->ws + ws_s_off, rhs2 ? ctx->ws + ws_g_off : (double*)nullptr);
+                       out_s, rhs2 ? out_g : (double*)nullptr);
     KK_HIP(hipGetLastError());
     return KK_OK;
 }
 
 int kk_launch_unproject(kk_ctx ctx, const double* V, int64_t ld, int m, const double* w_in, double* w_out,
                         const kk_coef* coef_host, const double* coef_dev, double alpha, double beta, int add_idx,
-                        const double* add_dev, int64_t nrm_off) {
+                        const double* add_dev, double* nrm_out3) {
     kk_part p = kk_partition(ctx, ld);
     dim3 g(p.nblk), b(KK_TPB);
     static const kk_coef zero_coef = {};
     const kk_coef& ch = coef_host ? *coef_host : zero_coef;
     double* part = part_row(ctx, PART_SCAL_A);
-    const bool norm = nrm_off >= 0, bzero = (beta == 0.0);
+    const bool norm = nrm_out3 != nullptr, bzero = (beta == 0.0);
     kk_prof_scope* ps = new kk_prof_scope(ctx, "k_unproject");
     if (norm && bzero)
         hipLaunchKernelGGL((k_unproject<true, true>), g, b, 0, ctx->stream, V, ld, m, w_in, w_out, ch, coef_dev, alpha, beta, add_idx, add_dev, p.rpb, part);
@@ -739,25 +739,25 @@ int kk_launch_unproject(kk_ctx ctx, const double* V, int64_t ld, int m, const do
         hipLaunchKernelGGL((k_unproject<false, false>), g, b, 0, ctx->stream, V, ld, m, w_in, w_out, ch, coef_dev, alpha, beta, add_idx, add_dev, p.rpb, part);
     delete ps;
     KK_HIP(hipGetLastError());
-    if (norm) return finalize_scalar(ctx, PART_SCAL_A, p.nblk, nrm_off, true);
+    if (norm) return finalize_scalar(ctx, PART_SCAL_A, p.nblk, nrm_out3, true);
     return KK_OK;
 }
 
 int kk_launch_mgs_step(kk_ctx ctx, double* w, int64_t ld, const double* q_prev, const double* s_prev_dev,
-                       const double* q_next, int64_t ws_dot_off, int64_t ws_nrm_off) {
+                       const double* q_next, double* dot_out, double* nrm_out3) {
     kk_part p = kk_partition(ctx, ld);
     dim3 g(p.nblk), b(KK_TPB);
     double* pd = part_row(ctx, PART_SCAL_A);
     double* pn = part_row(ctx, PART_SCAL_B);
     kk_prof_scope* ps = new kk_prof_scope(ctx, "k_mgs_step");
-    if (ws_nrm_off >= 0)
+    if (nrm_out3)
         hipLaunchKernelGGL((k_mgs_step<true>), g, b, 0, ctx->stream, w, ld, p.rpb, q_prev, s_prev_dev, q_next, pd, pn);
     else
         hipLaunchKernelGGL((k_mgs_step<false>), g, b, 0, ctx->stream, w, ld, p.rpb, q_prev, s_prev_dev, q_next, pd, pn);
     delete ps;
     KK_HIP(hipGetLastError());
-    if (q_next) KK_TRY(finalize_scalar(ctx, PART_SCAL_A, p.nblk, ws_dot_off, false));
-    if (ws_nrm_off >= 0) KK_TRY(finalize_scalar(ctx, PART_SCAL_B, p.nblk, ws_nrm_off, true));
+    if (q_next) KK_TRY(finalize_scalar(ctx, PART_SCAL_A, p.nblk, dot_out, false));
+    if (nrm_out3) KK_TRY(finalize_scalar(ctx, PART_SCAL_B, p.nblk, nrm_out3, true));
     return KK_OK;
 }
 
@@ -767,7 +767,7 @@ int kk_launch_spmv(kk_ctx ctx, const kk_sparse_dev& M, const double* x, double* 
     spmv_epi e;
     e.a1 = f.a1; e.a0 = f.a0; e.bprev = f.bprev;
     e.xs_dev = f.xscale_dev; e.bprev_dev = f.bprev_dev; e.vprev = f.vprev;
-    e.dot_mode = f.dot_mode; e.want_nrm = f.nrm_slot >= 0 ? 1 : 0;
+    e.dot_mode = f.dot_mode; e.want_nrm = f.nrm_out ? 1 : 0;
     e.n_local = M.n_ghost > 0 ? M.n_local : -1;
     e.ghost = M.ghost;
     double* pd = part_row(ctx, PART_SCAL_A);
@@ -797,12 +797,12 @@ int kk_launch_spmv(kk_ctx ctx, const kk_sparse_dev& M, const double* x, double* 
     }
     delete ps;
     KK_HIP(hipGetLastError());
-    if (nblk > KK_MAX_BLOCKS && (f.dot_mode || f.nrm_slot >= 0)) {
+    if (nblk > KK_MAX_BLOCKS && (f.dot_mode || f.nrm_out)) {
         kk_set_error("spmv grid %d exceeds partial buffer", nblk);
         return KK_ERR_INVALID;
     }
-    if (f.dot_mode) KK_TRY(finalize_scalar(ctx, PART_SCAL_A, nblk, WS_SCAL + f.dot_slot, false));
-    if (f.nrm_slot >= 0) KK_TRY(finalize_scalar(ctx, PART_SCAL_B, nblk, WS_SCAL + f.nrm_slot, true));
+    if (f.dot_mode) KK_TRY(finalize_scalar(ctx, PART_SCAL_A, nblk, f.dot_out, false));
+    if (f.nrm_out) KK_TRY(finalize_scalar(ctx, PART_SCAL_B, nblk, f.nrm_out, true));
     return KK_OK;
 }
 

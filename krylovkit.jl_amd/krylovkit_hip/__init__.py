@@ -11,6 +11,7 @@ from .core import (ClassicalGramSchmidt, ClassicalGramSchmidt2, ClassicalGramSch
                    SparseOperator, default_context, device_count)
 from .factorizations import (ArnoldiFactorization, ArnoldiIterator, GKLFactorization, GKLIterator,
                              LanczosFactorization, LanczosIterator, expand_, initialize, initialize_, shrink_)
+from . import dist
 from .solvers import GKL, GMRES, ConvergenceInfo, Lanczos, eigsolve, linsolve, svdsolve
 
 _lib.load()  # fail at import time if libkrylov_hip.so is missing

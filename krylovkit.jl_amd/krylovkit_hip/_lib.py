@@ -84,8 +84,7 @@ SIGNATURES = {
     "kk_csc_create": (C.c_int, [c_vp, C.c_int64, C.c_int64, C.c_int64, c_i64p, c_i64p, c_dp, C.c_int, C.c_int, c_vpp]),
     "kk_op_free": (C.c_int, [c_vp]),
     "kk_op_info": (C.c_int, [c_vp, c_i64p, c_i64p, c_i64p, c_ip, c_i64p]),
-    "kk_op_set_ghost": (C.c_int, [c_vp, C.c_int64, C.c_int64]),
-    "kk_op_ghost_ptr": (C.c_int, [c_vp, C.c_int, c_vpp]),
+    "kk_op_set_ghost": (C.c_int, [c_vp, C.c_int64, C.c_int64, c_vp]),
     "kk_spmv": (C.c_int, [c_vp, C.c_int, c_vp, C.c_int, c_vp, C.c_int]),
     "kk_spmv_affine": (C.c_int, [c_vp, c_vp, C.c_int, c_vp, C.c_int, C.c_double, C.c_double]),
     "kk_gather": (C.c_int, [c_vp, C.c_int, c_vp, C.c_int64, c_vp]),
@@ -104,13 +103,13 @@ SIGNATURES = {
     "kk_arnoldi_initialize": (C.c_int, [c_vp, c_vp, C.c_int, C.c_int, C.c_double, c_dp, c_dp]),
     "kk_gkl_expand": (C.c_int, [c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_double, C.c_double, c_dp, c_dp, c_ip, c_ip]),
     "kk_gkl_initialize": (C.c_int, [c_vp, c_vp, c_vp, c_dp, c_dp]),
-    "kk_ws_ptr": (C.c_int, [c_vp, c_vpp, c_i64p]),
-    "kk_project_dev": (C.c_int, [c_vp, C.c_int, C.c_int, c_vp, C.c_int, C.c_int64]),
-    "kk_unproject_dev": (C.c_int, [c_vp, C.c_int, c_vp, C.c_int, C.c_int, C.c_int64, C.c_int64]),
-    "kk_dot_dev": (C.c_int, [c_vp, C.c_int, c_vp, C.c_int, C.c_int64]),
-    "kk_axpy_dev": (C.c_int, [c_vp, C.c_int, c_vp, C.c_int, C.c_int64, C.c_double]),
-    "kk_ws_read": (C.c_int, [c_vp, C.c_int64, C.c_int64, c_dp]),
-    "kk_ws_write": (C.c_int, [c_vp, C.c_int64, C.c_int64, c_dp]),
+    "kk_apply_fused_dev": (C.c_int, [c_vp, c_vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, c_vp]),
+    "kk_project_dev": (C.c_int, [c_vp, C.c_int, C.c_int, c_vp, C.c_int, C.c_int, c_vp]),
+    "kk_unproject_dev": (C.c_int, [c_vp, C.c_int, c_vp, C.c_int, C.c_int, c_dp, C.c_double, C.c_double, c_vp]),
+    "kk_dot_dev": (C.c_int, [c_vp, C.c_int, c_vp, C.c_int, c_vp]),
+    "kk_nrm2_dev": (C.c_int, [c_vp, C.c_int, c_vp]),
+    "kk_axpy_dev": (C.c_int, [c_vp, C.c_int, c_vp, C.c_int, c_vp, C.c_double]),
+    "kk_scal_rsqrt_dev": (C.c_int, [c_vp, C.c_int, c_vp]),
 }
 
 _lib = None

@@ -119,21 +119,6 @@ class Context:
         check(self._lib.kk_ctx_prof_get(self.handle, kernel_class.encode(), C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
-    # split-phase scalar workspace (multi-GPU)
-    def ws_ptr(self):
-        p, n = C.c_void_p(), C.c_int64()
-        check(self._lib.kk_ws_ptr(self.handle, C.byref(p), C.byref(n)))
-        return p.value, n.value
-
-    def ws_read(self, off: int, count: int) -> np.ndarray:
-        out = np.empty(count)
-        check(self._lib.kk_ws_read(self.handle, off, count, out.ctypes.data_as(_lib.c_dp)))
-        return out
-
-    def ws_write(self, off: int, values: Sequence[float]):
-        a = np.ascontiguousarray(values, dtype=np.float64)
-        check(self._lib.kk_ws_write(self.handle, off, a.size, a.ctypes.data_as(_lib.c_dp)))
-
 
 _default_ctx: Optional[Context] = None
 

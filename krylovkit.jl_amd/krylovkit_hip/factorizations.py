@@ -76,7 +76,10 @@ class LanczosIterator:  # lanczos.jl:129-153
 
 
 def initialize(it, V: Optional[DeviceBasis] = None):
-    """initialize(iter) for LanczosIterator / ArnoldiIterator / GKLIterator."""
+    """initialize(iter) for LanczosIterator / ArnoldiIterator / GKLIterator (and any iterator
+    object that brings its own `initialize` / `expand`, e.g. the row-sharded ones of dist.py)."""
+    if hasattr(it, "initialize"):
+        return it.initialize(V)
     if isinstance(it, LanczosIterator):
         return _lanczos_initialize(it, V)
     if isinstance(it, ArnoldiIterator):
@@ -87,6 +90,8 @@ def initialize(it, V: Optional[DeviceBasis] = None):
 
 
 def expand_(it, fact):
+    if hasattr(it, "expand"):
+        return it.expand(fact)
     if isinstance(it, LanczosIterator):
         return _lanczos_expand(it, fact)
     if isinstance(it, ArnoldiIterator):

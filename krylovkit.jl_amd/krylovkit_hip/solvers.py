@@ -60,7 +60,7 @@ class GKL:  # algorithms.jl:200-217
 
 # -------------------------------------------------------------------- eigsolve (Lanczos)
 def eigsolve(A, x0, howmany: int = 1, which: str = "LM", alg: Optional[Lanczos] = None, *, return_device: bool = False,
-             **kw):
+             iterator=None, **kw):
     """eigsolve(A, x0, howmany, which, alg::Lanczos) (src/eigsolve/lanczos.jl:1-155).
 
     A: SparseOperator or scipy.sparse matrix (must be symmetric).  Returns
@@ -69,8 +69,10 @@ def eigsolve(A, x0, howmany: int = 1, which: str = "LM", alg: Optional[Lanczos] 
     krylovdim, maxiter = alg.krylovdim, alg.maxiter
     if howmany > krylovdim:
         raise ValueError(f"krylov dimension {krylovdim} too small to compute {howmany} eigenvalues")
-    op = _as_operator(A)
-    it = LanczosIterator(op, x0, alg.orth, True, capacity=krylovdim + 2)
+    if iterator is not None:  # e.g. dist.DistLanczosIterator: same control flow, sharded vectors
+        it = iterator
+    else:
+        it = LanczosIterator(_as_operator(A), x0, alg.orth, True, capacity=krylovdim + 2)
     fact = initialize(it)
     numops = 1
     numiter = 1
@@ -125,6 +127,8 @@ def eigsolve(A, x0, howmany: int = 1, which: str = "LM", alg: Optional[Lanczos] 
             B.basistransform(U[:, :keep])  # :109
             HipVec(B, keep).scale_from_(fact.r, 1.0 / beta)  # B[keep+1] = scale!!(r, 1/beta)  :111
             fact = shrink_(fact, keep)  # :114
+            if hasattr(it, "recompute_gram"):
+                it.recompute_gram(fact)
             numiter += 1
     hm = howmany
     if converged > howmany:
@@ -135,7 +139,7 @@ def eigsolve(A, x0, howmany: int = 1, which: str = "LM", alg: Optional[Lanczos] 
     Vc = U[:, :hm]
     B = fact.basis()
     K = len(fact)
-    out = DeviceBasis(B.n, max(hm, 1), op.ctx)
+    out = DeviceBasis(B.n, max(hm, 1), B.ctx)
     for i in range(hm):  # vectors = [B*v for v in cols(V)]   :131-133
         B.times(Vc[:, i], HipVec(out, i), 0, K)
     out.length = hm

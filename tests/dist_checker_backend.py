@@ -1,0 +1,90 @@
+"""CPU checker backend for krylovkit_hip.dist (TEST INFRASTRUCTURE): plain NumPy on torch CPU
+tensors, same interface as HipBackend, so the partition / halo-exchange / all-reduce logic of
+the row-sharded path can run under gloo with world_size 2 on a machine without a GPU."""
+import numpy as np
+import torch
+
+
+class _Basis:
+    def __init__(self, n, cap):
+        self.n, self.capacity, self.length = n, cap, 0
+        self.cols = np.zeros((cap, n))
+
+    def __len__(self):
+        return self.length
+
+
+class _Op:
+    def __init__(self, A, n_local, ghost):
+        self.A, self.n_local, self.ghost = A.tocsr(), n_local, ghost
+        self.n_ghost = A.shape[1] - n_local
+
+
+class CheckerBackend:
+    name = "checker"
+
+    def alloc(self, count, dtype="float64"):
+        return torch.zeros(count, dtype=getattr(torch, dtype))
+
+    def to_host(self, t):
+        return t.numpy().copy()
+
+    def from_host_i64(self, a):
+        return torch.as_tensor(np.ascontiguousarray(a, dtype=np.int64))
+
+    def sync(self):
+        pass
+
+    def make_basis(self, n, cap):
+        return _Basis(n, cap)
+
+    def make_operator(self, A_local, n_local, ghost):
+        return _Op(A_local, n_local, ghost)
+
+    def upload(self, b, col, x):
+        b.cols[col] = x
+
+    def copy_vec(self, dst, dcol, src, scol):
+        dst.cols[dcol] = src.cols[scol]
+
+    def download(self, b, col):
+        return b.cols[col].copy()
+
+    def gather(self, b, col, idx, out):
+        out[: idx.numel()] = torch.from_numpy(b.cols[col][idx.numpy()])
+
+    def scal(self, b, col, a):
+        b.cols[col] *= a
+
+    def copy_scal(self, b, cy, cx, a):
+        b.cols[cy] = a * b.cols[cx]
+
+    def apply_fused(self, op, b, cv, cprev, cw, beta_old, dot_mode, out):
+        x = np.concatenate([b.cols[cv], op.ghost.numpy()[: op.n_ghost]])
+        ax = op.A @ x
+        w = ax.copy()
+        if cprev >= 0:
+            w -= beta_old * b.cols[cprev]
+        if dot_mode == 1:
+            out[0] = float(b.cols[cv] @ ax)
+        elif dot_mode == 2:
+            out[0] = float(b.cols[cv] @ w)
+        b.cols[cw] = w
+
+    def project(self, b, c0, m, cx, crhs2, out):
+        V = b.cols[c0:c0 + m]
+        out[:m] = torch.from_numpy(V @ b.cols[cx])
+        if crhs2 >= 0:
+            out[m:2 * m] = torch.from_numpy(V @ b.cols[crhs2])
+
+    def unproject(self, b, cy, c0, m, coef, alpha, beta, nrm_out):
+        y = beta * b.cols[cy] + alpha * (np.asarray(coef) @ b.cols[c0:c0 + m])
+        b.cols[cy] = y
+        if nrm_out is not None:
+            nrm_out[0] = float(y @ y)
+
+    def dot(self, b, cx, cy, out):
+        out[0] = float(b.cols[cx] @ b.cols[cy])
+
+    def nrm2(self, b, cx, out3):
+        out3[0] = float(b.cols[cx] @ b.cols[cx])

