@@ -84,8 +84,14 @@ class HipBackend:
         self.device = torch.device("cuda", device_index)
         torch.cuda.set_device(self.device)
         self.ctx = Context(device_index)
-        # share torch's current stream so kernels and RCCL collectives are ordered without host syncs
-        self.ctx.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        # One explicit (non-default) HIP stream shared by libkrylov_hip's kernels, torch's copies and
+        # the RCCL collectives, so everything is stream-ordered without host syncs.  (The legacy
+        # default stream has handle 0, which kk_ctx_set_stream reads as "use the context's own
+        # stream" -- and a non-blocking stream does not synchronise with the default one.)
+        self.stream = torch.cuda.Stream(self.device)
+        torch.cuda.set_stream(self.stream)
+        assert self.stream.cuda_stream != 0
+        self.ctx.set_stream(self.stream.cuda_stream)
         self._lib = self.ctx._lib
 
     # buffers
