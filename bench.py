@@ -112,18 +112,19 @@ def cpu_baseline(orth_code: int, target_seconds: float = 15.0):
                                be.ctypes.data_as(dp), C.byref(passes), None)
         return (time.perf_counter() - t0) if rc == 0 else None, n
 
-    dt, n = run(10)                      # calibration: 40 000 rows
+    cal_ny = 50
+    dt, n = run(cal_ny)                  # calibration: 200 000 rows (basis of 100 vectors = 160 MB, out of cache)
     if dt is None:
         return None
-    if cores > 8 and dt > 2.0:           # oversubscribed container (visible cores != usable cores): retry narrow
+    if cores > 8 and dt > 5.0:           # oversubscribed container (visible cores != usable cores): retry narrow
         cores_wide, dt_wide = cores, dt
         cores = 8
-        dt, n = run(10)
+        dt, n = run(cal_ny)
         if dt is None or dt > dt_wide:
             cores, dt = cores_wide, dt_wide
-    if dt < target_seconds / 3:
-        ny = int(min(250, max(10, 10 * target_seconds / max(dt, 1e-3))))
-        if ny > 12:
+    if dt < target_seconds / 2:
+        ny = int(min(NY, max(cal_ny, cal_ny * target_seconds / max(dt, 1e-3))))
+        if ny > cal_ny * 1.2:
             dt2, n2 = run(ny)
             if dt2 is not None:
                 dt, n = dt2, n2
