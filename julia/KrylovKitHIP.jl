@@ -1,0 +1,205 @@
+# KrylovKitHIP.jl -- the reference-side binding of libkrylov_hip.so.
+#
+# This is the shim a KrylovKit.jl maintainer (or user) adds next to KrylovKit: a device vector
+# type + a device operator type that satisfy the L1 protocol (VectorInterface verbs, `apply`),
+# plus method overloads of the L2/L3 entry points for that type which forward to the FUSED
+# C-ABI calls.  KrylovKit's own eigsolve / linsolve / svdsolve (L5), its algorithm structs
+# (L4) and its small dense LAPACK work (L0) run unchanged on the host.
+#
+# NOTE: the build image has no Julia toolchain, so this file has not been executed here; the
+# identical ccall sequence is exercised through the ctypes mirror
+# (krylovkit.jl_amd/krylovkit_hip) by tests/test_gpu_parity.py.  Signatures are exactly those of
+# include/krylov_hip.h.
+module KrylovKitHIP
+
+using KrylovKit, VectorInterface, LinearAlgebra, SparseArrays
+import KrylovKit: apply, apply_normal, apply_adjoint, expand!, initialize, shrink!, basis,
+                  OrthonormalBasis, LanczosIterator, LanczosFactorization, ArnoldiIterator,
+                  ArnoldiFactorization, GKLIterator, GKLFactorization, orthogonalize!!,
+                  project!!, unproject!!, rank1update!, basistransform!,
+                  ClassicalGramSchmidt, ModifiedGramSchmidt, ClassicalGramSchmidt2,
+                  ModifiedGramSchmidt2, ClassicalGramSchmidtIR, ModifiedGramSchmidtIR
+
+const lib = "libkrylov_hip"
+
+# ---------------------------------------------------------------- error handling
+# mirrors chklapackerror (src/dense/linalg.jl:447): integer status -> Julia exception
+function chk(status::Cint)
+    status == 0 && return nothing
+    msg = unsafe_string(ccall((:kk_last_error, lib), Cstring, ()))
+    status == -2 && throw(DimensionMismatch(msg))
+    status == -5 && throw(ArgumentError(msg))          # "initial vector should not have norm zero"
+    error("libkrylov_hip error $status: $msg")
+end
+
+# ---------------------------------------------------------------- handles
+mutable struct HipContext
+    h::Ptr{Cvoid}
+    function HipContext(device::Integer = 0)
+        r = Ref{Ptr{Cvoid}}()
+        chk(ccall((:kk_ctx_create, lib), Cint, (Cint, Ref{Ptr{Cvoid}}), device, r))
+        finalizer(c -> ccall((:kk_ctx_destroy, lib), Cint, (Ptr{Cvoid},), c.h), new(r[]))
+    end
+end
+
+"Contiguous HBM slab of `capacity` columns: replaces the Vector{T} inside OrthonormalBasis{T}."
+mutable struct HipSlab
+    h::Ptr{Cvoid}
+    n::Int
+    capacity::Int
+    ctx::HipContext
+    function HipSlab(ctx::HipContext, n::Integer, capacity::Integer)
+        r = Ref{Ptr{Cvoid}}()
+        chk(ccall((:kk_basis_create, lib), Cint, (Ptr{Cvoid}, Int64, Cint, Ref{Ptr{Cvoid}}), ctx.h, n, capacity, r))
+        finalizer(s -> ccall((:kk_basis_free, lib), Cint, (Ptr{Cvoid},), s.h), new(r[], n, capacity, ctx))
+    end
+end
+
+"The device vector type T of OrthonormalBasis{T}: one column of a slab."
+struct HipVec
+    slab::HipSlab
+    col::Cint            # 0-based column
+end
+
+"Device sparse operator built from Julia's SparseMatrixCSC{Float64,Int64} arrays as they are."
+mutable struct HipOperator
+    h::Ptr{Cvoid}
+    size::Tuple{Int,Int}
+    function HipOperator(ctx::HipContext, A::SparseMatrixCSC{Float64,Int64}; symmetric::Bool = issymmetric(A))
+        r = Ref{Ptr{Cvoid}}()
+        chk(ccall((:kk_csc_create, lib), Cint,
+                  (Ptr{Cvoid}, Int64, Int64, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Cint, Cint, Ref{Ptr{Cvoid}}),
+                  ctx.h, size(A, 1), size(A, 2), nnz(A), A.colptr, A.rowval, A.nzval, 1, symmetric ? 1 : 0, r))
+        finalizer(o -> ccall((:kk_op_free, lib), Cint, (Ptr{Cvoid},), o.h), new(r[], size(A)))
+    end
+end
+
+orthcode(::ClassicalGramSchmidt) = (Cint(0), 0.0)
+orthcode(::ModifiedGramSchmidt) = (Cint(1), 0.0)
+orthcode(::ClassicalGramSchmidt2) = (Cint(2), 0.0)
+orthcode(::ModifiedGramSchmidt2) = (Cint(3), 0.0)
+orthcode(o::ClassicalGramSchmidtIR) = (Cint(4), Float64(o.η))
+orthcode(o::ModifiedGramSchmidtIR) = (Cint(5), Float64(o.η))
+
+# ---------------------------------------------------------------- L1: VectorInterface verbs
+# (SURVEY.md Appendix B; the un-fused fallback that makes EVERY KrylovKit algorithm run)
+VectorInterface.scalartype(::Type{HipVec}) = Float64
+function VectorInterface.inner(x::HipVec, y::HipVec)
+    r = Ref{Float64}()
+    chk(ccall((:kk_vec_dot, lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Ref{Float64}), x.slab.h, x.col, y.slab.h, y.col, r))
+    return r[]
+end
+function LinearAlgebra.norm(x::HipVec)
+    r = Ref{Float64}()
+    chk(ccall((:kk_vec_nrm2, lib), Cint, (Ptr{Cvoid}, Cint, Ref{Float64}), x.slab.h, x.col, r))
+    return r[]
+end
+function VectorInterface.add!!(y::HipVec, x::HipVec, α::Number = 1, β::Number = 1)
+    chk(ccall((:kk_vec_axpby, lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Float64, Float64), y.slab.h, y.col, x.slab.h, x.col, α, β))
+    return y
+end
+function VectorInterface.scale!!(x::HipVec, α::Number)
+    chk(ccall((:kk_vec_scal, lib), Cint, (Ptr{Cvoid}, Cint, Float64), x.slab.h, x.col, α))
+    return x
+end
+function VectorInterface.scale!!(y::HipVec, x::HipVec, α::Number)
+    chk(ccall((:kk_vec_copy_scal, lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Float64), y.slab.h, y.col, x.slab.h, x.col, α))
+    return y
+end
+# fresh vectors (`scale`, `zerovector`) come from a per-context scratch slab; see INTEGRATION.md
+# for the allocation policy (free-list of columns).
+
+# ---------------------------------------------------------------- L1: operator protocol (src/apply.jl:1-19)
+function apply(A::HipOperator, x::HipVec, y::HipVec = scratch_like(x); transpose::Bool = false)
+    chk(ccall((:kk_spmv, lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint), A.h, transpose, x.slab.h, x.col, y.slab.h, y.col))
+    return y
+end
+apply_normal(A::HipOperator, x::HipVec) = apply(A, x)
+apply_adjoint(A::HipOperator, x::HipVec) = apply(A, x; transpose = true)
+
+# ---------------------------------------------------------------- L2: orthonormal.jl entry points
+# project!! (orthonormal.jl:88-118), unproject!! (:132-196), orthogonalize!! (:378-452),
+# basistransform! (:291-354), rmul!(b, Givens / Householder) (dense/givens.jl, reflector.jl:143-154)
+slab_range(b::OrthonormalBasis{HipVec}) = (first(b).slab, first(b).col, Cint(length(b)))   # columns are contiguous by construction
+
+function orthogonalize!!(w::HipVec, b::OrthonormalBasis{HipVec}, x::AbstractVector, alg::KrylovKit.Orthogonalizer)
+    slab, c0, m = slab_range(b)
+    code, η = orthcode(alg)
+    xs = Vector{Float64}(undef, m)
+    chk(ccall((:kk_orthogonalize, lib), Cint,
+              (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Cint, Cint, Float64, Ptr{Float64}, Ptr{Float64}, Ptr{Cint}),
+              slab.h, c0, m, w.slab.h, w.col, code, η, xs, C_NULL, C_NULL))
+    copyto!(x, xs)
+    return (w, x)
+end
+function basistransform!(b::OrthonormalBasis{HipVec}, U::AbstractMatrix)
+    slab, c0, m = slab_range(b)
+    Ud = Matrix{Float64}(U)
+    size(Ud, 1) == m || throw(DimensionMismatch())
+    chk(ccall((:kk_basistransform, lib), Cint, (Ptr{Cvoid}, Cint, Cint, Cint, Ptr{Float64}, Cint), slab.h, c0, m, size(Ud, 2), Ud, m))
+    return b
+end
+function LinearAlgebra.rmul!(b::OrthonormalBasis{HipVec}, G::LinearAlgebra.Givens)
+    slab, c0, _ = slab_range(b)
+    chk(ccall((:kk_givens_rmul, lib), Cint, (Ptr{Cvoid}, Cint, Cint, Float64, Float64), slab.h, c0 + G.i1 - 1, c0 + G.i2 - 1, G.c, G.s))
+    return b
+end
+
+# ---------------------------------------------------------------- L3: fused expand! (the hot path)
+# Lanczos: factorizations/lanczos.jl:250-272.  One ccall = scale + SpMV(+three-term tail, alpha)
+# + projection pass + update (+ norm): one host sync.
+function expand!(iter::LanczosIterator{HipOperator,HipVec}, state::LanczosFactorization; verbosity::Int = 0)
+    βold = KrylovKit.normres(state)
+    V = state.V
+    slab, c0, k = slab_range(V)
+    code, η = orthcode(iter.orth)
+    α, β, np = Ref{Float64}(), Ref{Float64}(), Ref{Cint}()
+    chk(ccall((:kk_lanczos_expand, lib), Cint,
+              (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cint, Cint, Float64, Float64, Ref{Float64}, Ref{Float64}, Ref{Cint}),
+              iter.operator.h, slab.h, c0, k, code, η, βold, α, β, np))
+    push!(V, HipVec(slab, c0 + k))             # V = push!(V, scale!!(r, 1/βold))      lanczos.jl:257
+    push!(state.αs, α[]); push!(state.βs, β[])  #                                       :261-262
+    state.k += 1
+    state.r = HipVec(slab, c0 + k + 1)
+    return state
+end
+
+# Arnoldi: factorizations/arnoldi.jl:199-219 (GMRES: linsolve/gmres.jl:59)
+function expand!(iter::ArnoldiIterator{HipOperator,HipVec}, state::ArnoldiFactorization; verbosity::Int = 0)
+    state.k += 1
+    k = state.k
+    V, H = state.V, state.H
+    slab, c0, kk = slab_range(V)
+    code, η = orthcode(iter.orth)
+    β = KrylovKit.normres(state)
+    m = length(H)
+    resize!(H, m + k + 1)
+    βn, np = Ref{Float64}(), Ref{Cint}()
+    chk(ccall((:kk_arnoldi_expand, lib), Cint,
+              (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cint, Cint, Float64, Float64, Ptr{Float64}, Ref{Float64}, Ref{Cint}),
+              iter.operator.h, slab.h, c0, kk, code, η, β, pointer(H, m + 1), βn, np))
+    H[m + k + 1] = βn[]
+    push!(V, HipVec(slab, c0 + kk))
+    state.r = HipVec(slab, c0 + kk + 1)
+    return state
+end
+
+# GKL: factorizations/gkl.jl:246-269
+function expand!(iter::GKLIterator{HipOperator,HipVec}, state::GKLFactorization; verbosity::Int = 0)
+    βold = KrylovKit.normres(state)
+    U, V = state.U, state.V
+    su, _, k = slab_range(U)
+    sv, _, _ = slab_range(V)
+    code, η = orthcode(iter.orth)
+    α, β, pv, pu = Ref{Float64}(), Ref{Float64}(), Ref{Cint}(), Ref{Cint}()
+    chk(ccall((:kk_gkl_expand, lib), Cint,
+              (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cint, Float64, Float64, Ref{Float64}, Ref{Float64}, Ref{Cint}, Ref{Cint}),
+              iter.operator.h, su.h, sv.h, k, code, η, βold, α, β, pv, pu))
+    push!(U, HipVec(su, k)); push!(V, HipVec(sv, k))
+    push!(state.αs, α[]); push!(state.βs, β[])
+    state.k += 1
+    state.r = HipVec(su, k + 1)
+    return state
+end
+
+end # module
