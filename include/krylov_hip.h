@@ -203,6 +203,42 @@ int kk_gkl_expand(kk_op op, kk_basis bu, kk_basis bv, int k, kk_orth_t orth, dou
 /* GKL initialize (gkl.jl:183-215): bu column 0 holds u0 on entry. */
 int kk_gkl_initialize(kk_op op, kk_basis bu, kk_basis bv, double* alpha, double* beta);
 
+/* ---------------------------------------------------------------- BlockLanczos (config 5)
+ * src/factorizations/blocklanczos.jl.  A Block of p vectors = p consecutive columns of a slab.
+ * kk_ctx_set_option("block_mode", v): 0 = strict (every inner/add!! pair executed sequentially as
+ * the reference does), 1 = panel (default): block_inner / block_reorthogonalize! run as
+ * tall-skinny panels on v_mfma_f64_16x16x4_f64 + a multi-right-hand-side update kernel. */
+/* block_inner (blocklanczos.jl:43-52): M[i + ldm*j] = inner(X[i], Y[j]); X = columns cx..cx+p-1 of bx */
+int kk_block_inner(kk_basis bx, int cx, int p, kk_basis by, int cy, int q, double* M, int ldm);
+/* apply(f, ::Block) (blocklanczos.jl:39): Y[j] = A X[j], j < nb (one SpMM: the matrix is read once) */
+int kk_block_apply(kk_op op, kk_basis bx, int cx, kk_basis by, int cy, int nb);
+/* W[j] = beta*W[j] + alpha*sum_i b[c0+i]*S[i + lds*j], i < m, j < q: the AX[j] -= X[i]*M[i,j] +
+ * Xprev[i]*conj(B[j,i]) update (blocklanczos.jl:253-260), the panel update of
+ * block_reorthogonalize!, basistransform! of a residual block (eigsolve/blocklanczos.jl:96).
+ * norms (optional, q doubles) receives |W[j]| of the result. W must not overlap the basis range. */
+int kk_block_update(kk_basis bw, int cw, int q, kk_basis b, int c0, int m, const double* S, int lds, double alpha,
+                    double beta, double* norms);
+/* block_qr! (blocklanczos.jl:312-353): MGS QR with rank detection of the p columns c_in..c_in+p-1.
+ * The orthonormal vectors are written COMPACTED to columns c_out..c_out+ngood-1 (c_out == c_in:
+ * in place; otherwise the input block is left untouched and serves as `Rcopy`, blocklanczos.jl:209).
+ * R (ngood x p, column-major, ldr >= p) = R[good_idx, :]; good_idx[p] (0-based); *is_drift as in :334-336. */
+int kk_block_qr(kk_basis b, int c_in, int p, int c_out, double tol, double* R, int ldr, int* good_idx, int* ngood,
+                int* is_drift);
+/* block_reorthogonalize! (blocklanczos.jl:277-284): W = columns cw..cw+q-1 against basis columns c0..c0+m-1 */
+int kk_block_reorthogonalize(kk_basis b, int c0, int m, int cw, int q);
+/* initialize(::BlockLanczosIterator) (blocklanczos.jl:159-198).  On entry columns c_x0..c_x0+bs0-1 hold
+ * the start block.  On return columns 0..bs-1 = V (orthonormalised start block, bs = rank), columns
+ * c_r..c_r+bs-1 = residual block; M1 (bs x bs, ldm) = block_inner(X1, A X1); *norm_R = Frobenius norm. */
+int kk_blocklanczos_initialize(kk_op op, kk_basis b, int c_x0, int bs0, int c_r, double qr_tol, int* bs,
+                               double* M1, int ldm, double* norm_R);
+/* expand!(::BlockLanczosIterator, state) (blocklanczos.jl:200-240) + block_lanczosrecurrence (:242-263).
+ * Columns 0..k-1 = V, the residual block (bs_r vectors) sits in columns c_r.. ; the new basis
+ * vectors go to columns k..k+bs_next-1 and the new residual block to columns c_rnext.. (must not
+ * overlap [0, k+bs_r)).  B (bs_next x bs_r, ldb), M (bs_next x bs_next, ldm) are the new blocks of
+ * the block-tridiagonal matrix (blocklanczos.jl:220-221,229). */
+int kk_blocklanczos_expand(kk_op op, kk_basis b, int k, int bs_r, int c_r, int c_rnext, double qr_tol, int* bs_next,
+                           double* B, int ldb, double* M, int ldm, double* norm_R, int* is_drift);
+
 /* ---------------------------------------------------------------- split-phase pieces for
  * row-sharded (one process per GPU) runs.  Every inner-product-type result is a LOCAL partial
  * written to a CALLER-OWNED device buffer (e.g. a torch tensor), so the caller can all-reduce

@@ -10,6 +10,7 @@
 
 #define KK_MAX_M 256          // max basis vectors touched by one project/unproject call
 #define KK_MAX_BLOCKS 4096    // max thread blocks of a reducing kernel (partials row stride)
+#define KK_BLK_SCRATCH 131072 // doubles of device/pinned scratch for block matrices (gram panels, S)
 #define KK_TPB 256            // threads per block of every streaming kernel (4 waves)
 #define KK_SUB 512            // rows covered by one block sub-step: 256 threads x 2 rows (16 B/lane)
 #define KK_RG 4               // sub-steps per row group (8 rows per thread in registers)
@@ -60,6 +61,9 @@ struct kk_ctx_s {
     double* partials = nullptr;  // device partial sums [(2*KK_MAX_M + 8) * KK_MAX_BLOCKS]
     double* h_pin = nullptr;     // pinned host staging [4][WS_TOTAL]
     double* h_U = nullptr;       // pinned staging for basistransform's U [KK_MAX_M^2]
+    double* blk = nullptr;       // device scratch for small block matrices [KK_BLK_SCRATCH]
+    double* h_blk = nullptr;     // pinned twin of blk
+    int block_mode = 1;          // 0 strict, 1 panel (MFMA gram + multi-rhs update)
     int blocks_per_cu = 8;
     int mgs_mode = 1;
     int fuse_passes = 1;         // fuse unproject(pass i) with project(pass i+1)
@@ -182,3 +186,10 @@ int kk_launch_givens(kk_ctx ctx, double* q1, double* q2, int64_t ld, double c, d
 int kk_launch_householder(kk_ctx ctx, double* V, int64_t ld, int m, const kk_coef* v, double beta);
 int kk_launch_rank1(kk_ctx ctx, double* V, int64_t ld, int m, const double* y, const kk_coef* x, double alpha,
                     double beta);
+
+// ---- block (multi-vector) launchers
+int kk_launch_block_gram(kk_ctx ctx, const double* X, int64_t ldx, int p, const double* Y, int64_t ldy, int q, int64_t ld,
+                         double* C_dev, int ldc);
+int kk_launch_block_update(kk_ctx ctx, const double* V, int64_t ld, int m, const double* Win, double* Wout, int64_t ldw_in,
+                           int64_t ldw_out, int nb, const double* S_dev, double alpha, double beta, double* norms2_dev);
+int kk_launch_spmm(kk_ctx ctx, const kk_sparse_dev& M, const double* X, int64_t ldx, double* Y, int64_t ldy, int nb);

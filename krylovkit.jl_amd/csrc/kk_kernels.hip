@@ -618,6 +618,199 @@ __global__ __launch_bounds__(KK_TPB) void k_rank1(double* __restrict__ V, int64_
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Block (multi-vector) kernels for BlockLanczos (src/factorizations/blocklanczos.jl)
+// ------------------------------------------------------------------------------------------
+// block_inner / the tall-skinny panel  C = X' Y  (p x q, q <= 16 per launch): the one place where
+// the path is a genuine dense contraction, done on v_mfma_f64_16x16x4_f64.
+//   D[i][j] += sum_k A[i][k] B[k][j],  i = X column (16 per group), j = Y column, k = 4 rows.
+//   A operand: lane l holds A[i = l&15][k = l>>4];  B operand: lane l holds B[k = l>>4][j = l&15];
+//   C/D (f64 map): lane l, reg r -> row i = (l>>4) + 4r, col j = l&15.
+// Lane (c = l&15, kq = l>>4) streams BG_T consecutive rows of column c (16 B loads); MFMA t uses
+// element t, so the 4 k-slots of MFMA t are rows {kq*T + t}: any row->slot map is valid as long
+// as A and B use the same one.  X is read exactly once, Y once per launch.
+#define BG_T 8                       // rows per lane per chunk (4 x dwordx4)
+#define BG_CHUNK (4 * BG_T)          // rows per wave chunk
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+template <int NG>  // NG groups of 16 X-columns
+__global__ __launch_bounds__(KK_TPB) void k_block_gram(const double* __restrict__ X, int64_t ldx, int p,
+                                                       const double* __restrict__ Y, int64_t ldy, int q, int64_t ld,
+                                                       int64_t rpb, double* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];  // [NG][4][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, kq = lane >> 4;
+    const int64_t r0 = (int64_t)blockIdx.x * rpb, r1 = imin(r0 + rpb, ld);
+    v4d acc[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) acc[g] = v4d{0.0, 0.0, 0.0, 0.0};
+    const bool yok = c < q;
+    for (int64_t rc = r0 + wave * BG_CHUNK; rc < r1; rc += 4 * BG_CHUNK) {
+        const int64_t row = rc + kq * BG_T;
+        double yv[BG_T];
+        if (yok) {
+            const double* yp = Y + (int64_t)c * ldy + row;
+#pragma unroll
+            for (int t = 0; t < BG_T; t += 2) { d2 v = ld2(yp + t); yv[t] = v.x; yv[t + 1] = v.y; }
+        } else {
+#pragma unroll
+            for (int t = 0; t < BG_T; ++t) yv[t] = 0.0;
+        }
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int col = g * 16 + c;
+            double xv[BG_T];
+            if (col < p) {
+                const double* xp = X + (int64_t)col * ldx + row;
+#pragma unroll
+                for (int t = 0; t < BG_T; t += 2) { d2 v = ld2(xp + t); xv[t] = v.x; xv[t + 1] = v.y; }
+            } else {
+#pragma unroll
+                for (int t = 0; t < BG_T; ++t) xv[t] = 0.0;
+            }
+#pragma unroll
+            for (int t = 0; t < BG_T; ++t) acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(xv[t], yv[t], acc[g], 0, 0, 0);
+        }
+    }
+    // combine the 4 waves through LDS in a fixed order, then one coalesced partial tile per block
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    double* a = &lds[(g * 4 + r) * 64 + lane];
+                    *a = (w == 0) ? acc[g][r] : (*a + acc[g][r]);
+                }
+        }
+        __syncthreads();
+    }
+    double* dst = part + (int64_t)blockIdx.x * (NG * 256);
+    for (int e = tid; e < NG * 256; e += KK_TPB) dst[e] = lds[e];
+}
+
+// C[i + ldc*j] = sum_b part[b][e(i,j)]   (one thread per output entry)
+__global__ __launch_bounds__(KK_TPB) void k_finalize_gram(const double* __restrict__ part, int nblk, int ng, int p, int q,
+                                                          double* __restrict__ C, int ldc) {
+    const int idx = blockIdx.x * KK_TPB + threadIdx.x;
+    if (idx >= p * q) return;
+    const int i = idx % p, j = idx / p;
+    const int g = i >> 4, ii = i & 15;          // ii = (lane>>4) + 4 r  ->  r = ii>>2, lane>>4 = ii&3
+    const int r = ii >> 2, lane = ((ii & 3) << 4) | j;
+    const int e = (g * 4 + r) * 64 + lane;
+    const int64_t stride = (int64_t)ng * 256;
+    double a = 0;
+    for (int b = 0; b < nblk; ++b) a += part[(int64_t)b * stride + e];
+    C[i + (int64_t)ldc * j] = a;
+}
+
+// W[:, j] = beta*W[:, j] + alpha * sum_c V[:, c] S[c*nb + j]   for j < nb <= NB, c < m
+// (three-term block update, block_reorthogonalize! panel update, CholQR back-substitution).
+// S lives in device memory (scalar loads); fused column norms |W_j|^2 -> partials.
+template <int NB, bool BZERO>
+__global__ __launch_bounds__(KK_TPB) void k_block_update(const double* __restrict__ V, int64_t ld, int m, const double* Win,
+                                                         double* Wout, int64_t ldw_in, int64_t ldw_out, int nb,
+                                                         const double* __restrict__ S, double alpha, double beta,
+                                                         int64_t rpb, double* __restrict__ part_nrm) {
+    __shared__ double sm[4];
+    const int64_t r0 = (int64_t)blockIdx.x * rpb, r1 = imin(r0 + rpb, ld);
+    double nacc[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) nacc[j] = 0.0;
+    for (int64_t r = r0 + threadIdx.x * 2; r < r1; r += KK_SUB) {
+        d2 w[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            if (!BZERO && j < nb) { w[j] = ld2(Win + (int64_t)j * ldw_in + r); w[j].x *= beta; w[j].y *= beta; }
+            else w[j] = d2{0.0, 0.0};
+        }
+        int c = 0;
+        for (; c + 4 <= m; c += 4) {
+            d2 x[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) x[u] = ld2(V + (int64_t)(c + u) * ld + r);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const double* Sc = S + (int64_t)(c + u) * nb;
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    if (j < nb) {
+                        const double s = alpha * Sc[j];
+                        w[j].x = fma(s, x[u].x, w[j].x); w[j].y = fma(s, x[u].y, w[j].y);
+                    }
+                }
+            }
+        }
+        for (; c < m; ++c) {
+            const d2 x = ld2(V + (int64_t)c * ld + r);
+            const double* Sc = S + (int64_t)c * nb;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                if (j < nb) {
+                    const double s = alpha * Sc[j];
+                    w[j].x = fma(s, x.x, w[j].x); w[j].y = fma(s, x.y, w[j].y);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            if (j < nb) {
+                st2(Wout + (int64_t)j * ldw_out + r, w[j]);
+                nacc[j] = fma(w[j].x, w[j].x, nacc[j]); nacc[j] = fma(w[j].y, w[j].y, nacc[j]);
+            }
+        }
+    }
+    if (part_nrm) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            if (j < nb) {
+                double t = block_sum(nacc[j], sm);
+                if (threadIdx.x == 0) part_nrm[(int64_t)j * KK_MAX_BLOCKS + blockIdx.x] = t;
+            }
+        }
+    }
+}
+
+// SpMM on ELL: Y[:, j] = A X[:, j], j < nb <= NB (apply(f, ::Block), blocklanczos.jl:39): the matrix
+// is streamed once for the whole block instead of once per vector.
+template <int NB>
+__global__ __launch_bounds__(KK_TPB) void k_spmm_ell(const int32_t* __restrict__ ecol, const double* __restrict__ eval,
+                                                     int64_t ell_ld, int width, int64_t nrows,
+                                                     const double* __restrict__ X, int64_t ldx, double* __restrict__ Y,
+                                                     int64_t ldy, int nb, int nb_logical) {
+    const int per = (nb_logical + 7) >> 3;
+    const int nbx = gridDim.x >> 3;
+    const int xcd = blockIdx.x & 7;
+    for (int cblk = blockIdx.x >> 3; cblk < per; cblk += nbx) {
+        const int lb = xcd * per + cblk;
+        if (lb >= nb_logical) break;
+        const int64_t row = ((int64_t)lb * KK_TPB + threadIdx.x) * 2;
+        if (row >= nrows) continue;
+        d2 acc[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[j] = d2{0.0, 0.0};
+        for (int k = 0; k < width; ++k) {
+            const int2 cc = *reinterpret_cast<const int2*>(ecol + (int64_t)k * ell_ld + row);
+            const d2 v = ld2(eval + (int64_t)k * ell_ld + row);
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                if (j < nb) {
+                    acc[j].x = fma(v.x, X[(int64_t)j * ldx + cc.x], acc[j].x);
+                    acc[j].y = fma(v.y, X[(int64_t)j * ldx + cc.y], acc[j].y);
+                }
+            }
+        }
+        const bool last_odd = (row + 1 >= nrows);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            if (j < nb) {
+                if (last_odd) acc[j].y = 0.0;
+                st2(Y + (int64_t)j * ldy + row, acc[j]);
+            }
+        }
+    }
+}
+
 // ==========================================================================================
 // host-side launchers
 // ==========================================================================================
@@ -841,6 +1034,106 @@ int kk_launch_rank1(kk_ctx ctx, double* V, int64_t ld, int m, const double* y, c
     kk_prof_scope ps(ctx, "k_rank1");
     kk_part p = kk_partition(ctx, ld);
     hipLaunchKernelGGL(k_rank1, dim3(p.nblk), dim3(KK_TPB), 0, ctx->stream, V, ld, m, y, *x, alpha, beta, p.rpb);
+    KK_HIP(hipGetLastError());
+    return KK_OK;
+}
+
+// ---- block launchers ---------------------------------------------------------------------
+// C (p x q, column-major ldc) = X' Y on device memory `C_dev`; p <= 128, q <= 16 per call
+int kk_launch_block_gram(kk_ctx ctx, const double* X, int64_t ldx, int p, const double* Y, int64_t ldy, int q, int64_t ld,
+                         double* C_dev, int ldc) {
+    if (p <= 0 || q <= 0) return KK_OK;
+    if (p > 128 || q > 16) { kk_set_error("kk_launch_block_gram: p=%d q=%d exceed one launch (128 x 16)", p, q); return KK_ERR_INVALID; }
+    kk_part pt = kk_partition(ctx, ld);
+    // cap the grid: every block leaves an NG*256-double partial tile
+    int nblk = pt.nblk;
+    int64_t rpb = pt.rpb;
+    const int maxb = 2 * ctx->num_cus;
+    if (nblk > maxb) {
+        const int64_t nsub = ld / KK_SUB;
+        const int64_t spb = (nsub + maxb - 1) / maxb;
+        rpb = spb * KK_SUB;
+        nblk = (int)((nsub + spb - 1) / spb);
+    }
+    const int ng = (p + 15) / 16;
+    int NG = 1;
+    while (NG < ng) NG *= 2;
+    const size_t shm = (size_t)NG * 256 * sizeof(double);
+    double* part = ctx->partials;
+    {
+        kk_prof_scope ps(ctx, "k_block_gram");
+        dim3 g(nblk), b(KK_TPB);
+        switch (NG) {
+            case 1: hipLaunchKernelGGL((k_block_gram<1>), g, b, shm, ctx->stream, X, ldx, p, Y, ldy, q, ld, rpb, part); break;
+            case 2: hipLaunchKernelGGL((k_block_gram<2>), g, b, shm, ctx->stream, X, ldx, p, Y, ldy, q, ld, rpb, part); break;
+            case 4: hipLaunchKernelGGL((k_block_gram<4>), g, b, shm, ctx->stream, X, ldx, p, Y, ldy, q, ld, rpb, part); break;
+            default: hipLaunchKernelGGL((k_block_gram<8>), g, b, shm, ctx->stream, X, ldx, p, Y, ldy, q, ld, rpb, part); break;
+        }
+    }
+    KK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_finalize_gram, dim3((p * q + KK_TPB - 1) / KK_TPB), dim3(KK_TPB), 0, ctx->stream, part, nblk, NG, p, q,
+                       C_dev, ldc);
+    KK_HIP(hipGetLastError());
+    return KK_OK;
+}
+
+// Wout[:, j] = beta*Win[:, j] + alpha * sum_c V[:, c] S_dev[c*nb + j], j < nb <= 16; optional norms2_dev[nb]
+int kk_launch_block_update(kk_ctx ctx, const double* V, int64_t ld, int m, const double* Win, double* Wout, int64_t ldw_in,
+                           int64_t ldw_out, int nb, const double* S_dev, double alpha, double beta, double* norms2_dev) {
+    if (nb <= 0) return KK_OK;
+    if (nb > 16) { kk_set_error("kk_launch_block_update: nb=%d > 16", nb); return KK_ERR_INVALID; }
+    kk_part p = kk_partition(ctx, ld);
+    dim3 g(p.nblk), b(KK_TPB);
+    double* part = norms2_dev ? ctx->partials : nullptr;
+    const bool bz = (beta == 0.0);
+    {
+        kk_prof_scope ps(ctx, "k_block_update");
+#define BU_CASE(NBT) \
+        if (bz) hipLaunchKernelGGL((k_block_update<NBT, true>), g, b, 0, ctx->stream, V, ld, m, Win, Wout, ldw_in, ldw_out, nb, S_dev, alpha, beta, p.rpb, part); \
+        else hipLaunchKernelGGL((k_block_update<NBT, false>), g, b, 0, ctx->stream, V, ld, m, Win, Wout, ldw_in, ldw_out, nb, S_dev, alpha, beta, p.rpb, part);
+        if (nb <= 4) { BU_CASE(4) } else if (nb <= 8) { BU_CASE(8) } else { BU_CASE(16) }
+#undef BU_CASE
+    }
+    KK_HIP(hipGetLastError());
+    if (norms2_dev) {
+        hipLaunchKernelGGL(k_finalize_project, dim3((nb + 3) / 4), dim3(KK_TPB), 0, ctx->stream, part, p.nblk, nb, norms2_dev,
+                           (double*)nullptr);
+        KK_HIP(hipGetLastError());
+    }
+    return KK_OK;
+}
+
+// Y[:, j] = A X[:, j], j < nb (any nb: processed 16 / 8 / 4 columns at a time)
+int kk_launch_spmm(kk_ctx ctx, const kk_sparse_dev& M, const double* X, int64_t ldx, double* Y, int64_t ldy, int nb) {
+    if (M.format != 0 || M.n_ghost > 0) {  // CSR / ghosted operators: one SpMV per column
+        for (int j = 0; j < nb; ++j) {
+            kk_spmv_fuse f;
+            KK_TRY(kk_launch_spmv(ctx, M, X + (int64_t)j * ldx, Y + (int64_t)j * ldy, ldy, f));
+        }
+        return KK_OK;
+    }
+    const int nb_logical = (int)((M.nrows + 2 * KK_TPB - 1) / (2 * KK_TPB));
+    const int per = (nb_logical + 7) / 8;
+    const int nbx = std::min(per, KK_MAX_BLOCKS / 8);
+    dim3 g(nbx * 8), b(KK_TPB);
+    int j0 = 0;
+    while (j0 < nb) {
+        const int rem = nb - j0;
+        const double* x = X + (int64_t)j0 * ldx;
+        double* y = Y + (int64_t)j0 * ldy;
+        kk_prof_scope ps(ctx, "k_spmm_ell");
+        if (rem > 8) {
+            const int n = std::min(rem, 16);
+            hipLaunchKernelGGL((k_spmm_ell<16>), g, b, 0, ctx->stream, M.ell_col, M.ell_val, M.ell_ld, M.width, M.nrows, x, ldx, y, ldy, n, nb_logical);
+            j0 += n;
+        } else if (rem > 4) {
+            hipLaunchKernelGGL((k_spmm_ell<8>), g, b, 0, ctx->stream, M.ell_col, M.ell_val, M.ell_ld, M.width, M.nrows, x, ldx, y, ldy, rem, nb_logical);
+            j0 += rem;
+        } else {
+            hipLaunchKernelGGL((k_spmm_ell<4>), g, b, 0, ctx->stream, M.ell_col, M.ell_val, M.ell_ld, M.width, M.nrows, x, ldx, y, ldy, rem, nb_logical);
+            j0 += rem;
+        }
+    }
     KK_HIP(hipGetLastError());
     return KK_OK;
 }

@@ -9,10 +9,11 @@ from ._lib import DimensionMismatch, KrylovHipError, NoDeviceError
 from .core import (ClassicalGramSchmidt, ClassicalGramSchmidt2, ClassicalGramSchmidtIR, Context, DeviceBasis, HipVec,
                    KrylovDefaults, ModifiedGramSchmidt, ModifiedGramSchmidt2, ModifiedGramSchmidtIR, Orthogonalizer,
                    SparseOperator, default_context, device_count)
-from .factorizations import (ArnoldiFactorization, ArnoldiIterator, GKLFactorization, GKLIterator,
+from .factorizations import (ArnoldiFactorization, ArnoldiIterator, Block, BlockLanczosFactorization, BlockLanczosIterator,
+                             GKLFactorization, GKLIterator, block_inner, block_qr_, block_reorthogonalize_,
                              LanczosFactorization, LanczosIterator, expand_, initialize, initialize_, shrink_)
 from . import dist
-from .solvers import GKL, GMRES, ConvergenceInfo, Lanczos, eigsolve, linsolve, svdsolve
+from .solvers import GKL, GMRES, BlockLanczos, ConvergenceInfo, Lanczos, eigsolve, eigsolve_block, linsolve, svdsolve
 
 _lib.load()  # fail at import time if libkrylov_hip.so is missing
 

@@ -103,6 +103,13 @@ SIGNATURES = {
     "kk_arnoldi_initialize": (C.c_int, [c_vp, c_vp, C.c_int, C.c_int, C.c_double, c_dp, c_dp]),
     "kk_gkl_expand": (C.c_int, [c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_double, C.c_double, c_dp, c_dp, c_ip, c_ip]),
     "kk_gkl_initialize": (C.c_int, [c_vp, c_vp, c_vp, c_dp, c_dp]),
+    "kk_block_inner": (C.c_int, [c_vp, C.c_int, C.c_int, c_vp, C.c_int, C.c_int, c_dp, C.c_int]),
+    "kk_block_apply": (C.c_int, [c_vp, c_vp, C.c_int, c_vp, C.c_int, C.c_int]),
+    "kk_block_update": (C.c_int, [c_vp, C.c_int, C.c_int, c_vp, C.c_int, C.c_int, c_dp, C.c_int, C.c_double, C.c_double, c_dp]),
+    "kk_block_qr": (C.c_int, [c_vp, C.c_int, C.c_int, C.c_int, C.c_double, c_dp, C.c_int, c_ip, c_ip, c_ip]),
+    "kk_block_reorthogonalize": (C.c_int, [c_vp, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "kk_blocklanczos_initialize": (C.c_int, [c_vp, c_vp, C.c_int, C.c_int, C.c_int, C.c_double, c_ip, c_dp, C.c_int, c_dp]),
+    "kk_blocklanczos_expand": (C.c_int, [c_vp, c_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, c_ip, c_dp, C.c_int, c_dp, C.c_int, c_dp, c_ip]),
     "kk_apply_fused_dev": (C.c_int, [c_vp, c_vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, c_vp]),
     "kk_project_dev": (C.c_int, [c_vp, C.c_int, C.c_int, c_vp, C.c_int, C.c_int, c_vp]),
     "kk_unproject_dev": (C.c_int, [c_vp, C.c_int, c_vp, C.c_int, C.c_int, c_dp, C.c_double, C.c_double, c_vp]),

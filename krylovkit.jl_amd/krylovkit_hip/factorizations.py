@@ -386,3 +386,129 @@ def _gkl_shrink(st: GKLFactorization, k: int) -> GKLFactorization:
     st.k = k
     HipVec(st.U, k).scale_(st.normres)
     return st
+
+
+# =========================================================================================
+# BlockLanczos -- src/factorizations/blocklanczos.jl
+# =========================================================================================
+@dataclass
+class Block:
+    """Block{T} (blocklanczos.jl:10-17): `size` consecutive columns of a slab."""
+    basis: DeviceBasis
+    col: int
+    size: int
+
+    def __len__(self):
+        return self.size
+
+    def __getitem__(self, i: int) -> HipVec:
+        return HipVec(self.basis, self.col + i)
+
+    def norm(self) -> float:
+        """LinearAlgebra.norm(b::Block) (blocklanczos.jl:37): Frobenius norm."""
+        return float(np.sqrt(sum(self[i].norm() ** 2 for i in range(self.size))))
+
+
+def block_inner(B1: Block, B2: Block) -> np.ndarray:
+    """block_inner (blocklanczos.jl:43-52) -> kk_block_inner."""
+    M = np.zeros((len(B1), len(B2)), order="F")
+    if M.size:
+        check(B1.basis._lib.kk_block_inner(B1.basis.handle, B1.col, len(B1), B2.basis.handle, B2.col, len(B2),
+                                           M.ctypes.data_as(_lib.c_dp), max(len(B1), 1)))
+    return M
+
+
+def block_qr_(block: Block, tol: float, out_col: Optional[int] = None):
+    """block_qr! (blocklanczos.jl:312-353) -> (R[good_idx, :], good_idx, is_drift); the orthonormal
+    vectors end up compacted at columns out_col.. (default: in place)."""
+    p = len(block)
+    out_col = block.col if out_col is None else out_col
+    R = np.zeros((p, p), order="F")
+    good = (C.c_int * p)()
+    ng, drift = C.c_int(), C.c_int()
+    check(block.basis._lib.kk_block_qr(block.basis.handle, block.col, p, out_col, tol, R.ctypes.data_as(_lib.c_dp), p,
+                                       good, C.byref(ng), C.byref(drift)))
+    return R[: ng.value, :].copy(), list(good[: ng.value]), bool(drift.value)
+
+
+def block_reorthogonalize_(R: Block, V: DeviceBasis, m: Optional[int] = None):
+    """block_reorthogonalize! (blocklanczos.jl:277-284)."""
+    m = len(V) if m is None else m
+    check(V._lib.kk_block_reorthogonalize(V.handle, 0, m, R.col, len(R)))
+    return R
+
+
+@dataclass
+class BlockLanczosFactorization:  # blocklanczos.jl:89-96
+    k: int
+    V: DeviceBasis
+    H: np.ndarray
+    r_col: int     # first column of the residual block
+    R_size: int
+    norm_R: float
+    area: tuple = (0, 0)  # the two residual areas of the slab (used alternately)
+
+    def __len__(self):
+        return self.k
+
+    @property
+    def normres(self) -> float:
+        return self.norm_R
+
+    def basis(self) -> DeviceBasis:
+        return self.V
+
+    def residual(self) -> Block:
+        return Block(self.V, self.r_col, self.R_size)
+
+
+@dataclass
+class BlockLanczosIterator:  # blocklanczos.jl:133-157
+    operator: SparseOperator
+    x0: object            # list of numpy vectors (the start block)
+    maxdim: int
+    orth: Orthogonalizer = KrylovDefaults.orth
+    qr_tol: float = KrylovDefaults.tol
+
+    def __post_init__(self):
+        if self.orth.name != "mgs2":
+            raise ValueError("BlockLanczosIterator only supports ModifiedGramSchmidt2 orthogonalizer")  # :154-155
+
+    def initialize(self, V: Optional[DeviceBasis] = None) -> BlockLanczosFactorization:
+        """initialize(iter::BlockLanczosIterator) (blocklanczos.jl:159-198) -> kk_blocklanczos_initialize."""
+        op = self.operator
+        bs0 = len(self.x0)
+        area_a, area_b = self.maxdim, self.maxdim + bs0
+        if V is None:
+            V = DeviceBasis(op.shape[0], self.maxdim + 2 * bs0, op.ctx)
+        for j, x in enumerate(self.x0):
+            _upload_x0(V, x, area_b + j)
+        bs, nr = C.c_int(), C.c_double()
+        M1 = np.zeros((bs0, bs0), order="F")
+        check(V._lib.kk_blocklanczos_initialize(op.handle, V.handle, area_b, bs0, area_a, self.qr_tol, C.byref(bs),
+                                                M1.ctypes.data_as(_lib.c_dp), bs0, C.byref(nr)))
+        b = bs.value
+        H = np.zeros((self.maxdim, self.maxdim))
+        H[:b, :b] = M1[:b, :b]
+        V.length = b
+        return BlockLanczosFactorization(b, V, H, area_a, b, nr.value, (area_a, area_b))
+
+    def expand(self, st: BlockLanczosFactorization) -> BlockLanczosFactorization:
+        """expand!(iter::BlockLanczosIterator, state) (blocklanczos.jl:200-240) -> kk_blocklanczos_expand."""
+        V, k, bs = st.V, st.k, st.R_size
+        c_next = st.area[1] if st.r_col == st.area[0] else st.area[0]
+        B = np.zeros((bs, bs), order="F")
+        M = np.zeros((bs, bs), order="F")
+        bsn, nr, drift = C.c_int(), C.c_double(), C.c_int()
+        check(V._lib.kk_blocklanczos_expand(self.operator.handle, V.handle, k, bs, st.r_col, c_next, self.qr_tol,
+                                            C.byref(bsn), B.ctypes.data_as(_lib.c_dp), bs, M.ctypes.data_as(_lib.c_dp), bs,
+                                            C.byref(nr), C.byref(drift)))
+        n = bsn.value
+        st.H[k:k + n, k - bs:k] = B[:n, :bs]                 # :220
+        st.H[k - bs:k, k:k + n] = B[:n, :bs].T               # :221
+        st.H[k:k + n, k:k + n] = M[:n, :n]                   # :229
+        st.r_col, st.R_size, st.norm_R = c_next, n, nr.value
+        st.k += n
+        V.length = st.k
+        st.last_drift = bool(drift.value)
+        return st

@@ -334,3 +334,96 @@ def svdsolve(A, x0, howmany: int = 1, which: str = "LR", alg: Optional[GKL] = No
         right.append(outV.download(i))
     normres = np.abs(f[:howmany])
     return values, left, right, ConvergenceInfo(converged, None, normres, numiter, numops)
+
+
+# -------------------------------------------------------------------- eigsolve (BlockLanczos)
+@dataclass
+class BlockLanczos:  # algorithms.jl:152-171 (blockkrylovdim default 100, algorithms.jl:561)
+    orth: Orthogonalizer = KrylovDefaults.orth
+    krylovdim: int = 100
+    maxiter: int = KrylovDefaults.maxiter
+    tol: float = KrylovDefaults.tol
+    qr_tol: float = KrylovDefaults.tol
+    eager: bool = False
+    verbosity: int = 0
+
+
+def eigsolve_block(A, x0, howmany: int = 1, which: str = "SR", alg: Optional[BlockLanczos] = None, **kw):
+    """eigsolve(A, x0::Block, howmany, which, alg::BlockLanczos) (src/eigsolve/blocklanczos.jl:1-144).
+    x0: list of numpy start vectors (the Block)."""
+    from .factorizations import Block, BlockLanczosIterator, block_inner
+
+    alg = alg or BlockLanczos(**kw)
+    krylovdim, maxiter, tol = alg.krylovdim, alg.maxiter, alg.tol
+    if howmany > krylovdim:
+        raise ValueError(f"krylov dimension {krylovdim} too small to compute {howmany} eigenvalues")
+    op = _as_operator(A)
+    bs = len(x0)
+    it = BlockLanczosIterator(op, x0, krylovdim + bs, alg.orth, alg.qr_tol)
+    fact = it.initialize()
+    numops = bs + 1
+    numiter = 1
+    converged = 0
+    normresiduals = D = U = None
+    while True:
+        K = len(fact)
+        beta = fact.normres
+        if K >= krylovdim or beta <= tol or (alg.eager and K >= howmany):  # :39
+            BTD = fact.H[:K, :K]
+            D, U = np.linalg.eigh((BTD + BTD.T) / 2)  # eigen(Hermitian(BTD))  :42
+            p = dense.sortperm(D, which)
+            D, U = D[p], np.array(U[:, p])
+            bs_R = fact.R_size
+            r = fact.residual()
+            UU = U[K - bs_R:K, :]
+            Rm = block_inner(r, r)  # :51
+            normresiduals = np.sqrt(np.maximum(np.einsum("ik,ij,jk->k", UU, Rm, UU), 0.0))
+            converged = 0
+            while converged < K and normresiduals[converged] <= tol:
+                converged += 1
+            if converged >= howmany or beta <= tol:
+                break
+        if K < krylovdim:
+            fact = it.expand(fact)
+            numops += fact.R_size
+        else:  # :68-104
+            if numiter >= maxiter:
+                break
+            keep = max((3 * krylovdim + 2 * converged) // (5 * bs), 1) * bs
+            H = np.zeros((keep + bs, keep))
+            for j in range(keep):
+                H[j, j] = D[j]
+                H[keep:, j] = U[K - bs:K, j]
+            for j in range(keep, 0, -1):  # :80-87
+                hb, hv, nu = dense.householder(H[j + bs - 1, :j], j - 1)
+                H[j + bs - 1, j - 1] = nu
+                H[j + bs - 1, : j - 1] = 0.0
+                rr = np.arange(j)
+                dense.lmul_householder(hb, hv, rr, H)
+                dense.rmul_householder(H, hb, hv, rr, slice(0, j + bs - 1))
+                dense.rmul_householder(U, hb, hv, rr)
+            fact.H[:] = 0.0
+            Hk = H[:keep, :keep]
+            fact.H[:keep, :keep] = (Hk + Hk.T) / 2
+            B = fact.basis()
+            B.basistransform(U[:, :keep])  # :92
+            view_H = H[keep + bs - bs_R:keep + bs, keep - bs_R:keep]
+            B.length = fact.r_col + bs_R  # address the residual block as a basis range
+            B.basistransform(np.ascontiguousarray(view_H), c0=fact.r_col)  # basistransform!(R_new, view_H)  :96
+            B.length = keep
+            fact.k = keep
+            numiter += 1
+    hm = howmany
+    if converged > howmany:
+        hm = converged
+    elif len(D) < howmany:
+        hm = len(D)
+    values = D[:hm]
+    K = len(fact)
+    B = fact.basis()
+    out = DeviceBasis(B.n, max(hm, 1), op.ctx)
+    vectors = []
+    for i in range(hm):
+        B.times(U[:, i], HipVec(out, i), 0, K)
+        vectors.append(out.download(i))
+    return values, vectors, ConvergenceInfo(converged, None, normresiduals[:hm], numiter, numops)

@@ -1107,6 +1107,235 @@ def svdsolve_gkl(A, x0: np.ndarray, howmany: int = 1, which: str = "LR", *, kryl
 
 
 # --------------------------------------------------------------------------------------
+# BlockLanczos -- src/factorizations/blocklanczos.jl, src/eigsolve/blocklanczos.jl
+# A Block is a python list of ndarrays.
+# --------------------------------------------------------------------------------------
+def block_inner(B1: Sequence[np.ndarray], B2: Sequence[np.ndarray]) -> np.ndarray:
+    """block_inner (blocklanczos.jl:43-52): M[i,j] = inner(B1[i], B2[j]), p*q scalar calls."""
+    M = np.empty((len(B1), len(B2)))
+    for j in range(len(B2)):
+        for i in range(len(B1)):
+            M[i, j] = inner(B1[i], B2[j])
+    return M
+
+
+def block_norm(B: Sequence[np.ndarray]) -> float:
+    """LinearAlgebra.norm(b::Block) = norm(b.vec) (blocklanczos.jl:37): Frobenius norm."""
+    return math.sqrt(sum(inner(b, b) for b in B))
+
+
+def block_reorthogonalize(R: List[np.ndarray], V: Sequence[np.ndarray]) -> List[np.ndarray]:
+    """block_reorthogonalize! (blocklanczos.jl:277-284): one MGS sweep of every R[i] against V."""
+    for i in range(len(R)):
+        for q in V:
+            R[i], _ = orthogonalize_vec(R[i], q, MGS)
+    return R
+
+
+def block_qr(block: List[np.ndarray], tol: float):
+    """block_qr! (blocklanczos.jl:312-353): in-place MGS QR with rank detection (beta < tol ->
+    zero vector, dropped from good_idx) and one DGKS correction when tol < beta < 100 tol.
+    Returns (R[good_idx, :], good_idx, is_drift)."""
+    n = len(block)
+    is_drift = False
+    idx = [True] * n
+    R = np.zeros((n, n))
+    beta = math.sqrt(inner(block[0], block[0]))
+    if beta > tol:
+        R[0, 0] = beta
+        block[0] = scale_(block[0], 1.0 / beta)
+    else:
+        block[0][:] = 0.0
+        idx[0] = False
+    for j in range(1, n):
+        for i in range(j):  # first MGS  :328-331
+            R[i, j] = inner(block[i], block[j])
+            block[j] = add(block[j], block[i], -R[i, j])
+        beta = norm(block[j])
+        if tol < beta < 100 * tol:  # DGKS  :334-342
+            is_drift = True
+            for i in range(j):
+                d = inner(block[i], block[j])
+                R[i, j] += d
+                block[j] = add(block[j], block[i], -d)
+            beta = norm(block[j])
+        if beta < tol:
+            block[j][:] = 0.0
+            idx[j] = False
+        else:
+            R[j, j] = beta
+            block[j] = scale_(block[j], 1.0 / beta)
+    good = [i for i in range(n) if idx[i]]
+    return R[good, :], good, is_drift
+
+
+@dataclass
+class BlockLanczosFactorization:  # blocklanczos.jl:89-96
+    k: int
+    V: List[np.ndarray]
+    H: np.ndarray
+    R: List[np.ndarray]
+    R_size: int
+    norm_R: float
+
+    def __len__(self):
+        return self.k
+
+    @property
+    def normres(self):
+        return self.norm_R
+
+
+@dataclass
+class BlockLanczosIterator:  # blocklanczos.jl:133-157
+    operator: object
+    x0: List[np.ndarray]
+    maxdim: int
+    orth: Orthogonalizer = MGS2
+    qr_tol: float = 1e-12
+
+    def __post_init__(self):
+        if self.orth.name != "mgs2":
+            raise ValueError("BlockLanczosIterator only supports ModifiedGramSchmidt2 orthogonalizer")
+
+
+def blocklanczos_initialize(it: BlockLanczosIterator) -> BlockLanczosFactorization:
+    """initialize(iter::BlockLanczosIterator) (blocklanczos.jl:159-198)."""
+    X0 = it.x0
+    beta0 = block_norm(X0)
+    if beta0 == 0:
+        raise ValueError("initial vector should not have norm zero")
+    X1 = [np.array(x, dtype=np.float64) for x in X0]
+    _, good, _ = block_qr(X1, it.qr_tol)
+    X1 = [X1[i] for i in good]
+    V = list(X1)
+    bs = len(X1)
+    AX1 = [apply(it.operator, x) for x in X1]
+    M1 = block_inner(X1, AX1)
+    BTD = np.zeros((it.maxdim, it.maxdim))
+    BTD[:bs, :bs] = M1
+    for j in range(bs):
+        for i in range(bs):
+            AX1[j] = add(AX1[j], X1[i], -M1[i, j])
+    return BlockLanczosFactorization(bs, V, BTD, AX1, bs, block_norm(AX1))
+
+
+def block_lanczosrecurrence(operator, V: List[np.ndarray], B: np.ndarray):
+    """block_lanczosrecurrence (blocklanczos.jl:242-263)."""
+    bs, bs_prev = B.shape
+    k = len(V)
+    X = V[k - bs:k]
+    AX = [apply(operator, x) for x in X]
+    M = block_inner(X, AX)
+    Xprev = V[k - bs_prev - bs:k - bs]
+    for j in range(len(X)):
+        for i in range(len(X)):
+            AX[j] = add(AX[j], X[i], -M[i, j])
+        for i in range(len(Xprev)):
+            AX[j] = add(AX[j], Xprev[i], -B[j, i])
+    block_reorthogonalize(AX, V)
+    return AX, M
+
+
+def blocklanczos_expand(it: BlockLanczosIterator, st: BlockLanczosFactorization) -> BlockLanczosFactorization:
+    """expand!(iter::BlockLanczosIterator, state) (blocklanczos.jl:200-240)."""
+    k = st.k
+    R = st.R[: st.R_size]
+    bs = len(R)
+    V = st.V
+    Rcopy = [r.copy() for r in R]
+    B, good, is_drift = block_qr(R, it.qr_tol)
+    if is_drift:  # :212-216
+        block_reorthogonalize(R, V)
+        _, good, is_drift = block_qr(R, it.qr_tol)
+        B = block_inner([R[i] for i in good], Rcopy)
+    bs_next = len(good)
+    V.extend(R[i] for i in good)
+    st.H[k:k + bs_next, k - bs:k] = B[:bs_next, :bs]
+    st.H[k - bs:k, k:k + bs_next] = B[:bs_next, :bs].T
+    Rnext, Mnext = block_lanczosrecurrence(it.operator, V, B)
+    st.H[k:k + bs_next, k:k + bs_next] = Mnext[:bs_next, :bs_next]
+    st.R[:bs_next] = Rnext
+    st.norm_R = block_norm(Rnext)
+    st.k += bs_next
+    st.R_size = bs_next
+    return st
+
+
+def eigsolve_blocklanczos(A, x0: List[np.ndarray], howmany: int = 1, which: str = "SR", *, krylovdim: int = 100,
+                          maxiter: int = 100, tol: float = 1e-12, qr_tol: float = 1e-12, eager: bool = False):
+    """eigsolve(A, x0::Block, howmany, which, alg::BlockLanczos) (src/eigsolve/blocklanczos.jl:1-144)."""
+    if howmany > krylovdim:
+        raise ValueError("krylov dimension too small")
+    bs = len(x0)
+    it = BlockLanczosIterator(A, x0, krylovdim + bs, MGS2, qr_tol)
+    fact = blocklanczos_initialize(it)
+    numops = bs + 1
+    numiter = 1
+    converged = 0
+    normresiduals = D = U = None
+    while True:
+        K = len(fact)
+        beta = fact.normres
+        if K >= krylovdim or beta <= tol or (eager and K >= howmany):  # :39
+            BTD = fact.H[:K, :K]
+            D, U = np.linalg.eigh((BTD + BTD.T) / 2)  # eigen(Hermitian(BTD))
+            p = sortperm(D, which)
+            D, U = D[p], U[:, p]
+            bs_R = fact.R_size
+            r = fact.R[:bs_R]
+            UU = U[K - bs_R:K, :]
+            Rm = block_inner(r, r)
+            normresiduals = np.array([math.sqrt(max(float(UU[:, i] @ Rm @ UU[:, i]), 0.0)) for i in range(K)])
+            converged = 0
+            while converged < K and normresiduals[converged] <= tol:
+                converged += 1
+            if converged >= howmany or beta <= tol:
+                break
+        if K < krylovdim:
+            fact = blocklanczos_expand(it, fact)
+            numops += fact.R_size
+        else:  # :68-104
+            if numiter >= maxiter:
+                break
+            keep = max((3 * krylovdim + 2 * converged) // (5 * bs), 1) * bs
+            H = np.zeros((keep + bs, keep))
+            for j in range(keep):
+                H[j, j] = D[j]
+                H[keep:, j] = U[K - bs:K, j]
+            U = np.array(U)
+            for j in range(keep, 0, -1):  # :80-87
+                hb, hv, nu = householder_vec(H[j + bs - 1, :j], j - 1)  # householder(H, j+bs, 1:j, j)
+                H[j + bs - 1, j - 1] = nu
+                H[j + bs - 1, : j - 1] = 0.0
+                rr = np.arange(j)
+                householder_lmul(hb, hv, rr, H)
+                householder_rmul_mat(H, hb, hv, rr, rows=slice(0, j + bs - 1))
+                householder_rmul_mat(U, hb, hv, rr)
+            fact.H[:] = 0.0
+            Hk = H[:keep, :keep]
+            fact.H[:keep, :keep] = (Hk + Hk.T) / 2
+            basistransform(fact.V, U[:, :keep])  # :92
+            Rnew = list(fact.R[:bs_R])
+            view_H = H[keep + bs - bs_R:keep + bs, keep - bs_R:keep]
+            basistransform(Rnew, view_H)  # :96
+            fact.R[:bs_R] = Rnew[:bs_R]
+            while len(fact.V) > keep:  # the reference pops while length(fact) > keep
+                fact.V.pop()
+            fact.k = keep
+            numiter += 1
+    hm = howmany
+    if converged > howmany:
+        hm = converged
+    elif len(D) < howmany:
+        hm = len(D)
+    values = D[:hm]
+    K = len(fact)
+    vectors = [basis_times(fact.V[:K], U[:, i]) for i in range(hm)]
+    return values, vectors, ConvergenceInfo(converged, None, normresiduals[:hm], numiter, numops)
+
+
+# --------------------------------------------------------------------------------------
 # Synthetic operators of SURVEY.md §8(d) (shared by tests and bench; pure functions of shape/seed)
 # --------------------------------------------------------------------------------------
 def laplacian_2d(nx: int, ny: int, shift_diag: Optional[np.ndarray] = None) -> sp.csr_matrix:

@@ -438,3 +438,163 @@ def test_dist_hip_backend_world1(kk, ko, ctx):
         assert info.converged >= 3 and relerr(vals[:3], ev[:3]) < 1e-10
     finally:
         dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------ BlockLanczos (config 5)
+@pytest.mark.parametrize("block_mode", [0, 1])
+def test_block_primitives(kk, ko, ctx, block_mode):
+    """test/block.jl:74-86 (block_inner), :105-124 (block_reorthogonalize!), :142-161 (block_qr! rank deficiency)."""
+    ctx.set_option("block_mode", block_mode)
+    rng = np.random.default_rng(31)
+    for n, p, q in ((100, 6, 6), (5000, 20, 7), (70001, 37, 16), (3000, 130, 3)):
+        X, Y = rng.standard_normal((n, p)), rng.standard_normal((n, q))
+        S = kk.DeviceBasis(n, p + q, ctx)
+        for j in range(p):
+            S.upload(j, X[:, j])
+        for j in range(q):
+            S.upload(p + j, Y[:, j])
+        M = kk.block_inner(kk.Block(S, 0, p), kk.Block(S, p, q))
+        ref = X.T @ Y
+        assert np.max(np.abs(M - ref)) <= 1e-13 * np.sqrt(n) * np.max(np.abs(ref)) + 1e-12, (n, p, q)
+    # block_reorthogonalize!
+    n, m, q = 4000, 45, 9
+    Qm, _ = np.linalg.qr(rng.standard_normal((n, m)))
+    W = rng.standard_normal((n, q))
+    S = kk.DeviceBasis(n, m + q, ctx)
+    for j in range(m):
+        S.upload(j, Qm[:, j])
+    for j in range(q):
+        S.upload(m + j, W[:, j])
+    S.length = m
+    kk.block_reorthogonalize_(kk.Block(S, m, q), S)
+    Wd = np.stack([S.download(m + j) for j in range(q)], 1)
+    assert np.linalg.norm(Qm.T @ Wd) < 1e-11 * np.linalg.norm(W)
+    Wo = ko.block_reorthogonalize([W[:, j].copy() for j in range(q)], [Qm[:, j] for j in range(m)])
+    np.testing.assert_allclose(Wd, np.stack(Wo, 1), atol=1e-11 * np.linalg.norm(W))
+    # block_qr! with dependent columns, in place and out of place
+    n, p = 3000, 6
+    A = [rng.standard_normal(n) for _ in range(p)]
+    Cc = A + [A[0] + 2 * A[1], A[2] - A[3]]
+    Cm = np.stack(Cc, 1)
+    for out_col in (None, 10):
+        S = kk.DeviceBasis(n, 20, ctx)
+        for j in range(p + 2):
+            S.upload(j, Cm[:, j])
+        R, good, drift = kk.block_qr_(kk.Block(S, 0, p + 2), 1e-10, out_col)
+        Ro, goodo, drifto = ko.block_qr([c.copy() for c in Cc], 1e-10)
+        assert good == goodo and R.shape == Ro.shape == (p, p + 2)
+        c0 = 0 if out_col is None else out_col
+        Qd = np.stack([S.download(c0 + j) for j in range(len(good))], 1)
+        np.testing.assert_allclose(Qd @ R, Cm, atol=1e-10)
+        assert np.max(np.abs(Qd.T @ Qd - np.eye(p))) < 1e-12
+        np.testing.assert_allclose(R, Ro, atol=1e-9 * np.max(np.abs(Ro)))
+        if out_col is not None:  # input block untouched (serves as Rcopy)
+            np.testing.assert_array_equal(S.download(3), Cm[:, 3])
+    ctx.set_option("block_mode", 1)
+
+
+@pytest.mark.parametrize("block_mode", [0, 1])
+def test_block_apply_update(kk, ko, ctx, block_mode):
+    ctx.set_option("block_mode", block_mode)
+    rng = np.random.default_rng(2)
+    for A in (ko.laplacian_2d(37, 23), ko.sparse_random(500, 500, 9, 3)):
+        n = A.shape[0]
+        for nb in (1, 5, 16, 20):
+            X = rng.standard_normal((n, nb))
+            S = kk.DeviceBasis(n, 2 * nb, ctx)
+            for j in range(nb):
+                S.upload(j, X[:, j])
+            op = kk.SparseOperator(A, ctx)
+            from krylovkit_hip._lib import check
+            check(S._lib.kk_block_apply(op.handle, S.handle, 0, S.handle, nb, nb))
+            Y = np.stack([S.download(nb + j) for j in range(nb)], 1)
+            np.testing.assert_allclose(Y, A @ X, rtol=1e-12, atol=1e-12)
+    n, m, q = 2001, 23, 19
+    V, W, Sm = rng.standard_normal((n, m)), rng.standard_normal((n, q)), rng.standard_normal((m, q))
+    S = kk.DeviceBasis(n, m + q, ctx)
+    for j in range(m):
+        S.upload(j, V[:, j])
+    for j in range(q):
+        S.upload(m + j, W[:, j])
+    from krylovkit_hip._lib import check, c_dp
+    Sf = np.asfortranarray(Sm)
+    norms = np.zeros(q)
+    check(S._lib.kk_block_update(S.handle, m, q, S.handle, 0, m, Sf.ctypes.data_as(c_dp), m, -0.5, 2.0, norms.ctypes.data_as(c_dp)))
+    ref = 2.0 * W - 0.5 * V @ Sm
+    Wd = np.stack([S.download(m + j) for j in range(q)], 1)
+    np.testing.assert_allclose(Wd, ref, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(norms, np.linalg.norm(ref, axis=0), rtol=1e-12)
+    ctx.set_option("block_mode", 1)
+
+
+@pytest.mark.parametrize("block_mode", [0, 1])
+def test_blocklanczos_factorization(kk, ko, ctx, block_mode):
+    """test/factorize.jl:387-401: V'V = I, A V = V H + R B' after every expand!; parity of H with the oracle."""
+    ctx.set_option("block_mode", block_mode)
+    nx, ny, bs = 30, 20, 4
+    n = nx * ny
+    A = ko.laplacian_2d(nx, ny, shift_diag=10 * np.linspace(0, 1, n) ** 2)
+    rng = np.random.default_rng(7)
+    x0 = [rng.random(n) for _ in range(bs)]
+    it = kk.BlockLanczosIterator(kk.SparseOperator(A, ctx, symmetric=True), x0, 40 + bs)
+    f = it.initialize()
+    oit = ko.BlockLanczosIterator(A, [x.copy() for x in x0], 40 + bs)
+    of = ko.blocklanczos_initialize(oit)
+    for _ in range(8):
+        f = it.expand(f)
+        of = ko.blocklanczos_expand(oit, of)
+        k = len(f)
+        assert k == len(of) and f.R_size == of.R_size
+        V = f.V.to_numpy()
+        R = np.stack([f.residual()[j].get() for j in range(f.R_size)], 1)
+        H = f.H[:k, :k]
+        E = np.zeros((k, f.R_size)); E[k - f.R_size:, :] = np.eye(f.R_size)
+        assert np.max(np.abs(V.T @ V - np.eye(k))) < 1e-12
+        assert np.max(np.abs(A @ V - V @ H - R @ E.T)) < 1e-10
+        assert abs(f.normres - np.linalg.norm(R)) < 1e-11
+        assert np.max(np.abs(V.T @ R)) < 1e-11
+    # H agrees with the oracle's up to the sign/rotation freedom-free quantities: its spectrum
+    np.testing.assert_allclose(np.linalg.eigvalsh(f.H[:k, :k]), np.linalg.eigvalsh(of.H[:k, :k]), atol=1e-9)
+    np.testing.assert_allclose(np.abs(f.H[:k, :k]), np.abs(of.H[:k, :k]), atol=1e-8)
+    ctx.set_option("block_mode", 1)
+
+
+@pytest.mark.parametrize("block_mode", [0, 1])
+def test_blocklanczos_issue143_known_answer_on_device(kk, ko, ctx, block_mode):
+    """The reference's regression test test/issues.jl:114-128 on the HIP path: all 71 eigenvalues,
+    numiter == 1, numops == length(D) + 1 (rank-deficient last block: 20+20+20+11)."""
+    import scipy.sparse as sps
+    from pathlib import Path
+    ctx.set_option("block_mode", block_mode)
+    A = np.load(Path(__file__).resolve().parent / "golden" / "issue143_A.npy")
+    rng = np.random.default_rng(143)
+    x0 = [rng.standard_normal(71) for _ in range(20)]
+    D, V, info = kk.eigsolve_block(kk.SparseOperator(sps.csr_matrix(A), ctx, symmetric=True), x0, 4, "SR",
+                                   kk.BlockLanczos(tol=1e-8))
+    ev = np.linalg.eigvalsh(A)
+    assert len(D) == len(ev)
+    np.testing.assert_allclose(np.sort(D), ev, rtol=0, atol=1e-10 * np.max(np.abs(ev)))
+    U = np.stack(V, 1)
+    assert np.max(np.abs(A @ U - U * D)) < 1e-9 * np.max(np.abs(ev))
+    assert info.converged == len(D) and info.numiter == 1 and info.numops == len(D) + 1
+    Do, Vo, oinfo = ko.eigsolve_blocklanczos(A, [x.copy() for x in x0], 4, "SR", tol=1e-8)
+    assert (info.numiter, info.numops, info.converged) == (oinfo.numiter, oinfo.numops, oinfo.converged)
+    ctx.set_option("block_mode", 1)
+
+
+def test_eigsolve_block_with_restarts(kk, ko, ctx):
+    """test/eigsolve.jl:551-600 style: BlockLanczos with restarts vs dense eigenvalues and vs the oracle."""
+    nx, ny, bs = 24, 18, 3
+    n = nx * ny
+    A = ko.laplacian_2d(nx, ny, shift_diag=10 * np.linspace(0, 1, n) ** 2)
+    ev = np.linalg.eigvalsh(A.toarray())
+    rng = np.random.default_rng(9)
+    x0 = [rng.random(n) for _ in range(bs)]
+    D, V, info = kk.eigsolve_block(kk.SparseOperator(A, ctx, symmetric=True), x0, 5, "SR",
+                                   kk.BlockLanczos(krylovdim=30, tol=1e-10, maxiter=200))
+    Do, Vo, oinfo = ko.eigsolve_blocklanczos(A, [x.copy() for x in x0], 5, "SR", krylovdim=30, tol=1e-10, maxiter=200)
+    assert info.converged >= 5
+    assert relerr(D[:5], ev[:5]) < 1e-10 and relerr(D[:5], Do[:5]) < 1e-10
+    assert (info.numiter, info.numops) == (oinfo.numiter, oinfo.numops)
+    for lam, v in zip(D[:5], V[:5]):
+        assert np.linalg.norm(A @ v - lam * v) < 1e-8

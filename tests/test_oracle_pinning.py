@@ -260,3 +260,66 @@ def test_small_dense_helpers(ko):
         for i in range(1, min(j + 1, k) + 1):
             assert ko.packed_index(i, j) == off
             off += 1
+
+
+def test_blocklanczos_issue143_known_answer(ko):
+    """test/issues.jl:114-128 verbatim: eigsolve(A, Block of 20 randn(71), 4, :SR, BlockLanczos(tol=1e-8))
+    returns ALL 71 eigenvalues with numiter == 1 and numops == length(D) + 1."""
+    A = np.load(GOLD / "issue143_A.npy")
+    rng = np.random.default_rng(143)
+    x0 = [rng.standard_normal(71) for _ in range(20)]
+    D, V, info = ko.eigsolve_blocklanczos(A, x0, 4, "SR", tol=1e-8)
+    ev = np.linalg.eigvalsh(A)
+    assert len(D) == len(ev)
+    np.testing.assert_allclose(np.sort(D), ev, rtol=0, atol=TOL * np.max(np.abs(ev)))
+    U = np.stack(V, 1)
+    assert np.max(np.abs(A @ U - U * D)) < TOL * np.max(np.abs(ev)) * 10
+    assert info.converged == len(D)
+    assert info.numiter == 1
+    assert info.numops == len(D) + 1
+    assert np.max(info.normres) < TOL
+
+
+def test_blocklanczos_toric_code_known_answer(ko):
+    """test/eigsolve.jl:537-543: exactly 4 of the 10 lowest eigenvalues of -H equal -16 (block size 5)."""
+    H = toric_code_hamiltonian(3, 3)
+    rng = np.random.default_rng(5)
+    x0 = [rng.random(H.shape[0]) for _ in range(5)]
+    tol = 1e-6
+    D, U, info = ko.eigsolve_blocklanczos(-H, x0, 10, "SR", tol=tol, maxiter=1)
+    assert np.sum(np.abs(D[:10] + 16.0) < 2.0 - tol) == 4
+    assert np.sum(np.abs(D[:10] + 16.0) < tol) == 4
+
+
+def test_blocklanczos_bs1_equals_lanczos(ko):
+    """test/eigsolve.jl:685-715: BlockLanczos with block size 1 == Lanczos (values, numops + 1)."""
+    n = 100
+    A = rand_sym(n, 21)
+    x0 = np.random.default_rng(22).random(n)
+    D1, V1, i1 = ko.eigsolve_lanczos(A, x0, 3, "SR", krylovdim=30, tol=1e-10, maxiter=50, orth=ko.MGS2)
+    D2, V2, i2 = ko.eigsolve_blocklanczos(A, [x0.copy()], 3, "SR", krylovdim=30, tol=1e-10, maxiter=50)
+    assert i1.converged >= 3 and i2.converged >= 3
+    np.testing.assert_allclose(D1[:3], D2[:3], rtol=0, atol=TOL)
+    assert i1.numiter == i2.numiter
+    assert i1.numops + 1 == i2.numops
+
+
+def test_block_primitives(ko):
+    """test/block.jl:74-86,105-124,142-161."""
+    rng = np.random.default_rng(31)
+    n, p = 100, 6
+    A = [rng.standard_normal(n) for _ in range(p)]
+    B = [rng.standard_normal(n) for _ in range(p)]
+    np.testing.assert_allclose(ko.block_inner(A, B), np.stack(A, 1).T @ np.stack(B, 1), atol=1e-12)
+    Q, _ = np.linalg.qr(rng.standard_normal((n, 10)))
+    b0 = [Q[:, j].copy() for j in range(10)]
+    b1 = ko.block_reorthogonalize([a.copy() for a in A], b0)
+    assert np.linalg.norm(ko.block_inner(b0, b1)) < TOL
+    # rank-deficient block: Q*R ~ A, Q'Q ~ I, fewer good columns
+    C = [a.copy() for a in A] + [A[0] + 2 * A[1], A[2] - A[3]]
+    Cm = np.stack(C, 1)
+    R, good, drift = ko.block_qr(C, 1e-10)
+    assert len(good) == p and R.shape == (p, p + 2)
+    Qm = np.stack([C[i] for i in good], 1)
+    np.testing.assert_allclose(Qm @ R, Cm, atol=1e-10)
+    assert np.max(np.abs(Qm.T @ Qm - np.eye(p))) < 1e-12
