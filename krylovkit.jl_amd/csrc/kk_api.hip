@@ -124,6 +124,8 @@ extern "C" int kk_ctx_set_option(kk_ctx c, const char* key, double value) {
     } else if (!strcmp(key, "mgs_mode")) {
         KK_CHECK(value == 0 || value == 1, KK_ERR_INVALID, "mgs_mode must be 0 (strict) or 1 (lowsync)");
         c->mgs_mode = (int)value;
+    } else if (!strcmp(key, "fuse_passes")) {
+        c->fuse_passes = value != 0;
     } else if (!strcmp(key, "block_mode")) {
         KK_CHECK(value == 0 || value == 1, KK_ERR_INVALID, "block_mode must be 0 (strict) or 1 (panel)");
         c->block_mode = (int)value;
@@ -139,6 +141,7 @@ extern "C" int kk_ctx_get_option(kk_ctx c, const char* key, double* value) {
     else if (!strcmp(key, "mgs_mode")) *value = c->mgs_mode;
     else if (!strcmp(key, "num_cus")) *value = c->num_cus;
     else if (!strcmp(key, "block_mode")) *value = c->block_mode;
+    else if (!strcmp(key, "fuse_passes")) *value = c->fuse_passes;
     else {
         kk_set_error("unknown option '%s'", key);
         return KK_ERR_INVALID;
@@ -790,11 +793,25 @@ static int orth_run(kk_basis b, int c0, int m, double* w, kk_orth_t alg, double 
             passes = 1;
         } break;
         case KK_CGS2: {  // :394-399
-            KK_TRY(pass_cgs(c, V, ld, m, w, false, 0));
-            KK_TRY(pass_cgs(c, V, ld, m, w, want_norm, 1));
-            KK_TRY(stream_sync(c));
-            for (int j = 0; j < m; ++j) x[j] = pin(c, WS_S, 0)[j] + pin(c, WS_S, 1)[j];
-            nn = pin(c, WS_SCAL + SC_NRM2, 1)[1];
+            if (c->fuse_passes && m <= 128) {
+                // s1 = V'w ; [w1 = w - V s1 ; s2 = V'w1] fused (V read once) ; w2 = w1 - V s2 (+ norm)
+                KK_TRY(kk_launch_project(c, V, ld, m, w, nullptr, nullptr, nullptr, WSP(c, WS_S), WSP(c, WS_G)));
+                KK_TRY(ws_fetch_async(c, WS_S, m, 0));
+                KK_TRY(kk_launch_unproj_proj(c, V, ld, m, w, w, nullptr, WSP(c, WS_S), WSP(c, WS_G), nullptr));
+                KK_TRY(ws_fetch_async(c, WS_G, m, 0));
+                KK_TRY(kk_launch_unproject(c, V, ld, m, w, w, nullptr, WSP(c, WS_G), -1.0, 1.0, -1, nullptr,
+                                           want_norm ? SCP(c, SC_NRM2) : nullptr));
+                if (want_norm) KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2, 2, 0));
+                KK_TRY(stream_sync(c));
+                for (int j = 0; j < m; ++j) x[j] = pin(c, WS_S, 0)[j] + pin(c, WS_G, 0)[j];
+                nn = pin(c, WS_SCAL + SC_NRM2, 0)[1];
+            } else {
+                KK_TRY(pass_cgs(c, V, ld, m, w, false, 0));
+                KK_TRY(pass_cgs(c, V, ld, m, w, want_norm, 1));
+                KK_TRY(stream_sync(c));
+                for (int j = 0; j < m; ++j) x[j] = pin(c, WS_S, 0)[j] + pin(c, WS_S, 1)[j];
+                nn = pin(c, WS_SCAL + SC_NRM2, 1)[1];
+            }
             passes = 2;
         } break;
         case KK_CGSIR: {  // :400-412
@@ -828,7 +845,25 @@ static int orth_run(kk_basis b, int c0, int m, double* w, kk_orth_t alg, double 
             passes = 1;
         } break;
         case KK_MGS2: {  // :434-439
-            if (lowsync) {
+            if (lowsync && c->fuse_passes && m <= 128) {
+                // p1 = V'w -> s1 = (I+L)^-1 p1 ; [w1 = w - V s1 ; p2 = V'w1] fused ; s2 = (I+L)^-1 p2 ; w2 = w1 - V s2
+                KK_TRY(lowsync_project(b, c0, m, w, nullptr, nullptr, 0));
+                kk_coef ch;
+                memset(&ch, 0, sizeof(ch));
+                memcpy(ch.v, pin(c, WS_S, 0), m * sizeof(double));
+                gram_solve(b, c0, m, ch.v);
+                memcpy(x, ch.v, m * sizeof(double));
+                KK_TRY(kk_launch_unproj_proj(c, V, ld, m, w, w, &ch, nullptr, WSP(c, WS_G), nullptr));
+                KK_TRY(ws_fetch_async(c, WS_G, m, 0));
+                KK_TRY(stream_sync(c));
+                memcpy(ch.v, pin(c, WS_G, 0), m * sizeof(double));
+                gram_solve(b, c0, m, ch.v);
+                for (int j = 0; j < m; ++j) x[j] += ch.v[j];
+                KK_TRY(kk_launch_unproject(c, V, ld, m, w, w, &ch, nullptr, -1.0, 1.0, -1, nullptr,
+                                           want_norm ? SCP(c, SC_NRM2) : nullptr));
+                if (want_norm) KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2, 2, 0));
+                KK_TRY(stream_sync(c));
+            } else if (lowsync) {
                 KK_TRY(pass_mgs_lowsync(b, c0, m, w, x, false, 0));
                 KK_TRY(pass_mgs_lowsync(b, c0, m, w, tmp.data(), want_norm, 0));
                 KK_TRY(stream_sync(c));
@@ -1394,9 +1429,105 @@ extern "C" int kk_block_reorthogonalize(kk_basis b, int c0, int m, int cw, int q
     return block_reorth_run(b, c0, m, cw, q);
 }
 
-// block_qr! (blocklanczos.jl:312-353), faithful column-by-column MGS with DGKS and rank detection.
+// ---- small dense helpers for the CholQR2 fast path (p <= 64, host) -------------------------
+// upper Cholesky G = R'R (column-major p x p); returns false if a pivot is not safely positive:
+// pivot^2 must exceed rel^2 * G_jj and abs_min^2
+static bool chol_upper_safe(const std::vector<double>& G, int p, std::vector<double>& R, double rel, double abs_min) {
+    R.assign((size_t)p * p, 0.0);
+    for (int j = 0; j < p; ++j) {
+        for (int i = 0; i < j; ++i) {
+            double t = G[i + (size_t)p * j];
+            for (int k = 0; k < i; ++k) t -= R[k + (size_t)p * i] * R[k + (size_t)p * j];
+            R[i + (size_t)p * j] = t / R[i + (size_t)p * i];
+        }
+        double d2 = G[j + (size_t)p * j];
+        for (int k = 0; k < j; ++k) d2 -= R[k + (size_t)p * j] * R[k + (size_t)p * j];
+        const double gjj = G[j + (size_t)p * j];
+        if (!(d2 > rel * rel * gjj) || !(d2 > abs_min * abs_min) || !std::isfinite(d2)) return false;
+        R[j + (size_t)p * j] = std::sqrt(d2);
+    }
+    return true;
+}
+static void triu_inverse(const std::vector<double>& R, int p, std::vector<double>& Ri) {
+    Ri.assign((size_t)p * p, 0.0);
+    for (int j = 0; j < p; ++j) {
+        Ri[j + (size_t)p * j] = 1.0 / R[j + (size_t)p * j];
+        for (int i = j - 1; i >= 0; --i) {
+            double t = 0;
+            for (int k = i + 1; k <= j; ++k) t += R[i + (size_t)p * k] * Ri[k + (size_t)p * j];
+            Ri[i + (size_t)p * j] = -t / R[i + (size_t)p * i];
+        }
+    }
+}
+
+static int block_qr_strict(kk_basis b, int c_in, int p, int c_out, double tol, double* R, int ldr, int* good_idx, int* ngood,
+                           int* is_drift);
+
+// block_qr! (blocklanczos.jl:312-353).  Panel mode, out of place: CholQR2 on the MFMA Gram panel
+//   G = B'B -> R1 = chol(G) -> Q1 = B R1^-1 -> G2 = Q1'Q1 -> R2 = chol(G2) -> Q = Q1 R2^-1, R = R2 R1
+// (768 N bytes instead of ~240 p N for the column-by-column sweep).  It is taken only when every
+// Cholesky pivot is safely away from the reference's rank / DGKS thresholds (beta_j > 1000 tol and
+// beta_j > 1e-5 |b_j|), in which case the reference's block_qr! keeps every column and does not
+// drift; otherwise the faithful column-by-column path below runs on the untouched input.
 static int block_qr_run(kk_basis b, int c_in, int p, int c_out, double tol, double* R, int ldr, int* good_idx, int* ngood,
                         int* is_drift) {
+    kk_ctx c = b->ctx;
+    if (c->block_mode == 1 && c_out != c_in && p <= 64 && p >= 2) {
+        const int64_t ld = b->ld;
+        std::vector<double> G((size_t)p * p), R1, R2, Ri;
+        KK_TRY(block_inner_run(c, b->col(c_in), ld, p, b->col(c_in), ld, p, ld, G.data(), p));
+        if (chol_upper_safe(G, p, R1, 1e-5, 1000.0 * tol)) {
+            triu_inverse(R1, p, Ri);
+            // Q1 = B * R1^-1 (out of place)
+            for (int j0 = 0; j0 < p; j0 += 16) {
+                const int nb = std::min(16, p - j0);
+                KK_TRY(stream_sync(c));
+                for (int i = 0; i < p; ++i)
+                    for (int j = 0; j < nb; ++j) c->h_blk[(size_t)i * nb + j] = Ri[i + (size_t)p * (j0 + j)];
+                KK_HIP(hipMemcpyAsync(c->blk, c->h_blk, (size_t)p * nb * sizeof(double), hipMemcpyHostToDevice, c->stream));
+                KK_TRY(kk_launch_block_update(c, b->col(c_in), ld, p, nullptr, b->col(c_out + j0), ld, ld, nb, c->blk, 1.0, 0.0,
+                                              nullptr));
+            }
+            KK_TRY(block_inner_run(c, b->col(c_out), ld, p, b->col(c_out), ld, p, ld, G.data(), p));
+            double dev = 0;
+            for (int j = 0; j < p; ++j)
+                for (int i = 0; i < p; ++i) dev = std::max(dev, std::fabs(G[i + (size_t)p * j] - (i == j ? 1.0 : 0.0)));
+            if (dev < 1e-3 && chol_upper_safe(G, p, R2, 1e-2, 0.0)) {
+                triu_inverse(R2, p, Ri);
+                // Q = Q1 * R2^-1: needs all p input columns per row before any write -> via scratch columns
+                // is avoided by processing in ONE launch per 16 output columns reading the old values:
+                // output columns j0.. only depend on input columns <= j0+15 (upper-triangular), and
+                // are written after the kernel has read them (row-local), so go right-to-left.
+                for (int j0 = ((p - 1) / 16) * 16; j0 >= 0; j0 -= 16) {
+                    const int nb = std::min(16, p - j0);
+                    const int mm = j0 + nb;  // rows of R2^-1 that can be non-zero for these columns
+                    KK_TRY(stream_sync(c));
+                    for (int i = 0; i < mm; ++i)
+                        for (int j = 0; j < nb; ++j) c->h_blk[(size_t)i * nb + j] = Ri[i + (size_t)p * (j0 + j)];
+                    KK_HIP(hipMemcpyAsync(c->blk, c->h_blk, (size_t)mm * nb * sizeof(double), hipMemcpyHostToDevice, c->stream));
+                    KK_TRY(kk_launch_block_update(c, b->col(c_out), ld, mm, nullptr, b->col(c_out + j0), ld, ld, nb, c->blk, 1.0,
+                                                  0.0, nullptr));
+                }
+                // R = R2 * R1
+                for (int j = 0; j < p; ++j)
+                    for (int i = 0; i < p; ++i) {
+                        double t = 0;
+                        for (int k = i; k <= j; ++k) t += R2[i + (size_t)p * k] * R1[k + (size_t)p * j];
+                        R[i + (size_t)ldr * j] = (i <= j) ? t : 0.0;
+                    }
+                for (int j = 0; j < p; ++j) good_idx[j] = j;
+                *ngood = p;
+                if (is_drift) *is_drift = 0;
+                return KK_OK;
+            }
+        }
+    }
+    return block_qr_strict(b, c_in, p, c_out, tol, R, ldr, good_idx, ngood, is_drift);
+}
+
+// faithful column-by-column MGS with DGKS and rank detection (blocklanczos.jl:312-353)
+static int block_qr_strict(kk_basis b, int c_in, int p, int c_out, double tol, double* R, int ldr, int* good_idx, int* ngood,
+                           int* is_drift) {
     kk_ctx c = b->ctx;
     const int64_t ld = b->ld;
     std::vector<double> Rf((size_t)p * p, 0.0);  // full p x p, column-major

@@ -193,3 +193,5 @@ int kk_launch_block_gram(kk_ctx ctx, const double* X, int64_t ldx, int p, const 
 int kk_launch_block_update(kk_ctx ctx, const double* V, int64_t ld, int m, const double* Win, double* Wout, int64_t ldw_in,
                            int64_t ldw_out, int nb, const double* S_dev, double alpha, double beta, double* norms2_dev);
 int kk_launch_spmm(kk_ctx ctx, const kk_sparse_dev& M, const double* X, int64_t ldx, double* Y, int64_t ldy, int nb);
+int kk_launch_unproj_proj(kk_ctx ctx, const double* V, int64_t ld, int m, const double* w_in, double* w_out,
+                          const kk_coef* coef_host, const double* coef_dev, double* out_s, double* nrm_out3);

@@ -354,6 +354,74 @@ __global__ __launch_bounds__(KK_TPB) void k_unproject(const double* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------
+// fused  unproject(pass i) + project(pass i+1):   w1 = w - V c ;  s2 = V' w1      (V read ONCE)
+// For the 2-pass orthogonalisers (CGS2 / low-sync MGS2, orthonormal.jl:394-399,434-439) this turns
+// 4 sweeps over the basis into 3.  A block holds a 128-row x m tile of V in registers: wave v owns
+// columns v, v+4, v+8, ... (CT per wave), every lane 2 rows (16 B, 1 KiB contiguous per wave load).
+//   step 1: per-wave partial of (V c) over its columns -> LDS -> all waves get w1 for the 128 rows
+//   step 2: every wave dots ITS columns (still in registers) with w1 -> per-lane accumulators
+// ------------------------------------------------------------------------------------------
+template <int CT>
+__global__ __launch_bounds__(KK_TPB) void k_unproj_proj(const double* __restrict__ V, int64_t ld, int m, const double* w_in,
+                                                        double* w_out, kk_coef ch, const double* __restrict__ coef_dev,
+                                                        int64_t rpb, double* __restrict__ part, double* __restrict__ part_nrm) {
+    __shared__ d2 red[4][64];
+    __shared__ double sc[KK_MAX_M];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < m) sc[tid] = -(coef_dev ? coef_dev[tid] : ch.v[tid]);
+    __syncthreads();
+    const int64_t r0 = (int64_t)blockIdx.x * rpb, r1 = imin(r0 + rpb, ld);
+    double acc[CT];
+#pragma unroll
+    for (int i = 0; i < CT; ++i) acc[i] = 0.0;
+    double nacc = 0.0;
+    for (int64_t r = r0 + lane * 2; r < r1; r += 128) {
+        d2 x[CT];
+        d2 u{0.0, 0.0};
+#pragma unroll
+        for (int i = 0; i < CT; ++i) {
+            const int c = wave + 4 * i;
+            if (c < m) x[i] = ld2(V + (int64_t)c * ld + r);
+            else x[i] = d2{0.0, 0.0};
+        }
+        d2 wv = ld2(w_in + r);
+#pragma unroll
+        for (int i = 0; i < CT; ++i) {
+            const int c = wave + 4 * i;
+            if (c < m) {
+                const double s = sc[c];
+                u.x = fma(s, x[i].x, u.x); u.y = fma(s, x[i].y, u.y);
+            }
+        }
+        red[wave][lane] = u;
+        __syncthreads();
+        const d2 a = red[0][lane], b = red[1][lane], cc = red[2][lane], d = red[3][lane];
+        wv.x += (a.x + b.x) + (cc.x + d.x);
+        wv.y += (a.y + b.y) + (cc.y + d.y);
+        if (wave == 0) {
+            st2(w_out + r, wv);
+            nacc = fma(wv.x, wv.x, nacc); nacc = fma(wv.y, wv.y, nacc);
+        }
+#pragma unroll
+        for (int i = 0; i < CT; ++i) {
+            acc[i] = fma(x[i].x, wv.x, acc[i]);
+            acc[i] = fma(x[i].y, wv.y, acc[i]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < CT; ++i) {
+        const int c = wave + 4 * i;
+        const double tot = wave_sum(acc[i]);
+        if (c < m && lane == 0) part[(int64_t)c * KK_MAX_BLOCKS + blockIdx.x] = tot;
+    }
+    if (part_nrm && wave == 0) {
+        const double tn = wave_sum(nacc);
+        if (lane == 0) part_nrm[blockIdx.x] = tn;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // strict modified Gram-Schmidt step (src/orthonormal.jl:417-421), fused across the j boundary:
 //   w -= s_prev * q_prev   (axpy of step j-1, skipped if q_prev == nullptr)
 //   partial <q_next, w>    (dot of step j, skipped if q_next == nullptr)
@@ -708,7 +776,7 @@ __global__ __launch_bounds__(KK_TPB) void k_finalize_gram(const double* __restri
 // (three-term block update, block_reorthogonalize! panel update, CholQR back-substitution).
 // S lives in device memory (scalar loads); fused column norms |W_j|^2 -> partials.
 template <int NB, bool BZERO>
-__global__ __launch_bounds__(KK_TPB) void k_block_update(const double* __restrict__ V, int64_t ld, int m, const double* Win,
+__global__ __launch_bounds__(KK_TPB) void k_block_update(const double* V, int64_t ld, int m, const double* Win,
                                                          double* Wout, int64_t ldw_in, int64_t ldw_out, int nb,
                                                          const double* __restrict__ S, double alpha, double beta,
                                                          int64_t rpb, double* __restrict__ part_nrm) {
@@ -1135,5 +1203,34 @@ int kk_launch_spmm(kk_ctx ctx, const kk_sparse_dev& M, const double* X, int64_t 
         }
     }
     KK_HIP(hipGetLastError());
+    return KK_OK;
+}
+
+// fused w_out = w_in - V c ; out_s = V' w_out  (m <= 128).  Optional |w_out|^2 -> nrm_out3.
+int kk_launch_unproj_proj(kk_ctx ctx, const double* V, int64_t ld, int m, const double* w_in, double* w_out,
+                          const kk_coef* coef_host, const double* coef_dev, double* out_s, double* nrm_out3) {
+    if (m > 128) { kk_set_error("kk_launch_unproj_proj: m=%d > 128", m); return KK_ERR_INVALID; }
+    // rows per block: multiple of 512 (128 | 512); cap the grid so the per-column partial rows fit
+    kk_part p = kk_partition(ctx, ld);
+    static const kk_coef zero_coef = {};
+    const kk_coef& ch = coef_host ? *coef_host : zero_coef;
+    double* part = ctx->partials;
+    double* pn = part_row(ctx, PART_SCAL_A);
+    dim3 g(p.nblk), b(KK_TPB);
+    const int ct = (m + 3) / 4;
+    {
+        kk_prof_scope ps(ctx, "k_unproj_proj");
+#define UP_CASE(CTT) hipLaunchKernelGGL((k_unproj_proj<CTT>), g, b, 0, ctx->stream, V, ld, m, w_in, w_out, ch, coef_dev, p.rpb, part, nrm_out3 ? pn : (double*)nullptr)
+        if (ct <= 4) UP_CASE(4);
+        else if (ct <= 8) UP_CASE(8);
+        else if (ct <= 16) UP_CASE(16);
+        else if (ct <= 24) UP_CASE(24);
+        else UP_CASE(32);
+#undef UP_CASE
+    }
+    KK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_finalize_project, dim3((m + 3) / 4), dim3(KK_TPB), 0, ctx->stream, part, p.nblk, m, out_s, (double*)nullptr);
+    KK_HIP(hipGetLastError());
+    if (nrm_out3) return finalize_scalar(ctx, PART_SCAL_A, p.nblk, nrm_out3, true);
     return KK_OK;
 }
