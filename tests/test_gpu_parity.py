@@ -598,3 +598,31 @@ def test_eigsolve_block_with_restarts(kk, ko, ctx):
     assert (info.numiter, info.numops) == (oinfo.numiter, oinfo.numops)
     for lam, v in zip(D[:5], V[:5]):
         assert np.linalg.norm(A @ v - lam * v) < 1e-8
+
+
+@pytest.mark.parametrize("n,m", [(300, 5), (5000, 33), (40000, 61), (20000, 100), (9000, 128), (9000, 130)])
+def test_fused_unproject_project_matches_unfused(kk, ko, ctx, n, m):
+    """The fused [w -= V s1 ; s2 = V'w] kernel (V read once) against the two separate passes, CGS2 and MGS2."""
+    rng = np.random.default_rng(n + m)
+    Q, _ = np.linalg.qr(rng.standard_normal((n, m)))
+    w0 = Q @ rng.standard_normal(m) * 20 + rng.standard_normal(n)
+    res = {}
+    for fuse in (0, 1):
+        ctx.set_option("fuse_passes", fuse)
+        for dev in (kk.ClassicalGramSchmidt2(), kk.ModifiedGramSchmidt2()):
+            B = kk.DeviceBasis(n, m + 1, ctx)
+            for j in range(m):
+                B.upload(j, Q[:, j])
+            B.length = m
+            vw = B[m].set(w0)
+            x, nrm, passes = B.orthogonalize(vw, dev)
+            res[(fuse, dev.name)] = (x.copy(), nrm, vw.get())
+            assert passes == 2
+    ctx.set_option("fuse_passes", 1)
+    for name in ("cgs2", "mgs2"):
+        x0_, n0, w0_ = res[(0, name)]
+        x1_, n1, w1_ = res[(1, name)]
+        assert np.max(np.abs(x0_ - x1_)) <= 1e-12 * np.linalg.norm(w0)
+        assert abs(n0 - n1) <= 1e-12 * n0
+        np.testing.assert_allclose(w0_, w1_, rtol=0, atol=1e-12 * np.linalg.norm(w0))
+        assert np.max(np.abs(Q.T @ w1_)) < 1e-12 * np.linalg.norm(w0)
