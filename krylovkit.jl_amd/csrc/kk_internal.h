@@ -64,7 +64,7 @@ struct kk_ctx_s {
     double* blk = nullptr;       // device scratch for small block matrices [KK_BLK_SCRATCH]
     double* h_blk = nullptr;     // pinned twin of blk
     int block_mode = 1;          // 0 strict, 1 panel (MFMA gram + multi-rhs update)
-    int blocks_per_cu = 8;
+    int blocks_per_cu = 4;       // 4 resident 256-thread blocks per CU (measured best on the 10M-row sweep)
     int mgs_mode = 1;
     int fuse_passes = 1;         // fuse unproject(pass i) with project(pass i+1)
     hipEvent_t t0 = nullptr, t1 = nullptr;
