@@ -752,7 +752,7 @@ __global__ __launch_bounds__(KK_TPB) void k_block_gram(const double* __restrict_
             if (col < p) {
                 const double* xp = X + (int64_t)col * ldx + row;
 #pragma unroll
-                for (int t = 0; t < BG_T; t += 2) { d2 v = ld2s(xp + t); xv[t] = v.x; xv[t + 1] = v.y; }
+                for (int t = 0; t < BG_T; t += 2) { d2 v = ld2(xp + t); xv[t] = v.x; xv[t + 1] = v.y; }  // plain: X == Y panels re-hit L2
             } else {
 #pragma unroll
                 for (int t = 0; t < BG_T; ++t) xv[t] = 0.0;
