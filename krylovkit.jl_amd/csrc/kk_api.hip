@@ -124,6 +124,8 @@ extern "C" int kk_ctx_set_option(kk_ctx c, const char* key, double value) {
     } else if (!strcmp(key, "mgs_mode")) {
         KK_CHECK(value == 0 || value == 1, KK_ERR_INVALID, "mgs_mode must be 0 (strict) or 1 (lowsync)");
         c->mgs_mode = (int)value;
+    } else if (!strcmp(key, "speculate")) {
+        c->speculate = value != 0;
     } else if (!strcmp(key, "fuse_passes")) {
         c->fuse_passes = value != 0;
     } else if (!strcmp(key, "block_mode")) {
@@ -142,6 +144,7 @@ extern "C" int kk_ctx_get_option(kk_ctx c, const char* key, double* value) {
     else if (!strcmp(key, "num_cus")) *value = c->num_cus;
     else if (!strcmp(key, "block_mode")) *value = c->block_mode;
     else if (!strcmp(key, "fuse_passes")) *value = c->fuse_passes;
+    else if (!strcmp(key, "speculate")) *value = c->speculate;
     else {
         kk_set_error("unknown option '%s'", key);
         return KK_ERR_INVALID;
@@ -283,6 +286,7 @@ extern "C" int kk_basis_info(kk_basis b, int64_t* n, int64_t* ld, int* capacity,
 #define CHECK_COL(b, c) KK_CHECK((b) && (c) >= 0 && (c) < (b)->cap, KK_ERR_INVALID, "%s: column %d out of range", __func__, (c))
 static inline void gram_touch(kk_basis b, int col) {
     if (col < b->gram_rows) b->gram_rows = col;
+    b->spec_valid = false;  // any mutation of the slab cancels a speculative next-step SpMV
 }
 extern "C" int kk_basis_invalidate_gram(kk_basis b) {
     KK_CHECK(b, KK_ERR_INVALID, "null basis");
@@ -764,6 +768,7 @@ static int pass_mgs_lowsync(kk_basis b, int c0, int m, double* w, double* s_out,
 
 // orthogonalize!!(w, b[c0:c0+m), x, alg) -- all six algorithms (orthonormal.jl:378-452).
 // On return x[0..m) holds the accumulated coefficients; *nrm = |w| if want_norm.
+static int final_sync(kk_ctx c);
 static int orth_run(kk_basis b, int c0, int m, double* w, kk_orth_t alg, double eta, double* x, double* nrm,
                     int* npasses, bool want_norm) {
     kk_ctx c = b->ctx;
@@ -787,7 +792,7 @@ static int orth_run(kk_basis b, int c0, int m, double* w, kk_orth_t alg, double 
     switch (alg) {
         case KK_CGS: {
             KK_TRY(pass_cgs(c, V, ld, m, w, want_norm, 0));
-            KK_TRY(stream_sync(c));
+            KK_TRY(final_sync(c));
             memcpy(x, pin(c, WS_S, 0), m * sizeof(double));
             nn = pin(c, WS_SCAL + SC_NRM2, 0)[1];
             passes = 1;
@@ -802,13 +807,13 @@ static int orth_run(kk_basis b, int c0, int m, double* w, kk_orth_t alg, double 
                 KK_TRY(kk_launch_unproject(c, V, ld, m, w, w, nullptr, WSP(c, WS_G), -1.0, 1.0, -1, nullptr,
                                            want_norm ? SCP(c, SC_NRM2) : nullptr));
                 if (want_norm) KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2, 2, 0));
-                KK_TRY(stream_sync(c));
+                KK_TRY(final_sync(c));
                 for (int j = 0; j < m; ++j) x[j] = pin(c, WS_S, 0)[j] + pin(c, WS_G, 0)[j];
                 nn = pin(c, WS_SCAL + SC_NRM2, 0)[1];
             } else {
                 KK_TRY(pass_cgs(c, V, ld, m, w, false, 0));
                 KK_TRY(pass_cgs(c, V, ld, m, w, want_norm, 1));
-                KK_TRY(stream_sync(c));
+                KK_TRY(final_sync(c));
                 for (int j = 0; j < m; ++j) x[j] = pin(c, WS_S, 0)[j] + pin(c, WS_S, 1)[j];
                 nn = pin(c, WS_SCAL + SC_NRM2, 1)[1];
             }
@@ -835,10 +840,10 @@ static int orth_run(kk_basis b, int c0, int m, double* w, kk_orth_t alg, double 
         case KK_MGS: {
             if (lowsync) {
                 KK_TRY(pass_mgs_lowsync(b, c0, m, w, x, want_norm, 0));
-                KK_TRY(stream_sync(c));
+                KK_TRY(final_sync(c));
             } else {
                 KK_TRY(pass_mgs_strict(c, V, ld, m, w, WS_S, want_norm, 0, nullptr, nullptr, false));
-                KK_TRY(stream_sync(c));
+                KK_TRY(final_sync(c));
                 memcpy(x, pin(c, WS_S, 0), m * sizeof(double));
             }
             nn = pin(c, WS_SCAL + SC_NRM2, 0)[1];
@@ -862,18 +867,18 @@ static int orth_run(kk_basis b, int c0, int m, double* w, kk_orth_t alg, double 
                 KK_TRY(kk_launch_unproject(c, V, ld, m, w, w, &ch, nullptr, -1.0, 1.0, -1, nullptr,
                                            want_norm ? SCP(c, SC_NRM2) : nullptr));
                 if (want_norm) KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2, 2, 0));
-                KK_TRY(stream_sync(c));
+                KK_TRY(final_sync(c));
             } else if (lowsync) {
                 KK_TRY(pass_mgs_lowsync(b, c0, m, w, x, false, 0));
                 KK_TRY(pass_mgs_lowsync(b, c0, m, w, tmp.data(), want_norm, 0));
-                KK_TRY(stream_sync(c));
+                KK_TRY(final_sync(c));
                 for (int j = 0; j < m; ++j) x[j] += tmp[j];
             } else {
                 // the last axpy of sweep 1 is fused with the first dot of sweep 2
                 KK_TRY(pass_mgs_strict(c, V, ld, m, w, WS_S, false, 0, nullptr, nullptr, true));
                 KK_TRY(pass_mgs_strict(c, V, ld, m, w, WS_G, want_norm, 0, V + (int64_t)(m - 1) * ld,
                                        c->ws + WS_S + m - 1, false));
-                KK_TRY(stream_sync(c));
+                KK_TRY(final_sync(c));
                 for (int j = 0; j < m; ++j) x[j] = pin(c, WS_S, 0)[j] + pin(c, WS_G, 0)[j];
             }
             nn = pin(c, WS_SCAL + SC_NRM2, 0)[1];
@@ -1066,6 +1071,45 @@ extern "C" int kk_arnoldi_initialize(kk_op op, kk_basis b, int c0, kk_orth_t ort
     return krylov_initialize(op, b, c0, orth, eta, alpha, beta);
 }
 
+// Speculative first half of the NEXT expand!: w' = A (r/beta) - beta v  with the scale applied on
+// the fly from the device-resident beta, so the GPU keeps working while the host reads back
+// (alpha, beta), returns to the caller and re-enters.  r itself is NOT modified; the next expand
+// call normalises it in place (after this read) and skips its SpMV if (op, c0, k, beta) match.
+// Bit-identical to the non-speculative order: r*(1/beta) is formed with the same operands.
+static int speculate_next(kk_op op, kk_basis b, int c0, int k_next, int dot_mode, bool with_prev, double beta_host) {
+    kk_ctx c = b->ctx;
+    b->spec_valid = false;
+    if (!c->speculate || c0 + k_next + 2 > b->cap || k_next + 1 > KK_MAX_M) return KK_OK;
+    kk_spmv_fuse f;
+    f.xscale_dev = SCP(c, SC_INVNRM);
+    if (with_prev) { f.vprev = b->col(c0 + k_next - 1); f.bprev_dev = SCP(c, SC_NRM); }
+    f.dot_mode = dot_mode;
+    f.dot_out = SCP(c, SC_SPECA);
+    KK_TRY(kk_launch_spmv(c, op->A, b->col(c0 + k_next), b->col(c0 + k_next + 1), b->ld, f));
+    b->spec_valid = true; b->spec_op = op; b->spec_c0 = c0; b->spec_k = k_next; b->spec_dot_mode = dot_mode;
+    b->spec_beta = beta_host;
+    c->spec_owner = b;
+    return KK_OK;
+}
+// true if the previous expand on this basis already enqueued exactly this step's SpMV; moves the
+// speculative alpha into the regular slot
+static int spec_take(kk_op op, kk_basis b, int c0, int k, int dot_mode, double beta_old, bool* hit) {
+    kk_ctx c = b->ctx;
+    *hit = b->spec_valid && c->spec_owner == b && b->spec_op == op && b->spec_c0 == c0 && b->spec_k == k &&
+           b->spec_dot_mode == dot_mode && b->spec_beta == beta_old;
+    if (*hit && dot_mode)
+        KK_HIP(hipMemcpyAsync(SCP(c, SC_ALPHA0), SCP(c, SC_SPECA), sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    return KK_OK;
+}
+// the last synchronisation of an expand: a pending speculation request (Arnoldi) is enqueued first
+static int final_sync(kk_ctx c) {
+    if (c->spec_req.active) {
+        c->spec_req.active = false;
+        KK_TRY(speculate_next(c->spec_req.op, c->spec_req.b, c->spec_req.c0, c->spec_req.k_next, 0, false, 0.0));
+    }
+    return stream_sync(c);
+}
+
 extern "C" int kk_lanczos_expand(kk_op op, kk_basis b, int c0, int k, kk_orth_t orth, double eta, double beta_old,
                                  double* alpha, double* beta, int* npasses) {
     KK_TRY(check_square_op(op, b));
@@ -1080,17 +1124,21 @@ extern "C" int kk_lanczos_expand(kk_op op, kk_basis b, int c0, int k, kk_orth_t 
     double* v = b->col(c0 + k);           // holds r on entry
     const double* vprev = b->col(c0 + k - 1);
     double* w = b->col(c0 + k + 1);
+    const bool cgs_order = (orth == KK_CGS || orth == KK_CGS2 || orth == KK_CGSIR);
+    bool hit = false;
+    KK_TRY(spec_take(op, b, c0, k, cgs_order ? 1 : 2, beta_old, &hit));
     gram_touch(b, c0 + k);
     int passes = 0;
     // V = push!(V, scale!!(r, 1/beta_old))   lanczos.jl:257
     KK_TRY(kk_launch_scal(c, v, ld, 1.0 / beta_old, nullptr));
-    // w = A v - beta_old v_prev with the fused alpha dot   lanczos.jl:297-299 / 306-308
-    kk_spmv_fuse f;
-    f.vprev = vprev; f.bprev = beta_old;
-    const bool cgs_order = (orth == KK_CGS || orth == KK_CGS2 || orth == KK_CGSIR);
-    f.dot_mode = cgs_order ? 1 : 2;
-    f.dot_out = SCP(c, SC_ALPHA0);
-    KK_TRY(kk_launch_spmv(c, op->A, v, w, ld, f));
+    if (!hit) {
+        // w = A v - beta_old v_prev with the fused alpha dot   lanczos.jl:297-299 / 306-308
+        kk_spmv_fuse f;
+        f.vprev = vprev; f.bprev = beta_old;
+        f.dot_mode = cgs_order ? 1 : 2;
+        f.dot_out = SCP(c, SC_ALPHA0);
+        KK_TRY(kk_launch_spmv(c, op->A, v, w, ld, f));
+    }  // else: the previous expand already enqueued exactly this SpMV (speculate_next)
     const double* a0_dev = c->ws + WS_SCAL + SC_ALPHA0;
     double a = 0, bt = 0;
     const bool lowsync = c->mgs_mode == 1;
@@ -1124,6 +1172,7 @@ extern "C" int kk_lanczos_expand(kk_op op, kk_basis b, int c0, int k, kk_orth_t 
                                        SCP(c, SC_NRM2)));
             KK_TRY(ws_fetch_async(c, WS_S, m, 0));
             KK_TRY(ws_fetch_async(c, WS_SCAL, 4, 0));
+            KK_TRY(speculate_next(op, b, c0, k + 1, 1, true, 0.0));
             KK_TRY(stream_sync(c));
             a = pin(c, WS_SCAL + SC_ALPHA0)[0] + pin(c, WS_S)[m - 1];
         } else {
@@ -1138,6 +1187,7 @@ extern "C" int kk_lanczos_expand(kk_op op, kk_basis b, int c0, int k, kk_orth_t 
             ch.v[m - 1] += a0;
             KK_TRY(kk_launch_unproject(c, V, ld, m, w, w, &ch, nullptr, -1.0, 1.0, -1, nullptr, SCP(c, SC_NRM2)));
             KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2, 2, 0));
+            KK_TRY(speculate_next(op, b, c0, k + 1, 2, true, 0.0));
             KK_TRY(stream_sync(c));
         }
         bt = pin(c, WS_SCAL + SC_NRM)[0];
@@ -1157,6 +1207,7 @@ extern "C" int kk_lanczos_expand(kk_op op, kk_basis b, int c0, int k, kk_orth_t 
     *alpha = a;
     *beta = bt;
     if (npasses) *npasses = passes;
+    if (b->spec_valid) b->spec_beta = bt;  // the caller must come back with exactly this beta
     return KK_OK;
 }
 
@@ -1171,11 +1222,21 @@ extern "C" int kk_arnoldi_expand(kk_op op, kk_basis b, int c0, int k, kk_orth_t 
     const int m = k + 1;
     double* v = b->col(c0 + k);
     double* w = b->col(c0 + k + 1);
+    bool hit = false;
+    KK_TRY(spec_take(op, b, c0, k, 0, beta_old, &hit));
     gram_touch(b, c0 + k);
     KK_TRY(kk_launch_scal(c, v, b->ld, 1.0 / beta_old, nullptr));  // push!(V, scale(r, 1/beta))   arnoldi.jl:209
-    kk_spmv_fuse f;
-    KK_TRY(kk_launch_spmv(c, op->A, v, w, b->ld, f));               // w = apply(operator, last(V))  :242
-    return orth_run(b, c0, m, w, orth, eta, h, beta, npasses, true);  // orthogonalize!! + norm      :243-244
+    if (!hit) {
+        kk_spmv_fuse f;
+        KK_TRY(kk_launch_spmv(c, op->A, v, w, b->ld, f));           // w = apply(operator, last(V))  :242
+    }
+    // ask orth_run to enqueue the NEXT step's SpMV right before its final host sync (non-IR variants)
+    c->spec_req.active = (orth != KK_CGSIR && orth != KK_MGSIR);
+    c->spec_req.op = op; c->spec_req.b = b; c->spec_req.c0 = c0; c->spec_req.k_next = k + 1;
+    int st = orth_run(b, c0, m, w, orth, eta, h, beta, npasses, true);  // orthogonalize!! + norm      :243-244
+    c->spec_req.active = false;
+    if (st == KK_OK && b->spec_valid) b->spec_beta = *beta;
+    return st;
 }
 
 // ---- GKL ----------------------------------------------------------------------------------

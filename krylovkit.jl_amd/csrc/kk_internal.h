@@ -25,7 +25,8 @@
 #define WS_TOTAL (WS_USER + KK_WS_USER)
 // a finalize with_sqrt writes three consecutive slots: sum, sqrt(sum), 1/sqrt(sum)
 enum { SC_ALPHA0 = 0, SC_NRM2 = 1, SC_NRM = 2, SC_INVNRM = 3, SC_DOT = 4, SC_TMP0 = 5, SC_TMP1 = 6, SC_TMP2 = 7,
-       SC_NRM2B = 8, SC_NRMB = 9, SC_INVNRMB = 10, SC_DOTB = 11 };
+       SC_NRM2B = 8, SC_NRMB = 9, SC_INVNRMB = 10, SC_DOTB = 11,
+       SC_SPECA = 12 /* alpha of a speculative next-step SpMV: written by nothing else */ };
 
 void kk_set_error(const char* fmt, ...);
 int kk_hip_fail(hipError_t e, const char* what, const char* file, int line);
@@ -67,6 +68,9 @@ struct kk_ctx_s {
     int blocks_per_cu = 4;       // 4 resident 256-thread blocks per CU (measured best on the 10M-row sweep)
     int mgs_mode = 1;
     int fuse_passes = 1;         // fuse unproject(pass i) with project(pass i+1)
+    int speculate = 1;           // enqueue the next expand's SpMV before syncing the host
+    kk_basis spec_owner = nullptr;   // basis whose speculative result currently sits in SC_SPECA / its next column
+    struct { bool active = false; kk_op op = nullptr; kk_basis b = nullptr; int c0 = 0, k_next = 0; } spec_req;
     hipEvent_t t0 = nullptr, t1 = nullptr;
     bool prof = false;
     std::map<std::string, kk_prof_entry> prof_tab;
@@ -83,6 +87,11 @@ struct kk_basis_s {
     std::vector<double> gram;
     int gram_c0 = 0;    // first column the Gram rows refer to
     int gram_rows = 0;  // rows [0, gram_rows) of the strictly-lower Gram matrix are valid
+    // speculative next-step SpMV (hides the host round trip between two expand! calls)
+    bool spec_valid = false;
+    const void* spec_op = nullptr;
+    int spec_c0 = 0, spec_k = 0, spec_dot_mode = 0;
+    double spec_beta = 0;
     inline double* col(int c) const { return d + (int64_t)c * ld; }
 };
 
