@@ -73,6 +73,7 @@ extern "C" int kk_ctx_create(int device, kk_ctx* out) {
     if (getenv("KK_BLOCK_MODE")) c->block_mode = atoi(getenv("KK_BLOCK_MODE"));
     KK_HIP(hipEventCreate(&c->t0));
     KK_HIP(hipEventCreate(&c->t1));
+    KK_HIP(hipEventCreateWithFlags(&c->ev_fetch, hipEventDisableTiming));
     const char* env = getenv("KK_BLOCKS_PER_CU");
     if (env && atoi(env) > 0) c->blocks_per_cu = atoi(env);
     env = getenv("KK_MGS_MODE");
@@ -89,6 +90,7 @@ extern "C" int kk_ctx_destroy(kk_ctx c) {
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     (void)hipEventDestroy(c->t0);
     (void)hipEventDestroy(c->t1);
+    (void)hipEventDestroy(c->ev_fetch);
     (void)hipFree(c->ws);
     (void)hipFree(c->partials);
     (void)hipHostFree(c->h_pin);
@@ -1102,10 +1104,22 @@ static int spec_take(kk_op op, kk_basis b, int c0, int k, int dot_mode, double b
     return KK_OK;
 }
 // the last synchronisation of an expand: a pending speculation request (Arnoldi) is enqueued first
+// The host waits only for the read-backs queued so far (event), NOT for the speculative SpMV that
+// is enqueued behind them -- that one keeps the GPU busy during the host round trip.
+static int fetch_mark(kk_ctx c) {
+    KK_HIP(hipEventRecord(c->ev_fetch, c->stream));
+    return KK_OK;
+}
+static int fetch_wait(kk_ctx c) {
+    KK_HIP(hipEventSynchronize(c->ev_fetch));
+    return KK_OK;
+}
 static int final_sync(kk_ctx c) {
     if (c->spec_req.active) {
         c->spec_req.active = false;
+        KK_TRY(fetch_mark(c));
         KK_TRY(speculate_next(c->spec_req.op, c->spec_req.b, c->spec_req.c0, c->spec_req.k_next, 0, false, 0.0));
+        return fetch_wait(c);
     }
     return stream_sync(c);
 }
@@ -1172,8 +1186,9 @@ extern "C" int kk_lanczos_expand(kk_op op, kk_basis b, int c0, int k, kk_orth_t 
                                        SCP(c, SC_NRM2)));
             KK_TRY(ws_fetch_async(c, WS_S, m, 0));
             KK_TRY(ws_fetch_async(c, WS_SCAL, 4, 0));
+            KK_TRY(fetch_mark(c));
             KK_TRY(speculate_next(op, b, c0, k + 1, 1, true, 0.0));
-            KK_TRY(stream_sync(c));
+            KK_TRY(fetch_wait(c));
             a = pin(c, WS_SCAL + SC_ALPHA0)[0] + pin(c, WS_S)[m - 1];
         } else {
             KK_TRY(ws_fetch_async(c, WS_SCAL, 1, 0));
@@ -1187,8 +1202,9 @@ extern "C" int kk_lanczos_expand(kk_op op, kk_basis b, int c0, int k, kk_orth_t 
             ch.v[m - 1] += a0;
             KK_TRY(kk_launch_unproject(c, V, ld, m, w, w, &ch, nullptr, -1.0, 1.0, -1, nullptr, SCP(c, SC_NRM2)));
             KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2, 2, 0));
+            KK_TRY(fetch_mark(c));
             KK_TRY(speculate_next(op, b, c0, k + 1, 2, true, 0.0));
-            KK_TRY(stream_sync(c));
+            KK_TRY(fetch_wait(c));
         }
         bt = pin(c, WS_SCAL + SC_NRM)[0];
         passes = 1;

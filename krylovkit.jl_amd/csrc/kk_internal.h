@@ -72,6 +72,7 @@ struct kk_ctx_s {
     kk_basis spec_owner = nullptr;   // basis whose speculative result currently sits in SC_SPECA / its next column
     struct { bool active = false; kk_op op = nullptr; kk_basis b = nullptr; int c0 = 0, k_next = 0; } spec_req;
     hipEvent_t t0 = nullptr, t1 = nullptr;
+    hipEvent_t ev_fetch = nullptr;  // marks the end of the scalar read-backs of an expand (host waits on this, not on the stream)
     bool prof = false;
     std::map<std::string, kk_prof_entry> prof_tab;
     std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> prof_pending;
