@@ -86,7 +86,7 @@ int kk_ctx_timer_start(kk_ctx ctx);
 int kk_ctx_timer_stop(kk_ctx ctx, double* ms);
 /* per-kernel-class HIP-event timing (roofline leg of bench.py): when enabled every launch of
  * the named class is bracketed by events; totals are read back with kk_ctx_prof_get. */
-int kk_ctx_prof_enable(kk_ctx ctx, int on);
+int kk_ctx_prof_enable(kk_ctx ctx, int on); /* 0 off, 1 all kernel classes, 2 only k_project/k_unproject/k_unproj_proj */
 int kk_ctx_prof_reset(kk_ctx ctx);
 int kk_ctx_prof_get(kk_ctx ctx, const char* kernel_class, double* total_ms, int64_t* launches);
 

@@ -206,7 +206,7 @@ void kk_prof_end(kk_ctx c) {
 extern "C" int kk_ctx_prof_enable(kk_ctx c, int on) {
     KK_CHECK(c, KK_ERR_INVALID, "null ctx");
     if (!on && c->prof) prof_resolve(c);
-    c->prof = on != 0;
+    c->prof = (on == 2) ? 2 : (on != 0);
     return KK_OK;
 }
 extern "C" int kk_ctx_prof_reset(kk_ctx c) {

@@ -73,7 +73,7 @@ struct kk_ctx_s {
     struct { bool active = false; kk_op op = nullptr; kk_basis b = nullptr; int c0 = 0, k_next = 0; } spec_req;
     hipEvent_t t0 = nullptr, t1 = nullptr;
     hipEvent_t ev_fetch = nullptr;  // marks the end of the scalar read-backs of an expand (host waits on this, not on the stream)
-    bool prof = false;
+    int prof = 0;                // 0 off, 1 every kernel class, 2 only the basis-streaming classes (project/unproject)
     std::map<std::string, kk_prof_entry> prof_tab;
     std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> prof_pending;
     std::vector<hipEvent_t> event_pool;
@@ -142,11 +142,14 @@ void kk_prof_begin(kk_ctx ctx, const char* cls);
 void kk_prof_end(kk_ctx ctx);
 struct kk_prof_scope {
     kk_ctx c;
+    bool on;
     kk_prof_scope(kk_ctx ctx, const char* cls) : c(ctx) {
-        if (c->prof) kk_prof_begin(c, cls);
+        // k_project / k_unproject / k_unproj_proj all start with "k_proj" or "k_unproj"
+        on = c->prof == 1 || (c->prof == 2 && (cls[2] == 'p' || cls[2] == 'u'));
+        if (on) kk_prof_begin(c, cls);
     }
     ~kk_prof_scope() {
-        if (c->prof) kk_prof_end(c);
+        if (on) kk_prof_end(c);
     }
 };
 

@@ -13,6 +13,7 @@
 #include "kk_internal.h"
 
 typedef double2 d2;
+typedef double v4d __attribute__((ext_vector_type(4)));  // MFMA f64 16x16x4 accumulator fragment
 __device__ __forceinline__ int64_t imin(int64_t a, int64_t b) { return a < b ? a : b; }
 
 __device__ __forceinline__ d2 ld2(const double* p) { return *reinterpret_cast<const d2*>(p); }
@@ -654,6 +655,66 @@ __global__ __launch_bounds__(KK_TPB) void k_basistransform(double* __restrict__ 
     }
 }
 
+// basistransform! as a tall-skinny GEMM on v_mfma_f64_16x16x4_f64 (thick restart,
+// eigsolve/lanczos.jl:109): out[rows, 0:n] = V[rows, 0:m] * U, in place.
+//   D[i][j] += sum_k A[i][k] B[k][j];  k = 4 basis columns per MFMA, j = 16 output columns per tile.
+//   Lane (i = l&15, kq = l>>4) loads 4 CONSECUTIVE rows R0+4i..R0+4i+3 of column C+kq (32 B);
+//   MFMA t uses element t, i.e. its 16 "rows" are R0 + 4i + t.  The result regs of lane l for
+//   fixed (tile, r) and t = 0..3 are 4 consecutive rows R0 + 4((l>>4)+4r) + t -> 32 B stores.
+// A wave owns 64-row chunks: it reads all m columns of a chunk before writing the n outputs of
+// the same rows, so the transform is safely in place.  U sits in LDS (B operand).
+template <int NJ>
+__global__ __launch_bounds__(KK_TPB) void k_basistransform_mfma(double* V, int64_t ld, int m, int n, int npad,
+                                                                const double* __restrict__ U, int64_t rpb) {
+    extern __shared__ __attribute__((aligned(16))) double Us[];  // [m4][npad], zero padded
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m4 = (m + 3) & ~3;
+    for (int idx = tid; idx < m4 * npad; idx += KK_TPB) {
+        const int k = idx / npad, j = idx % npad;
+        Us[idx] = (k < m && j < n) ? U[(int64_t)j * m + k] : 0.0;
+    }
+    __syncthreads();
+    const int i = lane & 15, kq = lane >> 4;
+    const int64_t r0 = (int64_t)blockIdx.x * rpb, r1 = imin(r0 + rpb, ld);
+    for (int64_t R0 = r0 + wave * 64; R0 < r1; R0 += 256) {
+        v4d acc[NJ][4];
+#pragma unroll
+        for (int jt = 0; jt < NJ; ++jt)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[jt][t] = v4d{0.0, 0.0, 0.0, 0.0};
+        const double* vin = V + R0 + 4 * i;
+        for (int C = 0; C < m4; C += 4) {
+            const int col = C + kq;
+            double a[4];
+            if (col < m) {
+                const d2 x0 = ld2s(vin + (int64_t)col * ld), x1 = ld2s(vin + (int64_t)col * ld + 2);
+                a[0] = x0.x; a[1] = x0.y; a[2] = x1.x; a[3] = x1.y;
+            } else {
+                a[0] = a[1] = a[2] = a[3] = 0.0;
+            }
+            const double* urow = Us + (C + kq) * npad + i;
+#pragma unroll
+            for (int jt = 0; jt < NJ; ++jt) {
+                const double bv = urow[jt * 16];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[jt][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t], bv, acc[jt][t], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int jt = 0; jt < NJ; ++jt) {
+            const int col = jt * 16 + i;
+            if (col < n) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    double* o = V + (int64_t)col * ld + R0 + 4 * (kq + 4 * r);
+                    st2(o, d2{acc[jt][0][r], acc[jt][1][r]});
+                    st2(o + 2, d2{acc[jt][2][r], acc[jt][3][r]});
+                }
+            }
+        }
+    }
+}
+
 // rmul!(b, G::Givens) (dense/givens.jl:20-36): (q1,q2) <- (c q1 - s q2, s q1 + c q2)
 __global__ __launch_bounds__(KK_TPB) void k_givens(double* __restrict__ q1, double* __restrict__ q2, int64_t ld,
                                                    int64_t rpb, double c, double s) {
@@ -720,7 +781,6 @@ __global__ __launch_bounds__(KK_TPB) void k_rank1(double* __restrict__ V, int64_
 // as A and B use the same one.  X is read exactly once, Y once per launch.
 #define BG_T 8                       // rows per lane per chunk (4 x dwordx4)
 #define BG_CHUNK (4 * BG_T)          // rows per wave chunk
-typedef double v4d __attribute__((ext_vector_type(4)));
 
 template <int NG>  // NG groups of 16 X-columns
 __global__ __launch_bounds__(KK_TPB) void k_block_gram(const double* __restrict__ X, int64_t ldx, int p,
@@ -1090,6 +1150,34 @@ int kk_launch_spmv(kk_ctx ctx, const kk_sparse_dev& M, const double* x, double* 
 
 int kk_launch_basistransform(kk_ctx ctx, double* V, int64_t ld, int m, int n, const double* U_dev) {
     kk_prof_scope ps(ctx, "k_basistransform");
+    const int nj = (n + 15) / 16;
+    if (nj <= 6 && !getenv("KK_BASISTRANSFORM_LDS")) {
+        int npad = (n + 15) / 16 * 16;
+        while (npad % 32 != 16) npad += 16;   // B-operand rows land on disjoint LDS banks
+        const int m4 = (m + 3) & ~3;
+        const size_t shm = (size_t)m4 * npad * sizeof(double);
+        kk_part p = kk_partition(ctx, ld);
+        dim3 g(p.nblk), b(KK_TPB);
+#define BT_CASE(NJT)                                                                                                   \
+        {                                                                                                              \
+            KK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_basistransform_mfma<NJT>),                      \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));                         \
+            hipLaunchKernelGGL((k_basistransform_mfma<NJT>), g, b, shm, ctx->stream, V, ld, m, n, npad, U_dev, p.rpb);  \
+        }
+        if (shm <= 160 * 1024 - 256) {
+            switch (nj) {
+                case 1: BT_CASE(1) break;
+                case 2: BT_CASE(2) break;
+                case 3: BT_CASE(3) break;
+                case 4: BT_CASE(4) break;
+                case 5: BT_CASE(5) break;
+                default: BT_CASE(6) break;
+            }
+            KK_HIP(hipGetLastError());
+            return KK_OK;
+        }
+#undef BT_CASE
+    }
     const size_t shm = (size_t)m * (BT_ROWS + 1) * sizeof(double);
     int nb = (int)std::min<int64_t>(ld / BT_ROWS, (int64_t)ctx->num_cus * 8);
     if (nb < 1) nb = 1;

@@ -108,7 +108,8 @@ class Context:
         check(self._lib.kk_ctx_timer_stop(self.handle, C.byref(ms)))
         return ms.value
 
-    def prof_enable(self, on: bool = True):
+    def prof_enable(self, on=True):
+        """0/False off, 1/True every kernel class, 2 only the basis-streaming kernels (low overhead)."""
         check(self._lib.kk_ctx_prof_enable(self.handle, int(on)))
 
     def prof_reset(self):

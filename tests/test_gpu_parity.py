@@ -626,3 +626,24 @@ def test_fused_unproject_project_matches_unfused(kk, ko, ctx, n, m):
         assert abs(n0 - n1) <= 1e-12 * n0
         np.testing.assert_allclose(w0_, w1_, rtol=0, atol=1e-12 * np.linalg.norm(w0))
         assert np.max(np.abs(Q.T @ w1_)) < 1e-12 * np.linalg.norm(w0)
+
+
+@pytest.mark.parametrize("n,m,k", [(1000, 7, 3), (70001, 100, 60), (20000, 100, 77), (9000, 61, 61), (9000, 116, 96), (9000, 120, 100)])
+def test_basistransform_mfma_and_fallback(kk, ctx, n, m, k):
+    """basistransform! (orthonormal.jl:291-354) in place: the MFMA tall-skinny GEMM path (n <= 96) and the LDS fallback."""
+    rng = np.random.default_rng(n + m + k)
+    V = rng.standard_normal((n, m))
+    U = rng.standard_normal((m, k))
+    B = kk.DeviceBasis(n, m, ctx)
+    for j in range(m):
+        B.upload(j, V[:, j])
+    B.length = m
+    B.basistransform(U)
+    ref = V.copy()
+    ref[:, :k] = V @ U
+    got = B.to_numpy()
+    scale = np.abs(V) @ np.abs(U)
+    assert np.max(np.abs(got[:, :k] - ref[:, :k]) / scale) < 1e-14
+    np.testing.assert_array_equal(got[:, k:], V[:, k:])  # untouched columns
+    # pad rows must still be zero: norms only see n entries
+    assert abs(B[0].norm() - np.linalg.norm(ref[:, 0])) <= 1e-13 * np.linalg.norm(ref[:, 0])
