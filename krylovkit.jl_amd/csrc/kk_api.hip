@@ -678,10 +678,35 @@ extern "C" int kk_householder_rmul(kk_basis b, int c0, int m, const double* v, d
 
 // ---- Gram rows for the low-synchronisation MGS -------------------------------------------
 // gram(i, j) = <b_i, b_j>, j < i, stored at b->gram[i*cap + j]; rows [0, gram_rows) valid.
+static int block_inner_run(kk_ctx c, const double* X, int64_t ldx, int p, const double* Y, int64_t ldy, int q, int64_t ld,
+                           double* M, int ldm);
 static int gram_ensure(kk_basis b, int upto /* exclusive */) {
     kk_ctx c = b->ctx;
     if (b->gram.empty()) b->gram.assign((size_t)b->cap * b->cap, 0.0);
     if (b->gram_rows < 1) b->gram_rows = 1;  // row 0 has no strictly-lower entries
+    if (upto - b->gram_rows >= 4) {
+        // many rows missing (after a thick restart): one MFMA Gram panel sweep instead of one
+        // projection per row -- V is read ~upto/16 times instead of ~upto/2 times
+        const int lo = b->gram_rows;
+        std::vector<double> M;
+        for (int j0 = 0; j0 < upto - 1; j0 += 16) {
+            const int q = std::min(16, upto - 1 - j0);
+            const int i0 = std::max(lo, j0 + 1);
+            if (i0 >= upto) continue;
+            const int p = upto - i0;
+            M.assign((size_t)p * q, 0.0);
+            const int saved_mode = c->block_mode;
+            c->block_mode = 1;
+            int st = block_inner_run(c, b->col(i0), b->ld, p, b->col(j0), b->ld, q, b->ld, M.data(), p);
+            c->block_mode = saved_mode;
+            KK_TRY(st);
+            for (int jj = 0; jj < q; ++jj)
+                for (int ii = 0; ii < p; ++ii)
+                    if (j0 + jj < i0 + ii) b->gram[(size_t)(i0 + ii) * b->cap + j0 + jj] = M[ii + (size_t)p * jj];
+        }
+        b->gram_rows = upto;
+        return KK_OK;
+    }
     for (int i = b->gram_rows; i < upto; ++i) {
         for (int j0 = 0; j0 < i; j0 += KK_MAX_M) {
             const int mm = std::min(KK_MAX_M, i - j0);
