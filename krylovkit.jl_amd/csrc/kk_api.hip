@@ -566,7 +566,9 @@ static int get_matrix(kk_op op, int transpose, const kk_sparse_dev** M) {
 static int check_apply(kk_op op, int transpose, kk_basis bx, kk_basis by) {
     const int64_t in = transpose ? op->nrows : (op->A.n_ghost > 0 ? op->A.n_local : op->ncols);
     const int64_t outn = transpose ? op->ncols : op->nrows;
-    KK_CHECK(bx->n == in && by->n == outn, KK_ERR_DIM, "apply: operator is %lldx%lld%s, x has %lld rows, y has %lld rows",
+    // ghost-only operator (n_local == 0): every column comes from the caller's gathered buffer, x is unused
+    const bool ghost_only = !transpose && op->A.n_ghost > 0 && op->A.n_local == 0;
+    KK_CHECK((ghost_only || bx->n == in) && by->n == outn, KK_ERR_DIM, "apply: operator is %lldx%lld%s, x has %lld rows, y has %lld rows",
              (long long)op->nrows, (long long)op->ncols, transpose ? " (adjoint)" : "", (long long)bx->n, (long long)by->n);
     KK_CHECK(bx->ctx == op->ctx && by->ctx == op->ctx, KK_ERR_INVALID, "apply: objects belong to different contexts");
     return KK_OK;

@@ -127,6 +127,15 @@ class HipBackend:
     def download(self, basis, col):
         return basis.download(col)
 
+    def download_device(self, basis, col, t):
+        check(self._lib.kk_basis_download_device(basis.handle, col, C.c_void_p(t.data_ptr())))
+
+    def upload_device(self, basis, col, t):
+        check(self._lib.kk_basis_upload_device(basis.handle, col, C.c_void_p(t.data_ptr())))
+
+    def spmv(self, op, transpose, bx, cx, by, cy):
+        check(self._lib.kk_spmv(op.handle, int(transpose), bx.handle, cx, by.handle, cy))
+
     # split-phase compute (all stream-ordered, no host sync)
     def gather(self, basis, col, idx, out):
         check(self._lib.kk_gather(basis.handle, col, C.c_void_p(idx.data_ptr()), idx.numel(), C.c_void_p(out.data_ptr())))
@@ -342,3 +351,172 @@ class DistLanczosIterator:
             self._allreduce(self.buf[0:i])
             self.gram[i, :i] = be.to_host(self.buf[0:i])
         self.gram_rows = max(k, 1)
+
+
+# ------------------------------------------------------------------------------ GKL (config 4)
+class _LowSyncGram:
+    """Host copy of the strictly-lower Gram matrix of one sharded basis (low-sync MGS)."""
+
+    def __init__(self, cap: int):
+        self.L = np.zeros((cap, cap))
+        self.rows = 1
+
+    def solve(self, p: np.ndarray) -> np.ndarray:
+        s = p.copy()
+        for i in range(1, len(s)):
+            s[i] -= self.L[i, :i] @ s[:i]
+        return s
+
+
+class DistRectOperator:
+    """Row block of a rectangular sparse map A (m x n) for the sharded GKL (cfg 4):
+    U-vectors (length m) are sharded by the rows of A, V-vectors (length n) by an even partition.
+      A v   : all-gather of the short vector v (n doubles in total), local SpMV on the gathered buffer
+      A' u  : local transposed SpMV (full-length partial), reduce-scatter (sum) onto the V shards."""
+
+    def __init__(self, A_rows, row_part: Partition, col_part: Partition, backend, group=None):
+        import scipy.sparse as sp
+        import torch.distributed as dist
+
+        self.row_part, self.col_part, self.backend, self.group, self.dist = row_part, col_part, backend, group, dist
+        A = sp.csr_matrix(A_rows)
+        assert A.shape == (row_part.n_local, col_part.n_global)
+        counts = np.diff(col_part.offsets)
+        assert np.all(counts == counts[0]), "V partition must be even (all-gather / reduce-scatter of equal shards)"
+        self.n = col_part.n_global
+        self.vfull = backend.alloc(self.n)            # gathered v (the operator's ghost buffer)
+        self.zfull = backend.alloc(self.n)            # full-length partial of A'u
+        self.vloc = backend.alloc(col_part.n_local)   # this rank's V shard staging
+        self.local = backend.make_operator(A, 0, self.vfull)   # ghost-only: all columns read from vfull
+        self.zbasis = backend.make_basis(self.n, 1)
+
+    def apply_normal(self, Vb, cv, Ub, cu):
+        """U[cu] = (A v) restricted to my rows;  v = V[cv] sharded."""
+        be, dist = self.backend, self.dist
+        be.download_device(Vb, cv, self.vloc)
+        if self.col_part.world > 1:
+            dist.all_gather_into_tensor(self.vfull, self.vloc, group=self.group)
+        else:
+            self.vfull.copy_(self.vloc)
+        be.spmv(self.local, False, Vb, cv, Ub, cu)
+
+    def apply_adjoint(self, Ub, cu, Vb, cv):
+        """V[cv] = my shard of A' u;  u = U[cu] sharded by rows."""
+        be, dist = self.backend, self.dist
+        be.spmv(self.local, True, Ub, cu, self.zbasis, 0)
+        be.download_device(self.zbasis, 0, self.zfull)
+        if self.col_part.world > 1:
+            try:
+                dist.reduce_scatter_tensor(self.vloc, self.zfull, group=self.group)
+            except (RuntimeError, NotImplementedError):   # backend without reduce_scatter (gloo): all-reduce + slice
+                dist.all_reduce(self.zfull, group=self.group)
+                self.vloc.copy_(self.zfull[self.col_part.lo:self.col_part.hi])
+        else:
+            self.vloc.copy_(self.zfull)
+        be.upload_device(Vb, cv, self.vloc)
+
+
+@dataclass
+class DistGKLIterator:
+    """Row-sharded GKLIterator (factorizations/gkl.jl:137-152).  Orthogonalisers: cgs, mgs (no
+    re-orthogonalisation, gkl.jl:294-307), cgs2 (:308-323), mgs2 in its low-sync form (:324-346)."""
+    operator: DistRectOperator
+    u0_local: np.ndarray
+    orth: Orthogonalizer = KrylovDefaults.orth
+    capacity: int = KrylovDefaults.krylovdim + 2
+
+    def __post_init__(self):
+        if self.orth.name not in ("cgs", "mgs", "cgs2", "mgs2"):
+            raise NotImplementedError(f"{self.orth.name}: not offered row-sharded yet; use cgs2 / mgs2")
+        self.backend = self.operator.backend
+        self.buf = self.backend.alloc(2 * 256 + 8)
+        self.nbuf = self.backend.alloc(4)
+
+    def _allreduce(self, t):
+        if self.operator.row_part.world > 1:
+            self.operator.dist.all_reduce(t, group=self.operator.group)
+
+    def _norm(self, basis, col) -> float:
+        be = self.backend
+        be.nrm2(basis, col, self.nbuf)
+        self._allreduce(self.nbuf[0:1])
+        return float(np.sqrt(be.to_host(self.nbuf[0:1])[0]))
+
+    def _sweep(self, basis, m, col, gram: Optional[_LowSyncGram]):
+        """One orthogonalisation pass of (basis, col) against columns [0, m): classical (gram None)
+        or low-sync modified; the Gram row of the newest basis vector rides along."""
+        be = self.backend
+        ride = gram is not None and gram.rows == m - 1 and m >= 2
+        be.project(basis, 0, m, col, (m - 1) if ride else -1, self.buf[0:2 * m])
+        self._allreduce(self.buf[0:(2 * m if ride else m)])
+        h = be.to_host(self.buf[0:2 * m])
+        p = h[:m]
+        if gram is not None:
+            if ride:
+                gram.L[m - 1, :m - 1] = h[m:2 * m - 1]
+                gram.rows = m
+            assert gram.rows >= m, "Gram rows out of date"
+            p = gram.solve(p)
+        be.unproject(basis, col, 0, m, p, -1.0, 1.0, self.nbuf)
+        self._allreduce(self.nbuf[0:1])
+        return float(np.sqrt(be.to_host(self.nbuf[0:1])[0]))
+
+    def initialize(self, V=None):
+        """initialize(iter::GKLIterator) (gkl.jl:183-215), every inner product all-reduced."""
+        from .factorizations import GKLFactorization
+        be, op = self.backend, self.operator
+        U = be.make_basis(op.row_part.n_local, self.capacity)
+        Vb = be.make_basis(op.col_part.n_local, self.capacity)
+        be.upload(U, 0, np.asarray(self.u0_local, dtype=np.float64))
+        beta0 = self._norm(U, 0)
+        if beta0 == 0.0:
+            raise _lib.KrylovHipError(_lib.KK_ERR_ZERO_NORM, "initial vector should not have norm zero")
+        op.apply_adjoint(U, 0, Vb, 0)                    # v0 = A' u0
+        alpha = self._norm(Vb, 0) / beta0
+        op.apply_normal(Vb, 0, U, 1)                     # A v0
+        be.dot(U, 0, 1, self.buf)
+        self._allreduce(self.buf[0:1])
+        a2 = float(be.to_host(self.buf[0:1])[0]) / beta0 ** 2
+        if not abs(a2 - alpha * alpha) <= np.sqrt(np.finfo(float).eps) * max(abs(a2), alpha * alpha):
+            raise ValueError("operator and its adjoint are not compatible")   # gkl.jl:192
+        be.scal(U, 0, 1.0 / beta0)
+        be.scal(Vb, 0, 1.0 / (alpha * beta0))
+        be.scal(U, 1, 1.0 / (alpha * beta0))
+        be.unproject(U, 1, 0, 1, [alpha], -1.0, 1.0, self.nbuf)   # r -= alpha u
+        self._allreduce(self.nbuf[0:1])
+        beta = float(np.sqrt(be.to_host(self.nbuf[0:1])[0]))
+        U.length = Vb.length = 1
+        self.gram_u, self.gram_v = _LowSyncGram(self.capacity), _LowSyncGram(self.capacity)
+        return GKLFactorization(1, U, Vb, [alpha], [beta])
+
+    def expand(self, st):
+        """expand!(iter::GKLIterator, state) (gkl.jl:246-269) + gklrecurrence (:294-346)."""
+        be, op, U, V = self.backend, self.operator, st.U, st.V
+        k = len(U)
+        if k + 2 > U.capacity or k + 1 > V.capacity:
+            raise RuntimeError(f"GKL slabs are full at k={k}")
+        name = self.orth.name
+        beta_old = st.normres
+        be.scal(U, k, 1.0 / beta_old)                    # U = push!(U, scale!!(r, 1/beta_old))
+        op.apply_adjoint(U, k, V, k)                     # v = A' u
+        be.unproject(V, k, k - 1, 1, [beta_old], -1.0, 1.0, self.nbuf)   # v -= beta_old V[end]; |v|^2 partial
+        if name == "mgs2":
+            alpha = self._sweep(V, k, k, self.gram_v)    # for q in V: orthogonalize!!(v, q, MGS)   :330-335
+        else:
+            self._allreduce(self.nbuf[0:1])
+            alpha = float(np.sqrt(be.to_host(self.nbuf[0:1])[0]))
+        be.scal(V, k, 1.0 / alpha)
+        op.apply_normal(V, k, U, k + 1)                  # r = A v
+        be.unproject(U, k + 1, k, 1, [alpha], -1.0, 1.0, self.nbuf)      # r -= alpha u
+        if name == "cgs2":
+            beta = self._sweep(U, k + 1, k + 1, None)    # r, = orthogonalize!!(r, U, CGS)   :320
+        elif name == "mgs2":
+            beta = self._sweep(U, k + 1, k + 1, self.gram_u)   # :341-343
+        else:
+            self._allreduce(self.nbuf[0:1])
+            beta = float(np.sqrt(be.to_host(self.nbuf[0:1])[0]))
+        st.alphas.append(alpha)
+        st.betas.append(beta)
+        U.length = V.length = k + 1
+        st.k += 1
+        return st

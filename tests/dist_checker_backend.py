@@ -50,6 +50,19 @@ class CheckerBackend:
     def download(self, b, col):
         return b.cols[col].copy()
 
+    def download_device(self, b, col, t):
+        t[: b.n] = torch.from_numpy(b.cols[col])
+
+    def upload_device(self, b, col, t):
+        b.cols[col] = t.numpy()[: b.n].copy()
+
+    def spmv(self, op, transpose, bx, cx, by, cy):
+        if transpose:
+            by.cols[cy] = op.A.T @ bx.cols[cx]
+        else:
+            x = np.concatenate([bx.cols[cx][: op.n_local], op.ghost.numpy()[: op.n_ghost]])
+            by.cols[cy] = op.A @ x
+
     def gather(self, b, col, idx, out):
         out[: idx.numel()] = torch.from_numpy(b.cols[col][idx.numpy()])
 

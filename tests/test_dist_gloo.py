@@ -114,3 +114,76 @@ def test_partition_even():
     p = Partition.even(4000 * 10, 3, 1, align=4000)
     assert list(p.offsets) == [0, 16000, 28000, 40000] and p.n_local == 12000 and p.lo == 16000
     assert Partition.even(10, 1, 0).n_local == 10
+
+
+def _gkl_worker(rank, world, port, q):
+    sys.path.insert(0, str(ROOT / "krylovkit.jl_amd"))
+    sys.path.insert(0, str(ROOT / "oracle"))
+    sys.path.insert(0, str(ROOT / "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    import krylov_oracle as ko
+    from krylovkit_hip import dist as kd
+    from krylovkit_hip.core import Orthogonalizer
+    from dist_checker_backend import CheckerBackend
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        m, n = 240, 100
+        A = ko.sparse_random(m, n, 6, 41)
+        u0 = np.random.default_rng(6).random(m)
+        rp = kd.Partition.even(m, world, rank)
+        cp = kd.Partition.even(n, world, rank)
+        be = CheckerBackend()
+        op = kd.DistRectOperator(A[rp.lo:rp.hi, :], rp, cp, be)
+        res = {"rank": rank}
+        for name in ("cgs", "cgs2", "mgs2"):
+            it = kd.DistGKLIterator(op, u0[rp.lo:rp.hi], Orthogonalizer(name), capacity=18)
+            f = it.initialize()
+            for _ in range(14):
+                f = it.expand(f)
+            Ul = np.stack([be.download(f.U, j) for j in range(len(f.U))], 1)
+            Vl = np.stack([be.download(f.V, j) for j in range(len(f.V))], 1)
+            res[name] = (list(f.alphas), list(f.betas), Ul, Vl)
+        q.put(res)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_row_sharded_gkl_gloo_world2():
+    """cfg 4 (svdsolve/GKL, basis row-sharded): all-gather of v, reduce-scatter of A'u, all-reduced
+    inner products -- world_size 2 on gloo, checker backend, against the serial oracle."""
+    import torch.multiprocessing as mp
+    sys.path.insert(0, str(ROOT / "oracle"))
+    import krylov_oracle as ko
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gkl_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    out.sort(key=lambda r: r["rank"])
+    A = ko.sparse_random(240, 100, 6, 41)
+    u0 = np.random.default_rng(6).random(240)
+    for name, ref in (("cgs", ko.CGS), ("cgs2", ko.CGS2), ("mgs2", ko.MGS2)):
+        it = ko.GKLIterator(A, u0.copy(), ref)
+        f = ko.gkl_initialize(it)
+        for _ in range(14):
+            f = ko.gkl_expand(it, f)
+        tol = 1e-10 if name != "cgs" else 1e-6
+        for r in out:
+            np.testing.assert_allclose(r[name][0], f.alphas, rtol=tol, err_msg=name)
+            np.testing.assert_allclose(r[name][1], f.betas, rtol=tol, err_msg=name)
+        U = np.vstack([out[0][name][2], out[1][name][2]])
+        V = np.vstack([out[0][name][3], out[1][name][3]])
+        k = U.shape[1]
+        B = np.diag(f.alphas) + np.diag(f.betas[:-1], -1)
+        assert np.max(np.abs(A.T @ U - V @ B.T)) < 1e-9
+        if name == "mgs2":
+            assert np.max(np.abs(U.T @ U - np.eye(k))) < 1e-12 and np.max(np.abs(V.T @ V - np.eye(k))) < 1e-12

@@ -436,6 +436,22 @@ def test_dist_hip_backend_world1(kk, ko, ctx):
         vals, vecs, info = kk.eigsolve(None, None, 3, "SR", kk.Lanczos(krylovdim=30, tol=1e-10, maxiter=100), iterator=it)
         ev = np.linalg.eigvalsh(A.toarray())
         assert info.converged >= 3 and relerr(vals[:3], ev[:3]) < 1e-10
+        # sharded GKL (config 4): ghost-only local operator fed from the gathered v, transposed SpMV + scatter
+        Ar = ko.sparse_random(600, 250, 8, 21)
+        u0 = np.random.default_rng(6).random(600)
+        rop = kd.DistRectOperator(Ar, kd.Partition.even(600, 1, 0), kd.Partition.even(250, 1, 0), be)
+        for dev, ref in ((kk.ClassicalGramSchmidt2(), ko.CGS2), (kk.ModifiedGramSchmidt2(), ko.MGS2)):
+            git = kd.DistGKLIterator(rop, u0, dev, capacity=18)
+            gf = git.initialize()
+            oit = ko.GKLIterator(Ar, u0.copy(), ref)
+            of = ko.gkl_initialize(oit)
+            for _ in range(14):
+                gf = git.expand(gf)
+                of = ko.gkl_expand(oit, of)
+            assert relerr(gf.alphas, of.alphas) < 1e-10 and relerr(gf.betas, of.betas) < 1e-10, dev.name
+            Um, Vm = gf.U.to_numpy(), gf.V.to_numpy()
+            Bm = np.diag(gf.alphas) + np.diag(gf.betas[:-1], -1)
+            assert np.max(np.abs(Ar.T @ Um - Vm @ Bm.T)) < 1e-10
     finally:
         dist.destroy_process_group()
 
