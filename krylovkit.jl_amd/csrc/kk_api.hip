@@ -272,7 +272,7 @@ extern "C" int kk_basis_create(kk_ctx c, int64_t n, int capacity, kk_basis* out)
 }
 extern "C" int kk_basis_free(kk_basis b) {
     if (!b) return KK_OK;
-    (void)hipStreamSynchronize(b->ctx->stream);
+    (void)hipDeviceSynchronize();  // not the context's stream: finalizers may run after the context is gone
     (void)hipFree(b->d);
     delete b;
     return KK_OK;
@@ -516,7 +516,7 @@ extern "C" int kk_csc_create(kk_ctx c, int64_t nrows, int64_t ncols, int64_t nnz
 
 extern "C" int kk_op_free(kk_op op) {
     if (!op) return KK_OK;
-    (void)hipStreamSynchronize(op->ctx->stream);
+    (void)hipDeviceSynchronize();  // see kk_basis_free
     free_sparse(op->A);
     free_sparse(op->At);
     delete op;
