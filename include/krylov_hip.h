@@ -248,6 +248,11 @@ int kk_blocklanczos_expand(kk_op op, kk_basis b, int k, int bs_r, int c_r, int c
  * dev_dot[0] = local <v, A v> (dot_mode 1, lanczos.jl:298) or local <v, w> (dot_mode 2, :308); 0: none */
 int kk_apply_fused_dev(kk_op op, kk_basis b, int col_v, int col_prev, int col_w, double beta_old, int dot_mode,
                        void* dev_dot);
+/* same with device-resident scalars: w = A (xs*v) - bp*v_prev with xs = *dev_xscale (e.g. 1/beta of the
+ * previous iteration, all-reduced on the device) and bp = *dev_bprev; NULL pointers mean xs = 1, bp = beta_old.
+ * Lets the next iteration's SpMV be enqueued before the host has seen beta. */
+int kk_apply_fused_dev2(kk_op op, kk_basis b, int col_v, int col_prev, int col_w, const void* dev_xscale,
+                        const void* dev_bprev, double beta_old, int dot_mode, void* dev_dot);
 /* dev_out[j] = local <b[c0+j], x>, j < m; with a second right-hand side (col_rhs2 >= 0, same
  * basis as x) dev_out[m+j] = local <b[c0+j], rhs2>: the Gram row of the newest vector rides along. */
 int kk_project_dev(kk_basis b, int c0, int m, kk_basis bx, int cx, int col_rhs2, void* dev_out);
@@ -255,6 +260,9 @@ int kk_project_dev(kk_basis b, int c0, int m, kk_basis bx, int cx, int col_rhs2,
  * dev_nrm (optional, 3 doubles) = local |y|^2, its sqrt, 1/sqrt */
 int kk_unproject_dev(kk_basis by, int cy, kk_basis b, int c0, int m, const double* coef, double alpha, double beta,
                      void* dev_nrm);
+/* as kk_unproject_dev with the m coefficients read from device memory (no host round trip) */
+int kk_unproject_devcoef(kk_basis by, int cy, kk_basis b, int c0, int m, const void* dev_coef, double alpha,
+                         double beta, void* dev_nrm);
 int kk_dot_dev(kk_basis bx, int cx, kk_basis by, int cy, void* dev_out);      /* dev_out[0] = local <x,y> */
 int kk_nrm2_dev(kk_basis bx, int cx, void* dev_out3);                          /* local |x|^2, sqrt, 1/sqrt */
 /* y += sign * dev_a[0] * x   (device scalar, e.g. an all-reduced coefficient) */

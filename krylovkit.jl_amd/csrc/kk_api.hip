@@ -1812,6 +1812,29 @@ extern "C" int kk_apply_fused_dev(kk_op op, kk_basis b, int col_v, int col_prev,
     f.dot_out = (double*)dev_dot;
     return kk_launch_spmv(op->ctx, op->A, b->col(col_v), b->col(col_w), b->ld, f);
 }
+extern "C" int kk_apply_fused_dev2(kk_op op, kk_basis b, int col_v, int col_prev, int col_w, const void* dev_xscale,
+                                   const void* dev_bprev, double beta_old, int dot_mode, void* dev_dot) {
+    KK_TRY(check_square_op(op, b));
+    CHECK_COL(b, col_v); CHECK_COL(b, col_w);
+    KK_CHECK(col_prev < b->cap && col_v != col_w, KK_ERR_INVALID, "kk_apply_fused_dev2: bad columns");
+    KK_CHECK(dot_mode == 0 || dev_dot, KK_ERR_INVALID, "kk_apply_fused_dev2: dot requested without output buffer");
+    gram_touch(b, col_w);
+    kk_spmv_fuse f;
+    f.xscale_dev = (const double*)dev_xscale;
+    if (col_prev >= 0) { f.vprev = b->col(col_prev); f.bprev = beta_old; f.bprev_dev = (const double*)dev_bprev; }
+    f.dot_mode = dot_mode;
+    f.dot_out = (double*)dev_dot;
+    return kk_launch_spmv(op->ctx, op->A, b->col(col_v), b->col(col_w), b->ld, f);
+}
+extern "C" int kk_unproject_devcoef(kk_basis by, int cy, kk_basis b, int c0, int m, const void* dev_coef, double alpha,
+                                    double beta, void* dev_nrm) {
+    CHECK_RANGE(b, c0, m); CHECK_COL(by, cy); CHECK_SAME(b, by);
+    KK_CHECK(dev_coef || m == 0, KK_ERR_INVALID, "null coef");
+    KK_CHECK(!(by == b && cy >= c0 && cy < c0 + m), KK_ERR_INVALID, "kk_unproject_devcoef: y aliases a basis column");
+    gram_touch(by, cy);
+    return kk_launch_unproject(b->ctx, b->col(c0), b->ld, m, by->col(cy), by->col(cy), nullptr, (const double*)dev_coef, alpha,
+                               beta, -1, nullptr, (double*)dev_nrm);
+}
 extern "C" int kk_project_dev(kk_basis b, int c0, int m, kk_basis bx, int cx, int col_rhs2, void* dev_out) {
     CHECK_RANGE(b, c0, m); CHECK_COL(bx, cx); CHECK_SAME(b, bx);
     KK_CHECK(dev_out || m == 0, KK_ERR_INVALID, "null output");

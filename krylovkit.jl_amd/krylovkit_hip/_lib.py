@@ -111,6 +111,8 @@ SIGNATURES = {
     "kk_blocklanczos_initialize": (C.c_int, [c_vp, c_vp, C.c_int, C.c_int, C.c_int, C.c_double, c_ip, c_dp, C.c_int, c_dp]),
     "kk_blocklanczos_expand": (C.c_int, [c_vp, c_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, c_ip, c_dp, C.c_int, c_dp, C.c_int, c_dp, c_ip]),
     "kk_apply_fused_dev": (C.c_int, [c_vp, c_vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, c_vp]),
+    "kk_apply_fused_dev2": (C.c_int, [c_vp, c_vp, C.c_int, C.c_int, C.c_int, c_vp, c_vp, C.c_double, C.c_int, c_vp]),
+    "kk_unproject_devcoef": (C.c_int, [c_vp, C.c_int, c_vp, C.c_int, C.c_int, c_vp, C.c_double, C.c_double, c_vp]),
     "kk_project_dev": (C.c_int, [c_vp, C.c_int, C.c_int, c_vp, C.c_int, C.c_int, c_vp]),
     "kk_unproject_dev": (C.c_int, [c_vp, C.c_int, c_vp, C.c_int, C.c_int, c_dp, C.c_double, C.c_double, c_vp]),
     "kk_dot_dev": (C.c_int, [c_vp, C.c_int, c_vp, C.c_int, c_vp]),

@@ -146,9 +146,15 @@ class HipBackend:
     def copy_scal(self, basis, cy, cx, a: float):
         check(self._lib.kk_vec_copy_scal(basis.handle, cy, basis.handle, cx, a))
 
-    def apply_fused(self, op, basis, col_v, col_prev, col_w, beta_old, dot_mode, out):
-        check(self._lib.kk_apply_fused_dev(op.handle, basis.handle, col_v, col_prev, col_w, beta_old, dot_mode,
-                                           C.c_void_p(out.data_ptr())))
+    def apply_fused(self, op, basis, col_v, col_prev, col_w, beta_old, dot_mode, out, xscale=None, bprev=None):
+        check(self._lib.kk_apply_fused_dev2(op.handle, basis.handle, col_v, col_prev, col_w,
+                                            C.c_void_p(xscale.data_ptr() if xscale is not None else 0),
+                                            C.c_void_p(bprev.data_ptr() if bprev is not None else 0), beta_old, dot_mode,
+                                            C.c_void_p(out.data_ptr())))
+
+    def unproject_dev(self, basis, col_y, c0, m, coef_t, alpha, beta, nrm_out):
+        check(self._lib.kk_unproject_devcoef(basis.handle, col_y, basis.handle, c0, m, C.c_void_p(coef_t.data_ptr()), alpha,
+                                             beta, C.c_void_p(nrm_out.data_ptr() if nrm_out is not None else 0)))
 
     def project(self, basis, c0, m, col_x, col_rhs2, out):
         check(self._lib.kk_project_dev(basis.handle, c0, m, basis.handle, col_x, col_rhs2, C.c_void_p(out.data_ptr())))
@@ -252,9 +258,16 @@ class DistLanczosIterator:
                 "(their pass count is data dependent); use cgs2 / mgs2")
         be = self.operator.backend
         self.backend = be
+        import torch
+        self.torch = torch
         self.buf = be.alloc(2 * 256 + 8)   # [alpha0 | p (m) | g (m)]
         self.nbuf = be.alloc(4)            # [|w|^2, sqrt, 1/sqrt, spare]
-        self.gram: Optional[np.ndarray] = None  # strictly-lower Gram rows for the low-sync MGS
+        self.coef = be.alloc(256)          # coefficients of the update, formed on the device
+        self.res = be.alloc(4)             # [alpha0, s_m, |w|^2]: the one read-back per expand!
+        self.sc = be.alloc(2)              # [1/beta, beta] of the finished iteration (device scalars)
+        self.sbuf = be.alloc(1)            # alpha0 of a speculative next-step SpMV
+        self._spec = None
+        self.Ldev = None                   # strictly-lower Gram matrix of the basis (low-sync MGS), on the device
 
     def _allreduce(self, t):
         part = self.operator.part
@@ -294,47 +307,75 @@ class DistLanczosIterator:
             self._allreduce(self.nbuf[0:1])
             beta = float(np.sqrt(be.to_host(self.nbuf[0:1])[0]))
         V.length = 1
-        self.gram = np.zeros((self.capacity, self.capacity))
+        self.Ldev = be.alloc(self.capacity * self.capacity).reshape(self.capacity, self.capacity)
         self.gram_rows = 1
+        self._spec = None
         return LanczosFactorization(1, V, [alpha], [beta])
+
+    def _speculate(self, st, k_next: int, beta: float, dot_mode: int):
+        """Enqueue the halo exchange + SpMV of iteration k_next (on the RAW residual, the 1/beta
+        scale applied on the fly from the all-reduced device norm) before the host reads beta."""
+        V = st.V
+        self._spec = None
+        if k_next + 2 > V.capacity:
+            return
+        be, op = self.backend, self.operator
+        self.sc[1:2] = self.nbuf[0:1].sqrt()
+        self.sc[0:1] = 1.0 / self.sc[1:2]
+        op.halo_exchange(V, k_next)
+        be.apply_fused(op.local, V, k_next, k_next - 1, k_next + 1, 0.0, dot_mode, self.sbuf,
+                       xscale=self.sc[0:1], bprev=self.sc[1:2])
+        self._spec = [k_next, None, id(V)]
 
     # expand!(iter, state) -- lanczos.jl:250-272 + lanczosrecurrence :295-338
     def expand(self, st: LanczosFactorization) -> LanczosFactorization:
         be, op, V = self.backend, self.operator, st.V
+        torch = self.torch
         k = len(V)
         if k + 2 > V.capacity:
             raise RuntimeError(f"Lanczos slab of capacity {V.capacity} is full at k={k}")
         m = k + 1
         beta_old = st.normres
         name = self.orth.name
-        be.scal(V, k, 1.0 / beta_old)                       # V = push!(V, scale!!(r, 1/beta_old))
-        op.halo_exchange(V, k)
         dot_mode = 1 if name in ("cgs", "cgs2") else 2
-        be.apply_fused(op.local, V, k, k - 1, k + 1, beta_old, dot_mode, self.buf)
+        hit = self._spec is not None and self._spec == [k, beta_old, id(V)]
+        self._spec = None
+        be.scal(V, k, 1.0 / beta_old)                       # V = push!(V, scale!!(r, 1/beta_old))
+        if hit:
+            self.buf[0:1] = self.sbuf[0:1]                   # the SpMV of this step is already done
+        else:
+            op.halo_exchange(V, k)
+            be.apply_fused(op.local, V, k, k - 1, k + 1, beta_old, dot_mode, self.buf)
         if name in ("cgs", "mgs"):
             self._allreduce(self.buf[0:1])
-            alpha = float(be.to_host(self.buf[0:1])[0])
-            be.unproject(V, k + 1, k, 1, [alpha], -1.0, 1.0, self.nbuf)
+            self.res[0:1] = self.buf[0:1]
+            self.res[1:2] = 0.0
+            be.unproject_dev(V, k + 1, k, 1, self.buf[0:1], -1.0, 1.0, self.nbuf)
         else:
             be.project(V, 0, m, k + 1, k, self.buf[1:1 + 2 * m])
             self._allreduce(self.buf[0:1 + 2 * m])           # ONE all-reduce: alpha0, V'w, V'v
-            h = be.to_host(self.buf[0:1 + 2 * m])
-            alpha0, p, g = float(h[0]), h[1:1 + m], h[1 + m:1 + 2 * m]
-            s = p - alpha0 * g                               # = V'(w - alpha0 v)
+            a0, p, g = self.buf[0:1], self.buf[1:1 + m], self.buf[1 + m:1 + 2 * m]
+            s = p - a0 * g                                   # = V'(w - alpha0 v), on the device
             if name == "mgs2":
                 # low-sync MGS: (I + L) s = V'(w - alpha0 v), L = strictly lower Gram matrix of V
                 if self.gram_rows < k:
-                    raise RuntimeError("Gram rows out of date (basis changed outside expand); call invalidate()")
-                self.gram[k, :k] = g[:k]
+                    raise RuntimeError("Gram rows out of date (basis changed outside expand); call recompute_gram()")
+                self.Ldev[k, :k] = g[:k]
                 self.gram_rows = k + 1
-                for i in range(1, m):
-                    s[i] -= self.gram[i, :i] @ s[:i]
-            coef = s.copy()
-            coef[m - 1] += alpha0
-            alpha = alpha0 + float(s[m - 1])
-            be.unproject(V, k + 1, 0, m, coef, -1.0, 1.0, self.nbuf)
+                s = torch.linalg.solve_triangular(self.Ldev[:m, :m], s[:, None], upper=False, unitriangular=True)[:, 0]
+            self.coef[:m] = s
+            self.coef[m - 1:m] += a0
+            self.res[0:1] = a0
+            self.res[1:2] = s[m - 1:m]
+            be.unproject_dev(V, k + 1, 0, m, self.coef, -1.0, 1.0, self.nbuf)
         self._allreduce(self.nbuf[0:1])
-        beta = float(np.sqrt(be.to_host(self.nbuf[0:1])[0]))
+        self.res[2:3] = self.nbuf[0:1]
+        self._speculate(st, k + 1, 0.0, dot_mode)           # keeps the GPU / links busy during the read-back
+        h = be.to_host(self.res[0:3])                        # the ONE host synchronisation of this expand!
+        alpha = float(h[0] + h[1])
+        beta = float(np.sqrt(h[2]))
+        if self._spec is not None:
+            self._spec[1] = beta
         st.alphas.append(alpha)
         st.betas.append(beta)
         V.length = m
@@ -345,11 +386,12 @@ class DistLanczosIterator:
         """After a restart transformed the basis: rebuild the strictly-lower Gram rows."""
         be, V = self.backend, st.V
         k = len(V)
-        self.gram[:] = 0.0
+        self._spec = None
+        self.Ldev.zero_()
         for i in range(1, k):
             be.project(V, 0, i, i, -1, self.buf[0:i])
             self._allreduce(self.buf[0:i])
-            self.gram[i, :i] = be.to_host(self.buf[0:i])
+            self.Ldev[i, :i] = self.buf[0:i]
         self.gram_rows = max(k, 1)
 
 

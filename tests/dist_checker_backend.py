@@ -72,17 +72,23 @@ class CheckerBackend:
     def copy_scal(self, b, cy, cx, a):
         b.cols[cy] = a * b.cols[cx]
 
-    def apply_fused(self, op, b, cv, cprev, cw, beta_old, dot_mode, out):
+    def apply_fused(self, op, b, cv, cprev, cw, beta_old, dot_mode, out, xscale=None, bprev=None):
+        xs = float(xscale[0]) if xscale is not None else 1.0
+        bp = float(bprev[0]) if bprev is not None else beta_old
         x = np.concatenate([b.cols[cv], op.ghost.numpy()[: op.n_ghost]])
-        ax = op.A @ x
+        ax = (op.A @ x) * xs
+        v = b.cols[cv] * xs
         w = ax.copy()
         if cprev >= 0:
-            w -= beta_old * b.cols[cprev]
+            w -= bp * b.cols[cprev]
         if dot_mode == 1:
-            out[0] = float(b.cols[cv] @ ax)
+            out[0] = float(v @ ax)
         elif dot_mode == 2:
-            out[0] = float(b.cols[cv] @ w)
+            out[0] = float(v @ w)
         b.cols[cw] = w
+
+    def unproject_dev(self, b, cy, c0, m, coef_t, alpha, beta, nrm_out):
+        self.unproject(b, cy, c0, m, coef_t.numpy()[:m], alpha, beta, nrm_out)
 
     def project(self, b, c0, m, cx, crhs2, out):
         V = b.cols[c0:c0 + m]
