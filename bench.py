@@ -300,9 +300,14 @@ def main():
         }
         if world == 1 and not use_dist and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(orth.code)
-        print(json.dumps(out), flush=True)
+        line = json.dumps(out)
     if use_dist:
+        dist.barrier()
         dist.destroy_process_group()
+    sys.stdout.flush()
+    sys.stderr.flush()
+    if rank == 0:
+        print(line, flush=True)   # the ONE JSON line, last thing on stdout (RCCL prints its banner on stdout too)
 
 
 if __name__ == "__main__":
