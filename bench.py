@@ -306,6 +306,10 @@ def main():
         dist.destroy_process_group()
     sys.stdout.flush()
     sys.stderr.flush()
+    try:
+        C.CDLL(None).fflush(None)   # RCCL's version banner sits in the C stdio buffer until exit: push it out first
+    except Exception:
+        pass
     if rank == 0:
         print(line, flush=True)   # the ONE JSON line, last thing on stdout (RCCL prints its banner on stdout too)
 
