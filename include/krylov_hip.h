@@ -90,6 +90,25 @@ int kk_ctx_prof_enable(kk_ctx ctx, int on); /* 0 off, 1 all kernel classes, 2 on
 int kk_ctx_prof_reset(kk_ctx ctx);
 int kk_ctx_prof_get(kk_ctx ctx, const char* kernel_class, double* total_ms, int64_t* launches);
 
+/* ---------------------------------------------------------------- row-sharded operation (hooks)
+ * With these hooks EVERY entry point of this library works on row-sharded vectors (one process /
+ * context per GPU, each holding a contiguous row block of every vector): all inner-product-type
+ * results pass through a handful of finalize kernels, and right after each of them the library
+ * calls `allreduce(user, device_ptr, count)` so the caller can sum the `count` doubles at
+ * `device_ptr` across ranks IN PLACE on the context's stream (RCCL); sparse applies call the
+ * operator's halo hook first so the caller can fill the ghost buffer.  Host-side control flow then
+ * sees identical scalars on every rank.  Hooks return 0 on success. */
+typedef int (*kk_allreduce_fn)(void* user, void* device_ptr, int64_t count);
+typedef int (*kk_halo_fn)(void* user, const void* x_device);
+int kk_ctx_set_allreduce(kk_ctx ctx, kk_allreduce_fn fn, void* user);
+/* Let the caller own the two device scratch areas the reductions land in (e.g. torch tensors that
+ * RCCL can address): ws (ws_count doubles) and blk (blk_count doubles); sizes from kk_ctx_workspace_size. */
+int kk_ctx_workspace_size(kk_ctx ctx, int64_t* ws_count, int64_t* blk_count);
+int kk_ctx_set_workspace(kk_ctx ctx, void* ws_device, void* blk_device);
+int kk_op_set_halo_hook(kk_op op, kk_halo_fn fn, void* user);
+/* gather out[i] = x[idx[i]] from a raw device vector (packing halo send buffers inside a halo hook) */
+int kk_gather_ptr(kk_ctx ctx, const void* x_device, const int64_t* device_idx, int64_t count, void* device_out);
+
 /* ---------------------------------------------------------------- basis slab
  * replaces OrthonormalBasis{T} (src/orthonormal.jl:26-54) and the residual / work vectors of
  * the factorizations (factorizations/lanczos.jl:31-37, arnoldi.jl:31-36, gkl.jl:31-38). */

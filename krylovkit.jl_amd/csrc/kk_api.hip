@@ -63,12 +63,14 @@ extern "C" int kk_ctx_create(int device, kk_ctx* out) {
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     KK_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
-    KK_HIP(hipMalloc(&c->ws, WS_TOTAL * sizeof(double)));
-    KK_HIP(hipMemset(c->ws, 0, WS_TOTAL * sizeof(double)));
+    KK_HIP(hipMalloc(&c->ws_own, WS_TOTAL * sizeof(double)));
+    KK_HIP(hipMemset(c->ws_own, 0, WS_TOTAL * sizeof(double)));
+    c->ws = c->ws_own;
     KK_HIP(hipMalloc(&c->partials, (size_t)(2 * KK_MAX_M + 8) * KK_MAX_BLOCKS * sizeof(double)));
     KK_HIP(hipHostMalloc(&c->h_pin, 4 * WS_TOTAL * sizeof(double), hipHostMallocDefault));
     KK_HIP(hipHostMalloc(&c->h_U, (size_t)KK_MAX_M * KK_MAX_M * sizeof(double), hipHostMallocDefault));
-    KK_HIP(hipMalloc(&c->blk, (size_t)KK_BLK_SCRATCH * sizeof(double)));
+    KK_HIP(hipMalloc(&c->blk_own, (size_t)KK_BLK_SCRATCH * sizeof(double)));
+    c->blk = c->blk_own;
     KK_HIP(hipHostMalloc(&c->h_blk, (size_t)KK_BLK_SCRATCH * sizeof(double), hipHostMallocDefault));
     if (getenv("KK_BLOCK_MODE")) c->block_mode = atoi(getenv("KK_BLOCK_MODE"));
     KK_HIP(hipEventCreate(&c->t0));
@@ -91,11 +93,11 @@ extern "C" int kk_ctx_destroy(kk_ctx c) {
     (void)hipEventDestroy(c->t0);
     (void)hipEventDestroy(c->t1);
     (void)hipEventDestroy(c->ev_fetch);
-    (void)hipFree(c->ws);
+    (void)hipFree(c->ws_own);
     (void)hipFree(c->partials);
     (void)hipHostFree(c->h_pin);
     (void)hipHostFree(c->h_U);
-    (void)hipFree(c->blk);
+    (void)hipFree(c->blk_own);
     (void)hipHostFree(c->h_blk);
     (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -151,6 +153,27 @@ extern "C" int kk_ctx_get_option(kk_ctx c, const char* key, double* value) {
         kk_set_error("unknown option '%s'", key);
         return KK_ERR_INVALID;
     }
+    return KK_OK;
+}
+extern "C" int kk_ctx_set_allreduce(kk_ctx c, kk_allreduce_fn fn, void* user) {
+    KK_CHECK(c, KK_ERR_INVALID, "null ctx");
+    KK_HIP(hipStreamSynchronize(c->stream));
+    c->allreduce = fn;
+    c->allreduce_user = user;
+    return KK_OK;
+}
+extern "C" int kk_ctx_workspace_size(kk_ctx c, int64_t* ws_count, int64_t* blk_count) {
+    KK_CHECK(c, KK_ERR_INVALID, "null ctx");
+    if (ws_count) *ws_count = WS_TOTAL;
+    if (blk_count) *blk_count = KK_BLK_SCRATCH;
+    return KK_OK;
+}
+extern "C" int kk_ctx_set_workspace(kk_ctx c, void* ws_device, void* blk_device) {
+    KK_CHECK(c, KK_ERR_INVALID, "null ctx");
+    KK_HIP(hipStreamSynchronize(c->stream));
+    c->ws = ws_device ? (double*)ws_device : c->ws_own;
+    c->blk = blk_device ? (double*)blk_device : c->blk_own;
+    KK_HIP(hipMemsetAsync(c->ws, 0, WS_TOTAL * sizeof(double), c->stream));
     return KK_OK;
 }
 extern "C" int kk_ctx_timer_start(kk_ctx c) {
@@ -543,6 +566,17 @@ extern "C" int kk_op_set_ghost(kk_op op, int64_t n_local_cols, int64_t n_ghost, 
     op->A.n_ghost = n_ghost;
     op->A.ghost = (double*)device_ghost;  // caller-owned
     return KK_OK;
+}
+
+extern "C" int kk_op_set_halo_hook(kk_op op, kk_halo_fn fn, void* user) {
+    KK_CHECK(op, KK_ERR_INVALID, "null op");
+    op->A.halo = fn;
+    op->A.halo_user = user;
+    return KK_OK;
+}
+extern "C" int kk_gather_ptr(kk_ctx c, const void* x_device, const int64_t* device_idx, int64_t count, void* device_out) {
+    KK_CHECK(c && x_device && (count == 0 || (device_idx && device_out)), KK_ERR_INVALID, "kk_gather_ptr: null arg");
+    return kk_launch_gather(c, (const double*)x_device, device_idx, count, (double*)device_out);
 }
 
 static int get_matrix(kk_op op, int transpose, const kk_sparse_dev** M) {
@@ -1452,6 +1486,7 @@ static int block_inner_run(kk_ctx c, const double* X, int64_t ldx, int p, const 
                 KK_TRY(kk_launch_block_gram(c, X + (int64_t)i0 * ldx, ldx, std::min(128, p - i0), Y + (int64_t)j0 * ldy, ldy,
                                             std::min(16, q - j0), ld, c->blk + i0 + (int64_t)p * j0, p));
     }
+    if (c->block_mode != 0) KK_TRY(kk_allreduce(c, c->blk, (int64_t)p * q));
     KK_HIP(hipMemcpyAsync(c->h_blk, c->blk, (size_t)p * q * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     KK_TRY(stream_sync(c));
     for (int j = 0; j < q; ++j) memcpy(M + (size_t)j * ldm, c->h_blk + (size_t)j * p, p * sizeof(double));

@@ -58,7 +58,11 @@ struct kk_ctx_s {
     int num_cus = 256;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
-    double* ws = nullptr;        // device scalar workspace [WS_TOTAL]
+    double* ws = nullptr;        // device scalar workspace [WS_TOTAL] (ws_own unless the caller supplied one)
+    double* ws_own = nullptr;
+    double* blk_own = nullptr;
+    kk_allreduce_fn allreduce = nullptr;   // row-sharded operation: sum partial results across ranks in place
+    void* allreduce_user = nullptr;
     double* partials = nullptr;  // device partial sums [(2*KK_MAX_M + 8) * KK_MAX_BLOCKS]
     double* h_pin = nullptr;     // pinned host staging [4][WS_TOTAL]
     double* h_U = nullptr;       // pinned staging for basistransform's U [KK_MAX_M^2]
@@ -112,6 +116,8 @@ struct kk_sparse_dev {  // one direction (A or A') on the device
     // ghost columns (row-sharded operators)
     int64_t n_local = -1, n_ghost = 0;
     double* ghost = nullptr;
+    kk_halo_fn halo = nullptr;   // called with the x vector before every apply (fills `ghost`)
+    void* halo_user = nullptr;
     int64_t bytes = 0;
 };
 
@@ -208,3 +214,13 @@ int kk_launch_block_update(kk_ctx ctx, const double* V, int64_t ld, int m, const
 int kk_launch_spmm(kk_ctx ctx, const kk_sparse_dev& M, const double* X, int64_t ldx, double* Y, int64_t ldy, int nb);
 int kk_launch_unproj_proj(kk_ctx ctx, const double* V, int64_t ld, int m, const double* w_in, double* w_out,
                           const kk_coef* coef_host, const double* coef_dev, double* out_s, double* nrm_out3);
+// row-sharded hook: no-op unless kk_ctx_set_allreduce installed one
+static inline int kk_allreduce(kk_ctx ctx, double* dev_ptr, int64_t count) {
+    if (!ctx->allreduce || count <= 0) return KK_OK;
+    int st = ctx->allreduce(ctx->allreduce_user, dev_ptr, count);
+    if (st != 0) {
+        kk_set_error("all-reduce hook failed with status %d", st);
+        return KK_ERR_INVALID;
+    }
+    return KK_OK;
+}

@@ -119,6 +119,13 @@ __global__ __launch_bounds__(KK_TPB) void k_finalize_scalar(const double* __rest
     }
 }
 
+// t[1] = sqrt(t[0]), t[2] = 1/sqrt(t[0])  (after an all-reduce of a squared norm)
+__global__ void k_sqrt_triple(double* __restrict__ t) {
+    const double s = sqrt(t[0]);
+    t[1] = s;
+    t[2] = 1.0 / s;
+}
+
 // y = b*y + a*x ; a = a_host, or a_sign * (*a_dev) [mode 1], or a_sign / (*a_dev) [mode 2]
 template <bool BZERO>
 __global__ __launch_bounds__(KK_TPB) void k_axpby(double* __restrict__ y, const double* __restrict__ x, int64_t ld,
@@ -968,9 +975,17 @@ static inline double* part_row(kk_ctx ctx, int row) { return ctx->partials + (in
 #define PART_SCAL_B (2 * KK_MAX_M + 1)
 
 static int finalize_scalar(kk_ctx ctx, int part_row_idx, int n, double* out, bool with_sqrt) {
+    const bool sharded = ctx->allreduce != nullptr;
     hipLaunchKernelGGL(k_finalize_scalar, dim3(1), dim3(KK_TPB), 0, ctx->stream, part_row(ctx, part_row_idx), n,
-                       out, with_sqrt ? 1 : 0);
+                       out, (with_sqrt && !sharded) ? 1 : 0);
     KK_HIP(hipGetLastError());
+    if (sharded) {  // sum the local partial over the ranks, then (re)derive sqrt and 1/sqrt
+        KK_TRY(kk_allreduce(ctx, out, 1));
+        if (with_sqrt) {
+            hipLaunchKernelGGL(k_sqrt_triple, dim3(1), dim3(1), 0, ctx->stream, out);
+            KK_HIP(hipGetLastError());
+        }
+    }
     return KK_OK;
 }
 
@@ -1058,6 +1073,8 @@ int kk_launch_project(kk_ctx ctx, const double* V, int64_t ld, int m, const doub
     hipLaunchKernelGGL(k_finalize_project, dim3((total + 3) / 4), dim3(KK_TPB), 0, ctx->stream, part, p.nblk, m,
                        out_s, rhs2 ? out_g : (double*)nullptr);
     KK_HIP(hipGetLastError());
+    KK_TRY(kk_allreduce(ctx, out_s, m));
+    if (rhs2) KK_TRY(kk_allreduce(ctx, out_g, m));
     return KK_OK;
 }
 
@@ -1106,6 +1123,10 @@ int kk_launch_mgs_step(kk_ctx ctx, double* w, int64_t ld, const double* q_prev, 
 int kk_launch_spmv(kk_ctx ctx, const kk_sparse_dev& M, const double* x, double* y, int64_t ld_y_rows,
                    const kk_spmv_fuse& f) {
     (void)ld_y_rows;
+    if (M.halo) {  // row-sharded operator: let the caller fill the ghost buffer from x (P2P on this stream)
+        const int st = M.halo(M.halo_user, x);
+        if (st != 0) { kk_set_error("halo hook failed with status %d", st); return KK_ERR_INVALID; }
+    }
     spmv_epi e;
     e.a1 = f.a1; e.a0 = f.a0; e.bprev = f.bprev;
     e.xs_dev = f.xscale_dev; e.bprev_dev = f.bprev_dev; e.vprev = f.vprev;
@@ -1276,13 +1297,14 @@ int kk_launch_block_update(kk_ctx ctx, const double* V, int64_t ld, int m, const
         hipLaunchKernelGGL(k_finalize_project, dim3((nb + 3) / 4), dim3(KK_TPB), 0, ctx->stream, part, p.nblk, nb, norms2_dev,
                            (double*)nullptr);
         KK_HIP(hipGetLastError());
+        KK_TRY(kk_allreduce(ctx, norms2_dev, nb));
     }
     return KK_OK;
 }
 
 // Y[:, j] = A X[:, j], j < nb (any nb: processed 16 / 8 / 4 columns at a time)
 int kk_launch_spmm(kk_ctx ctx, const kk_sparse_dev& M, const double* X, int64_t ldx, double* Y, int64_t ldy, int nb) {
-    if (M.format != 0 || M.n_ghost > 0) {  // CSR / ghosted operators: one SpMV per column
+    if (M.format != 0 || M.n_ghost > 0 || M.halo) {  // CSR / ghosted operators: one SpMV per column
         for (int j = 0; j < nb; ++j) {
             kk_spmv_fuse f;
             KK_TRY(kk_launch_spmv(ctx, M, X + (int64_t)j * ldx, Y + (int64_t)j * ldy, ldy, f));
@@ -1340,6 +1362,7 @@ int kk_launch_unproj_proj(kk_ctx ctx, const double* V, int64_t ld, int m, const 
     KK_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_finalize_project, dim3((m + 3) / 4), dim3(KK_TPB), 0, ctx->stream, part, p.nblk, m, out_s, (double*)nullptr);
     KK_HIP(hipGetLastError());
+    KK_TRY(kk_allreduce(ctx, out_s, m));
     if (nrm_out3) return finalize_scalar(ctx, PART_SCAL_A, p.nblk, nrm_out3, true);
     return KK_OK;
 }

@@ -65,6 +65,11 @@ SIGNATURES = {
     "kk_ctx_prof_enable": (C.c_int, [c_vp, C.c_int]),
     "kk_ctx_prof_reset": (C.c_int, [c_vp]),
     "kk_ctx_prof_get": (C.c_int, [c_vp, C.c_char_p, c_dp, c_i64p]),
+    "kk_ctx_set_allreduce": (C.c_int, [c_vp, c_vp, c_vp]),
+    "kk_ctx_workspace_size": (C.c_int, [c_vp, c_i64p, c_i64p]),
+    "kk_ctx_set_workspace": (C.c_int, [c_vp, c_vp, c_vp]),
+    "kk_op_set_halo_hook": (C.c_int, [c_vp, c_vp, c_vp]),
+    "kk_gather_ptr": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, c_vp]),
     "kk_basis_create": (C.c_int, [c_vp, C.c_int64, C.c_int, c_vpp]),
     "kk_basis_free": (C.c_int, [c_vp]),
     "kk_basis_info": (C.c_int, [c_vp, c_i64p, c_i64p, c_ip, c_vpp]),

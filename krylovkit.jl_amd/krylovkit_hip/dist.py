@@ -562,3 +562,147 @@ class DistGKLIterator:
         U.length = V.length = k + 1
         st.k += 1
         return st
+
+
+# ------------------------------------------------------------------------------ hook-based sharding
+# libkrylov_hip calls an all-reduce hook after every finalize kernel and a halo hook before every
+# sparse apply (include/krylov_hip.h, "row-sharded operation").  Installing them turns the ORDINARY
+# objects -- SparseOperator on the local rows, DeviceBasis = local shard, Lanczos / Arnoldi /
+# BlockLanczos iterators, eigsolve / linsolve / eigsolve_block and all six orthogonalisers -- into
+# their row-sharded versions: the host control flow is unchanged and sees identical scalars on
+# every rank.  (The split-phase iterators above remain the latency-optimised path for Lanczos / GKL.)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64)
+HALO_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)
+
+
+class TorchCollective:
+    """Collectives over torch.distributed (backend "nccl" = RCCL over xGMI)."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist, self.group = dist, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+
+    def all_reduce(self, t):
+        if self.world > 1:
+            self.dist.all_reduce(t, group=self.group)
+
+    def all_gather_object(self, obj):
+        if self.world == 1:
+            return [obj]
+        out = [None] * self.world
+        self.dist.all_gather_object(out, obj, group=self.group)
+        return out
+
+    def exchange(self, sendbuf, send_counts, recvbuf, recv_counts):
+        dist = self.dist
+        ops, so, ro = [], 0, 0
+        for q in range(self.world):
+            if send_counts[q]:
+                ops.append(dist.P2POp(dist.isend, sendbuf[so:so + send_counts[q]], q, group=self.group))
+                so += send_counts[q]
+            if recv_counts[q]:
+                ops.append(dist.P2POp(dist.irecv, recvbuf[ro:ro + recv_counts[q]], q, group=self.group))
+                ro += recv_counts[q]
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+
+
+class ShardedContext:
+    """One rank of a row-sharded run: a HipBackend context with the library's all-reduce hook
+    installed; the two device scratch areas the reductions land in are torch tensors."""
+
+    def __init__(self, coll, device_index: int = 0, backend: Optional[HipBackend] = None):
+        self.coll = coll
+        self.backend = backend or HipBackend(device_index)
+        self.ctx = self.backend.ctx
+        lib = self.ctx._lib
+        nws, nblk = C.c_int64(), C.c_int64()
+        check(lib.kk_ctx_workspace_size(self.ctx.handle, C.byref(nws), C.byref(nblk)))
+        self.ws = self.backend.alloc(nws.value)
+        self.blk = self.backend.alloc(nblk.value)
+        check(lib.kk_ctx_set_workspace(self.ctx.handle, C.c_void_p(self.ws.data_ptr()), C.c_void_p(self.blk.data_ptr())))
+        self._bufs = [(self.ws.data_ptr(), self.ws), (self.blk.data_ptr(), self.blk)]
+        self.calls = 0
+
+        def _cb(user, ptr, count):
+            try:
+                for base, t in self._bufs:
+                    off = (ptr - base) // 8
+                    if 0 <= off and off + count <= t.numel():
+                        self.coll.all_reduce(t[off:off + count])
+                        self.calls += 1
+                        return 0
+                return 2  # pointer outside the registered scratch areas
+            except Exception:  # never let an exception cross the C boundary
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        self._cb = ALLREDUCE_FN(_cb)
+        check(lib.kk_ctx_set_allreduce(self.ctx.handle, self._cb, None))
+
+    def close(self):
+        check(self.ctx._lib.kk_ctx_set_allreduce(self.ctx.handle, None, None))
+        check(self.ctx._lib.kk_ctx_set_workspace(self.ctx.handle, None, None))
+
+    def operator(self, A_rows, part: Partition) -> "ShardedOperator":
+        return ShardedOperator(A_rows, part, self)
+
+    def basis(self, n_local: int, capacity: int) -> DeviceBasis:
+        return DeviceBasis(n_local, capacity, self.ctx)
+
+
+class ShardedOperator(SparseOperator):
+    """SparseOperator on this rank's rows (global column indices) whose applies exchange the ghost
+    entries through the library's halo hook -- usable wherever a SparseOperator is (iterators,
+    eigsolve, linsolve, eigsolve_block)."""
+
+    def __init__(self, A_rows, part: Partition, sctx: ShardedContext):
+        import scipy.sparse as sp
+        be, coll = sctx.backend, sctx.coll
+        self.part, self.sctx = part, sctx
+        A = sp.csr_matrix(A_rows)
+        nl = part.n_local
+        assert A.shape == (nl, part.n_global), (A.shape, nl, part.n_global)
+        cols = A.indices.astype(np.int64)
+        mine = (cols >= part.lo) & (cols < part.hi)
+        needed = np.unique(cols[~mine])
+        owner = np.searchsorted(part.offsets, needed, side="right") - 1
+        newcols = np.where(mine, cols - part.lo, nl + np.searchsorted(needed, cols))
+        A_loc = sp.csr_matrix((A.data, newcols.astype(np.int32), A.indptr), shape=(nl, nl + len(needed)))
+        self.n_ghost = len(needed)
+        requests = coll.all_gather_object(needed)
+        self.recv_counts = [int(np.sum(owner == q)) for q in range(part.world)]
+        send_lists = []
+        for q in range(part.world):
+            req = requests[q]
+            sel = req[(req >= part.lo) & (req < part.hi)] - part.lo if q != part.rank else np.zeros(0, dtype=np.int64)
+            send_lists.append(sel.astype(np.int64))
+        self.send_counts = [len(s_) for s_ in send_lists]
+        tot = sum(self.send_counts)
+        self.send_idx = be.from_host_i64(np.concatenate(send_lists) if tot else np.zeros(0, dtype=np.int64))
+        self.sendbuf = be.alloc(max(tot, 1))
+        self.ghost = be.alloc(max(self.n_ghost, 1))
+        super().__init__(A_loc, sctx.ctx)
+        self.shape = (nl, nl)  # as seen by the iterators: local rows x local columns
+        lib = self._lib
+        check(lib.kk_op_set_ghost(self.handle, nl, self.n_ghost, C.c_void_p(self.ghost.data_ptr() if self.n_ghost else 0)))
+
+        def _halo(user, xptr):
+            try:
+                if tot:
+                    check(lib.kk_gather_ptr(sctx.ctx.handle, C.c_void_p(xptr), C.c_void_p(self.send_idx.data_ptr()), tot,
+                                            C.c_void_p(self.sendbuf.data_ptr())))
+                coll.exchange(self.sendbuf, self.send_counts, self.ghost, self.recv_counts)
+                return 0
+            except Exception:
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        self._halo_cb = HALO_FN(_halo)
+        if part.world > 1:
+            check(lib.kk_op_set_halo_hook(self.handle, self._halo_cb, None))
