@@ -452,6 +452,12 @@ def test_dist_hip_backend_world1(kk, ko, ctx):
             Um, Vm = gf.U.to_numpy(), gf.V.to_numpy()
             Bm = np.diag(gf.alphas) + np.diag(gf.betas[:-1], -1)
             assert np.max(np.abs(Ar.T @ Um - Vm @ Bm.T)) < 1e-10
+        # hook-based sharding over torch.distributed (RCCL), world 1: callback plumbing / pointer resolution
+        sctx = kd.ShardedContext(kd.TorchCollective(), 0, backend=be)
+        hop = sctx.operator(A, part)
+        vals, vecs, info = kk.eigsolve(hop, x0, 2, "SR", kk.Lanczos(krylovdim=30, tol=1e-10, maxiter=100))
+        assert relerr(vals[:2], ev[:2]) < 1e-10 and sctx.calls > 100
+        sctx.close()
     finally:
         dist.destroy_process_group()
 
