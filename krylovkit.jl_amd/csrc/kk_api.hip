@@ -401,6 +401,7 @@ extern "C" int kk_vec_fill_random(kk_basis bx, int cx, uint64_t seed) {
 static void free_sparse(kk_sparse_dev& M) {
     (void)hipFree(M.ell_col); (void)hipFree(M.ell_val);
     (void)hipFree(M.rowptr); (void)hipFree(M.colind); (void)hipFree(M.val);
+    (void)hipFree(M.sell_off); (void)hipFree(M.sell_perm); (void)hipFree(M.sell_col); (void)hipFree(M.sell_val);
     M = kk_sparse_dev();
 }
 
@@ -413,7 +414,8 @@ static int upload_sparse(kk_ctx c, const kk_host_csr& h, kk_sparse_dev& M) {
     for (int64_t i = 0; i < nrows; ++i) maxw = std::max(maxw, h.rowptr[i + 1] - h.rowptr[i]);
     const bool force_csr = getenv("KK_SPMV_FORMAT") && !strcmp(getenv("KK_SPMV_FORMAT"), "csr");
     const bool force_ell = getenv("KK_SPMV_FORMAT") && !strcmp(getenv("KK_SPMV_FORMAT"), "ell");
-    const bool ell = !force_csr && (force_ell || (maxw <= 64 && (double)maxw * nrows <= 1.25 * (double)nnz + 4096));
+    const bool force_sell = getenv("KK_SPMV_FORMAT") && !strcmp(getenv("KK_SPMV_FORMAT"), "sell");
+    const bool ell = !force_csr && !force_sell && (force_ell || (maxw <= 64 && (double)maxw * nrows <= 1.25 * (double)nnz + 4096));
     if (ell) {
         M.format = 0;
         M.width = (int)std::max<int64_t>(maxw, 1);
@@ -432,6 +434,53 @@ static int upload_sparse(kk_ctx c, const kk_host_csr& h, kk_sparse_dev& M) {
         KK_HIP(hipMemcpy(M.ell_col, ec.data(), ec.size() * sizeof(int32_t), hipMemcpyHostToDevice));
         KK_HIP(hipMemcpy(M.ell_val, ev.data(), ev.size() * sizeof(double), hipMemcpyHostToDevice));
         M.bytes = ec.size() * 4 + ev.size() * 8;
+    } else if (!force_csr) {
+        // SELL-64-sigma: sort rows by length inside windows of sigma rows, slice into chunks of 64
+        M.format = 2;
+        const int64_t C = 64, sigma = 64 * 64;
+        const int64_t nchunks = (nrows + C - 1) / C;
+        std::vector<int32_t> perm((size_t)nchunks * C, -1);
+        std::vector<int32_t> order(nrows);
+        for (int64_t i = 0; i < nrows; ++i) order[i] = (int32_t)i;
+        for (int64_t w0 = 0; w0 < nrows; w0 += sigma) {
+            const int64_t w1 = std::min(nrows, w0 + sigma);
+            std::stable_sort(order.begin() + w0, order.begin() + w1, [&](int32_t a, int32_t b) {
+                return (h.rowptr[a + 1] - h.rowptr[a]) > (h.rowptr[b + 1] - h.rowptr[b]);
+            });
+        }
+        for (int64_t i = 0; i < nrows; ++i) perm[i] = order[i];
+        std::vector<int64_t> coff(nchunks + 1, 0);
+        for (int64_t c = 0; c < nchunks; ++c) {
+            int64_t wmax = 0;
+            for (int64_t l = 0; l < C; ++l) {
+                const int32_t r = perm[c * C + l];
+                if (r >= 0) wmax = std::max(wmax, h.rowptr[r + 1] - h.rowptr[r]);
+            }
+            coff[c + 1] = coff[c] + wmax * C;
+        }
+        const int64_t total = coff[nchunks];
+        std::vector<int32_t> sc((size_t)std::max<int64_t>(total, 1), 0);
+        std::vector<double> sv((size_t)std::max<int64_t>(total, 1), 0.0);
+        for (int64_t c = 0; c < nchunks; ++c)
+            for (int64_t l = 0; l < C; ++l) {
+                const int32_t r = perm[c * C + l];
+                if (r < 0) continue;
+                int64_t k = 0;
+                for (int64_t p = h.rowptr[r]; p < h.rowptr[r + 1]; ++p, ++k) {
+                    sc[coff[c] + k * C + l] = h.col[p];
+                    sv[coff[c] + k * C + l] = h.val[p];
+                }
+            }
+        M.sell_nchunks = nchunks;
+        KK_HIP(hipMalloc(&M.sell_off, (nchunks + 1) * sizeof(int64_t)));
+        KK_HIP(hipMalloc(&M.sell_perm, perm.size() * sizeof(int32_t)));
+        KK_HIP(hipMalloc(&M.sell_col, sc.size() * sizeof(int32_t)));
+        KK_HIP(hipMalloc(&M.sell_val, sv.size() * sizeof(double)));
+        KK_HIP(hipMemcpy(M.sell_off, coff.data(), (nchunks + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+        KK_HIP(hipMemcpy(M.sell_perm, perm.data(), perm.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        KK_HIP(hipMemcpy(M.sell_col, sc.data(), sc.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        KK_HIP(hipMemcpy(M.sell_val, sv.data(), sv.size() * sizeof(double), hipMemcpyHostToDevice));
+        M.bytes = (nchunks + 1) * 8 + perm.size() * 4 + sc.size() * 12;
     } else {
         M.format = 1;
         std::vector<int32_t> rp(nrows + 1);

@@ -633,6 +633,59 @@ __global__ __launch_bounds__(KK_TPB) void k_spmv_csr(const int32_t* __restrict__
     }
 }
 
+// SELL-64-sigma SpMV for irregular matrices (e.g. A' of the rectangular GKL map): one wavefront per
+// chunk of 64 rows of similar length (rows are sorted by length inside windows of sigma rows on the
+// host), data stored [chunk][k][lane] so every load is one contiguous 512 B (values) / 256 B
+// (columns) wave transaction and padding is limited to the spread inside one chunk.
+__global__ __launch_bounds__(KK_TPB) void k_spmv_sell(const int64_t* __restrict__ coff, const int32_t* __restrict__ perm,
+                                                      const int32_t* __restrict__ scol, const double* __restrict__ sval,
+                                                      int64_t nchunks, const double* __restrict__ x, double* __restrict__ y,
+                                                      spmv_epi e, double* __restrict__ part_dot, double* __restrict__ part_nrm) {
+    __shared__ double sm[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double dacc = 0, nacc = 0;
+    const double xs = e.xs_dev ? *e.xs_dev : 1.0;
+    const double bp = e.vprev ? (e.bprev_dev ? *e.bprev_dev : e.bprev) : 0.0;
+    for (int64_t c = (int64_t)blockIdx.x * 4 + wave; c < nchunks; c += (int64_t)gridDim.x * 4) {
+        const int64_t off = coff[c];
+        const int w = (int)((coff[c + 1] - off) >> 6);
+        const int32_t* cp = scol + off + lane;
+        const double* vp = sval + off + lane;
+        double s0 = 0, s1 = 0;
+        int k = 0;
+        for (; k + 4 <= w; k += 4) {
+            const int c0 = cp[(k + 0) * 64], c1 = cp[(k + 1) * 64], c2 = cp[(k + 2) * 64], c3 = cp[(k + 3) * 64];
+            const double v0 = vp[(k + 0) * 64], v1 = vp[(k + 1) * 64], v2 = vp[(k + 2) * 64], v3 = vp[(k + 3) * 64];
+            s0 = fma(v0, xload(x, e, c0), s0);
+            s1 = fma(v1, xload(x, e, c1), s1);
+            s0 = fma(v2, xload(x, e, c2), s0);
+            s1 = fma(v3, xload(x, e, c3), s1);
+        }
+        for (; k < w; ++k) s0 = fma(vp[k * 64], xload(x, e, cp[k * 64]), s0);
+        const int row = perm[c * 64 + lane];
+        if (row >= 0) {
+            const double s = (s0 + s1) * xs;
+            double out = e.a1 * s;
+            double xv = 0;
+            if (e.a0 != 0.0 || e.dot_mode) xv = x[row] * xs;
+            if (e.a0 != 0.0) out = fma(e.a0, xv, out);
+            if (e.dot_mode == 1) dacc = fma(xv, out, dacc);
+            if (e.vprev) out = fma(-bp, e.vprev[row], out);
+            if (e.dot_mode == 2) dacc = fma(xv, out, dacc);
+            if (e.want_nrm) nacc = fma(out, out, nacc);
+            y[row] = out;
+        }
+    }
+    if (e.dot_mode) {
+        double t = block_sum(dacc, sm);
+        if (threadIdx.x == 0) part_dot[blockIdx.x] = t;
+    }
+    if (e.want_nrm) {
+        double t = block_sum(nacc, sm);
+        if (threadIdx.x == 0) part_nrm[blockIdx.x] = t;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // restart-time kernels (per restart, not per iteration)
 // ------------------------------------------------------------------------------------------
@@ -1136,8 +1189,13 @@ int kk_launch_spmv(kk_ctx ctx, const kk_sparse_dev& M, const double* x, double* 
     double* pd = part_row(ctx, PART_SCAL_A);
     double* pn = part_row(ctx, PART_SCAL_B);
     int nblk = 0;
-    kk_prof_scope* ps = new kk_prof_scope(ctx, M.format == 0 ? "k_spmv_ell" : "k_spmv_csr");
-    if (M.format == 0) {
+    kk_prof_scope* ps = new kk_prof_scope(ctx, M.format == 0 ? "k_spmv_ell" : (M.format == 2 ? "k_spmv_sell" : "k_spmv_csr"));
+    if (M.format == 2) {
+        nblk = (int)std::min<int64_t>((M.sell_nchunks + 3) / 4, (int64_t)ctx->num_cus * 16);
+        if (nblk < 1) nblk = 1;
+        hipLaunchKernelGGL(k_spmv_sell, dim3(nblk), dim3(KK_TPB), 0, ctx->stream, M.sell_off, M.sell_perm, M.sell_col, M.sell_val,
+                           M.sell_nchunks, x, y, e, pd, pn);
+    } else if (M.format == 0) {
         const int nb_logical = (int)((M.nrows + 2 * KK_TPB - 1) / (2 * KK_TPB));
         const int per = (nb_logical + 7) / 8;
         const int nbx = std::min(per, KK_MAX_BLOCKS / 8);
