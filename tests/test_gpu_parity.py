@@ -161,15 +161,32 @@ def test_spmv_formats(kk, ko, ctx, via_csc):
             op.apply(kk.DeviceBasis(nc + 1, 1, ctx)[0], Y[0])
 
 
-def test_csr_forced(kk, ko, ctx, monkeypatch):
-    monkeypatch.setenv("KK_SPMV_FORMAT", "csr")
-    A = ko.laplacian_2d(50, 40)
-    op = kk.SparseOperator(A, ctx)
-    assert op.info()["format"] == "CSR"
-    x = np.random.default_rng(1).standard_normal(A.shape[1])
-    X = kk.DeviceBasis(A.shape[0], 2, ctx)
-    op.apply(X[0].set(x), X[1])
-    np.testing.assert_allclose(X[1].get(), A @ x, rtol=1e-13, atol=1e-13)
+@pytest.mark.parametrize("fmt", ["csr", "sell", "ell"])
+def test_spmv_format_forced(kk, ko, ctx, monkeypatch, fmt):
+    """Every device format (ELL, CSR, SELL-64-sigma) on the same matrices, incl. the fused Lanczos epilogue."""
+    monkeypatch.setenv("KK_SPMV_FORMAT", fmt)
+    rng = np.random.default_rng(1)
+    d = rng.integers(0, 70, size=9000)
+    rows = np.repeat(np.arange(9000), d)
+    Ar = sp.csr_matrix((rng.standard_normal(rows.size), (rows, rng.integers(0, 9000, rows.size))), shape=(9000, 9000))
+    for A in (ko.laplacian_2d(50, 40), (Ar + Ar.T).tocsr()):
+        op = kk.SparseOperator(A, ctx, symmetric=True)
+        assert op.info()["format"] == fmt.upper()
+        n = A.shape[0]
+        x = rng.standard_normal(n)
+        X = kk.DeviceBasis(n, 2, ctx)
+        op.apply(X[0].set(x), X[1])
+        scale = np.abs(A) @ np.abs(x) + 1e-300
+        assert np.max(np.abs(X[1].get() - A @ x) / scale) < 1e-14
+        x0 = rng.random(n)
+        it = kk.LanczosIterator(op, x0, kk.ClassicalGramSchmidt2(), capacity=14)
+        f = kk.initialize(it)
+        oit = ko.LanczosIterator(A, x0.copy(), ko.CGS2)
+        of = ko.lanczos_initialize(oit)
+        for _ in range(10):
+            f = kk.expand_(it, f)
+            of = ko.lanczos_expand(oit, of)
+        assert relerr(f.alphas, of.alphas) < 1e-10 and relerr(f.betas, of.betas) < 1e-10
 
 
 @pytest.mark.parametrize("mgs_mode", [0, 1])

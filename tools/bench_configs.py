@@ -87,7 +87,7 @@ def bench_gkl(ctx, full):
         for _ in range(K - 1):
             f = kk.expand_(it, f)
         ctx.prof_enable(0)
-        prof = {k: round(ctx.prof_get(k)[0], 2) for k in ("k_spmv_ell", "k_spmv_csr", "k_project", "k_unproject", "k_unproj_proj", "k_mgs_step", "k_scal", "k_dot")}
+        prof = {k: round(ctx.prof_get(k)[0], 2) for k in ("k_spmv_ell", "k_spmv_sell", "k_spmv_csr", "k_project", "k_unproject", "k_unproj_proj", "k_mgs_step", "k_scal", "k_dot")}
         out[orth.name] = {"gkl_it_per_s": round((K - 1) / best, 1), "alg_GBps": round(alg / best / 1e9, 1), "frac_8TBps": round(alg / best / 8e12, 4),
                           "sigma_max_est": max(np.linalg.svd(f.rayleighquotient(), compute_uv=False)), "kernel_ms_one_sweep": prof}
     print(json.dumps({"config": f"4: svdsolve(GKL) {m}x{n} sparse random nnz/row=20, krylovdim=30 (1 GPU)", **out}), flush=True)
