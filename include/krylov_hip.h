@@ -152,6 +152,11 @@ int kk_op_set_ghost(kk_op op, int64_t n_local_cols, int64_t n_ghost, void* devic
 int kk_spmv(kk_op op, int transpose, kk_basis bx, int cx, kk_basis by, int cy);
 /* affine form apply(op, x, a0, a1) = a0*x + a1*A*x (apply.jl:4-11) */
 int kk_spmv_affine(kk_op op, kk_basis bx, int cx, kk_basis by, int cy, double a0, double a1);
+/* short-recurrence solvers: q = a0*p + a1*A*p with the fused inner(p, q), and the fused CG
+ * update x += alpha p ; r -= alpha q ; *rnorm = |r|  (linsolve/cg.jl:35-36,61-66) */
+int kk_spmv_affine_dot(kk_op op, kk_basis bx, int cx, kk_basis by, int cy, double a0, double a1, double* dot);
+int kk_cg_update(kk_basis bx, int cx, kk_basis bp, int cp, kk_basis br, int cr, kk_basis bq, int cq, double alpha,
+                 double* rnorm);
 /* gather x[idx[i]] -> out[i] on device (packing halo/ghost send buffers) */
 int kk_gather(kk_basis bx, int cx, const int64_t* device_idx, int64_t count, void* device_out);
 

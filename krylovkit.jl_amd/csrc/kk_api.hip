@@ -681,6 +681,39 @@ extern "C" int kk_spmv_affine(kk_op op, kk_basis bx, int cx, kk_basis by, int cy
     return kk_launch_spmv(op->ctx, op->A, bx->col(cx), by->col(cy), by->ld, f);
 }
 
+// q = a0 p + a1 A p with the fused <p, q> (the CG / short-recurrence apply, linsolve/cg.jl:35-36,61-62)
+extern "C" int kk_spmv_affine_dot(kk_op op, kk_basis bx, int cx, kk_basis by, int cy, double a0, double a1, double* dot) {
+    KK_CHECK(op && dot, KK_ERR_INVALID, "null arg");
+    CHECK_COL(bx, cx); CHECK_COL(by, cy);
+    KK_TRY(check_apply(op, 0, bx, by));
+    KK_CHECK(!(bx == by && cx == cy), KK_ERR_INVALID, "kk_spmv_affine_dot: x and y must differ");
+    kk_ctx c = op->ctx;
+    gram_touch(by, cy);
+    kk_spmv_fuse f;
+    f.a0 = a0; f.a1 = a1;
+    f.dot_mode = 2;
+    f.dot_out = SCP(c, SC_DOT);
+    KK_TRY(kk_launch_spmv(c, op->A, bx->col(cx), by->col(cy), by->ld, f));
+    KK_TRY(ws_fetch_async(c, WS_SCAL + SC_DOT, 1, 0));
+    KK_TRY(stream_sync(c));
+    *dot = pin(c, WS_SCAL + SC_DOT)[0];
+    return KK_OK;
+}
+// x += alpha p ; r -= alpha q ; *rnorm = |r|   (linsolve/cg.jl:63-66 in one pass)
+extern "C" int kk_cg_update(kk_basis bx, int cx, kk_basis bp, int cp, kk_basis br, int cr, kk_basis bq, int cq, double alpha,
+                            double* rnorm) {
+    CHECK_COL(bx, cx); CHECK_COL(bp, cp); CHECK_COL(br, cr); CHECK_COL(bq, cq);
+    CHECK_SAME(bx, bp); CHECK_SAME(bx, br); CHECK_SAME(bx, bq);
+    KK_CHECK(rnorm, KK_ERR_INVALID, "null output");
+    kk_ctx c = bx->ctx;
+    gram_touch(bx, cx); gram_touch(br, cr);
+    KK_TRY(kk_launch_cg_update(c, bx->col(cx), bp->col(cp), br->col(cr), bq->col(cq), bx->ld, alpha, SCP(c, SC_NRM2)));
+    KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2, 2, 0));
+    KK_TRY(stream_sync(c));
+    *rnorm = pin(c, WS_SCAL + SC_NRM2)[1];
+    return KK_OK;
+}
+
 extern "C" int kk_gather(kk_basis bx, int cx, const int64_t* device_idx, int64_t count, void* device_out) {
     CHECK_COL(bx, cx);
     return kk_launch_gather(bx->ctx, bx->col(cx), device_idx, count, (double*)device_out);

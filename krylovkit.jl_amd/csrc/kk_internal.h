@@ -230,3 +230,5 @@ static inline int kk_allreduce(kk_ctx ctx, double* dev_ptr, int64_t count) {
     }
     return KK_OK;
 }
+int kk_launch_cg_update(kk_ctx ctx, double* x, const double* p, double* r, const double* q, int64_t ld, double alpha,
+                        double* nrm_out3);

@@ -156,6 +156,24 @@ __global__ __launch_bounds__(KK_TPB) void k_scal(double* __restrict__ x, int64_t
     }
 }
 
+// CG update fused (linsolve/cg.jl:63-66): x += alpha p ; r -= alpha q ; partial |r|^2
+__global__ __launch_bounds__(KK_TPB) void k_cg_update(double* __restrict__ x, const double* __restrict__ p, double* __restrict__ r,
+                                                      const double* __restrict__ q, int64_t ld, int64_t rpb, double alpha,
+                                                      double* __restrict__ part) {
+    __shared__ double sm[4];
+    const int64_t r0 = (int64_t)blockIdx.x * rpb, r1 = imin(r0 + rpb, ld);
+    double acc = 0;
+    for (int64_t i = r0 + threadIdx.x * 2; i < r1; i += KK_SUB) {
+        d2 xv = ld2(x + i), pv = ld2(p + i), rv = ld2(r + i), qv = ld2(q + i);
+        xv.x = fma(alpha, pv.x, xv.x); xv.y = fma(alpha, pv.y, xv.y);
+        rv.x = fma(-alpha, qv.x, rv.x); rv.y = fma(-alpha, qv.y, rv.y);
+        st2(x + i, xv); st2(r + i, rv);
+        acc = fma(rv.x, rv.x, acc); acc = fma(rv.y, rv.y, acc);
+    }
+    double t = block_sum(acc, sm);
+    if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+
 // counter-based uniform [0,1): splitmix64 of (seed, row) -> 53-bit mantissa. Independent of grid.
 __global__ __launch_bounds__(KK_TPB) void k_fill_random(double* __restrict__ x, int64_t n, uint64_t seed) {
     for (int64_t i = (int64_t)blockIdx.x * KK_TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * KK_TPB) {
@@ -1423,4 +1441,16 @@ int kk_launch_unproj_proj(kk_ctx ctx, const double* V, int64_t ld, int m, const 
     KK_TRY(kk_allreduce(ctx, out_s, m));
     if (nrm_out3) return finalize_scalar(ctx, PART_SCAL_A, p.nblk, nrm_out3, true);
     return KK_OK;
+}
+
+int kk_launch_cg_update(kk_ctx ctx, double* x, const double* p, double* r, const double* q, int64_t ld, double alpha,
+                        double* nrm_out3) {
+    kk_part pt = kk_partition(ctx, ld);
+    {
+        kk_prof_scope ps(ctx, "k_cg_update");
+        hipLaunchKernelGGL(k_cg_update, dim3(pt.nblk), dim3(KK_TPB), 0, ctx->stream, x, p, r, q, ld, pt.rpb, alpha,
+                           part_row(ctx, PART_SCAL_A));
+    }
+    KK_HIP(hipGetLastError());
+    return finalize_scalar(ctx, PART_SCAL_A, pt.nblk, nrm_out3, true);
 }

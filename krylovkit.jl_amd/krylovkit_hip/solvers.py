@@ -427,3 +427,81 @@ def eigsolve_block(A, x0, howmany: int = 1, which: str = "SR", alg: Optional[Blo
         B.times(U[:, i], HipVec(out, i), 0, K)
         vectors.append(out.download(i))
     return values, vectors, ConvergenceInfo(converged, None, normresiduals[:hm], numiter, numops)
+
+
+# -------------------------------------------------------------------- linsolve (CG)
+@dataclass
+class CG:  # algorithms.jl:325-337
+    maxiter: int = KrylovDefaults.maxiter
+    tol: float = KrylovDefaults.tol
+    verbosity: int = 0
+
+
+def linsolve_cg(A, b, x0=None, alg: Optional[CG] = None, a0: float = 0.0, a1: float = 1.0, **kw):
+    """linsolve(operator, b, x0, alg::CG, a0, a1) (src/linsolve/cg.jl:1-103) for a symmetric positive
+    definite a0 + a1*A.  Per iteration: one SpMV with the fused <p, q>, one fused update
+    (x += alpha p; r -= alpha q; |r|), one axpby (p = r + beta p)."""
+    import ctypes as C
+    from ._lib import check
+    op = _as_operator(A)
+    n = op.shape[0]
+    alg = alg or CG(**kw)
+    maxiter, tol = alg.maxiter, alg.tol
+    W = DeviceBasis(n, 5, op.ctx)  # 0 = b, 1 = x, 2 = r, 3 = p, 4 = q
+    vb, vx, vr, vp, vq = (HipVec(W, i) for i in range(5))
+    lib = W._lib
+    vb.set(np.asarray(b, dtype=np.float64))
+    if x0 is None:
+        vx.zero_()
+    else:
+        vx.set(np.asarray(x0, dtype=np.float64))
+    op.apply(vx, vq)                      # y0 = apply(operator, x0)   :3
+    vr.scale_from_(vb, 1.0)
+    if a0 != 0:
+        vr.add_(vx, -a0)
+    vr.add_(vq, -a1)
+    normr = vr.norm()
+    numops, numiter = 1, 0
+    if normr < tol:
+        return vx.get(), ConvergenceInfo(1, vr.get(), normr, numiter, numops)
+
+    def apply_dot():
+        d = C.c_double()
+        check(lib.kk_spmv_affine_dot(op.handle, W.handle, 3, W.handle, 4, a0, a1, C.byref(d)))
+        return d.value
+
+    def update(alpha):
+        nr = C.c_double()
+        check(lib.kk_cg_update(W.handle, 1, W.handle, 3, W.handle, 2, W.handle, 4, alpha, C.byref(nr)))
+        return nr.value
+
+    rho = normr ** 2
+    vp.scale_from_(vr, 1.0)               # :33-34
+    alpha = rho / apply_dot()
+    normr = update(alpha)
+    rho_old, rho = rho, normr ** 2
+    beta = rho / rho_old
+    numops += 1
+    numiter += 1
+    if normr < tol:
+        return vx.get(), ConvergenceInfo(1, vr.get(), normr, numiter, numops)
+    while True:                           # :60-101
+        vp.add_(vr, 1.0, beta)            # p = add!!(p, r, 1, beta)
+        alpha = rho / apply_dot()
+        normr = update(alpha)
+        if normr < tol:                   # recompute explicitly   :67-72
+            vr.scale_from_(vb, 1.0)
+            op.apply_affine(vx, vq, a0, a1)
+            vr.add_(vq, -1.0)
+            normr = vr.norm()
+            rho = normr ** 2
+            beta = 0.0
+        else:
+            rho_old, rho = rho, normr ** 2
+            beta = rho / rho_old
+        numops += 1
+        numiter += 1
+        if normr < tol:
+            return vx.get(), ConvergenceInfo(1, vr.get(), normr, numiter, numops)
+        if numiter >= maxiter:
+            return vx.get(), ConvergenceInfo(0, vr.get(), normr, numiter, numops)

@@ -1106,6 +1106,57 @@ def svdsolve_gkl(A, x0: np.ndarray, howmany: int = 1, which: str = "LR", *, kryl
     return values, left, right, ConvergenceInfo(converged, residuals, normres, numiter, numops)
 
 
+def cg(operator, b: np.ndarray, x0: Optional[np.ndarray] = None, a0: float = 0.0, a1: float = 1.0, *,
+       maxiter: int = 100, tol: float = 1e-12):
+    """linsolve(operator, b, x0, alg::CG, a0, a1) (linsolve/cg.jl:1-103)."""
+    b = np.asarray(b, dtype=np.float64)
+    x0 = np.zeros_like(b) if x0 is None else np.asarray(x0, dtype=np.float64)
+    y0 = apply(operator, x0)
+    r = scale(b, 1.0)
+    if a0 != 0:
+        r = add(r, x0, -a0)
+    r = add(r, y0, -a1)
+    x = x0.copy()
+    normr = norm(r)
+    numops, numiter = 1, 0
+    if normr < tol:
+        return x, ConvergenceInfo(1, r, normr, numiter, numops)
+    rho = normr ** 2
+    p = r.copy()
+    q = a0 * p + a1 * apply(operator, p)
+    alpha = rho / inner(p, q)
+    x = add(x, p, alpha)
+    r = add(r, q, -alpha)
+    normr = norm(r)
+    rho_old, rho = rho, normr ** 2
+    beta = rho / rho_old
+    numops += 1
+    numiter += 1
+    if normr < tol:
+        return x, ConvergenceInfo(1, r, normr, numiter, numops)
+    while True:
+        p = add(p, r, 1.0, beta)
+        q = a0 * p + a1 * apply(operator, p)
+        alpha = rho / inner(p, q)
+        x = add(x, p, alpha)
+        r = add(r, q, -alpha)
+        normr = norm(r)
+        if normr < tol:
+            r = b - (a0 * x + a1 * apply(operator, x))
+            normr = norm(r)
+            rho = normr ** 2
+            beta = 0.0
+        else:
+            rho_old, rho = rho, normr ** 2
+            beta = rho / rho_old
+        numops += 1
+        numiter += 1
+        if normr < tol:
+            return x, ConvergenceInfo(1, r, normr, numiter, numops)
+        if numiter >= maxiter:
+            return x, ConvergenceInfo(0, r, normr, numiter, numops)
+
+
 # --------------------------------------------------------------------------------------
 # BlockLanczos -- src/factorizations/blocklanczos.jl, src/eigsolve/blocklanczos.jl
 # A Block is a python list of ndarrays.

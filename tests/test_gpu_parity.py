@@ -686,3 +686,20 @@ def test_basistransform_mfma_and_fallback(kk, ctx, n, m, k):
     np.testing.assert_array_equal(got[:, k:], V[:, k:])  # untouched columns
     # pad rows must still be zero: norms only see n entries
     assert abs(B[0].norm() - np.linalg.norm(ref[:, 0])) <= 1e-13 * np.linalg.norm(ref[:, 0])
+
+
+def test_linsolve_cg(kk, ko, ctx):
+    """CG on device vectors (fused SpMV+dot, fused update): same iterates / counts as the oracle (linsolve/cg.jl)."""
+    A = ko.laplacian_2d(40, 30, shift_diag=0.5 + np.linspace(0, 1, 1200))
+    n = A.shape[0]
+    b = np.random.default_rng(4).random(n)
+    for a0, a1 in ((0.0, 1.0), (0.3, 0.9)):
+        tol = 1e-10 * np.linalg.norm(b)
+        x, info = kk.linsolve_cg(kk.SparseOperator(A, ctx, symmetric=True), b, None, kk.CG(500, tol), a0, a1)
+        xo, oinfo = ko.cg(A, b, None, a0, a1, maxiter=500, tol=tol)
+        assert info.converged == 1 and (info.numiter, info.numops) == (oinfo.numiter, oinfo.numops)
+        assert np.linalg.norm(a0 * x + a1 * (A @ x) - b) <= 1.01 * tol
+        np.testing.assert_allclose(x, xo, rtol=0, atol=1e-9 * np.linalg.norm(xo))
+    xs = np.random.default_rng(1).random(n)
+    x, info = kk.linsolve_cg(kk.SparseOperator(A, ctx, symmetric=True), A @ xs, xs, kk.CG(tol=1e-8))
+    assert info.numops == 1 and info.converged == 1

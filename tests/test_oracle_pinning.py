@@ -323,3 +323,19 @@ def test_block_primitives(ko):
     Qm = np.stack([C[i] for i in good], 1)
     np.testing.assert_allclose(Qm @ R, Cm, atol=1e-10)
     assert np.max(np.abs(Qm.T @ Qm - np.eye(p))) < 1e-12
+
+
+def test_cg_vs_dense(ko):
+    """test/linsolve.jl:4-62: CG on a positive definite matrix, b ~ (a0 + a1 A) x, numops == 1 from the solution."""
+    n = 100
+    rng = np.random.default_rng(41)
+    M = rng.random((n, n)) - 0.5
+    A = M @ M.T / n + np.eye(n)
+    b = rng.random(n)
+    for a0, a1 in ((0.0, 1.0), (0.5, 1.2)):
+        x, info = ko.cg(A, b, None, a0, a1, maxiter=300, tol=1e-11 * np.linalg.norm(b))
+        assert info.converged == 1
+        assert np.linalg.norm(b - (a0 * x + a1 * (A @ x))) <= 1.01e-11 * np.linalg.norm(b)
+    xs = rng.random(n)
+    x, info = ko.cg(A, A @ xs, xs, tol=1e-9)
+    assert info.numops == 1 and info.numiter == 0
