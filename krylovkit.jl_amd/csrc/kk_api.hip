@@ -296,6 +296,7 @@ extern "C" int kk_basis_create(kk_ctx c, int64_t n, int capacity, kk_basis* out)
 extern "C" int kk_basis_free(kk_basis b) {
     if (!b) return KK_OK;
     (void)hipDeviceSynchronize();  // not the context's stream: finalizers may run after the context is gone
+    (void)hipFree(b->d_gram);
     (void)hipFree(b->d);
     delete b;
     return KK_OK;
@@ -798,7 +799,29 @@ extern "C" int kk_householder_rmul(kk_basis b, int c0, int m, const double* v, d
 // gram(i, j) = <b_i, b_j>, j < i, stored at b->gram[i*cap + j]; rows [0, gram_rows) valid.
 static int block_inner_run(kk_ctx c, const double* X, int64_t ldx, int p, const double* Y, int64_t ldy, int q, int64_t ld,
                            double* M, int ldm);
+// device mirror of the host Gram rows (used by the on-device low-sync solve)
+static int gram_device(kk_basis b) {
+    if (b->gram.empty()) b->gram.assign((size_t)b->cap * b->cap, 0.0);
+    if (!b->d_gram) {
+        KK_HIP(hipMalloc(&b->d_gram, (size_t)b->cap * b->cap * sizeof(double)));
+        KK_HIP(hipMemcpy(b->d_gram, b->gram.data(), (size_t)b->cap * b->cap * sizeof(double), hipMemcpyHostToDevice));
+    }
+    return KK_OK;
+}
+static int gram_upload_rows(kk_basis b, int lo, int hi) {
+    if (!b->d_gram || hi <= lo) return KK_OK;
+    // pageable source: the runtime stages it before returning, so the host vector may change afterwards
+    KK_HIP(hipMemcpyAsync(b->d_gram + (size_t)lo * b->cap, b->gram.data() + (size_t)lo * b->cap,
+                          (size_t)(hi - lo) * b->cap * sizeof(double), hipMemcpyHostToDevice, b->ctx->stream));
+    return KK_OK;
+}
+static int gram_ensure_host(kk_basis b, int upto);
 static int gram_ensure(kk_basis b, int upto /* exclusive */) {
+    const int lo = std::max(b->gram_rows, 1);
+    KK_TRY(gram_ensure_host(b, upto));
+    return gram_upload_rows(b, std::min(lo, upto), std::max(upto, lo));
+}
+static int gram_ensure_host(kk_basis b, int upto /* exclusive */) {
     kk_ctx c = b->ctx;
     if (b->gram.empty()) b->gram.assign((size_t)b->cap * b->cap, 0.0);
     if (b->gram_rows < 1) b->gram_rows = 1;  // row 0 has no strictly-lower entries
@@ -893,8 +916,33 @@ static int lowsync_project(kk_basis b, int c0, int m, const double* w, const dou
     if (ride) {
         memcpy(&b->gram[(size_t)newest * b->cap], pin(c, WS_G, slot), (m - 1) * sizeof(double));
         b->gram_rows = newest + 1;
+        KK_TRY(gram_upload_rows(b, newest, newest + 1));
     }
     return KK_OK;
+}
+// Device-side variant (c0 == 0): p = V'(w - a*pre) [+ Gram row of the newest vector riding along],
+// then (I + L) s = p solved ON THE DEVICE; coefficients (s, with *a0_dev added to the last one) land in
+// ws[ws_coef..], plain s in ws[ws_s..].  No host synchronisation.  If *rode, the caller must fetch
+// ws[WS_G .. WS_G+m-1) with its final read-back and hand it to lowsync_commit_row().
+static int lowsync_project_dev(kk_basis b, int m, const double* w, const double* pre_vec, const double* pre_a,
+                               const double* a0_dev, int64_t ws_coef, int64_t ws_s, bool* rode) {
+    kk_ctx c = b->ctx;
+    const int newest = m - 1;
+    if (b->gram_rows < newest) KK_TRY(gram_ensure(b, newest));  // only after the basis was transformed (restart)
+    if (b->gram_rows < 1) b->gram_rows = 1;
+    const bool ride = (b->gram_rows == newest && newest > 0);
+    KK_TRY(gram_device(b));
+    KK_TRY(kk_launch_project(c, b->col(0), b->ld, m, w, pre_vec, pre_a, ride ? b->col(newest) : nullptr, WSP(c, WS_S),
+                             WSP(c, WS_G)));
+    KK_TRY(kk_launch_lowsync_solve(c, WSP(c, WS_S), ride ? WSP(c, WS_G) : nullptr, b->d_gram, b->cap, m, newest, a0_dev,
+                                   WSP(c, ws_coef), WSP(c, ws_s)));
+    *rode = ride;
+    return KK_OK;
+}
+static void lowsync_commit_row(kk_basis b, int m, const double* g_host) {
+    const int newest = m - 1;
+    memcpy(&b->gram[(size_t)newest * b->cap], g_host, (m - 1) * sizeof(double));
+    b->gram_rows = newest + 1;
 }
 // low-sync MGS sweep: p = V'w (one pass), s = (I+L)^-1 p on the host, w -= V s.
 static int pass_mgs_lowsync(kk_basis b, int c0, int m, double* w, double* s_out, bool want_norm, int slot) {
@@ -983,7 +1031,18 @@ static int orth_run(kk_basis b, int c0, int m, double* w, kk_orth_t alg, double 
             }
         } break;
         case KK_MGS: {
-            if (lowsync) {
+            if (lowsync && c->fuse_passes) {
+                bool rode = false;
+                KK_TRY(lowsync_project_dev(b, m, w, nullptr, nullptr, nullptr, WS_X, WS_Y, &rode));
+                KK_TRY(kk_launch_unproject(c, V, ld, m, w, w, nullptr, WSP(c, WS_X), -1.0, 1.0, -1, nullptr,
+                                           want_norm ? SCP(c, SC_NRM2) : nullptr));
+                KK_TRY(ws_fetch_async(c, WS_Y, m, 0));
+                if (rode) KK_TRY(ws_fetch_async(c, WS_G, m, 0));
+                if (want_norm) KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2, 2, 0));
+                KK_TRY(final_sync(c));
+                memcpy(x, pin(c, WS_Y, 0), m * sizeof(double));
+                if (rode) lowsync_commit_row(b, m, pin(c, WS_G, 0));
+            } else if (lowsync) {
                 KK_TRY(pass_mgs_lowsync(b, c0, m, w, x, want_norm, 0));
                 KK_TRY(final_sync(c));
             } else {
@@ -997,22 +1056,20 @@ static int orth_run(kk_basis b, int c0, int m, double* w, kk_orth_t alg, double 
         case KK_MGS2: {  // :434-439
             if (lowsync && c->fuse_passes && m <= 128) {
                 // p1 = V'w -> s1 = (I+L)^-1 p1 ; [w1 = w - V s1 ; p2 = V'w1] fused ; s2 = (I+L)^-1 p2 ; w2 = w1 - V s2
-                KK_TRY(lowsync_project(b, c0, m, w, nullptr, nullptr, 0));
-                kk_coef ch;
-                memset(&ch, 0, sizeof(ch));
-                memcpy(ch.v, pin(c, WS_S, 0), m * sizeof(double));
-                gram_solve(b, c0, m, ch.v);
-                memcpy(x, ch.v, m * sizeof(double));
-                KK_TRY(kk_launch_unproj_proj(c, V, ld, m, w, w, &ch, nullptr, WSP(c, WS_G), nullptr));
-                KK_TRY(ws_fetch_async(c, WS_G, m, 0));
-                KK_TRY(stream_sync(c));
-                memcpy(ch.v, pin(c, WS_G, 0), m * sizeof(double));
-                gram_solve(b, c0, m, ch.v);
-                for (int j = 0; j < m; ++j) x[j] += ch.v[j];
-                KK_TRY(kk_launch_unproject(c, V, ld, m, w, w, &ch, nullptr, -1.0, 1.0, -1, nullptr,
+                // -- both triangular solves on the device: ONE host synchronisation for the whole 2-pass step
+                bool rode = false;
+                KK_TRY(lowsync_project_dev(b, m, w, nullptr, nullptr, nullptr, WS_X, WS_Y, &rode));
+                KK_TRY(kk_launch_unproj_proj(c, V, ld, m, w, w, nullptr, WSP(c, WS_X), WSP(c, WS_S), nullptr));
+                KK_TRY(kk_launch_lowsync_solve(c, WSP(c, WS_S), nullptr, b->d_gram, b->cap, m, m - 1, nullptr, WSP(c, WS_X),
+                                               WSP(c, WS_Z)));
+                KK_TRY(kk_launch_unproject(c, V, ld, m, w, w, nullptr, WSP(c, WS_X), -1.0, 1.0, -1, nullptr,
                                            want_norm ? SCP(c, SC_NRM2) : nullptr));
+                KK_TRY(ws_fetch_async(c, WS_Y, 2 * KK_MAX_M, 0));   // s1 (WS_Y) and s2 (WS_Z) are adjacent
+                if (rode) KK_TRY(ws_fetch_async(c, WS_G, m, 0));
                 if (want_norm) KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2, 2, 0));
                 KK_TRY(final_sync(c));
+                for (int j = 0; j < m; ++j) x[j] = pin(c, WS_Y, 0)[j] + pin(c, WS_Z, 0)[j];
+                if (rode) lowsync_commit_row(b, m, pin(c, WS_G, 0));
             } else if (lowsync) {
                 KK_TRY(pass_mgs_lowsync(b, c0, m, w, x, false, 0));
                 KK_TRY(pass_mgs_lowsync(b, c0, m, w, tmp.data(), want_norm, 0));
@@ -1334,20 +1391,19 @@ extern "C" int kk_lanczos_expand(kk_op op, kk_basis b, int c0, int k, kk_orth_t 
             KK_TRY(fetch_wait(c));
             a = pin(c, WS_SCAL + SC_ALPHA0)[0] + pin(c, WS_S)[m - 1];
         } else {
-            KK_TRY(ws_fetch_async(c, WS_SCAL, 1, 0));
-            KK_TRY(lowsync_project(b, c0, m, w, v, a0_dev, 0));
-            kk_coef ch;
-            memset(&ch, 0, sizeof(ch));
-            memcpy(ch.v, pin(c, WS_S), m * sizeof(double));
-            gram_solve(b, c0, m, ch.v);
-            const double a0 = pin(c, WS_SCAL + SC_ALPHA0)[0];
-            a = a0 + ch.v[m - 1];
-            ch.v[m - 1] += a0;
-            KK_TRY(kk_launch_unproject(c, V, ld, m, w, w, &ch, nullptr, -1.0, 1.0, -1, nullptr, SCP(c, SC_NRM2)));
-            KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2, 2, 0));
+            // low-sync MGS2: project (Gram row riding along) -> triangular solve ON THE DEVICE (alpha0 folded
+            // into the last coefficient) -> update; one host synchronisation, as for CGS2
+            bool rode = false;
+            KK_TRY(lowsync_project_dev(b, m, w, v, a0_dev, a0_dev, WS_X, WS_Y, &rode));
+            KK_TRY(kk_launch_unproject(c, V, ld, m, w, w, nullptr, WSP(c, WS_X), -1.0, 1.0, -1, nullptr, SCP(c, SC_NRM2)));
+            KK_TRY(ws_fetch_async(c, WS_SCAL, 4, 0));
+            KK_TRY(ws_fetch_async(c, WS_Y + m - 1, 1, 0));
+            if (rode) KK_TRY(ws_fetch_async(c, WS_G, m, 0));
             KK_TRY(fetch_mark(c));
             KK_TRY(speculate_next(op, b, c0, k + 1, 2, true, 0.0));
             KK_TRY(fetch_wait(c));
+            a = pin(c, WS_SCAL + SC_ALPHA0)[0] + pin(c, WS_Y)[m - 1];
+            if (rode) lowsync_commit_row(b, m, pin(c, WS_G, 0));
         }
         bt = pin(c, WS_SCAL + SC_NRM)[0];
         passes = 1;

@@ -19,7 +19,9 @@
 #define WS_S 0                // coefficients of the current pass            [KK_MAX_M]
 #define WS_G (WS_S + KK_MAX_M)      // second right-hand side (Gram row)     [KK_MAX_M]
 #define WS_X (WS_G + KK_MAX_M)      // accumulated coefficients              [KK_MAX_M]
-#define WS_SCAL (WS_X + KK_MAX_M)   // named scalars                         [64]
+#define WS_Y (WS_X + KK_MAX_M)      // first-pass MGS coefficients (device solve)  [KK_MAX_M]
+#define WS_Z (WS_Y + KK_MAX_M)      // second-pass coefficients                  [KK_MAX_M]
+#define WS_SCAL (WS_Z + KK_MAX_M)   // named scalars                         [64]
 #define WS_USER (WS_SCAL + 64)      // split-phase API area                  [KK_WS_USER]
 #define KK_WS_USER 4096
 #define WS_TOTAL (WS_USER + KK_WS_USER)
@@ -92,6 +94,7 @@ struct kk_basis_s {
     std::vector<double> gram;
     int gram_c0 = 0;    // first column the Gram rows refer to
     int gram_rows = 0;  // rows [0, gram_rows) of the strictly-lower Gram matrix are valid
+    double* d_gram = nullptr;  // device mirror of `gram` (same layout), valid for the same rows
     // speculative next-step SpMV (hides the host round trip between two expand! calls)
     bool spec_valid = false;
     const void* spec_op = nullptr;
@@ -232,3 +235,7 @@ static inline int kk_allreduce(kk_ctx ctx, double* dev_ptr, int64_t count) {
 }
 int kk_launch_cg_update(kk_ctx ctx, double* x, const double* p, double* r, const double* q, int64_t ld, double alpha,
                         double* nrm_out3);
+// (I + L) s = p on the device (one block, exact forward substitution); optional ride-along Gram row
+// and the Lanczos alpha0 folded into the last coefficient.  See kk_kernels.hip.
+int kk_launch_lowsync_solve(kk_ctx ctx, const double* p, const double* g_ride, double* L, int cap, int m, int newest,
+                            const double* a0_dev, double* coef_out, double* s_out);

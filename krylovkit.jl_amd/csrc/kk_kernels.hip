@@ -468,6 +468,35 @@ __global__ __launch_bounds__(KK_TPB) void k_unproj_proj(const double* __restrict
     }
 }
 
+// low-sync MGS coefficient solve on the device: (I + L) s = p, L = strictly-lower Gram matrix of the
+// basis (row-major, leading dimension cap).  One 256-thread block, exact column-oriented forward
+// substitution in LDS (m <= 256 barriers of a single block, ~5 us).  If g_ride != nullptr the Gram
+// row of the newest basis vector (g_ride[0..m-2]) is first stored into L[newest][.].  coef_out gets
+// s (+ *a0 on the last entry: the Lanczos "w -= alpha0 v" folded into the update), s_out the plain s.
+__global__ __launch_bounds__(KK_TPB) void k_lowsync_solve(const double* __restrict__ p, const double* __restrict__ g_ride,
+                                                          double* L, int cap, int m, int newest,
+                                                          const double* __restrict__ a0, double* __restrict__ coef_out,
+                                                          double* __restrict__ s_out) {
+    __shared__ double rhs[KK_MAX_M];
+    const int i = threadIdx.x;
+    if (g_ride && i < m - 1) L[(int64_t)newest * cap + i] = g_ride[i];
+    if (i < m) rhs[i] = p[i];
+    __syncthreads();
+    for (int j = 0; j < m - 1; ++j) {
+        const double sj = rhs[j];
+        if (i > j && i < m) {
+            const double lij = (g_ride && i == newest) ? g_ride[j] : L[(int64_t)i * cap + j];
+            rhs[i] = fma(-lij, sj, rhs[i]);
+        }
+        __syncthreads();
+    }
+    if (i < m) {
+        const double s = rhs[i];
+        s_out[i] = s;
+        coef_out[i] = (a0 && i == m - 1) ? s + *a0 : s;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // strict modified Gram-Schmidt step (src/orthonormal.jl:417-421), fused across the j boundary:
 //   w -= s_prev * q_prev   (axpy of step j-1, skipped if q_prev == nullptr)
@@ -1453,4 +1482,12 @@ int kk_launch_cg_update(kk_ctx ctx, double* x, const double* p, double* r, const
     }
     KK_HIP(hipGetLastError());
     return finalize_scalar(ctx, PART_SCAL_A, pt.nblk, nrm_out3, true);
+}
+
+int kk_launch_lowsync_solve(kk_ctx ctx, const double* p, const double* g_ride, double* L, int cap, int m, int newest,
+                            const double* a0_dev, double* coef_out, double* s_out) {
+    hipLaunchKernelGGL(k_lowsync_solve, dim3(1), dim3(KK_TPB), 0, ctx->stream, p, g_ride, L, cap, m, newest, a0_dev, coef_out,
+                       s_out);
+    KK_HIP(hipGetLastError());
+    return KK_OK;
 }
