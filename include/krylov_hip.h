@@ -67,8 +67,8 @@ typedef enum {
  *   0 = strict:   one fused axpy+dot kernel per basis vector, sequential as in
  *                 src/orthonormal.jl:417-421 (32 N bytes / vector).
  *   1 = lowsync:  algebraically identical MGS coefficients from ONE projection pass plus a
- *                 triangular solve with the strictly-lower Gram matrix of the basis, maintained
- *                 incrementally (16 N bytes / vector).  Default. */
+ *                 triangular solve (on the device) with the strictly-lower Gram matrix of the
+ *                 basis, maintained incrementally (16 N bytes / vector).  Default. */
 
 /* ---------------------------------------------------------------- library / context */
 int kk_version(void);
