@@ -106,8 +106,39 @@ function VectorInterface.scale!!(y::HipVec, x::HipVec, α::Number)
     chk(ccall((:kk_vec_copy_scal, lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Float64), y.slab.h, y.col, x.slab.h, x.col, α))
     return y
 end
-# fresh vectors (`scale`, `zerovector`) come from a per-context scratch slab; see INTEGRATION.md
-# for the allocation policy (free-list of columns).
+# ---- host <-> device, fresh vectors
+function upload!(x::HipVec, h::Vector{Float64})
+    length(h) == x.slab.n || throw(DimensionMismatch())
+    chk(ccall((:kk_basis_upload, lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Float64}), x.slab.h, x.col, h))
+    return x
+end
+function download(x::HipVec)
+    h = Vector{Float64}(undef, x.slab.n)
+    chk(ccall((:kk_basis_download, lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Float64}), x.slab.h, x.col, h))
+    return h
+end
+# Fresh vectors (`scale(x, α)`, `zerovector(x)`, the result of `apply`) are columns of a per-context
+# scratch slab handed out from a free list; a finalizer-bearing wrapper returns the column.
+mutable struct ScratchPool
+    slab::HipSlab
+    free::Vector{Cint}
+end
+const POOLS = IdDict{HipContext,ScratchPool}()
+function scratch_like(x::HipVec; ncols::Int = 8)
+    pool = get!(POOLS, x.slab.ctx) do
+        ScratchPool(HipSlab(x.slab.ctx, x.slab.n, ncols), collect(Cint(0):Cint(ncols - 1)))
+    end
+    isempty(pool.free) && error("KrylovKitHIP: scratch pool exhausted (raise ncols)")
+    return HipVec(pool.slab, pop!(pool.free))
+end
+release!(x::HipVec) = (p = get(POOLS, x.slab.ctx, nothing); p !== nothing && p.slab === x.slab && push!(p.free, x.col); nothing)
+function VectorInterface.zerovector(x::HipVec, ::Type{Float64} = Float64)
+    y = scratch_like(x)
+    chk(ccall((:kk_vec_zero, lib), Cint, (Ptr{Cvoid}, Cint), y.slab.h, y.col))
+    return y
+end
+VectorInterface.zerovector!!(x::HipVec) = (chk(ccall((:kk_vec_zero, lib), Cint, (Ptr{Cvoid}, Cint), x.slab.h, x.col)); x)
+VectorInterface.scale(x::HipVec, α::Number) = scale!!(scratch_like(x), x, α)
 
 # ---------------------------------------------------------------- L1: operator protocol (src/apply.jl:1-19)
 function apply(A::HipOperator, x::HipVec, y::HipVec = scratch_like(x); transpose::Bool = false)
@@ -132,6 +163,38 @@ function orthogonalize!!(w::HipVec, b::OrthonormalBasis{HipVec}, x::AbstractVect
     copyto!(x, xs)
     return (w, x)
 end
+function project!!(y::AbstractVector, b::OrthonormalBasis{HipVec}, x::HipVec, α::Number = true, β::Number = false,
+                   r = Base.OneTo(length(b)))
+    slab, c0, _ = slab_range(b)
+    length(y) == length(r) || throw(DimensionMismatch())
+    ys = Vector{Float64}(y)
+    chk(ccall((:kk_project, lib), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Cint, Float64, Float64, Ptr{Float64}),
+              slab.h, c0 + first(r) - 1, length(r), x.slab.h, x.col, α, β, ys))
+    copyto!(y, ys)
+    return y
+end
+function unproject!!(y::HipVec, b::OrthonormalBasis{HipVec}, x::AbstractVector, α::Number = true, β::Number = false,
+                     r = Base.OneTo(length(b)))
+    slab, c0, _ = slab_range(b)
+    length(x) == length(r) || throw(DimensionMismatch())
+    chk(ccall((:kk_unproject, lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Cint, Ptr{Float64}, Float64, Float64),
+              y.slab.h, y.col, slab.h, c0 + first(r) - 1, length(r), Vector{Float64}(x), α, β))
+    return y
+end
+function rank1update!(b::OrthonormalBasis{HipVec}, y::HipVec, x::AbstractVector, α::Number = true, β::Number = true,
+                      r = Base.OneTo(length(b)))
+    slab, c0, _ = slab_range(b)
+    chk(ccall((:kk_rank1update, lib), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Cint, Ptr{Float64}, Float64, Float64),
+              slab.h, c0 + first(r) - 1, length(r), y.slab.h, y.col, Vector{Float64}(x), α, β))
+    return b
+end
+function LinearAlgebra.rmul!(b::OrthonormalBasis{HipVec}, H::KrylovKit.Householder)   # dense/reflector.jl:143-154
+    iszero(H.β) && return b
+    slab, c0, _ = slab_range(b)
+    chk(ccall((:kk_householder_rmul, lib), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Float64}, Float64),
+              slab.h, c0 + first(H.r) - 1, length(H.r), Vector{Float64}(H.v), H.β))
+    return b
+end
 function basistransform!(b::OrthonormalBasis{HipVec}, U::AbstractMatrix)
     slab, c0, m = slab_range(b)
     Ud = Matrix{Float64}(U)
@@ -143,6 +206,32 @@ function LinearAlgebra.rmul!(b::OrthonormalBasis{HipVec}, G::LinearAlgebra.Given
     slab, c0, _ = slab_range(b)
     chk(ccall((:kk_givens_rmul, lib), Cint, (Ptr{Cvoid}, Cint, Cint, Float64, Float64), slab.h, c0 + G.i1 - 1, c0 + G.i2 - 1, G.c, G.s))
     return b
+end
+
+# ---------------------------------------------------------------- L3: initialize / shrink!
+# initialize(iter::LanczosIterator) (factorizations/lanczos.jl:180-222): x0 is column 0 of a slab with
+# krylovdim + 2 columns; on return column 0 = v1, column 1 = r.
+function initialize(iter::LanczosIterator{HipOperator,HipVec}; verbosity::Int = 0)
+    x0 = iter.x₀
+    code, η = orthcode(iter.orth)
+    α, β = Ref{Float64}(), Ref{Float64}()
+    chk(ccall((:kk_lanczos_initialize, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cint, Float64, Ref{Float64}, Ref{Float64}),
+              iter.operator.h, x0.slab.h, x0.col, code, η, α, β))
+    V = OrthonormalBasis([HipVec(x0.slab, x0.col)])
+    return LanczosFactorization(1, V, [α[]], [β[]], HipVec(x0.slab, x0.col + 1))
+end
+# shrink!(state, k) (lanczos.jl:273-291): the vectors stay where they are; only the residual is rescaled
+function shrink!(state::LanczosFactorization{HipVec}, k; verbosity::Int = 0)
+    length(state) <= k && return state
+    V = state.V
+    while length(V) > k + 1
+        pop!(V)
+    end
+    r = pop!(V)
+    resize!(state.αs, k); resize!(state.βs, k)
+    state.k = k
+    state.r = scale!!(r, KrylovKit.normres(state))
+    return state
 end
 
 # ---------------------------------------------------------------- L3: fused expand! (the hot path)
@@ -200,6 +289,39 @@ function expand!(iter::GKLIterator{HipOperator,HipVec}, state::GKLFactorization;
     state.k += 1
     state.r = HipVec(su, k + 1)
     return state
+end
+
+# ---------------------------------------------------------------- BlockLanczos (factorizations/blocklanczos.jl)
+# A Block{HipVec} holds consecutive columns of one slab.
+block_range(B::KrylovKit.Block{HipVec}) = (first(B.vec).slab, first(B.vec).col, Cint(length(B)))
+function KrylovKit.block_inner(B₁::KrylovKit.Block{HipVec}, B₂::KrylovKit.Block{HipVec})
+    s1, c1, p = block_range(B₁); s2, c2, q = block_range(B₂)
+    M = Matrix{Float64}(undef, p, q)
+    chk(ccall((:kk_block_inner, lib), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Cint, Cint, Ptr{Float64}, Cint),
+              s1.h, c1, p, s2.h, c2, q, M, p))
+    return M
+end
+function KrylovKit.block_qr!(block::KrylovKit.Block{HipVec}, tol::Real)
+    s, c, p = block_range(block)
+    R = zeros(p, p); good = Vector{Cint}(undef, p); ng = Ref{Cint}(); drift = Ref{Cint}()
+    chk(ccall((:kk_block_qr, lib), Cint,
+              (Ptr{Cvoid}, Cint, Cint, Cint, Float64, Ptr{Float64}, Cint, Ptr{Cint}, Ref{Cint}, Ref{Cint}),
+              s.h, c, p, c, tol, R, p, good, ng, drift))
+    gi = Int.(good[1:ng[]]) .+ 1
+    return R[1:ng[], :], gi, drift[] != 0      # NB: the good vectors are compacted to the first ng columns
+end
+function KrylovKit.block_reorthogonalize!(R::KrylovKit.Block{HipVec}, V::OrthonormalBasis{HipVec})
+    sv, c0, m = slab_range(V); sr, cr, q = block_range(R)
+    sv === sr || error("block and basis must share a slab")
+    chk(ccall((:kk_block_reorthogonalize, lib), Cint, (Ptr{Cvoid}, Cint, Cint, Cint, Cint), sv.h, c0, m, cr, q))
+    return R
+end
+function apply(A::HipOperator, X::KrylovKit.Block{HipVec})
+    s, c, nb = block_range(X)
+    Y = KrylovKit.Block([scratch_like(X[1]) for _ in 1:nb])            # contiguous by construction of the pool
+    sy, cy, _ = block_range(Y)
+    chk(ccall((:kk_block_apply, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Cint), A.h, s.h, c, sy.h, cy, nb))
+    return Y
 end
 
 end # module
