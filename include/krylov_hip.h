@@ -157,6 +157,10 @@ int kk_spmv_affine(kk_op op, kk_basis bx, int cx, kk_basis by, int cy, double a0
 int kk_spmv_affine_dot(kk_op op, kk_basis bx, int cx, kk_basis by, int cy, double a0, double a1, double* dot);
 int kk_cg_update(kk_basis bx, int cx, kk_basis bp, int cp, kk_basis br, int cr, kk_basis bq, int cq, double alpha,
                  double* rnorm);
+/* one CG iteration body with ONE host sync: [p = r + beta p unless first]; q = a0 p + a1 A p; alpha = rho/<p,q>
+ * (formed on the device); x += alpha p; r -= alpha q; returns <p,q> and |r|  (linsolve/cg.jl:60-66) */
+int kk_cg_iterate(kk_op op, kk_basis b, int cx, int cr, int cp, int cq, double a0, double a1, double beta, int first,
+                  double rho, double* pq, double* rnorm);
 /* gather x[idx[i]] -> out[i] on device (packing halo/ghost send buffers) */
 int kk_gather(kk_basis bx, int cx, const int64_t* device_idx, int64_t count, void* device_out);
 

@@ -700,6 +700,30 @@ extern "C" int kk_spmv_affine_dot(kk_op op, kk_basis bx, int cx, kk_basis by, in
     *dot = pin(c, WS_SCAL + SC_DOT)[0];
     return KK_OK;
 }
+// One CG iteration body (linsolve/cg.jl:60-66) with ONE host synchronisation:
+//   [p = r + beta p]  (skipped when beta_is_first)   q = a0 p + a1 A p with fused <p,q> (stays on the device)
+//   alpha = rho / <p,q> formed inside the update kernel ; x += alpha p ; r -= alpha q ; |r|
+// columns of `b`: cx, cr, cp, cq.  Returns <p,q> and |r|.
+extern "C" int kk_cg_iterate(kk_op op, kk_basis b, int cx, int cr, int cp, int cq, double a0, double a1, double beta,
+                             int first, double rho, double* pq, double* rnorm) {
+    KK_TRY(check_square_op(op, b));
+    CHECK_COL(b, cx); CHECK_COL(b, cr); CHECK_COL(b, cp); CHECK_COL(b, cq);
+    KK_CHECK(pq && rnorm, KK_ERR_INVALID, "null output");
+    kk_ctx c = b->ctx;
+    gram_touch(b, std::min(std::min(cx, cr), std::min(cp, cq)));
+    if (!first) KK_TRY(kk_launch_axpby(c, b->col(cp), b->col(cr), b->ld, 1.0, beta, nullptr, 1.0, 0));   // p = add!!(p, r, 1, beta)
+    kk_spmv_fuse f;
+    f.a0 = a0; f.a1 = a1;
+    f.dot_mode = 2;
+    f.dot_out = SCP(c, SC_DOT);
+    KK_TRY(kk_launch_spmv(c, op->A, b->col(cp), b->col(cq), b->ld, f));
+    KK_TRY(kk_launch_cg_update(c, b->col(cx), b->col(cp), b->col(cr), b->col(cq), b->ld, rho, SCP(c, SC_DOT), SCP(c, SC_NRM2)));
+    KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2, 4, 0));   // NRM2, NRM, INVNRM, DOT
+    KK_TRY(stream_sync(c));
+    *pq = pin(c, WS_SCAL + SC_DOT)[0];
+    *rnorm = pin(c, WS_SCAL + SC_NRM)[0];
+    return KK_OK;
+}
 // x += alpha p ; r -= alpha q ; *rnorm = |r|   (linsolve/cg.jl:63-66 in one pass)
 extern "C" int kk_cg_update(kk_basis bx, int cx, kk_basis bp, int cp, kk_basis br, int cr, kk_basis bq, int cq, double alpha,
                             double* rnorm) {
@@ -708,7 +732,7 @@ extern "C" int kk_cg_update(kk_basis bx, int cx, kk_basis bp, int cp, kk_basis b
     KK_CHECK(rnorm, KK_ERR_INVALID, "null output");
     kk_ctx c = bx->ctx;
     gram_touch(bx, cx); gram_touch(br, cr);
-    KK_TRY(kk_launch_cg_update(c, bx->col(cx), bp->col(cp), br->col(cr), bq->col(cq), bx->ld, alpha, SCP(c, SC_NRM2)));
+    KK_TRY(kk_launch_cg_update(c, bx->col(cx), bp->col(cp), br->col(cr), bq->col(cq), bx->ld, alpha, nullptr, SCP(c, SC_NRM2)));
     KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2, 2, 0));
     KK_TRY(stream_sync(c));
     *rnorm = pin(c, WS_SCAL + SC_NRM2)[1];

@@ -234,7 +234,7 @@ static inline int kk_allreduce(kk_ctx ctx, double* dev_ptr, int64_t count) {
     return KK_OK;
 }
 int kk_launch_cg_update(kk_ctx ctx, double* x, const double* p, double* r, const double* q, int64_t ld, double alpha,
-                        double* nrm_out3);
+                        const double* pq_dev, double* nrm_out3);
 // (I + L) s = p on the device (one block, exact forward substitution); optional ride-along Gram row
 // and the Lanczos alpha0 folded into the last coefficient.  See kk_kernels.hip.
 int kk_launch_lowsync_solve(kk_ctx ctx, const double* p, const double* g_ride, double* L, int cap, int m, int newest,

@@ -159,8 +159,9 @@ __global__ __launch_bounds__(KK_TPB) void k_scal(double* __restrict__ x, int64_t
 // CG update fused (linsolve/cg.jl:63-66): x += alpha p ; r -= alpha q ; partial |r|^2
 __global__ __launch_bounds__(KK_TPB) void k_cg_update(double* __restrict__ x, const double* __restrict__ p, double* __restrict__ r,
                                                       const double* __restrict__ q, int64_t ld, int64_t rpb, double alpha,
-                                                      double* __restrict__ part) {
+                                                      const double* __restrict__ pq_dev, double* __restrict__ part) {
     __shared__ double sm[4];
+    if (pq_dev) alpha = alpha / *pq_dev;   // alpha = rho / <p, q> with the inner product still on the device
     const int64_t r0 = (int64_t)blockIdx.x * rpb, r1 = imin(r0 + rpb, ld);
     double acc = 0;
     for (int64_t i = r0 + threadIdx.x * 2; i < r1; i += KK_SUB) {
@@ -1473,11 +1474,11 @@ int kk_launch_unproj_proj(kk_ctx ctx, const double* V, int64_t ld, int m, const 
 }
 
 int kk_launch_cg_update(kk_ctx ctx, double* x, const double* p, double* r, const double* q, int64_t ld, double alpha,
-                        double* nrm_out3) {
+                        const double* pq_dev, double* nrm_out3) {
     kk_part pt = kk_partition(ctx, ld);
     {
         kk_prof_scope ps(ctx, "k_cg_update");
-        hipLaunchKernelGGL(k_cg_update, dim3(pt.nblk), dim3(KK_TPB), 0, ctx->stream, x, p, r, q, ld, pt.rpb, alpha,
+        hipLaunchKernelGGL(k_cg_update, dim3(pt.nblk), dim3(KK_TPB), 0, ctx->stream, x, p, r, q, ld, pt.rpb, alpha, pq_dev,
                            part_row(ctx, PART_SCAL_A));
     }
     KK_HIP(hipGetLastError());

@@ -94,6 +94,8 @@ SIGNATURES = {
     "kk_spmv_affine": (C.c_int, [c_vp, c_vp, C.c_int, c_vp, C.c_int, C.c_double, C.c_double]),
     "kk_spmv_affine_dot": (C.c_int, [c_vp, c_vp, C.c_int, c_vp, C.c_int, C.c_double, C.c_double, c_dp]),
     "kk_cg_update": (C.c_int, [c_vp, C.c_int, c_vp, C.c_int, c_vp, C.c_int, c_vp, C.c_int, C.c_double, c_dp]),
+    "kk_cg_iterate": (C.c_int, [c_vp, c_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int,
+                                C.c_double, c_dp, c_dp]),
     "kk_gather": (C.c_int, [c_vp, C.c_int, c_vp, C.c_int64, c_vp]),
     "kk_project": (C.c_int, [c_vp, C.c_int, C.c_int, c_vp, C.c_int, C.c_double, C.c_double, c_dp]),
     "kk_unproject": (C.c_int, [c_vp, C.c_int, c_vp, C.c_int, C.c_int, c_dp, C.c_double, C.c_double]),

@@ -465,20 +465,15 @@ def linsolve_cg(A, b, x0=None, alg: Optional[CG] = None, a0: float = 0.0, a1: fl
     if normr < tol:
         return vx.get(), ConvergenceInfo(1, vr.get(), normr, numiter, numops)
 
-    def apply_dot():
-        d = C.c_double()
-        check(lib.kk_spmv_affine_dot(op.handle, W.handle, 3, W.handle, 4, a0, a1, C.byref(d)))
-        return d.value
-
-    def update(alpha):
-        nr = C.c_double()
-        check(lib.kk_cg_update(W.handle, 1, W.handle, 3, W.handle, 2, W.handle, 4, alpha, C.byref(nr)))
+    def iterate(beta, first, rho):
+        """[p = r + beta p]; q = (a0 + a1 A) p; alpha = rho/<p,q>; x += alpha p; r -= alpha q -> |r|  (one host sync)"""
+        pq, nr = C.c_double(), C.c_double()
+        check(lib.kk_cg_iterate(op.handle, W.handle, 1, 2, 3, 4, a0, a1, beta, int(first), rho, C.byref(pq), C.byref(nr)))
         return nr.value
 
     rho = normr ** 2
     vp.scale_from_(vr, 1.0)               # :33-34
-    alpha = rho / apply_dot()
-    normr = update(alpha)
+    normr = iterate(0.0, True, rho)
     rho_old, rho = rho, normr ** 2
     beta = rho / rho_old
     numops += 1
@@ -486,9 +481,7 @@ def linsolve_cg(A, b, x0=None, alg: Optional[CG] = None, a0: float = 0.0, a1: fl
     if normr < tol:
         return vx.get(), ConvergenceInfo(1, vr.get(), normr, numiter, numops)
     while True:                           # :60-101
-        vp.add_(vr, 1.0, beta)            # p = add!!(p, r, 1, beta)
-        alpha = rho / apply_dot()
-        normr = update(alpha)
+        normr = iterate(beta, False, rho)  # p = add!!(p, r, 1, beta); q = apply; alpha = rho/inner(p,q); x, r updates
         if normr < tol:                   # recompute explicitly   :67-72
             vr.scale_from_(vb, 1.0)
             op.apply_affine(vx, vq, a0, a1)

@@ -123,6 +123,24 @@ def bench_block(ctx):
     ctx.set_option("block_mode", 1)
 
 
+def bench_cg(ctx):
+    import scipy.sparse as sps
+    nx, ny = 4000, 2500
+    N = nx * ny
+    A = (laplacian_rows(nx, ny, 0, ny) + sps.identity(N) * 0.5).tocsr()   # SPD, well conditioned enough for a short run
+    op = kk.SparseOperator(A, ctx, symmetric=True)
+    b = np.random.default_rng(4).random(N)
+    for rep in range(2):
+        ctx.sync(); t0 = time.perf_counter()
+        x, info = kk.linsolve_cg(op, b, None, kk.CG(60, 1e-30))
+        ctx.sync(); dt = time.perf_counter() - t0
+    its = info.numiter
+    alg = its * (84 + 48 + 24) * N
+    print(json.dumps({"config": "CG (SURVEY 8(f)-3) on the 10M-row shifted Laplacian, 60 iterations", "seconds": round(dt, 4),
+                      "it_per_s": round(its / dt, 1), "alg_GBps": round(alg / dt / 1e9, 1), "frac_8TBps": round(alg / dt / 8e12, 4),
+                      "normres": info.normres}), flush=True)
+
+
 if __name__ == "__main__":
     ctx = kk.default_context()
     what = [a for a in sys.argv[1:] if not a.startswith("--")] or ["gmres", "block", "gkl"]
@@ -130,5 +148,7 @@ if __name__ == "__main__":
         bench_gmres(ctx)
     if "block" in what:
         bench_block(ctx)
+    if "cg" in what:
+        bench_cg(ctx)
     if "gkl" in what:
         bench_gkl(ctx, "--full" in sys.argv)
