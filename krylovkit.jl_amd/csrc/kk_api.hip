@@ -700,6 +700,7 @@ extern "C" int kk_spmv_affine_dot(kk_op op, kk_basis bx, int cx, kk_basis by, in
     *dot = pin(c, WS_SCAL + SC_DOT)[0];
     return KK_OK;
 }
+static int check_square_op(kk_op op, kk_basis b);
 // One CG iteration body (linsolve/cg.jl:60-66) with ONE host synchronisation:
 //   [p = r + beta p]  (skipped when beta_is_first)   q = a0 p + a1 A p with fused <p,q> (stays on the device)
 //   alpha = rho / <p,q> formed inside the update kernel ; x += alpha p ; r -= alpha q ; |r|
