@@ -1,0 +1,111 @@
+"""Randomised (hypothesis) shapes for the streaming kernels: every (n, m) combination around the
+tile boundaries (512-row sub-steps, 2048-row groups, 4-column batches, 64-column accumulator groups,
+16-column MFMA tiles) must agree with NumPy."""
+import numpy as np
+import pytest
+from hypothesis import given, settings, strategies as st, HealthCheck
+
+pytestmark = pytest.mark.gpu
+SET = dict(max_examples=30, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+
+sizes = st.one_of(st.integers(1, 40), st.integers(500, 530), st.integers(2040, 2060), st.integers(4090, 4110),
+                  st.integers(1, 20000))
+cols = st.one_of(st.integers(1, 9), st.integers(60, 70), st.integers(125, 132), st.integers(1, 140))
+
+
+def _fill(kk, ctx, V):
+    n, m = V.shape
+    B = kk.DeviceBasis(n, m + 2, ctx)
+    for j in range(m):
+        B.upload(j, V[:, j])
+    B.length = m
+    return B
+
+
+@settings(**SET)
+@given(n=sizes, m=cols, seed=st.integers(0, 2**31 - 1))
+def test_project_unproject_random(kk, ctx, n, m, seed):
+    rng = np.random.default_rng(seed)
+    V, w, x = rng.standard_normal((n, m)), rng.standard_normal(n), rng.standard_normal(m)
+    B = _fill(kk, ctx, V)
+    vw = B[m].set(w)
+    y = B.project(vw)
+    tol = 1e-13 * (np.linalg.norm(w) * np.sqrt(n) + 1)
+    assert np.max(np.abs(y - V.T @ w)) <= tol * np.max(np.abs(V))
+    B.unproject(vw, x, alpha=-1.0, beta=1.0)
+    np.testing.assert_allclose(vw.get(), w - V @ x, rtol=1e-12, atol=1e-12 * (1 + np.abs(V) @ np.abs(x)).max())
+
+
+@settings(**SET)
+@given(n=sizes, m=st.integers(1, 128), seed=st.integers(0, 2**31 - 1), alg=st.sampled_from(["cgs2", "mgs2", "cgs", "mgs"]))
+def test_orthogonalize_random(kk, ctx, n, m, seed, alg):
+    m = min(m, n)
+    rng = np.random.default_rng(seed)
+    Q, _ = np.linalg.qr(rng.standard_normal((n, m)))
+    w = rng.standard_normal(n)
+    B = _fill(kk, ctx, Q)
+    vw = B[m].set(w)
+    x, nrm, _ = B.orthogonalize(vw, kk.Orthogonalizer(alg))
+    wd = vw.get()
+    nw = np.linalg.norm(w)
+    assert np.max(np.abs(Q.T @ wd)) <= 1e-12 * nw
+    np.testing.assert_allclose(wd + Q @ x, w, rtol=0, atol=1e-12 * nw)
+    assert abs(nrm - np.linalg.norm(wd)) <= 1e-12 * nw
+
+
+@settings(**SET)
+@given(n=sizes, p=st.integers(1, 40), q=st.integers(1, 20), seed=st.integers(0, 2**31 - 1))
+def test_block_gram_update_random(kk, ctx, n, p, q, seed):
+    rng = np.random.default_rng(seed)
+    X, Y = rng.standard_normal((n, p)), rng.standard_normal((n, q))
+    S = kk.DeviceBasis(n, p + q, ctx)
+    for j in range(p):
+        S.upload(j, X[:, j])
+    for j in range(q):
+        S.upload(p + j, Y[:, j])
+    M = kk.block_inner(kk.Block(S, 0, p), kk.Block(S, p, q))
+    ref = X.T @ Y
+    assert np.max(np.abs(M - ref)) <= 1e-13 * (np.sqrt(n) + 1) * (np.abs(X).T @ np.abs(Y)).max() + 1e-300
+    from krylovkit_hip._lib import check, c_dp
+    Sm = np.asfortranarray(rng.standard_normal((p, q)))
+    norms = np.zeros(q)
+    check(S._lib.kk_block_update(S.handle, p, q, S.handle, 0, p, Sm.ctypes.data_as(c_dp), p, -1.0, 1.0, norms.ctypes.data_as(c_dp)))
+    refW = Y - X @ Sm
+    W = np.stack([S.download(p + j) for j in range(q)], 1)
+    np.testing.assert_allclose(W, refW, rtol=1e-12, atol=1e-12 * (1 + (np.abs(X) @ np.abs(Sm)).max()))
+    np.testing.assert_allclose(norms, np.linalg.norm(refW, axis=0), rtol=1e-12, atol=1e-300)
+
+
+@settings(**SET)
+@given(n=sizes, m=st.integers(1, 120), frac=st.floats(0.1, 1.0), seed=st.integers(0, 2**31 - 1))
+def test_basistransform_random(kk, ctx, n, m, frac, seed):
+    k = max(1, int(m * frac))
+    rng = np.random.default_rng(seed)
+    V, U = rng.standard_normal((n, m)), rng.standard_normal((m, k))
+    B = _fill(kk, ctx, V)
+    B.basistransform(U)
+    got = B.to_numpy()
+    scale = (np.abs(V) @ np.abs(U)).max() + 1
+    assert np.max(np.abs(got[:, :k] - V @ U)) <= 1e-13 * scale
+    np.testing.assert_array_equal(got[:, k:], V[:, k:])
+
+
+@settings(**SET)
+@given(nrows=st.integers(1, 3000), ncols=st.integers(1, 3000), dens=st.floats(0.0005, 0.05), seed=st.integers(0, 2**31 - 1),
+       fmt=st.sampled_from(["auto", "csr", "sell"]))
+def test_spmv_random(kk, ctx, monkeypatch, nrows, ncols, dens, seed, fmt):
+    import scipy.sparse as sp
+    if fmt != "auto":
+        monkeypatch.setenv("KK_SPMV_FORMAT", fmt)
+    else:
+        monkeypatch.delenv("KK_SPMV_FORMAT", raising=False)
+    rng = np.random.default_rng(seed)
+    A = sp.random(nrows, ncols, density=dens, random_state=rng.integers(1 << 30), format="csr")
+    A.data[:] = rng.standard_normal(A.nnz)
+    op = kk.SparseOperator(A, ctx)
+    X, Y = kk.DeviceBasis(ncols, 2, ctx), kk.DeviceBasis(nrows, 2, ctx)
+    x, u = rng.standard_normal(ncols), rng.standard_normal(nrows)
+    op.apply(X[0].set(x), Y[0])
+    np.testing.assert_allclose(Y[0].get(), A @ x, rtol=1e-12, atol=1e-12 * (1 + (abs(A) @ abs(x)).max()))
+    op.apply_adjoint(Y[1].set(u), X[1])
+    np.testing.assert_allclose(X[1].get(), A.T @ u, rtol=1e-12, atol=1e-12 * (1 + (abs(A.T) @ abs(u)).max()))
