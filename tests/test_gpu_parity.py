@@ -703,3 +703,26 @@ def test_linsolve_cg(kk, ko, ctx):
     xs = np.random.default_rng(1).random(n)
     x, info = kk.linsolve_cg(kk.SparseOperator(A, ctx, symmetric=True), A @ xs, xs, kk.CG(tol=1e-8))
     assert info.numops == 1 and info.converged == 1
+
+
+@pytest.mark.parametrize("mgs_mode", [0, 1])
+def test_mgs_on_non_orthonormal_basis(kk, ko, ctx, mgs_mode):
+    """The low-sync form (I + L) s = V'w is exact algebra for ANY basis (MGS never divides by |q|^2):
+    coefficients must match the sequential oracle also when the 'basis' is far from orthonormal."""
+    ctx.set_option("mgs_mode", mgs_mode)
+    rng = np.random.default_rng(77)
+    n, m = 4000, 12
+    Q, _ = np.linalg.qr(rng.standard_normal((n, m)))
+    V = Q @ (np.eye(m) + 0.3 * rng.standard_normal((m, m)))      # correlated, non-normalised columns
+    w0 = rng.standard_normal(n)
+    for dev, ref in ((kk.ModifiedGramSchmidt(), ko.MGS), (kk.ModifiedGramSchmidt2(), ko.MGS2)):
+        B = kk.DeviceBasis(n, m + 1, ctx)
+        for j in range(m):
+            B.upload(j, V[:, j])
+        B.length = m
+        vw = B[m].set(w0)
+        x, nrm, _ = B.orthogonalize(vw, dev)
+        wr, xr = ko.orthogonalize(w0.copy(), [V[:, j].copy() for j in range(m)], ref)
+        np.testing.assert_allclose(x, xr, rtol=1e-9, atol=1e-10 * np.linalg.norm(w0))
+        np.testing.assert_allclose(vw.get(), wr, rtol=0, atol=1e-9 * np.linalg.norm(w0))
+    ctx.set_option("mgs_mode", 1)
