@@ -11,6 +11,7 @@
 //     HBM -> tiny finalize kernel.  No atomics.
 //   * rows n..ld-1 of every column are zero and stay zero, so no kernel needs a row bound check.
 #include "kk_internal.h"
+#include <memory>
 
 typedef double2 d2;
 typedef double v4d __attribute__((ext_vector_type(4)));  // MFMA f64 16x16x4 accumulator fragment
@@ -1159,7 +1160,7 @@ int kk_launch_project(kk_ctx ctx, const double* V, int64_t ld, int m, const doub
     kk_part p = kk_partition(ctx, ld);
     dim3 g(p.nblk), b(KK_TPB);
     double* part = ctx->partials;
-    kk_prof_scope* ps = new kk_prof_scope(ctx, "k_project");
+    std::unique_ptr<kk_prof_scope> ps(new kk_prof_scope(ctx, "k_project"));
     if (pre_vec && rhs2)
         hipLaunchKernelGGL((k_project<true, true>), g, b, 0, ctx->stream, V, ld, m, w, pre_vec, pre_a_dev, rhs2, p.rpb, part);
     else if (pre_vec)
@@ -1168,7 +1169,7 @@ int kk_launch_project(kk_ctx ctx, const double* V, int64_t ld, int m, const doub
         hipLaunchKernelGGL((k_project<false, true>), g, b, 0, ctx->stream, V, ld, m, w, pre_vec, pre_a_dev, rhs2, p.rpb, part);
     else
         hipLaunchKernelGGL((k_project<false, false>), g, b, 0, ctx->stream, V, ld, m, w, pre_vec, pre_a_dev, rhs2, p.rpb, part);
-    delete ps;
+    ps.reset();
     KK_HIP(hipGetLastError());
     const int total = rhs2 ? 2 * m : m;
     hipLaunchKernelGGL(k_finalize_project, dim3((total + 3) / 4), dim3(KK_TPB), 0, ctx->stream, part, p.nblk, m,
@@ -1188,7 +1189,7 @@ int kk_launch_unproject(kk_ctx ctx, const double* V, int64_t ld, int m, const do
     const kk_coef& ch = coef_host ? *coef_host : zero_coef;
     double* part = part_row(ctx, PART_SCAL_A);
     const bool norm = nrm_out3 != nullptr, bzero = (beta == 0.0);
-    kk_prof_scope* ps = new kk_prof_scope(ctx, "k_unproject");
+    std::unique_ptr<kk_prof_scope> ps(new kk_prof_scope(ctx, "k_unproject"));
     if (norm && bzero)
         hipLaunchKernelGGL((k_unproject<true, true>), g, b, 0, ctx->stream, V, ld, m, w_in, w_out, ch, coef_dev, alpha, beta, add_idx, add_dev, p.rpb, part);
     else if (norm)
@@ -1197,7 +1198,7 @@ int kk_launch_unproject(kk_ctx ctx, const double* V, int64_t ld, int m, const do
         hipLaunchKernelGGL((k_unproject<false, true>), g, b, 0, ctx->stream, V, ld, m, w_in, w_out, ch, coef_dev, alpha, beta, add_idx, add_dev, p.rpb, part);
     else
         hipLaunchKernelGGL((k_unproject<false, false>), g, b, 0, ctx->stream, V, ld, m, w_in, w_out, ch, coef_dev, alpha, beta, add_idx, add_dev, p.rpb, part);
-    delete ps;
+    ps.reset();
     KK_HIP(hipGetLastError());
     if (norm) return finalize_scalar(ctx, PART_SCAL_A, p.nblk, nrm_out3, true);
     return KK_OK;
@@ -1209,12 +1210,12 @@ int kk_launch_mgs_step(kk_ctx ctx, double* w, int64_t ld, const double* q_prev, 
     dim3 g(p.nblk), b(KK_TPB);
     double* pd = part_row(ctx, PART_SCAL_A);
     double* pn = part_row(ctx, PART_SCAL_B);
-    kk_prof_scope* ps = new kk_prof_scope(ctx, "k_mgs_step");
+    std::unique_ptr<kk_prof_scope> ps(new kk_prof_scope(ctx, "k_mgs_step"));
     if (nrm_out3)
         hipLaunchKernelGGL((k_mgs_step<true>), g, b, 0, ctx->stream, w, ld, p.rpb, q_prev, s_prev_dev, q_next, pd, pn);
     else
         hipLaunchKernelGGL((k_mgs_step<false>), g, b, 0, ctx->stream, w, ld, p.rpb, q_prev, s_prev_dev, q_next, pd, pn);
-    delete ps;
+    ps.reset();
     KK_HIP(hipGetLastError());
     if (q_next) KK_TRY(finalize_scalar(ctx, PART_SCAL_A, p.nblk, dot_out, false));
     if (nrm_out3) KK_TRY(finalize_scalar(ctx, PART_SCAL_B, p.nblk, nrm_out3, true));
@@ -1237,7 +1238,7 @@ int kk_launch_spmv(kk_ctx ctx, const kk_sparse_dev& M, const double* x, double* 
     double* pd = part_row(ctx, PART_SCAL_A);
     double* pn = part_row(ctx, PART_SCAL_B);
     int nblk = 0;
-    kk_prof_scope* ps = new kk_prof_scope(ctx, M.format == 0 ? "k_spmv_ell" : (M.format == 2 ? "k_spmv_sell" : "k_spmv_csr"));
+    std::unique_ptr<kk_prof_scope> ps(new kk_prof_scope(ctx, M.format == 0 ? "k_spmv_ell" : (M.format == 2 ? "k_spmv_sell" : "k_spmv_csr")));
     if (M.format == 2) {
         nblk = (int)std::min<int64_t>((M.sell_nchunks + 3) / 4, (int64_t)ctx->num_cus * 16);
         if (nblk < 1) nblk = 1;
@@ -1260,11 +1261,11 @@ int kk_launch_spmv(kk_ctx ctx, const kk_sparse_dev& M, const double* x, double* 
 #define CSR_CASE(LL) case LL: hipLaunchKernelGGL((k_spmv_csr<LL>), g, b, 0, ctx->stream, M.rowptr, M.colind, M.val, M.nrows, x, y, e, pd, pn); break;
         switch (L) {
             CSR_CASE(2) CSR_CASE(4) CSR_CASE(8) CSR_CASE(16) CSR_CASE(32) CSR_CASE(64)
-            default: delete ps; kk_set_error("bad lanes_per_row %d", L); return KK_ERR_INVALID;
+            default: ps.reset(); kk_set_error("bad lanes_per_row %d", L); return KK_ERR_INVALID;
         }
 #undef CSR_CASE
     }
-    delete ps;
+    ps.reset();
     KK_HIP(hipGetLastError());
     if (nblk > KK_MAX_BLOCKS && (f.dot_mode || f.nrm_out)) {
         kk_set_error("spmv grid %d exceeds partial buffer", nblk);
