@@ -129,3 +129,41 @@ def test_config5_blocklanczos_10M_properties(kk, ctx):
     S.unproject(W[0], H[:, k - bs], 0, k, -1.0, 1.0)
     W[0].add_(R[0], -1.0)
     assert W[0].norm() < 1e-10
+
+
+def test_config4_gkl_5Mx1M_properties(kk, ctx):
+    """svdsolve/GKL on the 5M x 1M random sparse map (nnz/row = 20), single GPU: bidiagonal relations
+    on sampled columns, orthonormality of both bases via device Gram panels, sigma_max bound."""
+    import scipy.sparse as sp
+    m, n, per, K = 5_000_000, 1_000_000, 20, 30
+    rng = np.random.default_rng(5)
+    cols = rng.integers(0, n, size=m * per, dtype=np.int32)
+    vals = rng.standard_normal(m * per)
+    A = sp.csr_matrix((vals, cols, np.arange(0, m * per + 1, per, dtype=np.int64)), shape=(m, n))
+    A.sum_duplicates()
+    op = kk.SparseOperator(A, ctx)
+    it = kk.GKLIterator(op, rng.random(m), kk.ModifiedGramSchmidt2(), capacity=K + 2)
+    f = kk.initialize(it)
+    for _ in range(K - 1):
+        f = kk.expand_(it, f)
+    al, be = np.array(f.alphas), np.array(f.betas)
+    assert np.all(al > 0) and np.all(be > 0)
+    assert _gram_offdiag_max(kk, f.U, K) < 1e-12 and _gram_offdiag_max(kk, f.V, K) < 1e-12
+    WU, WV = kk.DeviceBasis(m, 1, ctx), kk.DeviceBasis(n, 1, ctx)
+    for j in (0, 11, K - 1):
+        # A v_j = alpha_j u_j + beta_j u_{j+1}   (u_{K+1} = r / beta_K)
+        op.apply(f.V[j], WU[0])
+        WU[0].add_(f.U[j], -al[j])
+        if j < K - 1:
+            WU[0].add_(f.U[j + 1], -be[j])
+        else:
+            WU[0].add_(f.r, -1.0)
+        assert WU[0].norm() < 1e-10, j
+        # A' u_j = alpha_j v_j + beta_{j-1} v_{j-1}
+        op.apply_adjoint(f.U[j], WV[0])
+        WV[0].add_(f.V[j], -al[j])
+        if j > 0:
+            WV[0].add_(f.V[j - 1], -be[j - 1])
+        assert WV[0].norm() < 1e-10, j
+    smax = np.linalg.svd(f.rayleighquotient(), compute_uv=False)[0]
+    assert 0.9 * (np.sqrt(m * per / n) + np.sqrt(per)) < smax < 1.1 * (np.sqrt(m * per / n) + np.sqrt(per))  # Marchenko-Pastur edge
