@@ -13,7 +13,22 @@
 #define KK_BLK_SCRATCH 131072 // doubles of device/pinned scratch for block matrices (gram panels, S)
 #define KK_TPB 256            // threads per block of every streaming kernel (4 waves)
 #define KK_SUB 512            // rows covered by one block sub-step: 256 threads x 2 rows (16 B/lane)
-#define KK_RG 4               // sub-steps per row group (8 rows per thread in registers)
+// register tile of the two basis-streaming kernels: RG sub-steps of 512 rows per row group (2*RG rows per
+// lane) x CB basis columns per load batch  ->  RG*CB 16-byte loads in flight per lane.
+// Defaults from tools/tile_sweep.sh on MI355X (10M rows, m=2..100): project 8x2 is 7 % faster than 4x4,
+// unproject 8x4 3 % faster than 4x4; 16-row groups lose occupancy (unproject 16x4: -45 %).
+#ifndef KK_RG_P
+#define KK_RG_P 8
+#endif
+#ifndef KK_CB_P
+#define KK_CB_P 2
+#endif
+#ifndef KK_RG_U
+#define KK_RG_U 8
+#endif
+#ifndef KK_CB_U
+#define KK_CB_U 4
+#endif
 
 // scalar workspace layout (doubles)
 #define WS_S 0                // coefficients of the current pass            [KK_MAX_M]

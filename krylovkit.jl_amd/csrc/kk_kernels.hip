@@ -199,13 +199,13 @@ __global__ __launch_bounds__(KK_TPB) void k_gather(const double* __restrict__ x,
 // Lane-distributed accumulators: lane l of every wave owns columns l, 64+l, 128+l, 192+l.
 // ------------------------------------------------------------------------------------------
 template <bool PRE, bool RHS2, bool FULL>
-__device__ __forceinline__ void proj_batch(const double* __restrict__ Vc, int64_t ld, int ncol, int nsub, const d2 (&wv)[KK_RG],
-                                           const d2 (&gv)[KK_RG], int lane, int jj, double& acc, double& acc2) {
-    d2 x[4][KK_RG];
+__device__ __forceinline__ void proj_batch(const double* __restrict__ Vc, int64_t ld, int ncol, int nsub, const d2 (&wv)[KK_RG_P],
+                                           const d2 (&gv)[KK_RG_P], int lane, int jj, double& acc, double& acc2) {
+    d2 x[KK_CB_P][KK_RG_P];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < KK_CB_P; ++c) {
 #pragma unroll
-        for (int k = 0; k < KK_RG; ++k) {
+        for (int k = 0; k < KK_RG_P; ++k) {
             if (FULL || (c < ncol && k < nsub))
                 x[c][k] = ld2s(Vc + (int64_t)c * ld + k * KK_SUB);
             else
@@ -213,10 +213,10 @@ __device__ __forceinline__ void proj_batch(const double* __restrict__ Vc, int64_
         }
     }
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < KK_CB_P; ++c) {
         double t = 0;
 #pragma unroll
-        for (int k = 0; k < KK_RG; ++k) {
+        for (int k = 0; k < KK_RG_P; ++k) {
             t = fma(x[c][k].x, wv[k].x, t);
             t = fma(x[c][k].y, wv[k].y, t);
         }
@@ -225,7 +225,7 @@ __device__ __forceinline__ void proj_batch(const double* __restrict__ Vc, int64_
         if (RHS2) {
             double t2 = 0;
 #pragma unroll
-            for (int k = 0; k < KK_RG; ++k) {
+            for (int k = 0; k < KK_RG_P; ++k) {
                 t2 = fma(x[c][k].x, gv[k].x, t2);
                 t2 = fma(x[c][k].y, gv[k].y, t2);
             }
@@ -246,12 +246,12 @@ __global__ __launch_bounds__(KK_TPB) void k_project(const double* __restrict__ V
     double acc[4] = {0, 0, 0, 0}, acc2[4] = {0, 0, 0, 0};
     double a = 0;
     if (PRE) a = *pre_a;
-    for (int64_t rg = r0; rg < r1; rg += KK_SUB * KK_RG) {
-        const int nsub = (int)imin((int64_t)KK_RG, (r1 - rg) / KK_SUB);
+    for (int64_t rg = r0; rg < r1; rg += KK_SUB * KK_RG_P) {
+        const int nsub = (int)imin((int64_t)KK_RG_P, (r1 - rg) / KK_SUB);
         const int64_t off = rg + tid * 2;
-        d2 wv[KK_RG], gv[KK_RG];
+        d2 wv[KK_RG_P], gv[KK_RG_P];
 #pragma unroll
-        for (int k = 0; k < KK_RG; ++k) {
+        for (int k = 0; k < KK_RG_P; ++k) {
             if (k < nsub) {
                 wv[k] = ld2(w + off + k * KK_SUB);
                 if (PRE) {
@@ -273,12 +273,12 @@ __global__ __launch_bounds__(KK_TPB) void k_project(const double* __restrict__ V
                 const int jn = min(64, m - jq);
                 const double* Vq = V + (int64_t)jq * ld + off;
                 int jj = 0;
-                if (nsub == KK_RG) {
-                    for (; jj + 4 <= jn; jj += 4)
-                        proj_batch<PRE, RHS2, true>(Vq + (int64_t)jj * ld, ld, 4, KK_RG, wv, gv, lane, jj, acc[q], acc2[q]);
+                if (nsub == KK_RG_P) {
+                    for (; jj + KK_CB_P <= jn; jj += KK_CB_P)
+                        proj_batch<PRE, RHS2, true>(Vq + (int64_t)jj * ld, ld, KK_CB_P, KK_RG_P, wv, gv, lane, jj, acc[q], acc2[q]);
                 }
-                for (; jj < jn; jj += 4)
-                    proj_batch<PRE, RHS2, false>(Vq + (int64_t)jj * ld, ld, min(4, jn - jj), nsub, wv, gv, lane, jj, acc[q], acc2[q]);
+                for (; jj < jn; jj += KK_CB_P)
+                    proj_batch<PRE, RHS2, false>(Vq + (int64_t)jj * ld, ld, min(KK_CB_P, jn - jj), nsub, wv, gv, lane, jj, acc[q], acc2[q]);
             }
         }
     }
@@ -341,12 +341,12 @@ __global__ __launch_bounds__(KK_TPB) void k_unproject(const double* __restrict__
     __syncthreads();
     const int64_t r0 = (int64_t)blockIdx.x * rpb, r1 = imin(r0 + rpb, ld);
     double nacc = 0;
-    for (int64_t rg = r0; rg < r1; rg += KK_SUB * KK_RG) {
-        const int nsub = (int)imin((int64_t)KK_RG, (r1 - rg) / KK_SUB);
+    for (int64_t rg = r0; rg < r1; rg += KK_SUB * KK_RG_U) {
+        const int nsub = (int)imin((int64_t)KK_RG_U, (r1 - rg) / KK_SUB);
         const int64_t off = rg + tid * 2;
-        d2 wv[KK_RG];
+        d2 wv[KK_RG_U];
 #pragma unroll
-        for (int k = 0; k < KK_RG; ++k) {
+        for (int k = 0; k < KK_RG_U; ++k) {
             if (!BZERO && k < nsub) {
                 wv[k] = ld2(w_in + off + k * KK_SUB);
                 wv[k].x *= beta; wv[k].y *= beta;
@@ -356,18 +356,18 @@ __global__ __launch_bounds__(KK_TPB) void k_unproject(const double* __restrict__
         }
         const double* Vo = V + off;
         int j = 0;
-        if (nsub == KK_RG) {
-            for (; j + 4 <= m; j += 4) {
-                d2 x[4][KK_RG];
+        if (nsub == KK_RG_U) {
+            for (; j + KK_CB_U <= m; j += KK_CB_U) {
+                d2 x[KK_CB_U][KK_RG_U];
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
+                for (int c = 0; c < KK_CB_U; ++c)
 #pragma unroll
-                    for (int k = 0; k < KK_RG; ++k) x[c][k] = ld2s(Vo + (int64_t)(j + c) * ld + k * KK_SUB);
+                    for (int k = 0; k < KK_RG_U; ++k) x[c][k] = ld2s(Vo + (int64_t)(j + c) * ld + k * KK_SUB);
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
+                for (int c = 0; c < KK_CB_U; ++c) {
                     const double s = sc[j + c];
 #pragma unroll
-                    for (int k = 0; k < KK_RG; ++k) {
+                    for (int k = 0; k < KK_RG_U; ++k) {
                         wv[k].x = fma(s, x[c][k].x, wv[k].x);
                         wv[k].y = fma(s, x[c][k].y, wv[k].y);
                     }
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(KK_TPB) void k_unproject(const double* __restrict__
         for (; j < m; ++j) {
             const double s = sc[j];
 #pragma unroll
-            for (int k = 0; k < KK_RG; ++k) {
+            for (int k = 0; k < KK_RG_U; ++k) {
                 if (k < nsub) {
                     d2 x = ld2s(Vo + (int64_t)j * ld + k * KK_SUB);
                     wv[k].x = fma(s, x.x, wv[k].x);
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(KK_TPB) void k_unproject(const double* __restrict__
             }
         }
 #pragma unroll
-        for (int k = 0; k < KK_RG; ++k) {
+        for (int k = 0; k < KK_RG_U; ++k) {
             if (k < nsub) {
                 st2(w_out + off + k * KK_SUB, wv[k]);
                 if (NORM) {
