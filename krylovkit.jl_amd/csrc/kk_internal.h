@@ -23,6 +23,12 @@
 #ifndef KK_CB_P
 #define KK_CB_P 2
 #endif
+#ifndef KK_RG_P2             // project with a second right-hand side (Gram row ride-along of low-sync MGS)
+#define KK_RG_P2 16
+#endif
+#ifndef KK_CB_P2
+#define KK_CB_P2 1
+#endif
 #ifndef KK_RG_U
 #define KK_RG_U 8
 #endif

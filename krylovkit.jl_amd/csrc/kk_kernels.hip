@@ -40,6 +40,17 @@ __device__ __forceinline__ int2 ldi2s(const int32_t* p) {
 #endif
 }
 __device__ __forceinline__ void st2(double* p, d2 v) { *reinterpret_cast<d2*>(p) = v; }
+// work-vector store of the unproject pass: non-temporal (write-around) -- the 8(m+1)N-byte basis stream of the
+// same kernel would evict it before its next reader anyway; measured -1..-3 % on k_unproject
+__device__ __forceinline__ void st2s(double* p, d2 v) {
+#ifndef KK_NO_NT_LOADS
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    __builtin_nontemporal_store(v2d{v.x, v.y}, reinterpret_cast<v2d*>(p));
+#else
+    *reinterpret_cast<d2*>(p) = v;
+#endif
+}
+
 
 template <int CTRL>
 __device__ __forceinline__ double dpp_mov(double v) {
@@ -198,25 +209,23 @@ __global__ __launch_bounds__(KK_TPB) void k_gather(const double* __restrict__ x,
 // right-hand side g[j] = <V_j, rhs2>.  V is read exactly once (8 m N bytes), w once.
 // Lane-distributed accumulators: lane l of every wave owns columns l, 64+l, 128+l, 192+l.
 // ------------------------------------------------------------------------------------------
-template <bool PRE, bool RHS2, bool FULL>
-__device__ __forceinline__ void proj_batch(const double* __restrict__ Vc, int64_t ld, int ncol, int nsub, const d2 (&wv)[KK_RG_P],
-                                           const d2 (&gv)[KK_RG_P], int lane, int jj, double& acc, double& acc2) {
-    d2 x[KK_CB_P][KK_RG_P];
+// A block's row range is cut into row groups of RG 512-row chunks (2*RG rows per lane, held in registers
+// against CB columns per load batch); what is left after the full KK_RG_P groups goes through the same code
+// at RG/2, RG/4, .. 1 chunks with CB widened to keep the loads in flight (no masked slow path).
+template <int RG, int CB, bool RHS2>
+__device__ __forceinline__ void proj_batch(const double* __restrict__ Vc, int64_t ld, const d2 (&wv)[RG], const d2 (&gv)[RG],
+                                           int lane, int jj, double& acc, double& acc2) {
+    d2 x[CB][RG];
 #pragma unroll
-    for (int c = 0; c < KK_CB_P; ++c) {
+    for (int c = 0; c < CB; ++c) {
 #pragma unroll
-        for (int k = 0; k < KK_RG_P; ++k) {
-            if (FULL || (c < ncol && k < nsub))
-                x[c][k] = ld2s(Vc + (int64_t)c * ld + k * KK_SUB);
-            else
-                x[c][k] = d2{0.0, 0.0};
-        }
+        for (int k = 0; k < RG; ++k) x[c][k] = ld2s(Vc + (int64_t)c * ld + k * KK_SUB);
     }
 #pragma unroll
-    for (int c = 0; c < KK_CB_P; ++c) {
+    for (int c = 0; c < CB; ++c) {
         double t = 0;
 #pragma unroll
-        for (int k = 0; k < KK_RG_P; ++k) {
+        for (int k = 0; k < RG; ++k) {
             t = fma(x[c][k].x, wv[k].x, t);
             t = fma(x[c][k].y, wv[k].y, t);
         }
@@ -225,13 +234,66 @@ __device__ __forceinline__ void proj_batch(const double* __restrict__ Vc, int64_
         if (RHS2) {
             double t2 = 0;
 #pragma unroll
-            for (int k = 0; k < KK_RG_P; ++k) {
+            for (int k = 0; k < RG; ++k) {
                 t2 = fma(x[c][k].x, gv[k].x, t2);
                 t2 = fma(x[c][k].y, gv[k].y, t2);
             }
             double tot2 = wave_sum(t2);
             acc2 += (lane == jj + c) ? tot2 : 0.0;
         }
+    }
+}
+
+template <int RG, int CB, bool PRE, bool RHS2>
+__device__ __forceinline__ void proj_group(const double* __restrict__ V, int64_t ld, int m, const double* __restrict__ w,
+                                           const double* __restrict__ pre_vec, double a, const double* __restrict__ rhs2,
+                                           int64_t off, int lane, double* smw) {
+    d2 wv[RG], gv[RG];
+#pragma unroll
+    for (int k = 0; k < RG; ++k) {
+        wv[k] = ld2(w + off + k * KK_SUB);
+        if (PRE) {
+            d2 p = ld2(pre_vec + off + k * KK_SUB);
+            wv[k].x = fma(-a, p.x, wv[k].x);
+            wv[k].y = fma(-a, p.y, wv[k].y);
+        }
+        if (RHS2) gv[k] = ld2(rhs2 + off + k * KK_SUB);
+        else gv[k] = d2{0.0, 0.0};
+    }
+    // columns in segments of 64: lane l accumulates column jq + l of the segment, then folds it into its own
+    // LDS slot (same thread reads and writes the slot: no barrier) -- keeps the q loop rolled (code size)
+#pragma unroll 1
+    for (int jq = 0; jq < m; jq += 64) {
+        const int jn = min(64, m - jq);
+        const double* Vq = V + (int64_t)jq * ld + off;
+        double acc = 0, acc2 = 0;
+        int jj = 0;
+        for (; jj + CB <= jn; jj += CB) proj_batch<RG, CB, RHS2>(Vq + (int64_t)jj * ld, ld, wv, gv, lane, jj, acc, acc2);
+        for (; jj < jn; ++jj) proj_batch<RG, 1, RHS2>(Vq + (int64_t)jj * ld, ld, wv, gv, lane, jj, acc, acc2);
+        smw[jq + lane] += acc;
+        if (RHS2) smw[4 * KK_MAX_M + jq + lane] += acc2;
+    }
+}
+
+template <bool RHS2> struct proj_tile {
+    static constexpr int RG = RHS2 ? KK_RG_P2 : KK_RG_P;
+    static constexpr int CB = RHS2 ? KK_CB_P2 : KK_CB_P;
+};
+
+template <int H, bool PRE, bool RHS2>
+__device__ __forceinline__ void proj_tail(const double* __restrict__ V, int64_t ld, int m, const double* __restrict__ w,
+                                          const double* __restrict__ pre_vec, double a, const double* __restrict__ rhs2,
+                                          int64_t& rg, int64_t r1, int tid, int lane, double* smw) {
+    if constexpr (H >= 1) {
+        constexpr int LOADS = proj_tile<RHS2>::RG * proj_tile<RHS2>::CB;
+        constexpr int CBT = (LOADS / H) > 8 ? 8 : (LOADS / H);
+        // at most one group of H chunks, then H/2, ...; single chunks until the range is used up
+        while (rg + (int64_t)H * KK_SUB <= r1) {
+            proj_group<H, CBT, PRE, RHS2>(V, ld, m, w, pre_vec, a, rhs2, rg + tid * 2, lane, smw);
+            rg += (int64_t)H * KK_SUB;
+            if (H > 1) break;
+        }
+        proj_tail<H / 2, PRE, RHS2>(V, ld, m, w, pre_vec, a, rhs2, rg, r1, tid, lane, smw);
     }
 }
 
@@ -243,52 +305,19 @@ __global__ __launch_bounds__(KK_TPB) void k_project(const double* __restrict__ V
     __shared__ double sm[(RHS2 ? 2 : 1) * 4 * KK_MAX_M];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t r0 = (int64_t)blockIdx.x * rpb, r1 = imin(r0 + rpb, ld);
-    double acc[4] = {0, 0, 0, 0}, acc2[4] = {0, 0, 0, 0};
-    double a = 0;
-    if (PRE) a = *pre_a;
-    for (int64_t rg = r0; rg < r1; rg += KK_SUB * KK_RG_P) {
-        const int nsub = (int)imin((int64_t)KK_RG_P, (r1 - rg) / KK_SUB);
-        const int64_t off = rg + tid * 2;
-        d2 wv[KK_RG_P], gv[KK_RG_P];
-#pragma unroll
-        for (int k = 0; k < KK_RG_P; ++k) {
-            if (k < nsub) {
-                wv[k] = ld2(w + off + k * KK_SUB);
-                if (PRE) {
-                    d2 p = ld2(pre_vec + off + k * KK_SUB);
-                    wv[k].x = fma(-a, p.x, wv[k].x);
-                    wv[k].y = fma(-a, p.y, wv[k].y);
-                }
-                if (RHS2) gv[k] = ld2(rhs2 + off + k * KK_SUB);
-                else gv[k] = d2{0.0, 0.0};
-            } else {
-                wv[k] = d2{0.0, 0.0};
-                gv[k] = d2{0.0, 0.0};
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int jq = q * 64;
-            if (jq < m) {
-                const int jn = min(64, m - jq);
-                const double* Vq = V + (int64_t)jq * ld + off;
-                int jj = 0;
-                if (nsub == KK_RG_P) {
-                    for (; jj + KK_CB_P <= jn; jj += KK_CB_P)
-                        proj_batch<PRE, RHS2, true>(Vq + (int64_t)jj * ld, ld, KK_CB_P, KK_RG_P, wv, gv, lane, jj, acc[q], acc2[q]);
-                }
-                for (; jj < jn; jj += KK_CB_P)
-                    proj_batch<PRE, RHS2, false>(Vq + (int64_t)jj * ld, ld, min(KK_CB_P, jn - jj), nsub, wv, gv, lane, jj, acc[q], acc2[q]);
-            }
-        }
-    }
+    double* smw = sm + wave * KK_MAX_M;     // this wave's accumulator row; lane l owns slots l, 64+l, 128+l, 192+l
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        if (q * 64 < m) {
-            sm[wave * KK_MAX_M + q * 64 + lane] = acc[q];
-            if (RHS2) sm[4 * KK_MAX_M + wave * KK_MAX_M + q * 64 + lane] = acc2[q];
-        }
+        smw[q * 64 + lane] = 0.0;
+        if (RHS2) smw[4 * KK_MAX_M + q * 64 + lane] = 0.0;
     }
+    double a = 0;
+    if (PRE) a = *pre_a;
+    int64_t rg = r0;
+    constexpr int RG = proj_tile<RHS2>::RG, CB = proj_tile<RHS2>::CB;
+    for (; rg + (int64_t)RG * KK_SUB <= r1; rg += (int64_t)RG * KK_SUB)
+        proj_group<RG, CB, PRE, RHS2>(V, ld, m, w, pre_vec, a, rhs2, rg + tid * 2, lane, smw);
+    proj_tail<RG / 2, PRE, RHS2>(V, ld, m, w, pre_vec, a, rhs2, rg, r1, tid, lane, smw);
     __syncthreads();
     if (tid < m) {
         double t = (sm[tid] + sm[KK_MAX_M + tid]) + (sm[2 * KK_MAX_M + tid] + sm[3 * KK_MAX_M + tid]);
@@ -324,6 +353,72 @@ __global__ __launch_bounds__(KK_TPB) void k_finalize_project(const double* __res
 // Coefficients come from the kernarg segment (host vector, scalar loads) or from device memory;
 // coefficient add_idx may get a device scalar added (folds the Lanczos "w -= alpha v" into the pass).
 // ------------------------------------------------------------------------------------------
+template <int RG, int CB, bool NORM, bool BZERO>
+__device__ __forceinline__ void unproj_group(const double* __restrict__ V, int64_t ld, int m, const double* w_in, double* w_out,
+                                             const double* sc, double beta, int64_t off, double& nacc) {
+    d2 wv[RG];
+#pragma unroll
+    for (int k = 0; k < RG; ++k) {
+        if (!BZERO) {
+            wv[k] = ld2(w_in + off + k * KK_SUB);
+            wv[k].x *= beta; wv[k].y *= beta;
+        } else {
+            wv[k] = d2{0.0, 0.0};
+        }
+    }
+    const double* Vo = V + off;
+    int j = 0;
+    for (; j + CB <= m; j += CB) {
+        d2 x[CB][RG];
+#pragma unroll
+        for (int c = 0; c < CB; ++c)
+#pragma unroll
+            for (int k = 0; k < RG; ++k) x[c][k] = ld2s(Vo + (int64_t)(j + c) * ld + k * KK_SUB);
+#pragma unroll
+        for (int c = 0; c < CB; ++c) {
+            const double s = sc[j + c];
+#pragma unroll
+            for (int k = 0; k < RG; ++k) {
+                wv[k].x = fma(s, x[c][k].x, wv[k].x);
+                wv[k].y = fma(s, x[c][k].y, wv[k].y);
+            }
+        }
+    }
+    for (; j < m; ++j) {
+        const double s = sc[j];
+        d2 x[RG];
+#pragma unroll
+        for (int k = 0; k < RG; ++k) x[k] = ld2s(Vo + (int64_t)j * ld + k * KK_SUB);
+#pragma unroll
+        for (int k = 0; k < RG; ++k) {
+            wv[k].x = fma(s, x[k].x, wv[k].x);
+            wv[k].y = fma(s, x[k].y, wv[k].y);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < RG; ++k) {
+        st2s(w_out + off + k * KK_SUB, wv[k]);
+        if (NORM) {
+            nacc = fma(wv[k].x, wv[k].x, nacc);
+            nacc = fma(wv[k].y, wv[k].y, nacc);
+        }
+    }
+}
+
+template <int H, bool NORM, bool BZERO>
+__device__ __forceinline__ void unproj_tail(const double* __restrict__ V, int64_t ld, int m, const double* w_in, double* w_out,
+                                            const double* sc, double beta, int64_t& rg, int64_t r1, int tid, double& nacc) {
+    if constexpr (H >= 1) {
+        constexpr int CBT = (KK_RG_U * KK_CB_U / H) > 8 ? 8 : (KK_RG_U * KK_CB_U / H);
+        while (rg + (int64_t)H * KK_SUB <= r1) {
+            unproj_group<H, CBT, NORM, BZERO>(V, ld, m, w_in, w_out, sc, beta, rg + tid * 2, nacc);
+            rg += (int64_t)H * KK_SUB;
+            if (H > 1) break;
+        }
+        unproj_tail<H / 2, NORM, BZERO>(V, ld, m, w_in, w_out, sc, beta, rg, r1, tid, nacc);
+    }
+}
+
 template <bool NORM, bool BZERO>
 __global__ __launch_bounds__(KK_TPB) void k_unproject(const double* __restrict__ V, int64_t ld, int m,
                                                       const double* w_in, double* w_out,
@@ -341,61 +436,10 @@ __global__ __launch_bounds__(KK_TPB) void k_unproject(const double* __restrict__
     __syncthreads();
     const int64_t r0 = (int64_t)blockIdx.x * rpb, r1 = imin(r0 + rpb, ld);
     double nacc = 0;
-    for (int64_t rg = r0; rg < r1; rg += KK_SUB * KK_RG_U) {
-        const int nsub = (int)imin((int64_t)KK_RG_U, (r1 - rg) / KK_SUB);
-        const int64_t off = rg + tid * 2;
-        d2 wv[KK_RG_U];
-#pragma unroll
-        for (int k = 0; k < KK_RG_U; ++k) {
-            if (!BZERO && k < nsub) {
-                wv[k] = ld2(w_in + off + k * KK_SUB);
-                wv[k].x *= beta; wv[k].y *= beta;
-            } else {
-                wv[k] = d2{0.0, 0.0};
-            }
-        }
-        const double* Vo = V + off;
-        int j = 0;
-        if (nsub == KK_RG_U) {
-            for (; j + KK_CB_U <= m; j += KK_CB_U) {
-                d2 x[KK_CB_U][KK_RG_U];
-#pragma unroll
-                for (int c = 0; c < KK_CB_U; ++c)
-#pragma unroll
-                    for (int k = 0; k < KK_RG_U; ++k) x[c][k] = ld2s(Vo + (int64_t)(j + c) * ld + k * KK_SUB);
-#pragma unroll
-                for (int c = 0; c < KK_CB_U; ++c) {
-                    const double s = sc[j + c];
-#pragma unroll
-                    for (int k = 0; k < KK_RG_U; ++k) {
-                        wv[k].x = fma(s, x[c][k].x, wv[k].x);
-                        wv[k].y = fma(s, x[c][k].y, wv[k].y);
-                    }
-                }
-            }
-        }
-        for (; j < m; ++j) {
-            const double s = sc[j];
-#pragma unroll
-            for (int k = 0; k < KK_RG_U; ++k) {
-                if (k < nsub) {
-                    d2 x = ld2s(Vo + (int64_t)j * ld + k * KK_SUB);
-                    wv[k].x = fma(s, x.x, wv[k].x);
-                    wv[k].y = fma(s, x.y, wv[k].y);
-                }
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < KK_RG_U; ++k) {
-            if (k < nsub) {
-                st2(w_out + off + k * KK_SUB, wv[k]);
-                if (NORM) {
-                    nacc = fma(wv[k].x, wv[k].x, nacc);
-                    nacc = fma(wv[k].y, wv[k].y, nacc);
-                }
-            }
-        }
-    }
+    int64_t rg = r0;
+    for (; rg + (int64_t)KK_RG_U * KK_SUB <= r1; rg += (int64_t)KK_RG_U * KK_SUB)
+        unproj_group<KK_RG_U, KK_CB_U, NORM, BZERO>(V, ld, m, w_in, w_out, sc, beta, rg + tid * 2, nacc);
+    unproj_tail<KK_RG_U / 2, NORM, BZERO>(V, ld, m, w_in, w_out, sc, beta, rg, r1, tid, nacc);
     if (NORM) {
         double t = block_sum(nacc, sm);
         if (tid == 0) part[blockIdx.x] = t;
