@@ -161,6 +161,22 @@ int kk_cg_update(kk_basis bx, int cx, kk_basis bp, int cp, kk_basis br, int cr, 
  * (formed on the device); x += alpha p; r -= alpha q; returns <p,q> and |r|  (linsolve/cg.jl:60-66) */
 int kk_cg_iterate(kk_op op, kk_basis b, int cx, int cr, int cp, int cq, double a0, double a1, double beta, int first,
                   double rho, double* pq, double* rnorm);
+/* BiCGStab (linsolve/bicgstab.jl:118-199) in two calls per iteration.  rho, sigma, alpha, omega stay in device
+ * scalars between the calls; the host reads the two norms the reference compares with tol.
+ * kk_bicgstab_half, cols = {x, r, r_shadow, p, v, s, t, p_prev, v_prev} (9 columns of `b`):
+ *   [p = r + beta (p_prev - omega v_prev)] ; v = a0 p + a1 A p ; alpha = rho/<r_shadow, v> ; s = r - alpha v ;
+ *   returns |s| and alpha; t = a0 s + a1 A s (with <t,s>, <t,t>) is enqueued before the host waits for |s|.
+ *   mode 0: rho is the device value left by kk_bicgstab_full; mode 1 (first iteration): p == r already, rho =
+ *   <r_shadow, r> passed by the host; mode 2: rho passed by the host (r was replaced by the explicit residual);
+ *   mode 3: collect the half that the previous kk_bicgstab_full enqueued on `ahead_cols` (only waits).
+ * kk_bicgstab_full, cols = first 7 of the above: omega = <t,s>/<t,t> ; x += alpha p + omega s ; r = s - omega t ;
+ *   returns |r|, rho = <r_shadow, r>, omega.  redo_t != 0: the host replaced s by the explicit residual (:143-146).
+ *   ahead_cols != NULL: the next BiCG half is enqueued on those 9 columns (p, v double-buffered against
+ *   p_prev, v_prev) before the host waits, so the GPU works through the round trip. */
+int kk_bicgstab_half(kk_op op, kk_basis b, const int* cols, double a0, double a1, int mode, double rho,
+                     double* snorm, double* alpha);
+int kk_bicgstab_full(kk_op op, kk_basis b, const int* cols, double a0, double a1, int redo_t, const int* ahead_cols,
+                     double* rnorm, double* rho, double* omega);
 /* gather x[idx[i]] -> out[i] on device (packing halo/ghost send buffers) */
 int kk_gather(kk_basis bx, int cx, const int64_t* device_idx, int64_t count, void* device_out);
 

@@ -76,6 +76,7 @@ extern "C" int kk_ctx_create(int device, kk_ctx* out) {
     KK_HIP(hipEventCreate(&c->t0));
     KK_HIP(hipEventCreate(&c->t1));
     KK_HIP(hipEventCreateWithFlags(&c->ev_fetch, hipEventDisableTiming));
+    KK_HIP(hipEventCreateWithFlags(&c->ev_fetch2, hipEventDisableTiming));
     const char* env = getenv("KK_BLOCKS_PER_CU");
     if (env && atoi(env) > 0) c->blocks_per_cu = atoi(env);
     env = getenv("KK_MGS_MODE");
@@ -93,6 +94,7 @@ extern "C" int kk_ctx_destroy(kk_ctx c) {
     (void)hipEventDestroy(c->t0);
     (void)hipEventDestroy(c->t1);
     (void)hipEventDestroy(c->ev_fetch);
+    (void)hipEventDestroy(c->ev_fetch2);
     (void)hipFree(c->ws_own);
     (void)hipFree(c->partials);
     (void)hipHostFree(c->h_pin);
@@ -737,6 +739,99 @@ extern "C" int kk_cg_update(kk_basis bx, int cx, kk_basis bp, int cp, kk_basis b
     KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2, 2, 0));
     KK_TRY(stream_sync(c));
     *rnorm = pin(c, WS_SCAL + SC_NRM2)[1];
+    return KK_OK;
+}
+
+// ---- BiCGStab (linsolve/bicgstab.jl:118-199), one call per half step.  cols = {x, r, r_shadow, p, v, s, t}.
+// The recurrence scalars rho, sigma, alpha, omega never leave the device; the host reads only the two norms the
+// reference tests against tol (and alpha / rho for the rare explicit-residual branches).
+static int fetch_mark(kk_ctx c);
+static int fetch_wait(kk_ctx c);
+static int bicg_apply_t(kk_op op, kk_basis b, const int* cols, double a0, double a1) {
+    kk_ctx c = b->ctx;
+    kk_spmv_fuse f;                       // t = (a0 + a1 A) s with <t,s> and <t,t>     (:157-160)
+    f.a0 = a0; f.a1 = a1;
+    f.dot_mode = 2; f.dot_out = SCP(c, SC_BICG + 5);
+    f.nrm_out = SCP(c, SC_BICG + 6);
+    return kk_launch_spmv(c, op->A, b->col(cols[5]), b->col(cols[6]), b->ld, f);
+}
+// BiCG half: [p = r + beta (p_prev - omega v_prev)] ; v = (a0 + a1 A) p ; sigma = <r_shadow, v> ; alpha = rho/sigma ;
+// s = r - alpha v, then (touching nothing else) the stabiliser's t = (a0 + a1 A) s.  Everything is enqueued; the
+// read-back of the scalars goes to pinned slot `slot` and is marked by event `ev`.
+// cols = {x, r, r_shadow, p, v, s, t, p_prev, v_prev}; p_prev/v_prev may equal p/v (in place) or be the other half of
+// a double buffer, so that a run-ahead half can be discarded without having destroyed p and v.
+static int bicg_half_enqueue(kk_op op, kk_basis b, const int* cols, double a0, double a1, int mode, double rho, int slot,
+                             hipEvent_t ev) {
+    kk_ctx c = b->ctx;
+    gram_touch(b, *std::min_element(cols, cols + 7));
+    double* sc = SCP(c, SC_BICG);
+    double *r = b->col(cols[1]), *rs = b->col(cols[2]), *pp = b->col(cols[3]), *v = b->col(cols[4]), *sv = b->col(cols[5]);
+    if (mode != 0) KK_TRY(kk_launch_set_scalar(c, sc, rho));
+    if (mode != 1) KK_TRY(kk_launch_bicg_p(c, pp, b->col(cols[7]), r, b->col(cols[8]), b->ld, sc));
+    kk_spmv_fuse f;
+    f.a0 = a0; f.a1 = a1;
+    f.dot_mode = 3; f.dot_vec = rs; f.dot_out = SCP(c, SC_BICG + 2);
+    KK_TRY(kk_launch_spmv(c, op->A, pp, v, b->ld, f));
+    KK_TRY(kk_launch_bicg_s(c, sv, r, v, b->ld, sc, SCP(c, SC_BICG_SN)));
+    KK_TRY(ws_fetch_async(c, WS_SCAL + SC_BICG, 16, slot));
+    KK_HIP(hipEventRecord(ev, c->stream));
+    return bicg_apply_t(op, b, cols, a0, a1);
+}
+static int bicg_check_cols(kk_basis b, const int* cols, int n) {
+    KK_CHECK(cols, KK_ERR_INVALID, "null cols");
+    for (int i = 0; i < n; ++i) CHECK_COL(b, cols[i]);
+    return KK_OK;
+}
+// mode 0: rho is the device value left by kk_bicgstab_full; 1 (first iteration, :34-52): p already equals r, rho comes
+// from the host; 2: rho comes from the host (r was replaced by the explicit residual, :175-179); 3: collect the half
+// that the previous kk_bicgstab_full already enqueued (ahead_cols) -- nothing is launched, the host only waits.
+extern "C" int kk_bicgstab_half(kk_op op, kk_basis b, const int* cols, double a0, double a1, int mode, double rho,
+                                double* snorm, double* alpha) {
+    KK_TRY(check_square_op(op, b));
+    KK_CHECK(snorm && alpha, KK_ERR_INVALID, "null arg");
+    KK_CHECK(mode >= 0 && mode <= 3, KK_ERR_INVALID, "kk_bicgstab_half: mode must be 0..3");
+    KK_TRY(bicg_check_cols(b, cols, 9));
+    kk_ctx c = b->ctx;
+    int slot = 0;
+    if (mode == 3) {
+        KK_CHECK(c->bicg_ahead, KK_ERR_INVALID, "kk_bicgstab_half: mode 3 without a run-ahead half");
+        slot = 1;
+        KK_HIP(hipEventSynchronize(c->ev_fetch2));
+    } else {
+        KK_TRY(bicg_half_enqueue(op, b, cols, a0, a1, mode, rho, 0, c->ev_fetch));
+        KK_HIP(hipEventSynchronize(c->ev_fetch));
+    }
+    c->bicg_ahead = false;
+    *snorm = pin(c, WS_SCAL + SC_BICG_SN, slot)[1];
+    *alpha = pin(c, WS_SCAL + SC_BICG, slot)[3];
+    return KK_OK;
+}
+// stabiliser half: omega = <t,s>/<t,t> ; x += alpha p + omega s ; r = s - omega t ; returns |r|, rho = <r_shadow, r>
+// and omega.  redo_t: s was replaced by the host (explicit residual, :143-146) -> recompute t first.
+// ahead_cols (9 columns, or NULL): enqueue the NEXT BiCG half on those columns before waiting, so that the GPU keeps
+// working through the host round trip; the next kk_bicgstab_half(mode 3) collects it, any other mode discards it.
+extern "C" int kk_bicgstab_full(kk_op op, kk_basis b, const int* cols, double a0, double a1, int redo_t,
+                                const int* ahead_cols, double* rnorm, double* rho, double* omega) {
+    KK_TRY(check_square_op(op, b));
+    KK_CHECK(rnorm && rho && omega, KK_ERR_INVALID, "null arg");
+    KK_TRY(bicg_check_cols(b, cols, 7));
+    if (ahead_cols) KK_TRY(bicg_check_cols(b, ahead_cols, 9));
+    kk_ctx c = b->ctx;
+    gram_touch(b, *std::min_element(cols, cols + 7));
+    double* sc = SCP(c, SC_BICG);
+    if (redo_t) KK_TRY(bicg_apply_t(op, b, cols, a0, a1));
+    KK_TRY(kk_launch_bicg_xr(c, b->col(cols[0]), b->col(cols[3]), b->col(cols[5]), b->col(cols[6]), b->col(cols[1]),
+                             b->col(cols[2]), b->ld, sc, SCP(c, SC_BICG_RN), sc));
+    KK_TRY(ws_fetch_async(c, WS_SCAL + SC_BICG, 16, 0));
+    KK_TRY(fetch_mark(c));
+    if (ahead_cols) {
+        KK_TRY(bicg_half_enqueue(op, b, ahead_cols, a0, a1, 0, 0.0, 1, c->ev_fetch2));
+        c->bicg_ahead = true;
+    }
+    KK_TRY(fetch_wait(c));
+    *rnorm = pin(c, WS_SCAL + SC_BICG_RN)[1];
+    *rho = pin(c, WS_SCAL + SC_BICG)[0];
+    *omega = pin(c, WS_SCAL + SC_BICG)[4];
     return KK_OK;
 }
 

@@ -49,7 +49,9 @@
 // a finalize with_sqrt writes three consecutive slots: sum, sqrt(sum), 1/sqrt(sum)
 enum { SC_ALPHA0 = 0, SC_NRM2 = 1, SC_NRM = 2, SC_INVNRM = 3, SC_DOT = 4, SC_TMP0 = 5, SC_TMP1 = 6, SC_TMP2 = 7,
        SC_NRM2B = 8, SC_NRMB = 9, SC_INVNRMB = 10, SC_DOTB = 11,
-       SC_SPECA = 12 /* alpha of a speculative next-step SpMV: written by nothing else */ };
+       SC_SPECA = 12 /* alpha of a speculative next-step SpMV: written by nothing else */,
+       SC_BICG = 16 /* rho, rho_old, sigma, alpha, omega, <t,s>, <t,t> (+2 for the sqrt triple) */,
+       SC_BICG_SN = 25 /* |s|^2, |s|, 1/|s| */, SC_BICG_RN = 28 /* |r|^2, |r|, 1/|r| */ };
 
 void kk_set_error(const char* fmt, ...);
 int kk_hip_fail(hipError_t e, const char* what, const char* file, int line);
@@ -99,6 +101,8 @@ struct kk_ctx_s {
     kk_basis spec_owner = nullptr;   // basis whose speculative result currently sits in SC_SPECA / its next column
     struct { bool active = false; kk_op op = nullptr; kk_basis b = nullptr; int c0 = 0, k_next = 0; } spec_req;
     hipEvent_t t0 = nullptr, t1 = nullptr;
+    hipEvent_t ev_fetch2 = nullptr; // read-backs of a run-ahead BiCGStab half
+    bool bicg_ahead = false;        // a BiCG half was enqueued by kk_bicgstab_full and not collected yet
     hipEvent_t ev_fetch = nullptr;  // marks the end of the scalar read-backs of an expand (host waits on this, not on the stream)
     int prof = 0;                // 0 off, 1 every kernel class, 2 only the basis-streaming classes (project/unproject)
     std::map<std::string, kk_prof_entry> prof_tab;
@@ -204,7 +208,9 @@ struct kk_spmv_fuse {
     double bprev = 0.0;
     const double* bprev_dev = nullptr;   // if set: weight = *bprev_dev (device scalar)
     int dot_mode = 0;                // 0 none, 1 = <x, A x> before subtracting vprev (CGS order,
-                                     // lanczos.jl:298), 2 = <x, y> after (MGS order, lanczos.jl:308)
+                                     // lanczos.jl:298), 2 = <x, y> after (MGS order, lanczos.jl:308),
+                                     // 3 = <dot_vec, y> (BiCGStab <r_shadow, A p>)
+    const double* dot_vec = nullptr; // third vector of dot_mode 3
     double* dot_out = nullptr;       // device scalar receiving the dot (required when dot_mode != 0)
     double* nrm_out = nullptr;       // optional: device triple receiving |y|^2, sqrt, 1/sqrt
 };
@@ -258,5 +264,11 @@ int kk_launch_cg_update(kk_ctx ctx, double* x, const double* p, double* r, const
                         const double* pq_dev, double* nrm_out3);
 // (I + L) s = p on the device (one block, exact forward substitution); optional ride-along Gram row
 // and the Lanczos alpha0 folded into the last coefficient.  See kk_kernels.hip.
+int kk_launch_bicg_p(kk_ctx ctx, double* p_out, const double* p, const double* r, const double* v, int64_t ld,
+                     const double* sc);
+int kk_launch_set_scalar(kk_ctx ctx, double* dst, double v);
+int kk_launch_bicg_s(kk_ctx ctx, double* s, const double* r, const double* v, int64_t ld, double* sc, double* nrm_out3);
+int kk_launch_bicg_xr(kk_ctx ctx, double* x, const double* p, const double* s, const double* t, double* r,
+                      const double* rs, int64_t ld, double* sc, double* nrm_out3, double* rho_out);
 int kk_launch_lowsync_solve(kk_ctx ctx, const double* p, const double* g_ride, double* L, int cap, int m, int newest,
                             const double* a0_dev, double* coef_out, double* s_out);

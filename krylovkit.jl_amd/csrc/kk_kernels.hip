@@ -187,6 +187,75 @@ __global__ __launch_bounds__(KK_TPB) void k_cg_update(double* __restrict__ x, co
     if (threadIdx.x == 0) part[blockIdx.x] = t;
 }
 
+// ---- BiCGStab (linsolve/bicgstab.jl:118-199) as three fused vector kernels; every scalar of the recurrence
+// stays in the context's device scalars sc[] = {rho, rho_old, sigma, alpha, omega, <t,s>, <t,t>}
+enum { BI_RHO = 0, BI_RHO_OLD = 1, BI_SIGMA = 2, BI_ALPHA = 3, BI_OMEGA = 4, BI_TS = 5, BI_TT = 6 /* triple 6..8 */,
+       BI_ALPHA_OLD = 15 /* alpha of the last completed full step: a run-ahead half overwrites BI_ALPHA */ };
+__global__ void k_set_scalar(double* dst, double v) { *dst = v; }
+// p_out = r + beta (p - omega v),  beta = (rho/rho_old)(alpha/omega)          (:121-125)
+__global__ __launch_bounds__(KK_TPB) void k_bicg_p(double* __restrict__ p_out, const double* __restrict__ p,
+                                                   const double* __restrict__ r, const double* __restrict__ v, int64_t ld,
+                                                   int64_t rpb, const double* __restrict__ sc) {
+    const double omega = sc[BI_OMEGA];
+    const double beta = (sc[BI_RHO] / sc[BI_RHO_OLD]) * (sc[BI_ALPHA_OLD] / omega);
+    const int64_t r0 = (int64_t)blockIdx.x * rpb, r1 = imin(r0 + rpb, ld);
+    for (int64_t i = r0 + threadIdx.x * 2; i < r1; i += KK_SUB) {
+        d2 pv = ld2(p + i), rv = ld2(r + i), vv = ld2(v + i);
+        pv.x = fma(-omega, vv.x, pv.x); pv.y = fma(-omega, vv.y, pv.y);
+        pv.x = fma(beta, pv.x, rv.x); pv.y = fma(beta, pv.y, rv.y);
+        st2(p_out + i, pv);
+    }
+}
+// alpha = rho/sigma ; s = r - alpha v ; partial |s|^2                          (:130-139)
+__global__ __launch_bounds__(KK_TPB) void k_bicg_s(double* __restrict__ s, const double* __restrict__ r,
+                                                   const double* __restrict__ v, int64_t ld, int64_t rpb,
+                                                   double* __restrict__ sc, double* __restrict__ part) {
+    __shared__ double sm[4];
+    const double alpha = sc[BI_RHO] / sc[BI_SIGMA];
+    if (blockIdx.x == 0 && threadIdx.x == 0) sc[BI_ALPHA] = alpha;
+    const int64_t r0 = (int64_t)blockIdx.x * rpb, r1 = imin(r0 + rpb, ld);
+    double acc = 0;
+    for (int64_t i = r0 + threadIdx.x * 2; i < r1; i += KK_SUB) {
+        d2 rv = ld2(r + i), vv = ld2(v + i);
+        rv.x = fma(-alpha, vv.x, rv.x); rv.y = fma(-alpha, vv.y, rv.y);
+        st2(s + i, rv);
+        acc = fma(rv.x, rv.x, acc); acc = fma(rv.y, rv.y, acc);
+    }
+    double t = block_sum(acc, sm);
+    if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+// omega = <t,s>/<t,t> ; x += alpha p + omega s ; r = s - omega t ; partials |r|^2 and <r_shadow, r>   (:160-169,120)
+__global__ __launch_bounds__(KK_TPB) void k_bicg_xr(double* __restrict__ x, const double* __restrict__ p,
+                                                    const double* __restrict__ s, const double* __restrict__ t,
+                                                    double* __restrict__ r, const double* __restrict__ rs, int64_t ld,
+                                                    int64_t rpb, double* __restrict__ sc, double* __restrict__ part_n,
+                                                    double* __restrict__ part_d) {
+    __shared__ double sm[4];
+    const double alpha = sc[BI_ALPHA];
+    const double omega = sc[BI_TS] / sc[BI_TT];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        sc[BI_OMEGA] = omega;
+        sc[BI_ALPHA_OLD] = alpha;
+        sc[BI_RHO_OLD] = sc[BI_RHO];   // the finalize of <r_shadow, r> (next kernel in the stream) overwrites BI_RHO
+    }
+    const int64_t r0 = (int64_t)blockIdx.x * rpb, r1 = imin(r0 + rpb, ld);
+    double nacc = 0, dacc = 0;
+    for (int64_t i = r0 + threadIdx.x * 2; i < r1; i += KK_SUB) {
+        d2 xv = ld2(x + i), pv = ld2(p + i), sv = ld2(s + i), tv = ld2(t + i), zv = ld2(rs + i);
+        xv.x = fma(alpha, pv.x, xv.x); xv.y = fma(alpha, pv.y, xv.y);
+        xv.x = fma(omega, sv.x, xv.x); xv.y = fma(omega, sv.y, xv.y);
+        sv.x = fma(-omega, tv.x, sv.x); sv.y = fma(-omega, tv.y, sv.y);
+        st2(x + i, xv); st2(r + i, sv);
+        nacc = fma(sv.x, sv.x, nacc); nacc = fma(sv.y, sv.y, nacc);
+        dacc = fma(zv.x, sv.x, dacc); dacc = fma(zv.y, sv.y, dacc);
+    }
+    double a = block_sum(nacc, sm);
+    if (threadIdx.x == 0) part_n[blockIdx.x] = a;
+    __syncthreads();
+    double b = block_sum(dacc, sm);
+    if (threadIdx.x == 0) part_d[blockIdx.x] = b;
+}
+
 // counter-based uniform [0,1): splitmix64 of (seed, row) -> 53-bit mantissa. Independent of grid.
 __global__ __launch_bounds__(KK_TPB) void k_fill_random(double* __restrict__ x, int64_t n, uint64_t seed) {
     for (int64_t i = (int64_t)blockIdx.x * KK_TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * KK_TPB) {
@@ -619,6 +688,7 @@ struct spmv_epi {
     int want_nrm;
     int64_t n_local;  // < 0: no ghost
     const double* ghost;
+    const double* dvec;  // dot_mode 3: <dvec, y>
 };
 
 __device__ __forceinline__ double xload(const double* __restrict__ x, const spmv_epi& e, int c) {
@@ -658,7 +728,7 @@ __global__ __launch_bounds__(KK_TPB) void k_spmv_ell(const int32_t* __restrict__
             s0 *= xs; s1 *= xs;
             d2 out{e.a1 * s0, e.a1 * s1};
             d2 xv{0.0, 0.0};
-            if (e.a0 != 0.0 || e.dot_mode) {
+            if (e.a0 != 0.0 || e.dot_mode == 1 || e.dot_mode == 2) {
                 xv = ld2(x + row);
                 xv.x *= xs; xv.y *= xs;
             }
@@ -670,6 +740,7 @@ __global__ __launch_bounds__(KK_TPB) void k_spmv_ell(const int32_t* __restrict__
             }
             if (row + 1 >= nrows) out.y = 0.0;  // odd nrows: keep the pad row zero
             if (e.dot_mode == 2) { dacc = fma(xv.x, out.x, dacc); dacc = fma(xv.y, out.y, dacc); }
+            if (e.dot_mode == 3) { const d2 z = ld2(e.dvec + row); dacc = fma(z.x, out.x, dacc); dacc = fma(z.y, out.y, dacc); }
             if (e.want_nrm) { nacc = fma(out.x, out.x, nacc); nacc = fma(out.y, out.y, nacc); }
             st2(y + row, out);
         }
@@ -704,7 +775,7 @@ __global__ __launch_bounds__(KK_TPB) void k_spmv_csr(const int32_t* __restrict__
             s *= xs;
             double out = e.a1 * s;
             double xv = 0;
-            if (e.a0 != 0.0 || e.dot_mode) xv = x[row] * xs;
+            if (e.a0 != 0.0 || e.dot_mode == 1 || e.dot_mode == 2) xv = x[row] * xs;
             if (e.a0 != 0.0) out = fma(e.a0, xv, out);
             if (e.dot_mode == 1) dacc = fma(xv, out, dacc);
             if (e.vprev) {
@@ -712,6 +783,7 @@ __global__ __launch_bounds__(KK_TPB) void k_spmv_csr(const int32_t* __restrict__
                 out = fma(-bp, e.vprev[row], out);
             }
             if (e.dot_mode == 2) dacc = fma(xv, out, dacc);
+            if (e.dot_mode == 3) dacc = fma(e.dvec[row], out, dacc);
             if (e.want_nrm) nacc = fma(out, out, nacc);
             y[row] = out;
         }
@@ -760,11 +832,12 @@ __global__ __launch_bounds__(KK_TPB) void k_spmv_sell(const int64_t* __restrict_
             const double s = (s0 + s1) * xs;
             double out = e.a1 * s;
             double xv = 0;
-            if (e.a0 != 0.0 || e.dot_mode) xv = x[row] * xs;
+            if (e.a0 != 0.0 || e.dot_mode == 1 || e.dot_mode == 2) xv = x[row] * xs;
             if (e.a0 != 0.0) out = fma(e.a0, xv, out);
             if (e.dot_mode == 1) dacc = fma(xv, out, dacc);
             if (e.vprev) out = fma(-bp, e.vprev[row], out);
             if (e.dot_mode == 2) dacc = fma(xv, out, dacc);
+            if (e.dot_mode == 3) dacc = fma(e.dvec[row], out, dacc);
             if (e.want_nrm) nacc = fma(out, out, nacc);
             y[row] = out;
         }
@@ -1279,6 +1352,7 @@ int kk_launch_spmv(kk_ctx ctx, const kk_sparse_dev& M, const double* x, double* 
     e.dot_mode = f.dot_mode; e.want_nrm = f.nrm_out ? 1 : 0;
     e.n_local = M.n_ghost > 0 ? M.n_local : -1;
     e.ghost = M.ghost;
+    e.dvec = f.dot_vec;
     double* pd = part_row(ctx, PART_SCAL_A);
     double* pn = part_row(ctx, PART_SCAL_B);
     int nblk = 0;
@@ -1528,6 +1602,42 @@ int kk_launch_cg_update(kk_ctx ctx, double* x, const double* p, double* r, const
     }
     KK_HIP(hipGetLastError());
     return finalize_scalar(ctx, PART_SCAL_A, pt.nblk, nrm_out3, true);
+}
+
+int kk_launch_bicg_p(kk_ctx ctx, double* p_out, const double* p, const double* r, const double* v, int64_t ld,
+                     const double* sc) {
+    kk_part pt = kk_partition(ctx, ld);
+    kk_prof_scope ps(ctx, "k_bicg_p");
+    hipLaunchKernelGGL(k_bicg_p, dim3(pt.nblk), dim3(KK_TPB), 0, ctx->stream, p_out, p, r, v, ld, pt.rpb, sc);
+    KK_HIP(hipGetLastError());
+    return KK_OK;
+}
+int kk_launch_set_scalar(kk_ctx ctx, double* dst, double v) {
+    hipLaunchKernelGGL(k_set_scalar, dim3(1), dim3(1), 0, ctx->stream, dst, v);
+    KK_HIP(hipGetLastError());
+    return KK_OK;
+}
+int kk_launch_bicg_s(kk_ctx ctx, double* s, const double* r, const double* v, int64_t ld, double* sc, double* nrm_out3) {
+    kk_part pt = kk_partition(ctx, ld);
+    {
+        kk_prof_scope ps(ctx, "k_bicg_s");
+        hipLaunchKernelGGL(k_bicg_s, dim3(pt.nblk), dim3(KK_TPB), 0, ctx->stream, s, r, v, ld, pt.rpb, sc,
+                           part_row(ctx, PART_SCAL_A));
+    }
+    KK_HIP(hipGetLastError());
+    return finalize_scalar(ctx, PART_SCAL_A, pt.nblk, nrm_out3, true);
+}
+int kk_launch_bicg_xr(kk_ctx ctx, double* x, const double* p, const double* s, const double* t, double* r,
+                      const double* rs, int64_t ld, double* sc, double* nrm_out3, double* rho_out) {
+    kk_part pt = kk_partition(ctx, ld);
+    {
+        kk_prof_scope ps(ctx, "k_bicg_xr");
+        hipLaunchKernelGGL(k_bicg_xr, dim3(pt.nblk), dim3(KK_TPB), 0, ctx->stream, x, p, s, t, r, rs, ld, pt.rpb, sc,
+                           part_row(ctx, PART_SCAL_A), part_row(ctx, PART_SCAL_B));
+    }
+    KK_HIP(hipGetLastError());
+    KK_TRY(finalize_scalar(ctx, PART_SCAL_A, pt.nblk, nrm_out3, true));
+    return finalize_scalar(ctx, PART_SCAL_B, pt.nblk, rho_out, false);
 }
 
 int kk_launch_lowsync_solve(kk_ctx ctx, const double* p, const double* g_ride, double* L, int cap, int m, int newest,

@@ -498,3 +498,100 @@ def linsolve_cg(A, b, x0=None, alg: Optional[CG] = None, a0: float = 0.0, a1: fl
             return vx.get(), ConvergenceInfo(1, vr.get(), normr, numiter, numops)
         if numiter >= maxiter:
             return vx.get(), ConvergenceInfo(0, vr.get(), normr, numiter, numops)
+
+
+# -------------------------------------------------------------------- linsolve (BiCGStab)
+@dataclass
+class BiCGStab:  # algorithms.jl:469-481
+    maxiter: int = KrylovDefaults.maxiter
+    tol: float = KrylovDefaults.tol
+    verbosity: int = 0
+
+
+def linsolve_bicgstab(A, b, x0=None, alg: Optional[BiCGStab] = None, a0: float = 0.0, a1: float = 1.0, **kw):
+    """linsolve(operator, b, x0, alg::BiCGStab, a0, a1) (src/linsolve/bicgstab.jl:1-203) for a general a0 + a1*A.
+    Per iteration: two SpMVs (each with its inner products fused) and three fused vector kernels
+    (kk_bicgstab_half / kk_bicgstab_full); rho, sigma, alpha, omega stay on the device, the host reads the two
+    norms the reference compares with tol."""
+    import ctypes as C
+    from ._lib import check
+    op = _as_operator(A)
+    n = op.shape[0]
+    alg = alg or BiCGStab(**kw)
+    maxiter, tol = alg.maxiter, alg.tol
+    # 0 = b, 1 = x, 2 = r, 3 = r_shadow, 4/9 = p (double buffer), 5/10 = v (double buffer), 6 = s, 7 = t, 8 = xhalf
+    W = DeviceBasis(n, 11, op.ctx)
+    vb, vx, vr, vrs, _, _, vs, vt, vh, _, _ = (HipVec(W, i) for i in range(11))
+    lib = W._lib
+    cur, alt = (4, 5), (9, 10)
+
+    def colarr(pv, prev):
+        return (C.c_int * 9)(1, 2, 3, pv[0], pv[1], 6, 7, prev[0], prev[1])
+
+    vb.set(np.asarray(b, dtype=np.float64))
+    if x0 is None:
+        vx.zero_()
+    else:
+        vx.set(np.asarray(x0, dtype=np.float64))
+    op.apply(vx, vt)                      # y0 = apply(operator, x0)   :3
+    vr.scale_from_(vb, 1.0)
+    if a0 != 0:
+        vr.add_(vx, -a0)
+    vr.add_(vt, -a1)
+    normr = vr.norm()
+    numops, numiter = 1, 0
+    if normr < tol:                       # :22-28
+        return vx.get(), ConvergenceInfo(1, vr.get(), normr, numiter, numops)
+    numiter += 1
+    vrs.scale_from_(vr, 1.0)              # shadow residual   :35
+    rho = vrs.inner(vr)
+    if np.isclose(rho, 0.0):              # :39-46
+        return vx.get(), ConvergenceInfo(0, vr.get(), normr, numiter, numops)
+    HipVec(W, cur[0]).scale_from_(vr, 1.0)   # p = r
+    first = True
+    mode = 1       # 1: first iteration; 0: rho on the device; 2: rho handed over again; 3: half already enqueued
+    cols = colarr(cur, cur)
+    snorm, alpha, rnorm, rho_c, omega = (C.c_double() for _ in range(5))
+    while True:
+        if not first:
+            numiter += 1
+        # BiCG half: p update, v = A p, alpha, s = r - alpha v (and, run ahead of the host, t = A s)
+        check(lib.kk_bicgstab_half(op.handle, W.handle, cols, a0, a1, mode, rho, C.byref(snorm), C.byref(alpha)))
+        numops += 1
+        normr = snorm.value
+        redo_t = 0
+        if normr < tol:                   # explicit residual at the half step   :65-80 / :142-157
+            vh.scale_from_(vx, 1.0)
+            vh.add_(HipVec(W, cols[3]), alpha.value)      # xhalf = x + alpha p
+            op.apply_affine(vh, vt, a0, a1)
+            vs.scale_from_(vb, 1.0)
+            vs.add_(vt, -1.0)
+            numops += 1
+            normr_act = vs.norm()
+            if normr_act < tol:
+                return vh.get(), ConvergenceInfo(1, vs.get(), normr_act, numiter, numops)
+            redo_t = 1                    # s was replaced: t = A s has to be recomputed
+        numops += 1                       # t = apply(operator, s, a0, a1)   :83 / :163
+        last = (not first) and numiter >= maxiter
+        nxt = None if last else colarr(alt, cur)     # next half into the other p/v buffers, reading the current ones
+        check(lib.kk_bicgstab_full(op.handle, W.handle, cols, a0, a1, redo_t, nxt, C.byref(rnorm), C.byref(rho_c),
+                                   C.byref(omega)))
+        normr = rnorm.value
+        rho = rho_c.value
+        mode = 3
+        if normr < tol:                   # explicit residual at the full step   :94-110 / :175-190
+            op.apply_affine(vx, vt, a0, a1)
+            vr.scale_from_(vb, 1.0)
+            vr.add_(vt, -1.0)
+            numops += 1
+            normr_act = vr.norm()
+            if normr_act < tol:
+                return vx.get(), ConvergenceInfo(1, vr.get(), normr_act, numiter, numops)
+            rho = vrs.inner(vr)           # r was replaced: the next rho = <r_shadow, r> is that of the NEW r   :120
+            mode = 2                      # ... and the run-ahead half (old r, old rho) is discarded and redone
+        if last:                          # :191-198
+            return vx.get(), ConvergenceInfo(0, vr.get(), normr, numiter, numops)
+        first = False
+        cols = nxt
+        cur, alt = alt, cur
+

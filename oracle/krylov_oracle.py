@@ -1426,3 +1426,70 @@ def sparse_random(nrows: int, ncols: int, nnz_per_row: int, seed: int) -> sp.csr
     rows = np.repeat(np.arange(nrows), nnz_per_row)
     A = sp.coo_matrix((vals.ravel(), (rows, cols.ravel())), shape=(nrows, ncols))
     return sp.csr_matrix(A)
+
+
+def bicgstab(operator, b: np.ndarray, x0: Optional[np.ndarray] = None, a0: float = 0.0, a1: float = 1.0, *,
+             maxiter: int = 100, tol: float = 1e-12):
+    """linsolve(operator, b, x0, alg::BiCGStab, a0, a1) (linsolve/bicgstab.jl:1-203)."""
+    b = np.asarray(b, dtype=np.float64)
+    x0 = np.zeros_like(b) if x0 is None else np.asarray(x0, dtype=np.float64)
+
+    def aff(z):  # apply(operator, z, a0, a1)  (apply.jl:4-11)
+        return a0 * z + a1 * apply(operator, z)
+
+    y0 = apply(operator, x0)                                   # :3
+    r = scale(b, 1.0)
+    if a0 != 0:
+        r = add(r, x0, -a0)
+    r = add(r, y0, -a1)
+    x = x0.copy()
+    normr = norm(r)
+    numops, numiter = 1, 0
+    if normr < tol:                                            # :22-28
+        return x, ConvergenceInfo(1, r, normr, numiter, numops)
+    numiter += 1
+    r_shadow = r.copy()                                        # :35
+    rho = inner(r_shadow, r)
+    if np.isclose(rho, 0.0):                                   # :39-46
+        return x, ConvergenceInfo(0, r, normr, numiter, numops)
+    p = r.copy()
+    v = None
+    omega = alpha = 1.0
+    first = True
+    while True:
+        if not first:                                          # :118-125
+            numiter += 1
+            rho_old = rho
+            rho = inner(r_shadow, r)
+            beta = (rho / rho_old) * (alpha / omega)
+            p = add(p, v, -omega)
+            p = add(p, r, 1.0, beta)
+        v = aff(p)                                             # :50 / :127
+        numops += 1
+        sigma = inner(r_shadow, v)
+        alpha = rho / sigma
+        s = add(r.copy(), v, -alpha)                           # half step residual
+        xhalf = add(x.copy(), p, alpha)
+        normr = norm(s)
+        if normr < tol:                                        # :65-80 / :142-157
+            s = add(b.copy(), aff(xhalf), -1.0)
+            numops += 1
+            normr_act = norm(s)
+            if normr_act < tol:
+                return xhalf, ConvergenceInfo(1, s, normr_act, numiter, numops)
+        t = aff(s)                                             # :83 / :163
+        numops += 1
+        omega = inner(t, s) / inner(t, t)
+        x = add(xhalf, s, omega)
+        r = add(s.copy(), t, -omega)
+        normr = norm(r)
+        if normr < tol:                                        # :94-110 / :175-190
+            r = add(b.copy(), aff(x), -1.0)
+            numops += 1
+            normr_act = norm(r)
+            if normr_act < tol:
+                return x, ConvergenceInfo(1, r, normr_act, numiter, numops)
+        if not first and numiter >= maxiter:                   # :191-198 (only inside the while loop)
+            return x, ConvergenceInfo(0, r, normr, numiter, numops)
+        first = False
+

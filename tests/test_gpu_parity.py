@@ -705,6 +705,31 @@ def test_linsolve_cg(kk, ko, ctx):
     assert info.numops == 1 and info.converged == 1
 
 
+def test_linsolve_bicgstab(kk, ko, ctx):
+    """BiCGStab on device vectors (3 fused vector kernels + 2 SpMVs with fused inner products per iteration, scalars
+    on the device): same counts and iterates as the oracle (linsolve/bicgstab.jl), incl. early stop at maxiter."""
+    A = ko.convection_diffusion_2d(40, 30)
+    n = A.shape[0]
+    b = np.random.default_rng(4).random(n)
+    for a0, a1 in ((0.0, 1.0), (0.3, 0.9)):
+        tol = 1e-10 * np.linalg.norm(b)
+        x, info = kk.linsolve_bicgstab(kk.SparseOperator(A, ctx), b, None, kk.BiCGStab(500, tol), a0, a1)
+        xo, oinfo = ko.bicgstab(A, b, None, a0, a1, maxiter=500, tol=tol)
+        assert info.converged == 1 and oinfo.converged == 1
+        assert abs(info.numiter - oinfo.numiter) <= 1 and abs(info.numops - oinfo.numops) <= 2
+        assert np.linalg.norm(a0 * x + a1 * (A @ x) - b) <= 1.01 * tol
+        np.testing.assert_allclose(x, xo, rtol=0, atol=1e-8 * np.linalg.norm(xo))
+    # fixed small iteration count: the recurrence itself is compared (no convergence-branch luck involved)
+    x, info = kk.linsolve_bicgstab(kk.SparseOperator(A, ctx), b, None, kk.BiCGStab(6, 1e-30))
+    xo, oinfo = ko.bicgstab(A, b, None, maxiter=6, tol=1e-30)
+    assert (info.converged, info.numiter, info.numops) == (0, oinfo.numiter, oinfo.numops) == (0, 6, 13)
+    np.testing.assert_allclose(x, xo, rtol=0, atol=1e-11 * np.linalg.norm(xo))
+    np.testing.assert_allclose(info.normres, oinfo.normres, rtol=1e-8)
+    xs = np.random.default_rng(1).random(n)
+    x, info = kk.linsolve_bicgstab(kk.SparseOperator(A, ctx), A @ xs, xs, kk.BiCGStab(tol=1e-8))
+    assert info.numops == 1 and info.converged == 1
+
+
 @pytest.mark.parametrize("mgs_mode", [0, 1])
 def test_mgs_on_non_orthonormal_basis(kk, ko, ctx, mgs_mode):
     """The low-sync form (I + L) s = V'w is exact algebra for ANY basis (MGS never divides by |q|^2):

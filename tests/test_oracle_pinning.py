@@ -339,3 +339,36 @@ def test_cg_vs_dense(ko):
     xs = rng.random(n)
     x, info = ko.cg(A, A @ xs, xs, tol=1e-9)
     assert info.numops == 1 and info.numiter == 0
+
+
+def test_bicgstab_reference_cases(ko):
+    """test/linsolve.jl:288-350 (BiCGStab small problem) and :352-395 (large problem), real Float64 case."""
+    rng = np.random.default_rng(31)
+    n = 10
+    A = rng.random((n, n)) - 0.5
+    A = np.eye(n) - 0.9 * A / np.max(np.abs(np.linalg.eigvals(A)))
+    b = rng.random(n)
+    tol = 1e-10 * np.linalg.norm(b)
+    x, info = ko.bicgstab(A, b, np.zeros(n), maxiter=4 * n, tol=tol)
+    assert info.converged > 0
+    np.testing.assert_allclose(A @ x, b, rtol=0, atol=10 * tol)
+    x2, info2 = ko.bicgstab(A, b, x, maxiter=4 * n, tol=tol)      # restart from the solution: one operator application
+    assert info2.numops == 1 and info2.converged == 1
+    a0, a1 = rng.random() + 1, rng.random()
+    x, info = ko.bicgstab(A, b, np.zeros(n), a0, a1, maxiter=4 * n, tol=tol)
+    assert info.converged > 0
+    np.testing.assert_allclose(a0 * x + a1 * (A @ x), b, rtol=0, atol=10 * tol)
+    # large problem: maxiter = 2 stops early with b = (a0 + a1 A) x + residual exactly   (:360-366)
+    N = 60
+    A = rng.random((N, N)) - 0.5
+    b = rng.random(N)
+    a0 = np.max(np.abs(np.linalg.eigvals(A)))
+    a1 = -0.9 * rng.random()
+    x, info = ko.bicgstab(A, b, np.zeros(N), a0, a1, maxiter=2, tol=1e-10 * np.linalg.norm(b))
+    np.testing.assert_allclose(a0 * x + a1 * (A @ x) + info.residual, b, rtol=0, atol=1e-12 * np.linalg.norm(b))
+    if info.converged == 0:
+        assert info.numiter == 2
+    x, info = ko.bicgstab(A, b, x, a0, a1, maxiter=10 * N, tol=1e-10 * np.linalg.norm(b))
+    assert info.converged > 0
+    np.testing.assert_allclose(a0 * x + a1 * (A @ x), b, rtol=0, atol=1e-9 * np.linalg.norm(b))
+

@@ -144,6 +144,26 @@ def bench_cg(ctx):
                       "frac_8TBps": round(alg / per_it / 8e12, 4), "normres": info.normres}), flush=True)
 
 
+def bench_bicgstab(ctx, nx=4000, ny=2500):
+    N = nx * ny
+    A = convdiff(nx, ny)                                   # config-3 operator (nonsymmetric)
+    op = kk.SparseOperator(A, ctx)
+    b = np.random.default_rng(4).random(N)
+    times = {}
+    for iters in (20, 120):
+        for rep in range(2):
+            ctx.sync(); t0 = time.perf_counter()
+            x, info = kk.linsolve_bicgstab(op, b, None, kk.BiCGStab(iters, 1e-300))
+            ctx.sync(); times[iters] = time.perf_counter() - t0
+    per_it = (times[120] - times[20]) / 100
+    alg = (2 * 84 + 8 + 32 + 24 + 56) * N     # 2 SpMV (+ r_shadow read in the first) ; p update ; s ; x/r update
+    print(json.dumps({"config": f"BiCGStab (SURVEY 8(f)-3) on the {N}-row convection-diffusion operator (config-3 stencil)",
+                      "seconds_20": round(times[20], 4), "seconds_120": round(times[120], 4),
+                      "ms_per_iteration": round(per_it * 1e3, 4), "it_per_s": round(1 / per_it, 1),
+                      "alg_GBps": round(alg / per_it / 1e9, 1), "frac_8TBps": round(alg / per_it / 8e12, 4),
+                      "normres": info.normres}), flush=True)
+
+
 if __name__ == "__main__":
     ctx = kk.default_context()
     what = [a for a in sys.argv[1:] if not a.startswith("--")] or ["gmres", "block", "gkl"]
@@ -153,5 +173,8 @@ if __name__ == "__main__":
         bench_block(ctx)
     if "cg" in what:
         bench_cg(ctx)
+    if "bicgstab" in what:
+        bench_bicgstab(ctx)
+        bench_bicgstab(ctx, 2000, 1000)
     if "gkl" in what:
         bench_gkl(ctx, "--full" in sys.argv)
