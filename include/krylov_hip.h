@@ -177,6 +177,12 @@ int kk_bicgstab_half(kk_op op, kk_basis b, const int* cols, double a0, double a1
                      double* snorm, double* alpha);
 int kk_bicgstab_full(kk_op op, kk_basis b, const int* cols, double a0, double a1, int redo_t, const int* ahead_cols,
                      double* rnorm, double* rho, double* omega);
+/* LSMR (lssolve/lsmr.jl:61-128) fused vector updates.
+ * kk_lsmr_step_u:  Ah = Av - c Ah ; u = Av - alpha u ; *beta = |u|        (:64-68; one pass, one host sync)
+ * kk_lsmr_update:  hbar = h - c1 hbar ; x += c2 hbar ; h = v - c3 h (cv < 0: skip the h update)   (:121-128)
+ *   called once for (h, hbar, x, v) and once, with cv = -1 and c2 negated, for (Ah, Ahbar, r). Stream-ordered. */
+int kk_lsmr_step_u(kk_basis b, int c_av, int c_ah, int c_u, double c, double alpha, double* beta);
+int kk_lsmr_update(kk_basis b, int ch, int chbar, int cx, kk_basis bv, int cv, double c1, double c2, double c3);
 /* gather x[idx[i]] -> out[i] on device (packing halo/ghost send buffers) */
 int kk_gather(kk_basis bx, int cx, const int64_t* device_idx, int64_t count, void* device_out);
 

@@ -835,6 +835,34 @@ extern "C" int kk_bicgstab_full(kk_op op, kk_basis b, const int* cols, double a0
     return KK_OK;
 }
 
+// ---- LSMR (lssolve/lsmr.jl:61-128) fused vector updates.
+// Ah = Av - c Ah ; u = Av - alpha u ; returns beta = |u|     (columns of one basis in the row space of A, :64-68)
+extern "C" int kk_lsmr_step_u(kk_basis b, int c_av, int c_ah, int c_u, double c, double alpha, double* beta) {
+    CHECK_COL(b, c_av); CHECK_COL(b, c_ah); CHECK_COL(b, c_u);
+    KK_CHECK(beta, KK_ERR_INVALID, "null output");
+    KK_CHECK(c_av != c_ah && c_av != c_u && c_ah != c_u, KK_ERR_INVALID, "kk_lsmr_step_u: columns must differ");
+    kk_ctx c_ = b->ctx;
+    gram_touch(b, std::min(c_ah, c_u));
+    KK_TRY(kk_launch_lsmr_u(c_, b->col(c_av), b->col(c_ah), b->col(c_u), b->ld, c, alpha, SCP(c_, SC_NRM2)));
+    KK_TRY(ws_fetch_async(c_, WS_SCAL + SC_NRM2, 2, 0));
+    KK_TRY(stream_sync(c_));
+    *beta = pin(c_, WS_SCAL + SC_NRM2)[1];
+    return KK_OK;
+}
+// hbar = h - c1 hbar ; x += c2 hbar ; h = v - c3 h (skipped when cv < 0).  Used for (h, hbar, x, v) in the domain of A
+// and, with cv < 0, for (Ah, Ahbar, r) with c2 negated in the row space (:121-128).  Stream-ordered, no host sync.
+extern "C" int kk_lsmr_update(kk_basis b, int ch, int chbar, int cx, kk_basis bv, int cv, double c1, double c2, double c3) {
+    CHECK_COL(b, ch); CHECK_COL(b, chbar); CHECK_COL(b, cx);
+    KK_CHECK(ch != chbar && ch != cx && chbar != cx, KK_ERR_INVALID, "kk_lsmr_update: columns must differ");
+    const double* v = nullptr;
+    if (cv >= 0) {
+        CHECK_COL(bv, cv); CHECK_SAME(b, bv);
+        v = bv->col(cv);
+    }
+    gram_touch(b, std::min(std::min(ch, chbar), cx));
+    return kk_launch_lsmr_hx(b->ctx, b->col(ch), b->col(chbar), b->col(cx), v, b->ld, c1, c2, c3);
+}
+
 extern "C" int kk_gather(kk_basis bx, int cx, const int64_t* device_idx, int64_t count, void* device_out) {
     CHECK_COL(bx, cx);
     return kk_launch_gather(bx->ctx, bx->col(cx), device_idx, count, (double*)device_out);

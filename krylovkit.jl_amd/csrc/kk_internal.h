@@ -270,5 +270,9 @@ int kk_launch_set_scalar(kk_ctx ctx, double* dst, double v);
 int kk_launch_bicg_s(kk_ctx ctx, double* s, const double* r, const double* v, int64_t ld, double* sc, double* nrm_out3);
 int kk_launch_bicg_xr(kk_ctx ctx, double* x, const double* p, const double* s, const double* t, double* r,
                       const double* rs, int64_t ld, double* sc, double* nrm_out3, double* rho_out);
+int kk_launch_lsmr_u(kk_ctx ctx, const double* av, double* ah, double* u, int64_t ld, double c, double alpha,
+                     double* nrm_out3);
+int kk_launch_lsmr_hx(kk_ctx ctx, double* h, double* hbar, double* x, const double* v, int64_t ld, double c1, double c2,
+                      double c3);
 int kk_launch_lowsync_solve(kk_ctx ctx, const double* p, const double* g_ride, double* L, int cap, int m, int newest,
                             const double* a0_dev, double* coef_out, double* s_out);

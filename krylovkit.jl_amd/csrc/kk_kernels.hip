@@ -256,6 +256,43 @@ __global__ __launch_bounds__(KK_TPB) void k_bicg_xr(double* __restrict__ x, cons
     if (threadIdx.x == 0) part_d[blockIdx.x] = b;
 }
 
+// ---- LSMR (lssolve/lsmr.jl:61-110) vector updates, fused
+// Ah = Av - c Ah ; u = Av - alpha u ; partial |u|^2                              (:64-68)
+__global__ __launch_bounds__(KK_TPB) void k_lsmr_u(const double* __restrict__ av, double* __restrict__ ah,
+                                                   double* __restrict__ u, int64_t ld, int64_t rpb, double c, double alpha,
+                                                   double* __restrict__ part) {
+    __shared__ double sm[4];
+    const int64_t r0 = (int64_t)blockIdx.x * rpb, r1 = imin(r0 + rpb, ld);
+    double acc = 0;
+    for (int64_t i = r0 + threadIdx.x * 2; i < r1; i += KK_SUB) {
+        const d2 a = ld2(av + i);
+        d2 h = ld2(ah + i), uv = ld2(u + i);
+        h.x = fma(-c, h.x, a.x); h.y = fma(-c, h.y, a.y);
+        uv.x = fma(-alpha, uv.x, a.x); uv.y = fma(-alpha, uv.y, a.y);
+        st2(ah + i, h); st2(u + i, uv);
+        acc = fma(uv.x, uv.x, acc); acc = fma(uv.y, uv.y, acc);
+    }
+    double t = block_sum(acc, sm);
+    if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+// hbar = h - c1 hbar ; x += c2 hbar ; [h = v - c3 h when v != nullptr]           (:121-128)
+__global__ __launch_bounds__(KK_TPB) void k_lsmr_hx(double* __restrict__ h, double* __restrict__ hbar, double* __restrict__ x,
+                                                    const double* __restrict__ v, int64_t ld, int64_t rpb, double c1,
+                                                    double c2, double c3) {
+    const int64_t r0 = (int64_t)blockIdx.x * rpb, r1 = imin(r0 + rpb, ld);
+    for (int64_t i = r0 + threadIdx.x * 2; i < r1; i += KK_SUB) {
+        d2 hv = ld2(h + i), hb = ld2(hbar + i), xv = ld2(x + i);
+        hb.x = fma(-c1, hb.x, hv.x); hb.y = fma(-c1, hb.y, hv.y);
+        xv.x = fma(c2, hb.x, xv.x); xv.y = fma(c2, hb.y, xv.y);
+        st2(hbar + i, hb); st2(x + i, xv);
+        if (v) {
+            const d2 vv = ld2(v + i);
+            hv.x = fma(-c3, hv.x, vv.x); hv.y = fma(-c3, hv.y, vv.y);
+            st2(h + i, hv);
+        }
+    }
+}
+
 // counter-based uniform [0,1): splitmix64 of (seed, row) -> 53-bit mantissa. Independent of grid.
 __global__ __launch_bounds__(KK_TPB) void k_fill_random(double* __restrict__ x, int64_t n, uint64_t seed) {
     for (int64_t i = (int64_t)blockIdx.x * KK_TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * KK_TPB) {
@@ -1638,6 +1675,26 @@ int kk_launch_bicg_xr(kk_ctx ctx, double* x, const double* p, const double* s, c
     KK_HIP(hipGetLastError());
     KK_TRY(finalize_scalar(ctx, PART_SCAL_A, pt.nblk, nrm_out3, true));
     return finalize_scalar(ctx, PART_SCAL_B, pt.nblk, rho_out, false);
+}
+
+int kk_launch_lsmr_u(kk_ctx ctx, const double* av, double* ah, double* u, int64_t ld, double c, double alpha,
+                     double* nrm_out3) {
+    kk_part pt = kk_partition(ctx, ld);
+    {
+        kk_prof_scope ps(ctx, "k_lsmr_u");
+        hipLaunchKernelGGL(k_lsmr_u, dim3(pt.nblk), dim3(KK_TPB), 0, ctx->stream, av, ah, u, ld, pt.rpb, c, alpha,
+                           part_row(ctx, PART_SCAL_A));
+    }
+    KK_HIP(hipGetLastError());
+    return finalize_scalar(ctx, PART_SCAL_A, pt.nblk, nrm_out3, true);
+}
+int kk_launch_lsmr_hx(kk_ctx ctx, double* h, double* hbar, double* x, const double* v, int64_t ld, double c1, double c2,
+                      double c3) {
+    kk_part pt = kk_partition(ctx, ld);
+    kk_prof_scope ps(ctx, "k_lsmr_hx");
+    hipLaunchKernelGGL(k_lsmr_hx, dim3(pt.nblk), dim3(KK_TPB), 0, ctx->stream, h, hbar, x, v, ld, pt.rpb, c1, c2, c3);
+    KK_HIP(hipGetLastError());
+    return KK_OK;
 }
 
 int kk_launch_lowsync_solve(kk_ctx ctx, const double* p, const double* g_ride, double* L, int cap, int m, int newest,

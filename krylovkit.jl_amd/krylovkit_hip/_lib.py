@@ -99,6 +99,8 @@ SIGNATURES = {
     "kk_bicgstab_half": (C.c_int, [c_vp, c_vp, C.POINTER(C.c_int), C.c_double, C.c_double, C.c_int, C.c_double, c_dp, c_dp]),
     "kk_bicgstab_full": (C.c_int, [c_vp, c_vp, C.POINTER(C.c_int), C.c_double, C.c_double, C.c_int, C.POINTER(C.c_int),
                                    c_dp, c_dp, c_dp]),
+    "kk_lsmr_step_u": (C.c_int, [c_vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, c_dp]),
+    "kk_lsmr_update": (C.c_int, [c_vp, C.c_int, C.c_int, C.c_int, c_vp, C.c_int, C.c_double, C.c_double, C.c_double]),
     "kk_gather": (C.c_int, [c_vp, C.c_int, c_vp, C.c_int64, c_vp]),
     "kk_project": (C.c_int, [c_vp, C.c_int, C.c_int, c_vp, C.c_int, C.c_double, C.c_double, c_dp]),
     "kk_unproject": (C.c_int, [c_vp, C.c_int, c_vp, C.c_int, C.c_int, c_dp, C.c_double, C.c_double]),

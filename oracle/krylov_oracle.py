@@ -1493,3 +1493,82 @@ def bicgstab(operator, b: np.ndarray, x0: Optional[np.ndarray] = None, a0: float
             return x, ConvergenceInfo(0, r, normr, numiter, numops)
         first = False
 
+
+def lsmr(operator, b: np.ndarray, lam: float = 0.0, *, krylovdim: int = 30, maxiter: int = 100, tol: float = 1e-12,
+         orth=MGS):
+    """lssolve(operator, b, alg::LSMR, lambda) (lssolve/lsmr.jl:1-151).  `operator` is a matrix (A @ x, A.T @ x) or a
+    pair of callables (apply_normal, apply_adjoint) (apply.jl:14-19)."""
+    if isinstance(operator, tuple):
+        f_normal, f_adjoint = operator
+    else:
+        f_normal, f_adjoint = (lambda z: operator @ z), (lambda z: operator.T @ z)
+    u = np.asarray(b, dtype=np.float64).copy()
+    v = np.asarray(f_adjoint(u), dtype=np.float64).copy()      # :4
+    beta = norm(u)
+    u = scale_(u, 1 / beta)
+    v = scale_(v, 1 / beta)
+    alpha = norm(v)
+    v = scale_(v, 1 / alpha)
+    V = [v]                                                    # OrthonormalBasis([v])   :15
+    K = krylovdim
+    alphabar, zetabar, rho, theta, rhobar, cbar, sbar = alpha, alpha * beta, 1.0, 0.0, 1.0, 1.0, 0.0
+    abszetabar = abs(zetabar)
+    x = np.zeros_like(v)
+    h = v.copy()
+    hbar = np.zeros_like(v)
+    r = scale(u, beta)
+    Ah = np.zeros_like(u)
+    Ahbar = np.zeros_like(u)
+    numiter, numops = 0, 1
+    if abszetabar < tol:                                       # :48-58
+        return x, ConvergenceInfo(1, r, abszetabar, numiter, numops)
+    while True:
+        numiter += 1
+        Av = np.asarray(f_normal(v), dtype=np.float64).copy()  # :63
+        numops += 1
+        Ah = add(Ah, Av, 1.0, -theta / rho)
+        u = add(Av, u, -alpha)                                 # :68
+        beta = norm(u)
+        if beta > tol:
+            u = scale_(u, 1 / beta)
+            v = add(np.asarray(f_adjoint(u), dtype=np.float64).copy(), v, -beta)   # :73
+            numops += 1
+            if K > 1:
+                v, _ = orthogonalize(v, V, orth)               # :76-78
+            alpha = norm(v)
+            if alpha > tol:
+                v = scale_(v, 1 / alpha)
+                if numiter < K:
+                    V.append(v)
+                else:
+                    V[(numiter + 1 - 1) % K] = v               # mod1(numiter + 1, K), 0-based   :86
+        alphahat = float(np.hypot(alphabar, lam))              # :92-94
+        chat = alphabar / alphahat
+        shat = lam / alphahat
+        rhoold = rho                                           # :97-102
+        rho = float(np.hypot(alphahat, beta))
+        c = alphahat / rho
+        s_ = beta / rho
+        theta = s_ * alpha
+        alphabar = c * alpha
+        rhobarold = rhobar                                     # :105-112
+        thetabar = sbar * rho
+        cbarrho = cbar * rho
+        rhobar = float(np.hypot(cbarrho, theta))
+        cbar = cbarrho / rhobar
+        sbar = theta / rhobar
+        zeta = cbar * zetabar
+        zetabar = -sbar * zetabar
+        c1 = thetabar * rho / (rhoold * rhobarold)
+        hbar = add(hbar, h, 1.0, -c1)                          # :115-116
+        Ahbar = add(Ahbar, Ah, 1.0, -c1)
+        c2 = zeta / (rho * rhobar)
+        x = add(x, hbar, c2)                                   # :118-119
+        r = add(r, Ahbar, -c2)
+        h = add(h, v, 1.0, -theta / rho)                       # :121
+        abszetabar = abs(zetabar)
+        if abszetabar <= tol:
+            return x, ConvergenceInfo(1, r, abszetabar, numiter, numops)
+        if numiter >= maxiter:
+            return x, ConvergenceInfo(0, r, abszetabar, numiter, numops)
+

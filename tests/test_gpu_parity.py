@@ -730,6 +730,34 @@ def test_linsolve_bicgstab(kk, ko, ctx):
     assert info.numops == 1 and info.converged == 1
 
 
+def test_lssolve_lsmr(kk, ko, ctx):
+    """LSMR on device vectors (lssolve/lsmr.jl): issue #133 known answer, then a sparse rectangular least-squares
+    problem with / without damping against the oracle (counts equal, iterates to 1e-9)."""
+    import scipy.sparse as sp
+    x, info = kk.lssolve(sp.identity(2, format="csr"), np.array([1.0, 0.0]))
+    assert np.array_equal(x, [1.0, 0.0])
+    assert (info.converged, info.numiter, info.numops, info.normres) == (1, 1, 2, 0.0)
+    rng = np.random.default_rng(5)
+    A = (sp.random(3000, 800, density=0.01, random_state=3, format="csr") + sp.eye(3000, 800, format="csr")).tocsr()
+    b = rng.random(3000)
+    for lam, K, orth_d, orth_o in ((0.0, 30, kk.ModifiedGramSchmidt(), ko.MGS), (0.7, 8, kk.ClassicalGramSchmidt2(), ko.CGS2),
+                                   (0.0, 1, kk.ModifiedGramSchmidt(), ko.MGS)):
+        tol = 1e-9 * np.linalg.norm(b)
+        x, info = kk.lssolve(kk.SparseOperator(A, ctx), b, kk.LSMR(orth_d, 400, K, tol), lam)
+        xo, oinfo = ko.lsmr(A, b, lam, krylovdim=K, maxiter=400, tol=tol, orth=orth_o)
+        assert info.converged == 1 and (info.numiter, info.numops) == (oinfo.numiter, oinfo.numops)
+        r = b - A @ x
+        assert np.linalg.norm(A.T @ r - lam ** 2 * x) <= 5 * tol
+        np.testing.assert_allclose(info.residual, r, rtol=0, atol=1e-9 * np.linalg.norm(b))
+        np.testing.assert_allclose(x, xo, rtol=0, atol=1e-8 * np.linalg.norm(xo))
+    # fixed iteration count (no convergence-branch luck): recurrence scalars must agree
+    x, info = kk.lssolve(kk.SparseOperator(A, ctx), b, kk.LSMR(kk.ModifiedGramSchmidt(), 7, 30, 1e-30))
+    xo, oinfo = ko.lsmr(A, b, krylovdim=30, maxiter=7, tol=1e-30)
+    assert (info.converged, info.numiter, info.numops) == (0, 7, 15) == (oinfo.converged, oinfo.numiter, oinfo.numops)
+    np.testing.assert_allclose(info.normres, oinfo.normres, rtol=1e-9)
+    np.testing.assert_allclose(x, xo, rtol=0, atol=1e-12 * np.linalg.norm(xo))
+
+
 @pytest.mark.parametrize("mgs_mode", [0, 1])
 def test_mgs_on_non_orthonormal_basis(kk, ko, ctx, mgs_mode):
     """The low-sync form (I + L) s = V'w is exact algebra for ANY basis (MGS never divides by |q|^2):

@@ -372,3 +372,34 @@ def test_bicgstab_reference_cases(ko):
     assert info.converged > 0
     np.testing.assert_allclose(a0 * x + a1 * (A @ x), b, rtol=0, atol=1e-9 * np.linalg.norm(b))
 
+
+def test_lsmr_reference_cases(ko):
+    """test/issues.jl:22-29 (issue #133, exact known answer) and test/lssolve.jl:2-60 (rank-deficient small problem)."""
+    x, info = ko.lsmr(np.eye(2), np.array([1.0, 0.0]), tol=1e-12)
+    assert np.array_equal(x, [1.0, 0.0])
+    assert (info.converged, info.numiter, info.numops, info.normres) == (1, 1, 2, 0.0)
+    rng = np.random.default_rng(17)
+    n = 10
+    A = rng.random((2 * n, n))
+    U, S, Vt = np.linalg.svd(A, full_matrices=False)
+    invS = 1 / S
+    S[-1] = 0.0
+    invS[-1] = 0.0
+    A = U @ np.diag(S) @ Vt
+    b = rng.random(2 * n)
+    tol = 10 * n * np.finfo(float).eps
+    x, info = ko.lsmr(A, b, maxiter=3, krylovdim=1, tol=1e-12 * np.linalg.norm(b))   # no reorthogonalisation
+    r = b - A @ x
+    np.testing.assert_allclose(info.residual, r, atol=1e-12)
+    np.testing.assert_allclose(info.normres, np.linalg.norm(A.T @ r), rtol=1e-8)
+    assert info.converged == 0
+    # reorthogonalisation is essential to converge in exactly n iterations   (:38-44)
+    x, info = ko.lsmr(A, b, maxiter=n, tol=tol, krylovdim=n)
+    assert info.converged > 0
+    assert abs(Vt[-1] @ x) < tol
+    np.testing.assert_allclose(x, Vt.T @ (invS * (U.T @ b)), atol=1e-9)
+    lam = rng.random()
+    x, info = ko.lsmr(A, b, lam, maxiter=n, tol=tol, krylovdim=n)
+    assert info.converged > 0
+    np.testing.assert_allclose(A.T @ (b - A @ x), lam ** 2 * x, atol=2 * tol * 10)
+
