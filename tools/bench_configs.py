@@ -93,6 +93,35 @@ def bench_gkl(ctx, full):
     print(json.dumps({"config": f"4: svdsolve(GKL) {m}x{n} sparse random nnz/row=20, krylovdim=30 (1 GPU)", **out}), flush=True)
 
 
+def bench_lsmr(ctx, full):
+    m, n, per = (5_000_000, 1_000_000, 20) if full else (1_000_000, 200_000, 20)
+    rng = np.random.default_rng(5)
+    cols = rng.integers(0, n, size=m * per, dtype=np.int32)
+    vals = rng.standard_normal(m * per)
+    indptr = np.arange(0, m * per + 1, per, dtype=np.int64)
+    A = sp.csr_matrix((vals, cols, indptr), shape=(m, n))
+    A.sum_duplicates()
+    op = kk.SparseOperator(A, ctx)
+    b = rng.random(m)
+    out = {}
+    for K in (1, 30):
+        times = {}
+        for iters in (20, 120):
+            for rep in range(3):
+                ctx.sync(); t0 = time.perf_counter()
+                x, info = kk.lssolve(op, b, kk.LSMR(kk.ModifiedGramSchmidt(), iters, K, 1e-300))
+                ctx.sync(); times[iters] = time.perf_counter() - t0
+        per_it = (times[120] - times[20]) / 100
+        ctx.prof_reset(); ctx.prof_enable(1)
+        kk.lssolve(op, b, kk.LSMR(kk.ModifiedGramSchmidt(), 50, K, 1e-300))
+        ctx.prof_enable(0)
+        prof = {k: round(ctx.prof_get(k)[0], 2) for k in ("k_spmv_ell", "k_spmv_sell", "k_spmv_csr", "k_project", "k_unproject",
+                                                            "k_lsmr_u", "k_lsmr_hx", "k_axpby", "k_scal", "k_block_gram")}
+        out[f"krylovdim={K}"] = {"ms_per_iteration": round(per_it * 1e3, 4), "it_per_s": round(1 / per_it, 1),
+                                 "normres": info.normres, "kernel_ms_50_iterations": prof}
+    print(json.dumps({"config": f"LSMR (SURVEY 8(f)-3) {m}x{n} sparse random nnz/row=20 (config-4 operator)", **out}), flush=True)
+
+
 def bench_block(ctx):
     nx, ny, bs, K = 4000, 2500, 16, 100
     N = nx * ny
@@ -173,6 +202,8 @@ if __name__ == "__main__":
         bench_block(ctx)
     if "cg" in what:
         bench_cg(ctx)
+    if "lsmr" in what:
+        bench_lsmr(ctx, "--full" in sys.argv)
     if "bicgstab" in what:
         bench_bicgstab(ctx)
         bench_bicgstab(ctx, 2000, 1000)
