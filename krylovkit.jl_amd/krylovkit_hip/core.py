@@ -352,6 +352,7 @@ class SparseOperator:
         if not sp.issparse(A):
             raise TypeError("SparseOperator needs a scipy.sparse matrix")
         self.shape = A.shape
+        self.symmetric = bool(symmetric)
         flags = _lib.KK_OP_SYMMETRIC if symmetric else 0
         h = C.c_void_p()
         if via_csc or A.format == "csc":

@@ -40,6 +40,16 @@ class Lanczos:  # algorithms.jl:110-127
 
 
 @dataclass
+class Arnoldi:  # algorithms.jl:235-252
+    orth: Orthogonalizer = KrylovDefaults.orth
+    krylovdim: int = KrylovDefaults.krylovdim
+    maxiter: int = KrylovDefaults.maxiter
+    tol: float = KrylovDefaults.tol
+    eager: bool = False
+    verbosity: int = 0
+
+
+@dataclass
 class GMRES:  # algorithms.jl:373-390
     orth: Orthogonalizer = KrylovDefaults.orth
     maxiter: int = KrylovDefaults.maxiter

@@ -1572,3 +1572,133 @@ def lsmr(operator, b: np.ndarray, lam: float = 0.0, *, krylovdim: int = 30, maxi
         if numiter >= maxiter:
             return x, ConvergenceInfo(0, r, abszetabar, numiter, numops)
 
+
+def expintegrator(A, t: float, u: Sequence[np.ndarray], *, krylovdim: int = 30, maxiter: int = 100, tol: float = 1e-12,
+                  orth: Orthogonalizer = MGS2, method: str = "lanczos", eager: bool = False):
+    """expintegrator(A, t, u::Tuple, alg::Union{Lanczos,Arnoldi}) (matrixfun/expintegrator.jl:100-323), real t.
+    exponentiate(A, t, v) = expintegrator(A, t, (v,)) (matrixfun/exponentiate.jl:83-84)."""
+    import scipy.linalg as sla
+    u = [np.asarray(z, dtype=np.float64) for z in u]
+    if len(u) == 1:                                            # :101
+        u = [u[0], np.zeros_like(u[0])]
+    p = len(u) - 1
+    u0 = u[0]
+    Au0 = apply(A, u0)
+    numops = 1
+    w0 = scale(u0, 1.0)
+    K = krylovdim
+    HH = np.zeros((K + p + 1, K + p + 1))
+    eta = tol                                                  # :120-134
+    totalerr = 0.0
+    sgn = float(np.sign(t))
+    tau = abs(t)
+    if np.isfinite(tau):
+        dtau = tau
+        dtaumin = tau / maxiter
+        maxerr = tau * eta
+    else:
+        dtau = 1.0
+        dtaumin = 0.0
+        maxerr = eta
+    gamma = 0.8
+    tau0 = 0.0
+    w: List[Optional[np.ndarray]] = [None] * (p + 1)
+    w[0] = w0
+    w[1] = scale(Au0, 1.0)
+
+    def stage_vectors(first: bool):
+        nonlocal numops
+        for j in range(1, p + 1):                              # :146-158 / :293-301
+            if j > 1 or not first:
+                w[j] = apply(A, w[j - 1])
+                numops += 1
+            lfac = 1
+            for l in range(0, p - j + 1):
+                w[j] = add(w[j], u[j + l], (sgn * tau0) ** l / lfac)
+                lfac *= l + 1
+
+    def small_exp(fact, step):
+        Kc = len(fact)
+        H = np.zeros((Kc + p + 1, Kc + p + 1))
+        rq = fact.rayleighquotient()
+        if isinstance(rq, tuple):
+            d, e = rq
+            rq = np.diag(d) + np.diag(e, 1) + np.diag(e, -1)
+        H[:Kc, :Kc] = rq * (sgn * step)
+        H[0, Kc] = 1.0
+        for i in range(1, p + 1):
+            H[Kc + i - 1, Kc + i] = 1.0
+        return sla.expm(H)
+
+    def take_step(fact, expH, step):
+        nonlocal w0
+        Kc = len(fact)
+        jfac = 1
+        for j in range(1, p):
+            w0 = add(w0, w[j], (sgn * step) ** j / jfac)
+            jfac *= j + 1
+        w[p] = unproject(w[p], fact.V[:Kc], expH[:Kc, Kc + p - 1])      # :233 / :263
+        w[p] = add(w[p], fact.r, expH[Kc - 1, Kc + p])
+        w0 = add(w0, w[p], beta * (sgn * step) ** p)
+        w[0] = w0
+
+    stage_vectors(True)
+    beta = norm(w[p])
+    if beta < eta and p == 1:                                  # :161-166
+        return w0, ConvergenceInfo(1, None, beta, 0, numops)
+    mk_iter = LanczosIterator if method == "lanczos" else ArnoldiIterator
+    init, init_, expand = ((lanczos_initialize, lanczos_initialize_, lanczos_expand) if method == "lanczos"
+                           else (arnoldi_initialize, arnoldi_initialize_, arnoldi_expand))
+    it = mk_iter(A, w[p], orth)
+    fact = init(it)
+    numops += 1
+    numiter = 1
+    while True:
+        Kc = len(fact)
+        if Kc == krylovdim:                                    # :184-241
+            if numiter < maxiter:
+                dtau = min(dtau, tau - tau0)
+                if np.isfinite(tau):
+                    dtaumin = (tau - tau0) / (maxiter - numiter + 1)
+            else:
+                dtau = tau - tau0
+            expH = small_exp(fact, dtau)
+            eps_ = abs(dtau ** p * beta * fact.normres * expH[Kc - 1, Kc + p])
+            omega = eps_ / (dtau * eta)
+            q = Kc / 2
+            while numiter < maxiter and omega >= 1.0 and dtau > dtaumin:
+                eps_prev, dtau_prev = eps_, dtau
+                dtau = max(dtau * (gamma / omega) ** (1 / (q + 1)), dtaumin)
+                expH = small_exp(fact, dtau)
+                eps_ = abs(dtau ** p * beta * fact.normres * expH[Kc - 1, Kc + p])
+                omega = eps_ / (dtau * eta)
+                q = max(0.0, math.log(eps_ / eps_prev) / math.log(dtau / dtau_prev) - 1)
+            tau0 = tau0 + dtau if numiter < maxiter else tau
+            totalerr += eps_
+            take_step(fact, expH, dtau)
+            if omega < gamma:
+                dtau *= (gamma / omega) ** (1 / (q + 1))
+        elif fact.normres <= (tau - tau0) * eta or eager:      # :242-268
+            step = tau - tau0
+            expH = small_exp(fact, step)
+            eps_ = abs(step ** p * beta * fact.normres * expH[Kc - 1, Kc + p])
+            omega = eps_ / (step * eta)
+            if omega < 1.0:
+                totalerr += eps_
+                take_step(fact, expH, step)
+                tau0 = tau
+        if tau0 >= tau:                                        # :269-285
+            return w0, ConvergenceInfo(1 if totalerr <= maxerr else 0, None, totalerr, numiter, numops)
+        if Kc < krylovdim:
+            fact = expand(it, fact)
+            numops += 1
+        else:
+            stage_vectors(False)
+            beta = norm(w[p])
+            if beta < eta and p == 1:                          # :302-307
+                return w0, ConvergenceInfo(1, None, beta, numiter, numops)
+            it = mk_iter(A, w[p], orth)
+            fact = init_(it, fact)
+            numops += 1
+            numiter += 1
+

@@ -758,6 +758,32 @@ def test_lssolve_lsmr(kk, ko, ctx):
     np.testing.assert_allclose(x, xo, rtol=0, atol=1e-12 * np.linalg.norm(xo))
 
 
+@pytest.mark.parametrize("method", ["lanczos", "arnoldi"])
+def test_expintegrator(kk, ko, ctx, method):
+    """exponentiate / expintegrator on device vectors (matrixfun/expintegrator.jl): same result, numiter and numops as
+    the oracle, for one-shot (krylovdim large enough) and multi-step (small krylovdim) runs, p = 1 and p = 3."""
+    import scipy.sparse.linalg as spl
+    A = ko.laplacian_2d(30, 20) if method == "lanczos" else ko.convection_diffusion_2d(30, 20)
+    A = (A / 8.0).tocsr()
+    n = A.shape[0]
+    rng = np.random.default_rng(9)
+    op = kk.SparseOperator(A, ctx, symmetric=(method == "lanczos"))
+    mk = kk.Lanczos if method == "lanczos" else kk.Arnoldi
+    for t, K in ((0.7, 40), (-2.5, 12), (6.0, 10)):
+        v = rng.random(n)
+        w, info = kk.exponentiate(op, t, v, mk(kk.ModifiedGramSchmidt2(), K, 100, 1e-11))
+        wo, oinfo = ko.expintegrator(A, t, (v,), krylovdim=K, maxiter=100, tol=1e-11, orth=ko.MGS2, method=method)
+        assert info.converged == 1 and (info.numiter, info.numops) == (oinfo.numiter, oinfo.numops)
+        np.testing.assert_allclose(w, wo, rtol=0, atol=1e-10 * np.linalg.norm(wo))
+        np.testing.assert_allclose(w, spl.expm_multiply(t * A.tocsc(), v), rtol=0, atol=1e-8 * np.linalg.norm(v))
+    u = [rng.random(n) for _ in range(4)]
+    for K, orth_d, orth_o in ((12, kk.ClassicalGramSchmidt2(), ko.CGS2), (25, kk.ModifiedGramSchmidtIR(), ko.MGSIR())):
+        w, info = kk.expintegrator(op, 1.3, u, mk(orth_d, K, 100, 1e-11))
+        wo, oinfo = ko.expintegrator(A, 1.3, u, krylovdim=K, maxiter=100, tol=1e-11, orth=orth_o, method=method)
+        assert info.converged == 1 and (info.numiter, info.numops) == (oinfo.numiter, oinfo.numops)
+        np.testing.assert_allclose(w, wo, rtol=0, atol=1e-10 * np.linalg.norm(wo))
+
+
 @pytest.mark.parametrize("mgs_mode", [0, 1])
 def test_mgs_on_non_orthonormal_basis(kk, ko, ctx, mgs_mode):
     """The low-sync form (I + L) s = V'w is exact algebra for ANY basis (MGS never divides by |q|^2):

@@ -403,3 +403,74 @@ def test_lsmr_reference_cases(ko):
     assert info.converged > 0
     np.testing.assert_allclose(A.T @ (b - A @ x), lam ** 2 * x, atol=2 * tol * 10)
 
+
+def _phi(A, v, p):
+    """test/expintegrator.jl:1-13: phi_p(A) v through the augmented matrix exponential."""
+    import scipy.linalg as sla
+    m = A.shape[0]
+    Ap = np.zeros((m + p, m + p))
+    Ap[:m, :m] = A
+    Ap[:m, m] = v
+    for k in range(1, p):
+        Ap[m + k - 1, m + k] = 1.0
+    return sla.expm(Ap)[:m, -1]
+
+
+@pytest.mark.parametrize("method", ["lanczos", "arnoldi"])
+def test_expintegrator_reference_cases(ko, method):
+    """test/expintegrator.jl:15-118 (full Krylov space) and :120-191 (iterative, krylovdim < n), real Float64."""
+    import scipy.linalg as sla
+    rng = np.random.default_rng(23)
+    n = 10
+    A = rng.random((n, n)) - 0.5
+    if method == "lanczos":
+        A = (A + A.T) / 2
+    for orth in (ko.CGS2, ko.MGS2, ko.CGSIR(), ko.MGSIR()):
+        W = np.zeros((n, n))
+        for k in range(n):
+            W[:, k], _ = ko.expintegrator(A, 1.0, (np.eye(n)[:, k],), krylovdim=n, maxiter=2, tol=1e-12, orth=orth, method=method)
+        np.testing.assert_allclose(W, sla.expm(A), atol=1e-10)
+        for t in (rng.random(), -rng.random()):
+            for p in range(1, 6):
+                u = [rng.random(n) for _ in range(p + 1)]
+                w, info = ko.expintegrator(A, t, u, krylovdim=n, maxiter=2, tol=1e-12, orth=orth, method=method)
+                w2 = sla.expm(t * A) @ u[0]
+                for j in range(1, p + 1):
+                    w2 = w2 + t ** j * _phi(t * A, u[j], j)
+                assert info.converged > 0
+                np.testing.assert_allclose(w, w2, atol=1e-9)
+    # iterative: N = 100, krylovdim 20   (:120-191)
+    N = 100
+    A = rng.random((N, N)) - 0.5
+    if method == "lanczos":
+        A = (A + A.T) / 2
+    s = np.max(np.abs(np.linalg.eigvals(A)))
+    A = A / s
+    for p in (1, 3):
+        u = [rng.random(N) for _ in range(p + 1)]
+        w1, info = ko.expintegrator(A, 1.0, u, krylovdim=20, maxiter=100, tol=1e-10, method=method)
+        assert info.converged > 0
+        w2 = sla.expm(A) @ u[0]
+        for j in range(1, p + 1):
+            w2 = w2 + _phi(A, u[j], j)
+        np.testing.assert_allclose(w1, w2, atol=1e-8)
+        w1e, infoe = ko.expintegrator(A, 1.0, u, krylovdim=20, maxiter=100, tol=1e-10, method=method, eager=True)
+        assert infoe.converged > 0
+        np.testing.assert_allclose(w1e, w2, atol=1e-8)
+
+
+def test_expintegrator_fixed_point_branch(ko):
+    """Analogue of test/expintegrator.jl:193-214 (fixed-point branch, :161-166 / :302-307) with a real negative
+    definite A instead of the reference's shifted complex one: t = 1000 converges to the fixed point of the ODE."""
+    rng = np.random.default_rng(29)
+    n = 10
+    A = rng.random((n, n)) - 0.5
+    A = -(A @ A.T) - np.eye(n) * 0.1
+    v0, v1 = rng.random(n), rng.random(n)
+    w1, info1 = ko.expintegrator(A, 1000.0, (v0,), krylovdim=n, maxiter=100, tol=1e-12, method="arnoldi")
+    assert info1.converged > 0
+    np.testing.assert_allclose(w1, np.zeros(n), atol=1e-9)
+    w2, info2 = ko.expintegrator(A, 1000.0, (v0, v1), krylovdim=n, maxiter=100, tol=1e-12, method="arnoldi")
+    assert info2.converged > 0
+    np.testing.assert_allclose(A @ w2 + v1, np.zeros(n), atol=1e-8)
+
