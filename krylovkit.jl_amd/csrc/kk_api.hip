@@ -1794,6 +1794,29 @@ extern "C" int kk_block_apply(kk_op op, kk_basis bx, int cx, kk_basis by, int cy
     return kk_launch_spmm(op->ctx, op->A, bx->col(cx), bx->ld, by->col(cy), by->ld, nb);
 }
 
+// stage the m x nb coefficient panel S[:, j0 : j0+nb] (host, column-major, leading dimension lds) for
+// kk_launch_block_update: row-major on the device with the row stride padded to the kernel's width (4 / 8 / 16,
+// zeros in the pad) so that the kernel reads whole rows with wide scalar loads and needs no j < nb branches
+static int stage_coef(kk_ctx c, const double* S, int lds, int m, int j0, int nb, const double** dev_out) {
+    // ring of KK_STAGE_SLOTS staging slots (same offset in the pinned and the device scratch): the host only waits
+    // for the stream when the ring wraps, not before every launch
+    const int st = kk_bu_stride(nb);
+    KK_CHECK((int64_t)m * st <= KK_STAGE_DOUBLES, KK_ERR_UNSUPPORTED, "block update: coefficient panel %d x %d too large", m, st);
+    if (c->stage_slot >= KK_STAGE_SLOTS) {
+        KK_TRY(stream_sync(c));
+        c->stage_slot = 0;
+    }
+    const size_t off = (size_t)c->stage_slot * KK_STAGE_DOUBLES;
+    c->stage_slot++;
+    for (int i = 0; i < m; ++i) {
+        double* row = c->h_blk + off + (size_t)i * st;
+        for (int j = 0; j < nb; ++j) row[j] = S[i + (size_t)lds * (j0 + j)];
+        for (int j = nb; j < st; ++j) row[j] = 0.0;
+    }
+    if (m > 0) KK_HIP(hipMemcpyAsync(c->blk + off, c->h_blk + off, (size_t)m * st * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    *dev_out = c->blk + off;
+    return KK_OK;
+}
 // W[:, j] = beta W[:, j] + alpha V S[:, j]  (S host, m x q col-major lds); norms_host optional
 static int block_update_run(kk_ctx c, const double* V, int64_t ld, int m, double* W, int64_t ldw, int q, const double* S,
                             int lds, double alpha, double beta, double* norms) {
@@ -1802,11 +1825,9 @@ static int block_update_run(kk_ctx c, const double* V, int64_t ld, int m, double
     double* nrm_dev = c->blk + KK_BLK_SCRATCH / 2;  // q doubles
     for (int j0 = 0; j0 < q; j0 += 16) {
         const int nb = std::min(16, q - j0);
-        KK_TRY(stream_sync(c));  // h_blk is reused as staging
-        for (int i = 0; i < m; ++i)
-            for (int j = 0; j < nb; ++j) c->h_blk[(size_t)i * nb + j] = S[i + (size_t)lds * (j0 + j)];
-        if (m > 0) KK_HIP(hipMemcpyAsync(c->blk, c->h_blk, (size_t)m * nb * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        KK_TRY(kk_launch_block_update(c, V, ld, m, W + (int64_t)j0 * ldw, W + (int64_t)j0 * ldw, ldw, ldw, nb, c->blk, alpha,
+        const double* Sd = nullptr;
+        KK_TRY(stage_coef(c, S, lds, m, j0, nb, &Sd));
+        KK_TRY(kk_launch_block_update(c, V, ld, m, W + (int64_t)j0 * ldw, W + (int64_t)j0 * ldw, ldw, ldw, nb, Sd, alpha,
                                       beta, norms ? nrm_dev + j0 : nullptr));
     }
     if (norms) {
@@ -1906,11 +1927,9 @@ static int block_qr_run(kk_basis b, int c_in, int p, int c_out, double tol, doub
             // Q1 = B * R1^-1 (out of place)
             for (int j0 = 0; j0 < p; j0 += 16) {
                 const int nb = std::min(16, p - j0);
-                KK_TRY(stream_sync(c));
-                for (int i = 0; i < p; ++i)
-                    for (int j = 0; j < nb; ++j) c->h_blk[(size_t)i * nb + j] = Ri[i + (size_t)p * (j0 + j)];
-                KK_HIP(hipMemcpyAsync(c->blk, c->h_blk, (size_t)p * nb * sizeof(double), hipMemcpyHostToDevice, c->stream));
-                KK_TRY(kk_launch_block_update(c, b->col(c_in), ld, p, nullptr, b->col(c_out + j0), ld, ld, nb, c->blk, 1.0, 0.0,
+                const double* Sd = nullptr;
+                KK_TRY(stage_coef(c, Ri.data(), p, p, j0, nb, &Sd));
+                KK_TRY(kk_launch_block_update(c, b->col(c_in), ld, p, nullptr, b->col(c_out + j0), ld, ld, nb, Sd, 1.0, 0.0,
                                               nullptr));
             }
             KK_TRY(block_inner_run(c, b->col(c_out), ld, p, b->col(c_out), ld, p, ld, G.data(), p));
@@ -1926,11 +1945,9 @@ static int block_qr_run(kk_basis b, int c_in, int p, int c_out, double tol, doub
                 for (int j0 = ((p - 1) / 16) * 16; j0 >= 0; j0 -= 16) {
                     const int nb = std::min(16, p - j0);
                     const int mm = j0 + nb;  // rows of R2^-1 that can be non-zero for these columns
-                    KK_TRY(stream_sync(c));
-                    for (int i = 0; i < mm; ++i)
-                        for (int j = 0; j < nb; ++j) c->h_blk[(size_t)i * nb + j] = Ri[i + (size_t)p * (j0 + j)];
-                    KK_HIP(hipMemcpyAsync(c->blk, c->h_blk, (size_t)mm * nb * sizeof(double), hipMemcpyHostToDevice, c->stream));
-                    KK_TRY(kk_launch_block_update(c, b->col(c_out), ld, mm, nullptr, b->col(c_out + j0), ld, ld, nb, c->blk, 1.0,
+                    const double* Sd = nullptr;
+                    KK_TRY(stage_coef(c, Ri.data(), p, mm, j0, nb, &Sd));
+                    KK_TRY(kk_launch_block_update(c, b->col(c_out), ld, mm, nullptr, b->col(c_out + j0), ld, ld, nb, Sd, 1.0,
                                                   0.0, nullptr));
                 }
                 // R = R2 * R1

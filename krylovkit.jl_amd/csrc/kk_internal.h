@@ -11,6 +11,8 @@
 #define KK_MAX_M 256          // max basis vectors touched by one project/unproject call
 #define KK_MAX_BLOCKS 4096    // max thread blocks of a reducing kernel (partials row stride)
 #define KK_BLK_SCRATCH 131072 // doubles of device/pinned scratch for block matrices (gram panels, S)
+#define KK_STAGE_SLOTS 8      // ring of coefficient-panel staging slots inside the block scratch (first half)
+#define KK_STAGE_DOUBLES 4096  // doubles per slot (KK_MAX_M rows x 16)
 #define KK_TPB 256            // threads per block of every streaming kernel (4 waves)
 #define KK_SUB 512            // rows covered by one block sub-step: 256 threads x 2 rows (16 B/lane)
 // register tile of the two basis-streaming kernels: RG sub-steps of 512 rows per row group (2*RG rows per
@@ -102,6 +104,7 @@ struct kk_ctx_s {
     struct { bool active = false; kk_op op = nullptr; kk_basis b = nullptr; int c0 = 0, k_next = 0; } spec_req;
     hipEvent_t t0 = nullptr, t1 = nullptr;
     hipEvent_t ev_fetch2 = nullptr; // read-backs of a run-ahead BiCGStab half
+    int stage_slot = 0;             // next free coefficient staging slot (stage_coef)
     bool bicg_ahead = false;        // a BiCG half was enqueued by kk_bicgstab_full and not collected yet
     hipEvent_t ev_fetch = nullptr;  // marks the end of the scalar read-backs of an expand (host waits on this, not on the stream)
     int prof = 0;                // 0 off, 1 every kernel class, 2 only the basis-streaming classes (project/unproject)
@@ -245,6 +248,8 @@ int kk_launch_rank1(kk_ctx ctx, double* V, int64_t ld, int m, const double* y, c
 // ---- block (multi-vector) launchers
 int kk_launch_block_gram(kk_ctx ctx, const double* X, int64_t ldx, int p, const double* Y, int64_t ldy, int q, int64_t ld,
                          double* C_dev, int ldc);
+// row stride (= kernel width NB) of the coefficient panel handed to kk_launch_block_update for nb right-hand sides
+static inline int kk_bu_stride(int nb) { return nb <= 4 ? 4 : (nb <= 8 ? 8 : 16); }
 int kk_launch_block_update(kk_ctx ctx, const double* V, int64_t ld, int m, const double* Win, double* Wout, int64_t ldw_in,
                            int64_t ldw_out, int nb, const double* S_dev, double alpha, double beta, double* norms2_dev);
 int kk_launch_spmm(kk_ctx ctx, const kk_sparse_dev& M, const double* X, int64_t ldx, double* Y, int64_t ldy, int nb);

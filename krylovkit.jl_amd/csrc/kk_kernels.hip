@@ -1039,9 +1039,9 @@ __global__ __launch_bounds__(KK_TPB) void k_rank1(double* __restrict__ V, int64_
 //   D[i][j] += sum_k A[i][k] B[k][j],  i = X column (16 per group), j = Y column, k = 4 rows.
 //   A operand: lane l holds A[i = l&15][k = l>>4];  B operand: lane l holds B[k = l>>4][j = l&15];
 //   C/D (f64 map): lane l, reg r -> row i = (l>>4) + 4r, col j = l&15.
-// Lane (c = l&15, kq = l>>4) streams BG_T consecutive rows of column c (16 B loads); MFMA t uses
-// element t, so the 4 k-slots of MFMA t are rows {kq*T + t}: any row->slot map is valid as long
-// as A and B use the same one.  X is read exactly once, Y once per launch.
+// Lane (c = l&15, kq = l>>4) streams BG_T rows of column c of a 32-row chunk with 16 B loads, the four lanes of a
+// column covering 64 contiguous bytes per load instruction; MFMA t uses element t of every lane: any row->k-slot
+// map is valid as long as A and B use the same one.  X is read exactly once, Y once per launch.
 #define BG_T 8                       // rows per lane per chunk (4 x dwordx4)
 #define BG_CHUNK (4 * BG_T)          // rows per wave chunk
 
@@ -1058,12 +1058,14 @@ __global__ __launch_bounds__(KK_TPB) void k_block_gram(const double* __restrict_
     for (int g = 0; g < NG; ++g) acc[g] = v4d{0.0, 0.0, 0.0, 0.0};
     const bool yok = c < q;
     for (int64_t rc = r0 + wave * BG_CHUNK; rc < r1; rc += 4 * BG_CHUNK) {
-        const int64_t row = rc + kq * BG_T;
+        // rows of lane (c, kq): {rc + 4t + 2kq, +1 : t = 0,2,4,6}  -- the four lanes of one column read 64
+        // contiguous bytes per load instruction (same row -> k-slot map for X and Y, so the contraction is unchanged)
+        const int64_t row = rc + kq * 2;
         double yv[BG_T];
         if (yok) {
             const double* yp = Y + (int64_t)c * ldy + row;
 #pragma unroll
-            for (int t = 0; t < BG_T; t += 2) { d2 v = ld2(yp + t); yv[t] = v.x; yv[t + 1] = v.y; }
+            for (int t = 0; t < BG_T; t += 2) { d2 v = ld2(yp + 4 * t); yv[t] = v.x; yv[t + 1] = v.y; }
         } else {
 #pragma unroll
             for (int t = 0; t < BG_T; ++t) yv[t] = 0.0;
@@ -1075,7 +1077,7 @@ __global__ __launch_bounds__(KK_TPB) void k_block_gram(const double* __restrict_
             if (col < p) {
                 const double* xp = X + (int64_t)col * ldx + row;
 #pragma unroll
-                for (int t = 0; t < BG_T; t += 2) { d2 v = ld2(xp + t); xv[t] = v.x; xv[t + 1] = v.y; }  // plain: X == Y panels re-hit L2
+                for (int t = 0; t < BG_T; t += 2) { d2 v = ld2(xp + 4 * t); xv[t] = v.x; xv[t + 1] = v.y; }  // plain: X == Y panels re-hit L2
             } else {
 #pragma unroll
                 for (int t = 0; t < BG_T; ++t) xv[t] = 0.0;
@@ -1116,7 +1118,7 @@ __global__ __launch_bounds__(KK_TPB) void k_finalize_gram(const double* __restri
     C[i + (int64_t)ldc * j] = a;
 }
 
-// W[:, j] = beta*W[:, j] + alpha * sum_c V[:, c] S[c*nb + j]   for j < nb <= NB, c < m
+// W[:, j] = beta*W[:, j] + alpha * sum_c V[:, c] S[c*NB + j]   for j < nb <= NB, c < m   (S rows padded to NB)
 // (three-term block update, block_reorthogonalize! panel update, CholQR back-substitution).
 // S lives in device memory (scalar loads); fused column norms |W_j|^2 -> partials.
 template <int NB, bool BZERO>
@@ -1124,51 +1126,63 @@ __global__ __launch_bounds__(KK_TPB) void k_block_update(const double* V, int64_
                                                          double* Wout, int64_t ldw_in, int64_t ldw_out, int nb,
                                                          const double* __restrict__ S, double alpha, double beta,
                                                          int64_t rpb, double* __restrict__ part_nrm) {
+    // per-thread column-norm accumulators live in LDS (slot [j][tid], touched by its owner only): the 2*NB VGPRs
+    // they would cost are what keeps the NB=16 instantiation at 4 waves/SIMD with the load pipeline below
+    __shared__ double nsm[NB * KK_TPB];
     __shared__ double sm[4];
+    const int tid = threadIdx.x;
     const int64_t r0 = (int64_t)blockIdx.x * rpb, r1 = imin(r0 + rpb, ld);
-    double nacc[NB];
+    if (part_nrm) {
 #pragma unroll
-    for (int j = 0; j < NB; ++j) nacc[j] = 0.0;
-    for (int64_t r = r0 + threadIdx.x * 2; r < r1; r += KK_SUB) {
-        d2 w[NB];
+        for (int j = 0; j < NB; ++j) nsm[j * KK_TPB + tid] = 0.0;
+    }
+    for (int64_t r = r0 + tid * 2; r < r1; r += KK_SUB) {
+        d2 acc[NB];          // acc_j = sum_c S[c][j] V_c   (S straight from scalar registers into the FMA)
 #pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            if (!BZERO && j < nb) { w[j] = ld2(Win + (int64_t)j * ldw_in + r); w[j].x *= beta; w[j].y *= beta; }
-            else w[j] = d2{0.0, 0.0};
-        }
+        for (int j = 0; j < NB; ++j) acc[j] = d2{0.0, 0.0};
         int c = 0;
+        d2 xn[4];            // software pipeline: the loads of batch c+4 are in flight while batch c is multiplied
+        if (m >= 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) xn[u] = ld2s(V + (int64_t)u * ld + r);
+        }
         for (; c + 4 <= m; c += 4) {
             d2 x[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) x[u] = ld2s(V + (int64_t)(c + u) * ld + r);
+            for (int u = 0; u < 4; ++u) x[u] = xn[u];
+            if (c + 8 <= m) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) xn[u] = ld2s(V + (int64_t)(c + 4 + u) * ld + r);
+            }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const double* Sc = S + (int64_t)(c + u) * nb;
+                const double* Sc = S + (int64_t)(c + u) * NB;   // rows padded to NB by the caller (zeros beyond nb)
 #pragma unroll
                 for (int j = 0; j < NB; ++j) {
-                    if (j < nb) {
-                        const double s = alpha * Sc[j];
-                        w[j].x = fma(s, x[u].x, w[j].x); w[j].y = fma(s, x[u].y, w[j].y);
-                    }
+                    const double sv = Sc[j];
+                    acc[j].x = fma(sv, x[u].x, acc[j].x); acc[j].y = fma(sv, x[u].y, acc[j].y);
                 }
             }
         }
         for (; c < m; ++c) {
             const d2 x = ld2(V + (int64_t)c * ld + r);
-            const double* Sc = S + (int64_t)c * nb;
+            const double* Sc = S + (int64_t)c * NB;
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
-                if (j < nb) {
-                    const double s = alpha * Sc[j];
-                    w[j].x = fma(s, x.x, w[j].x); w[j].y = fma(s, x.y, w[j].y);
-                }
+                const double sv = Sc[j];
+                acc[j].x = fma(sv, x.x, acc[j].x); acc[j].y = fma(sv, x.y, acc[j].y);
             }
         }
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             if (j < nb) {
-                st2(Wout + (int64_t)j * ldw_out + r, w[j]);
-                nacc[j] = fma(w[j].x, w[j].x, nacc[j]); nacc[j] = fma(w[j].y, w[j].y, nacc[j]);
+                d2 w{alpha * acc[j].x, alpha * acc[j].y};
+                if (!BZERO) {
+                    const d2 wi = ld2(Win + (int64_t)j * ldw_in + r);
+                    w.x = fma(beta, wi.x, w.x); w.y = fma(beta, wi.y, w.y);
+                }
+                st2(Wout + (int64_t)j * ldw_out + r, w);
+                if (part_nrm) nsm[j * KK_TPB + tid] += fma(w.x, w.x, w.y * w.y);
             }
         }
     }
@@ -1176,8 +1190,8 @@ __global__ __launch_bounds__(KK_TPB) void k_block_update(const double* V, int64_
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             if (j < nb) {
-                double t = block_sum(nacc[j], sm);
-                if (threadIdx.x == 0) part_nrm[(int64_t)j * KK_MAX_BLOCKS + blockIdx.x] = t;
+                double t = block_sum(nsm[j * KK_TPB + tid], sm);
+                if (tid == 0) part_nrm[(int64_t)j * KK_MAX_BLOCKS + blockIdx.x] = t;
             }
         }
     }
