@@ -145,3 +145,45 @@ def test_sharded_eigsolve_gmres_block(kk, ko, ctx):
         D, numiter, numops, conv = res[0][("block", mode)]
         assert len(D) == 71 and numiter == 1 and numops == 72 and conv == 71
         np.testing.assert_allclose(np.sort(D), ev143, rtol=0, atol=1e-10 * np.max(np.abs(ev143)))
+
+
+def test_sharded_short_recurrences_and_exponentiate(kk, ko, ctx):
+    """SURVEY 8(f)-3/4 rows on row shards through the same hooks: CG, BiCGStab (device-resident rho/alpha/omega are
+    all-reduced sums, so both ranks take the same branches) and exponentiate, against the serial oracle."""
+    from krylovkit_hip import dist as kd
+    world = 2
+    nx, ny = 24, 18
+    n = nx * ny
+    A = ko.laplacian_2d(nx, ny, shift_diag=0.5 + np.linspace(0, 1, n))
+    Cm = ko.convection_diffusion_2d(nx, ny)
+    E = (ko.laplacian_2d(nx, ny) / 8.0).tocsr()
+    b = np.random.default_rng(4).random(n)
+    v = np.random.default_rng(6).random(n)
+    tol = 1e-10 * np.linalg.norm(b)
+
+    def fn(rank, sctx, coll):
+        part = kd.Partition.even(n, world, rank, align=nx)
+        sl = slice(part.lo, part.hi)
+        out = {}
+        x, info = kk.linsolve_cg(sctx.operator(A[sl, :], part), b[sl], None, kk.CG(500, tol), 0.3, 0.9)
+        out["cg"] = (x, info.numiter, info.numops, info.converged)
+        x, info = kk.linsolve_bicgstab(sctx.operator(Cm[sl, :], part), b[sl], None, kk.BiCGStab(7, 1e-30))
+        out["bicg"] = (x, info.numiter, info.numops, info.converged, info.normres)
+        w, info = kk.exponentiate(sctx.operator(E[sl, :], part), -1.5, v[sl], kk.Lanczos(kk.ModifiedGramSchmidt2(), 12, 100, 1e-11))
+        out["exp"] = (w, info.numiter, info.numops, info.converged)
+        return out
+
+    res = run_ranks(world, fn)
+    xo, oinfo = ko.cg(A, b, None, 0.3, 0.9, maxiter=500, tol=tol)
+    xg = np.concatenate([res[0]["cg"][0], res[1]["cg"][0]])
+    assert res[0]["cg"][1:] == res[1]["cg"][1:] == (oinfo.numiter, oinfo.numops, 1)
+    np.testing.assert_allclose(xg, xo, rtol=0, atol=1e-9 * np.linalg.norm(xo))
+    xo, oinfo = ko.bicgstab(Cm, b, None, maxiter=7, tol=1e-30)
+    xg = np.concatenate([res[0]["bicg"][0], res[1]["bicg"][0]])
+    assert res[0]["bicg"][1:4] == res[1]["bicg"][1:4] == (oinfo.numiter, oinfo.numops, 0)
+    assert relerr(res[0]["bicg"][4], oinfo.normres) < 1e-8
+    np.testing.assert_allclose(xg, xo, rtol=0, atol=1e-10 * np.linalg.norm(xo))
+    wo, oinfo = ko.expintegrator(E, -1.5, (v,), krylovdim=12, maxiter=100, tol=1e-11, orth=ko.MGS2, method="lanczos")
+    wg = np.concatenate([res[0]["exp"][0], res[1]["exp"][0]])
+    assert res[0]["exp"][1:] == res[1]["exp"][1:] == (oinfo.numiter, oinfo.numops, 1)
+    np.testing.assert_allclose(wg, wo, rtol=0, atol=1e-10 * np.linalg.norm(wo))
