@@ -74,7 +74,10 @@ def eigsolve(A, x0, howmany: int = 1, which: str = "LM", alg: Optional[Lanczos] 
     """eigsolve(A, x0, howmany, which, alg::Lanczos) (src/eigsolve/lanczos.jl:1-155).
 
     A: SparseOperator or scipy.sparse matrix (must be symmetric).  Returns
-    (values, vectors, ConvergenceInfo); vectors are numpy arrays unless return_device."""
+    (values, vectors, ConvergenceInfo); vectors are numpy arrays unless return_device.
+    With alg::Arnoldi the general (non-symmetric) method of src/eigsolve/arnoldi.jl is used."""
+    if isinstance(alg, Arnoldi):
+        return _eigsolve_arnoldi(A, x0, howmany, which, alg)
     alg = alg or Lanczos(**kw)
     krylovdim, maxiter = alg.krylovdim, alg.maxiter
     if howmany > krylovdim:
@@ -160,6 +163,127 @@ def eigsolve(A, x0, howmany: int = 1, which: str = "LM", alg: Optional[Lanczos] 
     vectors = [out.download(i) for i in range(hm)]
     info.residual = [fact.r.get() * Vc[-1, i] for i in range(hm)]  # :134-136
     return values, vectors, info
+
+
+# -------------------------------------------------------------------- eigsolve / schursolve (Arnoldi)
+def _set_packed_hessenberg(fact, H: np.ndarray, K: int):
+    """copy!(rayleighquotient(fact), H) (eigsolve/arnoldi.jl:443): write the K x K dense H back into the packed
+    Hessenberg storage (dense/packedhessenberg.jl:32-48)."""
+    from .factorizations import packed_index
+    for j in range(1, K + 1):
+        for i in range(1, min(j + 1, K) + 1):
+            fact.H[packed_index(i, j)] = float(H[i - 1, j - 1])
+
+
+def _schursolve(A, x0, howmany: int, which: str, alg: Arnoldi):
+    """_schursolve (src/eigsolve/arnoldi.jl:361-464): Krylov-Schur restarted Arnoldi.  Device work: kk_arnoldi_expand,
+    kk_basistransform, one scaled copy per restart; the K x K Schur algebra is host LAPACK as in the reference."""
+    krylovdim, maxiter = alg.krylovdim, alg.maxiter
+    if howmany > krylovdim:
+        raise ValueError(f"krylov dimension {krylovdim} too small to compute {howmany} eigenvalues")
+    numiter = 1
+    it = ArnoldiIterator(_as_operator(A), x0, alg.orth, capacity=krylovdim + 2)
+    fact = initialize(it)
+    numops = 1
+    tol = alg.tol
+    converged = 0
+    T = U = f = None
+    while True:
+        beta = fact.normres
+        K = len(fact)
+        if K == krylovdim or beta <= tol or (alg.eager and K >= howmany):   # process  :389
+            T, U, values = dense.hschur(fact.rayleighquotient())
+            T, U, values = dense.permuteschur(T, U, dense.sortperm_general(values, which))
+            f = U[K - 1, :] * beta                                           # :400
+            converged = 0
+            while converged < K and abs(f[converged]) <= tol:
+                converged += 1
+            if 0 < converged < K and T[converged, converged - 1] != 0:       # do not split a 2x2 block  :405
+                converged -= 1
+            if converged >= howmany or beta <= tol:
+                break
+        if K < krylovdim:                                                    # expand  :416
+            fact = expand_(it, fact)
+            numops += 1
+        else:                                                                # shrink  :419-449
+            if numiter == maxiter:
+                break
+            keep = (3 * krylovdim + 2 * converged) // 5
+            if T[keep, keep - 1] != 0:
+                if keep > 1:
+                    keep -= 1
+                else:
+                    keep += 1
+                    if krylovdim == 2:
+                        break
+            H = np.array(T)                                                  # the K x K view the reference reuses
+            dense.restorearnoldiform(U, H, f, keep)                          # :441
+            _set_packed_hessenberg(fact, H, K)
+            B = fact.basis()
+            B.basistransform(np.ascontiguousarray(U[:, :keep]))              # :444
+            HipVec(B, keep).scale_from_(fact.r, 1.0 / beta)                  # B[keep+1] = scale!!(residual, 1/beta)
+            fact = shrink_(fact, keep)
+            numiter += 1
+    return T, U, fact, converged, numiter, numops
+
+
+def _arnoldi_howmany(T, fact, howmany, converged):
+    hm = howmany                                                             # :286-293
+    if howmany < len(fact) and T[howmany, howmany - 1] != 0:
+        hm += 1
+    elif T.shape[0] < howmany:
+        hm = T.shape[0]
+    if converged > howmany:
+        hm = converged
+    return hm
+
+
+def _times_complex(B: DeviceBasis, K: int, coeffs: np.ndarray):
+    """[B * v for v in cols(V)] with complex coefficient vectors: real and imaginary parts are two real kk_unproject
+    calls on the device; the complex vector is assembled on the host."""
+    out = DeviceBasis(B.n, 2, B.ctx)
+    vecs = []
+    for i in range(coeffs.shape[1]):
+        c = coeffs[:, i]
+        B.times(np.ascontiguousarray(c.real), HipVec(out, 0), 0, K)
+        re = out.download(0)
+        if np.any(c.imag != 0):
+            B.times(np.ascontiguousarray(c.imag), HipVec(out, 1), 0, K)
+            vecs.append(re + 1j * out.download(1))
+        else:
+            vecs.append(re)
+    return vecs
+
+
+def schursolve(A, x0, howmany: int = 1, which: str = "LM", alg: Optional[Arnoldi] = None, **kw):
+    """schursolve(A, x0, howmany, which, alg::Arnoldi) (src/eigsolve/arnoldi.jl:237-275):
+    returns (T, vectors, values, info) with A * vectors ~ vectors * T."""
+    alg = alg or Arnoldi(**kw)
+    T, U, fact, converged, numiter, numops = _schursolve(A, x0, howmany, which, alg)
+    hm = _arnoldi_howmany(T, fact, howmany, converged)
+    TT = T[:hm, :hm]
+    values = dense.schur2eigvals(TT)
+    K = len(fact)
+    vectors = _times_complex(fact.basis(), K, U[:, :hm])
+    r = fact.r.get()
+    residuals = [r * U[K - 1, i] for i in range(hm)]
+    normres = np.array([fact.normres * abs(U[K - 1, i]) for i in range(hm)])
+    return TT, vectors, values, ConvergenceInfo(converged, residuals, normres, numiter, numops)
+
+
+def _eigsolve_arnoldi(A, x0, howmany: int, which: str, alg: Arnoldi):
+    """eigsolve(A, x0, howmany, which, alg::Arnoldi) (src/eigsolve/arnoldi.jl:277-316)."""
+    T, U, fact, converged, numiter, numops = _schursolve(A, x0, howmany, which, alg)
+    hm = _arnoldi_howmany(T, fact, howmany, converged)
+    TT = T[:hm, :hm]
+    values = dense.schur2eigvals(TT)
+    V = U[:, :hm] @ dense.schur2eigvecs(TT)                                   # :297
+    K = len(fact)
+    vectors = _times_complex(fact.basis(), K, V)
+    r = fact.r.get()
+    residuals = [r * V[K - 1, i] for i in range(hm)]
+    normres = np.array([fact.normres * abs(V[K - 1, i]) for i in range(hm)])
+    return values, vectors, ConvergenceInfo(converged, residuals, normres, numiter, numops)
 
 
 # -------------------------------------------------------------------- linsolve (GMRES)

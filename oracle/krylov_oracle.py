@@ -1702,3 +1702,173 @@ def expintegrator(A, t: float, u: Sequence[np.ndarray], *, krylovdim: int = 30, 
             numops += 1
             numiter += 1
 
+
+# --------------------------------------------------------------------------------------
+# eigsolve / schursolve with Arnoldi (Krylov-Schur) -- src/eigsolve/arnoldi.jl, dense/linalg.jl:152-383
+# --------------------------------------------------------------------------------------
+def _eigsort_complex(which: str):
+    """eigsort (eigsolve/eigsolve.jl:334-355)."""
+    if which == "LM":
+        return np.abs, True
+    if which == "LR":
+        return np.real, True
+    if which == "SR":
+        return np.real, False
+    if which == "LI":
+        return np.imag, True
+    if which == "SI":
+        return np.imag, False
+    raise ValueError(f"invalid specification of which eigenvalues to target: which = {which}")
+
+
+def _schur_values(T: np.ndarray) -> np.ndarray:
+    """schur2eigvals for real quasi-triangular T (dense/linalg.jl:166-189)."""
+    n = T.shape[0]
+    out = np.zeros(n, dtype=complex)
+    i = 0
+    while i < n:
+        if i + 1 < n and T[i + 1, i] != 0:
+            tr2 = (T[i, i] + T[i + 1, i + 1]) / 2
+            df = (T[i, i] - T[i + 1, i + 1]) / 2
+            disc = df * df + T[i, i + 1] * T[i + 1, i]
+            out[i] = tr2 + 1j * math.sqrt(-disc)
+            out[i + 1] = tr2 - 1j * math.sqrt(-disc)
+            i += 2
+        else:
+            out[i] = T[i, i]
+            i += 1
+    return out
+
+
+def _permute_schur(T: np.ndarray, Q: np.ndarray, order: Sequence[int]):
+    """permuteschur!(T, Q, order) for real T (dense/linalg.jl:356-383) through LAPACK trexc."""
+    from scipy.linalg import lapack
+    n = T.shape[0]
+    p = [k + 1 for k in order]
+    T, Q = np.array(T, order="F"), np.array(Q, order="F")
+    i = 1
+    while i <= len(p):
+        ifirst, ilast = p[i - 1], i
+        if ifirst == n or T[ifirst, ifirst - 1] == 0:
+            T, Q, info = lapack.dtrexc(T, Q, ifirst, ilast)
+            assert info == 0
+            for k in range(i, len(p)):
+                if p[k] < p[i - 1]:
+                    p[k] += 1
+            i += 1
+        else:
+            if p[i] != ifirst + 1:
+                raise RuntimeError("cannot split 2x2 blocks when permuting schur decomposition")
+            T, Q, info = lapack.dtrexc(T, Q, ifirst, ilast)
+            assert info == 0
+            for k in range(i + 1, len(p)):
+                if p[k] < p[i - 1]:
+                    p[k] += 2
+            i += 2
+    return T, Q, _schur_values(T)
+
+
+def _schur_eigvecs(T: np.ndarray) -> np.ndarray:
+    """schur2eigvecs for real T (dense/linalg.jl:223-246): normalised eigenvectors in diagonal order.  LAPACK trevc is
+    not exposed by SciPy; the eigenvectors of the small quasi-triangular matrix come from numpy.linalg.eig, matched
+    to the diagonal order of T (they are unique up to a phase when the eigenvalues are distinct)."""
+    lam = _schur_values(T)
+    w, X = np.linalg.eig(T)
+    n = T.shape[0]
+    out = np.zeros((n, n), dtype=complex)
+    free = list(range(n))
+    for j in range(n):
+        k = min(free, key=lambda q: abs(w[q] - lam[j]))
+        free.remove(k)
+        out[:, j] = X[:, k] / np.linalg.norm(X[:, k])
+    return out
+
+
+def _schursolve_arnoldi(A, x0, howmany, which, krylovdim, maxiter, tol, orth, eager):
+    """_schursolve (eigsolve/arnoldi.jl:361-464)."""
+    import scipy.linalg as sla
+    if howmany > krylovdim:
+        raise ValueError(f"krylov dimension {krylovdim} too small to compute {howmany} eigenvalues")
+    numiter = 1
+    it = ArnoldiIterator(A, np.asarray(x0, dtype=np.float64), orth)
+    fact = arnoldi_initialize(it)
+    numops = 1
+    converged = 0
+    T = U = f = None
+    while True:
+        beta = fact.normres
+        K = len(fact)
+        if K == krylovdim or beta <= tol or (eager and K >= howmany):          # :389
+            T, U = sla.schur(fact.rayleighquotient(), output="real")            # hschur!  :396
+            vals = _schur_values(T)
+            by, rev = _eigsort_complex(which)
+            key = by(vals)
+            perm = np.argsort(-key if rev else key, kind="stable")
+            T, U, vals = _permute_schur(T, U, list(perm))
+            f = U[K - 1, :] * beta                                              # :400
+            converged = 0
+            while converged < K and abs(f[converged]) <= tol:
+                converged += 1
+            if 0 < converged < K and T[converged, converged - 1] != 0:
+                converged -= 1
+            if converged >= howmany or beta <= tol:
+                break
+        if K < krylovdim:
+            fact = arnoldi_expand(it, fact)
+            numops += 1
+        else:
+            if numiter == maxiter:
+                break
+            keep = (3 * krylovdim + 2 * converged) // 5
+            if T[keep, keep - 1] != 0:                                          # :424-436
+                if keep > 1:
+                    keep -= 1
+                else:
+                    keep += 1
+                    if krylovdim == 2:
+                        break
+            H = np.array(T)
+            for j in range(keep):                                               # _restorearnoldiform!  :466-480
+                H[keep, j] = f[j]
+            for j in range(keep, 0, -1):
+                hb, hv, nu = householder_vec(H[j, :j], j - 1)
+                H[j, j - 1] = nu
+                H[j, : j - 1] = 0.0
+                r = np.arange(j)
+                householder_lmul(hb, hv, r, H)
+                householder_rmul_mat(H, hb, hv, r, rows=slice(0, j))
+                householder_rmul_mat(U, hb, hv, r)
+            for j in range(1, K + 1):                                           # copy!(rayleighquotient(fact), H)  :443
+                for i in range(1, min(j + 1, K) + 1):
+                    fact.H[packed_index(i, j)] = float(H[i - 1, j - 1])
+            B = basistransform(list(fact.V[:K]), U[:, :keep])                   # :444
+            for j in range(keep):
+                fact.V[j] = B[j]
+            fact.V[keep] = scale(fact.r, 1.0 / beta)                            # B[keep+1] = scale!!(residual, 1/beta)
+            fact = arnoldi_shrink(fact, keep)
+            numiter += 1
+    return T, U, fact, converged, numiter, numops
+
+
+def eigsolve_arnoldi(A, x0, howmany: int = 1, which: str = "LM", *, krylovdim: int = 30, maxiter: int = 100,
+                     tol: float = 1e-12, orth: Orthogonalizer = MGS2, eager: bool = False):
+    """eigsolve(A, x0, howmany, which, alg::Arnoldi) (eigsolve/arnoldi.jl:277-316): complex eigenvalues, eigenvectors
+    (numpy arrays), ConvergenceInfo."""
+    T, U, fact, converged, numiter, numops = _schursolve_arnoldi(A, x0, howmany, which, krylovdim, maxiter, tol, orth, eager)
+    hm = howmany
+    if howmany < len(fact) and T[howmany, howmany - 1] != 0:
+        hm += 1
+    elif T.shape[0] < howmany:
+        hm = T.shape[0]
+    if converged > howmany:
+        hm = converged
+    TT = T[:hm, :hm]
+    values = _schur_values(TT)
+    V = U[:, :hm] @ _schur_eigvecs(TT)
+    K = len(fact)
+    Bm = np.stack(fact.V[:K], axis=1)
+    vectors = [Bm @ V[:, i] for i in range(hm)]
+    residuals = [fact.r * V[K - 1, i] for i in range(hm)]
+    normres = np.array([fact.normres * abs(V[K - 1, i]) for i in range(hm)])
+    return values, vectors, ConvergenceInfo(converged, residuals, normres, numiter, numops)
+

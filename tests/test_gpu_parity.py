@@ -784,6 +784,34 @@ def test_expintegrator(kk, ko, ctx, method):
         np.testing.assert_allclose(w, wo, rtol=0, atol=1e-10 * np.linalg.norm(wo))
 
 
+@pytest.mark.parametrize("which", ["LM", "LR", "SR"])
+def test_eigsolve_arnoldi(kk, ko, ctx, which):
+    """eigsolve(A, x0, howmany, which, alg::Arnoldi) (eigsolve/arnoldi.jl): Krylov-Schur restarts on the device basis
+    (kk_arnoldi_expand, kk_basistransform) for a real non-symmetric operator with complex-conjugate eigenvalue pairs:
+    same restart / operation counts and eigenvalues as the oracle, eigen-residuals, schursolve relation."""
+    import scipy.sparse as sp
+    n = 500
+    rng = np.random.default_rng(12)
+    A = (sp.random(n, n, density=0.02, random_state=7, format="csr") - 0.5 * sp.random(n, n, density=0.02, random_state=8, format="csr")
+         + sp.diags(np.linspace(-1, 1, n))).tocsr()
+    x0 = rng.random(n)
+    op = kk.SparseOperator(A, ctx)
+    alg = kk.Arnoldi(kk.ModifiedGramSchmidt2(), 30, 50, 1e-10)
+    vals, vecs, info = kk.eigsolve(op, x0, 4, which, alg)
+    ovals, ovecs, oinfo = ko.eigsolve_arnoldi(A, x0, 4, which, krylovdim=30, maxiter=50, tol=1e-10, orth=ko.MGS2)
+    assert info.converged >= 4 and (info.converged, info.numiter, info.numops) == (oinfo.converged, oinfo.numiter, oinfo.numops)
+    assert len(vals) == len(ovals)
+    np.testing.assert_allclose(vals, ovals, rtol=0, atol=1e-9 * np.max(np.abs(ovals)))
+    for lam, v, nr in zip(vals, vecs, info.normres):
+        assert abs(np.linalg.norm(v) - 1) < 1e-9
+        assert np.linalg.norm(A @ v - lam * v) <= max(5 * nr, 1e-9)
+    T, Q, svals, sinfo = kk.schursolve(op, x0, 4, which, alg)
+    Qm = np.stack(Q, axis=1).real
+    np.testing.assert_allclose(Qm.T @ Qm, np.eye(Qm.shape[1]), atol=1e-9)
+    np.testing.assert_allclose(A @ Qm, Qm @ T, atol=1e-8)
+    np.testing.assert_allclose(svals, vals[:len(svals)], rtol=0, atol=1e-9 * np.max(np.abs(ovals)))
+
+
 @pytest.mark.parametrize("mgs_mode", [0, 1])
 def test_mgs_on_non_orthonormal_basis(kk, ko, ctx, mgs_mode):
     """The low-sync form (I + L) s = V'w is exact algebra for ANY basis (MGS never divides by |q|^2):

@@ -474,3 +474,63 @@ def test_expintegrator_fixed_point_branch(ko):
     assert info2.converged > 0
     np.testing.assert_allclose(A @ w2 + v1, np.zeros(n), atol=1e-8)
 
+
+def _sorted_eigs(D):
+    """test/eigsolve.jl:208: sort by imag (rev) then stably by real."""
+    D = np.asarray(D)
+    D = D[np.argsort(-D.imag, kind="stable")]
+    return D[np.argsort(D.real, kind="stable")]
+
+
+@pytest.mark.parametrize("orth_name", ["CGS2", "MGS2", "CGSIR", "MGSIR"])
+def test_arnoldi_eigsolve_full(ko, orth_name):
+    """test/eigsolve.jl:137-214 (Arnoldi - eigsolve full): n1 smallest-real + n2 largest-real values = spectrum."""
+    orth = getattr(ko, orth_name)
+    orth = orth() if callable(orth) else orth
+    rng = np.random.default_rng(41)
+    n = 10
+    A = rng.random((n, n)) - 0.5
+    v = rng.random(n)
+    n1 = n // 2
+    D1, V1, info1 = ko.eigsolve_arnoldi(A, v, n1, "SR", krylovdim=n, maxiter=1, tol=1e-12, orth=orth)
+    n2 = n - n1
+    D2, V2, info2 = ko.eigsolve_arnoldi(A, v, n2, "LR", krylovdim=2 * n, maxiter=1, tol=1e-12, orth=orth)
+    D = _sorted_eigs(np.linalg.eigvals(A))
+    D2s = _sorted_eigs(D2)
+    np.testing.assert_allclose(np.concatenate([D1[:n1], D2s[len(D2s) - n2:]]), D, atol=1e-9)
+    for Dk, Vk in ((D1, V1), (D2, V2)):
+        Uk = np.stack(Vk, axis=1)
+        np.testing.assert_allclose(A @ Uk, Uk * Dk[None, :], atol=1e-9)
+
+
+def test_arnoldi_eigsolve_iteratively(ko):
+    """test/eigsolve.jl:262-330 (Arnoldi - eigsolve iteratively): N = 100, krylovdim = 3n, eager, restarts."""
+    rng = np.random.default_rng(43)
+    N, n = 100, 10
+    A = rng.random((N, N)) - 0.5
+    v = rng.random(N)
+    ev = np.linalg.eigvals(A)
+    ev = ev[np.argsort(-ev.imag, kind="stable")]
+    kw = dict(krylovdim=3 * n, maxiter=20, tol=1e-12, eager=True)
+    D1, V1, info1 = ko.eigsolve_arnoldi(A, v, n, "SR", **kw)
+    D2, V2, info2 = ko.eigsolve_arnoldi(A, v, n, "LR", **kw)
+    D3, V3, info3 = ko.eigsolve_arnoldi(A, v, n, "LM", **kw)
+    l1, l2, l3 = info1.converged, info2.converged, info3.converged
+    assert l1 > 0 and l2 > 0 and l3 > 0
+
+    def close_as_sets(a, b):
+        a, b = list(a), list(b)
+        for z in a:
+            k = int(np.argmin([abs(z - w) for w in b]))
+            assert abs(z - b[k]) < 1e-8 * max(1.0, abs(z))
+            b.pop(k)
+
+    close_as_sets(D1[:l1], ev[np.argsort(ev.real, kind="stable")][:l1])
+    close_as_sets(D2[:l2], ev[np.argsort(-ev.real, kind="stable")][:l2])
+    close_as_sets(D3[:l3], ev[np.argsort(-np.abs(ev), kind="stable")][:l3])
+    for Dk, Vk, infok in ((D1, V1, info1), (D2, V2, info2), (D3, V3, info3)):
+        Uk = np.stack(Vk, axis=1)
+        Rk = np.stack(infok.residual, axis=1)
+        np.testing.assert_allclose(A @ Uk, Uk * Dk[None, :] + Rk, atol=1e-9)     # :318-320
+        assert np.all(infok.normres[:infok.converged] <= 1e-12 * 1.0001)
+
