@@ -405,7 +405,128 @@ static void free_sparse(kk_sparse_dev& M) {
     (void)hipFree(M.ell_col); (void)hipFree(M.ell_val);
     (void)hipFree(M.rowptr); (void)hipFree(M.colind); (void)hipFree(M.val);
     (void)hipFree(M.sell_off); (void)hipFree(M.sell_perm); (void)hipFree(M.sell_col); (void)hipFree(M.sell_val);
+    for (int t = 0; t < M.ntiles; ++t) free_sparse(M.tiles[t]);
+    delete[] M.tiles;
     M = kk_sparse_dev();
+}
+
+// SELL-64-sigma image of a host CSR matrix on the device (fills the sell_* fields of M, sets format = 2)
+static int build_sell(const kk_host_csr& h, kk_sparse_dev& M, int64_t sigma = 64 * 64) {
+    const int64_t nrows = h.nrows;
+    // SELL-64-sigma: sort rows by length inside windows of sigma rows, slice into chunks of 64
+    M.format = 2;
+    M.sell_sigma = sigma;
+    const int64_t C = 64;
+    const int64_t nchunks = (nrows + C - 1) / C;
+    std::vector<int32_t> perm((size_t)nchunks * C, -1);
+    std::vector<int32_t> order(nrows);
+    for (int64_t i = 0; i < nrows; ++i) order[i] = (int32_t)i;
+    for (int64_t w0 = 0; w0 < nrows; w0 += sigma) {
+        const int64_t w1 = std::min(nrows, w0 + sigma);
+        std::stable_sort(order.begin() + w0, order.begin() + w1, [&](int32_t a, int32_t b) {
+            return (h.rowptr[a + 1] - h.rowptr[a]) > (h.rowptr[b + 1] - h.rowptr[b]);
+        });
+    }
+    for (int64_t i = 0; i < nrows; ++i) perm[i] = order[i];
+    std::vector<int64_t> coff(nchunks + 1, 0);
+    for (int64_t c = 0; c < nchunks; ++c) {
+        int64_t wmax = 0;
+        for (int64_t l = 0; l < C; ++l) {
+            const int32_t r = perm[c * C + l];
+            if (r >= 0) wmax = std::max(wmax, h.rowptr[r + 1] - h.rowptr[r]);
+        }
+        coff[c + 1] = coff[c] + wmax * C;
+    }
+    const int64_t total = coff[nchunks];
+    std::vector<int32_t> sc((size_t)std::max<int64_t>(total, 1), 0);
+    std::vector<double> sv((size_t)std::max<int64_t>(total, 1), 0.0);
+    for (int64_t c = 0; c < nchunks; ++c)
+        for (int64_t l = 0; l < C; ++l) {
+            const int32_t r = perm[c * C + l];
+            if (r < 0) continue;
+            int64_t k = 0;
+            for (int64_t p = h.rowptr[r]; p < h.rowptr[r + 1]; ++p, ++k) {
+                sc[coff[c] + k * C + l] = h.col[p];
+                sv[coff[c] + k * C + l] = h.val[p];
+            }
+        }
+    M.sell_nchunks = nchunks;
+    KK_HIP(hipMalloc(&M.sell_off, (nchunks + 1) * sizeof(int64_t)));
+    KK_HIP(hipMalloc(&M.sell_perm, perm.size() * sizeof(int32_t)));
+    KK_HIP(hipMalloc(&M.sell_col, sc.size() * sizeof(int32_t)));
+    KK_HIP(hipMalloc(&M.sell_val, sv.size() * sizeof(double)));
+    KK_HIP(hipMemcpy(M.sell_off, coff.data(), (nchunks + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+    KK_HIP(hipMemcpy(M.sell_perm, perm.data(), perm.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    KK_HIP(hipMemcpy(M.sell_col, sc.data(), sc.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    KK_HIP(hipMemcpy(M.sell_val, sv.data(), sv.size() * sizeof(double), hipMemcpyHostToDevice));
+    M.bytes = (nchunks + 1) * 8 + perm.size() * 4 + sc.size() * 12;
+    return KK_OK;
+}
+
+// Column-tiled SELL for operators whose gathers have no locality (rows touching columns all over a vector that does
+// not fit the 4 MB L2 of an XCD, e.g. the random rectangular map of the GKL configuration and its transpose): the
+// columns are cut into tiles of `tile_cols`, every tile is its own SELL matrix over ALL rows, and an apply runs the
+// tiles one after the other accumulating into y, so that each launch gathers from one L2-resident slice of x.
+static int build_tiled(const kk_host_csr& h, int64_t tile_cols, kk_sparse_dev& M) {
+    const int64_t nrows = h.nrows, nnz = h.rowptr[nrows];
+    const int T = (int)((h.ncols + tile_cols - 1) / tile_cols);
+    M.format = 3;
+    M.ntiles = T;
+    M.tiles = new kk_sparse_dev[T];
+    M.tile_cols = tile_cols;
+    // pass 1: entries per (tile, row); pass 2: scatter into per-tile CSR
+    std::vector<kk_host_csr> ht(T);
+    for (int t = 0; t < T; ++t) {
+        ht[t].nrows = nrows; ht[t].ncols = h.ncols;
+        ht[t].rowptr.assign(nrows + 1, 0);
+    }
+    for (int64_t i = 0; i < nrows; ++i)
+        for (int64_t p = h.rowptr[i]; p < h.rowptr[i + 1]; ++p) ht[h.col[p] / tile_cols].rowptr[i + 1]++;
+    for (int t = 0; t < T; ++t) {
+        for (int64_t i = 0; i < nrows; ++i) ht[t].rowptr[i + 1] += ht[t].rowptr[i];
+        ht[t].col.resize(ht[t].rowptr[nrows]);
+        ht[t].val.resize(ht[t].rowptr[nrows]);
+    }
+    {
+        std::vector<int64_t> cur(T);
+        for (int64_t i = 0; i < nrows; ++i) {
+            for (int t = 0; t < T; ++t) cur[t] = ht[t].rowptr[i];
+            for (int64_t p = h.rowptr[i]; p < h.rowptr[i + 1]; ++p) {
+                const int t = (int)(h.col[p] / tile_cols);
+                const int64_t q = cur[t]++;
+                ht[t].col[q] = h.col[p];
+                ht[t].val[q] = h.val[p];
+            }
+        }
+    }
+    M.bytes = 0;
+    for (int t = 0; t < T; ++t) {
+        kk_sparse_dev& S = M.tiles[t];
+        S.nrows = nrows; S.ncols = h.ncols; S.nnz = ht[t].rowptr[nrows];
+        KK_TRY(build_sell(ht[t], S, KK_TPB));   // sigma = the 256 rows of one thread block: k_spmv_sellw
+        M.bytes += S.bytes;
+        kk_host_csr().rowptr.swap(ht[t].rowptr);
+        std::vector<int32_t>().swap(ht[t].col);
+        std::vector<double>().swap(ht[t].val);
+    }
+    (void)nnz;
+    return KK_OK;
+}
+
+// mean distance between the smallest and the largest column index of a row (sampled): small for stencils / banded
+// operators whose gathers are cache friendly as they are, ~ncols for random sparsity
+static double mean_row_span(const kk_host_csr& h) {
+    const int64_t step = std::max<int64_t>(1, h.nrows / 65536);
+    double sum = 0;
+    int64_t cnt = 0;
+    for (int64_t i = 0; i < h.nrows; i += step) {
+        if (h.rowptr[i + 1] == h.rowptr[i]) continue;
+        int32_t lo = h.col[h.rowptr[i]], hi = lo;
+        for (int64_t p = h.rowptr[i]; p < h.rowptr[i + 1]; ++p) { lo = std::min(lo, h.col[p]); hi = std::max(hi, h.col[p]); }
+        sum += (double)(hi - lo);
+        ++cnt;
+    }
+    return cnt ? sum / cnt : 0.0;
 }
 
 static int upload_sparse(kk_ctx c, const kk_host_csr& h, kk_sparse_dev& M) {
@@ -419,6 +540,13 @@ static int upload_sparse(kk_ctx c, const kk_host_csr& h, kk_sparse_dev& M) {
     const bool force_ell = getenv("KK_SPMV_FORMAT") && !strcmp(getenv("KK_SPMV_FORMAT"), "ell");
     const bool force_sell = getenv("KK_SPMV_FORMAT") && !strcmp(getenv("KK_SPMV_FORMAT"), "sell");
     const bool ell = !force_csr && !force_sell && (force_ell || (maxw <= 64 && (double)maxw * nrows <= 1.25 * (double)nnz + 4096));
+    // column tiling: default tile = 3 MB of the gathered vector (an XCD's L2 is 4 MB; measured optimum on the
+    // config-4 operator, flat between 2 and 4 MB); KK_SPMV_TILE_COLS overrides (0 = never)
+    int64_t tile_cols = 393216;
+    if (const char* tc = getenv("KK_SPMV_TILE_COLS")) tile_cols = atoll(tc);
+    const bool fmt_forced = force_csr || force_ell || force_sell;
+    if (!fmt_forced && tile_cols > 0 && 2 * h.ncols > 3 * tile_cols && nnz > 0 && mean_row_span(h) > 1.5 * (double)tile_cols)
+        return build_tiled(h, tile_cols, M);
     if (ell) {
         M.format = 0;
         M.width = (int)std::max<int64_t>(maxw, 1);
@@ -438,52 +566,7 @@ static int upload_sparse(kk_ctx c, const kk_host_csr& h, kk_sparse_dev& M) {
         KK_HIP(hipMemcpy(M.ell_val, ev.data(), ev.size() * sizeof(double), hipMemcpyHostToDevice));
         M.bytes = ec.size() * 4 + ev.size() * 8;
     } else if (!force_csr) {
-        // SELL-64-sigma: sort rows by length inside windows of sigma rows, slice into chunks of 64
-        M.format = 2;
-        const int64_t C = 64, sigma = 64 * 64;
-        const int64_t nchunks = (nrows + C - 1) / C;
-        std::vector<int32_t> perm((size_t)nchunks * C, -1);
-        std::vector<int32_t> order(nrows);
-        for (int64_t i = 0; i < nrows; ++i) order[i] = (int32_t)i;
-        for (int64_t w0 = 0; w0 < nrows; w0 += sigma) {
-            const int64_t w1 = std::min(nrows, w0 + sigma);
-            std::stable_sort(order.begin() + w0, order.begin() + w1, [&](int32_t a, int32_t b) {
-                return (h.rowptr[a + 1] - h.rowptr[a]) > (h.rowptr[b + 1] - h.rowptr[b]);
-            });
-        }
-        for (int64_t i = 0; i < nrows; ++i) perm[i] = order[i];
-        std::vector<int64_t> coff(nchunks + 1, 0);
-        for (int64_t c = 0; c < nchunks; ++c) {
-            int64_t wmax = 0;
-            for (int64_t l = 0; l < C; ++l) {
-                const int32_t r = perm[c * C + l];
-                if (r >= 0) wmax = std::max(wmax, h.rowptr[r + 1] - h.rowptr[r]);
-            }
-            coff[c + 1] = coff[c] + wmax * C;
-        }
-        const int64_t total = coff[nchunks];
-        std::vector<int32_t> sc((size_t)std::max<int64_t>(total, 1), 0);
-        std::vector<double> sv((size_t)std::max<int64_t>(total, 1), 0.0);
-        for (int64_t c = 0; c < nchunks; ++c)
-            for (int64_t l = 0; l < C; ++l) {
-                const int32_t r = perm[c * C + l];
-                if (r < 0) continue;
-                int64_t k = 0;
-                for (int64_t p = h.rowptr[r]; p < h.rowptr[r + 1]; ++p, ++k) {
-                    sc[coff[c] + k * C + l] = h.col[p];
-                    sv[coff[c] + k * C + l] = h.val[p];
-                }
-            }
-        M.sell_nchunks = nchunks;
-        KK_HIP(hipMalloc(&M.sell_off, (nchunks + 1) * sizeof(int64_t)));
-        KK_HIP(hipMalloc(&M.sell_perm, perm.size() * sizeof(int32_t)));
-        KK_HIP(hipMalloc(&M.sell_col, sc.size() * sizeof(int32_t)));
-        KK_HIP(hipMalloc(&M.sell_val, sv.size() * sizeof(double)));
-        KK_HIP(hipMemcpy(M.sell_off, coff.data(), (nchunks + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
-        KK_HIP(hipMemcpy(M.sell_perm, perm.data(), perm.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-        KK_HIP(hipMemcpy(M.sell_col, sc.data(), sc.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-        KK_HIP(hipMemcpy(M.sell_val, sv.data(), sv.size() * sizeof(double), hipMemcpyHostToDevice));
-        M.bytes = (nchunks + 1) * 8 + perm.size() * 4 + sc.size() * 12;
+        KK_TRY(build_sell(h, M));
     } else {
         M.format = 1;
         std::vector<int32_t> rp(nrows + 1);

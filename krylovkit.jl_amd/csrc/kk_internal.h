@@ -132,7 +132,8 @@ struct kk_basis_s {
 };
 
 struct kk_sparse_dev {  // one direction (A or A') on the device
-    int format = -1;    // 0 = ELL (column-major, padded), 1 = CSR, 2 = SELL-64-sigma (sliced ELL, rows sorted by length inside sigma-row windows)
+    int format = -1;    // 0 = ELL (column-major, padded), 1 = CSR, 2 = SELL-64-sigma (sliced ELL, rows sorted by length inside
+                        // sigma-row windows), 3 = column-tiled SELL (`tiles`, each of format 2 over all rows)
     int64_t nrows = 0, ncols = 0, nnz = 0;
     // ELL
     int width = 0;
@@ -146,10 +147,15 @@ struct kk_sparse_dev {  // one direction (A or A') on the device
     int lanes_per_row = 4;
     // SELL-C-sigma (C = 64 rows per chunk = one wavefront)
     int64_t sell_nchunks = 0;
+    int64_t sell_sigma = 0;        // sorting window (rows); == KK_TPB selects the window kernel k_spmv_sellw
     int64_t* sell_off = nullptr;   // [nchunks + 1] element offset of each chunk
     int32_t* sell_perm = nullptr;  // [nchunks * 64] original row of each slot (-1 = padding slot)
     int32_t* sell_col = nullptr;
     double* sell_val = nullptr;
+    // column tiles (format 3)
+    int ntiles = 0;
+    int64_t tile_cols = 0;
+    kk_sparse_dev* tiles = nullptr;
     // ghost columns (row-sharded operators)
     int64_t n_local = -1, n_ghost = 0;
     double* ghost = nullptr;

@@ -716,6 +716,22 @@ __global__ __launch_bounds__(KK_TPB) void k_mgs_step(double* __restrict__ w, int
 //   dot = <x, ax> (mode 1)  or <x, y> (mode 2)    nrm2 = |y|^2
 // Column indices >= n_local address the ghost buffer (row-sharded operators).
 // ------------------------------------------------------------------------------------------
+// streamed-once matrix entries (SELL): scalar non-temporal loads, so that they do not evict the gathered slice of x
+__device__ __forceinline__ int ldc(const int32_t* p) {
+#ifndef KK_NO_NT_LOADS
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ double ldv(const double* p) {
+#ifndef KK_NO_NT_LOADS
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+
 struct spmv_epi {
     double a1, a0, bprev;
     const double* xs_dev;
@@ -726,6 +742,8 @@ struct spmv_epi {
     int64_t n_local;  // < 0: no ghost
     const double* ghost;
     const double* dvec;  // dot_mode 3: <dvec, y>
+    int acc;             // column-tiled apply: 0 = whole matrix, 1 = first tile (y = raw sums), 2 = middle tile
+                         // (y += raw sums), 3 = last tile (sum = y + raw, then the epilogue)
 };
 
 __device__ __forceinline__ double xload(const double* __restrict__ x, const spmv_epi& e, int c) {
@@ -856,17 +874,21 @@ __global__ __launch_bounds__(KK_TPB) void k_spmv_sell(const int64_t* __restrict_
         double s0 = 0, s1 = 0;
         int k = 0;
         for (; k + 4 <= w; k += 4) {
-            const int c0 = cp[(k + 0) * 64], c1 = cp[(k + 1) * 64], c2 = cp[(k + 2) * 64], c3 = cp[(k + 3) * 64];
-            const double v0 = vp[(k + 0) * 64], v1 = vp[(k + 1) * 64], v2 = vp[(k + 2) * 64], v3 = vp[(k + 3) * 64];
+            const int c0 = ldc(cp + (k + 0) * 64), c1 = ldc(cp + (k + 1) * 64), c2 = ldc(cp + (k + 2) * 64), c3 = ldc(cp + (k + 3) * 64);
+            const double v0 = ldv(vp + (k + 0) * 64), v1 = ldv(vp + (k + 1) * 64), v2 = ldv(vp + (k + 2) * 64), v3 = ldv(vp + (k + 3) * 64);
             s0 = fma(v0, xload(x, e, c0), s0);
             s1 = fma(v1, xload(x, e, c1), s1);
             s0 = fma(v2, xload(x, e, c2), s0);
             s1 = fma(v3, xload(x, e, c3), s1);
         }
-        for (; k < w; ++k) s0 = fma(vp[k * 64], xload(x, e, cp[k * 64]), s0);
+        for (; k < w; ++k) s0 = fma(ldv(vp + k * 64), xload(x, e, ldc(cp + k * 64)), s0);
         const int row = perm[c * 64 + lane];
         if (row >= 0) {
-            const double s = (s0 + s1) * xs;
+            double raw = s0 + s1;
+            if (e.acc == 1) { y[row] = raw; continue; }
+            if (e.acc == 2) { y[row] += raw; continue; }
+            if (e.acc == 3) raw += y[row];
+            const double s = raw * xs;
             double out = e.a1 * s;
             double xv = 0;
             if (e.a0 != 0.0 || e.dot_mode == 1 || e.dot_mode == 2) xv = x[row] * xs;
@@ -878,6 +900,94 @@ __global__ __launch_bounds__(KK_TPB) void k_spmv_sell(const int64_t* __restrict_
             if (e.want_nrm) nacc = fma(out, out, nacc);
             y[row] = out;
         }
+    }
+    if (e.dot_mode) {
+        double t = block_sum(dacc, sm);
+        if (threadIdx.x == 0) part_dot[blockIdx.x] = t;
+    }
+    if (e.want_nrm) {
+        double t = block_sum(nacc, sm);
+        if (threadIdx.x == 0) part_nrm[blockIdx.x] = t;
+    }
+}
+
+// Window variant of the SELL kernel for sigma = 256 = the rows of one thread block (used by the column tiles, where
+// a row has only a handful of entries per tile and the row-sorted result order would turn the y update into
+// scattered 8-byte accesses): the four waves compute the raw sums of the four chunks of a 256-row window in the sorted
+// order, park them in LDS under the row's position in the window, and after a barrier thread t finishes row
+// base + t -- y, x, v_prev and the inner-product operands are all read and written coalesced.
+__global__ __launch_bounds__(KK_TPB) void k_spmv_sellw(const int64_t* __restrict__ coff, const int32_t* __restrict__ perm,
+                                                       const int32_t* __restrict__ scol, const double* __restrict__ sval,
+                                                       int64_t nchunks, int64_t nrows, const double* __restrict__ x,
+                                                       double* __restrict__ y, spmv_epi e, double* __restrict__ part_dot,
+                                                       double* __restrict__ part_nrm) {
+    __shared__ double res[KK_TPB];
+    __shared__ double sm[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double dacc = 0, nacc = 0;
+    const double xs = e.xs_dev ? *e.xs_dev : 1.0;
+    const double bp = e.vprev ? (e.bprev_dev ? *e.bprev_dev : e.bprev) : 0.0;
+    const int64_t nwin = (nchunks + 3) >> 2;
+    // the chunk descriptor of the NEXT window is fetched while the current one is processed, and the old y of the
+    // accumulating tiles is requested before the gathers: two of the four dependent memory round trips per window go
+    int64_t win = blockIdx.x;
+    int64_t off = 0, offn = 0;
+    int32_t prow = -1;
+    if (win < nwin && win * 4 + wave < nchunks) {
+        off = coff[win * 4 + wave]; offn = coff[win * 4 + wave + 1];
+        prow = perm[(win * 4 + wave) * 64 + lane];
+    }
+    for (; win < nwin; win += gridDim.x) {
+        const int64_t c = win * 4 + wave;
+        const int64_t row = win * KK_TPB + tid;
+        double yold = 0.0;
+        if (e.acc >= 2 && row < nrows) yold = y[row];
+        const int64_t wnext = win + gridDim.x;
+        int64_t off2 = 0, offn2 = 0;
+        int32_t prow2 = -1;
+        if (wnext < nwin && wnext * 4 + wave < nchunks) {
+            off2 = coff[wnext * 4 + wave]; offn2 = coff[wnext * 4 + wave + 1];
+            prow2 = perm[(wnext * 4 + wave) * 64 + lane];
+        }
+        if (c < nchunks) {
+            const int w = (int)((offn - off) >> 6);
+            const int32_t* cp = scol + off + lane;
+            const double* vp = sval + off + lane;
+            double s0 = 0, s1 = 0;
+            int k = 0;
+            for (; k + 4 <= w; k += 4) {
+                const int c0 = ldc(cp + (k + 0) * 64), c1 = ldc(cp + (k + 1) * 64), c2 = ldc(cp + (k + 2) * 64), c3 = ldc(cp + (k + 3) * 64);
+                const double v0 = ldv(vp + (k + 0) * 64), v1 = ldv(vp + (k + 1) * 64), v2 = ldv(vp + (k + 2) * 64), v3 = ldv(vp + (k + 3) * 64);
+                s0 = fma(v0, xload(x, e, c0), s0);
+                s1 = fma(v1, xload(x, e, c1), s1);
+                s0 = fma(v2, xload(x, e, c2), s0);
+                s1 = fma(v3, xload(x, e, c3), s1);
+            }
+            for (; k < w; ++k) s0 = fma(ldv(vp + k * 64), xload(x, e, ldc(cp + k * 64)), s0);
+            if (prow >= 0) res[prow - win * KK_TPB] = s0 + s1;
+        }
+        __syncthreads();
+        if (row < nrows) {
+            double raw = res[tid];
+            if (e.acc == 1) y[row] = raw;
+            else if (e.acc == 2) y[row] = yold + raw;
+            else {
+                if (e.acc == 3) raw += yold;
+                const double s = raw * xs;
+                double out = e.a1 * s;
+                double xv = 0;
+                if (e.a0 != 0.0 || e.dot_mode == 1 || e.dot_mode == 2) xv = x[row] * xs;
+                if (e.a0 != 0.0) out = fma(e.a0, xv, out);
+                if (e.dot_mode == 1) dacc = fma(xv, out, dacc);
+                if (e.vprev) out = fma(-bp, e.vprev[row], out);
+                if (e.dot_mode == 2) dacc = fma(xv, out, dacc);
+                if (e.dot_mode == 3) dacc = fma(e.dvec[row], out, dacc);
+                if (e.want_nrm) nacc = fma(out, out, nacc);
+                y[row] = out;
+            }
+        }
+        __syncthreads();
+        off = off2; offn = offn2; prow = prow2;
     }
     if (e.dot_mode) {
         double t = block_sum(dacc, sm);
@@ -1404,15 +1514,30 @@ int kk_launch_spmv(kk_ctx ctx, const kk_sparse_dev& M, const double* x, double* 
     e.n_local = M.n_ghost > 0 ? M.n_local : -1;
     e.ghost = M.ghost;
     e.dvec = f.dot_vec;
+    e.acc = 0;
     double* pd = part_row(ctx, PART_SCAL_A);
     double* pn = part_row(ctx, PART_SCAL_B);
     int nblk = 0;
-    std::unique_ptr<kk_prof_scope> ps(new kk_prof_scope(ctx, M.format == 0 ? "k_spmv_ell" : (M.format == 2 ? "k_spmv_sell" : "k_spmv_csr")));
+    std::unique_ptr<kk_prof_scope> ps(new kk_prof_scope(ctx, M.format == 0 ? "k_spmv_ell" : (M.format >= 2 ? "k_spmv_sell" : "k_spmv_csr")));
     if (M.format == 2) {
         nblk = (int)std::min<int64_t>((M.sell_nchunks + 3) / 4, (int64_t)ctx->num_cus * 16);
         if (nblk < 1) nblk = 1;
         hipLaunchKernelGGL(k_spmv_sell, dim3(nblk), dim3(KK_TPB), 0, ctx->stream, M.sell_off, M.sell_perm, M.sell_col, M.sell_val,
                            M.sell_nchunks, x, y, e, pd, pn);
+    } else if (M.format == 3) {
+        // column tiles one after the other: tile t gathers from the L2-resident slice [t, t+1) * tile_cols of x and
+        // accumulates into y; the epilogue (scaling, a0 x, - beta v_prev, inner products) runs with the last tile
+        if (f.vprev == y) { ps.reset(); kk_set_error("tiled spmv: v_prev must not alias y"); return KK_ERR_INVALID; }
+        for (int t = 0; t < M.ntiles; ++t) {
+            const kk_sparse_dev& S = M.tiles[t];
+            spmv_epi et = e;
+            et.acc = M.ntiles == 1 ? 0 : (t == 0 ? 1 : (t == M.ntiles - 1 ? 3 : 2));
+            if (et.acc == 1 || et.acc == 2) { et.dot_mode = 0; et.want_nrm = 0; }
+            nblk = (int)std::min<int64_t>((S.sell_nchunks + 3) / 4, (int64_t)ctx->num_cus * 16);
+            if (nblk < 1) nblk = 1;
+            hipLaunchKernelGGL(k_spmv_sellw, dim3(nblk), dim3(KK_TPB), 0, ctx->stream, S.sell_off, S.sell_perm, S.sell_col, S.sell_val,
+                               S.sell_nchunks, S.nrows, x, y, et, pd, pn);
+        }
     } else if (M.format == 0) {
         const int nb_logical = (int)((M.nrows + 2 * KK_TPB - 1) / (2 * KK_TPB));
         const int per = (nb_logical + 7) / 8;

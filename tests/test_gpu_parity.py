@@ -189,6 +189,60 @@ def test_spmv_format_forced(kk, ko, ctx, monkeypatch, fmt):
         assert relerr(f.alphas, of.alphas) < 1e-10 and relerr(f.betas, of.betas) < 1e-10
 
 
+@pytest.mark.parametrize("tile_cols", [64, 1000])
+def test_spmv_column_tiled(kk, ko, ctx, monkeypatch, tile_cols):
+    """Column-tiled SELL (the format chosen for operators whose gathers have no locality; forced onto small matrices
+    by shrinking the tile): plain / adjoint / affine apply, the fused Lanczos epilogue (dot modes, v_prev, norm),
+    the GKL recurrence on a rectangular map, rows that are empty in some tiles, banded matrices stay untiled."""
+    monkeypatch.setenv("KK_SPMV_TILE_COLS", str(tile_cols))
+    rng = np.random.default_rng(21)
+    n = 5000
+    d = rng.integers(0, 40, size=n)
+    d[::7] = 0                                                   # empty rows
+    rows = np.repeat(np.arange(n), d)
+    Ar = sp.csr_matrix((rng.standard_normal(rows.size), (rows, rng.integers(0, n, rows.size))), shape=(n, n))
+    S = (Ar + Ar.T).tocsr()
+    op = kk.SparseOperator(S, ctx, symmetric=True)
+    assert op.info()["format"] == "SELL-tiled"
+    if tile_cols == 1000:
+        assert kk.SparseOperator(ko.laplacian_2d(100, 80), ctx).info()["format"] == "ELL"   # banded (span 200): no tiling
+    x = rng.standard_normal(n)
+    X = kk.DeviceBasis(n, 3, ctx)
+    op.apply(X[0].set(x), X[1])
+    scale = np.abs(S) @ np.abs(x) + 1e-300
+    assert np.max(np.abs(X[1].get() - S @ x) / scale) < 1e-14
+    op.apply_affine(X[0], X[2], 0.7, -1.3)
+    np.testing.assert_allclose(X[2].get(), 0.7 * x - 1.3 * (S @ x), rtol=1e-12, atol=1e-12)
+    x0 = rng.random(n)
+    for dev, ref in ((kk.ClassicalGramSchmidt2(), ko.CGS2), (kk.ModifiedGramSchmidt2(), ko.MGS2)):
+        it = kk.LanczosIterator(op, x0, dev, capacity=14)
+        f = kk.initialize(it)
+        oit = ko.LanczosIterator(S, x0.copy(), ref)
+        of = ko.lanczos_initialize(oit)
+        for _ in range(10):
+            f = kk.expand_(it, f)
+            of = ko.lanczos_expand(oit, of)
+        assert relerr(f.alphas, of.alphas) < 1e-10 and relerr(f.betas, of.betas) < 1e-10
+    # rectangular map and its transpose (both tiled), GKL recurrence
+    R = sp.random(4000, 3500, density=0.01, random_state=5, format="csr")
+    rop = kk.SparseOperator(R, ctx)
+    assert rop.info()["format"] == "SELL-tiled"
+    U, V = kk.DeviceBasis(4000, 1, ctx), kk.DeviceBasis(3500, 1, ctx)
+    u = rng.standard_normal(4000)
+    rop.apply_adjoint(U[0].set(u), V[0])
+    scale = np.abs(R.T) @ np.abs(u) + 1e-300
+    assert np.max(np.abs(V[0].get() - R.T @ u) / scale) < 1e-14
+    u0 = rng.random(4000)
+    it = kk.GKLIterator(rop, u0, kk.ModifiedGramSchmidt2(), capacity=12)
+    f = kk.initialize(it)
+    oit = ko.GKLIterator(R, u0.copy(), ko.MGS2)
+    of = ko.gkl_initialize(oit)
+    for _ in range(8):
+        f = kk.expand_(it, f)
+        of = ko.gkl_expand(oit, of)
+    assert relerr(f.alphas, of.alphas) < 1e-10 and relerr(f.betas, of.betas) < 1e-10
+
+
 @pytest.mark.parametrize("mgs_mode", [0, 1])
 def test_lanczos_factorization(kk, ko, ctx, mgs_mode):
     """test/factorize.jl:140-148 invariants after every expand! + (alpha, beta) parity with the oracle."""
