@@ -833,3 +833,193 @@ def lssolve(A, b, alg: Optional[LSMR] = None, lam: float = 0.0, *, rtol: float =
         if numiter >= maxiter:
             return result(0)
 
+
+
+# -------------------------------------------------------------------- geneigsolve (Golub-Ye)
+@dataclass
+class GolubYe:  # algorithms.jl:310-325
+    orth: Orthogonalizer = KrylovDefaults.orth
+    krylovdim: int = KrylovDefaults.krylovdim
+    maxiter: int = KrylovDefaults.maxiter
+    tol: float = KrylovDefaults.tol
+    verbosity: int = 0
+
+
+def _checkposdef(z: float) -> float:  # KrylovKit.jl:143-148
+    if not z > 0:
+        raise ValueError(f"operator does not appear to be positive definite: diagonal element {z}")
+    return z
+
+
+def geneigsolve(AB, x0, howmany: int = 1, which: str = "SR", alg: Optional[GolubYe] = None, **kw):
+    """geneigsolve((A, B), x0, howmany, which, alg::GolubYe) (src/eigsolve/golubye.jl:1-180) for a real symmetric A and a
+    symmetric positive definite B, both device sparse operators.  The inner iteration is the Lanczos recurrence of
+    A - rho B on the device basis (two SpMVs + the same orthogonalisation passes per step, golubye.jl:182-281); the
+    projected K x K pencil is solved on the host (LAPACK sygvd through SciPy, as the reference does)."""
+    from .core import ClassicalGramSchmidt, ModifiedGramSchmidt
+    from .factorizations import Block, block_inner
+    alg = alg or GolubYe(**kw)
+    if which in ("LI", "SI"):
+        raise ValueError(f"Eigenvalue selector which = {which} invalid: real eigenvalues expected with Lanczos algorithm")
+    A, B = (_as_operator(M) for M in AB)
+    krylovdim, maxiter, tol, orth = alg.krylovdim, alg.maxiter, alg.tol, alg.orth
+    if howmany > krylovdim:
+        raise ValueError(f"krylov dimension {krylovdim} too small to compute {howmany} eigenvalues")
+    n, ctx = A.shape[0], A.ctx
+    cap = krylovdim + 2
+    V, BV = DeviceBasis(n, cap, ctx), DeviceBasis(n, cap, ctx)
+    Xv, Xr = DeviceBasis(n, cap, ctx), DeviceBasis(n, cap, ctx)     # Ritz vectors / residuals of the last process step
+    S = DeviceBasis(n, 5, ctx)                                      # scratch: av, bv, vold, tmp, r
+    av, bv, vold, tmp, rs = (HipVec(S, i) for i in range(5))
+    CGS, MGS = ClassicalGramSchmidt(), ModifiedGramSchmidt()
+    name = orth.name
+
+    v = HipVec(V, 0).set(np.asarray(x0, dtype=np.float64))
+    A.apply(v, av); B.apply(v, bv)                                  # genapply  :7
+    numops = 1
+    beta0 = v.norm()
+    if beta0 == 0:
+        raise ValueError("initial vector should not have norm zero")
+    xax, xbx = v.inner(av) / beta0 ** 2, v.inner(bv) / beta0 ** 2
+    v.scale_(1 / beta0); av.scale_(1 / beta0); bv.scale_(1 / beta0)
+    rho = xax / _checkposdef(xbx)
+    r = rs.scale_from_(av, 1.0).add_(bv, -rho)                      # r = av - rho bv   :21
+    HipVec(BV, 0).scale_from_(bv, 1.0)
+    vold.scale_from_(v, 1.0)
+    V.length = BV.length = 1
+    HHA = np.zeros((krylovdim + 1, krylovdim + 1))
+    numiter = 1
+    alpha, beta = r.orthogonalize_against_(v, orth)                 # :44-45
+    converged = 0
+    values: List[float] = []
+    nvec = 0
+    normres: List[float] = []
+    K = 1
+    HHA[0, 0] = alpha
+    by, rev = dense.eigsort(which)
+    cur_v = cur_bv = None                                           # (v, bv) of the last Ritz pair looked at
+
+    def recurrence(Kc, beta_old):
+        """golubyerecurrence (:182-281) for V[Kc-1] = v; leaves w in `rs`, B v in BV[Kc-1]; returns (alpha, beta)."""
+        nonlocal numops
+        vK, vprev = HipVec(V, Kc - 1), HipVec(V, Kc - 2)
+        bvK = HipVec(BV, Kc - 1)
+        A.apply(vK, rs); B.apply(vK, bvK)
+        numops += 1
+        w = rs.add_(bvK, -rho)
+        if name in ("cgs", "cgs2", "cgsir"):
+            a = vK.inner(w)
+            w.add_(vprev, -beta_old)
+            w.add_(vK, -a)
+            if name == "cgs":
+                return a, w.norm()
+            if name == "cgs2":
+                s, b, _ = V.orthogonalize(w, CGS, 0, Kc)
+                return a + s[-1], b
+            ab2 = a * a + beta_old * beta_old
+            b = w.norm()
+            nold = math.sqrt(b * b + ab2)
+            while np.finfo(float).eps < b < orth.eta * nold:
+                nold = b
+                s, b, _ = V.orthogonalize(w, CGS, 0, Kc)
+                a += s[-1]
+            return a, b
+        w.add_(vprev, -beta_old)
+        a, b = w.orthogonalize_against_(vK, MGS)
+        if name == "mgs":
+            return a, b
+        if name == "mgs2":
+            s, b, _ = V.orthogonalize(w, MGS, 0, Kc)                 # for q in V: orthogonalize!!(w, q, MGS); s = last
+            return a + s[-1], b
+        ab2 = a * a + beta_old * beta_old
+        nold = math.sqrt(b * b + ab2)
+        while np.finfo(float).eps < b < orth.eta * nold:
+            nold = b
+            s, b, _ = V.orthogonalize(w, MGS, 0, Kc)
+            a += s[-1]
+        return a, b
+
+    def extend(vn: HipVec):
+        """push a new (already orthonormalised) vector and its row / column of HHA   (:66-81 / :85-95)"""
+        nonlocal K, numops
+        A.apply(vn, av); B.apply(vn, bv)
+        numops += 1
+        av.add_(bv, -rho)
+        h = V.project(av, 0, K)
+        HHA[:K, K] = h
+        HHA[K, :K] = h
+        HHA[K, K] = vn.inner(av)
+        HipVec(V, K).scale_from_(vn, 1.0)
+        HipVec(BV, K).scale_from_(bv, 1.0)
+        K += 1
+        V.length = BV.length = K
+
+    while True:
+        beta = r.norm()
+        if beta <= tol and K < howmany:                             # :59-67
+            howmany = K
+        if K == krylovdim - converged or beta <= tol:               # process  :68
+            if numiter > 1:
+                V.orthonormalize(vold, orth, 0, K)                  # orthonormalize!!(vold, V)   :64
+                extend(vold)
+            for i in range(converged):                              # re-add the converged Ritz vectors   :83-96
+                tmp.scale_from_(HipVec(Xv, i), 1.0)
+                V.orthonormalize(tmp, orth, 0, K)
+                extend(tmp)
+            M = block_inner(Block(V, 0, K), Block(BV, 0, K))        # buildHB!  :284-295
+            HB = np.tril(M) + np.tril(M, -1).T
+            for j in range(K):
+                _checkposdef(HB[j, j])
+            HA = HHA[:K, :K] + rho * HB
+            import scipy.linalg as sla
+            D, Z = sla.eigh(HA, HB)                                  # geneigh!  :102
+            key = by(D)
+            perm = np.argsort(-key if rev else key, kind="stable")
+            converged = 0
+            values, normres, nvec = [], [], 0
+            for k in range(K):                                      # :110-133
+                z = np.ascontiguousarray(Z[:, perm[k]])
+                cur_v = V.times(z, HipVec(Xv, nvec), 0, K)          # v = unproject!!(zerovector, V, z)
+                r = HipVec(Xr, nvec)
+                A.apply(cur_v, r); B.apply(cur_v, bv)
+                numops += 1
+                rho = cur_v.inner(r) / _checkposdef(cur_v.inner(bv))
+                r.add_(bv, -rho)
+                beta = r.norm()
+                if beta < tol * float(np.linalg.norm(z)):
+                    converged += 1
+                elif numiter < maxiter:
+                    break
+                values.append(rho)
+                normres.append(beta)
+                nvec += 1
+                if k + 1 == howmany and numiter == maxiter:
+                    break
+            if converged >= howmany:
+                howmany = converged
+                break
+        if K < krylovdim - converged:                               # expand  :143-157
+            HipVec(V, K).scale_from_(r, 1 / beta)
+            V.length = K + 1
+            HHA[K, K - 1] = HHA[K - 1, K] = beta
+            K += 1
+            BV.length = K
+            alpha, beta = recurrence(K, beta)
+            r = rs
+            HHA[K - 1, K - 1] = alpha
+        else:                                                       # restart  :158-177
+            if numiter == maxiter:
+                break
+            HHA[:] = 0.0
+            K = 1
+            invb = 1 / cur_v.norm()
+            v = HipVec(V, 0).scale_from_(cur_v, invb)
+            HipVec(BV, 0).scale_from_(bv, invb)
+            r = rs.scale_from_(r, invb)
+            V.length = BV.length = 1
+            alpha, beta = r.orthogonalize_against_(v, orth)
+            HHA[0, 0] = alpha
+            numiter += 1
+    vectors = [Xv.download(i) for i in range(nvec)]
+    residuals = [Xr.download(i) for i in range(nvec)]
+    return np.array(values), vectors, ConvergenceInfo(converged, residuals, np.array(normres), numiter, numops)

@@ -1872,3 +1872,185 @@ def eigsolve_arnoldi(A, x0, howmany: int = 1, which: str = "LM", *, krylovdim: i
     normres = np.array([fact.normres * abs(V[K - 1, i]) for i in range(hm)])
     return values, vectors, ConvergenceInfo(converged, residuals, normres, numiter, numops)
 
+
+# --------------------------------------------------------------------------------------
+# geneigsolve with Golub-Ye -- src/eigsolve/golubye.jl
+# --------------------------------------------------------------------------------------
+def _checkposdef(z: float) -> float:
+    if not z > 0:                                              # KrylovKit.jl:143-148
+        raise ValueError(f"operator does not appear to be positive definite: diagonal element {z}")
+    return z
+
+
+def golubyerecurrence(A, B, rho, V: List[np.ndarray], beta, orth: Orthogonalizer):
+    """golubyerecurrence (golubye.jl:182-281): Lanczos recurrence of A - rho B; returns (w, alpha, beta, B v)."""
+    v = V[-1]
+    av, bv = apply(A, v), apply(B, v)                          # genapply (apply.jl:22)
+    w = add(av, bv, -rho)
+    n = orth.name
+    if n in ("cgs", "cgs2", "cgsir"):
+        alpha = inner(v, w)
+        w = add(w, V[-2], -beta)
+        w = add(w, v, -alpha)
+        if n == "cgs2":
+            w, s = orthogonalize(w, V, CGS)
+            alpha += s[-1]
+            beta = norm(w)
+        elif n == "cgsir":
+            ab2 = alpha * alpha + beta * beta
+            beta = norm(w)
+            nold = math.sqrt(beta * beta + ab2)
+            while EPS < beta < orth.eta * nold:
+                nold = beta
+                w, s = orthogonalize(w, V, CGS)
+                alpha += s[-1]
+                beta = norm(w)
+        else:
+            beta = norm(w)
+        return w, alpha, beta, bv
+    w = add(w, V[-2], -beta)
+    w, alpha = orthogonalize_vec(w, v, MGS)
+    if n == "mgs2":
+        s = alpha
+        for q in V:
+            w, s = orthogonalize_vec(w, q, MGS)
+        alpha += s
+        beta = norm(w)
+    elif n == "mgsir":
+        ab2 = alpha * alpha + beta * beta
+        beta = norm(w)
+        nold = math.sqrt(beta * beta + ab2)
+        while EPS < beta < orth.eta * nold:
+            nold = beta
+            s = 0.0
+            for q in V:
+                w, s = orthogonalize_vec(w, q, MGS)
+            alpha += s
+            beta = norm(w)
+    else:
+        beta = norm(w)
+    return w, alpha, beta, bv
+
+
+def geneigsolve_golubye(A, B, x0, howmany: int = 1, which: str = "SR", *, krylovdim: int = 30, maxiter: int = 100,
+                        tol: float = 1e-12, orth: Orthogonalizer = MGS2):
+    """geneigsolve((A, B), x0, howmany, which, alg::GolubYe) (eigsolve/golubye.jl:1-180), real symmetric A, s.p.d. B."""
+    import scipy.linalg as sla
+    if howmany > krylovdim:
+        raise ValueError(f"krylov dimension {krylovdim} too small to compute {howmany} eigenvalues")
+    x0 = np.asarray(x0, dtype=np.float64)
+    ax0, bx0 = apply(A, x0), apply(B, x0)
+    numops = 1
+    beta0 = norm(x0)
+    if beta0 == 0:
+        raise ValueError("initial vector should not have norm zero")
+    xax = inner(x0, ax0) / beta0 ** 2
+    xbx = inner(x0, bx0) / beta0 ** 2
+    v = scale(x0, 1 / beta0)
+    av = scale(ax0, 1 / beta0)
+    bv = scale(bx0, 1 / beta0)
+    rho = xax / _checkposdef(xbx)
+    r = add(av, bv, -rho)
+    HHA = np.zeros((krylovdim + 1, krylovdim + 1))
+    numiter = 1
+    vold = v
+    V: List[np.ndarray] = [v]
+    BV: List[np.ndarray] = [bv]
+    r, alpha = orthogonalize_vec(r, v, orth)                   # :44
+    beta = norm(r)
+    converged = 0
+    values: List[float] = []
+    vectors: List[np.ndarray] = []
+    residuals: List[np.ndarray] = []
+    normres: List[float] = []
+    K = 1
+    HHA[0, 0] = alpha
+    by, rev = eigsort_key(which)
+    while True:
+        beta = norm(r)
+        if beta <= tol and K < howmany:                        # :59-67
+            howmany = K
+        if K == krylovdim - converged or beta <= tol:          # process  :68
+            def extend(vnew):
+                nonlocal K, numops
+                avn, bvn = apply(A, vnew), apply(B, vnew)
+                numops += 1
+                avn = add(avn, bvn, -rho)
+                for i in range(K):
+                    HHA[i, K] = inner(V[i], avn)
+                    HHA[K, i] = HHA[i, K]
+                K += 1
+                HHA[K - 1, K - 1] = inner(vnew, avn)
+                V.append(vnew)
+                BV.append(bvn)
+
+            if numiter > 1:                                    # :69-82
+                vn, _, _ = orthonormalize(vold, V, orth)
+                extend(vn)
+            for i in range(converged):                         # :83-96
+                vn, _, _ = orthonormalize(vectors[i].copy(), V, orth)
+                extend(vn)
+            HA = HHA[:K, :K].copy()
+            HB = np.zeros((K, K))
+            for j in range(K):                                 # buildHB!  :284-295
+                HB[j, j] = _checkposdef(inner(V[j], BV[j]))
+                for i in range(j + 1, K):
+                    HB[i, j] = inner(V[i], BV[j])
+                    HB[j, i] = HB[i, j]
+            HA += rho * HB
+            D, Z = sla.eigh(HA, HB)                            # geneigh! -> sygvd  :102
+            key = by(D)
+            perm = np.argsort(-key if rev else key, kind="stable")
+            converged = 0
+            values, vectors, residuals, normres = [], [], [], []
+            for k in range(K):                                 # :110-133
+                z = Z[:, perm[k]]
+                v = unproject(np.zeros_like(vold), V, z)
+                av, bv = apply(A, v), apply(B, v)
+                numops += 1
+                rho = inner(v, av) / _checkposdef(inner(v, bv))
+                r = add(av, bv, -rho)
+                beta = norm(r)
+                if beta < tol * norm(z):
+                    converged += 1
+                elif numiter < maxiter:
+                    break
+                values.append(rho)
+                vectors.append(v)
+                residuals.append(r)
+                normres.append(beta)
+                if k + 1 == howmany and numiter == maxiter:
+                    break
+            if converged >= howmany:
+                howmany = converged
+                break
+        if K < krylovdim - converged:                          # expand  :143-157
+            v = scale_(r, 1 / beta)
+            V.append(v)
+            HHA[K, K - 1] = beta
+            HHA[K - 1, K] = beta
+            beta_old = beta
+            r, alpha, beta, bv = golubyerecurrence(A, B, rho, V, beta_old, orth)
+            numops += 1
+            K += 1
+            HHA[K - 1, K - 1] = alpha
+            BV.append(bv)
+        else:                                                  # restart  :158-177
+            if numiter == maxiter:
+                break
+            V.clear()
+            BV.clear()
+            HHA[:] = 0.0
+            K = 1
+            invb = 1 / norm(v)
+            v = scale_(v, invb)
+            bv = scale_(bv, invb)
+            r = scale_(r, invb)
+            r, alpha = orthogonalize_vec(r, v, orth)
+            beta = norm(r)
+            V.append(v)
+            HHA[0, 0] = alpha
+            BV.append(bv)
+            numiter += 1
+    return np.array(values), vectors, ConvergenceInfo(converged, residuals, np.array(normres), numiter, numops)
+

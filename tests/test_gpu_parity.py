@@ -866,6 +866,42 @@ def test_eigsolve_arnoldi(kk, ko, ctx, which):
     np.testing.assert_allclose(svals, vals[:len(svals)], rtol=0, atol=1e-9 * np.max(np.abs(ovals)))
 
 
+@pytest.mark.parametrize("orth_name", ["cgs2", "mgs2", "cgsir", "mgsir", "cgs", "mgs"])
+def test_geneigsolve_golubye(kk, ko, ctx, orth_name):
+    """geneigsolve((A, B), x0, howmany, which, alg::GolubYe) (eigsolve/golubye.jl) on device vectors: A = shifted 2-D
+    Laplacian, B = s.p.d. mass-like matrix; restarts, converged-vector re-insertion, B-orthonormal Ritz vectors; counts
+    and values against the oracle."""
+    import scipy.linalg as sla
+    import scipy.sparse as sp
+    dev = {"cgs": kk.ClassicalGramSchmidt(), "mgs": kk.ModifiedGramSchmidt(), "cgs2": kk.ClassicalGramSchmidt2(),
+           "mgs2": kk.ModifiedGramSchmidt2(), "cgsir": kk.ClassicalGramSchmidtIR(), "mgsir": kk.ModifiedGramSchmidtIR()}[orth_name]
+    ref = {"cgs": ko.CGS, "mgs": ko.MGS, "cgs2": ko.CGS2, "mgs2": ko.MGS2, "cgsir": ko.CGSIR(), "mgsir": ko.MGSIR()}[orth_name]
+    nx, ny = 12, 10
+    n = nx * ny
+    A = ko.laplacian_2d(nx, ny, shift_diag=np.linspace(0, 2, n))
+    T1 = sp.diags([np.full(n - 1, 1.0), np.full(n, 4.0), np.full(n - 1, 1.0)], [-1, 0, 1], format="csr") / 6.0
+    B = (T1 + sp.diags(np.linspace(0.5, 1.5, n))).tocsr()
+    x0 = np.random.default_rng(8).random(n)
+    opA, opB = kk.SparseOperator(A, ctx, symmetric=True), kk.SparseOperator(B, ctx, symmetric=True)
+    reorth = orth_name not in ("cgs", "mgs")
+    for which, hm in (("SR", 3), ("LR", 2)):
+        kw = dict(krylovdim=14, maxiter=60 if reorth else 3, tol=1e-9)
+        vals, vecs, info = kk.geneigsolve((opA, opB), x0, hm, which, kk.GolubYe(dev, kw["krylovdim"], kw["maxiter"], kw["tol"]))
+        ovals, ovecs, oinfo = ko.geneigsolve_golubye(A, B, x0, hm, which, orth=ref, **kw)
+        assert (info.converged, info.numiter, info.numops) == (oinfo.converged, oinfo.numiter, oinfo.numops)
+        assert len(vals) == len(ovals)
+        np.testing.assert_allclose(vals, ovals, rtol=1e-8, atol=1e-10)
+        if reorth:
+            assert info.converged >= hm
+            exact = sla.eigh(A.toarray(), B.toarray(), eigvals_only=True)
+            exact = exact[:len(vals)] if which == "SR" else exact[::-1][:len(vals)]
+            np.testing.assert_allclose(vals[:info.converged], exact[:info.converged], rtol=1e-7, atol=1e-8)
+        U = np.stack(vecs, axis=1)
+        R = np.stack(info.residual, axis=1)
+        np.testing.assert_allclose(U.T @ (B @ U), np.eye(U.shape[1]), atol=1e-7)
+        np.testing.assert_allclose(A @ U, (B @ U) * vals[None, :] + R, atol=1e-8)
+
+
 @pytest.mark.parametrize("mgs_mode", [0, 1])
 def test_mgs_on_non_orthonormal_basis(kk, ko, ctx, mgs_mode):
     """The low-sync form (I + L) s = V'w is exact algebra for ANY basis (MGS never divides by |q|^2):

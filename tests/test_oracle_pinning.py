@@ -534,3 +534,53 @@ def test_arnoldi_eigsolve_iteratively(ko):
         np.testing.assert_allclose(A @ Uk, Uk * Dk[None, :] + Rk, atol=1e-9)     # :318-320
         assert np.all(infok.normres[:infok.converged] <= 1e-12 * 1.0001)
 
+
+@pytest.mark.parametrize("orth_name", ["CGS2", "MGS2", "CGSIR", "MGSIR"])
+def test_golubye_geneigsolve_full(ko, orth_name):
+    """test/geneigsolve.jl:1-113 (GolubYe - geneigsolve full), real Float64."""
+    import scipy.linalg as sla
+    orth = getattr(ko, orth_name)
+    orth = orth() if callable(orth) else orth
+    rng = np.random.default_rng(51)
+    n = 10
+    A = rng.random((n, n)) - 0.5
+    A = (A + A.T) / 2
+    B = rng.random((n, n)) - 0.5
+    B = np.real(sla.sqrtm(B @ B.T))
+    v = rng.random(n)
+    n1 = n // 2
+    D1, V1, info = ko.geneigsolve_golubye(A, B, v, n1, "SR", krylovdim=n, maxiter=1, tol=1e-12, orth=orth)
+    n2 = n - n1
+    D2, V2, info2 = ko.geneigsolve_golubye(A, B, v, n2, "LR", krylovdim=n, maxiter=1, tol=1e-12, orth=orth)
+    ref = sla.eigh(A, B, eigvals_only=True)
+    np.testing.assert_allclose(np.concatenate([D1[:n1], D2[:n2][::-1]]), ref, atol=1e-8)
+    for Dk, Vk in ((D1, V1), (D2, V2)):
+        U = np.stack(Vk, axis=1)
+        np.testing.assert_allclose(U.T @ B @ U, np.eye(U.shape[1]), atol=1e-8)
+        np.testing.assert_allclose(A @ U, B @ U * Dk[None, :], atol=1e-7)
+
+
+def test_golubye_geneigsolve_iteratively(ko):
+    """test/geneigsolve.jl:115-172 (GolubYe - geneigsolve iteratively): N = 100, krylovdim = 3n, restarts."""
+    import scipy.linalg as sla
+    rng = np.random.default_rng(53)
+    N, n = 100, 10
+    A = rng.random((N, N)) - 0.5
+    A = (A + A.T) / 2
+    B = rng.random((N, N)) - 0.5
+    B = np.real(sla.sqrtm(B @ B.T))
+    v = rng.random(N)
+    tol = np.linalg.cond(B) * 1e-12
+    D1, V1, info1 = ko.geneigsolve_golubye(A, B, v, n, "SR", krylovdim=3 * n, maxiter=100, tol=tol)
+    D2, V2, info2 = ko.geneigsolve_golubye(A, B, v, n, "LR", krylovdim=3 * n, maxiter=100, tol=tol)
+    l1, l2 = info1.converged, info2.converged
+    assert l1 > 0 and l2 > 0
+    ref = sla.eigh(A, B, eigvals_only=True)
+    np.testing.assert_allclose(D1[:l1], ref[:l1], rtol=1e-7, atol=1e-7)
+    np.testing.assert_allclose(D2[:l2], ref[::-1][:l2], rtol=1e-7, atol=1e-7)
+    for Dk, Vk, infok in ((D1, V1, info1), (D2, V2, info2)):
+        U = np.stack(Vk, axis=1)
+        R = np.stack(infok.residual, axis=1)
+        np.testing.assert_allclose(U.T @ B @ U, np.eye(U.shape[1]), atol=1e-7)
+        np.testing.assert_allclose(A @ U, B @ U * Dk[None, :] + R, atol=1e-8)
+
