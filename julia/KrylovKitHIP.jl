@@ -324,4 +324,53 @@ function apply(A::HipOperator, X::KrylovKit.Block{HipVec})
     return Y
 end
 
+# ---------------------------------------------------------------- short-recurrence solvers (SURVEY 8(f)-3)
+# The loop bodies of linsolve(::CG) and linsolve(::BiCGStab) as fused device calls.  KrylovKit's own methods work
+# unchanged through the L1 verbs above; these specialisations replace the 6-10 verb calls of an iteration by one or
+# two library calls that keep the recurrence scalars on the device.  The surrounding control flow (tolerance checks,
+# explicit residual on convergence, ConvergenceInfo) is the reference's, see linsolve/cg.jl:60-101 and
+# linsolve/bicgstab.jl:118-199; krylovkit_hip/solvers.py holds the executed mirror of exactly this sequence.
+
+# one CG iteration: [p = r + beta p]; q = a0 p + a1 A p; alpha = rho/<p,q>; x += alpha p; r -= alpha q; returns |r|
+function cg_iterate!(A::HipOperator, slab::HipSlab, cx, cr, cp, cq, a0, a1, beta, first::Bool, rho)
+    pq = Ref{Float64}(); nr = Ref{Float64}()
+    chk(ccall((:kk_cg_iterate, lib), Cint,
+              (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cint, Cint, Cint, Float64, Float64, Float64, Cint, Float64, Ref{Float64}, Ref{Float64}),
+              A.h, slab.h, cx, cr, cp, cq, a0, a1, beta, first, rho, pq, nr))
+    return nr[]
+end
+
+# BiCGStab half steps; cols = (x, r, r_shadow, p, v, s, t, p_prev, v_prev) are columns of one slab
+function bicgstab_half!(A::HipOperator, slab::HipSlab, cols::NTuple{9,Cint}, a0, a1, mode::Integer, rho)
+    sn = Ref{Float64}(); al = Ref{Float64}()
+    c = collect(cols)
+    chk(ccall((:kk_bicgstab_half, lib), Cint,
+              (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cint}, Float64, Float64, Cint, Float64, Ref{Float64}, Ref{Float64}),
+              A.h, slab.h, c, a0, a1, mode, rho, sn, al))
+    return sn[], al[]
+end
+function bicgstab_full!(A::HipOperator, slab::HipSlab, cols::NTuple{9,Cint}, a0, a1, redo_t::Bool,
+                        ahead::Union{Nothing,NTuple{9,Cint}})
+    rn = Ref{Float64}(); rho = Ref{Float64}(); om = Ref{Float64}()
+    c = collect(cols)
+    a = ahead === nothing ? Ptr{Cint}(C_NULL) : pointer(collect(ahead))
+    chk(ccall((:kk_bicgstab_full, lib), Cint,
+              (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cint}, Float64, Float64, Cint, Ptr{Cint}, Ref{Float64}, Ref{Float64}, Ref{Float64}),
+              A.h, slab.h, c, a0, a1, redo_t, a, rn, rho, om))
+    return rn[], rho[], om[]
+end
+
+# LSMR vector updates (lssolve/lsmr.jl:64-68, 115-121)
+function lsmr_step_u!(slab::HipSlab, c_av, c_ah, c_u, c, alpha)
+    beta = Ref{Float64}()
+    chk(ccall((:kk_lsmr_step_u, lib), Cint, (Ptr{Cvoid}, Cint, Cint, Cint, Float64, Float64, Ref{Float64}),
+              slab.h, c_av, c_ah, c_u, c, alpha, beta))
+    return beta[]
+end
+function lsmr_update!(slab::HipSlab, ch, chbar, cx, vslab::Union{Nothing,HipSlab}, cv, c1, c2, c3)
+    chk(ccall((:kk_lsmr_update, lib), Cint, (Ptr{Cvoid}, Cint, Cint, Cint, Ptr{Cvoid}, Cint, Float64, Float64, Float64),
+              slab.h, ch, chbar, cx, vslab === nothing ? C_NULL : vslab.h, cv, c1, c2, c3))
+    return nothing
+end
+
 end # module
