@@ -353,11 +353,13 @@ function bicgstab_full!(A::HipOperator, slab::HipSlab, cols::NTuple{9,Cint}, a0,
                         ahead::Union{Nothing,NTuple{9,Cint}})
     rn = Ref{Float64}(); rho = Ref{Float64}(); om = Ref{Float64}()
     c = collect(cols)
-    a = ahead === nothing ? Cint[] : collect(ahead)          # arrays passed to ccall are rooted for the call
-    chk(ccall((:kk_bicgstab_full, lib), Cint,
-              (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cint}, Float64, Float64, Cint, Ptr{Cint}, Ref{Float64}, Ref{Float64}, Ref{Float64}),
-              A.h, slab.h, c, a0, a1, redo_t, isempty(a) ? Ptr{Cint}(C_NULL) : pointer(a), rn, rho, om))
-    GC.@preserve a nothing
+    a = ahead === nothing ? Cint[] : collect(ahead)
+    GC.@preserve a begin
+        pa = isempty(a) ? Ptr{Cint}(C_NULL) : pointer(a)
+        chk(ccall((:kk_bicgstab_full, lib), Cint,
+                  (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cint}, Float64, Float64, Cint, Ptr{Cint}, Ref{Float64}, Ref{Float64}, Ref{Float64}),
+                  A.h, slab.h, c, a0, a1, redo_t, pa, rn, rho, om))
+    end
     return rn[], rho[], om[]
 end
 
