@@ -8,7 +8,7 @@ from . import _lib
 from ._lib import DimensionMismatch, KrylovHipError, NoDeviceError
 from .core import (ClassicalGramSchmidt, ClassicalGramSchmidt2, ClassicalGramSchmidtIR, Context, DeviceBasis, HipVec,
                    KrylovDefaults, ModifiedGramSchmidt, ModifiedGramSchmidt2, ModifiedGramSchmidtIR, Orthogonalizer,
-                   SparseOperator, default_context, device_count)
+                   SparseOperator, FunctionOperator, default_context, device_count)
 from .factorizations import (ArnoldiFactorization, ArnoldiIterator, Block, BlockLanczosFactorization, BlockLanczosIterator,
                              GKLFactorization, GKLIterator, block_inner, block_qr_, block_reorthogonalize_,
                              LanczosFactorization, LanczosIterator, expand_, initialize, initialize_, shrink_)

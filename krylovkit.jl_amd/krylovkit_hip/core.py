@@ -403,3 +403,40 @@ class SparseOperator:
         """apply(op, x, a0, a1) = a0*x + a1*A*x (apply.jl:4-11)"""
         check(self._lib.kk_spmv_affine(self.handle, x.basis.handle, x.col, y.basis.handle, y.col, a0, a1))
         return y
+
+
+class FunctionOperator:
+    """apply(f, x) = f(x) (src/apply.jl:2): a linear map given as a callable instead of a matrix.  `f(x, y)` receives two
+    HipVec and must leave y = A x using device-side work only (compositions / polynomials of SparseOperators, a
+    shift-and-invert through an inner solver, ...).  The fused kk_*_expand entry points need a sparse kk_op, so with a
+    function the iterators issue the reference's un-fused sequence instead: one call of f per `expand!`, then the
+    recurrence through the L1 verbs and the fused orthogonalisation passes (kk_orthogonalize, kk_orthogonalize_vec).
+    `adjoint` is the callable for apply_adjoint (apply.jl:15), `symmetric` the promise needed by Lanczos."""
+
+    def __init__(self, f, n: int, ctx: Optional[Context] = None, symmetric: bool = False, adjoint=None, n_out: Optional[int] = None):
+        self.f, self.adjoint = f, adjoint
+        self.shape = (n if n_out is None else n_out, n)
+        self.ctx = ctx or default_context()
+        self.symmetric = bool(symmetric)
+        self.handle = None      # no kk_op behind a function
+
+    def apply(self, x: HipVec, y: HipVec, transpose: bool = False) -> HipVec:
+        if transpose:
+            if self.adjoint is None:
+                if not self.symmetric:
+                    raise ValueError("FunctionOperator: no adjoint callable was given")
+                self.f(x, y)
+            else:
+                self.adjoint(x, y)
+        else:
+            self.f(x, y)
+        return y
+
+    def apply_adjoint(self, x: HipVec, y: HipVec) -> HipVec:
+        return self.apply(x, y, True)
+
+    def apply_affine(self, x: HipVec, y: HipVec, a0: float, a1: float) -> HipVec:
+        """apply(f, x, a0, a1) = a0 x + a1 f(x) (apply.jl:4-11)"""
+        self.f(x, y)
+        return y.add_(x, a0, a1)
+

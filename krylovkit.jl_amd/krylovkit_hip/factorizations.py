@@ -21,13 +21,88 @@ import numpy as np
 
 from . import _lib
 from ._lib import check
-from .core import (Context, DeviceBasis, HipVec, KrylovDefaults, Orthogonalizer, SparseOperator, default_context)
+from .core import (ClassicalGramSchmidt, Context, DeviceBasis, FunctionOperator, HipVec, KrylovDefaults,
+                   ModifiedGramSchmidt, Orthogonalizer, SparseOperator, default_context)
 
 
 def _as_operator(A, ctx=None) -> SparseOperator:
-    if isinstance(A, SparseOperator):
+    if isinstance(A, (SparseOperator, FunctionOperator)):
         return A
     return SparseOperator(A, ctx)
+
+
+_EPS = float(np.finfo(np.float64).eps)
+
+
+def lanczos_recurrence_unfused(V: DeviceBasis, c0: int, K: int, w: HipVec, beta_old: float, orth: Orthogonalizer,
+                               have_prev: bool = True):
+    """lanczosrecurrence x6 (factorizations/lanczos.jl:295-376) AFTER the operator application, for w = A V[K-1] already
+    in `w`: the three-term part through the L1 verbs, the re-orthogonalisation through the fused pass entry points.
+    Basis vectors are columns c0 .. c0+K-1 of V.  Returns (alpha, beta); w holds the new residual."""
+    v = HipVec(V, c0 + K - 1)
+    vprev = HipVec(V, c0 + K - 2) if have_prev else None
+    name = orth.name
+    if name in ("cgs", "cgs2", "cgsir"):                        # :297-301, :313-323, :341-356
+        a = v.inner(w)
+        if vprev is not None:
+            w.add_(vprev, -beta_old)
+        w.add_(v, -a)
+        if name == "cgs":
+            return a, w.norm()
+        if name == "cgs2":
+            s, b, _ = V.orthogonalize(w, ClassicalGramSchmidt(), c0, K)
+            return a + s[-1], b
+        ab2 = a * a + beta_old * beta_old
+        b = w.norm()
+        nold = float(np.sqrt(b * b + ab2))
+        while _EPS < b < orth.eta * nold:
+            nold = b
+            s, b, _ = V.orthogonalize(w, ClassicalGramSchmidt(), c0, K)
+            a += s[-1]
+        return a, b
+    if vprev is not None:                                       # :306-310, :326-338, :359-375
+        w.add_(vprev, -beta_old)
+    a, b = w.orthogonalize_against_(v, ModifiedGramSchmidt())
+    if name == "mgs":
+        return a, b
+    if name == "mgs2":
+        s, b, _ = V.orthogonalize(w, ModifiedGramSchmidt(), c0, K)   # for q in V: orthogonalize!!(w, q, MGS); s = last
+        return a + s[-1], b
+    ab2 = a * a + beta_old * beta_old
+    nold = float(np.sqrt(b * b + ab2))
+    while _EPS < b < orth.eta * nold:
+        nold = b
+        s, b, _ = V.orthogonalize(w, ModifiedGramSchmidt(), c0, K)
+        a += s[-1]
+    return a, b
+
+
+def _krylov_initialize_unfused(op, V: DeviceBasis, orth: Orthogonalizer):
+    """initialize(iter) for a function operator (lanczos.jl:180-222 == arnoldi.jl:135-175): returns (alpha, beta)."""
+    x0, r = HipVec(V, 0), HipVec(V, 1)
+    beta0 = x0.norm()
+    if beta0 == 0:
+        raise _lib.KrylovHipError(_lib.KK_ERR_ZERO_NORM, "initial vector should not have norm zero")
+    op.apply(x0, r)                                              # Ax0   :186
+    alpha = x0.inner(r) / (beta0 * beta0)
+    x0.scale_(1.0 / beta0)                                       # v
+    r.scale_(1.0 / beta0)                                        # :194
+    beta_old = r.norm()
+    r.add_(x0, -alpha)
+    beta = r.norm()
+    if orth.name in ("cgs2", "mgs2"):                            # :200-204
+        da = x0.inner(r)
+        alpha += da
+        r.add_(x0, -da)
+        beta = r.norm()
+    elif orth.name in ("cgsir", "mgsir"):                        # :205-213
+        while _EPS < beta < orth.eta * beta_old:
+            beta_old = beta
+            da = x0.inner(r)
+            alpha += da
+            r.add_(x0, -da)
+            beta = r.norm()
+    return alpha, beta
 
 
 # =========================================================================================
@@ -133,6 +208,10 @@ def _lanczos_initialize(it: LanczosIterator, V: Optional[DeviceBasis] = None) ->
     if V is None:
         V = DeviceBasis(n, it.capacity, op.ctx)
     _upload_x0(V, it.x0, 0)
+    if isinstance(op, FunctionOperator):
+        alpha, beta = _krylov_initialize_unfused(op, V, it.orth)
+        V.length = 1
+        return LanczosFactorization(1, V, [alpha], [beta])
     a, b = C.c_double(), C.c_double()
     check(V._lib.kk_lanczos_initialize(op.handle, V.handle, 0, it.orth.code, it.orth.eta, C.byref(a), C.byref(b)))
     V.length = 1
@@ -169,8 +248,14 @@ def _lanczos_expand(it: LanczosIterator, st: LanczosFactorization) -> LanczosFac
             HipVec(V, j).scale_from_(HipVec(V, c0 + j), 1.0)
         c0 = st.window = 0
     a, b, npass = C.c_double(), C.c_double(), C.c_int()
-    check(V._lib.kk_lanczos_expand(it.operator.handle, V.handle, c0, nv, it.orth.code, it.orth.eta, beta_old,
-                                   C.byref(a), C.byref(b), C.byref(npass)))
+    if isinstance(it.operator, FunctionOperator):   # un-fused: V[k+1] = r / beta ; w = f(v) ; recurrence   :256-259
+        vnew, w = HipVec(V, c0 + nv), HipVec(V, c0 + nv + 1)
+        vnew.scale_(1.0 / beta_old)
+        it.operator.apply(vnew, w)
+        a.value, b.value = lanczos_recurrence_unfused(V, c0, nv + 1, w, beta_old, it.orth, have_prev=nv >= 1)
+    else:
+        check(V._lib.kk_lanczos_expand(it.operator.handle, V.handle, c0, nv, it.orth.code, it.orth.eta, beta_old,
+                                       C.byref(a), C.byref(b), C.byref(npass)))
     st.alphas.append(a.value)  # push!(alphas, real(alpha))   :261
     st.betas.append(b.value)
     V.length = nv + 1
@@ -250,6 +335,10 @@ def _arnoldi_initialize(it: ArnoldiIterator, V: Optional[DeviceBasis] = None) ->
     if V is None:
         V = DeviceBasis(op.shape[0], it.capacity, op.ctx)
     _upload_x0(V, it.x0, 0)
+    if isinstance(op, FunctionOperator):
+        alpha, beta = _krylov_initialize_unfused(op, V, it.orth)
+        V.length = 1
+        return ArnoldiFactorization(1, V, [alpha, beta])
     a, b = C.c_double(), C.c_double()
     check(V._lib.kk_arnoldi_initialize(op.handle, V.handle, 0, it.orth.code, it.orth.eta, C.byref(a), C.byref(b)))
     V.length = 1
@@ -279,8 +368,16 @@ def _arnoldi_expand(it: ArnoldiIterator, st: ArnoldiFactorization) -> ArnoldiFac
     beta_old = st.normres
     h = np.zeros(k + 1)
     b, npass = C.c_double(), C.c_int()
-    check(V._lib.kk_arnoldi_expand(it.operator.handle, V.handle, 0, k, it.orth.code, it.orth.eta, beta_old,
-                                   h.ctypes.data_as(_lib.c_dp), C.byref(b), C.byref(npass)))
+    if isinstance(it.operator, FunctionOperator):   # un-fused arnoldirecurrence!! (arnoldi.jl:239-245)
+        vnew, w = HipVec(V, k), HipVec(V, k + 1)
+        vnew.scale_(1.0 / beta_old)                  # V[k+1] = scale(r, 1/beta)   :209
+        it.operator.apply(vnew, w)
+        V.length = k + 1
+        hx, b.value, npass.value = V.orthogonalize(w, it.orth, 0, k + 1)
+        h[:] = hx
+    else:
+        check(V._lib.kk_arnoldi_expand(it.operator.handle, V.handle, 0, k, it.orth.code, it.orth.eta, beta_old,
+                                       h.ctypes.data_as(_lib.c_dp), C.byref(b), C.byref(npass)))
     st.k += 1
     V.length = k + 1
     st.H.extend(float(t) for t in h)  # H[m+1 : m+k]   :211-212

@@ -856,8 +856,7 @@ def geneigsolve(AB, x0, howmany: int = 1, which: str = "SR", alg: Optional[Golub
     symmetric positive definite B, both device sparse operators.  The inner iteration is the Lanczos recurrence of
     A - rho B on the device basis (two SpMVs + the same orthogonalisation passes per step, golubye.jl:182-281); the
     projected K x K pencil is solved on the host (LAPACK sygvd through SciPy, as the reference does)."""
-    from .core import ClassicalGramSchmidt, ModifiedGramSchmidt
-    from .factorizations import Block, block_inner
+    from .factorizations import Block, block_inner, lanczos_recurrence_unfused
     alg = alg or GolubYe(**kw)
     if which in ("LI", "SI"):
         raise ValueError(f"Eigenvalue selector which = {which} invalid: real eigenvalues expected with Lanczos algorithm")
@@ -871,8 +870,6 @@ def geneigsolve(AB, x0, howmany: int = 1, which: str = "SR", alg: Optional[Golub
     Xv, Xr = DeviceBasis(n, cap, ctx), DeviceBasis(n, cap, ctx)     # Ritz vectors / residuals of the last process step
     S = DeviceBasis(n, 5, ctx)                                      # scratch: av, bv, vold, tmp, r
     av, bv, vold, tmp, rs = (HipVec(S, i) for i in range(5))
-    CGS, MGS = ClassicalGramSchmidt(), ModifiedGramSchmidt()
-    name = orth.name
 
     v = HipVec(V, 0).set(np.asarray(x0, dtype=np.float64))
     A.apply(v, av); B.apply(v, bv)                                  # genapply  :7
@@ -902,42 +899,11 @@ def geneigsolve(AB, x0, howmany: int = 1, which: str = "SR", alg: Optional[Golub
     def recurrence(Kc, beta_old):
         """golubyerecurrence (:182-281) for V[Kc-1] = v; leaves w in `rs`, B v in BV[Kc-1]; returns (alpha, beta)."""
         nonlocal numops
-        vK, vprev = HipVec(V, Kc - 1), HipVec(V, Kc - 2)
-        bvK = HipVec(BV, Kc - 1)
+        vK, bvK = HipVec(V, Kc - 1), HipVec(BV, Kc - 1)
         A.apply(vK, rs); B.apply(vK, bvK)
         numops += 1
         w = rs.add_(bvK, -rho)
-        if name in ("cgs", "cgs2", "cgsir"):
-            a = vK.inner(w)
-            w.add_(vprev, -beta_old)
-            w.add_(vK, -a)
-            if name == "cgs":
-                return a, w.norm()
-            if name == "cgs2":
-                s, b, _ = V.orthogonalize(w, CGS, 0, Kc)
-                return a + s[-1], b
-            ab2 = a * a + beta_old * beta_old
-            b = w.norm()
-            nold = math.sqrt(b * b + ab2)
-            while np.finfo(float).eps < b < orth.eta * nold:
-                nold = b
-                s, b, _ = V.orthogonalize(w, CGS, 0, Kc)
-                a += s[-1]
-            return a, b
-        w.add_(vprev, -beta_old)
-        a, b = w.orthogonalize_against_(vK, MGS)
-        if name == "mgs":
-            return a, b
-        if name == "mgs2":
-            s, b, _ = V.orthogonalize(w, MGS, 0, Kc)                 # for q in V: orthogonalize!!(w, q, MGS); s = last
-            return a + s[-1], b
-        ab2 = a * a + beta_old * beta_old
-        nold = math.sqrt(b * b + ab2)
-        while np.finfo(float).eps < b < orth.eta * nold:
-            nold = b
-            s, b, _ = V.orthogonalize(w, MGS, 0, Kc)
-            a += s[-1]
-        return a, b
+        return lanczos_recurrence_unfused(V, 0, Kc, w, beta_old, orth)   # the six variants of :182-281
 
     def extend(vn: HipVec):
         """push a new (already orthonormalised) vector and its row / column of HHA   (:66-81 / :85-95)"""

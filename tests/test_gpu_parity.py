@@ -902,6 +902,61 @@ def test_geneigsolve_golubye(kk, ko, ctx, orth_name):
         np.testing.assert_allclose(A @ U, (B @ U) * vals[None, :] + R, atol=1e-8)
 
 
+def test_function_operator(kk, ko, ctx):
+    """apply(f, x) = f(x) (apply.jl:2): a callable operator drives the same iterators through the un-fused sequence
+    (one call of f, L1 verbs, fused orthogonalisation passes).  (1) f = a SparseOperator's apply must reproduce the
+    fused kk_lanczos_expand / kk_arnoldi_expand results for all six orthogonalisers; (2) f = A^2 (two SpMVs) in
+    eigsolve, against the oracle driven by the same composite map; (3) Arnoldi eigsolve and exponentiate."""
+    nx, ny = 30, 20
+    n = nx * ny
+    A = ko.laplacian_2d(nx, ny, shift_diag=np.linspace(0, 3, n))
+    Cm = ko.convection_diffusion_2d(nx, ny)
+    x0 = np.random.default_rng(13).random(n)
+    opA, opC = kk.SparseOperator(A, ctx, symmetric=True), kk.SparseOperator(Cm, ctx)
+    fA = kk.FunctionOperator(lambda x, y: opA.apply(x, y), n, ctx, symmetric=True)
+    fC = kk.FunctionOperator(lambda x, y: opC.apply(x, y), n, ctx)
+    devs = [kk.ClassicalGramSchmidt(), kk.ModifiedGramSchmidt(), kk.ClassicalGramSchmidt2(), kk.ModifiedGramSchmidt2(),
+            kk.ClassicalGramSchmidtIR(), kk.ModifiedGramSchmidtIR()]
+    for dev in devs:
+        f1 = kk.initialize(kk.LanczosIterator(opA, x0, dev, capacity=20))
+        f2 = kk.initialize(kk.LanczosIterator(fA, x0, dev, capacity=20))
+        it1, it2 = kk.LanczosIterator(opA, x0, dev, capacity=20), kk.LanczosIterator(fA, x0, dev, capacity=20)
+        f1, f2 = kk.initialize(it1), kk.initialize(it2)
+        for _ in range(15):
+            f1, f2 = kk.expand_(it1, f1), kk.expand_(it2, f2)
+        assert relerr(f2.alphas, f1.alphas) < 1e-10 and relerr(f2.betas, f1.betas) < 1e-9, dev.name
+        a1, a2 = kk.ArnoldiIterator(opC, x0, dev, capacity=20), kk.ArnoldiIterator(fC, x0, dev, capacity=20)
+        g1, g2 = kk.initialize(a1), kk.initialize(a2)
+        for _ in range(12):
+            g1, g2 = kk.expand_(a1, g1), kk.expand_(a2, g2)
+        np.testing.assert_allclose(g2.rayleighquotient(), g1.rayleighquotient(), rtol=0, atol=1e-10)
+        assert abs(g2.normres - g1.normres) < 1e-10
+    # (2) composite map A^2 through a scratch column
+    S = kk.DeviceBasis(n, 1, ctx)
+
+    def a2(x, y):
+        opA.apply(x, S[0])
+        opA.apply(S[0], y)
+
+    f2op = kk.FunctionOperator(a2, n, ctx, symmetric=True)
+    vals, vecs, info = kk.eigsolve(f2op, x0, 3, "LM", kk.Lanczos(kk.ModifiedGramSchmidt2(), 24, 100, 1e-10))
+    ovals, _, oinfo = ko.eigsolve_lanczos(lambda z: A @ (A @ z), x0, 3, "LM", krylovdim=24, maxiter=100, tol=1e-10, orth=ko.MGS2)
+    assert info.converged >= 3 and (info.numiter, info.numops) == (oinfo.numiter, oinfo.numops)
+    np.testing.assert_allclose(vals[:3], ovals[:3], rtol=1e-10)
+    ev = np.linalg.eigvalsh(A.toarray()) ** 2
+    np.testing.assert_allclose(np.sort(vals[:3])[::-1], np.sort(ev)[::-1][:3], rtol=1e-9)
+    # (3) Arnoldi eigsolve and exponentiate with a callable
+    vals, vecs, info = kk.eigsolve(fC, x0, 2, "LR", kk.Arnoldi(kk.ModifiedGramSchmidt2(), 30, 60, 1e-9))
+    ovals, _, oinfo = ko.eigsolve_arnoldi(lambda z: Cm @ z, x0, 2, "LR", krylovdim=30, maxiter=60, tol=1e-9, orth=ko.MGS2)
+    assert (info.converged, info.numiter, info.numops) == (oinfo.converged, oinfo.numiter, oinfo.numops)
+    np.testing.assert_allclose(vals, ovals, rtol=0, atol=1e-8 * np.max(np.abs(ovals)))
+    fE = kk.FunctionOperator(lambda x, y: opA.apply(x, y).scale_(-0.25), n, ctx, symmetric=True)
+    w, info = kk.exponentiate(fE, 0.8, x0, kk.Lanczos(kk.ModifiedGramSchmidt2(), 20, 100, 1e-11))
+    wo, oinfo = ko.expintegrator(lambda z: -0.25 * (A @ z), 0.8, (x0,), krylovdim=20, maxiter=100, tol=1e-11, orth=ko.MGS2)
+    assert (info.converged, info.numiter, info.numops) == (1, oinfo.numiter, oinfo.numops)
+    np.testing.assert_allclose(w, wo, rtol=0, atol=1e-10 * np.linalg.norm(wo))
+
+
 @pytest.mark.parametrize("mgs_mode", [0, 1])
 def test_mgs_on_non_orthonormal_basis(kk, ko, ctx, mgs_mode):
     """The low-sync form (I + L) s = V'w is exact algebra for ANY basis (MGS never divides by |q|^2):
