@@ -902,6 +902,33 @@ def test_geneigsolve_golubye(kk, ko, ctx, orth_name):
         np.testing.assert_allclose(A @ U, (B @ U) * vals[None, :] + R, atol=1e-8)
 
 
+def test_short_recurrence_entry_points_reject_bad_arguments(kk, ko, ctx):
+    """Error behaviour of the 8(f)-3 entry points: status < 0 and a message, never a crash or a silent no-op."""
+    import ctypes as C
+    from krylovkit_hip import _lib
+    A = ko.convection_diffusion_2d(10, 8)
+    op = kk.SparseOperator(A, ctx)
+    W = kk.DeviceBasis(80, 9, ctx)
+    lib = W._lib
+    d = [C.c_double() for _ in range(3)]
+    good = (C.c_int * 9)(0, 1, 2, 3, 4, 5, 6, 3, 4)
+    bad = (C.c_int * 9)(0, 1, 2, 3, 4, 5, 99, 3, 4)
+    for cols, mode in ((good, 7), (good, 3), (bad, 1)):      # unknown mode; collect without a run-ahead half; column range
+        with pytest.raises(kk.KrylovHipError):
+            _lib.check(lib.kk_bicgstab_half(op.handle, W.handle, cols, 0.0, 1.0, mode, 1.0, C.byref(d[0]), C.byref(d[1])))
+    with pytest.raises(kk.KrylovHipError):
+        _lib.check(lib.kk_bicgstab_full(op.handle, W.handle, bad, 0.0, 1.0, 0, None, C.byref(d[0]), C.byref(d[1]), C.byref(d[2])))
+    with pytest.raises(kk.KrylovHipError):
+        _lib.check(lib.kk_lsmr_step_u(W.handle, 1, 1, 2, 0.5, 0.5, C.byref(d[0])))           # aliased columns
+    with pytest.raises(kk.KrylovHipError):
+        _lib.check(lib.kk_lsmr_update(W.handle, 1, 2, 2, None, -1, 0.1, 0.2, 0.3))
+    R = kk.SparseOperator(ko.sparse_random(50, 30, 3, 1), ctx)
+    with pytest.raises(kk.KrylovHipError):                                                    # rectangular map in a square solver
+        kk.linsolve_bicgstab(R, np.ones(50))
+    with pytest.raises(ValueError):
+        kk.geneigsolve((op, op), np.ones(80), 1, "LI")
+
+
 def test_function_operator(kk, ko, ctx):
     """apply(f, x) = f(x) (apply.jl:2): a callable operator drives the same iterators through the un-fused sequence
     (one call of f, L1 verbs, fused orthogonalisation passes).  (1) f = a SparseOperator's apply must reproduce the

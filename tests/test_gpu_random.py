@@ -92,13 +92,15 @@ def test_basistransform_random(kk, ctx, n, m, frac, seed):
 
 @settings(**SET)
 @given(nrows=st.integers(1, 3000), ncols=st.integers(1, 3000), dens=st.floats(0.0005, 0.05), seed=st.integers(0, 2**31 - 1),
-       fmt=st.sampled_from(["auto", "csr", "sell"]))
+       fmt=st.sampled_from(["auto", "csr", "sell", "tiled17", "tiled300"]))
 def test_spmv_random(kk, ctx, monkeypatch, nrows, ncols, dens, seed, fmt):
     import scipy.sparse as sp
-    if fmt != "auto":
+    monkeypatch.delenv("KK_SPMV_FORMAT", raising=False)
+    monkeypatch.delenv("KK_SPMV_TILE_COLS", raising=False)
+    if fmt.startswith("tiled"):                      # column-tiled SELL forced onto small shapes by a tiny tile width
+        monkeypatch.setenv("KK_SPMV_TILE_COLS", fmt[5:])
+    elif fmt != "auto":
         monkeypatch.setenv("KK_SPMV_FORMAT", fmt)
-    else:
-        monkeypatch.delenv("KK_SPMV_FORMAT", raising=False)
     rng = np.random.default_rng(seed)
     A = sp.random(nrows, ncols, density=dens, random_state=rng.integers(1 << 30), format="csr")
     A.data[:] = rng.standard_normal(A.nnz)
