@@ -290,7 +290,12 @@ def _eigsolve_arnoldi(A, x0, howmany: int, which: str, alg: Arnoldi):
 def linsolve(A, b, x0=None, alg: Optional[GMRES] = None, a0: float = 0.0, a1: float = 1.0, *, atol: Optional[float] = None,
              rtol: Optional[float] = None, return_device: bool = False, **kw):
     """linsolve(operator, b, x0, alg::GMRES, a0, a1) (src/linsolve/gmres.jl:1-151), with the
-    tolerance handling of the front-end (`tol = max(atol, rtol*norm(b))`, linsolve/linsolve.jl:135-140)."""
+    tolerance handling of the front-end (`tol = max(atol, rtol*norm(b))`, linsolve/linsolve.jl:135-140).
+    Like the reference's method table, `alg::CG` and `alg::BiCGStab` select those solvers (linsolve/cg.jl, bicgstab.jl)."""
+    if isinstance(alg, CG):
+        return linsolve_cg(A, b, x0, alg, a0, a1)
+    if isinstance(alg, BiCGStab):
+        return linsolve_bicgstab(A, b, x0, alg, a0, a1)
     op = _as_operator(A)
     ctx = op.ctx
     n = op.shape[0]

@@ -780,7 +780,7 @@ def test_linsolve_bicgstab(kk, ko, ctx):
     np.testing.assert_allclose(x, xo, rtol=0, atol=1e-11 * np.linalg.norm(xo))
     np.testing.assert_allclose(info.normres, oinfo.normres, rtol=1e-8)
     xs = np.random.default_rng(1).random(n)
-    x, info = kk.linsolve_bicgstab(kk.SparseOperator(A, ctx), A @ xs, xs, kk.BiCGStab(tol=1e-8))
+    x, info = kk.linsolve(kk.SparseOperator(A, ctx), A @ xs, xs, kk.BiCGStab(tol=1e-8))   # dispatch on the algorithm type
     assert info.numops == 1 and info.converged == 1
 
 
