@@ -473,8 +473,10 @@ __device__ __forceinline__ void unproj_group(const double* __restrict__ V, int64
         }
     }
     const double* Vo = V + off;
-    int j = 0;
-    for (; j + CB <= m; j += CB) {
+    // columns from the LAST to the first: the project pass that precedes an unproject streams the basis in ascending
+    // column order, so its tail (the last ~256 MB = 3 columns of a 10M-row basis) is still in the Infinity Cache
+    int j = m - CB;
+    for (; j >= 0; j -= CB) {
         d2 x[CB][RG];
 #pragma unroll
         for (int c = 0; c < CB; ++c)
@@ -490,7 +492,8 @@ __device__ __forceinline__ void unproj_group(const double* __restrict__ V, int64
             }
         }
     }
-    for (; j < m; ++j) {
+    const int mrem = j + CB;     // columns [0, mrem) are left (mrem < CB)
+    for (j = 0; j < mrem; ++j) {
         const double s = sc[j];
         d2 x[RG];
 #pragma unroll
