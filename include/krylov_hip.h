@@ -69,6 +69,10 @@ typedef enum {
  *   1 = lowsync:  algebraically identical MGS coefficients from ONE projection pass plus a
  *                 triangular solve (on the device) with the strictly-lower Gram matrix of the
  *                 basis, maintained incrementally (16 N bytes / vector).  Default. */
+/* Other kk_ctx_set_option keys: "blocks_per_cu" (grid of the streaming kernels, default 4), "block_mode" (0 strict
+ * block QR / re-orthogonalisation, 1 MFMA panels + CholQR2, default), "fuse_passes", "speculate" (next-step SpMV
+ * enqueued before the host reads alpha/beta), "keep_mb" (MB of trailing basis columns a project pass leaves
+ * cache-allocated for the unproject pass that follows; default 160 of the 256 MB Infinity Cache, 0 = none). */
 
 /* ---------------------------------------------------------------- library / context */
 int kk_version(void);

@@ -132,6 +132,9 @@ extern "C" int kk_ctx_set_option(kk_ctx c, const char* key, double value) {
         c->mgs_mode = (int)value;
     } else if (!strcmp(key, "speculate")) {
         c->speculate = value != 0;
+    } else if (!strcmp(key, "keep_mb")) {
+        KK_CHECK(value >= 0 && value <= 4096, KK_ERR_INVALID, "keep_mb out of range");
+        c->keep_mb = (int)value;
     } else if (!strcmp(key, "fuse_passes")) {
         c->fuse_passes = value != 0;
     } else if (!strcmp(key, "block_mode")) {
@@ -149,6 +152,7 @@ extern "C" int kk_ctx_get_option(kk_ctx c, const char* key, double* value) {
     else if (!strcmp(key, "mgs_mode")) *value = c->mgs_mode;
     else if (!strcmp(key, "num_cus")) *value = c->num_cus;
     else if (!strcmp(key, "block_mode")) *value = c->block_mode;
+    else if (!strcmp(key, "keep_mb")) *value = c->keep_mb;
     else if (!strcmp(key, "fuse_passes")) *value = c->fuse_passes;
     else if (!strcmp(key, "speculate")) *value = c->speculate;
     else {

@@ -98,6 +98,8 @@ struct kk_ctx_s {
     int block_mode = 1;          // 0 strict, 1 panel (MFMA gram + multi-rhs update)
     int blocks_per_cu = 4;       // 4 resident 256-thread blocks per CU (measured best on the 10M-row sweep)
     int mgs_mode = 1;
+    int keep_mb = 160;           // MB of trailing basis columns a project pass leaves cache-allocated for the unproject
+                                 // pass that follows (the Infinity Cache holds 256 MB); 0 = all loads non-temporal
     int fuse_passes = 1;         // fuse unproject(pass i) with project(pass i+1)
     int speculate = 1;           // enqueue the next expand's SpMV before syncing the host
     kk_basis spec_owner = nullptr;   // basis whose speculative result currently sits in SC_SPECA / its next column

@@ -195,6 +195,9 @@ def bench_bicgstab(ctx, nx=4000, ny=2500):
 
 if __name__ == "__main__":
     ctx = kk.default_context()
+    import os
+    if os.environ.get("KK_KEEP_MB"):
+        ctx.set_option("keep_mb", float(os.environ["KK_KEEP_MB"]))
     what = [a for a in sys.argv[1:] if not a.startswith("--")] or ["gmres", "block", "gkl"]
     if "gmres" in what:
         bench_gmres(ctx)
