@@ -1,0 +1,385 @@
+// libkrylov_hip.so, C ABI part 6: block (multi-vector) operations and the BlockLanczos steps
+// (src/factorizations/blocklanczos.jl).
+#include "kk_host.h"
+
+// ------------------------------------------------------------------------------------------
+// BlockLanczos (src/factorizations/blocklanczos.jl)
+// ------------------------------------------------------------------------------------------
+
+// M_host (p x q, ldm) = X' Y.  Panel mode: MFMA gram tiles into device scratch, ONE D2H + sync.
+int block_inner_run(kk_ctx c, const double* X, int64_t ldx, int p, const double* Y, int64_t ldy, int q, int64_t ld,
+                           double* M, int ldm) {
+    if (p == 0 || q == 0) return KK_OK;
+    KK_CHECK((int64_t)p * q <= KK_BLK_SCRATCH, KK_ERR_UNSUPPORTED, "block_inner: %d x %d too large", p, q);
+    if (c->block_mode == 0) {  // strict: p*q scalar inner calls (blocklanczos.jl:47-50)
+        for (int j = 0; j < q; ++j)
+            for (int i = 0; i < p; ++i)
+                KK_TRY(kk_launch_dot(c, X + (int64_t)i * ldx, Y + (int64_t)j * ldy, ld, c->blk + i + (int64_t)p * j));
+    } else {
+        for (int j0 = 0; j0 < q; j0 += 16)
+            for (int i0 = 0; i0 < p; i0 += 128)
+                KK_TRY(kk_launch_block_gram(c, X + (int64_t)i0 * ldx, ldx, std::min(128, p - i0), Y + (int64_t)j0 * ldy, ldy,
+                                            std::min(16, q - j0), ld, c->blk + i0 + (int64_t)p * j0, p));
+    }
+    if (c->block_mode != 0) KK_TRY(kk_allreduce(c, c->blk, (int64_t)p * q));
+    KK_HIP(hipMemcpyAsync(c->h_blk, c->blk, (size_t)p * q * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    KK_TRY(stream_sync(c));
+    for (int j = 0; j < q; ++j) memcpy(M + (size_t)j * ldm, c->h_blk + (size_t)j * p, p * sizeof(double));
+    return KK_OK;
+}
+
+KK_API int kk_block_inner(kk_basis bx, int cx, int p, kk_basis by, int cy, int q, double* M, int ldm) {
+    CHECK_BLOCK(bx, cx, p); CHECK_BLOCK(by, cy, q); CHECK_SAME(bx, by);
+    KK_CHECK(M && ldm >= p, KK_ERR_INVALID, "kk_block_inner: bad output");
+    return block_inner_run(bx->ctx, bx->col(cx), bx->ld, p, by->col(cy), by->ld, q, bx->ld, M, ldm);
+}
+
+KK_API int kk_block_apply(kk_op op, kk_basis bx, int cx, kk_basis by, int cy, int nb) {
+    KK_CHECK(op, KK_ERR_INVALID, "null op");
+    CHECK_BLOCK(bx, cx, nb); CHECK_BLOCK(by, cy, nb);
+    KK_TRY(check_apply(op, 0, bx, by));
+    KK_CHECK(!(bx == by && cx < cy + nb && cy < cx + nb), KK_ERR_INVALID, "kk_block_apply: blocks overlap");
+    gram_touch(by, cy);
+    return kk_launch_spmm(op->ctx, op->A, bx->col(cx), bx->ld, by->col(cy), by->ld, nb);
+}
+
+// stage the m x nb coefficient panel S[:, j0 : j0+nb] (host, column-major, leading dimension lds) for
+// kk_launch_block_update: row-major on the device with the row stride padded to the kernel's width (4 / 8 / 16,
+// zeros in the pad) so that the kernel reads whole rows with wide scalar loads and needs no j < nb branches
+static int stage_coef(kk_ctx c, const double* S, int lds, int m, int j0, int nb, const double** dev_out) {
+    // ring of KK_STAGE_SLOTS staging slots (same offset in the pinned and the device scratch): the host only waits
+    // for the stream when the ring wraps, not before every launch
+    const int st = kk_bu_stride(nb);
+    KK_CHECK((int64_t)m * st <= KK_STAGE_DOUBLES, KK_ERR_UNSUPPORTED, "block update: coefficient panel %d x %d too large", m, st);
+    if (c->stage_slot >= KK_STAGE_SLOTS) {
+        KK_TRY(stream_sync(c));
+        c->stage_slot = 0;
+    }
+    const size_t off = (size_t)c->stage_slot * KK_STAGE_DOUBLES;
+    c->stage_slot++;
+    for (int i = 0; i < m; ++i) {
+        double* row = c->h_blk + off + (size_t)i * st;
+        for (int j = 0; j < nb; ++j) row[j] = S[i + (size_t)lds * (j0 + j)];
+        for (int j = nb; j < st; ++j) row[j] = 0.0;
+    }
+    if (m > 0) KK_HIP(hipMemcpyAsync(c->blk + off, c->h_blk + off, (size_t)m * st * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    *dev_out = c->blk + off;
+    return KK_OK;
+}
+// W[:, j] = beta W[:, j] + alpha V S[:, j]  (S host, m x q col-major lds); norms_host optional
+static int block_update_run(kk_ctx c, const double* V, int64_t ld, int m, double* W, int64_t ldw, int q, const double* S,
+                            int lds, double alpha, double beta, double* norms) {
+    if (q == 0) return KK_OK;
+    KK_CHECK((int64_t)m * 16 + 64 <= KK_BLK_SCRATCH / 2, KK_ERR_UNSUPPORTED, "block_update: m=%d too large", m);
+    double* nrm_dev = c->blk + KK_BLK_SCRATCH / 2;  // q doubles
+    for (int j0 = 0; j0 < q; j0 += 16) {
+        const int nb = std::min(16, q - j0);
+        const double* Sd = nullptr;
+        KK_TRY(stage_coef(c, S, lds, m, j0, nb, &Sd));
+        KK_TRY(kk_launch_block_update(c, V, ld, m, W + (int64_t)j0 * ldw, W + (int64_t)j0 * ldw, ldw, ldw, nb, Sd, alpha,
+                                      beta, norms ? nrm_dev + j0 : nullptr));
+    }
+    if (norms) {
+        KK_HIP(hipMemcpyAsync(c->h_blk + KK_BLK_SCRATCH / 2, nrm_dev, q * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        KK_TRY(stream_sync(c));
+        for (int j = 0; j < q; ++j) norms[j] = std::sqrt(c->h_blk[KK_BLK_SCRATCH / 2 + j]);
+    }
+    return KK_OK;
+}
+
+KK_API int kk_block_update(kk_basis bw, int cw, int q, kk_basis b, int c0, int m, const double* S, int lds,
+                               double alpha, double beta, double* norms) {
+    CHECK_BLOCK(bw, cw, q); CHECK_BLOCK(b, c0, m); CHECK_SAME(bw, b);
+    KK_CHECK(S || m == 0, KK_ERR_INVALID, "null S");
+    KK_CHECK(lds >= m, KK_ERR_DIM, "kk_block_update: lds < m");
+    KK_CHECK(!(bw == b && cw < c0 + m && c0 < cw + q), KK_ERR_INVALID, "kk_block_update: W overlaps the basis range");
+    gram_touch(bw, cw);
+    return block_update_run(b->ctx, b->col(c0), b->ld, m, bw->col(cw), bw->ld, q, S, lds, alpha, beta, norms);
+}
+
+// block_reorthogonalize!(W, V) (blocklanczos.jl:277-284)
+static int block_reorth_run(kk_basis b, int c0, int m, int cw, int q) {
+    kk_ctx c = b->ctx;
+    if (m == 0 || q == 0) return KK_OK;
+    if (c->block_mode == 0) {  // strict: every W[i] swept against every basis vector, sequentially
+        for (int i = 0; i < q; ++i) {
+            for (int j0 = 0; j0 < m; j0 += KK_MAX_M) {
+                const int mm = std::min(KK_MAX_M, m - j0);
+                KK_TRY(pass_mgs_strict(c, b->col(c0 + j0), b->ld, mm, b->col(cw + i), WS_S, false, 0, nullptr, nullptr, false));
+            }
+        }
+        return stream_sync(c);
+    }
+    // panel: P = V' W (MFMA), W -= V P.  Differs from the sequential sweep by L*P with L the
+    // strictly-lower Gram matrix of V (O(eps)) -- far below roundoff of the update itself.
+    std::vector<double> P((size_t)m * q);
+    KK_TRY(block_inner_run(c, b->col(c0), b->ld, m, b->col(cw), b->ld, q, b->ld, P.data(), m));
+    return block_update_run(c, b->col(c0), b->ld, m, b->col(cw), b->ld, q, P.data(), m, -1.0, 1.0, nullptr);
+}
+
+KK_API int kk_block_reorthogonalize(kk_basis b, int c0, int m, int cw, int q) {
+    CHECK_BLOCK(b, c0, m); CHECK_BLOCK(b, cw, q);
+    KK_CHECK(!(cw < c0 + m && c0 < cw + q), KK_ERR_INVALID, "kk_block_reorthogonalize: W overlaps the basis range");
+    gram_touch(b, cw);
+    return block_reorth_run(b, c0, m, cw, q);
+}
+
+// ---- small dense helpers for the CholQR2 fast path (p <= 64, host) -------------------------
+// upper Cholesky G = R'R (column-major p x p); returns false if a pivot is not safely positive:
+// pivot^2 must exceed rel^2 * G_jj and abs_min^2
+static bool chol_upper_safe(const std::vector<double>& G, int p, std::vector<double>& R, double rel, double abs_min) {
+    R.assign((size_t)p * p, 0.0);
+    for (int j = 0; j < p; ++j) {
+        for (int i = 0; i < j; ++i) {
+            double t = G[i + (size_t)p * j];
+            for (int k = 0; k < i; ++k) t -= R[k + (size_t)p * i] * R[k + (size_t)p * j];
+            R[i + (size_t)p * j] = t / R[i + (size_t)p * i];
+        }
+        double d2 = G[j + (size_t)p * j];
+        for (int k = 0; k < j; ++k) d2 -= R[k + (size_t)p * j] * R[k + (size_t)p * j];
+        const double gjj = G[j + (size_t)p * j];
+        if (!(d2 > rel * rel * gjj) || !(d2 > abs_min * abs_min) || !std::isfinite(d2)) return false;
+        R[j + (size_t)p * j] = std::sqrt(d2);
+    }
+    return true;
+}
+static void triu_inverse(const std::vector<double>& R, int p, std::vector<double>& Ri) {
+    Ri.assign((size_t)p * p, 0.0);
+    for (int j = 0; j < p; ++j) {
+        Ri[j + (size_t)p * j] = 1.0 / R[j + (size_t)p * j];
+        for (int i = j - 1; i >= 0; --i) {
+            double t = 0;
+            for (int k = i + 1; k <= j; ++k) t += R[i + (size_t)p * k] * Ri[k + (size_t)p * j];
+            Ri[i + (size_t)p * j] = -t / R[i + (size_t)p * i];
+        }
+    }
+}
+
+static int block_qr_strict(kk_basis b, int c_in, int p, int c_out, double tol, double* R, int ldr, int* good_idx, int* ngood,
+                           int* is_drift);
+
+// block_qr! (blocklanczos.jl:312-353).  Panel mode, out of place: CholQR2 on the MFMA Gram panel
+//   G = B'B -> R1 = chol(G) -> Q1 = B R1^-1 -> G2 = Q1'Q1 -> R2 = chol(G2) -> Q = Q1 R2^-1, R = R2 R1
+// (768 N bytes instead of ~240 p N for the column-by-column sweep).  It is taken only when every
+// Cholesky pivot is safely away from the reference's rank / DGKS thresholds (beta_j > 1000 tol and
+// beta_j > 1e-5 |b_j|), in which case the reference's block_qr! keeps every column and does not
+// drift; otherwise the faithful column-by-column path below runs on the untouched input.
+static int block_qr_run(kk_basis b, int c_in, int p, int c_out, double tol, double* R, int ldr, int* good_idx, int* ngood,
+                        int* is_drift) {
+    kk_ctx c = b->ctx;
+    if (c->block_mode == 1 && c_out != c_in && p <= 64 && p >= 2) {
+        const int64_t ld = b->ld;
+        std::vector<double> G((size_t)p * p), R1, R2, Ri;
+        KK_TRY(block_inner_run(c, b->col(c_in), ld, p, b->col(c_in), ld, p, ld, G.data(), p));
+        if (chol_upper_safe(G, p, R1, 1e-5, 1000.0 * tol)) {
+            triu_inverse(R1, p, Ri);
+            // Q1 = B * R1^-1 (out of place)
+            for (int j0 = 0; j0 < p; j0 += 16) {
+                const int nb = std::min(16, p - j0);
+                const double* Sd = nullptr;
+                KK_TRY(stage_coef(c, Ri.data(), p, p, j0, nb, &Sd));
+                KK_TRY(kk_launch_block_update(c, b->col(c_in), ld, p, nullptr, b->col(c_out + j0), ld, ld, nb, Sd, 1.0, 0.0,
+                                              nullptr));
+            }
+            KK_TRY(block_inner_run(c, b->col(c_out), ld, p, b->col(c_out), ld, p, ld, G.data(), p));
+            double dev = 0;
+            for (int j = 0; j < p; ++j)
+                for (int i = 0; i < p; ++i) dev = std::max(dev, std::fabs(G[i + (size_t)p * j] - (i == j ? 1.0 : 0.0)));
+            if (dev < 1e-3 && chol_upper_safe(G, p, R2, 1e-2, 0.0)) {
+                triu_inverse(R2, p, Ri);
+                // Q = Q1 * R2^-1: needs all p input columns per row before any write -> via scratch columns
+                // is avoided by processing in ONE launch per 16 output columns reading the old values:
+                // output columns j0.. only depend on input columns <= j0+15 (upper-triangular), and
+                // are written after the kernel has read them (row-local), so go right-to-left.
+                for (int j0 = ((p - 1) / 16) * 16; j0 >= 0; j0 -= 16) {
+                    const int nb = std::min(16, p - j0);
+                    const int mm = j0 + nb;  // rows of R2^-1 that can be non-zero for these columns
+                    const double* Sd = nullptr;
+                    KK_TRY(stage_coef(c, Ri.data(), p, mm, j0, nb, &Sd));
+                    KK_TRY(kk_launch_block_update(c, b->col(c_out), ld, mm, nullptr, b->col(c_out + j0), ld, ld, nb, Sd, 1.0,
+                                                  0.0, nullptr));
+                }
+                // R = R2 * R1
+                for (int j = 0; j < p; ++j)
+                    for (int i = 0; i < p; ++i) {
+                        double t = 0;
+                        for (int k = i; k <= j; ++k) t += R2[i + (size_t)p * k] * R1[k + (size_t)p * j];
+                        R[i + (size_t)ldr * j] = (i <= j) ? t : 0.0;
+                    }
+                for (int j = 0; j < p; ++j) good_idx[j] = j;
+                *ngood = p;
+                if (is_drift) *is_drift = 0;
+                return KK_OK;
+            }
+        }
+    }
+    return block_qr_strict(b, c_in, p, c_out, tol, R, ldr, good_idx, ngood, is_drift);
+}
+
+// faithful column-by-column MGS with DGKS and rank detection (blocklanczos.jl:312-353)
+static int block_qr_strict(kk_basis b, int c_in, int p, int c_out, double tol, double* R, int ldr, int* good_idx, int* ngood,
+                           int* is_drift) {
+    kk_ctx c = b->ctx;
+    const int64_t ld = b->ld;
+    std::vector<double> Rf((size_t)p * p, 0.0);  // full p x p, column-major
+    std::vector<char> idx(p, 1);
+    bool drift = false;
+    if (c_out != c_in)
+        for (int j = 0; j < p; ++j) KK_TRY(kk_launch_copy_scal(c, b->col(c_out + j), b->col(c_in + j), ld, 1.0));
+    double* Q = b->col(c_out);
+    auto finish_col = [&](int j, double beta) -> int {
+        if ((j == 0 && beta > tol) || (j > 0 && !(beta < tol))) {  // :319 uses beta > tol, :343 uses beta < tol
+            Rf[j + (size_t)p * j] = beta;
+            return kk_launch_scal(c, Q + (int64_t)j * ld, ld, 1.0 / beta, nullptr);
+        }
+        idx[j] = 0;
+        KK_HIP(hipMemsetAsync(Q + (int64_t)j * ld, 0, ld * sizeof(double), c->stream));
+        return KK_OK;
+    };
+    // column 1
+    KK_TRY(kk_launch_nrm2(c, Q, ld, SCP(c, SC_NRM2)));
+    KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2, 2, 0));
+    KK_TRY(stream_sync(c));
+    KK_TRY(finish_col(0, pin(c, WS_SCAL + SC_NRM2)[1]));
+    for (int j = 1; j < p; ++j) {
+        double* w = Q + (int64_t)j * ld;
+        KK_TRY(pass_mgs_strict(c, Q, ld, j, w, WS_S, true, 0, nullptr, nullptr, false));  // first MGS :328-332
+        KK_TRY(stream_sync(c));
+        for (int i = 0; i < j; ++i) Rf[i + (size_t)p * j] = pin(c, WS_S)[i];
+        double beta = pin(c, WS_SCAL + SC_NRM2)[1];
+        if (tol < beta && beta < 100 * tol) {  // DGKS :334-342
+            drift = true;
+            KK_TRY(pass_mgs_strict(c, Q, ld, j, w, WS_S, true, 0, nullptr, nullptr, false));
+            KK_TRY(stream_sync(c));
+            for (int i = 0; i < j; ++i) Rf[i + (size_t)p * j] += pin(c, WS_S)[i];
+            beta = pin(c, WS_SCAL + SC_NRM2)[1];
+        }
+        KK_TRY(finish_col(j, beta));
+    }
+    // compact the good vectors to the front (push!(V, R[good_idx]), blocklanczos.jl:219)
+    int ng = 0;
+    for (int j = 0; j < p; ++j) {
+        if (!idx[j]) continue;
+        if (ng != j) KK_TRY(kk_launch_copy_scal(c, Q + (int64_t)ng * ld, Q + (int64_t)j * ld, ld, 1.0));
+        good_idx[ng] = j;
+        for (int jj = 0; jj < p; ++jj) R[ng + (size_t)ldr * jj] = Rf[j + (size_t)p * jj];
+        ++ng;
+    }
+    *ngood = ng;
+    if (is_drift) *is_drift = drift ? 1 : 0;
+    return KK_OK;
+}
+
+KK_API int kk_block_qr(kk_basis b, int c_in, int p, int c_out, double tol, double* R, int ldr, int* good_idx,
+                           int* ngood, int* is_drift) {
+    CHECK_BLOCK(b, c_in, p); CHECK_BLOCK(b, c_out, p);
+    KK_CHECK(p >= 1 && p <= KK_MAX_M, KK_ERR_INVALID, "kk_block_qr: p=%d", p);
+    KK_CHECK(R && good_idx && ngood && ldr >= p, KK_ERR_INVALID, "kk_block_qr: bad output arguments");
+    KK_CHECK(c_out == c_in || c_out + p <= c_in || c_in + p <= c_out, KK_ERR_INVALID, "kk_block_qr: partial overlap");
+    gram_touch(b, std::min(c_in, c_out));
+    return block_qr_run(b, c_in, p, c_out, tol, R, ldr, good_idx, ngood, is_drift);
+}
+
+KK_API int kk_blocklanczos_initialize(kk_op op, kk_basis b, int c_x0, int bs0, int c_r, double qr_tol, int* bs,
+                                          double* M1, int ldm, double* norm_R) {
+    KK_TRY(check_square_op(op, b));
+    CHECK_BLOCK(b, c_x0, bs0); CHECK_BLOCK(b, c_r, bs0); CHECK_BLOCK(b, 0, bs0);
+    KK_CHECK(bs0 >= 1 && bs && M1 && norm_R && ldm >= bs0, KK_ERR_INVALID, "kk_blocklanczos_initialize: bad arguments");
+    KK_CHECK(c_r >= bs0 && (c_x0 == 0 || c_x0 >= bs0) && !(c_x0 < c_r + bs0 && c_r < c_x0 + bs0), KK_ERR_INVALID,
+             "kk_blocklanczos_initialize: column ranges overlap");
+    kk_ctx c = b->ctx;
+    gram_touch(b, 0);
+    // beta0 = norm(X0) (Frobenius) must not vanish  :168-169
+    std::vector<double> G((size_t)bs0 * bs0), R((size_t)bs0 * bs0);
+    std::vector<int> good(bs0);
+    double n2 = 0;
+    for (int j = 0; j < bs0; ++j) {
+        KK_TRY(kk_launch_nrm2(c, b->col(c_x0 + j), b->ld, SCP(c, SC_NRM2)));
+        KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2, 1, 0));
+        KK_TRY(stream_sync(c));
+        n2 += pin(c, WS_SCAL + SC_NRM2)[0];
+    }
+    if (n2 == 0.0) {
+        kk_set_error("initial vector should not have norm zero");
+        return KK_ERR_ZERO_NORM;
+    }
+    int ng = 0, drift = 0;
+    KK_TRY(block_qr_run(b, c_x0, bs0, 0, qr_tol, R.data(), bs0, good.data(), &ng, &drift));  // X1 = block_qr!(X0)[good]  :175-177
+    KK_CHECK(ng >= 1, KK_ERR_ZERO_NORM, "kk_blocklanczos_initialize: start block has numerical rank 0");
+    // AX1 = A X1 ; M1 = block_inner(X1, AX1) ; AX1[j] -= X1[i] M1[i,j]   :181-192
+    KK_TRY(kk_launch_spmm(c, op->A, b->col(0), b->ld, b->col(c_r), b->ld, ng));
+    KK_TRY(block_inner_run(c, b->col(0), b->ld, ng, b->col(c_r), b->ld, ng, b->ld, M1, ldm));
+    std::vector<double> nr(ng);
+    KK_TRY(block_update_run(c, b->col(0), b->ld, ng, b->col(c_r), b->ld, ng, M1, ldm, -1.0, 1.0, nr.data()));
+    double f = 0;
+    for (int j = 0; j < ng; ++j) f += nr[j] * nr[j];
+    *norm_R = std::sqrt(f);
+    *bs = ng;
+    return KK_OK;
+}
+
+KK_API int kk_blocklanczos_expand(kk_op op, kk_basis b, int k, int bs_r, int c_r, int c_rnext, double qr_tol,
+                                      int* bs_next, double* B, int ldb, double* M, int ldm, double* norm_R, int* is_drift) {
+    KK_TRY(check_square_op(op, b));
+    CHECK_BLOCK(b, 0, k + bs_r); CHECK_BLOCK(b, c_r, bs_r); CHECK_BLOCK(b, c_rnext, bs_r);
+    KK_CHECK(k >= bs_r && bs_r >= 1 && bs_next && B && M && norm_R && ldb >= bs_r && ldm >= bs_r, KK_ERR_INVALID,
+             "kk_blocklanczos_expand: bad arguments");
+    KK_CHECK(c_r >= k + bs_r && c_rnext >= k + bs_r && (c_rnext + bs_r <= c_r || c_r + bs_r <= c_rnext), KK_ERR_INVALID,
+             "kk_blocklanczos_expand: residual blocks must lie beyond column k+bs_r and not overlap");
+    kk_ctx c = b->ctx;
+    gram_touch(b, k);
+    std::vector<int> good(bs_r);
+    int ng = 0, drift = 0;
+    // B, good_idx, is_drift = block_qr!(R, qr_tol); out of place: the input block stays intact as Rcopy   :209-211
+    KK_TRY(block_qr_run(b, c_r, bs_r, k, qr_tol, B, ldb, good.data(), &ng, &drift));
+    const int drift_first = drift;
+    if (drift) {  // :212-216
+        KK_TRY(block_reorth_run(b, 0, k, k, ng));
+        std::vector<double> R2((size_t)ng * ng);
+        std::vector<int> good2(ng);
+        int ng2 = 0, d2 = 0;
+        KK_TRY(block_qr_run(b, k, ng, k, qr_tol, R2.data(), ng, good2.data(), &ng2, &d2));
+        ng = ng2;
+        KK_TRY(block_inner_run(c, b->col(k), b->ld, ng, b->col(c_r), b->ld, bs_r, b->ld, B, ldb));  // B = block_inner(R[good], Rcopy)
+    }
+    KK_CHECK(ng >= 1, KK_ERR_ZERO_NORM, "kk_blocklanczos_expand: residual block has numerical rank 0 (invariant subspace)");
+    const int kn = k + ng;
+    // block_lanczosrecurrence :242-263 : AX = A X ; M = block_inner(X, AX)
+    double* AX = b->col(c_rnext);
+    KK_TRY(kk_launch_spmm(c, op->A, b->col(k), b->ld, AX, b->ld, ng));
+    KK_TRY(block_inner_run(c, b->col(k), b->ld, ng, AX, b->ld, ng, b->ld, M, ldm));
+    // AX[j] -= sum_i X[i] M[i,j] + sum_i Xprev[i] conj(B[j,i]): one update over the contiguous [Xprev | X]
+    {
+        const int mm = bs_r + ng;
+        std::vector<double> S((size_t)mm * ng);
+        for (int j = 0; j < ng; ++j) {
+            for (int i = 0; i < bs_r; ++i) S[i + (size_t)mm * j] = B[j + (size_t)ldb * i];
+            for (int i = 0; i < ng; ++i) S[bs_r + i + (size_t)mm * j] = M[i + (size_t)ldm * j];
+        }
+        KK_TRY(block_update_run(c, b->col(k - bs_r), b->ld, mm, AX, b->ld, ng, S.data(), mm, -1.0, 1.0, nullptr));
+    }
+    // block_reorthogonalize!(AX, V) with fused Frobenius norm of the result
+    std::vector<double> nr(ng);
+    if (c->block_mode == 0) {
+        KK_TRY(block_reorth_run(b, 0, kn, c_rnext, ng));
+        double f = 0;
+        for (int j = 0; j < ng; ++j) {
+            KK_TRY(kk_launch_nrm2(c, AX + (int64_t)j * b->ld, b->ld, SCP(c, SC_NRM2)));
+            KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2, 1, 0));
+            KK_TRY(stream_sync(c));
+            f += pin(c, WS_SCAL + SC_NRM2)[0];
+        }
+        *norm_R = std::sqrt(f);
+    } else {
+        std::vector<double> P((size_t)kn * ng);
+        KK_TRY(block_inner_run(c, b->col(0), b->ld, kn, AX, b->ld, ng, b->ld, P.data(), kn));
+        KK_TRY(block_update_run(c, b->col(0), b->ld, kn, AX, b->ld, ng, P.data(), kn, -1.0, 1.0, nr.data()));
+        double f = 0;
+        for (int j = 0; j < ng; ++j) f += nr[j] * nr[j];
+        *norm_R = std::sqrt(f);
+    }
+    *bs_next = ng;
+    if (is_drift) *is_drift = drift_first;
+    return KK_OK;
+}
+

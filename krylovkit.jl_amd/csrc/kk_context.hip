@@ -1,0 +1,387 @@
+// libkrylov_hip.so, C ABI part 1 (include/krylov_hip.h): error reporting, contexts and their options, event
+// profiling, basis slabs and the L1 vector verbs.  Host-side C++ only orchestrates kernel launches on one HIP stream;
+// there is NO CPU compute fallback anywhere in this library.
+#include "kk_host.h"
+
+static thread_local std::string g_last_error;
+
+void kk_set_error(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+}
+int kk_hip_fail(hipError_t e, const char* what, const char* file, int line) {
+    kk_set_error("HIP error %d (%s) in %s at %s:%d", (int)e, hipGetErrorString(e), what, file, line);
+    return KK_ERR_HIP;
+}
+
+// ------------------------------------------------------------------------------------------
+// library / context
+// ------------------------------------------------------------------------------------------
+KK_API int kk_version(void) { return KK_VERSION; }
+KK_API const char* kk_last_error(void) { return g_last_error.c_str(); }
+
+KK_API int kk_device_count(int* count) {
+    KK_CHECK(count, KK_ERR_INVALID, "kk_device_count: null pointer");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        n = 0;
+    }
+    *count = n;
+    return KK_OK;
+}
+
+KK_API int kk_ctx_create(int device, kk_ctx* out) {
+    KK_CHECK(out, KK_ERR_INVALID, "kk_ctx_create: null out");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        kk_set_error("kk_ctx_create: no HIP device visible; libkrylov_hip has no CPU fallback");
+        return KK_ERR_NO_DEVICE;
+    }
+    KK_CHECK(device >= 0 && device < n, KK_ERR_INVALID, "kk_ctx_create: device %d out of range [0,%d)", device, n);
+    KK_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    KK_HIP(hipGetDeviceProperties(&prop, device));
+    kk_ctx c = new kk_ctx_s();
+    c->device = device;
+    c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    KK_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    KK_HIP(hipMalloc(&c->ws_own, WS_TOTAL * sizeof(double)));
+    KK_HIP(hipMemset(c->ws_own, 0, WS_TOTAL * sizeof(double)));
+    c->ws = c->ws_own;
+    KK_HIP(hipMalloc(&c->partials, (size_t)(2 * KK_MAX_M + 8) * KK_MAX_BLOCKS * sizeof(double)));
+    KK_HIP(hipHostMalloc(&c->h_pin, 4 * WS_TOTAL * sizeof(double), hipHostMallocDefault));
+    KK_HIP(hipHostMalloc(&c->h_U, (size_t)KK_MAX_M * KK_MAX_M * sizeof(double), hipHostMallocDefault));
+    KK_HIP(hipMalloc(&c->blk_own, (size_t)KK_BLK_SCRATCH * sizeof(double)));
+    c->blk = c->blk_own;
+    KK_HIP(hipHostMalloc(&c->h_blk, (size_t)KK_BLK_SCRATCH * sizeof(double), hipHostMallocDefault));
+    if (getenv("KK_BLOCK_MODE")) c->block_mode = atoi(getenv("KK_BLOCK_MODE"));
+    KK_HIP(hipEventCreate(&c->t0));
+    KK_HIP(hipEventCreate(&c->t1));
+    KK_HIP(hipEventCreateWithFlags(&c->ev_fetch, hipEventDisableTiming));
+    KK_HIP(hipEventCreateWithFlags(&c->ev_fetch2, hipEventDisableTiming));
+    const char* env = getenv("KK_BLOCKS_PER_CU");
+    if (env && atoi(env) > 0) c->blocks_per_cu = atoi(env);
+    env = getenv("KK_MGS_MODE");
+    if (env) c->mgs_mode = atoi(env);
+    *out = c;
+    return KK_OK;
+}
+
+KK_API int kk_ctx_destroy(kk_ctx c) {
+    if (!c) return KK_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& p : c->prof_pending) { c->event_pool.push_back(p.second.first); c->event_pool.push_back(p.second.second); }
+    for (auto e : c->event_pool) (void)hipEventDestroy(e);
+    (void)hipEventDestroy(c->t0);
+    (void)hipEventDestroy(c->t1);
+    (void)hipEventDestroy(c->ev_fetch);
+    (void)hipEventDestroy(c->ev_fetch2);
+    (void)hipFree(c->ws_own);
+    (void)hipFree(c->partials);
+    (void)hipHostFree(c->h_pin);
+    (void)hipHostFree(c->h_U);
+    (void)hipFree(c->blk_own);
+    (void)hipHostFree(c->h_blk);
+    (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return KK_OK;
+}
+
+KK_API int kk_ctx_set_stream(kk_ctx c, void* s) {
+    KK_CHECK(c, KK_ERR_INVALID, "null ctx");
+    KK_HIP(hipStreamSynchronize(c->stream));
+    c->stream = s ? (hipStream_t)s : c->own_stream;
+    return KK_OK;
+}
+KK_API int kk_ctx_get_stream(kk_ctx c, void** s) {
+    KK_CHECK(c && s, KK_ERR_INVALID, "null arg");
+    *s = (void*)c->stream;
+    return KK_OK;
+}
+KK_API int kk_ctx_sync(kk_ctx c) {
+    KK_CHECK(c, KK_ERR_INVALID, "null ctx");
+    KK_HIP(hipStreamSynchronize(c->stream));
+    return KK_OK;
+}
+KK_API int kk_ctx_set_option(kk_ctx c, const char* key, double value) {
+    KK_CHECK(c && key, KK_ERR_INVALID, "null arg");
+    if (!strcmp(key, "blocks_per_cu")) {
+        KK_CHECK(value >= 1 && value * c->num_cus <= KK_MAX_BLOCKS, KK_ERR_INVALID, "blocks_per_cu out of range");
+        c->blocks_per_cu = (int)value;
+    } else if (!strcmp(key, "mgs_mode")) {
+        KK_CHECK(value == 0 || value == 1, KK_ERR_INVALID, "mgs_mode must be 0 (strict) or 1 (lowsync)");
+        c->mgs_mode = (int)value;
+    } else if (!strcmp(key, "speculate")) {
+        c->speculate = value != 0;
+    } else if (!strcmp(key, "keep_mb")) {
+        KK_CHECK(value >= 0 && value <= 4096, KK_ERR_INVALID, "keep_mb out of range");
+        c->keep_mb = (int)value;
+    } else if (!strcmp(key, "fuse_passes")) {
+        c->fuse_passes = value != 0;
+    } else if (!strcmp(key, "block_mode")) {
+        KK_CHECK(value == 0 || value == 1, KK_ERR_INVALID, "block_mode must be 0 (strict) or 1 (panel)");
+        c->block_mode = (int)value;
+    } else {
+        kk_set_error("unknown option '%s'", key);
+        return KK_ERR_INVALID;
+    }
+    return KK_OK;
+}
+KK_API int kk_ctx_get_option(kk_ctx c, const char* key, double* value) {
+    KK_CHECK(c && key && value, KK_ERR_INVALID, "null arg");
+    if (!strcmp(key, "blocks_per_cu")) *value = c->blocks_per_cu;
+    else if (!strcmp(key, "mgs_mode")) *value = c->mgs_mode;
+    else if (!strcmp(key, "num_cus")) *value = c->num_cus;
+    else if (!strcmp(key, "block_mode")) *value = c->block_mode;
+    else if (!strcmp(key, "keep_mb")) *value = c->keep_mb;
+    else if (!strcmp(key, "fuse_passes")) *value = c->fuse_passes;
+    else if (!strcmp(key, "speculate")) *value = c->speculate;
+    else {
+        kk_set_error("unknown option '%s'", key);
+        return KK_ERR_INVALID;
+    }
+    return KK_OK;
+}
+KK_API int kk_ctx_set_allreduce(kk_ctx c, kk_allreduce_fn fn, void* user) {
+    KK_CHECK(c, KK_ERR_INVALID, "null ctx");
+    KK_HIP(hipStreamSynchronize(c->stream));
+    c->allreduce = fn;
+    c->allreduce_user = user;
+    return KK_OK;
+}
+KK_API int kk_ctx_workspace_size(kk_ctx c, int64_t* ws_count, int64_t* blk_count) {
+    KK_CHECK(c, KK_ERR_INVALID, "null ctx");
+    if (ws_count) *ws_count = WS_TOTAL;
+    if (blk_count) *blk_count = KK_BLK_SCRATCH;
+    return KK_OK;
+}
+KK_API int kk_ctx_set_workspace(kk_ctx c, void* ws_device, void* blk_device) {
+    KK_CHECK(c, KK_ERR_INVALID, "null ctx");
+    KK_HIP(hipStreamSynchronize(c->stream));
+    c->ws = ws_device ? (double*)ws_device : c->ws_own;
+    c->blk = blk_device ? (double*)blk_device : c->blk_own;
+    KK_HIP(hipMemsetAsync(c->ws, 0, WS_TOTAL * sizeof(double), c->stream));
+    return KK_OK;
+}
+KK_API int kk_ctx_timer_start(kk_ctx c) {
+    KK_CHECK(c, KK_ERR_INVALID, "null ctx");
+    KK_HIP(hipEventRecord(c->t0, c->stream));
+    return KK_OK;
+}
+KK_API int kk_ctx_timer_stop(kk_ctx c, double* ms) {
+    KK_CHECK(c && ms, KK_ERR_INVALID, "null arg");
+    KK_HIP(hipEventRecord(c->t1, c->stream));
+    KK_HIP(hipEventSynchronize(c->t1));
+    float f = 0;
+    KK_HIP(hipEventElapsedTime(&f, c->t0, c->t1));
+    *ms = f;
+    return KK_OK;
+}
+
+// ---- per-kernel-class event profiling
+static hipEvent_t prof_event(kk_ctx c) {
+    if (!c->event_pool.empty()) {
+        hipEvent_t e = c->event_pool.back();
+        c->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+static void prof_resolve(kk_ctx c) {
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& p : c->prof_pending) {
+        float f = 0;
+        if (hipEventElapsedTime(&f, p.second.first, p.second.second) == hipSuccess) {
+            auto& e = c->prof_tab[p.first];
+            e.ms += f;
+            e.launches += 1;
+        }
+        c->event_pool.push_back(p.second.first);
+        c->event_pool.push_back(p.second.second);
+    }
+    c->prof_pending.clear();
+}
+void kk_prof_begin(kk_ctx c, const char* cls) {
+    hipEvent_t a = prof_event(c), b = prof_event(c);
+    (void)hipEventRecord(a, c->stream);
+    c->prof_pending.push_back({cls, {a, b}});
+}
+void kk_prof_end(kk_ctx c) {
+    if (c->prof_pending.empty()) return;
+    (void)hipEventRecord(c->prof_pending.back().second.second, c->stream);
+    if (c->prof_pending.size() > 8192) prof_resolve(c);
+}
+KK_API int kk_ctx_prof_enable(kk_ctx c, int on) {
+    KK_CHECK(c, KK_ERR_INVALID, "null ctx");
+    if (!on && c->prof) prof_resolve(c);
+    c->prof = (on == 2) ? 2 : (on != 0);
+    return KK_OK;
+}
+KK_API int kk_ctx_prof_reset(kk_ctx c) {
+    KK_CHECK(c, KK_ERR_INVALID, "null ctx");
+    prof_resolve(c);
+    c->prof_tab.clear();
+    return KK_OK;
+}
+KK_API int kk_ctx_prof_get(kk_ctx c, const char* cls, double* total_ms, int64_t* launches) {
+    KK_CHECK(c && cls, KK_ERR_INVALID, "null arg");
+    prof_resolve(c);
+    auto it = c->prof_tab.find(cls);
+    if (total_ms) *total_ms = it == c->prof_tab.end() ? 0.0 : it->second.ms;
+    if (launches) *launches = it == c->prof_tab.end() ? 0 : it->second.launches;
+    return KK_OK;
+}
+
+kk_part kk_partition(kk_ctx c, int64_t ld) {
+    const int64_t nsub = ld / KK_SUB;
+    int64_t target = (int64_t)c->num_cus * c->blocks_per_cu;
+    if (target > KK_MAX_BLOCKS) target = KK_MAX_BLOCKS;
+    if (target < 1) target = 1;
+    const int64_t spb = std::max<int64_t>(1, (nsub + target - 1) / target);
+    kk_part p;
+    p.rpb = spb * KK_SUB;
+    p.nblk = (int)std::max<int64_t>(1, (nsub + spb - 1) / spb);
+    return p;
+}
+
+// D2H fetch of `count` workspace doubles starting at `off` into pinned slot `slot` (queued; no sync)
+int ws_fetch_async(kk_ctx c, int64_t off, int64_t count, int slot) {
+    KK_HIP(hipMemcpyAsync(c->h_pin + (int64_t)slot * WS_TOTAL + off, c->ws + off, count * sizeof(double),
+                          hipMemcpyDeviceToHost, c->stream));
+    return KK_OK;
+}
+int stream_sync(kk_ctx c) {
+    KK_HIP(hipStreamSynchronize(c->stream));
+    return KK_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// basis slab
+// ------------------------------------------------------------------------------------------
+KK_API int kk_basis_create(kk_ctx c, int64_t n, int capacity, kk_basis* out) {
+    KK_CHECK(c && out, KK_ERR_INVALID, "kk_basis_create: null arg");
+    KK_CHECK(n > 0 && capacity > 0, KK_ERR_INVALID, "kk_basis_create: n=%lld capacity=%d", (long long)n, capacity);
+    KK_HIP(hipSetDevice(c->device));
+    int64_t ld = (n + KK_SUB - 1) / KK_SUB * KK_SUB;
+    if (((ld / KK_SUB) & 1) == 0) ld += KK_SUB;  // odd number of 4 KiB row chunks per column: no channel aliasing
+    kk_basis b = new kk_basis_s();
+    b->ctx = c; b->n = n; b->ld = ld; b->cap = capacity;
+    size_t bytes = (size_t)ld * capacity * sizeof(double);
+    hipError_t e = hipMalloc(&b->d, bytes);
+    if (e != hipSuccess) {
+        delete b;
+        kk_set_error("kk_basis_create: hipMalloc of %zu bytes failed: %s", bytes, hipGetErrorString(e));
+        return KK_ERR_NOMEM;
+    }
+    KK_HIP(hipMemsetAsync(b->d, 0, bytes, c->stream));
+    *out = b;
+    return KK_OK;
+}
+KK_API int kk_basis_free(kk_basis b) {
+    if (!b) return KK_OK;
+    (void)hipDeviceSynchronize();  // not the context's stream: finalizers may run after the context is gone
+    (void)hipFree(b->d_gram);
+    (void)hipFree(b->d);
+    delete b;
+    return KK_OK;
+}
+KK_API int kk_basis_info(kk_basis b, int64_t* n, int64_t* ld, int* capacity, void** dptr) {
+    KK_CHECK(b, KK_ERR_INVALID, "null basis");
+    if (n) *n = b->n;
+    if (ld) *ld = b->ld;
+    if (capacity) *capacity = b->cap;
+    if (dptr) *dptr = b->d;
+    return KK_OK;
+}
+KK_API int kk_basis_invalidate_gram(kk_basis b) {
+    KK_CHECK(b, KK_ERR_INVALID, "null basis");
+    b->gram_rows = 0;
+    return KK_OK;
+}
+KK_API int kk_basis_upload(kk_basis b, int col, const double* host) {
+    CHECK_COL(b, col);
+    KK_CHECK(host, KK_ERR_INVALID, "null host pointer");
+    gram_touch(b, col);
+    KK_HIP(hipMemcpyAsync(b->col(col), host, b->n * sizeof(double), hipMemcpyHostToDevice, b->ctx->stream));
+    return stream_sync(b->ctx);
+}
+KK_API int kk_basis_download(kk_basis b, int col, double* host) {
+    CHECK_COL(b, col);
+    KK_CHECK(host, KK_ERR_INVALID, "null host pointer");
+    KK_HIP(hipMemcpyAsync(host, b->col(col), b->n * sizeof(double), hipMemcpyDeviceToHost, b->ctx->stream));
+    return stream_sync(b->ctx);
+}
+KK_API int kk_basis_upload_device(kk_basis b, int col, const void* dptr) {
+    CHECK_COL(b, col);
+    gram_touch(b, col);
+    KK_HIP(hipMemcpyAsync(b->col(col), dptr, b->n * sizeof(double), hipMemcpyDeviceToDevice, b->ctx->stream));
+    return KK_OK;
+}
+KK_API int kk_basis_download_device(kk_basis b, int col, void* dptr) {
+    CHECK_COL(b, col);
+    KK_HIP(hipMemcpyAsync(dptr, b->col(col), b->n * sizeof(double), hipMemcpyDeviceToDevice, b->ctx->stream));
+    return KK_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// L1 verbs
+// ------------------------------------------------------------------------------------------
+
+KK_API int kk_vec_dot(kk_basis bx, int cx, kk_basis by, int cy, double* out) {
+    CHECK_COL(bx, cx); CHECK_COL(by, cy); CHECK_SAME(bx, by);
+    KK_CHECK(out, KK_ERR_INVALID, "null out");
+    kk_ctx c = bx->ctx;
+    KK_TRY(kk_launch_dot(c, bx->col(cx), by->col(cy), bx->ld, SCP(c, SC_DOT)));
+    KK_TRY(ws_fetch_async(c, WS_SCAL + SC_DOT, 1, 0));
+    KK_TRY(stream_sync(c));
+    *out = *pin(c, WS_SCAL + SC_DOT);
+    return KK_OK;
+}
+KK_API int kk_vec_nrm2(kk_basis bx, int cx, double* out) {
+    CHECK_COL(bx, cx);
+    KK_CHECK(out, KK_ERR_INVALID, "null out");
+    kk_ctx c = bx->ctx;
+    KK_TRY(kk_launch_nrm2(c, bx->col(cx), bx->ld, SCP(c, SC_NRM2)));
+    KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2, 2, 0));
+    KK_TRY(stream_sync(c));
+    *out = pin(c, WS_SCAL + SC_NRM2)[1];
+    return KK_OK;
+}
+KK_API int kk_vec_axpby(kk_basis by, int cy, kk_basis bx, int cx, double a, double b) {
+    CHECK_COL(bx, cx); CHECK_COL(by, cy); CHECK_SAME(bx, by);
+    gram_touch(by, cy);
+    return kk_launch_axpby(by->ctx, by->col(cy), bx->col(cx), by->ld, a, b, nullptr, 1.0, 0);
+}
+KK_API int kk_vec_scal(kk_basis bx, int cx, double a) {
+    CHECK_COL(bx, cx);
+    gram_touch(bx, cx);
+    return kk_launch_scal(bx->ctx, bx->col(cx), bx->ld, a, nullptr);
+}
+KK_API int kk_vec_copy_scal(kk_basis by, int cy, kk_basis bx, int cx, double a) {
+    CHECK_COL(bx, cx); CHECK_COL(by, cy); CHECK_SAME(bx, by);
+    gram_touch(by, cy);
+    return kk_launch_copy_scal(by->ctx, by->col(cy), bx->col(cx), by->ld, a);
+}
+KK_API int kk_vec_zero(kk_basis bx, int cx) {
+    CHECK_COL(bx, cx);
+    gram_touch(bx, cx);
+    KK_HIP(hipMemsetAsync(bx->col(cx), 0, bx->ld * sizeof(double), bx->ctx->stream));
+    return KK_OK;
+}
+KK_API int kk_vec_fill_random(kk_basis bx, int cx, uint64_t seed) {
+    CHECK_COL(bx, cx);
+    gram_touch(bx, cx);
+    return kk_launch_fill_random(bx->ctx, bx->col(cx), bx->n, seed);
+}
+

@@ -1,0 +1,61 @@
+// Host-side internals shared by the C-ABI translation units of libkrylov_hip.so (kk_context / kk_sparse / kk_orth /
+// kk_krylov / kk_block / kk_solvers / kk_dev .hip).  Nothing here is exported: the library is built with
+// -fvisibility=hidden and only the KK_API entry points of include/krylov_hip.h are visible.
+#pragma once
+#include "kk_internal.h"
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+
+#define KK_API extern "C" __attribute__((visibility("default")))
+
+static const double KK_EPS = std::numeric_limits<double>::epsilon();
+#define WSP(c, off) ((c)->ws + (off))
+#define SCP(c, slot) ((c)->ws + WS_SCAL + (slot))
+
+// ---- argument checks (status + message, never an exception across the C boundary)
+#define CHECK_COL(b, c) KK_CHECK((b) && (c) >= 0 && (c) < (b)->cap, KK_ERR_INVALID, "%s: column %d out of range", __func__, (c))
+#define CHECK_SAME(bx, by) KK_CHECK((bx)->ctx == (by)->ctx && (bx)->n == (by)->n && (bx)->ld == (by)->ld, KK_ERR_DIM, "%s: vector length mismatch (%lld vs %lld)", __func__, (long long)(bx)->n, (long long)(by)->n)
+#define CHECK_RANGE(b, c0, m) KK_CHECK((b) && (c0) >= 0 && (m) >= 0 && (c0) + (m) <= (b)->cap && (m) <= KK_MAX_M, KK_ERR_INVALID, "%s: column range [%d,%d) invalid (capacity %d, max %d per call)", __func__, (c0), (c0) + (m), (b) ? (b)->cap : 0, KK_MAX_M)
+#define CHECK_BLOCK(b, c0, p) KK_CHECK((b) && (c0) >= 0 && (p) >= 0 && (c0) + (p) <= (b)->cap, KK_ERR_INVALID, "%s: block [%d,%d) outside capacity %d", __func__, (c0), (c0) + (p), (b) ? (b)->cap : 0)
+
+// ---- scalar read-backs (kk_context.hip): results of the finalize kernels travel through the pinned mirror of the
+// scalar workspace; `slot` selects one of its 4 copies
+int ws_fetch_async(kk_ctx c, int64_t off, int64_t count, int slot);
+int stream_sync(kk_ctx c);
+static inline const double* pin(kk_ctx c, int64_t off, int slot = 0) { return c->h_pin + (int64_t)slot * WS_TOTAL + off; }
+// any mutation of a slab column: invalidates the cached Gram rows from that column on and a speculative next-step SpMV
+static inline void gram_touch(kk_basis b, int col) {
+    if (col < b->gram_rows) b->gram_rows = col;
+    b->spec_valid = false;
+}
+
+// ---- sparse operators (kk_sparse.hip)
+int get_matrix(kk_op op, int transpose, const kk_sparse_dev** M);
+int check_apply(kk_op op, int transpose, kk_basis bx, kk_basis by);
+
+// ---- orthogonalisation (kk_orth.hip)
+int orth_run(kk_basis b, int c0, int m, double* w, kk_orth_t alg, double eta, double* x, double* nrm, int* npasses,
+             bool want_norm);
+int orth_vec_run(kk_ctx c, const double* q, double* w, int64_t ld, kk_orth_t alg, double eta, double* s_out,
+                 double* nrm_out, bool want_norm);
+// one strict MGS sweep over V[0:m) with the fused axpy+dot kernel; coefficients land in the scalar workspace at ws_s
+int pass_mgs_strict(kk_ctx c, const double* V, int64_t ld, int m, double* w, int64_t ws_s, bool want_norm, int slot,
+                    const double* carry_q, const double* carry_s, bool leave_carry);
+int gram_ensure(kk_basis b, int upto /* exclusive */);
+int lowsync_project_dev(kk_basis b, int m, const double* w, const double* pre_vec, const double* pre_a,
+                        const double* a0_dev, int64_t ws_coef, int64_t ws_s, bool* rode);
+void lowsync_commit_row(kk_basis b, int m, const double* g_host);
+
+// ---- Krylov steps (kk_krylov.hip)
+int check_square_op(kk_op op, kk_basis b);
+int fetch_mark(kk_ctx c);    // record the event that marks the end of the scalar read-backs of a step ...
+int fetch_wait(kk_ctx c);    // ... and wait for it (not for work enqueued after it)
+int final_sync(kk_ctx c);    // fetch_mark + speculative next-step apply (if requested) + fetch_wait
+
+// ---- block operations (kk_block.hip)
+int block_inner_run(kk_ctx c, const double* X, int64_t ldx, int p, const double* Y, int64_t ldy, int q, int64_t ld,
+                    double* M, int ldm);

@@ -183,7 +183,7 @@ struct kk_op_s {
     int64_t n_local_cols = -1, n_ghost = 0;
 };
 
-// ---- launch helpers (kk_api.hip)
+// ---- launch helpers (kk_context.hip)
 struct kk_part {  // static even row partition of [0, ld) over nblk blocks
     int nblk;
     int64_t rpb;  // rows per block, multiple of KK_SUB
@@ -204,7 +204,7 @@ struct kk_prof_scope {
     }
 };
 
-// ---- kernels launchers (kk_kernels.hip)
+// ---- kernel launchers (kk_kernels_*.hip)
 // coefficient vector passed by value in the kernarg segment (no H2D copy, scalar loads)
 struct kk_coef {
     double v[KK_MAX_M];
@@ -276,7 +276,7 @@ static inline int kk_allreduce(kk_ctx ctx, double* dev_ptr, int64_t count) {
 int kk_launch_cg_update(kk_ctx ctx, double* x, const double* p, double* r, const double* q, int64_t ld, double alpha,
                         const double* pq_dev, double* nrm_out3);
 // (I + L) s = p on the device (one block, exact forward substitution); optional ride-along Gram row
-// and the Lanczos alpha0 folded into the last coefficient.  See kk_kernels.hip.
+// and the Lanczos alpha0 folded into the last coefficient.  See kk_kernels_stream.hip.
 int kk_launch_bicg_p(kk_ctx ctx, double* p_out, const double* p, const double* r, const double* v, int64_t ld,
                      const double* sc);
 int kk_launch_set_scalar(kk_ctx ctx, double* dst, double v);

@@ -1,0 +1,442 @@
+// gfx950 sparse kernels: SpMV on ELL / CSR / SELL-64-sigma / column-tiled SELL with the fused Krylov epilogue, and SpMM
+// on ELL for the block path.
+#include "kk_device.h"
+
+// ------------------------------------------------------------------------------------------
+// SpMV.  ELL (column-major, padded to `width`) with 2 rows per lane for regular matrices
+// (stencils); CSR with L lanes per row (L = 64 is row-per-wavefront) otherwise.
+// Fused epilogue (Lanczos three-term tail, lanczos.jl:297-310):
+//   ax  = xs * sum_k val*x[col]            (xs: optional device scalar, e.g. 1/alpha in GKL)
+//   y   = a1*ax + a0*x[row] - bprev*vprev[row]
+//   dot = <x, ax> (mode 1)  or <x, y> (mode 2)    nrm2 = |y|^2
+// Column indices >= n_local address the ghost buffer (row-sharded operators).
+// ------------------------------------------------------------------------------------------
+// streamed-once matrix entries (SELL): scalar non-temporal loads, so that they do not evict the gathered slice of x
+__device__ __forceinline__ int ldc(const int32_t* p) {
+#ifndef KK_NO_NT_LOADS
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ double ldv(const double* p) {
+#ifndef KK_NO_NT_LOADS
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+
+struct spmv_epi {
+    double a1, a0, bprev;
+    const double* xs_dev;
+    const double* bprev_dev;
+    const double* vprev;
+    int dot_mode;
+    int want_nrm;
+    int64_t n_local;  // < 0: no ghost
+    const double* ghost;
+    const double* dvec;  // dot_mode 3: <dvec, y>
+    int acc;             // column-tiled apply: 0 = whole matrix, 1 = first tile (y = raw sums), 2 = middle tile
+                         // (y += raw sums), 3 = last tile (sum = y + raw, then the epilogue)
+};
+
+__device__ __forceinline__ double xload(const double* __restrict__ x, const spmv_epi& e, int c) {
+    if (e.n_local >= 0 && c >= e.n_local) return e.ghost[c - e.n_local];
+    return x[c];
+}
+
+__global__ __launch_bounds__(KK_TPB) void k_spmv_ell(const int32_t* __restrict__ ecol, const double* __restrict__ eval,
+                                                     int64_t ell_ld, int width, int64_t nrows,
+                                                     const double* __restrict__ x, double* __restrict__ y, spmv_epi e,
+                                                     int nb_logical, double* __restrict__ part_dot,
+                                                     double* __restrict__ part_nrm) {
+    __shared__ double sm[4];
+    // XCD banding: block b runs on XCD b & 7 and walks the band [xcd*per, (xcd+1)*per) of logical
+    // 512-row chunks with stride nbx, so the blocks resident on one XCD sweep a contiguous row
+    // window together and stencil neighbours (+-nx rows) are L2 hits of the same XCD.
+    const int per = (nb_logical + 7) >> 3;
+    const int nbx = gridDim.x >> 3;
+    const int xcd = blockIdx.x & 7;
+    double dacc = 0, nacc = 0;
+    const double xs = e.xs_dev ? *e.xs_dev : 1.0;
+    const double bp = e.vprev ? (e.bprev_dev ? *e.bprev_dev : e.bprev) : 0.0;
+    for (int c = blockIdx.x >> 3; c < per; c += nbx) {
+        const int lb = xcd * per + c;
+        if (lb >= nb_logical) break;
+        const int64_t row = ((int64_t)lb * KK_TPB + threadIdx.x) * 2;
+        if (row < nrows) {  // ell_ld is even and >= nrows; pad entries have val 0, col 0
+            double s0 = 0, s1 = 0;
+            const int32_t* cp = ecol + row;
+            const double* vp = eval + row;
+            for (int k = 0; k < width; ++k) {
+                const int2 cc = ldi2s(cp + (int64_t)k * ell_ld);
+                const d2 v = ld2s(vp + (int64_t)k * ell_ld);
+                s0 = fma(v.x, xload(x, e, cc.x), s0);
+                s1 = fma(v.y, xload(x, e, cc.y), s1);
+            }
+            s0 *= xs; s1 *= xs;
+            d2 out{e.a1 * s0, e.a1 * s1};
+            d2 xv{0.0, 0.0};
+            if (e.a0 != 0.0 || e.dot_mode == 1 || e.dot_mode == 2) {
+                xv = ld2(x + row);
+                xv.x *= xs; xv.y *= xs;
+            }
+            if (e.a0 != 0.0) { out.x = fma(e.a0, xv.x, out.x); out.y = fma(e.a0, xv.y, out.y); }
+            if (e.dot_mode == 1) { dacc = fma(xv.x, out.x, dacc); dacc = fma(xv.y, out.y, dacc); }
+            if (e.vprev) {
+                const d2 p = ld2(e.vprev + row);
+                out.x = fma(-bp, p.x, out.x); out.y = fma(-bp, p.y, out.y);
+            }
+            if (row + 1 >= nrows) out.y = 0.0;  // odd nrows: keep the pad row zero
+            if (e.dot_mode == 2) { dacc = fma(xv.x, out.x, dacc); dacc = fma(xv.y, out.y, dacc); }
+            if (e.dot_mode == 3) { const d2 z = ld2(e.dvec + row); dacc = fma(z.x, out.x, dacc); dacc = fma(z.y, out.y, dacc); }
+            if (e.want_nrm) { nacc = fma(out.x, out.x, nacc); nacc = fma(out.y, out.y, nacc); }
+            st2(y + row, out);
+        }
+    }
+    if (e.dot_mode) {
+        double t = block_sum(dacc, sm);
+        if (threadIdx.x == 0) part_dot[blockIdx.x] = t;
+    }
+    if (e.want_nrm) {
+        double t = block_sum(nacc, sm);
+        if (threadIdx.x == 0) part_nrm[blockIdx.x] = t;
+    }
+}
+
+template <int L>
+__global__ __launch_bounds__(KK_TPB) void k_spmv_csr(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind,
+                                                     const double* __restrict__ val, int64_t nrows,
+                                                     const double* __restrict__ x, double* __restrict__ y, spmv_epi e,
+                                                     double* __restrict__ part_dot, double* __restrict__ part_nrm) {
+    __shared__ double sm[4];
+    constexpr int RPB = KK_TPB / L;  // rows per block iteration
+    const int sub = threadIdx.x % L, rl = threadIdx.x / L;
+    double dacc = 0, nacc = 0;
+    const double xs = e.xs_dev ? *e.xs_dev : 1.0;
+    for (int64_t row = (int64_t)blockIdx.x * RPB + rl; row < nrows; row += (int64_t)gridDim.x * RPB) {
+        const int b = rowptr[row], en = rowptr[row + 1];
+        double s = 0;
+        for (int k = b + sub; k < en; k += L) s = fma(val[k], xload(x, e, colind[k]), s);
+#pragma unroll
+        for (int o = L / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, L);
+        if (sub == 0) {
+            s *= xs;
+            double out = e.a1 * s;
+            double xv = 0;
+            if (e.a0 != 0.0 || e.dot_mode == 1 || e.dot_mode == 2) xv = x[row] * xs;
+            if (e.a0 != 0.0) out = fma(e.a0, xv, out);
+            if (e.dot_mode == 1) dacc = fma(xv, out, dacc);
+            if (e.vprev) {
+                const double bp = e.bprev_dev ? *e.bprev_dev : e.bprev;
+                out = fma(-bp, e.vprev[row], out);
+            }
+            if (e.dot_mode == 2) dacc = fma(xv, out, dacc);
+            if (e.dot_mode == 3) dacc = fma(e.dvec[row], out, dacc);
+            if (e.want_nrm) nacc = fma(out, out, nacc);
+            y[row] = out;
+        }
+    }
+    if (e.dot_mode) {
+        double t = block_sum(dacc, sm);
+        if (threadIdx.x == 0) part_dot[blockIdx.x] = t;
+    }
+    if (e.want_nrm) {
+        double t = block_sum(nacc, sm);
+        if (threadIdx.x == 0) part_nrm[blockIdx.x] = t;
+    }
+}
+
+// SELL-64-sigma SpMV for irregular matrices (e.g. A' of the rectangular GKL map): one wavefront per
+// chunk of 64 rows of similar length (rows are sorted by length inside windows of sigma rows on the
+// host), data stored [chunk][k][lane] so every load is one contiguous 512 B (values) / 256 B
+// (columns) wave transaction and padding is limited to the spread inside one chunk.
+__global__ __launch_bounds__(KK_TPB) void k_spmv_sell(const int64_t* __restrict__ coff, const int32_t* __restrict__ perm,
+                                                      const int32_t* __restrict__ scol, const double* __restrict__ sval,
+                                                      int64_t nchunks, const double* __restrict__ x, double* __restrict__ y,
+                                                      spmv_epi e, double* __restrict__ part_dot, double* __restrict__ part_nrm) {
+    __shared__ double sm[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double dacc = 0, nacc = 0;
+    const double xs = e.xs_dev ? *e.xs_dev : 1.0;
+    const double bp = e.vprev ? (e.bprev_dev ? *e.bprev_dev : e.bprev) : 0.0;
+    for (int64_t c = (int64_t)blockIdx.x * 4 + wave; c < nchunks; c += (int64_t)gridDim.x * 4) {
+        const int64_t off = coff[c];
+        const int w = (int)((coff[c + 1] - off) >> 6);
+        const int32_t* cp = scol + off + lane;
+        const double* vp = sval + off + lane;
+        double s0 = 0, s1 = 0;
+        int k = 0;
+        for (; k + 4 <= w; k += 4) {
+            const int c0 = ldc(cp + (k + 0) * 64), c1 = ldc(cp + (k + 1) * 64), c2 = ldc(cp + (k + 2) * 64), c3 = ldc(cp + (k + 3) * 64);
+            const double v0 = ldv(vp + (k + 0) * 64), v1 = ldv(vp + (k + 1) * 64), v2 = ldv(vp + (k + 2) * 64), v3 = ldv(vp + (k + 3) * 64);
+            s0 = fma(v0, xload(x, e, c0), s0);
+            s1 = fma(v1, xload(x, e, c1), s1);
+            s0 = fma(v2, xload(x, e, c2), s0);
+            s1 = fma(v3, xload(x, e, c3), s1);
+        }
+        for (; k < w; ++k) s0 = fma(ldv(vp + k * 64), xload(x, e, ldc(cp + k * 64)), s0);
+        const int row = perm[c * 64 + lane];
+        if (row >= 0) {
+            double raw = s0 + s1;
+            if (e.acc == 1) { y[row] = raw; continue; }
+            if (e.acc == 2) { y[row] += raw; continue; }
+            if (e.acc == 3) raw += y[row];
+            const double s = raw * xs;
+            double out = e.a1 * s;
+            double xv = 0;
+            if (e.a0 != 0.0 || e.dot_mode == 1 || e.dot_mode == 2) xv = x[row] * xs;
+            if (e.a0 != 0.0) out = fma(e.a0, xv, out);
+            if (e.dot_mode == 1) dacc = fma(xv, out, dacc);
+            if (e.vprev) out = fma(-bp, e.vprev[row], out);
+            if (e.dot_mode == 2) dacc = fma(xv, out, dacc);
+            if (e.dot_mode == 3) dacc = fma(e.dvec[row], out, dacc);
+            if (e.want_nrm) nacc = fma(out, out, nacc);
+            y[row] = out;
+        }
+    }
+    if (e.dot_mode) {
+        double t = block_sum(dacc, sm);
+        if (threadIdx.x == 0) part_dot[blockIdx.x] = t;
+    }
+    if (e.want_nrm) {
+        double t = block_sum(nacc, sm);
+        if (threadIdx.x == 0) part_nrm[blockIdx.x] = t;
+    }
+}
+
+// Window variant of the SELL kernel for sigma = 256 = the rows of one thread block (used by the column tiles, where
+// a row has only a handful of entries per tile and the row-sorted result order would turn the y update into
+// scattered 8-byte accesses): the four waves compute the raw sums of the four chunks of a 256-row window in the sorted
+// order, park them in LDS under the row's position in the window, and after a barrier thread t finishes row
+// base + t -- y, x, v_prev and the inner-product operands are all read and written coalesced.
+__global__ __launch_bounds__(KK_TPB) void k_spmv_sellw(const int64_t* __restrict__ coff, const int32_t* __restrict__ perm,
+                                                       const int32_t* __restrict__ scol, const double* __restrict__ sval,
+                                                       int64_t nchunks, int64_t nrows, const double* __restrict__ x,
+                                                       double* __restrict__ y, spmv_epi e, double* __restrict__ part_dot,
+                                                       double* __restrict__ part_nrm) {
+    __shared__ double res[KK_TPB];
+    __shared__ double sm[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double dacc = 0, nacc = 0;
+    const double xs = e.xs_dev ? *e.xs_dev : 1.0;
+    const double bp = e.vprev ? (e.bprev_dev ? *e.bprev_dev : e.bprev) : 0.0;
+    const int64_t nwin = (nchunks + 3) >> 2;
+    // the chunk descriptor of the NEXT window is fetched while the current one is processed, and the old y of the
+    // accumulating tiles is requested before the gathers: two of the four dependent memory round trips per window go
+    int64_t win = blockIdx.x;
+    int64_t off = 0, offn = 0;
+    int32_t prow = -1;
+    if (win < nwin && win * 4 + wave < nchunks) {
+        off = coff[win * 4 + wave]; offn = coff[win * 4 + wave + 1];
+        prow = perm[(win * 4 + wave) * 64 + lane];
+    }
+    for (; win < nwin; win += gridDim.x) {
+        const int64_t c = win * 4 + wave;
+        const int64_t row = win * KK_TPB + tid;
+        double yold = 0.0;
+        if (e.acc >= 2 && row < nrows) yold = y[row];
+        const int64_t wnext = win + gridDim.x;
+        int64_t off2 = 0, offn2 = 0;
+        int32_t prow2 = -1;
+        if (wnext < nwin && wnext * 4 + wave < nchunks) {
+            off2 = coff[wnext * 4 + wave]; offn2 = coff[wnext * 4 + wave + 1];
+            prow2 = perm[(wnext * 4 + wave) * 64 + lane];
+        }
+        if (c < nchunks) {
+            const int w = (int)((offn - off) >> 6);
+            const int32_t* cp = scol + off + lane;
+            const double* vp = sval + off + lane;
+            double s0 = 0, s1 = 0;
+            int k = 0;
+            for (; k + 4 <= w; k += 4) {
+                const int c0 = ldc(cp + (k + 0) * 64), c1 = ldc(cp + (k + 1) * 64), c2 = ldc(cp + (k + 2) * 64), c3 = ldc(cp + (k + 3) * 64);
+                const double v0 = ldv(vp + (k + 0) * 64), v1 = ldv(vp + (k + 1) * 64), v2 = ldv(vp + (k + 2) * 64), v3 = ldv(vp + (k + 3) * 64);
+                s0 = fma(v0, xload(x, e, c0), s0);
+                s1 = fma(v1, xload(x, e, c1), s1);
+                s0 = fma(v2, xload(x, e, c2), s0);
+                s1 = fma(v3, xload(x, e, c3), s1);
+            }
+            for (; k < w; ++k) s0 = fma(ldv(vp + k * 64), xload(x, e, ldc(cp + k * 64)), s0);
+            if (prow >= 0) res[prow - win * KK_TPB] = s0 + s1;
+        }
+        __syncthreads();
+        if (row < nrows) {
+            double raw = res[tid];
+            if (e.acc == 1) y[row] = raw;
+            else if (e.acc == 2) y[row] = yold + raw;
+            else {
+                if (e.acc == 3) raw += yold;
+                const double s = raw * xs;
+                double out = e.a1 * s;
+                double xv = 0;
+                if (e.a0 != 0.0 || e.dot_mode == 1 || e.dot_mode == 2) xv = x[row] * xs;
+                if (e.a0 != 0.0) out = fma(e.a0, xv, out);
+                if (e.dot_mode == 1) dacc = fma(xv, out, dacc);
+                if (e.vprev) out = fma(-bp, e.vprev[row], out);
+                if (e.dot_mode == 2) dacc = fma(xv, out, dacc);
+                if (e.dot_mode == 3) dacc = fma(e.dvec[row], out, dacc);
+                if (e.want_nrm) nacc = fma(out, out, nacc);
+                y[row] = out;
+            }
+        }
+        __syncthreads();
+        off = off2; offn = offn2; prow = prow2;
+    }
+    if (e.dot_mode) {
+        double t = block_sum(dacc, sm);
+        if (threadIdx.x == 0) part_dot[blockIdx.x] = t;
+    }
+    if (e.want_nrm) {
+        double t = block_sum(nacc, sm);
+        if (threadIdx.x == 0) part_nrm[blockIdx.x] = t;
+    }
+}
+
+// SpMM on ELL: Y[:, j] = A X[:, j], j < nb <= NB (apply(f, ::Block), blocklanczos.jl:39): the matrix
+// is streamed once for the whole block instead of once per vector.
+template <int NB>
+__global__ __launch_bounds__(KK_TPB) void k_spmm_ell(const int32_t* __restrict__ ecol, const double* __restrict__ eval,
+                                                     int64_t ell_ld, int width, int64_t nrows,
+                                                     const double* __restrict__ X, int64_t ldx, double* __restrict__ Y,
+                                                     int64_t ldy, int nb, int nb_logical) {
+    const int per = (nb_logical + 7) >> 3;
+    const int nbx = gridDim.x >> 3;
+    const int xcd = blockIdx.x & 7;
+    for (int cblk = blockIdx.x >> 3; cblk < per; cblk += nbx) {
+        const int lb = xcd * per + cblk;
+        if (lb >= nb_logical) break;
+        const int64_t row = ((int64_t)lb * KK_TPB + threadIdx.x) * 2;
+        if (row >= nrows) continue;
+        d2 acc[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[j] = d2{0.0, 0.0};
+        for (int k = 0; k < width; ++k) {
+            const int2 cc = ldi2s(ecol + (int64_t)k * ell_ld + row);
+            const d2 v = ld2s(eval + (int64_t)k * ell_ld + row);
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                if (j < nb) {
+                    acc[j].x = fma(v.x, X[(int64_t)j * ldx + cc.x], acc[j].x);
+                    acc[j].y = fma(v.y, X[(int64_t)j * ldx + cc.y], acc[j].y);
+                }
+            }
+        }
+        const bool last_odd = (row + 1 >= nrows);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            if (j < nb) {
+                if (last_odd) acc[j].y = 0.0;
+                st2(Y + (int64_t)j * ldy + row, acc[j]);
+            }
+        }
+    }
+}
+
+// ---- launchers
+int kk_launch_spmv(kk_ctx ctx, const kk_sparse_dev& M, const double* x, double* y, int64_t ld_y_rows,
+                   const kk_spmv_fuse& f) {
+    (void)ld_y_rows;
+    if (M.halo) {  // row-sharded operator: let the caller fill the ghost buffer from x (P2P on this stream)
+        const int st = M.halo(M.halo_user, x);
+        if (st != 0) { kk_set_error("halo hook failed with status %d", st); return KK_ERR_INVALID; }
+    }
+    spmv_epi e;
+    e.a1 = f.a1; e.a0 = f.a0; e.bprev = f.bprev;
+    e.xs_dev = f.xscale_dev; e.bprev_dev = f.bprev_dev; e.vprev = f.vprev;
+    e.dot_mode = f.dot_mode; e.want_nrm = f.nrm_out ? 1 : 0;
+    e.n_local = M.n_ghost > 0 ? M.n_local : -1;
+    e.ghost = M.ghost;
+    e.dvec = f.dot_vec;
+    e.acc = 0;
+    double* pd = part_row(ctx, PART_SCAL_A);
+    double* pn = part_row(ctx, PART_SCAL_B);
+    int nblk = 0;
+    std::unique_ptr<kk_prof_scope> ps(new kk_prof_scope(ctx, M.format == 0 ? "k_spmv_ell" : (M.format >= 2 ? "k_spmv_sell" : "k_spmv_csr")));
+    if (M.format == 2) {
+        nblk = (int)std::min<int64_t>((M.sell_nchunks + 3) / 4, (int64_t)ctx->num_cus * 16);
+        if (nblk < 1) nblk = 1;
+        hipLaunchKernelGGL(k_spmv_sell, dim3(nblk), dim3(KK_TPB), 0, ctx->stream, M.sell_off, M.sell_perm, M.sell_col, M.sell_val,
+                           M.sell_nchunks, x, y, e, pd, pn);
+    } else if (M.format == 3) {
+        // column tiles one after the other: tile t gathers from the L2-resident slice [t, t+1) * tile_cols of x and
+        // accumulates into y; the epilogue (scaling, a0 x, - beta v_prev, inner products) runs with the last tile
+        if (f.vprev == y) { ps.reset(); kk_set_error("tiled spmv: v_prev must not alias y"); return KK_ERR_INVALID; }
+        for (int t = 0; t < M.ntiles; ++t) {
+            const kk_sparse_dev& S = M.tiles[t];
+            spmv_epi et = e;
+            et.acc = M.ntiles == 1 ? 0 : (t == 0 ? 1 : (t == M.ntiles - 1 ? 3 : 2));
+            if (et.acc == 1 || et.acc == 2) { et.dot_mode = 0; et.want_nrm = 0; }
+            nblk = (int)std::min<int64_t>((S.sell_nchunks + 3) / 4, (int64_t)ctx->num_cus * 16);
+            if (nblk < 1) nblk = 1;
+            hipLaunchKernelGGL(k_spmv_sellw, dim3(nblk), dim3(KK_TPB), 0, ctx->stream, S.sell_off, S.sell_perm, S.sell_col, S.sell_val,
+                               S.sell_nchunks, S.nrows, x, y, et, pd, pn);
+        }
+    } else if (M.format == 0) {
+        const int nb_logical = (int)((M.nrows + 2 * KK_TPB - 1) / (2 * KK_TPB));
+        const int per = (nb_logical + 7) / 8;
+        const int nbx = std::min(per, KK_MAX_BLOCKS / 8);
+        nblk = nbx * 8;
+        hipLaunchKernelGGL(k_spmv_ell, dim3(nblk), dim3(KK_TPB), 0, ctx->stream, M.ell_col, M.ell_val, M.ell_ld, M.width,
+                           M.nrows, x, y, e, nb_logical, pd, pn);
+    } else {
+        const int L = M.lanes_per_row;
+        const int rpb = KK_TPB / L;
+        int64_t want = (M.nrows + rpb - 1) / rpb;
+        nblk = (int)std::min<int64_t>(want, (int64_t)ctx->num_cus * 16);
+        if (nblk < 1) nblk = 1;
+        dim3 g(nblk), b(KK_TPB);
+#define CSR_CASE(LL) case LL: hipLaunchKernelGGL((k_spmv_csr<LL>), g, b, 0, ctx->stream, M.rowptr, M.colind, M.val, M.nrows, x, y, e, pd, pn); break;
+        switch (L) {
+            CSR_CASE(2) CSR_CASE(4) CSR_CASE(8) CSR_CASE(16) CSR_CASE(32) CSR_CASE(64)
+            default: ps.reset(); kk_set_error("bad lanes_per_row %d", L); return KK_ERR_INVALID;
+        }
+#undef CSR_CASE
+    }
+    ps.reset();
+    KK_HIP(hipGetLastError());
+    if (nblk > KK_MAX_BLOCKS && (f.dot_mode || f.nrm_out)) {
+        kk_set_error("spmv grid %d exceeds partial buffer", nblk);
+        return KK_ERR_INVALID;
+    }
+    if (f.dot_mode) KK_TRY(finalize_scalar(ctx, PART_SCAL_A, nblk, f.dot_out, false));
+    if (f.nrm_out) KK_TRY(finalize_scalar(ctx, PART_SCAL_B, nblk, f.nrm_out, true));
+    return KK_OK;
+}
+
+// Y[:, j] = A X[:, j], j < nb (any nb: processed 16 / 8 / 4 columns at a time)
+int kk_launch_spmm(kk_ctx ctx, const kk_sparse_dev& M, const double* X, int64_t ldx, double* Y, int64_t ldy, int nb) {
+    if (M.format != 0 || M.n_ghost > 0 || M.halo) {  // CSR / ghosted operators: one SpMV per column
+        for (int j = 0; j < nb; ++j) {
+            kk_spmv_fuse f;
+            KK_TRY(kk_launch_spmv(ctx, M, X + (int64_t)j * ldx, Y + (int64_t)j * ldy, ldy, f));
+        }
+        return KK_OK;
+    }
+    const int nb_logical = (int)((M.nrows + 2 * KK_TPB - 1) / (2 * KK_TPB));
+    const int per = (nb_logical + 7) / 8;
+    const int nbx = std::min(per, KK_MAX_BLOCKS / 8);
+    dim3 g(nbx * 8), b(KK_TPB);
+    int j0 = 0;
+    while (j0 < nb) {
+        const int rem = nb - j0;
+        const double* x = X + (int64_t)j0 * ldx;
+        double* y = Y + (int64_t)j0 * ldy;
+        kk_prof_scope ps(ctx, "k_spmm_ell");
+        if (rem > 8) {
+            const int n = std::min(rem, 16);
+            hipLaunchKernelGGL((k_spmm_ell<16>), g, b, 0, ctx->stream, M.ell_col, M.ell_val, M.ell_ld, M.width, M.nrows, x, ldx, y, ldy, n, nb_logical);
+            j0 += n;
+        } else if (rem > 4) {
+            hipLaunchKernelGGL((k_spmm_ell<8>), g, b, 0, ctx->stream, M.ell_col, M.ell_val, M.ell_ld, M.width, M.nrows, x, ldx, y, ldy, rem, nb_logical);
+            j0 += rem;
+        } else {
+            hipLaunchKernelGGL((k_spmm_ell<4>), g, b, 0, ctx->stream, M.ell_col, M.ell_val, M.ell_ld, M.width, M.nrows, x, ldx, y, ldy, rem, nb_logical);
+            j0 += rem;
+        }
+    }
+    KK_HIP(hipGetLastError());
+    return KK_OK;
+}
+

@@ -1,0 +1,416 @@
+// libkrylov_hip.so, C ABI part 5: the fused L3 steps -- initialize / expand! of Lanczos, Arnoldi and GKL with the
+// speculative next-step apply (src/factorizations/{lanczos,arnoldi,gkl}.jl).
+#include "kk_host.h"
+
+// ------------------------------------------------------------------------------------------
+// L3 fused expand! steps
+// ------------------------------------------------------------------------------------------
+int check_square_op(kk_op op, kk_basis b) {
+    KK_CHECK(op && b, KK_ERR_INVALID, "null arg");
+    KK_CHECK(op->ctx == b->ctx, KK_ERR_INVALID, "operator and basis belong to different contexts");
+    const int64_t in = op->A.n_ghost > 0 ? op->A.n_local : op->ncols;
+    KK_CHECK(op->nrows == b->n && in == b->n, KK_ERR_DIM, "operator is %lldx%lld but vectors have %lld rows",
+             (long long)op->nrows, (long long)op->ncols, (long long)b->n);
+    return KK_OK;
+}
+
+// initialize (factorizations/lanczos.jl:180-222 == arnoldi.jl:135-175): col c0 = x0 -> v ; col c0+1 = r
+static int krylov_initialize(kk_op op, kk_basis b, int c0, kk_orth_t orth, double eta, double* alpha, double* beta) {
+    KK_TRY(check_square_op(op, b));
+    KK_CHECK(c0 >= 0 && c0 + 2 <= b->cap, KK_ERR_INVALID, "initialize: need columns %d..%d", c0, c0 + 1);
+    KK_CHECK(alpha && beta, KK_ERR_INVALID, "null output");
+    kk_ctx c = b->ctx;
+    double* x0 = b->col(c0);
+    double* r = b->col(c0 + 1);
+    gram_touch(b, c0);
+    // beta0 = norm(x0); Ax0 = A x0 with fused <x0, Ax0>
+    KK_TRY(kk_launch_nrm2(c, x0, b->ld, SCP(c, SC_NRM2)));
+    kk_spmv_fuse f;
+    f.dot_mode = 1; f.dot_out = SCP(c, SC_ALPHA0);
+    KK_TRY(kk_launch_spmv(c, op->A, x0, r, b->ld, f));
+    KK_TRY(ws_fetch_async(c, WS_SCAL, 16, 0));
+    KK_TRY(stream_sync(c));
+    const double beta0 = pin(c, WS_SCAL + SC_NRM)[0];
+    if (beta0 == 0.0) {
+        kk_set_error("initial vector should not have norm zero");
+        return KK_ERR_ZERO_NORM;
+    }
+    double a = pin(c, WS_SCAL + SC_ALPHA0)[0] / (beta0 * beta0);
+    KK_TRY(kk_launch_scal(c, x0, b->ld, 1.0 / beta0, nullptr));   // v = x0/beta0      :190
+    KK_TRY(kk_launch_scal(c, r, b->ld, 1.0 / beta0, nullptr));    // r = Ax0/beta0     :194
+    const bool ir = (orth == KK_CGSIR || orth == KK_MGSIR);
+    double beta_old = 0;
+    if (ir) {
+        KK_TRY(kk_launch_nrm2(c, r, b->ld, SCP(c, SC_NRM2B)));  // beta_old = norm(r) :196
+        KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2B, 2, 1));
+    }
+    // r -= alpha v ; beta = norm(r)
+    KK_TRY(kk_launch_axpby(c, r, x0, b->ld, -a, 1.0, nullptr, 1.0, 0));
+    KK_TRY(kk_launch_nrm2(c, r, b->ld, SCP(c, SC_NRM2)));
+    KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2, 2, 0));
+    KK_TRY(stream_sync(c));
+    double bt = pin(c, WS_SCAL + SC_NRM2)[1];
+    if (ir) beta_old = pin(c, WS_SCAL + SC_NRM2B, 1)[1];
+    auto correct = [&]() -> int {  // dalpha = <v,r>; alpha += dalpha; r -= dalpha v; beta = |r|   :201-204
+        KK_TRY(kk_launch_mgs_step(c, r, b->ld, nullptr, nullptr, x0, WSP(c, WS_S), nullptr));
+        KK_TRY(kk_launch_mgs_step(c, r, b->ld, x0, c->ws + WS_S, nullptr, nullptr, SCP(c, SC_NRM2)));
+        KK_TRY(ws_fetch_async(c, WS_S, 1, 0));
+        KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2, 2, 0));
+        KK_TRY(stream_sync(c));
+        a += pin(c, WS_S)[0];
+        bt = pin(c, WS_SCAL + SC_NRM2)[1];
+        return KK_OK;
+    };
+    if (orth == KK_CGS2 || orth == KK_MGS2) {
+        KK_TRY(correct());
+    } else if (ir) {
+        while (KK_EPS < bt && bt < eta * beta_old) {
+            beta_old = bt;
+            KK_TRY(correct());
+        }
+    }
+    *alpha = a;
+    *beta = bt;
+    return KK_OK;
+}
+
+KK_API int kk_lanczos_initialize(kk_op op, kk_basis b, int c0, kk_orth_t orth, double eta, double* alpha,
+                                     double* beta) {
+    return krylov_initialize(op, b, c0, orth, eta, alpha, beta);
+}
+KK_API int kk_arnoldi_initialize(kk_op op, kk_basis b, int c0, kk_orth_t orth, double eta, double* alpha,
+                                     double* beta) {
+    return krylov_initialize(op, b, c0, orth, eta, alpha, beta);
+}
+
+// Speculative first half of the NEXT expand!: w' = A (r/beta) - beta v  with the scale applied on
+// the fly from the device-resident beta, so the GPU keeps working while the host reads back
+// (alpha, beta), returns to the caller and re-enters.  r itself is NOT modified; the next expand
+// call normalises it in place (after this read) and skips its SpMV if (op, c0, k, beta) match.
+// Bit-identical to the non-speculative order: r*(1/beta) is formed with the same operands.
+static int speculate_next(kk_op op, kk_basis b, int c0, int k_next, int dot_mode, bool with_prev, double beta_host) {
+    kk_ctx c = b->ctx;
+    b->spec_valid = false;
+    if (!c->speculate || c0 + k_next + 2 > b->cap || k_next + 1 > KK_MAX_M) return KK_OK;
+    kk_spmv_fuse f;
+    f.xscale_dev = SCP(c, SC_INVNRM);
+    if (with_prev) { f.vprev = b->col(c0 + k_next - 1); f.bprev_dev = SCP(c, SC_NRM); }
+    f.dot_mode = dot_mode;
+    f.dot_out = SCP(c, SC_SPECA);
+    KK_TRY(kk_launch_spmv(c, op->A, b->col(c0 + k_next), b->col(c0 + k_next + 1), b->ld, f));
+    b->spec_valid = true; b->spec_op = op; b->spec_c0 = c0; b->spec_k = k_next; b->spec_dot_mode = dot_mode;
+    b->spec_beta = beta_host;
+    c->spec_owner = b;
+    return KK_OK;
+}
+// true if the previous expand on this basis already enqueued exactly this step's SpMV; moves the
+// speculative alpha into the regular slot
+static int spec_take(kk_op op, kk_basis b, int c0, int k, int dot_mode, double beta_old, bool* hit) {
+    kk_ctx c = b->ctx;
+    *hit = b->spec_valid && c->spec_owner == b && b->spec_op == op && b->spec_c0 == c0 && b->spec_k == k &&
+           b->spec_dot_mode == dot_mode && b->spec_beta == beta_old;
+    if (*hit && dot_mode)
+        KK_HIP(hipMemcpyAsync(SCP(c, SC_ALPHA0), SCP(c, SC_SPECA), sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    return KK_OK;
+}
+// the last synchronisation of an expand: a pending speculation request (Arnoldi) is enqueued first
+// The host waits only for the read-backs queued so far (event), NOT for the speculative SpMV that
+// is enqueued behind them -- that one keeps the GPU busy during the host round trip.
+int fetch_mark(kk_ctx c) {
+    KK_HIP(hipEventRecord(c->ev_fetch, c->stream));
+    return KK_OK;
+}
+int fetch_wait(kk_ctx c) {
+    KK_HIP(hipEventSynchronize(c->ev_fetch));
+    return KK_OK;
+}
+int final_sync(kk_ctx c) {
+    if (c->spec_req.active) {
+        c->spec_req.active = false;
+        KK_TRY(fetch_mark(c));
+        KK_TRY(speculate_next(c->spec_req.op, c->spec_req.b, c->spec_req.c0, c->spec_req.k_next, 0, false, 0.0));
+        return fetch_wait(c);
+    }
+    return stream_sync(c);
+}
+
+KK_API int kk_lanczos_expand(kk_op op, kk_basis b, int c0, int k, kk_orth_t orth, double eta, double beta_old,
+                                 double* alpha, double* beta, int* npasses) {
+    KK_TRY(check_square_op(op, b));
+    KK_CHECK(k >= 1 && c0 >= 0 && c0 + k + 2 <= b->cap && k + 1 <= KK_MAX_M, KK_ERR_INVALID,
+             "kk_lanczos_expand: need k >= 1 and columns %d..%d within capacity %d", c0, c0 + k + 1, b->cap);
+    KK_CHECK(alpha && beta, KK_ERR_INVALID, "null output");
+    KK_CHECK(beta_old != 0.0, KK_ERR_ZERO_NORM, "kk_lanczos_expand: residual norm is zero");
+    kk_ctx c = b->ctx;
+    const int64_t ld = b->ld;
+    const int m = k + 1;                  // basis size after the push
+    double* V = b->col(c0);
+    double* v = b->col(c0 + k);           // holds r on entry
+    const double* vprev = b->col(c0 + k - 1);
+    double* w = b->col(c0 + k + 1);
+    const bool cgs_order = (orth == KK_CGS || orth == KK_CGS2 || orth == KK_CGSIR);
+    bool hit = false;
+    KK_TRY(spec_take(op, b, c0, k, cgs_order ? 1 : 2, beta_old, &hit));
+    gram_touch(b, c0 + k);
+    int passes = 0;
+    // V = push!(V, scale!!(r, 1/beta_old))   lanczos.jl:257
+    KK_TRY(kk_launch_scal(c, v, ld, 1.0 / beta_old, nullptr));
+    if (!hit) {
+        // w = A v - beta_old v_prev with the fused alpha dot   lanczos.jl:297-299 / 306-308
+        kk_spmv_fuse f;
+        f.vprev = vprev; f.bprev = beta_old;
+        f.dot_mode = cgs_order ? 1 : 2;
+        f.dot_out = SCP(c, SC_ALPHA0);
+        KK_TRY(kk_launch_spmv(c, op->A, v, w, ld, f));
+    }  // else: the previous expand already enqueued exactly this SpMV (speculate_next)
+    const double* a0_dev = c->ws + WS_SCAL + SC_ALPHA0;
+    double a = 0, bt = 0;
+    const bool lowsync = c->mgs_mode == 1;
+    if (orth == KK_CGS || orth == KK_MGS || orth == KK_CGSIR || orth == KK_MGSIR) {
+        // w -= alpha v ; beta = |w|
+        KK_TRY(kk_launch_mgs_step(c, w, ld, v, a0_dev, nullptr, nullptr, SCP(c, SC_NRM2)));
+        KK_TRY(ws_fetch_async(c, WS_SCAL, 4, 0));
+        KK_TRY(stream_sync(c));
+        a = pin(c, WS_SCAL + SC_ALPHA0)[0];
+        bt = pin(c, WS_SCAL + SC_NRM)[0];
+        if (orth == KK_CGSIR || orth == KK_MGSIR) {  // lanczos.jl:346-354 / 363-374
+            const double ab2 = a * a + beta_old * beta_old;
+            double nold = std::sqrt(bt * bt + ab2);
+            std::vector<double> s(m);
+            while (KK_EPS < bt && bt < eta * nold) {
+                nold = bt;
+                double nn = 0;
+                int p1 = 0;
+                KK_TRY(orth_run(b, c0, m, w, orth == KK_CGSIR ? KK_CGS : KK_MGS, eta, s.data(), &nn, &p1, true));
+                a += s[m - 1];
+                bt = nn;
+                ++passes;
+            }
+        }
+    } else if (orth == KK_CGS2 || (orth == KK_MGS2 && lowsync && c0 == 0)) {
+        // one projection pass with "w -= alpha0 v" folded in (read V twice in total):
+        //   s = V'(w - alpha0 v) ; w <- w - V (s + alpha0 e_m) ; beta = |w|     lanczos.jl:318-322 / 329-336
+        if (orth == KK_CGS2) {
+            KK_TRY(kk_launch_project(c, V, ld, m, w, v, a0_dev, nullptr, WSP(c, WS_S), WSP(c, WS_G)));
+            KK_TRY(kk_launch_unproject(c, V, ld, m, w, w, nullptr, c->ws + WS_S, -1.0, 1.0, m - 1, a0_dev,
+                                       SCP(c, SC_NRM2)));
+            KK_TRY(ws_fetch_async(c, WS_S, m, 0));
+            KK_TRY(ws_fetch_async(c, WS_SCAL, 4, 0));
+            KK_TRY(fetch_mark(c));
+            KK_TRY(speculate_next(op, b, c0, k + 1, 1, true, 0.0));
+            KK_TRY(fetch_wait(c));
+            a = pin(c, WS_SCAL + SC_ALPHA0)[0] + pin(c, WS_S)[m - 1];
+        } else {
+            // low-sync MGS2: project (Gram row riding along) -> triangular solve ON THE DEVICE (alpha0 folded
+            // into the last coefficient) -> update; one host synchronisation, as for CGS2
+            bool rode = false;
+            KK_TRY(lowsync_project_dev(b, m, w, v, a0_dev, a0_dev, WS_X, WS_Y, &rode));
+            KK_TRY(kk_launch_unproject(c, V, ld, m, w, w, nullptr, WSP(c, WS_X), -1.0, 1.0, -1, nullptr, SCP(c, SC_NRM2)));
+            KK_TRY(ws_fetch_async(c, WS_SCAL, 4, 0));
+            KK_TRY(ws_fetch_async(c, WS_Y + m - 1, 1, 0));
+            if (rode) KK_TRY(ws_fetch_async(c, WS_G, m, 0));
+            KK_TRY(fetch_mark(c));
+            KK_TRY(speculate_next(op, b, c0, k + 1, 2, true, 0.0));
+            KK_TRY(fetch_wait(c));
+            a = pin(c, WS_SCAL + SC_ALPHA0)[0] + pin(c, WS_Y)[m - 1];
+            if (rode) lowsync_commit_row(b, m, pin(c, WS_G, 0));
+        }
+        bt = pin(c, WS_SCAL + SC_NRM)[0];
+        passes = 1;
+    } else if (orth == KK_MGS2) {
+        // strict: w -= alpha0 v fused with the first dot of the sweep   lanczos.jl:329-334
+        KK_TRY(pass_mgs_strict(c, V, ld, m, w, WS_S, true, 0, v, a0_dev, false));
+        KK_TRY(ws_fetch_async(c, WS_SCAL, 1, 0));
+        KK_TRY(stream_sync(c));
+        a = pin(c, WS_SCAL + SC_ALPHA0)[0] + pin(c, WS_S)[m - 1];
+        bt = pin(c, WS_SCAL + SC_NRM2)[1];
+        passes = 1;
+    } else {
+        kk_set_error("unknown orthogonalizer %d", (int)orth);
+        return KK_ERR_INVALID;
+    }
+    *alpha = a;
+    *beta = bt;
+    if (npasses) *npasses = passes;
+    if (b->spec_valid) b->spec_beta = bt;  // the caller must come back with exactly this beta
+    return KK_OK;
+}
+
+KK_API int kk_arnoldi_expand(kk_op op, kk_basis b, int c0, int k, kk_orth_t orth, double eta, double beta_old,
+                                 double* h, double* beta, int* npasses) {
+    KK_TRY(check_square_op(op, b));
+    KK_CHECK(k >= 1 && c0 >= 0 && c0 + k + 2 <= b->cap && k + 1 <= KK_MAX_M, KK_ERR_INVALID,
+             "kk_arnoldi_expand: need k >= 1 and columns %d..%d within capacity %d", c0, c0 + k + 1, b->cap);
+    KK_CHECK(h && beta, KK_ERR_INVALID, "null output");
+    KK_CHECK(beta_old != 0.0, KK_ERR_ZERO_NORM, "kk_arnoldi_expand: residual norm is zero");
+    kk_ctx c = b->ctx;
+    const int m = k + 1;
+    double* v = b->col(c0 + k);
+    double* w = b->col(c0 + k + 1);
+    bool hit = false;
+    KK_TRY(spec_take(op, b, c0, k, 0, beta_old, &hit));
+    gram_touch(b, c0 + k);
+    KK_TRY(kk_launch_scal(c, v, b->ld, 1.0 / beta_old, nullptr));  // push!(V, scale(r, 1/beta))   arnoldi.jl:209
+    if (!hit) {
+        kk_spmv_fuse f;
+        KK_TRY(kk_launch_spmv(c, op->A, v, w, b->ld, f));           // w = apply(operator, last(V))  :242
+    }
+    // ask orth_run to enqueue the NEXT step's SpMV right before its final host sync (non-IR variants)
+    c->spec_req.active = (orth != KK_CGSIR && orth != KK_MGSIR);
+    c->spec_req.op = op; c->spec_req.b = b; c->spec_req.c0 = c0; c->spec_req.k_next = k + 1;
+    int st = orth_run(b, c0, m, w, orth, eta, h, beta, npasses, true);  // orthogonalize!! + norm      :243-244
+    c->spec_req.active = false;
+    if (st == KK_OK && b->spec_valid) b->spec_beta = *beta;
+    return st;
+}
+
+// ---- GKL ----------------------------------------------------------------------------------
+static int check_gkl(kk_op op, kk_basis bu, kk_basis bv) {
+    KK_CHECK(op && bu && bv, KK_ERR_INVALID, "null arg");
+    KK_CHECK(op->ctx == bu->ctx && op->ctx == bv->ctx, KK_ERR_INVALID, "objects belong to different contexts");
+    KK_CHECK(op->nrows == bu->n && op->ncols == bv->n, KK_ERR_DIM,
+             "GKL: operator is %lldx%lld, U vectors have %lld rows, V vectors %lld", (long long)op->nrows,
+             (long long)op->ncols, (long long)bu->n, (long long)bv->n);
+    KK_CHECK(op->A.n_ghost == 0, KK_ERR_UNSUPPORTED, "GKL on ghosted (row-sharded) operators goes through the split-phase API");
+    return KK_OK;
+}
+
+KK_API int kk_gkl_initialize(kk_op op, kk_basis bu, kk_basis bv, double* alpha, double* beta) {
+    KK_TRY(check_gkl(op, bu, bv));
+    KK_CHECK(bu->cap >= 2 && bv->cap >= 1, KK_ERR_INVALID, "GKL initialize: capacity too small");
+    KK_CHECK(alpha && beta, KK_ERR_INVALID, "null output");
+    kk_ctx c = bu->ctx;
+    const kk_sparse_dev* At;
+    KK_TRY(get_matrix(op, 1, &At));
+    double* u0 = bu->col(0);
+    double* v0 = bv->col(0);
+    double* r = bu->col(1);
+    gram_touch(bu, 0); gram_touch(bv, 0);
+    // beta0 = |u0| ; v0 = A' u0 (with |v0|^2) ; Av0 = A v0 (with <u0, A v0> computed separately)
+    KK_TRY(kk_launch_nrm2(c, u0, bu->ld, SCP(c, SC_NRM2B)));
+    kk_spmv_fuse f1;
+    f1.nrm_out = SCP(c, SC_NRM2);
+    KK_TRY(kk_launch_spmv(c, *At, u0, v0, bv->ld, f1));
+    kk_spmv_fuse f2;
+    KK_TRY(kk_launch_spmv(c, op->A, v0, r, bu->ld, f2));
+    KK_TRY(kk_launch_dot(c, u0, r, bu->ld, SCP(c, SC_DOT)));
+    KK_TRY(ws_fetch_async(c, WS_SCAL, 16, 0));
+    KK_TRY(stream_sync(c));
+    const double beta0 = pin(c, WS_SCAL + SC_NRMB)[0];
+    if (beta0 == 0.0) {
+        kk_set_error("initial vector should not have norm zero");
+        return KK_ERR_ZERO_NORM;
+    }
+    const double a = pin(c, WS_SCAL + SC_NRM)[0] / beta0;                 // alpha = |v0|/beta0   gkl.jl:189
+    const double a2 = pin(c, WS_SCAL + SC_DOT)[0] / (beta0 * beta0);      // alpha^2 check        :191-192
+    if (!(std::fabs(a2 - a * a) <= std::sqrt(KK_EPS) * std::max(std::fabs(a2), a * a))) {
+        kk_set_error("operator and its adjoint are not compatible");
+        return KK_ERR_INVALID;
+    }
+    KK_TRY(kk_launch_scal(c, u0, bu->ld, 1.0 / beta0, nullptr));          // u = u0/beta0
+    KK_TRY(kk_launch_scal(c, v0, bv->ld, 1.0 / (a * beta0), nullptr));    // v = v0/(alpha beta0)
+    // r = Av0/(alpha beta0) - alpha u
+    KK_TRY(kk_launch_axpby(c, r, u0, bu->ld, -a, 1.0 / (a * beta0), nullptr, 1.0, 0));
+    KK_TRY(kk_launch_nrm2(c, r, bu->ld, SCP(c, SC_NRM2)));
+    KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2, 2, 0));
+    KK_TRY(stream_sync(c));
+    *alpha = a;
+    *beta = pin(c, WS_SCAL + SC_NRM)[0];
+    return KK_OK;
+}
+
+KK_API int kk_gkl_expand(kk_op op, kk_basis bu, kk_basis bv, int k, kk_orth_t orth, double eta, double beta_old,
+                             double* alpha, double* beta, int* npasses_v, int* npasses_u) {
+    KK_TRY(check_gkl(op, bu, bv));
+    KK_CHECK(k >= 1 && k + 2 <= bu->cap && k + 1 <= bv->cap && k + 1 <= KK_MAX_M, KK_ERR_INVALID,
+             "kk_gkl_expand: k=%d does not fit capacities %d / %d", k, bu->cap, bv->cap);
+    KK_CHECK(alpha && beta, KK_ERR_INVALID, "null output");
+    KK_CHECK(beta_old != 0.0, KK_ERR_ZERO_NORM, "kk_gkl_expand: residual norm is zero");
+    kk_ctx c = bu->ctx;
+    const kk_sparse_dev* At;
+    KK_TRY(get_matrix(op, 1, &At));
+    double* u = bu->col(k);            // holds r on entry
+    double* v = bv->col(k);
+    double* r = bu->col(k + 1);
+    const double* vlast = bv->col(k - 1);
+    gram_touch(bu, k); gram_touch(bv, k);
+    int pv = 0, pu = 0;
+    double a = 0, bt = 0;
+    std::vector<double> tmp(k + 1);
+    // U = push!(U, scale!!(r, 1/beta_old))   gkl.jl:254
+    KK_TRY(kk_launch_scal(c, u, bu->ld, 1.0 / beta_old, nullptr));
+    // v = A'u - beta_old V[end]  (fused), alpha = |v| fused when no sweep follows
+    kk_spmv_fuse f1;
+    f1.vprev = vlast; f1.bprev = beta_old;
+    const bool v_sweep = (orth == KK_MGS2 || orth == KK_CGSIR || orth == KK_MGSIR);
+    f1.nrm_out = SCP(c, SC_NRM2);
+    KK_TRY(kk_launch_spmv(c, *At, u, v, bv->ld, f1));
+    if (orth == KK_MGS2) {  // gkl.jl:330-336
+        double nn = 0;
+        KK_TRY(orth_run(bv, 0, k, v, KK_MGS, eta, tmp.data(), &nn, nullptr, true));
+        a = nn;
+        pv = 1;
+        // publish alpha / 1/alpha on the device for the next kernels
+        double hv[3] = {a * a, a, 1.0 / a};
+        KK_HIP(hipMemcpyAsync(c->ws + WS_SCAL + SC_NRM2, hv, sizeof(hv), hipMemcpyHostToDevice, c->stream));
+        KK_TRY(stream_sync(c));
+    } else if (orth == KK_CGSIR || orth == KK_MGSIR) {  // gkl.jl:353-360 / 380-389
+        KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2, 2, 0));
+        KK_TRY(stream_sync(c));
+        a = pin(c, WS_SCAL + SC_NRM)[0];
+        double nold = std::sqrt(a * a + beta_old * beta_old);
+        while ((orth == KK_CGSIR || KK_EPS < a) && a < eta * nold) {
+            nold = a;
+            double nn = 0;
+            KK_TRY(orth_run(bv, 0, k, v, orth == KK_CGSIR ? KK_CGS : KK_MGS, eta, tmp.data(), &nn, nullptr, true));
+            a = nn;
+            ++pv;
+            if (a == 0.0) break;
+        }
+        double hv[3] = {a * a, a, 1.0 / a};
+        KK_HIP(hipMemcpyAsync(c->ws + WS_SCAL + SC_NRM2, hv, sizeof(hv), hipMemcpyHostToDevice, c->stream));
+        KK_TRY(stream_sync(c));
+    }
+    (void)v_sweep;
+    const double* alpha_dev = c->ws + WS_SCAL + SC_NRM;
+    const double* inva_dev = c->ws + WS_SCAL + SC_INVNRM;
+    // v = scale!!(v, inv(alpha))
+    KK_TRY(kk_launch_scal(c, v, bv->ld, 0.0, inva_dev));
+    // r = A v - alpha u (fused), beta = |r| fused when no sweep follows
+    kk_spmv_fuse f2;
+    f2.vprev = u; f2.bprev_dev = alpha_dev;
+    f2.nrm_out = SCP(c, SC_NRM2B);
+    KK_TRY(kk_launch_spmv(c, op->A, v, r, bu->ld, f2));
+    if (orth == KK_CGS || orth == KK_MGS) {
+        KK_TRY(ws_fetch_async(c, WS_SCAL, 16, 0));
+        KK_TRY(stream_sync(c));
+        a = pin(c, WS_SCAL + SC_NRM)[0];
+        bt = pin(c, WS_SCAL + SC_NRMB)[0];
+    } else if (orth == KK_CGS2 || orth == KK_MGS2) {  // gkl.jl:319-321 / 341-344
+        KK_TRY(ws_fetch_async(c, WS_SCAL, 16, 2));
+        double nn = 0;
+        KK_TRY(orth_run(bu, 0, k + 1, r, orth == KK_CGS2 ? KK_CGS : KK_MGS, eta, tmp.data(), &nn, nullptr, true));
+        a = pin(c, WS_SCAL + SC_NRM, 2)[0];
+        bt = nn;
+        pu = 1;
+    } else {  // IR: gkl.jl:364-370 / 394-401
+        KK_TRY(ws_fetch_async(c, WS_SCAL, 16, 0));
+        KK_TRY(stream_sync(c));
+        a = pin(c, WS_SCAL + SC_NRM)[0];
+        bt = pin(c, WS_SCAL + SC_NRMB)[0];
+        double nold = std::sqrt(a * a + bt * bt);
+        while (KK_EPS < bt && bt < eta * nold) {
+            nold = bt;
+            double nn = 0;
+            KK_TRY(orth_run(bu, 0, k + 1, r, orth == KK_CGSIR ? KK_CGS : KK_MGS, eta, tmp.data(), &nn, nullptr, true));
+            bt = nn;
+            ++pu;
+        }
+    }
+    *alpha = a;
+    *beta = bt;
+    if (npasses_v) *npasses_v = pv;
+    if (npasses_u) *npasses_u = pu;
+    return KK_OK;
+}
+

@@ -1,0 +1,472 @@
+// libkrylov_hip.so, C ABI part 4: L2 basis operations (project / unproject / rank-1 update / basis transform / Givens /
+// Householder), the low-synchronisation Gram bookkeeping and the six orthogonalisers (src/orthonormal.jl).
+#include "kk_host.h"
+
+// ------------------------------------------------------------------------------------------
+// L2 basis operations
+// ------------------------------------------------------------------------------------------
+
+KK_API int kk_project(kk_basis b, int c0, int m, kk_basis bx, int cx, double alpha, double beta, double* y) {
+    CHECK_RANGE(b, c0, m); CHECK_COL(bx, cx); CHECK_SAME(b, bx);
+    KK_CHECK(y || m == 0, KK_ERR_INVALID, "null y");
+    if (m == 0) return KK_OK;
+    kk_ctx c = b->ctx;
+    KK_TRY(kk_launch_project(c, b->col(c0), b->ld, m, bx->col(cx), nullptr, nullptr, nullptr, WSP(c, WS_S), WSP(c, WS_G)));
+    KK_TRY(ws_fetch_async(c, WS_S, m, 0));
+    KK_TRY(stream_sync(c));
+    const double* s = pin(c, WS_S);
+    for (int j = 0; j < m; ++j) y[j] = (beta == 0.0) ? alpha * s[j] : beta * y[j] + alpha * s[j];
+    return KK_OK;
+}
+
+KK_API int kk_unproject(kk_basis by, int cy, kk_basis b, int c0, int m, const double* x, double alpha, double beta) {
+    CHECK_RANGE(b, c0, m); CHECK_COL(by, cy); CHECK_SAME(b, by);
+    KK_CHECK(x || m == 0, KK_ERR_INVALID, "null x");
+    KK_CHECK(!(by == b && cy >= c0 && cy < c0 + m), KK_ERR_INVALID, "kk_unproject: y aliases a basis column");
+    gram_touch(by, cy);
+    kk_coef ch;
+    memset(&ch, 0, sizeof(ch));
+    for (int j = 0; j < m; ++j) ch.v[j] = x[j];
+    return kk_launch_unproject(b->ctx, b->col(c0), b->ld, m, by->col(cy), by->col(cy), &ch, nullptr, alpha, beta, -1,
+                               nullptr, nullptr);
+}
+
+KK_API int kk_rank1update(kk_basis b, int c0, int m, kk_basis by, int cy, const double* x, double alpha, double beta) {
+    CHECK_RANGE(b, c0, m); CHECK_COL(by, cy); CHECK_SAME(b, by);
+    KK_CHECK(x || m == 0, KK_ERR_INVALID, "null x");
+    KK_CHECK(!(by == b && cy >= c0 && cy < c0 + m), KK_ERR_INVALID, "kk_rank1update: y aliases a basis column");
+    if (m == 0) return KK_OK;
+    gram_touch(b, c0);
+    kk_coef ch;
+    memset(&ch, 0, sizeof(ch));
+    for (int j = 0; j < m; ++j) ch.v[j] = x[j];
+    return kk_launch_rank1(b->ctx, b->col(c0), b->ld, m, by->col(cy), &ch, alpha, beta);
+}
+
+KK_API int kk_basistransform(kk_basis b, int c0, int m, int n, const double* U, int ldu) {
+    CHECK_RANGE(b, c0, m);
+    KK_CHECK(U && n >= 0 && n <= m && ldu >= m, KK_ERR_DIM, "kk_basistransform: U must be m x n with n <= m, ldu >= m");
+    if (n == 0 || m == 0) return KK_OK;
+    kk_ctx c = b->ctx;
+    gram_touch(b, c0);
+    // pack U (m x n, leading dimension m) into the pinned staging area, then into device scratch
+    KK_TRY(stream_sync(c));
+    double* hp = c->h_U;  // pinned KK_MAX_M x KK_MAX_M staging
+    for (int j = 0; j < n; ++j) memcpy(hp + (size_t)j * m, U + (size_t)j * ldu, m * sizeof(double));
+    double* dU = c->partials;  // reuse the partial-sum buffer as U scratch (>= 2 MiB)
+    KK_HIP(hipMemcpyAsync(dU, hp, (size_t)m * n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    return kk_launch_basistransform(c, b->col(c0), b->ld, m, n, dU);
+}
+
+KK_API int kk_givens_rmul(kk_basis b, int i1, int i2, double cc, double s) {
+    CHECK_COL(b, i1); CHECK_COL(b, i2);
+    KK_CHECK(i1 != i2, KK_ERR_INVALID, "kk_givens_rmul: i1 == i2");
+    gram_touch(b, std::min(i1, i2));
+    return kk_launch_givens(b->ctx, b->col(i1), b->col(i2), b->ld, cc, s);
+}
+
+KK_API int kk_householder_rmul(kk_basis b, int c0, int m, const double* v, double beta) {
+    CHECK_RANGE(b, c0, m);
+    KK_CHECK(v || m == 0, KK_ERR_INVALID, "null v");
+    if (m == 0 || beta == 0.0) return KK_OK;  // iszero(beta) && return b  (reflector.jl:147)
+    gram_touch(b, c0);
+    kk_coef ch;
+    memset(&ch, 0, sizeof(ch));
+    for (int j = 0; j < m; ++j) ch.v[j] = v[j];
+    return kk_launch_householder(b->ctx, b->col(c0), b->ld, m, &ch, beta);
+}
+
+// ---- Gram rows for the low-synchronisation MGS -------------------------------------------
+// gram(i, j) = <b_i, b_j>, j < i, stored at b->gram[i*cap + j]; rows [0, gram_rows) valid.
+// device mirror of the host Gram rows (used by the on-device low-sync solve)
+static int gram_device(kk_basis b) {
+    if (b->gram.empty()) b->gram.assign((size_t)b->cap * b->cap, 0.0);
+    if (!b->d_gram) {
+        KK_HIP(hipMalloc(&b->d_gram, (size_t)b->cap * b->cap * sizeof(double)));
+        KK_HIP(hipMemcpy(b->d_gram, b->gram.data(), (size_t)b->cap * b->cap * sizeof(double), hipMemcpyHostToDevice));
+    }
+    return KK_OK;
+}
+static int gram_upload_rows(kk_basis b, int lo, int hi) {
+    if (!b->d_gram || hi <= lo) return KK_OK;
+    // pageable source: the runtime stages it before returning, so the host vector may change afterwards
+    KK_HIP(hipMemcpyAsync(b->d_gram + (size_t)lo * b->cap, b->gram.data() + (size_t)lo * b->cap,
+                          (size_t)(hi - lo) * b->cap * sizeof(double), hipMemcpyHostToDevice, b->ctx->stream));
+    return KK_OK;
+}
+static int gram_ensure_host(kk_basis b, int upto);
+int gram_ensure(kk_basis b, int upto /* exclusive */) {
+    const int lo = std::max(b->gram_rows, 1);
+    KK_TRY(gram_ensure_host(b, upto));
+    return gram_upload_rows(b, std::min(lo, upto), std::max(upto, lo));
+}
+static int gram_ensure_host(kk_basis b, int upto /* exclusive */) {
+    kk_ctx c = b->ctx;
+    if (b->gram.empty()) b->gram.assign((size_t)b->cap * b->cap, 0.0);
+    if (b->gram_rows < 1) b->gram_rows = 1;  // row 0 has no strictly-lower entries
+    if (upto - b->gram_rows >= 4) {
+        // many rows missing (after a thick restart): one MFMA Gram panel sweep instead of one
+        // projection per row -- V is read ~upto/16 times instead of ~upto/2 times
+        const int lo = b->gram_rows;
+        std::vector<double> M;
+        for (int j0 = 0; j0 < upto - 1; j0 += 16) {
+            const int q = std::min(16, upto - 1 - j0);
+            const int i0 = std::max(lo, j0 + 1);
+            if (i0 >= upto) continue;
+            const int p = upto - i0;
+            M.assign((size_t)p * q, 0.0);
+            const int saved_mode = c->block_mode;
+            c->block_mode = 1;
+            int st = block_inner_run(c, b->col(i0), b->ld, p, b->col(j0), b->ld, q, b->ld, M.data(), p);
+            c->block_mode = saved_mode;
+            KK_TRY(st);
+            for (int jj = 0; jj < q; ++jj)
+                for (int ii = 0; ii < p; ++ii)
+                    if (j0 + jj < i0 + ii) b->gram[(size_t)(i0 + ii) * b->cap + j0 + jj] = M[ii + (size_t)p * jj];
+        }
+        b->gram_rows = upto;
+        return KK_OK;
+    }
+    for (int i = b->gram_rows; i < upto; ++i) {
+        for (int j0 = 0; j0 < i; j0 += KK_MAX_M) {
+            const int mm = std::min(KK_MAX_M, i - j0);
+            KK_TRY(kk_launch_project(c, b->col(j0), b->ld, mm, b->col(i), nullptr, nullptr, nullptr, WSP(c, WS_G), WSP(c, WS_G)));
+            KK_TRY(ws_fetch_async(c, WS_G, mm, 1));
+            KK_TRY(stream_sync(c));
+            memcpy(&b->gram[(size_t)i * b->cap + j0], pin(c, WS_G, 1), mm * sizeof(double));
+        }
+        b->gram_rows = i + 1;
+    }
+    return KK_OK;
+}
+// solve (I + L) s = p in place, L = strictly lower Gram block of columns [c0, c0+m)
+static void gram_solve(kk_basis b, int c0, int m, double* p) {
+    for (int i = 1; i < m; ++i) {
+        const double* row = &b->gram[(size_t)(c0 + i) * b->cap + c0];
+        double t = p[i];
+        for (int j = 0; j < i; ++j) t -= row[j] * p[j];
+        p[i] = t;
+    }
+}
+
+// ---- one orthogonalisation pass; coefficient results land in pinned slot `slot` ------------
+// CGS pass:  s = V'w ; w -= V s ; optional |w| (orthonormal.jl:378-384)
+static int pass_cgs(kk_ctx c, const double* V, int64_t ld, int m, double* w, bool want_norm, int slot) {
+    KK_TRY(kk_launch_project(c, V, ld, m, w, nullptr, nullptr, nullptr, WSP(c, WS_S), WSP(c, WS_G)));
+    KK_TRY(ws_fetch_async(c, WS_S, m, slot));
+    KK_TRY(kk_launch_unproject(c, V, ld, m, w, w, nullptr, c->ws + WS_S, -1.0, 1.0, -1, nullptr,
+                               want_norm ? SCP(c, SC_NRM2) : nullptr));
+    if (want_norm) KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2, 2, slot));
+    return KK_OK;
+}
+// strict MGS sweep (orthonormal.jl:414-423): `carry` = pending axpy (q, &s) left over from a
+// previous sweep whose last subtraction is fused into this sweep's first dot.
+int pass_mgs_strict(kk_ctx c, const double* V, int64_t ld, int m, double* w, int64_t ws_s, bool want_norm,
+                           int slot, const double* carry_q, const double* carry_s, bool leave_carry) {
+    const double* qp = carry_q;
+    const double* sp = carry_s;
+    for (int j = 0; j < m; ++j) {
+        const double* q = V + (int64_t)j * ld;
+        KK_TRY(kk_launch_mgs_step(c, w, ld, qp, sp, q, WSP(c, ws_s + j), nullptr));
+        qp = q;
+        sp = c->ws + ws_s + j;
+    }
+    if (!leave_carry) {
+        KK_TRY(kk_launch_mgs_step(c, w, ld, qp, sp, nullptr, nullptr, want_norm ? SCP(c, SC_NRM2) : nullptr));
+        if (want_norm) KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2, 2, slot));
+    }
+    KK_TRY(ws_fetch_async(c, ws_s, m, slot));
+    return KK_OK;
+}
+// Projection for the low-sync MGS: p = V'(w - a*pre) into pinned slot `slot` (synchronised on
+// return).  The Gram row of the newest basis vector (column c0+m-1) rides along as a second
+// right-hand side of the same kernel when it is the only row missing -- no extra pass over V.
+static int lowsync_project(kk_basis b, int c0, int m, const double* w, const double* pre_vec, const double* pre_a,
+                           int slot) {
+    kk_ctx c = b->ctx;
+    KK_TRY(gram_ensure(b, c0 + m - 1));
+    const int newest = c0 + m - 1;
+    const bool ride = (b->gram_rows == newest && newest > 0 && c0 == 0);
+    if (!ride) KK_TRY(gram_ensure(b, c0 + m));
+    KK_TRY(kk_launch_project(c, b->col(c0), b->ld, m, w, pre_vec, pre_a, ride ? b->col(newest) : nullptr, WSP(c, WS_S), WSP(c, WS_G)));
+    KK_TRY(ws_fetch_async(c, WS_S, m, slot));
+    if (ride) KK_TRY(ws_fetch_async(c, WS_G, m, slot));
+    KK_TRY(stream_sync(c));
+    if (ride) {
+        memcpy(&b->gram[(size_t)newest * b->cap], pin(c, WS_G, slot), (m - 1) * sizeof(double));
+        b->gram_rows = newest + 1;
+        KK_TRY(gram_upload_rows(b, newest, newest + 1));
+    }
+    return KK_OK;
+}
+// Device-side variant (c0 == 0): p = V'(w - a*pre) [+ Gram row of the newest vector riding along],
+// then (I + L) s = p solved ON THE DEVICE; coefficients (s, with *a0_dev added to the last one) land in
+// ws[ws_coef..], plain s in ws[ws_s..].  No host synchronisation.  If *rode, the caller must fetch
+// ws[WS_G .. WS_G+m-1) with its final read-back and hand it to lowsync_commit_row().
+int lowsync_project_dev(kk_basis b, int m, const double* w, const double* pre_vec, const double* pre_a,
+                               const double* a0_dev, int64_t ws_coef, int64_t ws_s, bool* rode) {
+    kk_ctx c = b->ctx;
+    const int newest = m - 1;
+    if (b->gram_rows < newest) KK_TRY(gram_ensure(b, newest));  // only after the basis was transformed (restart)
+    if (b->gram_rows < 1) b->gram_rows = 1;
+    const bool ride = (b->gram_rows == newest && newest > 0);
+    KK_TRY(gram_device(b));
+    KK_TRY(kk_launch_project(c, b->col(0), b->ld, m, w, pre_vec, pre_a, ride ? b->col(newest) : nullptr, WSP(c, WS_S),
+                             WSP(c, WS_G)));
+    KK_TRY(kk_launch_lowsync_solve(c, WSP(c, WS_S), ride ? WSP(c, WS_G) : nullptr, b->d_gram, b->cap, m, newest, a0_dev,
+                                   WSP(c, ws_coef), WSP(c, ws_s)));
+    *rode = ride;
+    return KK_OK;
+}
+void lowsync_commit_row(kk_basis b, int m, const double* g_host) {
+    const int newest = m - 1;
+    memcpy(&b->gram[(size_t)newest * b->cap], g_host, (m - 1) * sizeof(double));
+    b->gram_rows = newest + 1;
+}
+// low-sync MGS sweep: p = V'w (one pass), s = (I+L)^-1 p on the host, w -= V s.
+static int pass_mgs_lowsync(kk_basis b, int c0, int m, double* w, double* s_out, bool want_norm, int slot) {
+    kk_ctx c = b->ctx;
+    KK_TRY(lowsync_project(b, c0, m, w, nullptr, nullptr, slot));
+    kk_coef ch;
+    memset(&ch, 0, sizeof(ch));
+    memcpy(ch.v, pin(c, WS_S, slot), m * sizeof(double));
+    gram_solve(b, c0, m, ch.v);
+    memcpy(s_out, ch.v, m * sizeof(double));
+    KK_TRY(kk_launch_unproject(c, b->col(c0), b->ld, m, w, w, &ch, nullptr, -1.0, 1.0, -1, nullptr,
+                               want_norm ? SCP(c, SC_NRM2) : nullptr));
+    if (want_norm) KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2, 2, slot));
+    return KK_OK;
+}
+
+// orthogonalize!!(w, b[c0:c0+m), x, alg) -- all six algorithms (orthonormal.jl:378-452).
+// On return x[0..m) holds the accumulated coefficients; *nrm = |w| if want_norm.
+int orth_run(kk_basis b, int c0, int m, double* w, kk_orth_t alg, double eta, double* x, double* nrm,
+                    int* npasses, bool want_norm) {
+    kk_ctx c = b->ctx;
+    const double* V = b->col(c0);
+    const int64_t ld = b->ld;
+    int passes = 0;
+    double nn = 0;
+    if (m == 0) {
+        if (want_norm || alg == KK_CGSIR || alg == KK_MGSIR) {
+            KK_TRY(kk_launch_nrm2(c, w, ld, SCP(c, SC_NRM2)));
+            KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2, 2, 0));
+            KK_TRY(stream_sync(c));
+            nn = pin(c, WS_SCAL + SC_NRM2)[1];
+        }
+        if (nrm) *nrm = nn;
+        if (npasses) *npasses = 0;
+        return KK_OK;
+    }
+    const bool lowsync = c->mgs_mode == 1 && c0 == 0;
+    std::vector<double> tmp(m);
+    switch (alg) {
+        case KK_CGS: {
+            KK_TRY(pass_cgs(c, V, ld, m, w, want_norm, 0));
+            KK_TRY(final_sync(c));
+            memcpy(x, pin(c, WS_S, 0), m * sizeof(double));
+            nn = pin(c, WS_SCAL + SC_NRM2, 0)[1];
+            passes = 1;
+        } break;
+        case KK_CGS2: {  // :394-399
+            if (c->fuse_passes && m <= 128) {
+                // s1 = V'w ; [w1 = w - V s1 ; s2 = V'w1] fused (V read once) ; w2 = w1 - V s2 (+ norm)
+                KK_TRY(kk_launch_project(c, V, ld, m, w, nullptr, nullptr, nullptr, WSP(c, WS_S), WSP(c, WS_G)));
+                KK_TRY(ws_fetch_async(c, WS_S, m, 0));
+                KK_TRY(kk_launch_unproj_proj(c, V, ld, m, w, w, nullptr, WSP(c, WS_S), WSP(c, WS_G), nullptr));
+                KK_TRY(ws_fetch_async(c, WS_G, m, 0));
+                KK_TRY(kk_launch_unproject(c, V, ld, m, w, w, nullptr, WSP(c, WS_G), -1.0, 1.0, -1, nullptr,
+                                           want_norm ? SCP(c, SC_NRM2) : nullptr));
+                if (want_norm) KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2, 2, 0));
+                KK_TRY(final_sync(c));
+                for (int j = 0; j < m; ++j) x[j] = pin(c, WS_S, 0)[j] + pin(c, WS_G, 0)[j];
+                nn = pin(c, WS_SCAL + SC_NRM2, 0)[1];
+            } else {
+                KK_TRY(pass_cgs(c, V, ld, m, w, false, 0));
+                KK_TRY(pass_cgs(c, V, ld, m, w, want_norm, 1));
+                KK_TRY(final_sync(c));
+                for (int j = 0; j < m; ++j) x[j] = pin(c, WS_S, 0)[j] + pin(c, WS_S, 1)[j];
+                nn = pin(c, WS_SCAL + SC_NRM2, 1)[1];
+            }
+            passes = 2;
+        } break;
+        case KK_CGSIR: {  // :400-412
+            KK_TRY(kk_launch_nrm2(c, w, ld, SCP(c, SC_NRM2B)));
+            KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2B, 2, 1));
+            KK_TRY(pass_cgs(c, V, ld, m, w, true, 0));
+            KK_TRY(stream_sync(c));
+            double nold = pin(c, WS_SCAL + SC_NRM2B, 1)[1];
+            memcpy(x, pin(c, WS_S, 0), m * sizeof(double));
+            nn = pin(c, WS_SCAL + SC_NRM2, 0)[1];
+            passes = 1;
+            while (KK_EPS < nn && nn < eta * nold) {
+                nold = nn;
+                KK_TRY(pass_cgs(c, V, ld, m, w, true, 0));
+                KK_TRY(stream_sync(c));
+                for (int j = 0; j < m; ++j) x[j] += pin(c, WS_S, 0)[j];
+                nn = pin(c, WS_SCAL + SC_NRM2, 0)[1];
+                ++passes;
+            }
+        } break;
+        case KK_MGS: {
+            if (lowsync && c->fuse_passes) {
+                bool rode = false;
+                KK_TRY(lowsync_project_dev(b, m, w, nullptr, nullptr, nullptr, WS_X, WS_Y, &rode));
+                KK_TRY(kk_launch_unproject(c, V, ld, m, w, w, nullptr, WSP(c, WS_X), -1.0, 1.0, -1, nullptr,
+                                           want_norm ? SCP(c, SC_NRM2) : nullptr));
+                KK_TRY(ws_fetch_async(c, WS_Y, m, 0));
+                if (rode) KK_TRY(ws_fetch_async(c, WS_G, m, 0));
+                if (want_norm) KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2, 2, 0));
+                KK_TRY(final_sync(c));
+                memcpy(x, pin(c, WS_Y, 0), m * sizeof(double));
+                if (rode) lowsync_commit_row(b, m, pin(c, WS_G, 0));
+            } else if (lowsync) {
+                KK_TRY(pass_mgs_lowsync(b, c0, m, w, x, want_norm, 0));
+                KK_TRY(final_sync(c));
+            } else {
+                KK_TRY(pass_mgs_strict(c, V, ld, m, w, WS_S, want_norm, 0, nullptr, nullptr, false));
+                KK_TRY(final_sync(c));
+                memcpy(x, pin(c, WS_S, 0), m * sizeof(double));
+            }
+            nn = pin(c, WS_SCAL + SC_NRM2, 0)[1];
+            passes = 1;
+        } break;
+        case KK_MGS2: {  // :434-439
+            if (lowsync && c->fuse_passes && m <= 128) {
+                // p1 = V'w -> s1 = (I+L)^-1 p1 ; [w1 = w - V s1 ; p2 = V'w1] fused ; s2 = (I+L)^-1 p2 ; w2 = w1 - V s2
+                // -- both triangular solves on the device: ONE host synchronisation for the whole 2-pass step
+                bool rode = false;
+                KK_TRY(lowsync_project_dev(b, m, w, nullptr, nullptr, nullptr, WS_X, WS_Y, &rode));
+                KK_TRY(kk_launch_unproj_proj(c, V, ld, m, w, w, nullptr, WSP(c, WS_X), WSP(c, WS_S), nullptr));
+                KK_TRY(kk_launch_lowsync_solve(c, WSP(c, WS_S), nullptr, b->d_gram, b->cap, m, m - 1, nullptr, WSP(c, WS_X),
+                                               WSP(c, WS_Z)));
+                KK_TRY(kk_launch_unproject(c, V, ld, m, w, w, nullptr, WSP(c, WS_X), -1.0, 1.0, -1, nullptr,
+                                           want_norm ? SCP(c, SC_NRM2) : nullptr));
+                KK_TRY(ws_fetch_async(c, WS_Y, 2 * KK_MAX_M, 0));   // s1 (WS_Y) and s2 (WS_Z) are adjacent
+                if (rode) KK_TRY(ws_fetch_async(c, WS_G, m, 0));
+                if (want_norm) KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2, 2, 0));
+                KK_TRY(final_sync(c));
+                for (int j = 0; j < m; ++j) x[j] = pin(c, WS_Y, 0)[j] + pin(c, WS_Z, 0)[j];
+                if (rode) lowsync_commit_row(b, m, pin(c, WS_G, 0));
+            } else if (lowsync) {
+                KK_TRY(pass_mgs_lowsync(b, c0, m, w, x, false, 0));
+                KK_TRY(pass_mgs_lowsync(b, c0, m, w, tmp.data(), want_norm, 0));
+                KK_TRY(final_sync(c));
+                for (int j = 0; j < m; ++j) x[j] += tmp[j];
+            } else {
+                // the last axpy of sweep 1 is fused with the first dot of sweep 2
+                KK_TRY(pass_mgs_strict(c, V, ld, m, w, WS_S, false, 0, nullptr, nullptr, true));
+                KK_TRY(pass_mgs_strict(c, V, ld, m, w, WS_G, want_norm, 0, V + (int64_t)(m - 1) * ld,
+                                       c->ws + WS_S + m - 1, false));
+                KK_TRY(final_sync(c));
+                for (int j = 0; j < m; ++j) x[j] = pin(c, WS_S, 0)[j] + pin(c, WS_G, 0)[j];
+            }
+            nn = pin(c, WS_SCAL + SC_NRM2, 0)[1];
+            passes = 2;
+        } break;
+        case KK_MGSIR: {  // :440-452
+            KK_TRY(kk_launch_nrm2(c, w, ld, SCP(c, SC_NRM2B)));
+            KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2B, 2, 1));
+            if (lowsync) KK_TRY(pass_mgs_lowsync(b, c0, m, w, x, true, 0));
+            else KK_TRY(pass_mgs_strict(c, V, ld, m, w, WS_S, true, 0, nullptr, nullptr, false));
+            KK_TRY(stream_sync(c));
+            double nold = pin(c, WS_SCAL + SC_NRM2B, 1)[1];
+            if (!lowsync) memcpy(x, pin(c, WS_S, 0), m * sizeof(double));
+            nn = pin(c, WS_SCAL + SC_NRM2, 0)[1];
+            passes = 1;
+            while (KK_EPS < nn && nn < eta * nold) {
+                nold = nn;
+                if (lowsync) KK_TRY(pass_mgs_lowsync(b, c0, m, w, tmp.data(), true, 0));
+                else KK_TRY(pass_mgs_strict(c, V, ld, m, w, WS_S, true, 0, nullptr, nullptr, false));
+                KK_TRY(stream_sync(c));
+                for (int j = 0; j < m; ++j) x[j] += lowsync ? tmp[j] : pin(c, WS_S, 0)[j];
+                nn = pin(c, WS_SCAL + SC_NRM2, 0)[1];
+                ++passes;
+            }
+        } break;
+        default:
+            kk_set_error("unknown orthogonalizer %d", (int)alg);
+            return KK_ERR_INVALID;
+    }
+    if (nrm) *nrm = nn;
+    if (npasses) *npasses = passes;
+    return KK_OK;
+}
+
+KK_API int kk_orthogonalize(kk_basis b, int c0, int m, kk_basis bw, int cw, kk_orth_t alg, double eta, double* x,
+                                double* nrm, int* npasses) {
+    CHECK_RANGE(b, c0, m); CHECK_COL(bw, cw); CHECK_SAME(b, bw);
+    KK_CHECK(x || m == 0, KK_ERR_INVALID, "null x");
+    KK_CHECK(!(bw == b && cw >= c0 && cw < c0 + m), KK_ERR_INVALID, "kk_orthogonalize: w aliases a basis column");
+    gram_touch(bw, cw);
+    return orth_run(b, c0, m, bw->col(cw), alg, eta, x, nrm, npasses, nrm != nullptr);
+}
+
+KK_API int kk_orthonormalize(kk_basis b, int c0, int m, kk_basis bw, int cw, kk_orth_t alg, double eta, double* x,
+                                 double* nrm, int* npasses) {
+    CHECK_RANGE(b, c0, m); CHECK_COL(bw, cw); CHECK_SAME(b, bw);
+    KK_CHECK(x || m == 0, KK_ERR_INVALID, "null x");
+    KK_CHECK(!(bw == b && cw >= c0 && cw < c0 + m), KK_ERR_INVALID, "kk_orthonormalize: w aliases a basis column");
+    gram_touch(bw, cw);
+    double nn = 0;
+    KK_TRY(orth_run(b, c0, m, bw->col(cw), alg, eta, x, &nn, npasses, true));
+    if (nrm) *nrm = nn;
+    return kk_launch_scal(b->ctx, bw->col(cw), bw->ld, 1.0 / nn, nullptr);  // scale!!(v, inv(beta))  :525
+}
+
+// _orthogonalize!!(v, q, alg) (orthonormal.jl:455-489)
+int orth_vec_run(kk_ctx c, const double* q, double* w, int64_t ld, kk_orth_t alg, double eta, double* s_out,
+                        double* nrm, bool want_norm) {
+    double s = 0, nn = 0;
+    if (alg == KK_CGS || alg == KK_MGS) {
+        KK_TRY(kk_launch_mgs_step(c, w, ld, nullptr, nullptr, q, WSP(c, WS_S), nullptr));
+        KK_TRY(kk_launch_mgs_step(c, w, ld, q, c->ws + WS_S, nullptr, nullptr, want_norm ? SCP(c, SC_NRM2) : nullptr));
+        KK_TRY(ws_fetch_async(c, WS_S, 1, 0));
+        if (want_norm) KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2, 2, 0));
+        KK_TRY(stream_sync(c));
+        s = pin(c, WS_S)[0];
+        nn = pin(c, WS_SCAL + SC_NRM2)[1];
+    } else if (alg == KK_CGS2 || alg == KK_MGS2) {
+        KK_TRY(kk_launch_mgs_step(c, w, ld, nullptr, nullptr, q, WSP(c, WS_S), nullptr));
+        KK_TRY(kk_launch_mgs_step(c, w, ld, q, c->ws + WS_S, q, WSP(c, WS_S + 1), nullptr));
+        KK_TRY(kk_launch_mgs_step(c, w, ld, q, c->ws + WS_S + 1, nullptr, nullptr, want_norm ? SCP(c, SC_NRM2) : nullptr));
+        KK_TRY(ws_fetch_async(c, WS_S, 2, 0));
+        if (want_norm) KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2, 2, 0));
+        KK_TRY(stream_sync(c));
+        s = pin(c, WS_S)[0] + pin(c, WS_S)[1];
+        nn = pin(c, WS_SCAL + SC_NRM2)[1];
+    } else {
+        KK_TRY(kk_launch_nrm2(c, w, ld, SCP(c, SC_NRM2B)));
+        KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2B, 2, 1));
+        KK_TRY(kk_launch_mgs_step(c, w, ld, nullptr, nullptr, q, WSP(c, WS_S), nullptr));
+        KK_TRY(kk_launch_mgs_step(c, w, ld, q, c->ws + WS_S, nullptr, nullptr, SCP(c, SC_NRM2)));
+        KK_TRY(ws_fetch_async(c, WS_S, 1, 0));
+        KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2, 2, 0));
+        KK_TRY(stream_sync(c));
+        double nold = pin(c, WS_SCAL + SC_NRM2B, 1)[1];
+        s = pin(c, WS_S)[0];
+        nn = pin(c, WS_SCAL + SC_NRM2)[1];
+        while (KK_EPS < nn && nn < eta * nold) {
+            nold = nn;
+            KK_TRY(kk_launch_mgs_step(c, w, ld, nullptr, nullptr, q, WSP(c, WS_S), nullptr));
+            KK_TRY(kk_launch_mgs_step(c, w, ld, q, c->ws + WS_S, nullptr, nullptr, SCP(c, SC_NRM2)));
+            KK_TRY(ws_fetch_async(c, WS_S, 1, 0));
+            KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2, 2, 0));
+            KK_TRY(stream_sync(c));
+            s += pin(c, WS_S)[0];
+            nn = pin(c, WS_SCAL + SC_NRM2)[1];
+        }
+    }
+    if (s_out) *s_out = s;
+    if (nrm) *nrm = nn;
+    return KK_OK;
+}
+
+KK_API int kk_orthogonalize_vec(kk_basis bq, int cq, kk_basis bw, int cw, kk_orth_t alg, double eta, double* s,
+                                    double* nrm) {
+    CHECK_COL(bq, cq); CHECK_COL(bw, cw); CHECK_SAME(bq, bw);
+    KK_CHECK(!(bq == bw && cq == cw), KK_ERR_INVALID, "kk_orthogonalize_vec: q and w must differ");
+    gram_touch(bw, cw);
+    return orth_vec_run(bq->ctx, bq->col(cq), bw->col(cw), bw->ld, alg, eta, s, nrm, nrm != nullptr);
+}
+

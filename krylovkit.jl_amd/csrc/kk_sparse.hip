@@ -1,0 +1,396 @@
+// libkrylov_hip.so, C ABI part 2: sparse operators -- host CSR/CSC intake, device formats (ELL, CSR, SELL-64-sigma,
+// column-tiled SELL), apply / apply_adjoint / affine apply, ghost columns and halo hooks of row-sharded operators.
+#include "kk_host.h"
+
+// ------------------------------------------------------------------------------------------
+// operators
+// ------------------------------------------------------------------------------------------
+static void free_sparse(kk_sparse_dev& M) {
+    (void)hipFree(M.ell_col); (void)hipFree(M.ell_val);
+    (void)hipFree(M.rowptr); (void)hipFree(M.colind); (void)hipFree(M.val);
+    (void)hipFree(M.sell_off); (void)hipFree(M.sell_perm); (void)hipFree(M.sell_col); (void)hipFree(M.sell_val);
+    for (int t = 0; t < M.ntiles; ++t) free_sparse(M.tiles[t]);
+    delete[] M.tiles;
+    M = kk_sparse_dev();
+}
+
+// SELL-64-sigma image of a host CSR matrix on the device (fills the sell_* fields of M, sets format = 2)
+static int build_sell(const kk_host_csr& h, kk_sparse_dev& M, int64_t sigma = 64 * 64) {
+    const int64_t nrows = h.nrows;
+    // SELL-64-sigma: sort rows by length inside windows of sigma rows, slice into chunks of 64
+    M.format = 2;
+    M.sell_sigma = sigma;
+    const int64_t C = 64;
+    const int64_t nchunks = (nrows + C - 1) / C;
+    std::vector<int32_t> perm((size_t)nchunks * C, -1);
+    std::vector<int32_t> order(nrows);
+    for (int64_t i = 0; i < nrows; ++i) order[i] = (int32_t)i;
+    for (int64_t w0 = 0; w0 < nrows; w0 += sigma) {
+        const int64_t w1 = std::min(nrows, w0 + sigma);
+        std::stable_sort(order.begin() + w0, order.begin() + w1, [&](int32_t a, int32_t b) {
+            return (h.rowptr[a + 1] - h.rowptr[a]) > (h.rowptr[b + 1] - h.rowptr[b]);
+        });
+    }
+    for (int64_t i = 0; i < nrows; ++i) perm[i] = order[i];
+    std::vector<int64_t> coff(nchunks + 1, 0);
+    for (int64_t c = 0; c < nchunks; ++c) {
+        int64_t wmax = 0;
+        for (int64_t l = 0; l < C; ++l) {
+            const int32_t r = perm[c * C + l];
+            if (r >= 0) wmax = std::max(wmax, h.rowptr[r + 1] - h.rowptr[r]);
+        }
+        coff[c + 1] = coff[c] + wmax * C;
+    }
+    const int64_t total = coff[nchunks];
+    std::vector<int32_t> sc((size_t)std::max<int64_t>(total, 1), 0);
+    std::vector<double> sv((size_t)std::max<int64_t>(total, 1), 0.0);
+    for (int64_t c = 0; c < nchunks; ++c)
+        for (int64_t l = 0; l < C; ++l) {
+            const int32_t r = perm[c * C + l];
+            if (r < 0) continue;
+            int64_t k = 0;
+            for (int64_t p = h.rowptr[r]; p < h.rowptr[r + 1]; ++p, ++k) {
+                sc[coff[c] + k * C + l] = h.col[p];
+                sv[coff[c] + k * C + l] = h.val[p];
+            }
+        }
+    M.sell_nchunks = nchunks;
+    KK_HIP(hipMalloc(&M.sell_off, (nchunks + 1) * sizeof(int64_t)));
+    KK_HIP(hipMalloc(&M.sell_perm, perm.size() * sizeof(int32_t)));
+    KK_HIP(hipMalloc(&M.sell_col, sc.size() * sizeof(int32_t)));
+    KK_HIP(hipMalloc(&M.sell_val, sv.size() * sizeof(double)));
+    KK_HIP(hipMemcpy(M.sell_off, coff.data(), (nchunks + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+    KK_HIP(hipMemcpy(M.sell_perm, perm.data(), perm.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    KK_HIP(hipMemcpy(M.sell_col, sc.data(), sc.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    KK_HIP(hipMemcpy(M.sell_val, sv.data(), sv.size() * sizeof(double), hipMemcpyHostToDevice));
+    M.bytes = (nchunks + 1) * 8 + perm.size() * 4 + sc.size() * 12;
+    return KK_OK;
+}
+
+// Column-tiled SELL for operators whose gathers have no locality (rows touching columns all over a vector that does
+// not fit the 4 MB L2 of an XCD, e.g. the random rectangular map of the GKL configuration and its transpose): the
+// columns are cut into tiles of `tile_cols`, every tile is its own SELL matrix over ALL rows, and an apply runs the
+// tiles one after the other accumulating into y, so that each launch gathers from one L2-resident slice of x.
+static int build_tiled(const kk_host_csr& h, int64_t tile_cols, kk_sparse_dev& M) {
+    const int64_t nrows = h.nrows, nnz = h.rowptr[nrows];
+    const int T = (int)((h.ncols + tile_cols - 1) / tile_cols);
+    M.format = 3;
+    M.ntiles = T;
+    M.tiles = new kk_sparse_dev[T];
+    M.tile_cols = tile_cols;
+    // pass 1: entries per (tile, row); pass 2: scatter into per-tile CSR
+    std::vector<kk_host_csr> ht(T);
+    for (int t = 0; t < T; ++t) {
+        ht[t].nrows = nrows; ht[t].ncols = h.ncols;
+        ht[t].rowptr.assign(nrows + 1, 0);
+    }
+    for (int64_t i = 0; i < nrows; ++i)
+        for (int64_t p = h.rowptr[i]; p < h.rowptr[i + 1]; ++p) ht[h.col[p] / tile_cols].rowptr[i + 1]++;
+    for (int t = 0; t < T; ++t) {
+        for (int64_t i = 0; i < nrows; ++i) ht[t].rowptr[i + 1] += ht[t].rowptr[i];
+        ht[t].col.resize(ht[t].rowptr[nrows]);
+        ht[t].val.resize(ht[t].rowptr[nrows]);
+    }
+    {
+        std::vector<int64_t> cur(T);
+        for (int64_t i = 0; i < nrows; ++i) {
+            for (int t = 0; t < T; ++t) cur[t] = ht[t].rowptr[i];
+            for (int64_t p = h.rowptr[i]; p < h.rowptr[i + 1]; ++p) {
+                const int t = (int)(h.col[p] / tile_cols);
+                const int64_t q = cur[t]++;
+                ht[t].col[q] = h.col[p];
+                ht[t].val[q] = h.val[p];
+            }
+        }
+    }
+    M.bytes = 0;
+    for (int t = 0; t < T; ++t) {
+        kk_sparse_dev& S = M.tiles[t];
+        S.nrows = nrows; S.ncols = h.ncols; S.nnz = ht[t].rowptr[nrows];
+        KK_TRY(build_sell(ht[t], S, KK_TPB));   // sigma = the 256 rows of one thread block: k_spmv_sellw
+        M.bytes += S.bytes;
+        kk_host_csr().rowptr.swap(ht[t].rowptr);
+        std::vector<int32_t>().swap(ht[t].col);
+        std::vector<double>().swap(ht[t].val);
+    }
+    (void)nnz;
+    return KK_OK;
+}
+
+// mean distance between the smallest and the largest column index of a row (sampled): small for stencils / banded
+// operators whose gathers are cache friendly as they are, ~ncols for random sparsity
+static double mean_row_span(const kk_host_csr& h) {
+    const int64_t step = std::max<int64_t>(1, h.nrows / 65536);
+    double sum = 0;
+    int64_t cnt = 0;
+    for (int64_t i = 0; i < h.nrows; i += step) {
+        if (h.rowptr[i + 1] == h.rowptr[i]) continue;
+        int32_t lo = h.col[h.rowptr[i]], hi = lo;
+        for (int64_t p = h.rowptr[i]; p < h.rowptr[i + 1]; ++p) { lo = std::min(lo, h.col[p]); hi = std::max(hi, h.col[p]); }
+        sum += (double)(hi - lo);
+        ++cnt;
+    }
+    return cnt ? sum / cnt : 0.0;
+}
+
+static int upload_sparse(kk_ctx c, const kk_host_csr& h, kk_sparse_dev& M) {
+    const int64_t nrows = h.nrows, nnz = h.rowptr[nrows];
+    M.nrows = nrows; M.ncols = h.ncols; M.nnz = nnz;
+    KK_CHECK(nnz < (int64_t)1 << 31, KK_ERR_UNSUPPORTED, "nnz >= 2^31 not supported (int32 row pointers on device)");
+    KK_CHECK(h.ncols < (int64_t)1 << 31 && nrows < (int64_t)1 << 31, KK_ERR_UNSUPPORTED, "dimension >= 2^31 not supported");
+    int64_t maxw = 0;
+    for (int64_t i = 0; i < nrows; ++i) maxw = std::max(maxw, h.rowptr[i + 1] - h.rowptr[i]);
+    const bool force_csr = getenv("KK_SPMV_FORMAT") && !strcmp(getenv("KK_SPMV_FORMAT"), "csr");
+    const bool force_ell = getenv("KK_SPMV_FORMAT") && !strcmp(getenv("KK_SPMV_FORMAT"), "ell");
+    const bool force_sell = getenv("KK_SPMV_FORMAT") && !strcmp(getenv("KK_SPMV_FORMAT"), "sell");
+    const bool ell = !force_csr && !force_sell && (force_ell || (maxw <= 64 && (double)maxw * nrows <= 1.25 * (double)nnz + 4096));
+    // column tiling: default tile = 3 MB of the gathered vector (an XCD's L2 is 4 MB; measured optimum on the
+    // config-4 operator, flat between 2 and 4 MB); KK_SPMV_TILE_COLS overrides (0 = never)
+    int64_t tile_cols = 393216;
+    if (const char* tc = getenv("KK_SPMV_TILE_COLS")) tile_cols = atoll(tc);
+    const bool fmt_forced = force_csr || force_ell || force_sell;
+    if (!fmt_forced && tile_cols > 0 && 2 * h.ncols > 3 * tile_cols && nnz > 0 && mean_row_span(h) > 1.5 * (double)tile_cols)
+        return build_tiled(h, tile_cols, M);
+    if (ell) {
+        M.format = 0;
+        M.width = (int)std::max<int64_t>(maxw, 1);
+        M.ell_ld = (nrows + 63) / 64 * 64;
+        std::vector<int32_t> ec((size_t)M.ell_ld * M.width, 0);
+        std::vector<double> ev((size_t)M.ell_ld * M.width, 0.0);
+        for (int64_t i = 0; i < nrows; ++i) {
+            int k = 0;
+            for (int64_t p = h.rowptr[i]; p < h.rowptr[i + 1]; ++p, ++k) {
+                ec[(size_t)k * M.ell_ld + i] = h.col[p];
+                ev[(size_t)k * M.ell_ld + i] = h.val[p];
+            }
+        }
+        KK_HIP(hipMalloc(&M.ell_col, ec.size() * sizeof(int32_t)));
+        KK_HIP(hipMalloc(&M.ell_val, ev.size() * sizeof(double)));
+        KK_HIP(hipMemcpy(M.ell_col, ec.data(), ec.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        KK_HIP(hipMemcpy(M.ell_val, ev.data(), ev.size() * sizeof(double), hipMemcpyHostToDevice));
+        M.bytes = ec.size() * 4 + ev.size() * 8;
+    } else if (!force_csr) {
+        KK_TRY(build_sell(h, M));
+    } else {
+        M.format = 1;
+        std::vector<int32_t> rp(nrows + 1);
+        for (int64_t i = 0; i <= nrows; ++i) rp[i] = (int32_t)h.rowptr[i];
+        KK_HIP(hipMalloc(&M.rowptr, (nrows + 1) * sizeof(int32_t)));
+        KK_HIP(hipMalloc(&M.colind, std::max<int64_t>(nnz, 1) * sizeof(int32_t)));
+        KK_HIP(hipMalloc(&M.val, std::max<int64_t>(nnz, 1) * sizeof(double)));
+        KK_HIP(hipMemcpy(M.rowptr, rp.data(), (nrows + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
+        KK_HIP(hipMemcpy(M.colind, h.col.data(), nnz * sizeof(int32_t), hipMemcpyHostToDevice));
+        KK_HIP(hipMemcpy(M.val, h.val.data(), nnz * sizeof(double), hipMemcpyHostToDevice));
+        const double avg = nrows ? (double)nnz / nrows : 1;
+        int L = 2;
+        while (L * 2 <= avg && L < 64) L *= 2;
+        M.lanes_per_row = L;
+        M.bytes = (nrows + 1) * 4 + nnz * 12;
+    }
+    return KK_OK;
+}
+
+static void transpose_csr(const kk_host_csr& a, kk_host_csr& t) {
+    t.nrows = a.ncols; t.ncols = a.nrows;
+    const int64_t nnz = a.rowptr[a.nrows];
+    t.rowptr.assign(t.nrows + 1, 0);
+    t.col.resize(nnz); t.val.resize(nnz);
+    for (int64_t p = 0; p < nnz; ++p) t.rowptr[a.col[p] + 1]++;
+    for (int64_t i = 0; i < t.nrows; ++i) t.rowptr[i + 1] += t.rowptr[i];
+    std::vector<int64_t> cur(t.rowptr.begin(), t.rowptr.end() - 1);
+    for (int64_t i = 0; i < a.nrows; ++i)
+        for (int64_t p = a.rowptr[i]; p < a.rowptr[i + 1]; ++p) {
+            const int64_t q = cur[a.col[p]]++;
+            t.col[q] = (int32_t)i;
+            t.val[q] = a.val[p];
+        }
+}
+
+KK_API int kk_csr_create(kk_ctx c, int64_t nrows, int64_t ncols, int64_t nnz, const int64_t* rowptr,
+                             const int32_t* colind, const double* val, int index_base, int flags, kk_op* out) {
+    KK_CHECK(c && out && rowptr && (nnz == 0 || (colind && val)), KK_ERR_INVALID, "kk_csr_create: null arg");
+    KK_CHECK(nrows > 0 && ncols > 0 && nnz >= 0, KK_ERR_INVALID, "kk_csr_create: bad dimensions");
+    KK_CHECK(index_base == 0 || index_base == 1, KK_ERR_INVALID, "index_base must be 0 or 1");
+    KK_CHECK(rowptr[nrows] - index_base == nnz, KK_ERR_DIM, "kk_csr_create: rowptr[nrows] != nnz");
+    KK_HIP(hipSetDevice(c->device));
+    kk_op op = new kk_op_s();
+    op->ctx = c; op->nrows = nrows; op->ncols = ncols; op->nnz = nnz; op->flags = flags;
+    kk_host_csr& h = op->hA;
+    h.nrows = nrows; h.ncols = ncols;
+    h.rowptr.resize(nrows + 1);
+    for (int64_t i = 0; i <= nrows; ++i) h.rowptr[i] = rowptr[i] - index_base;
+    h.col.resize(nnz); h.val.assign(val, val + nnz);
+    for (int64_t p = 0; p < nnz; ++p) {
+        const int64_t cc = (int64_t)colind[p] - index_base;
+        if (cc < 0 || cc >= ncols) {
+            delete op;
+            kk_set_error("kk_csr_create: column index %lld out of range at entry %lld", (long long)cc, (long long)p);
+            return KK_ERR_DIM;
+        }
+        h.col[p] = (int32_t)cc;
+    }
+    int s = upload_sparse(c, h, op->A);
+    if (s != KK_OK) { free_sparse(op->A); delete op; return s; }
+    if (flags & KK_OP_SYMMETRIC) { kk_host_csr().rowptr.swap(h.rowptr); h.col.clear(); h.col.shrink_to_fit(); h.val.clear(); h.val.shrink_to_fit(); }
+    *out = op;
+    return KK_OK;
+}
+
+KK_API int kk_csc_create(kk_ctx c, int64_t nrows, int64_t ncols, int64_t nnz, const int64_t* colptr,
+                             const int64_t* rowval, const double* nzval, int index_base, int flags, kk_op* out) {
+    KK_CHECK(c && out && colptr && (nnz == 0 || (rowval && nzval)), KK_ERR_INVALID, "kk_csc_create: null arg");
+    KK_CHECK(nrows > 0 && ncols > 0 && nnz >= 0, KK_ERR_INVALID, "kk_csc_create: bad dimensions");
+    KK_CHECK(index_base == 0 || index_base == 1, KK_ERR_INVALID, "index_base must be 0 or 1");
+    KK_CHECK(colptr[ncols] - index_base == nnz, KK_ERR_DIM, "kk_csc_create: colptr[ncols] != nnz");
+    KK_HIP(hipSetDevice(c->device));
+    // the CSC arrays of A are the CSR arrays of A'
+    kk_host_csr ht;
+    ht.nrows = ncols; ht.ncols = nrows;
+    ht.rowptr.resize(ncols + 1);
+    for (int64_t i = 0; i <= ncols; ++i) ht.rowptr[i] = colptr[i] - index_base;
+    ht.col.resize(nnz); ht.val.assign(nzval, nzval + nnz);
+    for (int64_t p = 0; p < nnz; ++p) {
+        const int64_t r = rowval[p] - index_base;
+        if (r < 0 || r >= nrows) {
+            kk_set_error("kk_csc_create: row index %lld out of range at entry %lld", (long long)r, (long long)p);
+            return KK_ERR_DIM;
+        }
+        ht.col[p] = (int32_t)r;
+    }
+    kk_op op = new kk_op_s();
+    op->ctx = c; op->nrows = nrows; op->ncols = ncols; op->nnz = nnz; op->flags = flags;
+    int s;
+    if (flags & KK_OP_SYMMETRIC) {
+        s = upload_sparse(c, ht, op->A);  // A == A'
+    } else {
+        transpose_csr(ht, op->hA);
+        s = upload_sparse(c, op->hA, op->A);
+        if (s == KK_OK) {
+            s = upload_sparse(c, ht, op->At);
+            op->have_At = (s == KK_OK);
+            kk_host_csr().rowptr.swap(op->hA.rowptr); op->hA.col.clear(); op->hA.val.clear();
+        }
+    }
+    if (s != KK_OK) { free_sparse(op->A); free_sparse(op->At); delete op; return s; }
+    *out = op;
+    return KK_OK;
+}
+
+KK_API int kk_op_free(kk_op op) {
+    if (!op) return KK_OK;
+    (void)hipDeviceSynchronize();  // see kk_basis_free
+    free_sparse(op->A);
+    free_sparse(op->At);
+    delete op;
+    return KK_OK;
+}
+
+KK_API int kk_op_info(kk_op op, int64_t* nrows, int64_t* ncols, int64_t* nnz, int* format, int64_t* bytes) {
+    KK_CHECK(op, KK_ERR_INVALID, "null op");
+    if (nrows) *nrows = op->nrows;
+    if (ncols) *ncols = op->ncols;
+    if (nnz) *nnz = op->nnz;
+    if (format) *format = op->A.format;
+    if (bytes) *bytes = op->A.bytes + op->At.bytes;
+    return KK_OK;
+}
+
+KK_API int kk_op_set_ghost(kk_op op, int64_t n_local_cols, int64_t n_ghost, void* device_ghost) {
+    KK_CHECK(op, KK_ERR_INVALID, "null op");
+    KK_CHECK(n_local_cols >= 0 && n_ghost >= 0 && n_local_cols + n_ghost == op->ncols, KK_ERR_DIM,
+             "kk_op_set_ghost: n_local (%lld) + n_ghost (%lld) != ncols (%lld)", (long long)n_local_cols,
+             (long long)n_ghost, (long long)op->ncols);
+    KK_CHECK(n_ghost == 0 || device_ghost, KK_ERR_INVALID, "kk_op_set_ghost: null ghost buffer");
+    op->A.n_local = n_local_cols;
+    op->A.n_ghost = n_ghost;
+    op->A.ghost = (double*)device_ghost;  // caller-owned
+    return KK_OK;
+}
+
+KK_API int kk_op_set_halo_hook(kk_op op, kk_halo_fn fn, void* user) {
+    KK_CHECK(op, KK_ERR_INVALID, "null op");
+    op->A.halo = fn;
+    op->A.halo_user = user;
+    return KK_OK;
+}
+KK_API int kk_gather_ptr(kk_ctx c, const void* x_device, const int64_t* device_idx, int64_t count, void* device_out) {
+    KK_CHECK(c && x_device && (count == 0 || (device_idx && device_out)), KK_ERR_INVALID, "kk_gather_ptr: null arg");
+    return kk_launch_gather(c, (const double*)x_device, device_idx, count, (double*)device_out);
+}
+
+int get_matrix(kk_op op, int transpose, const kk_sparse_dev** M) {
+    if (!transpose || (op->flags & KK_OP_SYMMETRIC)) {
+        *M = &op->A;
+        return KK_OK;
+    }
+    if (!op->have_At) {
+        KK_CHECK(!op->hA.rowptr.empty(), KK_ERR_INVALID, "transpose requested but host copy is gone");
+        kk_host_csr ht;
+        transpose_csr(op->hA, ht);
+        KK_TRY(upload_sparse(op->ctx, ht, op->At));
+        op->have_At = true;
+        kk_host_csr().rowptr.swap(op->hA.rowptr); op->hA.col.clear(); op->hA.col.shrink_to_fit(); op->hA.val.clear(); op->hA.val.shrink_to_fit();
+    }
+    *M = &op->At;
+    return KK_OK;
+}
+
+// dimension check of y = op(A) x ; with ghosts the x-vector holds the local columns only
+int check_apply(kk_op op, int transpose, kk_basis bx, kk_basis by) {
+    const int64_t in = transpose ? op->nrows : (op->A.n_ghost > 0 ? op->A.n_local : op->ncols);
+    const int64_t outn = transpose ? op->ncols : op->nrows;
+    // ghost-only operator (n_local == 0): every column comes from the caller's gathered buffer, x is unused
+    const bool ghost_only = !transpose && op->A.n_ghost > 0 && op->A.n_local == 0;
+    KK_CHECK((ghost_only || bx->n == in) && by->n == outn, KK_ERR_DIM, "apply: operator is %lldx%lld%s, x has %lld rows, y has %lld rows",
+             (long long)op->nrows, (long long)op->ncols, transpose ? " (adjoint)" : "", (long long)bx->n, (long long)by->n);
+    KK_CHECK(bx->ctx == op->ctx && by->ctx == op->ctx, KK_ERR_INVALID, "apply: objects belong to different contexts");
+    return KK_OK;
+}
+
+KK_API int kk_spmv(kk_op op, int transpose, kk_basis bx, int cx, kk_basis by, int cy) {
+    KK_CHECK(op, KK_ERR_INVALID, "null op");
+    CHECK_COL(bx, cx); CHECK_COL(by, cy);
+    KK_TRY(check_apply(op, transpose, bx, by));
+    KK_CHECK(!(bx == by && cx == cy), KK_ERR_INVALID, "kk_spmv: x and y must differ");
+    const kk_sparse_dev* M;
+    KK_TRY(get_matrix(op, transpose, &M));
+    gram_touch(by, cy);
+    kk_spmv_fuse f;
+    return kk_launch_spmv(op->ctx, *M, bx->col(cx), by->col(cy), by->ld, f);
+}
+
+KK_API int kk_spmv_affine(kk_op op, kk_basis bx, int cx, kk_basis by, int cy, double a0, double a1) {
+    KK_CHECK(op, KK_ERR_INVALID, "null op");
+    CHECK_COL(bx, cx); CHECK_COL(by, cy);
+    KK_TRY(check_apply(op, 0, bx, by));
+    KK_CHECK(op->nrows == op->ncols || op->A.n_ghost > 0, KK_ERR_DIM, "affine apply needs a square operator");
+    KK_CHECK(!(bx == by && cx == cy), KK_ERR_INVALID, "kk_spmv_affine: x and y must differ");
+    gram_touch(by, cy);
+    kk_spmv_fuse f;
+    f.a0 = a0; f.a1 = a1;
+    return kk_launch_spmv(op->ctx, op->A, bx->col(cx), by->col(cy), by->ld, f);
+}
+
+// q = a0 p + a1 A p with the fused <p, q> (the CG / short-recurrence apply, linsolve/cg.jl:35-36,61-62)
+KK_API int kk_spmv_affine_dot(kk_op op, kk_basis bx, int cx, kk_basis by, int cy, double a0, double a1, double* dot) {
+    KK_CHECK(op && dot, KK_ERR_INVALID, "null arg");
+    CHECK_COL(bx, cx); CHECK_COL(by, cy);
+    KK_TRY(check_apply(op, 0, bx, by));
+    KK_CHECK(!(bx == by && cx == cy), KK_ERR_INVALID, "kk_spmv_affine_dot: x and y must differ");
+    kk_ctx c = op->ctx;
+    gram_touch(by, cy);
+    kk_spmv_fuse f;
+    f.a0 = a0; f.a1 = a1;
+    f.dot_mode = 2;
+    f.dot_out = SCP(c, SC_DOT);
+    KK_TRY(kk_launch_spmv(c, op->A, bx->col(cx), by->col(cy), by->ld, f));
+    KK_TRY(ws_fetch_async(c, WS_SCAL + SC_DOT, 1, 0));
+    KK_TRY(stream_sync(c));
+    *dot = pin(c, WS_SCAL + SC_DOT)[0];
+    return KK_OK;
+}
+KK_API int kk_gather(kk_basis bx, int cx, const int64_t* device_idx, int64_t count, void* device_out) {
+    CHECK_COL(bx, cx);
+    return kk_launch_gather(bx->ctx, bx->col(cx), device_idx, count, (double*)device_out);
+}
+
