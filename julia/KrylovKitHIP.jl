@@ -329,7 +329,7 @@ end
 # unchanged through the L1 verbs above; these specialisations replace the 6-10 verb calls of an iteration by one or
 # two library calls that keep the recurrence scalars on the device.  The surrounding control flow (tolerance checks,
 # explicit residual on convergence, ConvergenceInfo) is the reference's, see linsolve/cg.jl:60-101 and
-# linsolve/bicgstab.jl:118-199; krylovkit_hip/solvers.py holds the executed mirror of exactly this sequence.
+# linsolve/bicgstab.jl:118-199; krylovkit_hip/linsolve.py holds the executed mirror of exactly this sequence.
 
 # one CG iteration: [p = r + beta p]; q = a0 p + a1 A p; alpha = rho/<p,q>; x += alpha p; r -= alpha q; returns |r|
 function cg_iterate!(A::HipOperator, slab::HipSlab, cx, cr, cp, cq, a0, a1, beta, first::Bool, rho)
