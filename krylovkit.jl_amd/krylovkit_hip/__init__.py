@@ -13,7 +13,7 @@ from .factorizations import (ArnoldiFactorization, ArnoldiIterator, Block, Block
                              GKLFactorization, GKLIterator, block_inner, block_qr_, block_reorthogonalize_,
                              LanczosFactorization, LanczosIterator, expand_, initialize, initialize_, shrink_)
 from . import dist
-from .solvers import CG, GKL, GMRES, LSMR, Arnoldi, BiCGStab, GolubYe, geneigsolve, BlockLanczos, linsolve_bicgstab, linsolve_cg, lssolve, schursolve, ConvergenceInfo, Lanczos, eigsolve, eigsolve_block, linsolve, svdsolve
+from .solvers import CG, GKL, GMRES, LSMR, Arnoldi, BiArnoldi, BiCGStab, GolubYe, bieigsolve, geneigsolve, BlockLanczos, linsolve_bicgstab, linsolve_cg, lssolve, schursolve, ConvergenceInfo, Lanczos, eigsolve, eigsolve_block, linsolve, svdsolve
 
 from .matrixfun import expintegrator, exponentiate
 

@@ -38,6 +38,16 @@ class Arnoldi:  # algorithms.jl:235-252
 
 
 @dataclass
+class BiArnoldi:  # algorithms.jl:274-291
+    orth: Orthogonalizer = KrylovDefaults.orth
+    krylovdim: int = KrylovDefaults.krylovdim
+    maxiter: int = KrylovDefaults.maxiter
+    tol: float = KrylovDefaults.tol
+    eager: bool = False
+    verbosity: int = 0
+
+
+@dataclass
 class GMRES:  # algorithms.jl:373-390
     orth: Orthogonalizer = KrylovDefaults.orth
     maxiter: int = KrylovDefaults.maxiter

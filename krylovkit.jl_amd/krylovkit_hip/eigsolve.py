@@ -236,6 +236,142 @@ def _eigsolve_arnoldi(A, x0, howmany: int, which: str, alg: Arnoldi):
     return values, vectors, ConvergenceInfo(converged, residuals, normres, numiter, numops)
 
 
+# -------------------------------------------------------------------- bieigsolve (BiArnoldi)
+def _bischursolve(A, v0, w0, howmany: int, which: str, alg):
+    """_bischursolve (src/eigsolve/biarnoldi.jl:196-393): two-sided Krylov-Schur.  Two Arnoldi factorizations on the
+    device -- V for A (fused kk_arnoldi_expand), W for A' (the adjoint as a function operator, un-fused sequence);
+    their coupling M = W'V, the oblique corrections of the residuals and the K x K Schur algebra follow the reference
+    (host LAPACK for the small matrices, kk_project / kk_unproject / kk_basistransform for everything N-long)."""
+    import scipy.linalg as sla
+    from .core import FunctionOperator
+    krylovdim, maxiter, tol = alg.krylovdim, alg.maxiter, alg.tol
+    if howmany > krylovdim:
+        raise ValueError(f"krylov dimension {krylovdim} too small to compute {howmany} eigenvalues")
+    op = _as_operator(A)
+    n = op.shape[0]
+    opT = FunctionOperator(lambda x, y: op.apply(x, y, True), n, op.ctx)      # apply_adjoint (apply.jl:15)
+    numiter = 1
+    itV = ArnoldiIterator(op, v0, alg.orth, capacity=krylovdim + 2)             # BiArnoldiIterator (factorizations/biarnoldi.jl:24-41)
+    itW = ArnoldiIterator(opT, w0, alg.orth, capacity=krylovdim + 2)
+    fV, fW = initialize(itV), initialize(itW)
+    numops = 1
+    R = DeviceBasis(n, 2, op.ctx)                                               # the two corrected residuals
+    rV, rW = HipVec(R, 0), HipVec(R, 1)
+    MM = np.zeros((krylovdim, krylovdim))
+    MM[0, 0] = HipVec(fW.V, 0).inner(HipVec(fV.V, 0))
+    converged = 0
+    S = T = Q = Z = h = k = M = None
+    MinvWv = MinvVw = None
+    while True:
+        bv, bw = fV.normres, fW.normres
+        Lk = len(fV)
+        if Lk == krylovdim or (bv <= tol and bw <= tol) or (alg.eager and Lk >= howmany):   # process  :232
+            H, K = fV.rayleighquotient(), fW.rayleighquotient()
+            M = MM[:Lk, :Lk]
+            rV.scale_from_(fV.r, 1 / bv)                                        # v_{l+1}, w_{l+1}   :248-254
+            rW.scale_from_(fW.r, 1 / bw)
+            V, W = fV.basis(), fW.basis()
+            Wv = W.project(rV, 0, Lk)                                           # W' v, V' w   :256-259
+            Vw = V.project(rW, 0, Lk)
+            lu = sla.lu_factor(M)                                               # :260-262
+            MinvWv = sla.lu_solve(lu, Wv)
+            MinvVw = sla.lu_solve(lu, Vw, trans=1)
+            H[:, Lk - 1] += bv * MinvWv                                         # :263-264
+            K[:, Lk - 1] += bw * MinvVw
+            V.unproject(rV, MinvWv, 0, Lk, -1.0, 1.0)                           # oblique corrections   :265-268
+            W.unproject(rW, MinvVw, 0, Lk, -1.0, 1.0)
+            brV, brW = rV.norm(), rW.norm()
+            S, Q, valsH = dense.hschur(H)                                       # :271-278
+            T, Z, valsK = dense.hschur(K)
+            S, Q, _ = dense.permuteschur(S, Q, dense.sortperm_general(valsH, which))
+            T, Z, _ = dense.permuteschur(T, Z, dense.sortperm_general(np.conj(valsK), which))
+            h = Q[Lk - 1, :] * bv                                               # :280-281
+            k = Z[Lk - 1, :] * bw
+            converged = 0
+            while converged < Lk and max(brV * abs(h[converged]), brW * abs(k[converged])) <= tol:
+                converged += 1
+            if 0 < converged < Lk and S[converged, converged - 1] != 0:
+                converged -= 1
+            if converged >= howmany or (bv <= tol and bw <= tol):
+                break
+        if Lk < krylovdim:                                                      # expand  :303-312
+            fV, fW = expand_(itV, fV), expand_(itW, fW)
+            V, W = fV.basis(), fW.basis()
+            vL, wL = HipVec(V, Lk), HipVec(W, Lk)
+            MM[:Lk, Lk] = W.project(vL, 0, Lk)                                  # <W_i, V_{L+1}>
+            MM[Lk, :Lk] = V.project(wL, 0, Lk)                                  # <W_{L+1}, V_i>
+            MM[Lk, Lk] = wL.inner(vL)
+            numops += 2
+        else:                                                                   # shrink  :313-358
+            if numiter == maxiter:
+                break
+            keep = (3 * krylovdim + 2 * converged) // 5
+            stuck = False
+            while S[keep, keep - 1] != 0 or T[keep, keep - 1] != 0:
+                if keep > 1:
+                    keep -= 1
+                else:
+                    keep += 1
+                    if krylovdim == 2:
+                        stuck = True
+                        break
+            if stuck:
+                break
+            H, K = np.array(S), np.array(T)
+            VQv = -Q[:, :keep].T @ MinvWv
+            WZw = -Z[:, :keep].T @ MinvVw
+            H[:keep, :keep] += np.outer(VQv, h[:keep])
+            K[:keep, :keep] += np.outer(WZw, k[:keep])
+            V, W = fV.basis(), fW.basis()
+            V.unproject(rV, Q[:, :keep] @ VQv, 0, Lk, -1.0, 1.0)
+            W.unproject(rW, Z[:, :keep] @ WZw, 0, Lk, -1.0, 1.0)
+            brV, brW = rV.norm(), rW.norm()
+            rV.scale_(1 / brV)
+            rW.scale_(1 / brW)
+            h, k = h * brV, k * brW
+            dense.restorearnoldiform(Q, H, h, keep)
+            dense.restorearnoldiform(Z, K, k, keep)
+            for fact, Hm, Um, rnew in ((fV, H, Q, rV), (fW, K, Z, rW)):
+                _set_packed_hessenberg(fact, Hm, Lk)
+                B = fact.basis()
+                B.basistransform(np.ascontiguousarray(Um[:, :keep]))
+                HipVec(B, keep).scale_from_(rnew, 1.0)                          # V[keep+1] = v_hat
+                shrink_(fact, keep)
+            MM[:keep, :keep] = Z[:, :keep].T @ (M @ Q[:, :keep])                # :352-356
+            numiter += 1
+    return (S, T), (Q, Z), (fV, fW), (rV, rW), (h, k), M, converged, numiter, numops
+
+
+def bieigsolve(A, v0, w0, howmany: int = 1, which: str = "LM", alg=None, **kw):
+    """bieigsolve(f, v0, w0, howmany, which, alg::BiArnoldi) (src/eigsolve/biarnoldi.jl:127-194): eigenvalues with right
+    and left eigenvectors (W'V = I) of a general operator.  Returns (values, (vectorsV, vectorsW), (infoV, infoW))."""
+    from .algorithms import BiArnoldi
+    alg = alg or BiArnoldi(**kw)
+    (S, T), (Q, Z), (fV, fW), (rV, rW), (h, k), M, converged, numiter, numops = _bischursolve(A, v0, w0, howmany, which, alg)
+    hm = howmany
+    if howmany < T.shape[0] and T[howmany, howmany - 1] != 0:
+        hm += 1
+    elif T.shape[0] < howmany:
+        hm = T.shape[0]
+    if converged > howmany:
+        hm = converged
+    SS = S[:hm, :hm]
+    valuesS = dense.schur2eigvals(SS)
+    vecsS = dense.schur2eigvecs(SS)
+    ZMQ = Z[:, :hm].T @ M @ Q[:, :hm]
+    vecsT = np.linalg.inv((ZMQ @ vecsS).conj().T)
+    Lk = len(fV)
+    vectorsS = _times_complex(fV.basis(), Lk, Q[:, :hm] @ vecsS)
+    vectorsT = _times_complex(fW.basis(), Lk, Z[:, :hm] @ vecsT)
+    hVS = [h[:hm] @ vecsS[:, i] for i in range(hm)]
+    kVT = [k[:hm] @ vecsT[:, i] for i in range(hm)]
+    rVh, rWh = rV.get(), rW.get()
+    nV, nW = float(np.linalg.norm(rVh)), float(np.linalg.norm(rWh))
+    infoS = ConvergenceInfo(converged, [rVh * s for s in hVS], np.array([nV * abs(s) for s in hVS]), numiter, numops)
+    infoT = ConvergenceInfo(converged, [rWh * s for s in kVT], np.array([nW * abs(s) for s in kVT]), numiter, numops)
+    return valuesS, (vectorsS, vectorsT), (infoS, infoT)
+
+
 # -------------------------------------------------------------------- svdsolve (GKL)
 def svdsolve(A, x0, howmany: int = 1, which: str = "LR", alg: Optional[GKL] = None, **kw):
     """svdsolve(A, x0, howmany, which, alg::GKL) (src/eigsolve/svdsolve.jl:144-314)."""

@@ -2054,3 +2054,169 @@ def geneigsolve_golubye(A, B, x0, howmany: int = 1, which: str = "SR", *, krylov
             numiter += 1
     return np.array(values), vectors, ConvergenceInfo(converged, residuals, np.array(normres), numiter, numops)
 
+
+# --------------------------------------------------------------------------------------
+# bieigsolve with BiArnoldi (two-sided Krylov-Schur) -- src/eigsolve/biarnoldi.jl, factorizations/biarnoldi.jl
+# --------------------------------------------------------------------------------------
+def _restore_arnoldi_form(U, H, f, keep):
+    """_restorearnoldiform!(U, H, f, keep) (eigsolve/arnoldi.jl:466-480)."""
+    for j in range(keep):
+        H[keep, j] = f[j]
+    for j in range(keep, 0, -1):
+        hb, hv, nu = householder_vec(H[j, :j], j - 1)
+        H[j, j - 1] = nu
+        H[j, : j - 1] = 0.0
+        r = np.arange(j)
+        householder_lmul(hb, hv, r, H)
+        householder_rmul_mat(H, hb, hv, r, rows=slice(0, j))
+        householder_rmul_mat(U, hb, hv, r)
+
+
+def _bischursolve(A, v0, w0, howmany, which, krylovdim, maxiter, tol, orth, eager):
+    """_bischursolve (eigsolve/biarnoldi.jl:196-393), real Float64."""
+    import scipy.linalg as sla
+    if howmany > krylovdim:
+        raise ValueError(f"krylov dimension {krylovdim} too small to compute {howmany} eigenvalues")
+    if isinstance(A, tuple):
+        fn, fa = A
+    else:
+        fn, fa = (lambda z: A @ z), (lambda z: A.T @ z)
+    numiter = 1
+    itV = ArnoldiIterator(fn, np.asarray(v0, dtype=np.float64), orth)       # BiArnoldiIterator (factorizations/biarnoldi.jl:24-41)
+    itW = ArnoldiIterator(fa, np.asarray(w0, dtype=np.float64), orth)
+    fV, fW = arnoldi_initialize(itV), arnoldi_initialize(itW)
+    numops = 1
+    MM = np.zeros((krylovdim, krylovdim))
+    MM[0, 0] = inner(fW.V[0], fV.V[0])
+    converged = 0
+    by, rev = _eigsort_complex(which)
+    S = T = Q = Z = rV = rW = h = k = M = None
+    MinvWv = MinvVw = None
+    while True:
+        bv, bw = fV.normres, fW.normres
+        Lk = len(fV)
+        if Lk == krylovdim or (bv <= tol and bw <= tol) or (eager and Lk >= howmany):     # process  :232
+            H = fV.rayleighquotient()
+            K = fW.rayleighquotient()
+            M = MM[:Lk, :Lk]
+            rV = scale(fV.r, 1 / bv)                                                   # :248-254
+            rW = scale(fW.r, 1 / bw)
+            V, W = fV.V[:Lk], fW.V[:Lk]
+            Wv = np.array([inner(W[i], rV) for i in range(Lk)])
+            Vw = np.array([inner(V[i], rW) for i in range(Lk)])
+            lu = sla.lu_factor(M)                                                      # :260-262
+            MinvWv = sla.lu_solve(lu, Wv)
+            MinvVw = sla.lu_solve(lu, Vw, trans=1)
+            H[:, Lk - 1] += bv * MinvWv                                                # :263-264
+            K[:, Lk - 1] += bw * MinvVw
+            for i in range(Lk):
+                rV = add(rV, V[i], -MinvWv[i])
+                rW = add(rW, W[i], -MinvVw[i])
+            brV, brW = norm(rV), norm(rW)
+            S, Q = sla.schur(H, output="real")                                         # hschur!  :271-272
+            T, Z = sla.schur(K, output="real")
+            valsH, valsK = _schur_values(S), _schur_values(T)
+            kH = by(valsH)
+            kK = by(np.conj(valsK))
+            pH = np.argsort(-kH if rev else kH, kind="stable")
+            pK = np.argsort(-kK if rev else kK, kind="stable")
+            S, Q, _ = _permute_schur(S, Q, list(pH))
+            T, Z, _ = _permute_schur(T, Z, list(pK))
+            h = Q[Lk - 1, :] * bv                                                      # :280-281
+            k = Z[Lk - 1, :] * bw
+            converged = 0
+            while converged < Lk:
+                if max(brV * abs(h[converged]), brW * abs(k[converged])) <= tol:
+                    converged += 1
+                else:
+                    break
+            if 0 < converged < Lk and S[converged, converged - 1] != 0:
+                converged -= 1
+            if converged >= howmany or (bv <= tol and bw <= tol):
+                break
+        if Lk < krylovdim:                                                             # expand  :303-312
+            fV = arnoldi_expand(itV, fV)
+            fW = arnoldi_expand(itW, fW)
+            V, W = fV.V, fW.V                                                          # V[L+1], W[L+1] are the vectors just pushed
+            for i in range(Lk):
+                MM[i, Lk] = inner(W[i], V[Lk])
+                MM[Lk, i] = inner(W[Lk], V[i])
+            MM[Lk, Lk] = inner(W[Lk], V[Lk])
+            numops += 2
+        else:                                                                          # shrink  :313-358
+            if numiter == maxiter:
+                break
+            keep = (3 * krylovdim + 2 * converged) // 5
+            stuck = False
+            while S[keep, keep - 1] != 0 or T[keep, keep - 1] != 0:
+                if keep > 1:
+                    keep -= 1
+                else:
+                    keep += 1
+                    if krylovdim == 2:
+                        stuck = True
+                        break
+            if stuck:
+                break
+            H, K = np.array(S), np.array(T)
+            VQv = -Q[:, :keep].T @ MinvWv
+            WZw = -Z[:, :keep].T @ MinvVw
+            H[:keep, :keep] += np.outer(VQv, h[:keep])
+            K[:keep, :keep] += np.outer(WZw, k[:keep])
+            QVQv = Q[:, :keep] @ VQv
+            ZWZw = Z[:, :keep] @ WZw
+            V, W = fV.V[:Lk], fW.V[:Lk]
+            for i in range(Lk):
+                rV = add(rV, V[i], -QVQv[i])
+                rW = add(rW, W[i], -ZWZw[i])
+            brV, brW = norm(rV), norm(rW)
+            rV = scale_(rV, 1 / brV)
+            rW = scale_(rW, 1 / brW)
+            h = h * brV
+            k = k * brW
+            _restore_arnoldi_form(Q, H, h, keep)
+            _restore_arnoldi_form(Z, K, k, keep)
+            for fact, Hm, Um, rnew in ((fV, H, Q, rV), (fW, K, Z, rW)):
+                for j in range(1, Lk + 1):                                             # copy!(rayleighquotient(fact), H)
+                    for i in range(1, min(j + 1, Lk) + 1):
+                        fact.H[packed_index(i, j)] = float(Hm[i - 1, j - 1])
+                B = basistransform(list(fact.V[:Lk]), Um[:, :keep])
+                for j in range(keep):
+                    fact.V[j] = B[j]
+                fact.V[keep] = rnew
+                arnoldi_shrink(fact, keep)
+            MM[:keep, :keep] = Z[:, :keep].T @ (M @ Q[:, :keep])                       # :352-356
+            numiter += 1
+    return (S, T), (Q, Z), (fV, fW), (rV, rW), (h, k), M, converged, numiter, numops
+
+
+def bieigsolve_biarnoldi(A, v0, w0, howmany: int = 1, which: str = "LM", *, krylovdim: int = 30, maxiter: int = 100,
+                         tol: float = 1e-12, orth: Orthogonalizer = MGS2, eager: bool = False):
+    """bieigsolve(f, v0, w0, howmany, which, alg::BiArnoldi) (eigsolve/biarnoldi.jl:127-194): eigenvalues, right and left
+    eigenvectors (biorthonormal: W' V = I), two ConvergenceInfo."""
+    (S, T), (Q, Z), (fV, fW), (rV, rW), (h, k), M, converged, numiter, numops = _bischursolve(
+        A, v0, w0, howmany, which, krylovdim, maxiter, tol, orth, eager)
+    hm = howmany
+    if howmany < T.shape[0] and T[howmany, howmany - 1] != 0:
+        hm += 1
+    elif T.shape[0] < howmany:
+        hm = T.shape[0]
+    if converged > howmany:
+        hm = converged
+    SS = S[:hm, :hm]
+    valuesS = _schur_values(SS)
+    vecsS = _schur_eigvecs(SS)
+    ZMQ = Z[:, :hm].T @ M @ Q[:, :hm]
+    vecsT = np.linalg.inv((ZMQ @ vecsS).conj().T)
+    VS = Q[:, :hm] @ vecsS
+    VT = Z[:, :hm] @ vecsT
+    Lk = len(fV)
+    Vm, Wm = np.stack(fV.V[:Lk], axis=1), np.stack(fW.V[:Lk], axis=1)
+    vectorsS = [Vm @ VS[:, i] for i in range(hm)]
+    vectorsT = [Wm @ VT[:, i] for i in range(hm)]
+    hVS = [h[:hm] @ vecsS[:, i] for i in range(hm)]
+    kVT = [k[:hm] @ vecsT[:, i] for i in range(hm)]
+    infoS = ConvergenceInfo(converged, [rV * s for s in hVS], np.array([norm(rV) * abs(s) for s in hVS]), numiter, numops)
+    infoT = ConvergenceInfo(converged, [rW * s for s in kVT], np.array([norm(rW) * abs(s) for s in kVT]), numiter, numops)
+    return valuesS, (vectorsS, vectorsT), (infoS, infoT)
+

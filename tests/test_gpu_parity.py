@@ -984,6 +984,32 @@ def test_function_operator(kk, ko, ctx):
     np.testing.assert_allclose(w, wo, rtol=0, atol=1e-10 * np.linalg.norm(wo))
 
 
+@pytest.mark.parametrize("which", ["LM", "SR"])
+def test_bieigsolve_biarnoldi(kk, ko, ctx, which):
+    """bieigsolve(f, v0, w0, howmany, which, alg::BiArnoldi) (eigsolve/biarnoldi.jl): two device Arnoldi factorizations
+    (A fused, A' through the function-operator path), oblique residual corrections, two-sided Krylov-Schur restarts;
+    counts and eigenvalues against the oracle, right / left eigen-relations, biorthogonality W'V = I."""
+    import scipy.sparse as sp
+    n = 400
+    rng = np.random.default_rng(14)
+    A = (sp.random(n, n, density=0.03, random_state=17, format="csr") - 0.5 * sp.random(n, n, density=0.03, random_state=18, format="csr")
+         + sp.diags(np.linspace(-1, 1, n))).tocsr()
+    v0, w0 = rng.random(n), rng.random(n)
+    alg = kk.BiArnoldi(kk.ModifiedGramSchmidt2(), 30, 60, 1e-9)
+    vals, (VR, WL), (iV, iW) = kk.bieigsolve(kk.SparseOperator(A, ctx), v0, w0, 3, which, alg)
+    ovals, (oVR, oWL), (oV, oW) = ko.bieigsolve_biarnoldi(A, v0, w0, 3, which, krylovdim=30, maxiter=60, tol=1e-9, orth=ko.MGS2)
+    assert iV.converged >= 3 and (iV.converged, iV.numiter, iV.numops) == (oV.converged, oV.numiter, oV.numops)
+    assert len(vals) == len(ovals)
+    np.testing.assert_allclose(vals, ovals, rtol=0, atol=1e-8 * np.max(np.abs(ovals)))
+    UV, UW = np.stack(VR, axis=1), np.stack(WL, axis=1)
+    RV, RW = np.stack(iV.residual, axis=1), np.stack(iW.residual, axis=1)
+    np.testing.assert_allclose(A @ UV, UV * vals[None, :] + RV, atol=1e-8)
+    np.testing.assert_allclose(A.T @ UW, UW * np.conj(vals)[None, :] + RW, atol=1e-8)
+    l = iV.converged
+    assert np.max(iV.normres[:l]) < 1e-7 and np.max(iW.normres[:l]) < 1e-7
+    np.testing.assert_allclose((UW.conj().T @ UV)[:l, :l], np.eye(l), atol=1e-6)
+
+
 @pytest.mark.parametrize("mgs_mode", [0, 1])
 def test_mgs_on_non_orthonormal_basis(kk, ko, ctx, mgs_mode):
     """The low-sync form (I + L) s = V'w is exact algebra for ANY basis (MGS never divides by |q|^2):

@@ -584,3 +584,52 @@ def test_golubye_geneigsolve_iteratively(ko):
         np.testing.assert_allclose(U.T @ B @ U, np.eye(U.shape[1]), atol=1e-7)
         np.testing.assert_allclose(A @ U, B @ U * Dk[None, :] + R, atol=1e-8)
 
+
+@pytest.mark.parametrize("orth_name", ["CGS2", "MGS2", "CGSIR", "MGSIR"])
+def test_biarnoldi_bieigsolve_full(ko, orth_name):
+    """test/bieigsolve.jl:1-135 (BiArnoldi - eigsolve full), real Float64: spectrum, right / left eigenvectors,
+    biorthogonality."""
+    orth = getattr(ko, orth_name)
+    orth = orth() if callable(orth) else orth
+    rng = np.random.default_rng(61)
+    n = 10
+    A = rng.random((n, n)) - 0.5
+    v, w = rng.random(n), rng.random(n)
+    n1 = n // 2
+    D1, (V1, W1), (i1, _) = ko.bieigsolve_biarnoldi(A, v, w, n1, "SR", krylovdim=n, maxiter=1, tol=1e-12, orth=orth)
+    n2 = n - n1
+    D2, (V2, W2), (i2, _) = ko.bieigsolve_biarnoldi(A, v, w, n2, "LR", krylovdim=2 * n, maxiter=1, tol=1e-12, orth=orth)
+    D = _sorted_eigs(np.linalg.eigvals(A))
+    D2s = _sorted_eigs(D2)
+    np.testing.assert_allclose(np.concatenate([D1[:n1], D2s[len(D2s) - n2:]]), D, atol=1e-8)
+    for Dk, Vk, Wk in ((D1, V1, W1), (D2, V2, W2)):
+        UV, UW = np.stack(Vk, axis=1), np.stack(Wk, axis=1)
+        np.testing.assert_allclose(A @ UV, UV * Dk[None, :], atol=1e-8)
+        np.testing.assert_allclose(A.T @ UW, UW * np.conj(Dk)[None, :], atol=1e-8)
+        np.testing.assert_allclose(UW.conj().T @ UV, np.eye(UV.shape[1]), atol=1e-8)
+
+
+@pytest.mark.parametrize("eager", [True, False])
+def test_biarnoldi_bieigsolve_iteratively(ko, eager):
+    """test/bieigsolve.jl:137-230 (BiArnoldi - eigsolve iteratively): N = 100, krylovdim = 3n, restarts."""
+    rng = np.random.default_rng(63)
+    N, n = 100, 10
+    A = rng.random((N, N)) - 0.5
+    v, w = rng.random(N), rng.random(N)
+    ev = np.linalg.eigvals(A)
+    for which, order in (("SR", np.argsort(ev.real, kind="stable")), ("LR", np.argsort(-ev.real, kind="stable")),
+                         ("LM", np.argsort(-np.abs(ev), kind="stable"))):
+        D, (Vr, Wl), (iV, iW) = ko.bieigsolve_biarnoldi(A, v, w, n, which, krylovdim=3 * n, maxiter=30, tol=1e-11, eager=eager)
+        l = iV.converged
+        assert l > 0
+        ref = list(ev[order][:l + 2])
+        for z in D[:l]:
+            j = int(np.argmin([abs(z - r) for r in ref]))
+            assert abs(z - ref[j]) < 1e-7 * max(1.0, abs(z))
+            ref.pop(j)
+        UV, UW = np.stack(Vr, axis=1), np.stack(Wl, axis=1)
+        RV, RW = np.stack(iV.residual, axis=1), np.stack(iW.residual, axis=1)
+        np.testing.assert_allclose(A @ UV, UV * D[None, :] + RV, atol=1e-8)
+        np.testing.assert_allclose(A.T @ UW, UW * np.conj(D)[None, :] + RW, atol=1e-8)
+        np.testing.assert_allclose((UW.conj().T @ UV)[:l, :l], np.eye(l), atol=1e-6)
+
