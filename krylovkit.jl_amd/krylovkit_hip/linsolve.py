@@ -102,10 +102,15 @@ def linsolve(A, b, x0=None, alg: Optional[GMRES] = None, a0: float = 0.0, a1: fl
         if beta > tol and numiter < maxiter:  # :110-117
             fact.r.scale_(1.0 / fact.normres)  # push!(V, scale!!(w, 1/normres))
             V.length = k + 1
+            # rmul!(V, gs[i]') for i = 1..k, then r = y[k+1] V[k+1] (gmres.jl:113-117): only the rotated V[k+1] is used
+            # afterwards (the slab is re-initialised), so the k rotations are accumulated on the (k+1)-square host
+            # identity and applied as ONE pass over the basis instead of k two-vector launches
+            Zr = np.eye(k + 1)
             for i in range(k):
                 i1, i2, c, s = gs[i]
-                V.rmul_givens(i1, i2, c, -s)  # rmul!(V, gs[i]')
-            vr.scale_from_(HipVec(V, k), y[k])  # r = scale!!(r, V[k+1], y[k+1])
+                z1, z2 = Zr[:, i1].copy(), Zr[:, i2].copy()
+                Zr[:, i1], Zr[:, i2] = c * z1 + s * z2, -s * z1 + c * z2
+            V.unproject(vr, Zr[:, k], 0, k + 1, y[k], 0.0)
             V.length = k
         else:  # :119-132
             vr.scale_from_(vb, 1.0)
