@@ -177,6 +177,7 @@ __device__ __forceinline__ void proj_group(const double* __restrict__ V, int64_t
         const int jkeep = max(0, min(jn, (m - keep) - jq));
         for (; jj + CB <= jkeep; jj += CB) proj_batch<RG, CB, RHS2>(Vq + (int64_t)jj * ld, ld, wv, gv, lane, jj, acc, acc2);
         for (; jj < jkeep; ++jj) proj_batch<RG, 1, RHS2>(Vq + (int64_t)jj * ld, ld, wv, gv, lane, jj, acc, acc2);
+        for (; jj + CB <= jn; jj += CB) proj_batch<RG, CB, RHS2, true>(Vq + (int64_t)jj * ld, ld, wv, gv, lane, jj, acc, acc2);
         for (; jj < jn; ++jj) proj_batch<RG, 1, RHS2, true>(Vq + (int64_t)jj * ld, ld, wv, gv, lane, jj, acc, acc2);
         smw[jq + lane] += acc;
         if (RHS2) smw[4 * KK_MAX_M + jq + lane] += acc2;
