@@ -324,6 +324,14 @@ int kk_axpy_dev(kk_basis by, int cy, kk_basis bx, int cx, const void* dev_a, dou
 /* x *= 1/sqrt(dev_nrm2[0])   (normalise by an all-reduced squared norm, no host round trip) */
 int kk_scal_rsqrt_dev(kk_basis bx, int cx, const void* dev_nrm2);
 
+/* row-sharded Lanczos step, coefficient algebra between its two all-reduces in one launch (no host sync):
+ * buf = [alpha0 | V'w (m) | V'v (m)] summed over the ranks; rhs = V'w - alpha0 V'v; lowsync != 0 stores V'v[0:m-1] as the
+ * Gram row of the newest vector in L (cap x cap, row-major) and solves (I + L) s = rhs; coef_out = s with alpha0 added to
+ * its last entry; res = {alpha0, s[m-1]}.  kk_norm_scalars_dev: sc = {1/sqrt(n2), sqrt(n2)}, *res2 = n2. */
+int kk_lanczos_coef_dev(kk_ctx ctx, const void* buf_dev, void* L_dev, int cap, int m, int lowsync, void* coef_out_dev,
+                        void* res_dev);
+int kk_norm_scalars_dev(kk_ctx ctx, const void* nrm2_dev, void* sc_dev, void* res2_dev);
+
 #ifdef __cplusplus
 }
 #endif

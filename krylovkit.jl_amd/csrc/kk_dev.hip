@@ -85,3 +85,19 @@ KK_API int kk_scal_rsqrt_dev(kk_basis bx, int cx, const void* dev_nrm2) {
     return kk_launch_scal(bx->ctx, bx->col(cx), bx->ld, 0.0, (const double*)dev_nrm2, 1);
 }
 
+// coefficient algebra of a row-sharded Lanczos step on the device, between its two all-reduces: see k_lanczos_coef.
+// buf_dev = [alpha0 | V'w (m) | V'v (m)], L_dev = cap x cap row-major strictly-lower Gram matrix (lowsync only),
+// coef_out_dev (m), res_dev (>= 2).  Stream-ordered, no host synchronisation.
+KK_API int kk_lanczos_coef_dev(kk_ctx c, const void* buf_dev, void* L_dev, int cap, int m, int lowsync, void* coef_out_dev,
+                               void* res_dev) {
+    KK_CHECK(c && buf_dev && coef_out_dev && res_dev, KK_ERR_INVALID, "null arg");
+    KK_CHECK(m >= 1 && m <= KK_MAX_M, KK_ERR_INVALID, "kk_lanczos_coef_dev: m = %d out of range", m);
+    KK_CHECK(!lowsync || (L_dev && cap >= m), KK_ERR_INVALID, "kk_lanczos_coef_dev: Gram matrix missing or too small");
+    return kk_launch_lanczos_coef(c, (const double*)buf_dev, (double*)L_dev, cap, m, lowsync, (double*)coef_out_dev, (double*)res_dev);
+}
+// sc_dev = {1/sqrt(*nrm2_dev), sqrt(*nrm2_dev)}, *res2_dev = *nrm2_dev (device scalars of the speculative next apply)
+KK_API int kk_norm_scalars_dev(kk_ctx c, const void* nrm2_dev, void* sc_dev, void* res2_dev) {
+    KK_CHECK(c && nrm2_dev && sc_dev && res2_dev, KK_ERR_INVALID, "null arg");
+    return kk_launch_norm_scalars(c, (const double*)nrm2_dev, (double*)sc_dev, (double*)res2_dev);
+}
+

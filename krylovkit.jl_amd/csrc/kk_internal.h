@@ -287,5 +287,7 @@ int kk_launch_lsmr_u(kk_ctx ctx, const double* av, double* ah, double* u, int64_
                      double* nrm_out3);
 int kk_launch_lsmr_hx(kk_ctx ctx, double* h, double* hbar, double* x, const double* v, int64_t ld, double c1, double c2,
                       double c3);
+int kk_launch_lanczos_coef(kk_ctx ctx, const double* buf, double* L, int cap, int m, int lowsync, double* coef_out, double* res);
+int kk_launch_norm_scalars(kk_ctx ctx, const double* nrm2, double* sc, double* res2);
 int kk_launch_lowsync_solve(kk_ctx ctx, const double* p, const double* g_ride, double* L, int cap, int m, int newest,
                             const double* a0_dev, double* coef_out, double* s_out);

@@ -455,6 +455,40 @@ __global__ __launch_bounds__(KK_TPB) void k_lowsync_solve(const double* __restri
     }
 }
 
+// Row-sharded Lanczos step (krylovkit_hip/dist.py), coefficient algebra between the two all-reduces in ONE launch:
+//   buf = [alpha0 | p = V'w (m) | g = V'v (m)] (already summed over the ranks);  rhs = p - alpha0 g = V'(w - alpha0 v);
+//   lowsync != 0: g[0:m-1] is stored as the Gram row of the newest vector and (I + L) s = rhs is solved exactly;
+//   coef = s with alpha0 folded into the last entry (the update w -= V coef then also removes alpha0 v);
+//   res[0] = alpha0, res[1] = s[m-1]  (alpha = res[0] + res[1] on the host).
+__global__ __launch_bounds__(KK_TPB) void k_lanczos_coef(const double* __restrict__ buf, double* L, int cap, int m, int lowsync,
+                                                         double* __restrict__ coef_out, double* __restrict__ res) {
+    __shared__ double rhs[KK_MAX_M];
+    const int i = threadIdx.x;
+    const double a0 = buf[0];
+    const double* p = buf + 1;
+    const double* g = buf + 1 + m;
+    if (i < m) rhs[i] = fma(-a0, g[i], p[i]);
+    if (lowsync && i < m - 1) L[(int64_t)(m - 1) * cap + i] = g[i];
+    __syncthreads();
+    if (lowsync) {
+        for (int j = 0; j < m - 1; ++j) {
+            const double sj = rhs[j];
+            if (i > j && i < m) {
+                const double lij = (i == m - 1) ? g[j] : L[(int64_t)i * cap + j];
+                rhs[i] = fma(-lij, sj, rhs[i]);
+            }
+            __syncthreads();
+        }
+    }
+    if (i < m) coef_out[i] = (i == m - 1) ? rhs[i] + a0 : rhs[i];
+    if (i == 0) { res[0] = a0; res[1] = rhs[m - 1]; }
+}
+// sc = {1/sqrt(nrm2), sqrt(nrm2)}, res2 = nrm2: the device scalars of the speculative next-step apply
+__global__ void k_norm_scalars(const double* __restrict__ nrm2, double* __restrict__ sc, double* __restrict__ res2) {
+    const double n2 = *nrm2, r = sqrt(n2);
+    sc[0] = 1.0 / r; sc[1] = r; *res2 = n2;
+}
+
 // ------------------------------------------------------------------------------------------
 // strict modified Gram-Schmidt step (src/orthonormal.jl:417-421), fused across the j boundary:
 //   w -= s_prev * q_prev   (axpy of step j-1, skipped if q_prev == nullptr)
@@ -710,3 +744,13 @@ int kk_launch_lowsync_solve(kk_ctx ctx, const double* p, const double* g_ride, d
     return KK_OK;
 }
 
+int kk_launch_lanczos_coef(kk_ctx ctx, const double* buf, double* L, int cap, int m, int lowsync, double* coef_out, double* res) {
+    hipLaunchKernelGGL(k_lanczos_coef, dim3(1), dim3(KK_TPB), 0, ctx->stream, buf, L, cap, m, lowsync, coef_out, res);
+    KK_HIP(hipGetLastError());
+    return KK_OK;
+}
+int kk_launch_norm_scalars(kk_ctx ctx, const double* nrm2, double* sc, double* res2) {
+    hipLaunchKernelGGL(k_norm_scalars, dim3(1), dim3(1), 0, ctx->stream, nrm2, sc, res2);
+    KK_HIP(hipGetLastError());
+    return KK_OK;
+}

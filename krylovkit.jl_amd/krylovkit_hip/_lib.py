@@ -102,6 +102,8 @@ SIGNATURES = {
     "kk_lsmr_step_u": (C.c_int, [c_vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, c_dp]),
     "kk_lsmr_update": (C.c_int, [c_vp, C.c_int, C.c_int, C.c_int, c_vp, C.c_int, C.c_double, C.c_double, C.c_double]),
     "kk_gather": (C.c_int, [c_vp, C.c_int, c_vp, C.c_int64, c_vp]),
+    "kk_lanczos_coef_dev": (C.c_int, [c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int, c_vp, c_vp]),
+    "kk_norm_scalars_dev": (C.c_int, [c_vp, c_vp, c_vp, c_vp]),
     "kk_project": (C.c_int, [c_vp, C.c_int, C.c_int, c_vp, C.c_int, C.c_double, C.c_double, c_dp]),
     "kk_unproject": (C.c_int, [c_vp, C.c_int, c_vp, C.c_int, C.c_int, c_dp, C.c_double, C.c_double]),
     "kk_rank1update": (C.c_int, [c_vp, C.c_int, C.c_int, c_vp, C.c_int, c_dp, C.c_double, C.c_double]),

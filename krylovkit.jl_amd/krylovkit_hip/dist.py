@@ -164,6 +164,18 @@ class HipBackend:
         check(self._lib.kk_unproject_dev(basis.handle, col_y, basis.handle, c0, m, ca.ctypes.data_as(_lib.c_dp), alpha,
                                          beta, C.c_void_p(nrm_out.data_ptr() if nrm_out is not None else 0)))
 
+    def lanczos_coef(self, buf, L, m: int, lowsync: bool, coef, res):
+        """coefficient algebra of a sharded Lanczos step in one launch (kk_lanczos_coef_dev)"""
+        check(self._lib.kk_lanczos_coef_dev(self.ctx.handle, C.c_void_p(buf.data_ptr()),
+                                            C.c_void_p(L.data_ptr()) if L is not None else None,
+                                            int(L.shape[1]) if L is not None else 0, m, int(bool(lowsync)),
+                                            C.c_void_p(coef.data_ptr()), C.c_void_p(res.data_ptr())))
+
+    def norm_scalars(self, nrm2, sc, res2):
+        """sc = {1/sqrt(nrm2), sqrt(nrm2)}, res2 = nrm2 on the device (kk_norm_scalars_dev)"""
+        check(self._lib.kk_norm_scalars_dev(self.ctx.handle, C.c_void_p(nrm2.data_ptr()), C.c_void_p(sc.data_ptr()),
+                                            C.c_void_p(res2.data_ptr())))
+
     def dot(self, basis, cx, cy, out):
         check(self._lib.kk_dot_dev(basis.handle, cx, basis.handle, cy, C.c_void_p(out.data_ptr())))
 
@@ -260,12 +272,12 @@ class DistLanczosIterator:
         self.backend = be
         import torch
         self.torch = torch
-        self.buf = be.alloc(2 * 256 + 8)   # [alpha0 | p (m) | g (m)]
+        self.bufs = [be.alloc(2 * 256 + 8), be.alloc(2 * 256 + 8)]   # [alpha0 | p (m) | g (m)], used alternately: the
+        self.buf = self.bufs[0]                                       # speculative SpMV writes alpha0 into the other one
         self.nbuf = be.alloc(4)            # [|w|^2, sqrt, 1/sqrt, spare]
         self.coef = be.alloc(256)          # coefficients of the update, formed on the device
         self.res = be.alloc(4)             # [alpha0, s_m, |w|^2]: the one read-back per expand!
         self.sc = be.alloc(2)              # [1/beta, beta] of the finished iteration (device scalars)
-        self.sbuf = be.alloc(1)            # alpha0 of a speculative next-step SpMV
         self._spec = None
         self.Ldev = None                   # strictly-lower Gram matrix of the basis (low-sync MGS), on the device
 
@@ -320,10 +332,9 @@ class DistLanczosIterator:
         if k_next + 2 > V.capacity:
             return
         be, op = self.backend, self.operator
-        self.sc[1:2] = self.nbuf[0:1].sqrt()
-        self.sc[0:1] = 1.0 / self.sc[1:2]
+        nxt = self.bufs[1] if self.buf is self.bufs[0] else self.bufs[0]
         op.halo_exchange(V, k_next)
-        be.apply_fused(op.local, V, k_next, k_next - 1, k_next + 1, 0.0, dot_mode, self.sbuf,
+        be.apply_fused(op.local, V, k_next, k_next - 1, k_next + 1, 0.0, dot_mode, nxt,
                        xscale=self.sc[0:1], bprev=self.sc[1:2])
         self._spec = [k_next, None, id(V)]
 
@@ -341,8 +352,8 @@ class DistLanczosIterator:
         hit = self._spec is not None and self._spec == [k, beta_old, id(V)]
         self._spec = None
         be.scal(V, k, 1.0 / beta_old)                       # V = push!(V, scale!!(r, 1/beta_old))
-        if hit:
-            self.buf[0:1] = self.sbuf[0:1]                   # the SpMV of this step is already done
+        if hit:                                              # the SpMV of this step is already done: its alpha0 sits
+            self.buf = self.bufs[1] if self.buf is self.bufs[0] else self.bufs[0]   # in the other buffer
         else:
             op.halo_exchange(V, k)
             be.apply_fused(op.local, V, k, k - 1, k + 1, beta_old, dot_mode, self.buf)
@@ -354,26 +365,18 @@ class DistLanczosIterator:
         else:
             be.project(V, 0, m, k + 1, k, self.buf[1:1 + 2 * m])
             self._allreduce(self.buf[0:1 + 2 * m])           # ONE all-reduce: alpha0, V'w, V'v
-            a0, p, g = self.buf[0:1], self.buf[1:1 + m], self.buf[1 + m:1 + 2 * m]
-            s = p - a0 * g                                   # = V'(w - alpha0 v), on the device
-            if name == "mgs2":
-                # low-sync MGS: (I + L) s = V'(w - alpha0 v), L = strictly lower Gram matrix of V
+            lowsync = name == "mgs2"
+            if lowsync:
+                # low-sync MGS: (I + L) s = V'(w - alpha0 v), L = strictly lower Gram matrix of V; V'v is its newest row
                 if self.gram_rows < k:
                     raise RuntimeError("Gram rows out of date (basis changed outside expand); call recompute_gram()")
-                self.Ldev[k, :k] = g[:k]
                 self.gram_rows = k + 1
-                # (I + L)^-1 = I - L + L^2 - ...; |L| = O(eps) for a 2-pass orthogonaliser, so two terms are
-                # exact to O(|L|^3) ~ 1e-45 relative -- two m x m matrix-vector products instead of a
-                # triangular solve (no host round trip, no trsm launch)
-                Lm = self.Ldev[:m, :m]
-                s = s - torch.mv(Lm, s - torch.mv(Lm, s))
-            self.coef[:m] = s
-            self.coef[m - 1:m] += a0
-            self.res[0:1] = a0
-            self.res[1:2] = s[m - 1:m]
+            # s = V'w - alpha0 V'v [then the exact triangular solve], alpha0 folded into the last coefficient, and the two
+            # scalars the host needs -- one launch between the two all-reduces
+            be.lanczos_coef(self.buf, self.Ldev if lowsync else None, m, lowsync, self.coef, self.res)
             be.unproject_dev(V, k + 1, 0, m, self.coef, -1.0, 1.0, self.nbuf)
         self._allreduce(self.nbuf[0:1])
-        self.res[2:3] = self.nbuf[0:1]
+        be.norm_scalars(self.nbuf, self.sc, self.res[2:3])  # 1/beta, beta for the speculative apply; |w|^2 for the host
         self._speculate(st, k + 1, 0.0, dot_mode)           # keeps the GPU / links busy during the read-back
         h = be.to_host(self.res[0:3])                        # the ONE host synchronisation of this expand!
         alpha = float(h[0] + h[1])

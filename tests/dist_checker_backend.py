@@ -102,6 +102,27 @@ class CheckerBackend:
         if nrm_out is not None:
             nrm_out[0] = float(y @ y)
 
+    def lanczos_coef(self, buf, L, m, lowsync, coef, res):
+        h = buf.numpy()
+        a0, p, g = h[0], h[1:1 + m].copy(), h[1 + m:1 + 2 * m].copy()
+        s = p - a0 * g
+        if lowsync:
+            Lm = L.numpy()
+            Lm[m - 1, :m - 1] = g[:m - 1]
+            for j in range(m - 1):                      # exact forward substitution with I + L
+                s[j + 1:] -= Lm[j + 1:m, j] * s[j]
+        c = s.copy()
+        c[m - 1] += a0
+        coef[:m] = torch.from_numpy(c)
+        res[0] = float(a0)
+        res[1] = float(s[m - 1])
+
+    def norm_scalars(self, nrm2, sc, res2):
+        n2 = float(nrm2[0])
+        sc[0] = 1.0 / np.sqrt(n2)
+        sc[1] = np.sqrt(n2)
+        res2[0] = n2
+
     def dot(self, b, cx, cy, out):
         out[0] = float(b.cols[cx] @ b.cols[cy])
 
