@@ -101,6 +101,21 @@ class HipBackend:
     def to_host(self, t) -> np.ndarray:
         return t.cpu().numpy()
 
+    def fetch_begin(self, t):
+        """Start the read-back of a few device scalars (pinned buffer + event on the shared stream); work enqueued
+        afterwards -- the speculative next-step apply -- is NOT waited for by fetch_end."""
+        n = t.numel()
+        if getattr(self, "_pin", None) is None or self._pin.numel() < n:
+            self._pin = self.torch.empty(max(n, 16), dtype=self.torch.float64, pin_memory=True)
+            self._pin_ev = self.torch.cuda.Event()
+        self._pin[:n].copy_(t, non_blocking=True)
+        self._pin_ev.record(self.stream)
+        return n
+
+    def fetch_end(self, n) -> np.ndarray:
+        self._pin_ev.synchronize()
+        return self._pin[:n].numpy().copy()
+
     def from_host_i64(self, a: np.ndarray):
         return self.torch.as_tensor(np.ascontiguousarray(a, dtype=np.int64), device=self.device)
 
@@ -377,8 +392,9 @@ class DistLanczosIterator:
             be.unproject_dev(V, k + 1, 0, m, self.coef, -1.0, 1.0, self.nbuf)
         self._allreduce(self.nbuf[0:1])
         be.norm_scalars(self.nbuf, self.sc, self.res[2:3])  # 1/beta, beta for the speculative apply; |w|^2 for the host
-        self._speculate(st, k + 1, 0.0, dot_mode)           # keeps the GPU / links busy during the read-back
-        h = be.to_host(self.res[0:3])                        # the ONE host synchronisation of this expand!
+        tok = be.fetch_begin(self.res[0:3])                  # read-back queued BEFORE the speculative work ...
+        self._speculate(st, k + 1, 0.0, dot_mode)           # ... which keeps the GPU / links busy meanwhile
+        h = be.fetch_end(tok)                                # the ONE host synchronisation of this expand!
         alpha = float(h[0] + h[1])
         beta = float(np.sqrt(h[2]))
         if self._spec is not None:

@@ -29,6 +29,12 @@ class CheckerBackend:
     def to_host(self, t):
         return t.numpy().copy()
 
+    def fetch_begin(self, t):
+        return t.numpy().copy()
+
+    def fetch_end(self, tok):
+        return tok
+
     def from_host_i64(self, a):
         return torch.as_tensor(np.ascontiguousarray(a, dtype=np.int64))
 
