@@ -17,8 +17,9 @@
 #define KK_SUB 512            // rows covered by one block sub-step: 256 threads x 2 rows (16 B/lane)
 // register tile of the two basis-streaming kernels: RG sub-steps of 512 rows per row group (2*RG rows per
 // lane) x CB basis columns per load batch  ->  RG*CB 16-byte loads in flight per lane.
-// Defaults from tools/tile_sweep.sh on MI355X (10M rows, m=2..100): project 8x2 is 7 % faster than 4x4,
-// unproject 8x4 3 % faster than 4x4; 16-row groups lose occupancy (unproject 16x4: -45 %).
+// Defaults from tools/tile_sweep.sh on MI355X (10M rows, m=2..100): project 8x2 (16x1 with the Gram-row ride-along),
+// unproject 16x2 -- 7 % faster than 8x4 once the leftover chunks of a block run through the same code at 8/4/2/1
+// chunks (before that, 16-row groups lost 45 % in the masked tail path).
 #ifndef KK_RG_P
 #define KK_RG_P 8
 #endif
@@ -32,10 +33,10 @@
 #define KK_CB_P2 1
 #endif
 #ifndef KK_RG_U
-#define KK_RG_U 8
+#define KK_RG_U 16
 #endif
 #ifndef KK_CB_U
-#define KK_CB_U 4
+#define KK_CB_U 2
 #endif
 
 // scalar workspace layout (doubles)
