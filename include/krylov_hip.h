@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define KK_VERSION 100 /* 0.1.0 */
+#define KK_VERSION 200 /* 0.2.0 */
 
 /* status codes */
 #define KK_OK 0
@@ -110,6 +110,46 @@ int kk_ctx_set_allreduce(kk_ctx ctx, kk_allreduce_fn fn, void* user);
 int kk_ctx_workspace_size(kk_ctx ctx, int64_t* ws_count, int64_t* blk_count);
 int kk_ctx_set_workspace(kk_ctx ctx, void* ws_device, void* blk_device);
 int kk_op_set_halo_hook(kk_op op, kk_halo_fn fn, void* user);
+
+/* ---------------------------------------------------------------- row-sharded operation, native (RCCL inside the library)
+ * north_star: "the basis is optionally sharded row-wise across the 8 GPUs of one node with RCCL allreduce over xGMI".
+ * The reference has no communication layer, so these entry points replace nothing in it; they are
+ * what a Julia host needs IN ADDITION to the single-GPU calls: one process per GPU, each creates its context, rank 0
+ * calls kk_comm_get_unique_id and hands the 128 bytes to the others (any channel: MPI.jl, a file, a socket), everyone
+ * calls kk_comm_init.  From then on EVERY entry point of this header works on row-sharded vectors -- a basis of
+ * `n` rows is this rank's block of the global vectors -- and issues its own collectives on the context stream:
+ *   - all inner-product-type results (every finalize site) are summed with ncclAllReduce(f64, sum);
+ *     kk_lanczos_expand with the projection-based orthogonalisers (CGS2, low-sync MGS2) needs exactly TWO per step:
+ *     [alpha0 | V'w | V'v] (2m+1 doubles) and |w|^2;
+ *   - operators made by kk_csr_create_sharded exchange their ghost entries with grouped ncclSend / ncclRecv before an apply;
+ *   - rectangular maps made by kk_csr_create_sharded_rect (GKL / svdsolve) all-gather the short vector for A x and
+ *     reduce-scatter the partial result of A' x.
+ * Host-side control flow sees identical scalars on every rank.  librccl is loaded (dlopen) at the first kk_comm_* call.
+ * flags of kk_comm_init: KK_COMM_FORCE_COLLECTIVES issues the collectives even at world = 1 (plumbing tests on a
+ * one-GPU box; by default a communicator of one rank costs nothing). */
+#define KK_COMM_ID_BYTES 128
+#define KK_COMM_FORCE_COLLECTIVES 1
+int kk_comm_get_unique_id(void* id128);
+int kk_comm_init(kk_ctx ctx, const void* id128, int rank, int world, int flags);
+int kk_comm_destroy(kk_ctx ctx);
+int kk_comm_info(kk_ctx ctx, int* rank, int* world, int* rccl_version);
+/* collectives issued so far: all-reduces, grouped ghost exchanges, all-gather / reduce-scatter calls */
+int kk_comm_stats(kk_ctx ctx, int64_t* n_allreduce, int64_t* n_p2p_groups, int64_t* n_gather);
+/* caller-visible all-reduce of `count` doubles in device memory on the context stream; op: 0 sum, 1 max, 2 min */
+int kk_comm_allreduce(kk_ctx ctx, void* dev_ptr, int64_t count, int op);
+int kk_comm_barrier(kk_ctx ctx); /* every rank has reached this call and drained its stream */
+/* This rank's rows [row_offsets[rank], row_offsets[rank+1]) of a SQUARE global operator, CSR with GLOBAL int64 column
+ * indices; row_offsets (world+1 entries, row_offsets[0] = 0) is the row partition = the ownership of the vector
+ * entries.  The ghost-exchange plan is negotiated inside (collective call: every rank of the communicator must make it).
+ * Applies take / produce local blocks (nrows_local entries).  Without a communicator: world = 1, plain operator. */
+int kk_csr_create_sharded(kk_ctx ctx, int64_t nrows_local, const int64_t* row_offsets, int64_t nnz, const int64_t* rowptr,
+                          const int64_t* colind_global, const double* val, int index_base, int flags, kk_op* out);
+/* This rank's rows of a RECTANGULAR global map (apply_normal / apply_adjoint of svdsolve, apply.jl:14-15).  The short
+ * vectors (length ncols_global) are sharded evenly: rank r owns entries [r*s, min((r+1)*s, ncols_global)),
+ * s = ceil(ncols_global / world); *ncols_local receives this rank's count (the `n` of its V-basis). */
+int kk_csr_create_sharded_rect(kk_ctx ctx, int64_t nrows_local, int64_t ncols_global, int64_t nnz, const int64_t* rowptr,
+                               const int64_t* colind_global, const double* val, int index_base, kk_op* out,
+                               int64_t* ncols_local);
 /* gather out[i] = x[idx[i]] from a raw device vector (packing halo send buffers inside a halo hook) */
 int kk_gather_ptr(kk_ctx ctx, const void* x_device, const int64_t* device_idx, int64_t count, void* device_out);
 

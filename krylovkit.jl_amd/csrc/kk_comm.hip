@@ -1,0 +1,252 @@
+// libkrylov_hip.so, C ABI part 8: the multi-GPU layer.  One process (context) per GPU, every N-vector row-sharded;
+// the library owns an RCCL communicator (kk_comm_init) and issues the collectives of the path itself, on the context
+// stream, between its own kernels:
+//   * ncclAllReduce(sum, f64) of the <= 2m+1 doubles of every inner-product-type result (all finalize sites),
+//   * grouped ncclSend / ncclRecv of the ghost entries before a sparse apply (kk_csr_create_sharded),
+//   * ncclAllGather / ncclReduceScatter of the short vectors of a rectangular map (kk_csr_create_sharded_rect, GKL).
+// The reference has no communication layer at all; this is north_star's "basis row-sharded
+// across the 8 GPUs of one node with RCCL allreduce over xGMI".  librccl is dlopen'ed at the first kk_comm_* call so
+// single-GPU processes never map it (573 MB) and a torch-bundled copy loaded earlier in the process is reused.
+#include "kk_host.h"
+#include <dlfcn.h>
+#include <mutex>
+#include <rccl/rccl.h>
+
+namespace {
+struct rccl_api {
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*ReduceScatter)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*GetVersion)(int*) = nullptr;
+};
+rccl_api g_rccl;
+std::mutex g_rccl_mutex;
+
+int rccl_load() {
+    std::lock_guard<std::mutex> lk(g_rccl_mutex);
+    if (g_rccl.handle) return KK_OK;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    void* h = nullptr;
+    const char* env = getenv("KK_RCCL_LIB");
+    if (env && *env) h = dlopen(env, RTLD_NOW | RTLD_LOCAL);
+    for (size_t i = 0; !h && i < sizeof(names) / sizeof(names[0]); ++i) h = dlopen(names[i], RTLD_NOW | RTLD_NOLOAD);  // already mapped?
+    for (size_t i = 0; !h && i < sizeof(names) / sizeof(names[0]); ++i) h = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
+    if (!h) {
+        kk_set_error("kk_comm: cannot load librccl (%s); set KK_RCCL_LIB", dlerror());
+        return KK_ERR_UNSUPPORTED;
+    }
+#define KK_SYM(field, name)                                                      \
+    do {                                                                         \
+        *(void**)(&g_rccl.field) = dlsym(h, name);                               \
+        if (!g_rccl.field) {                                                     \
+            kk_set_error("kk_comm: librccl lacks the symbol %s", name);          \
+            dlclose(h);                                                          \
+            return KK_ERR_UNSUPPORTED;                                           \
+        }                                                                        \
+    } while (0)
+    KK_SYM(GetUniqueId, "ncclGetUniqueId");
+    KK_SYM(CommInitRank, "ncclCommInitRank");
+    KK_SYM(CommDestroy, "ncclCommDestroy");
+    KK_SYM(AllReduce, "ncclAllReduce");
+    KK_SYM(AllGather, "ncclAllGather");
+    KK_SYM(ReduceScatter, "ncclReduceScatter");
+    KK_SYM(Send, "ncclSend");
+    KK_SYM(Recv, "ncclRecv");
+    KK_SYM(GroupStart, "ncclGroupStart");
+    KK_SYM(GroupEnd, "ncclGroupEnd");
+    KK_SYM(GetErrorString, "ncclGetErrorString");
+    KK_SYM(GetVersion, "ncclGetVersion");
+#undef KK_SYM
+    g_rccl.handle = h;
+    return KK_OK;
+}
+int rccl_fail(ncclResult_t r, const char* what, int line) {
+    kk_set_error("RCCL error %d (%s) in %s at kk_comm.hip:%d", (int)r, g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?", what, line);
+    return KK_ERR_HIP;
+}
+}  // namespace
+#define KK_NCCL(call)                                                  \
+    do {                                                               \
+        ncclResult_t _r = (call);                                      \
+        if (_r != ncclSuccess) return rccl_fail(_r, #call, __LINE__);  \
+    } while (0)
+
+static_assert(KK_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "kk_comm id size must match ncclUniqueId");
+
+// ------------------------------------------------------------------------------------------
+// communicator
+// ------------------------------------------------------------------------------------------
+KK_API int kk_comm_get_unique_id(void* id128) {
+    KK_CHECK(id128, KK_ERR_INVALID, "kk_comm_get_unique_id: null buffer");
+    KK_TRY(rccl_load());
+    ncclUniqueId id;
+    KK_NCCL(g_rccl.GetUniqueId(&id));
+    memcpy(id128, id.internal, NCCL_UNIQUE_ID_BYTES);
+    return KK_OK;
+}
+
+KK_API int kk_comm_init(kk_ctx c, const void* id128, int rank, int world, int flags) {
+    KK_CHECK(c && id128, KK_ERR_INVALID, "kk_comm_init: null arg");
+    KK_CHECK(world >= 1 && rank >= 0 && rank < world, KK_ERR_INVALID, "kk_comm_init: rank %d of %d", rank, world);
+    KK_CHECK(!c->comm, KK_ERR_INVALID, "kk_comm_init: the context already has a communicator");
+    KK_CHECK(!c->allreduce, KK_ERR_INVALID, "kk_comm_init: an all-reduce hook is installed (use one mechanism)");
+    KK_TRY(rccl_load());
+    KK_HIP(hipSetDevice(c->device));
+    KK_HIP(hipStreamSynchronize(c->stream));
+    ncclUniqueId id;
+    memcpy(id.internal, id128, NCCL_UNIQUE_ID_BYTES);
+    ncclComm_t comm = nullptr;
+    KK_NCCL(g_rccl.CommInitRank(&comm, world, id, rank));
+    kk_comm_s* k = new kk_comm_s();
+    k->nccl = comm; k->rank = rank; k->world = world;
+    k->active = world > 1 || (flags & KK_COMM_FORCE_COLLECTIVES) != 0;
+    c->comm = k;
+    c->spec_owner = nullptr;   // a speculative apply enqueued before the switch carries an un-sharded alpha
+    return KK_OK;
+}
+
+KK_API int kk_comm_destroy(kk_ctx c) {
+    KK_CHECK(c, KK_ERR_INVALID, "null ctx");
+    if (!c->comm) return KK_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    ncclComm_t comm = (ncclComm_t)c->comm->nccl;
+    delete c->comm;
+    c->comm = nullptr;
+    c->spec_owner = nullptr;
+    if (comm && g_rccl.CommDestroy) KK_NCCL(g_rccl.CommDestroy(comm));
+    return KK_OK;
+}
+
+KK_API int kk_comm_info(kk_ctx c, int* rank, int* world, int* rccl_version) {
+    KK_CHECK(c, KK_ERR_INVALID, "null ctx");
+    if (rank) *rank = c->comm ? c->comm->rank : 0;
+    if (world) *world = c->comm ? c->comm->world : 1;
+    if (rccl_version) {
+        *rccl_version = 0;
+        if (c->comm && g_rccl.GetVersion) (void)g_rccl.GetVersion(rccl_version);
+    }
+    return KK_OK;
+}
+
+KK_API int kk_comm_stats(kk_ctx c, int64_t* n_allreduce, int64_t* n_p2p_groups, int64_t* n_gather) {
+    KK_CHECK(c, KK_ERR_INVALID, "null ctx");
+    if (n_allreduce) *n_allreduce = c->comm ? c->comm->n_allreduce : 0;
+    if (n_p2p_groups) *n_p2p_groups = c->comm ? c->comm->n_p2p : 0;
+    if (n_gather) *n_gather = c->comm ? c->comm->n_gather : 0;
+    return KK_OK;
+}
+
+int kk_comm_allreduce_sum(kk_ctx c, double* dev_ptr, int64_t count) {
+    kk_comm_s* k = c->comm;
+    if (!k || !k->active || count <= 0) return KK_OK;
+    KK_NCCL(g_rccl.AllReduce(dev_ptr, dev_ptr, (size_t)count, ncclDouble, ncclSum, (ncclComm_t)k->nccl, c->stream));
+    ++k->n_allreduce;
+    return KK_OK;
+}
+
+// caller-visible collective on the context stream (e.g. the max of a per-rank time); op: 0 sum, 1 max, 2 min
+KK_API int kk_comm_allreduce(kk_ctx c, void* dev_ptr, int64_t count, int op) {
+    KK_CHECK(c && (dev_ptr || count == 0), KK_ERR_INVALID, "kk_comm_allreduce: null arg");
+    KK_CHECK(op >= 0 && op <= 2, KK_ERR_INVALID, "kk_comm_allreduce: op must be 0 (sum), 1 (max) or 2 (min)");
+    kk_comm_s* k = c->comm;
+    if (!k || !k->active || count <= 0) return KK_OK;
+    const ncclRedOp_t ro = op == 0 ? ncclSum : (op == 1 ? ncclMax : ncclMin);
+    KK_NCCL(g_rccl.AllReduce(dev_ptr, dev_ptr, (size_t)count, ncclDouble, ro, (ncclComm_t)k->nccl, c->stream));
+    ++k->n_allreduce;
+    return KK_OK;
+}
+
+// all ranks have reached this point and their streams are drained
+KK_API int kk_comm_barrier(kk_ctx c) {
+    KK_CHECK(c, KK_ERR_INVALID, "null ctx");
+    if (c->comm && c->comm->world > 1) {
+        double* t = SCP(c, SC_TMP2);
+        KK_HIP(hipMemsetAsync(t, 0, sizeof(double), c->stream));
+        KK_NCCL(g_rccl.AllReduce(t, t, 1, ncclDouble, ncclSum, (ncclComm_t)c->comm->nccl, c->stream));
+    }
+    KK_HIP(hipStreamSynchronize(c->stream));
+    return KK_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// internal: integer exchanges used while a sharded operator is set up, ghost exchange, gather / scatter
+// ------------------------------------------------------------------------------------------
+int kk_comm_allgather_i64(kk_ctx c, const int64_t* d_send, int64_t* d_recv, int64_t count) {
+    kk_comm_s* k = c->comm;
+    if (!k || k->world == 1) {
+        KK_HIP(hipMemcpyAsync(d_recv, d_send, count * sizeof(int64_t), hipMemcpyDeviceToDevice, c->stream));
+        return KK_OK;
+    }
+    KK_NCCL(g_rccl.AllGather(d_send, d_recv, (size_t)count, ncclInt64, (ncclComm_t)k->nccl, c->stream));
+    return KK_OK;
+}
+// grouped point-to-point: segment q of d_send (send_counts[q] elements) goes to rank q, segment q of d_recv comes from it
+static int p2p_group(kk_ctx c, const void* d_send, const int64_t* send_counts, void* d_recv, const int64_t* recv_counts,
+                     ncclDataType_t dt) {
+    kk_comm_s* k = c->comm;
+    if (!k || k->world == 1) return KK_OK;
+    const size_t es = 8;
+    KK_NCCL(g_rccl.GroupStart());
+    int64_t so = 0, ro = 0;
+    ncclResult_t bad = ncclSuccess;
+    for (int q = 0; q < k->world && bad == ncclSuccess; ++q) {
+        if (send_counts[q] > 0)
+            bad = g_rccl.Send((const char*)d_send + so * es, (size_t)send_counts[q], dt, q, (ncclComm_t)k->nccl, c->stream);
+        so += send_counts[q];
+        if (bad == ncclSuccess && recv_counts[q] > 0)
+            bad = g_rccl.Recv((char*)d_recv + ro * es, (size_t)recv_counts[q], dt, q, (ncclComm_t)k->nccl, c->stream);
+        ro += recv_counts[q];
+    }
+    ncclResult_t end = g_rccl.GroupEnd();
+    if (bad != ncclSuccess) return rccl_fail(bad, "ncclSend/ncclRecv", __LINE__);
+    if (end != ncclSuccess) return rccl_fail(end, "ncclGroupEnd", __LINE__);
+    ++k->n_p2p;
+    return KK_OK;
+}
+int kk_comm_exchange_i64(kk_ctx c, const int64_t* d_send, const int64_t* send_counts, int64_t* d_recv,
+                         const int64_t* recv_counts) {
+    return p2p_group(c, d_send, send_counts, d_recv, recv_counts, ncclInt64);
+}
+
+// fill the ghost buffer of a row-sharded operator from the vector x it is about to be applied to
+int kk_halo_exchange(kk_ctx c, const kk_sparse_dev& M, const double* x) {
+    const kk_halo_plan* p = M.plan;
+    if (!p || (p->total_send == 0 && p->total_recv == 0)) return KK_OK;
+    KK_CHECK(c->comm && c->comm->world == (int)p->send_counts.size(), KK_ERR_INVALID,
+             "ghost exchange: the operator was created for another communicator");
+    if (p->total_send) KK_TRY(kk_launch_gather(c, x, p->d_send_idx, p->total_send, p->d_sendbuf));
+    return p2p_group(c, p->d_sendbuf, p->send_counts.data(), p->d_ghost, p->recv_counts.data(), ncclDouble);
+}
+
+// vfull = all-gather of the `shard`-strided local pieces (stage); world 1: plain copy
+int kk_comm_allgather_f64(kk_ctx c, const double* d_stage, double* d_full, int64_t shard) {
+    kk_comm_s* k = c->comm;
+    if (!k || k->world == 1) {
+        KK_HIP(hipMemcpyAsync(d_full, d_stage, shard * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        return KK_OK;
+    }
+    KK_NCCL(g_rccl.AllGather(d_stage, d_full, (size_t)shard, ncclDouble, (ncclComm_t)k->nccl, c->stream));
+    ++k->n_gather;
+    return KK_OK;
+}
+// stage = my shard of the sum over ranks of d_full
+int kk_comm_reducescatter_f64(kk_ctx c, const double* d_full, double* d_stage, int64_t shard) {
+    kk_comm_s* k = c->comm;
+    if (!k || k->world == 1) {
+        KK_HIP(hipMemcpyAsync(d_stage, d_full, shard * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        return KK_OK;
+    }
+    KK_NCCL(g_rccl.ReduceScatter(d_full, d_stage, (size_t)shard, ncclDouble, ncclSum, (ncclComm_t)k->nccl, c->stream));
+    ++k->n_gather;
+    return KK_OK;
+}

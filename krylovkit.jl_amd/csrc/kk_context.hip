@@ -36,6 +36,26 @@ KK_API int kk_device_count(int* count) {
     return KK_OK;
 }
 
+// device-side resources of a context; on failure the caller destroys the partially built context
+static int ctx_allocate(kk_ctx c) {
+    KK_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    KK_HIP(hipMalloc(&c->ws_own, WS_TOTAL * sizeof(double)));
+    KK_HIP(hipMemset(c->ws_own, 0, WS_TOTAL * sizeof(double)));
+    c->ws = c->ws_own;
+    KK_HIP(hipMalloc(&c->partials, (size_t)(2 * KK_MAX_M + 8) * KK_MAX_BLOCKS * sizeof(double)));
+    KK_HIP(hipHostMalloc(&c->h_pin, 4 * WS_TOTAL * sizeof(double), hipHostMallocDefault));
+    KK_HIP(hipHostMalloc(&c->h_U, (size_t)KK_MAX_M * KK_MAX_M * sizeof(double), hipHostMallocDefault));
+    KK_HIP(hipMalloc(&c->blk_own, (size_t)KK_BLK_SCRATCH * sizeof(double)));
+    c->blk = c->blk_own;
+    KK_HIP(hipHostMalloc(&c->h_blk, (size_t)KK_BLK_SCRATCH * sizeof(double), hipHostMallocDefault));
+    KK_HIP(hipEventCreate(&c->t0));
+    KK_HIP(hipEventCreate(&c->t1));
+    KK_HIP(hipEventCreateWithFlags(&c->ev_fetch, hipEventDisableTiming));
+    KK_HIP(hipEventCreateWithFlags(&c->ev_fetch2, hipEventDisableTiming));
+    return KK_OK;
+}
+
 KK_API int kk_ctx_create(int device, kk_ctx* out) {
     KK_CHECK(out, KK_ERR_INVALID, "kk_ctx_create: null out");
     int n = 0;
@@ -48,25 +68,22 @@ KK_API int kk_ctx_create(int device, kk_ctx* out) {
     KK_HIP(hipSetDevice(device));
     hipDeviceProp_t prop;
     KK_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {   // the library carries gfx950 code objects only
+        kk_set_error("kk_ctx_create: device %d is %s, not gfx950 (MI355X); libkrylov_hip has no other code path", device,
+                     prop.gcnArchName);
+        return KK_ERR_NO_DEVICE;
+    }
     kk_ctx c = new kk_ctx_s();
     c->device = device;
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    KK_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
-    c->stream = c->own_stream;
-    KK_HIP(hipMalloc(&c->ws_own, WS_TOTAL * sizeof(double)));
-    KK_HIP(hipMemset(c->ws_own, 0, WS_TOTAL * sizeof(double)));
-    c->ws = c->ws_own;
-    KK_HIP(hipMalloc(&c->partials, (size_t)(2 * KK_MAX_M + 8) * KK_MAX_BLOCKS * sizeof(double)));
-    KK_HIP(hipHostMalloc(&c->h_pin, 4 * WS_TOTAL * sizeof(double), hipHostMallocDefault));
-    KK_HIP(hipHostMalloc(&c->h_U, (size_t)KK_MAX_M * KK_MAX_M * sizeof(double), hipHostMallocDefault));
-    KK_HIP(hipMalloc(&c->blk_own, (size_t)KK_BLK_SCRATCH * sizeof(double)));
-    c->blk = c->blk_own;
-    KK_HIP(hipHostMalloc(&c->h_blk, (size_t)KK_BLK_SCRATCH * sizeof(double), hipHostMallocDefault));
+    const int st = ctx_allocate(c);
+    if (st != KK_OK) {   // release whatever was created before the failing call
+        const std::string msg = kk_last_error();
+        kk_ctx_destroy(c);
+        kk_set_error("%s", msg.c_str());
+        return st;
+    }
     if (getenv("KK_BLOCK_MODE")) c->block_mode = atoi(getenv("KK_BLOCK_MODE"));
-    KK_HIP(hipEventCreate(&c->t0));
-    KK_HIP(hipEventCreate(&c->t1));
-    KK_HIP(hipEventCreateWithFlags(&c->ev_fetch, hipEventDisableTiming));
-    KK_HIP(hipEventCreateWithFlags(&c->ev_fetch2, hipEventDisableTiming));
     const char* env = getenv("KK_BLOCKS_PER_CU");
     if (env && atoi(env) > 0) c->blocks_per_cu = atoi(env);
     env = getenv("KK_MGS_MODE");
@@ -78,20 +95,21 @@ KK_API int kk_ctx_create(int device, kk_ctx* out) {
 KK_API int kk_ctx_destroy(kk_ctx c) {
     if (!c) return KK_OK;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->comm) (void)kk_comm_destroy(c);
     for (auto& p : c->prof_pending) { c->event_pool.push_back(p.second.first); c->event_pool.push_back(p.second.second); }
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
-    (void)hipEventDestroy(c->t0);
-    (void)hipEventDestroy(c->t1);
-    (void)hipEventDestroy(c->ev_fetch);
-    (void)hipEventDestroy(c->ev_fetch2);
+    if (c->t0) (void)hipEventDestroy(c->t0);
+    if (c->t1) (void)hipEventDestroy(c->t1);
+    if (c->ev_fetch) (void)hipEventDestroy(c->ev_fetch);
+    if (c->ev_fetch2) (void)hipEventDestroy(c->ev_fetch2);
     (void)hipFree(c->ws_own);
     (void)hipFree(c->partials);
-    (void)hipHostFree(c->h_pin);
-    (void)hipHostFree(c->h_U);
+    if (c->h_pin) (void)hipHostFree(c->h_pin);
+    if (c->h_U) (void)hipHostFree(c->h_U);
     (void)hipFree(c->blk_own);
-    (void)hipHostFree(c->h_blk);
-    (void)hipStreamDestroy(c->own_stream);
+    if (c->h_blk) (void)hipHostFree(c->h_blk);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return KK_OK;
 }

@@ -37,6 +37,17 @@ static inline void gram_touch(kk_basis b, int col) {
 int get_matrix(kk_op op, int transpose, const kk_sparse_dev** M);
 int check_apply(kk_op op, int transpose, kk_basis bx, kk_basis by);
 
+// row-sharded rectangular map (kk_csr_create_sharded_rect): y = A x with the all-gather of the short vector,
+// y = A' x with the reduce-scatter of the partial result
+int rect_apply(kk_op op, int transpose, const double* x, double* y);
+
+// ---- communicator internals (kk_comm.hip)
+int kk_comm_allgather_i64(kk_ctx c, const int64_t* d_send, int64_t* d_recv, int64_t count);
+int kk_comm_exchange_i64(kk_ctx c, const int64_t* d_send, const int64_t* send_counts, int64_t* d_recv,
+                         const int64_t* recv_counts);
+int kk_comm_allgather_f64(kk_ctx c, const double* d_stage, double* d_full, int64_t shard);
+int kk_comm_reducescatter_f64(kk_ctx c, const double* d_full, double* d_stage, int64_t shard);
+
 // ---- orthogonalisation (kk_orth.hip)
 int orth_run(kk_basis b, int c0, int m, double* w, kk_orth_t alg, double eta, double* x, double* nrm, int* npasses,
              bool want_norm);
@@ -46,6 +57,7 @@ int orth_vec_run(kk_ctx c, const double* q, double* w, int64_t ld, kk_orth_t alg
 int pass_mgs_strict(kk_ctx c, const double* V, int64_t ld, int m, double* w, int64_t ws_s, bool want_norm, int slot,
                     const double* carry_q, const double* carry_s, bool leave_carry);
 int gram_ensure(kk_basis b, int upto /* exclusive */);
+int gram_device(kk_basis b);   // device mirror of the host Gram rows (created on first use)
 int lowsync_project_dev(kk_basis b, int m, const double* w, const double* pre_vec, const double* pre_a,
                         const double* a0_dev, int64_t ws_coef, int64_t ws_s, bool* rode);
 void lowsync_commit_row(kk_basis b, int m, const double* g_host);

@@ -46,8 +46,9 @@
 #define WS_Y (WS_X + KK_MAX_M)      // first-pass MGS coefficients (device solve)  [KK_MAX_M]
 #define WS_Z (WS_Y + KK_MAX_M)      // second-pass coefficients                  [KK_MAX_M]
 #define WS_SCAL (WS_Z + KK_MAX_M)   // named scalars                         [64]
-#define WS_USER (WS_SCAL + 64)      // split-phase API area                  [KK_WS_USER]
+#define WS_USER (WS_SCAL + 64)      // row-sharded fused steps: [alpha0 | V'w (m) | V'v (m)] of ONE all-reduce   [KK_WS_USER]
 #define KK_WS_USER 4096
+#define WS_SHBUF WS_USER
 #define WS_TOTAL (WS_USER + KK_WS_USER)
 // a finalize with_sqrt writes three consecutive slots: sum, sqrt(sum), 1/sqrt(sum)
 enum { SC_ALPHA0 = 0, SC_NRM2 = 1, SC_NRM = 2, SC_INVNRM = 3, SC_DOT = 4, SC_TMP0 = 5, SC_TMP1 = 6, SC_TMP2 = 7,
@@ -81,8 +82,18 @@ struct kk_prof_entry {
     int64_t launches = 0;
 };
 
+// RCCL communicator of a row-sharded run (kk_comm.hip); the library dlopens librccl at kk_comm_init
+struct kk_comm_s {
+    void* nccl = nullptr;   // ncclComm_t
+    int rank = 0, world = 1;
+    bool active = false;    // collectives are issued: world > 1, or forced at world 1 (plumbing tests on a 1-GPU box)
+    int64_t n_allreduce = 0, n_p2p = 0, n_gather = 0;   // statistics (kk_comm_stats)
+};
+
 struct kk_ctx_s {
     int device = 0;
+    kk_comm_s* comm = nullptr;   // set by kk_comm_init: every reduction of the library is summed over the ranks
+    bool ar_suspend = false;     // fused sharded steps collect several local partials and all-reduce them at once
     int num_cus = 256;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
@@ -164,8 +175,27 @@ struct kk_sparse_dev {  // one direction (A or A') on the device
     double* ghost = nullptr;
     kk_halo_fn halo = nullptr;   // called with the x vector before every apply (fills `ghost`)
     void* halo_user = nullptr;
+    struct kk_halo_plan* plan = nullptr;   // native ghost exchange (kk_csr_create_sharded): grouped ncclSend / ncclRecv
     int64_t bytes = 0;
 };
+// ghost exchange plan of a row-sharded operator: before every apply the entries x[send_idx] go to their peers and the
+// peers' entries land in the ghost buffer (both library-owned), all on the context stream
+struct kk_halo_plan {
+    std::vector<int64_t> send_counts, recv_counts;   // per peer rank
+    int64_t total_send = 0, total_recv = 0;
+    int64_t* d_send_idx = nullptr;
+    double* d_sendbuf = nullptr;
+    double* d_ghost = nullptr;
+};
+// all-gather / reduce-scatter plan of a row-sharded rectangular map (GKL, config 4): the short vectors (length ncols
+// of A) are sharded evenly with stride `shard`; A x gathers them into `vfull`, A' u reduce-scatters `zfull`
+struct kk_gather_plan {
+    int64_t ncols_global = 0, shard = 0, n_local = 0;
+    double* vfull = nullptr;   // world * shard
+    double* zfull = nullptr;   // world * shard
+    double* stage = nullptr;   // shard
+};
+int kk_halo_exchange(kk_ctx ctx, const kk_sparse_dev& M, const double* x);
 
 struct kk_host_csr {
     int64_t nrows = 0, ncols = 0;
@@ -182,6 +212,7 @@ struct kk_op_s {
     kk_host_csr hA;  // kept until A' has been built (or never needed)
     bool have_At = false;
     int64_t n_local_cols = -1, n_ghost = 0;
+    kk_gather_plan* gather = nullptr;   // row-sharded rectangular map
 };
 
 // ---- launch helpers (kk_context.hip)
@@ -264,9 +295,21 @@ int kk_launch_block_update(kk_ctx ctx, const double* V, int64_t ld, int m, const
 int kk_launch_spmm(kk_ctx ctx, const kk_sparse_dev& M, const double* X, int64_t ldx, double* Y, int64_t ldy, int nb);
 int kk_launch_unproj_proj(kk_ctx ctx, const double* V, int64_t ld, int m, const double* w_in, double* w_out,
                           const kk_coef* coef_host, const double* coef_dev, double* out_s, double* nrm_out3);
-// row-sharded hook: no-op unless kk_ctx_set_allreduce installed one
+// row-sharded operation: sum `count` doubles at dev_ptr over the ranks, in place, on the context stream -- through the
+// library's own RCCL communicator (kk_comm_init) or the caller's hook (kk_ctx_set_allreduce); no-op otherwise
+int kk_comm_allreduce_sum(kk_ctx ctx, double* dev_ptr, int64_t count);
+static inline bool kk_sharded(kk_ctx ctx) {
+    return !ctx->ar_suspend && ((ctx->comm && ctx->comm->active) || ctx->allreduce);
+}
+struct kk_ar_suspend {   // RAII: local partials only inside the scope
+    kk_ctx c; bool prev;
+    explicit kk_ar_suspend(kk_ctx ctx) : c(ctx), prev(ctx->ar_suspend) { c->ar_suspend = true; }
+    ~kk_ar_suspend() { c->ar_suspend = prev; }
+};
 static inline int kk_allreduce(kk_ctx ctx, double* dev_ptr, int64_t count) {
-    if (!ctx->allreduce || count <= 0) return KK_OK;
+    if (count <= 0 || ctx->ar_suspend) return KK_OK;
+    if (ctx->comm && ctx->comm->active) return kk_comm_allreduce_sum(ctx, dev_ptr, count);
+    if (!ctx->allreduce) return KK_OK;
     int st = ctx->allreduce(ctx->allreduce_user, dev_ptr, count);
     if (st != 0) {
         kk_set_error("all-reduce hook failed with status %d", st);

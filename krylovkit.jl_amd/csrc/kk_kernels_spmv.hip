@@ -338,6 +338,7 @@ __global__ __launch_bounds__(KK_TPB) void k_spmm_ell(const int32_t* __restrict__
 int kk_launch_spmv(kk_ctx ctx, const kk_sparse_dev& M, const double* x, double* y, int64_t ld_y_rows,
                    const kk_spmv_fuse& f) {
     (void)ld_y_rows;
+    if (M.plan) KK_TRY(kk_halo_exchange(ctx, M, x));   // row-sharded operator with a native plan: grouped ncclSend / ncclRecv
     if (M.halo) {  // row-sharded operator: let the caller fill the ghost buffer from x (P2P on this stream)
         const int st = M.halo(M.halo_user, x);
         if (st != 0) { kk_set_error("halo hook failed with status %d", st); return KK_ERR_INVALID; }
@@ -407,7 +408,7 @@ int kk_launch_spmv(kk_ctx ctx, const kk_sparse_dev& M, const double* x, double* 
 
 // Y[:, j] = A X[:, j], j < nb (any nb: processed 16 / 8 / 4 columns at a time)
 int kk_launch_spmm(kk_ctx ctx, const kk_sparse_dev& M, const double* X, int64_t ldx, double* Y, int64_t ldy, int nb) {
-    if (M.format != 0 || M.n_ghost > 0 || M.halo) {  // CSR / ghosted operators: one SpMV per column
+    if (M.format != 0 || M.n_ghost > 0 || M.halo || M.plan) {  // CSR / ghosted operators: one SpMV per column
         for (int j = 0; j < nb; ++j) {
             kk_spmv_fuse f;
             KK_TRY(kk_launch_spmv(ctx, M, X + (int64_t)j * ldx, Y + (int64_t)j * ldy, ldy, f));

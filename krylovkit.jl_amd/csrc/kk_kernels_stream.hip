@@ -558,7 +558,7 @@ int finalize_rows(kk_ctx ctx, const double* part, int nblk, int m, double* ws_a,
 }
 
 int finalize_scalar(kk_ctx ctx, int part_row_idx, int n, double* out, bool with_sqrt) {
-    const bool sharded = ctx->allreduce != nullptr;
+    const bool sharded = kk_sharded(ctx);
     hipLaunchKernelGGL(k_finalize_scalar, dim3(1), dim3(KK_TPB), 0, ctx->stream, part_row(ctx, part_row_idx), n,
                        out, (with_sqrt && !sharded) ? 1 : 0);
     KK_HIP(hipGetLastError());

@@ -105,12 +105,12 @@ static int speculate_next(kk_op op, kk_basis b, int c0, int k_next, int dot_mode
 }
 // true if the previous expand on this basis already enqueued exactly this step's SpMV; moves the
 // speculative alpha into the regular slot
-static int spec_take(kk_op op, kk_basis b, int c0, int k, int dot_mode, double beta_old, bool* hit) {
+static int spec_take(kk_op op, kk_basis b, int c0, int k, int dot_mode, double beta_old, double* a0_slot, bool* hit) {
     kk_ctx c = b->ctx;
     *hit = b->spec_valid && c->spec_owner == b && b->spec_op == op && b->spec_c0 == c0 && b->spec_k == k &&
            b->spec_dot_mode == dot_mode && b->spec_beta == beta_old;
     if (*hit && dot_mode)
-        KK_HIP(hipMemcpyAsync(SCP(c, SC_ALPHA0), SCP(c, SC_SPECA), sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        KK_HIP(hipMemcpyAsync(a0_slot, SCP(c, SC_SPECA), sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     return KK_OK;
 }
 // the last synchronisation of an expand: a pending speculation request (Arnoldi) is enqueued first
@@ -149,8 +149,14 @@ KK_API int kk_lanczos_expand(kk_op op, kk_basis b, int c0, int k, kk_orth_t orth
     const double* vprev = b->col(c0 + k - 1);
     double* w = b->col(c0 + k + 1);
     const bool cgs_order = (orth == KK_CGS || orth == KK_CGS2 || orth == KK_CGSIR);
+    const bool lowsync = c->mgs_mode == 1;
+    // Row-sharded run, projection-based orthogonaliser: the alpha0 partial of the SpMV and the two projection panels
+    // stay LOCAL, land side by side in ws[WS_SHBUF ..] = [alpha0 | V'w | V'v] and are summed by ONE all-reduce; the
+    // second (and last) one is |w|^2.  SURVEY.md 8(e).
+    const bool sh_fused = kk_sharded(c) && (orth == KK_CGS2 || (orth == KK_MGS2 && lowsync && c0 == 0));
+    double* a0_slot = sh_fused ? WSP(c, WS_SHBUF) : SCP(c, SC_ALPHA0);
     bool hit = false;
-    KK_TRY(spec_take(op, b, c0, k, cgs_order ? 1 : 2, beta_old, &hit));
+    KK_TRY(spec_take(op, b, c0, k, cgs_order ? 1 : 2, beta_old, a0_slot, &hit));
     gram_touch(b, c0 + k);
     int passes = 0;
     // V = push!(V, scale!!(r, 1/beta_old))   lanczos.jl:257
@@ -160,12 +166,15 @@ KK_API int kk_lanczos_expand(kk_op op, kk_basis b, int c0, int k, kk_orth_t orth
         kk_spmv_fuse f;
         f.vprev = vprev; f.bprev = beta_old;
         f.dot_mode = cgs_order ? 1 : 2;
-        f.dot_out = SCP(c, SC_ALPHA0);
-        KK_TRY(kk_launch_spmv(c, op->A, v, w, ld, f));
+        f.dot_out = a0_slot;
+        const bool prev_suspend = c->ar_suspend;
+        if (sh_fused) c->ar_suspend = true;
+        const int st = kk_launch_spmv(c, op->A, v, w, ld, f);
+        c->ar_suspend = prev_suspend;
+        KK_TRY(st);
     }  // else: the previous expand already enqueued exactly this SpMV (speculate_next)
     const double* a0_dev = c->ws + WS_SCAL + SC_ALPHA0;
     double a = 0, bt = 0;
-    const bool lowsync = c->mgs_mode == 1;
     if (orth == KK_CGS || orth == KK_MGS || orth == KK_CGSIR || orth == KK_MGSIR) {
         // w -= alpha v ; beta = |w|
         KK_TRY(kk_launch_mgs_step(c, w, ld, v, a0_dev, nullptr, nullptr, SCP(c, SC_NRM2)));
@@ -187,6 +196,35 @@ KK_API int kk_lanczos_expand(kk_op op, kk_basis b, int c0, int k, kk_orth_t orth
                 ++passes;
             }
         }
+    } else if (sh_fused) {
+        double* buf = WSP(c, WS_SHBUF);
+        const bool ls = (orth == KK_MGS2);
+        if (ls) {  // low-sync MGS: the strictly-lower Gram rows of the basis, V'v being the newest one (rides along)
+            if (b->gram_rows < m - 1) KK_TRY(gram_ensure(b, m - 1));  // only after the basis was transformed (restart)
+            if (b->gram_rows < 1) b->gram_rows = 1;
+            KK_TRY(gram_device(b));
+        }
+        {
+            kk_ar_suspend local_only(c);
+            KK_TRY(kk_launch_project(c, V, ld, m, w, nullptr, nullptr, v, buf + 1, buf + 1 + m));
+        }
+        KK_TRY(kk_allreduce(c, buf, 1 + 2 * m));                      // all-reduce 1 of 2: alpha0, V'w, V'v
+        // rhs = V'w - alpha0 V'v = V'(w - alpha0 v) [exact low-sync triangular solve], alpha0 folded into the last coefficient
+        KK_TRY(kk_launch_lanczos_coef(c, buf, ls ? b->d_gram : nullptr, b->cap, m, ls ? 1 : 0, WSP(c, WS_X), SCP(c, SC_TMP0)));
+        KK_TRY(kk_launch_unproject(c, V, ld, m, w, w, nullptr, WSP(c, WS_X), -1.0, 1.0, -1, nullptr,
+                                   SCP(c, SC_NRM2)));                  // all-reduce 2 of 2 inside: |w|^2
+        KK_TRY(ws_fetch_async(c, WS_SCAL, 8, 0));
+        if (ls) KK_TRY(ws_fetch_async(c, WS_SHBUF + 1 + m, m, 0));
+        KK_TRY(fetch_mark(c));
+        {
+            kk_ar_suspend local_only(c);   // the speculative alpha0 partial joins the next step's all-reduce
+            KK_TRY(speculate_next(op, b, c0, k + 1, cgs_order ? 1 : 2, true, 0.0));
+        }
+        KK_TRY(fetch_wait(c));
+        a = pin(c, WS_SCAL + SC_TMP0)[0] + pin(c, WS_SCAL + SC_TMP1)[0];
+        bt = pin(c, WS_SCAL + SC_NRM)[0];
+        if (ls) lowsync_commit_row(b, m, pin(c, WS_SHBUF + 1 + m, 0));
+        passes = 1;
     } else if (orth == KK_CGS2 || (orth == KK_MGS2 && lowsync && c0 == 0)) {
         // one projection pass with "w -= alpha0 v" folded in (read V twice in total):
         //   s = V'(w - alpha0 v) ; w <- w - V (s + alpha0 e_m) ; beta = |w|     lanczos.jl:318-322 / 329-336
@@ -248,7 +286,7 @@ KK_API int kk_arnoldi_expand(kk_op op, kk_basis b, int c0, int k, kk_orth_t orth
     double* v = b->col(c0 + k);
     double* w = b->col(c0 + k + 1);
     bool hit = false;
-    KK_TRY(spec_take(op, b, c0, k, 0, beta_old, &hit));
+    KK_TRY(spec_take(op, b, c0, k, 0, beta_old, SCP(c, SC_ALPHA0), &hit));
     gram_touch(b, c0 + k);
     KK_TRY(kk_launch_scal(c, v, b->ld, 1.0 / beta_old, nullptr));  // push!(V, scale(r, 1/beta))   arnoldi.jl:209
     if (!hit) {
@@ -268,11 +306,44 @@ KK_API int kk_arnoldi_expand(kk_op op, kk_basis b, int c0, int k, kk_orth_t orth
 static int check_gkl(kk_op op, kk_basis bu, kk_basis bv) {
     KK_CHECK(op && bu && bv, KK_ERR_INVALID, "null arg");
     KK_CHECK(op->ctx == bu->ctx && op->ctx == bv->ctx, KK_ERR_INVALID, "objects belong to different contexts");
-    KK_CHECK(op->nrows == bu->n && op->ncols == bv->n, KK_ERR_DIM,
+    const int64_t ncols = op->gather ? op->gather->n_local : op->ncols;   // row-sharded map: this rank's shard of the short vectors
+    KK_CHECK(op->nrows == bu->n && ncols == bv->n, KK_ERR_DIM,
              "GKL: operator is %lldx%lld, U vectors have %lld rows, V vectors %lld", (long long)op->nrows,
-             (long long)op->ncols, (long long)bu->n, (long long)bv->n);
-    KK_CHECK(op->A.n_ghost == 0, KK_ERR_UNSUPPORTED, "GKL on ghosted (row-sharded) operators goes through the split-phase API");
+             (long long)ncols, (long long)bu->n, (long long)bv->n);
+    KK_CHECK(op->gather || op->A.n_ghost == 0, KK_ERR_UNSUPPORTED,
+             "GKL on a row-sharded map needs an operator made by kk_csr_create_sharded_rect");
     return KK_OK;
+}
+// v = A'u - beta_old vlast with |v|^2 -> SC_NRM2 triple ; r = A v - alpha u (alpha = *alpha_dev) with |r|^2 -> SC_NRM2B triple.
+// Single GPU: fused into the SpMV epilogue.  Row-sharded map: the reduce-scatter / all-gather sits between the sparse
+// product and the vector update, so the update is a one-column unproject with the fused norm (all-reduced in its finalize).
+static int gkl_apply_adjoint(kk_op op, const kk_sparse_dev* At, kk_basis bv, const double* u, double* v, const double* vlast,
+                             double beta_old) {
+    kk_ctx c = op->ctx;
+    if (!op->gather) {
+        kk_spmv_fuse f1;
+        if (vlast) { f1.vprev = vlast; f1.bprev = beta_old; }
+        f1.nrm_out = SCP(c, SC_NRM2);
+        return kk_launch_spmv(c, *At, u, v, bv->ld, f1);
+    }
+    KK_TRY(rect_apply(op, 1, u, v));
+    if (!vlast) return kk_launch_nrm2(c, v, bv->ld, SCP(c, SC_NRM2));
+    kk_coef one;
+    memset(&one, 0, sizeof(one));
+    one.v[0] = beta_old;
+    return kk_launch_unproject(c, vlast, bv->ld, 1, v, v, &one, nullptr, -1.0, 1.0, -1, nullptr, SCP(c, SC_NRM2));
+}
+static int gkl_apply_normal(kk_op op, kk_basis bu, const double* v, double* r, const double* u, const double* alpha_dev) {
+    kk_ctx c = op->ctx;
+    if (!op->gather) {
+        kk_spmv_fuse f2;
+        if (u) { f2.vprev = u; f2.bprev_dev = alpha_dev; }
+        f2.nrm_out = SCP(c, SC_NRM2B);
+        return kk_launch_spmv(c, op->A, v, r, bu->ld, f2);
+    }
+    KK_TRY(rect_apply(op, 0, v, r));
+    if (!u) return KK_OK;
+    return kk_launch_unproject(c, u, bu->ld, 1, r, r, nullptr, alpha_dev, -1.0, 1.0, -1, nullptr, SCP(c, SC_NRM2B));
 }
 
 KK_API int kk_gkl_initialize(kk_op op, kk_basis bu, kk_basis bv, double* alpha, double* beta) {
@@ -288,11 +359,12 @@ KK_API int kk_gkl_initialize(kk_op op, kk_basis bu, kk_basis bv, double* alpha, 
     gram_touch(bu, 0); gram_touch(bv, 0);
     // beta0 = |u0| ; v0 = A' u0 (with |v0|^2) ; Av0 = A v0 (with <u0, A v0> computed separately)
     KK_TRY(kk_launch_nrm2(c, u0, bu->ld, SCP(c, SC_NRM2B)));
-    kk_spmv_fuse f1;
-    f1.nrm_out = SCP(c, SC_NRM2);
-    KK_TRY(kk_launch_spmv(c, *At, u0, v0, bv->ld, f1));
-    kk_spmv_fuse f2;
-    KK_TRY(kk_launch_spmv(c, op->A, v0, r, bu->ld, f2));
+    KK_TRY(gkl_apply_adjoint(op, At, bv, u0, v0, nullptr, 0.0));
+    if (op->gather) KK_TRY(rect_apply(op, 0, v0, r));
+    else {
+        kk_spmv_fuse f2;
+        KK_TRY(kk_launch_spmv(c, op->A, v0, r, bu->ld, f2));
+    }
     KK_TRY(kk_launch_dot(c, u0, r, bu->ld, SCP(c, SC_DOT)));
     KK_TRY(ws_fetch_async(c, WS_SCAL, 16, 0));
     KK_TRY(stream_sync(c));
@@ -340,11 +412,8 @@ KK_API int kk_gkl_expand(kk_op op, kk_basis bu, kk_basis bv, int k, kk_orth_t or
     // U = push!(U, scale!!(r, 1/beta_old))   gkl.jl:254
     KK_TRY(kk_launch_scal(c, u, bu->ld, 1.0 / beta_old, nullptr));
     // v = A'u - beta_old V[end]  (fused), alpha = |v| fused when no sweep follows
-    kk_spmv_fuse f1;
-    f1.vprev = vlast; f1.bprev = beta_old;
     const bool v_sweep = (orth == KK_MGS2 || orth == KK_CGSIR || orth == KK_MGSIR);
-    f1.nrm_out = SCP(c, SC_NRM2);
-    KK_TRY(kk_launch_spmv(c, *At, u, v, bv->ld, f1));
+    KK_TRY(gkl_apply_adjoint(op, At, bv, u, v, vlast, beta_old));
     if (orth == KK_MGS2) {  // gkl.jl:330-336
         double nn = 0;
         KK_TRY(orth_run(bv, 0, k, v, KK_MGS, eta, tmp.data(), &nn, nullptr, true));
@@ -377,10 +446,7 @@ KK_API int kk_gkl_expand(kk_op op, kk_basis bu, kk_basis bv, int k, kk_orth_t or
     // v = scale!!(v, inv(alpha))
     KK_TRY(kk_launch_scal(c, v, bv->ld, 0.0, inva_dev));
     // r = A v - alpha u (fused), beta = |r| fused when no sweep follows
-    kk_spmv_fuse f2;
-    f2.vprev = u; f2.bprev_dev = alpha_dev;
-    f2.nrm_out = SCP(c, SC_NRM2B);
-    KK_TRY(kk_launch_spmv(c, op->A, v, r, bu->ld, f2));
+    KK_TRY(gkl_apply_normal(op, bu, v, r, u, alpha_dev));
     if (orth == KK_CGS || orth == KK_MGS) {
         KK_TRY(ws_fetch_async(c, WS_SCAL, 16, 0));
         KK_TRY(stream_sync(c));

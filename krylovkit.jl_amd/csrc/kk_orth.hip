@@ -79,7 +79,7 @@ KK_API int kk_householder_rmul(kk_basis b, int c0, int m, const double* v, doubl
 // ---- Gram rows for the low-synchronisation MGS -------------------------------------------
 // gram(i, j) = <b_i, b_j>, j < i, stored at b->gram[i*cap + j]; rows [0, gram_rows) valid.
 // device mirror of the host Gram rows (used by the on-device low-sync solve)
-static int gram_device(kk_basis b) {
+int gram_device(kk_basis b) {
     if (b->gram.empty()) b->gram.assign((size_t)b->cap * b->cap, 0.0);
     if (!b->d_gram) {
         KK_HIP(hipMalloc(&b->d_gram, (size_t)b->cap * b->cap * sizeof(double)));

@@ -190,6 +190,16 @@ static int upload_sparse(kk_ctx c, const kk_host_csr& h, kk_sparse_dev& M) {
     return KK_OK;
 }
 
+// pointer array of a compressed format: starts at index_base, monotone, ends at nnz (a malformed array would send the
+// packing loops out of bounds on the host)
+static int check_ptr_array(const char* who, const int64_t* ptr, int64_t n, int64_t nnz, int index_base) {
+    KK_CHECK(ptr[0] - index_base == 0, KK_ERR_DIM, "%s: pointer array does not start at %d", who, index_base);
+    for (int64_t i = 0; i < n; ++i)
+        KK_CHECK(ptr[i] <= ptr[i + 1], KK_ERR_DIM, "%s: pointer array decreases at position %lld", who, (long long)i);
+    KK_CHECK(ptr[n] - index_base == nnz, KK_ERR_DIM, "%s: last pointer entry != nnz", who);
+    return KK_OK;
+}
+
 static void transpose_csr(const kk_host_csr& a, kk_host_csr& t) {
     t.nrows = a.ncols; t.ncols = a.nrows;
     const int64_t nnz = a.rowptr[a.nrows];
@@ -211,7 +221,9 @@ KK_API int kk_csr_create(kk_ctx c, int64_t nrows, int64_t ncols, int64_t nnz, co
     KK_CHECK(c && out && rowptr && (nnz == 0 || (colind && val)), KK_ERR_INVALID, "kk_csr_create: null arg");
     KK_CHECK(nrows > 0 && ncols > 0 && nnz >= 0, KK_ERR_INVALID, "kk_csr_create: bad dimensions");
     KK_CHECK(index_base == 0 || index_base == 1, KK_ERR_INVALID, "index_base must be 0 or 1");
-    KK_CHECK(rowptr[nrows] - index_base == nnz, KK_ERR_DIM, "kk_csr_create: rowptr[nrows] != nnz");
+    KK_TRY(check_ptr_array("kk_csr_create", rowptr, nrows, nnz, index_base));
+    KK_CHECK(nnz < (int64_t)1 << 31 && nrows < (int64_t)1 << 31 && ncols < (int64_t)1 << 31, KK_ERR_UNSUPPORTED,
+             "kk_csr_create: nnz / dimensions >= 2^31 are not supported (int32 indices on the device)");
     KK_HIP(hipSetDevice(c->device));
     kk_op op = new kk_op_s();
     op->ctx = c; op->nrows = nrows; op->ncols = ncols; op->nnz = nnz; op->flags = flags;
@@ -241,7 +253,9 @@ KK_API int kk_csc_create(kk_ctx c, int64_t nrows, int64_t ncols, int64_t nnz, co
     KK_CHECK(c && out && colptr && (nnz == 0 || (rowval && nzval)), KK_ERR_INVALID, "kk_csc_create: null arg");
     KK_CHECK(nrows > 0 && ncols > 0 && nnz >= 0, KK_ERR_INVALID, "kk_csc_create: bad dimensions");
     KK_CHECK(index_base == 0 || index_base == 1, KK_ERR_INVALID, "index_base must be 0 or 1");
-    KK_CHECK(colptr[ncols] - index_base == nnz, KK_ERR_DIM, "kk_csc_create: colptr[ncols] != nnz");
+    KK_TRY(check_ptr_array("kk_csc_create", colptr, ncols, nnz, index_base));
+    KK_CHECK(nnz < (int64_t)1 << 31 && nrows < (int64_t)1 << 31 && ncols < (int64_t)1 << 31, KK_ERR_UNSUPPORTED,
+             "kk_csc_create: nnz / dimensions >= 2^31 are not supported (int32 indices on the device)");
     KK_HIP(hipSetDevice(c->device));
     // the CSC arrays of A are the CSR arrays of A'
     kk_host_csr ht;
@@ -279,9 +293,210 @@ KK_API int kk_csc_create(kk_ctx c, int64_t nrows, int64_t ncols, int64_t nnz, co
 KK_API int kk_op_free(kk_op op) {
     if (!op) return KK_OK;
     (void)hipDeviceSynchronize();  // see kk_basis_free
+    if (kk_halo_plan* p = op->A.plan) {
+        (void)hipFree(p->d_send_idx); (void)hipFree(p->d_sendbuf); (void)hipFree(p->d_ghost);
+        delete p;
+        op->A.plan = nullptr;
+    }
+    if (kk_gather_plan* g = op->gather) {
+        (void)hipFree(g->vfull); (void)hipFree(g->zfull); (void)hipFree(g->stage);
+        delete g;
+    }
     free_sparse(op->A);
     free_sparse(op->At);
     delete op;
+    return KK_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// row-sharded operators with a native (RCCL) exchange plan
+// ------------------------------------------------------------------------------------------
+static void comm_shape(kk_ctx c, int* rank, int* world) {
+    *rank = c->comm ? c->comm->rank : 0;
+    *world = c->comm ? c->comm->world : 1;
+}
+
+// Row block [row_offsets[rank], row_offsets[rank+1]) of a square global operator with GLOBAL column indices.  Columns
+// owned by other ranks become ghost columns; the request lists are exchanged here (all-gather of the counts, grouped
+// send / recv of the indices) so that the caller needs no communication code of its own.
+KK_API int kk_csr_create_sharded(kk_ctx c, int64_t nrows_local, const int64_t* row_offsets, int64_t nnz,
+                                 const int64_t* rowptr, const int64_t* colind, const double* val, int index_base,
+                                 int flags, kk_op* out) {
+    KK_CHECK(c && out && row_offsets && rowptr && (nnz == 0 || (colind && val)), KK_ERR_INVALID, "kk_csr_create_sharded: null arg");
+    KK_CHECK(index_base == 0 || index_base == 1, KK_ERR_INVALID, "index_base must be 0 or 1");
+    int rank, world;
+    comm_shape(c, &rank, &world);
+    for (int q = 0; q < world; ++q)
+        KK_CHECK(row_offsets[q] <= row_offsets[q + 1], KK_ERR_DIM, "kk_csr_create_sharded: row_offsets must be non-decreasing");
+    const int64_t lo = row_offsets[rank], hi = row_offsets[rank + 1], n_global = row_offsets[world];
+    KK_CHECK(row_offsets[0] == 0 && hi - lo == nrows_local && nrows_local > 0, KK_ERR_DIM,
+             "kk_csr_create_sharded: rank %d owns rows [%lld,%lld) but nrows_local = %lld", rank, (long long)lo, (long long)hi,
+             (long long)nrows_local);
+    KK_TRY(check_ptr_array("kk_csr_create_sharded", rowptr, nrows_local, nnz, index_base));
+    KK_HIP(hipSetDevice(c->device));
+    // ghost columns: sorted unique global ids outside [lo, hi) -> grouped by owner
+    std::vector<int64_t> needed;
+    for (int64_t p = 0; p < nnz; ++p) {
+        const int64_t g = colind[p] - index_base;
+        KK_CHECK(g >= 0 && g < n_global, KK_ERR_DIM, "kk_csr_create_sharded: column index %lld out of range at entry %lld",
+                 (long long)g, (long long)p);
+        if (g < lo || g >= hi) needed.push_back(g);
+    }
+    std::sort(needed.begin(), needed.end());
+    needed.erase(std::unique(needed.begin(), needed.end()), needed.end());
+    const int64_t n_ghost = (int64_t)needed.size();
+    KK_CHECK(nrows_local + n_ghost < (int64_t)1 << 31 && nnz < (int64_t)1 << 31, KK_ERR_UNSUPPORTED,
+             "kk_csr_create_sharded: local block too large for int32 indices");
+    std::vector<int64_t> recv_counts(world, 0), send_counts(world, 0);
+    for (int64_t g : needed) {
+        const int q = (int)(std::upper_bound(row_offsets, row_offsets + world + 1, g) - row_offsets) - 1;
+        recv_counts[q]++;
+    }
+    kk_op op = new kk_op_s();
+    op->ctx = c; op->nrows = nrows_local; op->ncols = nrows_local + n_ghost; op->nnz = nnz; op->flags = flags;
+    kk_host_csr h;
+    h.nrows = nrows_local; h.ncols = nrows_local + n_ghost;
+    h.rowptr.resize(nrows_local + 1);
+    for (int64_t i = 0; i <= nrows_local; ++i) h.rowptr[i] = rowptr[i] - index_base;
+    h.col.resize(nnz); h.val.assign(val, val + nnz);
+    for (int64_t p = 0; p < nnz; ++p) {
+        const int64_t g = colind[p] - index_base;
+        h.col[p] = (g >= lo && g < hi) ? (int32_t)(g - lo)
+                                       : (int32_t)(nrows_local + (std::lower_bound(needed.begin(), needed.end(), g) - needed.begin()));
+    }
+    int s = upload_sparse(c, h, op->A);
+    if (s != KK_OK) { free_sparse(op->A); delete op; return s; }
+    kk_halo_plan* plan = new kk_halo_plan();
+    op->A.plan = plan;
+    auto fail = [&](int st) { kk_op_free(op); return st; };
+    int64_t *d_a = nullptr, *d_b = nullptr;
+    if (world > 1) {
+        // counts[r * world + q] = number of entries rank r needs from rank q
+        hipError_t e1 = hipMalloc(&d_a, world * sizeof(int64_t)), e2 = hipMalloc(&d_b, (size_t)world * world * sizeof(int64_t));
+        if (e1 != hipSuccess || e2 != hipSuccess) { (void)hipFree(d_a); (void)hipFree(d_b); return fail(kk_hip_fail(e1 != hipSuccess ? e1 : e2, "hipMalloc", __FILE__, __LINE__)); }
+        std::vector<int64_t> all((size_t)world * world);
+        (void)hipMemcpyAsync(d_a, recv_counts.data(), world * sizeof(int64_t), hipMemcpyHostToDevice, c->stream);
+        s = kk_comm_allgather_i64(c, d_a, d_b, world);
+        if (s == KK_OK && hipMemcpyAsync(all.data(), d_b, all.size() * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream) != hipSuccess) s = KK_ERR_HIP;
+        if (s == KK_OK && hipStreamSynchronize(c->stream) != hipSuccess) s = KK_ERR_HIP;
+        (void)hipFree(d_a); (void)hipFree(d_b);
+        if (s != KK_OK) return fail(s);
+        for (int q = 0; q < world; ++q) send_counts[q] = all[(size_t)q * world + rank];
+        send_counts[rank] = 0;
+    }
+    plan->send_counts = send_counts; plan->recv_counts = recv_counts;
+    for (int q = 0; q < world; ++q) { plan->total_send += send_counts[q]; plan->total_recv += recv_counts[q]; }
+    {
+        hipError_t e = hipMalloc(&plan->d_ghost, std::max<int64_t>(n_ghost, 1) * sizeof(double));
+        if (e == hipSuccess) e = hipMemsetAsync(plan->d_ghost, 0, std::max<int64_t>(n_ghost, 1) * sizeof(double), c->stream);
+        if (e == hipSuccess) e = hipMalloc(&plan->d_sendbuf, std::max<int64_t>(plan->total_send, 1) * sizeof(double));
+        if (e == hipSuccess) e = hipMalloc(&plan->d_send_idx, std::max<int64_t>(plan->total_send, 1) * sizeof(int64_t));
+        if (e != hipSuccess) return fail(kk_hip_fail(e, "hipMalloc (ghost plan)", __FILE__, __LINE__));
+    }
+    if (world > 1) {
+        // my request list (global ids grouped by owner) goes out, the peers' request lists come in -> local send indices
+        int64_t* d_req = nullptr;
+        hipError_t e = hipMalloc(&d_req, std::max<int64_t>(n_ghost, 1) * sizeof(int64_t));
+        if (e != hipSuccess) return fail(kk_hip_fail(e, "hipMalloc", __FILE__, __LINE__));
+        (void)hipMemcpyAsync(d_req, needed.data(), n_ghost * sizeof(int64_t), hipMemcpyHostToDevice, c->stream);
+        s = kk_comm_exchange_i64(c, d_req, recv_counts.data(), plan->d_send_idx, send_counts.data());
+        std::vector<int64_t> idx((size_t)plan->total_send);
+        if (s == KK_OK && plan->total_send &&
+            hipMemcpyAsync(idx.data(), plan->d_send_idx, idx.size() * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream) != hipSuccess) s = KK_ERR_HIP;
+        if (s == KK_OK && hipStreamSynchronize(c->stream) != hipSuccess) s = KK_ERR_HIP;
+        (void)hipFree(d_req);
+        if (s != KK_OK) return fail(s);
+        for (int64_t& g : idx) {
+            if (g < lo || g >= hi) { kk_set_error("kk_csr_create_sharded: a peer requested row %lld which rank %d does not own", (long long)g, rank); return fail(KK_ERR_DIM); }
+            g -= lo;
+        }
+        if (plan->total_send) (void)hipMemcpyAsync(plan->d_send_idx, idx.data(), idx.size() * sizeof(int64_t), hipMemcpyHostToDevice, c->stream);
+        if (hipStreamSynchronize(c->stream) != hipSuccess) return fail(KK_ERR_HIP);
+    }
+    op->A.n_local = nrows_local;
+    op->A.n_ghost = n_ghost;
+    op->A.ghost = plan->d_ghost;
+    op->n_local_cols = nrows_local; op->n_ghost = n_ghost;
+    *out = op;
+    return KK_OK;
+}
+
+// Row block of a rectangular map A (nrows_global x ncols_global) for the sharded GKL.  The
+// long vectors (rows of A) are sharded by this rank's rows, the short ones (columns of A) evenly with stride
+// shard = ceil(ncols_global / world): rank r owns columns [r*shard, min((r+1)*shard, ncols_global)).
+//   A x : all-gather of the short vector, local SpMV on the gathered buffer
+//   A'x : local transposed SpMV (full-length partial), reduce-scatter (sum) onto the shards
+KK_API int kk_csr_create_sharded_rect(kk_ctx c, int64_t nrows_local, int64_t ncols_global, int64_t nnz, const int64_t* rowptr,
+                                      const int64_t* colind, const double* val, int index_base, kk_op* out,
+                                      int64_t* ncols_local) {
+    KK_CHECK(c && out && rowptr && (nnz == 0 || (colind && val)), KK_ERR_INVALID, "kk_csr_create_sharded_rect: null arg");
+    KK_CHECK(nrows_local > 0 && ncols_global > 0 && nnz >= 0, KK_ERR_INVALID, "kk_csr_create_sharded_rect: bad dimensions");
+    KK_CHECK(index_base == 0 || index_base == 1, KK_ERR_INVALID, "index_base must be 0 or 1");
+    KK_TRY(check_ptr_array("kk_csr_create_sharded_rect", rowptr, nrows_local, nnz, index_base));
+    int rank, world;
+    comm_shape(c, &rank, &world);
+    const int64_t shard = (ncols_global + world - 1) / world;
+    const int64_t full = shard * world;
+    const int64_t n_loc = std::max<int64_t>(0, std::min(shard, ncols_global - rank * shard));
+    KK_CHECK(n_loc > 0, KK_ERR_DIM, "kk_csr_create_sharded_rect: rank %d owns no columns (%lld columns over %d ranks)", rank,
+             (long long)ncols_global, world);
+    KK_CHECK(full < (int64_t)1 << 31 && nnz < (int64_t)1 << 31 && nrows_local < (int64_t)1 << 31, KK_ERR_UNSUPPORTED,
+             "kk_csr_create_sharded_rect: local block too large for int32 indices");
+    KK_HIP(hipSetDevice(c->device));
+    kk_op op = new kk_op_s();
+    op->ctx = c; op->nrows = nrows_local; op->ncols = full; op->nnz = nnz; op->flags = 0;
+    kk_host_csr& h = op->hA;   // kept: the transposed image is built from it on first use
+    h.nrows = nrows_local; h.ncols = full;
+    h.rowptr.resize(nrows_local + 1);
+    for (int64_t i = 0; i <= nrows_local; ++i) h.rowptr[i] = rowptr[i] - index_base;
+    h.col.resize(nnz); h.val.assign(val, val + nnz);
+    for (int64_t p = 0; p < nnz; ++p) {
+        const int64_t g = colind[p] - index_base;
+        if (g < 0 || g >= ncols_global) {
+            delete op;
+            kk_set_error("kk_csr_create_sharded_rect: column index %lld out of range at entry %lld", (long long)g, (long long)p);
+            return KK_ERR_DIM;
+        }
+        h.col[p] = (int32_t)g;
+    }
+    int s = upload_sparse(c, h, op->A);
+    if (s != KK_OK) { free_sparse(op->A); delete op; return s; }
+    kk_gather_plan* g = new kk_gather_plan();
+    op->gather = g;
+    g->ncols_global = ncols_global; g->shard = shard; g->n_local = n_loc;
+    const int64_t pad = (full + KK_SUB - 1) / KK_SUB * KK_SUB + KK_SUB;   // the SpMV kernels may store whole row tiles
+    hipError_t e = hipMalloc(&g->vfull, pad * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&g->zfull, pad * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&g->stage, (shard + KK_SUB) * sizeof(double));
+    if (e == hipSuccess) e = hipMemsetAsync(g->vfull, 0, pad * sizeof(double), c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(g->zfull, 0, pad * sizeof(double), c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(g->stage, 0, (shard + KK_SUB) * sizeof(double), c->stream);
+    if (e != hipSuccess) { kk_op_free(op); return kk_hip_fail(e, "hipMalloc (gather plan)", __FILE__, __LINE__); }
+    // ghost-only operator: every column is read from the gathered buffer
+    op->A.n_local = 0;
+    op->A.n_ghost = full;
+    op->A.ghost = g->vfull;
+    op->n_local_cols = 0; op->n_ghost = full;
+    if (ncols_local) *ncols_local = n_loc;
+    *out = op;
+    return KK_OK;
+}
+
+// y = A x (x: this rank's shard of a short vector, y: this rank's rows) or y = A' x (x: this rank's rows, y: shard)
+int rect_apply(kk_op op, int transpose, const double* x, double* y) {
+    kk_ctx c = op->ctx;
+    kk_gather_plan* g = op->gather;
+    kk_spmv_fuse f;
+    if (!transpose) {
+        KK_HIP(hipMemcpyAsync(g->stage, x, g->n_local * sizeof(double), hipMemcpyDeviceToDevice, c->stream));  // tail stays zero
+        KK_TRY(kk_comm_allgather_f64(c, g->stage, g->vfull, g->shard));
+        return kk_launch_spmv(c, op->A, x, y, 0, f);
+    }
+    const kk_sparse_dev* At;
+    KK_TRY(get_matrix(op, 1, &At));
+    KK_TRY(kk_launch_spmv(c, *At, x, g->zfull, 0, f));
+    KK_TRY(kk_comm_reducescatter_f64(c, g->zfull, g->stage, g->shard));
+    KK_HIP(hipMemcpyAsync(y, g->stage, g->n_local * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     return KK_OK;
 }
 
@@ -337,6 +552,13 @@ int get_matrix(kk_op op, int transpose, const kk_sparse_dev** M) {
 
 // dimension check of y = op(A) x ; with ghosts the x-vector holds the local columns only
 int check_apply(kk_op op, int transpose, kk_basis bx, kk_basis by) {
+    if (op->gather) {
+        const int64_t inr = transpose ? op->nrows : op->gather->n_local, outr = transpose ? op->gather->n_local : op->nrows;
+        KK_CHECK(bx->n == inr && by->n == outr, KK_ERR_DIM, "apply: sharded map has %lld local rows / %lld local columns%s, x has %lld rows, y has %lld rows",
+                 (long long)op->nrows, (long long)op->gather->n_local, transpose ? " (adjoint)" : "", (long long)bx->n, (long long)by->n);
+        KK_CHECK(bx->ctx == op->ctx && by->ctx == op->ctx, KK_ERR_INVALID, "apply: objects belong to different contexts");
+        return KK_OK;
+    }
     const int64_t in = transpose ? op->nrows : (op->A.n_ghost > 0 ? op->A.n_local : op->ncols);
     const int64_t outn = transpose ? op->ncols : op->nrows;
     // ghost-only operator (n_local == 0): every column comes from the caller's gathered buffer, x is unused
@@ -352,6 +574,10 @@ KK_API int kk_spmv(kk_op op, int transpose, kk_basis bx, int cx, kk_basis by, in
     CHECK_COL(bx, cx); CHECK_COL(by, cy);
     KK_TRY(check_apply(op, transpose, bx, by));
     KK_CHECK(!(bx == by && cx == cy), KK_ERR_INVALID, "kk_spmv: x and y must differ");
+    if (op->gather) {
+        gram_touch(by, cy);
+        return rect_apply(op, transpose, bx->col(cx), by->col(cy));
+    }
     const kk_sparse_dev* M;
     KK_TRY(get_matrix(op, transpose, &M));
     gram_touch(by, cy);
@@ -363,7 +589,7 @@ KK_API int kk_spmv_affine(kk_op op, kk_basis bx, int cx, kk_basis by, int cy, do
     KK_CHECK(op, KK_ERR_INVALID, "null op");
     CHECK_COL(bx, cx); CHECK_COL(by, cy);
     KK_TRY(check_apply(op, 0, bx, by));
-    KK_CHECK(op->nrows == op->ncols || op->A.n_ghost > 0, KK_ERR_DIM, "affine apply needs a square operator");
+    KK_CHECK(!op->gather && (op->nrows == op->ncols || op->A.n_ghost > 0), KK_ERR_DIM, "affine apply needs a square operator");
     KK_CHECK(!(bx == by && cx == cy), KK_ERR_INVALID, "kk_spmv_affine: x and y must differ");
     gram_touch(by, cy);
     kk_spmv_fuse f;

@@ -135,7 +135,19 @@ SIGNATURES = {
     "kk_nrm2_dev": (C.c_int, [c_vp, C.c_int, c_vp]),
     "kk_axpy_dev": (C.c_int, [c_vp, C.c_int, c_vp, C.c_int, c_vp, C.c_double]),
     "kk_scal_rsqrt_dev": (C.c_int, [c_vp, C.c_int, c_vp]),
+    # multi-GPU: RCCL inside the library
+    "kk_comm_get_unique_id": (C.c_int, [c_vp]),
+    "kk_comm_init": (C.c_int, [c_vp, c_vp, C.c_int, C.c_int, C.c_int]),
+    "kk_comm_destroy": (C.c_int, [c_vp]),
+    "kk_comm_info": (C.c_int, [c_vp, c_ip, c_ip, c_ip]),
+    "kk_comm_stats": (C.c_int, [c_vp, c_i64p, c_i64p, c_i64p]),
+    "kk_comm_allreduce": (C.c_int, [c_vp, c_vp, C.c_int64, C.c_int]),
+    "kk_comm_barrier": (C.c_int, [c_vp]),
+    "kk_csr_create_sharded": (C.c_int, [c_vp, C.c_int64, c_i64p, C.c_int64, c_i64p, c_i64p, c_dp, C.c_int, C.c_int, c_vpp]),
+    "kk_csr_create_sharded_rect": (C.c_int, [c_vp, C.c_int64, C.c_int64, C.c_int64, c_i64p, c_i64p, c_dp, C.c_int, c_vpp, c_i64p]),
 }
+KK_COMM_ID_BYTES = 128
+KK_COMM_FORCE_COLLECTIVES = 1
 
 _lib = None
 

@@ -17,10 +17,18 @@ from .factorizations import (ArnoldiIterator, GKLIterator, LanczosIterator, _as_
 
 # -------------------------------------------------------------------- linsolve (GMRES)
 def linsolve(A, b, x0=None, alg: Optional[GMRES] = None, a0: float = 0.0, a1: float = 1.0, *, atol: Optional[float] = None,
-             rtol: Optional[float] = None, return_device: bool = False, **kw):
-    """linsolve(operator, b, x0, alg::GMRES, a0, a1) (src/linsolve/gmres.jl:1-151), with the
-    tolerance handling of the front-end (`tol = max(atol, rtol*norm(b))`, linsolve/linsolve.jl:135-140).
-    Like the reference's method table, `alg::CG` and `alg::BiCGStab` select those solvers (linsolve/cg.jl, bicgstab.jl)."""
+             rtol: Optional[float] = None, tol: Optional[float] = None, return_device: bool = False,
+             trace: Optional[list] = None, **kw):
+    """linsolve(operator, b, x0, alg::GMRES, a0, a1) (src/linsolve/gmres.jl:1-151).
+    Without an algorithm struct the keyword front-end of the reference applies (`linselector`,
+    linsolve/linsolve.jl:123-151): atol and rtol both default to KrylovDefaults.tol and
+    `tol = max(atol, rtol*norm(b))`; GMRES is selected.  With an explicit `alg` its own `tol` is used, exactly as
+    `linsolve(f, b, x0, alg, a0, a1)` does; atol / rtol / tol then make no sense and raise.
+    Like the reference's method table, `alg::CG` and `alg::BiCGStab` select those solvers (linsolve/cg.jl, bicgstab.jl).
+    `trace` (optional list) receives (numiter, k, beta) after every inner step (the residual estimates of gmres.jl:53,94)."""
+    if alg is not None and (atol is not None or rtol is not None or tol is not None):
+        raise TypeError("linsolve: atol / rtol / tol belong to the keyword front-end; with an explicit algorithm struct "
+                        "the tolerance is alg.tol (linsolve/linsolve.jl:112-121)")
     if isinstance(alg, CG):
         return linsolve_cg(A, b, x0, alg, a0, a1)
     if isinstance(alg, BiCGStab):
@@ -29,9 +37,13 @@ def linsolve(A, b, x0=None, alg: Optional[GMRES] = None, a0: float = 0.0, a1: fl
     ctx = op.ctx
     n = op.shape[0]
     b = np.asarray(b, dtype=np.float64)
-    alg = alg or GMRES(**{k: v for k, v in kw.items() if k in ("orth", "maxiter", "krylovdim", "tol", "verbosity")})
-    if atol is not None or rtol is not None:
-        alg = GMRES(alg.orth, alg.maxiter, alg.krylovdim, max(atol or 0.0, (rtol or 0.0) * float(np.linalg.norm(b))))
+    if alg is None:
+        if tol is None:   # tol::Real = max(atol, rtol * norm(b))   linsolve.jl:131-133
+            atol = KrylovDefaults.tol if atol is None else atol
+            rtol = KrylovDefaults.tol if rtol is None else rtol
+            tol = max(atol, rtol * float(np.linalg.norm(b)))
+        alg = GMRES(kw.get("orth", KrylovDefaults.orth), kw.get("maxiter", KrylovDefaults.maxiter),
+                    kw.get("krylovdim", KrylovDefaults.krylovdim), tol)
     krylovdim, maxiter, tol = alg.krylovdim, alg.maxiter, alg.tol
     # work vectors: 0 = b, 1 = x, 2 = r, 3 = tmp
     W = DeviceBasis(n, 4, ctx)
@@ -70,6 +82,8 @@ def linsolve(A, b, x0=None, alg: Optional[GMRES] = None, a0: float = 0.0, a1: fl
         y[1] = 0.0
         y[0], y[1] = c * y[0] + s * y[1], -s * y[0] + c * y[1]
         beta = abs(y[1])
+        if trace is not None:
+            trace.append((numiter, 1, beta))
         while R[k - 1, k - 1] != 0 and beta > tol and len(fact) < krylovdim:  # :55
             fact = expand_(it, fact)
             numops += 1
@@ -95,6 +109,8 @@ def linsolve(A, b, x0=None, alg: Optional[GMRES] = None, a0: float = 0.0, a1: fl
                 y[k] = 0.0
                 y[k - 1], y[k] = c * y[k - 1] + s * y[k], -s * y[k - 1] + c * y[k]
             beta = abs(y[k])
+            if trace is not None:
+                trace.append((numiter, k, beta))
         kk = k - 1 if (R[k - 1, k - 1] == 0 and y[k - 1] == 0) else k  # :98-102
         dense.ldiv_upper(R, y, kk)
         V = fact.basis()
@@ -234,7 +250,7 @@ def linsolve_bicgstab(A, b, x0=None, alg: Optional[BiCGStab] = None, a0: float =
     numiter += 1
     vrs.scale_from_(vr, 1.0)              # shadow residual   :35
     rho = vrs.inner(vr)
-    if np.isclose(rho, 0.0):              # :39-46
+    if rho == 0.0:                        # `rho ≈ 0.0` with isapprox's atol = 0: only an exact zero   :39-46
         return vx.get(), ConvergenceInfo(0, vr.get(), normr, numiter, numops)
     HipVec(W, cur[0]).scale_from_(vr, 1.0)   # p = r
     first = True

@@ -187,4 +187,267 @@ int kkref_lanczos(int64_t n, const int64_t* colptr, const int64_t* rowval, const
     return rc;
 }
 
+
+/* ------------------------------------------------------------------------------------------------
+ * Arnoldi / restarted GMRES  (config 3)
+ * ------------------------------------------------------------------------------------------------ */
+/* orthogonalize!!(w, V[0..m), x, alg) with coefficient accumulation -- src/orthonormal.jl:378-452 */
+static void orth_full(int64_t n, int m, double** V, double* w, double* x, int orth, double eta, double* tmp, int* passes) {
+    int j;
+    switch (orth) {
+        case 0: /* CGS :378-384 */
+            cgs_pass(n, m, V, w, x);
+            ++*passes;
+            break;
+        case 2: /* CGS2 :394-399: orthogonalize, then reorthogonalize!! (:385-393, x .+= s) */
+            cgs_pass(n, m, V, w, x);
+            cgs_pass(n, m, V, w, tmp);
+            for (j = 0; j < m; ++j) x[j] += tmp[j];
+            *passes += 2;
+            break;
+        case 4: { /* CGSIR :400-412 */
+            double nold = dnrm2(n, w);
+            cgs_pass(n, m, V, w, x);
+            double nnew = dnrm2(n, w);
+            ++*passes;
+            while (DBL_EPSILON < nnew && nnew < eta * nold) {
+                nold = nnew;
+                cgs_pass(n, m, V, w, tmp);
+                for (j = 0; j < m; ++j) x[j] += tmp[j];
+                nnew = dnrm2(n, w);
+                ++*passes;
+            }
+        } break;
+        case 1: /* MGS :414-423 */
+            for (j = 0; j < m; ++j) { x[j] = ddot(n, V[j], w); daxpy(n, -x[j], V[j], w); }
+            ++*passes;
+            break;
+        case 3: /* MGS2 :434-439 (second sweep accumulates, :424-433) */
+            for (j = 0; j < m; ++j) { x[j] = ddot(n, V[j], w); daxpy(n, -x[j], V[j], w); }
+            for (j = 0; j < m; ++j) { double s = ddot(n, V[j], w); daxpy(n, -s, V[j], w); x[j] += s; }
+            *passes += 2;
+            break;
+        default: { /* MGSIR :440-452 */
+            double nold = dnrm2(n, w);
+            for (j = 0; j < m; ++j) { x[j] = ddot(n, V[j], w); daxpy(n, -x[j], V[j], w); }
+            double nnew = dnrm2(n, w);
+            ++*passes;
+            while (DBL_EPSILON < nnew && nnew < eta * nold) {
+                nold = nnew;
+                for (j = 0; j < m; ++j) { double s = ddot(n, V[j], w); daxpy(n, -s, V[j], w); x[j] += s; }
+                nnew = dnrm2(n, w);
+                ++*passes;
+            }
+        }
+    }
+}
+/* _orthogonalize!!(v, q, alg) -- src/orthonormal.jl:455-473 (non-IR variants); returns the coefficient */
+static double orth_vec(int64_t n, const double* q, double* v, int orth, double eta) {
+    double s = ddot(n, q, v);
+    daxpy(n, -s, q, v);
+    if (orth == 2 || orth == 3) { /* :465-473 */
+        double ds = ddot(n, q, v);
+        daxpy(n, -ds, q, v);
+        s += ds;
+    }
+    return s;
+}
+static double orth_vec_ir(int64_t n, const double* q, double* v, double eta) { /* :474-489 */
+    double nold = dnrm2(n, v);
+    double s = ddot(n, q, v);
+    daxpy(n, -s, q, v);
+    double nnew = dnrm2(n, v);
+    while (DBL_EPSILON < nnew && nnew < eta * nold) {
+        nold = nnew;
+        double ds = ddot(n, q, v);
+        daxpy(n, -ds, q, v);
+        s += ds;
+        nnew = dnrm2(n, v);
+    }
+    return s;
+}
+/* LinearAlgebra.givensAlgorithm, real case (LAPACK dlartg semantics): [c s; -s c][f; g] = [r; 0] */
+static void givens_fg(double f, double g, double* c, double* s, double* r) {
+    if (g == 0) { *c = 1; *s = 0; *r = f; return; }
+    if (f == 0) { *c = 0; *s = 1; *r = g; return; }
+    double rr = hypot(f, g);
+    double cc = f / rr, ss = g / rr;
+    if (fabs(f) > fabs(g) && cc < 0) { cc = -cc; ss = -ss; rr = -rr; }
+    *c = cc; *s = ss; *r = rr;
+}
+/* packed Hessenberg H[i,j], 1-based, i <= j+1  (dense/packedhessenberg.jl:32-39) */
+static inline size_t hidx(int i, int j) { return (size_t)(((j * j + j - 2) >> 1) + i - 1); }
+
+/*
+ * linsolve(A, b, x0, GMRES(orth; krylovdim, maxiter, tol), a0, a1)  -- src/linsolve/gmres.jl:1-151 on the Arnoldi
+ * factorization of src/factorizations/arnoldi.jl:135-245.  A in CSC with 1-based Int64 indices.  x receives the
+ * solution (x0 on entry may be NULL = zero).  info = {converged, numiter, numops}; *normres = final residual norm.
+ * trace (optional, trace_cap doubles) receives the residual estimate beta after every inner step (gmres.jl:53,94),
+ * *trace_len their number.  Returns 0, -1 on allocation failure.
+ */
+int kkref_gmres(int64_t n, const int64_t* colptr, const int64_t* rowval, const double* nzval, const double* b,
+                const double* x0, double a0, double a1, int krylovdim, int maxiter, double tol, int orth, double eta,
+                int nthreads, double* x, int* info, double* normres, double* trace, int trace_cap, int* trace_len) {
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+    const int K = krylovdim;
+    double** V = (double**)calloc((size_t)K + 2, sizeof(double*));
+    double* H = (double*)calloc((size_t)(K + 2) * (K + 3) / 2 + 8, sizeof(double));
+    double* R = (double*)calloc((size_t)K * K, sizeof(double)); /* column-major K x K */
+    double* y = (double*)calloc((size_t)K + 2, sizeof(double));
+    double* gc = (double*)calloc((size_t)K + 1, sizeof(double));
+    double* gsn = (double*)calloc((size_t)K + 1, sizeof(double));
+    int* g1 = (int*)calloc((size_t)K + 1, sizeof(int));
+    int* g2 = (int*)calloc((size_t)K + 1, sizeof(int));
+    double* hx = (double*)calloc((size_t)K + 2, sizeof(double));
+    double* tmp = (double*)calloc((size_t)K + 2, sizeof(double));
+    double* r = (double*)malloc((size_t)n * sizeof(double));
+    double* t = (double*)malloc((size_t)n * sizeof(double));
+    if (!V || !H || !R || !y || !gc || !gsn || !g1 || !g2 || !hx || !tmp || !r || !t) return -1;
+    int passes = 0, ntrace = 0, rc = 0;
+    int64_t i;
+    /* r = b - a0 x0 - a1 A x0 ; x = x0   :3-12 */
+    if (x0) memcpy(x, x0, (size_t)n * sizeof(double)); else memset(x, 0, (size_t)n * sizeof(double));
+    csc_mul(n, n, colptr, rowval, nzval, x, t);
+    memcpy(r, b, (size_t)n * sizeof(double));
+    if (a0 != 0) daxpy(n, -a0, x, r);
+    daxpy(n, -a1, t, r);
+    double beta = dnrm2(n, r);
+    int numiter = 0, numops = 1, converged = 0, k = 0, nv = 0;
+    if (beta < tol) { converged = 1; goto done; } /* :21-27 */
+    /* fact = initialize(ArnoldiIterator(A, r, orth))   arnoldi.jl:135-175 */
+    {
+        double* v = (double*)malloc((size_t)n * sizeof(double));
+        double* w = (double*)malloc((size_t)n * sizeof(double));
+        if (!v || !w) { rc = -1; goto done; }
+        const double beta0 = beta; /* norm(r) */
+        csc_mul(n, n, colptr, rowval, nzval, r, w);
+        double alpha = ddot(n, r, w) / (beta0 * beta0);
+        memcpy(v, r, (size_t)n * sizeof(double));
+        dscal(n, 1.0 / beta0, v);
+        dscal(n, 1.0 / beta0, w);
+        double bold = dnrm2(n, w);
+        daxpy(n, -alpha, v, w);
+        double bn = dnrm2(n, w);
+        if (orth == 2 || orth == 3) {
+            double da = ddot(n, v, w); alpha += da; daxpy(n, -da, v, w); bn = dnrm2(n, w);
+        } else if (orth >= 4) {
+            while (DBL_EPSILON < bn && bn < eta * bold) {
+                bold = bn;
+                double da = ddot(n, v, w); alpha += da; daxpy(n, -da, v, w); bn = dnrm2(n, w);
+            }
+        }
+        V[0] = v; nv = 1;
+        V[1] = w; /* residual lives in slot nv */
+        H[0] = alpha; H[1] = bn;
+        k = 1;
+        numops += 1;
+    }
+    for (;;) { /* restart loop :44-149 */
+        numiter += 1;
+        y[0] = beta;
+        k = 1;
+        double nres = fabs(H[hidx(2, 1)]);
+        R[0] = a0 + a1 * H[hidx(1, 1)];
+        givens_fg(R[0], a1 * nres, &gc[0], &gsn[0], &R[0]);
+        g1[0] = 0; g2[0] = 1;
+        y[1] = 0;
+        { double y1 = y[0], y2 = y[1]; y[0] = gc[0] * y1 + gsn[0] * y2; y[1] = -gsn[0] * y1 + gc[0] * y2; }
+        beta = fabs(y[1]);
+        if (trace && ntrace < trace_cap) trace[ntrace++] = beta;
+        int len = 1;
+        while (R[(size_t)(k - 1) * K + (k - 1)] != 0 && beta > tol && len < K) { /* :55 */
+            /* expand!  arnoldi.jl:199-219 : push!(V, scale(r, 1/beta)) ; w = A v ; orthogonalize ; norm */
+            double* vnew = V[nv];
+            dscal(n, 1.0 / nres, vnew); /* scale(r, 1/beta): non-mutating in the reference, same values */
+            nv += 1;
+            double* w = (double*)malloc((size_t)n * sizeof(double));
+            if (!w) { rc = -1; goto done; }
+            csc_mul(n, n, colptr, rowval, nzval, vnew, w);
+            orth_full(n, nv, V, w, hx, orth, eta, tmp, &passes);
+            double bn = dnrm2(n, w);
+            V[nv] = w;
+            len = nv; k = len;
+            for (int ii = 1; ii <= k; ++ii) H[hidx(ii, k)] = hx[ii - 1];
+            H[hidx(k + 1, k)] = bn;
+            nres = bn;
+            numops += 1;
+            double* Rk = R + (size_t)(k - 1) * K;
+            for (int ii = 1; ii <= k - 1; ++ii) Rk[ii - 1] = a1 * H[hidx(ii, k)];
+            Rk[k - 1] = a0 + a1 * H[hidx(k, k)];
+            for (int ii = 0; ii < k - 1; ++ii) { /* lmul!(gs[i], Rk) :72-76 */
+                double u1 = Rk[g1[ii]], u2 = Rk[g2[ii]];
+                Rk[g1[ii]] = gc[ii] * u1 + gsn[ii] * u2;
+                Rk[g2[ii]] = -gsn[ii] * u1 + gc[ii] * u2;
+            }
+            if (hypot(Rk[k - 1], a1 * nres) < tol) { /* :79-86 */
+                double rr;
+                givens_fg(0.0, y[k - 1], &gc[k - 1], &gsn[k - 1], &rr);
+                y[k] = rr;
+                g1[k - 1] = k; g2[k - 1] = k - 1;
+                y[k - 1] = 0; Rk[k - 1] = 0;
+            } else { /* :88-90 */
+                givens_fg(Rk[k - 1], a1 * nres, &gc[k - 1], &gsn[k - 1], &Rk[k - 1]);
+                g1[k - 1] = k - 1; g2[k - 1] = k;
+                y[k] = 0;
+                double y1 = y[k - 1], y2 = y[k];
+                y[k - 1] = gc[k - 1] * y1 + gsn[k - 1] * y2;
+                y[k] = -gsn[k - 1] * y1 + gc[k - 1] * y2;
+            }
+            beta = fabs(y[k]);
+            if (trace && ntrace < trace_cap) trace[ntrace++] = beta;
+        }
+        /* triangular solve :98-102 (ldiv!, dense/linalg.jl:96-106) */
+        int kk2 = (R[(size_t)(k - 1) * K + (k - 1)] == 0 && y[k - 1] == 0) ? k - 1 : k;
+        for (int j = kk2 - 1; j >= 0; --j) {
+            y[j] = y[j] / R[(size_t)j * K + j];
+            for (int ii = 0; ii < j; ++ii) y[ii] -= R[(size_t)j * K + ii] * y[j];
+        }
+        for (int ii = 0; ii < k; ++ii) daxpy(n, y[ii], V[ii], x); /* :105-108 */
+        if (beta > tol && numiter < maxiter) { /* :110-117 */
+            dscal(n, 1.0 / nres, V[nv]); /* push!(V, scale!!(w, 1/normres)) */
+            for (int ii = 0; ii < k; ++ii) { /* rmul!(V, gs[i]')  dense/givens.jl:30-36 with s -> -s */
+                double* q1 = V[g1[ii]]; double* q2 = V[g2[ii]];
+                const double c = gc[ii], s = -gsn[ii];
+#pragma omp parallel for simd schedule(static)
+                for (i = 0; i < n; ++i) { double u1 = q1[i], u2 = q2[i]; q1[i] = c * u1 - s * u2; q2[i] = s * u1 + c * u2; }
+            }
+            const double yk = y[k];
+            const double* vk = V[k];
+#pragma omp parallel for simd schedule(static)
+            for (i = 0; i < n; ++i) r[i] = vk[i] * yk; /* r = scale!!(r, V[k+1], y[k+1]) */
+        } else { /* :119-132 */
+            memcpy(r, b, (size_t)n * sizeof(double));
+            csc_mul(n, n, colptr, rowval, nzval, x, t);
+#pragma omp parallel for simd schedule(static)
+            for (i = 0; i < n; ++i) r[i] -= a0 * x[i] + a1 * t[i]; /* add!!(r, apply(op, x, a0, a1), -1) */
+            numops += 1;
+            beta = dnrm2(n, r);
+            if (beta < tol) { converged = 1; goto done; }
+        }
+        if (numiter >= maxiter) goto done;
+        /* fact = initialize!(ArnoldiIterator(A, r, orth), fact)   arnoldi.jl:176-198 */
+        for (int j = 1; j <= nv; ++j) { free(V[j]); V[j] = NULL; }
+        {
+            double* v = V[0];
+            const double nr = dnrm2(n, r);
+            memcpy(v, r, (size_t)n * sizeof(double));
+            dscal(n, 1.0 / nr, v); /* V[1] = scale!!(V[1], x0, 1/norm(x0)) */
+            double* w = (double*)malloc((size_t)n * sizeof(double));
+            if (!w) { rc = -1; goto done; }
+            csc_mul(n, n, colptr, rowval, nzval, v, w);
+            double al = (orth >= 4) ? orth_vec_ir(n, v, w, eta) : orth_vec(n, v, w, orth, eta);
+            double bn = dnrm2(n, w);
+            nv = 1; V[1] = w;
+            H[0] = al; H[1] = bn; /* the reference does NOT count this apply in numops (gmres.jl:147-148) */
+        }
+    }
+done:
+    if (info) { info[0] = converged; info[1] = numiter; info[2] = numops; }
+    if (normres) *normres = beta;
+    if (trace_len) *trace_len = ntrace;
+    for (int j = 0; j < K + 2; ++j) free(V[j]);
+    free(V); free(H); free(R); free(y); free(gc); free(gsn); free(g1); free(g2); free(hx); free(tmp); free(r); free(t);
+    return rc;
+}
+
 int kkref_num_threads(void) { return omp_get_max_threads(); }

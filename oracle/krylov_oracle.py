@@ -971,6 +971,8 @@ def gmres(operator, b: np.ndarray, x0: Optional[np.ndarray] = None, a0: float = 
         y[1] = 0.0
         y[0], y[1] = c * y[0] + s * y[1], -s * y[0] + c * y[1]
         beta = abs(y[1])
+        if trace is not None:
+            trace.append((numiter, 1, beta))
         while R[k - 1, k - 1] != 0 and beta > tol and len(fact) < krylovdim:  # :55
             fact = arnoldi_expand(it, fact)
             numops += 1

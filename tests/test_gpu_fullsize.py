@@ -167,3 +167,90 @@ def test_config4_gkl_5Mx1M_properties(kk, ctx):
         assert WV[0].norm() < 1e-10, j
     smax = np.linalg.svd(f.rayleighquotient(), compute_uv=False)[0]
     assert 0.9 * (np.sqrt(m * per / n) + np.sqrt(per)) < smax < 1.1 * (np.sqrt(m * per / n) + np.sqrt(per))  # Marchenko-Pastur edge
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Parity at BASELINE.json's headline sizes against the CPU restatement of the reference path (oracle/cpu_ref.c):
+# north_star -- "Ritz values / residuals within 1e-10 relative for Float64, GMRES residual norm bit-matching iteration
+# count ... eigenvalues matching CPU reference to 1e-10" on the 10M-row run itself.
+# ---------------------------------------------------------------------------------------------------------------------
+def _tri_eigs(al, be):
+    return np.linalg.eigvalsh(np.diag(al) + np.diag(be[:-1], 1) + np.diag(be[:-1], -1))
+
+
+@pytest.fixture(scope="module")
+def cfg2_cpu_reference():
+    """(alpha, beta) of initialize + 99 expand! on the 4000 x 2500 Laplacian by oracle/cpu_ref.c, per orthogonaliser
+    (computed once per orthogonaliser: ~15-30 s of host time each)."""
+    import cpu_ref_lib as cr
+    from bench import laplacian_rows, NX, NY
+    lib = cr.load()
+    A = laplacian_rows(NX, NY, 0, NY)
+    cache = {}
+
+    def get(orth_code, x0):
+        if orth_code not in cache:
+            al, be, _, _ = cr.run_lanczos(lib, A, x0, 99, orth_code, nthreads=cr.usable_threads())
+            cache[orth_code] = (al, be)
+        return cache[orth_code]
+
+    return get
+
+
+@pytest.mark.parametrize("orth_name,mgs_mode", [("mgs2", 1), ("mgs2", 0), ("cgs2", 1)])
+def test_config2_lanczos_10M_parity_with_cpu_reference(kk, ctx, cfg2_cpu_reference, orth_name, mgs_mode):
+    """src/factorizations/lanczos.jl:250-272 + :313-338 at N = 10^7, krylovdim = 100: alpha / beta trajectories and the Ritz
+    values of the 100 x 100 tridiagonal, GPU (low-sync MGS2, strict MGS2, CGS2) vs the CPU reference path, <= 1e-10 relative."""
+    from bench import laplacian_rows, NX, NY
+    N, K = NX * NY, 100
+    ctx.set_option("mgs_mode", mgs_mode)
+    try:
+        op = kk.SparseOperator(laplacian_rows(NX, NY, 0, NY), ctx, symmetric=True, via_csc=True)
+        x0b = kk.DeviceBasis(N, 1, ctx)
+        x0b[0].rand_(3)
+        x0 = x0b[0].get()
+        V = kk.DeviceBasis(N, K + 2, ctx)
+        orth = kk.Orthogonalizer(orth_name)
+        it = kk.LanczosIterator(op, x0b[0], orth, capacity=K + 2)
+        f = kk.initialize(it, V)
+        for _ in range(K - 1):
+            f = kk.expand_(it, f)
+        al_g, be_g = np.array(f.alphas), np.array(f.betas)
+    finally:
+        ctx.set_option("mgs_mode", 1)
+    al_c, be_c = cfg2_cpu_reference(orth.code, x0)
+    assert np.max(np.abs(al_g - al_c) / np.abs(al_c)) <= 1e-10
+    assert np.max(np.abs(be_g - be_c) / np.abs(be_c)) <= 1e-10
+    th_g, th_c = _tri_eigs(al_g, be_g), _tri_eigs(al_c, be_c)
+    assert np.max(np.abs(th_g - th_c) / np.abs(th_c)) <= 1e-10
+    V.free(); x0b.free(); op.free()
+
+
+def test_config3_gmres_2M_parity_with_cpu_reference(kk, ctx):
+    """src/linsolve/gmres.jl:44-149 on the 2M-row convection-diffusion operator, krylovdim = 60: one full restart cycle
+    plus the start of the second.  numiter / numops / converged equal to the CPU reference path, the residual estimate
+    after EVERY inner step (gmres.jl:53,94) and the final residual norm within 1e-10 relative."""
+    import cpu_ref_lib as cr
+    from tools.bench_configs import convdiff
+    nx, ny = 2000, 1000
+    N = nx * ny
+    A = convdiff(nx, ny)
+    b = np.random.default_rng(4).random(N)
+    nb = np.linalg.norm(b)
+    tol = 1e-10 * nb
+    lib = cr.load()
+    xc, ic, tc = cr.run_gmres(lib, A, b, None, 0.0, 1.0, 60, 2, tol, 3, nthreads=cr.usable_threads())
+    tr = []
+    x, info = kk.linsolve(kk.SparseOperator(A, ctx), b, None, kk.GMRES(kk.ModifiedGramSchmidt2(), 2, 60, tol), trace=tr)
+    assert (info.converged, info.numiter, info.numops) == (ic["converged"], ic["numiter"], ic["numops"])
+    tg = np.array([t[2] for t in tr])
+    assert len(tg) == len(tc) == 120
+    assert np.max(np.abs(tg - tc) / tc) <= 1e-10
+    assert abs(info.normres - ic["normres"]) <= 1e-10 * ic["normres"]
+    assert np.linalg.norm(x - xc) <= 1e-9 * np.linalg.norm(xc)
+    # CGS2 as well: same counts, same trace to 1e-10
+    xc2, ic2, tc2 = cr.run_gmres(lib, A, b, None, 0.0, 1.0, 60, 1, tol, 2, nthreads=cr.usable_threads())
+    tr2 = []
+    x2, info2 = kk.linsolve(kk.SparseOperator(A, ctx), b, None, kk.GMRES(kk.ClassicalGramSchmidt2(), 1, 60, tol), trace=tr2)
+    assert (info2.converged, info2.numiter, info2.numops) == (ic2["converged"], ic2["numiter"], ic2["numops"])
+    assert np.max(np.abs(np.array([t[2] for t in tr2]) - tc2) / tc2) <= 1e-10

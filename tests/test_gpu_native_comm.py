@@ -1,0 +1,178 @@
+"""The library's own multi-GPU layer (kk_comm_* / kk_csr_create_sharded*, RCCL inside libkrylov_hip.so) on the ONE GPU
+of the box: a communicator of world size 1 with KK_COMM_FORCE_COLLECTIVES issues every collective for real
+(ncclAllReduce / ncclAllGather / ncclReduceScatter on the context stream, no torch anywhere), so the sharded code paths --
+the two-all-reduce Lanczos step, the gather / scatter GKL step, the generic finalize sites -- run exactly as they do on
+8 GPUs and must reproduce the serial oracle.  (Two logical ranks are covered by tests/test_gpu_sharded_hooks.py through
+the hook mechanism, which enters the same fused code; real multi-GPU runs are the driver's.)"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def relerr(a, b):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300)))
+
+
+@pytest.fixture()
+def comm(kk):
+    from krylovkit_hip import dist as kd
+    c = kk.Context(0)
+    cm = kd.NativeComm.single(c, force_collectives=True)
+    yield cm
+    cm.close()
+    c.close()
+
+
+def orth_pairs(kk, ko):
+    return [(kk.ClassicalGramSchmidt(), ko.CGS), (kk.ModifiedGramSchmidt(), ko.MGS), (kk.ClassicalGramSchmidt2(), ko.CGS2),
+            (kk.ModifiedGramSchmidt2(), ko.MGS2), (kk.ClassicalGramSchmidtIR(0.75), ko.CGSIR(0.75)),
+            (kk.ModifiedGramSchmidtIR(0.75), ko.MGSIR(0.75))]
+
+
+def test_comm_info_and_scalar_allreduce(kk, comm):
+    info = comm.info()
+    assert info["rank"] == 0 and info["world"] == 1 and info["rccl_version"] >= 20000
+    assert comm.allreduce_scalar(3.25, "max") == 3.25 and comm.allreduce_scalar(-1.5, "sum") == -1.5
+    comm.barrier()
+    assert comm.stats()["allreduce"] >= 2   # forced: the collectives really ran
+
+
+@pytest.mark.parametrize("mgs_mode", [0, 1])
+def test_native_sharded_lanczos_matches_oracle(kk, ko, comm, mgs_mode):
+    """factorizations/lanczos.jl:250-376 through kk_lanczos_expand with the library's communicator active."""
+    from krylovkit_hip import dist as kd
+    ctx = comm.ctx
+    ctx.set_option("mgs_mode", mgs_mode)
+    nx, ny, steps = 40, 30, 25
+    n = nx * ny
+    A = ko.laplacian_2d(nx, ny, shift_diag=10 * np.linspace(0, 1, n) ** 2)
+    x0 = np.random.default_rng(3).random(n)
+    part = kd.Partition.even(n, 1, 0, align=nx)
+    op = kd.NativeShardedOperator(A, part, ctx, symmetric=True)
+    for dev, ref in orth_pairs(kk, ko):
+        it = kk.LanczosIterator(op, x0, dev, capacity=steps + 3)
+        f = kk.initialize(it)
+        oit = ko.LanczosIterator(A, x0.copy(), ref)
+        of = ko.lanczos_initialize(oit)
+        before = comm.stats()["allreduce"]
+        for _ in range(steps):
+            f = kk.expand_(it, f)
+            of = ko.lanczos_expand(oit, of)
+        per_step = (comm.stats()["allreduce"] - before) / steps
+        tol = 1e-10 if dev.is_reorth else 1e-6
+        assert relerr(f.alphas, of.alphas) < tol and relerr(f.betas, of.betas) < tol, dev.name
+        V = f.V.to_numpy()
+        if dev.is_reorth:
+            assert np.max(np.abs(V.T @ V - np.eye(V.shape[1]))) < 1e-12
+        if dev.name == "cgs2" or (dev.name == "mgs2" and mgs_mode == 1):
+            assert per_step == 2.0, (dev.name, per_step)   # [alpha0 | V'w | V'v] and |w|^2: SURVEY.md 8(e)
+        # thick-restart style mutation + continue: the Gram bookkeeping of the low-sync path must recover
+        if dev.name == "mgs2":
+            k = len(f)
+            Q, _ = np.linalg.qr(np.random.default_rng(1).standard_normal((k, k)))
+            f.V.basistransform(Q)
+            Vn = f.V.to_numpy()
+            w = kk.DeviceBasis(n, 1, ctx)[0].set(np.random.default_rng(2).random(n))
+            x, nrm, _ = f.V.orthogonalize(w, dev)
+            assert np.max(np.abs(Vn.T @ w.get())) < 1e-12 * max(1.0, nrm)
+    ctx.set_option("mgs_mode", 1)
+
+
+def test_native_sharded_eigsolve_and_gmres(kk, ko, comm):
+    from krylovkit_hip import dist as kd
+    ctx = comm.ctx
+    nx, ny = 32, 24
+    n = nx * ny
+    A = ko.laplacian_2d(nx, ny, shift_diag=10 * np.linspace(0, 1, n) ** 2)
+    x0 = np.random.default_rng(3).random(n)
+    part = kd.Partition.even(n, 1, 0)
+    op = kd.NativeShardedOperator(A, part, ctx, symmetric=True)
+    vals, vecs, info = kk.eigsolve(op, x0, 3, "LM", krylovdim=20, tol=1e-10, maxiter=50, orth=kk.ModifiedGramSchmidt2())
+    ovals, ovecs, oinfo = ko.eigsolve_lanczos(A, x0.copy(), 3, "LM", krylovdim=20, tol=1e-10, maxiter=50, orth=ko.MGS2)
+    assert info.converged >= 3 and (info.numiter, info.numops) == (oinfo.numiter, oinfo.numops)
+    assert relerr(vals[:3], ovals[:3]) < 1e-10
+    B = ko.convection_diffusion_2d(nx, ny)
+    b = np.random.default_rng(4).random(n)
+    tol = 1e-9 * np.linalg.norm(b)
+    opB = kd.NativeShardedOperator(B, part, ctx)
+    tr, otr = [], []
+    x, ginfo = kk.linsolve(opB, b, None, kk.GMRES(kk.ModifiedGramSchmidt2(), 20, 25, tol), trace=tr)
+    ox, oinfo = ko.gmres(B, b, krylovdim=25, maxiter=20, tol=tol, orth=ko.MGS2, trace=otr)
+    assert (ginfo.converged, ginfo.numiter, ginfo.numops) == (oinfo.converged, oinfo.numiter, oinfo.numops)
+    assert len(tr) == len(otr) and relerr([t[2] for t in tr], [t[2] for t in otr]) < 1e-6
+    assert np.linalg.norm(B @ x - b) < 2 * tol
+
+
+@pytest.mark.parametrize("mgs_mode", [0, 1])
+def test_native_sharded_gkl_matches_oracle(kk, ko, comm, mgs_mode):
+    """factorizations/gkl.jl:183-404 on a kk_csr_create_sharded_rect map: all-gather before A v, reduce-scatter after A'u."""
+    from krylovkit_hip import dist as kd
+    ctx = comm.ctx
+    ctx.set_option("mgs_mode", mgs_mode)
+    A = ko.sparse_random(600, 250, 8, 21)
+    u0 = np.random.default_rng(6).random(600)
+    steps = 15
+    op = kd.NativeShardedRectOperator(A, 250, ctx)
+    assert op.shape == (600, 250)
+    for dev, ref in orth_pairs(kk, ko):
+        it = kk.GKLIterator(op, u0, dev, capacity=steps + 3)
+        f = kk.initialize(it)
+        oit = ko.GKLIterator(A, u0.copy(), ref)
+        of = ko.gkl_initialize(oit)
+        g0 = comm.stats()["gather"]
+        for _ in range(steps):
+            f = kk.expand_(it, f)
+            of = ko.gkl_expand(oit, of)
+        assert comm.stats()["gather"] - g0 == 2 * steps   # one all-gather + one reduce-scatter per expand!
+        tol = 1e-10 if dev.is_reorth else 1e-6
+        assert relerr(f.alphas, of.alphas) < tol and relerr(f.betas, of.betas) < tol, dev.name
+        U, V, r, Bm = f.U.to_numpy(), f.V.to_numpy(), f.r.get(), f.rayleighquotient()
+        ek = np.zeros(len(f)); ek[-1] = 1
+        assert np.max(np.abs(A @ V - U @ Bm - np.outer(r, ek))) < 1e-11
+        assert np.max(np.abs(A.T @ U - V @ Bm.T)) < 1e-10
+    # apply / apply_adjoint through the public kk_spmv
+    xb, yb = kk.DeviceBasis(250, 1, ctx), kk.DeviceBasis(600, 1, ctx)
+    xv = np.random.default_rng(9).standard_normal(250)
+    op.apply(xb[0].set(xv), yb[0])
+    np.testing.assert_allclose(yb[0].get(), A @ xv, rtol=0, atol=1e-12)
+    yv = np.random.default_rng(10).standard_normal(600)
+    op.apply_adjoint(yb[0].set(yv), xb[0])
+    np.testing.assert_allclose(xb[0].get(), A.T @ yv, rtol=0, atol=1e-12)
+    ctx.set_option("mgs_mode", 1)
+
+
+def test_native_sharded_blocklanczos_issue143(kk, ko, comm):
+    """test/issues.jl:39-129 known answer through the sharded finalize sites (block Gram panels all-reduced)."""
+    from pathlib import Path
+    from krylovkit_hip import dist as kd
+    import scipy.sparse as sp
+    ctx = comm.ctx
+    A = np.load(Path(__file__).parent / "golden" / "issue143_A.npy")
+    n = A.shape[0]
+    part = kd.Partition.even(n, 1, 0)
+    op = kd.NativeShardedOperator(sp.csr_matrix(A), part, ctx, symmetric=True)
+    rng = np.random.default_rng(143)
+    x0 = [rng.standard_normal(n) for _ in range(20)]
+    D, V, info = kk.eigsolve_block(op, x0, 4, "SR", kk.BlockLanczos(tol=1e-8))
+    ev = np.linalg.eigvalsh(A)
+    assert len(D) == len(ev)
+    np.testing.assert_allclose(np.sort(D), ev, rtol=0, atol=1e-10 * np.max(np.abs(ev)))
+    assert info.converged == len(D) and info.numiter == 1 and info.numops == len(D) + 1
+
+
+def test_sharded_create_rejects_bad_input(kk, comm):
+    import ctypes as C
+    from krylovkit_hip import _lib
+    lib, ctx = comm.ctx._lib, comm.ctx
+    h = C.c_void_p()
+    offs = (C.c_int64 * 2)(0, 4)
+    rowptr = (C.c_int64 * 5)(0, 1, 2, 3, 4)
+    col = (C.c_int64 * 4)(0, 1, 2, 9)     # column 9 outside the 4 x 4 operator
+    val = (C.c_double * 4)(1, 1, 1, 1)
+    assert lib.kk_csr_create_sharded(ctx.handle, 4, offs, 4, rowptr, col, val, 0, 0, C.byref(h)) == _lib.KK_ERR_DIM
+    bad_ptr = (C.c_int64 * 5)(0, 2, 1, 3, 4)   # not monotone
+    col2 = (C.c_int64 * 4)(0, 1, 2, 3)
+    assert lib.kk_csr_create_sharded(ctx.handle, 4, offs, 4, bad_ptr, col2, val, 0, 0, C.byref(h)) == _lib.KK_ERR_DIM
+    assert lib.kk_csr_create_sharded(ctx.handle, 3, offs, 4, rowptr, col2, val, 0, 0, C.byref(h)) == _lib.KK_ERR_DIM

@@ -34,3 +34,22 @@ for sub, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
 for ctr, d in res.items():
     for k, v in sorted(d.items(), key=lambda kv: -kv[1]["sum"])[:8]:
         print(ctr, k[:60], v["dispatches"], f"{v['avg_per_dispatch']:.4g}")
+
+# 3. HBM bytes per launch for bench.py's roofline.traffic: (2*FETCH_SIZE + WRITE_SIZE) * 1024 per the gfx950 correction of
+# MI355X_MICROARCH.md (FETCH_SIZE reports half of a wide coalesced read stream), stamped with the hash of the kernel
+# sources it was measured on -- bench.py drops the figure when the sources have changed since.
+if "FETCH_SIZE" in res and "WRITE_SIZE" in res and "--no-traffic" not in sys.argv:
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+    from bench import kernel_source_sha  # noqa: E402
+    traffic = {"_comment": "HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --steps 2 "
+                           "--warmup 1`, (2*FETCH_SIZE + WRITE_SIZE)*1024 as MI355X_MICROARCH.md prescribes for gfx950, averaged over the "
+                           "launches of the run", "source_sha": kernel_source_sha(), "stamped_by": f"tools/profile_gpu.sh {tag}"}
+    for short in ("k_project", "k_unproject", "k_spmv_ell", "k_scal", "k_mgs_step", "k_unproj_proj"):
+        f = [v for k, v in res["FETCH_SIZE"].items() if k.startswith("void " + short) or k.startswith(short)]
+        w = [v for k, v in res["WRITE_SIZE"].items() if k.startswith("void " + short) or k.startswith(short)]
+        if f and w:
+            nf = sum(v["dispatches"] for v in f)
+            nw = sum(v["dispatches"] for v in w)
+            traffic[short] = round((2 * sum(v["sum"] for v in f) / nf + sum(v["sum"] for v in w) / nw) * 1024)
+    (dst / "traffic.json").write_text(json.dumps(traffic, indent=1))
+    print("traffic.json:", traffic)
