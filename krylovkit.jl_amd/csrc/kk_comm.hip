@@ -231,7 +231,7 @@ int kk_halo_exchange(kk_ctx c, const kk_sparse_dev& M, const double* x) {
 // vfull = all-gather of the `shard`-strided local pieces (stage); world 1: plain copy
 int kk_comm_allgather_f64(kk_ctx c, const double* d_stage, double* d_full, int64_t shard) {
     kk_comm_s* k = c->comm;
-    if (!k || k->world == 1) {
+    if (!k || !k->active) {
         KK_HIP(hipMemcpyAsync(d_full, d_stage, shard * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
         return KK_OK;
     }
@@ -242,7 +242,7 @@ int kk_comm_allgather_f64(kk_ctx c, const double* d_stage, double* d_full, int64
 // stage = my shard of the sum over ranks of d_full
 int kk_comm_reducescatter_f64(kk_ctx c, const double* d_full, double* d_stage, int64_t shard) {
     kk_comm_s* k = c->comm;
-    if (!k || k->world == 1) {
+    if (!k || !k->active) {
         KK_HIP(hipMemcpyAsync(d_stage, d_full, shard * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
         return KK_OK;
     }

@@ -53,6 +53,12 @@ static int ctx_allocate(kk_ctx c) {
     KK_HIP(hipEventCreate(&c->t1));
     KK_HIP(hipEventCreateWithFlags(&c->ev_fetch, hipEventDisableTiming));
     KK_HIP(hipEventCreateWithFlags(&c->ev_fetch2, hipEventDisableTiming));
+    KK_HIP(hipMalloc(&c->d_sync, KK_SYNC_BYTES));
+    KK_HIP(hipMemset(c->d_sync, 0, KK_SYNC_BYTES));
+    KK_HIP(hipHostMalloc((void**)&c->h_sync, 64, hipHostMallocDefault));
+    c->h_sync[0] = 0;
+    int coop = 0;
+    if (hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, c->device) != hipSuccess || !coop) c->mgs_persist = 0;
     return KK_OK;
 }
 
@@ -88,6 +94,12 @@ KK_API int kk_ctx_create(int device, kk_ctx* out) {
     if (env && atoi(env) > 0) c->blocks_per_cu = atoi(env);
     env = getenv("KK_MGS_MODE");
     if (env) c->mgs_mode = atoi(env);
+    env = getenv("KK_MGS_PERSIST");
+    if (env) c->mgs_persist = c->mgs_persist && atoi(env) != 0;
+    env = getenv("KK_PERSIST_THREADS");
+    if (env && (atoi(env) == 512 || atoi(env) == 1024)) c->persist_threads = atoi(env);
+    env = getenv("KK_PERSIST_NT");
+    if (env) c->persist_nt = atoi(env) != 0;
     *out = c;
     return KK_OK;
 }
@@ -108,6 +120,8 @@ KK_API int kk_ctx_destroy(kk_ctx c) {
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     if (c->h_U) (void)hipHostFree(c->h_U);
     (void)hipFree(c->blk_own);
+    (void)hipFree(c->d_sync);
+    if (c->h_sync) (void)hipHostFree(c->h_sync);
     if (c->h_blk) (void)hipHostFree(c->h_blk);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -145,6 +159,13 @@ KK_API int kk_ctx_set_option(kk_ctx c, const char* key, double value) {
         c->keep_mb = (int)value;
     } else if (!strcmp(key, "fuse_passes")) {
         c->fuse_passes = value != 0;
+    } else if (!strcmp(key, "mgs_persist")) {
+        c->mgs_persist = value != 0;
+    } else if (!strcmp(key, "persist_threads")) {
+        KK_CHECK(value == 512 || value == 1024, KK_ERR_INVALID, "persist_threads must be 512 or 1024");
+        c->persist_threads = (int)value;
+    } else if (!strcmp(key, "persist_nt")) {
+        c->persist_nt = value != 0;
     } else if (!strcmp(key, "block_mode")) {
         KK_CHECK(value == 0 || value == 1, KK_ERR_INVALID, "block_mode must be 0 (strict) or 1 (panel)");
         c->block_mode = (int)value;
@@ -162,6 +183,9 @@ KK_API int kk_ctx_get_option(kk_ctx c, const char* key, double* value) {
     else if (!strcmp(key, "block_mode")) *value = c->block_mode;
     else if (!strcmp(key, "keep_mb")) *value = c->keep_mb;
     else if (!strcmp(key, "fuse_passes")) *value = c->fuse_passes;
+    else if (!strcmp(key, "mgs_persist")) *value = c->mgs_persist;
+    else if (!strcmp(key, "persist_threads")) *value = c->persist_threads;
+    else if (!strcmp(key, "persist_nt")) *value = c->persist_nt;
     else if (!strcmp(key, "speculate")) *value = c->speculate;
     else {
         kk_set_error("unknown option '%s'", key);

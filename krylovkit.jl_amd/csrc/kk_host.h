@@ -56,6 +56,9 @@ int orth_vec_run(kk_ctx c, const double* q, double* w, int64_t ld, kk_orth_t alg
 // one strict MGS sweep over V[0:m) with the fused axpy+dot kernel; coefficients land in the scalar workspace at ws_s
 int pass_mgs_strict(kk_ctx c, const double* V, int64_t ld, int m, double* w, int64_t ws_s, bool want_norm, int slot,
                     const double* carry_q, const double* carry_s, bool leave_carry);
+int pass_mgs_strict_sweeps(kk_ctx c, const double* V, int64_t ld, int m, int nsweeps, double* w, const int64_t* ws_s,
+                           bool want_norm, int slot, const double* carry_q, const double* carry_s);
+int persist_check(kk_ctx c);
 int gram_ensure(kk_basis b, int upto /* exclusive */);
 int gram_device(kk_basis b);   // device mirror of the host Gram rows (created on first use)
 int lowsync_project_dev(kk_basis b, int m, const double* w, const double* pre_vec, const double* pre_a,

@@ -13,6 +13,9 @@
 #define KK_BLK_SCRATCH 131072 // doubles of device/pinned scratch for block matrices (gram panels, S)
 #define KK_STAGE_SLOTS 8      // ring of coefficient-panel staging slots inside the block scratch (first half)
 #define KK_STAGE_DOUBLES 4096  // doubles per slot (KK_MAX_M rows x 16)
+// synchronisation area of the persistent strict-MGS kernel: 2 granule sets x 2 granules per block (8 bytes each) + error flag
+#define KK_SYNC_ERR_OFFSET (4 * KK_MAX_BLOCKS * 8)
+#define KK_SYNC_BYTES (KK_SYNC_ERR_OFFSET + 64)
 #define KK_TPB 256            // threads per block of every streaming kernel (4 waves)
 #define KK_SUB 512            // rows covered by one block sub-step: 256 threads x 2 rows (16 B/lane)
 // register tile of the two basis-streaming kernels: RG sub-steps of 512 rows per row group (2*RG rows per
@@ -112,6 +115,12 @@ struct kk_ctx_s {
     int mgs_mode = 1;
     int keep_mb = 160;           // MB of trailing basis columns a project pass leaves cache-allocated for the unproject
                                  // pass that follows (the Infinity Cache holds 256 MB); 0 = all loads non-temporal
+    int mgs_persist = 1;         // strict MGS sweeps through the persistent register-resident kernel when the vector fits
+    int persist_threads = 1024;  // threads per block (= per CU) of that kernel: 1024 (<= 40 doubles of w per thread) or 512 (<= 80)
+    int persist_nt = 1;          // second read of a basis vector (served by the Infinity Cache) with non-temporal loads
+    void* d_sync = nullptr;      // device: hand-off granules + error flag of the in-kernel grid reduction (KK_SYNC_BYTES)
+    int* h_sync = nullptr;       // pinned: read-back of the error flag
+    bool persist_pending = false;  // a persistent launch has not been checked for a barrier timeout yet
     int fuse_passes = 1;         // fuse unproject(pass i) with project(pass i+1)
     int speculate = 1;           // enqueue the next expand's SpMV before syncing the host
     kk_basis spec_owner = nullptr;   // basis whose speculative result currently sits in SC_SPECA / its next column
@@ -331,6 +340,9 @@ int kk_launch_lsmr_u(kk_ctx ctx, const double* av, double* ah, double* u, int64_
                      double* nrm_out3);
 int kk_launch_lsmr_hx(kk_ctx ctx, double* h, double* hbar, double* x, const double* v, int64_t ld, double c1, double c2,
                       double c3);
+bool kk_mgs_persist_eligible(kk_ctx ctx, int64_t ld, int m, int nsweeps);
+int kk_launch_mgs_persist(kk_ctx ctx, const double* V, int64_t ld, int m, int nsweeps, double* w, const double* carry_q,
+                          const double* carry_s, double* out_s, int out_stride, double* nrm_out3);
 int kk_launch_lanczos_coef(kk_ctx ctx, const double* buf, double* L, int cap, int m, int lowsync, double* coef_out, double* res);
 int kk_launch_norm_scalars(kk_ctx ctx, const double* nrm2, double* sc, double* res2);
 int kk_launch_lowsync_solve(kk_ctx ctx, const double* p, const double* g_ride, double* L, int cap, int m, int newest,

@@ -1,0 +1,243 @@
+// Persistent cooperative kernel for the STRICT modified Gram-Schmidt sweep (SURVEY.md 8(a) row a6, section 7 hard part (b)):
+// the reference's sequential order  for q in V: s = <q, w>; w -= s q   (src/orthonormal.jl:414-439, used by
+// lanczosrecurrence MGS2 at factorizations/lanczos.jl:325-338 and by arnoldirecurrence!! through orthogonalize!!)
+// with the work vector w RESIDENT IN REGISTERS for the whole sweep.
+//
+//   * grid = one block per CU (co-resident: cooperative launch), PT threads each; thread t of block b owns the rows
+//     ((i*G + b)*PT + t)*2 + {0,1}, i < NV, i.e. NV double2 = 2*NV doubles of w in VGPRs.  256 CUs x 1024 threads x 40
+//     doubles = 10.48 M rows: the whole 10M-row work vector of BASELINE.json configs[1] lives on chip (80 MB of the
+//     128 MB of vector registers).
+//   * step j streams q_{j-1} and q_j once each:  w -= s_{j-1} q_{j-1}  (the pending axpy, as k_mgs_step fuses it) and the
+//     partial <q_j, w>.  q_j was read one step earlier as the "next" vector with cache-allocating loads, so its second read
+//     is served by the 256 MB Infinity Cache; HBM sees every basis vector ONCE per sweep (8 N bytes per vector instead of
+//     the 32 N of the launch-per-vector kernel and the 16 N of the projection-based passes), w twice per sweep (16 N).
+//   * the global inner product needs every block: one deterministic grid reduction per vector -- per-block partial ->
+//     agent-scope release/acquire counter -> every block sums the G partials in the same fixed order (bitwise identical
+//     s on all blocks, bitwise reproducible run to run).  Every spin is bounded by the wall clock: on a timeout the error
+//     flag is raised, no block writes w back (HBM still holds the input) and the host reports the failure.
+#include "kk_internal.h"
+#include "kk_device.h"
+
+#define KK_PERSIST_TIMEOUT_TICKS 300000000ll   // 3 s of the 100 MHz wall clock
+#define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+typedef unsigned long long gu64;
+
+template <int NW>
+__device__ __forceinline__ double block_sum_w(double v, double* sm /* >= NW doubles */) {
+    v = wave_sum(v);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) sm[wave] = v;
+    __syncthreads();
+    double t = 0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) t += sm[i];   // fixed order: identical bits in every thread
+    __syncthreads();
+    return t;
+}
+
+// Sum of `acc` over all threads of all blocks (every block is resident: one per CU).  Data-tagged hand-off
+// (cdna_hip_programming.md Guideline 16, form R2 / "allgather"): a block publishes its partial as two naturally aligned
+// 8-byte granules {tag = epoch, 32 bits of the double}, each written by ONE write-through (sc1) store -- the data is the
+// flag, no counter, no fence; wave 0 of every block sweeps the 2G granules with relaxed agent-scope loads until every tag
+// equals the epoch and adds the partials in a fixed order, so all blocks obtain the same bits.  Two granule sets are used
+// alternately (epoch parity): a fast block can publish step s+1 while a slow one still sweeps step s; it cannot reach
+// step s+2 before the slow one has published s+1, i.e. has finished that sweep.  Returns false on a timeout.
+template <int PT>
+__device__ __forceinline__ bool grid_sum(double acc, int step, gu64* __restrict__ gran, int* __restrict__ err, double* sm,
+                                         double* out) {
+    const int G = gridDim.x;
+    const double v = block_sum_w<PT / 64>(acc, sm);
+    const unsigned epoch = (unsigned)step + 1u;
+    gu64* g = gran + (size_t)(step & 1) * 2 * G;
+    if (threadIdx.x == 0) {
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+        __hip_atomic_store(g + 2 * blockIdx.x, ((unsigned long long)epoch << 32) | (bits >> 32), RLX_AGENT);
+        __hip_atomic_store(g + 2 * blockIdx.x + 1, ((unsigned long long)epoch << 32) | (bits & 0xffffffffull), RLX_AGENT);
+    }
+    if (threadIdx.x < 64) {   // wave 0 sweeps
+        const int lane = threadIdx.x;
+        const long long t0 = wall_clock64();
+        double total = 0;
+        int good = 1;
+        for (;;) {
+            bool ok = true;
+            double x = 0;
+            for (int b = lane; b < G; b += 64) {
+                const unsigned long long hi = __hip_atomic_load(g + 2 * b, RLX_AGENT);
+                const unsigned long long lo = __hip_atomic_load(g + 2 * b + 1, RLX_AGENT);
+                ok = ok && (unsigned)(hi >> 32) == epoch && (unsigned)(lo >> 32) == epoch;
+                x += __longlong_as_double((long long)(((hi & 0xffffffffull) << 32) | (lo & 0xffffffffull)));
+            }
+            if (__all(ok)) { total = wave_sum(x); break; }
+            __builtin_amdgcn_s_sleep(1);
+            if (wall_clock64() - t0 > KK_PERSIST_TIMEOUT_TICKS || __hip_atomic_load(err, RLX_AGENT)) { good = 0; break; }
+        }
+        if (lane == 0) {
+            if (!good) __hip_atomic_store(err, 1, RLX_AGENT);
+            sm[0] = total;
+            sm[1] = good ? 1.0 : 0.0;
+        }
+    }
+    __syncthreads();
+    const double total = sm[0];
+    const bool good = sm[1] != 0.0;
+    __syncthreads();
+    *out = total;
+    return good;
+}
+
+// Row ownership: grid-row i (i < NV) is the contiguous span [i*stride, (i+1)*stride) of the vector, stride = G*PT*2; thread
+// t of block b owns the double2 at element offset (b*PT + t)*2 inside every grid-row.  All streams go through buffer
+// descriptors (base = the column, num_records = ld*8 bytes): the lane part of the address is ONE 32-bit byte offset shared
+// by all loads, the grid-row part a scalar offset, and rows beyond ld read as zero / are not written (hardware bounds
+// check) -- no per-load 64-bit address registers and no tail masks, which is what lets 40 doubles of w per thread live in
+// the 128 registers of a 1024-thread block.
+__device__ __forceinline__ d2 bload(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, bool nt) {
+    const v4u t = nt ? __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 2) : __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    d2 o;
+    o.x = __longlong_as_double((long long)(((unsigned long long)t.y << 32) | t.x));
+    o.y = __longlong_as_double((long long)(((unsigned long long)t.w << 32) | t.z));
+    return o;
+}
+__device__ __forceinline__ void bstore(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, d2 v) {
+    const unsigned long long a = (unsigned long long)__double_as_longlong(v.x), b = (unsigned long long)__double_as_longlong(v.y);
+    v4u t;
+    t.x = (unsigned)a; t.y = (unsigned)(a >> 32); t.z = (unsigned)b; t.w = (unsigned)(b >> 32);
+    __builtin_amdgcn_raw_buffer_store_b128(t, r, voff, soff, 0);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t col_rsrc(const double* p, int64_t ld) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (int)(ld * 8), 0x00020000);
+}
+
+// x -= s*p with the result tied to x's own registers: left to the register allocator the updated work vector migrates
+// into the registers of the loaded operand, old and new copies overlap and the 40-doubles-per-thread budget is lost to
+// copies (measured: 164 spilled registers at NV = 20 without this)
+__device__ __forceinline__ void fnma_inplace(double& x, double s, double p) {
+    asm("v_fma_f64 %0, -%1, %2, %0" : "+v"(x) : "v"(s), "v"(p));
+}
+
+template <int NV, int B, bool NTPREV, bool NORM /* false: axpy + dot with q_next, true: axpy + squared norm */>
+__device__ __forceinline__ void persist_step(d2 (&wr)[NV], __amdgpu_buffer_rsrc_t rp, __amdgpu_buffer_rsrc_t rn, double sp,
+                                             unsigned sbytes, unsigned voff, double& a0, double& a1) {
+#pragma unroll
+    for (int i0 = 0; i0 < NV; i0 += B) {
+        d2 p[B], q[B];
+#pragma unroll
+        for (int u = 0; u < B; ++u) {
+            if (i0 + u < NV) {
+                p[u] = bload(rp, voff, (unsigned)(i0 + u) * sbytes, NTPREV);
+                if (!NORM) q[u] = bload(rn, voff, (unsigned)(i0 + u) * sbytes, false);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < B; ++u) {
+            if (i0 + u < NV) {
+                d2& x = wr[i0 + u];
+                fnma_inplace(x.x, sp, p[u].x);
+                fnma_inplace(x.y, sp, p[u].y);
+                const d2 y = NORM ? x : q[u];
+                if (u & 1) { a1 = fma(y.x, x.x, a1); a1 = fma(y.y, x.y, a1); }
+                else { a0 = fma(y.x, x.x, a0); a0 = fma(y.y, x.y, a0); }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);   // keep the loads of one batch together: w stays the only long-lived register set
+    }
+}
+
+// nsweeps strict MGS sweeps of w against V[:, 0:m) (+ an optional pending axpy w -= *carry_s * carry_q in front, + the
+// squared norm of the result).  out_s[sweep * out_stride + j] = coefficient of sweep `sweep`, vector j.
+// Every step has the same shape -- pending axpy with (q_prev, s_prev), then the inner product with q_next -- so that the
+// work vector stays in ONE register set through the loop; a step with nothing pending (the first one without a carry)
+// runs the axpy with s_prev = 0 against a column of V.
+template <int NV, int PT, bool NTPREV>
+__global__ __launch_bounds__(PT) void k_mgs_persist(const double* __restrict__ V, int64_t ld, int m, int nsweeps,
+                                                    double* __restrict__ w, const double* __restrict__ carry_q,
+                                                    const double* __restrict__ carry_s, double* __restrict__ out_s,
+                                                    int out_stride, double* __restrict__ nrm_out3,
+                                                    gu64* __restrict__ gran, int* __restrict__ err) {
+    __shared__ double sm[PT / 64];
+    constexpr int B = (PT == 1024 && NV > 16) ? 2 : 4;   // loads in flight per stream and lane; 128-register budget at 1024 threads
+    const unsigned sbytes = gridDim.x * PT * 16u;                      // one grid-row in bytes
+    const unsigned voff = (blockIdx.x * PT + threadIdx.x) * 16u;       // this lane's byte offset inside a grid-row
+    const __amdgpu_buffer_rsrc_t rw = col_rsrc(w, ld);
+    d2 wr[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) wr[i] = bload(rw, voff, (unsigned)i * sbytes, false);
+    const double* qp = carry_q ? carry_q : V;   // nothing pending: s_prev = 0 against a (finite) basis column
+    double sp = carry_q ? *carry_s : 0.0;
+    const int nsteps = m * nsweeps;
+    for (int s = 0; s < nsteps; ++s) {
+        const double* qn = V + (int64_t)(s % m) * ld;
+        double a0 = 0, a1 = 0, total;
+        persist_step<NV, B, NTPREV, false>(wr, col_rsrc(qp, ld), col_rsrc(qn, ld), sp, sbytes, voff, a0, a1);
+        if (!grid_sum<PT>(a0 + a1, s, gran, err, sm, &total)) return;   // timeout: w in HBM is untouched
+        if (blockIdx.x == 0 && threadIdx.x == 0) out_s[(s / m) * out_stride + (s % m)] = total;
+        sp = total;
+        qp = qn;
+    }
+    {   // last pending axpy, fused with the squared norm of the result
+        double a0 = 0, a1 = 0, total;
+        persist_step<NV, B, NTPREV, true>(wr, col_rsrc(qp, ld), col_rsrc(qp, ld), sp, sbytes, voff, a0, a1);
+        if (nrm_out3) {
+            if (!grid_sum<PT>(a0 + a1, nsteps, gran, err, sm, &total)) return;
+            if (blockIdx.x == 0 && threadIdx.x == 0) {
+                const double rt = sqrt(total);
+                nrm_out3[0] = total; nrm_out3[1] = rt; nrm_out3[2] = 1.0 / rt;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) bstore(rw, voff, (unsigned)i * sbytes, wr[i]);
+}
+
+// ---- launcher ------------------------------------------------------------------------------
+// Eligible when the vector fits the register file of the chip (NV <= 20 double2 per thread at 1024 threads per CU), the
+// step counters fit the synchronisation area and the context is not row-sharded (a sharded sweep needs one all-reduce
+// per vector, which cannot be issued from inside a kernel).
+bool kk_mgs_persist_eligible(kk_ctx ctx, int64_t ld, int m, int nsweeps) {
+    if (!ctx->mgs_persist || kk_sharded(ctx) || !ctx->d_sync) return false;
+    if (ctx->num_cus > KK_MAX_BLOCKS || ld * 8 >= ((int64_t)1 << 31)) return false;
+    const int pt = ctx->persist_threads;
+    const int64_t per_thread2 = (ld + (int64_t)ctx->num_cus * pt * 2 - 1) / ((int64_t)ctx->num_cus * pt * 2);
+    return per_thread2 <= (pt == 1024 ? 20 : 40);
+}
+
+template <int NV, int PT>
+static int launch_persist(kk_ctx ctx, void** args, bool ntprev) {
+    const dim3 g(ctx->num_cus), b(PT);
+    hipError_t e = ntprev ? hipLaunchCooperativeKernel((const void*)k_mgs_persist<NV, PT, true>, g, b, args, 0, ctx->stream)
+                          : hipLaunchCooperativeKernel((const void*)k_mgs_persist<NV, PT, false>, g, b, args, 0, ctx->stream);
+    if (e != hipSuccess) return kk_hip_fail(e, "hipLaunchCooperativeKernel(k_mgs_persist)", __FILE__, __LINE__);
+    return KK_OK;
+}
+
+int kk_launch_mgs_persist(kk_ctx ctx, const double* V, int64_t ld, int m, int nsweeps, double* w, const double* carry_q,
+                          const double* carry_s, double* out_s, int out_stride, double* nrm_out3) {
+    const int pt = ctx->persist_threads;
+    const int nv = (int)((ld + (int64_t)ctx->num_cus * pt * 2 - 1) / ((int64_t)ctx->num_cus * pt * 2));
+    // granules: 2 sets x 2 per block, zeroed (tag 0 = never a valid epoch) before every launch, followed by the error flag
+    unsigned long long* gran = (unsigned long long*)ctx->d_sync;
+    int* err = (int*)((char*)ctx->d_sync + KK_SYNC_ERR_OFFSET);
+    KK_HIP(hipMemsetAsync(gran, 0, (size_t)4 * ctx->num_cus * sizeof(unsigned long long), ctx->stream));
+    void* args[] = {(void*)&V, (void*)&ld, (void*)&m, (void*)&nsweeps, (void*)&w, (void*)&carry_q, (void*)&carry_s,
+                    (void*)&out_s, (void*)&out_stride, (void*)&nrm_out3, (void*)&gran, (void*)&err};
+    const bool nt = ctx->persist_nt != 0;
+    kk_prof_scope ps(ctx, "k_mgs_persist");
+    if (pt == 1024) {
+        if (nv <= 4) return launch_persist<4, 1024>(ctx, args, nt);
+        if (nv <= 8) return launch_persist<8, 1024>(ctx, args, nt);
+        if (nv <= 12) return launch_persist<12, 1024>(ctx, args, nt);
+        if (nv <= 16) return launch_persist<16, 1024>(ctx, args, nt);
+        if (nv <= 20) return launch_persist<20, 1024>(ctx, args, nt);
+    } else {
+        if (nv <= 8) return launch_persist<8, 512>(ctx, args, nt);
+        if (nv <= 16) return launch_persist<16, 512>(ctx, args, nt);
+        if (nv <= 24) return launch_persist<24, 512>(ctx, args, nt);
+        if (nv <= 32) return launch_persist<32, 512>(ctx, args, nt);
+        if (nv <= 40) return launch_persist<40, 512>(ctx, args, nt);
+    }
+    kk_set_error("kk_launch_mgs_persist: vector of %lld rows does not fit the register file", (long long)ld);
+    return KK_ERR_UNSUPPORTED;
+}

@@ -257,9 +257,13 @@ KK_API int kk_lanczos_expand(kk_op op, kk_basis b, int c0, int k, kk_orth_t orth
         passes = 1;
     } else if (orth == KK_MGS2) {
         // strict: w -= alpha0 v fused with the first dot of the sweep   lanczos.jl:329-334
-        KK_TRY(pass_mgs_strict(c, V, ld, m, w, WS_S, true, 0, v, a0_dev, false));
+        const int64_t offs[1] = {WS_S};
+        KK_TRY(pass_mgs_strict_sweeps(c, V, ld, m, 1, w, offs, true, 0, v, a0_dev));
         KK_TRY(ws_fetch_async(c, WS_SCAL, 1, 0));
-        KK_TRY(stream_sync(c));
+        KK_TRY(fetch_mark(c));
+        if (!kk_sharded(c)) KK_TRY(speculate_next(op, b, c0, k + 1, 2, true, 0.0));   // |w| and 1/|w| are on the device
+        KK_TRY(fetch_wait(c));
+        KK_TRY(persist_check(c));
         a = pin(c, WS_SCAL + SC_ALPHA0)[0] + pin(c, WS_S)[m - 1];
         bt = pin(c, WS_SCAL + SC_NRM2)[1];
         passes = 1;

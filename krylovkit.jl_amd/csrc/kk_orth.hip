@@ -178,6 +178,52 @@ int pass_mgs_strict(kk_ctx c, const double* V, int64_t ld, int m, double* w, int
     KK_TRY(ws_fetch_async(c, ws_s, m, slot));
     return KK_OK;
 }
+// `nsweeps` (1 or 2) strict MGS sweeps; sweep i leaves its coefficients at ws[ws_s[i] ..] (fetched into pinned slot
+// `slot`).  When the work vector fits the register file of the chip the whole thing is ONE launch of the persistent
+// kernel (w resident on chip, every basis vector read once from HBM per sweep); otherwise one fused axpy+dot launch
+// per basis vector.  The order of operations -- and therefore every bit of the result -- is the same on both routes
+// up to the summation order inside an inner product.
+int pass_mgs_strict_sweeps(kk_ctx c, const double* V, int64_t ld, int m, int nsweeps, double* w, const int64_t* ws_s,
+                           bool want_norm, int slot, const double* carry_q, const double* carry_s) {
+    if (m > 0 && kk_mgs_persist_eligible(c, ld, m, nsweeps)) {
+        // both sweeps' coefficient areas must be addressable as out_s + sweep * stride
+        const int stride = nsweeps > 1 ? (int)(ws_s[1] - ws_s[0]) : KK_MAX_M;
+        if (stride >= m) {
+            KK_TRY(kk_launch_mgs_persist(c, V, ld, m, nsweeps, w, carry_q, carry_s, WSP(c, ws_s[0]), stride,
+                                         want_norm ? SCP(c, SC_NRM2) : nullptr));
+            int* err = (int*)((char*)c->d_sync + KK_SYNC_ERR_OFFSET);
+            KK_HIP(hipMemcpyAsync(c->h_sync, err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            c->persist_pending = true;
+            for (int i = 0; i < nsweeps; ++i) KK_TRY(ws_fetch_async(c, ws_s[i], m, slot));
+            if (want_norm) KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2, 2, slot));
+            return KK_OK;
+        }
+    }
+    const double* cq = carry_q;
+    const double* cs = carry_s;
+    for (int i = 0; i < nsweeps; ++i) {
+        const bool last = (i == nsweeps - 1);
+        KK_TRY(pass_mgs_strict(c, V, ld, m, w, ws_s[i], last && want_norm, slot, cq, cs, !last));
+        cq = V + (int64_t)(m - 1) * ld;
+        cs = c->ws + ws_s[i] + m - 1;
+    }
+    return KK_OK;
+}
+// after the host synchronisation that follows a persistent launch: did its grid barrier time out?
+int persist_check(kk_ctx c) {
+    if (!c->persist_pending) return KK_OK;
+    c->persist_pending = false;
+    if (c->h_sync[0] != 0) {
+        c->h_sync[0] = 0;
+        (void)hipMemsetAsync((char*)c->d_sync + KK_SYNC_ERR_OFFSET, 0, sizeof(int), c->stream);
+        c->mgs_persist = 0;   // the caller may retry: the work vector in HBM was not modified
+        kk_set_error("persistent MGS kernel: grid barrier timed out (GPU shared with another job?); the work vector is "
+                     "unchanged, the persistent route is now disabled for this context -- repeat the call");
+        return KK_ERR_HIP;
+    }
+    return KK_OK;
+}
+
 // Projection for the low-sync MGS: p = V'(w - a*pre) into pinned slot `slot` (synchronised on
 // return).  The Gram row of the newest basis vector (column c0+m-1) rides along as a second
 // right-hand side of the same kernel when it is the only row missing -- no extra pass over V.
@@ -324,8 +370,10 @@ int orth_run(kk_basis b, int c0, int m, double* w, kk_orth_t alg, double eta, do
                 KK_TRY(pass_mgs_lowsync(b, c0, m, w, x, want_norm, 0));
                 KK_TRY(final_sync(c));
             } else {
-                KK_TRY(pass_mgs_strict(c, V, ld, m, w, WS_S, want_norm, 0, nullptr, nullptr, false));
+                const int64_t offs[1] = {WS_S};
+                KK_TRY(pass_mgs_strict_sweeps(c, V, ld, m, 1, w, offs, want_norm, 0, nullptr, nullptr));
                 KK_TRY(final_sync(c));
+                KK_TRY(persist_check(c));
                 memcpy(x, pin(c, WS_S, 0), m * sizeof(double));
             }
             nn = pin(c, WS_SCAL + SC_NRM2, 0)[1];
@@ -355,10 +403,10 @@ int orth_run(kk_basis b, int c0, int m, double* w, kk_orth_t alg, double eta, do
                 for (int j = 0; j < m; ++j) x[j] += tmp[j];
             } else {
                 // the last axpy of sweep 1 is fused with the first dot of sweep 2
-                KK_TRY(pass_mgs_strict(c, V, ld, m, w, WS_S, false, 0, nullptr, nullptr, true));
-                KK_TRY(pass_mgs_strict(c, V, ld, m, w, WS_G, want_norm, 0, V + (int64_t)(m - 1) * ld,
-                                       c->ws + WS_S + m - 1, false));
+                const int64_t offs[2] = {WS_S, WS_G};
+                KK_TRY(pass_mgs_strict_sweeps(c, V, ld, m, 2, w, offs, want_norm, 0, nullptr, nullptr));
                 KK_TRY(final_sync(c));
+                KK_TRY(persist_check(c));
                 for (int j = 0; j < m; ++j) x[j] = pin(c, WS_S, 0)[j] + pin(c, WS_G, 0)[j];
             }
             nn = pin(c, WS_SCAL + SC_NRM2, 0)[1];
@@ -367,9 +415,11 @@ int orth_run(kk_basis b, int c0, int m, double* w, kk_orth_t alg, double eta, do
         case KK_MGSIR: {  // :440-452
             KK_TRY(kk_launch_nrm2(c, w, ld, SCP(c, SC_NRM2B)));
             KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2B, 2, 1));
+            const int64_t ir_offs[1] = {WS_S};
             if (lowsync) KK_TRY(pass_mgs_lowsync(b, c0, m, w, x, true, 0));
-            else KK_TRY(pass_mgs_strict(c, V, ld, m, w, WS_S, true, 0, nullptr, nullptr, false));
+            else KK_TRY(pass_mgs_strict_sweeps(c, V, ld, m, 1, w, ir_offs, true, 0, nullptr, nullptr));
             KK_TRY(stream_sync(c));
+            KK_TRY(persist_check(c));
             double nold = pin(c, WS_SCAL + SC_NRM2B, 1)[1];
             if (!lowsync) memcpy(x, pin(c, WS_S, 0), m * sizeof(double));
             nn = pin(c, WS_SCAL + SC_NRM2, 0)[1];
@@ -377,8 +427,9 @@ int orth_run(kk_basis b, int c0, int m, double* w, kk_orth_t alg, double eta, do
             while (KK_EPS < nn && nn < eta * nold) {
                 nold = nn;
                 if (lowsync) KK_TRY(pass_mgs_lowsync(b, c0, m, w, tmp.data(), true, 0));
-                else KK_TRY(pass_mgs_strict(c, V, ld, m, w, WS_S, true, 0, nullptr, nullptr, false));
+                else KK_TRY(pass_mgs_strict_sweeps(c, V, ld, m, 1, w, ir_offs, true, 0, nullptr, nullptr));
                 KK_TRY(stream_sync(c));
+                KK_TRY(persist_check(c));
                 for (int j = 0; j < m; ++j) x[j] += lowsync ? tmp[j] : pin(c, WS_S, 0)[j];
                 nn = pin(c, WS_SCAL + SC_NRM2, 0)[1];
                 ++passes;
