@@ -318,6 +318,89 @@ KK_API int kk_blocklanczos_initialize(kk_op op, kk_basis b, int c_x0, int bs0, i
     return KK_OK;
 }
 
+// device-side layout of the asynchronous block step inside the second half of the block scratch (doubles)
+#define AB_BASE (KK_BLK_SCRATCH / 2 + 64)
+#define AB_FLAG (AB_BASE)            // [4]   0 = fine, 1 / 2 = a CholQR2 safety test failed
+#define AB_NRM (AB_BASE + 4)         // [16]  squared column norms of the new residual block
+#define AB_B (AB_BASE + 20)          // [256] B = R2 R1, column-major ld 16
+#define AB_M (AB_BASE + 276)         // [256] M = X' A X, column-major ld 16
+#define AB_READBACK 532              // flag + norms + B + M travel to the host in ONE copy
+#define AB_G (AB_BASE + 532)         // [256] Gram panels of the two CholQR2 rounds
+#define AB_R1 (AB_BASE + 788)        // [256]
+#define AB_S1 (AB_BASE + 1044)       // [256] staged R1^-1
+#define AB_S2 (AB_BASE + 1300)       // [256] staged R2^-1
+#define AB_S3 (AB_BASE + 1556)       // [512] three-term panel [B' ; M]
+#define AB_P (AB_BASE + 2068)        // [KK_MAX_M * 16] re-orthogonalisation panel V'(AX), row-major
+#define AB_END (AB_P + KK_MAX_M * 16)
+static_assert(AB_END <= KK_BLK_SCRATCH, "block scratch too small for the asynchronous block step");
+
+// expand!(::BlockLanczosIterator) without a host round trip between its kernels (panel mode, 2 <= block size <= 16, no rank
+// drop, no DGKS drift): CholQR2 of the residual block with both Cholesky factorisations, the triangular inverses and
+// every coefficient panel formed ON THE DEVICE, the Gram panels written straight in the layout the update kernel reads;
+// ONE host synchronisation at the end returns B, M, the column norms and the safety flag.  The input block (c_r) and the
+// basis are not modified, so a raised flag (*fine = false) simply sends the caller to the synchronous route below.
+static int blocklanczos_expand_async(kk_op op, kk_basis b, int k, int p, int c_r, int c_rnext, double qr_tol, double* B,
+                                     int ldb, double* M, int ldm, double* norm_R, bool* fine) {
+    kk_ctx c = b->ctx;
+    const int64_t ld = b->ld;
+    const int st = kk_bu_stride(p);
+    double* D = c->blk;
+    KK_HIP(hipMemsetAsync(D + AB_FLAG, 0, 4 * sizeof(double), c->stream));
+    // ---- block_qr! as CholQR2, out of place: residual block (c_r) -> new basis block (columns k..k+p-1)
+    KK_TRY(kk_launch_block_gram(c, b->col(c_r), ld, p, b->col(c_r), ld, p, ld, D + AB_G, p));
+    KK_TRY(kk_allreduce(c, D + AB_G, (int64_t)p * p));
+    KK_TRY(kk_launch_blk_chol1(c, D + AB_G, p, 1000.0 * qr_tol, D + AB_R1, D + AB_S1, st, D + AB_FLAG));
+    if (c->block_fuse & 1) {   // Q1 = B R1^-1 written and G2 = Q1'Q1 accumulated in ONE pass over the block
+        KK_TRY(kk_launch_block_gram_tile(c, nullptr, 0, p, nullptr, 0, b->col(c_r), ld, p, D + AB_S1, st, 1.0, 0.0, b->col(k), ld, p,
+                                         ld, D + AB_G, 1, p));
+    } else {
+        KK_TRY(kk_launch_block_update(c, b->col(c_r), ld, p, nullptr, b->col(k), ld, ld, p, D + AB_S1, 1.0, 0.0, nullptr));
+        KK_TRY(kk_launch_block_gram(c, b->col(k), ld, p, b->col(k), ld, p, ld, D + AB_G, p));
+    }
+    KK_TRY(kk_allreduce(c, D + AB_G, (int64_t)p * p));
+    KK_TRY(kk_launch_blk_chol2(c, D + AB_G, p, D + AB_R1, D + AB_B, 16, D + AB_S2, D + AB_S3, st, D + AB_FLAG));
+    KK_TRY(kk_launch_block_update(c, b->col(k), ld, p, nullptr, b->col(k), ld, ld, p, D + AB_S2, 1.0, 0.0, nullptr));  // Q = Q1 R2^-1 in place (row-local)
+    // ---- block_lanczosrecurrence: AX = A X ; M = X' AX ; AX -= [Xprev X] [B' ; M]
+    double* AX = b->col(c_rnext);
+    KK_TRY(kk_launch_spmm(c, op->A, b->col(k), ld, AX, ld, p));
+    KK_TRY(kk_launch_block_gram(c, b->col(k), ld, p, AX, ld, p, ld, D + AB_M, 16));
+    KK_TRY(kk_allreduce(c, D + AB_M, 256));
+    KK_TRY(kk_launch_blk_fill_m(c, D + AB_M, 16, p, D + AB_S3, st));
+    const int kn = k + p;
+    KK_CHECK(kn <= KK_MAX_M, KK_ERR_UNSUPPORTED, "block step: %d basis vectors exceed the panel limit", kn);
+    if (c->block_fuse & 2) {
+        // P = V'(AX - [Xprev X] S3) with the three-term result formed on the fly (never written); the update below then
+        // subtracts V (P + [0; S3]) from the original AX:  AX - [Xprev X] S3 - V P
+        for (int i0 = 0; i0 < kn; i0 += 128)
+            KK_TRY(kk_launch_block_gram_tile(c, b->col(i0), ld, std::min(128, kn - i0), AX, ld, b->col(k - p), ld, 2 * p, D + AB_S3, st,
+                                             -1.0, 1.0, nullptr, 0, p, ld, D + AB_P + (int64_t)i0 * st, st, 1));
+        KK_TRY(kk_allreduce(c, D + AB_P, (int64_t)kn * st));
+        KK_TRY(kk_launch_blk_combine(c, D + AB_P, D + AB_S3, kn, 2 * p, st));
+    } else {
+        KK_TRY(kk_launch_block_update(c, b->col(k - p), ld, 2 * p, AX, AX, ld, ld, p, D + AB_S3, -1.0, 1.0, nullptr));
+        // ---- block_reorthogonalize!(AX, V): P = V' AX written row-major = the update's coefficient panel; fused column norms
+        for (int i0 = 0; i0 < kn; i0 += 128)
+            KK_TRY(kk_launch_block_gram_rs(c, b->col(i0), ld, std::min(128, kn - i0), AX, ld, p, ld, D + AB_P + (int64_t)i0 * st, st, 1));
+        KK_TRY(kk_allreduce(c, D + AB_P, (int64_t)kn * st));
+    }
+    KK_TRY(kk_launch_block_update(c, b->col(0), ld, kn, AX, AX, ld, ld, p, D + AB_P, -1.0, 1.0, D + AB_NRM));
+    // ---- the one read-back
+    KK_HIP(hipMemcpyAsync(c->h_blk + AB_BASE, D + AB_BASE, AB_READBACK * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    KK_TRY(stream_sync(c));
+    const double* H = c->h_blk + AB_BASE;
+    *fine = (H[0] == 0.0);
+    if (!*fine) return KK_OK;
+    for (int j = 0; j < p; ++j)
+        for (int i = 0; i < p; ++i) {
+            B[i + (size_t)ldb * j] = H[20 + i + 16 * j];
+            M[i + (size_t)ldm * j] = H[276 + i + 16 * j];
+        }
+    double f = 0;
+    for (int j = 0; j < p; ++j) f += H[4 + j];
+    *norm_R = std::sqrt(f);
+    return KK_OK;
+}
+
 KK_API int kk_blocklanczos_expand(kk_op op, kk_basis b, int k, int bs_r, int c_r, int c_rnext, double qr_tol,
                                       int* bs_next, double* B, int ldb, double* M, int ldm, double* norm_R, int* is_drift) {
     KK_TRY(check_square_op(op, b));
@@ -328,6 +411,17 @@ KK_API int kk_blocklanczos_expand(kk_op op, kk_basis b, int k, int bs_r, int c_r
              "kk_blocklanczos_expand: residual blocks must lie beyond column k+bs_r and not overlap");
     kk_ctx c = b->ctx;
     gram_touch(b, k);
+    if (c->block_mode == 1 && c->block_async && bs_r >= 2 && bs_r <= 16 && k + bs_r <= KK_MAX_M) {
+        bool fine = false;
+        if (kk_bu_stride(bs_r) > bs_r)   // pad columns of the row-major panels: zero once, the kernels write only the first bs_r
+            KK_HIP(hipMemsetAsync(c->blk + AB_P, 0, (size_t)(k + bs_r) * kk_bu_stride(bs_r) * sizeof(double), c->stream));
+        KK_TRY(blocklanczos_expand_async(op, b, k, bs_r, c_r, c_rnext, qr_tol, B, ldb, M, ldm, norm_R, &fine));
+        if (fine) {
+            *bs_next = bs_r;
+            if (is_drift) *is_drift = 0;
+            return KK_OK;
+        }   // else: a pivot came close to the rank / DGKS thresholds -- the faithful route decides (inputs untouched)
+    }
     std::vector<int> good(bs_r);
     int ng = 0, drift = 0;
     // B, good_idx, is_drift = block_qr!(R, qr_tol); out of place: the input block stays intact as Rcopy   :209-211

@@ -166,6 +166,19 @@ KK_API int kk_ctx_set_option(kk_ctx c, const char* key, double value) {
         c->persist_threads = (int)value;
     } else if (!strcmp(key, "persist_nt")) {
         c->persist_nt = value != 0;
+    } else if (!strcmp(key, "gram_nt")) {
+        c->gram_nt = value != 0;
+    } else if (!strcmp(key, "block_fuse")) {
+        KK_CHECK(value >= 0 && value <= 3, KK_ERR_INVALID, "block_fuse is a bit mask: 1 = CholQR2 round 2, 2 = three-term + panel");
+        c->block_fuse = (int)value;
+    } else if (!strcmp(key, "block_async")) {
+        c->block_async = value != 0;
+    } else if (!strcmp(key, "bu_prefetch")) {
+        KK_CHECK(value == 0 || value == 1 || value == 8 || value == 16 || value == 24, KK_ERR_INVALID, "bu_prefetch must be 0, 1, 8, 16 or 24");
+        c->bu_prefetch = (int)value;
+    } else if (!strcmp(key, "spmm_bpc")) {
+        KK_CHECK(value >= 0 && value <= 16, KK_ERR_INVALID, "spmm_bpc out of range");
+        c->spmm_bpc = (int)value;
     } else if (!strcmp(key, "block_mode")) {
         KK_CHECK(value == 0 || value == 1, KK_ERR_INVALID, "block_mode must be 0 (strict) or 1 (panel)");
         c->block_mode = (int)value;
@@ -181,6 +194,10 @@ KK_API int kk_ctx_get_option(kk_ctx c, const char* key, double* value) {
     else if (!strcmp(key, "mgs_mode")) *value = c->mgs_mode;
     else if (!strcmp(key, "num_cus")) *value = c->num_cus;
     else if (!strcmp(key, "block_mode")) *value = c->block_mode;
+    else if (!strcmp(key, "block_async")) *value = c->block_async;
+    else if (!strcmp(key, "block_fuse")) *value = c->block_fuse;
+    else if (!strcmp(key, "spmm_bpc")) *value = c->spmm_bpc;
+    else if (!strcmp(key, "bu_prefetch")) *value = c->bu_prefetch;
     else if (!strcmp(key, "keep_mb")) *value = c->keep_mb;
     else if (!strcmp(key, "fuse_passes")) *value = c->fuse_passes;
     else if (!strcmp(key, "mgs_persist")) *value = c->mgs_persist;

@@ -111,6 +111,11 @@ struct kk_ctx_s {
     double* blk = nullptr;       // device scratch for small block matrices [KK_BLK_SCRATCH]
     double* h_blk = nullptr;     // pinned twin of blk
     int block_mode = 1;          // 0 strict, 1 panel (MFMA gram + multi-rhs update)
+    int spmm_bpc = 4;            // resident blocks per CU of the multi-column sparse apply (L2 window, see kk_launch_spmm); 0 = fill the chip
+    int bu_prefetch = 1;         // block update kernel: 1 = coefficient panel in LDS (default), 0 = scalar-load kernel of round 1, 8/16/24 = deep-prefetch experiments
+    int gram_nt = 0;             // Gram panel: non-temporal loads for the X stream
+    int block_fuse = 1;          // asynchronous block step, tile-fused Gram kernels (bit mask): 1 = CholQR2 round 2 (Q1 and its Gram in one pass), 2 = three-term update formed on the fly inside the re-orthogonalisation panel
+    int block_async = 1;         // panel mode: whole block step enqueued without host round trips (device-side CholQR2 algebra)
     int blocks_per_cu = 4;       // 4 resident 256-thread blocks per CU (measured best on the 10M-row sweep)
     int mgs_mode = 1;
     int keep_mb = 160;           // MB of trailing basis columns a project pass leaves cache-allocated for the unproject
@@ -297,6 +302,16 @@ int kk_launch_rank1(kk_ctx ctx, double* V, int64_t ld, int m, const double* y, c
 // ---- block (multi-vector) launchers
 int kk_launch_block_gram(kk_ctx ctx, const double* X, int64_t ldx, int p, const double* Y, int64_t ldy, int q, int64_t ld,
                          double* C_dev, int ldc);
+int kk_launch_block_gram_rs(kk_ctx ctx, const double* X, int64_t ldx, int p, const double* Y, int64_t ldy, int q, int64_t ld,
+                            double* C_dev, int rs, int cs);
+int kk_launch_blk_chol1(kk_ctx ctx, const double* G, int p, double abs_min, double* R1, double* S1, int st, double* flag);
+int kk_launch_blk_chol2(kk_ctx ctx, const double* G2, int p, const double* R1, double* B, int ldb, double* S2, double* S3, int st,
+                        double* flag);
+int kk_launch_blk_fill_m(kk_ctx ctx, const double* M, int ldm, int p, double* S3, int st);
+int kk_launch_blk_combine(kk_ctx ctx, double* P, const double* S3, int kn, int nz, int st);
+int kk_launch_block_gram_tile(kk_ctx ctx, const double* X, int64_t ldx, int p, const double* Yin, int64_t ldy, const double* Z,
+                              int64_t ldz, int nz, const double* S_dev, int st, double alpha, double beta, double* Yout,
+                              int64_t ldyo, int q, int64_t ld, double* C_dev, int rs, int cs);
 // row stride (= kernel width NB) of the coefficient panel handed to kk_launch_block_update for nb right-hand sides
 static inline int kk_bu_stride(int nb) { return nb <= 4 ? 4 : (nb <= 8 ? 8 : 16); }
 int kk_launch_block_update(kk_ctx ctx, const double* V, int64_t ld, int m, const double* Win, double* Wout, int64_t ldw_in,

@@ -18,7 +18,7 @@
 template <int NG>  // NG groups of 16 X-columns
 __global__ __launch_bounds__(KK_TPB) void k_block_gram(const double* __restrict__ X, int64_t ldx, int p,
                                                        const double* __restrict__ Y, int64_t ldy, int q, int64_t ld,
-                                                       int64_t rpb, double* __restrict__ part) {
+                                                       int64_t rpb, double* __restrict__ part, int nt_x) {
     extern __shared__ __attribute__((aligned(16))) double lds[];  // [NG][4][64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, kq = lane >> 4;
@@ -27,6 +27,7 @@ __global__ __launch_bounds__(KK_TPB) void k_block_gram(const double* __restrict_
 #pragma unroll
     for (int g = 0; g < NG; ++g) acc[g] = v4d{0.0, 0.0, 0.0, 0.0};
     const bool yok = c < q;
+    const bool xnt = (X != Y) && nt_x;
     for (int64_t rc = r0 + wave * BG_CHUNK; rc < r1; rc += 4 * BG_CHUNK) {
         // rows of lane (c, kq): {rc + 4t + 2kq, +1 : t = 0,2,4,6}  -- the four lanes of one column read 64
         // contiguous bytes per load instruction (same row -> k-slot map for X and Y, so the contraction is unchanged)
@@ -46,8 +47,13 @@ __global__ __launch_bounds__(KK_TPB) void k_block_gram(const double* __restrict_
             double xv[BG_T];
             if (col < p) {
                 const double* xp = X + (int64_t)col * ldx + row;
+                if (xnt) {   // X is streamed once: non-temporal, as in the single-vector kernels
 #pragma unroll
-                for (int t = 0; t < BG_T; t += 2) { d2 v = ld2(xp + 4 * t); xv[t] = v.x; xv[t + 1] = v.y; }  // plain: X == Y panels re-hit L2
+                    for (int t = 0; t < BG_T; t += 2) { d2 v = ld2s(xp + 4 * t); xv[t] = v.x; xv[t + 1] = v.y; }
+                } else {     // X == Y panels re-hit L2
+#pragma unroll
+                    for (int t = 0; t < BG_T; t += 2) { d2 v = ld2(xp + 4 * t); xv[t] = v.x; xv[t + 1] = v.y; }
+                }
             } else {
 #pragma unroll
                 for (int t = 0; t < BG_T; ++t) xv[t] = 0.0;
@@ -73,9 +79,150 @@ __global__ __launch_bounds__(KK_TPB) void k_block_gram(const double* __restrict_
     for (int e = tid; e < NG * 256; e += KK_TPB) dst[e] = lds[e];
 }
 
+// Gram panel against a tile that is COMPUTED on the fly instead of read:
+//     T(rows, q) = beta * Yin + alpha * Z(rows, nz) S(nz, q)            C = X' T
+//   * three-term update + re-orthogonalisation panel of block_lanczosrecurrence in one pass (blocklanczos.jl:253-260 then
+//     :277-284):  T = AX - [Xprev X][B'; M]  is never written -- the update that follows subtracts V (P + [0; B'; M]) from
+//     the ORIGINAL AX -- which removes one read and one write of the 16-column block per step (and with the write the
+//     read/write mixing penalty: tools/stream_tile.hip, 6.9 TB/s read-only vs 5.1 TB/s with 16 output columns);
+//   * second round of CholQR2:  T = B R1^-1 is stored (STORE) and its Gram matrix T'T accumulated in the same pass (XT).
+// Per 32-row chunk a wave first forms its tile with plain FMAs in row-owner layout (lane = row, 8 columns each, Z read with
+// 256-byte contiguous 8-byte loads, coefficients broadcast from LDS), parks it in a wave-private LDS slab [16][36] and reads
+// it back in the column-owner layout of the MFMA B operand; X is streamed exactly as in k_block_gram.
+#define BGT_LD 36                    // row stride (doubles) of the LDS tile: 16-byte aligned, spreads the columns over the banks
+template <int NG, bool XT, bool STORE, bool HASY>
+__global__ __launch_bounds__(KK_TPB) void k_block_gram_tile(const double* __restrict__ X, int64_t ldx, int p,
+                                                            const double* __restrict__ Yin, int64_t ldy,
+                                                            const double* __restrict__ Z, int64_t ldz, int nz,
+                                                            const double* __restrict__ S, int st, double alpha, double beta,
+                                                            double* __restrict__ Yout, int64_t ldyo, int q, int64_t ld,
+                                                            int64_t rpb, double* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];  // [NG*256] reduction | [nz*16] coefficients | [4][16*BGT_LD] tiles
+    double* csm = lds + NG * 256;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double* tile = csm + 32 * 16 + wave * (16 * BGT_LD);
+    for (int e = tid; e < nz * 16; e += KK_TPB) { const int z = e >> 4, j = e & 15; csm[e] = j < q ? S[(int64_t)z * st + j] : 0.0; }
+    __syncthreads();
+    const int c = lane & 15, kq = lane >> 4;
+    // row-owner layout of phase 1: lane = (row rl of the chunk, half h); half h multiplies the Z columns [h*nzh, (h+1)*nzh)
+    // into all 16 tile columns (no Z element is loaded twice) and brings in the Y columns 8h .. 8h+7; the two partial
+    // tiles are added in the LDS slab.  The loads of the NEXT chunk are issued before the MFMA phase of the current one.
+    const int rl = lane & 31, h = lane >> 5;
+    const int nzh = (nz + 1) >> 1, z0 = h * nzh, zn = (z0 + nzh <= nz) ? nzh : (nz > z0 ? nz - z0 : 0);
+    const int64_t r0 = (int64_t)blockIdx.x * rpb, r1 = imin(r0 + rpb, ld);
+    v4d acc[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) acc[g] = v4d{0.0, 0.0, 0.0, 0.0};
+    double zr[16], yr[8];
+    auto fetch = [&](int64_t rc) {
+        const int64_t row = rc + rl;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) zr[u] = (u < zn) ? Z[(int64_t)(z0 + u) * ldz + row] : 0.0;
+        if (HASY) {
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) yr[jj] = (8 * h + jj < q) ? Yin[(int64_t)(8 * h + jj) * ldy + row] : 0.0;
+        }
+    };
+    int64_t rc = r0 + wave * BG_CHUNK;
+    if (rc < r1) fetch(rc);
+    for (; rc < r1; rc += 4 * BG_CHUNK) {
+        // ---- phase 1: the tile
+        {
+            double t[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) t[j] = 0.0;
+            if (HASY) {
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) {
+                    if (h == 0) t[jj] = beta * yr[jj];
+                    else t[8 + jj] = beta * yr[jj];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                if (u < zn) {   // wave-uniform per half except for the odd-nz remainder
+                    const double zv = alpha * zr[u];
+                    const d2* sc = reinterpret_cast<const d2*>(csm + (z0 + u) * 16);
+#pragma unroll
+                    for (int j2 = 0; j2 < 8; ++j2) {
+                        const d2 sv = sc[j2];
+                        t[2 * j2] = fma(zv, sv.x, t[2 * j2]);
+                        t[2 * j2 + 1] = fma(zv, sv.y, t[2 * j2 + 1]);
+                    }
+                }
+            }
+            if (h == 0) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) tile[j * BGT_LD + rl] = t[j];
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (h == 1) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) tile[j * BGT_LD + rl] += t[j];
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (STORE) {
+                const int64_t row = rc + rl;
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj)
+                    if (8 * h + jj < q) Yout[(int64_t)(8 * h + jj) * ldyo + row] = tile[(8 * h + jj) * BGT_LD + rl];
+            }
+        }
+        if (rc + 4 * BG_CHUNK < r1) fetch(rc + 4 * BG_CHUNK);   // in flight during the MFMA phase below
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slab is wave-private: LDS is in order per wave
+        // ---- phase 2: Gram of the tile against X (column-owner layout, as k_block_gram)
+        double yv[BG_T];
+#pragma unroll
+        for (int t = 0; t < BG_T; t += 2) {
+            const d2 v = *reinterpret_cast<const d2*>(tile + c * BGT_LD + 4 * t + 2 * kq);
+            yv[t] = v.x; yv[t + 1] = v.y;
+        }
+        const int64_t row = rc + kq * 2;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            double xv[BG_T];
+            if (XT) {
+#pragma unroll
+                for (int t = 0; t < BG_T; ++t) xv[t] = yv[t];
+            } else {
+                const int col = g * 16 + c;
+                if (col < p) {
+                    const double* xp = X + (int64_t)col * ldx + row;
+#pragma unroll
+                    for (int t = 0; t < BG_T; t += 2) { d2 v = ld2s(xp + 4 * t); xv[t] = v.x; xv[t + 1] = v.y; }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < BG_T; ++t) xv[t] = 0.0;
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < BG_T; ++t) acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(xv[t], yv[t], acc[g], 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");   // the next chunk overwrites the slab only after these reads
+    }
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    double* a = &lds[(g * 4 + r) * 64 + lane];
+                    *a = (w == 0) ? acc[g][r] : (*a + acc[g][r]);
+                }
+        }
+        __syncthreads();
+    }
+    double* dst = part + (int64_t)blockIdx.x * (NG * 256);
+    for (int e = tid; e < NG * 256; e += KK_TPB) dst[e] = lds[e];
+}
+
 // C[i + ldc*j] = sum_b part[b][e(i,j)]   (one thread per output entry)
+// (C[i*rs + j*cs]: rs = 1, cs = ldc is the column-major panel; rs = row stride, cs = 1 writes the panel row-major, i.e.
+// directly in the coefficient layout k_block_update reads)
 __global__ __launch_bounds__(KK_TPB) void k_finalize_gram(const double* __restrict__ part, int nblk, int ng, int p, int q,
-                                                          double* __restrict__ C, int ldc) {
+                                                          double* __restrict__ C, int rs, int cs) {
     const int idx = blockIdx.x * KK_TPB + threadIdx.x;
     if (idx >= p * q) return;
     const int i = idx % p, j = idx / p;
@@ -85,7 +232,105 @@ __global__ __launch_bounds__(KK_TPB) void k_finalize_gram(const double* __restri
     const int64_t stride = (int64_t)ng * 256;
     double a = 0;
     for (int b = 0; b < nblk; ++b) a += part[(int64_t)b * stride + e];
-    C[i + (int64_t)ldc * j] = a;
+    C[(int64_t)i * rs + (int64_t)j * cs] = a;
+}
+
+// ---- one-block dense helpers of the asynchronous block step (p <= 16): the Cholesky factors, their inverses and the
+// coefficient panels are formed on the device so that a whole BlockLanczos expand! is enqueued without a host round trip;
+// the host reads the flag afterwards and repeats the step on the synchronous route if a safety test failed.
+// upper Cholesky G = R'R in LDS; returns false (uniformly) if a pivot is not safely positive:
+// pivot^2 must exceed rel^2 * G_jj and abs_min^2   (same test as the host-side chol_upper_safe)
+__device__ bool chol16(const double* G, int p, double (*R)[17], double rel, double abs_min) {
+    // single-thread algorithm executed by thread 0 (p <= 16: ~700 flops), everyone else waits
+    __shared__ int ok_s;
+    if (threadIdx.x == 0) {
+        bool ok = true;
+        for (int j = 0; j < p && ok; ++j) {
+            for (int i = 0; i < j; ++i) {
+                double t = G[i + p * j];
+                for (int k = 0; k < i; ++k) t -= R[k][i] * R[k][j];
+                R[i][j] = t / R[i][i];
+            }
+            double d2 = G[j + p * j];
+            for (int k = 0; k < j; ++k) d2 -= R[k][j] * R[k][j];
+            const double gjj = G[j + p * j];
+            if (!(d2 > rel * rel * gjj) || !(d2 > abs_min * abs_min) || !(d2 < 1e300)) ok = false;
+            else R[j][j] = sqrt(d2);
+            for (int i = j + 1; i < p; ++i) R[i][j] = 0.0;
+        }
+        ok_s = ok ? 1 : 0;
+    }
+    __syncthreads();
+    return ok_s != 0;
+}
+__device__ void triu_inv16(double (*R)[17], int p, double (*Ri)[17]) {
+    if (threadIdx.x == 0) {
+        for (int j = 0; j < p; ++j) {
+            for (int i = 0; i < p; ++i) Ri[i][j] = 0.0;
+            Ri[j][j] = 1.0 / R[j][j];
+            for (int i = j - 1; i >= 0; --i) {
+                double t = 0;
+                for (int k = i + 1; k <= j; ++k) t += R[i][k] * Ri[k][j];
+                Ri[i][j] = -t / R[i][i];
+            }
+        }
+    }
+    __syncthreads();
+}
+// CholQR2, first factor: G (p x p col-major) -> R1 (p x p col-major, ld p) and the staged panel of R1^-1 (row-major, stride st)
+__global__ __launch_bounds__(64) void k_blk_chol1(const double* __restrict__ G, int p, double abs_min, double* __restrict__ R1out,
+                                                  double* __restrict__ S1, int st, double* __restrict__ flag) {
+    __shared__ double R[16][17], Ri[16][17];
+    const bool ok = chol16(G, p, R, 1e-5, abs_min);
+    if (!ok) { if (threadIdx.x == 0) flag[0] = 1.0; return; }
+    triu_inv16(R, p, Ri);
+    for (int e = threadIdx.x; e < p * st; e += 64) { const int i = e / st, j = e % st; S1[e] = j < p ? Ri[i][j] : 0.0; }
+    for (int e = threadIdx.x; e < p * p; e += 64) R1out[e] = R[e % p][e / p];
+}
+// second factor: G2 = Q1'Q1 must be close to I; R2 = chol(G2); staged panel of R2^-1; B = R2 R1 (p x p col-major, ld ldb);
+// rows 0..p-1 of the three-term panel S3 (row-major, stride st): S3[i][j] = B[j][i]
+__global__ __launch_bounds__(64) void k_blk_chol2(const double* __restrict__ G2, int p, const double* __restrict__ R1,
+                                                  double* __restrict__ Bout, int ldb, double* __restrict__ S2, double* __restrict__ S3,
+                                                  int st, double* __restrict__ flag) {
+    __shared__ double R[16][17], Ri[16][17], Bm[16][17];
+    __shared__ double dev_s;
+    if (threadIdx.x == 0) {
+        double dev = 0;
+        for (int j = 0; j < p; ++j)
+            for (int i = 0; i < p; ++i) dev = fmax(dev, fabs(G2[i + p * j] - (i == j ? 1.0 : 0.0)));
+        dev_s = (dev < 1e-3) ? 0.0 : 1.0;   // NaN compares false -> flagged
+        if (!(dev < 1e-3)) dev_s = 1.0;
+    }
+    __syncthreads();
+    if (flag[0] != 0.0) return;   // first factor already failed
+    if (dev_s != 0.0) { if (threadIdx.x == 0) flag[0] = 2.0; return; }
+    const bool ok = chol16(G2, p, R, 1e-2, 0.0);
+    if (!ok) { if (threadIdx.x == 0) flag[0] = 2.0; return; }
+    triu_inv16(R, p, Ri);
+    for (int e = threadIdx.x; e < p * p; e += 64) {   // B = R2 R1 (upper triangular)
+        const int i = e % p, j = e / p;
+        double t = 0;
+        for (int k = i; k <= j; ++k) t += R[i][k] * R1[k + p * j];
+        Bm[i][j] = (i <= j) ? t : 0.0;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < p * p; e += 64) Bout[(e % p) + ldb * (e / p)] = Bm[e % p][e / p];
+    for (int e = threadIdx.x; e < p * st; e += 64) {
+        const int i = e / st, j = e % st;
+        S2[e] = j < p ? Ri[i][j] : 0.0;
+        S3[e] = j < p ? Bm[j][i] : 0.0;
+    }
+}
+// C = P + [0 ; S3]: the re-orthogonalisation panel with the three-term coefficients added to its last nz rows (row-major, stride st)
+__global__ __launch_bounds__(KK_TPB) void k_blk_combine(double* __restrict__ P, const double* __restrict__ S3, int kn, int nz, int st) {
+    for (int e = threadIdx.x; e < nz * st; e += KK_TPB) P[(int64_t)(kn - nz) * st + e] += S3[e];
+}
+// rows p..2p-1 of the three-term panel: S3[p + i][j] = M[i][j]  (M col-major, ld ldm)
+__global__ __launch_bounds__(64) void k_blk_fill_m(const double* __restrict__ M, int ldm, int p, double* __restrict__ S3, int st) {
+    for (int e = threadIdx.x; e < p * st; e += 64) {
+        const int i = e / st, j = e % st;
+        S3[(p + i) * st + j] = j < p ? M[i + ldm * j] : 0.0;
+    }
 }
 
 // W[:, j] = beta*W[:, j] + alpha * sum_c V[:, c] S[c*NB + j]   for j < nb <= NB, c < m   (S rows padded to NB)
@@ -167,11 +412,240 @@ __global__ __launch_bounds__(KK_TPB) void k_block_update(const double* V, int64_
     }
 }
 
+// Variant with the coefficient panel in LDS.  The round-1 kernel fetches the 16 coefficients of every basis column with
+// scalar loads right before their FMAs; tools/stream_tile.hip shows that a pure read of the same 112 columns WITH the
+// same 16 FMAs per double runs at 6.8 TB/s, the update at 5.0: the difference is the exposed scalar-cache latency (five
+// lgkmcnt(0) waits per batch of four columns, 64 SGPRs cannot hold a second batch).  Here the block copies the panel
+// (m x NB doubles, <= 17 KB) to LDS once and every lane reads the coefficients with broadcast ds_read_b128 (same address
+// in all lanes: conflict-free), NB/2 at a time; the column norms are reduced per iteration with wave sums instead of
+// per-thread LDS accumulators (32 KB less LDS per block).
+template <int NB, bool BZERO>
+__global__ __launch_bounds__(KK_TPB, 4) void k_block_update_lds(const double* V, int64_t ld, int m, const double* Win,
+                                                             double* Wout, int64_t ldw_in, int64_t ldw_out, int nb,
+                                                             const double* __restrict__ S, double alpha, double beta,
+                                                             int64_t rpb, double* __restrict__ part_nrm) {
+    extern __shared__ __attribute__((aligned(16))) double ssm[];   // [m][NB] coefficients, then [NB][4] norm slots
+    double* nsl = ssm + (size_t)m * NB;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    for (int e = tid; e < m * NB; e += KK_TPB) ssm[e] = S[e];
+    if (tid < NB * 4) nsl[tid] = 0.0;
+    __syncthreads();
+    const int64_t r0 = (int64_t)blockIdx.x * rpb, r1 = imin(r0 + rpb, ld);
+    for (int64_t r = r0 + tid * 2; r < r1; r += KK_SUB) {
+        d2 acc[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[j] = d2{0.0, 0.0};
+        int c = 0;
+        d2 xn[4];
+        if (m >= 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) xn[u] = ld2s(V + (int64_t)u * ld + r);
+        }
+        for (; c + 4 <= m; c += 4) {
+            d2 x[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) x[u] = xn[u];
+            if (c + 8 <= m) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) xn[u] = ld2s(V + (int64_t)(c + 4 + u) * ld + r);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const d2* Sc = reinterpret_cast<const d2*>(ssm + (size_t)(c + u) * NB);
+#pragma unroll
+                for (int j2 = 0; j2 < NB / 2; ++j2) {
+                    const d2 sv = Sc[j2];
+                    acc[2 * j2].x = fma(sv.x, x[u].x, acc[2 * j2].x); acc[2 * j2].y = fma(sv.x, x[u].y, acc[2 * j2].y);
+                    acc[2 * j2 + 1].x = fma(sv.y, x[u].x, acc[2 * j2 + 1].x); acc[2 * j2 + 1].y = fma(sv.y, x[u].y, acc[2 * j2 + 1].y);
+                }
+            }
+        }
+        for (; c < m; ++c) {
+            const d2 x = ld2(V + (int64_t)c * ld + r);
+            const d2* Sc = reinterpret_cast<const d2*>(ssm + (size_t)c * NB);
+#pragma unroll
+            for (int j2 = 0; j2 < NB / 2; ++j2) {
+                const d2 sv = Sc[j2];
+                acc[2 * j2].x = fma(sv.x, x.x, acc[2 * j2].x); acc[2 * j2].y = fma(sv.x, x.y, acc[2 * j2].y);
+                acc[2 * j2 + 1].x = fma(sv.y, x.x, acc[2 * j2 + 1].x); acc[2 * j2 + 1].y = fma(sv.y, x.y, acc[2 * j2 + 1].y);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            if (j < nb) {
+                d2 w{alpha * acc[j].x, alpha * acc[j].y};
+                if (!BZERO) {
+                    const d2 wi = ld2(Win + (int64_t)j * ldw_in + r);
+                    w.x = fma(beta, wi.x, w.x); w.y = fma(beta, wi.y, w.y);
+                }
+                st2(Wout + (int64_t)j * ldw_out + r, w);
+                if (part_nrm) {
+                    const double t = wave_sum(fma(w.x, w.x, w.y * w.y));
+                    if (lane == 0) nsl[j * 4 + wave] += t;
+                }
+            }
+        }
+    }
+    if (part_nrm) {
+        __syncthreads();
+        if (tid < nb) part_nrm[(int64_t)tid * KK_MAX_BLOCKS + blockIdx.x] = (nsl[tid * 4] + nsl[tid * 4 + 1]) + (nsl[tid * 4 + 2] + nsl[tid * 4 + 3]);
+    }
+}
+
+// Deep-prefetch variant: a ring of PF basis-column loads (16 B each) stays in flight per lane -- as many bytes in flight as
+// the single-vector unproject kernel keeps with its 32 x 2 tile -- at 2 blocks per CU (up to 256 registers per lane).
+// Same arithmetic, same summation order as k_block_update.
+template <int NB, bool BZERO, int PF>
+__global__ __launch_bounds__(KK_TPB, 2) void k_block_update_pf(const double* V, int64_t ld, int m, const double* Win,
+                                                               double* Wout, int64_t ldw_in, int64_t ldw_out, int nb,
+                                                               const double* __restrict__ S, double alpha, double beta,
+                                                               int64_t rpb, double* __restrict__ part_nrm) {
+    __shared__ double nsm[NB * KK_TPB];
+    __shared__ double sm[4];
+    const int tid = threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.x * rpb, r1 = imin(r0 + rpb, ld);
+    if (part_nrm) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) nsm[j * KK_TPB + tid] = 0.0;
+    }
+    for (int64_t r = r0 + tid * 2; r < r1; r += KK_SUB) {
+        d2 acc[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[j] = d2{0.0, 0.0};
+        d2 x[PF];
+#pragma unroll
+        for (int u = 0; u < PF; ++u)
+            if (u < m) x[u] = ld2s(V + (int64_t)u * ld + r);
+        int c = 0;
+        for (; c + PF <= m; c += PF) {
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const d2 xv = x[u];
+                if (c + u + PF < m) x[u] = ld2s(V + (int64_t)(c + u + PF) * ld + r);   // uniform branch
+                const double* Sc = S + (int64_t)(c + u) * NB;
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    const double sv = Sc[j];
+                    acc[j].x = fma(sv, xv.x, acc[j].x); acc[j].y = fma(sv, xv.y, acc[j].y);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            if (c + u < m) {
+                const d2 xv = x[u];
+                const double* Sc = S + (int64_t)(c + u) * NB;
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    const double sv = Sc[j];
+                    acc[j].x = fma(sv, xv.x, acc[j].x); acc[j].y = fma(sv, xv.y, acc[j].y);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            if (j < nb) {
+                d2 w{alpha * acc[j].x, alpha * acc[j].y};
+                if (!BZERO) {
+                    const d2 wi = ld2(Win + (int64_t)j * ldw_in + r);
+                    w.x = fma(beta, wi.x, w.x); w.y = fma(beta, wi.y, w.y);
+                }
+                st2(Wout + (int64_t)j * ldw_out + r, w);
+                if (part_nrm) nsm[j * KK_TPB + tid] += fma(w.x, w.x, w.y * w.y);
+            }
+        }
+    }
+    if (part_nrm) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            if (j < nb) {
+                double t = block_sum(nsm[j * KK_TPB + tid], sm);
+                if (tid == 0) part_nrm[(int64_t)j * KK_MAX_BLOCKS + blockIdx.x] = t;
+            }
+        }
+    }
+}
+
 // ---- launchers
 // ---- block launchers ---------------------------------------------------------------------
 // C (p x q, column-major ldc) = X' Y on device memory `C_dev`; p <= 128, q <= 16 per call
 int kk_launch_block_gram(kk_ctx ctx, const double* X, int64_t ldx, int p, const double* Y, int64_t ldy, int q, int64_t ld,
                          double* C_dev, int ldc) {
+    return kk_launch_block_gram_rs(ctx, X, ldx, p, Y, ldy, q, ld, C_dev, 1, ldc);
+}
+int kk_launch_blk_chol1(kk_ctx ctx, const double* G, int p, double abs_min, double* R1, double* S1, int st, double* flag) {
+    hipLaunchKernelGGL(k_blk_chol1, dim3(1), dim3(64), 0, ctx->stream, G, p, abs_min, R1, S1, st, flag);
+    KK_HIP(hipGetLastError());
+    return KK_OK;
+}
+int kk_launch_blk_chol2(kk_ctx ctx, const double* G2, int p, const double* R1, double* B, int ldb, double* S2, double* S3, int st,
+                        double* flag) {
+    hipLaunchKernelGGL(k_blk_chol2, dim3(1), dim3(64), 0, ctx->stream, G2, p, R1, B, ldb, S2, S3, st, flag);
+    KK_HIP(hipGetLastError());
+    return KK_OK;
+}
+int kk_launch_blk_fill_m(kk_ctx ctx, const double* M, int ldm, int p, double* S3, int st) {
+    hipLaunchKernelGGL(k_blk_fill_m, dim3(1), dim3(64), 0, ctx->stream, M, ldm, p, S3, st);
+    KK_HIP(hipGetLastError());
+    return KK_OK;
+}
+int kk_launch_blk_combine(kk_ctx ctx, double* P, const double* S3, int kn, int nz, int st) {
+    hipLaunchKernelGGL(k_blk_combine, dim3(1), dim3(KK_TPB), 0, ctx->stream, P, S3, kn, nz, st);
+    KK_HIP(hipGetLastError());
+    return KK_OK;
+}
+// C (p x q, strides rs / cs) = X' T with the tile T = beta*Yin + alpha * Z S formed on the fly (k_block_gram_tile);
+// X == nullptr: C = T' T (p = q).  Yout != nullptr: T is also written there.
+int kk_launch_block_gram_tile(kk_ctx ctx, const double* X, int64_t ldx, int p, const double* Yin, int64_t ldy, const double* Z,
+                              int64_t ldz, int nz, const double* S_dev, int st, double alpha, double beta, double* Yout,
+                              int64_t ldyo, int q, int64_t ld, double* C_dev, int rs, int cs) {
+    if (p <= 0 || q <= 0) return KK_OK;
+    if (p > 128 || q > 16 || nz > 32) { kk_set_error("kk_launch_block_gram_tile: p=%d q=%d nz=%d exceed one launch", p, q, nz); return KK_ERR_INVALID; }
+    kk_part pt = kk_partition(ctx, ld);
+    int nblk = pt.nblk;
+    int64_t rpb = pt.rpb;
+    const int maxb = 2 * ctx->num_cus;
+    if (nblk > maxb) {
+        const int64_t nsub = ld / KK_SUB;
+        const int64_t spb = (nsub + maxb - 1) / maxb;
+        rpb = spb * KK_SUB;
+        nblk = (int)((nsub + spb - 1) / spb);
+    }
+    const int ng = (p + 15) / 16;
+    int NG = 1;
+    while (NG < ng) NG *= 2;
+    const size_t shm = ((size_t)NG * 256 + 32 * 16 + 4 * 16 * BGT_LD) * sizeof(double);
+    double* part = ctx->partials;
+    const bool xt = (X == nullptr), store = (Yout != nullptr), hasy = (Yin != nullptr && beta != 0.0);
+    {
+        kk_prof_scope ps(ctx, "k_block_gram");
+        dim3 g(nblk), b(KK_TPB);
+#define GT_ARGS X, ldx, p, Yin, ldy, Z, ldz, nz, S_dev, st, alpha, beta, Yout, ldyo, q, ld, rpb, part
+        if (xt) {
+            if (store) hipLaunchKernelGGL((k_block_gram_tile<1, true, true, false>), g, b, shm, ctx->stream, GT_ARGS);
+            else hipLaunchKernelGGL((k_block_gram_tile<1, true, false, false>), g, b, shm, ctx->stream, GT_ARGS);
+        } else if (hasy && !store) {
+            switch (NG) {
+                case 1: hipLaunchKernelGGL((k_block_gram_tile<1, false, false, true>), g, b, shm, ctx->stream, GT_ARGS); break;
+                case 2: hipLaunchKernelGGL((k_block_gram_tile<2, false, false, true>), g, b, shm, ctx->stream, GT_ARGS); break;
+                case 4: hipLaunchKernelGGL((k_block_gram_tile<4, false, false, true>), g, b, shm, ctx->stream, GT_ARGS); break;
+                default: hipLaunchKernelGGL((k_block_gram_tile<8, false, false, true>), g, b, shm, ctx->stream, GT_ARGS); break;
+            }
+        } else {
+            kk_set_error("kk_launch_block_gram_tile: unsupported combination");
+            return KK_ERR_UNSUPPORTED;
+        }
+#undef GT_ARGS
+    }
+    KK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_finalize_gram, dim3((p * q + KK_TPB - 1) / KK_TPB), dim3(KK_TPB), 0, ctx->stream, part, nblk, NG, p, q,
+                       C_dev, rs, cs);
+    KK_HIP(hipGetLastError());
+    return KK_OK;
+}
+// general output strides: C[i*rs + j*cs]
+int kk_launch_block_gram_rs(kk_ctx ctx, const double* X, int64_t ldx, int p, const double* Y, int64_t ldy, int q, int64_t ld,
+                            double* C_dev, int rs, int cs) {
     if (p <= 0 || q <= 0) return KK_OK;
     if (p > 128 || q > 16) { kk_set_error("kk_launch_block_gram: p=%d q=%d exceed one launch (128 x 16)", p, q); return KK_ERR_INVALID; }
     kk_part pt = kk_partition(ctx, ld);
@@ -194,15 +668,15 @@ int kk_launch_block_gram(kk_ctx ctx, const double* X, int64_t ldx, int p, const 
         kk_prof_scope ps(ctx, "k_block_gram");
         dim3 g(nblk), b(KK_TPB);
         switch (NG) {
-            case 1: hipLaunchKernelGGL((k_block_gram<1>), g, b, shm, ctx->stream, X, ldx, p, Y, ldy, q, ld, rpb, part); break;
-            case 2: hipLaunchKernelGGL((k_block_gram<2>), g, b, shm, ctx->stream, X, ldx, p, Y, ldy, q, ld, rpb, part); break;
-            case 4: hipLaunchKernelGGL((k_block_gram<4>), g, b, shm, ctx->stream, X, ldx, p, Y, ldy, q, ld, rpb, part); break;
-            default: hipLaunchKernelGGL((k_block_gram<8>), g, b, shm, ctx->stream, X, ldx, p, Y, ldy, q, ld, rpb, part); break;
+            case 1: hipLaunchKernelGGL((k_block_gram<1>), g, b, shm, ctx->stream, X, ldx, p, Y, ldy, q, ld, rpb, part, ctx->gram_nt); break;
+            case 2: hipLaunchKernelGGL((k_block_gram<2>), g, b, shm, ctx->stream, X, ldx, p, Y, ldy, q, ld, rpb, part, ctx->gram_nt); break;
+            case 4: hipLaunchKernelGGL((k_block_gram<4>), g, b, shm, ctx->stream, X, ldx, p, Y, ldy, q, ld, rpb, part, ctx->gram_nt); break;
+            default: hipLaunchKernelGGL((k_block_gram<8>), g, b, shm, ctx->stream, X, ldx, p, Y, ldy, q, ld, rpb, part, ctx->gram_nt); break;
         }
     }
     KK_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_finalize_gram, dim3((p * q + KK_TPB - 1) / KK_TPB), dim3(KK_TPB), 0, ctx->stream, part, nblk, NG, p, q,
-                       C_dev, ldc);
+                       C_dev, rs, cs);
     KK_HIP(hipGetLastError());
     return KK_OK;
 }
@@ -221,7 +695,20 @@ int kk_launch_block_update(kk_ctx ctx, const double* V, int64_t ld, int m, const
 #define BU_CASE(NBT) \
         if (bz) hipLaunchKernelGGL((k_block_update<NBT, true>), g, b, 0, ctx->stream, V, ld, m, Win, Wout, ldw_in, ldw_out, nb, S_dev, alpha, beta, p.rpb, part); \
         else hipLaunchKernelGGL((k_block_update<NBT, false>), g, b, 0, ctx->stream, V, ld, m, Win, Wout, ldw_in, ldw_out, nb, S_dev, alpha, beta, p.rpb, part);
-        if (nb <= 4) { BU_CASE(4) } else if (nb <= 8) { BU_CASE(8) } else { BU_CASE(16) }
+#define BU_PF(NBT, PFD) \
+        if (bz) hipLaunchKernelGGL((k_block_update_pf<NBT, true, PFD>), g, b, 0, ctx->stream, V, ld, m, Win, Wout, ldw_in, ldw_out, nb, S_dev, alpha, beta, p.rpb, part); \
+        else hipLaunchKernelGGL((k_block_update_pf<NBT, false, PFD>), g, b, 0, ctx->stream, V, ld, m, Win, Wout, ldw_in, ldw_out, nb, S_dev, alpha, beta, p.rpb, part);
+        const size_t shm = ((size_t)m * kk_bu_stride(nb) + 64) * sizeof(double);
+#define BU_LDS(NBT) \
+        if (bz) hipLaunchKernelGGL((k_block_update_lds<NBT, true>), g, b, shm, ctx->stream, V, ld, m, Win, Wout, ldw_in, ldw_out, nb, S_dev, alpha, beta, p.rpb, part); \
+        else hipLaunchKernelGGL((k_block_update_lds<NBT, false>), g, b, shm, ctx->stream, V, ld, m, Win, Wout, ldw_in, ldw_out, nb, S_dev, alpha, beta, p.rpb, part);
+        if (ctx->bu_prefetch == 1 && m * kk_bu_stride(nb) <= 8192) { if (nb <= 4) { BU_LDS(4) } else if (nb <= 8) { BU_LDS(8) } else { BU_LDS(16) } }
+        else if (nb > 8 && ctx->bu_prefetch == 16) { BU_PF(16, 16) }
+        else if (nb > 8 && ctx->bu_prefetch == 8) { BU_PF(16, 8) }
+        else if (nb > 8 && ctx->bu_prefetch == 24) { BU_PF(16, 24) }
+        else if (nb <= 4) { BU_CASE(4) } else if (nb <= 8) { BU_CASE(8) } else { BU_CASE(16) }
+#undef BU_PF
+#undef BU_LDS
 #undef BU_CASE
     }
     KK_HIP(hipGetLastError());

@@ -417,7 +417,12 @@ int kk_launch_spmm(kk_ctx ctx, const kk_sparse_dev& M, const double* X, int64_t 
     }
     const int nb_logical = (int)((M.nrows + 2 * KK_TPB - 1) / (2 * KK_TPB));
     const int per = (nb_logical + 7) / 8;
-    const int nbx = std::min(per, KK_MAX_BLOCKS / 8);
+    // Each XCD sweeps a contiguous band of rows; the rows its resident blocks work on at one time are the window whose
+    // gathered entries must stay in that XCD's 4 MB L2 for the +-nx neighbours of a stencil to be L2 hits.  With nb
+    // right-hand sides the window holds nb columns: spmm_bpc resident blocks per CU x 32 CUs x 512 rows x nb x 8 bytes
+    // (2 blocks per CU, nb = 16: 4 MB), so the grid is capped instead of filling every slot as the 1-column SpMV does.
+    int nbx = std::min(per, KK_MAX_BLOCKS / 8);
+    if (ctx->spmm_bpc > 0) nbx = std::min(nbx, std::max(1, ctx->num_cus / 8) * ctx->spmm_bpc);
     dim3 g(nbx * 8), b(KK_TPB);
     int j0 = 0;
     while (j0 < nb) {

@@ -652,6 +652,77 @@ def test_blocklanczos_factorization(kk, ko, ctx, block_mode):
     ctx.set_option("block_mode", 1)
 
 
+@pytest.mark.parametrize("bs", [2, 3, 5, 8, 16])
+def test_blocklanczos_async_step_matches_synchronous(kk, ko, ctx, bs):
+    """The asynchronous block step (CholQR2 algebra on the device, one host sync per expand!) against the synchronous panel
+    route and the oracle: same block sizes, H up to roundoff, invariants of test/factorize.jl:387-401."""
+    nx, ny = 40, 25
+    n = nx * ny
+    A = ko.laplacian_2d(nx, ny, shift_diag=10 * np.linspace(0, 1, n) ** 2)
+    rng = np.random.default_rng(70 + bs)
+    x0 = [rng.random(n) for _ in range(bs)]
+    steps = 5 if bs < 16 else 4
+    Hs = {}
+    for mode in (1, 2, 0):   # 1: asynchronous + tile-fused Gram kernels, 2: asynchronous with separate kernels, 0: synchronous
+        ctx.set_option("block_async", 1 if mode else 0)
+        ctx.set_option("block_fuse", 3 if mode == 1 else 0)
+        it = kk.BlockLanczosIterator(kk.SparseOperator(A, ctx, symmetric=True), x0, (steps + 1) * bs + bs)
+        f = it.initialize()
+        for _ in range(steps):
+            f = it.expand(f)
+            assert f.R_size == bs and not f.last_drift
+        k = len(f)
+        V = f.V.to_numpy()
+        R = np.stack([f.residual()[j].get() for j in range(f.R_size)], 1)
+        H = f.H[:k, :k]
+        E = np.zeros((k, bs)); E[k - bs:, :] = np.eye(bs)
+        assert np.max(np.abs(V.T @ V - np.eye(k))) < 1e-12
+        assert np.max(np.abs(A @ V - V @ H - R @ E.T)) < 1e-10
+        assert abs(f.normres - np.linalg.norm(R)) < 1e-11 and np.max(np.abs(V.T @ R)) < 1e-11
+        Hs[mode] = H.copy()
+    ctx.set_option("block_async", 1)
+    ctx.set_option("block_fuse", 1)
+    np.testing.assert_allclose(Hs[1], Hs[0], atol=1e-10)
+    np.testing.assert_allclose(Hs[2], Hs[0], atol=1e-10)
+    oit = ko.BlockLanczosIterator(A, [x.copy() for x in x0], (steps + 1) * bs + bs)
+    of = ko.blocklanczos_initialize(oit)
+    for _ in range(steps):
+        of = ko.blocklanczos_expand(oit, of)
+    np.testing.assert_allclose(np.linalg.eigvalsh(Hs[1]), np.linalg.eigvalsh(of.H[:k, :k]), atol=1e-9)
+
+
+def test_blocklanczos_async_step_hands_rank_drop_to_faithful_route(kk, ko, ctx):
+    """A residual block that loses rank must not be accepted by the asynchronous CholQR2 step: the safety flag sends it to
+    the reference's column-by-column block_qr! (blocklanczos.jl:312-353) and the block shrinks exactly as in the oracle."""
+    n, bs = 300, 4
+    rng = np.random.default_rng(5)
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    lam = np.concatenate([np.array([10.0, 9.0, 8.0]), np.linspace(0.1, 1.0, n - 3)])
+    Ad = (Q * lam) @ Q.T
+    Ad = (Ad + Ad.T) / 2
+    # start block inside an invariant subspace of dimension 6: the third block cannot have full rank
+    X0 = Q[:, :6] @ rng.standard_normal((6, bs))
+    x0 = [X0[:, j].copy() for j in range(bs)]
+    it = kk.BlockLanczosIterator(kk.SparseOperator(sp.csr_matrix(Ad), ctx, symmetric=True), x0, 40)
+    oit = ko.BlockLanczosIterator(Ad, [x.copy() for x in x0], 40)
+    f, of = it.initialize(), ko.blocklanczos_initialize(oit)
+    sizes, osizes = [f.R_size], [of.R_size]
+    for _ in range(2):
+        try:
+            f = it.expand(f)
+            sizes.append(f.R_size)
+        except kk.KrylovHipError:
+            sizes.append(0)
+            break
+        try:
+            of = ko.blocklanczos_expand(oit, of)
+            osizes.append(of.R_size)
+        except Exception:
+            osizes.append(0)
+            break
+    assert sizes[:len(osizes)] == osizes[:len(sizes)] and min(sizes) < bs
+
+
 @pytest.mark.parametrize("block_mode", [0, 1])
 def test_blocklanczos_issue143_known_answer_on_device(kk, ko, ctx, block_mode):
     """The reference's regression test test/issues.jl:114-128 on the HIP path: all 71 eigenvalues,

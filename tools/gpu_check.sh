@@ -22,6 +22,9 @@ for step in "$@"; do
     configs)  timeout 1200 python tools/bench_configs.py gmres block > $OUT/configs.jsonl 2> $OUT/configs.err; echo "configs rc=$?"; cat $OUT/configs.jsonl ;;
     strict)   timeout 900 python tools/strict_sweep.py > $OUT/strict.jsonl 2> $OUT/strict.err; echo "strict rc=$?"; cat $OUT/strict.jsonl; tail -3 $OUT/strict.err ;;
     orthtests) timeout 1200 python -m pytest tests/test_gpu_parity.py -x -q -k "orthogonalize or lanczos or arnoldi or gkl or mgs" > $OUT/t_orth.log 2>&1; echo "orthtests rc=$?" ;;
+    blocksweep) timeout 900 python tools/block_sweep.py > $OUT/block_sweep.jsonl 2> $OUT/block_sweep.err; echo "blocksweep rc=$?"; cat $OUT/block_sweep.jsonl; tail -3 $OUT/block_sweep.err ;;
+    blocktests) timeout 1200 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py -x -q -k "block" > $OUT/t_block.log 2>&1; echo "blocktests rc=$?" ;;
+    blockmicro) timeout 900 python tools/block_micro.py > $OUT/block_micro.jsonl 2> $OUT/block_micro.err; echo "blockmicro rc=$?"; cat $OUT/block_micro.jsonl; tail -3 $OUT/block_micro.err ;;
     prof)     bash tools/profile_gpu.sh $TAG > $OUT/prof.log 2>&1; echo "prof rc=$?"; tail -5 $OUT/prof.log ;;
     *) echo "unknown step $step" ;;
   esac
