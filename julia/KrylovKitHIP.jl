@@ -1,26 +1,39 @@
 # KrylovKitHIP.jl -- the reference-side binding of libkrylov_hip.so.
 #
-# This is the shim a KrylovKit.jl maintainer (or user) adds next to KrylovKit: a device vector
-# type + a device operator type that satisfy the L1 protocol (VectorInterface verbs, `apply`),
-# plus method overloads of the L2/L3 entry points for that type which forward to the FUSED
-# C-ABI calls.  KrylovKit's own eigsolve / linsolve / svdsolve (L5), its algorithm structs
+# This is the shim a KrylovKit.jl maintainer (or user) adds next to KrylovKit: a device vector type + a device operator type
+# that satisfy the L1 protocol (VectorInterface verbs, `apply`), plus method overloads of the L2/L3 entry points for that
+# type which forward to the FUSED C-ABI calls.  KrylovKit's own eigsolve / linsolve / svdsolve (L5), its algorithm structs
 # (L4) and its small dense LAPACK work (L0) run unchanged on the host.
 #
-# NOTE: the build image has no Julia toolchain, so this file has not been executed here; the
-# identical ccall sequence is exercised through the ctypes mirror
-# (krylovkit.jl_amd/krylovkit_hip) by tests/test_gpu_parity.py.  Signatures are exactly those of
-# include/krylov_hip.h.
+# Layout contract.  The library works on slabs: a Krylov basis is a run of consecutive columns of ONE slab, its residual the
+# column right behind it (include/krylov_hip.h).  KrylovKit's host code, however, moves vectors by reference
+# (`B[keep+1] = scale!!(r, 1/β)` in src/eigsolve/lanczos.jl:111, `push!(V, scale!!(r, 1/βold))` in
+# src/factorizations/lanczos.jl:257, `state.r = r` after `initialize!`, ...).  The shim keeps both worlds consistent with
+# three rules:
+#   1. element i of an `OrthonormalBasis{HipVec}` lives in column c0+i-1 of the slab of its first element ("home" column);
+#      `push!` and `setindex!` are overloaded to COPY a vector that comes from elsewhere into its home column;
+#   2. the fused `expand!` methods first bring the residual to the column behind the basis (a no-op in steady state);
+#   3. slabs that hold a basis are dedicated to it (created by the fused `initialize` methods, grown by `sizehint!` / on
+#      demand); every other vector (`apply`, `scale`, `zerovector`, `copy(::Block)`) is a column of a scratch pool and is
+#      returned to the pool by a finalizer.
+#
+# NOTE: the build image has no Julia toolchain, so this file has not been executed here.  tests/test_julia_shim_lint.py
+# checks every `ccall` below against include/krylov_hip.h (symbol exists, argument count, C type of every argument, return
+# type); the identical call sequence is exercised through the ctypes mirror (krylovkit.jl_amd/krylovkit_hip) by the GPU
+# tests.  INTEGRATION.md walks `eigsolve` through one thick restart column by column.
 module KrylovKitHIP
 
 using KrylovKit, VectorInterface, LinearAlgebra, SparseArrays
 import KrylovKit: apply, apply_normal, apply_adjoint, expand!, initialize, shrink!, basis,
                   OrthonormalBasis, LanczosIterator, LanczosFactorization, ArnoldiIterator,
-                  ArnoldiFactorization, GKLIterator, GKLFactorization, orthogonalize!!,
+                  ArnoldiFactorization, GKLIterator, GKLFactorization, BlockLanczosIterator,
+                  BlockLanczosFactorization, Block, orthogonalize!!,
                   project!!, unproject!!, rank1update!, basistransform!,
                   ClassicalGramSchmidt, ModifiedGramSchmidt, ClassicalGramSchmidt2,
                   ModifiedGramSchmidt2, ClassicalGramSchmidtIR, ModifiedGramSchmidtIR
 
 const lib = "libkrylov_hip"
+const KK_MAX_M = 256            # basis columns per project / unproject call (csrc/kk_internal.h); wider ranges are chunked here
 
 # ---------------------------------------------------------------- error handling
 # mirrors chklapackerror (src/dense/linalg.jl:447): integer status -> Julia exception
@@ -48,31 +61,52 @@ mutable struct HipSlab
     n::Int
     capacity::Int
     ctx::HipContext
+    used::BitVector          # column allocator of scratch slabs (all false for a slab dedicated to a basis)
     function HipSlab(ctx::HipContext, n::Integer, capacity::Integer)
         r = Ref{Ptr{Cvoid}}()
         chk(ccall((:kk_basis_create, lib), Cint, (Ptr{Cvoid}, Int64, Cint, Ref{Ptr{Cvoid}}), ctx.h, n, capacity, r))
-        finalizer(s -> ccall((:kk_basis_free, lib), Cint, (Ptr{Cvoid},), s.h), new(r[], n, capacity, ctx))
+        finalizer(s -> ccall((:kk_basis_free, lib), Cint, (Ptr{Cvoid},), s.h), new(r[], n, capacity, ctx, falses(capacity)))
     end
 end
 
-"The device vector type T of OrthonormalBasis{T}: one column of a slab."
-struct HipVec
+"The device vector type T of OrthonormalBasis{T}: one column of a slab.  `pooled` vectors own their column of a scratch slab."
+mutable struct HipVec
     slab::HipSlab
     col::Cint            # 0-based column
-end
-
-"Device sparse operator built from Julia's SparseMatrixCSC{Float64,Int64} arrays as they are."
-mutable struct HipOperator
-    h::Ptr{Cvoid}
-    size::Tuple{Int,Int}
-    function HipOperator(ctx::HipContext, A::SparseMatrixCSC{Float64,Int64}; symmetric::Bool = issymmetric(A))
-        r = Ref{Ptr{Cvoid}}()
-        chk(ccall((:kk_csc_create, lib), Cint,
-                  (Ptr{Cvoid}, Int64, Int64, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Cint, Cint, Ref{Ptr{Cvoid}}),
-                  ctx.h, size(A, 1), size(A, 2), nnz(A), A.colptr, A.rowval, A.nzval, 1, symmetric ? 1 : 0, r))
-        finalizer(o -> ccall((:kk_op_free, lib), Cint, (Ptr{Cvoid},), o.h), new(r[], size(A)))
+    pooled::Bool
+    function HipVec(slab::HipSlab, col::Integer, pooled::Bool = false)
+        v = new(slab, Cint(col), pooled)
+        pooled && finalizer(release!, v)
+        return v
     end
 end
+function release!(v::HipVec)
+    if v.pooled
+        v.slab.used[v.col + 1] = false
+        v.pooled = false
+    end
+    return nothing
+end
+samecolumn(x::HipVec, slab::HipSlab, col::Integer) = x.slab === slab && x.col == col
+
+"Device sparse operator (kk_op).  `HipOperator(ctx, A)` takes Julia's SparseMatrixCSC{Float64,Int64} arrays as they are."
+mutable struct HipOperator
+    h::Ptr{Cvoid}
+    size::Tuple{Int,Int}      # (rows, columns) as the iterators see them: local blocks for a row-sharded operator
+    ctx::HipContext
+    function HipOperator(h::Ptr{Cvoid}, sz::Tuple{Int,Int}, ctx::HipContext)
+        finalizer(o -> ccall((:kk_op_free, lib), Cint, (Ptr{Cvoid},), o.h), new(h, sz, ctx))
+    end
+end
+function HipOperator(ctx::HipContext, A::SparseMatrixCSC{Float64,Int64}; symmetric::Bool = issymmetric(A))
+    r = Ref{Ptr{Cvoid}}()
+    chk(ccall((:kk_csc_create, lib), Cint,
+              (Ptr{Cvoid}, Int64, Int64, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Cint, Cint, Ref{Ptr{Cvoid}}),
+              ctx.h, size(A, 1), size(A, 2), nnz(A), A.colptr, A.rowval, A.nzval, 1, symmetric ? 1 : 0, r))
+    return HipOperator(r[], size(A), ctx)
+end
+Base.size(A::HipOperator) = A.size
+Base.size(A::HipOperator, i::Integer) = A.size[i]
 
 orthcode(::ClassicalGramSchmidt) = (Cint(0), 0.0)
 orthcode(::ModifiedGramSchmidt) = (Cint(1), 0.0)
@@ -80,6 +114,50 @@ orthcode(::ClassicalGramSchmidt2) = (Cint(2), 0.0)
 orthcode(::ModifiedGramSchmidt2) = (Cint(3), 0.0)
 orthcode(o::ClassicalGramSchmidtIR) = (Cint(4), Float64(o.η))
 orthcode(o::ModifiedGramSchmidtIR) = (Cint(5), Float64(o.η))
+
+# ---------------------------------------------------------------- scratch pool: fresh vectors
+# `scale(x, α)`, `zerovector(x)`, the result of `apply`, `copy(::Block)`: columns of per-(context, length) scratch slabs,
+# allocated first-fit in ASCENDING order (a block of nb vectors gets nb consecutive columns) and returned by finalizers.
+const POOLS = Dict{Tuple{UInt,Int},Vector{HipSlab}}()
+function take_columns!(slab::HipSlab, count::Int)
+    run = 0
+    for c in 1:slab.capacity
+        run = slab.used[c] ? 0 : run + 1
+        if run == count
+            slab.used[(c - count + 1):c] .= true
+            return c - count          # 0-based first column
+        end
+    end
+    return -1
+end
+function fresh_columns(ctx::HipContext, n::Int, count::Int)
+    slabs = get!(POOLS, (UInt(pointer_from_objref(ctx)), n)) do
+        HipSlab[]
+    end
+    for attempt in 1:2
+        for s in slabs
+            c = take_columns!(s, count)
+            c >= 0 && return (s, c)
+        end
+        attempt == 1 && GC.gc(false)      # run the finalizers of dead scratch vectors, then look again
+    end
+    s = HipSlab(ctx, n, max(16, 2 * count))
+    push!(slabs, s)
+    return (s, take_columns!(s, count))
+end
+function fresh_like(x::HipVec)
+    s, c = fresh_columns(x.slab.ctx, x.slab.n, 1)
+    return HipVec(s, c, true)
+end
+"nb fresh vectors in consecutive columns (the layout `block_range` / kk_block_* expect)"
+function fresh_block(x::HipVec, nb::Int)
+    s, c = fresh_columns(x.slab.ctx, x.slab.n, nb)
+    return [HipVec(s, c + j - 1, true) for j in 1:nb]
+end
+function copyto_column!(dst::HipVec, src::HipVec)     # dst = src
+    chk(ccall((:kk_vec_copy_scal, lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Float64), dst.slab.h, dst.col, src.slab.h, src.col, 1.0))
+    return dst
+end
 
 # ---------------------------------------------------------------- L1: VectorInterface verbs
 # (SURVEY.md Appendix B; the un-fused fallback that makes EVERY KrylovKit algorithm run)
@@ -98,6 +176,7 @@ function VectorInterface.add!!(y::HipVec, x::HipVec, α::Number = 1, β::Number 
     chk(ccall((:kk_vec_axpby, lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Float64, Float64), y.slab.h, y.col, x.slab.h, x.col, α, β))
     return y
 end
+VectorInterface.add(y::HipVec, x::HipVec, α::Number = 1, β::Number = 1) = add!!(scale!!(fresh_like(y), y, 1), x, α, β)
 function VectorInterface.scale!!(x::HipVec, α::Number)
     chk(ccall((:kk_vec_scal, lib), Cint, (Ptr{Cvoid}, Cint, Float64), x.slab.h, x.col, α))
     return x
@@ -106,7 +185,13 @@ function VectorInterface.scale!!(y::HipVec, x::HipVec, α::Number)
     chk(ccall((:kk_vec_copy_scal, lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Float64), y.slab.h, y.col, x.slab.h, x.col, α))
     return y
 end
-# ---- host <-> device, fresh vectors
+VectorInterface.scale(x::HipVec, α::Number) = scale!!(fresh_like(x), x, α)
+function VectorInterface.zerovector!!(x::HipVec)
+    chk(ccall((:kk_vec_zero, lib), Cint, (Ptr{Cvoid}, Cint), x.slab.h, x.col))
+    return x
+end
+VectorInterface.zerovector(x::HipVec, ::Type{Float64} = Float64) = zerovector!!(fresh_like(x))
+# ---- host <-> device
 function upload!(x::HipVec, h::Vector{Float64})
     length(h) == x.slab.n || throw(DimensionMismatch())
     chk(ccall((:kk_basis_upload, lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Float64}), x.slab.h, x.col, h))
@@ -117,44 +202,108 @@ function download(x::HipVec)
     chk(ccall((:kk_basis_download, lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Float64}), x.slab.h, x.col, h))
     return h
 end
-# Fresh vectors (`scale(x, α)`, `zerovector(x)`, the result of `apply`) are columns of a per-context
-# scratch slab handed out from a free list; a finalizer-bearing wrapper returns the column.
-mutable struct ScratchPool
-    slab::HipSlab
-    free::Vector{Cint}
+"start vector on the device: x₀ = HipVec(ctx, rand(n))"
+function HipVec(ctx::HipContext, h::Vector{Float64})
+    s, c = fresh_columns(ctx, length(h), 1)
+    return upload!(HipVec(s, c, true), h)
 end
-const POOLS = IdDict{HipContext,ScratchPool}()
-function scratch_like(x::HipVec; ncols::Int = 8)
-    pool = get!(POOLS, x.slab.ctx) do
-        ScratchPool(HipSlab(x.slab.ctx, x.slab.n, ncols), collect(Cint(0):Cint(ncols - 1)))
-    end
-    isempty(pool.free) && error("KrylovKitHIP: scratch pool exhausted (raise ncols)")
-    return HipVec(pool.slab, pop!(pool.free))
-end
-release!(x::HipVec) = (p = get(POOLS, x.slab.ctx, nothing); p !== nothing && p.slab === x.slab && push!(p.free, x.col); nothing)
-function VectorInterface.zerovector(x::HipVec, ::Type{Float64} = Float64)
-    y = scratch_like(x)
-    chk(ccall((:kk_vec_zero, lib), Cint, (Ptr{Cvoid}, Cint), y.slab.h, y.col))
-    return y
-end
-VectorInterface.zerovector!!(x::HipVec) = (chk(ccall((:kk_vec_zero, lib), Cint, (Ptr{Cvoid}, Cint), x.slab.h, x.col)); x)
-VectorInterface.scale(x::HipVec, α::Number) = scale!!(scratch_like(x), x, α)
 
 # ---------------------------------------------------------------- L1: operator protocol (src/apply.jl:1-19)
-function apply(A::HipOperator, x::HipVec, y::HipVec = scratch_like(x); transpose::Bool = false)
+function apply(A::HipOperator, x::HipVec, y::HipVec = fresh_like(x); transpose::Bool = false)
+    if y.slab.n != (transpose ? A.size[2] : A.size[1])           # rectangular map: the result lives in the other space
+        s, c = fresh_columns(x.slab.ctx, transpose ? A.size[2] : A.size[1], 1)
+        y = HipVec(s, c, true)
+    end
     chk(ccall((:kk_spmv, lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint), A.h, transpose, x.slab.h, x.col, y.slab.h, y.col))
     return y
 end
 apply_normal(A::HipOperator, x::HipVec) = apply(A, x)
 apply_adjoint(A::HipOperator, x::HipVec) = apply(A, x; transpose = true)
+# affine form apply(op, x, a₀, a₁) = a₀ x + a₁ A x (src/apply.jl:4-11), one fused launch
+function apply(A::HipOperator, x::HipVec, a₀::Number, a₁::Number)
+    y = fresh_like(x)
+    chk(ccall((:kk_spmv_affine, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Float64, Float64), A.h, x.slab.h, x.col, y.slab.h, y.col, a₀, a₁))
+    return y
+end
+
+# ---------------------------------------------------------------- rule 1: home columns of a basis
+# (home slab, 0-based home column) of element i; `nothing` while the basis is empty (its first element defines the origin)
+function home(b::OrthonormalBasis{HipVec}, i::Integer)
+    isempty(b.basis) && return nothing
+    f = b.basis[1]
+    return (f.slab, Int(f.col) + i - 1)
+end
+# move a basis (and nothing else) into a larger dedicated slab; the elements are re-bound in place (HipVec is mutable)
+function grow!(b::OrthonormalBasis{HipVec}, ncols::Int)
+    isempty(b.basis) && return b
+    old, c0 = b.basis[1].slab, Int(b.basis[1].col)
+    old.capacity - c0 >= ncols && return b
+    new = HipSlab(old.ctx, old.n, ncols)
+    for (i, v) in enumerate(b.basis)
+        copyto_column!(HipVec(new, i - 1), v)
+        release!(v)
+        v.slab = new
+        v.col = Cint(i - 1)
+    end
+    return b
+end
+# a scratch vector cannot be the origin of a basis (its neighbours belong to other vectors): give the basis its own slab
+function dedicate!(b::OrthonormalBasis{HipVec}, ncols::Int = 32)
+    (isempty(b.basis) || !any(b.basis[1].slab.used)) && return b
+    f = b.basis[1]
+    new = HipSlab(f.slab.ctx, f.slab.n, max(ncols, length(b.basis) + 2))
+    for (i, v) in enumerate(b.basis)
+        copyto_column!(HipVec(new, i - 1), v)
+        release!(v)
+        v.slab = new
+        v.col = Cint(i - 1)
+    end
+    return b
+end
+function place!(b::OrthonormalBasis{HipVec}, v::HipVec, i::Integer)
+    h = home(b, i)
+    if h === nothing                       # first element
+        v.pooled || return v
+        dst = HipVec(HipSlab(v.slab.ctx, v.slab.n, 32), 0)
+        return copyto_column!(dst, v)
+    end
+    dedicate!(b)
+    slab, col = home(b, i)
+    samecolumn(v, slab, col) && return v
+    if col >= slab.capacity
+        grow!(b, 2 * (col + 1))
+        slab, col = home(b, i)
+    end
+    return copyto_column!(HipVec(slab, col), v)
+end
+Base.push!(b::OrthonormalBasis{HipVec}, v::HipVec) = (push!(b.basis, place!(b, v, length(b.basis) + 1)); b)
+function Base.setindex!(b::OrthonormalBasis{HipVec}, v::HipVec, i::Integer)     # e.g. B[keep+1] = scale!!(r, 1/β), eigsolve/lanczos.jl:111
+    1 <= i <= length(b.basis) || throw(BoundsError(b.basis, i))
+    b.basis[i] = place!(b, v, i)
+    return b
+end
+# sizehint!(fact, krylovdim) (eigsolve/lanczos.jl:27, linsolve/gmres.jl:41): make room for krylovdim vectors + residual + 1
+Base.sizehint!(b::OrthonormalBasis{HipVec}, k::Int) = (sizehint!(b.basis, k); dedicate!(b, k + 2); grow!(b, k + 2); b)
+# (slab, first column, length) of a basis whose elements are at home
+function slab_range(b::OrthonormalBasis{HipVec})
+    f = first(b)
+    return (f.slab, f.col, Cint(length(b)))
+end
+# rule 2: the vector `r` as the column behind the basis (copy only if it is somewhere else)
+function residual_home!(b::OrthonormalBasis{HipVec}, r::HipVec)
+    dedicate!(b)
+    slab, c0, k = slab_range(b)
+    Int(c0) + Int(k) + 2 <= slab.capacity || (grow!(b, 2 * (Int(k) + 2)); (slab, c0, k) = slab_range(b))
+    samecolumn(r, slab, c0 + k) && return r
+    return copyto_column!(HipVec(slab, c0 + k), r)
+end
 
 # ---------------------------------------------------------------- L2: orthonormal.jl entry points
-# project!! (orthonormal.jl:88-118), unproject!! (:132-196), orthogonalize!! (:378-452),
+# project!! (orthonormal.jl:88-118), unproject!! (:132-196), orthogonalize!! (:378-452 and :455-489),
 # basistransform! (:291-354), rmul!(b, Givens / Householder) (dense/givens.jl, reflector.jl:143-154)
-slab_range(b::OrthonormalBasis{HipVec}) = (first(b).slab, first(b).col, Cint(length(b)))   # columns are contiguous by construction
-
 function orthogonalize!!(w::HipVec, b::OrthonormalBasis{HipVec}, x::AbstractVector, alg::KrylovKit.Orthogonalizer)
     slab, c0, m = slab_range(b)
+    m <= KK_MAX_M || error("KrylovKitHIP: orthogonalize!! against more than $KK_MAX_M vectors")
     code, η = orthcode(alg)
     xs = Vector{Float64}(undef, m)
     chk(ccall((:kk_orthogonalize, lib), Cint,
@@ -163,13 +312,23 @@ function orthogonalize!!(w::HipVec, b::OrthonormalBasis{HipVec}, x::AbstractVect
     copyto!(x, xs)
     return (w, x)
 end
+function orthogonalize!!(v::HipVec, q::HipVec, alg::KrylovKit.Orthogonalizer)     # vector against vector
+    code, η = orthcode(alg)
+    s = Ref{Float64}()
+    chk(ccall((:kk_orthogonalize_vec, lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Cint, Float64, Ref{Float64}, Ptr{Float64}),
+              q.slab.h, q.col, v.slab.h, v.col, code, η, s, C_NULL))
+    return (v, s[])
+end
 function project!!(y::AbstractVector, b::OrthonormalBasis{HipVec}, x::HipVec, α::Number = true, β::Number = false,
                    r = Base.OneTo(length(b)))
     slab, c0, _ = slab_range(b)
     length(y) == length(r) || throw(DimensionMismatch())
     ys = Vector{Float64}(y)
-    chk(ccall((:kk_project, lib), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Cint, Float64, Float64, Ptr{Float64}),
-              slab.h, c0 + first(r) - 1, length(r), x.slab.h, x.col, α, β, ys))
+    for j0 in 0:KK_MAX_M:(length(r) - 1)                 # panels of at most KK_MAX_M basis vectors
+        mm = min(KK_MAX_M, length(r) - j0)
+        chk(ccall((:kk_project, lib), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Cint, Float64, Float64, Ptr{Float64}),
+                  slab.h, c0 + first(r) - 1 + j0, mm, x.slab.h, x.col, α, β, pointer(ys, j0 + 1)))
+    end
     copyto!(y, ys)
     return y
 end
@@ -177,8 +336,12 @@ function unproject!!(y::HipVec, b::OrthonormalBasis{HipVec}, x::AbstractVector, 
                      r = Base.OneTo(length(b)))
     slab, c0, _ = slab_range(b)
     length(x) == length(r) || throw(DimensionMismatch())
-    chk(ccall((:kk_unproject, lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Cint, Ptr{Float64}, Float64, Float64),
-              y.slab.h, y.col, slab.h, c0 + first(r) - 1, length(r), Vector{Float64}(x), α, β))
+    xs = Vector{Float64}(x)
+    for j0 in 0:KK_MAX_M:(length(r) - 1)                 # y = β y + α Σ ... : β applies to the first panel only
+        mm = min(KK_MAX_M, length(r) - j0)
+        chk(ccall((:kk_unproject, lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Cint, Ptr{Float64}, Float64, Float64),
+                  y.slab.h, y.col, slab.h, c0 + first(r) - 1 + j0, mm, pointer(xs, j0 + 1), α, j0 == 0 ? β : 1.0))
+    end
     return y
 end
 function rank1update!(b::OrthonormalBasis{HipVec}, y::HipVec, x::AbstractVector, α::Number = true, β::Number = true,
@@ -195,7 +358,7 @@ function LinearAlgebra.rmul!(b::OrthonormalBasis{HipVec}, H::KrylovKit.Household
               slab.h, c0 + first(H.r) - 1, length(H.r), Vector{Float64}(H.v), H.β))
     return b
 end
-function basistransform!(b::OrthonormalBasis{HipVec}, U::AbstractMatrix)
+function basistransform!(b::OrthonormalBasis{HipVec}, U::AbstractMatrix)    # orthonormal.jl:291-354
     slab, c0, m = slab_range(b)
     Ud = Matrix{Float64}(U)
     size(Ud, 1) == m || throw(DimensionMismatch())
@@ -208,65 +371,83 @@ function LinearAlgebra.rmul!(b::OrthonormalBasis{HipVec}, G::LinearAlgebra.Given
     return b
 end
 
-# ---------------------------------------------------------------- L3: initialize / shrink!
-# initialize(iter::LanczosIterator) (factorizations/lanczos.jl:180-222): x0 is column 0 of a slab with
-# krylovdim + 2 columns; on return column 0 = v1, column 1 = r.
+# ---------------------------------------------------------------- L3: fused initialize
+# initialize(iter) for Lanczos (factorizations/lanczos.jl:180-222) and Arnoldi (arnoldi.jl:135-175): the factorization gets
+# a slab of its own; column 0 = x₀ on entry, v₁ on return, column 1 = r.  iter.x₀ itself is not modified.
+function krylov_slab(x₀::HipVec, ncols::Int = 32)
+    slab = HipSlab(x₀.slab.ctx, x₀.slab.n, ncols)
+    copyto_column!(HipVec(slab, 0), x₀)
+    return slab
+end
 function initialize(iter::LanczosIterator{HipOperator,HipVec}; verbosity::Int = 0)
-    x0 = iter.x₀
+    slab = krylov_slab(iter.x₀)
     code, η = orthcode(iter.orth)
     α, β = Ref{Float64}(), Ref{Float64}()
     chk(ccall((:kk_lanczos_initialize, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cint, Float64, Ref{Float64}, Ref{Float64}),
-              iter.operator.h, x0.slab.h, x0.col, code, η, α, β))
-    V = OrthonormalBasis([HipVec(x0.slab, x0.col)])
-    return LanczosFactorization(1, V, [α[]], [β[]], HipVec(x0.slab, x0.col + 1))
+              iter.operator.h, slab.h, 0, code, η, α, β))
+    return LanczosFactorization(1, OrthonormalBasis([HipVec(slab, 0)]), [α[]], [β[]], HipVec(slab, 1))
 end
-# shrink!(state, k) (lanczos.jl:273-291): the vectors stay where they are; only the residual is rescaled
-function shrink!(state::LanczosFactorization{HipVec}, k; verbosity::Int = 0)
-    length(state) <= k && return state
-    V = state.V
-    while length(V) > k + 1
-        pop!(V)
-    end
-    r = pop!(V)
-    resize!(state.αs, k); resize!(state.βs, k)
-    state.k = k
-    state.r = scale!!(r, KrylovKit.normres(state))
-    return state
+function initialize(iter::ArnoldiIterator{HipOperator,HipVec}; verbosity::Int = 0)
+    slab = krylov_slab(iter.x₀)
+    code, η = orthcode(iter.orth)
+    α, β = Ref{Float64}(), Ref{Float64}()
+    chk(ccall((:kk_arnoldi_initialize, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cint, Float64, Ref{Float64}, Ref{Float64}),
+              iter.operator.h, slab.h, 0, code, η, α, β))
+    return ArnoldiFactorization(1, OrthonormalBasis([HipVec(slab, 0)]), [α[], β[]], HipVec(slab, 1))
 end
+# initialize(iter::GKLIterator) (gkl.jl:183-215): U and V get one slab each; U column 0 = u₀ on entry
+function initialize(iter::GKLIterator{HipOperator,HipVec}; verbosity::Int = 0)
+    u₀ = iter.u₀
+    su = krylov_slab(u₀)
+    sv = HipSlab(u₀.slab.ctx, size(iter.operator, 2), 32)
+    α, β = Ref{Float64}(), Ref{Float64}()
+    chk(ccall((:kk_gkl_initialize, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{Float64}, Ref{Float64}),
+              iter.operator.h, su.h, sv.h, α, β))
+    return GKLFactorization(1, OrthonormalBasis([HipVec(su, 0)]), OrthonormalBasis([HipVec(sv, 0)]), [α[]], [β[]], HipVec(su, 1))
+end
+# initialize!(iter, state) (lanczos.jl:223-249, arnoldi.jl:176-198, gkl.jl:216-245) and shrink! (lanczos.jl:273-291,
+# arnoldi.jl:220-236, gkl.jl:270-291) need no overload: the reference's generic code runs on the verbs above, `V[1] = ...`
+# and `push!` keep every basis vector in its home column (rule 1), and whatever vector ends up in `state.r` is brought
+# behind the basis by the next expand! (rule 2).
 
 # ---------------------------------------------------------------- L3: fused expand! (the hot path)
 # Lanczos: factorizations/lanczos.jl:250-272.  One ccall = scale + SpMV(+three-term tail, alpha)
 # + projection pass + update (+ norm): one host sync.
-function expand!(iter::LanczosIterator{HipOperator,HipVec}, state::LanczosFactorization; verbosity::Int = 0)
+function expand!(iter::LanczosIterator{HipOperator,HipVec}, state::LanczosFactorization{HipVec}; verbosity::Int = 0)
     βold = KrylovKit.normres(state)
     V = state.V
+    residual_home!(V, state.r)
     slab, c0, k = slab_range(V)
     code, η = orthcode(iter.orth)
     α, β, np = Ref{Float64}(), Ref{Float64}(), Ref{Cint}()
     chk(ccall((:kk_lanczos_expand, lib), Cint,
               (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cint, Cint, Float64, Float64, Ref{Float64}, Ref{Float64}, Ref{Cint}),
               iter.operator.h, slab.h, c0, k, code, η, βold, α, β, np))
-    push!(V, HipVec(slab, c0 + k))             # V = push!(V, scale!!(r, 1/βold))      lanczos.jl:257
+    push!(V, HipVec(slab, c0 + k))             # V = push!(V, scale!!(r, 1/βold))      lanczos.jl:257 (already in place)
     push!(state.αs, α[]); push!(state.βs, β[])  #                                       :261-262
+    !iter.keepvecs && popfirst!(state.V)        #                                       :264
     state.k += 1
     state.r = HipVec(slab, c0 + k + 1)
     return state
 end
 
 # Arnoldi: factorizations/arnoldi.jl:199-219 (GMRES: linsolve/gmres.jl:59)
-function expand!(iter::ArnoldiIterator{HipOperator,HipVec}, state::ArnoldiFactorization; verbosity::Int = 0)
+function expand!(iter::ArnoldiIterator{HipOperator,HipVec}, state::ArnoldiFactorization{HipVec}; verbosity::Int = 0)
+    V, H = state.V, state.H
+    β = KrylovKit.normres(state)
+    residual_home!(V, state.r)
+    slab, c0, kk = slab_range(V)
     state.k += 1
     k = state.k
-    V, H = state.V, state.H
-    slab, c0, kk = slab_range(V)
     code, η = orthcode(iter.orth)
-    β = KrylovKit.normres(state)
     m = length(H)
     resize!(H, m + k + 1)
     βn, np = Ref{Float64}(), Ref{Cint}()
-    chk(ccall((:kk_arnoldi_expand, lib), Cint,
-              (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cint, Cint, Float64, Float64, Ptr{Float64}, Ref{Float64}, Ref{Cint}),
-              iter.operator.h, slab.h, c0, kk, code, η, β, pointer(H, m + 1), βn, np))
+    GC.@preserve H begin
+        chk(ccall((:kk_arnoldi_expand, lib), Cint,
+                  (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cint, Cint, Float64, Float64, Ptr{Float64}, Ref{Float64}, Ref{Cint}),
+                  iter.operator.h, slab.h, c0, kk, code, η, β, pointer(H, m + 1), βn, np))
+    end
     H[m + k + 1] = βn[]
     push!(V, HipVec(slab, c0 + kk))
     state.r = HipVec(slab, c0 + kk + 1)
@@ -274,11 +455,15 @@ function expand!(iter::ArnoldiIterator{HipOperator,HipVec}, state::ArnoldiFactor
 end
 
 # GKL: factorizations/gkl.jl:246-269
-function expand!(iter::GKLIterator{HipOperator,HipVec}, state::GKLFactorization; verbosity::Int = 0)
+function expand!(iter::GKLIterator{HipOperator,HipVec}, state::GKLFactorization{HipVec,HipVec}; verbosity::Int = 0)
     βold = KrylovKit.normres(state)
     U, V = state.U, state.V
-    su, _, k = slab_range(U)
-    sv, _, _ = slab_range(V)
+    residual_home!(U, state.r)
+    dedicate!(V)
+    su, cu, k = slab_range(U)
+    sv, cv, kv = slab_range(V)
+    (cu == 0 && cv == 0 && kv == k) || error("KrylovKitHIP: GKL bases must start at column 0 of their slabs")
+    Int(k) + 1 <= sv.capacity || (grow!(V, 2 * (Int(k) + 1)); sv = first(V).slab)
     code, η = orthcode(iter.orth)
     α, β, pv, pu = Ref{Float64}(), Ref{Float64}(), Ref{Cint}(), Ref{Cint}()
     chk(ccall((:kk_gkl_expand, lib), Cint,
@@ -292,36 +477,188 @@ function expand!(iter::GKLIterator{HipOperator,HipVec}, state::GKLFactorization;
 end
 
 # ---------------------------------------------------------------- BlockLanczos (factorizations/blocklanczos.jl)
-# A Block{HipVec} holds consecutive columns of one slab.
-block_range(B::KrylovKit.Block{HipVec}) = (first(B.vec).slab, first(B.vec).col, Cint(length(B)))
-function KrylovKit.block_inner(B₁::KrylovKit.Block{HipVec}, B₂::KrylovKit.Block{HipVec})
-    s1, c1, p = block_range(B₁); s2, c2, q = block_range(B₂)
+# A Block{HipVec} used with the kk_block_* entry points holds consecutive columns of one slab.
+function block_range(B::Block{HipVec})
+    s, c = first(B.vec).slab, first(B.vec).col
+    all(i -> samecolumn(B.vec[i], s, c + i - 1), 1:length(B)) || error("KrylovKitHIP: the vectors of this Block are not consecutive columns of one slab")
+    return (s, c, Cint(length(B)))
+end
+# a Block whose vectors sit anywhere -> consecutive scratch columns
+function contiguous(B::Block{HipVec})
+    s, c = first(B.vec).slab, first(B.vec).col
+    all(i -> samecolumn(B.vec[i], s, c + i - 1), 1:length(B)) && return B
+    vs = fresh_block(first(B.vec), length(B))
+    for i in 1:length(B)
+        copyto_column!(vs[i], B.vec[i])
+    end
+    return Block(vs)
+end
+function Base.copy(B::Block{HipVec})                               # blocklanczos.jl:62: Rcopy = copy(R)
+    vs = fresh_block(first(B.vec), length(B))
+    for i in 1:length(B)
+        copyto_column!(vs[i], B.vec[i])
+    end
+    return Block(vs)
+end
+function KrylovKit.block_inner(B₁::Block{HipVec}, B₂::Block{HipVec})    # blocklanczos.jl:43-52
+    s1, c1, p = block_range(contiguous(B₁)); s2, c2, q = block_range(contiguous(B₂))
     M = Matrix{Float64}(undef, p, q)
     chk(ccall((:kk_block_inner, lib), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Cint, Cint, Ptr{Float64}, Cint),
               s1.h, c1, p, s2.h, c2, q, M, p))
     return M
 end
-function KrylovKit.block_qr!(block::KrylovKit.Block{HipVec}, tol::Real)
+# block_qr! (blocklanczos.jl:312-353) is IN PLACE in the reference: vector j stays at index j, dependent ones are zeroed,
+# the caller indexes with the returned good_idx.  kk_block_qr compacts the good vectors to the front; on a rank drop they are
+# moved back to their original positions here.
+function KrylovKit.block_qr!(block::Block{HipVec}, tol::Real)
     s, c, p = block_range(block)
     R = zeros(p, p); good = Vector{Cint}(undef, p); ng = Ref{Cint}(); drift = Ref{Cint}()
     chk(ccall((:kk_block_qr, lib), Cint,
               (Ptr{Cvoid}, Cint, Cint, Cint, Float64, Ptr{Float64}, Cint, Ptr{Cint}, Ref{Cint}, Ref{Cint}),
               s.h, c, p, c, tol, R, p, good, ng, drift))
-    gi = Int.(good[1:ng[]]) .+ 1
-    return R[1:ng[], :], gi, drift[] != 0      # NB: the good vectors are compacted to the first ng columns
+    n = Int(ng[])
+    gi = Int.(good[1:n]) .+ 1
+    if n < p
+        for i in n:-1:1                                   # good[i] >= i: moving from the back never overwrites a good vector
+            gi[i] != i && copyto_column!(block.vec[gi[i]], block.vec[i])
+        end
+        for j in setdiff(1:p, gi)
+            zerovector!!(block.vec[j])
+        end
+    end
+    return R[1:n, :], gi, drift[] != 0
 end
-function KrylovKit.block_reorthogonalize!(R::KrylovKit.Block{HipVec}, V::OrthonormalBasis{HipVec})
-    sv, c0, m = slab_range(V); sr, cr, q = block_range(R)
-    sv === sr || error("block and basis must share a slab")
+function KrylovKit.block_reorthogonalize!(R::Block{HipVec}, V::OrthonormalBasis{HipVec})   # blocklanczos.jl:277-284
+    sv, c0, m = slab_range(V)
+    sr, cr, q = block_range(R)
+    if sv !== sr                                          # kk_block_reorthogonalize addresses ONE slab: go through the basis slab
+        Int(c0) + Int(m) + Int(q) <= sv.capacity || (grow!(V, Int(m) + 2 * Int(q)); (sv, c0, m) = slab_range(V))
+        tmp = [copyto_column!(HipVec(sv, c0 + m + j - 1), R.vec[j]) for j in 1:Int(q)]
+        chk(ccall((:kk_block_reorthogonalize, lib), Cint, (Ptr{Cvoid}, Cint, Cint, Cint, Cint), sv.h, c0, m, c0 + m, q))
+        for j in 1:Int(q)
+            copyto_column!(R.vec[j], tmp[j])
+        end
+        return R
+    end
     chk(ccall((:kk_block_reorthogonalize, lib), Cint, (Ptr{Cvoid}, Cint, Cint, Cint, Cint), sv.h, c0, m, cr, q))
     return R
 end
-function apply(A::HipOperator, X::KrylovKit.Block{HipVec})
-    s, c, nb = block_range(X)
-    Y = KrylovKit.Block([scratch_like(X[1]) for _ in 1:nb])            # contiguous by construction of the pool
+function apply(A::HipOperator, X::Block{HipVec})                   # blocklanczos.jl:39, one SpMM
+    Xc = contiguous(X)
+    s, c, nb = block_range(Xc)
+    Y = Block(fresh_block(first(X.vec), Int(nb)))
     sy, cy, _ = block_range(Y)
     chk(ccall((:kk_block_apply, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Cint), A.h, s.h, c, sy.h, cy, nb))
     return Y
+end
+
+# fused initialize / expand!  (blocklanczos.jl:159-240).  Slab layout: columns 0 .. maxdim-1 basis, then two residual areas
+# of bs₀ columns used alternately (block_qr! runs out of place: the untouched input is the reference's `Rcopy`), then the
+# start block.
+function initialize(iter::BlockLanczosIterator{HipOperator,HipVec}; verbosity::Int = 0)
+    X₀ = iter.x₀
+    bs₀, maxdim = length(X₀), iter.maxdim
+    x = first(X₀.vec)
+    slab = HipSlab(x.slab.ctx, x.slab.n, maxdim + 3 * bs₀)
+    area_a, area_b, c_x0 = maxdim, maxdim + bs₀, maxdim + 2 * bs₀
+    for j in 1:bs₀
+        copyto_column!(HipVec(slab, c_x0 + j - 1), X₀.vec[j])
+    end
+    bs, nr = Ref{Cint}(), Ref{Float64}()
+    M₁ = zeros(bs₀, bs₀)
+    chk(ccall((:kk_blocklanczos_initialize, lib), Cint,
+              (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cint, Cint, Float64, Ref{Cint}, Ptr{Float64}, Cint, Ref{Float64}),
+              iter.operator.h, slab.h, c_x0, bs₀, area_a, Float64(iter.qr_tol), bs, M₁, bs₀, nr))
+    b = Int(bs[])
+    BTD = zeros(Float64, maxdim, maxdim)
+    BTD[1:b, 1:b] = view(M₁, 1:b, 1:b)
+    V = OrthonormalBasis([HipVec(slab, j - 1) for j in 1:b])
+    R = Block([HipVec(slab, area_a + j - 1) for j in 1:bs₀])          # R.vec keeps bs₀ slots, R_size says how many are live
+    return BlockLanczosFactorization(b, V, BTD, R, b, nr[])
+end
+function expand!(iter::BlockLanczosIterator{HipOperator,HipVec}, state::BlockLanczosFactorization{HipVec}; verbosity::Int = 0)
+    k, bs = state.k, state.R_size
+    V = state.V
+    slab, c0, kv = slab_range(V)
+    (c0 == 0 && kv == k) || error("KrylovKitHIP: BlockLanczos basis must start at column 0 of its slab")
+    maxdim, bs₀ = iter.maxdim, length(state.R.vec)
+    slab.capacity >= maxdim + 2 * bs₀ || error("KrylovKitHIP: this BlockLanczosFactorization was not created by the fused initialize")
+    area_a, area_b = maxdim, maxdim + bs₀
+    # the live residual block as consecutive columns of one of the two areas (it is there unless a restart re-bound it)
+    c_r = Int(first(state.R.vec).col)
+    if !(first(state.R.vec).slab === slab && (c_r == area_a || c_r == area_b) &&
+         all(j -> samecolumn(state.R.vec[j], slab, c_r + j - 1), 1:bs))
+        for j in 1:bs
+            copyto_column!(HipVec(slab, area_a + j - 1), state.R.vec[j])
+        end
+        c_r = area_a
+    end
+    c_next = c_r == area_a ? area_b : area_a
+    bsn, nr, drift = Ref{Cint}(), Ref{Float64}(), Ref{Cint}()
+    B = zeros(bs, bs); M = zeros(bs, bs)
+    chk(ccall((:kk_blocklanczos_expand, lib), Cint,
+              (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cint, Cint, Cint, Float64, Ref{Cint}, Ptr{Float64}, Cint, Ptr{Float64}, Cint, Ref{Float64}, Ref{Cint}),
+              iter.operator.h, slab.h, k, bs, c_r, c_next, Float64(iter.qr_tol), bsn, B, bs, M, bs, nr, drift))
+    n = Int(bsn[])
+    for j in 1:n
+        push!(V, HipVec(slab, k + j - 1))                              # push!(V, R[good_idx])                    :219
+    end
+    state.H[(k + 1):(k + n), (k - bs + 1):k] = view(B, 1:n, 1:bs)      #                                          :220
+    state.H[(k - bs + 1):k, (k + 1):(k + n)] = view(B, 1:n, 1:bs)'     #                                          :221
+    state.H[(k + 1):(k + n), (k + 1):(k + n)] = view(M, 1:n, 1:n)      #                                          :229
+    for j in 1:n
+        state.R.vec[j] = HipVec(slab, c_next + j - 1)                  # state.R.vec[1:bs_next] = Rnext.vec        :233
+    end
+    state.norm_R = nr[]
+    state.k += n
+    state.R_size = n
+    return state
+end
+
+# ---------------------------------------------------------------- multi-GPU: RCCL inside libkrylov_hip
+# One Julia process per GPU.  Rank 0 obtains the 128-byte communicator id and hands it to the others over any channel
+# (MPI.jl `MPI.Bcast!`, a shared file, a socket); every rank then calls `init_comm!`.  From that point ALL methods of this
+# file work on row-sharded vectors (a slab of n rows is this rank's block) and the library issues its collectives itself.
+function comm_unique_id()
+    id = Vector{UInt8}(undef, 128)
+    chk(ccall((:kk_comm_get_unique_id, lib), Cint, (Ptr{UInt8},), id))
+    return id
+end
+function init_comm!(ctx::HipContext, id::Vector{UInt8}, rank::Integer, world::Integer; force_collectives::Bool = false)
+    length(id) == 128 || throw(ArgumentError("communicator id must have 128 bytes"))
+    chk(ccall((:kk_comm_init, lib), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Cint, Cint, Cint), ctx.h, id, rank, world, force_collectives ? 1 : 0))
+    return ctx
+end
+destroy_comm!(ctx::HipContext) = (chk(ccall((:kk_comm_destroy, lib), Cint, (Ptr{Cvoid},), ctx.h)); ctx)
+comm_barrier(ctx::HipContext) = (chk(ccall((:kk_comm_barrier, lib), Cint, (Ptr{Cvoid},), ctx.h)); nothing)
+"""
+    sharded_operator(ctx, Arows, row_offsets; symmetric)
+
+This rank's rows of a square global operator: `Arows` holds them as the columns of a SparseMatrixCSC (i.e. `Arows = A[rows, :]'`
+stored column-wise = CSR of the row block, global column indices as its row indices), `row_offsets` (0-based, world+1 entries)
+is the row partition.  The ghost-exchange plan is negotiated inside the library (collective call).
+"""
+function sharded_operator(ctx::HipContext, ArowsT::SparseMatrixCSC{Float64,Int64}, row_offsets::Vector{Int64}; symmetric::Bool = false)
+    r = Ref{Ptr{Cvoid}}()
+    nloc = size(ArowsT, 2)
+    chk(ccall((:kk_csr_create_sharded, lib), Cint,
+              (Ptr{Cvoid}, Int64, Ptr{Int64}, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Cint, Cint, Ref{Ptr{Cvoid}}),
+              ctx.h, nloc, row_offsets, nnz(ArowsT), ArowsT.colptr, ArowsT.rowval, ArowsT.nzval, 1, symmetric ? 1 : 0, r))
+    return HipOperator(r[], (nloc, nloc), ctx)
+end
+"""
+    sharded_rect_operator(ctx, ArowsT, ncols_global)
+
+This rank's rows of a rectangular global map for svdsolve / GKL (`ArowsT` as above); the short vectors are sharded evenly,
+`size(op, 2)` is this rank's share.
+"""
+function sharded_rect_operator(ctx::HipContext, ArowsT::SparseMatrixCSC{Float64,Int64}, ncols_global::Integer)
+    r = Ref{Ptr{Cvoid}}(); ncl = Ref{Int64}()
+    nloc = size(ArowsT, 2)
+    chk(ccall((:kk_csr_create_sharded_rect, lib), Cint,
+              (Ptr{Cvoid}, Int64, Int64, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Cint, Ref{Ptr{Cvoid}}, Ref{Int64}),
+              ctx.h, nloc, ncols_global, nnz(ArowsT), ArowsT.colptr, ArowsT.rowval, ArowsT.nzval, 1, r, ncl))
+    return HipOperator(r[], (nloc, Int(ncl[])), ctx)
 end
 
 # ---------------------------------------------------------------- short-recurrence solvers (SURVEY 8(f)-3)

@@ -146,6 +146,7 @@ SIGNATURES = {
     "kk_csr_create_sharded": (C.c_int, [c_vp, C.c_int64, c_i64p, C.c_int64, c_i64p, c_i64p, c_dp, C.c_int, C.c_int, c_vpp]),
     "kk_csr_create_sharded_rect": (C.c_int, [c_vp, C.c_int64, C.c_int64, C.c_int64, c_i64p, c_i64p, c_dp, C.c_int, c_vpp, c_i64p]),
 }
+KK_MAX_M = 256   # basis vectors per project / unproject / fused expand call (csrc/kk_internal.h)
 KK_COMM_ID_BYTES = 128
 KK_COMM_FORCE_COLLECTIVES = 1
 

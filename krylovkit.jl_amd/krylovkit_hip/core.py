@@ -210,7 +210,11 @@ class DeviceBasis:
             y = np.zeros(m)
         if y.shape != (m,):
             raise _lib.DimensionMismatch(_lib.KK_ERR_DIM, "project: length(y) != length(r)")
-        check(self._lib.kk_project(self.handle, c0, m, x.basis.handle, x.col, alpha, beta, _dp(y)))
+        for j0 in range(0, m, _lib.KK_MAX_M):     # the library takes at most KK_MAX_M basis vectors per call
+            mm = min(_lib.KK_MAX_M, m - j0)
+            yj = np.ascontiguousarray(y[j0:j0 + mm])
+            check(self._lib.kk_project(self.handle, c0 + j0, mm, x.basis.handle, x.col, alpha, beta, _dp(yj)))
+            y[j0:j0 + mm] = yj
         return y
 
     def unproject(self, y: "HipVec", x: Sequence[float], c0: int = 0, m: Optional[int] = None, alpha: float = 1.0,
@@ -220,7 +224,12 @@ class DeviceBasis:
         xa = np.ascontiguousarray(x, dtype=np.float64)
         if xa.shape != (m,):
             raise _lib.DimensionMismatch(_lib.KK_ERR_DIM, "unproject: length(x) != length(r)")
-        check(self._lib.kk_unproject(y.basis.handle, y.col, self.handle, c0, m, _dp(xa), alpha, beta))
+        if m == 0:
+            check(self._lib.kk_unproject(y.basis.handle, y.col, self.handle, c0, 0, _dp(xa), alpha, beta))
+        for j0 in range(0, m, _lib.KK_MAX_M):     # panels of KK_MAX_M vectors; beta applies to the first one only
+            mm = min(_lib.KK_MAX_M, m - j0)
+            xj = np.ascontiguousarray(xa[j0:j0 + mm])
+            check(self._lib.kk_unproject(y.basis.handle, y.col, self.handle, c0 + j0, mm, _dp(xj), alpha, beta if j0 == 0 else 1.0))
         return y
 
     def rank1update(self, y: "HipVec", x: Sequence[float], c0: int = 0, m: Optional[int] = None, alpha: float = 1.0,

@@ -148,6 +148,14 @@ class LanczosIterator:  # lanczos.jl:129-153
     def __post_init__(self):
         if not self.keepvecs and self.orth.is_reorth:
             raise ValueError("Cannot use reorthogonalization without keeping all Krylov vectors")  # lanczos.jl:140-142
+        _check_capacity(self.capacity, self.keepvecs)
+
+
+def _check_capacity(capacity: int, keepvecs: bool = True):
+    """The fused expand! entry points address at most KK_MAX_M basis vectors (a library limit the reference does not have):
+    say so when the iterator is built, not halfway through a factorization."""
+    if keepvecs and capacity > _lib.KK_MAX_M + 1:
+        raise ValueError(f"krylovdim {capacity - 2} exceeds the {_lib.KK_MAX_M - 1} basis vectors a fused expand! can address")
 
 
 def initialize(it, V: Optional[DeviceBasis] = None):
@@ -328,6 +336,9 @@ class ArnoldiIterator:  # arnoldi.jl:98-106
     orth: Orthogonalizer = KrylovDefaults.orth
     capacity: int = KrylovDefaults.krylovdim + 2
 
+    def __post_init__(self):
+        _check_capacity(self.capacity)
+
 
 def _arnoldi_initialize(it: ArnoldiIterator, V: Optional[DeviceBasis] = None) -> ArnoldiFactorization:
     """initialize(iter::ArnoldiIterator) (arnoldi.jl:135-175)"""
@@ -438,6 +449,9 @@ class GKLIterator:  # gkl.jl:137-152
     u0: object
     orth: Orthogonalizer = KrylovDefaults.orth
     capacity: int = KrylovDefaults.krylovdim + 2
+
+    def __post_init__(self):
+        _check_capacity(self.capacity)
 
 
 def _gkl_initialize(it: GKLIterator) -> GKLFactorization:

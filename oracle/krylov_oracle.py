@@ -1452,7 +1452,7 @@ def bicgstab(operator, b: np.ndarray, x0: Optional[np.ndarray] = None, a0: float
     numiter += 1
     r_shadow = r.copy()                                        # :35
     rho = inner(r_shadow, r)
-    if np.isclose(rho, 0.0):                                   # :39-46
+    if rho == 0.0:   # `ρ ≈ 0.0` = isapprox with atol = 0: true only for an exact zero   :39-46
         return x, ConvergenceInfo(0, r, normr, numiter, numops)
     p = r.copy()
     v = None

@@ -1102,3 +1102,50 @@ def test_mgs_on_non_orthonormal_basis(kk, ko, ctx, mgs_mode):
         np.testing.assert_allclose(x, xr, rtol=1e-9, atol=1e-10 * np.linalg.norm(w0))
         np.testing.assert_allclose(vw.get(), wr, rtol=0, atol=1e-9 * np.linalg.norm(w0))
     ctx.set_option("mgs_mode", 1)
+
+
+def test_wide_basis_is_chunked_and_capacity_is_checked_early(kk, ko, ctx):
+    """A basis wider than the library's per-call limit (KK_MAX_M = 256 columns, a limit the reference does not have) is
+    processed in panels by project!! / unproject!!; a krylovdim the fused expand! cannot address is refused when the
+    iterator is built."""
+    n, m = 2000, 300
+    rng = np.random.default_rng(11)
+    Vh = rng.standard_normal((n, m))
+    B = kk.DeviceBasis(n, m + 1, ctx)
+    for j in range(m):
+        B.upload(j, Vh[:, j])
+    B.length = m
+    w = rng.standard_normal(n)
+    vw = B[m].set(w)
+    y = B.project(vw)
+    np.testing.assert_allclose(y, Vh.T @ w, rtol=1e-12, atol=1e-10)
+    c = rng.standard_normal(m)
+    B.unproject(vw, c, 0, m, -0.5, 2.0)
+    np.testing.assert_allclose(vw.get(), 2.0 * w - 0.5 * Vh @ c, rtol=1e-12, atol=1e-9)
+    A = ko.laplacian_2d(20, 10)
+    with pytest.raises(ValueError):
+        kk.LanczosIterator(kk.SparseOperator(A, ctx, symmetric=True), np.ones(200), kk.ModifiedGramSchmidt2(), capacity=300)
+    with pytest.raises(ValueError):
+        kk.ArnoldiIterator(kk.SparseOperator(A, ctx), np.ones(200), kk.ModifiedGramSchmidt2(), capacity=300)
+
+
+def test_linsolve_front_end_tolerances_and_bicgstab_breakdown_test(kk, ko, ctx):
+    """ADVICE r1: the keyword front-end defaults atol = rtol = 1e-12 and uses tol = max(atol, rtol*|b|) (linsolve/linsolve.jl:123-151);
+    BiCGStab's breakdown test `rho ≈ 0` is an exact-zero test (isapprox with atol = 0, bicgstab.jl:39)."""
+    A = ko.convection_diffusion_2d(20, 15)
+    n = A.shape[0]
+    rng = np.random.default_rng(8)
+    b = 1e6 * rng.random(n)                               # |b| >> 1: an absolute 1e-12 would be unreachable
+    x, info = kk.linsolve(kk.SparseOperator(A, ctx), b, krylovdim=40, maxiter=50)
+    assert info.converged == 1 and np.linalg.norm(A @ x - b) <= 1e-12 * np.linalg.norm(b) * 1.01
+    xo, oinfo = ko.gmres(A, b, krylovdim=40, maxiter=50, tol=max(1e-12, 1e-12 * np.linalg.norm(b)), orth=ko.MGS2)
+    assert (info.numiter, info.numops) == (oinfo.numiter, oinfo.numops)
+    x2, info2 = kk.linsolve(kk.SparseOperator(A, ctx), b, rtol=1e-6, krylovdim=40, maxiter=50)   # only rtol given: atol keeps its default
+    assert info2.converged == 1 and info2.numops < info.numops
+    with pytest.raises(TypeError):
+        kk.linsolve(kk.SparseOperator(A, ctx), b, None, kk.GMRES(tol=1e-8), rtol=1e-6)
+    bs = 1e-6 * rng.random(n)                             # |r0|^2 = 1e-12-ish: np.isclose(rho, 0) would have stopped here
+    xs, sinfo = kk.linsolve(kk.SparseOperator(A, ctx), bs, None, kk.BiCGStab(tol=1e-16, maxiter=400))
+    xso, soinfo = ko.bicgstab(A, bs, tol=1e-16, maxiter=400)
+    assert sinfo.numiter > 1 and sinfo.converged == soinfo.converged == 1
+    assert np.linalg.norm(A @ xs - bs) < 1e-15

