@@ -282,7 +282,7 @@ function Base.setindex!(b::OrthonormalBasis{HipVec}, v::HipVec, i::Integer)     
     b.basis[i] = place!(b, v, i)
     return b
 end
-# sizehint!(fact, krylovdim) (eigsolve/lanczos.jl:27, linsolve/gmres.jl:41): make room for krylovdim vectors + residual + 1
+# sizehint!(fact, krylovdim) (eigsolve/lanczos.jl:23, linsolve/gmres.jl:41): make room for krylovdim vectors + residual + 1
 Base.sizehint!(b::OrthonormalBasis{HipVec}, k::Int) = (sizehint!(b.basis, k); dedicate!(b, k + 2); grow!(b, k + 2); b)
 # (slab, first column, length) of a basis whose elements are at home
 function slab_range(b::OrthonormalBasis{HipVec})

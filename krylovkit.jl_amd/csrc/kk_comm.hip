@@ -228,6 +228,44 @@ int kk_halo_exchange(kk_ctx c, const kk_sparse_dev& M, const double* x) {
     return p2p_group(c, p->d_sendbuf, p->send_counts.data(), p->d_ghost, p->recv_counts.data(), ncclDouble);
 }
 
+// ghost exchange for a block of nb <= 16 vectors: nb gathers, then ONE group with nb sends / receives per peer
+int kk_halo_exchange_block(kk_ctx c, const kk_sparse_dev& M, const double* X, int64_t ldx, int nb, const double** G, int64_t* ldg) {
+    kk_halo_plan* p = M.plan;
+    KK_CHECK(p && nb >= 1 && nb <= 16, KK_ERR_INVALID, "block ghost exchange: bad arguments");
+    const int64_t ng = std::max<int64_t>(p->total_recv, 1), ns = std::max<int64_t>(p->total_send, 1);
+    if (!p->d_ghost_blk) {
+        KK_HIP(hipMalloc(&p->d_ghost_blk, (size_t)16 * ng * sizeof(double)));
+        KK_HIP(hipMalloc(&p->d_sendbuf_blk, (size_t)16 * ns * sizeof(double)));
+        KK_HIP(hipMemsetAsync(p->d_ghost_blk, 0, (size_t)16 * ng * sizeof(double), c->stream));
+    }
+    *G = p->d_ghost_blk;
+    *ldg = ng;
+    if (p->total_send == 0 && p->total_recv == 0) return KK_OK;
+    kk_comm_s* k = c->comm;
+    KK_CHECK(k && k->world == (int)p->send_counts.size(), KK_ERR_INVALID, "ghost exchange: the operator was created for another communicator");
+    for (int j = 0; j < nb; ++j)
+        if (p->total_send) KK_TRY(kk_launch_gather(c, X + (int64_t)j * ldx, p->d_send_idx, p->total_send, p->d_sendbuf_blk + (int64_t)j * ns));
+    if (k->world == 1) return KK_OK;
+    KK_NCCL(g_rccl.GroupStart());
+    ncclResult_t bad = ncclSuccess;
+    for (int j = 0; j < nb && bad == ncclSuccess; ++j) {
+        int64_t so = 0, ro = 0;
+        for (int q = 0; q < k->world && bad == ncclSuccess; ++q) {
+            if (p->send_counts[q] > 0)
+                bad = g_rccl.Send(p->d_sendbuf_blk + (int64_t)j * ns + so, (size_t)p->send_counts[q], ncclDouble, q, (ncclComm_t)k->nccl, c->stream);
+            so += p->send_counts[q];
+            if (bad == ncclSuccess && p->recv_counts[q] > 0)
+                bad = g_rccl.Recv(p->d_ghost_blk + (int64_t)j * ng + ro, (size_t)p->recv_counts[q], ncclDouble, q, (ncclComm_t)k->nccl, c->stream);
+            ro += p->recv_counts[q];
+        }
+    }
+    ncclResult_t end = g_rccl.GroupEnd();
+    if (bad != ncclSuccess) return rccl_fail(bad, "ncclSend/ncclRecv (block)", __LINE__);
+    if (end != ncclSuccess) return rccl_fail(end, "ncclGroupEnd (block)", __LINE__);
+    ++k->n_p2p;
+    return KK_OK;
+}
+
 // vfull = all-gather of the `shard`-strided local pieces (stage); world 1: plain copy
 int kk_comm_allgather_f64(kk_ctx c, const double* d_stage, double* d_full, int64_t shard) {
     kk_comm_s* k = c->comm;

@@ -200,6 +200,8 @@ struct kk_halo_plan {
     int64_t* d_send_idx = nullptr;
     double* d_sendbuf = nullptr;
     double* d_ghost = nullptr;
+    double* d_sendbuf_blk = nullptr;   // [16][total_send], [16][n_ghost]: block applies (allocated on first use)
+    double* d_ghost_blk = nullptr;
 };
 // all-gather / reduce-scatter plan of a row-sharded rectangular map (GKL, config 4): the short vectors (length ncols
 // of A) are sharded evenly with stride `shard`; A x gathers them into `vfull`, A' u reduce-scatters `zfull`
@@ -210,6 +212,8 @@ struct kk_gather_plan {
     double* stage = nullptr;   // shard
 };
 int kk_halo_exchange(kk_ctx ctx, const kk_sparse_dev& M, const double* x);
+// the same for nb vectors X[:, j] at once (one grouped exchange): *G = ghost block, column j at *G + j * *ldg
+int kk_halo_exchange_block(kk_ctx ctx, const kk_sparse_dev& M, const double* X, int64_t ldx, int nb, const double** G, int64_t* ldg);
 
 struct kk_host_csr {
     int64_t nrows = 0, ncols = 0;

@@ -300,7 +300,10 @@ template <int NB>
 __global__ __launch_bounds__(KK_TPB) void k_spmm_ell(const int32_t* __restrict__ ecol, const double* __restrict__ eval,
                                                      int64_t ell_ld, int width, int64_t nrows,
                                                      const double* __restrict__ X, int64_t ldx, double* __restrict__ Y,
-                                                     int64_t ldy, int nb, int nb_logical) {
+                                                     int64_t ldy, int nb, int nb_logical, int64_t n_local,
+                                                     const double* __restrict__ G, int64_t ldg) {
+    // row-sharded operator: columns >= n_local read the ghost block G (column j of the block at G + j*ldg), filled by
+    // ONE grouped exchange for all nb vectors before the launch (kk_halo_exchange_block)
     const int per = (nb_logical + 7) >> 3;
     const int nbx = gridDim.x >> 3;
     const int xcd = blockIdx.x & 7;
@@ -318,8 +321,10 @@ __global__ __launch_bounds__(KK_TPB) void k_spmm_ell(const int32_t* __restrict__
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
                 if (j < nb) {
-                    acc[j].x = fma(v.x, X[(int64_t)j * ldx + cc.x], acc[j].x);
-                    acc[j].y = fma(v.y, X[(int64_t)j * ldx + cc.y], acc[j].y);
+                    const double x0 = (n_local < 0 || cc.x < n_local) ? X[(int64_t)j * ldx + cc.x] : G[(int64_t)j * ldg + (cc.x - n_local)];
+                    const double x1 = (n_local < 0 || cc.y < n_local) ? X[(int64_t)j * ldx + cc.y] : G[(int64_t)j * ldg + (cc.y - n_local)];
+                    acc[j].x = fma(v.x, x0, acc[j].x);
+                    acc[j].y = fma(v.y, x1, acc[j].y);
                 }
             }
         }
@@ -408,7 +413,11 @@ int kk_launch_spmv(kk_ctx ctx, const kk_sparse_dev& M, const double* x, double* 
 
 // Y[:, j] = A X[:, j], j < nb (any nb: processed 16 / 8 / 4 columns at a time)
 int kk_launch_spmm(kk_ctx ctx, const kk_sparse_dev& M, const double* X, int64_t ldx, double* Y, int64_t ldy, int nb) {
-    if (M.format != 0 || M.n_ghost > 0 || M.halo || M.plan) {  // CSR / ghosted operators: one SpMV per column
+    // one launch for the block: ELL operators without ghosts, or with a native exchange plan (one grouped exchange for all
+    // nb vectors); CSR / SELL formats and hook-ghosted operators go column by column
+    const bool ghost_block = M.plan && M.n_ghost > 0;
+    const bool one_launch = M.format == 0 && !M.halo && (M.n_ghost == 0 || M.plan);
+    if (!one_launch) {
         for (int j = 0; j < nb; ++j) {
             kk_spmv_fuse f;
             KK_TRY(kk_launch_spmv(ctx, M, X + (int64_t)j * ldx, Y + (int64_t)j * ldy, ldy, f));
@@ -424,21 +433,28 @@ int kk_launch_spmm(kk_ctx ctx, const kk_sparse_dev& M, const double* X, int64_t 
     int nbx = std::min(per, KK_MAX_BLOCKS / 8);
     if (ctx->spmm_bpc > 0) nbx = std::min(nbx, std::max(1, ctx->num_cus / 8) * ctx->spmm_bpc);
     dim3 g(nbx * 8), b(KK_TPB);
+    const double* G = nullptr;
+    int64_t ldg = 0, nloc = -1;
+    if (ghost_block) {
+        KK_TRY(kk_halo_exchange_block(ctx, M, X, ldx, nb, &G, &ldg));
+        nloc = M.n_local;
+    }
     int j0 = 0;
     while (j0 < nb) {
         const int rem = nb - j0;
         const double* x = X + (int64_t)j0 * ldx;
         double* y = Y + (int64_t)j0 * ldy;
+        const double* gj = G ? G + (int64_t)j0 * ldg : nullptr;
         kk_prof_scope ps(ctx, "k_spmm_ell");
         if (rem > 8) {
             const int n = std::min(rem, 16);
-            hipLaunchKernelGGL((k_spmm_ell<16>), g, b, 0, ctx->stream, M.ell_col, M.ell_val, M.ell_ld, M.width, M.nrows, x, ldx, y, ldy, n, nb_logical);
+            hipLaunchKernelGGL((k_spmm_ell<16>), g, b, 0, ctx->stream, M.ell_col, M.ell_val, M.ell_ld, M.width, M.nrows, x, ldx, y, ldy, n, nb_logical, nloc, gj, ldg);
             j0 += n;
         } else if (rem > 4) {
-            hipLaunchKernelGGL((k_spmm_ell<8>), g, b, 0, ctx->stream, M.ell_col, M.ell_val, M.ell_ld, M.width, M.nrows, x, ldx, y, ldy, rem, nb_logical);
+            hipLaunchKernelGGL((k_spmm_ell<8>), g, b, 0, ctx->stream, M.ell_col, M.ell_val, M.ell_ld, M.width, M.nrows, x, ldx, y, ldy, rem, nb_logical, nloc, gj, ldg);
             j0 += rem;
         } else {
-            hipLaunchKernelGGL((k_spmm_ell<4>), g, b, 0, ctx->stream, M.ell_col, M.ell_val, M.ell_ld, M.width, M.nrows, x, ldx, y, ldy, rem, nb_logical);
+            hipLaunchKernelGGL((k_spmm_ell<4>), g, b, 0, ctx->stream, M.ell_col, M.ell_val, M.ell_ld, M.width, M.nrows, x, ldx, y, ldy, rem, nb_logical, nloc, gj, ldg);
             j0 += rem;
         }
     }

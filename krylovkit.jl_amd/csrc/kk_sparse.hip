@@ -295,6 +295,7 @@ KK_API int kk_op_free(kk_op op) {
     (void)hipDeviceSynchronize();  // see kk_basis_free
     if (kk_halo_plan* p = op->A.plan) {
         (void)hipFree(p->d_send_idx); (void)hipFree(p->d_sendbuf); (void)hipFree(p->d_ghost);
+        (void)hipFree(p->d_sendbuf_blk); (void)hipFree(p->d_ghost_blk);
         delete p;
         op->A.plan = nullptr;
     }
