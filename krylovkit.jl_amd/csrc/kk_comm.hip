@@ -194,8 +194,12 @@ int kk_comm_allgather_i64(kk_ctx c, const int64_t* d_send, int64_t* d_recv, int6
 static int p2p_group(kk_ctx c, const void* d_send, const int64_t* send_counts, void* d_recv, const int64_t* recv_counts,
                      ncclDataType_t dt) {
     kk_comm_s* k = c->comm;
-    if (!k || k->world == 1) return KK_OK;
     const size_t es = 8;
+    if (!k || k->world == 1) {   // loop-back plan of a one-rank run: this rank serves itself with a device copy
+        if (send_counts[0] > 0 && send_counts[0] == recv_counts[0])
+            KK_HIP(hipMemcpyAsync(d_recv, d_send, (size_t)send_counts[0] * es, hipMemcpyDeviceToDevice, c->stream));
+        return KK_OK;
+    }
     KK_NCCL(g_rccl.GroupStart());
     int64_t so = 0, ro = 0;
     ncclResult_t bad = ncclSuccess;
@@ -222,7 +226,7 @@ int kk_comm_exchange_i64(kk_ctx c, const int64_t* d_send, const int64_t* send_co
 int kk_halo_exchange(kk_ctx c, const kk_sparse_dev& M, const double* x) {
     const kk_halo_plan* p = M.plan;
     if (!p || (p->total_send == 0 && p->total_recv == 0)) return KK_OK;
-    KK_CHECK(c->comm && c->comm->world == (int)p->send_counts.size(), KK_ERR_INVALID,
+    KK_CHECK((c->comm ? c->comm->world : 1) == (int)p->send_counts.size(), KK_ERR_INVALID,
              "ghost exchange: the operator was created for another communicator");
     if (p->total_send) KK_TRY(kk_launch_gather(c, x, p->d_send_idx, p->total_send, p->d_sendbuf));
     return p2p_group(c, p->d_sendbuf, p->send_counts.data(), p->d_ghost, p->recv_counts.data(), ncclDouble);
@@ -242,10 +246,15 @@ int kk_halo_exchange_block(kk_ctx c, const kk_sparse_dev& M, const double* X, in
     *ldg = ng;
     if (p->total_send == 0 && p->total_recv == 0) return KK_OK;
     kk_comm_s* k = c->comm;
-    KK_CHECK(k && k->world == (int)p->send_counts.size(), KK_ERR_INVALID, "ghost exchange: the operator was created for another communicator");
+    KK_CHECK((k ? k->world : 1) == (int)p->send_counts.size(), KK_ERR_INVALID, "ghost exchange: the operator was created for another communicator");
     for (int j = 0; j < nb; ++j)
         if (p->total_send) KK_TRY(kk_launch_gather(c, X + (int64_t)j * ldx, p->d_send_idx, p->total_send, p->d_sendbuf_blk + (int64_t)j * ns));
-    if (k->world == 1) return KK_OK;
+    if (!k || k->world == 1) {   // loop-back plan: serve myself
+        for (int j = 0; j < nb; ++j)
+            KK_HIP(hipMemcpyAsync(p->d_ghost_blk + (int64_t)j * ng, p->d_sendbuf_blk + (int64_t)j * ns, (size_t)p->total_send * sizeof(double),
+                                  hipMemcpyDeviceToDevice, c->stream));
+        return KK_OK;
+    }
     KK_NCCL(g_rccl.GroupStart());
     ncclResult_t bad = ncclSuccess;
     for (int j = 0; j < nb && bad == ncclSuccess; ++j) {

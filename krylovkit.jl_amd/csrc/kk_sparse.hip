@@ -335,13 +335,23 @@ KK_API int kk_csr_create_sharded(kk_ctx c, int64_t nrows_local, const int64_t* r
              (long long)nrows_local);
     KK_TRY(check_ptr_array("kk_csr_create_sharded", rowptr, nrows_local, nnz, index_base));
     KK_HIP(hipSetDevice(c->device));
+    // Loop-back mode for one-GPU test boxes (KK_LOOPBACK_GHOST_FROM=r, world size 1 only): the columns >= r, although
+    // owned by this rank, are routed through the ghost machinery (request list, gather into the send buffer, exchange
+    // -- here a device copy to self --, ghost-indexed reads in the SpMV / SpMM kernels), so that every piece of the
+    // multi-GPU data path except the wire itself runs where no second GPU exists.
+    int64_t loop_from = -1;
+    if (world == 1) {
+        const char* lb = getenv("KK_LOOPBACK_GHOST_FROM");
+        if (lb && *lb) loop_from = atoll(lb);
+    }
+    auto is_ghost = [&](int64_t g) { return g < lo || g >= hi || (loop_from >= 0 && g >= loop_from); };
     // ghost columns: sorted unique global ids outside [lo, hi) -> grouped by owner
     std::vector<int64_t> needed;
     for (int64_t p = 0; p < nnz; ++p) {
         const int64_t g = colind[p] - index_base;
         KK_CHECK(g >= 0 && g < n_global, KK_ERR_DIM, "kk_csr_create_sharded: column index %lld out of range at entry %lld",
                  (long long)g, (long long)p);
-        if (g < lo || g >= hi) needed.push_back(g);
+        if (is_ghost(g)) needed.push_back(g);
     }
     std::sort(needed.begin(), needed.end());
     needed.erase(std::unique(needed.begin(), needed.end()), needed.end());
@@ -362,8 +372,8 @@ KK_API int kk_csr_create_sharded(kk_ctx c, int64_t nrows_local, const int64_t* r
     h.col.resize(nnz); h.val.assign(val, val + nnz);
     for (int64_t p = 0; p < nnz; ++p) {
         const int64_t g = colind[p] - index_base;
-        h.col[p] = (g >= lo && g < hi) ? (int32_t)(g - lo)
-                                       : (int32_t)(nrows_local + (std::lower_bound(needed.begin(), needed.end(), g) - needed.begin()));
+        h.col[p] = !is_ghost(g) ? (int32_t)(g - lo)
+                                : (int32_t)(nrows_local + (std::lower_bound(needed.begin(), needed.end(), g) - needed.begin()));
     }
     int s = upload_sparse(c, h, op->A);
     if (s != KK_OK) { free_sparse(op->A); delete op; return s; }
@@ -384,6 +394,8 @@ KK_API int kk_csr_create_sharded(kk_ctx c, int64_t nrows_local, const int64_t* r
         if (s != KK_OK) return fail(s);
         for (int q = 0; q < world; ++q) send_counts[q] = all[(size_t)q * world + rank];
         send_counts[rank] = 0;
+    } else if (loop_from >= 0) {
+        send_counts[0] = recv_counts[0];   // loop-back: this rank serves its own requests
     }
     plan->send_counts = send_counts; plan->recv_counts = recv_counts;
     for (int q = 0; q < world; ++q) { plan->total_send += send_counts[q]; plan->total_recv += recv_counts[q]; }
@@ -413,6 +425,11 @@ KK_API int kk_csr_create_sharded(kk_ctx c, int64_t nrows_local, const int64_t* r
         }
         if (plan->total_send) (void)hipMemcpyAsync(plan->d_send_idx, idx.data(), idx.size() * sizeof(int64_t), hipMemcpyHostToDevice, c->stream);
         if (hipStreamSynchronize(c->stream) != hipSuccess) return fail(KK_ERR_HIP);
+    }
+    if (world == 1 && loop_from >= 0 && plan->total_send) {   // loop-back: the request list is my own `needed`
+        std::vector<int64_t> idx(needed);
+        for (int64_t& g : idx) g -= lo;
+        if (hipMemcpy(plan->d_send_idx, idx.data(), idx.size() * sizeof(int64_t), hipMemcpyHostToDevice) != hipSuccess) return fail(KK_ERR_HIP);
     }
     op->A.n_local = nrows_local;
     op->A.n_ghost = n_ghost;

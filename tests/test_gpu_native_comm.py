@@ -176,3 +176,61 @@ def test_sharded_create_rejects_bad_input(kk, comm):
     col2 = (C.c_int64 * 4)(0, 1, 2, 3)
     assert lib.kk_csr_create_sharded(ctx.handle, 4, offs, 4, bad_ptr, col2, val, 0, 0, C.byref(h)) == _lib.KK_ERR_DIM
     assert lib.kk_csr_create_sharded(ctx.handle, 3, offs, 4, rowptr, col2, val, 0, 0, C.byref(h)) == _lib.KK_ERR_DIM
+
+
+def test_loopback_ghost_plan_runs_the_whole_exchange_path(kk, ko, comm, monkeypatch):
+    """One-GPU coverage of the multi-GPU data path short of the wire (SURVEY.md 8(e) "loopback shard mode"): with
+    KK_LOOPBACK_GHOST_FROM the columns >= r of a world-1 operator go through the native ghost plan -- request list, gather
+    into the send buffer, exchange (device copy to self), ghost-indexed reads of k_spmv_* and of the block apply k_spmm_ell.
+    Results must equal those of the plain operator / the oracle."""
+    from krylovkit_hip import dist as kd
+    ctx = comm.ctx
+    nx, ny = 36, 28
+    n = nx * ny
+    A = ko.laplacian_2d(nx, ny, shift_diag=10 * np.linspace(0, 1, n) ** 2)
+    part = kd.Partition.even(n, 1, 0)
+    monkeypatch.setenv("KK_LOOPBACK_GHOST_FROM", str(n // 2 + 5))
+    op = kd.NativeShardedOperator(A, part, ctx, symmetric=True)
+    monkeypatch.delenv("KK_LOOPBACK_GHOST_FROM")
+    assert op.info()["ncols"] > n            # ghost columns were appended
+    rng = np.random.default_rng(12)
+    B = kk.DeviceBasis(n, 40, ctx)
+    X = rng.standard_normal((n, 16))
+    for j in range(16):
+        B.upload(j, X[:, j])
+    # single vector, affine form, fused dot
+    op.apply(B[3], B[20])
+    np.testing.assert_allclose(B[20].get(), A @ X[:, 3], rtol=0, atol=1e-12)
+    op.apply_affine(B[3], B[21], 0.7, -0.4)
+    np.testing.assert_allclose(B[21].get(), 0.7 * X[:, 3] - 0.4 * (A @ X[:, 3]), rtol=0, atol=1e-12)
+    # block apply: ONE exchange for 16 vectors, ghost-aware SpMM
+    p0 = comm.stats()
+    import ctypes as C
+    from krylovkit_hip._lib import check
+    check(ctx._lib.kk_block_apply(op.handle, B.handle, 0, B.handle, 20, 16))
+    Y = np.stack([B.download(20 + j) for j in range(16)], 1)
+    np.testing.assert_allclose(Y, A @ X, rtol=0, atol=1e-11)
+    for nb in (3, 8, 11):
+        check(ctx._lib.kk_block_apply(op.handle, B.handle, 1, B.handle, 20, nb))
+        Y = np.stack([B.download(20 + j) for j in range(nb)], 1)
+        np.testing.assert_allclose(Y, A @ X[:, 1:1 + nb], rtol=0, atol=1e-11)
+    # a Lanczos run and a BlockLanczos run on the looped-back operator against the oracle
+    x0 = rng.random(n)
+    it = kk.LanczosIterator(op, x0, kk.ModifiedGramSchmidt2(), capacity=24)
+    f = kk.initialize(it)
+    oit = ko.LanczosIterator(A, x0.copy(), ko.MGS2)
+    of = ko.lanczos_initialize(oit)
+    for _ in range(20):
+        f = kk.expand_(it, f)
+        of = ko.lanczos_expand(oit, of)
+    assert relerr(f.alphas, of.alphas) < 1e-10 and relerr(f.betas, of.betas) < 1e-10
+    xb = [rng.random(n) for _ in range(4)]
+    bit = kk.BlockLanczosIterator(op, xb, 28)
+    bf = bit.initialize()
+    obit = ko.BlockLanczosIterator(A, [x.copy() for x in xb], 28)
+    obf = ko.blocklanczos_initialize(obit)
+    for _ in range(4):
+        bf = bit.expand(bf)
+        obf = ko.blocklanczos_expand(obit, obf)
+    k = len(bf)
+    np.testing.assert_allclose(np.linalg.eigvalsh(bf.H[:k, :k]), np.linalg.eigvalsh(obf.H[:k, :k]), atol=1e-9)

@@ -25,6 +25,8 @@ for step in "$@"; do
     blocksweep) timeout 900 python tools/block_sweep.py > $OUT/block_sweep.jsonl 2> $OUT/block_sweep.err; echo "blocksweep rc=$?"; cat $OUT/block_sweep.jsonl; tail -3 $OUT/block_sweep.err ;;
     blocktests) timeout 1200 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py -x -q -k "block" > $OUT/t_block.log 2>&1; echo "blocktests rc=$?" ;;
     blockmicro) timeout 900 python tools/block_micro.py > $OUT/block_micro.jsonl 2> $OUT/block_micro.err; echo "blockmicro rc=$?"; cat $OUT/block_micro.jsonl; tail -3 $OUT/block_micro.err ;;
+    advice)   timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "front_end or wide_basis" > $OUT/t_advice.log 2>&1; echo "advice rc=$?" ;;
+    cfg4pmc)  bash tools/profile_cfg4.sh $TAG > $OUT/cfg4pmc.log 2>&1; echo "cfg4pmc rc=$?"; tail -40 $OUT/cfg4pmc.log ;;
     prof)     bash tools/profile_gpu.sh $TAG > $OUT/prof.log 2>&1; echo "prof rc=$?"; tail -5 $OUT/prof.log ;;
     *) echo "unknown step $step" ;;
   esac
