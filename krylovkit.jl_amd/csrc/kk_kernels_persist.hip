@@ -107,8 +107,14 @@ __device__ __forceinline__ void bstore(__amdgpu_buffer_rsrc_t r, unsigned voff, 
     t.x = (unsigned)a; t.y = (unsigned)(a >> 32); t.z = (unsigned)b; t.w = (unsigned)(b >> 32);
     __builtin_amdgcn_raw_buffer_store_b128(t, r, voff, soff, 0);
 }
+// descriptor of one column.  The inputs are wave-uniform by construction; passing them through readfirstlane makes that
+// PROVABLE to the compiler (a loop-carried column pointer may otherwise be treated as divergent and every buffer access
+// turned into a waterfall loop: cdna_hip_programming.md T20).
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t col_rsrc(const double* p, int64_t ld) {
-    return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (int)(ld * 8), 0x00020000);
+    const unsigned long long a = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    const int bytes = __builtin_amdgcn_readfirstlane((int)(ld * 8));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, bytes, 0x00020000);
 }
 
 // x -= s*p with the result tied to x's own registers: left to the register allocator the updated work vector migrates
