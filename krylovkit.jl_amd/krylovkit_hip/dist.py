@@ -271,7 +271,9 @@ class DistSparseOperator:
 @dataclass
 class DistLanczosIterator:
     """Row-sharded LanczosIterator (factorizations/lanczos.jl:129-153).  `x0_local` is this
-    rank's block of the start vector.  Orthogonalisers: cgs, mgs, cgs2, mgs2 (low-sync form)."""
+    rank's block of the start vector.  All six orthogonalisers; mgs2 / mgsir sweeps in the low-sync form.
+    The pass count of cgsir / mgsir (lanczos.jl:339-376) is decided from all-reduced norms, so every rank
+    takes the same number of passes."""
     operator: DistSparseOperator
     x0_local: np.ndarray
     orth: Orthogonalizer = KrylovDefaults.orth
@@ -279,10 +281,8 @@ class DistLanczosIterator:
     keepvecs: bool = True
 
     def __post_init__(self):
-        if self.orth.name not in ("cgs", "mgs", "cgs2", "mgs2"):
-            raise NotImplementedError(
-                f"{self.orth.name}: the iterative-refinement orthogonalisers are not offered row-sharded yet "
-                "(their pass count is data dependent); use cgs2 / mgs2")
+        if self.orth.name not in ("cgs", "mgs", "cgs2", "mgs2", "cgsir", "mgsir"):
+            raise ValueError(f"unknown orthogonalizer {self.orth.name}")
         be = self.operator.backend
         self.backend = be
         import torch
@@ -322,17 +322,29 @@ class DistLanczosIterator:
         alpha = float(be.to_host(self.buf[0:1])[0]) / (beta0 * beta0)
         be.scal(V, 0, 1.0 / beta0)
         be.scal(V, 1, 1.0 / beta0)
+        ir = self.orth.name in ("cgsir", "mgsir")
+        if ir:                                                     # beta_old = norm(r) before the projection, :195
+            be.nrm2(V, 1, self.nbuf)
+            self._allreduce(self.nbuf[0:1])
+            beta_old = float(np.sqrt(be.to_host(self.nbuf[0:1])[0]))
         be.unproject(V, 1, 0, 1, [alpha], -1.0, 1.0, self.nbuf)   # r -= alpha v ; |r|^2 partial
         self._allreduce(self.nbuf[0:1])
         beta = float(np.sqrt(be.to_host(self.nbuf[0:1])[0]))
-        if self.orth.name in ("cgs2", "mgs2"):  # :200-204
+
+        def again(alpha):
             be.dot(V, 0, 1, self.buf)
             self._allreduce(self.buf[0:1])
             da = float(be.to_host(self.buf[0:1])[0])
-            alpha += da
             be.unproject(V, 1, 0, 1, [da], -1.0, 1.0, self.nbuf)
             self._allreduce(self.nbuf[0:1])
-            beta = float(np.sqrt(be.to_host(self.nbuf[0:1])[0]))
+            return alpha + da, float(np.sqrt(be.to_host(self.nbuf[0:1])[0]))
+
+        if self.orth.name in ("cgs2", "mgs2"):  # :200-204
+            alpha, beta = again(alpha)
+        elif ir:                                # :205-213
+            while float(np.finfo(np.float64).eps) < beta < self.orth.eta * beta_old:
+                beta_old = beta
+                alpha, beta = again(alpha)
         V.length = 1
         self.Ldev = be.alloc(self.capacity * self.capacity).reshape(self.capacity, self.capacity)
         self.gram_rows = 1
@@ -363,7 +375,8 @@ class DistLanczosIterator:
         m = k + 1
         beta_old = st.normres
         name = self.orth.name
-        dot_mode = 1 if name in ("cgs", "cgs2") else 2
+        dot_mode = 1 if name in ("cgs", "cgs2", "cgsir") else 2
+        ir = name in ("cgsir", "mgsir")
         hit = self._spec is not None and self._spec == [k, beta_old, id(V)]
         self._spec = None
         be.scal(V, k, 1.0 / beta_old)                       # V = push!(V, scale!!(r, 1/beta_old))
@@ -372,7 +385,7 @@ class DistLanczosIterator:
         else:
             op.halo_exchange(V, k)
             be.apply_fused(op.local, V, k, k - 1, k + 1, beta_old, dot_mode, self.buf)
-        if name in ("cgs", "mgs"):
+        if name in ("cgs", "mgs", "cgsir", "mgsir"):
             self._allreduce(self.buf[0:1])
             self.res[0:1] = self.buf[0:1]
             self.res[1:2] = 0.0
@@ -392,11 +405,15 @@ class DistLanczosIterator:
             be.unproject_dev(V, k + 1, 0, m, self.coef, -1.0, 1.0, self.nbuf)
         self._allreduce(self.nbuf[0:1])
         be.norm_scalars(self.nbuf, self.sc, self.res[2:3])  # 1/beta, beta for the speculative apply; |w|^2 for the host
-        tok = be.fetch_begin(self.res[0:3])                  # read-back queued BEFORE the speculative work ...
-        self._speculate(st, k + 1, 0.0, dot_mode)           # ... which keeps the GPU / links busy meanwhile
-        h = be.fetch_end(tok)                                # the ONE host synchronisation of this expand!
-        alpha = float(h[0] + h[1])
-        beta = float(np.sqrt(h[2]))
+        if ir:
+            alpha, beta = self._refine(st, k, beta_old)      # lanczos.jl:343-355 / :362-375, one host sync per extra pass
+            self._speculate(st, k + 1, 0.0, dot_mode)
+        else:
+            tok = be.fetch_begin(self.res[0:3])              # read-back queued BEFORE the speculative work ...
+            self._speculate(st, k + 1, 0.0, dot_mode)       # ... which keeps the GPU / links busy meanwhile
+            h = be.fetch_end(tok)                            # the ONE host synchronisation of this expand!
+            alpha = float(h[0] + h[1])
+            beta = float(np.sqrt(h[2]))
         if self._spec is not None:
             self._spec[1] = beta
         st.alphas.append(alpha)
@@ -404,6 +421,37 @@ class DistLanczosIterator:
         V.length = m
         st.k += 1
         return st
+
+    def _refine(self, st: LanczosFactorization, k: int, beta_old: float):
+        """The `while eps < beta < eta*nold` loop of the IR recurrences (lanczos.jl:343-355, :362-375): every extra
+        pass = project (one all-reduce) + coefficient kernel + unproject (one all-reduce of |w|^2); the loop condition
+        is evaluated on all-reduced scalars, identical on every rank."""
+        be, V = self.backend, st.V
+        m = k + 1
+        lowsync = self.orth.name == "mgsir"
+        h = be.to_host(self.res[0:3])
+        alpha, beta = float(h[0]), float(np.sqrt(h[2]))
+        nold = float(np.sqrt(beta * beta + alpha * alpha + beta_old * beta_old))
+        eps = float(np.finfo(np.float64).eps)
+        while eps < beta < self.orth.eta * nold:
+            nold = beta
+            if lowsync:
+                for i in range(max(self.gram_rows, 1), k):   # rows the refinement-free steps did not need
+                    be.project(V, 0, i, i, -1, self.buf[0:i])
+                    self._allreduce(self.buf[0:i])
+                    self.Ldev[i, :i] = self.buf[0:i]
+                self.gram_rows = k + 1
+            self.buf[0:1] = 0.0                               # no alpha0 term in a refinement pass
+            be.project(V, 0, m, k + 1, k, self.buf[1:1 + 2 * m])
+            self._allreduce(self.buf[0:1 + 2 * m])
+            be.lanczos_coef(self.buf, self.Ldev if lowsync else None, m, lowsync, self.coef, self.res)
+            be.unproject_dev(V, k + 1, 0, m, self.coef, -1.0, 1.0, self.nbuf)
+            self._allreduce(self.nbuf[0:1])
+            be.norm_scalars(self.nbuf, self.sc, self.res[2:3])
+            h = be.to_host(self.res[0:3])
+            alpha += float(h[1])                               # alpha += s[end]
+            beta = float(np.sqrt(h[2]))
+        return alpha, beta
 
     def recompute_gram(self, st: LanczosFactorization):
         """After a restart transformed the basis: rebuild the strictly-lower Gram rows."""
@@ -484,15 +532,16 @@ class DistRectOperator:
 @dataclass
 class DistGKLIterator:
     """Row-sharded GKLIterator (factorizations/gkl.jl:137-152).  Orthogonalisers: cgs, mgs (no
-    re-orthogonalisation, gkl.jl:294-307), cgs2 (:308-323), mgs2 in its low-sync form (:324-346)."""
+    re-orthogonalisation, gkl.jl:294-307), cgs2 (:308-323), mgs2 in its low-sync form (:324-346), cgsir / mgsir
+    (:347-404; pass counts decided from all-reduced norms)."""
     operator: DistRectOperator
     u0_local: np.ndarray
     orth: Orthogonalizer = KrylovDefaults.orth
     capacity: int = KrylovDefaults.krylovdim + 2
 
     def __post_init__(self):
-        if self.orth.name not in ("cgs", "mgs", "cgs2", "mgs2"):
-            raise NotImplementedError(f"{self.orth.name}: not offered row-sharded yet; use cgs2 / mgs2")
+        if self.orth.name not in ("cgs", "mgs", "cgs2", "mgs2", "cgsir", "mgsir"):
+            raise ValueError(f"unknown orthogonalizer {self.orth.name}")
         self.backend = self.operator.backend
         self.buf = self.backend.alloc(2 * 256 + 8)
         self.nbuf = self.backend.alloc(4)
@@ -511,6 +560,12 @@ class DistGKLIterator:
         """One orthogonalisation pass of (basis, col) against columns [0, m): classical (gram None)
         or low-sync modified; the Gram row of the newest basis vector rides along."""
         be = self.backend
+        if gram is not None:
+            for i in range(max(gram.rows, 1), m - 1):        # rows skipped while no refinement pass was needed (IR)
+                be.project(basis, 0, i, i, -1, self.buf[0:i])
+                self._allreduce(self.buf[0:i])
+                gram.L[i, :i] = be.to_host(self.buf[0:i])
+                gram.rows = i + 1
         ride = gram is not None and gram.rows == m - 1 and m >= 2
         be.project(basis, 0, m, col, (m - 1) if ride else -1, self.buf[0:2 * m])
         self._allreduce(self.buf[0:(2 * m if ride else m)])
@@ -565,11 +620,17 @@ class DistGKLIterator:
         be.scal(U, k, 1.0 / beta_old)                    # U = push!(U, scale!!(r, 1/beta_old))
         op.apply_adjoint(U, k, V, k)                     # v = A' u
         be.unproject(V, k, k - 1, 1, [beta_old], -1.0, 1.0, self.nbuf)   # v -= beta_old V[end]; |v|^2 partial
+        eps = float(np.finfo(np.float64).eps)
         if name == "mgs2":
             alpha = self._sweep(V, k, k, self.gram_v)    # for q in V: orthogonalize!!(v, q, MGS)   :330-335
         else:
             self._allreduce(self.nbuf[0:1])
             alpha = float(np.sqrt(be.to_host(self.nbuf[0:1])[0]))
+            if name in ("cgsir", "mgsir"):                # :353-358 (no eps guard for cgsir, as the reference) / :380-386
+                nold = float(np.sqrt(alpha * alpha + beta_old * beta_old))
+                while (name == "cgsir" or eps < alpha) and alpha < self.orth.eta * nold:
+                    nold = alpha
+                    alpha = self._sweep(V, k, k, self.gram_v if name == "mgsir" else None)
         be.scal(V, k, 1.0 / alpha)
         op.apply_normal(V, k, U, k + 1)                  # r = A v
         be.unproject(U, k + 1, k, 1, [alpha], -1.0, 1.0, self.nbuf)      # r -= alpha u
@@ -580,6 +641,11 @@ class DistGKLIterator:
         else:
             self._allreduce(self.nbuf[0:1])
             beta = float(np.sqrt(be.to_host(self.nbuf[0:1])[0]))
+            if name in ("cgsir", "mgsir"):                # :363-372 / :391-402
+                nold = float(np.sqrt(alpha * alpha + beta * beta))
+                while eps < beta < self.orth.eta * nold:
+                    nold = beta
+                    beta = self._sweep(U, k + 1, k + 1, self.gram_u if name == "mgsir" else None)
         st.alphas.append(alpha)
         st.betas.append(beta)
         U.length = V.length = k + 1

@@ -50,7 +50,7 @@ def _worker(rank, world, port, case, q):
         be = CheckerBackend()
         op = kd.DistSparseOperator(A[part.lo:part.hi, :], part, be)
         res = {"rank": rank, "n_ghost": op.n_ghost, "send": op.send_counts, "recv": op.recv_counts}
-        for name in ("cgs", "mgs", "cgs2", "mgs2"):
+        for name in ("cgs", "mgs", "cgs2", "mgs2", "cgsir", "mgsir"):
             it = kd.DistLanczosIterator(op, x0[part.lo:part.hi], Orthogonalizer(name), capacity=22)
             f = it.initialize()
             for _ in range(18):
@@ -92,18 +92,22 @@ def test_row_sharded_lanczos_gloo_world2(case):
         A = (R + R.T + sp.identity(n) * 4).tocsr()
         assert out[0]["n_ghost"] > 0 and out[0]["send"][1] == out[1]["recv"][0]
     x0 = np.random.default_rng(3).random(A.shape[0])
-    for name, ref in (("cgs", ko.CGS), ("mgs", ko.MGS), ("cgs2", ko.CGS2), ("mgs2", ko.MGS2)):
+    for name, ref in (("cgs", ko.CGS), ("mgs", ko.MGS), ("cgs2", ko.CGS2), ("mgs2", ko.MGS2), ("cgsir", ko.CGSIR()),
+                      ("mgsir", ko.MGSIR())):
         it = ko.LanczosIterator(A, x0.copy(), ref)
         f = ko.lanczos_initialize(it)
+        stats = {}
         for _ in range(18):
-            f = ko.lanczos_expand(it, f)
-        tol = 1e-10 if name.endswith("2") else 1e-7
+            f = ko.lanczos_expand(it, f, stats)
+        if name.endswith("ir"):
+            assert stats["passes"] > 0, "the refinement loop must have been exercised"
+        tol = 1e-7 if name in ("cgs", "mgs") else 1e-10
         for r in out:
             a, b, _ = r[name]
             np.testing.assert_allclose(a, f.alphas, rtol=tol, err_msg=name)
             np.testing.assert_allclose(b, f.betas, rtol=tol, err_msg=name)
         V = np.vstack([out[0][name][2], out[1][name][2]])  # re-assembled global basis
-        if name.endswith("2"):
+        if name not in ("cgs", "mgs"):
             assert np.max(np.abs(V.T @ V - np.eye(V.shape[1]))) < 1e-12
             np.testing.assert_allclose(np.abs(V), np.abs(np.stack(f.V, 1)), atol=1e-9)
 
@@ -138,8 +142,9 @@ def _gkl_worker(rank, world, port, q):
         be = CheckerBackend()
         op = kd.DistRectOperator(A[rp.lo:rp.hi, :], rp, cp, be)
         res = {"rank": rank}
-        for name in ("cgs", "cgs2", "mgs2"):
-            it = kd.DistGKLIterator(op, u0[rp.lo:rp.hi], Orthogonalizer(name), capacity=18)
+        for name in ("cgs", "cgs2", "mgs2", "cgsir", "mgsir"):
+            # eta close to 1 so that the refinement loops of BOTH bases run (with 1/sqrt(2) the U side never needs one here)
+            it = kd.DistGKLIterator(op, u0[rp.lo:rp.hi], Orthogonalizer(name, 0.9999), capacity=18)
             f = it.initialize()
             for _ in range(14):
                 f = it.expand(f)
@@ -171,11 +176,15 @@ def test_row_sharded_gkl_gloo_world2():
     out.sort(key=lambda r: r["rank"])
     A = ko.sparse_random(240, 100, 6, 41)
     u0 = np.random.default_rng(6).random(240)
-    for name, ref in (("cgs", ko.CGS), ("cgs2", ko.CGS2), ("mgs2", ko.MGS2)):
+    for name, ref in (("cgs", ko.CGS), ("cgs2", ko.CGS2), ("mgs2", ko.MGS2), ("cgsir", ko.CGSIR(0.9999)),
+                      ("mgsir", ko.MGSIR(0.9999))):
         it = ko.GKLIterator(A, u0.copy(), ref)
         f = ko.gkl_initialize(it)
+        stats = {}
         for _ in range(14):
-            f = ko.gkl_expand(it, f)
+            f = ko.gkl_expand(it, f, stats)
+        if name.endswith("ir"):   # the refinement loops of both bases must have been exercised
+            assert stats["passes_v"] > 0 and stats["passes_u"] > 0
         tol = 1e-10 if name != "cgs" else 1e-6
         for r in out:
             np.testing.assert_allclose(r[name][0], f.alphas, rtol=tol, err_msg=name)
@@ -185,5 +194,5 @@ def test_row_sharded_gkl_gloo_world2():
         k = U.shape[1]
         B = np.diag(f.alphas) + np.diag(f.betas[:-1], -1)
         assert np.max(np.abs(A.T @ U - V @ B.T)) < 1e-9
-        if name == "mgs2":
+        if name in ("mgs2", "mgsir"):
             assert np.max(np.abs(U.T @ U - np.eye(k))) < 1e-12 and np.max(np.abs(V.T @ V - np.eye(k))) < 1e-12

@@ -489,7 +489,8 @@ def test_dist_hip_backend_world1(kk, ko, ctx):
         part = kd.Partition.even(n, 1, 0, align=nx)
         op = kd.DistSparseOperator(A, part, be)
         for dev, ref in ((kk.ClassicalGramSchmidt2(), ko.CGS2), (kk.ModifiedGramSchmidt2(), ko.MGS2),
-                         (kk.ClassicalGramSchmidt(), ko.CGS), (kk.ModifiedGramSchmidt(), ko.MGS)):
+                         (kk.ClassicalGramSchmidt(), ko.CGS), (kk.ModifiedGramSchmidt(), ko.MGS),
+                         (kk.ClassicalGramSchmidtIR(), ko.CGSIR()), (kk.ModifiedGramSchmidtIR(), ko.MGSIR())):
             it = kd.DistLanczosIterator(op, x0, dev, capacity=24)
             f = it.initialize()
             oit = ko.LanczosIterator(A, x0.copy(), ref)
@@ -511,7 +512,8 @@ def test_dist_hip_backend_world1(kk, ko, ctx):
         Ar = ko.sparse_random(600, 250, 8, 21)
         u0 = np.random.default_rng(6).random(600)
         rop = kd.DistRectOperator(Ar, kd.Partition.even(600, 1, 0), kd.Partition.even(250, 1, 0), be)
-        for dev, ref in ((kk.ClassicalGramSchmidt2(), ko.CGS2), (kk.ModifiedGramSchmidt2(), ko.MGS2)):
+        for dev, ref in ((kk.ClassicalGramSchmidt2(), ko.CGS2), (kk.ModifiedGramSchmidt2(), ko.MGS2),
+                         (kk.ClassicalGramSchmidtIR(0.9999), ko.CGSIR(0.9999)), (kk.ModifiedGramSchmidtIR(0.9999), ko.MGSIR(0.9999))):
             git = kd.DistGKLIterator(rop, u0, dev, capacity=18)
             gf = git.initialize()
             oit = ko.GKLIterator(Ar, u0.copy(), ref)
