@@ -330,8 +330,9 @@ KK_API int kk_blocklanczos_initialize(kk_op op, kk_basis b, int c_x0, int bs0, i
 #define AB_S1 (AB_BASE + 1044)       // [256] staged R1^-1
 #define AB_S2 (AB_BASE + 1300)       // [256] staged R2^-1
 #define AB_S3 (AB_BASE + 1556)       // [512] three-term panel [B' ; M]
-#define AB_P (AB_BASE + 2068)        // [KK_MAX_M * 16] re-orthogonalisation panel V'(AX), row-major
-#define AB_END (AB_P + KK_MAX_M * 16)
+#define AB_P (AB_BASE + 2068)        // [3 * KK_MAX_M * 16] re-orthogonalisation panel V'(AX), row-major; the one-pass step appends
+                                     // the ride-along Gram panel V'X and the corrected panel (kn * st doubles each)
+#define AB_END (AB_P + 3 * KK_MAX_M * 16)
 static_assert(AB_END <= KK_BLK_SCRATCH, "block scratch too small for the asynchronous block step");
 
 // expand!(::BlockLanczosIterator) without a host round trip between its kernels (panel mode, 2 <= block size <= 16, no rank
@@ -345,6 +346,14 @@ static int blocklanczos_expand_async(kk_op op, kk_basis b, int k, int p, int c_r
     const int64_t ld = b->ld;
     const int st = kk_bu_stride(p);
     double* D = c->blk;
+    const int kn = k + p;
+    KK_CHECK(kn <= KK_MAX_M, KK_ERR_UNSUPPORTED, "block step: %d basis vectors exceed the panel limit", kn);
+    const bool onepass = (c->block_fuse & 4) != 0;
+    if (onepass) {   // Gram rows of the basis columns [0, k): known from the previous steps, recomputed after a restart
+        if (b->gram_c0 != 0) { b->gram_c0 = 0; b->gram_rows = 0; }
+        KK_TRY(gram_device(b));
+        if (b->gram_rows < k) KK_TRY(gram_ensure(b, k));
+    }
     KK_HIP(hipMemsetAsync(D + AB_FLAG, 0, 4 * sizeof(double), c->stream));
     // ---- block_qr! as CholQR2, out of place: residual block (c_r) -> new basis block (columns k..k+p-1)
     KK_TRY(kk_launch_block_gram(c, b->col(c_r), ld, p, b->col(c_r), ld, p, ld, D + AB_G, p));
@@ -363,11 +372,38 @@ static int blocklanczos_expand_async(kk_op op, kk_basis b, int k, int p, int c_r
     // ---- block_lanczosrecurrence: AX = A X ; M = X' AX ; AX -= [Xprev X] [B' ; M]
     double* AX = b->col(c_rnext);
     KK_TRY(kk_launch_spmm(c, op->A, b->col(k), ld, AX, ld, p));
+    if (onepass) {
+        // one pass: P = V'(A X) against the whole basis, AX -= V P.  Rows k-p .. k+p-1 of P are the three-term coefficients
+        // [B' ; M] (blocklanczos.jl:253-260), the other rows the re-orthogonalisation (:277-284); the reference subtracts the
+        // three-term part first and projects the remainder once more ("twice is enough").  A single classical pass is NOT:
+        // the orthogonality error E = V'V - I re-enters as E P and grows geometrically.  Here E is known -- the Gram rows of
+        // every new block ride along in the panel kernel -- and the coefficients are corrected to first order,
+        // P <- (I - E) P (k_blk_panel_correct), which leaves V'w = O(E^2 |P|) like the second pass does.  What remains is the
+        // rounding of the panel itself, eps |A x_j| instead of eps |w_j|: a column that loses more than a factor 10 of its
+        // norm raises flag 3 and the step is repeated on the two-pass route.  Saves the M panel, and one read + one write
+        // of [Xprev X AX] per step.
+        double* P = D + AB_P;
+        double* G2 = P + (int64_t)kn * st;
+        double* Pc = G2 + (int64_t)kn * st;
+        // two accumulator sets: 80 basis columns per launch keep the kernel at two waves per SIMD (128 columns: one)
+        const int chunk = c->gram2_chunk;
+        const int nch = (kn + chunk - 1) / chunk;
+        const int per = ((kn + nch - 1) / nch + 15) / 16 * 16;   // balanced chunks, whole 16-column groups
+        for (int i0 = 0; i0 < kn; i0 += per)
+            KK_TRY(kk_launch_block_gram2(c, b->col(i0), ld, std::min(per, kn - i0), AX, ld, p, b->col(k), ld, p, ld, P + (int64_t)i0 * st,
+                                         st, G2 + (int64_t)i0 * st, st));
+        KK_TRY(kk_allreduce(c, P, 2 * (int64_t)kn * st));
+        KK_TRY(kk_launch_blk_gram_rows(c, G2, st, k, p, b->d_gram, b->cap));
+        KK_TRY(kk_launch_blk_panel_m(c, P, st, k, p, D + AB_M, 16));
+        KK_TRY(kk_launch_blk_panel_correct(c, P, st, kn, p, b->d_gram, b->cap, Pc));
+        KK_TRY(kk_launch_block_update(c, b->col(0), ld, kn, AX, AX, ld, ld, p, Pc, -1.0, 1.0, D + AB_NRM));
+        KK_TRY(kk_launch_blk_onepass_check(c, P, st, kn, p, D + AB_NRM, 0.1, D + AB_FLAG));
+        KK_HIP(hipMemcpyAsync(c->h_blk + (G2 - D), G2, (size_t)kn * st * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        goto readback;
+    }
     KK_TRY(kk_launch_block_gram(c, b->col(k), ld, p, AX, ld, p, ld, D + AB_M, 16));
     KK_TRY(kk_allreduce(c, D + AB_M, 256));
     KK_TRY(kk_launch_blk_fill_m(c, D + AB_M, 16, p, D + AB_S3, st));
-    const int kn = k + p;
-    KK_CHECK(kn <= KK_MAX_M, KK_ERR_UNSUPPORTED, "block step: %d basis vectors exceed the panel limit", kn);
     if (c->block_fuse & 2) {
         // P = V'(AX - [Xprev X] S3) with the three-term result formed on the fly (never written); the update below then
         // subtracts V (P + [0; S3]) from the original AX:  AX - [Xprev X] S3 - V P
@@ -384,12 +420,19 @@ static int blocklanczos_expand_async(kk_op op, kk_basis b, int k, int p, int c_r
         KK_TRY(kk_allreduce(c, D + AB_P, (int64_t)kn * st));
     }
     KK_TRY(kk_launch_block_update(c, b->col(0), ld, kn, AX, AX, ld, ld, p, D + AB_P, -1.0, 1.0, D + AB_NRM));
+readback:
     // ---- the one read-back
     KK_HIP(hipMemcpyAsync(c->h_blk + AB_BASE, D + AB_BASE, AB_READBACK * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     KK_TRY(stream_sync(c));
     const double* H = c->h_blk + AB_BASE;
     *fine = (H[0] == 0.0);
     if (!*fine) return KK_OK;
+    if (onepass) {   // host mirror of the new Gram rows (strictly-lower storage), as the device kernel wrote them
+        const double* G2h = c->h_blk + AB_P + (int64_t)kn * st;
+        for (int i = 0; i < p; ++i)
+            for (int j = 0; j < k + i; ++j) b->gram[(size_t)(k + i) * b->cap + j] = G2h[(size_t)j * st + i];
+        b->gram_rows = kn;
+    }
     for (int j = 0; j < p; ++j)
         for (int i = 0; i < p; ++i) {
             B[i + (size_t)ldb * j] = H[20 + i + 16 * j];

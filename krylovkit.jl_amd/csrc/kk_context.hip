@@ -168,8 +168,20 @@ KK_API int kk_ctx_set_option(kk_ctx c, const char* key, double value) {
         c->persist_nt = value != 0;
     } else if (!strcmp(key, "gram_nt")) {
         c->gram_nt = value != 0;
+    } else if (!strcmp(key, "spmm_cols")) {
+        KK_CHECK(value == 4 || value == 8 || value == 16, KK_ERR_INVALID, "spmm_cols must be 4, 8 or 16");
+        c->spmm_cols = (int)value;
+    } else if (!strcmp(key, "spmm_rpl")) {
+        KK_CHECK(value == 1 || value == 2, KK_ERR_INVALID, "spmm_rpl must be 1 or 2");
+        c->spmm_rpl = (int)value;
+    } else if (!strcmp(key, "gram2_chunk")) {
+        KK_CHECK(value == 64 || value == 80 || value == 128, KK_ERR_INVALID, "gram2_chunk must be 64, 80 or 128");
+        c->gram2_chunk = (int)value;
+    } else if (!strcmp(key, "gram_bpc")) {
+        KK_CHECK(value >= 2 && value <= 16, KK_ERR_INVALID, "gram_bpc must be in 2..16");
+        c->gram_bpc = (int)value;
     } else if (!strcmp(key, "block_fuse")) {
-        KK_CHECK(value >= 0 && value <= 3, KK_ERR_INVALID, "block_fuse is a bit mask: 1 = CholQR2 round 2, 2 = three-term + panel");
+        KK_CHECK(value >= 0 && value <= 7, KK_ERR_INVALID, "block_fuse is a bit mask: 1 = CholQR2 round 2, 2 = three-term + panel, 4 = one-pass projection");
         c->block_fuse = (int)value;
     } else if (!strcmp(key, "block_async")) {
         c->block_async = value != 0;

@@ -112,9 +112,14 @@ struct kk_ctx_s {
     double* h_blk = nullptr;     // pinned twin of blk
     int block_mode = 1;          // 0 strict, 1 panel (MFMA gram + multi-rhs update)
     int spmm_bpc = 4;            // resident blocks per CU of the multi-column sparse apply (L2 window, see kk_launch_spmm); 0 = fill the chip
+    int spmm_rpl = 2;            // SpMM on ELL: rows per lane (1 or 2)
+    int spmm_cols = 16;          // SpMM on ELL: right-hand sides per launch (16, 8 or 4)
     int bu_prefetch = 1;         // block update kernel: 1 = coefficient panel in LDS (default), 0 = scalar-load kernel of round 1, 8/16/24 = deep-prefetch experiments
     int gram_nt = 0;             // Gram panel: non-temporal loads for the X stream
-    int block_fuse = 1;          // asynchronous block step, tile-fused Gram kernels (bit mask): 1 = CholQR2 round 2 (Q1 and its Gram in one pass), 2 = three-term update formed on the fly inside the re-orthogonalisation panel
+    int gram2_chunk = 80;        // two-panel Gram kernel (one-pass block step): basis columns per launch (64, 80 or 128)
+    int gram_bpc = 8;            // Gram panel: blocks per CU of a one-group (p <= 16) launch; NG groups -> gram_bpc / NG, >= 2
+    int block_fuse = 5;          // async block step, bit mask: 1 = CholQR2 round 2 fused (update + Gram in one pass), 2 = three-term
+                                 // update folded into the re-orthogonalisation panel, 4 = one-pass projection against the whole basis
     int block_async = 1;         // panel mode: whole block step enqueued without host round trips (device-side CholQR2 algebra)
     int blocks_per_cu = 4;       // 4 resident 256-thread blocks per CU (measured best on the 10M-row sweep)
     int mgs_mode = 1;
@@ -313,6 +318,12 @@ int kk_launch_blk_chol2(kk_ctx ctx, const double* G2, int p, const double* R1, d
                         double* flag);
 int kk_launch_blk_fill_m(kk_ctx ctx, const double* M, int ldm, int p, double* S3, int st);
 int kk_launch_blk_combine(kk_ctx ctx, double* P, const double* S3, int kn, int nz, int st);
+int kk_launch_block_gram2(kk_ctx ctx, const double* X, int64_t ldx, int p, const double* Y, int64_t ldy, int q, const double* Y2,
+                          int64_t ldy2, int q2, int64_t ld, double* C_dev, int rs, double* C2_dev, int rs2);
+int kk_launch_blk_gram_rows(kk_ctx ctx, const double* G2, int st, int k, int p, double* gram, int cap);
+int kk_launch_blk_panel_correct(kk_ctx ctx, const double* P, int st, int kn, int p, const double* gram, int cap, double* Pc);
+int kk_launch_blk_panel_m(kk_ctx ctx, const double* P, int st, int k, int p, double* M, int ldm);
+int kk_launch_blk_onepass_check(kk_ctx ctx, const double* P, int st, int kn, int p, const double* nrm2, double eta, double* flag);
 int kk_launch_block_gram_tile(kk_ctx ctx, const double* X, int64_t ldx, int p, const double* Yin, int64_t ldy, const double* Z,
                               int64_t ldz, int nz, const double* S_dev, int st, double alpha, double beta, double* Yout,
                               int64_t ldyo, int q, int64_t ld, double* C_dev, int rs, int cs);

@@ -15,7 +15,7 @@
 #define BG_T 8                       // rows per lane per chunk (4 x dwordx4)
 #define BG_CHUNK (4 * BG_T)          // rows per wave chunk
 
-template <int NG>  // NG groups of 16 X-columns
+template <int NG, bool SAME>  // NG groups of 16 X-columns; SAME: Y is X (p <= 16), one load stream feeds both operands
 __global__ __launch_bounds__(KK_TPB) void k_block_gram(const double* __restrict__ X, int64_t ldx, int p,
                                                        const double* __restrict__ Y, int64_t ldy, int q, int64_t ld,
                                                        int64_t rpb, double* __restrict__ part, int nt_x) {
@@ -33,7 +33,8 @@ __global__ __launch_bounds__(KK_TPB) void k_block_gram(const double* __restrict_
         // contiguous bytes per load instruction (same row -> k-slot map for X and Y, so the contraction is unchanged)
         const int64_t row = rc + kq * 2;
         double yv[BG_T];
-        if (yok) {
+        if (SAME) {
+        } else if (yok) {
             const double* yp = Y + (int64_t)c * ldy + row;
 #pragma unroll
             for (int t = 0; t < BG_T; t += 2) { d2 v = ld2(yp + 4 * t); yv[t] = v.x; yv[t + 1] = v.y; }
@@ -59,7 +60,8 @@ __global__ __launch_bounds__(KK_TPB) void k_block_gram(const double* __restrict_
                 for (int t = 0; t < BG_T; ++t) xv[t] = 0.0;
             }
 #pragma unroll
-            for (int t = 0; t < BG_T; ++t) acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(xv[t], yv[t], acc[g], 0, 0, 0);
+            for (int t = 0; t < BG_T; ++t)
+                acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(xv[t], SAME ? xv[t] : yv[t], acc[g], 0, 0, 0);
         }
     }
     // combine the 4 waves through LDS in a fixed order, then one coalesced partial tile per block
@@ -77,6 +79,79 @@ __global__ __launch_bounds__(KK_TPB) void k_block_gram(const double* __restrict_
     }
     double* dst = part + (int64_t)blockIdx.x * (NG * 256);
     for (int e = tid; e < NG * 256; e += KK_TPB) dst[e] = lds[e];
+}
+
+// Two panels in one pass over X:  C = X' Y  and  C2 = X' Y2  (q, q2 <= 16).  Used by the one-pass block step: Y = A Xnew and
+// Y2 = Xnew, the newest basis block, whose Gram rows against the whole basis ride along (the block analogue of the Gram
+// row that rides along in k_project for the low-synchronisation MGS).  When Y2 is group gx of X itself (block start a
+// multiple of 16) its registers serve as the A operand of that group too: the ride-along then costs no memory traffic.
+template <int NG>
+__global__ __launch_bounds__(KK_TPB) void k_block_gram2(const double* __restrict__ X, int64_t ldx, int p,
+                                                        const double* __restrict__ Y, int64_t ldy, int q,
+                                                        const double* __restrict__ Y2, int64_t ldy2, int q2, int gx, int64_t ld,
+                                                        int64_t rpb, double* __restrict__ part, double* __restrict__ part2) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];  // [NG][4][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, kq = lane >> 4;
+    const int64_t r0 = (int64_t)blockIdx.x * rpb, r1 = imin(r0 + rpb, ld);
+    v4d acc[NG], acc2[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) { acc[g] = v4d{0.0, 0.0, 0.0, 0.0}; acc2[g] = v4d{0.0, 0.0, 0.0, 0.0}; }
+    for (int64_t rc = r0 + wave * BG_CHUNK; rc < r1; rc += 4 * BG_CHUNK) {
+        const int64_t row = rc + kq * 2;
+        double yv[BG_T], zv[BG_T];
+#pragma unroll
+        for (int t = 0; t < BG_T; ++t) { yv[t] = 0.0; zv[t] = 0.0; }
+        if (c < q) {
+            const double* yp = Y + (int64_t)c * ldy + row;
+#pragma unroll
+            for (int t = 0; t < BG_T; t += 2) { d2 v = ld2(yp + 4 * t); yv[t] = v.x; yv[t + 1] = v.y; }
+        }
+        if (c < q2) {
+            const double* zp = Y2 + (int64_t)c * ldy2 + row;
+#pragma unroll
+            for (int t = 0; t < BG_T; t += 2) { d2 v = ld2(zp + 4 * t); zv[t] = v.x; zv[t + 1] = v.y; }
+        }
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int col = g * 16 + c;
+            double xv[BG_T];
+            if (g == gx) {        // uniform: this group IS the ride-along block (q2 = 16 columns, all inside p)
+#pragma unroll
+                for (int t = 0; t < BG_T; ++t) xv[t] = zv[t];
+            } else if (col < p) {
+                const double* xp = X + (int64_t)col * ldx + row;
+#pragma unroll
+                for (int t = 0; t < BG_T; t += 2) { d2 v = ld2(xp + 4 * t); xv[t] = v.x; xv[t + 1] = v.y; }
+            } else {
+#pragma unroll
+                for (int t = 0; t < BG_T; ++t) xv[t] = 0.0;
+            }
+#pragma unroll
+            for (int t = 0; t < BG_T; ++t) {
+                acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(xv[t], yv[t], acc[g], 0, 0, 0);
+                acc2[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(xv[t], zv[t], acc2[g], 0, 0, 0);
+            }
+        }
+    }
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int w = 0; w < 4; ++w) {
+            if (wave == w) {
+#pragma unroll
+                for (int g = 0; g < NG; ++g)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        double* a = &lds[(g * 4 + r) * 64 + lane];
+                        const double v = pass ? acc2[g][r] : acc[g][r];
+                        *a = (w == 0) ? v : (*a + v);
+                    }
+            }
+            __syncthreads();
+        }
+        double* dst = (pass ? part2 : part) + (int64_t)blockIdx.x * (NG * 256);
+        for (int e = tid; e < NG * 256; e += KK_TPB) dst[e] = lds[e];
+        __syncthreads();
+    }
 }
 
 // Gram panel against a tile that is COMPUTED on the fly instead of read:
@@ -218,21 +293,36 @@ __global__ __launch_bounds__(KK_TPB) void k_block_gram_tile(const double* __rest
     for (int e = tid; e < NG * 256; e += KK_TPB) dst[e] = lds[e];
 }
 
-// C[i + ldc*j] = sum_b part[b][e(i,j)]   (one thread per output entry)
-// (C[i*rs + j*cs]: rs = 1, cs = ldc is the column-major panel; rs = row stride, cs = 1 writes the panel row-major, i.e.
-// directly in the coefficient layout k_block_update reads)
+// C[i*rs + j*cs] = sum_b part[b][e(i,j)]: rs = 1, cs = ldc is the column-major panel; rs = row stride, cs = 1 writes the panel
+// row-major, i.e. directly in the coefficient layout k_block_update reads.  A block reduces 16 consecutive tile elements:
+// thread (el = tid & 15, sl = tid >> 4) adds the partial tiles sl, sl + 16, ... (128-byte coalesced loads), the 16 slices are
+// combined through LDS in a fixed order -- deterministic, and the reduction over up to 2048 partial tiles no longer runs
+// as one serial chain per output entry (306 us -> a few us per Gram panel at 8 blocks per CU).
 __global__ __launch_bounds__(KK_TPB) void k_finalize_gram(const double* __restrict__ part, int nblk, int ng, int p, int q,
                                                           double* __restrict__ C, int rs, int cs) {
-    const int idx = blockIdx.x * KK_TPB + threadIdx.x;
-    if (idx >= p * q) return;
-    const int i = idx % p, j = idx / p;
-    const int g = i >> 4, ii = i & 15;          // ii = (lane>>4) + 4 r  ->  r = ii>>2, lane>>4 = ii&3
-    const int r = ii >> 2, lane = ((ii & 3) << 4) | j;
-    const int e = (g * 4 + r) * 64 + lane;
+    __shared__ double sm[16][17];
+    const int el = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int e = blockIdx.x * 16 + el;                  // tile element: e = (g*4 + r)*64 + lane
     const int64_t stride = (int64_t)ng * 256;
-    double a = 0;
-    for (int b = 0; b < nblk; ++b) a += part[(int64_t)b * stride + e];
-    C[(int64_t)i * rs + (int64_t)j * cs] = a;
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    int b = sl;
+    for (; b + 48 < nblk; b += 64) {
+        a0 += part[(int64_t)b * stride + e];
+        a1 += part[(int64_t)(b + 16) * stride + e];
+        a2 += part[(int64_t)(b + 32) * stride + e];
+        a3 += part[(int64_t)(b + 48) * stride + e];
+    }
+    for (; b < nblk; b += 16) a0 += part[(int64_t)b * stride + e];
+    sm[sl][el] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (sl == 0) {
+        double a = 0;
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2) a += sm[s2][el];
+        const int g = e >> 8, r = (e >> 6) & 3, lane = e & 63;
+        const int j = lane & 15, i = g * 16 + (lane >> 4) + 4 * r;
+        if (i < p && j < q) C[(int64_t)i * rs + (int64_t)j * cs] = a;
+    }
 }
 
 // ---- one-block dense helpers of the asynchronous block step (p <= 16): the Cholesky factors, their inverses and the
@@ -240,42 +330,60 @@ __global__ __launch_bounds__(KK_TPB) void k_finalize_gram(const double* __restri
 // the host reads the flag afterwards and repeats the step on the synchronous route if a safety test failed.
 // upper Cholesky G = R'R in LDS; returns false (uniformly) if a pivot is not safely positive:
 // pivot^2 must exceed rel^2 * G_jj and abs_min^2   (same test as the host-side chol_upper_safe)
+// One wave (64 lanes, launch bounds 64): right-looking factorisation in LDS, every step a handful of LDS round trips
+// (thread-0-serial versions of these helpers took ~100 us per launch, 0.4 ms per block step).
+__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
 __device__ bool chol16(const double* G, int p, double (*R)[17], double rel, double abs_min) {
-    // single-thread algorithm executed by thread 0 (p <= 16: ~700 flops), everyone else waits
+    __shared__ double A[16][17], dg[16];
     __shared__ int ok_s;
-    if (threadIdx.x == 0) {
-        bool ok = true;
-        for (int j = 0; j < p && ok; ++j) {
-            for (int i = 0; i < j; ++i) {
-                double t = G[i + p * j];
-                for (int k = 0; k < i; ++k) t -= R[k][i] * R[k][j];
-                R[i][j] = t / R[i][i];
-            }
-            double d2 = G[j + p * j];
-            for (int k = 0; k < j; ++k) d2 -= R[k][j] * R[k][j];
-            const double gjj = G[j + p * j];
-            if (!(d2 > rel * rel * gjj) || !(d2 > abs_min * abs_min) || !(d2 < 1e300)) ok = false;
-            else R[j][j] = sqrt(d2);
-            for (int i = j + 1; i < p; ++i) R[i][j] = 0.0;
-        }
-        ok_s = ok ? 1 : 0;
+    const int lane = threadIdx.x;
+    for (int e = lane; e < 256; e += 64) {
+        const int i = e >> 4, j = e & 15;
+        const double g = (i < p && j < p) ? G[i + p * j] : 0.0;
+        A[i][j] = g; R[i][j] = 0.0;
+        if (i == j) dg[i] = g;
     }
-    __syncthreads();
+    if (lane == 0) ok_s = 1;
+    wave_sync();
+    for (int j = 0; j < p; ++j) {
+        const double d2 = A[j][j], gjj = dg[j];   // A[j][j] = G_jj - sum_k R[k][j]^2, subtracted for k ascending
+        if (!(d2 > rel * rel * gjj) || !(d2 > abs_min * abs_min) || !(d2 < 1e300)) { if (lane == 0) ok_s = 0; break; }   // uniform
+        const double rjj = sqrt(d2);
+        if (lane < 16) R[j][lane] = (lane == j) ? rjj : (lane > j && lane < p ? A[j][lane] / rjj : 0.0);
+        wave_sync();
+        for (int e = lane; e < 256; e += 64) {
+            const int a = e >> 4, b = e & 15;
+            if (a > j && b >= a && b < p) A[a][b] -= R[j][a] * R[j][b];
+        }
+        wave_sync();
+    }
+    wave_sync();
     return ok_s != 0;
 }
+// Ri = R^-1 (upper triangular): lane j owns column j, back substitution out of LDS with the column in registers
 __device__ void triu_inv16(double (*R)[17], int p, double (*Ri)[17]) {
-    if (threadIdx.x == 0) {
-        for (int j = 0; j < p; ++j) {
-            for (int i = 0; i < p; ++i) Ri[i][j] = 0.0;
-            Ri[j][j] = 1.0 / R[j][j];
-            for (int i = j - 1; i >= 0; --i) {
-                double t = 0;
-                for (int k = i + 1; k <= j; ++k) t += R[i][k] * Ri[k][j];
-                Ri[i][j] = -t / R[i][i];
+    const int j = threadIdx.x;
+    if (j < 16) {
+        double ri[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) ri[i] = 0.0;
+        if (j < p) {
+#pragma unroll
+            for (int i = 15; i >= 0; --i) {
+                if (i == j) ri[i] = 1.0 / R[j][j];
+                else if (i < j) {
+                    double t = 0;
+#pragma unroll
+                    for (int k = 15; k > 0; --k)
+                        if (k > i && k <= j) t += R[i][k] * ri[k];
+                    ri[i] = -t / R[i][i];
+                }
             }
         }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) Ri[i][j] = ri[i];
     }
-    __syncthreads();
+    wave_sync();
 }
 // CholQR2, first factor: G (p x p col-major) -> R1 (p x p col-major, ld p) and the staged panel of R1^-1 (row-major, stride st)
 __global__ __launch_bounds__(64) void k_blk_chol1(const double* __restrict__ G, int p, double abs_min, double* __restrict__ R1out,
@@ -293,17 +401,20 @@ __global__ __launch_bounds__(64) void k_blk_chol2(const double* __restrict__ G2,
                                                   double* __restrict__ Bout, int ldb, double* __restrict__ S2, double* __restrict__ S3,
                                                   int st, double* __restrict__ flag) {
     __shared__ double R[16][17], Ri[16][17], Bm[16][17];
-    __shared__ double dev_s;
-    if (threadIdx.x == 0) {
-        double dev = 0;
-        for (int j = 0; j < p; ++j)
-            for (int i = 0; i < p; ++i) dev = fmax(dev, fabs(G2[i + p * j] - (i == j ? 1.0 : 0.0)));
-        dev_s = (dev < 1e-3) ? 0.0 : 1.0;   // NaN compares false -> flagged
-        if (!(dev < 1e-3)) dev_s = 1.0;
+    __shared__ int bad_s;
+    if (threadIdx.x == 0) bad_s = 0;
+    wave_sync();
+    {
+        bool bad = false;
+        for (int e = threadIdx.x; e < p * p; e += 64) {
+            const int i = e % p, j = e / p;
+            if (!(fabs(G2[e] - (i == j ? 1.0 : 0.0)) < 1e-3)) bad = true;   // NaN compares false -> flagged
+        }
+        if (bad) bad_s = 1;
     }
-    __syncthreads();
+    wave_sync();
     if (flag[0] != 0.0) return;   // first factor already failed
-    if (dev_s != 0.0) { if (threadIdx.x == 0) flag[0] = 2.0; return; }
+    if (bad_s != 0) { if (threadIdx.x == 0) flag[0] = 2.0; return; }
     const bool ok = chol16(G2, p, R, 1e-2, 0.0);
     if (!ok) { if (threadIdx.x == 0) flag[0] = 2.0; return; }
     triu_inv16(R, p, Ri);
@@ -313,7 +424,7 @@ __global__ __launch_bounds__(64) void k_blk_chol2(const double* __restrict__ G2,
         for (int k = i; k <= j; ++k) t += R[i][k] * R1[k + p * j];
         Bm[i][j] = (i <= j) ? t : 0.0;
     }
-    __syncthreads();
+    wave_sync();
     for (int e = threadIdx.x; e < p * p; e += 64) Bout[(e % p) + ldb * (e / p)] = Bm[e % p][e / p];
     for (int e = threadIdx.x; e < p * st; e += 64) {
         const int i = e / st, j = e % st;
@@ -324,6 +435,60 @@ __global__ __launch_bounds__(64) void k_blk_chol2(const double* __restrict__ G2,
 // C = P + [0 ; S3]: the re-orthogonalisation panel with the three-term coefficients added to its last nz rows (row-major, stride st)
 __global__ __launch_bounds__(KK_TPB) void k_blk_combine(double* __restrict__ P, const double* __restrict__ S3, int kn, int nz, int st) {
     for (int e = threadIdx.x; e < nz * st; e += KK_TPB) P[(int64_t)(kn - nz) * st + e] += S3[e];
+}
+// One-pass block step (block_fuse bit 4): P = V'(A X) over the WHOLE basis is the coefficient panel of a single update
+// AX - V P (the three-term part [B'; M] is its rows k-p .. k+p-1); M = X'(A X) is rows k .. k+p-1 of the panel.
+__global__ __launch_bounds__(KK_TPB) void k_blk_panel_m(const double* __restrict__ P, int st, int k, int p, double* __restrict__ M, int ldm) {
+    for (int e = threadIdx.x; e < p * p; e += KK_TPB) { const int i = e % p, j = e / p; M[i + ldm * j] = P[(int64_t)(k + i) * st + j]; }
+}
+// Safety test of the one-pass step: column j lost more than a factor 1/eta of its norm in the single projection
+// (|w_j|^2 < eta^2 (|w_j|^2 + |P_j|^2), |A x_j|^2 = |w_j|^2 + |P_j|^2 for an orthonormal basis) -> flag 3: the caller repeats
+// the step on the two-pass route (three-term recurrence, then block_reorthogonalize!), as the reference orders it.
+__global__ __launch_bounds__(KK_TPB) void k_blk_onepass_check(const double* __restrict__ P, int st, int kn, int p,
+                                                              const double* __restrict__ nrm2, double eta2, double* __restrict__ flag) {
+    __shared__ double sm[16][17];
+    const int j = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    double s = 0;
+    if (j < p)
+        for (int i = sl; i < kn; i += 16) { const double v = P[(int64_t)i * st + j]; s = fma(v, v, s); }
+    sm[sl][j] = s;
+    __syncthreads();
+    if (sl == 0 && j < p) {
+        double t = 0;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) t += sm[u][j];
+        const double w2 = nrm2[j];
+        if (!(w2 >= eta2 * (w2 + t)) && flag[0] == 0.0) flag[0] = 3.0;   // NaN -> flagged; all writers store the same value
+    }
+}
+// Gram rows of the newest block from the ride-along panel G2[j][i] = <v_j, x_i> (row-major, stride st):
+//   gram[(k+i)*cap + j] = G2[j][i]  for j < k+i      (strictly-lower storage of kk_orth.hip, device mirror)
+__global__ __launch_bounds__(KK_TPB) void k_blk_gram_rows(const double* __restrict__ G2, int st, int k, int p, double* __restrict__ gram, int cap) {
+    const int kn = k + p;
+    for (int e = threadIdx.x + blockIdx.x * KK_TPB; e < kn * p; e += KK_TPB * gridDim.x) {
+        const int j = e / p, i = e % p;
+        if (j < k + i) gram[(int64_t)(k + i) * cap + j] = G2[(int64_t)j * st + i];
+    }
+}
+// One-pass projection with a non-orthonormal basis to first order: the coefficients of the projector onto span(V) are
+// (V'V)^-1 V'y ~ (I - E) V'y, E = V'V - I (off-diagonal part, from the strictly-lower Gram rows):
+//   Pc[i][j] = P[i][j] - sum_{l != i} G(i, l) P[l][j]
+// Without it the error E of the basis re-enters every new block multiplied by |P| / |w| > 1 and grows geometrically (one
+// classical Gram-Schmidt pass is not enough); with it V'w = O(E^2 |P|) + the rounding of the panel itself.
+__global__ __launch_bounds__(KK_TPB) void k_blk_panel_correct(const double* __restrict__ P, int st, int kn, int p,
+                                                              const double* __restrict__ gram, int cap, double* __restrict__ Pc) {
+    extern __shared__ double psm[];   // P staged: kn * st
+    for (int e = threadIdx.x; e < kn * st; e += KK_TPB) psm[e] = P[e];
+    __syncthreads();
+    for (int e = threadIdx.x; e < kn * st; e += KK_TPB) {
+        const int i = e / st, j = e % st;
+        double a = 0;
+        if (j < p) {
+            for (int l = 0; l < i; ++l) a = fma(gram[(int64_t)i * cap + l], psm[l * st + j], a);
+            for (int l = i + 1; l < kn; ++l) a = fma(gram[(int64_t)l * cap + i], psm[l * st + j], a);
+        }
+        Pc[e] = psm[e] - a;
+    }
 }
 // rows p..2p-1 of the three-term panel: S3[p + i][j] = M[i][j]  (M col-major, ld ldm)
 __global__ __launch_bounds__(64) void k_blk_fill_m(const double* __restrict__ M, int ldm, int p, double* __restrict__ S3, int st) {
@@ -589,10 +754,51 @@ int kk_launch_blk_fill_m(kk_ctx ctx, const double* M, int ldm, int p, double* S3
     KK_HIP(hipGetLastError());
     return KK_OK;
 }
+int kk_launch_blk_panel_m(kk_ctx ctx, const double* P, int st, int k, int p, double* M, int ldm) {
+    hipLaunchKernelGGL(k_blk_panel_m, dim3(1), dim3(KK_TPB), 0, ctx->stream, P, st, k, p, M, ldm);
+    KK_HIP(hipGetLastError());
+    return KK_OK;
+}
+int kk_launch_blk_onepass_check(kk_ctx ctx, const double* P, int st, int kn, int p, const double* nrm2, double eta, double* flag) {
+    hipLaunchKernelGGL(k_blk_onepass_check, dim3(1), dim3(KK_TPB), 0, ctx->stream, P, st, kn, p, nrm2, eta * eta, flag);
+    KK_HIP(hipGetLastError());
+    return KK_OK;
+}
+int kk_launch_blk_gram_rows(kk_ctx ctx, const double* G2, int st, int k, int p, double* gram, int cap) {
+    hipLaunchKernelGGL(k_blk_gram_rows, dim3(4), dim3(KK_TPB), 0, ctx->stream, G2, st, k, p, gram, cap);
+    KK_HIP(hipGetLastError());
+    return KK_OK;
+}
+int kk_launch_blk_panel_correct(kk_ctx ctx, const double* P, int st, int kn, int p, const double* gram, int cap, double* Pc) {
+    hipLaunchKernelGGL(k_blk_panel_correct, dim3(1), dim3(KK_TPB), (size_t)kn * st * sizeof(double), ctx->stream, P, st, kn, p, gram, cap, Pc);
+    KK_HIP(hipGetLastError());
+    return KK_OK;
+}
 int kk_launch_blk_combine(kk_ctx ctx, double* P, const double* S3, int kn, int nz, int st) {
     hipLaunchKernelGGL(k_blk_combine, dim3(1), dim3(KK_TPB), 0, ctx->stream, P, S3, kn, nz, st);
     KK_HIP(hipGetLastError());
     return KK_OK;
+}
+// Grid of a Gram panel kernel.  A wave keeps 4 KB per 16-column group in flight, so narrow panels need many resident waves
+// to cover the HBM latency (p = 16 at 2 blocks per CU: 3.1 TB/s); every block leaves an NG*256-double partial tile, which
+// bounds the grid from above.
+static void gram_grid(kk_ctx ctx, int64_t ld, int NG, int cap_bpc, int* nblk_out, int64_t* rpb_out) {
+    kk_part pt = kk_partition(ctx, ld);
+    int nblk = pt.nblk;
+    int64_t rpb = pt.rpb;
+    int bpc = ctx->gram_bpc / NG;
+    const int floor_bpc = NG <= 4 ? (ctx->gram_bpc < 4 ? ctx->gram_bpc : 4) : 2;   // NG = 8: 188 VGPRs, two waves per SIMD anyway
+    if (bpc < floor_bpc) bpc = floor_bpc;
+    if (bpc > cap_bpc) bpc = cap_bpc;
+    const int maxb = bpc * ctx->num_cus;
+    if (nblk > maxb) {
+        const int64_t nsub = ld / KK_SUB;
+        const int64_t spb = (nsub + maxb - 1) / maxb;
+        rpb = spb * KK_SUB;
+        nblk = (int)((nsub + spb - 1) / spb);
+    }
+    *nblk_out = nblk;
+    *rpb_out = rpb;
 }
 // C (p x q, strides rs / cs) = X' T with the tile T = beta*Yin + alpha * Z S formed on the fly (k_block_gram_tile);
 // X == nullptr: C = T' T (p = q).  Yout != nullptr: T is also written there.
@@ -601,19 +807,12 @@ int kk_launch_block_gram_tile(kk_ctx ctx, const double* X, int64_t ldx, int p, c
                               int64_t ldyo, int q, int64_t ld, double* C_dev, int rs, int cs) {
     if (p <= 0 || q <= 0) return KK_OK;
     if (p > 128 || q > 16 || nz > 32) { kk_set_error("kk_launch_block_gram_tile: p=%d q=%d nz=%d exceed one launch", p, q, nz); return KK_ERR_INVALID; }
-    kk_part pt = kk_partition(ctx, ld);
-    int nblk = pt.nblk;
-    int64_t rpb = pt.rpb;
-    const int maxb = 2 * ctx->num_cus;
-    if (nblk > maxb) {
-        const int64_t nsub = ld / KK_SUB;
-        const int64_t spb = (nsub + maxb - 1) / maxb;
-        rpb = spb * KK_SUB;
-        nblk = (int)((nsub + spb - 1) / spb);
-    }
     const int ng = (p + 15) / 16;
     int NG = 1;
     while (NG < ng) NG *= 2;
+    int nblk;
+    int64_t rpb;
+    gram_grid(ctx, ld, NG, 6, &nblk, &rpb);   // 24.5 KB of LDS per block
     const size_t shm = ((size_t)NG * 256 + 32 * 16 + 4 * 16 * BGT_LD) * sizeof(double);
     double* part = ctx->partials;
     const bool xt = (X == nullptr), store = (Yout != nullptr), hasy = (Yin != nullptr && beta != 0.0);
@@ -638,7 +837,7 @@ int kk_launch_block_gram_tile(kk_ctx ctx, const double* X, int64_t ldx, int p, c
 #undef GT_ARGS
     }
     KK_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_finalize_gram, dim3((p * q + KK_TPB - 1) / KK_TPB), dim3(KK_TPB), 0, ctx->stream, part, nblk, NG, p, q,
+    hipLaunchKernelGGL(k_finalize_gram, dim3(NG * 16), dim3(KK_TPB), 0, ctx->stream, part, nblk, NG, p, q,
                        C_dev, rs, cs);
     KK_HIP(hipGetLastError());
     return KK_OK;
@@ -648,35 +847,73 @@ int kk_launch_block_gram_rs(kk_ctx ctx, const double* X, int64_t ldx, int p, con
                             double* C_dev, int rs, int cs) {
     if (p <= 0 || q <= 0) return KK_OK;
     if (p > 128 || q > 16) { kk_set_error("kk_launch_block_gram: p=%d q=%d exceed one launch (128 x 16)", p, q); return KK_ERR_INVALID; }
-    kk_part pt = kk_partition(ctx, ld);
-    // cap the grid: every block leaves an NG*256-double partial tile
-    int nblk = pt.nblk;
-    int64_t rpb = pt.rpb;
-    const int maxb = 2 * ctx->num_cus;
-    if (nblk > maxb) {
-        const int64_t nsub = ld / KK_SUB;
-        const int64_t spb = (nsub + maxb - 1) / maxb;
-        rpb = spb * KK_SUB;
-        nblk = (int)((nsub + spb - 1) / spb);
-    }
     const int ng = (p + 15) / 16;
     int NG = 1;
     while (NG < ng) NG *= 2;
+    int nblk;
+    int64_t rpb;
+    gram_grid(ctx, ld, NG, 8, &nblk, &rpb);
     const size_t shm = (size_t)NG * 256 * sizeof(double);
     double* part = ctx->partials;
     {
         kk_prof_scope ps(ctx, "k_block_gram");
         dim3 g(nblk), b(KK_TPB);
-        switch (NG) {
-            case 1: hipLaunchKernelGGL((k_block_gram<1>), g, b, shm, ctx->stream, X, ldx, p, Y, ldy, q, ld, rpb, part, ctx->gram_nt); break;
-            case 2: hipLaunchKernelGGL((k_block_gram<2>), g, b, shm, ctx->stream, X, ldx, p, Y, ldy, q, ld, rpb, part, ctx->gram_nt); break;
-            case 4: hipLaunchKernelGGL((k_block_gram<4>), g, b, shm, ctx->stream, X, ldx, p, Y, ldy, q, ld, rpb, part, ctx->gram_nt); break;
-            default: hipLaunchKernelGGL((k_block_gram<8>), g, b, shm, ctx->stream, X, ldx, p, Y, ldy, q, ld, rpb, part, ctx->gram_nt); break;
+#define BG_ARGS X, ldx, p, Y, ldy, q, ld, rpb, part, ctx->gram_nt
+        if (NG == 1 && X == Y && ldx == ldy && p == q) {
+            hipLaunchKernelGGL((k_block_gram<1, true>), g, b, shm, ctx->stream, BG_ARGS);
+        } else {
+            switch (NG) {
+                case 1: hipLaunchKernelGGL((k_block_gram<1, false>), g, b, shm, ctx->stream, BG_ARGS); break;
+                case 2: hipLaunchKernelGGL((k_block_gram<2, false>), g, b, shm, ctx->stream, BG_ARGS); break;
+                case 4: hipLaunchKernelGGL((k_block_gram<4, false>), g, b, shm, ctx->stream, BG_ARGS); break;
+                default: hipLaunchKernelGGL((k_block_gram<8, false>), g, b, shm, ctx->stream, BG_ARGS); break;
+            }
         }
+#undef BG_ARGS
     }
     KK_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_finalize_gram, dim3((p * q + KK_TPB - 1) / KK_TPB), dim3(KK_TPB), 0, ctx->stream, part, nblk, NG, p, q,
+    hipLaunchKernelGGL(k_finalize_gram, dim3(NG * 16), dim3(KK_TPB), 0, ctx->stream, part, nblk, NG, p, q,
                        C_dev, rs, cs);
+    KK_HIP(hipGetLastError());
+    return KK_OK;
+}
+
+// C = X' Y and C2 = X' Y2 in one pass (both row-major panels: C[i*rs + j], C2[i*rs2 + j])
+int kk_launch_block_gram2(kk_ctx ctx, const double* X, int64_t ldx, int p, const double* Y, int64_t ldy, int q, const double* Y2,
+                          int64_t ldy2, int q2, int64_t ld, double* C_dev, int rs, double* C2_dev, int rs2) {
+    if (p <= 0 || q <= 0 || q2 <= 0) return KK_OK;
+    if (p > 128 || q > 16 || q2 > 16) { kk_set_error("kk_launch_block_gram2: p=%d q=%d q2=%d exceed one launch (128 x 16)", p, q, q2); return KK_ERR_INVALID; }
+    const int ng = (p + 15) / 16;
+    const int NG = ng <= 2 ? ng : (ng <= 4 ? 4 : (ng == 5 ? 5 : 8));
+    int nblk;
+    int64_t rpb;
+    gram_grid(ctx, ld, NG == 5 ? 8 : NG, NG >= 5 ? 2 : 8, &nblk, &rpb);   // NG >= 5: two blocks per CU fit (VGPRs), and the partial tiles double
+    if (2 * (int64_t)nblk * NG * 256 > (int64_t)(2 * KK_MAX_M + 8) * KK_MAX_BLOCKS) { kk_set_error("kk_launch_block_gram2: partial buffer too small"); return KK_ERR_INVALID; }
+    const size_t shm = (size_t)NG * 256 * sizeof(double);
+    double* part = ctx->partials;
+    double* part2 = part + (int64_t)nblk * NG * 256;
+    // ride-along block = a whole group of X?  (same leading dimension, starts on a 16-column boundary of this launch, 16 wide)
+    int gx = -1;
+    if (ldy2 == ldx && q2 == 16 && Y2 >= X) {
+        const int64_t off = Y2 - X;
+        if (off % ldx == 0 && (off / ldx) % 16 == 0 && off / ldx + 16 <= p) gx = (int)(off / ldx / 16);
+    }
+    {
+        kk_prof_scope ps(ctx, "k_block_gram");
+        dim3 g(nblk), b(KK_TPB);
+#define BG2_ARGS X, ldx, p, Y, ldy, q, Y2, ldy2, q2, gx, ld, rpb, part, part2
+        switch (NG) {
+            case 1: hipLaunchKernelGGL((k_block_gram2<1>), g, b, shm, ctx->stream, BG2_ARGS); break;
+            case 2: hipLaunchKernelGGL((k_block_gram2<2>), g, b, shm, ctx->stream, BG2_ARGS); break;
+            case 4: hipLaunchKernelGGL((k_block_gram2<4>), g, b, shm, ctx->stream, BG2_ARGS); break;
+            case 5: hipLaunchKernelGGL((k_block_gram2<5>), g, b, shm, ctx->stream, BG2_ARGS); break;
+            default: hipLaunchKernelGGL((k_block_gram2<8>), g, b, shm, ctx->stream, BG2_ARGS); break;
+        }
+#undef BG2_ARGS
+    }
+    KK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_finalize_gram, dim3(NG * 16), dim3(KK_TPB), 0, ctx->stream, part, nblk, NG, p, q, C_dev, rs, 1);
+    hipLaunchKernelGGL(k_finalize_gram, dim3(NG * 16), dim3(KK_TPB), 0, ctx->stream, part2, nblk, NG, p, q2, C2_dev, rs2, 1);
     KK_HIP(hipGetLastError());
     return KK_OK;
 }

@@ -295,8 +295,10 @@ __global__ __launch_bounds__(KK_TPB) void k_spmv_sellw(const int64_t* __restrict
 }
 
 // SpMM on ELL: Y[:, j] = A X[:, j], j < nb <= NB (apply(f, ::Block), blocklanczos.jl:39): the matrix
-// is streamed once for the whole block instead of once per vector.
-template <int NB>
+// is streamed once for the whole block instead of once per vector.  RPL = rows per lane: 2 (16-byte matrix loads, 512 rows
+// per block) or 1 (every gather instruction of a stencil row run covers 512 contiguous bytes and a block spans 256 rows,
+// which halves the row window -- resident blocks x rows x nb columns -- the XCD's L2 has to hold for the +-nx neighbours).
+template <int NB, int RPL>
 __global__ __launch_bounds__(KK_TPB) void k_spmm_ell(const int32_t* __restrict__ ecol, const double* __restrict__ eval,
                                                      int64_t ell_ld, int width, int64_t nrows,
                                                      const double* __restrict__ X, int64_t ldx, double* __restrict__ Y,
@@ -310,31 +312,51 @@ __global__ __launch_bounds__(KK_TPB) void k_spmm_ell(const int32_t* __restrict__
     for (int cblk = blockIdx.x >> 3; cblk < per; cblk += nbx) {
         const int lb = xcd * per + cblk;
         if (lb >= nb_logical) break;
-        const int64_t row = ((int64_t)lb * KK_TPB + threadIdx.x) * 2;
+        const int64_t row = ((int64_t)lb * KK_TPB + threadIdx.x) * RPL;
         if (row >= nrows) continue;
-        d2 acc[NB];
+        if (RPL == 2) {
+            d2 acc[NB];
 #pragma unroll
-        for (int j = 0; j < NB; ++j) acc[j] = d2{0.0, 0.0};
-        for (int k = 0; k < width; ++k) {
-            const int2 cc = ldi2s(ecol + (int64_t)k * ell_ld + row);
-            const d2 v = ld2s(eval + (int64_t)k * ell_ld + row);
+            for (int j = 0; j < NB; ++j) acc[j] = d2{0.0, 0.0};
+            for (int k = 0; k < width; ++k) {
+                const int2 cc = ldi2s(ecol + (int64_t)k * ell_ld + row);
+                const d2 v = ld2s(eval + (int64_t)k * ell_ld + row);
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    if (j < nb) {
+                        const double x0 = (n_local < 0 || cc.x < n_local) ? X[(int64_t)j * ldx + cc.x] : G[(int64_t)j * ldg + (cc.x - n_local)];
+                        const double x1 = (n_local < 0 || cc.y < n_local) ? X[(int64_t)j * ldx + cc.y] : G[(int64_t)j * ldg + (cc.y - n_local)];
+                        acc[j].x = fma(v.x, x0, acc[j].x);
+                        acc[j].y = fma(v.y, x1, acc[j].y);
+                    }
+                }
+            }
+            const bool last_odd = (row + 1 >= nrows);
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
                 if (j < nb) {
-                    const double x0 = (n_local < 0 || cc.x < n_local) ? X[(int64_t)j * ldx + cc.x] : G[(int64_t)j * ldg + (cc.x - n_local)];
-                    const double x1 = (n_local < 0 || cc.y < n_local) ? X[(int64_t)j * ldx + cc.y] : G[(int64_t)j * ldg + (cc.y - n_local)];
-                    acc[j].x = fma(v.x, x0, acc[j].x);
-                    acc[j].y = fma(v.y, x1, acc[j].y);
+                    if (last_odd) acc[j].y = 0.0;
+                    st2(Y + (int64_t)j * ldy + row, acc[j]);
                 }
             }
-        }
-        const bool last_odd = (row + 1 >= nrows);
+        } else {
+            double acc[NB];
 #pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            if (j < nb) {
-                if (last_odd) acc[j].y = 0.0;
-                st2(Y + (int64_t)j * ldy + row, acc[j]);
+            for (int j = 0; j < NB; ++j) acc[j] = 0.0;
+            for (int k = 0; k < width; ++k) {
+                const int cc = __builtin_nontemporal_load(ecol + (int64_t)k * ell_ld + row);
+                const double v = __builtin_nontemporal_load(eval + (int64_t)k * ell_ld + row);
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    if (j < nb) {
+                        const double x0 = (n_local < 0 || cc < n_local) ? X[(int64_t)j * ldx + cc] : G[(int64_t)j * ldg + (cc - n_local)];
+                        acc[j] = fma(v, x0, acc[j]);
+                    }
+                }
             }
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+                if (j < nb) Y[(int64_t)j * ldy + row] = acc[j];
         }
     }
 }
@@ -424,12 +446,14 @@ int kk_launch_spmm(kk_ctx ctx, const kk_sparse_dev& M, const double* X, int64_t 
         }
         return KK_OK;
     }
-    const int nb_logical = (int)((M.nrows + 2 * KK_TPB - 1) / (2 * KK_TPB));
+    const int rpl = ctx->spmm_rpl == 1 ? 1 : 2;
+    const int nb_logical = (int)((M.nrows + rpl * KK_TPB - 1) / (rpl * KK_TPB));
     const int per = (nb_logical + 7) / 8;
     // Each XCD sweeps a contiguous band of rows; the rows its resident blocks work on at one time are the window whose
     // gathered entries must stay in that XCD's 4 MB L2 for the +-nx neighbours of a stencil to be L2 hits.  With nb
-    // right-hand sides the window holds nb columns: spmm_bpc resident blocks per CU x 32 CUs x 512 rows x nb x 8 bytes
-    // (2 blocks per CU, nb = 16: 4 MB), so the grid is capped instead of filling every slot as the 1-column SpMV does.
+    // right-hand sides the window holds nb columns: spmm_bpc resident blocks per CU x 32 CUs x 256*rpl rows x nb x 8 bytes
+    // (2 blocks per CU, 2 rows per lane, nb = 16: 4 MB), so the grid is capped instead of filling every slot as the
+    // 1-column SpMV does.
     int nbx = std::min(per, KK_MAX_BLOCKS / 8);
     if (ctx->spmm_bpc > 0) nbx = std::min(nbx, std::max(1, ctx->num_cus / 8) * ctx->spmm_bpc);
     dim3 g(nbx * 8), b(KK_TPB);
@@ -446,17 +470,17 @@ int kk_launch_spmm(kk_ctx ctx, const kk_sparse_dev& M, const double* X, int64_t 
         double* y = Y + (int64_t)j0 * ldy;
         const double* gj = G ? G + (int64_t)j0 * ldg : nullptr;
         kk_prof_scope ps(ctx, "k_spmm_ell");
-        if (rem > 8) {
-            const int n = std::min(rem, 16);
-            hipLaunchKernelGGL((k_spmm_ell<16>), g, b, 0, ctx->stream, M.ell_col, M.ell_val, M.ell_ld, M.width, M.nrows, x, ldx, y, ldy, n, nb_logical, nloc, gj, ldg);
-            j0 += n;
-        } else if (rem > 4) {
-            hipLaunchKernelGGL((k_spmm_ell<8>), g, b, 0, ctx->stream, M.ell_col, M.ell_val, M.ell_ld, M.width, M.nrows, x, ldx, y, ldy, rem, nb_logical, nloc, gj, ldg);
-            j0 += rem;
-        } else {
-            hipLaunchKernelGGL((k_spmm_ell<4>), g, b, 0, ctx->stream, M.ell_col, M.ell_val, M.ell_ld, M.width, M.nrows, x, ldx, y, ldy, rem, nb_logical, nloc, gj, ldg);
-            j0 += rem;
-        }
+        const int n = std::min(rem > 8 ? std::min(rem, 16) : rem, ctx->spmm_cols);   // spmm_cols < 16: narrower row window per XCD
+#define SPMM_ARGS M.ell_col, M.ell_val, M.ell_ld, M.width, M.nrows, x, ldx, y, ldy, n, nb_logical, nloc, gj, ldg
+#define SPMM_CASE(NBT) \
+        if (rpl == 1) hipLaunchKernelGGL((k_spmm_ell<NBT, 1>), g, b, 0, ctx->stream, SPMM_ARGS); \
+        else hipLaunchKernelGGL((k_spmm_ell<NBT, 2>), g, b, 0, ctx->stream, SPMM_ARGS);
+        if (n > 8) { SPMM_CASE(16) }
+        else if (n > 4) { SPMM_CASE(8) }
+        else { SPMM_CASE(4) }
+#undef SPMM_CASE
+#undef SPMM_ARGS
+        j0 += n;
     }
     KK_HIP(hipGetLastError());
     return KK_OK;

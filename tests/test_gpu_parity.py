@@ -10,6 +10,8 @@ pytestmark = pytest.mark.gpu
 RTOL = 1e-12
 
 
+BLOCK_FUSE_DEFAULT = 5   # kk_ctx option block_fuse as the library ships it (bit 1: CholQR2 round 2, bit 4: one-pass projection)
+
 def orth_pairs(kk, ko):
     return [
         (kk.ClassicalGramSchmidt(), ko.CGS), (kk.ModifiedGramSchmidt(), ko.MGS),
@@ -665,9 +667,11 @@ def test_blocklanczos_async_step_matches_synchronous(kk, ko, ctx, bs):
     x0 = [rng.random(n) for _ in range(bs)]
     steps = 5 if bs < 16 else 4
     Hs = {}
-    for mode in (1, 2, 0):   # 1: asynchronous + tile-fused Gram kernels, 2: asynchronous with separate kernels, 0: synchronous
+    # 1: asynchronous + tile-fused Gram kernels, 2: asynchronous with separate kernels, 3: asynchronous one-pass projection
+    # (+ fused CholQR2 round), 0: synchronous
+    for mode in (1, 2, 3, 0):
         ctx.set_option("block_async", 1 if mode else 0)
-        ctx.set_option("block_fuse", 3 if mode == 1 else 0)
+        ctx.set_option("block_fuse", {1: 3, 2: 0, 3: 5, 0: 0}[mode])
         it = kk.BlockLanczosIterator(kk.SparseOperator(A, ctx, symmetric=True), x0, (steps + 1) * bs + bs)
         f = it.initialize()
         for _ in range(steps):
@@ -683,14 +687,43 @@ def test_blocklanczos_async_step_matches_synchronous(kk, ko, ctx, bs):
         assert abs(f.normres - np.linalg.norm(R)) < 1e-11 and np.max(np.abs(V.T @ R)) < 1e-11
         Hs[mode] = H.copy()
     ctx.set_option("block_async", 1)
-    ctx.set_option("block_fuse", 1)
+    ctx.set_option("block_fuse", BLOCK_FUSE_DEFAULT)
     np.testing.assert_allclose(Hs[1], Hs[0], atol=1e-10)
     np.testing.assert_allclose(Hs[2], Hs[0], atol=1e-10)
+    np.testing.assert_allclose(Hs[3], Hs[0], atol=1e-10)
     oit = ko.BlockLanczosIterator(A, [x.copy() for x in x0], (steps + 1) * bs + bs)
     of = ko.blocklanczos_initialize(oit)
     for _ in range(steps):
         of = ko.blocklanczos_expand(oit, of)
     np.testing.assert_allclose(np.linalg.eigvalsh(Hs[1]), np.linalg.eigvalsh(of.H[:k, :k]), atol=1e-9)
+
+
+def test_blocklanczos_one_pass_step_repeats_on_cancellation(kk, ko, ctx):
+    """The one-pass block step projects A X against the whole basis once; when a column loses more than a factor 10 of its
+    norm in that projection (A close to a multiple of the identity: |w_j| << |A x_j|) the device flag sends the step to the
+    two-pass route of the reference (three-term recurrence, then block_reorthogonalize!, blocklanczos.jl:253-284)."""
+    nx, ny, bs = 30, 20, 4
+    n = nx * ny
+    A = (ko.laplacian_2d(nx, ny) + 1000.0 * sp.identity(n)).tocsr()
+    rng = np.random.default_rng(11)
+    x0 = [rng.random(n) for _ in range(bs)]
+    ctx.set_option("block_async", 1)
+    ctx.set_option("block_fuse", 5)
+    it = kk.BlockLanczosIterator(kk.SparseOperator(A, ctx, symmetric=True), x0, 6 * bs)
+    oit = ko.BlockLanczosIterator(A, [x.copy() for x in x0], 6 * bs)
+    f, of = it.initialize(), ko.blocklanczos_initialize(oit)
+    ctx.prof_reset(); ctx.prof_enable(1)
+    for _ in range(3):
+        f = it.expand(f)
+        of = ko.blocklanczos_expand(oit, of)
+    ctx.prof_enable(0)
+    assert ctx.prof_get("k_spmm_ell")[1] == 6, "every step must have been repeated on the two-pass route"
+    ctx.set_option("block_fuse", BLOCK_FUSE_DEFAULT)
+    k = len(f)
+    V = f.V.to_numpy()
+    assert np.max(np.abs(V.T @ V - np.eye(k))) < 1e-12
+    np.testing.assert_allclose(np.linalg.eigvalsh(f.H[:k, :k]), np.linalg.eigvalsh(of.H[:k, :k]), rtol=1e-12)
+    assert abs(f.normres - of.normres) < 1e-9 * max(1.0, of.normres)
 
 
 def test_blocklanczos_async_step_hands_rank_drop_to_faithful_route(kk, ko, ctx):

@@ -1,6 +1,7 @@
 """Secondary measurements for BASELINE.json configs 3-5 on one MI355X (the judged bench line is
 bench.py = config 2).  usage: python tools/bench_configs.py [gmres] [gkl] [block] [--full]"""
 import json
+import os
 import sys
 import time
 from pathlib import Path
@@ -129,7 +130,7 @@ def bench_block(ctx):
     op = kk.SparseOperator(A, ctx, symmetric=True)
     rng = np.random.default_rng(7)
     x0 = [rng.random(N) for _ in range(bs)]
-    for mode in (1, 0):
+    for mode in [int(m_) for m_ in os.environ.get("KK_BENCH_BLOCK_MODES", "1,0").split(",")]:
         ctx.set_option("block_mode", mode)
         it = kk.BlockLanczosIterator(op, x0, K + bs)
         V = None

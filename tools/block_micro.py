@@ -38,7 +38,8 @@ def timeit(fn, reps=5):
 
 
 out = []
-for opts in (dict(bu_prefetch=0),):
+ONLY_SPMM = "--spmm" in sys.argv
+for opts in (() if ONLY_SPMM else (dict(bu_prefetch=0),)):
     for k_, v in opts.items():
         ctx.set_option(k_, v)
     for m in (16, 112):
@@ -52,22 +53,26 @@ for opts in (dict(bu_prefetch=0),):
             print(json.dumps(out[-1]), flush=True)
 ctx.set_option("bu_prefetch", 1)
 M = np.zeros((128, bs), order="F")
-for nt in (0, 1):
-    ctx.set_option("gram_nt", nt)
-    for p, same in ((16, True), (16, False), (64, False), (112, False)):
+ctx.set_option("gram_nt", 0)
+for bpc in (() if ONLY_SPMM else (2, 8)):
+    ctx.set_option("gram_bpc", bpc)
+    for p, same in ((16, True), (16, False), (32, False), (64, False), (112, False)):
         cy = 0 if same else 130
         def g():
             check(lib.kk_block_inner(S.handle, 0, p, S.handle, cy, bs, M.ctypes.data_as(c_dp), 128))
         dt = timeit(g)
         byts = (8 * p + (0 if same else 128)) * N
-        out.append({"kernel": "k_block_gram", "gram_nt": nt, "p": p, "X_is_Y": same, "ms": round(dt * 1e3, 3), "TBps": round(byts / dt / 1e12, 2)})
+        out.append({"kernel": "k_block_gram", "gram_bpc": bpc, "p": p, "X_is_Y": same, "ms": round(dt * 1e3, 3), "TBps": round(byts / dt / 1e12, 2)})
         print(json.dumps(out[-1]), flush=True)
-for bpc in (0, 2, 4, 8):
-    ctx.set_option("spmm_bpc", bpc)
-    def h():
-        check(lib.kk_block_apply(op.handle, S.handle, 0, S.handle, 130, bs))
-    dt = timeit(h)
-    byts = (12 * 5 + 4 + 256) * N
-    out.append({"kernel": "k_spmm_ell", "spmm_bpc": bpc, "ms": round(dt * 1e3, 3), "TBps": round(byts / dt / 1e12, 2)})
-    print(json.dumps(out[-1]), flush=True)
-ctx.set_option("spmm_bpc", 4)
+ctx.set_option("gram_bpc", 8)
+for cols in (16, 8, 4):
+    ctx.set_option("spmm_cols", cols)
+    for bpc in (0, 2, 4, 8):
+        ctx.set_option("spmm_bpc", bpc)
+        def h():
+            check(lib.kk_block_apply(op.handle, S.handle, 0, S.handle, 130, bs))
+        dt = timeit(h)
+        byts = (12 * 5 + 4 + 256) * N
+        out.append({"kernel": "k_spmm_ell", "spmm_cols": cols, "spmm_bpc": bpc, "ms": round(dt * 1e3, 3), "TBps": round(byts / dt / 1e12, 2)})
+        print(json.dumps(out[-1]), flush=True)
+ctx.set_option("spmm_bpc", 4); ctx.set_option("spmm_cols", 16)

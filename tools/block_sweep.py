@@ -38,10 +38,11 @@ def run():
     return time.perf_counter() - t0, steps, alg, f
 
 
-variants = [("async, separate kernels", dict(block_fuse=0)),
-            ("async, fused CholQR2 round 2", dict(block_fuse=1)),
-            ("async, fused three-term + panel", dict(block_fuse=2)),
-            ("async, both fused", dict(block_fuse=3))]
+variants = [("two-pass (three-term, then panel), fused CholQR2 round 2", dict(block_fuse=1, gram_bpc=8, spmm_bpc=4)),
+            ("one-pass projection with Gram correction, 80 columns per panel launch", dict(block_fuse=5, gram2_chunk=80)),
+            ("one-pass projection with Gram correction, 64 columns per panel launch", dict(block_fuse=5, gram2_chunk=64)),
+            ("one-pass projection with Gram correction, 128 columns per panel launch", dict(block_fuse=5, gram2_chunk=128)),
+            ("one-pass, 80 columns, spmm grid uncapped", dict(block_fuse=5, gram2_chunk=80, spmm_bpc=0))]
 for name, opts in variants:
     for k_, v in opts.items():
         ctx.set_option(k_, v)
@@ -56,4 +57,4 @@ for name, opts in variants:
     prof = {k_: round(ctx.prof_get(k_)[0], 2) for k_ in ("k_block_gram", "k_block_update", "k_spmm_ell", "k_block_qr_fused") if ctx.prof_get(k_)[1]}
     print(json.dumps({"variant": name, "ms_per_block_step": round(best / steps * 1e3, 3), "frac_8TBps": round(alg / best / 8e12, 4),
                       "normres": f.normres, "kernel_ms_one_run": prof}), flush=True)
-ctx.set_option("block_fuse", 1); ctx.set_option("spmm_bpc", 4)
+ctx.set_option("block_fuse", 5); ctx.set_option("spmm_bpc", 4)

@@ -27,6 +27,7 @@ for step in "$@"; do
     blockmicro) timeout 900 python tools/block_micro.py > $OUT/block_micro.jsonl 2> $OUT/block_micro.err; echo "blockmicro rc=$?"; cat $OUT/block_micro.jsonl; tail -3 $OUT/block_micro.err ;;
     advice)   timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "front_end or wide_basis" > $OUT/t_advice.log 2>&1; echo "advice rc=$?" ;;
     cfg4pmc)  bash tools/profile_cfg4.sh $TAG > $OUT/cfg4pmc.log 2>&1; echo "cfg4pmc rc=$?"; tail -40 $OUT/cfg4pmc.log ;;
+    cfg5pmc)  bash tools/profile_block.sh $TAG > $OUT/cfg5pmc.log 2>&1; echo "cfg5pmc rc=$?"; tail -60 $OUT/cfg5pmc.log ;;
     prof)     bash tools/profile_gpu.sh $TAG > $OUT/prof.log 2>&1; echo "prof rc=$?"; tail -5 $OUT/prof.log ;;
     *) echo "unknown step $step" ;;
   esac
