@@ -168,6 +168,11 @@ KK_API int kk_ctx_set_option(kk_ctx c, const char* key, double value) {
         c->persist_nt = value != 0;
     } else if (!strcmp(key, "gram_nt")) {
         c->gram_nt = value != 0;
+    } else if (!strcmp(key, "spmm_dia")) {
+        c->spmm_dia = value != 0;
+    } else if (!strcmp(key, "spmm_dia_lines")) {
+        KK_CHECK(value >= 2 && value <= 4096, KK_ERR_INVALID, "spmm_dia_lines must be in 2..4096");
+        c->spmm_dia_lines = (int)value;
     } else if (!strcmp(key, "spmm_cols")) {
         KK_CHECK(value == 4 || value == 8 || value == 16, KK_ERR_INVALID, "spmm_cols must be 4, 8 or 16");
         c->spmm_cols = (int)value;

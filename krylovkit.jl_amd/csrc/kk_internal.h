@@ -113,6 +113,8 @@ struct kk_ctx_s {
     int block_mode = 1;          // 0 strict, 1 panel (MFMA gram + multi-rhs update)
     int spmm_bpc = 4;            // resident blocks per CU of the multi-column sparse apply (L2 window, see kk_launch_spmm); 0 = fill the chip
     int spmm_rpl = 2;            // SpMM on ELL: rows per lane (1 or 2)
+    int spmm_dia = 1;            // multi-column apply of a detected grid stencil: sweeping diagonal kernel (0: ELL gather kernel)
+    int spmm_dia_lines = 16;     // ... grid lines per wave sweep
     int spmm_cols = 16;          // SpMM on ELL: right-hand sides per launch (16, 8 or 4)
     int bu_prefetch = 1;         // block update kernel: 1 = coefficient panel in LDS (default), 0 = scalar-load kernel of round 1, 8/16/24 = deep-prefetch experiments
     int gram_nt = 0;             // Gram panel: non-temporal loads for the X stream
@@ -173,6 +175,13 @@ struct kk_sparse_dev {  // one direction (A or A') on the device
     int64_t ell_ld = 0;
     int32_t* ell_col = nullptr;
     double* ell_val = nullptr;
+    // 2-D stencil diagonals next to the ELL arrays (square operators whose column offsets are a subset of
+    // {-D, 0, +D} + {-1, 0, +1}: 5-point / 9-point grids): dense diagonals dia_val[slot * dia_ld + row], zero where the
+    // matrix has no entry; slots ordered by offset.  Feeds the sweeping multi-column apply (k_spmm_dia).
+    int64_t dia_D = 0;             // far offset (grid line length); 0 = no stencil structure detected
+    int dia_pts = 0;               // 5 or 9 stored diagonals
+    int64_t dia_ld = 0;
+    double* dia_val = nullptr;
     // CSR
     int32_t* rowptr = nullptr;
     int32_t* colind = nullptr;

@@ -6,7 +6,7 @@
 // operators
 // ------------------------------------------------------------------------------------------
 static void free_sparse(kk_sparse_dev& M) {
-    (void)hipFree(M.ell_col); (void)hipFree(M.ell_val);
+    (void)hipFree(M.ell_col); (void)hipFree(M.ell_val); (void)hipFree(M.dia_val);
     (void)hipFree(M.rowptr); (void)hipFree(M.colind); (void)hipFree(M.val);
     (void)hipFree(M.sell_off); (void)hipFree(M.sell_perm); (void)hipFree(M.sell_col); (void)hipFree(M.sell_val);
     for (int t = 0; t < M.ntiles; ++t) free_sparse(M.tiles[t]);
@@ -133,6 +133,69 @@ static double mean_row_span(const kk_host_csr& h) {
     return cnt ? sum / cnt : 0.0;
 }
 
+// Grid-stencil structure of a square operator: every column offset col - row lies in {-D, 0, +D} + {-1, 0, +1} with one far
+// offset D >= 64 (5-point / 9-point discretisations on an nx x ny grid in natural ordering, D = nx; the coefficients may vary
+// from row to row).  Such an operator gets dense diagonals next to its ELL arrays; the multi-column apply then sweeps the grid
+// lines with a three-line register window instead of gathering (k_spmm_dia).  Returns quietly when the structure is absent.
+static int detect_stencil(const kk_host_csr& h, kk_sparse_dev& M) {
+    M.dia_D = 0;
+    if (getenv("KK_NO_DIA")) return KK_OK;
+    const int64_t n = h.nrows, nnz = h.rowptr[n];
+    if (n != h.ncols || n < 4096 || nnz < n) return KK_OK;
+    int64_t offs[9];
+    int no = 0;
+    for (int64_t i = 0; i < n; ++i)
+        for (int64_t p = h.rowptr[i]; p < h.rowptr[i + 1]; ++p) {
+            const int64_t o = (int64_t)h.col[p] - i;
+            bool seen = false;
+            for (int q = 0; q < no; ++q) seen |= (offs[q] == o);
+            if (!seen) {
+                if (no == 9) return KK_OK;
+                offs[no++] = o;
+            }
+        }
+    int64_t amax = 0;
+    for (int q = 0; q < no; ++q) amax = std::max<int64_t>(amax, offs[q] < 0 ? -offs[q] : offs[q]);
+    auto fits = [&](int64_t Dc) {   // every offset = a * Dc + s with a, s in {-1, 0, 1}
+        for (int q = 0; q < no; ++q) {
+            const int64_t a = offs[q] < 0 ? -offs[q] : offs[q];
+            if (!(a <= 1 || (a >= Dc - 1 && a <= Dc + 1))) return false;
+        }
+        return true;
+    };
+    int64_t D = 0;
+    if (amax >= 64 && fits(amax)) D = amax;
+    else if (amax - 1 >= 64 && fits(amax - 1)) D = amax - 1;
+    else return KK_OK;
+    bool corner = false;
+    for (int q = 0; q < no; ++q) {
+        const int64_t a = offs[q] < 0 ? -offs[q] : offs[q];
+        if (a == D - 1 || a == D + 1) corner = true;
+    }
+    if (D < 64 || D >= n) return KK_OK;
+    const int pts = corner ? 9 : 5;
+    if ((double)pts * n > 1.6 * (double)nnz + 4096) return KK_OK;   // diagonals mostly empty: the gather format is denser
+    const int64_t dld = (n + 63) / 64 * 64;
+    std::vector<double> dv((size_t)pts * dld, 0.0);
+    for (int64_t i = 0; i < n; ++i)
+        for (int64_t p = h.rowptr[i]; p < h.rowptr[i + 1]; ++p) {
+            const int64_t o = (int64_t)h.col[p] - i;
+            int slot;
+            if (pts == 5) slot = o == -D ? 0 : (o == -1 ? 1 : (o == 0 ? 2 : (o == 1 ? 3 : 4)));
+            else {
+                const int a = o < -1 ? 0 : (o > 1 ? 2 : 1);                  // line -1 / 0 / +1
+                const int64_t sft = o - (int64_t)(a - 1) * D;                // -1 / 0 / +1 inside the line
+                slot = a * 3 + (int)(sft + 1);
+            }
+            dv[(size_t)slot * dld + i] += h.val[p];   // duplicate entries of a row add up, as in the CSR apply
+        }
+    KK_HIP(hipMalloc(&M.dia_val, dv.size() * sizeof(double)));
+    KK_HIP(hipMemcpy(M.dia_val, dv.data(), dv.size() * sizeof(double), hipMemcpyHostToDevice));
+    M.dia_D = D; M.dia_pts = pts; M.dia_ld = dld;
+    M.bytes += (int64_t)dv.size() * 8;
+    return KK_OK;
+}
+
 static int upload_sparse(kk_ctx c, const kk_host_csr& h, kk_sparse_dev& M) {
     const int64_t nrows = h.nrows, nnz = h.rowptr[nrows];
     M.nrows = nrows; M.ncols = h.ncols; M.nnz = nnz;
@@ -169,6 +232,7 @@ static int upload_sparse(kk_ctx c, const kk_host_csr& h, kk_sparse_dev& M) {
         KK_HIP(hipMemcpy(M.ell_col, ec.data(), ec.size() * sizeof(int32_t), hipMemcpyHostToDevice));
         KK_HIP(hipMemcpy(M.ell_val, ev.data(), ev.size() * sizeof(double), hipMemcpyHostToDevice));
         M.bytes = ec.size() * 4 + ev.size() * 8;
+        KK_TRY(detect_stencil(h, M));
     } else if (!force_csr) {
         KK_TRY(build_sell(h, M));
     } else {

@@ -624,6 +624,64 @@ def test_block_apply_update(kk, ko, ctx, block_mode):
     ctx.set_option("block_mode", 1)
 
 
+def _grid_stencil(nx, ny, nine, rng, drop_tail=0):
+    """5- or 9-point operator with row-dependent coefficients on an nx x ny grid in natural ordering (offsets
+    {-nx, 0, nx} + {-1, 0, 1}); `drop_tail` removes the last rows / columns so n is not a multiple of nx."""
+    n = nx * ny
+    rows, cols, vals = [], [], []
+    shifts = [(-1, 0), (0, -1), (0, 0), (0, 1), (1, 0)] + ([(-1, -1), (-1, 1), (1, -1), (1, 1)] if nine else [])
+    ix, iy = np.meshgrid(np.arange(nx), np.arange(ny))
+    ix, iy = ix.ravel(), iy.ravel()
+    for dy, dx in shifts:
+        ok = (ix + dx >= 0) & (ix + dx < nx) & (iy + dy >= 0) & (iy + dy < ny)
+        r = (iy * nx + ix)[ok]
+        rows.append(r); cols.append(r + dy * nx + dx); vals.append(rng.standard_normal(r.size))
+    A = sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(n, n))
+    if drop_tail:
+        A = A[:n - drop_tail, :n - drop_tail].tocsr()
+    return A
+
+
+@pytest.mark.parametrize("nine", [False, True])
+def test_block_apply_grid_stencil_sweep(kk, ko, ctx, nine):
+    """apply(f, ::Block) on grid stencils goes through the sweeping diagonal kernel (k_spmm_dia: three-line register window,
+    +-1 neighbours by wave shifts) -- against SciPy and against the gather kernel, for line lengths around the 62-position
+    strip, block widths 2..16 and a truncated last line (coefficients are random, i.e. non-symmetric operators)."""
+    from krylovkit_hip._lib import check
+    rng = np.random.default_rng(17 + nine)
+    for nx, ny, drop in ((64, 70, 0), (125, 40, 0), (187, 30, 11), (66, 80, 0), (124, 40, 0), (300, 20, 299)):
+        A = _grid_stencil(nx, ny, nine, rng, drop)
+        n = A.shape[0]
+        op = kk.SparseOperator(A, ctx)
+        for nb in (2, 3, 5, 8, 13, 16):
+            X = rng.standard_normal((n, nb))
+            S = kk.DeviceBasis(n, 2 * nb, ctx)
+            for j in range(nb):
+                S.upload(j, X[:, j])
+            for dia in (1, 0):
+                ctx.set_option("spmm_dia", dia)
+                ctx.prof_reset(); ctx.prof_enable(1)
+                check(S._lib.kk_block_apply(op.handle, S.handle, 0, S.handle, nb, nb))
+                ctx.prof_enable(0)
+                Y = np.stack([S.download(nb + j) for j in range(nb)], 1)
+                np.testing.assert_allclose(Y, A @ X, rtol=1e-12, atol=1e-12, err_msg=f"nx={nx} nb={nb} dia={dia}")
+                assert (ctx.prof_get("k_spmm_dia")[1] > 0) == bool(dia), "the sweeping kernel must be the one that ran"
+            ctx.set_option("spmm_dia", 1)
+            S.free()
+    # no stencil structure -> gather kernel, silently
+    R = ko.sparse_random(5000, 5000, 7, 5)
+    op = kk.SparseOperator(R, ctx)
+    S = kk.DeviceBasis(5000, 8, ctx)
+    X = rng.standard_normal((5000, 4))
+    for j in range(4):
+        S.upload(j, X[:, j])
+    ctx.prof_reset(); ctx.prof_enable(1)
+    check(S._lib.kk_block_apply(op.handle, S.handle, 0, S.handle, 4, 4))
+    ctx.prof_enable(0)
+    assert ctx.prof_get("k_spmm_dia")[1] == 0
+    np.testing.assert_allclose(np.stack([S.download(4 + j) for j in range(4)], 1), R @ X, rtol=1e-12, atol=1e-12)
+
+
 @pytest.mark.parametrize("block_mode", [0, 1])
 def test_blocklanczos_factorization(kk, ko, ctx, block_mode):
     """test/factorize.jl:387-401: V'V = I, A V = V H + R B' after every expand!; parity of H with the oracle."""

@@ -144,7 +144,7 @@ def bench_block(ctx):
                 alg += (1856 + 16 * len(f)) * N
             ctx.sync(); best = min(best, time.perf_counter() - t0)
             ctx.prof_enable(False)
-        prof = {k: round(ctx.prof_get(k)[0], 2) for k in ("k_block_gram", "k_block_update", "k_spmm_ell", "k_mgs_step", "k_dot", "k_axpby", "k_scal")}
+        prof = {k: round(ctx.prof_get(k)[0], 2) for k in ("k_block_gram", "k_block_update", "k_spmm_ell", "k_spmm_dia", "k_mgs_step", "k_dot", "k_axpby", "k_scal")}
         print(json.dumps({"config": f"5: BlockLanczos bs={bs} N=1e7 krylovdim={K}, block_mode={mode}", "block_steps": steps,
                           "seconds": round(best, 4), "ms_per_block_step": round(best / steps * 1e3, 2),
                           "alg_GBps": round(alg / best / 1e9, 1), "frac_8TBps": round(alg / best / 8e12, 4),

@@ -38,11 +38,14 @@ def run():
     return time.perf_counter() - t0, steps, alg, f
 
 
-variants = [("two-pass (three-term, then panel), fused CholQR2 round 2", dict(block_fuse=1, gram_bpc=8, spmm_bpc=4)),
-            ("one-pass projection with Gram correction, 80 columns per panel launch", dict(block_fuse=5, gram2_chunk=80)),
-            ("one-pass projection with Gram correction, 64 columns per panel launch", dict(block_fuse=5, gram2_chunk=64)),
-            ("one-pass projection with Gram correction, 128 columns per panel launch", dict(block_fuse=5, gram2_chunk=128)),
-            ("one-pass, 80 columns, spmm grid uncapped", dict(block_fuse=5, gram2_chunk=80, spmm_bpc=0))]
+variants = [("two-pass (three-term, then panel), gather SpMM", dict(block_fuse=1, spmm_dia=0)),
+            ("one-pass projection with Gram correction, gather SpMM", dict(block_fuse=5, spmm_dia=0)),
+            ("one-pass projection with Gram correction, sweeping SpMM, 16 lines per sweep (shipped)", dict(block_fuse=5, spmm_dia=1, spmm_dia_lines=16)),
+            ("shipped, 8 grid lines per wave sweep", dict(spmm_dia_lines=8)),
+            ("shipped, 12 grid lines per wave sweep", dict(spmm_dia_lines=12)),
+            ("shipped, 24 grid lines per wave sweep", dict(spmm_dia_lines=24)),
+            ("shipped, 16 lines, 8 columns per launch", dict(spmm_dia_lines=16, spmm_cols=8)),
+            ("shipped, 32 lines, 8 columns per launch", dict(spmm_dia_lines=32, spmm_cols=8))]
 for name, opts in variants:
     for k_, v in opts.items():
         ctx.set_option(k_, v)
@@ -54,7 +57,7 @@ for name, opts in variants:
     ctx.prof_reset(); ctx.prof_enable(1)
     run()
     ctx.prof_enable(0)
-    prof = {k_: round(ctx.prof_get(k_)[0], 2) for k_ in ("k_block_gram", "k_block_update", "k_spmm_ell", "k_block_qr_fused") if ctx.prof_get(k_)[1]}
+    prof = {k_: round(ctx.prof_get(k_)[0], 2) for k_ in ("k_block_gram", "k_block_update", "k_spmm_ell", "k_spmm_dia", "k_block_qr_fused") if ctx.prof_get(k_)[1]}
     print(json.dumps({"variant": name, "ms_per_block_step": round(best / steps * 1e3, 3), "frac_8TBps": round(alg / best / 8e12, 4),
                       "normres": f.normres, "kernel_ms_one_run": prof}), flush=True)
-ctx.set_option("block_fuse", 5); ctx.set_option("spmm_bpc", 4)
+ctx.set_option("block_fuse", 5); ctx.set_option("spmm_dia_lines", 16); ctx.set_option("spmm_cols", 16)
