@@ -168,6 +168,8 @@ KK_API int kk_ctx_set_option(kk_ctx c, const char* key, double value) {
         c->persist_nt = value != 0;
     } else if (!strcmp(key, "gram_nt")) {
         c->gram_nt = value != 0;
+    } else if (!strcmp(key, "spmv_dia")) {
+        c->spmv_dia = value != 0;
     } else if (!strcmp(key, "spmm_dia")) {
         c->spmm_dia = value != 0;
     } else if (!strcmp(key, "spmm_dia_lines")) {

@@ -113,6 +113,7 @@ struct kk_ctx_s {
     int block_mode = 1;          // 0 strict, 1 panel (MFMA gram + multi-rhs update)
     int spmm_bpc = 4;            // resident blocks per CU of the multi-column sparse apply (L2 window, see kk_launch_spmm); 0 = fill the chip
     int spmm_rpl = 2;            // SpMM on ELL: rows per lane (1 or 2)
+    int spmv_dia = 1;            // single-column apply of a detected grid stencil: diagonal kernel (0: ELL gather kernel)
     int spmm_dia = 1;            // multi-column apply of a detected grid stencil: sweeping diagonal kernel (0: ELL gather kernel)
     int spmm_dia_lines = 16;     // ... grid lines per wave sweep
     int spmm_cols = 16;          // SpMM on ELL: right-hand sides per launch (16, 8 or 4)
@@ -128,7 +129,7 @@ struct kk_ctx_s {
     int keep_mb = 160;           // MB of trailing basis columns a project pass leaves cache-allocated for the unproject
                                  // pass that follows (the Infinity Cache holds 256 MB); 0 = all loads non-temporal
     int mgs_persist = 1;         // strict MGS sweeps through the persistent register-resident kernel when the vector fits
-    int persist_threads = 1024;  // threads per block (= per CU) of that kernel: 1024 (<= 40 doubles of w per thread) or 512 (<= 80)
+    int persist_threads = 512;   // threads per block (= per CU) of that kernel: 1024 (<= 40 doubles of w per thread) or 512 (<= 80)
     int persist_nt = 1;          // second read of a basis vector (served by the Infinity Cache) with non-temporal loads
     void* d_sync = nullptr;      // device: hand-off granules + error flag of the in-kernel grid reduction (KK_SYNC_BYTES)
     int* h_sync = nullptr;       // pinned: read-back of the error flag

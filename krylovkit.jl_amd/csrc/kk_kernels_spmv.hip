@@ -105,6 +105,70 @@ __global__ __launch_bounds__(KK_TPB) void k_spmv_ell(const int32_t* __restrict__
     }
 }
 
+// SpMV on the dense diagonals of a grid stencil (kk_sparse_dev::dia_*): no column indices (40 instead of 60 matrix bytes per
+// row for a 5-point operator), the neighbours are shifted contiguous loads instead of gathers; same XCD banding, same fused
+// epilogue as k_spmv_ell.
+struct dia_offs { int64_t o[9]; };
+__device__ __forceinline__ d2 dia_pair(const double* __restrict__ x, int64_t idx, int64_t nrows) {
+    if (!(idx & 1) && idx >= 0 && idx + 1 < nrows) return ld2(x + idx);   // idx parity is uniform over the grid (row is even)
+    d2 v;
+    v.x = (idx >= 0 && idx < nrows) ? x[idx] : 0.0;
+    v.y = (idx + 1 >= 0 && idx + 1 < nrows) ? x[idx + 1] : 0.0;
+    return v;
+}
+template <int PTS>
+__global__ __launch_bounds__(KK_TPB) void k_spmv_dia(const double* __restrict__ dval, int64_t dld, dia_offs offs, int64_t nrows,
+                                                     const double* __restrict__ x, double* __restrict__ y, spmv_epi e,
+                                                     int nb_logical, double* __restrict__ part_dot,
+                                                     double* __restrict__ part_nrm) {
+    __shared__ double sm[4];
+    const int per = (nb_logical + 7) >> 3;
+    const int nbx = gridDim.x >> 3;
+    const int xcd = blockIdx.x & 7;
+    double dacc = 0, nacc = 0;
+    const double xs = e.xs_dev ? *e.xs_dev : 1.0;
+    const double bp = e.vprev ? (e.bprev_dev ? *e.bprev_dev : e.bprev) : 0.0;
+    for (int c = blockIdx.x >> 3; c < per; c += nbx) {
+        const int lb = xcd * per + c;
+        if (lb >= nb_logical) break;
+        const int64_t row = ((int64_t)lb * KK_TPB + threadIdx.x) * 2;
+        if (row < nrows) {  // dia_ld is even and >= nrows; pad entries are 0
+            double s0 = 0, s1 = 0;
+            d2 xc{0.0, 0.0};
+#pragma unroll
+            for (int q = 0; q < PTS; ++q) {
+                const d2 v = ld2s(dval + (int64_t)q * dld + row);
+                const d2 xv = dia_pair(x, row + offs.o[q], nrows);
+                if (q == PTS / 2) xc = xv;                 // the middle slot is the main diagonal
+                s0 = fma(v.x, xv.x, s0);
+                s1 = fma(v.y, xv.y, s1);
+            }
+            s0 *= xs; s1 *= xs;
+            d2 out{e.a1 * s0, e.a1 * s1};
+            d2 xv{xc.x * xs, xc.y * xs};
+            if (e.a0 != 0.0) { out.x = fma(e.a0, xv.x, out.x); out.y = fma(e.a0, xv.y, out.y); }
+            if (e.dot_mode == 1) { dacc = fma(xv.x, out.x, dacc); dacc = fma(xv.y, out.y, dacc); }
+            if (e.vprev) {
+                const d2 p = ld2(e.vprev + row);
+                out.x = fma(-bp, p.x, out.x); out.y = fma(-bp, p.y, out.y);
+            }
+            if (row + 1 >= nrows) out.y = 0.0;  // odd nrows: keep the pad row zero
+            if (e.dot_mode == 2) { dacc = fma(xv.x, out.x, dacc); dacc = fma(xv.y, out.y, dacc); }
+            if (e.dot_mode == 3) { const d2 z = ld2(e.dvec + row); dacc = fma(z.x, out.x, dacc); dacc = fma(z.y, out.y, dacc); }
+            if (e.want_nrm) { nacc = fma(out.x, out.x, nacc); nacc = fma(out.y, out.y, nacc); }
+            st2(y + row, out);
+        }
+    }
+    if (e.dot_mode) {
+        double t = block_sum(dacc, sm);
+        if (threadIdx.x == 0) part_dot[blockIdx.x] = t;
+    }
+    if (e.want_nrm) {
+        double t = block_sum(nacc, sm);
+        if (threadIdx.x == 0) part_nrm[blockIdx.x] = t;
+    }
+}
+
 template <int L>
 __global__ __launch_bounds__(KK_TPB) void k_spmv_csr(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind,
                                                      const double* __restrict__ val, int64_t nrows,
@@ -457,7 +521,8 @@ int kk_launch_spmv(kk_ctx ctx, const kk_sparse_dev& M, const double* x, double* 
     double* pd = part_row(ctx, PART_SCAL_A);
     double* pn = part_row(ctx, PART_SCAL_B);
     int nblk = 0;
-    std::unique_ptr<kk_prof_scope> ps(new kk_prof_scope(ctx, M.format == 0 ? "k_spmv_ell" : (M.format >= 2 ? "k_spmv_sell" : "k_spmv_csr")));
+    const bool use_dia = M.format == 0 && M.dia_D > 0 && ctx->spmv_dia && M.n_ghost == 0;
+    std::unique_ptr<kk_prof_scope> ps(new kk_prof_scope(ctx, use_dia ? "k_spmv_dia" : (M.format == 0 ? "k_spmv_ell" : (M.format >= 2 ? "k_spmv_sell" : "k_spmv_csr"))));
     if (M.format == 2) {
         nblk = (int)std::min<int64_t>((M.sell_nchunks + 3) / 4, (int64_t)ctx->num_cus * 16);
         if (nblk < 1) nblk = 1;
@@ -477,6 +542,19 @@ int kk_launch_spmv(kk_ctx ctx, const kk_sparse_dev& M, const double* x, double* 
             hipLaunchKernelGGL(k_spmv_sellw, dim3(nblk), dim3(KK_TPB), 0, ctx->stream, S.sell_off, S.sell_perm, S.sell_col, S.sell_val,
                                S.sell_nchunks, S.nrows, x, y, et, pd, pn);
         }
+    } else if (use_dia) {
+        const int nb_logical = (int)((M.nrows + 2 * KK_TPB - 1) / (2 * KK_TPB));
+        const int per = (nb_logical + 7) / 8;
+        const int nbx = std::min(per, KK_MAX_BLOCKS / 8);
+        nblk = nbx * 8;
+        dia_offs of;
+        const int64_t D = M.dia_D;
+        if (M.dia_pts == 5) { const int64_t o5[5] = {-D, -1, 0, 1, D}; for (int q = 0; q < 5; ++q) of.o[q] = o5[q]; for (int q = 5; q < 9; ++q) of.o[q] = 0; }
+        else { const int64_t o9[9] = {-D - 1, -D, -D + 1, -1, 0, 1, D - 1, D, D + 1}; for (int q = 0; q < 9; ++q) of.o[q] = o9[q]; }
+        if (M.dia_pts == 5)
+            hipLaunchKernelGGL((k_spmv_dia<5>), dim3(nblk), dim3(KK_TPB), 0, ctx->stream, M.dia_val, M.dia_ld, of, M.nrows, x, y, e, nb_logical, pd, pn);
+        else
+            hipLaunchKernelGGL((k_spmv_dia<9>), dim3(nblk), dim3(KK_TPB), 0, ctx->stream, M.dia_val, M.dia_ld, of, M.nrows, x, y, e, nb_logical, pd, pn);
     } else if (M.format == 0) {
         const int nb_logical = (int)((M.nrows + 2 * KK_TPB - 1) / (2 * KK_TPB));
         const int per = (nb_logical + 7) / 8;

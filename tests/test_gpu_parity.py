@@ -682,6 +682,54 @@ def test_block_apply_grid_stencil_sweep(kk, ko, ctx, nine):
     np.testing.assert_allclose(np.stack([S.download(4 + j) for j in range(4)], 1), R @ X, rtol=1e-12, atol=1e-12)
 
 
+def test_grid_stencil_single_vector_apply_and_fused_epilogues(kk, ko, ctx):
+    """The diagonal SpMV of detected grid stencils (k_spmv_dia) against SciPy, the affine form, and -- through the fused
+    Lanczos / CG epilogues (inner products, v_prev term, norms, speculative scaled apply) -- against the oracle; every case also
+    with the gather kernel (spmv_dia = 0): the two must agree to rounding."""
+    rng = np.random.default_rng(23)
+    for nine in (False, True):
+        for nx, ny, drop in ((64, 70, 0), (131, 37, 0), (187, 30, 11)):
+            A = _grid_stencil(nx, ny, nine, rng, drop)
+            n = A.shape[0]
+            op = kk.SparseOperator(A, ctx)
+            X, Y = kk.DeviceBasis(n, 2, ctx), kk.DeviceBasis(n, 2, ctx)
+            x, u = rng.standard_normal(n), rng.standard_normal(n)
+            for dia in (1, 0):
+                ctx.set_option("spmv_dia", dia)
+                ctx.prof_reset(); ctx.prof_enable(1)
+                op.apply(X[0].set(x), Y[0])
+                ctx.prof_enable(0)
+                assert (ctx.prof_get("k_spmv_dia")[1] > 0) == bool(dia)
+                scale = np.abs(A) @ np.abs(x) + 1e-300
+                assert np.max(np.abs(Y[0].get() - A @ x) / scale) < 1e-14
+                op.apply_adjoint(Y[1].set(u), X[1])
+                scale = np.abs(A.T) @ np.abs(u) + 1e-300
+                assert np.max(np.abs(X[1].get() - A.T @ u) / scale) < 1e-14
+                op.apply_affine(X[0], Y[0], 0.7, -1.3)
+                np.testing.assert_allclose(Y[0].get(), 0.7 * x - 1.3 * (A @ x), rtol=1e-12, atol=1e-12)
+            ctx.set_option("spmv_dia", 1)
+    A = ko.laplacian_2d(70, 64, shift_diag=10 * np.linspace(0, 1, 70 * 64) ** 2)
+    n = A.shape[0]
+    x0 = rng.random(n)
+    for dia in (1, 0):
+        ctx.set_option("spmv_dia", dia)
+        for dev, ref in ((kk.ModifiedGramSchmidt2(), ko.MGS2), (kk.ClassicalGramSchmidt2(), ko.CGS2), (kk.ModifiedGramSchmidt(), ko.MGS)):
+            it = kk.LanczosIterator(kk.SparseOperator(A, ctx, symmetric=True), x0, dev, capacity=30)
+            oit = ko.LanczosIterator(A, x0.copy(), ref)
+            f, of = kk.initialize(it), ko.lanczos_initialize(oit)
+            for _ in range(25):
+                f, of = kk.expand_(it, f), ko.lanczos_expand(oit, of)
+            tol = 1e-10 if dev.is_reorth else 1e-6
+            assert relerr(f.alphas, of.alphas) < tol and relerr(f.betas, of.betas) < tol, (dia, dev.name)
+        b = rng.random(n)
+        tol = 1e-10 * np.linalg.norm(b)
+        xs, info = kk.linsolve_cg(kk.SparseOperator(A, ctx, symmetric=True), b, None, kk.CG(2000, tol), 0.3, 0.9)
+        xo, oinfo = ko.cg(A, b, None, 0.3, 0.9, maxiter=2000, tol=tol)
+        assert info.converged == 1 and (info.numiter, info.numops) == (oinfo.numiter, oinfo.numops)
+        np.testing.assert_allclose(xs, xo, rtol=0, atol=1e-9 * np.linalg.norm(xo))
+    ctx.set_option("spmv_dia", 1)
+
+
 @pytest.mark.parametrize("block_mode", [0, 1])
 def test_blocklanczos_factorization(kk, ko, ctx, block_mode):
     """test/factorize.jl:387-401: V'V = I, A V = V H + R B' after every expand!; parity of H with the oracle."""

@@ -88,7 +88,7 @@ def bench_gkl(ctx, full):
         for _ in range(K - 1):
             f = kk.expand_(it, f)
         ctx.prof_enable(0)
-        prof = {k: round(ctx.prof_get(k)[0], 2) for k in ("k_spmv_ell", "k_spmv_sell", "k_spmv_csr", "k_project", "k_unproject", "k_unproj_proj", "k_mgs_step", "k_scal", "k_dot")}
+        prof = {k: round(ctx.prof_get(k)[0], 2) for k in ("k_spmv_ell", "k_spmv_dia", "k_spmv_sell", "k_spmv_csr", "k_project", "k_unproject", "k_unproj_proj", "k_mgs_step", "k_scal", "k_dot")}
         out[orth.name] = {"gkl_it_per_s": round((K - 1) / best, 1), "alg_GBps": round(alg / best / 1e9, 1), "frac_8TBps": round(alg / best / 8e12, 4),
                           "sigma_max_est": max(np.linalg.svd(f.rayleighquotient(), compute_uv=False)), "kernel_ms_one_sweep": prof}
     print(json.dumps({"config": f"4: svdsolve(GKL) {m}x{n} sparse random nnz/row=20, krylovdim=30 (1 GPU)", **out}), flush=True)
@@ -116,7 +116,7 @@ def bench_lsmr(ctx, full):
         ctx.prof_reset(); ctx.prof_enable(1)
         kk.lssolve(op, b, kk.LSMR(kk.ModifiedGramSchmidt(), 50, K, 1e-300))
         ctx.prof_enable(0)
-        prof = {k: round(ctx.prof_get(k)[0], 2) for k in ("k_spmv_ell", "k_spmv_sell", "k_spmv_csr", "k_project", "k_unproject",
+        prof = {k: round(ctx.prof_get(k)[0], 2) for k in ("k_spmv_ell", "k_spmv_dia", "k_spmv_sell", "k_spmv_csr", "k_project", "k_unproject",
                                                             "k_lsmr_u", "k_lsmr_hx", "k_axpby", "k_scal", "k_block_gram")}
         out[f"krylovdim={K}"] = {"ms_per_iteration": round(per_it * 1e3, 4), "it_per_s": round(1 / per_it, 1),
                                  "normres": info.normres, "kernel_ms_50_iterations": prof}

@@ -51,7 +51,7 @@ for name, opts in [("lowsync", dict(mgs_mode=1)),
         ctx.prof_reset(); ctx.prof_enable(1)
         sweep()
         ctx.prof_enable(0)
-        prof = {k: round(ctx.prof_get(k)[0], 2) for k in ("k_mgs_persist", "k_mgs_step", "k_project", "k_unproject", "k_spmv_ell", "k_scal")
+        prof = {k: round(ctx.prof_get(k)[0], 2) for k in ("k_mgs_persist", "k_mgs_step", "k_project", "k_unproject", "k_spmv_ell", "k_spmv_dia", "k_scal")
                 if ctx.prof_get(k)[1]}
         al = np.array(f.alphas)
         if ref is None:

@@ -44,7 +44,7 @@ if "FETCH_SIZE" in res and "WRITE_SIZE" in res and "--no-traffic" not in sys.arg
     traffic = {"_comment": "HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --steps 2 "
                            "--warmup 1`, (2*FETCH_SIZE + WRITE_SIZE)*1024 as MI355X_MICROARCH.md prescribes for gfx950, averaged over the "
                            "launches of the run", "source_sha": kernel_source_sha(), "stamped_by": f"tools/profile_gpu.sh {tag}"}
-    for short in ("k_project", "k_unproject", "k_spmv_ell", "k_scal", "k_mgs_step", "k_mgs_persist", "k_unproj_proj"):
+    for short in ("k_project", "k_unproject", "k_spmv_ell", "k_spmv_dia", "k_scal", "k_mgs_step", "k_mgs_persist", "k_unproj_proj"):
         f = [v for k, v in res["FETCH_SIZE"].items() if k.startswith("void " + short) or k.startswith(short)]
         w = [v for k, v in res["WRITE_SIZE"].items() if k.startswith("void " + short) or k.startswith(short)]
         if f and w:
