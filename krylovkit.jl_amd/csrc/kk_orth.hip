@@ -82,6 +82,7 @@ KK_API int kk_householder_rmul(kk_basis b, int c0, int m, const double* v, doubl
 int gram_device(kk_basis b) {
     if (b->gram.empty()) b->gram.assign((size_t)b->cap * b->cap, 0.0);
     if (!b->d_gram) {
+        KK_HIP(hipSetDevice(b->ctx->device));   // lazy allocation: must land on the context's device, not the thread's current one
         KK_HIP(hipMalloc(&b->d_gram, (size_t)b->cap * b->cap * sizeof(double)));
         KK_HIP(hipMemcpy(b->d_gram, b->gram.data(), (size_t)b->cap * b->cap * sizeof(double), hipMemcpyHostToDevice));
     }
