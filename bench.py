@@ -238,6 +238,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-strict-leg", action="store_true")
     ap.add_argument("--ny", type=int, default=NY, help="grid rows per GPU (default 2500 -> 10M rows per GPU)")
+    ap.add_argument("--deadline", type=float, default=900.0, help="multi-rank runs only: abort if the whole run takes longer (seconds)")
     ap.add_argument("--backend", default="hip", choices=["hip", "checker"],
                     help="checker: NumPy stand-in of the device engine, CPU test of the launcher / rendezvous only (never a measurement)")
     args = ap.parse_args()
@@ -253,6 +254,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.backend == "checker":
         return main_checker(args, rank, world)
+    if world > 1:
+        # A multi-rank run that stops making progress (a rank died, a collective never completes) must not sit on the GPU
+        # box until an outer limit kills it: every rank gives itself a deadline and leaves with a message instead.
+        import threading
+
+        def _deadline():
+            sys.stderr.write(f"bench.py: rank {rank} of {world} did not finish within {args.deadline:.0f} s -- aborting the run\n")
+            sys.stderr.flush()
+            os._exit(3)
+
+        wd = threading.Timer(args.deadline, _deadline)
+        wd.daemon = True
+        wd.start()
 
     import krylovkit_hip as kk
     from krylovkit_hip import dist as kd
