@@ -13,7 +13,10 @@ from .factorizations import (ArnoldiFactorization, ArnoldiIterator, Block, Block
                              GKLFactorization, GKLIterator, block_inner, block_qr_, block_reorthogonalize_,
                              LanczosFactorization, LanczosIterator, expand_, initialize, initialize_, shrink_)
 from . import dist
-from .solvers import CG, GKL, GMRES, LSMR, Arnoldi, BiArnoldi, BiCGStab, GolubYe, bieigsolve, geneigsolve, BlockLanczos, linsolve_bicgstab, linsolve_cg, lssolve, schursolve, ConvergenceInfo, Lanczos, eigsolve, eigsolve_block, linsolve, svdsolve
+from .algorithms import CG, GKL, GMRES, LSMR, Arnoldi, BiArnoldi, BiCGStab, GolubYe, BlockLanczos, ConvergenceInfo, Lanczos
+from .eigsolve import bieigsolve, eigsolve, eigsolve_block, geneigsolve, schursolve, svdsolve
+from .linsolve import linsolve, linsolve_bicgstab, linsolve_cg
+from .lssolve import lssolve
 
 from .matrixfun import expintegrator, exponentiate
 

@@ -13,7 +13,7 @@ import scipy.linalg as sla
 
 from .core import DeviceBasis, HipVec
 from .factorizations import ArnoldiIterator, LanczosIterator, _as_operator, expand_, initialize, initialize_
-from .solvers import Arnoldi, ConvergenceInfo, Lanczos
+from .algorithms import Arnoldi, ConvergenceInfo, Lanczos
 
 
 def exponentiate(A, t: float, v, alg: Optional[Union[Lanczos, Arnoldi]] = None, **kw):
