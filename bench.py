@@ -414,11 +414,18 @@ def main():
     elapsed = time.perf_counter() - t0
     ctx.prof_enable(0)
     stats1 = comm.stats() if comm else None
+    ranks_agree = None
     if world > 1:
         import torch
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # every rank must have seen bit-identical scalars (all-reduced inner products): a cheap end-to-end check of the
+        # sharded path, printed with the collectives
+        mine = (float(fact.normres),) if args.config == "block" else (float(fact.alphas[-1]), float(fact.betas[-1]))
+        seen = [None] * world
+        dist.all_gather_object(seen, mine)
+        ranks_agree = all(v == seen[0] for v in seen)
 
     # ---------------- roofline of the dominant kernel (HIP events on the kernels' stream)
     roofline = None
@@ -514,7 +521,8 @@ def main():
             info = comm.info()
             per = {k: (stats1[k] - stats0[k]) / (K * sweep_its) for k in stats1}
             out["collectives"] = {"library": "RCCL inside libkrylov_hip (kk_comm_init)", "rccl_version": info["rccl_version"],
-                                  "ranks": info["world"], "per_iteration": {k: round(v, 3) for k, v in per.items()}}
+                                  "ranks": info["world"], "per_iteration": {k: round(v, 3) for k, v in per.items()},
+                                  "ranks_agree_bitwise": ranks_agree}
         if args.config == "lanczos" and world == 1 and not use_dist and not args.no_cpu_baseline:
             x0_host = x0_handle[0].get()                       # the GPU run's own start vector (80 MB over PCIe, once)
             base, al_c, be_c = cpu_baseline(orth.code, x0_host, args.ny)
@@ -564,11 +572,18 @@ def main_checker(args, rank: int, world: int):
         for _ in range(kd_ - 1):
             f = it.expand(f)
     elapsed = time.perf_counter() - t0
+    ranks_agree = None
     if world > 1:
         import torch
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # every rank must have seen bit-identical scalars (all-reduced inner products): a cheap end-to-end check of the
+        # sharded path, printed with the collectives
+        mine = (float(fact.normres),) if args.config == "block" else (float(fact.alphas[-1]), float(fact.betas[-1]))
+        seen = [None] * world
+        dist.all_gather_object(seen, mine)
+        ranks_agree = all(v == seen[0] for v in seen)
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
