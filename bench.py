@@ -572,18 +572,11 @@ def main_checker(args, rank: int, world: int):
         for _ in range(kd_ - 1):
             f = it.expand(f)
     elapsed = time.perf_counter() - t0
-    ranks_agree = None
     if world > 1:
         import torch
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        # every rank must have seen bit-identical scalars (all-reduced inner products): a cheap end-to-end check of the
-        # sharded path, printed with the collectives
-        mine = (float(fact.normres),) if args.config == "block" else (float(fact.alphas[-1]), float(fact.betas[-1]))
-        seen = [None] * world
-        dist.all_gather_object(seen, mine)
-        ranks_agree = all(v == seen[0] for v in seen)
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
