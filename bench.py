@@ -491,8 +491,10 @@ def main():
         strict = {"value": round(units_per_sweep / dts, 3), "unit": "it/s", "ms_per_step": round(dts * 1e3, 3),
                   "hbm_algorithmic_frac_of_peak_per_gpu": round(alg_sweep / dts / 1e9 / (HBM_PEAK_GBPS * world), 4),
                   "note": "mgs_mode=0: the reference's sequential order (src/orthonormal.jl:414-439), one basis vector after the other; "
-                          "persistent cooperative kernel, w resident in registers, one streaming read of every basis vector per sweep "
-                          "(the per-vector kernel it replaces moved 32 N bytes per vector: 365 it/s)",
+                          + ("row-sharded: one fused axpy+dot kernel and one all-reduce per basis vector (32 N bytes per vector; the "
+                             "persistent kernel cannot issue collectives)" if use_dist else
+                             "persistent cooperative kernel, w resident in registers, one streaming read of every basis vector per sweep "
+                             "(the per-vector kernel it replaces moved 32 N bytes per vector: 365 it/s)"),
                   "max_alpha_reldiff_vs_lowsync": float(np.max(np.abs(np.array(fs.alphas) - np.array(fact.alphas)) / np.abs(np.array(fact.alphas))))}
 
     line = None
