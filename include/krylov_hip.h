@@ -64,15 +64,22 @@ typedef enum {
 } kk_orth_t;
 
 /* How the MGS family is executed on the device (kk_ctx_set_option("mgs_mode", v)):
- *   0 = strict:   one fused axpy+dot kernel per basis vector, sequential as in
- *                 src/orthonormal.jl:417-421 (32 N bytes / vector).
+ *   0 = strict:   sequential as in src/orthonormal.jl:417-421, one basis vector after the other: a persistent
+ *                 cooperative kernel that keeps w in registers and reads every basis vector once (8 N bytes / vector;
+ *                 option "mgs_persist", default 1, "persist_threads" 512 / 1024); when w does not fit the register
+ *                 file of the chip, or the context is row-sharded, one fused axpy+dot kernel per vector (32 N bytes).
  *   1 = lowsync:  algebraically identical MGS coefficients from ONE projection pass plus a
  *                 triangular solve (on the device) with the strictly-lower Gram matrix of the
  *                 basis, maintained incrementally (16 N bytes / vector).  Default. */
 /* Other kk_ctx_set_option keys: "blocks_per_cu" (grid of the streaming kernels, default 4), "block_mode" (0 strict
  * block QR / re-orthogonalisation, 1 MFMA panels + CholQR2, default), "fuse_passes", "speculate" (next-step SpMV
  * enqueued before the host reads alpha/beta), "keep_mb" (MB of trailing basis columns a project pass leaves
- * cache-allocated for the unproject pass that follows; default 160 of the 256 MB Infinity Cache, 0 = none). */
+ * cache-allocated for the unproject pass that follows; default 160 of the 256 MB Infinity Cache, 0 = none),
+ * "block_async" (whole BlockLanczos step enqueued without a host round trip, default 1), "block_fuse" (bit mask of its
+ * pass structure: 1 = second CholQR2 round fused, 4 = one-pass projection with Gram correction; default 5; 0 / 1 = the
+ * reference's three-term-then-reorthogonalise order), "spmv_dia" / "spmm_dia" (diagonal kernels for operators detected
+ * as grid stencils, default 1; 0 = the general ELL gather kernels).  Tuning knobs without semantic effect:
+ * "gram_bpc", "gram2_chunk", "spmm_bpc", "spmm_cols", "spmm_rpl", "spmm_dia_lines", "bu_prefetch", "gram_nt", "persist_nt". */
 
 /* ---------------------------------------------------------------- library / context */
 int kk_version(void);
