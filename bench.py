@@ -281,7 +281,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("gloo", rank=rank, world_size=world)
-    ctx = kk.Context(local_rank) if use_dist else kk.default_context()
+    # one rank per GPU; if the launcher narrowed the visible devices per rank (HIP_VISIBLE_DEVICES), LOCAL_RANK wraps
+    ctx = kk.Context(local_rank % max(kk.device_count(), 1)) if use_dist else kk.default_context()
     comm = None
     if use_dist:
         comm = kd.NativeComm.from_torch_distributed(ctx, force_collectives=force_dist) if world > 1 else \
