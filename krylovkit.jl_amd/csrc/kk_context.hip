@@ -223,6 +223,14 @@ KK_API int kk_ctx_get_option(kk_ctx c, const char* key, double* value) {
     else if (!strcmp(key, "persist_threads")) *value = c->persist_threads;
     else if (!strcmp(key, "persist_nt")) *value = c->persist_nt;
     else if (!strcmp(key, "speculate")) *value = c->speculate;
+    else if (!strcmp(key, "spmv_dia")) *value = c->spmv_dia;
+    else if (!strcmp(key, "spmm_dia")) *value = c->spmm_dia;
+    else if (!strcmp(key, "spmm_dia_lines")) *value = c->spmm_dia_lines;
+    else if (!strcmp(key, "spmm_cols")) *value = c->spmm_cols;
+    else if (!strcmp(key, "spmm_rpl")) *value = c->spmm_rpl;
+    else if (!strcmp(key, "gram_bpc")) *value = c->gram_bpc;
+    else if (!strcmp(key, "gram2_chunk")) *value = c->gram2_chunk;
+    else if (!strcmp(key, "gram_nt")) *value = c->gram_nt;
     else {
         kk_set_error("unknown option '%s'", key);
         return KK_ERR_INVALID;
