@@ -193,7 +193,7 @@ int kk_csr_create(kk_ctx ctx, int64_t nrows, int64_t ncols, int64_t nnz, const i
 int kk_csc_create(kk_ctx ctx, int64_t nrows, int64_t ncols, int64_t nnz, const int64_t* colptr,
                   const int64_t* rowval, const double* nzval, int index_base, int flags, kk_op* out);
 int kk_op_free(kk_op op);
-int kk_op_info(kk_op op, int64_t* nrows, int64_t* ncols, int64_t* nnz, int* format /*0=ELL,1=CSR,2=SELL-64-sigma,3=column-tiled SELL*/,
+int kk_op_info(kk_op op, int64_t* nrows, int64_t* ncols, int64_t* nnz, int* format /*0=ELL,1=CSR,2=SELL-64-sigma,3=column-tiled SELL,4=ELL + grid-stencil diagonals*/,
                int64_t* device_bytes);
 /* Row-sharded operators (one process per GPU): column indices >= n_local_cols address a
  * caller-owned device buffer of n_ghost doubles that the caller fills before each apply
