@@ -170,6 +170,9 @@ KK_API int kk_ctx_set_option(kk_ctx c, const char* key, double value) {
         c->gram_nt = value != 0;
     } else if (!strcmp(key, "spmv_dia")) {
         c->spmv_dia = value != 0;
+    } else if (!strcmp(key, "spmv_dia_pairs")) {
+        KK_CHECK(value == 1 || value == 2, KK_ERR_INVALID, "spmv_dia_pairs must be 1 or 2");
+        c->spmv_dia_pairs = (int)value;
     } else if (!strcmp(key, "spmm_dia")) {
         c->spmm_dia = value != 0;
     } else if (!strcmp(key, "spmm_dia_lines")) {

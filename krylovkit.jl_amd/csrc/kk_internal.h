@@ -114,6 +114,7 @@ struct kk_ctx_s {
     int spmm_bpc = 4;            // resident blocks per CU of the multi-column sparse apply (L2 window, see kk_launch_spmm); 0 = fill the chip
     int spmm_rpl = 2;            // SpMM on ELL: rows per lane (1 or 2)
     int spmv_dia = 1;            // single-column apply of a detected grid stencil: diagonal kernel (0: ELL gather kernel)
+    int spmv_dia_pairs = 1;      // ... row pairs per lane (1 or 2)
     int spmm_dia = 1;            // multi-column apply of a detected grid stencil: sweeping diagonal kernel (0: ELL gather kernel)
     int spmm_dia_lines = 16;     // ... grid lines per wave sweep
     int spmm_cols = 16;          // SpMM on ELL: right-hand sides per launch (16, 8 or 4)

@@ -116,7 +116,7 @@ __device__ __forceinline__ d2 dia_pair(const double* __restrict__ x, int64_t idx
     v.y = (idx + 1 >= 0 && idx + 1 < nrows) ? x[idx + 1] : 0.0;
     return v;
 }
-template <int PTS>
+template <int PTS, int U>   // U row pairs per lane: a block covers U consecutive 512-row chunks, all their loads in flight together
 __global__ __launch_bounds__(KK_TPB) void k_spmv_dia(const double* __restrict__ dval, int64_t dld, dia_offs offs, int64_t nrows,
                                                      const double* __restrict__ x, double* __restrict__ y, spmv_epi e,
                                                      int nb_logical, double* __restrict__ part_dot,
@@ -131,32 +131,44 @@ __global__ __launch_bounds__(KK_TPB) void k_spmv_dia(const double* __restrict__ 
     for (int c = blockIdx.x >> 3; c < per; c += nbx) {
         const int lb = xcd * per + c;
         if (lb >= nb_logical) break;
-        const int64_t row = ((int64_t)lb * KK_TPB + threadIdx.x) * 2;
-        if (row < nrows) {  // dia_ld is even and >= nrows; pad entries are 0
-            double s0 = 0, s1 = 0;
-            d2 xc{0.0, 0.0};
+        const int64_t row0 = ((int64_t)lb * U * KK_TPB + threadIdx.x) * 2;
+        double s0[U], s1[U];
+        d2 xc[U];
 #pragma unroll
-            for (int q = 0; q < PTS; ++q) {
-                const d2 v = ld2s(dval + (int64_t)q * dld + row);
-                const d2 xv = dia_pair(x, row + offs.o[q], nrows);
-                if (q == PTS / 2) xc = xv;                 // the middle slot is the main diagonal
-                s0 = fma(v.x, xv.x, s0);
-                s1 = fma(v.y, xv.y, s1);
+        for (int u = 0; u < U; ++u) { s0[u] = 0; s1[u] = 0; xc[u] = d2{0.0, 0.0}; }
+#pragma unroll
+        for (int q = 0; q < PTS; ++q) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t row = row0 + (int64_t)u * 2 * KK_TPB;
+                if (row < nrows) {   // dia_ld is even and >= nrows; pad entries are 0
+                    const d2 v = ld2s(dval + (int64_t)q * dld + row);
+                    const d2 xv = dia_pair(x, row + offs.o[q], nrows);
+                    if (q == PTS / 2) xc[u] = xv;              // the middle slot is the main diagonal
+                    s0[u] = fma(v.x, xv.x, s0[u]);
+                    s1[u] = fma(v.y, xv.y, s1[u]);
+                }
             }
-            s0 *= xs; s1 *= xs;
-            d2 out{e.a1 * s0, e.a1 * s1};
-            d2 xv{xc.x * xs, xc.y * xs};
-            if (e.a0 != 0.0) { out.x = fma(e.a0, xv.x, out.x); out.y = fma(e.a0, xv.y, out.y); }
-            if (e.dot_mode == 1) { dacc = fma(xv.x, out.x, dacc); dacc = fma(xv.y, out.y, dacc); }
-            if (e.vprev) {
-                const d2 p = ld2(e.vprev + row);
-                out.x = fma(-bp, p.x, out.x); out.y = fma(-bp, p.y, out.y);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t row = row0 + (int64_t)u * 2 * KK_TPB;
+            if (row < nrows) {
+                const double t0 = s0[u] * xs, t1 = s1[u] * xs;
+                d2 out{e.a1 * t0, e.a1 * t1};
+                const d2 xv{xc[u].x * xs, xc[u].y * xs};
+                if (e.a0 != 0.0) { out.x = fma(e.a0, xv.x, out.x); out.y = fma(e.a0, xv.y, out.y); }
+                if (e.dot_mode == 1) { dacc = fma(xv.x, out.x, dacc); dacc = fma(xv.y, out.y, dacc); }
+                if (e.vprev) {
+                    const d2 p = ld2(e.vprev + row);
+                    out.x = fma(-bp, p.x, out.x); out.y = fma(-bp, p.y, out.y);
+                }
+                if (row + 1 >= nrows) out.y = 0.0;  // odd nrows: keep the pad row zero
+                if (e.dot_mode == 2) { dacc = fma(xv.x, out.x, dacc); dacc = fma(xv.y, out.y, dacc); }
+                if (e.dot_mode == 3) { const d2 z = ld2(e.dvec + row); dacc = fma(z.x, out.x, dacc); dacc = fma(z.y, out.y, dacc); }
+                if (e.want_nrm) { nacc = fma(out.x, out.x, nacc); nacc = fma(out.y, out.y, nacc); }
+                st2(y + row, out);
             }
-            if (row + 1 >= nrows) out.y = 0.0;  // odd nrows: keep the pad row zero
-            if (e.dot_mode == 2) { dacc = fma(xv.x, out.x, dacc); dacc = fma(xv.y, out.y, dacc); }
-            if (e.dot_mode == 3) { const d2 z = ld2(e.dvec + row); dacc = fma(z.x, out.x, dacc); dacc = fma(z.y, out.y, dacc); }
-            if (e.want_nrm) { nacc = fma(out.x, out.x, nacc); nacc = fma(out.y, out.y, nacc); }
-            st2(y + row, out);
         }
     }
     if (e.dot_mode) {
@@ -543,7 +555,8 @@ int kk_launch_spmv(kk_ctx ctx, const kk_sparse_dev& M, const double* x, double* 
                                S.sell_nchunks, S.nrows, x, y, et, pd, pn);
         }
     } else if (use_dia) {
-        const int nb_logical = (int)((M.nrows + 2 * KK_TPB - 1) / (2 * KK_TPB));
+        const int U = ctx->spmv_dia_pairs == 2 ? 2 : 1;
+        const int nb_logical = (int)((M.nrows + 2 * U * KK_TPB - 1) / (2 * U * KK_TPB));
         const int per = (nb_logical + 7) / 8;
         const int nbx = std::min(per, KK_MAX_BLOCKS / 8);
         nblk = nbx * 8;
@@ -551,10 +564,15 @@ int kk_launch_spmv(kk_ctx ctx, const kk_sparse_dev& M, const double* x, double* 
         const int64_t D = M.dia_D;
         if (M.dia_pts == 5) { const int64_t o5[5] = {-D, -1, 0, 1, D}; for (int q = 0; q < 5; ++q) of.o[q] = o5[q]; for (int q = 5; q < 9; ++q) of.o[q] = 0; }
         else { const int64_t o9[9] = {-D - 1, -D, -D + 1, -1, 0, 1, D - 1, D, D + 1}; for (int q = 0; q < 9; ++q) of.o[q] = o9[q]; }
-        if (M.dia_pts == 5)
-            hipLaunchKernelGGL((k_spmv_dia<5>), dim3(nblk), dim3(KK_TPB), 0, ctx->stream, M.dia_val, M.dia_ld, of, M.nrows, x, y, e, nb_logical, pd, pn);
-        else
-            hipLaunchKernelGGL((k_spmv_dia<9>), dim3(nblk), dim3(KK_TPB), 0, ctx->stream, M.dia_val, M.dia_ld, of, M.nrows, x, y, e, nb_logical, pd, pn);
+#define SPMV_DIA_ARGS dim3(nblk), dim3(KK_TPB), 0, ctx->stream, M.dia_val, M.dia_ld, of, M.nrows, x, y, e, nb_logical, pd, pn
+        if (M.dia_pts == 5) {
+            if (U == 2) hipLaunchKernelGGL((k_spmv_dia<5, 2>), SPMV_DIA_ARGS);
+            else hipLaunchKernelGGL((k_spmv_dia<5, 1>), SPMV_DIA_ARGS);
+        } else {
+            if (U == 2) hipLaunchKernelGGL((k_spmv_dia<9, 2>), SPMV_DIA_ARGS);
+            else hipLaunchKernelGGL((k_spmv_dia<9, 1>), SPMV_DIA_ARGS);
+        }
+#undef SPMV_DIA_ARGS
     } else if (M.format == 0) {
         const int nb_logical = (int)((M.nrows + 2 * KK_TPB - 1) / (2 * KK_TPB));
         const int per = (nb_logical + 7) / 8;

@@ -31,7 +31,10 @@ def sweep():
 
 
 ref = None
-for name, opts in [("lowsync", dict(mgs_mode=1)),
+for name, opts in [("lowsync", dict(mgs_mode=1, spmv_dia=1, spmv_dia_pairs=1)),
+                   ("lowsync, diagonal SpMV with 2 row pairs per lane", dict(mgs_mode=1, spmv_dia_pairs=2)),
+                   ("lowsync, ELL gather SpMV", dict(mgs_mode=1, spmv_dia=0)),
+                   ("lowsync again", dict(mgs_mode=1, spmv_dia=1, spmv_dia_pairs=1)),
                    ("strict step kernel", dict(mgs_mode=0, mgs_persist=0)),
                    ("strict persistent 1024 nt", dict(mgs_mode=0, mgs_persist=1, persist_threads=1024, persist_nt=1)),
                    ("strict persistent 1024 plain", dict(mgs_mode=0, mgs_persist=1, persist_threads=1024, persist_nt=0)),
