@@ -232,8 +232,9 @@ KK_API int kk_lanczos_expand(kk_op op, kk_basis b, int c0, int k, kk_orth_t orth
             KK_TRY(kk_launch_project(c, V, ld, m, w, v, a0_dev, nullptr, WSP(c, WS_S), WSP(c, WS_G)));
             KK_TRY(kk_launch_unproject(c, V, ld, m, w, w, nullptr, c->ws + WS_S, -1.0, 1.0, m - 1, a0_dev,
                                        SCP(c, SC_NRM2)));
-            KK_TRY(ws_fetch_async(c, WS_S, m, 0));
-            KK_TRY(ws_fetch_async(c, WS_SCAL, 4, 0));
+            // ONE read-back for coefficients and scalars: a D2H copy costs ~4.5 us on the stream whatever its size, and the
+            // workspace areas in between travel along for free (WS_S .. WS_SCAL+4 = 10 KB)
+            KK_TRY(ws_fetch_async(c, WS_S, WS_SCAL + 4 - WS_S, 0));
             KK_TRY(fetch_mark(c));
             KK_TRY(speculate_next(op, b, c0, k + 1, 1, true, 0.0));
             KK_TRY(fetch_wait(c));
@@ -244,9 +245,9 @@ KK_API int kk_lanczos_expand(kk_op op, kk_basis b, int c0, int k, kk_orth_t orth
             bool rode = false;
             KK_TRY(lowsync_project_dev(b, m, w, v, a0_dev, a0_dev, WS_X, WS_Y, &rode));
             KK_TRY(kk_launch_unproject(c, V, ld, m, w, w, nullptr, WSP(c, WS_X), -1.0, 1.0, -1, nullptr, SCP(c, SC_NRM2)));
-            KK_TRY(ws_fetch_async(c, WS_SCAL, 4, 0));
-            KK_TRY(ws_fetch_async(c, WS_Y + m - 1, 1, 0));
-            if (rode) KK_TRY(ws_fetch_async(c, WS_G, m, 0));
+            // ONE read-back (Gram row, last MGS coefficient, scalars): WS_G .. WS_SCAL+4 = 8 KB, see above
+            if (rode) KK_TRY(ws_fetch_async(c, WS_G, WS_SCAL + 4 - WS_G, 0));
+            else KK_TRY(ws_fetch_async(c, WS_Y + m - 1, WS_SCAL + 4 - (WS_Y + m - 1), 0));
             KK_TRY(fetch_mark(c));
             KK_TRY(speculate_next(op, b, c0, k + 1, 2, true, 0.0));
             KK_TRY(fetch_wait(c));
@@ -259,7 +260,7 @@ KK_API int kk_lanczos_expand(kk_op op, kk_basis b, int c0, int k, kk_orth_t orth
         // strict: w -= alpha0 v fused with the first dot of the sweep   lanczos.jl:329-334
         const int64_t offs[1] = {WS_S};
         KK_TRY(pass_mgs_strict_sweeps(c, V, ld, m, 1, w, offs, true, 0, v, a0_dev));
-        KK_TRY(ws_fetch_async(c, WS_SCAL, 1, 0));
+        if (!c->persist_pending) KK_TRY(ws_fetch_async(c, WS_SCAL, 1, 0));   // (the persistent route fetched the scalars already)
         KK_TRY(fetch_mark(c));
         if (!kk_sharded(c)) KK_TRY(speculate_next(op, b, c0, k + 1, 2, true, 0.0));   // |w| and 1/|w| are on the device
         KK_TRY(fetch_wait(c));

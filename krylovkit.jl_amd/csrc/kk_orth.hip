@@ -195,8 +195,11 @@ int pass_mgs_strict_sweeps(kk_ctx c, const double* V, int64_t ld, int m, int nsw
             int* err = (int*)((char*)c->d_sync + KK_SYNC_ERR_OFFSET);
             KK_HIP(hipMemcpyAsync(c->h_sync, err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
             c->persist_pending = true;
-            for (int i = 0; i < nsweeps; ++i) KK_TRY(ws_fetch_async(c, ws_s[i], m, slot));
-            if (want_norm) KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2, 2, slot));
+            // ONE read-back from the first coefficient area through the named scalars (alpha0, |w|^2, |w|, 1/|w|): a D2H copy
+            // costs ~4.5 us on the stream whatever its size, and the areas in between travel along for free (<= 10 KB)
+            int64_t lo = ws_s[0];
+            for (int i = 1; i < nsweeps; ++i) lo = std::min(lo, ws_s[i]);
+            KK_TRY(ws_fetch_async(c, lo, WS_SCAL + 8 - lo, slot));
             return KK_OK;
         }
     }
