@@ -213,8 +213,8 @@ KK_API int kk_lanczos_expand(kk_op op, kk_basis b, int c0, int k, kk_orth_t orth
         KK_TRY(kk_launch_lanczos_coef(c, buf, ls ? b->d_gram : nullptr, b->cap, m, ls ? 1 : 0, WSP(c, WS_X), SCP(c, SC_TMP0)));
         KK_TRY(kk_launch_unproject(c, V, ld, m, w, w, nullptr, WSP(c, WS_X), -1.0, 1.0, -1, nullptr,
                                    SCP(c, SC_NRM2)));                  // all-reduce 2 of 2 inside: |w|^2
-        KK_TRY(ws_fetch_async(c, WS_SCAL, 8, 0));
-        if (ls) KK_TRY(ws_fetch_async(c, WS_SHBUF + 1 + m, m, 0));
+        // ONE read-back: the scalars and, right behind them in the workspace, the all-reduced Gram row V'v
+        KK_TRY(ws_fetch_async(c, WS_SCAL, ls ? (WS_SHBUF + 1 + 2 * m) - WS_SCAL : 8, 0));
         KK_TRY(fetch_mark(c));
         {
             kk_ar_suspend local_only(c);   // the speculative alpha0 partial joins the next step's all-reduce

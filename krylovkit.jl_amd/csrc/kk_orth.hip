@@ -150,14 +150,18 @@ static void gram_solve(kk_basis b, int c0, int m, double* p) {
     }
 }
 
+// ONE read-back from workspace offset `lo` through the named scalars: a D2H copy costs ~4.5 us on the stream whatever its
+// size (<= 10 KB here), so coefficient areas, Gram row and norms travel in a single copy instead of two to four
+static int fetch_through_scalars(kk_ctx c, int64_t lo, int slot) { return ws_fetch_async(c, lo, WS_SCAL + 8 - lo, slot); }
+
 // ---- one orthogonalisation pass; coefficient results land in pinned slot `slot` ------------
 // CGS pass:  s = V'w ; w -= V s ; optional |w| (orthonormal.jl:378-384)
 static int pass_cgs(kk_ctx c, const double* V, int64_t ld, int m, double* w, bool want_norm, int slot) {
     KK_TRY(kk_launch_project(c, V, ld, m, w, nullptr, nullptr, nullptr, WSP(c, WS_S), WSP(c, WS_G)));
-    KK_TRY(ws_fetch_async(c, WS_S, m, slot));
     KK_TRY(kk_launch_unproject(c, V, ld, m, w, w, nullptr, c->ws + WS_S, -1.0, 1.0, -1, nullptr,
                                want_norm ? SCP(c, SC_NRM2) : nullptr));
-    if (want_norm) KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2, 2, slot));
+    if (want_norm) KK_TRY(fetch_through_scalars(c, WS_S, slot));
+    else KK_TRY(ws_fetch_async(c, WS_S, m, slot));
     return KK_OK;
 }
 // strict MGS sweep (orthonormal.jl:414-423): `carry` = pending axpy (q, &s) left over from a
@@ -322,12 +326,10 @@ int orth_run(kk_basis b, int c0, int m, double* w, kk_orth_t alg, double eta, do
             if (c->fuse_passes && m <= 128) {
                 // s1 = V'w ; [w1 = w - V s1 ; s2 = V'w1] fused (V read once) ; w2 = w1 - V s2 (+ norm)
                 KK_TRY(kk_launch_project(c, V, ld, m, w, nullptr, nullptr, nullptr, WSP(c, WS_S), WSP(c, WS_G)));
-                KK_TRY(ws_fetch_async(c, WS_S, m, 0));
                 KK_TRY(kk_launch_unproj_proj(c, V, ld, m, w, w, nullptr, WSP(c, WS_S), WSP(c, WS_G), nullptr));
-                KK_TRY(ws_fetch_async(c, WS_G, m, 0));
                 KK_TRY(kk_launch_unproject(c, V, ld, m, w, w, nullptr, WSP(c, WS_G), -1.0, 1.0, -1, nullptr,
                                            want_norm ? SCP(c, SC_NRM2) : nullptr));
-                if (want_norm) KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2, 2, 0));
+                KK_TRY(fetch_through_scalars(c, WS_S, 0));   // s1 (WS_S), s2 (WS_G), norm
                 KK_TRY(final_sync(c));
                 for (int j = 0; j < m; ++j) x[j] = pin(c, WS_S, 0)[j] + pin(c, WS_G, 0)[j];
                 nn = pin(c, WS_SCAL + SC_NRM2, 0)[1];
@@ -364,9 +366,7 @@ int orth_run(kk_basis b, int c0, int m, double* w, kk_orth_t alg, double eta, do
                 KK_TRY(lowsync_project_dev(b, m, w, nullptr, nullptr, nullptr, WS_X, WS_Y, &rode));
                 KK_TRY(kk_launch_unproject(c, V, ld, m, w, w, nullptr, WSP(c, WS_X), -1.0, 1.0, -1, nullptr,
                                            want_norm ? SCP(c, SC_NRM2) : nullptr));
-                KK_TRY(ws_fetch_async(c, WS_Y, m, 0));
-                if (rode) KK_TRY(ws_fetch_async(c, WS_G, m, 0));
-                if (want_norm) KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2, 2, 0));
+                KK_TRY(fetch_through_scalars(c, rode ? WS_G : WS_Y, 0));   // [Gram row,] coefficients (WS_Y), norm
                 KK_TRY(final_sync(c));
                 memcpy(x, pin(c, WS_Y, 0), m * sizeof(double));
                 if (rode) lowsync_commit_row(b, m, pin(c, WS_G, 0));
@@ -394,9 +394,7 @@ int orth_run(kk_basis b, int c0, int m, double* w, kk_orth_t alg, double eta, do
                                                WSP(c, WS_Z)));
                 KK_TRY(kk_launch_unproject(c, V, ld, m, w, w, nullptr, WSP(c, WS_X), -1.0, 1.0, -1, nullptr,
                                            want_norm ? SCP(c, SC_NRM2) : nullptr));
-                KK_TRY(ws_fetch_async(c, WS_Y, 2 * KK_MAX_M, 0));   // s1 (WS_Y) and s2 (WS_Z) are adjacent
-                if (rode) KK_TRY(ws_fetch_async(c, WS_G, m, 0));
-                if (want_norm) KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2, 2, 0));
+                KK_TRY(fetch_through_scalars(c, rode ? WS_G : WS_Y, 0));   // [Gram row,] s1 (WS_Y), s2 (WS_Z), norm
                 KK_TRY(final_sync(c));
                 for (int j = 0; j < m; ++j) x[j] = pin(c, WS_Y, 0)[j] + pin(c, WS_Z, 0)[j];
                 if (rode) lowsync_commit_row(b, m, pin(c, WS_G, 0));
