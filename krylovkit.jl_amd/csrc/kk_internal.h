@@ -184,6 +184,9 @@ struct kk_sparse_dev {  // one direction (A or A') on the device
     int dia_pts = 0;               // 5 or 9 stored diagonals
     int64_t dia_ld = 0;
     double* dia_val = nullptr;
+    // row-sharded stencil: rows [int_lo, int_hi) (both even) reference local columns only -> diagonal kernels; the boundary
+    // strips [0, int_lo) and [int_hi, nrows), whose rows read the ghost buffer, keep the gather kernels
+    int64_t int_lo = 0, int_hi = 0;
     // CSR
     int32_t* rowptr = nullptr;
     int32_t* colind = nullptr;

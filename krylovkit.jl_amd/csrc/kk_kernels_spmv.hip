@@ -50,8 +50,9 @@ __global__ __launch_bounds__(KK_TPB) void k_spmv_ell(const int32_t* __restrict__
                                                      int64_t ell_ld, int width, int64_t nrows,
                                                      const double* __restrict__ x, double* __restrict__ y, spmv_epi e,
                                                      int nb_logical, double* __restrict__ part_dot,
-                                                     double* __restrict__ part_nrm) {
+                                                     double* __restrict__ part_nrm, int64_t row_base, int64_t row_end) {
     __shared__ double sm[4];
+    // rows [row_base, row_end) of the operator (the whole matrix, or a boundary strip of a row-sharded stencil; row_base even)
     // XCD banding: block b runs on XCD b & 7 and walks the band [xcd*per, (xcd+1)*per) of logical
     // 512-row chunks with stride nbx, so the blocks resident on one XCD sweep a contiguous row
     // window together and stencil neighbours (+-nx rows) are L2 hits of the same XCD.
@@ -64,8 +65,8 @@ __global__ __launch_bounds__(KK_TPB) void k_spmv_ell(const int32_t* __restrict__
     for (int c = blockIdx.x >> 3; c < per; c += nbx) {
         const int lb = xcd * per + c;
         if (lb >= nb_logical) break;
-        const int64_t row = ((int64_t)lb * KK_TPB + threadIdx.x) * 2;
-        if (row < nrows) {  // ell_ld is even and >= nrows; pad entries have val 0, col 0
+        const int64_t row = row_base + ((int64_t)lb * KK_TPB + threadIdx.x) * 2;
+        if (row < row_end) {  // ell_ld is even and >= nrows; pad entries have val 0, col 0
             double s0 = 0, s1 = 0;
             const int32_t* cp = ecol + row;
             const double* vp = eval + row;
@@ -120,8 +121,9 @@ template <int PTS, int U>   // U row pairs per lane: a block covers U consecutiv
 __global__ __launch_bounds__(KK_TPB) void k_spmv_dia(const double* __restrict__ dval, int64_t dld, dia_offs offs, int64_t nrows,
                                                      const double* __restrict__ x, double* __restrict__ y, spmv_epi e,
                                                      int nb_logical, double* __restrict__ part_dot,
-                                                     double* __restrict__ part_nrm) {
+                                                     double* __restrict__ part_nrm, int64_t row_base, int64_t row_end) {
     __shared__ double sm[4];
+    // rows [row_base, row_end): the whole operator, or the ghost-free interior of a row-sharded stencil (row_base even)
     const int per = (nb_logical + 7) >> 3;
     const int nbx = gridDim.x >> 3;
     const int xcd = blockIdx.x & 7;
@@ -131,7 +133,7 @@ __global__ __launch_bounds__(KK_TPB) void k_spmv_dia(const double* __restrict__ 
     for (int c = blockIdx.x >> 3; c < per; c += nbx) {
         const int lb = xcd * per + c;
         if (lb >= nb_logical) break;
-        const int64_t row0 = ((int64_t)lb * U * KK_TPB + threadIdx.x) * 2;
+        const int64_t row0 = row_base + ((int64_t)lb * U * KK_TPB + threadIdx.x) * 2;
         double s0[U], s1[U];
         d2 xc[U];
 #pragma unroll
@@ -141,7 +143,7 @@ __global__ __launch_bounds__(KK_TPB) void k_spmv_dia(const double* __restrict__ 
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int64_t row = row0 + (int64_t)u * 2 * KK_TPB;
-                if (row < nrows) {   // dia_ld is even and >= nrows; pad entries are 0
+                if (row < row_end) {   // dia_ld is even and >= nrows; pad entries are 0
                     const d2 v = ld2s(dval + (int64_t)q * dld + row);
                     const d2 xv = dia_pair(x, row + offs.o[q], nrows);
                     if (q == PTS / 2) xc[u] = xv;              // the middle slot is the main diagonal
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(KK_TPB) void k_spmv_dia(const double* __restrict__ 
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t row = row0 + (int64_t)u * 2 * KK_TPB;
-            if (row < nrows) {
+            if (row < row_end) {
                 const double t0 = s0[u] * xs, t1 = s1[u] * xs;
                 d2 out{e.a1 * t0, e.a1 * t1};
                 const d2 xv{xc[u].x * xs, xc[u].y * xs};
@@ -379,7 +381,7 @@ __global__ __launch_bounds__(KK_TPB) void k_spmm_ell(const int32_t* __restrict__
                                                      int64_t ell_ld, int width, int64_t nrows,
                                                      const double* __restrict__ X, int64_t ldx, double* __restrict__ Y,
                                                      int64_t ldy, int nb, int nb_logical, int64_t n_local,
-                                                     const double* __restrict__ G, int64_t ldg) {
+                                                     const double* __restrict__ G, int64_t ldg, int64_t row_base, int64_t row_end) {
     // row-sharded operator: columns >= n_local read the ghost block G (column j of the block at G + j*ldg), filled by
     // ONE grouped exchange for all nb vectors before the launch (kk_halo_exchange_block)
     const int per = (nb_logical + 7) >> 3;
@@ -388,8 +390,8 @@ __global__ __launch_bounds__(KK_TPB) void k_spmm_ell(const int32_t* __restrict__
     for (int cblk = blockIdx.x >> 3; cblk < per; cblk += nbx) {
         const int lb = xcd * per + cblk;
         if (lb >= nb_logical) break;
-        const int64_t row = ((int64_t)lb * KK_TPB + threadIdx.x) * RPL;
-        if (row >= nrows) continue;
+        const int64_t row = row_base + ((int64_t)lb * KK_TPB + threadIdx.x) * RPL;   // rows [row_base, row_end), row_base even
+        if (row >= row_end) continue;
         if (RPL == 2) {
             d2 acc[NB];
 #pragma unroll
@@ -459,11 +461,14 @@ __device__ __forceinline__ double wave_from_right(double v) {   // lane l receiv
 template <int NB, int PTS>
 __global__ __launch_bounds__(KK_TPB) void k_spmm_dia(const double* __restrict__ dval, int64_t dld, int64_t D, int64_t nrows,
                                                      const double* __restrict__ X, int64_t ldx, double* __restrict__ Y,
-                                                     int64_t ldy, int nb, int strips, int lines, int64_t T) {
+                                                     int64_t ldy, int nb, int strips, int lines, int64_t Tlo, int64_t T,
+                                                     int64_t row_lo, int64_t row_hi) {
+    // grid lines [Tlo, T) are swept; results are stored for rows [row_lo, row_hi) only (the whole operator, or the
+    // ghost-free interior of a row-sharded stencil -- its window loads stay inside the local vector)
     const int lane = threadIdx.x & 63;
     const int64_t wv = (int64_t)blockIdx.x * (KK_TPB / 64) + (threadIdx.x >> 6);
     const int strip = (int)(wv % strips);
-    const int64_t t0 = (wv / strips) * lines;
+    const int64_t t0 = Tlo + (wv / strips) * lines;
     if (t0 >= T) return;
     const int64_t t1 = imin(t0 + lines, T);
     const int64_t i = (int64_t)strip * 62 + lane - 1;     // position inside the grid line (halo lanes: -1 / one past the strip)
@@ -483,7 +488,7 @@ __global__ __launch_bounds__(KK_TPB) void k_spmm_dia(const double* __restrict__ 
         double d[PTS];
 #pragma unroll
         for (int q = 0; q < PTS; ++q) d[q] = rok ? __builtin_nontemporal_load(dval + (int64_t)q * dld + r) : 0.0;
-        const bool st = own && rok;
+        const bool st = own && rok && r >= row_lo && r < row_hi;
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             if (j < nb) {
@@ -513,6 +518,42 @@ __global__ __launch_bounds__(KK_TPB) void k_spmm_dia(const double* __restrict__ 
     }
 }
 
+// ranged launches: rows [r0, r1) of an ELL / diagonal operator; partial sums go to pd / pn + *nblk_io, *nblk_io advances
+static void launch_spmv_ell_rows(kk_ctx ctx, const kk_sparse_dev& M, const double* x, double* y, const spmv_epi& e, int64_t r0,
+                                 int64_t r1, double* pd, double* pn, int* nblk_io, int max_blocks) {
+    if (r1 <= r0) return;
+    const int nb_logical = (int)((r1 - r0 + 2 * KK_TPB - 1) / (2 * KK_TPB));
+    const int per = (nb_logical + 7) / 8;
+    const int nbx = std::max(1, std::min(per, max_blocks / 8));
+    const int nblk = nbx * 8;
+    hipLaunchKernelGGL(k_spmv_ell, dim3(nblk), dim3(KK_TPB), 0, ctx->stream, M.ell_col, M.ell_val, M.ell_ld, M.width, M.nrows, x, y,
+                       e, nb_logical, pd + *nblk_io, pn + *nblk_io, r0, r1);
+    *nblk_io += nblk;
+}
+static void launch_spmv_dia_rows(kk_ctx ctx, const kk_sparse_dev& M, const double* x, double* y, const spmv_epi& e, int64_t r0,
+                                 int64_t r1, double* pd, double* pn, int* nblk_io, int max_blocks) {
+    if (r1 <= r0) return;
+    const int U = ctx->spmv_dia_pairs == 2 ? 2 : 1;
+    const int nb_logical = (int)((r1 - r0 + 2 * U * KK_TPB - 1) / (2 * U * KK_TPB));
+    const int per = (nb_logical + 7) / 8;
+    const int nbx = std::max(1, std::min(per, max_blocks / 8));
+    const int nblk = nbx * 8;
+    dia_offs of;
+    const int64_t D = M.dia_D;
+    if (M.dia_pts == 5) { const int64_t o5[5] = {-D, -1, 0, 1, D}; for (int q = 0; q < 5; ++q) of.o[q] = o5[q]; for (int q = 5; q < 9; ++q) of.o[q] = 0; }
+    else { const int64_t o9[9] = {-D - 1, -D, -D + 1, -1, 0, 1, D - 1, D, D + 1}; for (int q = 0; q < 9; ++q) of.o[q] = o9[q]; }
+#define SPMV_DIA_ARGS dim3(nblk), dim3(KK_TPB), 0, ctx->stream, M.dia_val, M.dia_ld, of, M.nrows, x, y, e, nb_logical, pd + *nblk_io, pn + *nblk_io, r0, r1
+    if (M.dia_pts == 5) {
+        if (U == 2) hipLaunchKernelGGL((k_spmv_dia<5, 2>), SPMV_DIA_ARGS);
+        else hipLaunchKernelGGL((k_spmv_dia<5, 1>), SPMV_DIA_ARGS);
+    } else {
+        if (U == 2) hipLaunchKernelGGL((k_spmv_dia<9, 2>), SPMV_DIA_ARGS);
+        else hipLaunchKernelGGL((k_spmv_dia<9, 1>), SPMV_DIA_ARGS);
+    }
+#undef SPMV_DIA_ARGS
+    *nblk_io += nblk;
+}
+
 // ---- launchers
 int kk_launch_spmv(kk_ctx ctx, const kk_sparse_dev& M, const double* x, double* y, int64_t ld_y_rows,
                    const kk_spmv_fuse& f) {
@@ -533,8 +574,12 @@ int kk_launch_spmv(kk_ctx ctx, const kk_sparse_dev& M, const double* x, double* 
     double* pd = part_row(ctx, PART_SCAL_A);
     double* pn = part_row(ctx, PART_SCAL_B);
     int nblk = 0;
-    const bool use_dia = M.format == 0 && M.dia_D > 0 && ctx->spmv_dia && M.n_ghost == 0;
-    std::unique_ptr<kk_prof_scope> ps(new kk_prof_scope(ctx, use_dia ? "k_spmv_dia" : (M.format == 0 ? "k_spmv_ell" : (M.format >= 2 ? "k_spmv_sell" : "k_spmv_csr"))));
+    // diagonal kernel: the whole operator when it has no ghost columns, the ghost-free interior rows [int_lo, int_hi) of a
+    // row-sharded stencil (the boundary strips go through the gather kernel, which reads the ghost buffer)
+    const bool dia_ok = M.format == 0 && M.dia_D > 0 && ctx->spmv_dia;
+    const bool use_dia = dia_ok && M.n_ghost == 0;
+    const bool use_split = dia_ok && M.n_ghost > 0 && M.int_hi > M.int_lo;
+    std::unique_ptr<kk_prof_scope> ps(new kk_prof_scope(ctx, (use_dia || use_split) ? "k_spmv_dia" : (M.format == 0 ? "k_spmv_ell" : (M.format >= 2 ? "k_spmv_sell" : "k_spmv_csr"))));
     if (M.format == 2) {
         nblk = (int)std::min<int64_t>((M.sell_nchunks + 3) / 4, (int64_t)ctx->num_cus * 16);
         if (nblk < 1) nblk = 1;
@@ -555,31 +600,13 @@ int kk_launch_spmv(kk_ctx ctx, const kk_sparse_dev& M, const double* x, double* 
                                S.sell_nchunks, S.nrows, x, y, et, pd, pn);
         }
     } else if (use_dia) {
-        const int U = ctx->spmv_dia_pairs == 2 ? 2 : 1;
-        const int nb_logical = (int)((M.nrows + 2 * U * KK_TPB - 1) / (2 * U * KK_TPB));
-        const int per = (nb_logical + 7) / 8;
-        const int nbx = std::min(per, KK_MAX_BLOCKS / 8);
-        nblk = nbx * 8;
-        dia_offs of;
-        const int64_t D = M.dia_D;
-        if (M.dia_pts == 5) { const int64_t o5[5] = {-D, -1, 0, 1, D}; for (int q = 0; q < 5; ++q) of.o[q] = o5[q]; for (int q = 5; q < 9; ++q) of.o[q] = 0; }
-        else { const int64_t o9[9] = {-D - 1, -D, -D + 1, -1, 0, 1, D - 1, D, D + 1}; for (int q = 0; q < 9; ++q) of.o[q] = o9[q]; }
-#define SPMV_DIA_ARGS dim3(nblk), dim3(KK_TPB), 0, ctx->stream, M.dia_val, M.dia_ld, of, M.nrows, x, y, e, nb_logical, pd, pn
-        if (M.dia_pts == 5) {
-            if (U == 2) hipLaunchKernelGGL((k_spmv_dia<5, 2>), SPMV_DIA_ARGS);
-            else hipLaunchKernelGGL((k_spmv_dia<5, 1>), SPMV_DIA_ARGS);
-        } else {
-            if (U == 2) hipLaunchKernelGGL((k_spmv_dia<9, 2>), SPMV_DIA_ARGS);
-            else hipLaunchKernelGGL((k_spmv_dia<9, 1>), SPMV_DIA_ARGS);
-        }
-#undef SPMV_DIA_ARGS
+        launch_spmv_dia_rows(ctx, M, x, y, e, 0, M.nrows, pd, pn, &nblk, KK_MAX_BLOCKS);
+    } else if (use_split) {
+        launch_spmv_dia_rows(ctx, M, x, y, e, M.int_lo, M.int_hi, pd, pn, &nblk, KK_MAX_BLOCKS - 512);
+        launch_spmv_ell_rows(ctx, M, x, y, e, 0, M.int_lo, pd, pn, &nblk, 256);
+        launch_spmv_ell_rows(ctx, M, x, y, e, M.int_hi, M.nrows, pd, pn, &nblk, 256);
     } else if (M.format == 0) {
-        const int nb_logical = (int)((M.nrows + 2 * KK_TPB - 1) / (2 * KK_TPB));
-        const int per = (nb_logical + 7) / 8;
-        const int nbx = std::min(per, KK_MAX_BLOCKS / 8);
-        nblk = nbx * 8;
-        hipLaunchKernelGGL(k_spmv_ell, dim3(nblk), dim3(KK_TPB), 0, ctx->stream, M.ell_col, M.ell_val, M.ell_ld, M.width,
-                           M.nrows, x, y, e, nb_logical, pd, pn);
+        launch_spmv_ell_rows(ctx, M, x, y, e, 0, M.nrows, pd, pn, &nblk, KK_MAX_BLOCKS);
     } else {
         const int L = M.lanes_per_row;
         const int rpb = KK_TPB / L;
@@ -618,12 +645,20 @@ int kk_launch_spmm(kk_ctx ctx, const kk_sparse_dev& M, const double* X, int64_t 
         }
         return KK_OK;
     }
-    if (M.dia_D > 0 && ctx->spmm_dia && !ghost_block && M.n_ghost == 0 && nb >= 2) {
-        // grid stencil: sweep the lines with a register window (every element of X read once)
+    const double* G = nullptr;
+    int64_t ldg = 0, nloc = -1;
+    if (ghost_block) {
+        KK_TRY(kk_halo_exchange_block(ctx, M, X, ldx, nb, &G, &ldg));
+        nloc = M.n_local;
+    }
+    // grid stencil: sweep the lines with a register window (every element of X read once) -- the whole operator, or the
+    // ghost-free interior rows of a row-sharded one
+    auto launch_dia = [&](int64_t row_lo, int64_t row_hi) {
+        if (row_hi <= row_lo) return;
         const int strips = (int)((M.dia_D + 61) / 62);
-        const int64_t T = (M.nrows + M.dia_D - 1) / M.dia_D;
+        const int64_t Tlo = row_lo / M.dia_D, T = (row_hi + M.dia_D - 1) / M.dia_D;
         const int lines = ctx->spmm_dia_lines;
-        const int64_t waves = (int64_t)strips * ((T + lines - 1) / lines);
+        const int64_t waves = (int64_t)strips * ((T - Tlo + lines - 1) / lines);
         dim3 g((unsigned)((waves + KK_TPB / 64 - 1) / (KK_TPB / 64))), b(KK_TPB);
         int j0 = 0;
         while (j0 < nb) {
@@ -632,7 +667,7 @@ int kk_launch_spmm(kk_ctx ctx, const kk_sparse_dev& M, const double* X, int64_t 
             const double* x = X + (int64_t)j0 * ldx;
             double* y = Y + (int64_t)j0 * ldy;
             kk_prof_scope ps(ctx, "k_spmm_dia");
-#define DIA_ARGS M.dia_val, M.dia_ld, M.dia_D, M.nrows, x, ldx, y, ldy, n, strips, lines, T
+#define DIA_ARGS M.dia_val, M.dia_ld, M.dia_D, M.nrows, x, ldx, y, ldy, n, strips, lines, Tlo, T, row_lo, row_hi
 #define DIA_CASE(NBT) \
             if (M.dia_pts == 5) hipLaunchKernelGGL((k_spmm_dia<NBT, 5>), g, b, 0, ctx->stream, DIA_ARGS); \
             else hipLaunchKernelGGL((k_spmm_dia<NBT, 9>), g, b, 0, ctx->stream, DIA_ARGS);
@@ -643,44 +678,51 @@ int kk_launch_spmm(kk_ctx ctx, const kk_sparse_dev& M, const double* X, int64_t 
 #undef DIA_ARGS
             j0 += n;
         }
-        KK_HIP(hipGetLastError());
-        return KK_OK;
-    }
-    const int rpl = ctx->spmm_rpl == 1 ? 1 : 2;
-    const int nb_logical = (int)((M.nrows + rpl * KK_TPB - 1) / (rpl * KK_TPB));
-    const int per = (nb_logical + 7) / 8;
-    // Each XCD sweeps a contiguous band of rows; the rows its resident blocks work on at one time are the window whose
-    // gathered entries must stay in that XCD's 4 MB L2 for the +-nx neighbours of a stencil to be L2 hits.  With nb
-    // right-hand sides the window holds nb columns: spmm_bpc resident blocks per CU x 32 CUs x 256*rpl rows x nb x 8 bytes
-    // (2 blocks per CU, 2 rows per lane, nb = 16: 4 MB), so the grid is capped instead of filling every slot as the
-    // 1-column SpMV does.
-    int nbx = std::min(per, KK_MAX_BLOCKS / 8);
-    if (ctx->spmm_bpc > 0) nbx = std::min(nbx, std::max(1, ctx->num_cus / 8) * ctx->spmm_bpc);
-    dim3 g(nbx * 8), b(KK_TPB);
-    const double* G = nullptr;
-    int64_t ldg = 0, nloc = -1;
-    if (ghost_block) {
-        KK_TRY(kk_halo_exchange_block(ctx, M, X, ldx, nb, &G, &ldg));
-        nloc = M.n_local;
-    }
-    int j0 = 0;
-    while (j0 < nb) {
-        const int rem = nb - j0;
-        const double* x = X + (int64_t)j0 * ldx;
-        double* y = Y + (int64_t)j0 * ldy;
-        const double* gj = G ? G + (int64_t)j0 * ldg : nullptr;
-        kk_prof_scope ps(ctx, "k_spmm_ell");
-        const int n = std::min(rem > 8 ? std::min(rem, 16) : rem, ctx->spmm_cols);   // spmm_cols < 16: narrower row window per XCD
-#define SPMM_ARGS M.ell_col, M.ell_val, M.ell_ld, M.width, M.nrows, x, ldx, y, ldy, n, nb_logical, nloc, gj, ldg
+    };
+    // gather kernel on the rows [r0, r1)
+    auto launch_ell = [&](int64_t r0, int64_t r1) {
+        if (r1 <= r0) return;
+        const int rpl = ctx->spmm_rpl == 1 ? 1 : 2;
+        const int nb_logical = (int)((r1 - r0 + rpl * KK_TPB - 1) / (rpl * KK_TPB));
+        const int per = (nb_logical + 7) / 8;
+        // Each XCD sweeps a contiguous band of rows; the rows its resident blocks work on at one time are the window whose
+        // gathered entries must stay in that XCD's 4 MB L2 for the +-nx neighbours of a stencil to be L2 hits.  With nb
+        // right-hand sides the window holds nb columns: spmm_bpc resident blocks per CU x 32 CUs x 256*rpl rows x nb x 8 bytes
+        // (2 blocks per CU, 2 rows per lane, nb = 16: 4 MB), so the grid is capped instead of filling every slot as the
+        // 1-column SpMV does.
+        int nbx = std::min(per, KK_MAX_BLOCKS / 8);
+        if (ctx->spmm_bpc > 0) nbx = std::min(nbx, std::max(1, ctx->num_cus / 8) * ctx->spmm_bpc);
+        if (nbx < 1) nbx = 1;
+        dim3 g(nbx * 8), b(KK_TPB);
+        int j0 = 0;
+        while (j0 < nb) {
+            const int rem = nb - j0;
+            const double* x = X + (int64_t)j0 * ldx;
+            double* y = Y + (int64_t)j0 * ldy;
+            const double* gj = G ? G + (int64_t)j0 * ldg : nullptr;
+            kk_prof_scope ps(ctx, "k_spmm_ell");
+            const int n = std::min(rem > 8 ? std::min(rem, 16) : rem, ctx->spmm_cols);   // spmm_cols < 16: narrower row window per XCD
+#define SPMM_ARGS M.ell_col, M.ell_val, M.ell_ld, M.width, M.nrows, x, ldx, y, ldy, n, nb_logical, nloc, gj, ldg, r0, r1
 #define SPMM_CASE(NBT) \
-        if (rpl == 1) hipLaunchKernelGGL((k_spmm_ell<NBT, 1>), g, b, 0, ctx->stream, SPMM_ARGS); \
-        else hipLaunchKernelGGL((k_spmm_ell<NBT, 2>), g, b, 0, ctx->stream, SPMM_ARGS);
-        if (n > 8) { SPMM_CASE(16) }
-        else if (n > 4) { SPMM_CASE(8) }
-        else { SPMM_CASE(4) }
+            if (rpl == 1) hipLaunchKernelGGL((k_spmm_ell<NBT, 1>), g, b, 0, ctx->stream, SPMM_ARGS); \
+            else hipLaunchKernelGGL((k_spmm_ell<NBT, 2>), g, b, 0, ctx->stream, SPMM_ARGS);
+            if (n > 8) { SPMM_CASE(16) }
+            else if (n > 4) { SPMM_CASE(8) }
+            else { SPMM_CASE(4) }
 #undef SPMM_CASE
 #undef SPMM_ARGS
-        j0 += n;
+            j0 += n;
+        }
+    };
+    const bool dia_ok = M.dia_D > 0 && ctx->spmm_dia && nb >= 2;
+    if (dia_ok && M.n_ghost == 0) {
+        launch_dia(0, M.nrows);
+    } else if (dia_ok && ghost_block && M.int_hi > M.int_lo) {
+        launch_dia(M.int_lo, M.int_hi);
+        launch_ell(0, M.int_lo);
+        launch_ell(M.int_hi, M.nrows);
+    } else {
+        launch_ell(0, M.nrows);
     }
     KK_HIP(hipGetLastError());
     return KK_OK;

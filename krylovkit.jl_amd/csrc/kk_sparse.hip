@@ -142,6 +142,7 @@ static int detect_stencil(const kk_host_csr& h, kk_sparse_dev& M) {
     if (getenv("KK_NO_DIA")) return KK_OK;
     const int64_t n = h.nrows, nnz = h.rowptr[n];
     if (n != h.ncols || n < 4096 || nnz < n) return KK_OK;
+    if (M.dia_val) { (void)hipFree(M.dia_val); M.dia_val = nullptr; }
     int64_t offs[9];
     int no = 0;
     for (int64_t i = 0; i < n; ++i)
@@ -193,6 +194,41 @@ static int detect_stencil(const kk_host_csr& h, kk_sparse_dev& M) {
     KK_HIP(hipMemcpy(M.dia_val, dv.data(), dv.size() * sizeof(double), hipMemcpyHostToDevice));
     M.dia_D = D; M.dia_pts = pts; M.dia_ld = dld;
     M.bytes += (int64_t)dv.size() * 8;
+    return KK_OK;
+}
+
+// Row-sharded stencil: the rows of the local block that reference no ghost column form (for a partition along grid lines)
+// one long run [int_lo, int_hi); if the local square part of the block has the grid-stencil structure, those rows can use
+// the diagonal kernels and only the boundary strips need the gather kernels with the ghost buffer.
+static int detect_stencil_sharded(const kk_host_csr& h, int64_t n_local, kk_sparse_dev& M) {
+    M.int_lo = M.int_hi = 0;
+    if (getenv("KK_NO_DIA") || M.format != 0 || n_local < 4096) return KK_OK;
+    // longest run of rows without ghost references
+    int64_t best_lo = 0, best_hi = 0, run_lo = 0;
+    for (int64_t i = 0; i <= n_local; ++i) {
+        bool ghost = (i == n_local);
+        if (!ghost)
+            for (int64_t p = h.rowptr[i]; p < h.rowptr[i + 1] && !ghost; ++p) ghost = h.col[p] >= n_local;
+        if (ghost) {
+            if (i - run_lo > best_hi - best_lo) { best_lo = run_lo; best_hi = i; }
+            run_lo = i + 1;
+        }
+    }
+    best_lo = (best_lo + 1) & ~(int64_t)1;   // both ends even: the kernels handle rows in pairs
+    best_hi = best_hi & ~(int64_t)1;
+    if (best_hi - best_lo < n_local / 2) return KK_OK;
+    // local square part (ghost entries dropped: the rows that have any are outside the interior and never use the diagonals)
+    kk_host_csr sq;
+    sq.nrows = n_local; sq.ncols = n_local;
+    sq.rowptr.assign(n_local + 1, 0);
+    sq.col.reserve(h.col.size()); sq.val.reserve(h.val.size());
+    for (int64_t i = 0; i < n_local; ++i) {
+        for (int64_t p = h.rowptr[i]; p < h.rowptr[i + 1]; ++p)
+            if (h.col[p] < n_local) { sq.col.push_back(h.col[p]); sq.val.push_back(h.val[p]); }
+        sq.rowptr[i + 1] = (int64_t)sq.col.size();
+    }
+    KK_TRY(detect_stencil(sq, M));
+    if (M.dia_D > 0) { M.int_lo = best_lo; M.int_hi = best_hi; }
     return KK_OK;
 }
 
@@ -440,6 +476,7 @@ KK_API int kk_csr_create_sharded(kk_ctx c, int64_t nrows_local, const int64_t* r
                                 : (int32_t)(nrows_local + (std::lower_bound(needed.begin(), needed.end(), g) - needed.begin()));
     }
     int s = upload_sparse(c, h, op->A);
+    if (s == KK_OK && n_ghost > 0) s = detect_stencil_sharded(h, nrows_local, op->A);
     if (s != KK_OK) { free_sparse(op->A); delete op; return s; }
     kk_halo_plan* plan = new kk_halo_plan();
     op->A.plan = plan;

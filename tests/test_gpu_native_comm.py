@@ -234,3 +234,65 @@ def test_loopback_ghost_plan_runs_the_whole_exchange_path(kk, ko, comm, monkeypa
         obf = ko.blocklanczos_expand(obit, obf)
     k = len(bf)
     np.testing.assert_allclose(np.linalg.eigvalsh(bf.H[:k, :k]), np.linalg.eigvalsh(obf.H[:k, :k]), atol=1e-9)
+
+
+@pytest.mark.parametrize("nine", [False, True])
+def test_loopback_sharded_stencil_uses_diagonal_kernels_on_the_interior(kk, ko, comm, monkeypatch, nine):
+    """A row-sharded grid stencil runs the diagonal kernels on its ghost-free interior rows and the gather kernels (ghost
+    buffer) on the boundary strips.  One-GPU coverage through the loop-back plan: the last grid line(s) of a world-1 operator
+    are routed through the ghost machinery, so the rows that reference them form the boundary strip."""
+    import scipy.sparse as sp
+    from krylovkit_hip import dist as kd
+    from krylovkit_hip._lib import check
+    ctx = comm.ctx
+    rng = np.random.default_rng(31 + nine)
+    nx, ny = 70, 66
+    n = nx * ny
+    if nine:   # symmetric 9-point operator with row-dependent coefficients
+        ix, iy = np.meshgrid(np.arange(nx), np.arange(ny)); ix, iy = ix.ravel(), iy.ravel()
+        rows, cols, vals = [], [], []
+        for dy, dx in ((0, 1), (1, -1), (1, 0), (1, 1)):
+            ok = (ix + dx >= 0) & (ix + dx < nx) & (iy + dy < ny)
+            r = (iy * nx + ix)[ok]
+            rows.append(r); cols.append(r + dy * nx + dx); vals.append(rng.standard_normal(r.size))
+        U = sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(n, n))
+        A = (U + U.T + sp.diags(4.0 + rng.random(n))).tocsr()
+    else:
+        A = ko.laplacian_2d(nx, ny, shift_diag=10 * np.linspace(0, 1, n) ** 2)
+    part = kd.Partition.even(n, 1, 0)
+    ghost_from = n - nx - 3                      # a bit more than the last grid line goes through the ghost buffer
+    monkeypatch.setenv("KK_LOOPBACK_GHOST_FROM", str(ghost_from))
+    op = kd.NativeShardedOperator(A, part, ctx, symmetric=True)
+    monkeypatch.delenv("KK_LOOPBACK_GHOST_FROM")
+    assert op.info()["ncols"] > n and op.info()["format"] == "ELL+DIA"
+    B = kk.DeviceBasis(n, 40, ctx)
+    X = rng.standard_normal((n, 16))
+    for j in range(16):
+        B.upload(j, X[:, j])
+    for dia in (1, 0):
+        ctx.set_option("spmv_dia", dia); ctx.set_option("spmm_dia", dia)
+        ctx.prof_reset(); ctx.prof_enable(1)
+        op.apply(B[3], B[20])
+        ctx.prof_enable(0)
+        assert (ctx.prof_get("k_spmv_dia")[1] > 0) == bool(dia)
+        np.testing.assert_allclose(B[20].get(), A @ X[:, 3], rtol=0, atol=1e-12)
+        op.apply_affine(B[3], B[21], 0.7, -0.4)
+        np.testing.assert_allclose(B[21].get(), 0.7 * X[:, 3] - 0.4 * (A @ X[:, 3]), rtol=0, atol=1e-12)
+        for nb in (2, 5, 8, 16):
+            ctx.prof_reset(); ctx.prof_enable(1)
+            check(ctx._lib.kk_block_apply(op.handle, B.handle, 0, B.handle, 20, nb))
+            ctx.prof_enable(0)
+            assert (ctx.prof_get("k_spmm_dia")[1] > 0) == bool(dia) and ctx.prof_get("k_spmm_ell")[1] > 0   # interior + strips
+            Y = np.stack([B.download(20 + j) for j in range(nb)], 1)
+            np.testing.assert_allclose(Y, A @ X[:, :nb], rtol=0, atol=1e-11)
+        # fused Lanczos epilogues (inner products and norms summed over the three launches of one apply)
+        x0 = np.random.default_rng(5).random(n)
+        it = kk.LanczosIterator(op, x0, kk.ModifiedGramSchmidt2(), capacity=24)
+        f = kk.initialize(it)
+        oit = ko.LanczosIterator(A, x0.copy(), ko.MGS2)
+        of = ko.lanczos_initialize(oit)
+        for _ in range(20):
+            f = kk.expand_(it, f)
+            of = ko.lanczos_expand(oit, of)
+        assert relerr(f.alphas, of.alphas) < 1e-10 and relerr(f.betas, of.betas) < 1e-10
+    ctx.set_option("spmv_dia", 1); ctx.set_option("spmm_dia", 1)
