@@ -77,7 +77,8 @@ typedef enum {
  * cache-allocated for the unproject pass that follows; default 160 of the 256 MB Infinity Cache, 0 = none),
  * "block_async" (whole BlockLanczos step enqueued without a host round trip, default 1), "block_fuse" (bit mask of its
  * pass structure: 1 = second CholQR2 round fused, 4 = one-pass projection with Gram correction; default 5; 0 / 1 = the
- * reference's three-term-then-reorthogonalise order), "spmv_dia" / "spmm_dia" (diagonal kernels for operators detected
+ * reference's three-term-then-reorthogonalise order), "qr_skip_tol" (the second CholQR2 back-substitution of that step is
+ * skipped when the block is orthonormal to this level after the first; default 2e-14, 0 = never), "spmv_dia" / "spmm_dia" (diagonal kernels for operators detected
  * as grid stencils, default 1; 0 = the general ELL gather kernels).  Tuning knobs without semantic effect:
  * "gram_bpc", "gram2_chunk", "spmm_bpc", "spmm_cols", "spmm_rpl", "spmm_dia_lines", "bu_prefetch", "gram_nt", "persist_nt". */
 

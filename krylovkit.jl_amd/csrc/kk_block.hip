@@ -368,7 +368,8 @@ static int blocklanczos_expand_async(kk_op op, kk_basis b, int k, int p, int c_r
     }
     KK_TRY(kk_allreduce(c, D + AB_G, (int64_t)p * p));
     KK_TRY(kk_launch_blk_chol2(c, D + AB_G, p, D + AB_R1, D + AB_B, 16, D + AB_S2, D + AB_S3, st, D + AB_FLAG));
-    KK_TRY(kk_launch_block_update(c, b->col(k), ld, p, nullptr, b->col(k), ld, ld, p, D + AB_S2, 1.0, 0.0, nullptr));  // Q = Q1 R2^-1 in place (row-local)
+    // Q = Q1 R2^-1 in place (row-local); not executed when k_blk_chol2 found Q1 orthonormal already (device flag)
+    KK_TRY(kk_launch_block_update(c, b->col(k), ld, p, nullptr, b->col(k), ld, ld, p, D + AB_S2, 1.0, 0.0, nullptr, D + AB_FLAG + 1));
     // ---- block_lanczosrecurrence: AX = A X ; M = X' AX ; AX -= [Xprev X] [B' ; M]
     double* AX = b->col(c_rnext);
     KK_TRY(kk_launch_spmm(c, op->A, b->col(k), ld, AX, ld, p));
@@ -425,6 +426,7 @@ readback:
     KK_HIP(hipMemcpyAsync(c->h_blk + AB_BASE, D + AB_BASE, AB_READBACK * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     KK_TRY(stream_sync(c));
     const double* H = c->h_blk + AB_BASE;
+    c->last_qr_dev = H[2];
     *fine = (H[0] == 0.0);
     if (!*fine) return KK_OK;
     if (onepass) {   // host mirror of the new Gram rows (strictly-lower storage), as the device kernel wrote them

@@ -184,6 +184,9 @@ KK_API int kk_ctx_set_option(kk_ctx c, const char* key, double value) {
     } else if (!strcmp(key, "spmm_rpl")) {
         KK_CHECK(value == 1 || value == 2, KK_ERR_INVALID, "spmm_rpl must be 1 or 2");
         c->spmm_rpl = (int)value;
+    } else if (!strcmp(key, "qr_skip_tol")) {
+        KK_CHECK(value >= 0 && value <= 1e-8, KK_ERR_INVALID, "qr_skip_tol must be in [0, 1e-8]");
+        c->qr_skip_tol = value;
     } else if (!strcmp(key, "gram2_chunk")) {
         KK_CHECK(value == 64 || value == 80 || value == 128, KK_ERR_INVALID, "gram2_chunk must be 64, 80 or 128");
         c->gram2_chunk = (int)value;
@@ -233,6 +236,8 @@ KK_API int kk_ctx_get_option(kk_ctx c, const char* key, double* value) {
     else if (!strcmp(key, "spmm_rpl")) *value = c->spmm_rpl;
     else if (!strcmp(key, "gram_bpc")) *value = c->gram_bpc;
     else if (!strcmp(key, "gram2_chunk")) *value = c->gram2_chunk;
+    else if (!strcmp(key, "qr_skip_tol")) *value = c->qr_skip_tol;
+    else if (!strcmp(key, "last_qr_dev")) *value = c->last_qr_dev;
     else if (!strcmp(key, "gram_nt")) *value = c->gram_nt;
     else {
         kk_set_error("unknown option '%s'", key);

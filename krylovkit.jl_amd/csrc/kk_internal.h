@@ -120,6 +120,8 @@ struct kk_ctx_s {
     int spmm_cols = 16;          // SpMM on ELL: right-hand sides per launch (16, 8 or 4)
     int bu_prefetch = 1;         // block update kernel: 1 = coefficient panel in LDS (default), 0 = scalar-load kernel of round 1, 8/16/24 = deep-prefetch experiments
     int gram_nt = 0;             // Gram panel: non-temporal loads for the X stream
+    double qr_skip_tol = 2e-14;  // async block step: skip the second CholQR2 back-substitution when |Q1'Q1 - I|_max <= this (0: never)
+    double last_qr_dev = 0;      // |Q1'Q1 - I|_max of the last asynchronous block step (diagnostics)
     int gram2_chunk = 80;        // two-panel Gram kernel (one-pass block step): basis columns per launch (64, 80 or 128)
     int gram_bpc = 8;            // Gram panel: blocks per CU of a one-group (p <= 16) launch; NG groups -> gram_bpc / NG, >= 2
     int block_fuse = 5;          // async block step, bit mask: 1 = CholQR2 round 2 fused (update + Gram in one pass), 2 = three-term
@@ -344,7 +346,8 @@ int kk_launch_block_gram_tile(kk_ctx ctx, const double* X, int64_t ldx, int p, c
 // row stride (= kernel width NB) of the coefficient panel handed to kk_launch_block_update for nb right-hand sides
 static inline int kk_bu_stride(int nb) { return nb <= 4 ? 4 : (nb <= 8 ? 8 : 16); }
 int kk_launch_block_update(kk_ctx ctx, const double* V, int64_t ld, int m, const double* Win, double* Wout, int64_t ldw_in,
-                           int64_t ldw_out, int nb, const double* S_dev, double alpha, double beta, double* norms2_dev);
+                           int64_t ldw_out, int nb, const double* S_dev, double alpha, double beta, double* norms2_dev,
+                           const double* skip_dev = nullptr);
 int kk_launch_spmm(kk_ctx ctx, const kk_sparse_dev& M, const double* X, int64_t ldx, double* Y, int64_t ldy, int nb);
 int kk_launch_unproj_proj(kk_ctx ctx, const double* V, int64_t ld, int m, const double* w_in, double* w_out,
                           const kk_coef* coef_host, const double* coef_dev, double* out_s, double* nrm_out3);

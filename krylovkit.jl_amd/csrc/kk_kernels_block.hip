@@ -399,22 +399,39 @@ __global__ __launch_bounds__(64) void k_blk_chol1(const double* __restrict__ G, 
 // rows 0..p-1 of the three-term panel S3 (row-major, stride st): S3[i][j] = B[j][i]
 __global__ __launch_bounds__(64) void k_blk_chol2(const double* __restrict__ G2, int p, const double* __restrict__ R1,
                                                   double* __restrict__ Bout, int ldb, double* __restrict__ S2, double* __restrict__ S3,
-                                                  int st, double* __restrict__ flag) {
+                                                  int st, double* __restrict__ flag, double skip_tol) {
     __shared__ double R[16][17], Ri[16][17], Bm[16][17];
-    __shared__ int bad_s;
-    if (threadIdx.x == 0) bad_s = 0;
-    wave_sync();
+    __shared__ double devs[64];
     {
-        bool bad = false;
+        double dev = 0.0;
         for (int e = threadIdx.x; e < p * p; e += 64) {
             const int i = e % p, j = e / p;
-            if (!(fabs(G2[e] - (i == j ? 1.0 : 0.0)) < 1e-3)) bad = true;   // NaN compares false -> flagged
+            const double d = fabs(G2[e] - (i == j ? 1.0 : 0.0));
+            dev = (d > dev || !(d == d)) ? (d == d ? d : 1e300) : dev;   // NaN -> huge -> flagged
         }
-        if (bad) bad_s = 1;
+        devs[threadIdx.x] = dev;
     }
     wave_sync();
+    double dev = 0.0;
+    for (int t = 0; t < 64; ++t) dev = fmax(dev, devs[t]);   // every lane: the same value
     if (flag[0] != 0.0) return;   // first factor already failed
-    if (bad_s != 0) { if (threadIdx.x == 0) flag[0] = 2.0; return; }
+    if (threadIdx.x == 0) flag[2] = dev;   // |Q1'Q1 - I|_max of this step (diagnostics)
+    if (!(dev < 1e-3)) { if (threadIdx.x == 0) flag[0] = 2.0; return; }
+    if (dev <= skip_tol) {
+        // Q1 = W R1^-1 is orthonormal to skip_tol already (a well-conditioned block: cond(W)^2 eps): the second round would
+        // be the identity up to that level.  B = R1, the back-substitution panel is the identity and flag[1] tells the
+        // update kernel that follows not to run at all (one read and one write of the block saved).
+        for (int e = threadIdx.x; e < p * p; e += 64) { const int i = e % p, j = e / p; Bm[i][j] = (i <= j) ? R1[i + p * j] : 0.0; }
+        wave_sync();
+        for (int e = threadIdx.x; e < p * p; e += 64) Bout[(e % p) + ldb * (e / p)] = Bm[e % p][e / p];
+        for (int e = threadIdx.x; e < p * st; e += 64) {
+            const int i = e / st, j = e % st;
+            S2[e] = (j == i) ? 1.0 : 0.0;
+            S3[e] = j < p ? Bm[j][i] : 0.0;
+        }
+        if (threadIdx.x == 0) flag[1] = 1.0;
+        return;
+    }
     const bool ok = chol16(G2, p, R, 1e-2, 0.0);
     if (!ok) { if (threadIdx.x == 0) flag[0] = 2.0; return; }
     triu_inv16(R, p, Ri);
@@ -588,7 +605,11 @@ template <int NB, bool BZERO>
 __global__ __launch_bounds__(KK_TPB, 4) void k_block_update_lds(const double* V, int64_t ld, int m, const double* Win,
                                                              double* Wout, int64_t ldw_in, int64_t ldw_out, int nb,
                                                              const double* __restrict__ S, double alpha, double beta,
-                                                             int64_t rpb, double* __restrict__ part_nrm) {
+                                                             int64_t rpb, double* __restrict__ part_nrm,
+                                                             const double* __restrict__ skip) {
+    // `skip` (optional device flag): the transform is the identity -- decided on the device by an earlier kernel of the
+    // same stream (second CholQR2 round of a block that is orthonormal already) -- and the pass is not executed
+    if (skip && *skip != 0.0) return;
     extern __shared__ __attribute__((aligned(16))) double ssm[];   // [m][NB] coefficients, then [NB][4] norm slots
     double* nsl = ssm + (size_t)m * NB;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -745,7 +766,7 @@ int kk_launch_blk_chol1(kk_ctx ctx, const double* G, int p, double abs_min, doub
 }
 int kk_launch_blk_chol2(kk_ctx ctx, const double* G2, int p, const double* R1, double* B, int ldb, double* S2, double* S3, int st,
                         double* flag) {
-    hipLaunchKernelGGL(k_blk_chol2, dim3(1), dim3(64), 0, ctx->stream, G2, p, R1, B, ldb, S2, S3, st, flag);
+    hipLaunchKernelGGL(k_blk_chol2, dim3(1), dim3(64), 0, ctx->stream, G2, p, R1, B, ldb, S2, S3, st, flag, ctx->qr_skip_tol);
     KK_HIP(hipGetLastError());
     return KK_OK;
 }
@@ -920,7 +941,8 @@ int kk_launch_block_gram2(kk_ctx ctx, const double* X, int64_t ldx, int p, const
 
 // Wout[:, j] = beta*Win[:, j] + alpha * sum_c V[:, c] S_dev[c*nb + j], j < nb <= 16; optional norms2_dev[nb]
 int kk_launch_block_update(kk_ctx ctx, const double* V, int64_t ld, int m, const double* Win, double* Wout, int64_t ldw_in,
-                           int64_t ldw_out, int nb, const double* S_dev, double alpha, double beta, double* norms2_dev) {
+                           int64_t ldw_out, int nb, const double* S_dev, double alpha, double beta, double* norms2_dev,
+                           const double* skip_dev) {
     if (nb <= 0) return KK_OK;
     if (nb > 16) { kk_set_error("kk_launch_block_update: nb=%d > 16", nb); return KK_ERR_INVALID; }
     kk_part p = kk_partition(ctx, ld);
@@ -937,8 +959,8 @@ int kk_launch_block_update(kk_ctx ctx, const double* V, int64_t ld, int m, const
         else hipLaunchKernelGGL((k_block_update_pf<NBT, false, PFD>), g, b, 0, ctx->stream, V, ld, m, Win, Wout, ldw_in, ldw_out, nb, S_dev, alpha, beta, p.rpb, part);
         const size_t shm = ((size_t)m * kk_bu_stride(nb) + 64) * sizeof(double);
 #define BU_LDS(NBT) \
-        if (bz) hipLaunchKernelGGL((k_block_update_lds<NBT, true>), g, b, shm, ctx->stream, V, ld, m, Win, Wout, ldw_in, ldw_out, nb, S_dev, alpha, beta, p.rpb, part); \
-        else hipLaunchKernelGGL((k_block_update_lds<NBT, false>), g, b, shm, ctx->stream, V, ld, m, Win, Wout, ldw_in, ldw_out, nb, S_dev, alpha, beta, p.rpb, part);
+        if (bz) hipLaunchKernelGGL((k_block_update_lds<NBT, true>), g, b, shm, ctx->stream, V, ld, m, Win, Wout, ldw_in, ldw_out, nb, S_dev, alpha, beta, p.rpb, part, skip_dev); \
+        else hipLaunchKernelGGL((k_block_update_lds<NBT, false>), g, b, shm, ctx->stream, V, ld, m, Win, Wout, ldw_in, ldw_out, nb, S_dev, alpha, beta, p.rpb, part, skip_dev);
         if (ctx->bu_prefetch == 1 && m * kk_bu_stride(nb) <= 8192) { if (nb <= 4) { BU_LDS(4) } else if (nb <= 8) { BU_LDS(8) } else { BU_LDS(16) } }
         else if (nb > 8 && ctx->bu_prefetch == 16) { BU_PF(16, 16) }
         else if (nb > 8 && ctx->bu_prefetch == 8) { BU_PF(16, 8) }

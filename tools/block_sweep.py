@@ -38,14 +38,10 @@ def run():
     return time.perf_counter() - t0, steps, alg, f
 
 
-variants = [("two-pass (three-term, then panel), gather SpMM", dict(block_fuse=1, spmm_dia=0)),
-            ("one-pass projection with Gram correction, gather SpMM", dict(block_fuse=5, spmm_dia=0)),
-            ("one-pass projection with Gram correction, sweeping SpMM, 16 lines per sweep (shipped)", dict(block_fuse=5, spmm_dia=1, spmm_dia_lines=16)),
-            ("shipped, 8 grid lines per wave sweep", dict(spmm_dia_lines=8)),
-            ("shipped, 12 grid lines per wave sweep", dict(spmm_dia_lines=12)),
-            ("shipped, 24 grid lines per wave sweep", dict(spmm_dia_lines=24)),
-            ("shipped, 16 lines, 8 columns per launch", dict(spmm_dia_lines=16, spmm_cols=8)),
-            ("shipped, 32 lines, 8 columns per launch", dict(spmm_dia_lines=32, spmm_cols=8))]
+variants = [("two-pass (three-term, then panel), gather SpMM, both CholQR2 rounds", dict(block_fuse=1, spmm_dia=0, qr_skip_tol=0)),
+            ("one-pass projection with Gram correction, sweeping SpMM, both CholQR2 rounds", dict(block_fuse=5, spmm_dia=1, qr_skip_tol=0)),
+            ("shipped: + second back-substitution skipped when |Q1'Q1 - I| <= 2e-14", dict(qr_skip_tol=2e-14)),
+            ("skip threshold 1e-12", dict(qr_skip_tol=1e-12))]
 for name, opts in variants:
     for k_, v in opts.items():
         ctx.set_option(k_, v)
@@ -59,5 +55,5 @@ for name, opts in variants:
     ctx.prof_enable(0)
     prof = {k_: round(ctx.prof_get(k_)[0], 2) for k_ in ("k_block_gram", "k_block_update", "k_spmm_ell", "k_spmm_dia", "k_block_qr_fused") if ctx.prof_get(k_)[1]}
     print(json.dumps({"variant": name, "ms_per_block_step": round(best / steps * 1e3, 3), "frac_8TBps": round(alg / best / 8e12, 4),
-                      "normres": f.normres, "kernel_ms_one_run": prof}), flush=True)
-ctx.set_option("block_fuse", 5); ctx.set_option("spmm_dia_lines", 16); ctx.set_option("spmm_cols", 16)
+                      "normres": f.normres, "last_qr_dev": ctx.get_option("last_qr_dev") if hasattr(ctx, "get_option") else None, "kernel_ms_one_run": prof}), flush=True)
+ctx.set_option("block_fuse", 5); ctx.set_option("qr_skip_tol", 2e-14)
