@@ -78,7 +78,8 @@ typedef enum {
  * "block_async" (whole BlockLanczos step enqueued without a host round trip, default 1), "block_fuse" (bit mask of its
  * pass structure: 1 = second CholQR2 round fused, 4 = one-pass projection with Gram correction; default 5; 0 / 1 = the
  * reference's three-term-then-reorthogonalise order), "qr_skip_tol" (the second CholQR2 back-substitution of that step is
- * skipped when the block is orthonormal to this level after the first; default 2e-14, 0 = never), "spmv_dia" / "spmm_dia" (diagonal kernels for operators detected
+ * skipped when the block is orthonormal to this level after the first; default 2e-14, 0 = never), "resid_gram" (Gram matrix of the residual block handed from one step to the next, default 1),
+ * "spmv_dia" / "spmm_dia" (diagonal kernels for operators detected
  * as grid stencils, default 1; 0 = the general ELL gather kernels).  Tuning knobs without semantic effect:
  * "gram_bpc", "gram2_chunk", "spmm_bpc", "spmm_cols", "spmm_rpl", "spmm_dia_lines", "bu_prefetch", "gram_nt", "persist_nt". */
 

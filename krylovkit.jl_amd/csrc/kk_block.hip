@@ -332,7 +332,9 @@ KK_API int kk_blocklanczos_initialize(kk_op op, kk_basis b, int c_x0, int bs0, i
 #define AB_S3 (AB_BASE + 1556)       // [512] three-term panel [B' ; M]
 #define AB_P (AB_BASE + 2068)        // [3 * KK_MAX_M * 16] re-orthogonalisation panel V'(AX), row-major; the one-pass step appends
                                      // the ride-along Gram panel V'X and the corrected panel (kn * st doubles each)
-#define AB_END (AB_P + 3 * KK_MAX_M * 16)
+#define AB_GYY (AB_P + 3 * KK_MAX_M * 16)   // [256] (A X)'(A X), column-major ld 16 (one-pass step)
+#define AB_GW (AB_GYY + 256)                // [256] Gram matrix of the residual block left behind, column-major ld p
+#define AB_END (AB_GW + 256)
 static_assert(AB_END <= KK_BLK_SCRATCH, "block scratch too small for the asynchronous block step");
 
 // expand!(::BlockLanczosIterator) without a host round trip between its kernels (panel mode, 2 <= block size <= 16, no rank
@@ -341,7 +343,7 @@ static_assert(AB_END <= KK_BLK_SCRATCH, "block scratch too small for the asynchr
 // ONE host synchronisation at the end returns B, M, the column norms and the safety flag.  The input block (c_r) and the
 // basis are not modified, so a raised flag (*fine = false) simply sends the caller to the synchronous route below.
 static int blocklanczos_expand_async(kk_op op, kk_basis b, int k, int p, int c_r, int c_rnext, double qr_tol, double* B,
-                                     int ldb, double* M, int ldm, double* norm_R, bool* fine) {
+                                     int ldb, double* M, int ldm, double* norm_R, bool* fine, bool use_gw) {
     kk_ctx c = b->ctx;
     const int64_t ld = b->ld;
     const int st = kk_bu_stride(p);
@@ -356,8 +358,12 @@ static int blocklanczos_expand_async(kk_op op, kk_basis b, int k, int p, int c_r
     }
     KK_HIP(hipMemsetAsync(D + AB_FLAG, 0, 4 * sizeof(double), c->stream));
     // ---- block_qr! as CholQR2, out of place: residual block (c_r) -> new basis block (columns k..k+p-1)
-    KK_TRY(kk_launch_block_gram(c, b->col(c_r), ld, p, b->col(c_r), ld, p, ld, D + AB_G, p));
-    KK_TRY(kk_allreduce(c, D + AB_G, (int64_t)p * p));
+    if (use_gw) {   // the previous step left the Gram matrix of this very block behind (all-reduced already)
+        KK_HIP(hipMemcpyAsync(D + AB_G, D + AB_GW, (size_t)p * p * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    } else {
+        KK_TRY(kk_launch_block_gram(c, b->col(c_r), ld, p, b->col(c_r), ld, p, ld, D + AB_G, p));
+        KK_TRY(kk_allreduce(c, D + AB_G, (int64_t)p * p));
+    }
     KK_TRY(kk_launch_blk_chol1(c, D + AB_G, p, 1000.0 * qr_tol, D + AB_R1, D + AB_S1, st, D + AB_FLAG));
     if (c->block_fuse & 1) {   // Q1 = B R1^-1 written and G2 = Q1'Q1 accumulated in ONE pass over the block
         KK_TRY(kk_launch_block_gram_tile(c, nullptr, 0, p, nullptr, 0, b->col(c_r), ld, p, D + AB_S1, st, 1.0, 0.0, b->col(k), ld, p,
@@ -390,15 +396,18 @@ static int blocklanczos_expand_async(kk_op op, kk_basis b, int k, int p, int c_r
         const int chunk = c->gram2_chunk;
         const int nch = (kn + chunk - 1) / chunk;
         const int per = ((kn + nch - 1) / nch + 15) / 16 * 16;   // balanced chunks, whole 16-column groups
+        const bool want_gw = c->resid_gram != 0;
         for (int i0 = 0; i0 < kn; i0 += per)
             KK_TRY(kk_launch_block_gram2(c, b->col(i0), ld, std::min(per, kn - i0), AX, ld, p, b->col(k), ld, p, ld, P + (int64_t)i0 * st,
-                                         st, G2 + (int64_t)i0 * st, st));
+                                         st, G2 + (int64_t)i0 * st, st, (want_gw && i0 == 0) ? D + AB_GYY : nullptr));
         KK_TRY(kk_allreduce(c, P, 2 * (int64_t)kn * st));
+        if (want_gw) KK_TRY(kk_allreduce(c, D + AB_GYY, 256));
         KK_TRY(kk_launch_blk_gram_rows(c, G2, st, k, p, b->d_gram, b->cap));
         KK_TRY(kk_launch_blk_panel_m(c, P, st, k, p, D + AB_M, 16));
         KK_TRY(kk_launch_blk_panel_correct(c, P, st, kn, p, b->d_gram, b->cap, Pc));
         KK_TRY(kk_launch_block_update(c, b->col(0), ld, kn, AX, AX, ld, ld, p, Pc, -1.0, 1.0, D + AB_NRM));
         KK_TRY(kk_launch_blk_onepass_check(c, P, st, kn, p, D + AB_NRM, 0.1, D + AB_FLAG));
+        if (want_gw) KK_TRY(kk_launch_blk_resid_gram(c, P, Pc, st, kn, p, D + AB_GYY, D + AB_NRM, D + AB_GW));
         KK_HIP(hipMemcpyAsync(c->h_blk + (G2 - D), G2, (size_t)kn * st * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         goto readback;
     }
@@ -429,6 +438,9 @@ readback:
     c->last_qr_dev = H[2];
     *fine = (H[0] == 0.0);
     if (!*fine) return KK_OK;
+    if (onepass && c->resid_gram) {   // the residual block in c_rnext now has its Gram matrix in AB_GW
+        c->gw_valid = true; c->gw_basis = b->uid; c->gw_col = c_rnext; c->gw_p = p;
+    }
     if (onepass) {   // host mirror of the new Gram rows (strictly-lower storage), as the device kernel wrote them
         const double* G2h = c->h_blk + AB_P + (int64_t)kn * st;
         for (int i = 0; i < p; ++i)
@@ -455,12 +467,16 @@ KK_API int kk_blocklanczos_expand(kk_op op, kk_basis b, int k, int bs_r, int c_r
     KK_CHECK(c_r >= k + bs_r && c_rnext >= k + bs_r && (c_rnext + bs_r <= c_r || c_r + bs_r <= c_rnext), KK_ERR_INVALID,
              "kk_blocklanczos_expand: residual blocks must lie beyond column k+bs_r and not overlap");
     kk_ctx c = b->ctx;
+    // cached Gram matrix of the incoming residual block (read before gram_touch, which drops it): only this very block,
+    // untouched since the step that produced it
+    const bool use_gw = c->gw_valid && c->resid_gram && (c->block_fuse & 4) && c->gw_basis == b->uid && c->gw_col == c_r && c->gw_p == bs_r;
+    c->gw_valid = false;
     gram_touch(b, k);
     if (c->block_mode == 1 && c->block_async && bs_r >= 2 && bs_r <= 16 && k + bs_r <= KK_MAX_M) {
         bool fine = false;
         if (kk_bu_stride(bs_r) > bs_r)   // pad columns of the row-major panels: zero once, the kernels write only the first bs_r
             KK_HIP(hipMemsetAsync(c->blk + AB_P, 0, (size_t)(k + bs_r) * kk_bu_stride(bs_r) * sizeof(double), c->stream));
-        KK_TRY(blocklanczos_expand_async(op, b, k, bs_r, c_r, c_rnext, qr_tol, B, ldb, M, ldm, norm_R, &fine));
+        KK_TRY(blocklanczos_expand_async(op, b, k, bs_r, c_r, c_rnext, qr_tol, B, ldb, M, ldm, norm_R, &fine, use_gw));
         if (fine) {
             *bs_next = bs_r;
             if (is_drift) *is_drift = 0;

@@ -2,6 +2,7 @@
 // profiling, basis slabs and the L1 vector verbs.  Host-side C++ only orchestrates kernel launches on one HIP stream;
 // there is NO CPU compute fallback anywhere in this library.
 #include "kk_host.h"
+#include <atomic>
 
 static thread_local std::string g_last_error;
 
@@ -184,6 +185,9 @@ KK_API int kk_ctx_set_option(kk_ctx c, const char* key, double value) {
     } else if (!strcmp(key, "spmm_rpl")) {
         KK_CHECK(value == 1 || value == 2, KK_ERR_INVALID, "spmm_rpl must be 1 or 2");
         c->spmm_rpl = (int)value;
+    } else if (!strcmp(key, "resid_gram")) {
+        c->resid_gram = value != 0;
+        c->gw_valid = false;
     } else if (!strcmp(key, "qr_skip_tol")) {
         KK_CHECK(value >= 0 && value <= 1e-8, KK_ERR_INVALID, "qr_skip_tol must be in [0, 1e-8]");
         c->qr_skip_tol = value;
@@ -237,6 +241,7 @@ KK_API int kk_ctx_get_option(kk_ctx c, const char* key, double* value) {
     else if (!strcmp(key, "gram_bpc")) *value = c->gram_bpc;
     else if (!strcmp(key, "gram2_chunk")) *value = c->gram2_chunk;
     else if (!strcmp(key, "qr_skip_tol")) *value = c->qr_skip_tol;
+    else if (!strcmp(key, "resid_gram")) *value = c->resid_gram;
     else if (!strcmp(key, "last_qr_dev")) *value = c->last_qr_dev;
     else if (!strcmp(key, "gram_nt")) *value = c->gram_nt;
     else {
@@ -370,6 +375,8 @@ KK_API int kk_basis_create(kk_ctx c, int64_t n, int capacity, kk_basis* out) {
     int64_t ld = (n + KK_SUB - 1) / KK_SUB * KK_SUB;
     if (((ld / KK_SUB) & 1) == 0) ld += KK_SUB;  // odd number of 4 KiB row chunks per column: no channel aliasing
     kk_basis b = new kk_basis_s();
+    static std::atomic<uint64_t> next_uid{1};
+    b->uid = next_uid++;
     b->ctx = c; b->n = n; b->ld = ld; b->cap = capacity;
     size_t bytes = (size_t)ld * capacity * sizeof(double);
     hipError_t e = hipMalloc(&b->d, bytes);

@@ -31,6 +31,8 @@ static inline const double* pin(kk_ctx c, int64_t off, int slot = 0) { return c-
 static inline void gram_touch(kk_basis b, int col) {
     if (col < b->gram_rows) b->gram_rows = col;
     b->spec_valid = false;
+    kk_ctx c = b->ctx;   // cached Gram matrix of a residual block: gone as soon as a column at or below its end may have changed
+    if (c->gw_valid && c->gw_basis == b->uid && col < c->gw_col + c->gw_p) c->gw_valid = false;
 }
 
 // ---- sparse operators (kk_sparse.hip)

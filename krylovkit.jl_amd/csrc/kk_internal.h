@@ -120,6 +120,12 @@ struct kk_ctx_s {
     int spmm_cols = 16;          // SpMM on ELL: right-hand sides per launch (16, 8 or 4)
     int bu_prefetch = 1;         // block update kernel: 1 = coefficient panel in LDS (default), 0 = scalar-load kernel of round 1, 8/16/24 = deep-prefetch experiments
     int gram_nt = 0;             // Gram panel: non-temporal loads for the X stream
+    // Gram matrix of the residual block the last asynchronous one-pass block step left behind (device, AB_GW), valid while
+    // nothing touched that block: the next step's first CholQR2 round starts from it instead of reading the block
+    bool gw_valid = false;
+    uint64_t gw_basis = 0;   // uid of the slab
+    int gw_col = -1, gw_p = 0;
+    int resid_gram = 1;          // use it (0: always run the Gram pass)
     double qr_skip_tol = 2e-14;  // async block step: skip the second CholQR2 back-substitution when |Q1'Q1 - I|_max <= this (0: never)
     double last_qr_dev = 0;      // |Q1'Q1 - I|_max of the last asynchronous block step (diagnostics)
     int gram2_chunk = 80;        // two-panel Gram kernel (one-pass block step): basis columns per launch (64, 80 or 128)
@@ -154,6 +160,7 @@ struct kk_ctx_s {
 
 struct kk_basis_s {
     kk_ctx ctx = nullptr;
+    uint64_t uid = 0;   // unique over the life of the process (a freed slab's address may be reused)
     int64_t n = 0, ld = 0;
     int cap = 0;
     double* d = nullptr;
@@ -335,7 +342,9 @@ int kk_launch_blk_chol2(kk_ctx ctx, const double* G2, int p, const double* R1, d
 int kk_launch_blk_fill_m(kk_ctx ctx, const double* M, int ldm, int p, double* S3, int st);
 int kk_launch_blk_combine(kk_ctx ctx, double* P, const double* S3, int kn, int nz, int st);
 int kk_launch_block_gram2(kk_ctx ctx, const double* X, int64_t ldx, int p, const double* Y, int64_t ldy, int q, const double* Y2,
-                          int64_t ldy2, int q2, int64_t ld, double* C_dev, int rs, double* C2_dev, int rs2);
+                          int64_t ldy2, int q2, int64_t ld, double* C_dev, int rs, double* C2_dev, int rs2, double* C3_dev = nullptr);
+int kk_launch_blk_resid_gram(kk_ctx ctx, const double* P, const double* Pc, int st, int kn, int p, const double* GYY,
+                             const double* nrm2, double* GW);
 int kk_launch_blk_gram_rows(kk_ctx ctx, const double* G2, int st, int k, int p, double* gram, int cap);
 int kk_launch_blk_panel_correct(kk_ctx ctx, const double* P, int st, int kn, int p, const double* gram, int cap, double* Pc);
 int kk_launch_blk_panel_m(kk_ctx ctx, const double* P, int st, int k, int p, double* M, int ldm);

@@ -89,12 +89,16 @@ template <int NG>
 __global__ __launch_bounds__(KK_TPB) void k_block_gram2(const double* __restrict__ X, int64_t ldx, int p,
                                                         const double* __restrict__ Y, int64_t ldy, int q,
                                                         const double* __restrict__ Y2, int64_t ldy2, int q2, int gx, int64_t ld,
-                                                        int64_t rpb, double* __restrict__ part, double* __restrict__ part2) {
+                                                        int64_t rpb, double* __restrict__ part, double* __restrict__ part2,
+                                                        double* __restrict__ part3) {
+    // part3 (optional): Y'Y as well -- Y's registers serve both MFMA operands, no memory traffic.  The one-pass block step
+    // gets |A X|-Gram this way and from it the Gram matrix of the NEXT residual block without reading that block
+    // (W'W = (AX)'(AX) - P'Pc to first order), i.e. the first CholQR2 Gram pass of the next step.
     extern __shared__ __attribute__((aligned(16))) double lds[];  // [NG][4][64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, kq = lane >> 4;
     const int64_t r0 = (int64_t)blockIdx.x * rpb, r1 = imin(r0 + rpb, ld);
-    v4d acc[NG], acc2[NG];
+    v4d acc[NG], acc2[NG], acc3 = v4d{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int g = 0; g < NG; ++g) { acc[g] = v4d{0.0, 0.0, 0.0, 0.0}; acc2[g] = v4d{0.0, 0.0, 0.0, 0.0}; }
     for (int64_t rc = r0 + wave * BG_CHUNK; rc < r1; rc += 4 * BG_CHUNK) {
@@ -111,6 +115,10 @@ __global__ __launch_bounds__(KK_TPB) void k_block_gram2(const double* __restrict
             const double* zp = Y2 + (int64_t)c * ldy2 + row;
 #pragma unroll
             for (int t = 0; t < BG_T; t += 2) { d2 v = ld2(zp + 4 * t); zv[t] = v.x; zv[t + 1] = v.y; }
+        }
+        if (part3) {
+#pragma unroll
+            for (int t = 0; t < BG_T; ++t) acc3 = __builtin_amdgcn_mfma_f64_16x16x4f64(yv[t], yv[t], acc3, 0, 0, 0);
         }
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
@@ -151,6 +159,19 @@ __global__ __launch_bounds__(KK_TPB) void k_block_gram2(const double* __restrict
         double* dst = (pass ? part2 : part) + (int64_t)blockIdx.x * (NG * 256);
         for (int e = tid; e < NG * 256; e += KK_TPB) dst[e] = lds[e];
         __syncthreads();
+    }
+    if (part3) {
+        for (int w = 0; w < 4; ++w) {
+            if (wave == w) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    double* a = &lds[r * 64 + lane];
+                    *a = (w == 0) ? acc3[r] : (*a + acc3[r]);
+                }
+            }
+            __syncthreads();
+        }
+        part3[(int64_t)blockIdx.x * 256 + tid] = lds[tid];
     }
 }
 
@@ -507,6 +528,24 @@ __global__ __launch_bounds__(KK_TPB) void k_blk_panel_correct(const double* __re
         Pc[e] = psm[e] - a;
     }
 }
+// Gram matrix of the new residual block W = AX - V Pc without reading it:  W'W = (AX)'(AX) - P'Pc  (first order in
+// E = V'V - I, which Pc = (I - E)P carries), P / Pc row-major kn x st, GYY = (AX)'(AX) column-major ld 16.  The diagonal is
+// replaced by the column norms the update kernel measured on the actual block (exact); the result is symmetrised and
+// written column-major with leading dimension p -- the layout k_blk_chol1 reads.  The subtraction loses
+// log2(|AX|^2 / |W|^2) bits; whatever that costs in orthonormality of Q1 = W R1^-1 is measured by the fused second round
+// (|Q1'Q1 - I|), which then runs its back-substitution or not.
+__global__ __launch_bounds__(KK_TPB) void k_blk_resid_gram(const double* __restrict__ P, const double* __restrict__ Pc, int st, int kn,
+                                                           int p, const double* __restrict__ GYY, const double* __restrict__ nrm2,
+                                                           double* __restrict__ GW) {
+    __shared__ double g[16][17];
+    const int i = threadIdx.x & 15, j = threadIdx.x >> 4;
+    double a = 0;
+    if (i < p && j < p)
+        for (int l = 0; l < kn; ++l) a = fma(P[(int64_t)l * st + i], Pc[(int64_t)l * st + j], a);
+    g[i][j] = (i < p && j < p) ? GYY[i + 16 * j] - a : 0.0;
+    __syncthreads();
+    if (i < p && j < p) GW[i + p * j] = (i == j) ? nrm2[i] : 0.5 * (g[i][j] + g[j][i]);
+}
 // rows p..2p-1 of the three-term panel: S3[p + i][j] = M[i][j]  (M col-major, ld ldm)
 __global__ __launch_bounds__(64) void k_blk_fill_m(const double* __restrict__ M, int ldm, int p, double* __restrict__ S3, int st) {
     for (int e = threadIdx.x; e < p * st; e += 64) {
@@ -795,6 +834,12 @@ int kk_launch_blk_panel_correct(kk_ctx ctx, const double* P, int st, int kn, int
     KK_HIP(hipGetLastError());
     return KK_OK;
 }
+int kk_launch_blk_resid_gram(kk_ctx ctx, const double* P, const double* Pc, int st, int kn, int p, const double* GYY,
+                             const double* nrm2, double* GW) {
+    hipLaunchKernelGGL(k_blk_resid_gram, dim3(1), dim3(KK_TPB), 0, ctx->stream, P, Pc, st, kn, p, GYY, nrm2, GW);
+    KK_HIP(hipGetLastError());
+    return KK_OK;
+}
 int kk_launch_blk_combine(kk_ctx ctx, double* P, const double* S3, int kn, int nz, int st) {
     hipLaunchKernelGGL(k_blk_combine, dim3(1), dim3(KK_TPB), 0, ctx->stream, P, S3, kn, nz, st);
     KK_HIP(hipGetLastError());
@@ -901,18 +946,20 @@ int kk_launch_block_gram_rs(kk_ctx ctx, const double* X, int64_t ldx, int p, con
 
 // C = X' Y and C2 = X' Y2 in one pass (both row-major panels: C[i*rs + j], C2[i*rs2 + j])
 int kk_launch_block_gram2(kk_ctx ctx, const double* X, int64_t ldx, int p, const double* Y, int64_t ldy, int q, const double* Y2,
-                          int64_t ldy2, int q2, int64_t ld, double* C_dev, int rs, double* C2_dev, int rs2) {
+                          int64_t ldy2, int q2, int64_t ld, double* C_dev, int rs, double* C2_dev, int rs2, double* C3_dev) {
     if (p <= 0 || q <= 0 || q2 <= 0) return KK_OK;
     if (p > 128 || q > 16 || q2 > 16) { kk_set_error("kk_launch_block_gram2: p=%d q=%d q2=%d exceed one launch (128 x 16)", p, q, q2); return KK_ERR_INVALID; }
     const int ng = (p + 15) / 16;
     const int NG = ng <= 2 ? ng : (ng <= 4 ? 4 : (ng == 5 ? 5 : 8));
     int nblk;
     int64_t rpb;
-    gram_grid(ctx, ld, NG == 5 ? 8 : NG, NG >= 5 ? 2 : 8, &nblk, &rpb);   // NG >= 5: two blocks per CU fit (VGPRs), and the partial tiles double
-    if (2 * (int64_t)nblk * NG * 256 > (int64_t)(2 * KK_MAX_M + 8) * KK_MAX_BLOCKS) { kk_set_error("kk_launch_block_gram2: partial buffer too small"); return KK_ERR_INVALID; }
+    // NG >= 5: two blocks per CU fit (VGPRs); the partial tiles double (+ one tile per block for Y'Y), which bounds the grid
+    gram_grid(ctx, ld, NG == 5 ? 8 : NG, NG >= 5 ? 2 : (NG == 4 ? 3 : 8), &nblk, &rpb);
+    if ((2 * (int64_t)NG + 1) * nblk * 256 > (int64_t)(2 * KK_MAX_M + 8) * KK_MAX_BLOCKS) { kk_set_error("kk_launch_block_gram2: partial buffer too small"); return KK_ERR_INVALID; }
     const size_t shm = (size_t)NG * 256 * sizeof(double);
     double* part = ctx->partials;
     double* part2 = part + (int64_t)nblk * NG * 256;
+    double* part3 = C3_dev ? part2 + (int64_t)nblk * NG * 256 : nullptr;
     // ride-along block = a whole group of X?  (same leading dimension, starts on a 16-column boundary of this launch, 16 wide)
     int gx = -1;
     if (ldy2 == ldx && q2 == 16 && Y2 >= X) {
@@ -922,7 +969,7 @@ int kk_launch_block_gram2(kk_ctx ctx, const double* X, int64_t ldx, int p, const
     {
         kk_prof_scope ps(ctx, "k_block_gram");
         dim3 g(nblk), b(KK_TPB);
-#define BG2_ARGS X, ldx, p, Y, ldy, q, Y2, ldy2, q2, gx, ld, rpb, part, part2
+#define BG2_ARGS X, ldx, p, Y, ldy, q, Y2, ldy2, q2, gx, ld, rpb, part, part2, part3
         switch (NG) {
             case 1: hipLaunchKernelGGL((k_block_gram2<1>), g, b, shm, ctx->stream, BG2_ARGS); break;
             case 2: hipLaunchKernelGGL((k_block_gram2<2>), g, b, shm, ctx->stream, BG2_ARGS); break;
@@ -935,6 +982,7 @@ int kk_launch_block_gram2(kk_ctx ctx, const double* X, int64_t ldx, int p, const
     KK_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_finalize_gram, dim3(NG * 16), dim3(KK_TPB), 0, ctx->stream, part, nblk, NG, p, q, C_dev, rs, 1);
     hipLaunchKernelGGL(k_finalize_gram, dim3(NG * 16), dim3(KK_TPB), 0, ctx->stream, part2, nblk, NG, p, q2, C2_dev, rs2, 1);
+    if (C3_dev) hipLaunchKernelGGL(k_finalize_gram, dim3(16), dim3(KK_TPB), 0, ctx->stream, part3, nblk, 1, q, q, C3_dev, 1, 16);   // column-major, ld 16
     KK_HIP(hipGetLastError());
     return KK_OK;
 }

@@ -778,10 +778,15 @@ def test_blocklanczos_async_step_matches_synchronous(kk, ko, ctx, bs):
     # (+ fused CholQR2 round), 0: synchronous
     # 4: as 3 but the second CholQR2 back-substitution always executed (qr_skip_tol = 0; the default skips it when the first
     # round left the block orthonormal to 2e-14, which is the case here: last_qr_dev ~ 1e-15)
-    for mode in (1, 2, 3, 4, 0):
+    # 5: as 3 but without the residual-block Gram matrix handed from step to step (resid_gram = 0: every step reads its
+    # residual block once more for the first CholQR2 Gram pass)
+    launches = {}
+    for mode in (1, 2, 3, 4, 5, 0):
         ctx.set_option("block_async", 1 if mode else 0)
-        ctx.set_option("block_fuse", {1: 3, 2: 0, 3: 5, 4: 5, 0: 0}[mode])
+        ctx.set_option("block_fuse", {1: 3, 2: 0, 3: 5, 4: 5, 5: 5, 0: 0}[mode])
         ctx.set_option("qr_skip_tol", 0.0 if mode == 4 else 2e-14)
+        ctx.set_option("resid_gram", 0 if mode == 5 else 1)
+        ctx.prof_reset(); ctx.prof_enable(1)
         it = kk.BlockLanczosIterator(kk.SparseOperator(A, ctx, symmetric=True), x0, (steps + 1) * bs + bs)
         f = it.initialize()
         for _ in range(steps):
@@ -796,15 +801,20 @@ def test_blocklanczos_async_step_matches_synchronous(kk, ko, ctx, bs):
         assert np.max(np.abs(A @ V - V @ H - R @ E.T)) < 1e-10
         assert abs(f.normres - np.linalg.norm(R)) < 1e-11 and np.max(np.abs(V.T @ R)) < 1e-11
         Hs[mode] = H.copy()
+        ctx.prof_enable(0)
+        launches[mode] = ctx.prof_get("k_block_gram")[1]
         if mode in (3, 4):
             assert 0 < ctx.get_option("last_qr_dev") < 2e-14    # the skip branch (3) / the full branch (4) were really taken
     ctx.set_option("qr_skip_tol", 2e-14)
+    ctx.set_option("resid_gram", 1)
+    assert launches[5] - launches[3] == steps - 1    # every step but the first started from the handed-over Gram matrix
     ctx.set_option("block_async", 1)
     ctx.set_option("block_fuse", BLOCK_FUSE_DEFAULT)
     np.testing.assert_allclose(Hs[1], Hs[0], atol=1e-10)
     np.testing.assert_allclose(Hs[2], Hs[0], atol=1e-10)
     np.testing.assert_allclose(Hs[3], Hs[0], atol=1e-10)
     np.testing.assert_allclose(Hs[4], Hs[0], atol=1e-10)
+    np.testing.assert_allclose(Hs[5], Hs[0], atol=1e-10)
     oit = ko.BlockLanczosIterator(A, [x.copy() for x in x0], (steps + 1) * bs + bs)
     of = ko.blocklanczos_initialize(oit)
     for _ in range(steps):

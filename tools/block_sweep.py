@@ -38,10 +38,10 @@ def run():
     return time.perf_counter() - t0, steps, alg, f
 
 
-variants = [("two-pass (three-term, then panel), gather SpMM, both CholQR2 rounds", dict(block_fuse=1, spmm_dia=0, qr_skip_tol=0)),
-            ("one-pass projection with Gram correction, sweeping SpMM, both CholQR2 rounds", dict(block_fuse=5, spmm_dia=1, qr_skip_tol=0)),
-            ("shipped: + second back-substitution skipped when |Q1'Q1 - I| <= 2e-14", dict(qr_skip_tol=2e-14)),
-            ("skip threshold 1e-12", dict(qr_skip_tol=1e-12))]
+variants = [("two-pass (three-term, then panel), gather SpMM, both CholQR2 rounds", dict(block_fuse=1, spmm_dia=0, qr_skip_tol=0, resid_gram=0)),
+            ("one-pass projection with Gram correction, sweeping SpMM, both CholQR2 rounds", dict(block_fuse=5, spmm_dia=1, qr_skip_tol=0, resid_gram=0)),
+            ("+ second back-substitution skipped when |Q1'Q1 - I| <= 2e-14", dict(qr_skip_tol=2e-14)),
+            ("shipped: + Gram matrix of the residual block from the panel pass (no first Gram pass)", dict(resid_gram=1))]
 for name, opts in variants:
     for k_, v in opts.items():
         ctx.set_option(k_, v)
@@ -56,4 +56,4 @@ for name, opts in variants:
     prof = {k_: round(ctx.prof_get(k_)[0], 2) for k_ in ("k_block_gram", "k_block_update", "k_spmm_ell", "k_spmm_dia", "k_block_qr_fused") if ctx.prof_get(k_)[1]}
     print(json.dumps({"variant": name, "ms_per_block_step": round(best / steps * 1e3, 3), "frac_8TBps": round(alg / best / 8e12, 4),
                       "normres": f.normres, "last_qr_dev": ctx.get_option("last_qr_dev") if hasattr(ctx, "get_option") else None, "kernel_ms_one_run": prof}), flush=True)
-ctx.set_option("block_fuse", 5); ctx.set_option("qr_skip_tol", 2e-14)
+ctx.set_option("block_fuse", 5); ctx.set_option("qr_skip_tol", 2e-14); ctx.set_option("resid_gram", 1)
