@@ -83,6 +83,13 @@ typedef enum {
  * as grid stencils, default 1; 0 = the general ELL gather kernels).  Tuning knobs without semantic effect:
  * "gram_bpc", "gram2_chunk", "spmm_bpc", "spmm_cols", "spmm_rpl", "spmm_dia_lines", "bu_prefetch", "gram_nt", "persist_nt". */
 
+/* Environment variables read by the library (all optional): KK_MGS_MODE, KK_BLOCK_MODE, KK_BLOCKS_PER_CU, KK_MGS_PERSIST,
+ * KK_PERSIST_THREADS, KK_PERSIST_NT (defaults of the options of the same name, read at kk_ctx_create); KK_SPMV_FORMAT = ell |
+ * sell | csr and KK_SPMV_TILE_COLS (force a device format / the column-tile width at operator creation); KK_NO_DIA (no
+ * grid-stencil diagonals); KK_BASISTRANSFORM_LDS (LDS-tile basistransform instead of the MFMA kernel); KK_RCCL_LIB (path of
+ * librccl for kk_comm_*); KK_LOOPBACK_GHOST_FROM = r (test aid, world size 1 only: columns >= r of a kk_csr_create_sharded
+ * operator go through the ghost-exchange machinery although this rank owns them). */
+
 /* ---------------------------------------------------------------- library / context */
 int kk_version(void);
 const char* kk_last_error(void);
