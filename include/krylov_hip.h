@@ -78,9 +78,9 @@ typedef enum {
  * "block_async" (whole BlockLanczos step enqueued without a host round trip, default 1), "block_fuse" (bit mask of its
  * pass structure: 1 = second CholQR2 round fused, 4 = one-pass projection with Gram correction; default 5; 0 / 1 = the
  * reference's three-term-then-reorthogonalise order), "qr_skip_tol" (the second CholQR2 back-substitution of that step is
- * skipped when the block is orthonormal to this level after the first; default 2e-14, 0 = never), "resid_gram" (Gram matrix of the residual block handed from one step to the next, default 1),
- * "spmv_dia" / "spmm_dia" (diagonal kernels for operators detected
- * as grid stencils, default 1; 0 = the general ELL gather kernels).  Tuning knobs without semantic effect:
+ * skipped when the block is orthonormal to this level after the first; default 2e-14, 0 = never), "resid_gram" (Gram matrix
+ * of the residual block handed from one step to the next, default 1), "spmv_dia" / "spmm_dia" (diagonal kernels for operators
+ * detected as grid stencils, default 1; 0 = the general ELL gather kernels).  Tuning knobs without semantic effect:
  * "gram_bpc", "gram2_chunk", "spmm_bpc", "spmm_cols", "spmm_rpl", "spmm_dia_lines", "bu_prefetch", "gram_nt", "persist_nt". */
 
 /* Environment variables read by the library (all optional): KK_MGS_MODE, KK_BLOCK_MODE, KK_BLOCKS_PER_CU, KK_MGS_PERSIST,
@@ -137,7 +137,9 @@ int kk_op_set_halo_hook(kk_op op, kk_halo_fn fn, void* user);
  *   - all inner-product-type results (every finalize site) are summed with ncclAllReduce(f64, sum);
  *     kk_lanczos_expand with the projection-based orthogonalisers (CGS2, low-sync MGS2) needs exactly TWO per step:
  *     [alpha0 | V'w | V'v] (2m+1 doubles) and |w|^2;
- *   - operators made by kk_csr_create_sharded exchange their ghost entries with grouped ncclSend / ncclRecv before an apply;
+ *   - operators made by kk_csr_create_sharded exchange their ghost entries with grouped ncclSend / ncclRecv before an apply
+ *     (a grid stencil partitioned along grid lines runs the diagonal kernels on the rows that need no ghost entry and
+ *     the gather kernels on its first and last line);
  *   - rectangular maps made by kk_csr_create_sharded_rect (GKL / svdsolve) all-gather the short vector for A x and
  *     reduce-scatter the partial result of A' x.
  * Host-side control flow sees identical scalars on every rank.  librccl is loaded (dlopen) at the first kk_comm_* call.
