@@ -431,6 +431,7 @@ __global__ __launch_bounds__(KK_TPB) void k_unproj_proj(const double* __restrict
 // substitution in LDS (m <= 256 barriers of a single block, ~5 us).  If g_ride != nullptr the Gram
 // row of the newest basis vector (g_ride[0..m-2]) is first stored into L[newest][.].  coef_out gets
 // s (+ *a0 on the last entry: the Lanczos "w -= alpha0 v" folded into the update), s_out the plain s.
+#define KK_LS_AHEAD 8
 __global__ __launch_bounds__(KK_TPB) void k_lowsync_solve(const double* __restrict__ p, const double* __restrict__ g_ride,
                                                           double* L, int cap, int m, int newest,
                                                           const double* __restrict__ a0, double* __restrict__ coef_out,
@@ -439,14 +440,27 @@ __global__ __launch_bounds__(KK_TPB) void k_lowsync_solve(const double* __restri
     const int i = threadIdx.x;
     if (g_ride && i < m - 1) L[(int64_t)newest * cap + i] = g_ride[i];
     if (i < m) rhs[i] = p[i];
+    // thread i walks row i of L; its entries are fetched KK_LS_AHEAD steps ahead of their use so that the global-load
+    // latency is not paid once per barrier (it was: ~130 ns x m per solve)
+    const double* lrow = (g_ride && i == newest) ? g_ride : L + (int64_t)i * cap;
+    const bool act = i < m;
+    double la[KK_LS_AHEAD];
+#pragma unroll
+    for (int u = 0; u < KK_LS_AHEAD; ++u) la[u] = (act && u < i) ? lrow[u] : 0.0;
     __syncthreads();
-    for (int j = 0; j < m - 1; ++j) {
-        const double sj = rhs[j];
-        if (i > j && i < m) {
-            const double lij = (g_ride && i == newest) ? g_ride[j] : L[(int64_t)i * cap + j];
-            rhs[i] = fma(-lij, sj, rhs[i]);
+    for (int j0 = 0; j0 < m - 1; j0 += KK_LS_AHEAD) {
+#pragma unroll
+        for (int u = 0; u < KK_LS_AHEAD; ++u) {
+            const int j = j0 + u;
+            if (j < m - 1) {   // uniform
+                const double lij = la[u];
+                const int jn = j + KK_LS_AHEAD;
+                la[u] = (act && jn < i) ? lrow[jn] : 0.0;
+                const double sj = rhs[j];
+                if (i > j && act) rhs[i] = fma(-lij, sj, rhs[i]);
+                __syncthreads();
+            }
         }
-        __syncthreads();
     }
     if (i < m) {
         const double s = rhs[i];
@@ -471,13 +485,24 @@ __global__ __launch_bounds__(KK_TPB) void k_lanczos_coef(const double* __restric
     if (lowsync && i < m - 1) L[(int64_t)(m - 1) * cap + i] = g[i];
     __syncthreads();
     if (lowsync) {
-        for (int j = 0; j < m - 1; ++j) {
-            const double sj = rhs[j];
-            if (i > j && i < m) {
-                const double lij = (i == m - 1) ? g[j] : L[(int64_t)i * cap + j];
-                rhs[i] = fma(-lij, sj, rhs[i]);
+        const double* lrow = (i == m - 1) ? g : L + (int64_t)i * cap;
+        const bool act = i < m;
+        double la[KK_LS_AHEAD];
+#pragma unroll
+        for (int u = 0; u < KK_LS_AHEAD; ++u) la[u] = (act && u < i) ? lrow[u] : 0.0;
+        for (int j0 = 0; j0 < m - 1; j0 += KK_LS_AHEAD) {
+#pragma unroll
+            for (int u = 0; u < KK_LS_AHEAD; ++u) {
+                const int j = j0 + u;
+                if (j < m - 1) {   // uniform
+                    const double lij = la[u];
+                    const int jn = j + KK_LS_AHEAD;
+                    la[u] = (act && jn < i) ? lrow[jn] : 0.0;
+                    const double sj = rhs[j];
+                    if (i > j && act) rhs[i] = fma(-lij, sj, rhs[i]);
+                    __syncthreads();
+                }
             }
-            __syncthreads();
         }
     }
     if (i < m) coef_out[i] = (i == m - 1) ? rhs[i] + a0 : rhs[i];
