@@ -87,8 +87,8 @@ typedef enum {
  * KK_PERSIST_THREADS, KK_PERSIST_NT (defaults of the options of the same name, read at kk_ctx_create); KK_SPMV_FORMAT = ell |
  * sell | csr and KK_SPMV_TILE_COLS (force a device format / the column-tile width at operator creation); KK_NO_DIA (no
  * grid-stencil diagonals); KK_BASISTRANSFORM_LDS (LDS-tile basistransform instead of the MFMA kernel); KK_RCCL_LIB (path of
- * librccl for kk_comm_*); KK_LOOPBACK_GHOST_FROM = r (test aid, world size 1 only: columns >= r of a kk_csr_create_sharded
- * operator go through the ghost-exchange machinery although this rank owns them). */
+ * librccl for kk_comm_*); KK_LOOPBACK_GHOST_FROM = r / KK_LOOPBACK_GHOST_BELOW = r2 (test aids, world size 1 only: columns >= r / < r2 of a
+ * kk_csr_create_sharded operator go through the ghost-exchange machinery although this rank owns them). */
 
 /* ---------------------------------------------------------------- library / context */
 int kk_version(void);

@@ -439,12 +439,14 @@ KK_API int kk_csr_create_sharded(kk_ctx c, int64_t nrows_local, const int64_t* r
     // owned by this rank, are routed through the ghost machinery (request list, gather into the send buffer, exchange
     // -- here a device copy to self --, ghost-indexed reads in the SpMV / SpMM kernels), so that every piece of the
     // multi-GPU data path except the wire itself runs where no second GPU exists.
-    int64_t loop_from = -1;
+    int64_t loop_from = -1, loop_below = 0;   // KK_LOOPBACK_GHOST_BELOW = r2: the columns < r2 as well (a middle rank's layout)
     if (world == 1) {
         const char* lb = getenv("KK_LOOPBACK_GHOST_FROM");
         if (lb && *lb) loop_from = atoll(lb);
+        const char* lb2 = getenv("KK_LOOPBACK_GHOST_BELOW");
+        if (lb2 && *lb2) { loop_below = atoll(lb2); if (loop_from < 0) loop_from = n_global; }
     }
-    auto is_ghost = [&](int64_t g) { return g < lo || g >= hi || (loop_from >= 0 && g >= loop_from); };
+    auto is_ghost = [&](int64_t g) { return g < lo || g >= hi || (loop_from >= 0 && (g >= loop_from || g < loop_below)); };
     // ghost columns: sorted unique global ids outside [lo, hi) -> grouped by owner
     std::vector<int64_t> needed;
     for (int64_t p = 0; p < nnz; ++p) {

@@ -260,10 +260,12 @@ def test_loopback_sharded_stencil_uses_diagonal_kernels_on_the_interior(kk, ko, 
     else:
         A = ko.laplacian_2d(nx, ny, shift_diag=10 * np.linspace(0, 1, n) ** 2)
     part = kd.Partition.even(n, 1, 0)
-    ghost_from = n - nx - 3                      # a bit more than the last grid line goes through the ghost buffer
+    ghost_from = n - nx - 3                      # a bit more than the last grid line goes through the ghost buffer ...
     monkeypatch.setenv("KK_LOOPBACK_GHOST_FROM", str(ghost_from))
+    monkeypatch.setenv("KK_LOOPBACK_GHOST_BELOW", str(nx + 5))   # ... and the first one: a middle rank, two boundary strips
     op = kd.NativeShardedOperator(A, part, ctx, symmetric=True)
     monkeypatch.delenv("KK_LOOPBACK_GHOST_FROM")
+    monkeypatch.delenv("KK_LOOPBACK_GHOST_BELOW")
     assert op.info()["ncols"] > n and op.info()["format"] == "ELL+DIA"
     B = kk.DeviceBasis(n, 40, ctx)
     X = rng.standard_normal((n, 16))
