@@ -21,10 +21,23 @@
 #include <stdlib.h>
 #include <string.h>
 
-static double ddot(int64_t n, const double* x, const double* y) { /* inner(x,y) */
+/* inner(x,y).  Deterministic whatever the number of threads and their scheduling: KK_DOT_CHUNKS fixed chunks, each summed
+ * front to back by one thread, the chunk sums added in chunk order -- the twin gives the same bits on every box, so the
+ * parity figures of bench.py / the full-size tests do not depend on how OpenMP combined a reduction that day. */
+#define KK_DOT_CHUNKS 1024
+static double ddot(int64_t n, const double* x, const double* y) {
+    double part[KK_DOT_CHUNKS];
+    const int64_t len = (n + KK_DOT_CHUNKS - 1) / KK_DOT_CHUNKS;
+#pragma omp parallel for schedule(static)
+    for (int c = 0; c < KK_DOT_CHUNKS; ++c) {
+        const int64_t lo = (int64_t)c * len, hi = lo + len < n ? lo + len : n;
+        double s = 0;
+#pragma omp simd reduction(+ : s)
+        for (int64_t i = lo; i < hi; ++i) s += x[i] * y[i];
+        part[c] = s;
+    }
     double s = 0;
-#pragma omp parallel for simd reduction(+ : s) schedule(static)
-    for (int64_t i = 0; i < n; ++i) s += x[i] * y[i];
+    for (int c = 0; c < KK_DOT_CHUNKS; ++c) s += part[c];
     return s;
 }
 static double dnrm2(int64_t n, const double* x) { return sqrt(ddot(n, x, x)); } /* norm(x) */
