@@ -235,6 +235,11 @@ def main():
                     help="strict = the reference's sequential MGS order (src/orthonormal.jl:414-439) as the headline run")
     ap.add_argument("--config", default="lanczos", choices=["lanczos", "gkl", "block"],
                     help="lanczos = BASELINE.json configs[1] (the judged line); gkl / block = configs[3] / configs[4], row-sharded")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="config lanczos, N > 1: weak = --ny grid lines (10M rows) PER GPU, the north_star reading; strong = the ONE 10M-row "
+                         "problem of BASELINE.json's metric split over the N GPUs.  The other mode runs as a secondary leg and is reported "
+                         "next to the headline value (N = 1: both coincide)")
+    ap.add_argument("--no-other-scaling-leg", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-strict-leg", action="store_true")
     ap.add_argument("--ny", type=int, default=NY, help="grid rows per GPU (default 2500 -> 10M rows per GPU)")
@@ -277,6 +282,7 @@ def main():
     use_dist = world > 1 or force_dist
     dist = None
     if world > 1:
+        import torch
         import torch.distributed as dist          # control plane only (gloo): communicator id + barriers
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
@@ -293,38 +299,56 @@ def main():
     barrier = dist.barrier if world > 1 else (lambda: None)
 
     # ------------------------------------------------------------ workload set-up (inputs resident in HBM afterwards)
-    x0_handle = None
-    if args.config == "lanczos":
-        n_local = NX * args.ny
-        sweep_its = KRYLOVDIM - 1
-        A = laplacian_rows(NX, args.ny * world, rank * args.ny, (rank + 1) * args.ny)
+    def build_lanczos(mode):
+        """operator + slab + start vector of config 2 for one scaling mode -> dict(sweep, n_local, n_global, ...)"""
+        if mode == "strong" and world > 1:       # the 10M-row problem itself, rows split along grid lines
+            ny_tot = args.ny
+            pt = kd.Partition.even(NX * ny_tot, world, rank, align=NX)
+            y0, y1 = pt.lo // NX, pt.hi // NX
+        else:                                     # 10M rows per GPU
+            ny_tot = args.ny * world
+            y0, y1 = rank * args.ny, (rank + 1) * args.ny
+            pt = kd.Partition.even(NX * ny_tot, world, rank, align=NX)
+        nl = NX * (y1 - y0)
+        A = laplacian_rows(NX, ny_tot, y0, y1)
         if use_dist:
-            part = kd.Partition.even(NX * args.ny * world, world, rank, align=NX)
-            op = kd.NativeShardedOperator(A, part, ctx, symmetric=True)    # kk_csr_create_sharded: ghost plan negotiated inside
+            op_ = kd.NativeShardedOperator(A, pt, ctx, symmetric=True)    # kk_csr_create_sharded: ghost plan negotiated inside
         else:
-            op = kk.SparseOperator(A, ctx, symmetric=True, via_csc=True)   # handed over as Julia's SparseMatrixCSC
+            op_ = kk.SparseOperator(A, ctx, symmetric=True, via_csc=True)   # handed over as Julia's SparseMatrixCSC
         del A
-        V = kk.DeviceBasis(n_local, KRYLOVDIM + 2, ctx)
-        x0 = kk.DeviceBasis(n_local, 1, ctx)
-        x0[0].rand_(3 + rank)                                              # x0 = rand!(similar(A, T, n)), resident in HBM
-        x0_handle = x0
-        it = kk.LanczosIterator(op, x0[0], orth, capacity=KRYLOVDIM + 2)
+        V_ = kk.DeviceBasis(nl, KRYLOVDIM + 2, ctx)
+        x0_ = kk.DeviceBasis(nl, 1, ctx)
+        x0_[0].rand_(3 + rank)                                              # x0 = rand!(similar(A, T, n)), resident in HBM
+        it_ = kk.LanczosIterator(op_, x0_[0], orth, capacity=KRYLOVDIM + 2)
 
-        def sweep():
-            fact = kk.initialize(it, V)
-            for _ in range(sweep_its):
-                fact = kk.expand_(it, fact)
+        def sweep_():
+            fact = kk.initialize(it_, V_)
+            for _ in range(KRYLOVDIM - 1):
+                fact = kk.expand_(it_, fact)
             return fact
 
-        units_per_sweep = sweep_its * world        # each rank advances a 10M-row shard per iteration (weak scaling)
-        alg_sweep = algorithmic_bytes_sweep(n_local * world, KRYLOVDIM)
-        scaling = "weak"
+        return dict(sweep=sweep_, n_local=nl, n_global=NX * ny_tot, ny_tot=ny_tot, x0=x0_, keep=(op_, V_, it_))
+
+    x0_handle = None
+    other_leg_mode = None
+    if args.config == "lanczos":
+        sweep_its = KRYLOVDIM - 1
+        prob = build_lanczos(args.scaling)
+        sweep, n_local, x0_handle = prob["sweep"], prob["n_local"], prob["x0"]
+        scaling = args.scaling if world > 1 else "weak"
+        if world > 1 and not args.no_other_scaling_leg:
+            other_leg_mode = "strong" if scaling == "weak" else "weak"
+        # weak: each rank advances a 10M-row shard per iteration, value = N x job iterations/s in units of 10M-row iterations;
+        # strong: the job IS one 10M-row problem, value = job iterations/s
+        units_per_sweep = sweep_its * world if scaling == "weak" else sweep_its
+        alg_sweep = algorithmic_bytes_sweep(prob["n_global"], KRYLOVDIM)
         metric = "lanczos_iterations_per_second"
-        unit = "it/s (10M-row Lanczos iterations, summed over GPUs)"
-        workload = (f"eigsolve(Lanczos) expand! sweep: {NX}x{args.ny * world} 5-point Laplacian ({n_local * world} rows, "
+        unit = "it/s (10M-row Lanczos iterations, summed over GPUs)" if scaling == "weak" else "it/s (Lanczos iterations of the one 10M-row problem)"
+        workload = (f"eigsolve(Lanczos) expand! sweep: {NX}x{prob['ny_tot']} 5-point Laplacian ({prob['n_global']} rows, "
                     f"SparseMatrixCSC handed over via kk_csc_create), krylovdim={KRYLOVDIM}, 1 step = initialize + {sweep_its} expand! (m=2..{KRYLOVDIM})")
         parallelism = "single GPU" if not use_dist else \
-            f"basis row-sharded over {world} GPUs (10M rows each); per iteration libkrylov_hip issues 2 ncclAllReduce (2m+1 and 1 doubles) + 1 grouped ncclSend/Recv ghost exchange"
+            (f"basis row-sharded over {world} GPUs ({n_local} rows each, {scaling} scaling); per iteration libkrylov_hip issues 2 ncclAllReduce "
+             "(2m+1 and 1 doubles) + 1 grouped ncclSend/Recv ghost exchange")
     elif args.config == "gkl":
         m_tot, n_tot, per, Kg = 5_000_000, 1_000_000, 20, 30
         if args.ny != NY:                           # reduced size for quick checks: --ny = rows / 2000
@@ -399,7 +423,7 @@ def main():
     ctx.prof_enable(0)
     breakdown = {}
     for name in ("k_project", "k_unproject", "k_unproj_proj", "k_spmv_ell", "k_spmv_dia", "k_spmv_sell", "k_spmv_csr", "k_scal", "k_mgs_step", "k_dot",
-                 "k_axpby", "k_block_gram", "k_block_update", "k_spmm_ell", "k_spmm_dia", "k_mgs_persist"):
+                 "k_axpby", "k_block_gram", "k_block_update", "k_spmm_ell", "k_spmm_dia", "k_mgs_persist", "nccl_allreduce", "nccl_p2p", "nccl_gather"):
         ms, n = ctx.prof_get(name)
         if n:
             breakdown[name] = round(ms, 3)
@@ -417,7 +441,6 @@ def main():
     stats1 = comm.stats() if comm else None
     ranks_agree = None
     if world > 1:
-        import torch
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -427,6 +450,42 @@ def main():
         seen = [None] * world
         dist.all_gather_object(seen, mine)
         ranks_agree = all(v == seen[0] for v in seen)
+
+    def timed(sweep_fn, k):
+        """K sweeps bracketed by barrier + sync on both sides, max over ranks"""
+        barrier(); sync()
+        t_ = time.perf_counter()
+        for _ in range(k):
+            f_ = sweep_fn()
+        barrier(); sync()
+        d_ = time.perf_counter() - t_
+        if world > 1:
+            tt = torch.tensor([d_], dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            d_ = float(tt.item())
+        return d_, f_
+
+    # The timed region above carries HIP-event pairs around the two basis-streaming kernels (the roofline object needs their
+    # durations from THIS region).  The same K sweeps once more with no event anywhere show what the bracketing costs.
+    unbracketed = None
+    if args.config == "lanczos" and not os.environ.get("KK_BENCH_NOPROF"):
+        d_, _ = timed(sweep, K)
+        unbracketed = {"value": round(units_per_sweep * K / d_, 3), "ms_per_step": round(d_ / K * 1e3, 3),
+                       "note": "same K sweeps, no HIP events recorded (the headline region brackets every k_project / k_unproject launch)"}
+
+    # ---------------- the other scaling mode of config 2 as a secondary leg (N > 1)
+    other_leg = None
+    if other_leg_mode:
+        prob2 = build_lanczos(other_leg_mode)
+        prob2["sweep"]()
+        d_, f2 = timed(prob2["sweep"], K)
+        u2 = sweep_its * world if other_leg_mode == "weak" else sweep_its
+        other_leg = {"scaling": other_leg_mode, "value": round(u2 * K / d_, 3), "ms_per_step": round(d_ / K * 1e3, 3),
+                     "rows_per_gpu": prob2["n_local"], "rows_total": prob2["n_global"],
+                     "job_iterations_per_second": round(sweep_its * K / d_, 3),
+                     "hbm_algorithmic_frac_of_peak_per_gpu": round(algorithmic_bytes_sweep(prob2["n_global"], KRYLOVDIM) * K / d_ / 1e9 / (HBM_PEAK_GBPS * world), 4),
+                     "unit": "it/s (10M-row Lanczos iterations, summed over GPUs)" if other_leg_mode == "weak" else "it/s (Lanczos iterations of the one 10M-row problem)"}
+        del prob2
 
     # ---------------- roofline of the dominant kernel (HIP events on the kernels' stream)
     roofline = None
@@ -518,6 +577,10 @@ def main():
         }
         if args.config != "block":
             out["last_alpha"], out["last_beta"] = fact.alphas[-1], fact.betas[-1]
+        if unbracketed:
+            out["without_event_bracketing"] = unbracketed
+        if other_leg:
+            out["other_scaling_leg"] = other_leg
         if strict:
             out["mgs2_strict"] = strict
         if comm:
@@ -525,6 +588,9 @@ def main():
             per = {k: (stats1[k] - stats0[k]) / (K * sweep_its) for k in stats1}
             out["collectives"] = {"library": "RCCL inside libkrylov_hip (kk_comm_init)", "rccl_version": info["rccl_version"],
                                   "ranks": info["world"], "per_iteration": {k: round(v, 3) for k, v in per.items()},
+                                  # stream time of the collectives in the event-profiled warm-up sweep (waiting for the peers included)
+                                  "per_iteration_us": {k: round(breakdown[k] * 1e3 / sweep_its, 2) for k in ("nccl_allreduce", "nccl_p2p", "nccl_gather")
+                                                       if k in breakdown},
                                   "ranks_agree_bitwise": ranks_agree}
         if args.config == "lanczos" and world == 1 and not use_dist and not args.no_cpu_baseline:
             x0_host = x0_handle[0].get()                       # the GPU run's own start vector (80 MB over PCIe, once)

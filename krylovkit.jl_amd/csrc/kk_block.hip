@@ -40,6 +40,10 @@ KK_API int kk_block_apply(kk_op op, kk_basis bx, int cx, kk_basis by, int cy, in
     KK_TRY(check_apply(op, 0, bx, by));
     KK_CHECK(!(bx == by && cx < cy + nb && cy < cx + nb), KK_ERR_INVALID, "kk_block_apply: blocks overlap");
     gram_touch(by, cy);
+    if (op->gather) {   // row-sharded rectangular map: its ghost-only matrix reads the all-gathered buffer, one column at a time
+        for (int j = 0; j < nb; ++j) KK_TRY(rect_apply(op, 0, bx->col(cx + j), by->col(cy + j)));
+        return KK_OK;
+    }
     return kk_launch_spmm(op->ctx, op->A, bx->col(cx), bx->ld, by->col(cy), by->ld, nb);
 }
 
@@ -475,7 +479,8 @@ KK_API int kk_blocklanczos_expand(kk_op op, kk_basis b, int k, int bs_r, int c_r
     if (c->block_mode == 1 && c->block_async && bs_r >= 2 && bs_r <= 16 && k + bs_r <= KK_MAX_M) {
         bool fine = false;
         if (kk_bu_stride(bs_r) > bs_r)   // pad columns of the row-major panels: zero once, the kernels write only the first bs_r
-            KK_HIP(hipMemsetAsync(c->blk + AB_P, 0, (size_t)(k + bs_r) * kk_bu_stride(bs_r) * sizeof(double), c->stream));
+            KK_HIP(hipMemsetAsync(c->blk + AB_P, 0, (size_t)((c->block_fuse & 4) ? 3 : 1) * (k + bs_r) * kk_bu_stride(bs_r) * sizeof(double),
+                                  c->stream));   // one-pass mode keeps three panels (P, G2, Pc) back to back
         KK_TRY(blocklanczos_expand_async(op, b, k, bs_r, c_r, c_rnext, qr_tol, B, ldb, M, ldm, norm_R, &fine, use_gw));
         if (fine) {
             *bs_next = bs_r;

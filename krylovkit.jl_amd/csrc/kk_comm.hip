@@ -149,6 +149,7 @@ KK_API int kk_comm_stats(kk_ctx c, int64_t* n_allreduce, int64_t* n_p2p_groups, 
 int kk_comm_allreduce_sum(kk_ctx c, double* dev_ptr, int64_t count) {
     kk_comm_s* k = c->comm;
     if (!k || !k->active || count <= 0) return KK_OK;
+    kk_prof_scope ps(c, "nccl_allreduce");   // stream time of the collective (waiting for the peers included) when profiling is on
     KK_NCCL(g_rccl.AllReduce(dev_ptr, dev_ptr, (size_t)count, ncclDouble, ncclSum, (ncclComm_t)k->nccl, c->stream));
     ++k->n_allreduce;
     return KK_OK;
@@ -178,6 +179,24 @@ KK_API int kk_comm_barrier(kk_ctx c) {
     return KK_OK;
 }
 
+// A collective entry point validates its arguments locally and then agrees on the outcome BEFORE the first data
+// collective: a rank that simply returned on bad input would leave its peers blocked in the exchange that follows.
+int kk_comm_agree_status(kk_ctx c, int local, int* worst) {
+    *worst = local;
+    kk_comm_s* k = c->comm;
+    if (!k || k->world == 1) return KK_OK;
+    double* t = SCP(c, SC_TMP2);
+    const double mine = (double)(-local);   // statuses are <= 0: the maximum of the negated codes is the worst one
+    KK_HIP(hipMemcpyAsync(t, &mine, sizeof(double), hipMemcpyHostToDevice, c->stream));
+    KK_HIP(hipStreamSynchronize(c->stream));   // `mine` is a stack variable
+    KK_NCCL(g_rccl.AllReduce(t, t, 1, ncclDouble, ncclMax, (ncclComm_t)k->nccl, c->stream));
+    double w = 0;
+    KK_HIP(hipMemcpyAsync(&w, t, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    KK_HIP(hipStreamSynchronize(c->stream));
+    *worst = -(int)w;
+    return KK_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // internal: integer exchanges used while a sharded operator is set up, ghost exchange, gather / scatter
 // ------------------------------------------------------------------------------------------
@@ -200,6 +219,7 @@ static int p2p_group(kk_ctx c, const void* d_send, const int64_t* send_counts, v
             KK_HIP(hipMemcpyAsync(d_recv, d_send, (size_t)send_counts[0] * es, hipMemcpyDeviceToDevice, c->stream));
         return KK_OK;
     }
+    kk_prof_scope ps(c, "nccl_p2p");
     KK_NCCL(g_rccl.GroupStart());
     int64_t so = 0, ro = 0;
     ncclResult_t bad = ncclSuccess;
@@ -255,6 +275,7 @@ int kk_halo_exchange_block(kk_ctx c, const kk_sparse_dev& M, const double* X, in
                                   hipMemcpyDeviceToDevice, c->stream));
         return KK_OK;
     }
+    kk_prof_scope ps(c, "nccl_p2p");
     KK_NCCL(g_rccl.GroupStart());
     ncclResult_t bad = ncclSuccess;
     for (int j = 0; j < nb && bad == ncclSuccess; ++j) {
@@ -282,6 +303,7 @@ int kk_comm_allgather_f64(kk_ctx c, const double* d_stage, double* d_full, int64
         KK_HIP(hipMemcpyAsync(d_full, d_stage, shard * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
         return KK_OK;
     }
+    kk_prof_scope ps(c, "nccl_gather");
     KK_NCCL(g_rccl.AllGather(d_stage, d_full, (size_t)shard, ncclDouble, (ncclComm_t)k->nccl, c->stream));
     ++k->n_gather;
     return KK_OK;
@@ -293,6 +315,7 @@ int kk_comm_reducescatter_f64(kk_ctx c, const double* d_full, double* d_stage, i
         KK_HIP(hipMemcpyAsync(d_stage, d_full, shard * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
         return KK_OK;
     }
+    kk_prof_scope ps(c, "nccl_gather");
     KK_NCCL(g_rccl.ReduceScatter(d_full, d_stage, (size_t)shard, ncclDouble, ncclSum, (ncclComm_t)k->nccl, c->stream));
     ++k->n_gather;
     return KK_OK;

@@ -162,6 +162,8 @@ KK_API int kk_ctx_set_option(kk_ctx c, const char* key, double value) {
         c->fuse_passes = value != 0;
     } else if (!strcmp(key, "mgs_persist")) {
         c->mgs_persist = value != 0;
+    } else if (!strcmp(key, "persist_fault")) {
+        c->persist_fault = (int)value;   // test hook: the next `value` persistent launches behave like a grid-barrier timeout
     } else if (!strcmp(key, "persist_threads")) {
         KK_CHECK(value == 512 || value == 1024, KK_ERR_INVALID, "persist_threads must be 512 or 1024");
         c->persist_threads = (int)value;
@@ -231,6 +233,7 @@ KK_API int kk_ctx_get_option(kk_ctx c, const char* key, double* value) {
     else if (!strcmp(key, "fuse_passes")) *value = c->fuse_passes;
     else if (!strcmp(key, "mgs_persist")) *value = c->mgs_persist;
     else if (!strcmp(key, "persist_threads")) *value = c->persist_threads;
+    else if (!strcmp(key, "persist_timeouts")) *value = c->persist_timeouts;
     else if (!strcmp(key, "persist_nt")) *value = c->persist_nt;
     else if (!strcmp(key, "speculate")) *value = c->speculate;
     else if (!strcmp(key, "spmv_dia")) *value = c->spmv_dia;

@@ -47,6 +47,8 @@ int rect_apply(kk_op op, int transpose, const double* x, double* y);
 int kk_comm_allgather_i64(kk_ctx c, const int64_t* d_send, int64_t* d_recv, int64_t count);
 int kk_comm_exchange_i64(kk_ctx c, const int64_t* d_send, const int64_t* send_counts, int64_t* d_recv,
                          const int64_t* recv_counts);
+// collective entry points: *worst = the most severe (most negative) status any rank brought along (world 1: `local`)
+int kk_comm_agree_status(kk_ctx c, int local, int* worst);
 int kk_comm_allgather_f64(kk_ctx c, const double* d_stage, double* d_full, int64_t shard);
 int kk_comm_reducescatter_f64(kk_ctx c, const double* d_full, double* d_stage, int64_t shard);
 
@@ -60,7 +62,7 @@ int pass_mgs_strict(kk_ctx c, const double* V, int64_t ld, int m, double* w, int
                     const double* carry_q, const double* carry_s, bool leave_carry);
 int pass_mgs_strict_sweeps(kk_ctx c, const double* V, int64_t ld, int m, int nsweeps, double* w, const int64_t* ws_s,
                            bool want_norm, int slot, const double* carry_q, const double* carry_s);
-int persist_check(kk_ctx c);
+int persist_check(kk_ctx c, bool* timed_out);
 int gram_ensure(kk_basis b, int upto /* exclusive */);
 int gram_device(kk_basis b);   // device mirror of the host Gram rows (created on first use)
 int lowsync_project_dev(kk_basis b, int m, const double* w, const double* pre_vec, const double* pre_a,

@@ -143,6 +143,8 @@ struct kk_ctx_s {
     void* d_sync = nullptr;      // device: hand-off granules + error flag of the in-kernel grid reduction (KK_SYNC_BYTES)
     int* h_sync = nullptr;       // pinned: read-back of the error flag
     bool persist_pending = false;  // a persistent launch has not been checked for a barrier timeout yet
+    int persist_timeouts = 0;      // grid-barrier timeouts recovered so far (each one switched the persistent route off)
+    int persist_fault = 0;         // test hook (option "persist_fault"): the next N persistent launches time out artificially
     int fuse_passes = 1;         // fuse unproject(pass i) with project(pass i+1)
     int speculate = 1;           // enqueue the next expand's SpMV before syncing the host
     kk_basis spec_owner = nullptr;   // basis whose speculative result currently sits in SC_SPECA / its next column

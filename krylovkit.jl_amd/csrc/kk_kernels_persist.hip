@@ -162,8 +162,12 @@ __global__ __launch_bounds__(PT) void k_mgs_persist(const double* __restrict__ V
                                                     double* __restrict__ w, const double* __restrict__ carry_q,
                                                     const double* __restrict__ carry_s, double* __restrict__ out_s,
                                                     int out_stride, double* __restrict__ nrm_out3,
-                                                    gu64* __restrict__ gran, int* __restrict__ err) {
+                                                    gu64* __restrict__ gran, int* __restrict__ err, int fault) {
     __shared__ double sm[PT / 64];
+    if (fault && blockIdx.x == 0) {   // test hook (option "persist_fault"): block 0 behaves like a block whose spin ran out
+        if (threadIdx.x == 0) __hip_atomic_store(err, 1, RLX_AGENT);
+        return;
+    }
     constexpr int B = (PT == 1024 && NV > 16) ? 2 : 4;   // loads in flight per stream and lane; 128-register budget at 1024 threads
     const unsigned sbytes = gridDim.x * PT * 16u;                      // one grid-row in bytes
     const unsigned voff = (blockIdx.x * PT + threadIdx.x) * 16u;       // this lane's byte offset inside a grid-row
@@ -194,6 +198,10 @@ __global__ __launch_bounds__(PT) void k_mgs_persist(const double* __restrict__ V
             }
         }
     }
+    // commit: a block that timed out in any grid reduction raised the flag and left; the blocks that got through re-read it
+    // here, so that either every block writes its rows of w back or (up to the microsecond around a 3 s timeout) none does
+    // and HBM still holds the input -- the host then repeats the sweep on the launch-per-vector route (persist_check)
+    if (__hip_atomic_load(err, RLX_AGENT)) return;
 #pragma unroll
     for (int i = 0; i < NV; ++i) bstore(rw, voff, (unsigned)i * sbytes, wr[i]);
 }
@@ -227,8 +235,10 @@ int kk_launch_mgs_persist(kk_ctx ctx, const double* V, int64_t ld, int m, int ns
     unsigned long long* gran = (unsigned long long*)ctx->d_sync;
     int* err = (int*)((char*)ctx->d_sync + KK_SYNC_ERR_OFFSET);
     KK_HIP(hipMemsetAsync(gran, 0, (size_t)4 * ctx->num_cus * sizeof(unsigned long long), ctx->stream));
+    int fault = 0;
+    if (ctx->persist_fault > 0) { --ctx->persist_fault; fault = 1; }
     void* args[] = {(void*)&V, (void*)&ld, (void*)&m, (void*)&nsweeps, (void*)&w, (void*)&carry_q, (void*)&carry_s,
-                    (void*)&out_s, (void*)&out_stride, (void*)&nrm_out3, (void*)&gran, (void*)&err};
+                    (void*)&out_s, (void*)&out_stride, (void*)&nrm_out3, (void*)&gran, (void*)&err, (void*)&fault};
     const bool nt = ctx->persist_nt != 0;
     kk_prof_scope ps(ctx, "k_mgs_persist");
     if (pt == 1024) {

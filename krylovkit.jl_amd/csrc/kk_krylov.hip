@@ -259,12 +259,22 @@ KK_API int kk_lanczos_expand(kk_op op, kk_basis b, int c0, int k, kk_orth_t orth
     } else if (orth == KK_MGS2) {
         // strict: w -= alpha0 v fused with the first dot of the sweep   lanczos.jl:329-334
         const int64_t offs[1] = {WS_S};
-        KK_TRY(pass_mgs_strict_sweeps(c, V, ld, m, 1, w, offs, true, 0, v, a0_dev));
-        if (!c->persist_pending) KK_TRY(ws_fetch_async(c, WS_SCAL, 1, 0));   // (the persistent route fetched the scalars already)
-        KK_TRY(fetch_mark(c));
-        if (!kk_sharded(c)) KK_TRY(speculate_next(op, b, c0, k + 1, 2, true, 0.0));   // |w| and 1/|w| are on the device
-        KK_TRY(fetch_wait(c));
-        KK_TRY(persist_check(c));
+        for (int attempt = 0;; ++attempt) {
+            KK_TRY(pass_mgs_strict_sweeps(c, V, ld, m, 1, w, offs, true, 0, v, a0_dev));
+            if (!c->persist_pending) KK_TRY(ws_fetch_async(c, WS_SCAL, 1, 0));   // (the persistent route fetched the scalars already)
+            KK_TRY(fetch_mark(c));
+            if (!kk_sharded(c)) KK_TRY(speculate_next(op, b, c0, k + 1, 2, true, 0.0));   // |w| and 1/|w| are on the device
+            KK_TRY(fetch_wait(c));
+            bool redo = false;
+            KK_TRY(persist_check(c, &redo));
+            if (!redo) break;
+            // The grid barrier of the persistent kernel timed out (GPU shared with another job): no block wrote w back, so w
+            // = A v - beta_old v_prev, the pending pair (v, alpha0) and the basis are exactly what the sweep started from.  v has
+            // already been scaled and the SpMV is done -- neither is repeated; only the sweep runs again, on the
+            // launch-per-vector route, and the speculative apply that consumed the norm of the failed launch is dropped.
+            b->spec_valid = false;
+            KK_CHECK(attempt == 0, KK_ERR_HIP, "kk_lanczos_expand: the launch-per-vector MGS route reported a grid-barrier timeout (internal error)");
+        }
         a = pin(c, WS_SCAL + SC_ALPHA0)[0] + pin(c, WS_S)[m - 1];
         bt = pin(c, WS_SCAL + SC_NRM2)[1];
         passes = 1;

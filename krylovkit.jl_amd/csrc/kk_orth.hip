@@ -217,19 +217,41 @@ int pass_mgs_strict_sweeps(kk_ctx c, const double* V, int64_t ld, int m, int nsw
     }
     return KK_OK;
 }
-// after the host synchronisation that follows a persistent launch: did its grid barrier time out?
-int persist_check(kk_ctx c) {
+// after the host synchronisation that follows a persistent launch: did its grid barrier time out?  Then no block wrote w
+// back (HBM holds the input of the sweep, the pending axpy operands are untouched), the persistent route is switched off
+// for this context and *timed_out tells the caller to repeat the sweep -- pass_mgs_strict_sweeps now takes the
+// launch-per-vector route.  Callers that enqueued dependent work behind the launch (a speculative next-step apply)
+// must cancel it first: it consumed scalars the failed launch never wrote.
+int persist_check(kk_ctx c, bool* timed_out) {
+    *timed_out = false;
     if (!c->persist_pending) return KK_OK;
     c->persist_pending = false;
     if (c->h_sync[0] != 0) {
         c->h_sync[0] = 0;
-        (void)hipMemsetAsync((char*)c->d_sync + KK_SYNC_ERR_OFFSET, 0, sizeof(int), c->stream);
-        c->mgs_persist = 0;   // the caller may retry: the work vector in HBM was not modified
-        kk_set_error("persistent MGS kernel: grid barrier timed out (GPU shared with another job?); the work vector is "
-                     "unchanged, the persistent route is now disabled for this context -- repeat the call");
-        return KK_ERR_HIP;
+        KK_HIP(hipMemsetAsync((char*)c->d_sync + KK_SYNC_ERR_OFFSET, 0, sizeof(int), c->stream));
+        c->mgs_persist = 0;
+        ++c->persist_timeouts;
+        *timed_out = true;
     }
     return KK_OK;
+}
+// strict sweeps + the synchronisation that ends them, with the recovery above folded in (no speculation involved)
+static int strict_sweeps_synced(kk_ctx c, const double* V, int64_t ld, int m, int nsweeps, double* w, const int64_t* ws_s,
+                                bool want_norm, int slot, bool last_sync /* final_sync: a requested speculative apply goes out */) {
+    const auto req = c->spec_req;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        KK_TRY(pass_mgs_strict_sweeps(c, V, ld, m, nsweeps, w, ws_s, want_norm, slot, nullptr, nullptr));
+        KK_TRY(last_sync ? final_sync(c) : stream_sync(c));
+        bool redo = false;
+        KK_TRY(persist_check(c, &redo));
+        if (!redo) return KK_OK;
+        if (last_sync && req.active) {   // the speculative apply final_sync enqueued read a norm the failed launch never wrote
+            req.b->spec_valid = false;
+            c->spec_req = req;
+        }
+    }
+    kk_set_error("strict MGS sweep: the launch-per-vector route reported a grid-barrier timeout (internal error)");
+    return KK_ERR_HIP;
 }
 
 // Projection for the low-sync MGS: p = V'(w - a*pre) into pinned slot `slot` (synchronised on
@@ -375,9 +397,7 @@ int orth_run(kk_basis b, int c0, int m, double* w, kk_orth_t alg, double eta, do
                 KK_TRY(final_sync(c));
             } else {
                 const int64_t offs[1] = {WS_S};
-                KK_TRY(pass_mgs_strict_sweeps(c, V, ld, m, 1, w, offs, want_norm, 0, nullptr, nullptr));
-                KK_TRY(final_sync(c));
-                KK_TRY(persist_check(c));
+                KK_TRY(strict_sweeps_synced(c, V, ld, m, 1, w, offs, want_norm, 0, true));
                 memcpy(x, pin(c, WS_S, 0), m * sizeof(double));
             }
             nn = pin(c, WS_SCAL + SC_NRM2, 0)[1];
@@ -406,9 +426,7 @@ int orth_run(kk_basis b, int c0, int m, double* w, kk_orth_t alg, double eta, do
             } else {
                 // the last axpy of sweep 1 is fused with the first dot of sweep 2
                 const int64_t offs[2] = {WS_S, WS_G};
-                KK_TRY(pass_mgs_strict_sweeps(c, V, ld, m, 2, w, offs, want_norm, 0, nullptr, nullptr));
-                KK_TRY(final_sync(c));
-                KK_TRY(persist_check(c));
+                KK_TRY(strict_sweeps_synced(c, V, ld, m, 2, w, offs, want_norm, 0, true));
                 for (int j = 0; j < m; ++j) x[j] = pin(c, WS_S, 0)[j] + pin(c, WS_G, 0)[j];
             }
             nn = pin(c, WS_SCAL + SC_NRM2, 0)[1];
@@ -418,20 +436,24 @@ int orth_run(kk_basis b, int c0, int m, double* w, kk_orth_t alg, double eta, do
             KK_TRY(kk_launch_nrm2(c, w, ld, SCP(c, SC_NRM2B)));
             KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2B, 2, 1));
             const int64_t ir_offs[1] = {WS_S};
-            if (lowsync) KK_TRY(pass_mgs_lowsync(b, c0, m, w, x, true, 0));
-            else KK_TRY(pass_mgs_strict_sweeps(c, V, ld, m, 1, w, ir_offs, true, 0, nullptr, nullptr));
-            KK_TRY(stream_sync(c));
-            KK_TRY(persist_check(c));
+            if (lowsync) {
+                KK_TRY(pass_mgs_lowsync(b, c0, m, w, x, true, 0));
+                KK_TRY(stream_sync(c));
+            } else {
+                KK_TRY(strict_sweeps_synced(c, V, ld, m, 1, w, ir_offs, true, 0, false));
+            }
             double nold = pin(c, WS_SCAL + SC_NRM2B, 1)[1];
             if (!lowsync) memcpy(x, pin(c, WS_S, 0), m * sizeof(double));
             nn = pin(c, WS_SCAL + SC_NRM2, 0)[1];
             passes = 1;
             while (KK_EPS < nn && nn < eta * nold) {
                 nold = nn;
-                if (lowsync) KK_TRY(pass_mgs_lowsync(b, c0, m, w, tmp.data(), true, 0));
-                else KK_TRY(pass_mgs_strict_sweeps(c, V, ld, m, 1, w, ir_offs, true, 0, nullptr, nullptr));
-                KK_TRY(stream_sync(c));
-                KK_TRY(persist_check(c));
+                if (lowsync) {
+                    KK_TRY(pass_mgs_lowsync(b, c0, m, w, tmp.data(), true, 0));
+                    KK_TRY(stream_sync(c));
+                } else {
+                    KK_TRY(strict_sweeps_synced(c, V, ld, m, 1, w, ir_offs, true, 0, false));
+                }
                 for (int j = 0; j < m; ++j) x[j] += lowsync ? tmp[j] : pin(c, WS_S, 0)[j];
                 nn = pin(c, WS_SCAL + SC_NRM2, 0)[1];
                 ++passes;

@@ -424,65 +424,85 @@ KK_API int kk_csr_create_sharded(kk_ctx c, int64_t nrows_local, const int64_t* r
                                  const int64_t* rowptr, const int64_t* colind, const double* val, int index_base,
                                  int flags, kk_op* out) {
     KK_CHECK(c && out && row_offsets && rowptr && (nnz == 0 || (colind && val)), KK_ERR_INVALID, "kk_csr_create_sharded: null arg");
-    KK_CHECK(index_base == 0 || index_base == 1, KK_ERR_INVALID, "index_base must be 0 or 1");
     int rank, world;
     comm_shape(c, &rank, &world);
-    for (int q = 0; q < world; ++q)
-        KK_CHECK(row_offsets[q] <= row_offsets[q + 1], KK_ERR_DIM, "kk_csr_create_sharded: row_offsets must be non-decreasing");
-    const int64_t lo = row_offsets[rank], hi = row_offsets[rank + 1], n_global = row_offsets[world];
-    KK_CHECK(row_offsets[0] == 0 && hi - lo == nrows_local && nrows_local > 0, KK_ERR_DIM,
-             "kk_csr_create_sharded: rank %d owns rows [%lld,%lld) but nrows_local = %lld", rank, (long long)lo, (long long)hi,
-             (long long)nrows_local);
-    KK_TRY(check_ptr_array("kk_csr_create_sharded", rowptr, nrows_local, nnz, index_base));
     KK_HIP(hipSetDevice(c->device));
     // Loop-back mode for one-GPU test boxes (KK_LOOPBACK_GHOST_FROM=r, world size 1 only): the columns >= r, although
     // owned by this rank, are routed through the ghost machinery (request list, gather into the send buffer, exchange
     // -- here a device copy to self --, ghost-indexed reads in the SpMV / SpMM kernels), so that every piece of the
     // multi-GPU data path except the wire itself runs where no second GPU exists.
     int64_t loop_from = -1, loop_below = 0;   // KK_LOOPBACK_GHOST_BELOW = r2: the columns < r2 as well (a middle rank's layout)
-    if (world == 1) {
-        const char* lb = getenv("KK_LOOPBACK_GHOST_FROM");
-        if (lb && *lb) loop_from = atoll(lb);
-        const char* lb2 = getenv("KK_LOOPBACK_GHOST_BELOW");
-        if (lb2 && *lb2) { loop_below = atoll(lb2); if (loop_from < 0) loop_from = n_global; }
+    int64_t lo = 0, hi = 0, n_global = 0, n_ghost = 0;
+    std::vector<int64_t> needed, recv_counts(world, 0), send_counts(world, 0);
+    kk_op op = nullptr;
+    // ---- part 1, LOCAL: validation, renumbering, upload.  This is a collective entry point: a rank that returned from
+    // here on bad input would leave its peers blocked in the all-gather below, so the local status is agreed on first.
+    auto local_part = [&]() -> int {
+        KK_CHECK(index_base == 0 || index_base == 1, KK_ERR_INVALID, "index_base must be 0 or 1");
+        for (int q = 0; q < world; ++q)
+            KK_CHECK(row_offsets[q] <= row_offsets[q + 1], KK_ERR_DIM, "kk_csr_create_sharded: row_offsets must be non-decreasing");
+        lo = row_offsets[rank]; hi = row_offsets[rank + 1]; n_global = row_offsets[world];
+        KK_CHECK(row_offsets[0] == 0 && hi - lo == nrows_local && nrows_local > 0, KK_ERR_DIM,
+                 "kk_csr_create_sharded: rank %d owns rows [%lld,%lld) but nrows_local = %lld", rank, (long long)lo, (long long)hi,
+                 (long long)nrows_local);
+        KK_TRY(check_ptr_array("kk_csr_create_sharded", rowptr, nrows_local, nnz, index_base));
+        if (world == 1) {
+            const char* lb = getenv("KK_LOOPBACK_GHOST_FROM");
+            if (lb && *lb) loop_from = atoll(lb);
+            const char* lb2 = getenv("KK_LOOPBACK_GHOST_BELOW");
+            if (lb2 && *lb2) { loop_below = atoll(lb2); if (loop_from < 0) loop_from = n_global; }
+        }
+        auto is_ghost = [&](int64_t g) { return g < lo || g >= hi || (loop_from >= 0 && (g >= loop_from || g < loop_below)); };
+        // ghost columns: sorted unique global ids outside [lo, hi) -> grouped by owner
+        for (int64_t p = 0; p < nnz; ++p) {
+            const int64_t g = colind[p] - index_base;
+            KK_CHECK(g >= 0 && g < n_global, KK_ERR_DIM, "kk_csr_create_sharded: column index %lld out of range at entry %lld",
+                     (long long)g, (long long)p);
+            if (is_ghost(g)) needed.push_back(g);
+        }
+        std::sort(needed.begin(), needed.end());
+        needed.erase(std::unique(needed.begin(), needed.end()), needed.end());
+        n_ghost = (int64_t)needed.size();
+        KK_CHECK(nrows_local + n_ghost < (int64_t)1 << 31 && nnz < (int64_t)1 << 31, KK_ERR_UNSUPPORTED,
+                 "kk_csr_create_sharded: local block too large for int32 indices");
+        for (int64_t g : needed) {
+            const int q = (int)(std::upper_bound(row_offsets, row_offsets + world + 1, g) - row_offsets) - 1;
+            recv_counts[q]++;
+        }
+        op = new kk_op_s();
+        op->ctx = c; op->nrows = nrows_local; op->ncols = nrows_local + n_ghost; op->nnz = nnz; op->flags = flags;
+        kk_host_csr h;
+        h.nrows = nrows_local; h.ncols = nrows_local + n_ghost;
+        h.rowptr.resize(nrows_local + 1);
+        for (int64_t i = 0; i <= nrows_local; ++i) h.rowptr[i] = rowptr[i] - index_base;
+        h.col.resize(nnz); h.val.assign(val, val + nnz);
+        for (int64_t p = 0; p < nnz; ++p) {
+            const int64_t g = colind[p] - index_base;
+            h.col[p] = !is_ghost(g) ? (int32_t)(g - lo)
+                                    : (int32_t)(nrows_local + (std::lower_bound(needed.begin(), needed.end(), g) - needed.begin()));
+        }
+        KK_TRY(upload_sparse(c, h, op->A));
+        if (n_ghost > 0) KK_TRY(detect_stencil_sharded(h, nrows_local, op->A));
+        kk_halo_plan* plan = new kk_halo_plan();
+        op->A.plan = plan;
+        hipError_t e = hipMalloc(&plan->d_ghost, std::max<int64_t>(n_ghost, 1) * sizeof(double));
+        if (e == hipSuccess) e = hipMemsetAsync(plan->d_ghost, 0, std::max<int64_t>(n_ghost, 1) * sizeof(double), c->stream);
+        if (e != hipSuccess) return kk_hip_fail(e, "hipMalloc (ghost buffer)", __FILE__, __LINE__);
+        return KK_OK;
+    };
+    int s = local_part();
+    auto fail = [&](int st) { if (op) kk_op_free(op); return st; };
+    {
+        int worst = s;
+        const int sa = kk_comm_agree_status(c, s, &worst);
+        if (sa != KK_OK) return fail(sa);
+        if (s != KK_OK) return fail(s);
+        if (worst != KK_OK) {
+            kk_set_error("kk_csr_create_sharded: another rank rejected its arguments (status %d); no operator was created on any rank", worst);
+            return fail(worst);
+        }
     }
-    auto is_ghost = [&](int64_t g) { return g < lo || g >= hi || (loop_from >= 0 && (g >= loop_from || g < loop_below)); };
-    // ghost columns: sorted unique global ids outside [lo, hi) -> grouped by owner
-    std::vector<int64_t> needed;
-    for (int64_t p = 0; p < nnz; ++p) {
-        const int64_t g = colind[p] - index_base;
-        KK_CHECK(g >= 0 && g < n_global, KK_ERR_DIM, "kk_csr_create_sharded: column index %lld out of range at entry %lld",
-                 (long long)g, (long long)p);
-        if (is_ghost(g)) needed.push_back(g);
-    }
-    std::sort(needed.begin(), needed.end());
-    needed.erase(std::unique(needed.begin(), needed.end()), needed.end());
-    const int64_t n_ghost = (int64_t)needed.size();
-    KK_CHECK(nrows_local + n_ghost < (int64_t)1 << 31 && nnz < (int64_t)1 << 31, KK_ERR_UNSUPPORTED,
-             "kk_csr_create_sharded: local block too large for int32 indices");
-    std::vector<int64_t> recv_counts(world, 0), send_counts(world, 0);
-    for (int64_t g : needed) {
-        const int q = (int)(std::upper_bound(row_offsets, row_offsets + world + 1, g) - row_offsets) - 1;
-        recv_counts[q]++;
-    }
-    kk_op op = new kk_op_s();
-    op->ctx = c; op->nrows = nrows_local; op->ncols = nrows_local + n_ghost; op->nnz = nnz; op->flags = flags;
-    kk_host_csr h;
-    h.nrows = nrows_local; h.ncols = nrows_local + n_ghost;
-    h.rowptr.resize(nrows_local + 1);
-    for (int64_t i = 0; i <= nrows_local; ++i) h.rowptr[i] = rowptr[i] - index_base;
-    h.col.resize(nnz); h.val.assign(val, val + nnz);
-    for (int64_t p = 0; p < nnz; ++p) {
-        const int64_t g = colind[p] - index_base;
-        h.col[p] = !is_ghost(g) ? (int32_t)(g - lo)
-                                : (int32_t)(nrows_local + (std::lower_bound(needed.begin(), needed.end(), g) - needed.begin()));
-    }
-    int s = upload_sparse(c, h, op->A);
-    if (s == KK_OK && n_ghost > 0) s = detect_stencil_sharded(h, nrows_local, op->A);
-    if (s != KK_OK) { free_sparse(op->A); delete op; return s; }
-    kk_halo_plan* plan = new kk_halo_plan();
-    op->A.plan = plan;
-    auto fail = [&](int st) { kk_op_free(op); return st; };
+    kk_halo_plan* plan = op->A.plan;
     int64_t *d_a = nullptr, *d_b = nullptr;
     if (world > 1) {
         // counts[r * world + q] = number of entries rank r needs from rank q
@@ -503,10 +523,9 @@ KK_API int kk_csr_create_sharded(kk_ctx c, int64_t nrows_local, const int64_t* r
     plan->send_counts = send_counts; plan->recv_counts = recv_counts;
     for (int q = 0; q < world; ++q) { plan->total_send += send_counts[q]; plan->total_recv += recv_counts[q]; }
     {
-        hipError_t e = hipMalloc(&plan->d_ghost, std::max<int64_t>(n_ghost, 1) * sizeof(double));
-        if (e == hipSuccess) e = hipMemsetAsync(plan->d_ghost, 0, std::max<int64_t>(n_ghost, 1) * sizeof(double), c->stream);
-        if (e == hipSuccess) e = hipMalloc(&plan->d_sendbuf, std::max<int64_t>(plan->total_send, 1) * sizeof(double));
+        hipError_t e = hipMalloc(&plan->d_sendbuf, std::max<int64_t>(plan->total_send, 1) * sizeof(double));
         if (e == hipSuccess) e = hipMalloc(&plan->d_send_idx, std::max<int64_t>(plan->total_send, 1) * sizeof(int64_t));
+        // (an allocation failure here is fatal for the run either way: the peers are already committed to the exchange below)
         if (e != hipSuccess) return fail(kk_hip_fail(e, "hipMalloc (ghost plan)", __FILE__, __LINE__));
     }
     if (world > 1) {

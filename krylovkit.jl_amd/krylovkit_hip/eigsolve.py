@@ -366,7 +366,7 @@ def bieigsolve(A, v0, w0, howmany: int = 1, which: str = "LM", alg=None, **kw):
     hVS = [h[:hm] @ vecsS[:, i] for i in range(hm)]
     kVT = [k[:hm] @ vecsT[:, i] for i in range(hm)]
     rVh, rWh = rV.get(), rW.get()
-    nV, nW = float(np.linalg.norm(rVh)), float(np.linalg.norm(rWh))
+    nV, nW = rV.norm(), rW.norm()   # device norms: all-reduced under a communicator
     infoS = ConvergenceInfo(converged, [rVh * s for s in hVS], np.array([nV * abs(s) for s in hVS]), numiter, numops)
     infoT = ConvergenceInfo(converged, [rWh * s for s in kVT], np.array([nW * abs(s) for s in kVT]), numiter, numops)
     return valuesS, (vectorsS, vectorsT), (infoS, infoT)

@@ -37,18 +37,20 @@ def linsolve(A, b, x0=None, alg: Optional[GMRES] = None, a0: float = 0.0, a1: fl
     ctx = op.ctx
     n = op.shape[0]
     b = np.asarray(b, dtype=np.float64)
-    if alg is None:
-        if tol is None:   # tol::Real = max(atol, rtol * norm(b))   linsolve.jl:131-133
-            atol = KrylovDefaults.tol if atol is None else atol
-            rtol = KrylovDefaults.tol if rtol is None else rtol
-            tol = max(atol, rtol * float(np.linalg.norm(b)))
-        alg = GMRES(kw.get("orth", KrylovDefaults.orth), kw.get("maxiter", KrylovDefaults.maxiter),
-                    kw.get("krylovdim", KrylovDefaults.krylovdim), tol)
-    krylovdim, maxiter, tol = alg.krylovdim, alg.maxiter, alg.tol
     # work vectors: 0 = b, 1 = x, 2 = r, 3 = tmp
     W = DeviceBasis(n, 4, ctx)
     vb, vx, vr, vt = HipVec(W, 0), HipVec(W, 1), HipVec(W, 2), HipVec(W, 3)
     vb.set(b)
+    if alg is None:
+        if tol is None:   # tol::Real = max(atol, rtol * norm(b))   linsolve.jl:131-133
+            atol = KrylovDefaults.tol if atol is None else atol
+            rtol = KrylovDefaults.tol if rtol is None else rtol
+            # norm(b) on the device: under a communicator `b` is this rank's block and the norm is all-reduced, so every
+            # rank forms the same tolerance (a host norm of the local block would let the ranks stop at different steps)
+            tol = max(atol, rtol * vb.norm())
+        alg = GMRES(kw.get("orth", KrylovDefaults.orth), kw.get("maxiter", KrylovDefaults.maxiter),
+                    kw.get("krylovdim", KrylovDefaults.krylovdim), tol)
+    krylovdim, maxiter, tol = alg.krylovdim, alg.maxiter, alg.tol
     if x0 is None:
         vx.zero_()
     else:

@@ -28,11 +28,12 @@ def lssolve(A, b, alg: Optional[LSMR] = None, lam: float = 0.0, *, rtol: float =
     op = _as_operator(A)
     nu, nv = op.shape
     b = np.asarray(b, dtype=np.float64)
+    BU = DeviceBasis(nu, 5, op.ctx)            # 0 = u, 1 = r, 2 = Ah, 3 = Ahbar, 4 = Av
     if alg is None:
-        kw.setdefault("tol", max(atol, rtol * float(np.linalg.norm(b))))
+        # norm(b) on the device (all-reduced under a communicator: identical tolerance on every rank)
+        kw.setdefault("tol", max(atol, rtol * HipVec(BU, 0).set(b).norm()))
         alg = LSMR(**kw)
     K, maxiter, tol = alg.krylovdim, alg.maxiter, alg.tol
-    BU = DeviceBasis(nu, 5, op.ctx)            # 0 = u, 1 = r, 2 = Ah, 3 = Ahbar, 4 = Av
     BV = DeviceBasis(nv, K + 5, op.ctx)        # 0..K-1 = V (circular), K / K+4 = work vectors, K+1 = x, K+2 = h, K+3 = hbar
     lib = BU._lib
     u, r, Ah, Ahbar, Av = (HipVec(BU, i) for i in range(5))

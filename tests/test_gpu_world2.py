@@ -1,0 +1,118 @@
+"""libkrylov_hip's NATIVE multi-rank path with more than one rank, on the one GPU of a test box  (SURVEY.md 8(e)).
+
+Real RCCL refuses two ranks on one device, so until an 8-GPU node runs the bench the code behind `kk_comm_init(world > 1)`
+-- the ghost-plan negotiation of kk_csr_create_sharded (all-gather of the counts, grouped exchange of the request lists),
+ONE grouped ncclSend / ncclRecv per sparse apply, ncclAllGather / ncclReduceScatter of the rectangular map, the
+all-reduce at every finalize site -- would be first-run code.  These tests start WORLD processes that all open cuda:0
+and set KK_RCCL_LIB to tests/fake_rccl/libfake_rccl.so (a stand-in that implements the twelve nccl* symbols
+csrc/kk_comm.hip binds over a mapped file + host staging; self-tested without a GPU in tests/test_fake_rccl.py).
+Everything above the nccl* calls is the shipped code: the ordinary iterators and drivers on local row blocks, compared
+with the serial oracle on the global problem inside every rank (tests/world2_worker.py)."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = Path(__file__).resolve().parent
+ROOT = HERE.parent
+FAKE = HERE / "fake_rccl" / "libfake_rccl.so"
+
+
+def _env(tmp_path):
+    subprocess.run(["make", "-s", "-C", str(HERE / "fake_rccl")], check=True)
+    env = dict(os.environ, KK_RCCL_LIB=str(FAKE), KK_FAKE_RCCL_DIR=str(tmp_path), KK_FAKE_RCCL_TIMEOUT="90")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return env
+
+
+def run_world(scenario, world, tmp_path, timeout=600):
+    env = _env(tmp_path)
+    procs = [subprocess.Popen([sys.executable, str(HERE / "world2_worker.py"), scenario, str(r), str(world), str(tmp_path)],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=timeout)[0])
+    except subprocess.TimeoutExpired:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        outs = [p.communicate()[0] for p in procs]
+        pytest.fail(f"world-{world} scenario {scenario} did not finish within {timeout} s\n" + "\n---\n".join(o[-3000:] for o in outs))
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"world2 {scenario} rank {r} OK" in o, f"rank {r} (exit {p.returncode}):\n{o[-6000:]}"
+    return [json.loads((tmp_path / f"report.{r}.json").read_text()) for r in range(world)]
+
+
+def test_world2_lanczos_grid_split(tmp_path):
+    """config-2 shape: stencil split along grid lines; six orthogonalisers x two MGS modes against the oracle; exactly two
+    all-reduces per expand! for CGS2 / low-sync MGS2; one ghost exchange per apply"""
+    reps = run_world("lanczos_grid", 2, tmp_path)
+    assert all(r["stats"]["p2p_groups"] > 0 and r["stats"]["allreduce"] > 0 for r in reps)
+    assert reps[0]["grid.mgs2.mgs1"] == reps[1]["grid.mgs2.mgs1"]        # bit-identical scalars on both ranks
+
+
+def test_world2_lanczos_random_sparsity_uneven_split(tmp_path):
+    """ghost-plan negotiation on a random sparsity pattern with blocks of different sizes; plain, affine and block applies"""
+    reps = run_world("lanczos_random", 2, tmp_path)
+    assert all(r["stats"]["p2p_groups"] > 0 for r in reps)
+
+
+def test_world3_lanczos_random_sparsity(tmp_path):
+    """three ranks: every rank exchanges with two peers in one group (a middle rank has ghosts on both sides)"""
+    run_world("lanczos_random", 3, tmp_path)
+
+
+def test_world2_gkl_sharded_rect(tmp_path):
+    """config-4 shape: kk_csr_create_sharded_rect, all-gather before A v and reduce-scatter after A'u across real peers,
+    six orthogonalisers x two MGS modes, svdsolve with restarts"""
+    reps = run_world("gkl", 2, tmp_path)
+    assert all(r["stats"]["gather"] > 0 for r in reps)
+
+
+def test_world2_blocklanczos(tmp_path):
+    """config-5 shape: sharded block step in both block modes + the issue-#143 known answer (rank drop) on an uneven split"""
+    run_world("block", 2, tmp_path)
+
+
+def test_world2_eigsolve_gmres_cg(tmp_path):
+    """drivers on local blocks: thick-restart eigsolve (numiter / numops = oracle), GMRES whose tolerance comes from the
+    all-reduced |b| (ranks with very different local norms stop at the same step), CG"""
+    reps = run_world("solvers", 2, tmp_path)
+    assert reps[0]["gmres"] == reps[1]["gmres"] and reps[0]["cg"] == reps[1]["cg"]
+
+
+def test_world2_collective_create_rejects_bad_input_on_all_ranks(tmp_path):
+    """kk_csr_create_sharded agrees on the local validation status before its first data collective"""
+    reps = run_world("bad_input", 2, tmp_path, timeout=200)
+    assert reps[0]["status"] == reps[1]["status"] != 0
+
+
+@pytest.mark.parametrize("config,extra", [("lanczos", []), ("lanczos", ["--scaling", "strong"]), ("gkl", []), ("block", [])])
+def test_world2_bench_end_to_end(tmp_path, config, extra):
+    """`python bench.py --gpus 2` exactly as the driver launches it (torch.distributed.run on 127.0.0.1), reduced size,
+    both ranks on cuda:0 over the stand-in: one JSON line, bit-identical scalars on both ranks, ghost exchanges counted"""
+    env = _env(tmp_path)
+    env["KK_BENCH_SPAWNED"] = ""
+    ny = {"lanczos": "64", "gkl": "50", "block": "64"}[config]
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--config", config, "--ny", ny,
+           "--deadline", "500"] + extra
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-6000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0
+    coll = line["collectives"]
+    assert coll["ranks"] == 2 and coll["rccl_version"] == 29999 and coll["ranks_agree_bitwise"] is True
+    per = coll["per_iteration"]
+    if config == "lanczos":
+        assert 2.0 <= per["allreduce"] <= 2.2 and per["p2p_groups"] >= 1.0          # 2 all-reduces + 1 ghost exchange per expand!
+        assert line["scaling"] == ("strong" if extra else "weak")
+    elif config == "gkl":
+        assert per["gather"] >= 2.0
+    else:
+        assert per["p2p_groups"] >= 1.0 and per["allreduce"] > 0

@@ -1,0 +1,310 @@
+"""One rank of a world-N run of libkrylov_hip's NATIVE multi-rank path (kk_comm_init, kk_csr_create_sharded*, the
+all-reduces at every finalize site) with every rank on the box's single GPU: KK_RCCL_LIB points at the test-only RCCL
+stand-in tests/fake_rccl/libfake_rccl.so, which moves the collectives through a mapped file.  Driven by
+tests/test_gpu_world2.py:   python world2_worker.py <scenario> <rank> <world> <rendezvous dir>
+Every scenario builds the same global problem on every rank (seeded), keeps its own row block, runs the ORDINARY
+iterators / drivers of krylovkit_hip on it and compares with the serial oracle (oracle/krylov_oracle.py) run on the
+global problem.  TEST INFRASTRUCTURE."""
+import json
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import scipy.sparse as sp
+
+HERE = Path(__file__).resolve().parent
+ROOT = HERE.parent
+sys.path.insert(0, str(ROOT / "krylovkit.jl_amd"))
+sys.path.insert(0, str(ROOT / "oracle"))
+
+import krylovkit_hip as kk            # noqa: E402
+from krylovkit_hip import dist as kd  # noqa: E402
+import krylov_oracle as ko            # noqa: E402
+
+scenario, rank, world, rdv = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), Path(sys.argv[4])
+
+
+def file_bcast(obj):
+    """rank 0's 128-byte communicator id reaches the other ranks through the rendezvous directory"""
+    f = rdv / "comm_id"
+    if rank == 0:
+        (rdv / "comm_id.tmp").write_bytes(obj)
+        (rdv / "comm_id.tmp").rename(f)
+        return obj
+    t0 = time.time()
+    while not f.exists():
+        assert time.time() - t0 < 120, "rank 0 never published the communicator id"
+        time.sleep(0.01)
+    return f.read_bytes()
+
+
+def relerr(a, b):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300)))
+
+
+def orth_pairs():
+    return [(kk.ClassicalGramSchmidt(), ko.CGS), (kk.ModifiedGramSchmidt(), ko.MGS), (kk.ClassicalGramSchmidt2(), ko.CGS2),
+            (kk.ModifiedGramSchmidt2(), ko.MGS2), (kk.ClassicalGramSchmidtIR(0.75), ko.CGSIR(0.75)),
+            (kk.ModifiedGramSchmidtIR(0.75), ko.MGSIR(0.75))]
+
+
+def uneven_offsets(n, seed):
+    """row blocks of clearly different sizes whose boundaries fall anywhere (not on grid lines)"""
+    cuts = np.sort(np.random.default_rng(seed).choice(np.arange(n // (4 * world), n - n // (4 * world)), world - 1, replace=False))
+    return np.concatenate([[0], cuts, [n]]).astype(np.int64)
+
+
+ctx = kk.Context(0)
+comm = kd.NativeComm(ctx, rank, world, file_bcast)
+info = comm.info()
+assert info["rank"] == rank and info["world"] == world and info["rccl_version"] == 29999, info   # the stand-in, not RCCL
+report = {"scenario": scenario, "rank": rank}
+
+
+def gather_rows(name, local):
+    """assemble a row-sharded array on every rank through the rendezvous directory (checks only, not the data path)"""
+    np.save(rdv / f"{name}.{rank}.tmp.npy", local)
+    (rdv / f"{name}.{rank}.tmp.npy").rename(rdv / f"{name}.{rank}.npy")
+    parts = []
+    for q in range(world):
+        f = rdv / f"{name}.{q}.npy"
+        t0 = time.time()
+        while not f.exists():
+            assert time.time() - t0 < 120, f"rank {q} never wrote {name}"
+            time.sleep(0.01)
+        parts.append(np.load(f))
+    return np.concatenate(parts, axis=0)
+
+
+def lanczos_against_oracle(A, part, x0, steps, tag, check_counts=True):
+    op = kd.NativeShardedOperator(A[part.lo:part.hi], part, ctx, symmetric=True)
+    assert comm.stats()["p2p_groups"] > 0, "the ghost plan negotiation must have used the grouped send / recv"
+    for mgs_mode in (0, 1):
+        ctx.set_option("mgs_mode", mgs_mode)
+        for dev, ref in orth_pairs():
+            it = kk.LanczosIterator(op, x0[part.lo:part.hi], dev, capacity=steps + 3)
+            f = kk.initialize(it)
+            oit = ko.LanczosIterator(A, x0.copy(), ref)
+            of = ko.lanczos_initialize(oit)
+            s0 = comm.stats()
+            for _ in range(steps):
+                f = kk.expand_(it, f)
+                of = ko.lanczos_expand(oit, of)
+            s1 = comm.stats()
+            tol = 1e-10 if dev.is_reorth else 1e-6
+            ea, eb = relerr(f.alphas, of.alphas), relerr(f.betas, of.betas)
+            assert ea < tol and eb < tol, (tag, dev.name, mgs_mode, ea, eb)
+            if check_counts:
+                assert (s1["p2p_groups"] - s0["p2p_groups"]) >= steps, (tag, dev.name)      # one ghost exchange per apply (+ speculation)
+                if dev.name == "cgs2" or (dev.name == "mgs2" and mgs_mode == 1):
+                    assert (s1["allreduce"] - s0["allreduce"]) / steps == 2.0, (tag, dev.name, s0, s1)
+            if dev.is_reorth:
+                V = gather_rows(f"V_{tag}_{dev.name}_{mgs_mode}", f.V.to_numpy())
+                assert np.max(np.abs(V.T @ V - np.eye(V.shape[1]))) < 1e-12, (tag, dev.name)
+                Vo = np.stack(of.V, axis=1) if isinstance(of.V, list) else np.asarray(of.V)
+                if Vo.shape == V.shape:
+                    sgn = np.sign(np.sum(V * Vo, axis=0))
+                    assert np.max(np.abs(V * sgn - Vo)) < 1e-8, (tag, dev.name)
+            report[f"{tag}.{dev.name}.mgs{mgs_mode}"] = [ea, eb]
+    ctx.set_option("mgs_mode", 1)
+    return op
+
+
+if scenario == "lanczos_grid":
+    # config-2 shape: 5-point stencil split along grid lines -> diagonal kernels on the interior, ghost strips at the seams
+    nx, ny = 40, 30 + world
+    n = nx * ny
+    A = ko.laplacian_2d(nx, ny, shift_diag=10 * np.linspace(0, 1, n) ** 2)
+    x0 = np.random.default_rng(3).random(n)
+    part = kd.Partition.even(n, world, rank, align=nx)
+    op = lanczos_against_oracle(A, part, x0, 25, "grid")
+    report["format"] = op.info()["format"]
+    assert report["format"] == "ELL+DIA", report["format"]
+elif scenario == "lanczos_random":
+    # random symmetric sparsity, uneven split: every rank needs scattered entries of every other one
+    n = 3000
+    R = sp.random(n, n, density=4.0 / n, random_state=np.random.default_rng(11), format="csr")
+    A = (R + R.T + sp.diags(4.0 + np.arange(n) / n)).tocsr()
+    x0 = np.random.default_rng(4).random(n)
+    part = kd.Partition(uneven_offsets(n, 5), rank)
+    op = lanczos_against_oracle(A, part, x0, 20, "random")
+    # plain applies, affine form, block applies (ONE grouped exchange for all columns)
+    nl = part.n_local
+    B = kk.DeviceBasis(nl, 40, ctx)
+    X = np.random.default_rng(12).standard_normal((n, 16))
+    for j in range(16):
+        B.upload(j, X[part.lo:part.hi, j])
+    op.apply(B[3], B[20])
+    np.testing.assert_allclose(B[20].get(), (A @ X[:, 3])[part.lo:part.hi], rtol=0, atol=1e-12)
+    op.apply_affine(B[3], B[21], 0.7, -0.4)
+    np.testing.assert_allclose(B[21].get(), (0.7 * X[:, 3] - 0.4 * (A @ X[:, 3]))[part.lo:part.hi], rtol=0, atol=1e-12)
+    from krylovkit_hip._lib import check
+    for nb in (16, 3, 11):
+        p0 = comm.stats()["p2p_groups"]
+        check(ctx._lib.kk_block_apply(op.handle, B.handle, 0, B.handle, 20, nb))
+        assert comm.stats()["p2p_groups"] - p0 == 1
+        Y = np.stack([B.download(20 + j) for j in range(nb)], 1)
+        np.testing.assert_allclose(Y, (A @ X[:, :nb])[part.lo:part.hi], rtol=0, atol=1e-11)
+    # inner products / norms through the L1 verbs are global
+    assert abs(B[0].inner(B[1]) - X[:, 0] @ X[:, 1]) < 1e-10 and abs(B[2].norm() - np.linalg.norm(X[:, 2])) < 1e-11
+elif scenario == "gkl":
+    # config-4 shape: rectangular random map, rows split unevenly, V-vectors sharded evenly (odd column count: padded shard)
+    for (m, nc, seed) in ((600, 250, 21), (700, 251, 22)):
+        A = ko.sparse_random(m, nc, 8, seed)
+        u0 = np.random.default_rng(6).random(m)
+        offs = uneven_offsets(m, seed)
+        r0, r1 = int(offs[rank]), int(offs[rank + 1])
+        op = kd.NativeShardedRectOperator(A[r0:r1], nc, ctx)
+        shard = -(-nc // world)
+        c0, c1 = rank * shard, min((rank + 1) * shard, nc)
+        assert op.shape == (r1 - r0, c1 - c0), op.shape
+        steps = 15
+        for mgs_mode in (0, 1):
+            ctx.set_option("mgs_mode", mgs_mode)
+            for dev, ref in orth_pairs():
+                it = kk.GKLIterator(op, u0[r0:r1], dev, capacity=steps + 3)
+                f = kk.initialize(it)
+                oit = ko.GKLIterator(A, u0.copy(), ref)
+                of = ko.gkl_initialize(oit)
+                g0 = comm.stats()["gather"]
+                for _ in range(steps):
+                    f = kk.expand_(it, f)
+                    of = ko.gkl_expand(oit, of)
+                assert comm.stats()["gather"] - g0 == 2 * steps   # one all-gather + one reduce-scatter per expand!
+                tol = 1e-10 if dev.is_reorth else 1e-6
+                ea, eb = relerr(f.alphas, of.alphas), relerr(f.betas, of.betas)
+                assert ea < tol and eb < tol, (dev.name, mgs_mode, ea, eb)
+                report[f"gkl{nc}.{dev.name}.mgs{mgs_mode}"] = [ea, eb]
+                if dev.name == "mgs2":
+                    U = gather_rows(f"U_{nc}_{mgs_mode}", f.U.to_numpy())
+                    V = gather_rows(f"Vg_{nc}_{mgs_mode}", f.V.to_numpy())
+                    Bm = f.rayleighquotient()
+                    assert np.max(np.abs(U.T @ U - np.eye(U.shape[1]))) < 1e-12 and np.max(np.abs(V.T @ V - np.eye(V.shape[1]))) < 1e-12
+                    assert np.max(np.abs(A.T @ U - V @ Bm.T)) < 1e-10
+        ctx.set_option("mgs_mode", 1)
+        xb, yb = kk.DeviceBasis(c1 - c0, 4, ctx), kk.DeviceBasis(r1 - r0, 4, ctx)
+        xv = np.random.default_rng(9).standard_normal((nc, 3))
+        for j in range(3):
+            xb.upload(j, xv[c0:c1, j])
+        op.apply(xb[0], yb[0])
+        np.testing.assert_allclose(yb[0].get(), (A @ xv[:, 0])[r0:r1], rtol=0, atol=1e-12)
+        yv = np.random.default_rng(10).standard_normal(m)
+        op.apply_adjoint(yb[3].set(yv[r0:r1]), xb[3])
+        np.testing.assert_allclose(xb[3].get(), (A.T @ yv)[c0:c1], rtol=0, atol=1e-12)
+        from krylovkit_hip._lib import check
+        check(ctx._lib.kk_block_apply(op.handle, xb.handle, 0, yb.handle, 0, 3))     # gathers per column (was: stale buffer)
+        Y = np.stack([yb.download(j) for j in range(3)], 1)
+        np.testing.assert_allclose(Y, (A @ xv)[r0:r1], rtol=0, atol=1e-12)
+    # svdsolve end to end on the sharded map
+    A = ko.sparse_random(600, 250, 8, 21)
+    offs = uneven_offsets(600, 21)
+    r0, r1 = int(offs[rank]), int(offs[rank + 1])
+    op = kd.NativeShardedRectOperator(A[r0:r1], 250, ctx)
+    u0 = np.random.default_rng(6).random(600)
+    S, _, _, sinfo = kk.svdsolve(op, u0[r0:r1], 4, "LR", krylovdim=20, tol=1e-10, maxiter=30)
+    So, _, _, soinfo = ko.svdsolve_gkl(A, u0.copy(), 4, "LR", krylovdim=20, tol=1e-10, maxiter=30)
+    assert (sinfo.converged, sinfo.numiter, sinfo.numops) == (soinfo.converged, soinfo.numiter, soinfo.numops)
+    assert relerr(S[:4], So[:4]) < 1e-10
+    report["svd"] = [float(s) for s in S[:4]]
+elif scenario == "block":
+    # config-5 shape: BlockLanczos on a row-sharded stencil, both block modes; the issue-#143 known answer with rank drop
+    nx, ny, bs = 36, 28 + world, 4
+    n = nx * ny
+    A = ko.laplacian_2d(nx, ny, shift_diag=10 * np.linspace(0, 1, n) ** 2)
+    part = kd.Partition.even(n, world, rank, align=nx)
+    op = kd.NativeShardedOperator(A[part.lo:part.hi], part, ctx, symmetric=True)
+    rng = np.random.default_rng(12)
+    xb = [rng.random(n) for _ in range(bs)]
+    obit = ko.BlockLanczosIterator(A, [x.copy() for x in xb], 28)
+    obf = ko.blocklanczos_initialize(obit)
+    for _ in range(5):
+        obf = ko.blocklanczos_expand(obit, obf)
+    ko_ev = np.linalg.eigvalsh(obf.H[:len(obf), :len(obf)])
+    for block_mode in (1, 0):
+        ctx.set_option("block_mode", block_mode)
+        bit = kk.BlockLanczosIterator(op, [x[part.lo:part.hi] for x in xb], 28)
+        bf = bit.initialize()
+        for _ in range(5):
+            bf = bit.expand(bf)
+        k = len(bf)
+        assert k == len(obf)
+        ev = np.linalg.eigvalsh(bf.H[:k, :k])
+        err = float(np.max(np.abs(ev - ko_ev)) / np.max(np.abs(ko_ev)))
+        assert err < 1e-10, (block_mode, err)
+        report[f"block.mode{block_mode}"] = err
+    ctx.set_option("block_mode", 1)
+    A143 = np.load(HERE / "golden" / "issue143_A.npy")
+    n = A143.shape[0]
+    part = kd.Partition(uneven_offsets(n, 3), rank)
+    op = kd.NativeShardedOperator(sp.csr_matrix(A143)[part.lo:part.hi], part, ctx, symmetric=True)
+    rng = np.random.default_rng(143)
+    x0 = [rng.standard_normal(n) for _ in range(20)]
+    D, V, binfo = kk.eigsolve_block(op, [x[part.lo:part.hi] for x in x0], 4, "SR", kk.BlockLanczos(tol=1e-8))
+    ev = np.linalg.eigvalsh(A143)
+    assert len(D) == len(ev) and binfo.converged == len(D) and binfo.numiter == 1 and binfo.numops == len(D) + 1
+    np.testing.assert_allclose(np.sort(D), ev, rtol=0, atol=1e-10 * np.max(np.abs(ev)))
+elif scenario == "solvers":
+    # thick-restart eigsolve, GMRES through the keyword front door (tolerance from the ALL-REDUCED norm of b), CG
+    nx, ny = 32, 24 + world
+    n = nx * ny
+    A = ko.laplacian_2d(nx, ny, shift_diag=10 * np.linspace(0, 1, n) ** 2)
+    x0 = np.random.default_rng(3).random(n)
+    part = kd.Partition(uneven_offsets(n, 8), rank)
+    lo, hi = part.lo, part.hi
+    op = kd.NativeShardedOperator(A[lo:hi], part, ctx, symmetric=True)
+    for mgs_mode in (1, 0):
+        ctx.set_option("mgs_mode", mgs_mode)
+        vals, vecs, einfo = kk.eigsolve(op, x0[lo:hi], 3, "LM", krylovdim=20, tol=1e-10, maxiter=50, orth=kk.ModifiedGramSchmidt2())
+        ovals, ovecs, oinfo = ko.eigsolve_lanczos(A, x0.copy(), 3, "LM", krylovdim=20, tol=1e-10, maxiter=50, orth=ko.MGS2)
+        assert einfo.converged >= 3 and (einfo.numiter, einfo.numops) == (oinfo.numiter, oinfo.numops), (mgs_mode, einfo, oinfo)
+        assert relerr(vals[:3], ovals[:3]) < 1e-10
+        v0 = gather_rows(f"eigvec{mgs_mode}", np.asarray(vecs[0]))
+        assert np.linalg.norm(A @ v0 - vals[0] * v0) < 1e-8
+    ctx.set_option("mgs_mode", 1)
+    Bm = ko.convection_diffusion_2d(nx, ny)
+    b = np.random.default_rng(4).random(n) * np.linspace(0.1, 3.0, n)     # local norms differ a lot from rank to rank
+    opB = kd.NativeShardedOperator(Bm[lo:hi], part, ctx)
+    tr, otr = [], []
+    x, ginfo = kk.linsolve(opB, b[lo:hi], None, None, krylovdim=25, maxiter=40, rtol=1e-9, atol=0.0, trace=tr)
+    ox, goinfo = ko.gmres(Bm, b, krylovdim=25, maxiter=40, tol=1e-9 * np.linalg.norm(b), orth=ko.MGS2, trace=otr)
+    assert ginfo.converged == 1 and (ginfo.converged, ginfo.numiter, ginfo.numops) == (goinfo.converged, goinfo.numiter, goinfo.numops)
+    assert len(tr) == len(otr) and relerr([t[2] for t in tr], [t[2] for t in otr]) < 1e-6
+    xg = gather_rows("gmres_x", np.asarray(x))
+    assert np.linalg.norm(Bm @ xg - b) < 2e-9 * np.linalg.norm(b)
+    report["gmres"] = [ginfo.numiter, ginfo.numops]
+    As = (A + sp.identity(n)).tocsr()
+    opS = kd.NativeShardedOperator(As[lo:hi], part, ctx, symmetric=True)
+    xc, cinfo = kk.linsolve(opS, b[lo:hi], None, kk.CG(300, 1e-9 * np.linalg.norm(b)))
+    xcg = gather_rows("cg_x", np.asarray(xc))
+    assert cinfo.converged == 1 and np.linalg.norm(As @ xcg - b) < 2e-9 * np.linalg.norm(b)
+    report["cg"] = [cinfo.numiter, cinfo.numops]
+elif scenario == "bad_input":
+    # a collective create call with bad input on ONE rank: every rank must come back with an error (nobody left waiting)
+    import ctypes as C
+    from krylovkit_hip import _lib
+    n = 8
+    offs = (C.c_int64 * (world + 1))(*[q * n for q in range(world + 1)])
+    rowptr = (C.c_int64 * (n + 1))(*range(n + 1))
+    cols = [rank * n + i for i in range(n)]
+    if rank == world - 1:
+        cols[-1] = world * n + 5          # out of range on the last rank only
+    col = (C.c_int64 * n)(*cols)
+    val = (C.c_double * n)(*([1.0] * n))
+    h = C.c_void_p()
+    st = ctx._lib.kk_csr_create_sharded(ctx.handle, n, offs, n, rowptr, col, val, 0, 0, C.byref(h))
+    assert st == _lib.KK_ERR_DIM, st
+    msg = ctx._lib.kk_last_error().decode()
+    assert ("out of range" in msg) if rank == world - 1 else ("another rank" in msg), msg
+    comm.barrier()                        # the communicator is still usable afterwards
+    report["status"] = st
+else:
+    raise SystemExit(f"unknown scenario {scenario}")
+
+report["stats"] = comm.stats()
+comm.barrier()
+comm.close()
+ctx.close()
+(rdv / f"report.{rank}.json").write_text(json.dumps(report))
+print(f"world2 {scenario} rank {rank} OK", flush=True)
