@@ -636,20 +636,37 @@ int kk_launch_spmv(kk_ctx ctx, const kk_sparse_dev& M, const double* x, double* 
 int kk_launch_spmm(kk_ctx ctx, const kk_sparse_dev& M, const double* X, int64_t ldx, double* Y, int64_t ldy, int nb) {
     // one launch for the block: ELL operators without ghosts, or with a native exchange plan (one grouped exchange for all
     // nb vectors); CSR / SELL formats and hook-ghosted operators go column by column
-    const bool ghost_block = M.plan && M.n_ghost > 0;
-    const bool one_launch = M.format == 0 && !M.halo && (M.n_ghost == 0 || M.plan);
-    if (!one_launch) {
-        for (int j = 0; j < nb; ++j) {
-            kk_spmv_fuse f;
-            KK_TRY(kk_launch_spmv(ctx, M, X + (int64_t)j * ldx, Y + (int64_t)j * ldy, ldy, f));
-        }
+    // A native exchange plan makes the apply a COLLECTIVE step: every rank must issue the same sequence of grouped
+    // exchanges, whatever storage format its own row block happened to get (ELL here, SELL on the neighbour) and whether or
+    // not it has ghost columns of its own (a rank without any still serves its peers).  So: with a plan, always one grouped
+    // exchange per <= 16 columns; the local format only decides which kernels read the received block.
+    const bool planned = M.plan != nullptr;
+    if (planned && nb > 16) {
+        for (int j0 = 0; j0 < nb; j0 += 16)
+            KK_TRY(kk_launch_spmm(ctx, M, X + (int64_t)j0 * ldx, ldx, Y + (int64_t)j0 * ldy, ldy, std::min(16, nb - j0)));
         return KK_OK;
     }
+    const bool ghost_block = planned && M.n_ghost > 0;
+    const bool one_launch = M.format == 0 && !M.halo && (M.n_ghost == 0 || M.plan);
     const double* G = nullptr;
     int64_t ldg = 0, nloc = -1;
-    if (ghost_block) {
+    if (planned) {
         KK_TRY(kk_halo_exchange_block(ctx, M, X, ldx, nb, &G, &ldg));
-        nloc = M.n_local;
+        if (ghost_block) nloc = M.n_local;
+    }
+    if (!one_launch) {   // CSR / SELL formats and hook-ghosted operators: column by column
+        for (int j = 0; j < nb; ++j) {
+            kk_spmv_fuse f;
+            if (planned) {   // the ghosts of column j are already here: same matrix, ghost buffer = column j of the block, no exchange
+                kk_sparse_dev Mj = M;
+                Mj.plan = nullptr;
+                Mj.ghost = const_cast<double*>(G) + (int64_t)j * ldg;
+                KK_TRY(kk_launch_spmv(ctx, Mj, X + (int64_t)j * ldx, Y + (int64_t)j * ldy, ldy, f));
+            } else {
+                KK_TRY(kk_launch_spmv(ctx, M, X + (int64_t)j * ldx, Y + (int64_t)j * ldy, ldy, f));
+            }
+        }
+        return KK_OK;
     }
     // grid stencil: sweep the lines with a register window (every element of X read once) -- the whole operator, or the
     // ghost-free interior rows of a row-sharded one

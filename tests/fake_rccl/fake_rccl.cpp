@@ -196,8 +196,17 @@ ncclResult_t combine_any(void* acc, const void* x, size_t n, ncclDataType_t dt, 
 
 // run a batch of sends / receives to completion: every operation advances whenever its mailbox allows it, so mutually
 // dependent operations of one group (A sends to B while B sends to A, several messages per peer) cannot deadlock
+bool tracing() {
+    static bool t = [] { const char* e = getenv("KK_FAKE_RCCL_TRACE"); return e && *e == '1'; }();
+    return t;
+}
 ncclResult_t run_p2p(std::vector<p2p_op>& ops) {
     if (ops.empty()) return ncclSuccess;
+    if (tracing()) {
+        fprintf(stderr, "fake_rccl[%d]: p2p batch:", ops[0].comm->rank);
+        for (p2p_op& o : ops) fprintf(stderr, " %s%d:%zu", o.is_send ? "S" : "R", o.peer, o.bytes);
+        fprintf(stderr, "\n");
+    }
     for (p2p_op& o : ops) {
         o.host.resize(o.bytes);
         if (o.is_send) FK_TRY(d2h(o.host.data(), o.dev, o.bytes, o.stream));
@@ -336,6 +345,7 @@ FK_EXPORT ncclResult_t ncclAllReduce(const void* send, void* recv, size_t count,
                                      hipStream_t s) {
     if (!c || (count && (!send || !recv))) return ncclInvalidArgument;
     if (g_group_depth) return ncclInvalidUsage;   // collectives inside a group are not needed by libkrylov_hip
+    if (tracing()) fprintf(stderr, "fake_rccl[%d]: allreduce %zu x dtype %d op %d\n", c->rank, count, (int)dt, (int)op);
     const size_t es = dtype_size(dt), per = c->slot_bytes / es;
     for (size_t off = 0; off < count || (count == 0 && off == 0); off += per) {
         const size_t n = count - off < per ? count - off : per;
@@ -354,6 +364,7 @@ FK_EXPORT ncclResult_t ncclAllReduce(const void* send, void* recv, size_t count,
 FK_EXPORT ncclResult_t ncclAllGather(const void* send, void* recv, size_t sendcount, ncclDataType_t dt, ncclComm_t c, hipStream_t s) {
     if (!c || (sendcount && (!send || !recv))) return ncclInvalidArgument;
     if (g_group_depth) return ncclInvalidUsage;
+    if (tracing()) fprintf(stderr, "fake_rccl[%d]: allgather %zu x dtype %d\n", c->rank, sendcount, (int)dt);
     const size_t es = dtype_size(dt), per = c->slot_bytes / es;
     for (size_t off = 0; off < sendcount || (sendcount == 0 && off == 0); off += per) {
         const size_t n = sendcount - off < per ? sendcount - off : per;
@@ -374,6 +385,7 @@ FK_EXPORT ncclResult_t ncclReduceScatter(const void* send, void* recv, size_t re
                                          hipStream_t s) {
     if (!c || (recvcount && (!send || !recv))) return ncclInvalidArgument;
     if (g_group_depth) return ncclInvalidUsage;
+    if (tracing()) fprintf(stderr, "fake_rccl[%d]: reducescatter %zu x dtype %d\n", c->rank, recvcount, (int)dt);
     const size_t es = dtype_size(dt), per = c->slot_bytes / es / (size_t)c->world;
     if (per == 0) return ncclInternalError;
     for (size_t off = 0; off < recvcount || (recvcount == 0 && off == 0); off += per) {

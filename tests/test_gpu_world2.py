@@ -44,8 +44,8 @@ def run_world(scenario, world, tmp_path, timeout=600):
                 p.kill()
         outs = [p.communicate()[0] for p in procs]
         pytest.fail(f"world-{world} scenario {scenario} did not finish within {timeout} s\n" + "\n---\n".join(o[-3000:] for o in outs))
-    for r, (p, o) in enumerate(zip(procs, outs)):
-        assert p.returncode == 0 and f"world2 {scenario} rank {r} OK" in o, f"rank {r} (exit {p.returncode}):\n{o[-6000:]}"
+    bad = [r for r, (p, o) in enumerate(zip(procs, outs)) if p.returncode != 0 or f"world2 {scenario} rank {r} OK" not in o]
+    assert not bad, "\n".join(f"=== rank {r} (exit {p.returncode}) ===\n{o[-5000:]}" for r, (p, o) in enumerate(zip(procs, outs)))
     return [json.loads((tmp_path / f"report.{r}.json").read_text()) for r in range(world)]
 
 
