@@ -1,5 +1,6 @@
 /*
- * cpu_ref.c -- C twin of oracle/krylov_oracle.py for the Lanczos expand! path.
+ * cpu_ref.c -- C twin of oracle/krylov_oracle.py for the expand! paths of Lanczos (config 2), Arnoldi / GMRES (config 3),
+ * GKL (config 4) and BlockLanczos (config 5).
  *
  * TEST INFRASTRUCTURE ONLY (tests/ and the cpu_baseline leg of bench.py).  It restates the
  * reference's CPU path *as the reference issues it*: one separately allocated vector per basis
@@ -460,6 +461,281 @@ done:
     if (trace_len) *trace_len = ntrace;
     for (int j = 0; j < K + 2; ++j) free(V[j]);
     free(V); free(H); free(R); free(y); free(gc); free(gsn); free(g1); free(g2); free(hx); free(tmp); free(r); free(t);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Sparse products for the two twins below.  y = A*x on a Julia SparseMatrixCSC runs as a serial scatter over the columns
+ * (csc_mul above), i.e. y[i] collects its terms a_ij*x_j in ascending j starting from zero; the same sum formed per row
+ * from the CSR image with ascending column indices gives the SAME bits and parallelises over rows.  adjoint(A)*x in
+ * SparseArrays is a per-column dot over the stored entries in storage order -- also one independent sum per output.
+ * Both products below are therefore bit-identical to the serial Julia loops whatever the thread count.
+ * ------------------------------------------------------------------------------------------------ */
+/* y[i] = sum over the stored entries of segment i (ptr/idx/val 1-based), in storage order, of val * x[idx] */
+static void seg_dot_mul(int64_t nseg, const int64_t* ptr, const int64_t* idx, const double* val, const double* x, double* y) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < nseg; ++i) {
+        double s = 0;
+        for (int64_t p = ptr[i] - 1; p < ptr[i + 1] - 1; ++p) s += val[p] * x[idx[p] - 1];
+        y[i] = s;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * GKL (config 4): initialize (src/factorizations/gkl.jl:183-215) + `steps` expand! calls (:246-269) with the five
+ * gklrecurrence methods (:294-404).  A is nr x nc, handed over twice: as Julia's CSC (colptr/rowval/nzval: used for
+ * A'u, one dot per column) and as its CSR image with ascending columns (rowptr/colval/rval: used for A v, see above).
+ * alphas / betas hold steps+1 doubles; U_out (nr x (steps+2): the U vectors followed by the residual) and
+ * V_out (nc x (steps+1)) are optional, column-major.  Returns 0, -1 allocation / zero start vector, -2 if the
+ * compatibility test of :192 fails.
+ * ------------------------------------------------------------------------------------------------ */
+static void mgs_sweep(int64_t n, int m, double** Q, double* w) { /* for q in Q: orthogonalize!!(w, q, MGS)   orthonormal.jl:458-464 */
+    for (int j = 0; j < m; ++j) {
+        const double s = ddot(n, Q[j], w);
+        daxpy(n, -s, Q[j], w);
+    }
+}
+int kkref_gkl(int64_t nr, int64_t nc, const int64_t* colptr, const int64_t* rowval, const double* nzval,
+              const int64_t* rowptr, const int64_t* colval, const double* rval, const double* u0, int steps, int orth,
+              double eta, int nthreads, double* alphas, double* betas, double* U_out, double* V_out) {
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+    double** U = (double**)calloc((size_t)steps + 2, sizeof(double*));
+    double** V = (double**)calloc((size_t)steps + 2, sizeof(double*));
+    double* x = (double*)malloc(((size_t)steps + 2) * sizeof(double));
+    if (!U || !V || !x) return -1;
+    int rc = 0, k = 0;
+    double* r = NULL;
+    {   /* initialize :183-215 */
+        const double beta0 = dnrm2(nr, u0);
+        if (beta0 == 0) return -1;
+        double* v0 = (double*)malloc((size_t)nc * sizeof(double));
+        double* Av0 = (double*)malloc((size_t)nr * sizeof(double));
+        double* u = (double*)malloc((size_t)nr * sizeof(double));
+        if (!v0 || !Av0 || !u) return -1;
+        seg_dot_mul(nc, colptr, rowval, nzval, u0, v0);            /* v0 = apply_adjoint(A, u0) */
+        const double alpha = dnrm2(nc, v0) / beta0;
+        seg_dot_mul(nr, rowptr, colval, rval, v0, Av0);            /* Av0 = apply_normal(A, v0) */
+        const double alpha2 = ddot(nr, u0, Av0) / (beta0 * beta0);
+        if (!(fabs(alpha2 - alpha * alpha) <= sqrt(DBL_EPSILON) * fmax(fabs(alpha2), alpha * alpha))) return -2;   /* isapprox :192 */
+        memcpy(u, u0, (size_t)nr * sizeof(double));
+        dscal(nr, 1.0 / beta0, u);                                  /* u = scale(u0, 1/beta0) */
+        dscal(nc, 1.0 / (alpha * beta0), v0);                       /* v = scale(v0, 1/(alpha beta0)) */
+        dscal(nr, 1.0 / (alpha * beta0), Av0);                      /* r = scale!!(Av0, 1/(alpha beta0)) */
+        daxpy(nr, -alpha, u, Av0);                                  /* r = add!!(r, u, -alpha) */
+        U[0] = u; V[0] = v0; r = Av0;
+        alphas[0] = alpha; betas[0] = dnrm2(nr, r);
+        k = 1;
+    }
+    for (int it = 0; it < steps && rc == 0; ++it) {   /* expand! :246-269 */
+        const double bold = betas[k - 1];
+        dscal(nr, 1.0 / bold, r);                                   /* U = push!(U, scale!!(r, 1/beta_old)) */
+        U[k] = r;
+        const double* u = U[k];
+        const int mU = k + 1, mV = k;
+        double* v = (double*)malloc((size_t)nc * sizeof(double));
+        double* rn = (double*)malloc((size_t)nr * sizeof(double));
+        if (!v || !rn) { rc = -1; break; }
+        seg_dot_mul(nc, colptr, rowval, nzval, u, v);               /* v = apply_adjoint(A, u) */
+        daxpy(nc, -bold, V[mV - 1], v);                             /* v = add!!(v, V[end], -beta) */
+        double alpha, beta;
+        if (orth == 3) mgs_sweep(nc, mV, V, v);                     /* MGS2 :330-335 */
+        alpha = dnrm2(nc, v);
+        if (orth >= 4) {                                            /* CGSIR :353-358 (no eps guard) / MGSIR :380-386 */
+            double nold = sqrt(alpha * alpha + bold * bold);
+            while ((orth == 4 || DBL_EPSILON < alpha) && alpha < eta * nold) {
+                nold = alpha;
+                if (orth == 4) cgs_pass(nc, mV, V, v, x); else mgs_sweep(nc, mV, V, v);
+                alpha = dnrm2(nc, v);
+            }
+        }
+        dscal(nc, 1.0 / alpha, v);                                  /* v = scale!!(v, inv(alpha)) */
+        seg_dot_mul(nr, rowptr, colval, rval, v, rn);               /* r = apply_normal(A, v) */
+        daxpy(nr, -alpha, u, rn);                                   /* r = add!!(r, u, -alpha) */
+        if (orth == 2) cgs_pass(nr, mU, U, rn, x);                  /* CGS2 :320 */
+        else if (orth == 3) mgs_sweep(nr, mU, U, rn);               /* MGS2 :341-343 */
+        beta = dnrm2(nr, rn);
+        if (orth >= 4) {                                            /* :363-372 / :391-402 */
+            double nold = sqrt(alpha * alpha + beta * beta);
+            while (DBL_EPSILON < beta && beta < eta * nold) {
+                nold = beta;
+                if (orth == 4) cgs_pass(nr, mU, U, rn, x); else mgs_sweep(nr, mU, U, rn);
+                beta = dnrm2(nr, rn);
+            }
+        }
+        V[k] = v;
+        r = rn;
+        alphas[k] = alpha; betas[k] = beta;
+        ++k;
+    }
+    if (rc == 0 && U_out) {
+        for (int j = 0; j < k; ++j) memcpy(U_out + (size_t)j * nr, U[j], (size_t)nr * sizeof(double));
+        memcpy(U_out + (size_t)k * nr, r, (size_t)nr * sizeof(double));
+    }
+    if (rc == 0 && V_out)
+        for (int j = 0; j < k; ++j) memcpy(V_out + (size_t)j * nc, V[j], (size_t)nc * sizeof(double));
+    for (int j = 0; j < k; ++j) { free(U[j]); free(V[j]); }
+    free(r); free(U); free(V); free(x);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * BlockLanczos (config 5): initialize (src/factorizations/blocklanczos.jl:159-198) + expand! (:200-240) until the basis
+ * holds at least `target_dim` vectors or `max_steps` block steps were taken, with block_qr! (:312-353, MGS with the DGKS
+ * correction, rank drop), block_lanczosrecurrence (:242-263) and block_reorthogonalize! (:277-284).  A symmetric, CSC =
+ * CSR (one gather per row = column: the bits of Julia's scatter, see above).  X0: n x bs0 column-major.  H (ldh x ldh,
+ * column-major, zeroed here) receives the block-tridiagonal matrix; info = {k, R_size, number of block steps, numops
+ * (vector applies incl. the probe of :171)}; sizes[j] (optional, max_steps+1 ints) = block size pushed in step j.
+ * V_out (optional) n x (k + R_size): basis followed by the residual block.  Returns 0 / -1.
+ * ------------------------------------------------------------------------------------------------ */
+/* block_qr!(block, tol) :312-353 -> R (p x p column-major, full, rows of dropped vectors zero), good[], *ngood, *drift */
+static void block_qr(int64_t n, int p, double** blk, double tol, double* R, int* good, int* ngood, int* drift) {
+    *drift = 0;
+    memset(R, 0, (size_t)p * p * sizeof(double));
+    char idx[64];
+    for (int j = 0; j < p; ++j) idx[j] = 1;
+    double beta = sqrt(ddot(n, blk[0], blk[0]));
+    if (beta > tol) { R[0] = beta; dscal(n, 1.0 / beta, blk[0]); }
+    else { memset(blk[0], 0, (size_t)n * sizeof(double)); idx[0] = 0; }
+    for (int j = 1; j < p; ++j) {
+        for (int i = 0; i < j; ++i) {                       /* first MGS */
+            const double rij = ddot(n, blk[i], blk[j]);
+            R[(size_t)j * p + i] = rij;
+            daxpy(n, -rij, blk[i], blk[j]);
+        }
+        beta = dnrm2(n, blk[j]);
+        if (tol < beta && beta < 100 * tol) {               /* DGKS reorthogonalization */
+            *drift = 1;
+            for (int i = 0; i < j; ++i) {
+                const double d = ddot(n, blk[i], blk[j]);
+                R[(size_t)j * p + i] += d;
+                daxpy(n, -d, blk[i], blk[j]);
+            }
+            beta = dnrm2(n, blk[j]);
+        }
+        if (beta < tol) { memset(blk[j], 0, (size_t)n * sizeof(double)); idx[j] = 0; }
+        else { R[(size_t)j * p + j] = beta; dscal(n, 1.0 / beta, blk[j]); }
+    }
+    int g = 0;
+    for (int j = 0; j < p; ++j) if (idx[j]) good[g++] = j;
+    *ngood = g;
+}
+static void block_reorth(int64_t n, int p, double** Rb, int m, double** V) { /* :277-284 */
+    for (int i = 0; i < p; ++i) mgs_sweep(n, m, V, Rb[i]);
+}
+int kkref_blocklanczos(int64_t n, const int64_t* colptr, const int64_t* rowval, const double* nzval, const double* X0,
+                       int bs0, int target_dim, int max_steps, double qr_tol, int nthreads, double* H, int ldh, int* info,
+                       int* sizes, double* normR_out, double* V_out) {
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+    if (bs0 < 1 || bs0 > 64) return -1;
+    const int cap = target_dim + 2 * bs0 + 2;
+    double** V = (double**)calloc((size_t)cap, sizeof(double*));
+    double* Rm = (double*)malloc((size_t)bs0 * bs0 * sizeof(double));
+    double* B = (double*)calloc((size_t)bs0 * bs0, sizeof(double));    /* bs_next x bs, column-major ld bs0 */
+    double* M = (double*)malloc((size_t)bs0 * bs0 * sizeof(double));
+    double *blk[64], *cpy[64], *AX[64];
+    int good[64];
+    if (!V || !Rm || !B || !M) return -1;
+    memset(H, 0, (size_t)ldh * ldh * sizeof(double));
+    int nV = 0, numops = 0, nsteps = 0, rc = 0;
+    /* initialize :159-198 */
+    {
+        double* probe = (double*)malloc((size_t)n * sizeof(double));
+        if (!probe) return -1;
+        seg_dot_mul(n, colptr, rowval, nzval, X0, probe);   /* Ax0 = apply(A, x0): only its type matters (:171-172) */
+        free(probe);
+        numops += 1;
+    }
+    for (int j = 0; j < bs0; ++j) {
+        blk[j] = (double*)malloc((size_t)n * sizeof(double));
+        if (!blk[j]) return -1;
+        memcpy(blk[j], X0 + (size_t)j * n, (size_t)n * sizeof(double));   /* X1 = scale.(X0, one(alpha)) */
+    }
+    int ng = 0, drift = 0;
+    block_qr(n, bs0, blk, qr_tol, Rm, good, &ng, &drift);
+    for (int j = 0, g = 0; j < bs0; ++j) {
+        if (g < ng && good[g] == j) { V[nV++] = blk[j]; ++g; } else free(blk[j]);
+    }
+    int bs = ng;
+    if (bs == 0) return -1;
+    for (int j = 0; j < bs; ++j) {
+        AX[j] = (double*)malloc((size_t)n * sizeof(double));
+        if (!AX[j]) return -1;
+        seg_dot_mul(n, colptr, rowval, nzval, V[j], AX[j]);
+    }
+    numops += bs;
+    for (int j = 0; j < bs; ++j)
+        for (int i = 0; i < bs; ++i) M[(size_t)j * bs0 + i] = ddot(n, V[i], AX[j]);      /* M1 = block_inner(X1, AX1) */
+    for (int j = 0; j < bs; ++j)
+        for (int i = 0; i < bs; ++i) H[(size_t)j * ldh + i] = M[(size_t)j * bs0 + i];
+    for (int j = 0; j < bs; ++j)
+        for (int i = 0; i < bs; ++i) daxpy(n, -M[(size_t)j * bs0 + i], V[i], AX[j]);     /* first residual :187-191 */
+    int k = bs, R_size = bs;
+    if (sizes) sizes[0] = bs;
+    /* expand! :200-240 */
+    while (k < target_dim && nsteps < max_steps && rc == 0) {
+        const int p = R_size;
+        if (k + p > ldh || nV + p > cap) break;
+        for (int j = 0; j < p; ++j) {                        /* Rcopy = copy(R) */
+            cpy[j] = (double*)malloc((size_t)n * sizeof(double));
+            if (!cpy[j]) { rc = -1; break; }
+            memcpy(cpy[j], AX[j], (size_t)n * sizeof(double));
+        }
+        if (rc) break;
+        block_qr(n, p, AX, qr_tol, Rm, good, &ng, &drift);
+        for (int j = 0; j < p; ++j)
+            for (int g = 0; g < ng; ++g) B[(size_t)j * bs0 + g] = Rm[(size_t)j * p + good[g]];          /* B = R[good_idx, :] */
+        if (drift) {                                         /* :211-215 */
+            block_reorth(n, p, AX, nV, V);
+            block_qr(n, p, AX, qr_tol, Rm, good, &ng, &drift);
+            for (int j = 0; j < p; ++j)
+                for (int g = 0; g < ng; ++g) B[(size_t)j * bs0 + g] = ddot(n, AX[good[g]], cpy[j]);     /* block_inner(R[good], Rcopy) */
+        }
+        for (int j = 0; j < p; ++j) free(cpy[j]);
+        const int bsn = ng;
+        if (bsn == 0) break;
+        for (int j = 0, g = 0; j < p; ++j) {                 /* push!(V, R[good_idx]) */
+            if (g < ng && good[g] == j) { V[nV++] = AX[j]; ++g; } else free(AX[j]);
+        }
+        for (int j = 0; j < p; ++j)                          /* H[k+1:k+bsn, k-bs+1:k] = B ; transpose block :220-221 */
+            for (int g = 0; g < bsn; ++g) {
+                H[(size_t)(k - p + j) * ldh + (k + g)] = B[(size_t)j * bs0 + g];
+                H[(size_t)(k + g) * ldh + (k - p + j)] = B[(size_t)j * bs0 + g];
+            }
+        /* block_lanczosrecurrence :242-263: X = last bsn vectors, Xprev = the p before them */
+        double** X = V + (nV - bsn);
+        double** Xp = V + (nV - bsn - p);
+        for (int j = 0; j < bsn; ++j) {
+            AX[j] = (double*)malloc((size_t)n * sizeof(double));
+            if (!AX[j]) { rc = -1; break; }
+            seg_dot_mul(n, colptr, rowval, nzval, X[j], AX[j]);
+        }
+        if (rc) break;
+        numops += bsn;
+        for (int j = 0; j < bsn; ++j)
+            for (int i = 0; i < bsn; ++i) M[(size_t)j * bs0 + i] = ddot(n, X[i], AX[j]);
+        for (int j = 0; j < bsn; ++j) {
+            for (int i = 0; i < bsn; ++i) daxpy(n, -M[(size_t)j * bs0 + i], X[i], AX[j]);
+            for (int i = 0; i < p; ++i) daxpy(n, -B[(size_t)i * bs0 + j], Xp[i], AX[j]);     /* -conj(B[j, i]) */
+        }
+        block_reorth(n, bsn, AX, nV, V);
+        for (int j = 0; j < bsn; ++j)
+            for (int i = 0; i < bsn; ++i) H[(size_t)(k + j) * ldh + (k + i)] = M[(size_t)j * bs0 + i];
+        k += bsn;
+        R_size = bsn;
+        ++nsteps;
+        if (sizes) sizes[nsteps] = bsn;
+    }
+    double nr2 = 0;
+    for (int j = 0; j < R_size; ++j) { const double t = dnrm2(n, AX[j]); nr2 += t * t; }       /* norm(Block) = norm of the norms */
+    if (normR_out) *normR_out = sqrt(nr2);
+    if (info) { info[0] = k; info[1] = R_size; info[2] = nsteps; info[3] = numops; }
+    if (rc == 0 && V_out) {
+        for (int j = 0; j < nV; ++j) memcpy(V_out + (size_t)j * n, V[j], (size_t)n * sizeof(double));
+        for (int j = 0; j < R_size; ++j) memcpy(V_out + (size_t)(nV + j) * n, AX[j], (size_t)n * sizeof(double));
+    }
+    for (int j = 0; j < nV; ++j) free(V[j]);
+    for (int j = 0; j < R_size; ++j) free(AX[j]);
+    free(V); free(Rm); free(B); free(M);
     return rc;
 }
 

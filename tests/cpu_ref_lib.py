@@ -22,6 +22,12 @@ def load():
     lib.kkref_gmres.argtypes = [C.c_int64, _ip, _ip, _dp, _dp, _dp, C.c_double, C.c_double, C.c_int, C.c_int, C.c_double,
                                 C.c_int, C.c_double, C.c_int, _dp, C.POINTER(C.c_int), _dp, _dp, C.c_int, C.POINTER(C.c_int)]
     lib.kkref_gmres.restype = C.c_int
+    lib.kkref_gkl.argtypes = [C.c_int64, C.c_int64, _ip, _ip, _dp, _ip, _ip, _dp, _dp, C.c_int, C.c_int, C.c_double, C.c_int,
+                              _dp, _dp, _dp, _dp]
+    lib.kkref_gkl.restype = C.c_int
+    lib.kkref_blocklanczos.argtypes = [C.c_int64, _ip, _ip, _dp, _dp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, _dp, C.c_int,
+                                       C.POINTER(C.c_int), C.POINTER(C.c_int), _dp, _dp]
+    lib.kkref_blocklanczos.restype = C.c_int
     return lib
 
 
@@ -78,3 +84,51 @@ def run_gmres(lib, A, b, x0, a0, a1, krylovdim, maxiter, tol, orth, eta=0.75, nt
                          C.byref(normres), trace.ctypes.data_as(_dp), cap, C.byref(tl))
     assert rc == 0
     return x, dict(converged=info[0], numiter=info[1], numops=info[2], normres=normres.value), trace[:tl.value]
+
+
+def julia_csr(A):
+    """scipy sparse -> 1-based Int64 CSR image with ascending column indices (what a row-wise evaluation of Julia's
+    column-scatter product needs to give the same bits)"""
+    A = A.tocsr()
+    A.sort_indices()
+    return (np.ascontiguousarray(A.indptr, dtype=np.int64) + 1, np.ascontiguousarray(A.indices, dtype=np.int64) + 1,
+            np.ascontiguousarray(A.data, dtype=np.float64))
+
+
+def run_gkl(lib, A, u0, steps, orth, eta=0.75, nthreads=2, want_bases=False):
+    """initialize + `steps` expand! of the GKL factorization by oracle/cpu_ref.c::kkref_gkl -> (alphas, betas, U, V)"""
+    colptr, rowval, nz = julia_csc(A)
+    rowptr, colval, rv = julia_csr(A)
+    nr, nc = A.shape
+    u0 = np.ascontiguousarray(u0, dtype=np.float64)
+    al, be = np.zeros(steps + 1), np.zeros(steps + 1)
+    U = np.zeros((steps + 2) * nr) if want_bases else None
+    V = np.zeros((steps + 1) * nc) if want_bases else None
+    rc = lib.kkref_gkl(nr, nc, colptr.ctypes.data_as(_ip), rowval.ctypes.data_as(_ip), nz.ctypes.data_as(_dp),
+                       rowptr.ctypes.data_as(_ip), colval.ctypes.data_as(_ip), rv.ctypes.data_as(_dp), u0.ctypes.data_as(_dp),
+                       steps, orth, eta, nthreads, al.ctypes.data_as(_dp), be.ctypes.data_as(_dp),
+                       U.ctypes.data_as(_dp) if want_bases else None, V.ctypes.data_as(_dp) if want_bases else None)
+    assert rc == 0, rc
+    return al, be, (U.reshape(steps + 2, nr).T if want_bases else None), (V.reshape(steps + 1, nc).T if want_bases else None)
+
+
+def run_blocklanczos(lib, A, X0, target_dim, max_steps, qr_tol=1e-12, nthreads=2, want_basis=False):
+    """initialize + expand! of the BlockLanczos factorization by oracle/cpu_ref.c::kkref_blocklanczos on a symmetric A.
+    X0: n x bs0 (columns = start block) -> dict(H, k, R_size, steps, numops, sizes, norm_R, V)"""
+    colptr, rowval, nz = julia_csc(A)
+    n = A.shape[0]
+    X0 = np.asfortranarray(X0, dtype=np.float64)
+    bs0 = X0.shape[1]
+    ldh = target_dim + 2 * bs0
+    H = np.zeros((ldh, ldh), order="F")
+    info = (C.c_int * 4)()
+    sizes = (C.c_int * (max_steps + 2))()
+    nR = C.c_double()
+    Vb = np.zeros((n, ldh), order="F") if want_basis else None
+    rc = lib.kkref_blocklanczos(n, colptr.ctypes.data_as(_ip), rowval.ctypes.data_as(_ip), nz.ctypes.data_as(_dp),
+                                X0.ctypes.data_as(_dp), bs0, target_dim, max_steps, qr_tol, nthreads, H.ctypes.data_as(_dp), ldh,
+                                info, sizes, C.byref(nR), Vb.ctypes.data_as(_dp) if want_basis else None)
+    assert rc == 0, rc
+    k = info[0]
+    return dict(H=H[:k, :k].copy(), k=k, R_size=info[1], steps=info[2], numops=info[3], sizes=list(sizes[:info[2] + 1]),
+                norm_R=nR.value, V=(Vb[:, :k + info[1]] if want_basis else None))

@@ -322,8 +322,10 @@ def test_arnoldi_factorization(kk, ko, ctx, mgs_mode):
         assert np.max(np.abs(A @ V - V @ H - np.outer(r, ek))) < 1e-11
         assert abs(np.linalg.norm(r) - fact.normres) < 1e-12
         assert np.max(np.abs(V.T @ V - np.eye(k))) < (1e-12 if dev.is_reorth else 1e-8)
-        assert relerr(fact.H, ofact.H) < (1e-8 if dev.is_reorth else 1e-5) or \
-            np.max(np.abs(np.array(fact.H) - np.array(ofact.H))) < 1e-10
+        # the bar the path is held to: 1e-10 relative to |H| for the re-orthogonalising algorithms (entries that are
+        # themselves rounding residue of an orthogonalisation have no relative accuracy of their own)
+        dH = np.max(np.abs(np.array(fact.H) - np.array(ofact.H))) / np.max(np.abs(ofact.H))
+        assert dH < (1e-10 if dev.is_reorth else 1e-5), (dev.name, dH)
         fact = kk.shrink_(fact, 7)
         ofact = ko.arnoldi_shrink(ofact, 7)
         assert len(fact.H) == len(ofact.H) and len(fact.V) == 7
