@@ -240,6 +240,7 @@ def main():
                          "problem of BASELINE.json's metric split over the N GPUs.  The other mode runs as a secondary leg and is reported "
                          "next to the headline value (N = 1: both coincide)")
     ap.add_argument("--no-other-scaling-leg", action="store_true")
+    ap.add_argument("--parity-seeds", type=int, default=3, help="start vectors of the full-size parity block (each costs one CPU sweep)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-strict-leg", action="store_true")
     ap.add_argument("--ny", type=int, default=NY, help="grid rows per GPU (default 2500 -> 10M rows per GPU)")
@@ -596,7 +597,26 @@ def main():
             x0_host = x0_handle[0].get()                       # the GPU run's own start vector (80 MB over PCIe, once)
             base, al_c, be_c = cpu_baseline(orth.code, x0_host, args.ny)
             out["cpu_baseline"] = base
-            out["parity"] = parity_block(fact.alphas, fact.betas, al_c, be_c) if al_c is not None else None
+            par = parity_block(fact.alphas, fact.betas, al_c, be_c) if al_c is not None else None
+            if par is not None and args.parity_seeds > 1:
+                # The Ritz figure is rounding noise amplified by |T| / theta_min ~ 2e4: one start vector is thin evidence.
+                # More start vectors, each a full GPU sweep against a full CPU sweep; the block carries the maximum.
+                lib = _load_cpu_ref()
+                per_seed = [{"seed": 3, **{k: par[k] for k in ("alpha_relerr", "beta_relerr", "ritz_relerr", "ritz_abserr_over_norm")}}]
+                for sd in range(4, 3 + args.parity_seeds):
+                    x0_handle[0].rand_(sd)
+                    f2 = sweep()
+                    _, al2, be2 = _run_cpu_ref(lib, args.ny, x0_handle[0].get(), orth.code, base["cores"])
+                    if al2 is None:
+                        continue
+                    p2 = parity_block(f2.alphas, f2.betas, al2, be2)
+                    per_seed.append({"seed": sd, **{k: p2[k] for k in ("alpha_relerr", "beta_relerr", "ritz_relerr", "ritz_abserr_over_norm")}})
+                for k in ("alpha_relerr", "beta_relerr", "ritz_relerr", "ritz_abserr_over_norm"):
+                    par[k] = max(e[k] for e in per_seed)
+                par["per_start_vector"] = per_seed
+                par["ok"] = bool(max(par["alpha_relerr"], par["beta_relerr"], par["ritz_relerr"]) <= par["tol"])
+                par["note"] = f"maximum over {len(per_seed)} start vectors (rand seeds), each a full {NX}x{args.ny} GPU sweep vs a full CPU sweep"
+            out["parity"] = par
         line = json.dumps(out)
     if comm:
         comm.close()
@@ -621,7 +641,7 @@ def main_checker(args, rank: int, world: int):
     sys.path.insert(0, str(ROOT / "tests"))
     sys.path.insert(0, str(ROOT / "oracle"))
     from dist_checker_backend import CheckerBackend
-    from krylovkit_hip import dist as kd
+    import splitphase_dist as kd          # test-side exerciser of the split-phase C entry points (tests/splitphase_dist.py)
     import krylovkit_hip as kk
 
     if world > 1:

@@ -32,7 +32,7 @@ def eigsolve(A, x0, howmany: int = 1, which: str = "LM", alg: Optional[Lanczos] 
     krylovdim, maxiter = alg.krylovdim, alg.maxiter
     if howmany > krylovdim:
         raise ValueError(f"krylov dimension {krylovdim} too small to compute {howmany} eigenvalues")
-    if iterator is not None:  # e.g. dist.DistLanczosIterator: same control flow, sharded vectors
+    if iterator is not None:  # a caller-built iterator with the same initialize / expand interface (e.g. a split-phase sharded one)
         it = iterator
     else:
         it = LanczosIterator(_as_operator(A), x0, alg.orth, True, capacity=krylovdim + 2)

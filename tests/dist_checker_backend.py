@@ -1,5 +1,5 @@
-"""CPU checker backend for krylovkit_hip.dist (TEST INFRASTRUCTURE): plain NumPy on torch CPU
-tensors, same interface as HipBackend, so the partition / halo-exchange / all-reduce logic of
+"""CPU checker backend for tests/splitphase_dist.py (TEST INFRASTRUCTURE): plain NumPy on torch CPU
+tensors, same interface as its HipBackend, so the partition / halo-exchange / all-reduce logic of
 the row-sharded path can run under gloo with world_size 2 on a machine without a GPU."""
 import numpy as np
 import torch

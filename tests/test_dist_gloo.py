@@ -30,7 +30,7 @@ def _worker(rank, world, port, case, q):
     import torch.distributed as dist
     import scipy.sparse as sp
     import krylov_oracle as ko
-    from krylovkit_hip import dist as kd
+    import splitphase_dist as kd
     from krylovkit_hip.core import Orthogonalizer
     from dist_checker_backend import CheckerBackend
 
@@ -128,7 +128,7 @@ def _gkl_worker(rank, world, port, q):
     os.environ["MASTER_PORT"] = str(port)
     import torch.distributed as dist
     import krylov_oracle as ko
-    from krylovkit_hip import dist as kd
+    import splitphase_dist as kd
     from krylovkit_hip.core import Orthogonalizer
     from dist_checker_backend import CheckerBackend
 

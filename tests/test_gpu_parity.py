@@ -473,13 +473,17 @@ def test_error_behaviour(kk, ctx):
 
 
 def test_dist_hip_backend_world1(kk, ko, ctx):
-    """The row-sharded path (krylovkit_hip.dist) on the real HipBackend with RCCL, world_size 1:
-    torch device tensors handed to the split-phase C entry points, all-reduce plumbing, stream sharing."""
+    """The caller-owned-communicator mechanisms of the C ABI (split-phase kk_*_dev entry points, hooks) on the real device
+    with torch.distributed over RCCL, world_size 1 (exercisers: tests/splitphase_dist.py): torch device tensors handed to
+    the split-phase C entry points, all-reduce plumbing, stream sharing."""
     import os
     import socket
+    import sys
+    from pathlib import Path
     import torch
     import torch.distributed as dist
-    from krylovkit_hip import dist as kd
+    sys.path.insert(0, str(Path(__file__).resolve().parent))
+    import splitphase_dist as kd
 
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))

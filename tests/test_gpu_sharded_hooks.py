@@ -18,7 +18,7 @@ sys.path.insert(0, str(ROOT / "tests"))
 def run_ranks(world, fn):
     """fn(rank, sctx, coll) in `world` threads; returns the list of results (re-raises failures)."""
     import torch
-    from krylovkit_hip import dist as kd
+    import splitphase_dist as kd
     from loopback_collective import LoopbackCollective, LoopbackWorld
 
     shared = LoopbackWorld(world)
@@ -52,7 +52,7 @@ def relerr(a, b):
 
 
 def test_sharded_lanczos_all_orthogonalizers(kk, ko, ctx):
-    from krylovkit_hip import dist as kd
+    import splitphase_dist as kd
     nx, ny, steps, world = 40, 30, 20, 2
     n = nx * ny
     A = ko.laplacian_2d(nx, ny, shift_diag=10 * np.linspace(0, 1, n) ** 2)
@@ -95,7 +95,7 @@ def test_sharded_lanczos_all_orthogonalizers(kk, ko, ctx):
 
 
 def test_sharded_eigsolve_gmres_block(kk, ko, ctx):
-    from krylovkit_hip import dist as kd
+    import splitphase_dist as kd
     import scipy.sparse as sps
     world = 2
     nx, ny = 24, 18
@@ -150,7 +150,7 @@ def test_sharded_eigsolve_gmres_block(kk, ko, ctx):
 def test_sharded_short_recurrences_and_exponentiate(kk, ko, ctx):
     """SURVEY 8(f)-3/4 rows on row shards through the same hooks: CG, BiCGStab (device-resident rho/alpha/omega are
     all-reduced sums, so both ranks take the same branches) and exponentiate, against the serial oracle."""
-    from krylovkit_hip import dist as kd
+    import splitphase_dist as kd
     world = 2
     nx, ny = 24, 18
     n = nx * ny
