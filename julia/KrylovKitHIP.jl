@@ -301,7 +301,15 @@ end
 # ---------------------------------------------------------------- L2: orthonormal.jl entry points
 # project!! (orthonormal.jl:88-118), unproject!! (:132-196), orthogonalize!! (:378-452 and :455-489),
 # basistransform! (:291-354), rmul!(b, Givens / Householder) (dense/givens.jl, reflector.jl:143-154)
-function orthogonalize!!(w::HipVec, b::OrthonormalBasis{HipVec}, x::AbstractVector, alg::KrylovKit.Orthogonalizer)
+# One method per CONCRETE orthogonaliser, exactly as the reference defines them (orthonormal.jl:378-452): a single method on
+# the abstract `Orthogonalizer` would be ambiguous with the reference's (v::T, b::OrthonormalBasis{T}, x, ::ClassicalGramSchmidt)
+# ... -- more specific in the vector slots, less specific in the algorithm slot (found by tests/test_julia_shim_lint.py).
+for O in (:ClassicalGramSchmidt, :ModifiedGramSchmidt, :ClassicalGramSchmidt2, :ModifiedGramSchmidt2, :ClassicalGramSchmidtIR, :ModifiedGramSchmidtIR)
+    @eval function orthogonalize!!(w::HipVec, b::OrthonormalBasis{HipVec}, x::AbstractVector, alg::$O)
+        return device_orthogonalize!!(w, b, x, alg)
+    end
+end
+function device_orthogonalize!!(w::HipVec, b::OrthonormalBasis{HipVec}, x::AbstractVector, alg::KrylovKit.Orthogonalizer)
     slab, c0, m = slab_range(b)
     m <= KK_MAX_M || error("KrylovKitHIP: orthogonalize!! against more than $KK_MAX_M vectors")
     code, η = orthcode(alg)

@@ -147,7 +147,117 @@ def test_module_is_syntactically_balanced():
     for a, b in ("()", "[]", "{}"):
         assert code.count(a) == code.count(b), (a, code.count(a), code.count(b))
     # statement-level openers only: comprehension `for`s and ternaries carry no `end`
-    openers = len(re.findall(r"(?m)^\s*(?:function|if|for|while|let|try|module|struct|mutable struct|quote)\b", code))
+    openers = len(re.findall(r"(?m)^\s*(?:@eval\s+)?(?:function|if|for|while|let|try|module|struct|mutable struct|quote)\b", code))
     openers += len(re.findall(r"\bbegin\b", code)) + len(re.findall(r"(?m)\bdo\s*$", code))
     ends = len(re.findall(r"(?m)(?:^|[\s;)])end\b", code))
     assert openers == ends, (openers, ends)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# method signatures: every KrylovKit function the shim overloads must exist in the reference with a method of the same
+# shape (positional arity within the reference's range, keyword names a subset, abstract type heads in the same slots).
+# The table is extracted from /root/reference by tests/golden/make_reference_signatures.py and committed.
+# ------------------------------------------------------------------------------------------------------------------
+import json  # noqa: E402
+
+SIGS = json.loads((ROOT / "tests" / "golden" / "reference_signatures.json").read_text())
+OVERLOADED = ["initialize", "expand!", "orthogonalize!!", "project!!", "unproject!!", "rank1update!", "basistransform!",
+              "block_qr!", "block_inner", "block_reorthogonalize!", "apply", "apply_normal", "apply_adjoint"]
+
+
+CONCRETE_ORTHS = ("ClassicalGramSchmidt", "ModifiedGramSchmidt", "ClassicalGramSchmidt2", "ModifiedGramSchmidt2",
+                  "ClassicalGramSchmidtIR", "ModifiedGramSchmidtIR")
+
+
+def _parse_args(argstr):
+    pos, kw, in_kw = [], [], False
+    depth, cur, toks = 0, "", []
+    for ch in argstr:
+        if ch in "([{":
+            depth += 1
+        elif ch in ")]}":
+            depth -= 1
+        if ch in ",;" and depth == 0:
+            toks.append((cur.strip(), ch)); cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        toks.append((cur.strip(), ""))
+    for tok, sep in toks:
+        if tok:
+            name, _, rest = tok.partition("::")
+            typ = rest.partition("=")[0] if rest else ""
+            head = re.match(r"\s*([$A-Za-z_.0-9]+)", typ)
+            (kw if in_kw else pos).append({"name": name.partition("=")[0].strip(), "type": head.group(1) if head else "",
+                                           "optional": "=" in tok})
+        if sep == ";":
+            in_kw = True
+    return pos, [k["name"] for k in kw]
+
+
+def shim_methods(name):
+    out = []
+    for m in re.finditer(rf"(?m)^\s*(?:@eval\s+)?(?:function\s+)?(?:KrylovKit\.)?{re.escape(name)}\(", JL):
+        i = m.end() - 1
+        j = balanced(JL, i)
+        after = JL[j:j + 40]
+        if "function" not in m.group(0) and not re.match(r"\s*=", after):
+            continue
+        pos, kw = _parse_args(" ".join(JL[i + 1:j - 1].split()))
+        out.append((pos, kw, JL.count("\n", 0, m.start()) + 1))
+    return out
+
+
+def _compatible(shim_pos, shim_kw, ref):
+    rp = ref["positional"]
+    need = sum(1 for p in rp if not p["optional"])
+    n_shim_min = sum(1 for p in shim_pos if not p["optional"])
+    # an optional trailing argument generates one method per arity: some arity of the shim must be an arity of the reference
+    if n_shim_min < need or not (set(range(n_shim_min, len(shim_pos) + 1)) & set(range(need, len(rp) + 1))):
+        return False
+    if not set(shim_kw) <= set(ref["keywords"]) | {"transpose"}:      # `transpose` is the shim's own keyword of apply
+        return False
+    for sp, rpp in zip(shim_pos, rp):
+        st, rt = sp["type"].split(".")[-1], rpp["type"].split(".")[-1]
+        # a typed reference slot must be matched by the same type head in the shim (HipVec / HipOperator fill untyped or
+        # type-parameter slots: `operator`, `v::T`, `x`)
+        if st.startswith("$"):     # @eval loop over the six concrete orthogonalisers
+            st = rt if rt in CONCRETE_ORTHS else "?"
+        if rt and rt not in ("T", "S", "F", "Number", "Real", "Integer", "Int") and st and st != rt:
+            return False
+    return True
+
+
+def test_every_overload_matches_a_reference_method():
+    checked = 0
+    for name in OVERLOADED:
+        assert name in SIGS, f"the reference has no function {name}"
+        methods = shim_methods(name)
+        assert methods, f"the shim does not overload {name}"
+        for pos, kw, line in methods:
+            ok = any(_compatible(pos, kw, ref) for ref in SIGS[name])
+            assert ok, (f"KrylovKitHIP.jl:{line}: {name}({', '.join(p['name'] + ('::' + p['type'] if p['type'] else '') for p in pos)}"
+                        f"; {', '.join(kw)}) matches no method of the reference: "
+                        + "; ".join("(" + ", ".join(p["name"] + ("::" + p["type"] if p["type"] else "") for p in r["positional"]) + ")" for r in SIGS[name]))
+            checked += 1
+    assert checked >= 20
+
+
+def test_reference_signature_table_is_current():
+    """where the reference is mounted (build container) the committed table must equal a fresh extraction"""
+    import subprocess
+    import sys
+    if not Path("/root/reference/src").exists():
+        return
+    fresh = subprocess.run([sys.executable, str(ROOT / "tests" / "golden" / "make_reference_signatures.py")], capture_output=True, text=True)
+    assert fresh.returncode == 0, fresh.stderr
+    assert json.loads((ROOT / "tests" / "golden" / "reference_signatures.json").read_text()) == SIGS
+
+
+def test_julia_harness_covers_every_factorization():
+    rt = (ROOT / "julia" / "test" / "runtests.jl").read_text()
+    for it in ("LanczosIterator", "ArnoldiIterator", "GKLIterator", "BlockLanczosIterator"):
+        assert it in rt
+    for inv in ("V' * V ≈ I", "A * V ≈ V * H + r * e'", "A' * U ≈ V * B'", "A * V ≈ V * H + r * e", "norm(r) ≈ β"):
+        assert inv in rt, inv
+    assert "Val(:hip)" in rt and "issue143_A.npy" in rt and "eigsolve(" in rt and "linsolve(" in rt and "svdsolve(" in rt
