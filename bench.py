@@ -188,7 +188,7 @@ def parity_block(al_g, be_g, al_c, be_c):
 def kernel_source_sha() -> str:
     import hashlib
     h = hashlib.sha256()
-    for f in ("kk_kernels_stream.hip", "kk_device.h", "kk_internal.h"):
+    for f in ("kk_kernels_stream.hip", "kk_kernels_persist.hip", "kk_device.h", "kk_internal.h"):
         h.update((ROOT / "krylovkit.jl_amd" / "csrc" / f).read_bytes())
     return h.hexdigest()[:16]
 
@@ -231,8 +231,9 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--orth", default=os.environ.get("KK_BENCH_ORTH", "mgs2"), choices=["cgs2", "mgs2"])
-    ap.add_argument("--mgs-mode", default="lowsync", choices=["lowsync", "strict"],
-                    help="strict = the reference's sequential MGS order (src/orthonormal.jl:414-439) as the headline run")
+    ap.add_argument("--mgs-mode", default="auto", choices=["auto", "lowsync", "strict"],
+                    help="how the MGS family runs: auto (library default: the reference's sequential order, src/orthonormal.jl:414-439, "
+                         "through the persistent kernel where that is faster, the low-synchronisation form otherwise), or one of the two forced")
     ap.add_argument("--config", default="lanczos", choices=["lanczos", "gkl", "block"],
                     help="lanczos = BASELINE.json configs[1] (the judged line); gkl / block = configs[3] / configs[4], row-sharded")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
@@ -294,8 +295,8 @@ def main():
     if use_dist:
         comm = kd.NativeComm.from_torch_distributed(ctx, force_collectives=force_dist) if world > 1 else \
             kd.NativeComm.single(ctx, force_collectives=True)
-    if args.mgs_mode == "strict":
-        ctx.set_option("mgs_mode", 0)
+    MODE = {"strict": 0, "lowsync": 1, "auto": 2}
+    ctx.set_option("mgs_mode", MODE[args.mgs_mode])
     sync = ctx.sync
     barrier = dist.barrier if world > 1 else (lambda: None)
 
@@ -492,14 +493,55 @@ def main():
     roofline = None
     if args.config == "lanczos":
         classes = {}
-        for name in ("k_project", "k_unproject", "k_mgs_step"):
+        for name in ("k_project", "k_unproject", "k_mgs_step", "k_mgs_persist"):
             ms, n = ctx.prof_get(name)
             if n:
                 classes[name] = (ms, n)
         # the two basis-streaming kernels are within 1 % of each other: the ROOFLINE kernel is the one with more
         # algorithmic bytes (k_unproject: V once + w read and written), so that the object does not flip run to run
-        dom = "k_unproject" if "k_unproject" in classes else (max(classes, key=lambda k: classes[k][0]) if classes else None)
-        if dom in ("k_project", "k_unproject"):
+        dom = "k_mgs_persist" if "k_mgs_persist" in classes else \
+            ("k_unproject" if "k_unproject" in classes else (max(classes, key=lambda k: classes[k][0]) if classes else None))
+        if dom == "k_mgs_persist":
+            ms, n = classes[dom]
+            # one launch per expand at basis size m = 2..100: the whole MGS sweep of the reference (for q in V: s = <q, w>;
+            # w -= s q, the pending "w -= alpha v" in front, |w| behind).  ALGORITHMIC bytes:
+            # pass(m) = (16 m + 24) N -- every basis vector read twice, w read twice and written once.  The kernel itself
+            # moves less: w stays in registers, and `parked` of the `rows` grid-rows of a basis vector wait ON CHIP (LDS +
+            # spare registers) between the inner product and the update that uses them again, so only the rest is read a
+            # second time -- which is why `frac` can exceed 1 here; `hbm_model_*` give the bytes really requested.
+            per_sweep = sum((16 * m + 24) * n_local for m in range(2, KRYLOVDIM + 1))
+            bytes_per_launch = per_sweep / (KRYLOVDIM - 1)
+            avg_ms = ms / n
+            achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+            pt = int(ctx.get_option("persist_threads"))
+            rows = -(-(n_local + 511) // (256 * pt * 2))                        # grid-rows of double2 per thread (ld / (CUs * threads * 2))
+            lds_rows = min(rows, (160 * 1024 - 256) // (pt * 16)) if ctx.get_option("persist_lds") >= 1 else 0
+            reg_rows = min(rows - lds_rows, 8) if (ctx.get_option("persist_lds") >= 2 and pt == 512) else 0
+            reread = (rows - lds_rows - reg_rows) / rows
+            model = sum((8 * m * (1 + reread) + 8 * (1 + reread) + 16) * n_local for m in range(2, KRYLOVDIM + 1)) / (KRYLOVDIM - 1)
+            traffic, traffic_note = None, None
+            tf = ROOT / "profiles" / "traffic.json"
+            if tf.exists():
+                try:
+                    tj = json.loads(tf.read_text())
+                    if tj.get("source_sha") == kernel_source_sha():
+                        traffic = tj.get(dom)
+                        traffic_note = f"PMC passes of {tj.get('stamped_by', 'tools/profile_gpu.sh')} on the same kernel sources (sha {tj.get('source_sha')})"
+                    else:
+                        traffic_note = "profiles/traffic.json was measured on other kernel sources (hash mismatch): stale, not reported"
+                except Exception:
+                    traffic = None
+            roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                        "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_note": traffic_note,
+                        "launches": int(n), "avg_launch_ms": round(avg_ms, 5),
+                        "algorithmic_bytes_per_launch": round(bytes_per_launch),
+                        "on_chip_parking": {"grid_rows_per_thread": int(rows), "parked_in_lds": int(lds_rows), "parked_in_registers": int(reg_rows),
+                                            "second_read_fraction": round(reread, 4)},
+                        "hbm_model_bytes_per_launch": round(model), "hbm_model_GBps": round(model / (avg_ms * 1e-3) / 1e9, 1),
+                        "hbm_model_frac": round(model / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                        "timed_region_kernel_ms": {k: round(v[0], 3) for k, v in classes.items()},
+                        "one_sweep_kernel_ms_breakdown": breakdown}
+        elif dom in ("k_project", "k_unproject"):
             ms, n = classes[dom]
             # one launch per expand at basis size m = 2..100: project moves (8m + 8) N algorithmic bytes
             # (V once + w), unproject (8m + 16) N (V once + w read/write); their sum is pass(m) = (16m + 24) N.
@@ -533,30 +575,30 @@ def main():
                         "launches": int(n), "avg_launch_ms": round(ms / n, 5), "algorithmic_bytes_per_launch": 32 * n_local,
                         "one_sweep_kernel_ms_breakdown": breakdown}
 
-    # ---------------- secondary leg: the reference's sequential MGS2 order on the same workload (untimed region above)
-    strict = None
-    if args.config == "lanczos" and args.orth == "mgs2" and args.mgs_mode == "lowsync" and not args.no_strict_leg:
-        ctx.set_option("mgs_mode", 0)
+    # ---------------- secondary leg: the OTHER execution order of MGS2 on the same workload (the headline ran the library default)
+    strict, lowsync_leg = None, None
+    headline_is_strict = "k_mgs_persist" in breakdown or "k_mgs_step" in breakdown and breakdown.get("k_mgs_step", 0) > breakdown.get("k_project", 0)
+    if args.config == "lanczos" and args.orth == "mgs2" and not args.no_strict_leg:
+        other = 1 if headline_is_strict else 0
+        ctx.set_option("mgs_mode", other)
         sweep()
-        barrier(); sync()
-        t1 = time.perf_counter()
-        fs = sweep()
-        barrier(); sync()
-        dts = time.perf_counter() - t1
-        ctx.set_option("mgs_mode", 1)
-        if world > 1:
-            t = torch.tensor([dts], dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dts = float(t.item())
-        # strict MGS2 as the reference codes it: (176 + 16 m) N algorithmic bytes per expand as well
-        strict = {"value": round(units_per_sweep / dts, 3), "unit": "it/s", "ms_per_step": round(dts * 1e3, 3),
-                  "hbm_algorithmic_frac_of_peak_per_gpu": round(alg_sweep / dts / 1e9 / (HBM_PEAK_GBPS * world), 4),
-                  "note": "mgs_mode=0: the reference's sequential order (src/orthonormal.jl:414-439), one basis vector after the other; "
-                          + ("row-sharded: one fused axpy+dot kernel and one all-reduce per basis vector (32 N bytes per vector; the "
-                             "persistent kernel cannot issue collectives)" if use_dist else
-                             "persistent cooperative kernel, w resident in registers, one streaming read of every basis vector per sweep "
-                             "(the per-vector kernel it replaces moved 32 N bytes per vector: 365 it/s)"),
-                  "max_alpha_reldiff_vs_lowsync": float(np.max(np.abs(np.array(fs.alphas) - np.array(fact.alphas)) / np.abs(np.array(fact.alphas))))}
+        dts, fs = timed(sweep, 1)
+        ctx.set_option("mgs_mode", MODE[args.mgs_mode])
+        leg = {"value": round(units_per_sweep / dts, 3), "unit": "it/s", "ms_per_step": round(dts * 1e3, 3),
+               "hbm_algorithmic_frac_of_peak_per_gpu": round(alg_sweep / dts / 1e9 / (HBM_PEAK_GBPS * world), 4),
+               "max_alpha_reldiff_vs_headline": float(np.max(np.abs(np.array(fs.alphas) - np.array(fact.alphas)) / np.abs(np.array(fact.alphas))))}
+        if other == 0:
+            # strict MGS2 as the reference codes it: (176 + 16 m) N algorithmic bytes per expand as well
+            leg["note"] = ("mgs_mode=0: the reference's sequential order (src/orthonormal.jl:414-439), one basis vector after the other; "
+                           + ("row-sharded: one fused axpy+dot kernel and one all-reduce per basis vector (32 N bytes per vector; the "
+                              "persistent kernel cannot issue collectives)" if use_dist else
+                              "persistent cooperative kernel, w resident in registers"))
+            strict = leg
+        else:
+            leg["note"] = ("mgs_mode=1: low-synchronisation MGS2 -- one projection pass + exact triangular solve with the Gram matrix of the basis "
+                           "+ one update pass (k_project / k_unproject, the basis read twice per expand: 16 N bytes per vector); the "
+                           "round-1/2 headline configuration")
+            lowsync_leg = leg
 
     line = None
     if rank == 0:
@@ -568,7 +610,7 @@ def main():
             "config": {
                 "workload": workload,
                 "orth": {"cgs2": "ClassicalGramSchmidt2", "mgs2": "ModifiedGramSchmidt2 (reference default; "
-                         + ("low-sync form)" if args.mgs_mode == "lowsync" else "strict sequential order)")}[args.orth],
+                         + ("strict sequential order of src/orthonormal.jl:414-439, persistent kernel)" if headline_is_strict else "low-synchronisation form)")}[args.orth],
                 "rows_per_gpu": n_local, "parallelism": parallelism,
             },
             "job_iterations_per_second": round(sweep_its * K / elapsed, 3),
@@ -584,6 +626,8 @@ def main():
             out["other_scaling_leg"] = other_leg
         if strict:
             out["mgs2_strict"] = strict
+        if lowsync_leg:
+            out["mgs2_lowsync"] = lowsync_leg
         if comm:
             info = comm.info()
             per = {k: (stats1[k] - stats0[k]) / (K * sweep_its) for k in stats1}

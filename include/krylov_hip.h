@@ -65,12 +65,17 @@ typedef enum {
 
 /* How the MGS family is executed on the device (kk_ctx_set_option("mgs_mode", v)):
  *   0 = strict:   sequential as in src/orthonormal.jl:417-421, one basis vector after the other: a persistent
- *                 cooperative kernel that keeps w in registers and reads every basis vector once (8 N bytes / vector;
- *                 option "mgs_persist", default 1, "persist_threads" 512 / 1024); when w does not fit the register
- *                 file of the chip, or the context is row-sharded, one fused axpy+dot kernel per vector (32 N bytes).
+ *                 cooperative kernel that keeps w in registers for the whole sweep and parks the current basis vector on
+ *                 chip (LDS + spare registers) between its two uses, so that HBM sees ~1.3 reads per basis vector
+ *                 (10.5 N bytes / vector at N = 10^7; options "mgs_persist", default 1, "persist_threads" 512 / 1024,
+ *                 "persist_lds" 0 / 1 / 2); when w does not fit the register file of the chip, or the context is
+ *                 row-sharded, one fused axpy+dot kernel per vector (32 N bytes).
  *   1 = lowsync:  algebraically identical MGS coefficients from ONE projection pass plus a
  *                 triangular solve (on the device) with the strictly-lower Gram matrix of the
- *                 basis, maintained incrementally (16 N bytes / vector).  Default. */
+ *                 basis, maintained incrementally (16 N bytes / vector).
+ *   2 = auto:     (default) strict through the persistent kernel wherever that is the faster of the two -- the work vector
+ *                 fits the chip, the context is not row-sharded and the vectors have >= "persist_min_rows" (4e6) rows, so
+ *                 that the saved basis traffic outweighs one grid reduction per vector -- and lowsync otherwise. */
 /* Other kk_ctx_set_option keys: "blocks_per_cu" (grid of the streaming kernels, default 4), "block_mode" (0 strict
  * block QR / re-orthogonalisation, 1 MFMA panels + CholQR2, default), "fuse_passes", "speculate" (next-step SpMV
  * enqueued before the host reads alpha/beta), "keep_mb" (MB of trailing basis columns a project pass leaves
@@ -81,7 +86,8 @@ typedef enum {
  * skipped when the block is orthonormal to this level after the first; default 2e-14, 0 = never), "resid_gram" (Gram matrix
  * of the residual block handed from one step to the next, default 1), "spmv_dia" / "spmm_dia" (diagonal kernels for operators
  * detected as grid stencils, default 1; 0 = the general ELL gather kernels).  Tuning knobs without semantic effect:
- * "gram_bpc", "gram2_chunk", "spmm_bpc", "spmm_cols", "spmm_rpl", "spmm_dia_lines", "bu_prefetch", "gram_nt", "persist_nt". */
+ * "gram_bpc", "gram2_chunk", "spmm_bpc", "spmm_cols", "spmm_rpl", "spmm_dia_lines", "bu_prefetch", "gram_nt", "persist_nt",
+ * "persist_lds", "persist_min_rows".  Test hook: "persist_fault" (the next n persistent launches behave like a grid-barrier timeout). */
 
 /* Environment variables read by the library (all optional): KK_MGS_MODE, KK_BLOCK_MODE, KK_BLOCKS_PER_CU, KK_MGS_PERSIST,
  * KK_PERSIST_THREADS, KK_PERSIST_NT (defaults of the options of the same name, read at kk_ctx_create); KK_SPMV_FORMAT = ell |

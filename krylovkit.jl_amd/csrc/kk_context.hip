@@ -151,7 +151,7 @@ KK_API int kk_ctx_set_option(kk_ctx c, const char* key, double value) {
         KK_CHECK(value >= 1 && value * c->num_cus <= KK_MAX_BLOCKS, KK_ERR_INVALID, "blocks_per_cu out of range");
         c->blocks_per_cu = (int)value;
     } else if (!strcmp(key, "mgs_mode")) {
-        KK_CHECK(value == 0 || value == 1, KK_ERR_INVALID, "mgs_mode must be 0 (strict) or 1 (lowsync)");
+        KK_CHECK(value == 0 || value == 1 || value == 2, KK_ERR_INVALID, "mgs_mode must be 0 (strict), 1 (lowsync) or 2 (auto)");
         c->mgs_mode = (int)value;
     } else if (!strcmp(key, "speculate")) {
         c->speculate = value != 0;
@@ -169,6 +169,11 @@ KK_API int kk_ctx_set_option(kk_ctx c, const char* key, double value) {
         c->persist_threads = (int)value;
     } else if (!strcmp(key, "persist_nt")) {
         c->persist_nt = value != 0;
+    } else if (!strcmp(key, "persist_min_rows")) {
+        KK_CHECK(value >= 0, KK_ERR_INVALID, "persist_min_rows must be >= 0");
+        c->persist_min_rows = (int64_t)value;
+    } else if (!strcmp(key, "persist_lds")) {
+        c->persist_lds = (int)value;   // 0 off, 1 LDS, 2 LDS + spare registers
     } else if (!strcmp(key, "gram_nt")) {
         c->gram_nt = value != 0;
     } else if (!strcmp(key, "spmv_dia")) {
@@ -235,6 +240,8 @@ KK_API int kk_ctx_get_option(kk_ctx c, const char* key, double* value) {
     else if (!strcmp(key, "persist_threads")) *value = c->persist_threads;
     else if (!strcmp(key, "persist_timeouts")) *value = c->persist_timeouts;
     else if (!strcmp(key, "persist_nt")) *value = c->persist_nt;
+    else if (!strcmp(key, "persist_lds")) *value = c->persist_lds;
+    else if (!strcmp(key, "persist_min_rows")) *value = (double)c->persist_min_rows;
     else if (!strcmp(key, "speculate")) *value = c->speculate;
     else if (!strcmp(key, "spmv_dia")) *value = c->spmv_dia;
     else if (!strcmp(key, "spmm_dia")) *value = c->spmm_dia;

@@ -134,12 +134,16 @@ struct kk_ctx_s {
                                  // update folded into the re-orthogonalisation panel, 4 = one-pass projection against the whole basis
     int block_async = 1;         // panel mode: whole block step enqueued without host round trips (device-side CholQR2 algebra)
     int blocks_per_cu = 4;       // 4 resident 256-thread blocks per CU (measured best on the 10M-row sweep)
-    int mgs_mode = 1;
+    int mgs_mode = 2;            // MGS family: 0 strict (reference order), 1 low-synchronisation, 2 auto = strict through the persistent
+                                 // kernel where that is the faster one (eligible and >= persist_min_rows rows), low-sync otherwise
+    int64_t persist_min_rows = 4000000;   // auto mode: below this the per-vector grid reduction (~3 us) outweighs the saved basis traffic
     int keep_mb = 160;           // MB of trailing basis columns a project pass leaves cache-allocated for the unproject
                                  // pass that follows (the Infinity Cache holds 256 MB); 0 = all loads non-temporal
     int mgs_persist = 1;         // strict MGS sweeps through the persistent register-resident kernel when the vector fits
     int persist_threads = 512;   // threads per block (= per CU) of that kernel: 1024 (<= 40 doubles of w per thread) or 512 (<= 80)
     int persist_nt = 1;          // second read of a basis vector (served by the Infinity Cache) with non-temporal loads
+    int persist_lds = 2;         // park grid-rows of the current basis vector on chip between its two uses: 1 = as many as fit the LDS,
+                                 // 2 = those plus KK_PERSIST_NR more in spare registers (512-thread blocks), 0 = none (second read from memory)
     void* d_sync = nullptr;      // device: hand-off granules + error flag of the in-kernel grid reduction (KK_SYNC_BYTES)
     int* h_sync = nullptr;       // pinned: read-back of the error flag
     bool persist_pending = false;  // a persistent launch has not been checked for a barrier timeout yet
@@ -275,8 +279,8 @@ struct kk_prof_scope {
     kk_ctx c;
     bool on;
     kk_prof_scope(kk_ctx ctx, const char* cls) : c(ctx) {
-        // k_project / k_unproject / k_unproj_proj all start with "k_proj" or "k_unproj"
-        on = c->prof == 1 || (c->prof == 2 && (cls[2] == 'p' || cls[2] == 'u'));
+        // the basis-streaming classes: k_project / k_unproject / k_unproj_proj ("k_p", "k_u") and k_mgs_persist
+        on = c->prof == 1 || (c->prof == 2 && (cls[2] == 'p' || cls[2] == 'u' || (cls[2] == 'm' && cls[5] == '_' && cls[6] == 'p')));
         if (on) kk_prof_begin(c, cls);
     }
     ~kk_prof_scope() {
@@ -399,6 +403,11 @@ int kk_launch_lsmr_u(kk_ctx ctx, const double* av, double* ah, double* u, int64_
 int kk_launch_lsmr_hx(kk_ctx ctx, double* h, double* hbar, double* x, const double* v, int64_t ld, double c1, double c2,
                       double c3);
 bool kk_mgs_persist_eligible(kk_ctx ctx, int64_t ld, int m, int nsweeps);
+// does an MGS-family sweep over vectors of leading dimension ld run in the low-synchronisation form?  (option "mgs_mode")
+static inline bool kk_mgs_lowsync(kk_ctx ctx, int64_t ld, int m) {
+    if (ctx->mgs_mode != 2) return ctx->mgs_mode == 1;
+    return !(ld >= ctx->persist_min_rows && kk_mgs_persist_eligible(ctx, ld, m, 2));
+}
 int kk_launch_mgs_persist(kk_ctx ctx, const double* V, int64_t ld, int m, int nsweeps, double* w, const double* carry_q,
                           const double* carry_s, double* out_s, int out_stride, double* nrm_out3);
 int kk_launch_lanczos_coef(kk_ctx ctx, const double* buf, double* L, int cap, int m, int lowsync, double* coef_out, double* res);

@@ -124,16 +124,26 @@ __device__ __forceinline__ void fnma_inplace(double& x, double s, double p) {
     asm("v_fma_f64 %0, -%1, %2, %0" : "+v"(x) : "v"(s), "v"(p));
 }
 
-template <int NV, int B, bool NTPREV, bool NORM /* false: axpy + dot with q_next, true: axpy + squared norm */>
-__device__ __forceinline__ void persist_step(d2 (&wr)[NV], __amdgpu_buffer_rsrc_t rp, __amdgpu_buffer_rsrc_t rn, double sp,
-                                             unsigned sbytes, unsigned voff, double& a0, double& a1) {
+// The first NL grid-rows of every basis vector are PARKED IN LDS between the step that reads the vector as q_next (for the
+// inner product) and the following step that needs it again as q_prev (for the pending axpy): thread t keeps its own
+// double2 of grid-row i at lq[i * PT] (consecutive lanes, consecutive 16-byte slots: conflict-free ds_write_b128 /
+// ds_read_b128; only the owning thread ever touches a slot, so program order is all the synchronisation there is).  With
+// 512 threads per CU the 160 KB of LDS hold 19 of the (at N = 10^7) 39 grid-rows: the second read of a basis vector
+// shrinks from 8 N to ~4.1 N bytes of fabric traffic -- 12.1 N per vector instead of the 16 N of ANY projection-based
+// pass (project + unproject read the basis twice), which is what lets the reference's sequential order overtake them.
+template <int NV, int NL, int NR, int PT, int B, bool NTPREV, bool NORM /* false: axpy + dot with q_next, true: axpy + squared norm */,
+          bool PREV_LDS /* grid-rows < NL of q_prev come from LDS, the NR after them from registers */>
+__device__ __forceinline__ void persist_step(d2 (&wr)[NV], d2 (&qk)[NR > 0 ? NR : 1], __amdgpu_buffer_rsrc_t rp, __amdgpu_buffer_rsrc_t rn,
+                                             double sp, unsigned sbytes, unsigned voff, d2* __restrict__ lq, double& a0, double& a1) {
 #pragma unroll
     for (int i0 = 0; i0 < NV; i0 += B) {
         d2 p[B], q[B];
 #pragma unroll
         for (int u = 0; u < B; ++u) {
             if (i0 + u < NV) {
-                p[u] = bload(rp, voff, (unsigned)(i0 + u) * sbytes, NTPREV);
+                if (PREV_LDS && i0 + u < NL) p[u] = lq[(i0 + u) * PT];
+                else if (PREV_LDS && i0 + u < NL + NR) p[u] = qk[i0 + u - NL];
+                else p[u] = bload(rp, voff, (unsigned)(i0 + u) * sbytes, NTPREV);
                 if (!NORM) q[u] = bload(rn, voff, (unsigned)(i0 + u) * sbytes, false);
             }
         }
@@ -146,6 +156,8 @@ __device__ __forceinline__ void persist_step(d2 (&wr)[NV], __amdgpu_buffer_rsrc_
                 const d2 y = NORM ? x : q[u];
                 if (u & 1) { a1 = fma(y.x, x.x, a1); a1 = fma(y.y, x.y, a1); }
                 else { a0 = fma(y.x, x.x, a0); a0 = fma(y.y, x.y, a0); }
+                if (!NORM && i0 + u < NL) lq[(i0 + u) * PT] = q[u];   // park q_next for the next step's axpy
+                else if (!NORM && i0 + u < NL + NR) qk[i0 + u - NL] = q[u];
             }
         }
         __builtin_amdgcn_sched_barrier(0);   // keep the loads of one batch together: w stays the only long-lived register set
@@ -157,13 +169,14 @@ __device__ __forceinline__ void persist_step(d2 (&wr)[NV], __amdgpu_buffer_rsrc_
 // Every step has the same shape -- pending axpy with (q_prev, s_prev), then the inner product with q_next -- so that the
 // work vector stays in ONE register set through the loop; a step with nothing pending (the first one without a carry)
 // runs the axpy with s_prev = 0 against a column of V.
-template <int NV, int PT, bool NTPREV>
+template <int NV, int NL, int NR, int PT, bool NTPREV>
 __global__ __launch_bounds__(PT) void k_mgs_persist(const double* __restrict__ V, int64_t ld, int m, int nsweeps,
                                                     double* __restrict__ w, const double* __restrict__ carry_q,
                                                     const double* __restrict__ carry_s, double* __restrict__ out_s,
                                                     int out_stride, double* __restrict__ nrm_out3,
                                                     gu64* __restrict__ gran, int* __restrict__ err, int fault) {
     __shared__ double sm[PT / 64];
+    extern __shared__ d2 park[];   // NL * PT double2 (dynamic): the parked grid-rows of the current basis vector
     if (fault && blockIdx.x == 0) {   // test hook (option "persist_fault"): block 0 behaves like a block whose spin ran out
         if (threadIdx.x == 0) __hip_atomic_store(err, 1, RLX_AGENT);
         return;
@@ -171,6 +184,7 @@ __global__ __launch_bounds__(PT) void k_mgs_persist(const double* __restrict__ V
     constexpr int B = (PT == 1024 && NV > 16) ? 2 : 4;   // loads in flight per stream and lane; 128-register budget at 1024 threads
     const unsigned sbytes = gridDim.x * PT * 16u;                      // one grid-row in bytes
     const unsigned voff = (blockIdx.x * PT + threadIdx.x) * 16u;       // this lane's byte offset inside a grid-row
+    d2* lq = park + threadIdx.x;
     const __amdgpu_buffer_rsrc_t rw = col_rsrc(w, ld);
     d2 wr[NV];
 #pragma unroll
@@ -178,10 +192,18 @@ __global__ __launch_bounds__(PT) void k_mgs_persist(const double* __restrict__ V
     const double* qp = carry_q ? carry_q : V;   // nothing pending: s_prev = 0 against a (finite) basis column
     double sp = carry_q ? *carry_s : 0.0;
     const int nsteps = m * nsweeps;
+    d2 qk[NR > 0 ? NR : 1];   // NR more grid-rows of the current basis vector parked in spare registers
+    if (NL + NR > 0) {   // park the first q_prev (the carried vector, or the dummy that goes with s_prev = 0): every step then has ONE shape
+        const __amdgpu_buffer_rsrc_t r0 = col_rsrc(qp, ld);
+#pragma unroll
+        for (int i = 0; i < NL; ++i) lq[i * PT] = bload(r0, voff, (unsigned)i * sbytes, false);
+#pragma unroll
+        for (int i = 0; i < NR; ++i) qk[i] = bload(r0, voff, (unsigned)(NL + i) * sbytes, false);
+    }
     for (int s = 0; s < nsteps; ++s) {
         const double* qn = V + (int64_t)(s % m) * ld;
         double a0 = 0, a1 = 0, total;
-        persist_step<NV, B, NTPREV, false>(wr, col_rsrc(qp, ld), col_rsrc(qn, ld), sp, sbytes, voff, a0, a1);
+        persist_step<NV, NL, NR, PT, B, NTPREV, false, true>(wr, qk, col_rsrc(qp, ld), col_rsrc(qn, ld), sp, sbytes, voff, lq, a0, a1);
         if (!grid_sum<PT>(a0 + a1, s, gran, err, sm, &total)) return;   // timeout: w in HBM is untouched
         if (blockIdx.x == 0 && threadIdx.x == 0) out_s[(s / m) * out_stride + (s % m)] = total;
         sp = total;
@@ -189,7 +211,7 @@ __global__ __launch_bounds__(PT) void k_mgs_persist(const double* __restrict__ V
     }
     {   // last pending axpy, fused with the squared norm of the result
         double a0 = 0, a1 = 0, total;
-        persist_step<NV, B, NTPREV, true>(wr, col_rsrc(qp, ld), col_rsrc(qp, ld), sp, sbytes, voff, a0, a1);
+        persist_step<NV, NL, NR, PT, B, NTPREV, true, true>(wr, qk, col_rsrc(qp, ld), col_rsrc(qp, ld), sp, sbytes, voff, lq, a0, a1);
         if (nrm_out3) {
             if (!grid_sum<PT>(a0 + a1, nsteps, gran, err, sm, &total)) return;
             if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -218,13 +240,37 @@ bool kk_mgs_persist_eligible(kk_ctx ctx, int64_t ld, int m, int nsweeps) {
     return per_thread2 <= (pt == 1024 ? 20 : 40);
 }
 
+// grid-rows parked in LDS: what fits next to the reduction scratch in the 160 KB of a CU, at most all of them; 0 = off
 template <int NV, int PT>
-static int launch_persist(kk_ctx ctx, void** args, bool ntprev) {
+struct persist_park { static constexpr int full = (160 * 1024 - 256) / (PT * 16); static constexpr int n = NV < full ? NV : full; };
+
+template <int NV, int NL, int NR, int PT, bool NT>
+static int launch_persist_inst(kk_ctx ctx, void** args) {
+    const void* fn = (const void*)k_mgs_persist<NV, NL, NR, PT, NT>;
+    const size_t dyn = (size_t)NL * PT * sizeof(double) * 2;
+    static bool configured = false;   // one attribute call per instantiation and process
+    if (!configured && dyn > 0) {
+        hipError_t ea = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+        if (ea != hipSuccess) return kk_hip_fail(ea, "hipFuncSetAttribute(k_mgs_persist, MaxDynamicSharedMemorySize)", __FILE__, __LINE__);
+        configured = true;
+    }
     const dim3 g(ctx->num_cus), b(PT);
-    hipError_t e = ntprev ? hipLaunchCooperativeKernel((const void*)k_mgs_persist<NV, PT, true>, g, b, args, 0, ctx->stream)
-                          : hipLaunchCooperativeKernel((const void*)k_mgs_persist<NV, PT, false>, g, b, args, 0, ctx->stream);
+    hipError_t e = hipLaunchCooperativeKernel(fn, g, b, args, dyn, ctx->stream);
     if (e != hipSuccess) return kk_hip_fail(e, "hipLaunchCooperativeKernel(k_mgs_persist)", __FILE__, __LINE__);
     return KK_OK;
+}
+// grid-rows of the current basis vector kept in spare registers on top of the LDS-parked ones: only where the work vector
+// leaves room (512 threads: 256 registers per lane, w takes 4 NV of them) -- KK_PERSIST_NR picks the count at build time
+#ifndef KK_PERSIST_NR
+#define KK_PERSIST_NR 8
+#endif
+template <int NV, int PT>
+static int launch_persist(kk_ctx ctx, void** args, bool ntprev) {
+    constexpr int NL = persist_park<NV, PT>::n;
+    constexpr int NR = (PT == 512 && NV - NL > 0) ? (NV - NL < KK_PERSIST_NR ? NV - NL : KK_PERSIST_NR) : 0;
+    if (ctx->persist_lds == 2) return ntprev ? launch_persist_inst<NV, NL, NR, PT, true>(ctx, args) : launch_persist_inst<NV, NL, NR, PT, false>(ctx, args);
+    if (ctx->persist_lds) return ntprev ? launch_persist_inst<NV, NL, 0, PT, true>(ctx, args) : launch_persist_inst<NV, NL, 0, PT, false>(ctx, args);
+    return ntprev ? launch_persist_inst<NV, 0, 0, PT, true>(ctx, args) : launch_persist_inst<NV, 0, 0, PT, false>(ctx, args);
 }
 
 int kk_launch_mgs_persist(kk_ctx ctx, const double* V, int64_t ld, int m, int nsweeps, double* w, const double* carry_q,

@@ -149,7 +149,7 @@ KK_API int kk_lanczos_expand(kk_op op, kk_basis b, int c0, int k, kk_orth_t orth
     const double* vprev = b->col(c0 + k - 1);
     double* w = b->col(c0 + k + 1);
     const bool cgs_order = (orth == KK_CGS || orth == KK_CGS2 || orth == KK_CGSIR);
-    const bool lowsync = c->mgs_mode == 1;
+    const bool lowsync = kk_mgs_lowsync(c, ld, m);
     // Row-sharded run, projection-based orthogonaliser: the alpha0 partial of the SpMV and the two projection panels
     // stay LOCAL, land side by side in ws[WS_SHBUF ..] = [alpha0 | V'w | V'v] and are summed by ONE all-reduce; the
     // second (and last) one is |w|^2.  SURVEY.md 8(e).

@@ -334,7 +334,7 @@ int orth_run(kk_basis b, int c0, int m, double* w, kk_orth_t alg, double eta, do
         if (npasses) *npasses = 0;
         return KK_OK;
     }
-    const bool lowsync = c->mgs_mode == 1 && c0 == 0;
+    const bool lowsync = c0 == 0 && kk_mgs_lowsync(c, ld, m);
     std::vector<double> tmp(m);
     switch (alg) {
         case KK_CGS: {

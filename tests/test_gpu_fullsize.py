@@ -223,10 +223,12 @@ def test_config2_lanczos_10M_parity_more_start_vectors(kk, ctx, seed):
     V.free(); x0b.free(); op.free()
 
 
-@pytest.mark.parametrize("orth_name,mgs_mode", [("mgs2", 1), ("mgs2", 0), ("cgs2", 1)])
+@pytest.mark.parametrize("orth_name,mgs_mode", [("mgs2", 2), ("mgs2", 1), ("mgs2", 0), ("cgs2", 1)])
 def test_config2_lanczos_10M_parity_with_cpu_reference(kk, ctx, cfg2_cpu_reference, orth_name, mgs_mode):
     """src/factorizations/lanczos.jl:250-272 + :313-338 at N = 10^7, krylovdim = 100: alpha / beta trajectories and the Ritz
-    values of the 100 x 100 tridiagonal, GPU (low-sync MGS2, strict MGS2, CGS2) vs the CPU reference path, <= 1e-10 relative."""
+    values of the 100 x 100 tridiagonal, GPU (MGS2 in the library's default mode = the reference's sequential order through
+    the persistent kernel with the basis vector parked on chip, low-sync MGS2, strict MGS2 forced, CGS2) vs the CPU
+    reference path, <= 1e-10 relative."""
     from bench import laplacian_rows, NX, NY
     N, K = NX * NY, 100
     ctx.set_option("mgs_mode", mgs_mode)
@@ -242,8 +244,13 @@ def test_config2_lanczos_10M_parity_with_cpu_reference(kk, ctx, cfg2_cpu_referen
         for _ in range(K - 1):
             f = kk.expand_(it, f)
         al_g, be_g = np.array(f.alphas), np.array(f.betas)
+        if orth_name == "mgs2":   # which kernels ran: the persistent one in strict / auto mode, the projection pair otherwise
+            ctx.prof_reset(); ctx.prof_enable(1)
+            kk.expand_(it, f)
+            ctx.prof_enable(0)
+            assert (ctx.prof_get("k_mgs_persist")[1] > 0) == (mgs_mode != 1) and (ctx.prof_get("k_project")[1] > 0) == (mgs_mode == 1)
     finally:
-        ctx.set_option("mgs_mode", 1)
+        ctx.set_option("mgs_mode", 2)
     al_c, be_c = cfg2_cpu_reference(orth.code, x0)
     assert np.max(np.abs(al_g - al_c) / np.abs(al_c)) <= 1e-10
     assert np.max(np.abs(be_g - be_c) / np.abs(be_c)) <= 1e-10

@@ -77,7 +77,7 @@ def test_native_sharded_lanczos_matches_oracle(kk, ko, comm, mgs_mode):
             w = kk.DeviceBasis(n, 1, ctx)[0].set(np.random.default_rng(2).random(n))
             x, nrm, _ = f.V.orthogonalize(w, dev)
             assert np.max(np.abs(Vn.T @ w.get())) < 1e-12 * max(1.0, nrm)
-    ctx.set_option("mgs_mode", 1)
+    ctx.set_option("mgs_mode", 2)
 
 
 def test_native_sharded_eigsolve_and_gmres(kk, ko, comm):
@@ -140,7 +140,7 @@ def test_native_sharded_gkl_matches_oracle(kk, ko, comm, mgs_mode):
     yv = np.random.default_rng(10).standard_normal(600)
     op.apply_adjoint(yb[0].set(yv), xb[0])
     np.testing.assert_allclose(xb[0].get(), A.T @ yv, rtol=0, atol=1e-12)
-    ctx.set_option("mgs_mode", 1)
+    ctx.set_option("mgs_mode", 2)
 
 
 def test_native_sharded_blocklanczos_issue143(kk, ko, comm):

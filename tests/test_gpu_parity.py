@@ -111,7 +111,7 @@ def test_orthogonalize_all_algs(kk, ko, ctx, n, m, mgs_mode):
         vw.set(w0)
         x2, beta, _ = B.orthonormalize(vw, dev)
         assert abs(vw.norm() - 1) < 1e-13 and abs(beta - nrm) <= 1e-12 * nrm
-    ctx.set_option("mgs_mode", 1)
+    ctx.set_option("mgs_mode", 2)
 
 
 def test_orthogonalize_vec(kk, ko, ctx):
@@ -279,7 +279,7 @@ def test_lanczos_factorization(kk, ko, ctx, mgs_mode):
         ofact = ko.lanczos_shrink(ofact, 10)
         assert len(fact) == 10 and len(fact.V) == 10
         np.testing.assert_allclose(fact.r.get(), ofact.r, rtol=0, atol=1e-6 if not dev.is_reorth else 1e-10)
-    ctx.set_option("mgs_mode", 1)
+    ctx.set_option("mgs_mode", 2)
 
 
 def test_lanczos_keepvecs_false(kk, ko, ctx):
@@ -329,7 +329,7 @@ def test_arnoldi_factorization(kk, ko, ctx, mgs_mode):
         fact = kk.shrink_(fact, 7)
         ofact = ko.arnoldi_shrink(ofact, 7)
         assert len(fact.H) == len(ofact.H) and len(fact.V) == 7
-    ctx.set_option("mgs_mode", 1)
+    ctx.set_option("mgs_mode", 2)
 
 
 @pytest.mark.parametrize("mgs_mode", [0, 1])
@@ -359,7 +359,7 @@ def test_gkl_factorization(kk, ko, ctx, mgs_mode):
         assert relerr(fact.alphas, ofact.alphas) < tol and relerr(fact.betas, ofact.betas) < tol
         fact = kk.shrink_(fact, 5)
         assert len(fact.U) == 5 and len(fact.V) == 5
-    ctx.set_option("mgs_mode", 1)
+    ctx.set_option("mgs_mode", 2)
 
 
 def test_restart_kernels(kk, ko, ctx):
@@ -1266,7 +1266,7 @@ def test_mgs_on_non_orthonormal_basis(kk, ko, ctx, mgs_mode):
         wr, xr = ko.orthogonalize(w0.copy(), [V[:, j].copy() for j in range(m)], ref)
         np.testing.assert_allclose(x, xr, rtol=1e-9, atol=1e-10 * np.linalg.norm(w0))
         np.testing.assert_allclose(vw.get(), wr, rtol=0, atol=1e-9 * np.linalg.norm(w0))
-    ctx.set_option("mgs_mode", 1)
+    ctx.set_option("mgs_mode", 2)
 
 
 def test_wide_basis_is_chunked_and_capacity_is_checked_early(kk, ko, ctx):

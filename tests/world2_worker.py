@@ -108,7 +108,7 @@ def lanczos_against_oracle(A, part, x0, steps, tag, check_counts=True):
                     sgn = np.sign(np.sum(V * Vo, axis=0))
                     assert np.max(np.abs(V * sgn - Vo)) < 1e-8, (tag, dev.name)
             report[f"{tag}.{dev.name}.mgs{mgs_mode}"] = [ea, eb]
-    ctx.set_option("mgs_mode", 1)
+    ctx.set_option("mgs_mode", 2)
     return op
 
 
@@ -183,7 +183,7 @@ elif scenario == "gkl":
                     Bm = f.rayleighquotient()
                     assert np.max(np.abs(U.T @ U - np.eye(U.shape[1]))) < 1e-12 and np.max(np.abs(V.T @ V - np.eye(V.shape[1]))) < 1e-12
                     assert np.max(np.abs(A.T @ U - V @ Bm.T)) < 1e-10
-        ctx.set_option("mgs_mode", 1)
+        ctx.set_option("mgs_mode", 2)
         xb, yb = kk.DeviceBasis(c1 - c0, 4, ctx), kk.DeviceBasis(r1 - r0, 4, ctx)
         xv = np.random.default_rng(9).standard_normal((nc, 3))
         for j in range(3):
@@ -262,7 +262,7 @@ elif scenario == "solvers":
         assert relerr(vals[:3], ovals[:3]) < 1e-10
         v0 = gather_rows(f"eigvec{mgs_mode}", np.asarray(vecs[0]))
         assert np.linalg.norm(A @ v0 - vals[0] * v0) < 1e-8
-    ctx.set_option("mgs_mode", 1)
+    ctx.set_option("mgs_mode", 2)
     Bm = ko.convection_diffusion_2d(nx, ny)
     b = np.random.default_rng(4).random(n) * np.linspace(0.1, 3.0, n)     # local norms differ a lot from rank to rank
     opB = kd.NativeShardedOperator(Bm[lo:hi], part, ctx)

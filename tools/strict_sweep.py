@@ -32,14 +32,15 @@ def sweep():
 
 ref = None
 for name, opts in [("lowsync", dict(mgs_mode=1, spmv_dia=1, spmv_dia_pairs=1)),
-                   ("lowsync, diagonal SpMV with 2 row pairs per lane", dict(mgs_mode=1, spmv_dia_pairs=2)),
-                   ("lowsync, ELL gather SpMV", dict(mgs_mode=1, spmv_dia=0)),
-                   ("lowsync again", dict(mgs_mode=1, spmv_dia=1, spmv_dia_pairs=1)),
-                   ("strict step kernel", dict(mgs_mode=0, mgs_persist=0)),
-                   ("strict persistent 1024 nt", dict(mgs_mode=0, mgs_persist=1, persist_threads=1024, persist_nt=1)),
-                   ("strict persistent 1024 plain", dict(mgs_mode=0, mgs_persist=1, persist_threads=1024, persist_nt=0)),
-                   ("strict persistent 512 nt", dict(mgs_mode=0, mgs_persist=1, persist_threads=512, persist_nt=1)),
-                   ("strict persistent 512 plain", dict(mgs_mode=0, mgs_persist=1, persist_threads=512, persist_nt=0))]:
+                   ("strict persistent 1024 nt, no LDS parking", dict(mgs_mode=0, mgs_persist=1, persist_threads=1024, persist_nt=1, persist_lds=0)),
+                   ("strict persistent 512 nt, no LDS parking", dict(mgs_mode=0, mgs_persist=1, persist_threads=512, persist_nt=1, persist_lds=0)),
+                   ("strict persistent 512 plain, no LDS parking", dict(mgs_mode=0, mgs_persist=1, persist_threads=512, persist_nt=0, persist_lds=0)),
+                   ("strict persistent 1024 nt, LDS parking (9 of 20 grid-rows)", dict(mgs_mode=0, mgs_persist=1, persist_threads=1024, persist_nt=1, persist_lds=1)),
+                   ("strict persistent 512 nt, LDS parking (19 of 39 grid-rows)", dict(mgs_mode=0, mgs_persist=1, persist_threads=512, persist_nt=1, persist_lds=1)),
+                   ("strict persistent 512 plain, LDS parking", dict(mgs_mode=0, mgs_persist=1, persist_threads=512, persist_nt=0, persist_lds=1)),
+                   ("strict persistent 512 nt, LDS (19) + register (8) parking of 39 grid-rows", dict(mgs_mode=0, mgs_persist=1, persist_threads=512, persist_nt=1, persist_lds=2)),
+                   ("strict persistent 512 plain, LDS + register parking", dict(mgs_mode=0, mgs_persist=1, persist_threads=512, persist_nt=0, persist_lds=2)),
+                   ("lowsync again", dict(mgs_mode=1))]:
     for k, v in opts.items():
         ctx.set_option(k, v)
     try:
