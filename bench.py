@@ -473,7 +473,7 @@ def main():
     if args.config == "lanczos" and not os.environ.get("KK_BENCH_NOPROF"):
         d_, _ = timed(sweep, K)
         unbracketed = {"value": round(units_per_sweep * K / d_, 3), "ms_per_step": round(d_ / K * 1e3, 3),
-                       "note": "same K sweeps, no HIP events recorded (the headline region brackets every k_project / k_unproject launch)"}
+                       "note": "same K sweeps, no HIP events recorded (the headline region brackets every launch of the basis-streaming kernels)"}
 
     # ---------------- the other scaling mode of config 2 as a secondary leg (N > 1)
     other_leg = None
