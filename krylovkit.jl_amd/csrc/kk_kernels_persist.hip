@@ -46,7 +46,7 @@ __device__ __forceinline__ double block_sum_w(double v, double* sm /* >= NW doub
 // step s+2 before the slow one has published s+1, i.e. has finished that sweep.  Returns false on a timeout.
 template <int PT>
 __device__ __forceinline__ bool grid_sum(double acc, int step, gu64* __restrict__ gran, int* __restrict__ err, double* sm,
-                                         double* out) {
+                                         double* out, int relay) {
     const int G = gridDim.x;
     const double v = block_sum_w<PT / 64>(acc, sm);
     const unsigned epoch = (unsigned)step + 1u;
@@ -55,6 +55,36 @@ __device__ __forceinline__ bool grid_sum(double acc, int step, gu64* __restrict_
         const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
         __hip_atomic_store(g + 2 * blockIdx.x, ((unsigned long long)epoch << 32) | (bits >> 32), RLX_AGENT);
         __hip_atomic_store(g + 2 * blockIdx.x + 1, ((unsigned long long)epoch << 32) | (bits & 0xffffffffull), RLX_AGENT);
+    }
+    if (relay && blockIdx.x != 0) {
+        // relay form (option "persist_sync" = 1): only block 0 sweeps the 2G partial granules; it publishes the total as one
+        // tagged pair behind them and every other block polls just that pair -- two fabric hops instead of one, but 2 loads
+        // per poll and block instead of 2G.  Same bits either way: the one summation order is block 0's.
+        gu64* tg = gran + (size_t)4 * G + (size_t)(step & 1) * 2;
+        if (threadIdx.x == 0) {
+            const long long t0 = wall_clock64();
+            double total = 0;
+            int good = 1;
+            for (;;) {
+                const unsigned long long hi = __hip_atomic_load(tg, RLX_AGENT);
+                const unsigned long long lo = __hip_atomic_load(tg + 1, RLX_AGENT);
+                if ((unsigned)(hi >> 32) == epoch && (unsigned)(lo >> 32) == epoch) {
+                    total = __longlong_as_double((long long)(((hi & 0xffffffffull) << 32) | (lo & 0xffffffffull)));
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+                if (wall_clock64() - t0 > KK_PERSIST_TIMEOUT_TICKS || __hip_atomic_load(err, RLX_AGENT)) { good = 0; break; }
+            }
+            if (!good) __hip_atomic_store(err, 1, RLX_AGENT);
+            sm[0] = total;
+            sm[1] = good ? 1.0 : 0.0;
+        }
+        __syncthreads();
+        const double total = sm[0];
+        const bool good = sm[1] != 0.0;
+        __syncthreads();
+        *out = total;
+        return good;
     }
     if (threadIdx.x < 64) {   // wave 0 sweeps
         const int lane = threadIdx.x;
@@ -76,6 +106,12 @@ __device__ __forceinline__ bool grid_sum(double acc, int step, gu64* __restrict_
         }
         if (lane == 0) {
             if (!good) __hip_atomic_store(err, 1, RLX_AGENT);
+            if (relay && good) {   // block 0 hands the total to everybody else
+                gu64* tg = gran + (size_t)4 * G + (size_t)(step & 1) * 2;
+                const unsigned long long bits = (unsigned long long)__double_as_longlong(total);
+                __hip_atomic_store(tg, ((unsigned long long)epoch << 32) | (bits >> 32), RLX_AGENT);
+                __hip_atomic_store(tg + 1, ((unsigned long long)epoch << 32) | (bits & 0xffffffffull), RLX_AGENT);
+            }
             sm[0] = total;
             sm[1] = good ? 1.0 : 0.0;
         }
@@ -174,14 +210,17 @@ __global__ __launch_bounds__(PT) void k_mgs_persist(const double* __restrict__ V
                                                     double* __restrict__ w, const double* __restrict__ carry_q,
                                                     const double* __restrict__ carry_s, double* __restrict__ out_s,
                                                     int out_stride, double* __restrict__ nrm_out3,
-                                                    gu64* __restrict__ gran, int* __restrict__ err, int fault) {
+                                                    gu64* __restrict__ gran, int* __restrict__ err, int fault, int relay) {
     __shared__ double sm[PT / 64];
     extern __shared__ d2 park[];   // NL * PT double2 (dynamic): the parked grid-rows of the current basis vector
     if (fault && blockIdx.x == 0) {   // test hook (option "persist_fault"): block 0 behaves like a block whose spin ran out
         if (threadIdx.x == 0) __hip_atomic_store(err, 1, RLX_AGENT);
         return;
     }
-    constexpr int B = (PT == 1024 && NV > 16) ? 2 : 4;   // loads in flight per stream and lane; 128-register budget at 1024 threads
+#ifndef KK_PERSIST_B512
+#define KK_PERSIST_B512 4
+#endif
+    constexpr int B = (PT == 1024 && NV > 16) ? 2 : (PT == 512 ? KK_PERSIST_B512 : 4);   // loads in flight per stream and lane; 128-register budget at 1024 threads
     const unsigned sbytes = gridDim.x * PT * 16u;                      // one grid-row in bytes
     const unsigned voff = (blockIdx.x * PT + threadIdx.x) * 16u;       // this lane's byte offset inside a grid-row
     d2* lq = park + threadIdx.x;
@@ -204,7 +243,7 @@ __global__ __launch_bounds__(PT) void k_mgs_persist(const double* __restrict__ V
         const double* qn = V + (int64_t)(s % m) * ld;
         double a0 = 0, a1 = 0, total;
         persist_step<NV, NL, NR, PT, B, NTPREV, false, true>(wr, qk, col_rsrc(qp, ld), col_rsrc(qn, ld), sp, sbytes, voff, lq, a0, a1);
-        if (!grid_sum<PT>(a0 + a1, s, gran, err, sm, &total)) return;   // timeout: w in HBM is untouched
+        if (!grid_sum<PT>(a0 + a1, s, gran, err, sm, &total, relay)) return;   // timeout: w in HBM is untouched
         if (blockIdx.x == 0 && threadIdx.x == 0) out_s[(s / m) * out_stride + (s % m)] = total;
         sp = total;
         qp = qn;
@@ -213,7 +252,7 @@ __global__ __launch_bounds__(PT) void k_mgs_persist(const double* __restrict__ V
         double a0 = 0, a1 = 0, total;
         persist_step<NV, NL, NR, PT, B, NTPREV, true, true>(wr, qk, col_rsrc(qp, ld), col_rsrc(qp, ld), sp, sbytes, voff, lq, a0, a1);
         if (nrm_out3) {
-            if (!grid_sum<PT>(a0 + a1, nsteps, gran, err, sm, &total)) return;
+            if (!grid_sum<PT>(a0 + a1, nsteps, gran, err, sm, &total, relay)) return;
             if (blockIdx.x == 0 && threadIdx.x == 0) {
                 const double rt = sqrt(total);
                 nrm_out3[0] = total; nrm_out3[1] = rt; nrm_out3[2] = 1.0 / rt;
@@ -264,9 +303,12 @@ static int launch_persist_inst(kk_ctx ctx, void** args) {
 #ifndef KK_PERSIST_NR
 #define KK_PERSIST_NR 8
 #endif
+
 template <int NV, int PT>
 static int launch_persist(kk_ctx ctx, void** args, bool ntprev) {
     constexpr int NL = persist_park<NV, PT>::n;
+    // (256-thread blocks -- one wave per SIMD with the whole 512-register file -- were tried: w then takes 320 registers per
+    // lane and 39 + 12 of 77 grid-rows can be parked, no more than the 27 of 39 here: the on-chip capacity is what it is)
     constexpr int NR = (PT == 512 && NV - NL > 0) ? (NV - NL < KK_PERSIST_NR ? NV - NL : KK_PERSIST_NR) : 0;
     if (ctx->persist_lds == 2) return ntprev ? launch_persist_inst<NV, NL, NR, PT, true>(ctx, args) : launch_persist_inst<NV, NL, NR, PT, false>(ctx, args);
     if (ctx->persist_lds) return ntprev ? launch_persist_inst<NV, NL, 0, PT, true>(ctx, args) : launch_persist_inst<NV, NL, 0, PT, false>(ctx, args);
@@ -280,11 +322,12 @@ int kk_launch_mgs_persist(kk_ctx ctx, const double* V, int64_t ld, int m, int ns
     // granules: 2 sets x 2 per block, zeroed (tag 0 = never a valid epoch) before every launch, followed by the error flag
     unsigned long long* gran = (unsigned long long*)ctx->d_sync;
     int* err = (int*)((char*)ctx->d_sync + KK_SYNC_ERR_OFFSET);
-    KK_HIP(hipMemsetAsync(gran, 0, (size_t)4 * ctx->num_cus * sizeof(unsigned long long), ctx->stream));
+    KK_HIP(hipMemsetAsync(gran, 0, ((size_t)4 * ctx->num_cus + 8) * sizeof(unsigned long long), ctx->stream));
     int fault = 0;
     if (ctx->persist_fault > 0) { --ctx->persist_fault; fault = 1; }
+    int relay = ctx->persist_sync;
     void* args[] = {(void*)&V, (void*)&ld, (void*)&m, (void*)&nsweeps, (void*)&w, (void*)&carry_q, (void*)&carry_s,
-                    (void*)&out_s, (void*)&out_stride, (void*)&nrm_out3, (void*)&gran, (void*)&err, (void*)&fault};
+                    (void*)&out_s, (void*)&out_stride, (void*)&nrm_out3, (void*)&gran, (void*)&err, (void*)&fault, (void*)&relay};
     const bool nt = ctx->persist_nt != 0;
     kk_prof_scope ps(ctx, "k_mgs_persist");
     if (pt == 1024) {

@@ -40,7 +40,8 @@ for name, opts in [("lowsync", dict(mgs_mode=1, spmv_dia=1, spmv_dia_pairs=1)),
                    ("strict persistent 512 plain, LDS parking", dict(mgs_mode=0, mgs_persist=1, persist_threads=512, persist_nt=0, persist_lds=1)),
                    ("strict persistent 512 nt, LDS (19) + register (8) parking of 39 grid-rows", dict(mgs_mode=0, mgs_persist=1, persist_threads=512, persist_nt=1, persist_lds=2)),
                    ("strict persistent 512 plain, LDS + register parking", dict(mgs_mode=0, mgs_persist=1, persist_threads=512, persist_nt=0, persist_lds=2)),
-                   ("lowsync again", dict(mgs_mode=1))]:
+                   ("strict persistent 512 nt, LDS + register parking, relayed grid reduction", dict(mgs_mode=0, mgs_persist=1, persist_threads=512, persist_nt=1, persist_lds=2, persist_sync=1)),
+                   ("lowsync again", dict(mgs_mode=1, persist_sync=0))]:
     for k, v in opts.items():
         ctx.set_option(k, v)
     try:
