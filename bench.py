@@ -431,7 +431,7 @@ def main():
             breakdown[name] = round(ms, 3)
     # timed region: K sweeps; only the basis-streaming kernels (the dominant ones) carry HIP events
     ctx.prof_reset()
-    ctx.prof_enable(0 if os.environ.get("KK_BENCH_NOPROF") else 2)
+    ctx.prof_enable(0 if os.environ.get("KK_BENCH_NOPROF") else (1 if args.config == "block" else 2))   # block step: ms-scale kernels, every class
     stats0 = comm.stats() if comm else None
     barrier(); sync()
     t0 = time.perf_counter()
@@ -573,6 +573,32 @@ def main():
             roofline = {"kernel": dom, "bound": "hbm", "achieved": round(32.0 * n_local / (ms / n * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS,
                         "unit": "GB/s", "frac": round(32.0 * n_local / (ms / n * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "traffic": None,
                         "launches": int(n), "avg_launch_ms": round(ms / n, 5), "algorithmic_bytes_per_launch": 32 * n_local,
+                        "one_sweep_kernel_ms_breakdown": breakdown}
+
+    if args.config == "block":
+        # dominant kernel of the block step: k_block_update_lds, W <- W - V P with the whole basis (kn = 32 .. 112 columns after
+        # the push) streamed once and the 16-column residual block read and written: (8 kn + 256) N algorithmic bytes per launch;
+        # the sweep adds one 16 -> 16 column launch in initialize (256 N); launches skipped on the device (second CholQR2
+        # back-substitution, a few microseconds each) are in the launch count but carry no bytes
+        ms, n = ctx.prof_get("k_block_update")
+        if n:
+            per_sweep = (sum(8 * kn + 256 for kn in range(2 * bs, Kb + bs + 1, bs)) + 256) * float(n_local)
+            achieved = per_sweep * K / (ms * 1e-3) / 1e9
+            tfile = ROOT / "profiles" / "traffic_block.json"
+            traffic, traffic_note = None, None
+            if tfile.exists():
+                try:
+                    tj = json.loads(tfile.read_text())
+                    traffic = tj.get("k_block_update_bytes_per_sweep")
+                    traffic_note = tj.get("_comment")
+                except Exception:
+                    pass
+            roofline = {"kernel": "k_block_update_lds", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                        "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_note": traffic_note,
+                        "launches": int(n), "class_ms_per_sweep": round(ms / K, 3), "algorithmic_bytes_per_sweep": round(per_sweep),
+                        "per_block_step_ms": round(elapsed / K / sweep_its * 1e3, 3),
+                        "timed_region_kernel_ms": {k: round(ctx.prof_get(k)[0], 3) for k in ("k_block_update", "k_block_gram", "k_spmm_dia", "k_spmm_ell")
+                                                   if ctx.prof_get(k)[1]},
                         "one_sweep_kernel_ms_breakdown": breakdown}
 
     # ---------------- secondary leg: the OTHER execution order of MGS2 on the same workload (the headline ran the library default)

@@ -311,7 +311,6 @@ for O in (:ClassicalGramSchmidt, :ModifiedGramSchmidt, :ClassicalGramSchmidt2, :
 end
 function device_orthogonalize!!(w::HipVec, b::OrthonormalBasis{HipVec}, x::AbstractVector, alg::KrylovKit.Orthogonalizer)
     slab, c0, m = slab_range(b)
-    m <= KK_MAX_M || error("KrylovKitHIP: orthogonalize!! against more than $KK_MAX_M vectors")
     code, η = orthcode(alg)
     xs = Vector{Float64}(undef, m)
     chk(ccall((:kk_orthogonalize, lib), Cint,

@@ -137,7 +137,7 @@ int final_sync(kk_ctx c) {
 KK_API int kk_lanczos_expand(kk_op op, kk_basis b, int c0, int k, kk_orth_t orth, double eta, double beta_old,
                                  double* alpha, double* beta, int* npasses) {
     KK_TRY(check_square_op(op, b));
-    KK_CHECK(k >= 1 && c0 >= 0 && c0 + k + 2 <= b->cap && k + 1 <= KK_MAX_M, KK_ERR_INVALID,
+    KK_CHECK(k >= 1 && c0 >= 0 && c0 + k + 2 <= b->cap, KK_ERR_INVALID,
              "kk_lanczos_expand: need k >= 1 and columns %d..%d within capacity %d", c0, c0 + k + 1, b->cap);
     KK_CHECK(alpha && beta, KK_ERR_INVALID, "null output");
     KK_CHECK(beta_old != 0.0, KK_ERR_ZERO_NORM, "kk_lanczos_expand: residual norm is zero");
@@ -149,11 +149,12 @@ KK_API int kk_lanczos_expand(kk_op op, kk_basis b, int c0, int k, kk_orth_t orth
     const double* vprev = b->col(c0 + k - 1);
     double* w = b->col(c0 + k + 1);
     const bool cgs_order = (orth == KK_CGS || orth == KK_CGS2 || orth == KK_CGSIR);
-    const bool lowsync = kk_mgs_lowsync(c, ld, m);
+    const bool wide = m > KK_MAX_M;   // more basis vectors than one panel: base recurrence + whole passes through orth_run (panel by panel)
+    const bool lowsync = !wide && kk_mgs_lowsync(c, ld, m);
     // Row-sharded run, projection-based orthogonaliser: the alpha0 partial of the SpMV and the two projection panels
     // stay LOCAL, land side by side in ws[WS_SHBUF ..] = [alpha0 | V'w | V'v] and are summed by ONE all-reduce; the
     // second (and last) one is |w|^2.  SURVEY.md 8(e).
-    const bool sh_fused = kk_sharded(c) && (orth == KK_CGS2 || (orth == KK_MGS2 && lowsync && c0 == 0));
+    const bool sh_fused = !wide && kk_sharded(c) && (orth == KK_CGS2 || (orth == KK_MGS2 && lowsync && c0 == 0));
     double* a0_slot = sh_fused ? WSP(c, WS_SHBUF) : SCP(c, SC_ALPHA0);
     bool hit = false;
     KK_TRY(spec_take(op, b, c0, k, cgs_order ? 1 : 2, beta_old, a0_slot, &hit));
@@ -175,7 +176,7 @@ KK_API int kk_lanczos_expand(kk_op op, kk_basis b, int c0, int k, kk_orth_t orth
     }  // else: the previous expand already enqueued exactly this SpMV (speculate_next)
     const double* a0_dev = c->ws + WS_SCAL + SC_ALPHA0;
     double a = 0, bt = 0;
-    if (orth == KK_CGS || orth == KK_MGS || orth == KK_CGSIR || orth == KK_MGSIR) {
+    if (orth == KK_CGS || orth == KK_MGS || orth == KK_CGSIR || orth == KK_MGSIR || wide) {
         // w -= alpha v ; beta = |w|
         KK_TRY(kk_launch_mgs_step(c, w, ld, v, a0_dev, nullptr, nullptr, SCP(c, SC_NRM2)));
         KK_TRY(ws_fetch_async(c, WS_SCAL, 4, 0));
@@ -195,6 +196,14 @@ KK_API int kk_lanczos_expand(kk_op op, kk_basis b, int c0, int k, kk_orth_t orth
                 bt = nn;
                 ++passes;
             }
+        } else if (orth == KK_CGS2 || orth == KK_MGS2) {   // wide: the one unconditional re-orthogonalisation pass of :320-322 / :331-336
+            std::vector<double> s(m);
+            double nn = 0;
+            int p1 = 0;
+            KK_TRY(orth_run(b, c0, m, w, orth == KK_CGS2 ? KK_CGS : KK_MGS, eta, s.data(), &nn, &p1, true));
+            a += s[m - 1];
+            bt = nn;
+            passes = 1;
         }
     } else if (sh_fused) {
         double* buf = WSP(c, WS_SHBUF);
@@ -292,7 +301,7 @@ KK_API int kk_lanczos_expand(kk_op op, kk_basis b, int c0, int k, kk_orth_t orth
 KK_API int kk_arnoldi_expand(kk_op op, kk_basis b, int c0, int k, kk_orth_t orth, double eta, double beta_old,
                                  double* h, double* beta, int* npasses) {
     KK_TRY(check_square_op(op, b));
-    KK_CHECK(k >= 1 && c0 >= 0 && c0 + k + 2 <= b->cap && k + 1 <= KK_MAX_M, KK_ERR_INVALID,
+    KK_CHECK(k >= 1 && c0 >= 0 && c0 + k + 2 <= b->cap, KK_ERR_INVALID,
              "kk_arnoldi_expand: need k >= 1 and columns %d..%d within capacity %d", c0, c0 + k + 1, b->cap);
     KK_CHECK(h && beta, KK_ERR_INVALID, "null output");
     KK_CHECK(beta_old != 0.0, KK_ERR_ZERO_NORM, "kk_arnoldi_expand: residual norm is zero");
@@ -409,7 +418,7 @@ KK_API int kk_gkl_initialize(kk_op op, kk_basis bu, kk_basis bv, double* alpha, 
 KK_API int kk_gkl_expand(kk_op op, kk_basis bu, kk_basis bv, int k, kk_orth_t orth, double eta, double beta_old,
                              double* alpha, double* beta, int* npasses_v, int* npasses_u) {
     KK_TRY(check_gkl(op, bu, bv));
-    KK_CHECK(k >= 1 && k + 2 <= bu->cap && k + 1 <= bv->cap && k + 1 <= KK_MAX_M, KK_ERR_INVALID,
+    KK_CHECK(k >= 1 && k + 2 <= bu->cap && k + 1 <= bv->cap, KK_ERR_INVALID,
              "kk_gkl_expand: k=%d does not fit capacities %d / %d", k, bu->cap, bv->cap);
     KK_CHECK(alpha && beta, KK_ERR_INVALID, "null output");
     KK_CHECK(beta_old != 0.0, KK_ERR_ZERO_NORM, "kk_gkl_expand: residual norm is zero");

@@ -316,6 +316,82 @@ static int pass_mgs_lowsync(kk_basis b, int c0, int m, double* w, double* s_out,
 
 // orthogonalize!!(w, b[c0:c0+m), x, alg) -- all six algorithms (orthonormal.jl:378-452).
 // On return x[0..m) holds the accumulated coefficients; *nrm = |w| if want_norm.
+// orthogonalize!! against MORE than KK_MAX_M basis vectors (the reference knows no limit: krylovdim = 300 is legal): the
+// kernels take panels of <= KK_MAX_M columns, so a classical pass is projected panel by panel (the same inner products) and
+// subtracted panel by panel, a modified sweep runs the strict order through the panels one after the other.  One host
+// synchronisation per panel -- this is the rarely used wide route, not the tuned one.
+static int orth_run_wide(kk_basis b, int c0, int m, double* w, kk_orth_t alg, double eta, double* x, double* nrm, int* npasses,
+                         bool want_norm) {
+    kk_ctx c = b->ctx;
+    const int64_t ld = b->ld;
+    const bool classical = (alg == KK_CGS || alg == KK_CGS2 || alg == KK_CGSIR);
+    const bool ir = (alg == KK_CGSIR || alg == KK_MGSIR);
+    double nn = 0;
+    auto one_pass = [&](double* s, bool norm) -> int {   // s[0..m) = coefficients of ONE pass over all panels; nn = |w| if norm
+        if (classical) {
+            for (int j0 = 0; j0 < m; j0 += KK_MAX_M) {
+                const int mm = std::min(KK_MAX_M, m - j0);
+                KK_TRY(kk_launch_project(c, b->col(c0 + j0), ld, mm, w, nullptr, nullptr, nullptr, WSP(c, WS_S), WSP(c, WS_G)));
+                KK_TRY(ws_fetch_async(c, WS_S, mm, 0));
+                KK_TRY(stream_sync(c));
+                memcpy(s + j0, pin(c, WS_S, 0), mm * sizeof(double));
+            }
+            for (int j0 = 0; j0 < m; j0 += KK_MAX_M) {
+                const int mm = std::min(KK_MAX_M, m - j0);
+                kk_coef ch;
+                memset(&ch, 0, sizeof(ch));
+                memcpy(ch.v, s + j0, mm * sizeof(double));
+                const bool last = j0 + mm >= m;
+                KK_TRY(kk_launch_unproject(c, b->col(c0 + j0), ld, mm, w, w, &ch, nullptr, -1.0, 1.0, -1, nullptr,
+                                           (last && norm) ? SCP(c, SC_NRM2) : nullptr));
+            }
+            if (norm) {
+                KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2, 2, 0));
+                KK_TRY(stream_sync(c));
+                nn = pin(c, WS_SCAL + SC_NRM2, 0)[1];
+            }
+        } else {
+            for (int j0 = 0; j0 < m; j0 += KK_MAX_M) {
+                const int mm = std::min(KK_MAX_M, m - j0);
+                const bool last = j0 + mm >= m;
+                const int64_t offs[1] = {WS_S};
+                KK_TRY(strict_sweeps_synced(c, b->col(c0 + j0), ld, mm, 1, w, offs, last && norm, 0, false));
+                memcpy(s + j0, pin(c, WS_S, 0), mm * sizeof(double));
+                if (last && norm) nn = pin(c, WS_SCAL + SC_NRM2, 0)[1];
+            }
+        }
+        return KK_OK;
+    };
+    std::vector<double> tmp(m);
+    int passes = 0;
+    if (!ir) {
+        const bool two = (alg == KK_CGS2 || alg == KK_MGS2);
+        KK_TRY(one_pass(x, want_norm && !two));
+        passes = 1;
+        if (two) {
+            KK_TRY(one_pass(tmp.data(), want_norm));
+            for (int j = 0; j < m; ++j) x[j] += tmp[j];
+            passes = 2;
+        }
+    } else {   // orthonormal.jl:400-412 / :440-452
+        KK_TRY(kk_launch_nrm2(c, w, ld, SCP(c, SC_NRM2B)));
+        KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2B, 2, 1));
+        KK_TRY(stream_sync(c));
+        double nold = pin(c, WS_SCAL + SC_NRM2B, 1)[1];
+        KK_TRY(one_pass(x, true));
+        passes = 1;
+        while (KK_EPS < nn && nn < eta * nold) {
+            nold = nn;
+            KK_TRY(one_pass(tmp.data(), true));
+            for (int j = 0; j < m; ++j) x[j] += tmp[j];
+            ++passes;
+        }
+    }
+    if (nrm) *nrm = nn;
+    if (npasses) *npasses = passes;
+    return KK_OK;
+}
+
 int orth_run(kk_basis b, int c0, int m, double* w, kk_orth_t alg, double eta, double* x, double* nrm,
                     int* npasses, bool want_norm) {
     kk_ctx c = b->ctx;
@@ -323,6 +399,7 @@ int orth_run(kk_basis b, int c0, int m, double* w, kk_orth_t alg, double eta, do
     const int64_t ld = b->ld;
     int passes = 0;
     double nn = 0;
+    if (m > KK_MAX_M) return orth_run_wide(b, c0, m, w, alg, eta, x, nrm, npasses, want_norm);
     if (m == 0) {
         if (want_norm || alg == KK_CGSIR || alg == KK_MGSIR) {
             KK_TRY(kk_launch_nrm2(c, w, ld, SCP(c, SC_NRM2)));
@@ -470,7 +547,7 @@ int orth_run(kk_basis b, int c0, int m, double* w, kk_orth_t alg, double eta, do
 
 KK_API int kk_orthogonalize(kk_basis b, int c0, int m, kk_basis bw, int cw, kk_orth_t alg, double eta, double* x,
                                 double* nrm, int* npasses) {
-    CHECK_RANGE(b, c0, m); CHECK_COL(bw, cw); CHECK_SAME(b, bw);
+    CHECK_BLOCK(b, c0, m); CHECK_COL(bw, cw); CHECK_SAME(b, bw);   // any m: more than KK_MAX_M vectors go panel by panel
     KK_CHECK(x || m == 0, KK_ERR_INVALID, "null x");
     KK_CHECK(!(bw == b && cw >= c0 && cw < c0 + m), KK_ERR_INVALID, "kk_orthogonalize: w aliases a basis column");
     gram_touch(bw, cw);
@@ -479,7 +556,7 @@ KK_API int kk_orthogonalize(kk_basis b, int c0, int m, kk_basis bw, int cw, kk_o
 
 KK_API int kk_orthonormalize(kk_basis b, int c0, int m, kk_basis bw, int cw, kk_orth_t alg, double eta, double* x,
                                  double* nrm, int* npasses) {
-    CHECK_RANGE(b, c0, m); CHECK_COL(bw, cw); CHECK_SAME(b, bw);
+    CHECK_BLOCK(b, c0, m); CHECK_COL(bw, cw); CHECK_SAME(b, bw);
     KK_CHECK(x || m == 0, KK_ERR_INVALID, "null x");
     KK_CHECK(!(bw == b && cw >= c0 && cw < c0 + m), KK_ERR_INVALID, "kk_orthonormalize: w aliases a basis column");
     gram_touch(bw, cw);

@@ -152,10 +152,9 @@ class LanczosIterator:  # lanczos.jl:129-153
 
 
 def _check_capacity(capacity: int, keepvecs: bool = True):
-    """The fused expand! entry points address at most KK_MAX_M basis vectors (a library limit the reference does not have):
-    say so when the iterator is built, not halfway through a factorization."""
-    if keepvecs and capacity > _lib.KK_MAX_M + 1:
-        raise ValueError(f"krylovdim {capacity - 2} exceeds the {_lib.KK_MAX_M - 1} basis vectors a fused expand! can address")
+    """No limit, as in the reference: beyond KK_MAX_M basis vectors the library's expand! entry points orthogonalise panel
+    by panel (csrc/kk_orth.hip::orth_run_wide) instead of through the single-panel fused kernels."""
+    return None
 
 
 def initialize(it, V: Optional[DeviceBasis] = None):

@@ -1,0 +1,92 @@
+"""More basis vectors than one kernel panel (KK_MAX_M = 256): the reference has no limit on krylovdim, so every
+`orthogonalize!!` / `expand!` entry point goes panel by panel beyond it (csrc/kk_orth.hip::orth_run_wide) and must keep
+matching the oracle -- src/orthonormal.jl:378-452, src/factorizations/{lanczos,arnoldi,gkl}.jl."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def relerr(a, b):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300)))
+
+
+def pairs(kk, ko):
+    return [(kk.ClassicalGramSchmidt(), ko.CGS), (kk.ModifiedGramSchmidt(), ko.MGS), (kk.ClassicalGramSchmidt2(), ko.CGS2),
+            (kk.ModifiedGramSchmidt2(), ko.MGS2), (kk.ClassicalGramSchmidtIR(0.99), ko.CGSIR(0.99)),
+            (kk.ModifiedGramSchmidtIR(0.99), ko.MGSIR(0.99))]
+
+
+@pytest.mark.parametrize("mgs_mode", [0, 1])
+def test_orthogonalize_against_300_vectors(kk, ko, ctx, mgs_mode):
+    ctx.set_option("mgs_mode", mgs_mode)
+    rng = np.random.default_rng(7)
+    n, m = 2500, 300
+    Q, _ = np.linalg.qr(rng.standard_normal((n, m)))
+    B = kk.DeviceBasis(n, m + 2, ctx)
+    for j in range(m):
+        B.upload(j, Q[:, j])
+    B.length = m
+    w = rng.standard_normal(n)
+    for dev, ref in pairs(kk, ko):
+        x, nrm, npass = B.orthogonalize(B[m].set(w), dev)
+        wo, xo = ko.orthogonalize(w.copy(), [Q[:, j].copy() for j in range(m)], ref)
+        np.testing.assert_allclose(x, xo, rtol=0, atol=1e-12 * np.linalg.norm(w), err_msg=dev.name)
+        np.testing.assert_allclose(B[m].get(), wo, rtol=0, atol=1e-12 * np.linalg.norm(w), err_msg=dev.name)
+        assert abs(nrm - np.linalg.norm(wo)) < 1e-12 * np.linalg.norm(w)
+    ctx.set_option("mgs_mode", 2)
+
+
+def test_lanczos_krylovdim_300(kk, ko, ctx):
+    """factorizations/lanczos.jl:250-376 with the basis growing to 300 vectors: fused expand below the panel limit, the
+    panel-by-panel route above it, one continuous (alpha, beta) trajectory"""
+    nx, ny, steps = 60, 50, 299
+    n = nx * ny
+    A = ko.laplacian_2d(nx, ny, shift_diag=10 * np.linspace(0, 1, n) ** 2)
+    x0 = np.random.default_rng(3).random(n)
+    op = kk.SparseOperator(A, ctx, symmetric=True)
+    for dev, ref in pairs(kk, ko)[2:]:
+        it = kk.LanczosIterator(op, x0, dev, capacity=steps + 3)
+        f = kk.initialize(it)
+        oit = ko.LanczosIterator(A, x0.copy(), ref)
+        of = ko.lanczos_initialize(oit)
+        for _ in range(steps):
+            f = kk.expand_(it, f)
+            of = ko.lanczos_expand(oit, of)
+        assert len(f) == 300
+        assert relerr(f.alphas, of.alphas) < 1e-9 and relerr(f.betas, of.betas) < 1e-9, dev.name
+        V = f.V.to_numpy()
+        assert np.max(np.abs(V.T @ V - np.eye(300))) < 1e-11, dev.name
+        T = np.diag(f.alphas) + np.diag(f.betas[:-1], 1) + np.diag(f.betas[:-1], -1)
+        ek = np.zeros(300); ek[-1] = 1
+        assert np.max(np.abs(A @ V - V @ T - np.outer(f.r.get(), ek))) < 1e-10, dev.name
+
+
+def test_arnoldi_and_gkl_beyond_the_panel_limit(kk, ko, ctx):
+    A = ko.convection_diffusion_2d(45, 40)
+    n = A.shape[0]
+    x0 = np.random.default_rng(4).random(n)
+    steps = 270
+    it = kk.ArnoldiIterator(kk.SparseOperator(A, ctx), x0, kk.ModifiedGramSchmidt2(), capacity=steps + 3)
+    f = kk.initialize(it)
+    for _ in range(steps):
+        f = kk.expand_(it, f)
+    k = len(f)
+    V, r, H = f.V.to_numpy(), f.r.get(), f.rayleighquotient()
+    ek = np.zeros(k); ek[-1] = 1
+    assert k == steps + 1 and np.max(np.abs(V.T @ V - np.eye(k))) < 1e-11
+    assert np.max(np.abs(A @ V - V @ H - np.outer(r, ek))) < 1e-10
+    # GKL: 260 steps on a rectangular map, CGS2 (r against U) and MGS2 (both bases)
+    Ar = ko.sparse_random(900, 700, 9, 3)
+    u0 = np.random.default_rng(6).random(900)
+    for dev in (kk.ClassicalGramSchmidt2(), kk.ModifiedGramSchmidt2()):
+        git = kk.GKLIterator(kk.SparseOperator(Ar, ctx), u0, dev, capacity=265)
+        gf = kk.initialize(git)
+        for _ in range(260):
+            gf = kk.expand_(git, gf)
+        U, Vv, B = gf.U.to_numpy(), gf.V.to_numpy(), gf.rayleighquotient()
+        kq = len(gf)
+        assert np.max(np.abs(U.T @ U - np.eye(kq))) < 1e-11, dev.name
+        ekq = np.zeros(kq); ekq[-1] = 1
+        assert np.max(np.abs(Ar @ Vv - U @ B - np.outer(gf.r.get(), ekq))) < 1e-10, dev.name
