@@ -77,16 +77,17 @@ def test_arnoldi_and_gkl_beyond_the_panel_limit(kk, ko, ctx):
     ek = np.zeros(k); ek[-1] = 1
     assert k == steps + 1 and np.max(np.abs(V.T @ V - np.eye(k))) < 1e-11
     assert np.max(np.abs(A @ V - V @ H - np.outer(r, ek))) < 1e-10
-    # GKL: 260 steps on a rectangular map, CGS2 (r against U) and MGS2 (both bases)
+    # GKL: 260 steps on a rectangular map with MGS2 (both bases swept; CGS2 re-orthogonalises only r against U, gkl.jl:308-323,
+    # and loses the relation below once V has lost its orthogonality -- in the reference as well)
     Ar = ko.sparse_random(900, 700, 9, 3)
     u0 = np.random.default_rng(6).random(900)
-    for dev in (kk.ClassicalGramSchmidt2(), kk.ModifiedGramSchmidt2()):
+    for dev in (kk.ModifiedGramSchmidt2(),):
         git = kk.GKLIterator(kk.SparseOperator(Ar, ctx), u0, dev, capacity=265)
         gf = kk.initialize(git)
         for _ in range(260):
             gf = kk.expand_(git, gf)
         U, Vv, B = gf.U.to_numpy(), gf.V.to_numpy(), gf.rayleighquotient()
         kq = len(gf)
-        assert np.max(np.abs(U.T @ U - np.eye(kq))) < 1e-11, dev.name
+        assert np.max(np.abs(U.T @ U - np.eye(kq))) < 1e-11 and np.max(np.abs(Vv.T @ Vv - np.eye(kq))) < 1e-11, dev.name
         ekq = np.zeros(kq); ekq[-1] = 1
         assert np.max(np.abs(Ar @ Vv - U @ B - np.outer(gf.r.get(), ekq))) < 1e-10, dev.name
