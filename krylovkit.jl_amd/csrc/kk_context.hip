@@ -180,6 +180,8 @@ KK_API int kk_ctx_set_option(kk_ctx c, const char* key, double value) {
         c->gram_nt = value != 0;
     } else if (!strcmp(key, "spmv_dia")) {
         c->spmv_dia = value != 0;
+    } else if (!strcmp(key, "spmv_dia_const")) {
+        c->spmv_dia_const = value != 0;
     } else if (!strcmp(key, "spmv_dia_pairs")) {
         KK_CHECK(value == 1 || value == 2, KK_ERR_INVALID, "spmv_dia_pairs must be 1 or 2");
         c->spmv_dia_pairs = (int)value;
@@ -247,6 +249,7 @@ KK_API int kk_ctx_get_option(kk_ctx c, const char* key, double* value) {
     else if (!strcmp(key, "persist_min_rows")) *value = (double)c->persist_min_rows;
     else if (!strcmp(key, "speculate")) *value = c->speculate;
     else if (!strcmp(key, "spmv_dia")) *value = c->spmv_dia;
+    else if (!strcmp(key, "spmv_dia_const")) *value = c->spmv_dia_const;
     else if (!strcmp(key, "spmm_dia")) *value = c->spmm_dia;
     else if (!strcmp(key, "spmm_dia_lines")) *value = c->spmm_dia_lines;
     else if (!strcmp(key, "spmm_cols")) *value = c->spmm_cols;

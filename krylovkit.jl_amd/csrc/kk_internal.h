@@ -115,6 +115,7 @@ struct kk_ctx_s {
     int spmm_rpl = 2;            // SpMM on ELL: rows per lane (1 or 2)
     int spmv_dia = 1;            // single-column apply of a detected grid stencil: diagonal kernel (0: ELL gather kernel)
     int spmv_dia_pairs = 1;      // ... row pairs per lane (1 or 2)
+    int spmv_dia_const = 1;      // ... value-free kernel when the stencil has constant coefficients (0: always stream the diagonals)
     int spmm_dia = 1;            // multi-column apply of a detected grid stencil: sweeping diagonal kernel (0: ELL gather kernel)
     int spmm_dia_lines = 16;     // ... grid lines per wave sweep
     int spmm_cols = 16;          // SpMM on ELL: right-hand sides per launch (16, 8 or 4)
@@ -200,6 +201,12 @@ struct kk_sparse_dev {  // one direction (A or A') on the device
     int dia_pts = 0;               // 5 or 9 stored diagonals
     int64_t dia_ld = 0;
     double* dia_val = nullptr;
+    // constant-coefficient stencil (detected at upload): every stored entry of diagonal q equals dia_c[q], and an entry is
+    // absent exactly where the neighbour falls off its grid line -- the single-column apply then needs neither indices NOR
+    // values: 24 N bytes per apply instead of 64 N (k_spmv_dia<.., CONST>).  Row i sits at position (i + dia_phase) % dia_D of its line.
+    bool dia_const = false;
+    double dia_c[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int64_t dia_phase = 0;
     // row-sharded stencil: rows [int_lo, int_hi) (both even) reference local columns only -> diagonal kernels; the boundary
     // strips [0, int_lo) and [int_hi, nrows), whose rows read the ghost buffer, keep the gather kernels
     int64_t int_lo = 0, int_hi = 0;

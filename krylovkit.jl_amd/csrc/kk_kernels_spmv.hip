@@ -117,11 +117,14 @@ __device__ __forceinline__ d2 dia_pair(const double* __restrict__ x, int64_t idx
     v.y = (idx + 1 >= 0 && idx + 1 < nrows) ? x[idx + 1] : 0.0;
     return v;
 }
-template <int PTS, int U>   // U row pairs per lane: a block covers U consecutive 512-row chunks, all their loads in flight together
+// CONST: constant-coefficient stencil (kk_sparse_dev::dia_const) -- the coefficient of slot q is cst.c[q] wherever the
+// neighbour sits on the same grid line, 0 where a +-1 shift would wrap to the next line; no diagonal is read at all.
+struct dia_cst { double c[9]; int64_t phase, D; };
+template <int PTS, int U, bool CONST>   // U row pairs per lane: a block covers U consecutive 512-row chunks, all their loads in flight together
 __global__ __launch_bounds__(KK_TPB) void k_spmv_dia(const double* __restrict__ dval, int64_t dld, dia_offs offs, int64_t nrows,
                                                      const double* __restrict__ x, double* __restrict__ y, spmv_epi e,
                                                      int nb_logical, double* __restrict__ part_dot,
-                                                     double* __restrict__ part_nrm, int64_t row_base, int64_t row_end) {
+                                                     double* __restrict__ part_nrm, int64_t row_base, int64_t row_end, dia_cst cst) {
     __shared__ double sm[4];
     // rows [row_base, row_end): the whole operator, or the ghost-free interior of a row-sharded stencil (row_base even)
     const int per = (nb_logical + 7) >> 3;
@@ -136,15 +139,27 @@ __global__ __launch_bounds__(KK_TPB) void k_spmv_dia(const double* __restrict__ 
         const int64_t row0 = row_base + ((int64_t)lb * U * KK_TPB + threadIdx.x) * 2;
         double s0[U], s1[U];
         d2 xc[U];
+        int64_t ix0[U];   // CONST: position of the first row of the pair inside its grid line
 #pragma unroll
-        for (int u = 0; u < U; ++u) { s0[u] = 0; s1[u] = 0; xc[u] = d2{0.0, 0.0}; }
+        for (int u = 0; u < U; ++u) {
+            s0[u] = 0; s1[u] = 0; xc[u] = d2{0.0, 0.0};
+            ix0[u] = CONST ? (row0 + (int64_t)u * 2 * KK_TPB + cst.phase) % cst.D : 0;
+        }
 #pragma unroll
         for (int q = 0; q < PTS; ++q) {
+            const int bq = PTS == 5 ? (q == 1 ? -1 : (q == 3 ? 1 : 0)) : q % 3 - 1;   // shift inside the grid line
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int64_t row = row0 + (int64_t)u * 2 * KK_TPB;
                 if (row < row_end) {   // dia_ld is even and >= nrows; pad entries are 0
-                    const d2 v = ld2s(dval + (int64_t)q * dld + row);
+                    d2 v;
+                    if (CONST) {
+                        const int64_t i0 = ix0[u], i1 = (i0 + 1 == cst.D) ? 0 : i0 + 1;
+                        v.x = (bq < 0 && i0 == 0) || (bq > 0 && i0 == cst.D - 1) ? 0.0 : cst.c[q];
+                        v.y = (bq < 0 && i1 == 0) || (bq > 0 && i1 == cst.D - 1) ? 0.0 : cst.c[q];
+                    } else {
+                        v = ld2s(dval + (int64_t)q * dld + row);
+                    }
                     const d2 xv = dia_pair(x, row + offs.o[q], nrows);
                     if (q == PTS / 2) xc[u] = xv;              // the middle slot is the main diagonal
                     s0[u] = fma(v.x, xv.x, s0[u]);
@@ -542,13 +557,17 @@ static void launch_spmv_dia_rows(kk_ctx ctx, const kk_sparse_dev& M, const doubl
     const int64_t D = M.dia_D;
     if (M.dia_pts == 5) { const int64_t o5[5] = {-D, -1, 0, 1, D}; for (int q = 0; q < 5; ++q) of.o[q] = o5[q]; for (int q = 5; q < 9; ++q) of.o[q] = 0; }
     else { const int64_t o9[9] = {-D - 1, -D, -D + 1, -1, 0, 1, D - 1, D, D + 1}; for (int q = 0; q < 9; ++q) of.o[q] = o9[q]; }
-#define SPMV_DIA_ARGS dim3(nblk), dim3(KK_TPB), 0, ctx->stream, M.dia_val, M.dia_ld, of, M.nrows, x, y, e, nb_logical, pd + *nblk_io, pn + *nblk_io, r0, r1
+    dia_cst cst;
+    for (int q = 0; q < 9; ++q) cst.c[q] = M.dia_c[q];
+    cst.phase = M.dia_phase; cst.D = D;
+    const bool cc = M.dia_const && ctx->spmv_dia_const;
+#define SPMV_DIA_ARGS dim3(nblk), dim3(KK_TPB), 0, ctx->stream, M.dia_val, M.dia_ld, of, M.nrows, x, y, e, nb_logical, pd + *nblk_io, pn + *nblk_io, r0, r1, cst
     if (M.dia_pts == 5) {
-        if (U == 2) hipLaunchKernelGGL((k_spmv_dia<5, 2>), SPMV_DIA_ARGS);
-        else hipLaunchKernelGGL((k_spmv_dia<5, 1>), SPMV_DIA_ARGS);
+        if (cc) { if (U == 2) hipLaunchKernelGGL((k_spmv_dia<5, 2, true>), SPMV_DIA_ARGS); else hipLaunchKernelGGL((k_spmv_dia<5, 1, true>), SPMV_DIA_ARGS); }
+        else { if (U == 2) hipLaunchKernelGGL((k_spmv_dia<5, 2, false>), SPMV_DIA_ARGS); else hipLaunchKernelGGL((k_spmv_dia<5, 1, false>), SPMV_DIA_ARGS); }
     } else {
-        if (U == 2) hipLaunchKernelGGL((k_spmv_dia<9, 2>), SPMV_DIA_ARGS);
-        else hipLaunchKernelGGL((k_spmv_dia<9, 1>), SPMV_DIA_ARGS);
+        if (cc) { if (U == 2) hipLaunchKernelGGL((k_spmv_dia<9, 2, true>), SPMV_DIA_ARGS); else hipLaunchKernelGGL((k_spmv_dia<9, 1, true>), SPMV_DIA_ARGS); }
+        else { if (U == 2) hipLaunchKernelGGL((k_spmv_dia<9, 2, false>), SPMV_DIA_ARGS); else hipLaunchKernelGGL((k_spmv_dia<9, 1, false>), SPMV_DIA_ARGS); }
     }
 #undef SPMV_DIA_ARGS
     *nblk_io += nblk;

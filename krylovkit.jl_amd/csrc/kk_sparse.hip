@@ -194,6 +194,39 @@ static int detect_stencil(const kk_host_csr& h, kk_sparse_dev& M) {
     KK_HIP(hipMemcpy(M.dia_val, dv.data(), dv.size() * sizeof(double), hipMemcpyHostToDevice));
     M.dia_D = D; M.dia_pts = pts; M.dia_ld = dld;
     M.bytes += (int64_t)dv.size() * 8;
+    // Constant coefficients?  (Laplacians, constant convection-diffusion operators ...)  Diagonal q must hold ONE value c_q
+    // wherever its neighbour exists -- inside the matrix and on the same grid line for the +-1 shifts -- and nothing elsewhere.
+    // The position of a row inside its line is (i + phase) % D; the phase is read off the first gap of the "+1" diagonal
+    // (a row-sharded block need not start at a line boundary).
+    M.dia_const = false;
+    {
+        int64_t o[9]; int b[9];
+        if (pts == 5) { const int64_t o5[5] = {-D, -1, 0, 1, D}; const int b5[5] = {0, -1, 0, 1, 0}; for (int q = 0; q < 5; ++q) { o[q] = o5[q]; b[q] = b5[q]; } }
+        else { for (int q = 0; q < 9; ++q) { b[q] = q % 3 - 1; o[q] = (int64_t)(q / 3 - 1) * D + b[q]; } }
+        const int qp = pts == 5 ? 3 : 5;   // the slot of offset +1
+        int64_t phase = -1;
+        for (int64_t i = 0; i + 1 < n && phase < 0; ++i)
+            if (dv[(size_t)qp * dld + i] == 0.0) phase = ((D - 1 - i) % D + D) % D;
+        bool ok = phase >= 0;
+        double cq[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int q = 0; q < pts && ok; ++q) {
+            bool have = false;
+            const double* dq = dv.data() + (size_t)q * dld;
+            for (int64_t i = 0; i < n; ++i) {
+                const int64_t j = i + o[q], ix = (i + phase) % D;
+                const bool valid = j >= 0 && j < n && ix + b[q] >= 0 && ix + b[q] < D;
+                if (valid) {
+                    if (!have) { cq[q] = dq[i]; have = true; }
+                    if (dq[i] != cq[q]) { ok = false; break; }
+                } else if (dq[i] != 0.0) { ok = false; break; }
+            }
+        }
+        if (ok) {
+            M.dia_const = true;
+            M.dia_phase = phase;
+            for (int q = 0; q < 9; ++q) M.dia_c[q] = cq[q];
+        }
+    }
     return KK_OK;
 }
 

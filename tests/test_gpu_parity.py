@@ -1314,3 +1314,60 @@ def test_linsolve_front_end_tolerances_and_bicgstab_breakdown_test(kk, ko, ctx):
     xso, soinfo = ko.bicgstab(A, bs, tol=1e-16, maxiter=400)
     assert sinfo.numiter > 1 and sinfo.converged == soinfo.converged == 1
     assert np.linalg.norm(A @ xs - bs) < 1e-15
+
+
+def test_constant_coefficient_stencil_needs_neither_indices_nor_values(kk, ko, ctx):
+    """A grid stencil whose diagonals hold ONE value each (Laplacians, constant convection-diffusion) is applied by the
+    value-free diagonal kernel (option spmv_dia_const, default on): bit-identical to the kernel that streams the diagonals
+    (same products, same order), equal to SciPy, through every fused epilogue; operators with varying coefficients, or with
+    entries that wrap around a grid line, keep streaming their diagonals."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(17)
+    nx, ny = 70, 61
+    n = nx * ny
+    lap = ko.laplacian_2d(nx, ny)                                   # constant 5-point
+    cd = ko.convection_diffusion_2d(nx, ny)                         # constant, non-symmetric 5-point
+    ix, iy = np.meshgrid(np.arange(nx), np.arange(ny)); ix, iy = ix.ravel(), iy.ravel()
+    rows, cols, vals = [], [], []
+    for dy in (-1, 0, 1):                                           # constant 9-point
+        for dx in (-1, 0, 1):
+            ok = (ix + dx >= 0) & (ix + dx < nx) & (iy + dy >= 0) & (iy + dy < ny)
+            r = (iy * nx + ix)[ok]
+            rows.append(r); cols.append(r + dy * nx + dx); vals.append(np.full(r.size, 8.0 if (dx, dy) == (0, 0) else -1.0 + 0.1 * dx + 0.01 * dy))
+    nine = sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(n, n))
+    wrap = lap.tolil(); wrap[nx - 1, nx] = -1.0; wrap = wrap.tocsr()      # one entry across a line end: not a pure stencil
+    varying = ko.laplacian_2d(nx, ny, shift_diag=np.linspace(0, 1, n))
+    B = kk.DeviceBasis(n, 8, ctx)
+    X = rng.standard_normal((n, 3))
+    for j in range(3):
+        B.upload(j, X[:, j])
+    for name, A, sym in (("laplacian", lap, True), ("convdiff", cd, False), ("nine", nine, False), ("wrap", wrap, False), ("varying", varying, True)):
+        op = kk.SparseOperator(A, ctx, symmetric=sym)
+        assert op.info()["format"] == "ELL+DIA", name
+        outs = []
+        for const in (1, 0):
+            ctx.set_option("spmv_dia_const", const)
+            op.apply(B[0], B[4])
+            op.apply_affine(B[1], B[5], 0.7, -0.4)
+            outs.append((B[4].get(), B[5].get()))
+        ctx.set_option("spmv_dia_const", 1)
+        assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]), name
+        np.testing.assert_allclose(outs[0][0], A @ X[:, 0], rtol=0, atol=1e-12, err_msg=name)
+        np.testing.assert_allclose(outs[0][1], 0.7 * X[:, 1] - 0.4 * (A @ X[:, 1]), rtol=0, atol=1e-12, err_msg=name)
+    # fused Lanczos epilogues (alpha dot, - beta v_prev, on-the-fly 1/beta scale of the speculative apply) on the constant operator
+    x0 = rng.random(n)
+    runs = []
+    for const in (1, 0):
+        ctx.set_option("spmv_dia_const", const)
+        it = kk.LanczosIterator(kk.SparseOperator(lap, ctx, symmetric=True), x0, kk.ModifiedGramSchmidt2(), capacity=30)
+        f = kk.initialize(it)
+        for _ in range(25):
+            f = kk.expand_(it, f)
+        runs.append((list(f.alphas), list(f.betas)))
+    ctx.set_option("spmv_dia_const", 1)
+    assert runs[0] == runs[1]
+    oit = ko.LanczosIterator(lap, x0.copy(), ko.MGS2)
+    of = ko.lanczos_initialize(oit)
+    for _ in range(25):
+        of = ko.lanczos_expand(oit, of)
+    assert relerr(runs[0][0], of.alphas) < 1e-10 and relerr(runs[0][1], of.betas) < 1e-10
