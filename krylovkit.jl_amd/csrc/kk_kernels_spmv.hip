@@ -143,7 +143,8 @@ __global__ __launch_bounds__(KK_TPB) void k_spmv_dia(const double* __restrict__ 
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             s0[u] = 0; s1[u] = 0; xc[u] = d2{0.0, 0.0};
-            ix0[u] = CONST ? (row0 + (int64_t)u * 2 * KK_TPB + cst.phase) % cst.D : 0;
+            // rows and D are below 2^31 (int32 device indices): a 32-bit remainder instead of the 64-bit software division
+            ix0[u] = CONST ? (int64_t)((unsigned)(row0 + (int64_t)u * 2 * KK_TPB + cst.phase) % (unsigned)cst.D) : 0;
         }
 #pragma unroll
         for (int q = 0; q < PTS; ++q) {
@@ -473,11 +474,11 @@ __device__ __forceinline__ double wave_from_right(double v) {   // lane l receiv
     hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
     return __hiloint2double(hi, lo);
 }
-template <int NB, int PTS>
+template <int NB, int PTS, bool CONST>
 __global__ __launch_bounds__(KK_TPB) void k_spmm_dia(const double* __restrict__ dval, int64_t dld, int64_t D, int64_t nrows,
                                                      const double* __restrict__ X, int64_t ldx, double* __restrict__ Y,
                                                      int64_t ldy, int nb, int strips, int lines, int64_t Tlo, int64_t T,
-                                                     int64_t row_lo, int64_t row_hi) {
+                                                     int64_t row_lo, int64_t row_hi, dia_cst cst) {
     // grid lines [Tlo, T) are swept; results are stored for rows [row_lo, row_hi) only (the whole operator, or the
     // ghost-free interior of a row-sharded stencil -- its window loads stay inside the local vector)
     const int lane = threadIdx.x & 63;
@@ -489,6 +490,7 @@ __global__ __launch_bounds__(KK_TPB) void k_spmm_dia(const double* __restrict__ 
     const int64_t i = (int64_t)strip * 62 + lane - 1;     // position inside the grid line (halo lanes: -1 / one past the strip)
     const bool own = lane >= 1 && lane <= 62 && i < D;
     int64_t r = t0 * D + i;                               // linear row of this lane on the current line
+    const int64_t ixc = CONST ? (((i + cst.phase) % D) + D) % D : 0;   // CONST: true position inside the grid line (the block may start mid-line)
     double xm[NB], x0[NB], xp[NB];
     auto fetch = [&](double* dst, int64_t rr) {
         const bool ok = rr >= 0 && rr < nrows;
@@ -501,8 +503,16 @@ __global__ __launch_bounds__(KK_TPB) void k_spmm_dia(const double* __restrict__ 
         fetch(xp, r + D);
         const bool rok = r >= 0 && r < nrows;
         double d[PTS];
+        if (CONST) {   // constant coefficients: c_q, except where a +-1 shift would leave the grid line (true position = ixc)
 #pragma unroll
-        for (int q = 0; q < PTS; ++q) d[q] = rok ? __builtin_nontemporal_load(dval + (int64_t)q * dld + r) : 0.0;
+            for (int q = 0; q < PTS; ++q) {
+                const int bq = PTS == 5 ? (q == 1 ? -1 : (q == 3 ? 1 : 0)) : q % 3 - 1;
+                d[q] = (!rok || (bq < 0 && ixc == 0) || (bq > 0 && ixc == D - 1)) ? 0.0 : cst.c[q];
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < PTS; ++q) d[q] = rok ? __builtin_nontemporal_load(dval + (int64_t)q * dld + r) : 0.0;
+        }
         const bool st = own && rok && r >= row_lo && r < row_hi;
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
@@ -689,6 +699,10 @@ int kk_launch_spmm(kk_ctx ctx, const kk_sparse_dev& M, const double* X, int64_t 
     }
     // grid stencil: sweep the lines with a register window (every element of X read once) -- the whole operator, or the
     // ghost-free interior rows of a row-sharded one
+    dia_cst cst;
+    for (int q = 0; q < 9; ++q) cst.c[q] = M.dia_c[q];
+    cst.phase = M.dia_phase; cst.D = M.dia_D;
+    const bool cc = M.dia_const && ctx->spmv_dia_const;
     auto launch_dia = [&](int64_t row_lo, int64_t row_hi) {
         if (row_hi <= row_lo) return;
         const int strips = (int)((M.dia_D + 61) / 62);
@@ -703,10 +717,12 @@ int kk_launch_spmm(kk_ctx ctx, const kk_sparse_dev& M, const double* X, int64_t 
             const double* x = X + (int64_t)j0 * ldx;
             double* y = Y + (int64_t)j0 * ldy;
             kk_prof_scope ps(ctx, "k_spmm_dia");
-#define DIA_ARGS M.dia_val, M.dia_ld, M.dia_D, M.nrows, x, ldx, y, ldy, n, strips, lines, Tlo, T, row_lo, row_hi
+#define DIA_ARGS M.dia_val, M.dia_ld, M.dia_D, M.nrows, x, ldx, y, ldy, n, strips, lines, Tlo, T, row_lo, row_hi, cst
 #define DIA_CASE(NBT) \
-            if (M.dia_pts == 5) hipLaunchKernelGGL((k_spmm_dia<NBT, 5>), g, b, 0, ctx->stream, DIA_ARGS); \
-            else hipLaunchKernelGGL((k_spmm_dia<NBT, 9>), g, b, 0, ctx->stream, DIA_ARGS);
+            if (cc) { if (M.dia_pts == 5) hipLaunchKernelGGL((k_spmm_dia<NBT, 5, true>), g, b, 0, ctx->stream, DIA_ARGS); \
+                      else hipLaunchKernelGGL((k_spmm_dia<NBT, 9, true>), g, b, 0, ctx->stream, DIA_ARGS); } \
+            else { if (M.dia_pts == 5) hipLaunchKernelGGL((k_spmm_dia<NBT, 5, false>), g, b, 0, ctx->stream, DIA_ARGS); \
+                   else hipLaunchKernelGGL((k_spmm_dia<NBT, 9, false>), g, b, 0, ctx->stream, DIA_ARGS); }
             if (n > 8) { DIA_CASE(16) }
             else if (n > 4) { DIA_CASE(8) }
             else { DIA_CASE(4) }

@@ -1352,6 +1352,16 @@ def test_constant_coefficient_stencil_needs_neither_indices_nor_values(kk, ko, c
             outs.append((B[4].get(), B[5].get()))
         ctx.set_option("spmv_dia_const", 1)
         assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]), name
+        # the multi-column sweeping apply has the same value-free form
+        from krylovkit_hip._lib import check
+        Ys = []
+        for const in (1, 0):
+            ctx.set_option("spmv_dia_const", const)
+            check(ctx._lib.kk_block_apply(op.handle, B.handle, 0, B.handle, 4, 3))
+            Ys.append(np.stack([B.download(4 + j) for j in range(3)], 1))
+        ctx.set_option("spmv_dia_const", 1)
+        assert np.array_equal(Ys[0], Ys[1]), name
+        np.testing.assert_allclose(Ys[0], A @ X, rtol=0, atol=1e-12, err_msg=name)
         np.testing.assert_allclose(outs[0][0], A @ X[:, 0], rtol=0, atol=1e-12, err_msg=name)
         np.testing.assert_allclose(outs[0][1], 0.7 * X[:, 1] - 0.4 * (A @ X[:, 1]), rtol=0, atol=1e-12, err_msg=name)
     # fused Lanczos epilogues (alpha dot, - beta v_prev, on-the-fly 1/beta scale of the speculative apply) on the constant operator
