@@ -12,17 +12,22 @@ eigsolve(Lanczos) on the 10M-row 5-point Laplacian (SparseMatrixCSC), krylovdim 
 One *step* = one full Krylov sweep of the hot path: `initialize` + 99 `expand!` calls
 (basis size m = 2..100), i.e. 99 Lanczos iterations (1 iteration = 1 expand! = 1 operator
 application, the reference's `numops` unit).  value = 99*K / elapsed  [iterations/s], inputs
-resident in HBM before the timed region.  N > 1 is WEAK scaling: every rank owns 10M rows of a
+resident in HBM before the timed region.  N > 1, `--scaling weak` (default): every rank owns 10M rows of a
 (4000 x 2500*N)-grid Laplacian, basis row-sharded, 2 RCCL all-reduces + 1 halo exchange per
-iteration.  value is the whole-job aggregate: every rank processes its 10M-row shard of each
+iteration; value is the whole-job aggregate: every rank processes its 10M-row shard of each
 iteration, so value = N * (job iterations / s) in units of 10M-row Lanczos iterations per second
 (identical to plain iterations/s at N = 1; "job_iterations_per_second" is also reported).
+`--scaling strong`: the ONE 10M-row problem split over the N ranks, value = job iterations/s.  The mode not chosen runs
+as a secondary leg ("other_scaling_leg").
 
 Extra objects: "roofline" (dominant kernel, HIP events recorded on the kernels' stream inside
 the timed region), "cpu_baseline" (the C twin of the oracle timed on the host cores, rank 0,
 N = 1 only: the FULL 10M-row sweep from the same start vector) and "parity" (alpha / beta trajectories and Ritz
-values of that CPU run against the GPU sweep, north_star's 1e-10 bar at the headline size), plus "mgs2_strict":
-the same sweep with the reference's sequential MGS2 order (mgs_mode = 0, src/orthonormal.jl:414-439).
+values of CPU runs against GPU sweeps for three start vectors, north_star's 1e-10 bar at the headline size), plus the
+OTHER execution order of MGS2 as a secondary leg: the headline runs the library default (`mgs_mode` auto: the reference's
+sequential order, src/orthonormal.jl:414-439, through the persistent kernel at N = 1 -> leg "mgs2_lowsync"; the
+low-synchronisation form on a sharded context -> leg "mgs2_strict"), and "without_event_bracketing" (the same sweeps with
+no HIP event in the timed region).
 """
 from __future__ import annotations
 
@@ -418,8 +423,8 @@ def main():
 
     # warm-up sweeps; the last one is event-profiled per kernel class (breakdown only, untimed)
     ctx.prof_reset()
-    for i in range(W):
-        ctx.prof_enable(1 if i == W - 1 else 0)
+    for i in range(max(W, 1)):   # --warmup 0 still runs this one profiled sweep: the per-kernel breakdown (and which MGS form ran) comes from it
+        ctx.prof_enable(1 if i == max(W, 1) - 1 else 0)
         sweep()
     barrier(); sync()
     ctx.prof_enable(0)
