@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define KK_VERSION 200 /* 0.2.0 */
+#define KK_VERSION 300 /* 0.3.0: mgs_mode auto is the default, no limit on the basis size, constant-coefficient stencils */
 
 /* status codes */
 #define KK_OK 0
@@ -210,7 +210,7 @@ int kk_csr_create(kk_ctx ctx, int64_t nrows, int64_t ncols, int64_t nnz, const i
 int kk_csc_create(kk_ctx ctx, int64_t nrows, int64_t ncols, int64_t nnz, const int64_t* colptr,
                   const int64_t* rowval, const double* nzval, int index_base, int flags, kk_op* out);
 int kk_op_free(kk_op op);
-int kk_op_info(kk_op op, int64_t* nrows, int64_t* ncols, int64_t* nnz, int* format /*0=ELL,1=CSR,2=SELL-64-sigma,3=column-tiled SELL,4=ELL + grid-stencil diagonals*/,
+int kk_op_info(kk_op op, int64_t* nrows, int64_t* ncols, int64_t* nnz, int* format /*0=ELL,1=CSR,2=SELL-64-sigma,3=column-tiled SELL,4=ELL + grid-stencil diagonals,5=the same with constant coefficients (applied without reading indices or values)*/,
                int64_t* device_bytes);
 /* Row-sharded operators (one process per GPU): column indices >= n_local_cols address a
  * caller-owned device buffer of n_ghost doubles that the caller fills before each apply

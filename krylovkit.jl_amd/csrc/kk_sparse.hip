@@ -678,7 +678,7 @@ KK_API int kk_op_info(kk_op op, int64_t* nrows, int64_t* ncols, int64_t* nnz, in
     if (nrows) *nrows = op->nrows;
     if (ncols) *ncols = op->ncols;
     if (nnz) *nnz = op->nnz;
-    if (format) *format = (op->A.format == 0 && op->A.dia_D > 0) ? 4 : op->A.format;
+    if (format) *format = (op->A.format == 0 && op->A.dia_D > 0) ? (op->A.dia_const ? 5 : 4) : op->A.format;
     if (bytes) *bytes = op->A.bytes + op->At.bytes;
     return KK_OK;
 }

@@ -398,7 +398,7 @@ class SparseOperator:
     def info(self):
         nr, nc, nnz, fmt, nb = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int(), C.c_int64()
         check(self._lib.kk_op_info(self.handle, C.byref(nr), C.byref(nc), C.byref(nnz), C.byref(fmt), C.byref(nb)))
-        return dict(nrows=nr.value, ncols=nc.value, nnz=nnz.value, format=("ELL", "CSR", "SELL", "SELL-tiled", "ELL+DIA")[fmt.value] if fmt.value in (0, 1, 2, 3, 4) else "?",
+        return dict(nrows=nr.value, ncols=nc.value, nnz=nnz.value, format=("ELL", "CSR", "SELL", "SELL-tiled", "ELL+DIA", "ELL+DIA const")[fmt.value] if fmt.value in (0, 1, 2, 3, 4, 5) else "?",
                     device_bytes=nb.value)
 
     def apply(self, x: HipVec, y: HipVec, transpose: bool = False) -> HipVec:

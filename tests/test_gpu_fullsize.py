@@ -30,7 +30,7 @@ def test_config2_lanczos_10M_properties(kk, ctx, orth_name):
     N, K = NX * NY, 100
     A = laplacian_rows(NX, NY, 0, NY)
     op = kk.SparseOperator(A, ctx, symmetric=True, via_csc=True)
-    assert op.info()["format"] == "ELL+DIA" and op.info()["nnz"] == 5 * N - 2 * (NX + NY)   # grid stencil: diagonals next to ELL
+    assert op.info()["format"] == "ELL+DIA const" and op.info()["nnz"] == 5 * N - 2 * (NX + NY)   # grid stencil: diagonals next to ELL
     V = kk.DeviceBasis(N, K + 4, ctx)
     x0 = kk.DeviceBasis(N, 1, ctx)
     x0[0].rand_(3)

@@ -266,7 +266,7 @@ def test_loopback_sharded_stencil_uses_diagonal_kernels_on_the_interior(kk, ko, 
     op = kd.NativeShardedOperator(A, part, ctx, symmetric=True)
     monkeypatch.delenv("KK_LOOPBACK_GHOST_FROM")
     monkeypatch.delenv("KK_LOOPBACK_GHOST_BELOW")
-    assert op.info()["ncols"] > n and op.info()["format"] == "ELL+DIA"
+    assert op.info()["ncols"] > n and op.info()["format"].startswith("ELL+DIA")
     B = kk.DeviceBasis(n, 40, ctx)
     X = rng.standard_normal((n, 16))
     for j in range(16):

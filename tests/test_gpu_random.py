@@ -137,7 +137,7 @@ def test_grid_stencil_kernels_random(kk, ctx, nx, ny, nine, nb, drop, seed):
         A = A[:n - drop, :n - drop].tocsr()
         n -= drop
     op = kk.SparseOperator(A, ctx)
-    assert op.info()["format"] == "ELL+DIA"
+    assert op.info()["format"].startswith("ELL+DIA")
     X = rng.standard_normal((n, nb))
     S = kk.DeviceBasis(n, 2 * nb + 1, ctx)
     for j in range(nb):
