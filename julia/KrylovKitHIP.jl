@@ -238,7 +238,7 @@ function grow!(b::OrthonormalBasis{HipVec}, ncols::Int)
     isempty(b.basis) && return b
     old, c0 = b.basis[1].slab, Int(b.basis[1].col)
     old.capacity - c0 >= ncols && return b
-    new = HipSlab(old.ctx, old.n, ncols)
+    new = HipSlab(old.ctx, old.n, max(ncols, 32))      # (a basis that sheds its oldest vector marches to the right: keepvecs = false)
     for (i, v) in enumerate(b.basis)
         copyto_column!(HipVec(new, i - 1), v)
         release!(v)
@@ -331,10 +331,12 @@ function project!!(y::AbstractVector, b::OrthonormalBasis{HipVec}, x::HipVec, α
     slab, c0, _ = slab_range(b)
     length(y) == length(r) || throw(DimensionMismatch())
     ys = Vector{Float64}(y)
-    for j0 in 0:KK_MAX_M:(length(r) - 1)                 # panels of at most KK_MAX_M basis vectors
-        mm = min(KK_MAX_M, length(r) - j0)
-        chk(ccall((:kk_project, lib), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Cint, Float64, Float64, Ptr{Float64}),
-                  slab.h, c0 + first(r) - 1 + j0, mm, x.slab.h, x.col, α, β, pointer(ys, j0 + 1)))
+    GC.@preserve ys begin
+        for j0 in 0:KK_MAX_M:(length(r) - 1)             # panels of at most KK_MAX_M basis vectors
+            mm = min(KK_MAX_M, length(r) - j0)
+            chk(ccall((:kk_project, lib), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Cint, Float64, Float64, Ptr{Float64}),
+                      slab.h, c0 + first(r) - 1 + j0, mm, x.slab.h, x.col, α, β, pointer(ys, j0 + 1)))
+        end
     end
     copyto!(y, ys)
     return y
@@ -344,10 +346,12 @@ function unproject!!(y::HipVec, b::OrthonormalBasis{HipVec}, x::AbstractVector, 
     slab, c0, _ = slab_range(b)
     length(x) == length(r) || throw(DimensionMismatch())
     xs = Vector{Float64}(x)
-    for j0 in 0:KK_MAX_M:(length(r) - 1)                 # y = β y + α Σ ... : β applies to the first panel only
-        mm = min(KK_MAX_M, length(r) - j0)
-        chk(ccall((:kk_unproject, lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Cint, Ptr{Float64}, Float64, Float64),
-                  y.slab.h, y.col, slab.h, c0 + first(r) - 1 + j0, mm, pointer(xs, j0 + 1), α, j0 == 0 ? β : 1.0))
+    GC.@preserve xs begin
+        for j0 in 0:KK_MAX_M:(length(r) - 1)             # y = β y + α Σ ... : β applies to the first panel only
+            mm = min(KK_MAX_M, length(r) - j0)
+            chk(ccall((:kk_unproject, lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Cint, Ptr{Float64}, Float64, Float64),
+                      y.slab.h, y.col, slab.h, c0 + first(r) - 1 + j0, mm, pointer(xs, j0 + 1), α, j0 == 0 ? β : 1.0))
+        end
     end
     return y
 end
