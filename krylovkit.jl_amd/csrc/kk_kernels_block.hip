@@ -515,10 +515,10 @@ __global__ __launch_bounds__(KK_TPB) void k_blk_gram_rows(const double* __restri
 // classical Gram-Schmidt pass is not enough); with it V'w = O(E^2 |P|) + the rounding of the panel itself.
 __global__ __launch_bounds__(KK_TPB) void k_blk_panel_correct(const double* __restrict__ P, int st, int kn, int p,
                                                               const double* __restrict__ gram, int cap, double* __restrict__ Pc) {
-    extern __shared__ double psm[];   // P staged: kn * st
+    extern __shared__ double psm[];   // P staged: kn * st (every block stages the whole panel and computes its 256 entries)
     for (int e = threadIdx.x; e < kn * st; e += KK_TPB) psm[e] = P[e];
     __syncthreads();
-    for (int e = threadIdx.x; e < kn * st; e += KK_TPB) {
+    for (int e = blockIdx.x * KK_TPB + threadIdx.x; e < kn * st; e += gridDim.x * KK_TPB) {
         const int i = e / st, j = e % st;
         double a = 0;
         if (j < p) {
@@ -830,7 +830,7 @@ int kk_launch_blk_gram_rows(kk_ctx ctx, const double* G2, int st, int k, int p, 
     return KK_OK;
 }
 int kk_launch_blk_panel_correct(kk_ctx ctx, const double* P, int st, int kn, int p, const double* gram, int cap, double* Pc) {
-    hipLaunchKernelGGL(k_blk_panel_correct, dim3(1), dim3(KK_TPB), (size_t)kn * st * sizeof(double), ctx->stream, P, st, kn, p, gram, cap, Pc);
+    hipLaunchKernelGGL(k_blk_panel_correct, dim3((kn * st + KK_TPB - 1) / KK_TPB), dim3(KK_TPB), (size_t)kn * st * sizeof(double), ctx->stream, P, st, kn, p, gram, cap, Pc);
     KK_HIP(hipGetLastError());
     return KK_OK;
 }
@@ -950,11 +950,11 @@ int kk_launch_block_gram2(kk_ctx ctx, const double* X, int64_t ldx, int p, const
     if (p <= 0 || q <= 0 || q2 <= 0) return KK_OK;
     if (p > 128 || q > 16 || q2 > 16) { kk_set_error("kk_launch_block_gram2: p=%d q=%d q2=%d exceed one launch (128 x 16)", p, q, q2); return KK_ERR_INVALID; }
     const int ng = (p + 15) / 16;
-    const int NG = ng <= 2 ? ng : (ng <= 4 ? 4 : (ng == 5 ? 5 : 8));
+    const int NG = ng <= 4 ? ng : (ng == 5 ? 5 : 8);   // 48-column chunks (kn = 96, 112) run three groups, not four with one empty
     int nblk;
     int64_t rpb;
     // NG >= 5: two blocks per CU fit (VGPRs); the partial tiles double (+ one tile per block for Y'Y), which bounds the grid
-    gram_grid(ctx, ld, NG == 5 ? 8 : NG, NG >= 5 ? 2 : (NG == 4 ? 3 : 8), &nblk, &rpb);
+    gram_grid(ctx, ld, NG == 5 ? 8 : (NG == 3 ? 4 : NG), NG >= 5 ? 2 : (NG >= 3 ? 3 : 8), &nblk, &rpb);
     if ((2 * (int64_t)NG + 1) * nblk * 256 > (int64_t)(2 * KK_MAX_M + 8) * KK_MAX_BLOCKS) { kk_set_error("kk_launch_block_gram2: partial buffer too small"); return KK_ERR_INVALID; }
     const size_t shm = (size_t)NG * 256 * sizeof(double);
     double* part = ctx->partials;
@@ -973,6 +973,7 @@ int kk_launch_block_gram2(kk_ctx ctx, const double* X, int64_t ldx, int p, const
         switch (NG) {
             case 1: hipLaunchKernelGGL((k_block_gram2<1>), g, b, shm, ctx->stream, BG2_ARGS); break;
             case 2: hipLaunchKernelGGL((k_block_gram2<2>), g, b, shm, ctx->stream, BG2_ARGS); break;
+            case 3: hipLaunchKernelGGL((k_block_gram2<3>), g, b, shm, ctx->stream, BG2_ARGS); break;
             case 4: hipLaunchKernelGGL((k_block_gram2<4>), g, b, shm, ctx->stream, BG2_ARGS); break;
             case 5: hipLaunchKernelGGL((k_block_gram2<5>), g, b, shm, ctx->stream, BG2_ARGS); break;
             default: hipLaunchKernelGGL((k_block_gram2<8>), g, b, shm, ctx->stream, BG2_ARGS); break;
