@@ -319,11 +319,11 @@ __global__ __launch_bounds__(KK_TPB) void k_block_gram_tile(const double* __rest
 // thread (el = tid & 15, sl = tid >> 4) adds the partial tiles sl, sl + 16, ... (128-byte coalesced loads), the 16 slices are
 // combined through LDS in a fixed order -- deterministic, and the reduction over up to 2048 partial tiles no longer runs
 // as one serial chain per output entry (306 us -> a few us per Gram panel at 8 blocks per CU).
-__global__ __launch_bounds__(KK_TPB) void k_finalize_gram(const double* __restrict__ part, int nblk, int ng, int p, int q,
-                                                          double* __restrict__ C, int rs, int cs) {
+__device__ __forceinline__ void finalize_gram_body(const double* __restrict__ part, int nblk, int ng, int p, int q,
+                                                   double* __restrict__ C, int rs, int cs, int blk) {
     __shared__ double sm[16][17];
     const int el = threadIdx.x & 15, sl = threadIdx.x >> 4;
-    const int e = blockIdx.x * 16 + el;                  // tile element: e = (g*4 + r)*64 + lane
+    const int e = blk * 16 + el;                         // tile element: e = (g*4 + r)*64 + lane
     const int64_t stride = (int64_t)ng * 256;
     double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
     int b = sl;
@@ -344,6 +344,21 @@ __global__ __launch_bounds__(KK_TPB) void k_finalize_gram(const double* __restri
         const int j = lane & 15, i = g * 16 + (lane >> 4) + 4 * r;
         if (i < p && j < q) C[(int64_t)i * rs + (int64_t)j * cs] = a;
     }
+}
+__global__ __launch_bounds__(KK_TPB) void k_finalize_gram(const double* __restrict__ part, int nblk, int ng, int p, int q,
+                                                          double* __restrict__ C, int rs, int cs) {
+    finalize_gram_body(part, nblk, ng, p, q, C, rs, cs, blockIdx.x);
+}
+// the three panels of one k_block_gram2 launch in ONE finalize launch: blocks [0, ng*16) -> C (X'Y), [ng*16, 2 ng*16) -> C2
+// (X'Y2), the last 16 -> C3 (Y'Y, one tile, column-major ld 16) when present
+__global__ __launch_bounds__(KK_TPB) void k_finalize_gram3(const double* __restrict__ part, const double* __restrict__ part2,
+                                                           const double* __restrict__ part3, int nblk, int ng, int p, int q, int q2,
+                                                           double* __restrict__ C, int rs, double* __restrict__ C2, int rs2,
+                                                           double* __restrict__ C3) {
+    const int nb1 = ng * 16;
+    if ((int)blockIdx.x < nb1) finalize_gram_body(part, nblk, ng, p, q, C, rs, 1, blockIdx.x);
+    else if ((int)blockIdx.x < 2 * nb1) finalize_gram_body(part2, nblk, ng, p, q2, C2, rs2, 1, blockIdx.x - nb1);
+    else finalize_gram_body(part3, nblk, 1, q, q, C3, 1, 16, blockIdx.x - 2 * nb1);
 }
 
 // ---- one-block dense helpers of the asynchronous block step (p <= 16): the Cholesky factors, their inverses and the
@@ -538,10 +553,15 @@ __global__ __launch_bounds__(KK_TPB) void k_blk_resid_gram(const double* __restr
                                                            int p, const double* __restrict__ GYY, const double* __restrict__ nrm2,
                                                            double* __restrict__ GW) {
     __shared__ double g[16][17];
+    extern __shared__ double pp[];   // both panels staged (2 * kn * st doubles): the kn-long sums then run out of LDS
+    double* ps = pp;
+    double* pcs = pp + (size_t)kn * st;
+    for (int e = threadIdx.x; e < kn * st; e += KK_TPB) { ps[e] = P[e]; pcs[e] = Pc[e]; }
+    __syncthreads();
     const int i = threadIdx.x & 15, j = threadIdx.x >> 4;
     double a = 0;
     if (i < p && j < p)
-        for (int l = 0; l < kn; ++l) a = fma(P[(int64_t)l * st + i], Pc[(int64_t)l * st + j], a);
+        for (int l = 0; l < kn; ++l) a = fma(ps[l * st + i], pcs[l * st + j], a);
     g[i][j] = (i < p && j < p) ? GYY[i + 16 * j] - a : 0.0;
     __syncthreads();
     if (i < p && j < p) GW[i + p * j] = (i == j) ? nrm2[i] : 0.5 * (g[i][j] + g[j][i]);
@@ -836,7 +856,7 @@ int kk_launch_blk_panel_correct(kk_ctx ctx, const double* P, int st, int kn, int
 }
 int kk_launch_blk_resid_gram(kk_ctx ctx, const double* P, const double* Pc, int st, int kn, int p, const double* GYY,
                              const double* nrm2, double* GW) {
-    hipLaunchKernelGGL(k_blk_resid_gram, dim3(1), dim3(KK_TPB), 0, ctx->stream, P, Pc, st, kn, p, GYY, nrm2, GW);
+    hipLaunchKernelGGL(k_blk_resid_gram, dim3(1), dim3(KK_TPB), (size_t)2 * kn * st * sizeof(double), ctx->stream, P, Pc, st, kn, p, GYY, nrm2, GW);
     KK_HIP(hipGetLastError());
     return KK_OK;
 }
@@ -981,9 +1001,8 @@ int kk_launch_block_gram2(kk_ctx ctx, const double* X, int64_t ldx, int p, const
 #undef BG2_ARGS
     }
     KK_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_finalize_gram, dim3(NG * 16), dim3(KK_TPB), 0, ctx->stream, part, nblk, NG, p, q, C_dev, rs, 1);
-    hipLaunchKernelGGL(k_finalize_gram, dim3(NG * 16), dim3(KK_TPB), 0, ctx->stream, part2, nblk, NG, p, q2, C2_dev, rs2, 1);
-    if (C3_dev) hipLaunchKernelGGL(k_finalize_gram, dim3(16), dim3(KK_TPB), 0, ctx->stream, part3, nblk, 1, q, q, C3_dev, 1, 16);   // column-major, ld 16
+    hipLaunchKernelGGL(k_finalize_gram3, dim3(2 * NG * 16 + (C3_dev ? 16 : 0)), dim3(KK_TPB), 0, ctx->stream, part, part2, part3, nblk, NG, p, q, q2,
+                       C_dev, rs, C2_dev, rs2, C3_dev);
     KK_HIP(hipGetLastError());
     return KK_OK;
 }
