@@ -651,6 +651,11 @@ def main():
         }
         if args.config != "block":
             out["last_alpha"], out["last_beta"] = fact.alphas[-1], fact.betas[-1]
+        if world > 1 and args.config == "lanczos":
+            out["scaling_note"] = ("rows are sharded: every inner product needs an all-reduce, which the persistent strict-MGS kernel of the N = 1 line "
+                                   "cannot issue from inside a launch, so mgs_mode auto runs the low-synchronisation form here (2 all-reduces per iteration, "
+                                   "basis read twice).  The like-for-like single-GPU rate for efficiency accounting is the N = 1 line's `mgs2_lowsync` leg, "
+                                   "not its headline value")
         if unbracketed:
             out["without_event_bracketing"] = unbracketed
         if other_leg:
