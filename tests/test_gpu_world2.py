@@ -87,6 +87,13 @@ def test_world2_eigsolve_gmres_cg(tmp_path):
     assert reps[0]["gmres"] == reps[1]["gmres"] and reps[0]["cg"] == reps[1]["cg"]
 
 
+def test_world2_bicgstab_lsmr_exponentiate(tmp_path):
+    """the short-recurrence solvers and the exponential integrator on local blocks: equal iteration / operation counts on
+    both ranks and against the serial oracle (LSMR through the all-gather / reduce-scatter map)"""
+    reps = run_world("solvers2", 2, tmp_path)
+    assert reps[0]["bicgstab"] == reps[1]["bicgstab"] and reps[0]["lsmr"] == reps[1]["lsmr"] and reps[0]["exponentiate"] == reps[1]["exponentiate"]
+
+
 def test_world2_collective_create_rejects_bad_input_on_all_ranks(tmp_path):
     """kk_csr_create_sharded agrees on the local validation status before its first data collective"""
     reps = run_world("bad_input", 2, tmp_path, timeout=200)

@@ -280,6 +280,45 @@ elif scenario == "solvers":
     xcg = gather_rows("cg_x", np.asarray(xc))
     assert cinfo.converged == 1 and np.linalg.norm(As @ xcg - b) < 2e-9 * np.linalg.norm(b)
     report["cg"] = [cinfo.numiter, cinfo.numops]
+elif scenario == "solvers2":
+    # SURVEY 8(f)-3/4 on local blocks: BiCGStab (device-resident rho / sigma / alpha / omega, two fused applies per iteration),
+    # LSMR on the row-sharded rectangular map (all-gather / reduce-scatter per iteration), exponentiate (Lanczos expand! + restarts)
+    nx, ny = 32, 24 + world
+    n = nx * ny
+    Bm = ko.convection_diffusion_2d(nx, ny)
+    part = kd.Partition(uneven_offsets(n, 9), rank)
+    lo, hi = part.lo, part.hi
+    b = np.random.default_rng(4).random(n)
+    tol = 1e-9 * np.linalg.norm(b)
+    opB = kd.NativeShardedOperator(Bm[lo:hi], part, ctx)
+    x, binfo = kk.linsolve_bicgstab(opB, b[lo:hi], None, kk.BiCGStab(500, tol), 0.3, 0.9)
+    xo, boinfo = ko.bicgstab(Bm, b, None, 0.3, 0.9, maxiter=500, tol=tol)
+    assert binfo.converged == 1 and (binfo.numiter, binfo.numops) == (boinfo.numiter, boinfo.numops), (binfo, boinfo)
+    xg = gather_rows("bicg_x", np.asarray(x))
+    assert np.linalg.norm(0.3 * xg + 0.9 * (Bm @ xg) - b) < 2 * tol
+    report["bicgstab"] = [binfo.numiter, binfo.numops]
+    Ar = ko.sparse_random(600, 250, 8, 21)
+    offs = uneven_offsets(600, 21)
+    r0, r1 = int(offs[rank]), int(offs[rank + 1])
+    opR = kd.NativeShardedRectOperator(Ar[r0:r1], 250, ctx)
+    br = np.random.default_rng(7).random(600)
+    ltol = 1e-10 * np.linalg.norm(br)
+    xl, linfo = kk.lssolve(opR, br[r0:r1], kk.LSMR(kk.ModifiedGramSchmidt2(), 400, 10, ltol), 0.1)
+    xlo, loinfo = ko.lsmr(Ar, br, 0.1, krylovdim=10, maxiter=400, tol=ltol, orth=ko.MGS2)
+    assert (linfo.converged, linfo.numiter, linfo.numops) == (loinfo.converged, loinfo.numiter, loinfo.numops), (linfo, loinfo)
+    shard = -(-250 // world)
+    xlg = gather_rows("lsmr_x", np.asarray(xl))
+    assert xlg.shape == (250,) and np.linalg.norm(xlg - xlo) <= 1e-8 * np.linalg.norm(xlo)
+    report["lsmr"] = [linfo.numiter, linfo.numops]
+    A = ko.laplacian_2d(nx, ny, shift_diag=10 * np.linspace(0, 1, n) ** 2)
+    opA = kd.NativeShardedOperator(A[lo:hi], part, ctx, symmetric=True)
+    v = np.random.default_rng(8).random(n)
+    w, einfo = kk.exponentiate(opA, -0.4, v[lo:hi], kk.Lanczos(kk.ModifiedGramSchmidt2(), 20, 100, 1e-11))
+    wo, eoinfo = ko.expintegrator(A, -0.4, (v,), krylovdim=20, maxiter=100, tol=1e-11, orth=ko.MGS2, method="lanczos")
+    wg = gather_rows("expm_w", np.asarray(w))
+    assert einfo.converged == 1 and (einfo.numiter, einfo.numops) == (eoinfo.numiter, eoinfo.numops)
+    assert np.linalg.norm(wg - wo) <= 1e-9 * np.linalg.norm(wo)
+    report["exponentiate"] = [einfo.numiter, einfo.numops]
 elif scenario == "bad_input":
     # a collective create call with bad input on ONE rank: every rank must come back with an error (nobody left waiting)
     import ctypes as C
