@@ -268,11 +268,14 @@ static int detect_stencil_sharded(const kk_host_csr& h, int64_t n_local, kk_spar
 static int upload_sparse(kk_ctx c, const kk_host_csr& h, kk_sparse_dev& M) {
     const int64_t nrows = h.nrows, nnz = h.rowptr[nrows];
     M.nrows = nrows; M.ncols = h.ncols; M.nnz = nnz;
-    KK_CHECK(nnz < (int64_t)1 << 31, KK_ERR_UNSUPPORTED, "nnz >= 2^31 not supported (int32 row pointers on device)");
+    // dimensions stay below 2^31 (int32 column indices on the device); the number of stored entries does not: every element
+    // offset of the ELL / SELL / tiled / diagonal images is 64-bit on the host and in the kernels.  Only the plain CSR image
+    // (KK_SPMV_FORMAT=csr, a debugging format) keeps int32 row pointers.
     KK_CHECK(h.ncols < (int64_t)1 << 31 && nrows < (int64_t)1 << 31, KK_ERR_UNSUPPORTED, "dimension >= 2^31 not supported");
     int64_t maxw = 0;
     for (int64_t i = 0; i < nrows; ++i) maxw = std::max(maxw, h.rowptr[i + 1] - h.rowptr[i]);
     const bool force_csr = getenv("KK_SPMV_FORMAT") && !strcmp(getenv("KK_SPMV_FORMAT"), "csr");
+    KK_CHECK(!force_csr || nnz < (int64_t)1 << 31, KK_ERR_UNSUPPORTED, "KK_SPMV_FORMAT=csr: nnz >= 2^31 not supported (int32 row pointers)");
     const bool force_ell = getenv("KK_SPMV_FORMAT") && !strcmp(getenv("KK_SPMV_FORMAT"), "ell");
     const bool force_sell = getenv("KK_SPMV_FORMAT") && !strcmp(getenv("KK_SPMV_FORMAT"), "sell");
     const bool ell = !force_csr && !force_sell && (force_ell || (maxw <= 64 && (double)maxw * nrows <= 1.25 * (double)nnz + 4096));
@@ -355,8 +358,8 @@ KK_API int kk_csr_create(kk_ctx c, int64_t nrows, int64_t ncols, int64_t nnz, co
     KK_CHECK(nrows > 0 && ncols > 0 && nnz >= 0, KK_ERR_INVALID, "kk_csr_create: bad dimensions");
     KK_CHECK(index_base == 0 || index_base == 1, KK_ERR_INVALID, "index_base must be 0 or 1");
     KK_TRY(check_ptr_array("kk_csr_create", rowptr, nrows, nnz, index_base));
-    KK_CHECK(nnz < (int64_t)1 << 31 && nrows < (int64_t)1 << 31 && ncols < (int64_t)1 << 31, KK_ERR_UNSUPPORTED,
-             "kk_csr_create: nnz / dimensions >= 2^31 are not supported (int32 indices on the device)");
+    KK_CHECK(nrows < (int64_t)1 << 31 && ncols < (int64_t)1 << 31, KK_ERR_UNSUPPORTED,
+             "kk_csr_create: dimensions >= 2^31 are not supported (int32 column indices on the device)");
     KK_HIP(hipSetDevice(c->device));
     kk_op op = new kk_op_s();
     op->ctx = c; op->nrows = nrows; op->ncols = ncols; op->nnz = nnz; op->flags = flags;
@@ -387,8 +390,8 @@ KK_API int kk_csc_create(kk_ctx c, int64_t nrows, int64_t ncols, int64_t nnz, co
     KK_CHECK(nrows > 0 && ncols > 0 && nnz >= 0, KK_ERR_INVALID, "kk_csc_create: bad dimensions");
     KK_CHECK(index_base == 0 || index_base == 1, KK_ERR_INVALID, "index_base must be 0 or 1");
     KK_TRY(check_ptr_array("kk_csc_create", colptr, ncols, nnz, index_base));
-    KK_CHECK(nnz < (int64_t)1 << 31 && nrows < (int64_t)1 << 31 && ncols < (int64_t)1 << 31, KK_ERR_UNSUPPORTED,
-             "kk_csc_create: nnz / dimensions >= 2^31 are not supported (int32 indices on the device)");
+    KK_CHECK(nrows < (int64_t)1 << 31 && ncols < (int64_t)1 << 31, KK_ERR_UNSUPPORTED,
+             "kk_csc_create: dimensions >= 2^31 are not supported (int32 row indices on the device)");
     KK_HIP(hipSetDevice(c->device));
     // the CSC arrays of A are the CSR arrays of A'
     kk_host_csr ht;
@@ -496,7 +499,7 @@ KK_API int kk_csr_create_sharded(kk_ctx c, int64_t nrows_local, const int64_t* r
         std::sort(needed.begin(), needed.end());
         needed.erase(std::unique(needed.begin(), needed.end()), needed.end());
         n_ghost = (int64_t)needed.size();
-        KK_CHECK(nrows_local + n_ghost < (int64_t)1 << 31 && nnz < (int64_t)1 << 31, KK_ERR_UNSUPPORTED,
+        KK_CHECK(nrows_local + n_ghost < (int64_t)1 << 31, KK_ERR_UNSUPPORTED,
                  "kk_csr_create_sharded: local block too large for int32 indices");
         for (int64_t g : needed) {
             const int q = (int)(std::upper_bound(row_offsets, row_offsets + world + 1, g) - row_offsets) - 1;
@@ -613,7 +616,7 @@ KK_API int kk_csr_create_sharded_rect(kk_ctx c, int64_t nrows_local, int64_t nco
     const int64_t n_loc = std::max<int64_t>(0, std::min(shard, ncols_global - rank * shard));
     KK_CHECK(n_loc > 0, KK_ERR_DIM, "kk_csr_create_sharded_rect: rank %d owns no columns (%lld columns over %d ranks)", rank,
              (long long)ncols_global, world);
-    KK_CHECK(full < (int64_t)1 << 31 && nnz < (int64_t)1 << 31 && nrows_local < (int64_t)1 << 31, KK_ERR_UNSUPPORTED,
+    KK_CHECK(full < (int64_t)1 << 31 && nrows_local < (int64_t)1 << 31, KK_ERR_UNSUPPORTED,
              "kk_csr_create_sharded_rect: local block too large for int32 indices");
     KK_HIP(hipSetDevice(c->device));
     kk_op op = new kk_op_s();

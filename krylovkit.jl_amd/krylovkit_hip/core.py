@@ -384,6 +384,25 @@ class SparseOperator:
         self.handle = h
         self.nnz = int(A.nnz)
 
+    @classmethod
+    def from_csr_arrays(cls, shape, rowptr, col, val, ctx: Optional[Context] = None, symmetric: bool = False):
+        """kk_csr_create on caller-built arrays (0-based int64 row pointers, int32 columns, f64 values) -- no scipy object in
+        between; what a host with more than 2^31 stored entries uses"""
+        self = cls.__new__(cls)
+        self.ctx = ctx or default_context()
+        self._lib = self.ctx._lib
+        self.shape = tuple(shape)
+        self.symmetric = bool(symmetric)
+        rowptr = np.ascontiguousarray(rowptr, dtype=np.int64)
+        col = np.ascontiguousarray(col, dtype=np.int32)
+        val = np.ascontiguousarray(val, dtype=np.float64)
+        h = C.c_void_p()
+        check(self._lib.kk_csr_create(self.ctx.handle, shape[0], shape[1], int(rowptr[-1]), rowptr.ctypes.data_as(_lib.c_i64p),
+                                      col.ctypes.data_as(_lib.c_i32p), _dp(val), 0, _lib.KK_OP_SYMMETRIC if symmetric else 0, C.byref(h)))
+        self.handle = h
+        self.nnz = int(rowptr[-1])
+        return self
+
     def free(self):
         if getattr(self, "handle", None):
             self._lib.kk_op_free(self.handle)
