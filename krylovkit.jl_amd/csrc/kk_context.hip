@@ -183,7 +183,7 @@ KK_API int kk_ctx_set_option(kk_ctx c, const char* key, double value) {
     } else if (!strcmp(key, "spmv_dia_const")) {
         c->spmv_dia_const = value != 0;
     } else if (!strcmp(key, "spmv_dia_pairs")) {
-        KK_CHECK(value == 1 || value == 2, KK_ERR_INVALID, "spmv_dia_pairs must be 1 or 2");
+        KK_CHECK(value == 0 || value == 1 || value == 2 || value == 4, KK_ERR_INVALID, "spmv_dia_pairs must be 0 (by size), 1, 2 or 4");
         c->spmv_dia_pairs = (int)value;
     } else if (!strcmp(key, "spmm_dia")) {
         c->spmm_dia = value != 0;

@@ -114,7 +114,7 @@ struct kk_ctx_s {
     int spmm_bpc = 4;            // resident blocks per CU of the multi-column sparse apply (L2 window, see kk_launch_spmm); 0 = fill the chip
     int spmm_rpl = 2;            // SpMM on ELL: rows per lane (1 or 2)
     int spmv_dia = 1;            // single-column apply of a detected grid stencil: diagonal kernel (0: ELL gather kernel)
-    int spmv_dia_pairs = 1;      // ... row pairs per lane (1 or 2)
+    int spmv_dia_pairs = 0;      // row pairs per lane of k_spmv_dia: 0 = by size, or 1 / 2 / 4 (4: value-free form only)
     int spmv_dia_const = 1;      // ... value-free kernel when the stencil has constant coefficients (0: always stream the diagonals)
     int spmm_dia = 1;            // multi-column apply of a detected grid stencil: sweeping diagonal kernel (0: ELL gather kernel)
     int spmm_dia_lines = 16;     // ... grid lines per wave sweep

@@ -41,9 +41,14 @@ struct spmv_epi {
                          // (y += raw sums), 3 = last tile (sum = y + raw, then the epilogue)
 };
 
+// gathered element of x; column indices >= n_local address the ghost buffer.  BRANCH-FREE (the address is selected, the
+// load is unconditional): with `if (ghost) return ghost[..]; return x[c];` every gather sits in its own basic block and
+// hipcc waits for it (`s_waitcnt vmcnt(0)`) before the next one is issued -- the gathers of an unrolled group then take
+// one memory round trip EACH instead of one together.
 __device__ __forceinline__ double xload(const double* __restrict__ x, const spmv_epi& e, int c) {
-    if (e.n_local >= 0 && c >= e.n_local) return e.ghost[c - e.n_local];
-    return x[c];
+    const bool g = e.n_local >= 0 && c >= e.n_local;
+    const double* p = g ? e.ghost + (c - e.n_local) : x + c;
+    return *p;
 }
 
 __global__ __launch_bounds__(KK_TPB) void k_spmv_ell(const int32_t* __restrict__ ecol, const double* __restrict__ eval,
@@ -70,11 +75,22 @@ __global__ __launch_bounds__(KK_TPB) void k_spmv_ell(const int32_t* __restrict__
             double s0 = 0, s1 = 0;
             const int32_t* cp = ecol + row;
             const double* vp = eval + row;
-            for (int k = 0; k < width; ++k) {
+            int k = 0;
+            for (; k + 4 <= width; k += 4) {   // four slots at a time: 8 matrix loads, then 8 gathers, then the products (slot order)
+                int2 cc[4]; d2 v[4]; double xa[4], xb[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { cc[u] = ldi2s(cp + (int64_t)(k + u) * ell_ld); v[u] = ld2s(vp + (int64_t)(k + u) * ell_ld); }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { xa[u] = xload(x, e, cc[u].x); xb[u] = xload(x, e, cc[u].y); }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { s0 = fma(v[u].x, xa[u], s0); s1 = fma(v[u].y, xb[u], s1); }
+            }
+            for (; k < width; ++k) {
                 const int2 cc = ldi2s(cp + (int64_t)k * ell_ld);
                 const d2 v = ld2s(vp + (int64_t)k * ell_ld);
-                s0 = fma(v.x, xload(x, e, cc.x), s0);
-                s1 = fma(v.y, xload(x, e, cc.y), s1);
+                const double xa = xload(x, e, cc.x), xb = xload(x, e, cc.y);
+                s0 = fma(v.x, xa, s0);
+                s1 = fma(v.y, xb, s1);
             }
             s0 *= xs; s1 *= xs;
             d2 out{e.a1 * s0, e.a1 * s1};
@@ -110,12 +126,16 @@ __global__ __launch_bounds__(KK_TPB) void k_spmv_ell(const int32_t* __restrict__
 // row for a 5-point operator), the neighbours are shifted contiguous loads instead of gathers; same XCD banding, same fused
 // epilogue as k_spmv_ell.
 struct dia_offs { int64_t o[9]; };
+// One pair x[idx], x[idx+1] of a shifted diagonal read, BRANCH-FREE: an index outside [0, nrows) reads x[0] instead and the
+// value is replaced by 0 afterwards.  (Round 2 / 3 tested the range first and loaded inside the branches: hipcc then puts
+// `s_waitcnt vmcnt(0)` behind every one of those loads -- five dependent memory round trips per block iteration, which
+// capped the constant-coefficient apply at 2.6-2.8 TB/s as soon as the vectors no longer fit the Infinity Cache,
+// tools/stencil_shape_sweep.py.)  Every load of an iteration is issued before the first value is used.
 __device__ __forceinline__ d2 dia_pair(const double* __restrict__ x, int64_t idx, int64_t nrows) {
-    if (!(idx & 1) && idx >= 0 && idx + 1 < nrows) return ld2(x + idx);   // idx parity is uniform over the grid (row is even)
-    d2 v;
-    v.x = (idx >= 0 && idx < nrows) ? x[idx] : 0.0;
-    v.y = (idx + 1 >= 0 && idx + 1 < nrows) ? x[idx + 1] : 0.0;
-    return v;
+    const bool ok0 = (unsigned long long)idx < (unsigned long long)nrows;
+    const bool ok1 = (unsigned long long)(idx + 1) < (unsigned long long)nrows;
+    const double a = x[ok0 ? idx : 0], b = x[ok1 ? idx + 1 : 0];
+    return d2{ok0 ? a : 0.0, ok1 ? b : 0.0};
 }
 // CONST: constant-coefficient stencil (kk_sparse_dev::dia_const) -- the coefficient of slot q is cst.c[q] wherever the
 // neighbour sits on the same grid line, 0 where a +-1 shift would wrap to the next line; no diagonal is read at all.
@@ -130,6 +150,7 @@ __global__ __launch_bounds__(KK_TPB) void k_spmv_dia(const double* __restrict__ 
     const int per = (nb_logical + 7) >> 3;
     const int nbx = gridDim.x >> 3;
     const int xcd = blockIdx.x & 7;
+    constexpr int QC = PTS / 2;          // the middle slot is the main diagonal
     double dacc = 0, nacc = 0;
     const double xs = e.xs_dev ? *e.xs_dev : 1.0;
     const double bp = e.vprev ? (e.bprev_dev ? *e.bprev_dev : e.bprev) : 0.0;
@@ -137,53 +158,62 @@ __global__ __launch_bounds__(KK_TPB) void k_spmv_dia(const double* __restrict__ 
         const int lb = xcd * per + c;
         if (lb >= nb_logical) break;
         const int64_t row0 = row_base + ((int64_t)lb * U * KK_TPB + threadIdx.x) * 2;
-        double s0[U], s1[U];
-        d2 xc[U];
-        int64_t ix0[U];   // CONST: position of the first row of the pair inside its grid line
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            s0[u] = 0; s1[u] = 0; xc[u] = d2{0.0, 0.0};
-            // rows and D are below 2^31 (int32 device indices): a 32-bit remainder instead of the 64-bit software division
-            ix0[u] = CONST ? (int64_t)((unsigned)(row0 + (int64_t)u * 2 * KK_TPB + cst.phase) % (unsigned)cst.D) : 0;
-        }
-#pragma unroll
-        for (int q = 0; q < PTS; ++q) {
-            const int bq = PTS == 5 ? (q == 1 ? -1 : (q == 3 ? 1 : 0)) : q % 3 - 1;   // shift inside the grid line
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int64_t row = row0 + (int64_t)u * 2 * KK_TPB;
-                if (row < row_end) {   // dia_ld is even and >= nrows; pad entries are 0
-                    d2 v;
-                    if (CONST) {
-                        const int64_t i0 = ix0[u], i1 = (i0 + 1 == cst.D) ? 0 : i0 + 1;
-                        v.x = (bq < 0 && i0 == 0) || (bq > 0 && i0 == cst.D - 1) ? 0.0 : cst.c[q];
-                        v.y = (bq < 0 && i1 == 0) || (bq > 0 && i1 == cst.D - 1) ? 0.0 : cst.c[q];
-                    } else {
-                        v = ld2s(dval + (int64_t)q * dld + row);
-                    }
-                    const d2 xv = dia_pair(x, row + offs.o[q], nrows);
-                    if (q == PTS / 2) xc[u] = xv;              // the middle slot is the main diagonal
-                    s0[u] = fma(v.x, xv.x, s0[u]);
-                    s1[u] = fma(v.y, xv.y, s1[u]);
-                }
-            }
-        }
+        // ---- phase 1: every load of this iteration (a lane whose rows lie beyond row_end loads row 0 and stores nothing)
+        d2 xv[U][PTS], dv[U][CONST ? 1 : PTS], pv[U], zv[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t row = row0 + (int64_t)u * 2 * KK_TPB;
-            if (row < row_end) {
-                const double t0 = s0[u] * xs, t1 = s1[u] * xs;
-                d2 out{e.a1 * t0, e.a1 * t1};
-                const d2 xv{xc[u].x * xs, xc[u].y * xs};
-                if (e.a0 != 0.0) { out.x = fma(e.a0, xv.x, out.x); out.y = fma(e.a0, xv.y, out.y); }
-                if (e.dot_mode == 1) { dacc = fma(xv.x, out.x, dacc); dacc = fma(xv.y, out.y, dacc); }
-                if (e.vprev) {
-                    const d2 p = ld2(e.vprev + row);
-                    out.x = fma(-bp, p.x, out.x); out.y = fma(-bp, p.y, out.y);
+            const int64_t rl = row < row_end ? row : 0;      // dia_ld, ld are even and >= nrows: the pair (rl, rl + 1) is inside the arrays
+            xv[u][QC] = ld2(x + rl);                         // centre pair: aligned (row is even); pad rows hold zeros
+#pragma unroll
+            for (int q = 0; q < PTS; ++q) {
+                if (q == QC) continue;
+                // the +-1 neighbours inside the line share one element with the centre pair: one new load each
+                if (q == QC - 1) { const bool ok = rl >= 1; const double a = x[ok ? rl - 1 : 0]; xv[u][q] = d2{ok ? a : 0.0, 0.0}; }
+                else if (q == QC + 1) { const bool ok = rl + 2 < nrows; const double b = x[ok ? rl + 2 : 0]; xv[u][q] = d2{0.0, ok ? b : 0.0}; }
+                else xv[u][q] = dia_pair(x, rl + offs.o[q], nrows);
+            }
+            if (!CONST) {
+#pragma unroll
+                for (int q = 0; q < PTS; ++q) dv[u][q] = ld2s(dval + (int64_t)q * dld + rl);
+            }
+            pv[u] = e.vprev ? ld2(e.vprev + rl) : d2{0.0, 0.0};
+            zv[u] = e.dot_mode == 3 ? ld2(e.dvec + rl) : d2{0.0, 0.0};
+        }
+        // ---- phase 2: products in slot order (the order of round 2: bit-identical results), epilogue, store
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t row = row0 + (int64_t)u * 2 * KK_TPB;
+            xv[u][QC - 1].y = xv[u][QC].x;                   // x[row] is the right element of the "-1" pair ...
+            xv[u][QC + 1].x = xv[u][QC].y;                   // ... and x[row + 1] the left element of the "+1" pair
+            if (row + 1 >= nrows) { xv[u][QC + 1].x = 0.0; } // (row + 1 outside the operator: the old range test gave 0; the pad row holds 0 anyway)
+            double s0 = 0, s1 = 0;
+            // CONST: position of the first row of the pair inside its grid line (rows and D are below 2^31: 32-bit remainder)
+            const int64_t i0 = CONST ? (int64_t)((unsigned)(row + cst.phase) % (unsigned)cst.D) : 0;
+            const int64_t i1 = (i0 + 1 == cst.D) ? 0 : i0 + 1;
+#pragma unroll
+            for (int q = 0; q < PTS; ++q) {
+                const int bq = PTS == 5 ? (q == 1 ? -1 : (q == 3 ? 1 : 0)) : q % 3 - 1;   // shift inside the grid line
+                d2 v;
+                if (CONST) {
+                    v.x = (bq < 0 && i0 == 0) || (bq > 0 && i0 == cst.D - 1) ? 0.0 : cst.c[q];
+                    v.y = (bq < 0 && i1 == 0) || (bq > 0 && i1 == cst.D - 1) ? 0.0 : cst.c[q];
+                } else {
+                    v = dv[u][q];
                 }
+                s0 = fma(v.x, xv[u][q].x, s0);
+                s1 = fma(v.y, xv[u][q].y, s1);
+            }
+            if (row < row_end) {
+                const double t0 = s0 * xs, t1 = s1 * xs;
+                d2 out{e.a1 * t0, e.a1 * t1};
+                const d2 xc{xv[u][QC].x * xs, xv[u][QC].y * xs};
+                if (e.a0 != 0.0) { out.x = fma(e.a0, xc.x, out.x); out.y = fma(e.a0, xc.y, out.y); }
+                if (e.dot_mode == 1) { dacc = fma(xc.x, out.x, dacc); dacc = fma(xc.y, out.y, dacc); }
+                if (e.vprev) { out.x = fma(-bp, pv[u].x, out.x); out.y = fma(-bp, pv[u].y, out.y); }
                 if (row + 1 >= nrows) out.y = 0.0;  // odd nrows: keep the pad row zero
-                if (e.dot_mode == 2) { dacc = fma(xv.x, out.x, dacc); dacc = fma(xv.y, out.y, dacc); }
-                if (e.dot_mode == 3) { const d2 z = ld2(e.dvec + row); dacc = fma(z.x, out.x, dacc); dacc = fma(z.y, out.y, dacc); }
+                if (e.dot_mode == 2) { dacc = fma(xc.x, out.x, dacc); dacc = fma(xc.y, out.y, dacc); }
+                if (e.dot_mode == 3) { dacc = fma(zv[u].x, out.x, dacc); dacc = fma(zv[u].y, out.y, dacc); }
                 if (e.want_nrm) { nacc = fma(out.x, out.x, nacc); nacc = fma(out.y, out.y, nacc); }
                 st2(y + row, out);
             }
@@ -265,10 +295,11 @@ __global__ __launch_bounds__(KK_TPB) void k_spmv_sell(const int64_t* __restrict_
         for (; k + 4 <= w; k += 4) {
             const int c0 = ldc(cp + (k + 0) * 64), c1 = ldc(cp + (k + 1) * 64), c2 = ldc(cp + (k + 2) * 64), c3 = ldc(cp + (k + 3) * 64);
             const double v0 = ldv(vp + (k + 0) * 64), v1 = ldv(vp + (k + 1) * 64), v2 = ldv(vp + (k + 2) * 64), v3 = ldv(vp + (k + 3) * 64);
-            s0 = fma(v0, xload(x, e, c0), s0);
-            s1 = fma(v1, xload(x, e, c1), s1);
-            s0 = fma(v2, xload(x, e, c2), s0);
-            s1 = fma(v3, xload(x, e, c3), s1);
+            const double x0 = xload(x, e, c0), x1 = xload(x, e, c1), x2 = xload(x, e, c2), x3 = xload(x, e, c3);
+            s0 = fma(v0, x0, s0);
+            s1 = fma(v1, x1, s1);
+            s0 = fma(v2, x2, s0);
+            s1 = fma(v3, x3, s1);
         }
         for (; k < w; ++k) s0 = fma(ldv(vp + k * 64), xload(x, e, ldc(cp + k * 64)), s0);
         const int row = perm[c * 64 + lane];
@@ -347,10 +378,11 @@ __global__ __launch_bounds__(KK_TPB) void k_spmv_sellw(const int64_t* __restrict
             for (; k + 4 <= w; k += 4) {
                 const int c0 = ldc(cp + (k + 0) * 64), c1 = ldc(cp + (k + 1) * 64), c2 = ldc(cp + (k + 2) * 64), c3 = ldc(cp + (k + 3) * 64);
                 const double v0 = ldv(vp + (k + 0) * 64), v1 = ldv(vp + (k + 1) * 64), v2 = ldv(vp + (k + 2) * 64), v3 = ldv(vp + (k + 3) * 64);
-                s0 = fma(v0, xload(x, e, c0), s0);
-                s1 = fma(v1, xload(x, e, c1), s1);
-                s0 = fma(v2, xload(x, e, c2), s0);
-                s1 = fma(v3, xload(x, e, c3), s1);
+                const double x0 = xload(x, e, c0), x1 = xload(x, e, c1), x2 = xload(x, e, c2), x3 = xload(x, e, c3);
+                s0 = fma(v0, x0, s0);
+                s1 = fma(v1, x1, s1);
+                s0 = fma(v2, x2, s0);
+                s1 = fma(v3, x3, s1);
             }
             for (; k < w; ++k) s0 = fma(ldv(vp + k * 64), xload(x, e, ldc(cp + k * 64)), s0);
             if (prow >= 0) res[prow - win * KK_TPB] = s0 + s1;
@@ -415,14 +447,23 @@ __global__ __launch_bounds__(KK_TPB) void k_spmm_ell(const int32_t* __restrict__
             for (int k = 0; k < width; ++k) {
                 const int2 cc = ldi2s(ecol + (int64_t)k * ell_ld + row);
                 const d2 v = ld2s(eval + (int64_t)k * ell_ld + row);
+                // branch-free gathers (address selected, load unconditional; columns j >= nb re-read column nb - 1 and their sums
+                // are never stored): all 2 NB loads of a slot are in flight together -- see xload()
+                const bool g0 = n_local >= 0 && cc.x >= n_local, g1 = n_local >= 0 && cc.y >= n_local;
+                const double* b0 = g0 ? G + (cc.x - n_local) : X + cc.x;
+                const double* b1 = g1 ? G + (cc.y - n_local) : X + cc.y;
+                const int64_t st0 = g0 ? ldg : ldx, st1 = g1 ? ldg : ldx;
+                double x0[NB], x1[NB];
 #pragma unroll
                 for (int j = 0; j < NB; ++j) {
-                    if (j < nb) {
-                        const double x0 = (n_local < 0 || cc.x < n_local) ? X[(int64_t)j * ldx + cc.x] : G[(int64_t)j * ldg + (cc.x - n_local)];
-                        const double x1 = (n_local < 0 || cc.y < n_local) ? X[(int64_t)j * ldx + cc.y] : G[(int64_t)j * ldg + (cc.y - n_local)];
-                        acc[j].x = fma(v.x, x0, acc[j].x);
-                        acc[j].y = fma(v.y, x1, acc[j].y);
-                    }
+                    const int jj = j < nb ? j : nb - 1;
+                    x0[j] = b0[(int64_t)jj * st0];
+                    x1[j] = b1[(int64_t)jj * st1];
+                }
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    acc[j].x = fma(v.x, x0[j], acc[j].x);
+                    acc[j].y = fma(v.y, x1[j], acc[j].y);
                 }
             }
             const bool last_odd = (row + 1 >= nrows);
@@ -440,13 +481,14 @@ __global__ __launch_bounds__(KK_TPB) void k_spmm_ell(const int32_t* __restrict__
             for (int k = 0; k < width; ++k) {
                 const int cc = __builtin_nontemporal_load(ecol + (int64_t)k * ell_ld + row);
                 const double v = __builtin_nontemporal_load(eval + (int64_t)k * ell_ld + row);
+                const bool g0 = n_local >= 0 && cc >= n_local;
+                const double* b0 = g0 ? G + (cc - n_local) : X + cc;
+                const int64_t st0 = g0 ? ldg : ldx;
+                double x0[NB];
 #pragma unroll
-                for (int j = 0; j < NB; ++j) {
-                    if (j < nb) {
-                        const double x0 = (n_local < 0 || cc < n_local) ? X[(int64_t)j * ldx + cc] : G[(int64_t)j * ldg + (cc - n_local)];
-                        acc[j] = fma(v, x0, acc[j]);
-                    }
-                }
+                for (int j = 0; j < NB; ++j) x0[j] = b0[(int64_t)(j < nb ? j : nb - 1) * st0];
+#pragma unroll
+                for (int j = 0; j < NB; ++j) acc[j] = fma(v, x0[j], acc[j]);
             }
 #pragma unroll
             for (int j = 0; j < NB; ++j)
@@ -558,7 +600,12 @@ static void launch_spmv_ell_rows(kk_ctx ctx, const kk_sparse_dev& M, const doubl
 static void launch_spmv_dia_rows(kk_ctx ctx, const kk_sparse_dev& M, const double* x, double* y, const spmv_epi& e, int64_t r0,
                                  int64_t r1, double* pd, double* pn, int* nblk_io, int max_blocks) {
     if (r1 <= r0) return;
-    const int U = ctx->spmv_dia_pairs == 2 ? 2 : 1;
+    const bool cc = M.dia_const && ctx->spmv_dia_const;
+    // row pairs per lane: 1 / 2 (/ 4 for the value-free form, whose lanes carry no diagonal values)
+    // 0 = by size (tools/stencil_shape_sweep.py): one pair while the vectors fit the Infinity Cache and the launch is short (more
+    // waves, shorter tail), the deepest form from 3e7 rows on, where the bytes in flight per CU are what sets the rate
+    const int want = ctx->spmv_dia_pairs > 0 ? ctx->spmv_dia_pairs : (r1 - r0 >= 30000000 ? 4 : 1);
+    const int U = want >= 4 ? (cc ? 4 : 2) : (want == 2 ? 2 : 1);
     const int nb_logical = (int)((r1 - r0 + 2 * U * KK_TPB - 1) / (2 * U * KK_TPB));
     const int per = (nb_logical + 7) / 8;
     const int nbx = std::max(1, std::min(per, max_blocks / 8));
@@ -570,14 +617,19 @@ static void launch_spmv_dia_rows(kk_ctx ctx, const kk_sparse_dev& M, const doubl
     dia_cst cst;
     for (int q = 0; q < 9; ++q) cst.c[q] = M.dia_c[q];
     cst.phase = M.dia_phase; cst.D = D;
-    const bool cc = M.dia_const && ctx->spmv_dia_const;
 #define SPMV_DIA_ARGS dim3(nblk), dim3(KK_TPB), 0, ctx->stream, M.dia_val, M.dia_ld, of, M.nrows, x, y, e, nb_logical, pd + *nblk_io, pn + *nblk_io, r0, r1, cst
     if (M.dia_pts == 5) {
-        if (cc) { if (U == 2) hipLaunchKernelGGL((k_spmv_dia<5, 2, true>), SPMV_DIA_ARGS); else hipLaunchKernelGGL((k_spmv_dia<5, 1, true>), SPMV_DIA_ARGS); }
-        else { if (U == 2) hipLaunchKernelGGL((k_spmv_dia<5, 2, false>), SPMV_DIA_ARGS); else hipLaunchKernelGGL((k_spmv_dia<5, 1, false>), SPMV_DIA_ARGS); }
+        if (cc) {
+            if (U == 4) hipLaunchKernelGGL((k_spmv_dia<5, 4, true>), SPMV_DIA_ARGS);
+            else if (U == 2) hipLaunchKernelGGL((k_spmv_dia<5, 2, true>), SPMV_DIA_ARGS);
+            else hipLaunchKernelGGL((k_spmv_dia<5, 1, true>), SPMV_DIA_ARGS);
+        } else { if (U == 2) hipLaunchKernelGGL((k_spmv_dia<5, 2, false>), SPMV_DIA_ARGS); else hipLaunchKernelGGL((k_spmv_dia<5, 1, false>), SPMV_DIA_ARGS); }
     } else {
-        if (cc) { if (U == 2) hipLaunchKernelGGL((k_spmv_dia<9, 2, true>), SPMV_DIA_ARGS); else hipLaunchKernelGGL((k_spmv_dia<9, 1, true>), SPMV_DIA_ARGS); }
-        else { if (U == 2) hipLaunchKernelGGL((k_spmv_dia<9, 2, false>), SPMV_DIA_ARGS); else hipLaunchKernelGGL((k_spmv_dia<9, 1, false>), SPMV_DIA_ARGS); }
+        if (cc) {
+            if (U == 4) hipLaunchKernelGGL((k_spmv_dia<9, 4, true>), SPMV_DIA_ARGS);
+            else if (U == 2) hipLaunchKernelGGL((k_spmv_dia<9, 2, true>), SPMV_DIA_ARGS);
+            else hipLaunchKernelGGL((k_spmv_dia<9, 1, true>), SPMV_DIA_ARGS);
+        } else { if (U == 2) hipLaunchKernelGGL((k_spmv_dia<9, 2, false>), SPMV_DIA_ARGS); else hipLaunchKernelGGL((k_spmv_dia<9, 1, false>), SPMV_DIA_ARGS); }
     }
 #undef SPMV_DIA_ARGS
     *nblk_io += nblk;

@@ -29,4 +29,4 @@ for name, opts, nbytes in (("ELL gather", dict(spmv_dia=0), 84), ("diagonals str
         ms = ctx.timer_stop() / 50
         print(json.dumps({"kernel": name, "apply": label, "ms": round(ms, 4), "bytes_per_row": nbytes - (8 if label == "y = A x" else 8),
                           "GBps": round((nbytes - 8) * N / ms / 1e6, 1)}), flush=True)
-ctx.set_option("spmv_dia", 1); ctx.set_option("spmv_dia_const", 1); ctx.set_option("spmv_dia_pairs", 1)
+ctx.set_option("spmv_dia", 1); ctx.set_option("spmv_dia_const", 1); ctx.set_option("spmv_dia_pairs", 0)
