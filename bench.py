@@ -193,7 +193,7 @@ def parity_block(al_g, be_g, al_c, be_c):
 def kernel_source_sha() -> str:
     import hashlib
     h = hashlib.sha256()
-    for f in ("kk_kernels_stream.hip", "kk_kernels_persist.hip", "kk_device.h", "kk_internal.h"):
+    for f in ("kk_kernels_stream.hip", "kk_kernels_persist.hip", "kk_kernels_spmv.hip", "kk_device.h", "kk_internal.h"):
         h.update((ROOT / "krylovkit.jl_amd" / "csrc" / f).read_bytes())
     return h.hexdigest()[:16]
 
