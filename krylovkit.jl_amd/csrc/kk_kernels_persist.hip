@@ -169,7 +169,7 @@ __device__ __forceinline__ void fnma_inplace(double& x, double s, double p) {
 // pass (project + unproject read the basis twice), which is what lets the reference's sequential order overtake them.
 template <int NV, int NL, int NR, int PT, int B, bool NTPREV, bool NORM /* false: axpy + dot with q_next, true: axpy + squared norm */,
           bool PREV_LDS /* grid-rows < NL of q_prev come from LDS, the NR after them from registers */>
-__device__ __forceinline__ void persist_step(d2 (&wr)[NV], d2 (&qk)[NR > 0 ? NR : 1], __amdgpu_buffer_rsrc_t rp, __amdgpu_buffer_rsrc_t rn,
+__device__ __forceinline__ void persist_step(d2 (&wr)[NV], d2 (&qk)[NR > 0 ? NR : 1], d2 (&qpre)[B], __amdgpu_buffer_rsrc_t rp, __amdgpu_buffer_rsrc_t rn,
                                              double sp, unsigned sbytes, unsigned voff, d2* __restrict__ lq, double& a0, double& a1) {
 #pragma unroll
     for (int i0 = 0; i0 < NV; i0 += B) {
@@ -180,7 +180,7 @@ __device__ __forceinline__ void persist_step(d2 (&wr)[NV], d2 (&qk)[NR > 0 ? NR 
                 if (PREV_LDS && i0 + u < NL) p[u] = lq[(i0 + u) * PT];
                 else if (PREV_LDS && i0 + u < NL + NR) p[u] = qk[i0 + u - NL];
                 else p[u] = bload(rp, voff, (unsigned)(i0 + u) * sbytes, NTPREV);
-                if (!NORM) q[u] = bload(rn, voff, (unsigned)(i0 + u) * sbytes, false);
+                if (!NORM) q[u] = (i0 == 0) ? qpre[u] : bload(rn, voff, (unsigned)(i0 + u) * sbytes, false);   // batch 0 was requested before the grid reduction
             }
         }
 #pragma unroll
@@ -239,10 +239,25 @@ __global__ __launch_bounds__(PT) void k_mgs_persist(const double* __restrict__ V
 #pragma unroll
         for (int i = 0; i < NR; ++i) qk[i] = bload(r0, voff, (unsigned)(NL + i) * sbytes, false);
     }
+    // The first batch of the NEXT basis vector is requested before the grid reduction of the current one and lands while the
+    // blocks wait for each other: the registers it lands in (one batch of B loads) are idle during the reduction anyway, and
+    // the step after the reduction starts on data instead of on a memory round trip.
+    d2 qpre[B];
+    {
+        const __amdgpu_buffer_rsrc_t r0 = col_rsrc(V, ld);
+#pragma unroll
+        for (int u = 0; u < B; ++u) qpre[u] = bload(r0, voff, (unsigned)(u < NV ? u : 0) * sbytes, false);
+    }
     for (int s = 0; s < nsteps; ++s) {
         const double* qn = V + (int64_t)(s % m) * ld;
         double a0 = 0, a1 = 0, total;
-        persist_step<NV, NL, NR, PT, B, NTPREV, false, true>(wr, qk, col_rsrc(qp, ld), col_rsrc(qn, ld), sp, sbytes, voff, lq, a0, a1);
+        persist_step<NV, NL, NR, PT, B, NTPREV, false, true>(wr, qk, qpre, col_rsrc(qp, ld), col_rsrc(qn, ld), sp, sbytes, voff, lq, a0, a1);
+        {   // (the column after the last one wraps to column 0: a valid address, the values are not used)
+            const __amdgpu_buffer_rsrc_t r2 = col_rsrc(V + (int64_t)((s + 1) % m) * ld, ld);
+#pragma unroll
+            for (int u = 0; u < B; ++u) qpre[u] = bload(r2, voff, (unsigned)(u < NV ? u : 0) * sbytes, false);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         if (!grid_sum<PT>(a0 + a1, s, gran, err, sm, &total, relay)) return;   // timeout: w in HBM is untouched
         if (blockIdx.x == 0 && threadIdx.x == 0) out_s[(s / m) * out_stride + (s % m)] = total;
         sp = total;
@@ -250,7 +265,7 @@ __global__ __launch_bounds__(PT) void k_mgs_persist(const double* __restrict__ V
     }
     {   // last pending axpy, fused with the squared norm of the result
         double a0 = 0, a1 = 0, total;
-        persist_step<NV, NL, NR, PT, B, NTPREV, true, true>(wr, qk, col_rsrc(qp, ld), col_rsrc(qp, ld), sp, sbytes, voff, lq, a0, a1);
+        persist_step<NV, NL, NR, PT, B, NTPREV, true, true>(wr, qk, qpre, col_rsrc(qp, ld), col_rsrc(qp, ld), sp, sbytes, voff, lq, a0, a1);
         if (nrm_out3) {
             if (!grid_sum<PT>(a0 + a1, nsteps, gran, err, sm, &total, relay)) return;
             if (blockIdx.x == 0 && threadIdx.x == 0) {
