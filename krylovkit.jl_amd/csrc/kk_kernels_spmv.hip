@@ -336,79 +336,101 @@ __global__ __launch_bounds__(KK_TPB) void k_spmv_sell(const int64_t* __restrict_
 // scattered 8-byte accesses): the four waves compute the raw sums of the four chunks of a 256-row window in the sorted
 // order, park them in LDS under the row's position in the window, and after a barrier thread t finishes row
 // base + t -- y, x, v_prev and the inner-product operands are all read and written coalesced.
+// R = 256-row rounds per sorting window (window = R * 256 rows = 4 R chunks; wave w takes chunks w, w + 4, ...): the wider
+// the window the less padding -- 21 % of all slots with 256-row windows on the config-4 operator, 6 % with 1024-row windows
+// (12 % less matrix memory) -- while the rows of a window are still finished coalesced from LDS.  The time follows only
+// weakly (-2.4 %): padding slots re-read x[0] from the L1, and what bounds these applies is the rate of L2 requests, one
+// per REAL nonzero (switching the padding lanes off for the gather changed nothing either).
+template <int R>
 __global__ __launch_bounds__(KK_TPB) void k_spmv_sellw(const int64_t* __restrict__ coff, const int32_t* __restrict__ perm,
                                                        const int32_t* __restrict__ scol, const double* __restrict__ sval,
                                                        int64_t nchunks, int64_t nrows, const double* __restrict__ x,
                                                        double* __restrict__ y, spmv_epi e, double* __restrict__ part_dot,
                                                        double* __restrict__ part_nrm) {
-    __shared__ double res[KK_TPB];
+    constexpr int W = R * KK_TPB;
+    __shared__ double res[W];
     __shared__ double sm[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double dacc = 0, nacc = 0;
     const double xs = e.xs_dev ? *e.xs_dev : 1.0;
     const double bp = e.vprev ? (e.bprev_dev ? *e.bprev_dev : e.bprev) : 0.0;
-    const int64_t nwin = (nchunks + 3) >> 2;
-    // the chunk descriptor of the NEXT window is fetched while the current one is processed, and the old y of the
+    const int64_t nwin = (nchunks + 4 * R - 1) / (4 * R);
+    // the chunk descriptors of the NEXT window are fetched while the current one is processed, and the old y of the
     // accumulating tiles is requested before the gathers: two of the four dependent memory round trips per window go
     int64_t win = blockIdx.x;
-    int64_t off = 0, offn = 0;
-    int32_t prow = -1;
-    if (win < nwin && win * 4 + wave < nchunks) {
-        off = coff[win * 4 + wave]; offn = coff[win * 4 + wave + 1];
-        prow = perm[(win * 4 + wave) * 64 + lane];
+    int64_t off[R], offn[R];
+    int32_t prow[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        off[r] = 0; offn[r] = 0; prow[r] = -1;
+        const int64_t c = win * 4 * R + 4 * r + wave;
+        if (win < nwin && c < nchunks) { off[r] = coff[c]; offn[r] = coff[c + 1]; prow[r] = perm[c * 64 + lane]; }
     }
     for (; win < nwin; win += gridDim.x) {
-        const int64_t c = win * 4 + wave;
-        const int64_t row = win * KK_TPB + tid;
-        double yold = 0.0;
-        if (e.acc >= 2 && row < nrows) yold = y[row];
+        double yold[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int64_t row = win * W + r * KK_TPB + tid;
+            yold[r] = (e.acc >= 2 && row < nrows) ? y[row] : 0.0;
+        }
         const int64_t wnext = win + gridDim.x;
-        int64_t off2 = 0, offn2 = 0;
-        int32_t prow2 = -1;
-        if (wnext < nwin && wnext * 4 + wave < nchunks) {
-            off2 = coff[wnext * 4 + wave]; offn2 = coff[wnext * 4 + wave + 1];
-            prow2 = perm[(wnext * 4 + wave) * 64 + lane];
+        int64_t off2[R], offn2[R];
+        int32_t prow2[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            off2[r] = 0; offn2[r] = 0; prow2[r] = -1;
+            const int64_t c = wnext * 4 * R + 4 * r + wave;
+            if (wnext < nwin && c < nchunks) { off2[r] = coff[c]; offn2[r] = coff[c + 1]; prow2[r] = perm[c * 64 + lane]; }
         }
-        if (c < nchunks) {
-            const int w = (int)((offn - off) >> 6);
-            const int32_t* cp = scol + off + lane;
-            const double* vp = sval + off + lane;
-            double s0 = 0, s1 = 0;
-            int k = 0;
-            for (; k + 4 <= w; k += 4) {
-                const int c0 = ldc(cp + (k + 0) * 64), c1 = ldc(cp + (k + 1) * 64), c2 = ldc(cp + (k + 2) * 64), c3 = ldc(cp + (k + 3) * 64);
-                const double v0 = ldv(vp + (k + 0) * 64), v1 = ldv(vp + (k + 1) * 64), v2 = ldv(vp + (k + 2) * 64), v3 = ldv(vp + (k + 3) * 64);
-                const double x0 = xload(x, e, c0), x1 = xload(x, e, c1), x2 = xload(x, e, c2), x3 = xload(x, e, c3);
-                s0 = fma(v0, x0, s0);
-                s1 = fma(v1, x1, s1);
-                s0 = fma(v2, x2, s0);
-                s1 = fma(v3, x3, s1);
-            }
-            for (; k < w; ++k) s0 = fma(ldv(vp + k * 64), xload(x, e, ldc(cp + k * 64)), s0);
-            if (prow >= 0) res[prow - win * KK_TPB] = s0 + s1;
-        }
-        __syncthreads();
-        if (row < nrows) {
-            double raw = res[tid];
-            if (e.acc == 1) y[row] = raw;
-            else if (e.acc == 2) y[row] = yold + raw;
-            else {
-                if (e.acc == 3) raw += yold;
-                const double s = raw * xs;
-                double out = e.a1 * s;
-                double xv = 0;
-                if (e.a0 != 0.0 || e.dot_mode == 1 || e.dot_mode == 2) xv = x[row] * xs;
-                if (e.a0 != 0.0) out = fma(e.a0, xv, out);
-                if (e.dot_mode == 1) dacc = fma(xv, out, dacc);
-                if (e.vprev) out = fma(-bp, e.vprev[row], out);
-                if (e.dot_mode == 2) dacc = fma(xv, out, dacc);
-                if (e.dot_mode == 3) dacc = fma(e.dvec[row], out, dacc);
-                if (e.want_nrm) nacc = fma(out, out, nacc);
-                y[row] = out;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int64_t c = win * 4 * R + 4 * r + wave;
+            if (c < nchunks) {
+                const int w = (int)((offn[r] - off[r]) >> 6);
+                const int32_t* cp = scol + off[r] + lane;
+                const double* vp = sval + off[r] + lane;
+                double s0 = 0, s1 = 0;
+                int k = 0;
+                for (; k + 4 <= w; k += 4) {
+                    const int c0 = ldc(cp + (k + 0) * 64), c1 = ldc(cp + (k + 1) * 64), c2 = ldc(cp + (k + 2) * 64), c3 = ldc(cp + (k + 3) * 64);
+                    const double v0 = ldv(vp + (k + 0) * 64), v1 = ldv(vp + (k + 1) * 64), v2 = ldv(vp + (k + 2) * 64), v3 = ldv(vp + (k + 3) * 64);
+                    const double x0 = xload(x, e, c0), x1 = xload(x, e, c1), x2 = xload(x, e, c2), x3 = xload(x, e, c3);
+                    s0 = fma(v0, x0, s0);
+                    s1 = fma(v1, x1, s1);
+                    s0 = fma(v2, x2, s0);
+                    s1 = fma(v3, x3, s1);
+                }
+                for (; k < w; ++k) s0 = fma(ldv(vp + k * 64), xload(x, e, ldc(cp + k * 64)), s0);
+                if (prow[r] >= 0) res[prow[r] - win * W] = s0 + s1;
             }
         }
         __syncthreads();
-        off = off2; offn = offn2; prow = prow2;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int64_t row = win * W + r * KK_TPB + tid;
+            if (row < nrows) {
+                double raw = res[r * KK_TPB + tid];
+                if (e.acc == 1) y[row] = raw;
+                else if (e.acc == 2) y[row] = yold[r] + raw;
+                else {
+                    if (e.acc == 3) raw += yold[r];
+                    const double s = raw * xs;
+                    double out = e.a1 * s;
+                    double xv = 0;
+                    if (e.a0 != 0.0 || e.dot_mode == 1 || e.dot_mode == 2) xv = x[row] * xs;
+                    if (e.a0 != 0.0) out = fma(e.a0, xv, out);
+                    if (e.dot_mode == 1) dacc = fma(xv, out, dacc);
+                    if (e.vprev) out = fma(-bp, e.vprev[row], out);
+                    if (e.dot_mode == 2) dacc = fma(xv, out, dacc);
+                    if (e.dot_mode == 3) dacc = fma(e.dvec[row], out, dacc);
+                    if (e.want_nrm) nacc = fma(out, out, nacc);
+                    y[row] = out;
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < R; ++r) { off[r] = off2[r]; offn[r] = offn2[r]; prow[r] = prow2[r]; }
     }
     if (e.dot_mode) {
         double t = block_sum(dacc, sm);
@@ -675,10 +697,15 @@ int kk_launch_spmv(kk_ctx ctx, const kk_sparse_dev& M, const double* x, double* 
             spmv_epi et = e;
             et.acc = M.ntiles == 1 ? 0 : (t == 0 ? 1 : (t == M.ntiles - 1 ? 3 : 2));
             if (et.acc == 1 || et.acc == 2) { et.dot_mode = 0; et.want_nrm = 0; }
-            nblk = (int)std::min<int64_t>((S.sell_nchunks + 3) / 4, (int64_t)ctx->num_cus * 16);
+            const int R = (int)(S.sell_sigma / KK_TPB);   // 256-row rounds per sorting window (build_tiled)
+            nblk = (int)std::min<int64_t>((S.sell_nchunks + 4 * R - 1) / (4 * R), (int64_t)ctx->num_cus * 16);
             if (nblk < 1) nblk = 1;
-            hipLaunchKernelGGL(k_spmv_sellw, dim3(nblk), dim3(KK_TPB), 0, ctx->stream, S.sell_off, S.sell_perm, S.sell_col, S.sell_val,
-                               S.sell_nchunks, S.nrows, x, y, et, pd, pn);
+#define SELLW_ARGS dim3(nblk), dim3(KK_TPB), 0, ctx->stream, S.sell_off, S.sell_perm, S.sell_col, S.sell_val, S.sell_nchunks, S.nrows, x, y, et, pd, pn
+            if (R == 4) hipLaunchKernelGGL((k_spmv_sellw<4>), SELLW_ARGS);
+            else if (R == 2) hipLaunchKernelGGL((k_spmv_sellw<2>), SELLW_ARGS);
+            else if (R == 8) hipLaunchKernelGGL((k_spmv_sellw<8>), SELLW_ARGS);
+            else hipLaunchKernelGGL((k_spmv_sellw<1>), SELLW_ARGS);
+#undef SELLW_ARGS
         }
     } else if (use_dia) {
         launch_spmv_dia_rows(ctx, M, x, y, e, 0, M.nrows, pd, pn, &nblk, KK_MAX_BLOCKS);

@@ -107,7 +107,12 @@ static int build_tiled(const kk_host_csr& h, int64_t tile_cols, kk_sparse_dev& M
     for (int t = 0; t < T; ++t) {
         kk_sparse_dev& S = M.tiles[t];
         S.nrows = nrows; S.ncols = h.ncols; S.nnz = ht[t].rowptr[nrows];
-        KK_TRY(build_sell(ht[t], S, KK_TPB));   // sigma = the 256 rows of one thread block: k_spmv_sellw
+        // sorting window = R rounds of the 256 rows of one thread block (k_spmv_sellw<R>): the wider the window the less
+        // padding (= fewer gather instructions, which is what bounds these applies), while the y update stays coalesced
+        int R = 4;
+        if (const char* rs = getenv("KK_SELLW_ROUNDS")) R = atoi(rs);
+        if (R != 1 && R != 2 && R != 4 && R != 8) R = 4;
+        KK_TRY(build_sell(ht[t], S, (int64_t)KK_TPB * R));
         M.bytes += S.bytes;
         kk_host_csr().rowptr.swap(ht[t].rowptr);
         std::vector<int32_t>().swap(ht[t].col);
