@@ -714,6 +714,13 @@ def test_grid_stencil_single_vector_apply_and_fused_epilogues(kk, ko, ctx):
                 assert np.max(np.abs(X[1].get() - A.T @ u) / scale) < 1e-14
                 op.apply_affine(X[0], Y[0], 0.7, -1.3)
                 np.testing.assert_allclose(Y[0].get(), 0.7 * x - 1.3 * (A @ x), rtol=1e-12, atol=1e-12)
+                if dia:   # 1 / 2 row pairs per lane of the diagonal kernel (4 falls back to 2 when the values are streamed): same bits
+                    ref = Y[0].get()
+                    for pairs in (1, 2, 4):
+                        ctx.set_option("spmv_dia_pairs", pairs)
+                        op.apply_affine(X[0], Y[0], 0.7, -1.3)
+                        assert np.array_equal(Y[0].get(), ref), (nine, nx, ny, pairs)
+                    ctx.set_option("spmv_dia_pairs", 0)
             ctx.set_option("spmv_dia", 1)
     A = ko.laplacian_2d(70, 64, shift_diag=10 * np.linspace(0, 1, 70 * 64) ** 2)
     n = A.shape[0]
@@ -1350,6 +1357,14 @@ def test_constant_coefficient_stencil_needs_neither_indices_nor_values(kk, ko, c
             op.apply(B[0], B[4])
             op.apply_affine(B[1], B[5], 0.7, -0.4)
             outs.append((B[4].get(), B[5].get()))
+            # 1 / 2 / 4 row pairs per lane (the 4-pair form exists for the value-free kernel; long vectors pick it by size):
+            # same products in the same order, so the same bits
+            for pairs in (1, 2, 4):
+                ctx.set_option("spmv_dia_pairs", pairs)
+                op.apply(B[0], B[6])
+                op.apply_affine(B[1], B[7], 0.7, -0.4)
+                assert np.array_equal(B[6].get(), outs[-1][0]) and np.array_equal(B[7].get(), outs[-1][1]), (name, const, pairs)
+            ctx.set_option("spmv_dia_pairs", 0)
         ctx.set_option("spmv_dia_const", 1)
         assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]), name
         # the multi-column sweeping apply has the same value-free form
