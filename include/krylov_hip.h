@@ -85,13 +85,16 @@ typedef enum {
  * reference's three-term-then-reorthogonalise order), "qr_skip_tol" (the second CholQR2 back-substitution of that step is
  * skipped when the block is orthonormal to this level after the first; default 2e-14, 0 = never), "resid_gram" (Gram matrix
  * of the residual block handed from one step to the next, default 1), "spmv_dia" / "spmm_dia" (diagonal kernels for operators
- * detected as grid stencils, default 1; 0 = the general ELL gather kernels).  Tuning knobs without semantic effect:
+ * detected as grid stencils, default 1; 0 = the general ELL gather kernels), "spmv_dia_const" (a stencil whose diagonals hold
+ * one value each is applied from its 5 / 9 coefficients, no indices and no values read; default 1, bit-identical to 0).
+ * Tuning knobs without semantic effect:
  * "gram_bpc", "gram2_chunk", "spmm_bpc", "spmm_cols", "spmm_rpl", "spmm_dia_lines", "bu_prefetch", "gram_nt", "persist_nt",
- * "persist_lds", "persist_min_rows".  Test hook: "persist_fault" (the next n persistent launches behave like a grid-barrier timeout). */
+ * "persist_lds", "persist_min_rows", "spmv_dia_pairs" (row pairs per lane of the diagonal SpMV: 0 = by size, 1 / 2 / 4).  Test hook: "persist_fault" (the next n persistent launches behave like a grid-barrier timeout). */
 
 /* Environment variables read by the library (all optional): KK_MGS_MODE, KK_BLOCK_MODE, KK_BLOCKS_PER_CU, KK_MGS_PERSIST,
  * KK_PERSIST_THREADS, KK_PERSIST_NT (defaults of the options of the same name, read at kk_ctx_create); KK_SPMV_FORMAT = ell |
- * sell | csr and KK_SPMV_TILE_COLS (force a device format / the column-tile width at operator creation); KK_NO_DIA (no
+ * sell | csr, KK_SPMV_TILE_COLS and KK_SELLW_ROUNDS = 1 | 2 | 4 | 8 (force a device format / the column-tile width / the
+ * sorting window of the tiled format in units of 256 rows, default 4, at operator creation); KK_NO_DIA (no
  * grid-stencil diagonals); KK_BASISTRANSFORM_LDS (LDS-tile basistransform instead of the MFMA kernel); KK_RCCL_LIB (path of
  * librccl for kk_comm_*); KK_LOOPBACK_GHOST_FROM = r / KK_LOOPBACK_GHOST_BELOW = r2 (test aids, world size 1 only: columns >= r / < r2 of a
  * kk_csr_create_sharded operator go through the ghost-exchange machinery although this rank owns them). */
