@@ -94,15 +94,31 @@ __device__ __forceinline__ bool grid_sum(double acc, int step, gu64* __restrict_
         for (;;) {
             bool ok = true;
             double x = 0;
-            for (int b = lane; b < G; b += 64) {
-                const unsigned long long hi = __hip_atomic_load(g + 2 * b, RLX_AGENT);
-                const unsigned long long lo = __hip_atomic_load(g + 2 * b + 1, RLX_AGENT);
-                ok = ok && (unsigned)(hi >> 32) == epoch && (unsigned)(lo >> 32) == epoch;
-                x += __longlong_as_double((long long)(((hi & 0xffffffffull) << 32) | (lo & 0xffffffffull)));
+            // (the error flag travels with the first batch instead of costing a failed pass a round trip of its own)
+            const int errv = __hip_atomic_load(err, RLX_AGENT);
+            // 256 blocks' granules per batch, ALL EIGHT loads of a lane issued before the first tag is looked at: written as
+            // `for (b = lane; b < G; b += 64) { load; load; test; }` the sweep made G / 64 = 4 dependent memory round trips
+            // (~0.9 us each under streaming load) per pass -- most of the 4.2 us this reduction cost per basis vector
+            for (int b0 = 0; b0 < G; b0 += 256) {
+                unsigned long long hi[4], lo[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int b = b0 + i * 64 + lane;
+                    const int bb = b < G ? b : 0;
+                    hi[i] = __hip_atomic_load(g + 2 * bb, RLX_AGENT);
+                    lo[i] = __hip_atomic_load(g + 2 * bb + 1, RLX_AGENT);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {   // same summation order as before: b ascending per lane
+                    if (b0 + i * 64 + lane < G) {
+                        ok = ok && (unsigned)(hi[i] >> 32) == epoch && (unsigned)(lo[i] >> 32) == epoch;
+                        x += __longlong_as_double((long long)(((hi[i] & 0xffffffffull) << 32) | (lo[i] & 0xffffffffull)));
+                    }
+                }
             }
             if (__all(ok)) { total = wave_sum(x); break; }
             __builtin_amdgcn_s_sleep(1);
-            if (wall_clock64() - t0 > KK_PERSIST_TIMEOUT_TICKS || __hip_atomic_load(err, RLX_AGENT)) { good = 0; break; }
+            if (wall_clock64() - t0 > KK_PERSIST_TIMEOUT_TICKS || errv) { good = 0; break; }
         }
         if (lane == 0) {
             if (!good) __hip_atomic_store(err, 1, RLX_AGENT);
@@ -234,8 +250,19 @@ __global__ __launch_bounds__(PT) void k_mgs_persist(const double* __restrict__ V
     d2 qk[NR > 0 ? NR : 1];   // NR more grid-rows of the current basis vector parked in spare registers
     if (NL + NR > 0) {   // park the first q_prev (the carried vector, or the dummy that goes with s_prev = 0): every step then has ONE shape
         const __amdgpu_buffer_rsrc_t r0 = col_rsrc(qp, ld);
+        // in batches of 4 loads -> 4 LDS writes: left alone, hipcc runs all NL loads through ONE register quad, i.e. NL
+        // dependent memory round trips (~1 us each) at the head of every launch
 #pragma unroll
-        for (int i = 0; i < NL; ++i) lq[i * PT] = bload(r0, voff, (unsigned)i * sbytes, false);
+        for (int i0 = 0; i0 < NL; i0 += 4) {
+            d2 t[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (i0 + u < NL) t[u] = bload(r0, voff, (unsigned)(i0 + u) * sbytes, false);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (i0 + u < NL) lq[(i0 + u) * PT] = t[u];
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int i = 0; i < NR; ++i) qk[i] = bload(r0, voff, (unsigned)(NL + i) * sbytes, false);
     }
