@@ -86,7 +86,16 @@ typedef enum {
  * skipped when the block is orthonormal to this level after the first; default 2e-14, 0 = never), "resid_gram" (Gram matrix
  * of the residual block handed from one step to the next, default 1), "spmv_dia" / "spmm_dia" (diagonal kernels for operators
  * detected as grid stencils, default 1; 0 = the general ELL gather kernels), "spmv_dia_const" (a stencil whose diagonals hold
- * one value each is applied from its 5 / 9 coefficients, no indices and no values read; default 1, bit-identical to 0).
+ * one value each is applied from its 5 / 9 coefficients, no indices and no values read; default 1, bit-identical to 0),
+ * "fold_scale" (default 1: a Lanczos / Arnoldi expand! whose sweep ran through the persistent kernel stores the residual
+ * already NORMALISED -- the kernel holds |w| before it writes w back -- so that the next expand! of the same factorization
+ * needs no scale pass (factorizations/lanczos.jl:257, arnoldi.jl:209); the slab remembers (column, beta) and ANY other
+ * entry point that is handed the slab first multiplies the column back, so residual(F), shrink! and restarts see r as
+ * before (to 1 ulp); kk_orthonormalize uses the same commit; 0 = every expand! runs its own scale pass; same alpha / beta
+ * bits either way).  A grid-barrier timeout of the persistent kernel (GPU shared with another job) is recovered inside the
+ * library on the launch-per-vector route in the same strict order; the persistent route is retried a few sweeps later
+ * (kk_ctx_get_option: "persist_timeouts", "persist_skip"); "persist_capacity_rows" = rows of a work vector the register
+ * file of the chip holds (longer vectors run the low-synchronisation form in auto mode).
  * Tuning knobs without semantic effect:
  * "gram_bpc", "gram2_chunk", "spmm_bpc", "spmm_cols", "spmm_rpl", "spmm_dia_lines", "bu_prefetch", "gram_nt", "persist_nt",
  * "persist_lds", "persist_min_rows", "spmv_dia_pairs" (row pairs per lane of the diagonal SpMV: 0 = by size, 1 / 2 / 4).  Test hook: "persist_fault" (the next n persistent launches behave like a grid-barrier timeout). */

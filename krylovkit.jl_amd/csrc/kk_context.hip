@@ -162,6 +162,7 @@ KK_API int kk_ctx_set_option(kk_ctx c, const char* key, double value) {
         c->fuse_passes = value != 0;
     } else if (!strcmp(key, "mgs_persist")) {
         c->mgs_persist = value != 0;
+        c->persist_skip = 0;
     } else if (!strcmp(key, "persist_fault")) {
         c->persist_fault = (int)value;   // test hook: the next `value` persistent launches behave like a grid-barrier timeout
     } else if (!strcmp(key, "persist_threads")) {
@@ -169,13 +170,14 @@ KK_API int kk_ctx_set_option(kk_ctx c, const char* key, double value) {
         c->persist_threads = (int)value;
     } else if (!strcmp(key, "persist_nt")) {
         c->persist_nt = value != 0;
-    } else if (!strcmp(key, "persist_sync")) {
-        c->persist_sync = value != 0;
     } else if (!strcmp(key, "persist_min_rows")) {
         KK_CHECK(value >= 0, KK_ERR_INVALID, "persist_min_rows must be >= 0");
         c->persist_min_rows = (int64_t)value;
     } else if (!strcmp(key, "persist_lds")) {
-        c->persist_lds = (int)value;   // 0 off, 1 LDS, 2 LDS + spare registers
+        KK_CHECK(value == 0 || value == 1 || value == 2, KK_ERR_INVALID, "persist_lds must be 0 (off), 1 (LDS) or 2 (LDS + spare registers)");
+        c->persist_lds = (int)value;
+    } else if (!strcmp(key, "fold_scale")) {
+        c->fold_scale = value != 0;   // 0: the persistent kernel stores w itself and every expand! runs its own scale pass (round-3 behaviour)
     } else if (!strcmp(key, "gram_nt")) {
         c->gram_nt = value != 0;
     } else if (!strcmp(key, "spmv_dia")) {
@@ -243,9 +245,11 @@ KK_API int kk_ctx_get_option(kk_ctx c, const char* key, double* value) {
     else if (!strcmp(key, "mgs_persist")) *value = c->mgs_persist;
     else if (!strcmp(key, "persist_threads")) *value = c->persist_threads;
     else if (!strcmp(key, "persist_timeouts")) *value = c->persist_timeouts;
+    else if (!strcmp(key, "persist_skip")) *value = c->persist_skip;
+    else if (!strcmp(key, "persist_capacity_rows")) *value = (double)kk_mgs_persist_capacity(c);
+    else if (!strcmp(key, "fold_scale")) *value = c->fold_scale;
     else if (!strcmp(key, "persist_nt")) *value = c->persist_nt;
     else if (!strcmp(key, "persist_lds")) *value = c->persist_lds;
-    else if (!strcmp(key, "persist_sync")) *value = c->persist_sync;
     else if (!strcmp(key, "persist_min_rows")) *value = (double)c->persist_min_rows;
     else if (!strcmp(key, "speculate")) *value = c->speculate;
     else if (!strcmp(key, "spmv_dia")) *value = c->spmv_dia;
@@ -418,7 +422,10 @@ KK_API int kk_basis_info(kk_basis b, int64_t* n, int64_t* ld, int* capacity, voi
     if (n) *n = b->n;
     if (ld) *ld = b->ld;
     if (capacity) *capacity = b->cap;
-    if (dptr) *dptr = b->d;
+    if (dptr) {
+        KK_TRY(norm_flush(b));   // whoever takes the raw pointer sees the residual itself, not its normalised form
+        *dptr = b->d;
+    }
     return KK_OK;
 }
 KK_API int kk_basis_invalidate_gram(kk_basis b) {

@@ -16,11 +16,12 @@ static const double KK_EPS = std::numeric_limits<double>::epsilon();
 #define WSP(c, off) ((c)->ws + (off))
 #define SCP(c, slot) ((c)->ws + WS_SCAL + (slot))
 
-// ---- argument checks (status + message, never an exception across the C boundary)
-#define CHECK_COL(b, c) KK_CHECK((b) && (c) >= 0 && (c) < (b)->cap, KK_ERR_INVALID, "%s: column %d out of range", __func__, (c))
+// ---- argument checks (status + message, never an exception across the C boundary).  Every check of a basis argument also
+// settles a pending normalised residual (norm_flush below): only the expand! that consumes it looks at the flag itself.
+#define CHECK_COL(b, c) do { KK_CHECK((b) && (c) >= 0 && (c) < (b)->cap, KK_ERR_INVALID, "%s: column %d out of range", __func__, (c)); KK_TRY(norm_flush(b)); } while (0)
 #define CHECK_SAME(bx, by) KK_CHECK((bx)->ctx == (by)->ctx && (bx)->n == (by)->n && (bx)->ld == (by)->ld, KK_ERR_DIM, "%s: vector length mismatch (%lld vs %lld)", __func__, (long long)(bx)->n, (long long)(by)->n)
-#define CHECK_RANGE(b, c0, m) KK_CHECK((b) && (c0) >= 0 && (m) >= 0 && (c0) + (m) <= (b)->cap && (m) <= KK_MAX_M, KK_ERR_INVALID, "%s: column range [%d,%d) invalid (capacity %d, max %d per call)", __func__, (c0), (c0) + (m), (b) ? (b)->cap : 0, KK_MAX_M)
-#define CHECK_BLOCK(b, c0, p) KK_CHECK((b) && (c0) >= 0 && (p) >= 0 && (c0) + (p) <= (b)->cap, KK_ERR_INVALID, "%s: block [%d,%d) outside capacity %d", __func__, (c0), (c0) + (p), (b) ? (b)->cap : 0)
+#define CHECK_RANGE(b, c0, m) do { KK_CHECK((b) && (c0) >= 0 && (m) >= 0 && (c0) + (m) <= (b)->cap && (m) <= KK_MAX_M, KK_ERR_INVALID, "%s: column range [%d,%d) invalid (capacity %d, max %d per call)", __func__, (c0), (c0) + (m), (b) ? (b)->cap : 0, KK_MAX_M); KK_TRY(norm_flush(b)); } while (0)
+#define CHECK_BLOCK(b, c0, p) do { KK_CHECK((b) && (c0) >= 0 && (p) >= 0 && (c0) + (p) <= (b)->cap, KK_ERR_INVALID, "%s: block [%d,%d) outside capacity %d", __func__, (c0), (c0) + (p), (b) ? (b)->cap : 0); KK_TRY(norm_flush(b)); } while (0)
 
 // ---- scalar read-backs (kk_context.hip): results of the finalize kernels travel through the pinned mirror of the
 // scalar workspace; `slot` selects one of its 4 copies
@@ -33,6 +34,17 @@ static inline void gram_touch(kk_basis b, int col) {
     b->spec_valid = false;
     kk_ctx c = b->ctx;   // cached Gram matrix of a residual block: gone as soon as a column at or below its end may have changed
     if (c->gw_valid && c->gw_basis == b->uid && col < c->gw_col + c->gw_p) c->gw_valid = false;
+}
+// A fused expand! whose sweep ran through the persistent kernel leaves the residual column NORMALISED (w / |w| written at the
+// kernel's commit, SURVEY a7: the scale!!(r, 1/beta) of factorizations/lanczos.jl:257 / arnoldi.jl:209 costs no pass of its
+// own) and notes (column, beta) on the slab.  The next expand! of the same factorization takes the column as its new basis
+// vector; anything else that looks at the slab first gets r = beta * column back (residual(F), shrink!, restarts).
+static inline int norm_flush(kk_basis b) {
+    if (!b || b->norm_col < 0) return KK_OK;
+    const int col = b->norm_col;
+    b->norm_col = -1;
+    gram_touch(b, col);   // (also drops a speculative apply formed from the normalised bits)
+    return kk_launch_scal(b->ctx, b->col(col), b->ld, b->norm_beta, nullptr);
 }
 
 // ---- sparse operators (kk_sparse.hip)

@@ -13,9 +13,12 @@
 #define KK_BLK_SCRATCH 131072 // doubles of device/pinned scratch for block matrices (gram panels, S)
 #define KK_STAGE_SLOTS 8      // ring of coefficient-panel staging slots inside the block scratch (first half)
 #define KK_STAGE_DOUBLES 4096  // doubles per slot (KK_MAX_M rows x 16)
-// synchronisation area of the persistent strict-MGS kernel: 2 granule sets x 2 granules per block (8 bytes each) + error flag
-#define KK_SYNC_ERR_OFFSET (4 * KK_MAX_BLOCKS * 8)
+// synchronisation area of the persistent MGS kernels: 2 granule sets x one 128-byte line per block + error flag
+#define KK_SYNC_LINE 128
+#define KK_SYNC_MAX_BLOCKS 1024
+#define KK_SYNC_ERR_OFFSET (2 * KK_SYNC_MAX_BLOCKS * KK_SYNC_LINE)
 #define KK_SYNC_BYTES (KK_SYNC_ERR_OFFSET + 64)
+#define KK_MAX_DEVICES 64     // per-device bookkeeping of function attributes
 #define KK_TPB 256            // threads per block of every streaming kernel (4 waves)
 #define KK_SUB 512            // rows covered by one block sub-step: 256 threads x 2 rows (16 B/lane)
 // register tile of the two basis-streaming kernels: RG sub-steps of 512 rows per row group (2*RG rows per
@@ -57,6 +60,8 @@
 enum { SC_ALPHA0 = 0, SC_NRM2 = 1, SC_NRM = 2, SC_INVNRM = 3, SC_DOT = 4, SC_TMP0 = 5, SC_TMP1 = 6, SC_TMP2 = 7,
        SC_NRM2B = 8, SC_NRMB = 9, SC_INVNRMB = 10, SC_DOTB = 11,
        SC_SPECA = 12 /* alpha of a speculative next-step SpMV: written by nothing else */,
+       SC_PERSIST_OK = 13 /* completion token of the last persistent MGS launch (travels with the sweep's scalars) */,
+       SC_XS = 14 /* factor a speculative apply still has to put on the residual of that launch: 1 (stored normalised) or 1/|w| */,
        SC_BICG = 16 /* rho, rho_old, sigma, alpha, omega, <t,s>, <t,t> (+2 for the sqrt triple) */,
        SC_BICG_SN = 25 /* |s|^2, |s|, 1/|s| */, SC_BICG_RN = 28 /* |r|^2, |r|, 1/|r| */ };
 
@@ -143,14 +148,21 @@ struct kk_ctx_s {
     int mgs_persist = 1;         // strict MGS sweeps through the persistent register-resident kernel when the vector fits
     int persist_threads = 512;   // threads per block (= per CU) of that kernel: 1024 (<= 40 doubles of w per thread) or 512 (<= 80)
     int persist_nt = 1;          // second read of a basis vector (served by the Infinity Cache) with non-temporal loads
-    int persist_sync = 0;        // grid reduction of that kernel: 0 = every block sweeps all partials, 1 = block 0 sweeps and relays the total
     int persist_lds = 2;         // park grid-rows of the current basis vector on chip between its two uses: 1 = as many as fit the LDS,
                                  // 2 = those plus KK_PERSIST_NR more in spare registers (512-thread blocks), 0 = none (second read from memory)
     void* d_sync = nullptr;      // device: hand-off granules + error flag of the in-kernel grid reduction (KK_SYNC_BYTES)
     int* h_sync = nullptr;       // pinned: read-back of the error flag
     bool persist_pending = false;  // a persistent launch has not been checked for a barrier timeout yet
-    int persist_timeouts = 0;      // grid-barrier timeouts recovered so far (each one switched the persistent route off)
+    int persist_slot = 0;          // pinned slot its scalars (and completion token) were fetched into
+    double persist_token = 0;      // token of the last launch (a launch that committed wrote it to SC_PERSIST_OK)
+    unsigned persist_epoch = 0;    // epochs handed out so far: tags of the grid reductions are unique over the life of the context
+    bool persist_norm_req = false; // the caller of the sweep wants w / |w| stored (expand!'s scale of the next step, orthonormalize!!)
+    bool persist_norm_done = false;  // ... and the last sweep went through a launch that was asked to do so
+    int persist_timeouts = 0;      // grid-barrier timeouts recovered so far
+    int persist_skip = 0;          // strict sweeps still to run on the launch-per-vector route before the persistent one is retried
+    int persist_backoff = 4;       // ... how many after the next timeout (doubles with every timeout in a row)
     int persist_fault = 0;         // test hook (option "persist_fault"): the next N persistent launches time out artificially
+    int fold_scale = 1;          // persistent kernel stores r / |r| at its commit when an expand! ends with it (no scale pass in the next step)
     int fuse_passes = 1;         // fuse unproject(pass i) with project(pass i+1)
     int speculate = 1;           // enqueue the next expand's SpMV before syncing the host
     kk_basis spec_owner = nullptr;   // basis whose speculative result currently sits in SC_SPECA / its next column
@@ -182,6 +194,11 @@ struct kk_basis_s {
     const void* spec_op = nullptr;
     int spec_c0 = 0, spec_k = 0, spec_dot_mode = 0;
     double spec_beta = 0;
+    // residual column left NORMALISED by a fused expand! (persistent kernel, w / |w| written at commit): logically the column
+    // still holds r = norm_beta * stored; the next expand! of the same factorization takes it as its new basis vector without
+    // the scale pass, every other access multiplies it back first (norm_flush)
+    int norm_col = -1;
+    double norm_beta = 0;
     inline double* col(int c) const { return d + (int64_t)c * ld; }
 };
 
@@ -417,7 +434,10 @@ static inline bool kk_mgs_lowsync(kk_ctx ctx, int64_t ld, int m) {
     return !(ld >= ctx->persist_min_rows && kk_mgs_persist_eligible(ctx, ld, m, 2));
 }
 int kk_launch_mgs_persist(kk_ctx ctx, const double* V, int64_t ld, int m, int nsweeps, double* w, const double* carry_q,
-                          const double* carry_s, double* out_s, int out_stride, double* nrm_out3);
+                          const double* carry_s, double* out_s, int out_stride, double* nrm_out3, bool normalize_w);
+int64_t kk_mgs_persist_capacity(kk_ctx ctx);
+// the kernel's own test for the normalised commit, on the host's copy of |w|
+static inline bool kk_persist_norm_applies(double nrm) { return nrm > 0.0 && 1.0 / nrm <= 1.79769313486231570815e308; }
 int kk_launch_lanczos_coef(kk_ctx ctx, const double* buf, double* L, int cap, int m, int lowsync, double* coef_out, double* res);
 int kk_launch_norm_scalars(kk_ctx ctx, const double* nrm2, double* sc, double* res2);
 int kk_launch_lowsync_solve(kk_ctx ctx, const double* p, const double* g_ride, double* L, int cap, int m, int newest,

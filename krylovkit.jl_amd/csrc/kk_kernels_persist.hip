@@ -38,53 +38,31 @@ __device__ __forceinline__ double block_sum_w(double v, double* sm /* >= NW doub
 }
 
 // Sum of `acc` over all threads of all blocks (every block is resident: one per CU).  Data-tagged hand-off
-// (cdna_hip_programming.md Guideline 16, form R2 / "allgather"): a block publishes its partial as two naturally aligned
-// 8-byte granules {tag = epoch, 32 bits of the double}, each written by ONE write-through (sc1) store -- the data is the
-// flag, no counter, no fence; wave 0 of every block sweeps the 2G granules with relaxed agent-scope loads until every tag
-// equals the epoch and adds the partials in a fixed order, so all blocks obtain the same bits.  Two granule sets are used
-// alternately (epoch parity): a fast block can publish step s+1 while a slow one still sweeps step s; it cannot reach
-// step s+2 before the slow one has published s+1, i.e. has finished that sweep.  Returns false on a timeout.
+// (cdna_hip_programming.md Guideline 16, form R2 / "allgather"): a block publishes its partial as ONE 16-byte granule
+// {epoch, high word, low word, epoch} on a 128-byte line of its own, written by a single write-through (sc1) dwordx4
+// store -- the data is the flag, no counter, no fence; wave 0 of every block sweeps the G granules (one sc1 dwordx4 load
+// each, all loads of a lane in flight before the first tag is looked at) until every tag pair equals the epoch and adds
+// the partials in a fixed order, so all blocks obtain the same bits.  Each 8-byte half of a granule carries its own tag:
+// even if the fabric split the 16 bytes into two naturally aligned halves, a half that is still old fails its tag.
+// Measured against the round-3 form (two separate 8-byte granules per block, contiguous for all blocks):
+// 3.06 -> 2.29 us per reduction on an idle chip (tools/grid_reduce_variants.hip, profiles/r03_grid_reduce_variants.jsonl).
+// Two granule sets are used alternately (epoch parity): a fast block can publish step s+1 while a slow one still sweeps
+// step s; it cannot reach step s+2 before the slow one has published s+1, i.e. has finished that sweep.  Epochs are
+// unique over the life of the context (`ebase` advances from launch to launch), so the area is never cleared between
+// launches.  Returns false on a timeout.
 template <int PT>
-__device__ __forceinline__ bool grid_sum(double acc, int step, gu64* __restrict__ gran, int* __restrict__ err, double* sm,
-                                         double* out, int relay) {
+__device__ __forceinline__ bool grid_sum(double acc, int step, unsigned ebase, char* __restrict__ sync, int* __restrict__ err,
+                                         double* sm, double* out) {
     const int G = gridDim.x;
     const double v = block_sum_w<PT / 64>(acc, sm);
-    const unsigned epoch = (unsigned)step + 1u;
-    gu64* g = gran + (size_t)(step & 1) * 2 * G;
+    const unsigned epoch = ebase + (unsigned)step + 1u;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(sync, 0, 2 * G * KK_SYNC_LINE, 0x00020000);
+    const unsigned set_off = (unsigned)(step & 1) * (unsigned)G * KK_SYNC_LINE;   // one 128-byte line per block and set
     if (threadIdx.x == 0) {
         const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
-        __hip_atomic_store(g + 2 * blockIdx.x, ((unsigned long long)epoch << 32) | (bits >> 32), RLX_AGENT);
-        __hip_atomic_store(g + 2 * blockIdx.x + 1, ((unsigned long long)epoch << 32) | (bits & 0xffffffffull), RLX_AGENT);
-    }
-    if (relay && blockIdx.x != 0) {
-        // relay form (option "persist_sync" = 1): only block 0 sweeps the 2G partial granules; it publishes the total as one
-        // tagged pair behind them and every other block polls just that pair -- two fabric hops instead of one, but 2 loads
-        // per poll and block instead of 2G.  Same bits either way: the one summation order is block 0's.
-        gu64* tg = gran + (size_t)4 * G + (size_t)(step & 1) * 2;
-        if (threadIdx.x == 0) {
-            const long long t0 = wall_clock64();
-            double total = 0;
-            int good = 1;
-            for (;;) {
-                const unsigned long long hi = __hip_atomic_load(tg, RLX_AGENT);
-                const unsigned long long lo = __hip_atomic_load(tg + 1, RLX_AGENT);
-                if ((unsigned)(hi >> 32) == epoch && (unsigned)(lo >> 32) == epoch) {
-                    total = __longlong_as_double((long long)(((hi & 0xffffffffull) << 32) | (lo & 0xffffffffull)));
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(1);
-                if (wall_clock64() - t0 > KK_PERSIST_TIMEOUT_TICKS || __hip_atomic_load(err, RLX_AGENT)) { good = 0; break; }
-            }
-            if (!good) __hip_atomic_store(err, 1, RLX_AGENT);
-            sm[0] = total;
-            sm[1] = good ? 1.0 : 0.0;
-        }
-        __syncthreads();
-        const double total = sm[0];
-        const bool good = sm[1] != 0.0;
-        __syncthreads();
-        *out = total;
-        return good;
+        v4u t;
+        t.x = epoch; t.y = (unsigned)(bits >> 32); t.z = (unsigned)bits; t.w = epoch;
+        __builtin_amdgcn_raw_buffer_store_b128(t, rs, set_off + blockIdx.x * KK_SYNC_LINE, 0, 16 /* sc1 */);
     }
     if (threadIdx.x < 64) {   // wave 0 sweeps
         const int lane = threadIdx.x;
@@ -96,23 +74,22 @@ __device__ __forceinline__ bool grid_sum(double acc, int step, gu64* __restrict_
             double x = 0;
             // (the error flag travels with the first batch instead of costing a failed pass a round trip of its own)
             const int errv = __hip_atomic_load(err, RLX_AGENT);
-            // 256 blocks' granules per batch, ALL EIGHT loads of a lane issued before the first tag is looked at: written as
-            // `for (b = lane; b < G; b += 64) { load; load; test; }` the sweep made G / 64 = 4 dependent memory round trips
-            // (~0.9 us each under streaming load) per pass -- most of the 4.2 us this reduction cost per basis vector
+            // 256 blocks' granules per batch, ALL loads of a lane issued before the first tag is looked at: written as
+            // `for (b = lane; b < G; b += 64) { load; test; }` the sweep makes G / 64 = 4 dependent memory round trips
+            // (~0.9 us each under streaming load) per pass
             for (int b0 = 0; b0 < G; b0 += 256) {
-                unsigned long long hi[4], lo[4];
+                v4u t[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int b = b0 + i * 64 + lane;
                     const int bb = b < G ? b : 0;
-                    hi[i] = __hip_atomic_load(g + 2 * bb, RLX_AGENT);
-                    lo[i] = __hip_atomic_load(g + 2 * bb + 1, RLX_AGENT);
+                    t[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, set_off + (unsigned)bb * KK_SYNC_LINE, 0, 16 /* sc1 */);
                 }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {   // same summation order as before: b ascending per lane
+                for (int i = 0; i < 4; ++i) {   // summation order: b ascending per lane, then across the lanes (wave_sum)
                     if (b0 + i * 64 + lane < G) {
-                        ok = ok && (unsigned)(hi[i] >> 32) == epoch && (unsigned)(lo[i] >> 32) == epoch;
-                        x += __longlong_as_double((long long)(((hi[i] & 0xffffffffull) << 32) | (lo[i] & 0xffffffffull)));
+                        ok = ok && t[i].x == epoch && t[i].w == epoch;
+                        x += __longlong_as_double((long long)(((unsigned long long)t[i].y << 32) | t[i].z));
                     }
                 }
             }
@@ -122,12 +99,6 @@ __device__ __forceinline__ bool grid_sum(double acc, int step, gu64* __restrict_
         }
         if (lane == 0) {
             if (!good) __hip_atomic_store(err, 1, RLX_AGENT);
-            if (relay && good) {   // block 0 hands the total to everybody else
-                gu64* tg = gran + (size_t)4 * G + (size_t)(step & 1) * 2;
-                const unsigned long long bits = (unsigned long long)__double_as_longlong(total);
-                __hip_atomic_store(tg, ((unsigned long long)epoch << 32) | (bits >> 32), RLX_AGENT);
-                __hip_atomic_store(tg + 1, ((unsigned long long)epoch << 32) | (bits & 0xffffffffull), RLX_AGENT);
-            }
             sm[0] = total;
             sm[1] = good ? 1.0 : 0.0;
         }
@@ -226,7 +197,8 @@ __global__ __launch_bounds__(PT) void k_mgs_persist(const double* __restrict__ V
                                                     double* __restrict__ w, const double* __restrict__ carry_q,
                                                     const double* __restrict__ carry_s, double* __restrict__ out_s,
                                                     int out_stride, double* __restrict__ nrm_out3,
-                                                    gu64* __restrict__ gran, int* __restrict__ err, int fault, int relay) {
+                                                    char* __restrict__ sync, int* __restrict__ err, int fault,
+                                                    unsigned ebase, int normalize, double* __restrict__ ok_out, double token) {
     __shared__ double sm[PT / 64];
     extern __shared__ d2 park[];   // NL * PT double2 (dynamic): the parked grid-rows of the current basis vector
     if (fault && blockIdx.x == 0) {   // test hook (option "persist_fault"): block 0 behaves like a block whose spin ran out
@@ -285,40 +257,55 @@ __global__ __launch_bounds__(PT) void k_mgs_persist(const double* __restrict__ V
             for (int u = 0; u < B; ++u) qpre[u] = bload(r2, voff, (unsigned)(u < NV ? u : 0) * sbytes, false);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (!grid_sum<PT>(a0 + a1, s, gran, err, sm, &total, relay)) return;   // timeout: w in HBM is untouched
+        if (!grid_sum<PT>(a0 + a1, s, ebase, sync, err, sm, &total)) return;   // timeout: w in HBM is untouched
         if (blockIdx.x == 0 && threadIdx.x == 0) out_s[(s / m) * out_stride + (s % m)] = total;
         sp = total;
         qp = qn;
     }
+    double inv = 1.0;
+    bool scale = false;
     {   // last pending axpy, fused with the squared norm of the result
         double a0 = 0, a1 = 0, total;
         persist_step<NV, NL, NR, PT, B, NTPREV, true, true>(wr, qk, qpre, col_rsrc(qp, ld), col_rsrc(qp, ld), sp, sbytes, voff, lq, a0, a1);
         if (nrm_out3) {
-            if (!grid_sum<PT>(a0 + a1, nsteps, gran, err, sm, &total, relay)) return;
-            if (blockIdx.x == 0 && threadIdx.x == 0) {
-                const double rt = sqrt(total);
-                nrm_out3[0] = total; nrm_out3[1] = rt; nrm_out3[2] = 1.0 / rt;
-            }
+            if (!grid_sum<PT>(a0 + a1, nsteps, ebase, sync, err, sm, &total)) return;
+            // every block holds the same bits of |w|^2: the normalised commit below needs no second exchange
+            const double rt = sqrt(total);
+            inv = 1.0 / rt;
+            scale = normalize && rt > 0.0 && inv <= 1.79769313486231570815e308;   // a zero (or overflowing) norm leaves w as it is; the host applies the same test
+            if (blockIdx.x == 0 && threadIdx.x == 0) { nrm_out3[0] = total; nrm_out3[1] = rt; nrm_out3[2] = inv; }
         }
     }
     // commit: a block that timed out in any grid reduction raised the flag and left; the blocks that got through re-read it
     // here, so that either every block writes its rows of w back or (up to the microsecond around a 3 s timeout) none does
-    // and HBM still holds the input -- the host then repeats the sweep on the launch-per-vector route (persist_check)
+    // and HBM still holds the input -- the host then repeats the sweep on the launch-per-vector route (persist_check).
+    // The completion token travels with the scalars of the sweep (one read-back instead of a second one for the flag).
     if (__hip_atomic_load(err, RLX_AGENT)) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { ok_out[0] = token; ok_out[1] = scale ? 1.0 : inv; }   // SC_PERSIST_OK, SC_XS
+    // `normalize`: scale!!(w, 1/|w|) of the NEXT expand! (factorizations/lanczos.jl:257, arnoldi.jl:209; orthonormalize!!
+    // orthonormal.jl:522-527) folded into the write-back -- the same product w[i] * (1/|w|) k_scal forms, so the
+    // stored vector has the bits of the separate pass, which is no longer needed (16 N bytes and one launch per expand!)
+    const double f = scale ? inv : 1.0;   // (x * 1.0 is x, bit for bit)
 #pragma unroll
-    for (int i = 0; i < NV; ++i) bstore(rw, voff, (unsigned)i * sbytes, wr[i]);
+    for (int i = 0; i < NV; ++i) {
+        d2 o = wr[i];
+        o.x *= f; o.y *= f;
+        bstore(rw, voff, (unsigned)i * sbytes, o);
+    }
 }
 
 // ---- launcher ------------------------------------------------------------------------------
-// Eligible when the vector fits the register file of the chip (NV <= 20 double2 per thread at 1024 threads per CU), the
-// step counters fit the synchronisation area and the context is not row-sharded (a sharded sweep needs one all-reduce
+// Eligible when the vector fits the register file of the chip (NV <= 20 double2 per thread at 1024 threads per CU, 40 at
+// 512), the blocks fit the synchronisation area and the context is not row-sharded (a sharded sweep needs one all-reduce
 // per vector, which cannot be issued from inside a kernel).
+int64_t kk_mgs_persist_capacity(kk_ctx ctx) {   // rows of a work vector the register file of the chip can hold
+    const int pt = ctx->persist_threads;
+    return (int64_t)ctx->num_cus * pt * 2 * (pt == 1024 ? 20 : 40);
+}
 bool kk_mgs_persist_eligible(kk_ctx ctx, int64_t ld, int m, int nsweeps) {
     if (!ctx->mgs_persist || kk_sharded(ctx) || !ctx->d_sync) return false;
-    if (ctx->num_cus > KK_MAX_BLOCKS || ld * 8 >= ((int64_t)1 << 31)) return false;
-    const int pt = ctx->persist_threads;
-    const int64_t per_thread2 = (ld + (int64_t)ctx->num_cus * pt * 2 - 1) / ((int64_t)ctx->num_cus * pt * 2);
-    return per_thread2 <= (pt == 1024 ? 20 : 40);
+    if (ctx->num_cus > KK_SYNC_MAX_BLOCKS || ld * 8 >= ((int64_t)1 << 31)) return false;
+    return ld <= kk_mgs_persist_capacity(ctx);
 }
 
 // grid-rows parked in LDS: what fits next to the reduction scratch in the 160 KB of a CU, at most all of them; 0 = off
@@ -329,11 +316,14 @@ template <int NV, int NL, int NR, int PT, bool NT>
 static int launch_persist_inst(kk_ctx ctx, void** args) {
     const void* fn = (const void*)k_mgs_persist<NV, NL, NR, PT, NT>;
     const size_t dyn = (size_t)NL * PT * sizeof(double) * 2;
-    static bool configured = false;   // one attribute call per instantiation and process
-    if (!configured && dyn > 0) {
+    // the opt-in to more than 64 KB of dynamic LDS is a per-DEVICE attribute of the function: one call per instantiation and
+    // device (a process may drive contexts on several GPUs), made with the context's device current
+    static bool configured[KK_MAX_DEVICES] = {};
+    const int dev = ctx->device;
+    if (dyn > 0 && (dev < 0 || dev >= KK_MAX_DEVICES || !configured[dev])) {
         hipError_t ea = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
         if (ea != hipSuccess) return kk_hip_fail(ea, "hipFuncSetAttribute(k_mgs_persist, MaxDynamicSharedMemorySize)", __FILE__, __LINE__);
-        configured = true;
+        if (dev >= 0 && dev < KK_MAX_DEVICES) configured[dev] = true;
     }
     const dim3 g(ctx->num_cus), b(PT);
     hipError_t e = hipLaunchCooperativeKernel(fn, g, b, args, dyn, ctx->stream);
@@ -357,19 +347,34 @@ static int launch_persist(kk_ctx ctx, void** args, bool ntprev) {
     return ntprev ? launch_persist_inst<NV, 0, 0, PT, true>(ctx, args) : launch_persist_inst<NV, 0, 0, PT, false>(ctx, args);
 }
 
+// `normalize`: store w / |w| instead of w (needs nrm_out3; a zero norm leaves w unscaled -- kk_persist_norm_applies is the
+// host's copy of the kernel's test).  The completion token lands in the scalar workspace (SC_PERSIST_OK) and is checked by
+// persist_check after the read-back of the sweep's scalars.
 int kk_launch_mgs_persist(kk_ctx ctx, const double* V, int64_t ld, int m, int nsweeps, double* w, const double* carry_q,
-                          const double* carry_s, double* out_s, int out_stride, double* nrm_out3) {
+                          const double* carry_s, double* out_s, int out_stride, double* nrm_out3, bool normalize_w) {
     const int pt = ctx->persist_threads;
     const int nv = (int)((ld + (int64_t)ctx->num_cus * pt * 2 - 1) / ((int64_t)ctx->num_cus * pt * 2));
-    // granules: 2 sets x 2 per block, zeroed (tag 0 = never a valid epoch) before every launch, followed by the error flag
-    unsigned long long* gran = (unsigned long long*)ctx->d_sync;
+    KK_HIP(hipSetDevice(ctx->device));   // the attribute call and the cooperative launch act on the CURRENT device
+    char* sync = (char*)ctx->d_sync;
     int* err = (int*)((char*)ctx->d_sync + KK_SYNC_ERR_OFFSET);
-    KK_HIP(hipMemsetAsync(gran, 0, ((size_t)4 * ctx->num_cus + 8) * sizeof(unsigned long long), ctx->stream));
+    // epochs: nsteps + 1 reductions, tags ebase + 1 .. ebase + nsteps + 1; unique over the life of the context, so that the
+    // granule area never needs clearing (it is zeroed at creation and when the 32-bit epoch counter is about to wrap)
+    const unsigned need = (unsigned)(m * nsweeps) + 2u;
+    if (ctx->persist_epoch > 0xffffffffu - need - 1u) {
+        KK_HIP(hipMemsetAsync(sync, 0, (size_t)KK_SYNC_ERR_OFFSET, ctx->stream));
+        ctx->persist_epoch = 0;
+    }
+    unsigned ebase = ctx->persist_epoch;
+    ctx->persist_epoch += need;
     int fault = 0;
     if (ctx->persist_fault > 0) { --ctx->persist_fault; fault = 1; }
-    int relay = ctx->persist_sync;
+    int normalize = (normalize_w && nrm_out3) ? 1 : 0;
+    ctx->persist_token += 1.0;
+    double token = ctx->persist_token;
+    double* ok_out = ctx->ws + WS_SCAL + SC_PERSIST_OK;
     void* args[] = {(void*)&V, (void*)&ld, (void*)&m, (void*)&nsweeps, (void*)&w, (void*)&carry_q, (void*)&carry_s,
-                    (void*)&out_s, (void*)&out_stride, (void*)&nrm_out3, (void*)&gran, (void*)&err, (void*)&fault, (void*)&relay};
+                    (void*)&out_s, (void*)&out_stride, (void*)&nrm_out3, (void*)&sync, (void*)&err, (void*)&fault,
+                    (void*)&ebase, (void*)&normalize, (void*)&ok_out, (void*)&token};
     const bool nt = ctx->persist_nt != 0;
     kk_prof_scope ps(ctx, "k_mgs_persist");
     if (pt == 1024) {

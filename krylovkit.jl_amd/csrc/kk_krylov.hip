@@ -18,6 +18,7 @@ int check_square_op(kk_op op, kk_basis b) {
 static int krylov_initialize(kk_op op, kk_basis b, int c0, kk_orth_t orth, double eta, double* alpha, double* beta) {
     KK_TRY(check_square_op(op, b));
     KK_CHECK(c0 >= 0 && c0 + 2 <= b->cap, KK_ERR_INVALID, "initialize: need columns %d..%d", c0, c0 + 1);
+    KK_TRY(norm_flush(b));
     KK_CHECK(alpha && beta, KK_ERR_INVALID, "null output");
     kk_ctx c = b->ctx;
     double* x0 = b->col(c0);
@@ -93,7 +94,9 @@ static int speculate_next(kk_op op, kk_basis b, int c0, int k_next, int dot_mode
     b->spec_valid = false;
     if (!c->speculate || c0 + k_next + 2 > b->cap || k_next + 1 > KK_MAX_M) return KK_OK;
     kk_spmv_fuse f;
-    f.xscale_dev = SCP(c, SC_INVNRM);
+    // a sweep that went through a normalising persistent launch left r / |r| in the column (or r itself when the norm was
+    // zero): the kernel wrote the factor that is still to be applied -- 1 or 1/|r| -- to SC_XS
+    f.xscale_dev = c->persist_norm_done ? SCP(c, SC_XS) : SCP(c, SC_INVNRM);
     if (with_prev) { f.vprev = b->col(c0 + k_next - 1); f.bprev_dev = SCP(c, SC_NRM); }
     f.dot_mode = dot_mode;
     f.dot_out = SCP(c, SC_SPECA);
@@ -156,12 +159,18 @@ KK_API int kk_lanczos_expand(kk_op op, kk_basis b, int c0, int k, kk_orth_t orth
     // second (and last) one is |w|^2.  SURVEY.md 8(e).
     const bool sh_fused = !wide && kk_sharded(c) && (orth == KK_CGS2 || (orth == KK_MGS2 && lowsync && c0 == 0));
     double* a0_slot = sh_fused ? WSP(c, WS_SHBUF) : SCP(c, SC_ALPHA0);
+    // the previous expand! of this factorization may have left r already normalised (persistent kernel): then the column IS
+    // the new basis vector; any other pending normalised column is settled first
+    const bool v_ready = b->norm_col == c0 + k && b->norm_beta == beta_old;
+    if (!v_ready) KK_TRY(norm_flush(b));
     bool hit = false;
     KK_TRY(spec_take(op, b, c0, k, cgs_order ? 1 : 2, beta_old, a0_slot, &hit));
     gram_touch(b, c0 + k);
     int passes = 0;
+    c->persist_norm_done = false;
     // V = push!(V, scale!!(r, 1/beta_old))   lanczos.jl:257
-    KK_TRY(kk_launch_scal(c, v, ld, 1.0 / beta_old, nullptr));
+    if (v_ready) b->norm_col = -1;
+    else KK_TRY(kk_launch_scal(c, v, ld, 1.0 / beta_old, nullptr));
     if (!hit) {
         // w = A v - beta_old v_prev with the fused alpha dot   lanczos.jl:297-299 / 306-308
         kk_spmv_fuse f;
@@ -269,7 +278,10 @@ KK_API int kk_lanczos_expand(kk_op op, kk_basis b, int c0, int k, kk_orth_t orth
         // strict: w -= alpha0 v fused with the first dot of the sweep   lanczos.jl:329-334
         const int64_t offs[1] = {WS_S};
         for (int attempt = 0;; ++attempt) {
-            KK_TRY(pass_mgs_strict_sweeps(c, V, ld, m, 1, w, offs, true, 0, v, a0_dev));
+            c->persist_norm_req = c->fold_scale != 0;   // the kernel holds |w| before it writes w back: store r / beta (next step's scale)
+            const int st_sw = pass_mgs_strict_sweeps(c, V, ld, m, 1, w, offs, true, 0, v, a0_dev);
+            c->persist_norm_req = false;
+            KK_TRY(st_sw);
             if (!c->persist_pending) KK_TRY(ws_fetch_async(c, WS_SCAL, 1, 0));   // (the persistent route fetched the scalars already)
             KK_TRY(fetch_mark(c));
             if (!kk_sharded(c)) KK_TRY(speculate_next(op, b, c0, k + 1, 2, true, 0.0));   // |w| and 1/|w| are on the device
@@ -287,6 +299,7 @@ KK_API int kk_lanczos_expand(kk_op op, kk_basis b, int c0, int k, kk_orth_t orth
         a = pin(c, WS_SCAL + SC_ALPHA0)[0] + pin(c, WS_S)[m - 1];
         bt = pin(c, WS_SCAL + SC_NRM2)[1];
         passes = 1;
+        if (c->persist_norm_done && kk_persist_norm_applies(bt)) { b->norm_col = c0 + k + 1; b->norm_beta = bt; }
     } else {
         kk_set_error("unknown orthogonalizer %d", (int)orth);
         return KK_ERR_INVALID;
@@ -309,10 +322,14 @@ KK_API int kk_arnoldi_expand(kk_op op, kk_basis b, int c0, int k, kk_orth_t orth
     const int m = k + 1;
     double* v = b->col(c0 + k);
     double* w = b->col(c0 + k + 1);
+    const bool v_ready = b->norm_col == c0 + k && b->norm_beta == beta_old;   // see kk_lanczos_expand
+    if (!v_ready) KK_TRY(norm_flush(b));
     bool hit = false;
     KK_TRY(spec_take(op, b, c0, k, 0, beta_old, SCP(c, SC_ALPHA0), &hit));
     gram_touch(b, c0 + k);
-    KK_TRY(kk_launch_scal(c, v, b->ld, 1.0 / beta_old, nullptr));  // push!(V, scale(r, 1/beta))   arnoldi.jl:209
+    c->persist_norm_done = false;
+    if (v_ready) b->norm_col = -1;
+    else KK_TRY(kk_launch_scal(c, v, b->ld, 1.0 / beta_old, nullptr));  // push!(V, scale(r, 1/beta))   arnoldi.jl:209
     if (!hit) {
         kk_spmv_fuse f;
         KK_TRY(kk_launch_spmv(c, op->A, v, w, b->ld, f));           // w = apply(operator, last(V))  :242
@@ -320,9 +337,12 @@ KK_API int kk_arnoldi_expand(kk_op op, kk_basis b, int c0, int k, kk_orth_t orth
     // ask orth_run to enqueue the NEXT step's SpMV right before its final host sync (non-IR variants)
     c->spec_req.active = (orth != KK_CGSIR && orth != KK_MGSIR);
     c->spec_req.op = op; c->spec_req.b = b; c->spec_req.c0 = c0; c->spec_req.k_next = k + 1;
+    c->persist_norm_req = c->fold_scale != 0 && (orth == KK_MGS || orth == KK_MGS2);   // one launch ends the step: it may store r / beta
     int st = orth_run(b, c0, m, w, orth, eta, h, beta, npasses, true);  // orthogonalize!! + norm      :243-244
+    c->persist_norm_req = false;
     c->spec_req.active = false;
     if (st == KK_OK && b->spec_valid) b->spec_beta = *beta;
+    if (st == KK_OK && c->persist_norm_done && kk_persist_norm_applies(*beta)) { b->norm_col = c0 + k + 1; b->norm_beta = *beta; }
     return st;
 }
 
@@ -336,6 +356,8 @@ static int check_gkl(kk_op op, kk_basis bu, kk_basis bv) {
              (long long)ncols, (long long)bu->n, (long long)bv->n);
     KK_CHECK(op->gather || op->A.n_ghost == 0, KK_ERR_UNSUPPORTED,
              "GKL on a row-sharded map needs an operator made by kk_csr_create_sharded_rect");
+    KK_TRY(norm_flush(bu));
+    KK_TRY(norm_flush(bv));
     return KK_OK;
 }
 // v = A'u - beta_old vlast with |v|^2 -> SC_NRM2 triple ; r = A v - alpha u (alpha = *alpha_dev) with |r|^2 -> SC_NRM2B triple.

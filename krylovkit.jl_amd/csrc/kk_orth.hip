@@ -190,20 +190,25 @@ int pass_mgs_strict(kk_ctx c, const double* V, int64_t ld, int m, double* w, int
 // up to the summation order inside an inner product.
 int pass_mgs_strict_sweeps(kk_ctx c, const double* V, int64_t ld, int m, int nsweeps, double* w, const int64_t* ws_s,
                            bool want_norm, int slot, const double* carry_q, const double* carry_s) {
+    c->persist_norm_done = false;
     if (m > 0 && kk_mgs_persist_eligible(c, ld, m, nsweeps)) {
         // both sweeps' coefficient areas must be addressable as out_s + sweep * stride
         const int stride = nsweeps > 1 ? (int)(ws_s[1] - ws_s[0]) : KK_MAX_M;
-        if (stride >= m) {
+        if (c->persist_skip > 0) {
+            --c->persist_skip;   // recovering from a grid-barrier timeout: this sweep takes the launch-per-vector route (same order)
+        } else if (stride >= m) {
+            const bool normalize = c->persist_norm_req && want_norm;
             KK_TRY(kk_launch_mgs_persist(c, V, ld, m, nsweeps, w, carry_q, carry_s, WSP(c, ws_s[0]), stride,
-                                         want_norm ? SCP(c, SC_NRM2) : nullptr));
-            int* err = (int*)((char*)c->d_sync + KK_SYNC_ERR_OFFSET);
-            KK_HIP(hipMemcpyAsync(c->h_sync, err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+                                         want_norm ? SCP(c, SC_NRM2) : nullptr, normalize));
             c->persist_pending = true;
-            // ONE read-back from the first coefficient area through the named scalars (alpha0, |w|^2, |w|, 1/|w|): a D2H copy
-            // costs ~4.5 us on the stream whatever its size, and the areas in between travel along for free (<= 10 KB)
+            c->persist_slot = slot;
+            c->persist_norm_done = normalize;
+            // ONE read-back from the first coefficient area through the named scalars (alpha0, |w|^2, |w|, 1/|w|, ... and the
+            // completion token of the launch): a D2H copy costs ~4.5 us on the stream whatever its size, and the areas in
+            // between travel along for free (<= 10 KB)
             int64_t lo = ws_s[0];
             for (int i = 1; i < nsweeps; ++i) lo = std::min(lo, ws_s[i]);
-            KK_TRY(ws_fetch_async(c, lo, WS_SCAL + 8 - lo, slot));
+            KK_TRY(ws_fetch_async(c, lo, WS_SCAL + 16 - lo, slot));
             return KK_OK;
         }
     }
@@ -218,20 +223,30 @@ int pass_mgs_strict_sweeps(kk_ctx c, const double* V, int64_t ld, int m, int nsw
     return KK_OK;
 }
 // after the host synchronisation that follows a persistent launch: did its grid barrier time out?  Then no block wrote w
-// back (HBM holds the input of the sweep, the pending axpy operands are untouched), the persistent route is switched off
-// for this context and *timed_out tells the caller to repeat the sweep -- pass_mgs_strict_sweeps now takes the
+// back (HBM holds the input of the sweep, the pending axpy operands are untouched), the persistent route is suspended
+// for the next few sweeps and *timed_out tells the caller to repeat the sweep -- pass_mgs_strict_sweeps now takes the
 // launch-per-vector route.  Callers that enqueued dependent work behind the launch (a speculative next-step apply)
 // must cancel it first: it consumed scalars the failed launch never wrote.
 int persist_check(kk_ctx c, bool* timed_out) {
     *timed_out = false;
     if (!c->persist_pending) return KK_OK;
     c->persist_pending = false;
-    if (c->h_sync[0] != 0) {
-        c->h_sync[0] = 0;
+    // a launch that committed wrote its token next to the scalars of the sweep (same read-back); anything else -- the flag
+    // was raised by a block whose spin ran out, blocks left without writing w back -- leaves the previous launch's token
+    if (pin(c, WS_SCAL + SC_PERSIST_OK, c->persist_slot)[0] != c->persist_token) {
         KK_HIP(hipMemsetAsync((char*)c->d_sync + KK_SYNC_ERR_OFFSET, 0, sizeof(int), c->stream));
-        c->mgs_persist = 0;
+        c->persist_norm_done = false;
         ++c->persist_timeouts;
+        // the route is NOT switched off for good -- a transient timeout (GPU shared with another job) used to move
+        // an auto-mode context from the reference's strict order to the low-sync form for the rest of its life, silently
+        // changing the rounding of every later sweep.  The sweep that failed is repeated on the launch-per-vector route
+        // (same strict order); the persistent route is retried after `persist_backoff` further strict sweeps, the interval
+        // doubling with every timeout in a row.
+        c->persist_skip = c->persist_backoff;
+        c->persist_backoff = std::min(c->persist_backoff * 2, 1 << 20);
         *timed_out = true;
+    } else if (c->persist_backoff > 4) {
+        c->persist_backoff = 4;   // a clean launch: back to the short retry interval
     }
     return KK_OK;
 }
@@ -560,10 +575,17 @@ KK_API int kk_orthonormalize(kk_basis b, int c0, int m, kk_basis bw, int cw, kk_
     KK_CHECK(x || m == 0, KK_ERR_INVALID, "null x");
     KK_CHECK(!(bw == b && cw >= c0 && cw < c0 + m), KK_ERR_INVALID, "kk_orthonormalize: w aliases a basis column");
     gram_touch(bw, cw);
+    kk_ctx c = b->ctx;
     double nn = 0;
-    KK_TRY(orth_run(b, c0, m, bw->col(cw), alg, eta, x, &nn, npasses, true));
+    // MGS / MGS2 end with one sweep launch: the persistent kernel can store w / |w| itself
+    c->persist_norm_done = false;
+    c->persist_norm_req = c->fold_scale != 0 && (alg == KK_MGS || alg == KK_MGS2);
+    const int st = orth_run(b, c0, m, bw->col(cw), alg, eta, x, &nn, npasses, true);
+    c->persist_norm_req = false;
+    KK_TRY(st);
     if (nrm) *nrm = nn;
-    return kk_launch_scal(b->ctx, bw->col(cw), bw->ld, 1.0 / nn, nullptr);  // scale!!(v, inv(beta))  :525
+    if (c->persist_norm_done && kk_persist_norm_applies(nn)) return KK_OK;   // already normalised at the kernel's commit
+    return kk_launch_scal(c, bw->col(cw), bw->ld, 1.0 / nn, nullptr);  // scale!!(v, inv(beta))  :525
 }
 
 // _orthogonalize!!(v, q, alg) (orthonormal.jl:455-489)
