@@ -191,11 +191,119 @@ def parity_block(al_g, be_g, al_c, be_c):
 
 
 def kernel_source_sha() -> str:
+    """hash of every device / host source of the library: PMC traffic figures are only reported for the sources they were
+    measured on (tools/profile_gpu.sh stamps them with this)"""
     import hashlib
     h = hashlib.sha256()
-    for f in ("kk_kernels_stream.hip", "kk_kernels_persist.hip", "kk_kernels_spmv.hip", "kk_device.h", "kk_internal.h"):
-        h.update((ROOT / "krylovkit.jl_amd" / "csrc" / f).read_bytes())
+    src = ROOT / "krylovkit.jl_amd" / "csrc"
+    for f in sorted(src.glob("*.hip")) + sorted(src.glob("*.h")):
+        h.update(f.read_bytes())
     return h.hexdigest()[:16]
+
+
+def stamped_traffic(fname: str):
+    """profiles/<fname> (written by tools/profile_gpu.sh from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes) if it
+    was measured on the current sources -> (dict, note); (None, note) otherwise"""
+    tf = ROOT / "profiles" / fname
+    if not tf.exists():
+        return None, f"profiles/{fname} absent: no counter pass on these sources yet"
+    try:
+        tj = json.loads(tf.read_text())
+    except Exception:
+        return None, f"profiles/{fname} unreadable"
+    if tj.get("source_sha") != kernel_source_sha():
+        return None, f"profiles/{fname} was measured on other kernel sources (hash mismatch): stale, not reported"
+    return tj, f"PMC passes of {tj.get('stamped_by', 'tools/profile_gpu.sh')} on the same kernel sources (sha {tj.get('source_sha')})"
+
+
+def physical_roofline(kernel: str, seconds: float, launches: int, traffic_bytes, model_bytes, alg_bytes, min_bytes=None, note=None):
+    """roofline object of one kernel class over a timed region: `achieved` = bytes the kernel really moved (counter traffic
+    when a stamped PMC pass exists, the byte model of DESIGN.md otherwise) / its event-timed duration; `frac` = achieved /
+    8 TB/s.  The SURVEY 8(d) contract figure (ALGORITHMIC bytes, which a kernel that keeps data on chip undercuts) is
+    carried as `algorithmic_equiv_*`, the least any kernel of that shape could move as `min_bytes` / `frac_of_min`."""
+    phys = traffic_bytes if traffic_bytes is not None else model_bytes
+    out = {"kernel": kernel, "bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s", "launches": int(launches),
+           "avg_launch_ms": round(seconds / max(launches, 1) * 1e3, 5)}
+    if phys is not None:
+        out["achieved"] = round(phys / seconds / 1e9, 1)
+        out["frac"] = round(phys / seconds / 1e9 / HBM_PEAK_GBPS, 4)
+    else:
+        out["achieved"] = out["frac"] = None
+    out["traffic"] = None if traffic_bytes is None else round(traffic_bytes / max(launches, 1))
+    out["traffic_source"] = "pmc" if traffic_bytes is not None else ("model" if model_bytes is not None else None)
+    if note:
+        out["traffic_note"] = note
+    if model_bytes is not None:
+        out["hbm_model_bytes_per_launch"] = round(model_bytes / max(launches, 1))
+        out["hbm_model_frac"] = round(model_bytes / seconds / 1e9 / HBM_PEAK_GBPS, 4)
+    if alg_bytes is not None:
+        out["algorithmic_bytes_per_launch"] = round(alg_bytes / max(launches, 1))
+        out["algorithmic_equiv_GBps"] = round(alg_bytes / seconds / 1e9, 1)
+        out["algorithmic_equiv_frac"] = round(alg_bytes / seconds / 1e9 / HBM_PEAK_GBPS, 4)
+    if min_bytes is not None:
+        out["min_bytes_per_launch"] = round(min_bytes / max(launches, 1))
+        out["frac_of_min"] = round(min_bytes / seconds / 1e9 / HBM_PEAK_GBPS, 4)
+    return out
+
+
+def convdiff_rows(nx: int, ny: int, px: float = 0.5, py: float = 0.25) -> sp.csr_matrix:
+    """SURVEY.md 8(d) cfg 3: 2-D convection-diffusion, 5-point central differences, cell Peclet numbers px / py (nonsymmetric)"""
+    n = nx * ny
+    r = np.arange(n, dtype=np.int64)
+    ix = r % nx
+    cols = [r, r - 1, r + 1, r - nx, r + nx]
+    vals = [np.full(n, 4.0), np.full(n, -(1 + px)), np.full(n, -(1 - px)), np.full(n, -(1 + py)), np.full(n, -(1 - py))]
+    ok = [np.ones(n, bool), ix > 0, ix < nx - 1, r - nx >= 0, r + nx < n]
+    rows = np.concatenate([r[m] for m in ok]); cc = np.concatenate([c[m] for c, m in zip(cols, ok)])
+    vv = np.concatenate([v[m] for v, m in zip(vals, ok)])
+    return sp.csr_matrix((vv, (rows, cc)), shape=(n, n))
+
+
+LEG_CLASSES = ("k_project", "k_unproject", "k_unproj_proj", "k_mgs_persist", "k_mgs_panel", "k_mgs_step", "k_spmv_ell", "k_spmv_dia", "k_spmv_sell",
+               "k_spmv_csr", "k_scal", "k_dot", "k_axpby", "k_block_gram", "k_block_update", "k_spmm_dia", "k_spmm_ell")
+
+
+def run_leg(ctx, name: str, sweep, units_per_sweep: int, K: int, model_bytes_per_sweep: dict, alg_bytes_per_sweep: float, meta: dict):
+    """One secondary configuration inside the default line: a warm-up sweep, K event-profiled timed sweeps, the rate, and a
+    roofline object for the kernel class that took the most time (physical bytes: stamped PMC traffic of this configuration
+    when there is one, the byte model otherwise)."""
+    sweep()
+    ctx.sync()
+    ctx.prof_reset(); ctx.prof_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(K):
+        fact = sweep()
+    ctx.sync()
+    dt = time.perf_counter() - t0
+    ctx.prof_enable(0)
+    classes = {}
+    for c in LEG_CLASSES:
+        ms, n = ctx.prof_get(c)
+        if n:
+            classes[c] = (ms, n)
+    tj, note = stamped_traffic("traffic_configs.json")
+    tcfg = (tj or {}).get("configs", {}).get(name, {}) if tj else {}
+    table = {}
+    for c, (ms, n) in sorted(classes.items(), key=lambda kv: -kv[1][0]):
+        tb = tcfg.get(c)          # bytes per sweep from the counters
+        mb = model_bytes_per_sweep.get(c)
+        phys = tb if tb is not None else mb
+        table[c] = {"ms_per_sweep": round(ms / K, 4), "launches_per_sweep": round(n / K, 2),
+                    "bytes_per_sweep": None if phys is None else round(phys), "bytes_source": "pmc" if tb is not None else ("model" if mb is not None else None),
+                    "frac": None if phys is None else round(phys * K / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
+    dom = max(classes, key=lambda c: classes[c][0]) if classes else None
+    roof = None
+    if dom:
+        ms, n = classes[dom]
+        tb, mb = tcfg.get(dom), model_bytes_per_sweep.get(dom)
+        roof = physical_roofline(dom, ms * 1e-3, n, None if tb is None else tb * K, None if mb is None else mb * K, None, note=note)
+    kernel_ms = sum(v[0] for v in classes.values()) / K
+    out = {"value": round(units_per_sweep * K / dt, 2), "ms_per_step": round(dt / K * 1e3, 3), "steps": K,
+           "kernel_ms_per_sweep": round(kernel_ms, 3),
+           "algorithmic_equiv_frac": round(alg_bytes_per_sweep * K / dt / 1e9 / HBM_PEAK_GBPS, 4),
+           "roofline": roof, "kernels": table}
+    out.update(meta)
+    return out, fact
 
 
 def self_launch(args) -> int:
@@ -249,6 +357,11 @@ def main():
     ap.add_argument("--parity-seeds", type=int, default=3, help="start vectors of the full-size parity block (each costs one CPU sweep)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-strict-leg", action="store_true")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="config lanczos, N = 1: skip the `configs` block (BASELINE.json configs[2..4] at full size + the general-format leg of configs[1])")
+    ap.add_argument("--config-steps", type=int, default=3, help="timed sweeps per entry of the `configs` block")
+    ap.add_argument("--only-leg", default=None, choices=["lanczos_ell", "gmres", "block", "gkl"],
+                    help="run nothing but the sweeps of ONE entry of the `configs` block (tools/profile_gpu.sh: counter passes per configuration)")
     ap.add_argument("--ny", type=int, default=NY, help="grid rows per GPU (default 2500 -> 10M rows per GPU)")
     ap.add_argument("--deadline", type=float, default=900.0, help="multi-rank runs only: abort if the whole run takes longer (seconds)")
     ap.add_argument("--backend", default="hip", choices=["hip", "checker"],
@@ -336,6 +449,118 @@ def main():
 
         return dict(sweep=sweep_, n_local=nl, n_global=NX * ny_tot, ny_tot=ny_tot, x0=x0_, keep=(op_, V_, it_))
 
+    def build_gkl(ny_arg):
+        """config 4: operator + iterator of the 5M x 1M sparse random map (rows of A and of U sharded over the ranks)"""
+        m_tot, n_tot, per, Kg = 5_000_000, 1_000_000, 20, 30
+        if ny_arg != NY:                            # reduced size for quick checks: --ny = rows / 2000
+            m_tot, n_tot = ny_arg * 2000, ny_arg * 400
+        r0, r1 = rank * m_tot // world, (rank + 1) * m_tot // world
+        A = gkl_rows(m_tot, n_tot, per, r0, r1)
+        nnz_loc = A.nnz
+        op = kd.NativeShardedRectOperator(A, n_tot, ctx) if use_dist else kk.SparseOperator(A, ctx)
+        del A
+        u0 = np.random.default_rng([6, rank]).random(r1 - r0)
+        it = kk.GKLIterator(op, u0, orth, capacity=Kg + 2)
+        its = Kg - 1
+
+        def sweep_():
+            fact = kk.initialize(it)
+            for _ in range(its):
+                fact = kk.expand_(it, fact)
+            return fact
+
+        nnz_tot = nnz_loc * world
+        spmv1 = 12 * nnz_tot + 4 * (m_tot + n_tot + 2) + 8 * (m_tot + n_tot) * 2     # one direction, CSR accounting of SURVEY 8(d)
+        alg = float(sum(2 * spmv1 + (16 + 24 + 16 * (k - 1) + 24 + 16) * n_tot + (16 + 24 + 16 * k + 24 + 16) * m_tot for k in range(2, Kg + 1)))
+        return dict(sweep=sweep_, sweep_its=its, n_local=r1 - r0, alg_sweep=alg, op=op, spmv_alg_bytes=spmv1, nnz=nnz_tot, shape=(m_tot, n_tot),
+                    workload=f"svdsolve(GKL) expand! sweep: {m_tot}x{n_tot} sparse random, {per} nnz/row, krylovdim={Kg}, 1 step = initialize + {its} expand!",
+                    keep=(op, it))
+
+    def build_block(ny_arg):
+        """config 5: BlockLanczos bs = 16 on the 10M-row Laplacian (rows split over the ranks)"""
+        bs_, Kb_ = 16, 100
+        ny_tot = ny_arg                             # 10M rows in total, split over the ranks (strong scaling)
+        assert ny_tot % world == 0
+        nyl = ny_tot // world
+        nl = NX * nyl
+        A = laplacian_rows(NX, ny_tot, rank * nyl, (rank + 1) * nyl)
+        if use_dist:
+            part = kd.Partition.even(NX * ny_tot, world, rank, align=NX)
+            op = kd.NativeShardedOperator(A, part, ctx, symmetric=True)
+        else:
+            op = kk.SparseOperator(A, ctx, symmetric=True)
+        del A
+        S = kk.DeviceBasis(nl, Kb_ + 3 * bs_, ctx)
+        it = kk.BlockLanczosIterator(op, [None] * bs_, Kb_ + bs_)
+        area_b = it.maxdim + bs_
+
+        def sweep_():
+            for j in range(bs_):
+                S[area_b + j].rand_(100 + j + 1000 * rank)
+            it.x0 = [S[area_b + j] for j in range(bs_)]
+            f = it.initialize(S)
+            while len(f) < Kb_:
+                f = it.expand(f)
+            return f
+
+        its = 6                                     # block steps after initialize: 16 -> 112 basis vectors
+        alg = float(sum((1856 + 16 * k) * NX * ny_tot for k in range(2 * bs_, Kb_ + bs_ + 1, bs_)))
+        return dict(sweep=sweep_, sweep_its=its, n_local=nl, alg_sweep=alg, bs=bs_, Kb=Kb_,
+                    workload=f"BlockLanczos eigsolve expand!: {NX}x{ny_tot} 5-point Laplacian, block size {bs_}, krylovdim={Kb_}, 1 step = initialize + {its} block expand!",
+                    keep=(op, S, it))
+
+    def leg_spec(name):
+        """workload of one entry of the `configs` block -> dict(sweep, units, model bytes per sweep and class, algorithmic bytes
+        per sweep, meta[, kmult, cleanup]); also what `--only-leg` runs under rocprofv3 for profiles/traffic_configs.json"""
+        if name == "lanczos_ell":
+            # configs[1] again with the operator applied the general way: ELL gather kernel on the SparseMatrixCSC's entries, no
+            # stencil recognition (neither the value-free constant-coefficient form nor the stored diagonals)
+            ctx.set_option("spmv_dia", 0)
+            return dict(sweep=prob["sweep"], units=KRYLOVDIM - 1, cleanup=lambda: ctx.set_option("spmv_dia", 1),
+                        model={"k_spmv_ell": 84.0 * prob["n_local"] * KRYLOVDIM, "k_scal": 16.0 * prob["n_local"] * 3},
+                        alg=algorithmic_bytes_sweep(prob["n_global"], KRYLOVDIM),
+                        meta={"metric": "lanczos_iterations_per_second", "unit": "it/s",
+                              "workload": "configs[1] with the library's stencil recognition OFF (option spmv_dia = 0): the general SparseMatrixCSC path, "
+                                          "ELL gather SpMV (12 bytes per stored entry + vectors = 84 N per apply)"})
+        if name == "gmres":
+            # configs[2]: linsolve(GMRES) 2M-row convection-diffusion, krylovdim 60: one Arnoldi cycle m = 2..60 (the restart
+            # kernels are measured by tools/restart_bench.py)
+            nxg, nyg, Kg_ = 2000, 1000, 60
+            Ng = nxg * nyg
+            opg = kk.SparseOperator(convdiff_rows(nxg, nyg), ctx)
+            Vg = kk.DeviceBasis(Ng, Kg_ + 2, ctx)
+            x0g = kk.DeviceBasis(Ng, 1, ctx); x0g[0].rand_(4)
+            itg = kk.ArnoldiIterator(opg, x0g[0], orth, capacity=Kg_ + 2)
+
+            def sweep_g():
+                f_ = kk.initialize(itg, Vg)
+                for _ in range(Kg_ - 1):
+                    f_ = kk.expand_(itg, f_)
+                return f_
+
+            ms_ = range(2, Kg_ + 1)
+            return dict(sweep=sweep_g, units=Kg_ - 1, kmult=3, keep=(opg, Vg, x0g, itg),
+                        model={"k_project": float(sum((8 * m + 16) * Ng for m in ms_)), "k_unproj_proj": float(sum((8 * m + 16) * Ng for m in ms_)),
+                               "k_unproject": float(sum((8 * m + 16) * Ng for m in ms_)), "k_mgs_panel": float(sum((16 * m + 16) * Ng for m in ms_)),
+                               "k_spmv_dia": 24.0 * Ng * Kg_, "k_scal": 16.0 * Ng * Kg_},
+                        alg=float(sum((144 + 32 * m) * Ng for m in ms_)),
+                        meta={"metric": "arnoldi_iterations_per_second", "unit": "it/s",
+                              "workload": f"linsolve(GMRES) expand! cycle: {nxg}x{nyg} convection-diffusion ({Ng} rows), krylovdim={Kg_}, orth {orth.name}, "
+                                          f"1 step = initialize + {Kg_ - 1} expand!"})
+        if name == "block":
+            gb = build_block(NY)     # configs[4]: BlockLanczos bs = 16, 10M rows
+            return dict(sweep=gb["sweep"], units=gb["sweep_its"], keep=gb,
+                        model={"k_block_update": (sum(8 * kn + 256 for kn in range(2 * gb["bs"], gb["Kb"] + gb["bs"] + 1, gb["bs"])) + 256) * float(gb["n_local"])},
+                        alg=gb["alg_sweep"], meta={"metric": "block_lanczos_steps_per_second", "unit": "block steps/s (bs=16, 10M rows)", "workload": gb["workload"]})
+        if name == "gkl":
+            gg = build_gkl(NY)       # configs[3]: svdsolve(GKL) 5M x 1M sparse random (one GPU holds the whole map)
+            return dict(sweep=gg["sweep"], units=gg["sweep_its"], keep=gg,
+                        model={"k_spmv_sell": float(gg["spmv_alg_bytes"]) * (gg["sweep_its"] * 2 + 2)}, alg=gg["alg_sweep"],
+                        meta={"metric": "gkl_iterations_per_second", "unit": "it/s", "workload": gg["workload"], "operator": gg["op"].info(),
+                              "bound_note": "the tiled SpMV is bound by the chip's random-gather rate (one L2 request per stored entry), not by HBM: "
+                                            "profiles/r03_gather_rate_ceiling.json, DESIGN.md section 3"})
+        raise SystemExit(f"unknown leg {name}")
+
     x0_handle = None
     other_leg_mode = None
     if args.config == "lanczos":
@@ -357,69 +582,38 @@ def main():
             (f"basis row-sharded over {world} GPUs ({n_local} rows each, {scaling} scaling); per iteration libkrylov_hip issues 2 ncclAllReduce "
              "(2m+1 and 1 doubles) + 1 grouped ncclSend/Recv ghost exchange")
     elif args.config == "gkl":
-        m_tot, n_tot, per, Kg = 5_000_000, 1_000_000, 20, 30
-        if args.ny != NY:                           # reduced size for quick checks: --ny = rows / 2000
-            m_tot, n_tot = args.ny * 2000, args.ny * 400
-        r0, r1 = rank * m_tot // world, (rank + 1) * m_tot // world
-        A = gkl_rows(m_tot, n_tot, per, r0, r1)
-        nnz_loc = A.nnz
-        op = kd.NativeShardedRectOperator(A, n_tot, ctx) if use_dist else kk.SparseOperator(A, ctx)
-        del A
-        u0 = np.random.default_rng([6, rank]).random(r1 - r0)
-        it = kk.GKLIterator(op, u0, orth, capacity=Kg + 2)
-        sweep_its = Kg - 1
-
-        def sweep():
-            fact = kk.initialize(it)
-            for _ in range(sweep_its):
-                fact = kk.expand_(it, fact)
-            return fact
-
+        g = build_gkl(args.ny)
+        sweep, sweep_its, n_local = g["sweep"], g["sweep_its"], g["n_local"]
         units_per_sweep = sweep_its                # the problem is fixed, ranks split its rows (strong scaling)
-        nnz_tot = nnz_loc * world
-        spmv = 2 * (12 * nnz_tot + 4 * (m_tot + n_tot + 2) + 8 * (m_tot + n_tot) * 2)
-        alg_sweep = float(sum(spmv + (16 + 24 + 16 * (k - 1) + 24 + 16) * n_tot + (16 + 24 + 16 * k + 24 + 16) * m_tot for k in range(2, Kg + 1)))
+        alg_sweep = g["alg_sweep"]
         scaling = "strong"
         metric = "gkl_iterations_per_second"
         unit = "it/s (GKL expand! on the whole 5M x 1M map)"
-        workload = f"svdsolve(GKL) expand! sweep: {m_tot}x{n_tot} sparse random, {per} nnz/row, krylovdim={Kg}, 1 step = initialize + {sweep_its} expand!"
+        workload = g["workload"]
         parallelism = "single GPU" if not use_dist else \
             f"rows of A and of the U basis sharded over {world} GPUs, V basis sharded evenly; per iteration 1 ncclAllGather (v) + 1 ncclReduceScatter (A'u) + the all-reduces of the sweeps"
-        n_local = r1 - r0
     else:  # block
-        bs, Kb = 16, 100
-        ny_tot = args.ny                            # 10M rows in total, split over the ranks (strong scaling)
-        assert ny_tot % world == 0
-        nyl = ny_tot // world
-        n_local = NX * nyl
-        A = laplacian_rows(NX, ny_tot, rank * nyl, (rank + 1) * nyl)
-        if use_dist:
-            part = kd.Partition.even(NX * ny_tot, world, rank, align=NX)
-            op = kd.NativeShardedOperator(A, part, ctx, symmetric=True)
-        else:
-            op = kk.SparseOperator(A, ctx, symmetric=True)
-        del A
-        S = kk.DeviceBasis(n_local, Kb + 3 * bs, ctx)
-        it = kk.BlockLanczosIterator(op, [None] * bs, Kb + bs)
-        area_b = it.maxdim + bs
-
-        def sweep():
-            for j in range(bs):
-                S[area_b + j].rand_(100 + j + 1000 * rank)
-            it.x0 = [S[area_b + j] for j in range(bs)]
-            f = it.initialize(S)
-            while len(f) < Kb:
-                f = it.expand(f)
-            return f
-
-        sweep_its = 6                               # block steps after initialize: 16 -> 112 basis vectors
+        g = build_block(args.ny)
+        sweep, sweep_its, n_local, bs, Kb = g["sweep"], g["sweep_its"], g["n_local"], g["bs"], g["Kb"]
         units_per_sweep = sweep_its
-        alg_sweep = float(sum((1856 + 16 * k) * NX * ny_tot for k in range(2 * bs, Kb + bs + 1, bs)))
+        alg_sweep = g["alg_sweep"]
         scaling = "strong"
         metric = "block_lanczos_steps_per_second"
         unit = "block steps/s (bs=16, 10M rows)"
-        workload = f"BlockLanczos eigsolve expand!: {NX}x{ny_tot} 5-point Laplacian, block size {bs}, krylovdim={Kb}, 1 step = initialize + {sweep_its} block expand!"
+        workload = g["workload"]
         parallelism = "single GPU" if not use_dist else f"rows sharded over {world} GPUs; Gram panels all-reduced (ncclAllReduce), ghost exchange per column of the block apply"
+
+    if args.only_leg:
+        assert args.config == "lanczos" and world == 1 and not use_dist
+        spec = leg_spec(args.only_leg)
+        nsw = 1 + max(1, args.config_steps)
+        for _ in range(nsw):
+            spec["sweep"]()
+        sync()
+        if spec.get("cleanup"):
+            spec["cleanup"]()
+        print(json.dumps({"only_leg": args.only_leg, "sweeps": nsw, "source_sha": kernel_source_sha()}), flush=True)
+        return
 
     # warm-up sweeps; the last one is event-profiled per kernel class (breakdown only, untimed)
     ctx.prof_reset()
@@ -490,7 +684,7 @@ def main():
         other_leg = {"scaling": other_leg_mode, "value": round(u2 * K / d_, 3), "ms_per_step": round(d_ / K * 1e3, 3),
                      "rows_per_gpu": prob2["n_local"], "rows_total": prob2["n_global"],
                      "job_iterations_per_second": round(sweep_its * K / d_, 3),
-                     "hbm_algorithmic_frac_of_peak_per_gpu": round(algorithmic_bytes_sweep(prob2["n_global"], KRYLOVDIM) * K / d_ / 1e9 / (HBM_PEAK_GBPS * world), 4),
+                     "algorithmic_equiv_frac_of_peak_per_gpu": round(algorithmic_bytes_sweep(prob2["n_global"], KRYLOVDIM) * K / d_ / 1e9 / (HBM_PEAK_GBPS * world), 4),
                      "unit": "it/s (10M-row Lanczos iterations, summed over GPUs)" if other_leg_mode == "weak" else "it/s (Lanczos iterations of the one 10M-row problem)"}
         del prob2
 
@@ -509,70 +703,54 @@ def main():
         if dom == "k_mgs_persist":
             ms, n = classes[dom]
             # one launch per expand at basis size m = 2..100: the whole MGS sweep of the reference (for q in V: s = <q, w>;
-            # w -= s q, the pending "w -= alpha v" in front, |w| behind).  ALGORITHMIC bytes:
-            # pass(m) = (16 m + 24) N -- every basis vector read twice, w read twice and written once.  The kernel itself
-            # moves less: w stays in registers, and `parked` of the `rows` grid-rows of a basis vector wait ON CHIP (LDS +
-            # spare registers) between the inner product and the update that uses them again, so only the rest is read a
-            # second time -- which is why `frac` can exceed 1 here; `hbm_model_*` give the bytes really requested.
-            per_sweep = sum((16 * m + 24) * n_local for m in range(2, KRYLOVDIM + 1))
-            bytes_per_launch = per_sweep / (KRYLOVDIM - 1)
-            avg_ms = ms / n
-            achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+            # w -= s q, the pending "w -= alpha v" in front, |w| behind, w / |w| stored).  What the launch really moves: w read and
+            # written once (it lives in registers in between), every basis vector once, plus the grid-rows of it that do not
+            # fit on chip (LDS + spare registers) between the inner product and the update a second time:
+            #   model(m) = (8 m (1 + reread) + 24) N.       `frac` is PHYSICAL: counter traffic (stamped PMC pass) or this model
+            # over the event-timed duration.  The contract figure of SURVEY 8(d), pass(m) = (16 m + 24) N -- every basis vector
+            # read twice -- is what the projection-based kernels move and is carried as algorithmic_equiv_*; the least a strict
+            # sweep with w on chip could move is (8 m + 16) N (min_bytes, frac_of_min).
+            launches_per_sweep = KRYLOVDIM - 1
             pt = int(ctx.get_option("persist_threads"))
-            rows = -(-(n_local + 511) // (256 * pt * 2))                        # grid-rows of double2 per thread (ld / (CUs * threads * 2))
+            ncu = int(ctx.get_option("num_cus"))
+            ld_rows = (n_local + 511) // 512 * 512
+            if (ld_rows // 512) % 2 == 0:
+                ld_rows += 512
+            rows = -(-ld_rows // (ncu * pt * 2))                                # grid-rows of double2 per thread
             lds_rows = min(rows, (160 * 1024 - 256) // (pt * 16)) if ctx.get_option("persist_lds") >= 1 else 0
             reg_rows = min(rows - lds_rows, 8) if (ctx.get_option("persist_lds") >= 2 and pt == 512) else 0
             reread = (rows - lds_rows - reg_rows) / rows
-            model = sum((8 * m * (1 + reread) + 8 * (1 + reread) + 16) * n_local for m in range(2, KRYLOVDIM + 1)) / (KRYLOVDIM - 1)
-            traffic, traffic_note = None, None
-            tf = ROOT / "profiles" / "traffic.json"
-            if tf.exists():
-                try:
-                    tj = json.loads(tf.read_text())
-                    if tj.get("source_sha") == kernel_source_sha():
-                        traffic = tj.get(dom)
-                        traffic_note = f"PMC passes of {tj.get('stamped_by', 'tools/profile_gpu.sh')} on the same kernel sources (sha {tj.get('source_sha')})"
-                    else:
-                        traffic_note = "profiles/traffic.json was measured on other kernel sources (hash mismatch): stale, not reported"
-                except Exception:
-                    traffic = None
-            roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_note": traffic_note,
-                        "launches": int(n), "avg_launch_ms": round(avg_ms, 5),
-                        "algorithmic_bytes_per_launch": round(bytes_per_launch),
-                        "on_chip_parking": {"grid_rows_per_thread": int(rows), "parked_in_lds": int(lds_rows), "parked_in_registers": int(reg_rows),
-                                            "second_read_fraction": round(reread, 4)},
-                        "hbm_model_bytes_per_launch": round(model), "hbm_model_GBps": round(model / (avg_ms * 1e-3) / 1e9, 1),
-                        "hbm_model_frac": round(model / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                        "timed_region_kernel_ms": {k: round(v[0], 3) for k, v in classes.items()},
-                        "one_sweep_kernel_ms_breakdown": breakdown}
+            scale_n = n / launches_per_sweep                                   # sweeps in the timed region
+            alg = sum((16 * m + 24) * n_local for m in range(2, KRYLOVDIM + 1)) * scale_n
+            model = sum((8 * m * (1 + reread) + 24) * n_local for m in range(2, KRYLOVDIM + 1)) * scale_n
+            least = sum((8 * m + 16) * n_local for m in range(2, KRYLOVDIM + 1)) * scale_n
+            tj, traffic_note = stamped_traffic("traffic.json")
+            per_launch = (tj or {}).get(dom)
+            roofline = physical_roofline(dom, ms * 1e-3, n, None if per_launch is None else per_launch * n, model, alg, least, traffic_note)
+            cap_rows = int(ctx.get_option("persist_capacity_rows"))
+            roofline["on_chip_parking"] = {"grid_rows_per_thread": int(rows), "parked_in_lds": int(lds_rows), "parked_in_registers": int(reg_rows),
+                                           "second_read_fraction": round(reread, 4)}
+            roofline["persist"] = {"eligible": True, "rows": int(ld_rows), "capacity_rows": cap_rows, "rows_per_thread": int(2 * rows),
+                                   "used_fraction_of_capacity": round(ld_rows / cap_rows, 4),
+                                   "beyond_capacity": "a work vector longer than capacity_rows does not fit the register file of the chip: mgs_mode auto then runs the "
+                                                      "low-synchronisation form (the `mgs2_lowsync` leg of this line); both sides of the limit are parity-tested "
+                                                      "(tests/test_gpu_fullsize.py)"}
+            roofline["scale_pass_folded"] = bool(ctx.get_option("fold_scale"))
+            roofline["timed_region_kernel_ms"] = {k: round(v[0], 3) for k, v in classes.items()}
+            roofline["one_sweep_kernel_ms_breakdown"] = breakdown
         elif dom in ("k_project", "k_unproject"):
             ms, n = classes[dom]
-            # one launch per expand at basis size m = 2..100: project moves (8m + 8) N algorithmic bytes
-            # (V once + w), unproject (8m + 16) N (V once + w read/write); their sum is pass(m) = (16m + 24) N.
+            # one launch per expand at basis size m = 2..100: project moves (8m + 8) N bytes (V once + w; + 8 N with the Gram
+            # row of the newest vector riding along), unproject (8m + 16) N (V once + w read/write): here the byte model IS the
+            # algorithmic count of SURVEY 8(d) (their sum is pass(m) = (16m + 24) N) and the counters agree with it within 1 %
             extra = 8 if dom == "k_project" else 16
-            per_sweep = sum((8 * m + extra) * n_local for m in range(2, KRYLOVDIM + 1))
-            bytes_per_launch = per_sweep / (KRYLOVDIM - 1)
-            avg_ms = ms / n
-            achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-            traffic, traffic_note = None, None
-            tf = ROOT / "profiles" / "traffic.json"
-            if tf.exists():
-                try:
-                    tj = json.loads(tf.read_text())
-                    if tj.get("source_sha") == kernel_source_sha():
-                        traffic = tj.get(dom)
-                        traffic_note = f"PMC passes of {tj.get('stamped_by', 'tools/profile_gpu.sh')} on the same kernel sources (sha {tj.get('source_sha')})"
-                    else:
-                        traffic_note = "profiles/traffic.json was measured on other kernel sources (hash mismatch): stale, not reported"
-                except Exception:
-                    traffic = None
-            roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_note": traffic_note,
-                        "launches": int(n), "avg_launch_ms": round(avg_ms, 5),
-                        "algorithmic_bytes_per_launch": round(bytes_per_launch),
-                        "timed_region_kernel_ms": {k: round(v[0], 3) for k, v in classes.items()},
-                        "one_sweep_kernel_ms_breakdown": breakdown}
+            scale_n = n / (KRYLOVDIM - 1)
+            model = sum((8 * m + extra) * n_local for m in range(2, KRYLOVDIM + 1)) * scale_n
+            tj, traffic_note = stamped_traffic("traffic.json")
+            per_launch = (tj or {}).get(dom)
+            roofline = physical_roofline(dom, ms * 1e-3, n, None if per_launch is None else per_launch * n, model, model, model, traffic_note)
+            roofline["timed_region_kernel_ms"] = {k: round(v[0], 3) for k, v in classes.items()}
+            roofline["one_sweep_kernel_ms_breakdown"] = breakdown
         elif dom == "k_mgs_step":
             ms, n = classes[dom]
             roofline = {"kernel": dom, "bound": "hbm", "achieved": round(32.0 * n_local / (ms / n * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS,
@@ -581,30 +759,31 @@ def main():
                         "one_sweep_kernel_ms_breakdown": breakdown}
 
     if args.config == "block":
-        # dominant kernel of the block step: k_block_update_lds, W <- W - V P with the whole basis (kn = 32 .. 112 columns after
-        # the push) streamed once and the 16-column residual block read and written: (8 kn + 256) N algorithmic bytes per launch;
-        # the sweep adds one 16 -> 16 column launch in initialize (256 N); launches skipped on the device (second CholQR2
-        # back-substitution, a few microseconds each) are in the launch count but carry no bytes
-        ms, n = ctx.prof_get("k_block_update")
-        if n:
-            per_sweep = (sum(8 * kn + 256 for kn in range(2 * bs, Kb + bs + 1, bs)) + 256) * float(n_local)
-            achieved = per_sweep * K / (ms * 1e-3) / 1e9
-            tfile = ROOT / "profiles" / "traffic_block.json"
-            traffic, traffic_note = None, None
-            if tfile.exists():
-                try:
-                    tj = json.loads(tfile.read_text())
-                    traffic = tj.get("k_block_update_bytes_per_sweep")
-                    traffic_note = tj.get("_comment")
-                except Exception:
-                    pass
-            roofline = {"kernel": "k_block_update_lds", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_note": traffic_note,
-                        "launches": int(n), "class_ms_per_sweep": round(ms / K, 3), "algorithmic_bytes_per_sweep": round(per_sweep),
-                        "per_block_step_ms": round(elapsed / K / sweep_its * 1e3, 3),
-                        "timed_region_kernel_ms": {k: round(ctx.prof_get(k)[0], 3) for k in ("k_block_update", "k_block_gram", "k_spmm_dia", "k_spmm_ell")
-                                                   if ctx.prof_get(k)[1]},
-                        "one_sweep_kernel_ms_breakdown": breakdown}
+        # the two basis-streaming classes of the block step.  k_block_update_lds: W <- W - V P with the whole basis (kn = 32 ..
+        # 112 columns after the push) streamed once and the 16-column residual block read and written: (8 kn + 256) N bytes per
+        # launch, + one 16 -> 16 column launch in initialize (256 N); launches skipped on the device (second CholQR2
+        # back-substitution, a few microseconds each) are in the launch count but carry no bytes.  k_block_gram: counters only.
+        tj, note = stamped_traffic("traffic_configs.json")
+        tcfg = (tj or {}).get("configs", {}).get("block", {}) if tj else {}
+        per_class = {}
+        for cls in ("k_block_gram", "k_block_update", "k_spmm_dia", "k_spmm_ell"):
+            ms, n = ctx.prof_get(cls)
+            if n:
+                per_class[cls] = (ms, n)
+        model = {"k_block_update": (sum(8 * kn + 256 for kn in range(2 * bs, Kb + bs + 1, bs)) + 256) * float(n_local)}
+        if per_class:
+            dom = max(per_class, key=lambda c_: per_class[c_][0])
+            ms, n = per_class[dom]
+            tb, mb = tcfg.get(dom), model.get(dom)
+            roofline = physical_roofline(dom, ms * 1e-3, n, None if tb is None else tb * K, None if mb is None else mb * K, None, note=note)
+            roofline["per_block_step_ms"] = round(elapsed / K / sweep_its * 1e3, 3)
+            roofline["classes"] = {c_: {"ms_per_sweep": round(v[0] / K, 3), "launches_per_sweep": round(v[1] / K, 1),
+                                        "bytes_per_sweep": (tcfg.get(c_) if tcfg.get(c_) is not None else (round(model[c_]) if c_ in model else None)),
+                                        "bytes_source": "pmc" if tcfg.get(c_) is not None else ("model" if c_ in model else None),
+                                        "frac": (round((tcfg.get(c_) if tcfg.get(c_) is not None else model[c_]) * K / (v[0] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
+                                                 if (tcfg.get(c_) is not None or c_ in model) else None)}
+                                   for c_, v in per_class.items()}
+            roofline["one_sweep_kernel_ms_breakdown"] = breakdown
 
     # ---------------- secondary leg: the OTHER execution order of MGS2 on the same workload (the headline ran the library default)
     strict, lowsync_leg = None, None
@@ -616,7 +795,7 @@ def main():
         dts, fs = timed(sweep, 1)
         ctx.set_option("mgs_mode", MODE[args.mgs_mode])
         leg = {"value": round(units_per_sweep / dts, 3), "unit": "it/s", "ms_per_step": round(dts * 1e3, 3),
-               "hbm_algorithmic_frac_of_peak_per_gpu": round(alg_sweep / dts / 1e9 / (HBM_PEAK_GBPS * world), 4),
+               "algorithmic_equiv_frac_of_peak_per_gpu": round(alg_sweep / dts / 1e9 / (HBM_PEAK_GBPS * world), 4),
                "max_alpha_reldiff_vs_headline": float(np.max(np.abs(np.array(fs.alphas) - np.array(fact.alphas)) / np.abs(np.array(fact.alphas))))}
         if other == 0:
             # strict MGS2 as the reference codes it: (176 + 16 m) N algorithmic bytes per expand as well
@@ -630,6 +809,44 @@ def main():
                            "+ one update pass (k_project / k_unproject, the basis read twice per expand: 16 N bytes per vector); the "
                            "round-1/2 headline configuration")
             lowsync_leg = leg
+
+    # ---------------- physical bytes of one whole sweep (config 2, one GPU): per class, counter traffic where stamped, byte model otherwise
+    sweep_physical = None
+    if args.config == "lanczos" and world == 1 and not use_dist and roofline and roofline.get("achieved"):
+        tj, _ = stamped_traffic("traffic.json")
+        tj = tj or {}
+        N_ = float(n_local)
+        fmt = prob["keep"][0].info()["format"]
+        spmv_cls = "k_spmv_dia" if "DIA" in fmt and ctx.get_option("spmv_dia") else "k_spmv_ell"
+        spmv_model = {"ELL+DIA const": 24.0, "ELL+DIA": 64.0}.get(fmt, 84.0) * N_ if spmv_cls == "k_spmv_dia" else 84.0 * N_
+        per_launch_dom = roofline["traffic"] if roofline.get("traffic") is not None else roofline.get("hbm_model_bytes_per_launch")
+        n_scal = 3 if (headline_is_strict and ctx.get_option("fold_scale")) else 2 + sweep_its
+        parts = {roofline["kernel"]: per_launch_dom * sweep_its * (2 if roofline["kernel"] in ("k_project", "k_unproject") else 1),
+                 spmv_cls: (tj.get(spmv_cls) or spmv_model) * (sweep_its + 1),
+                 "k_scal": (tj.get("k_scal") or 16.0 * N_) * n_scal,
+                 "initialize (norms, axpby, one vector-vector MGS2 step; model)": 88.0 * N_}
+        tot = float(sum(parts.values()))
+        sweep_physical = {"bytes_per_sweep": round(tot), "GBps": round(tot * K / elapsed / 1e9, 1),
+                          "frac_of_peak": round(tot * K / elapsed / 1e9 / HBM_PEAK_GBPS, 4),
+                          "parts_bytes": {k: round(v) for k, v in parts.items()},
+                          "note": "bytes the kernels of one sweep really move (counter traffic per launch where profiles/traffic.json is current, the "
+                                  "byte models of DESIGN.md section 3 otherwise) over the wall time of the sweep"}
+
+    # ---------------- `configs` block: BASELINE.json configs[2..4] at full size + the general-format leg of configs[1], one GPU
+    configs = None
+    if args.config == "lanczos" and world == 1 and not use_dist and not args.no_configs and args.ny == NY:
+        configs = {}
+        for key, name in (("lanczos_general_format", "lanczos_ell"), ("gmres_2M", "gmres"), ("block_10M_bs16", "block"), ("gkl_5Mx1M", "gkl")):
+            spec = leg_spec(name)
+            try:
+                leg, _ = run_leg(ctx, name, spec["sweep"], spec["units"], max(1, args.config_steps) * spec.get("kmult", 1), spec["model"], spec["alg"], spec["meta"])
+            finally:
+                if spec.get("cleanup"):
+                    spec["cleanup"]()
+            if name == "block":
+                leg["ms_per_block_step"] = round(leg["ms_per_step"] / spec["units"], 3)
+            configs[key] = leg
+            del spec
 
     line = None
     if rank == 0:
@@ -645,10 +862,15 @@ def main():
                 "rows_per_gpu": n_local, "parallelism": parallelism,
             },
             "job_iterations_per_second": round(sweep_its * K / elapsed, 3),
-            "hbm_algorithmic_GBps": round(alg_sweep * K / elapsed / 1e9, 1),
-            "hbm_algorithmic_frac_of_peak_per_gpu": round(alg_sweep * K / elapsed / 1e9 / (HBM_PEAK_GBPS * world), 4),
+            "hbm_physical": sweep_physical,
+            # the SURVEY 8(d) contract figure: ALGORITHMIC bytes (every basis vector read twice per pass) over the wall time.  It is
+            # what the target of BASELINE.md is written in (>= 0.60) and exceeds 1 once a kernel keeps data on chip between its two uses
+            "algorithmic_equiv_GBps": round(alg_sweep * K / elapsed / 1e9, 1),
+            "algorithmic_equiv_frac_of_peak_per_gpu": round(alg_sweep * K / elapsed / 1e9 / (HBM_PEAK_GBPS * world), 4),
             "roofline": roofline,
         }
+        if configs:
+            out["configs"] = configs
         if args.config != "block":
             out["last_alpha"], out["last_beta"] = fact.alphas[-1], fact.betas[-1]
         if world > 1 and args.config == "lanczos":

@@ -53,3 +53,50 @@ if "FETCH_SIZE" in res and "WRITE_SIZE" in res and "--no-traffic" not in sys.arg
             traffic[short] = round((2 * sum(v["sum"] for v in f) / nf + sum(v["sum"] for v in w) / nw) * 1024)
     (dst / "traffic.json").write_text(json.dumps(traffic, indent=1))
     print("traffic.json:", traffic)
+
+
+# 4. the same per entry of the bench line's `configs` block: bytes per SWEEP and kernel class ((2*FETCH_SIZE + WRITE_SIZE)*1024
+# summed over the launches of a class, divided by the sweeps `bench.py --only-leg` ran) -> traffic_configs.json
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from bench import LEG_CLASSES, kernel_source_sha  # noqa: E402,F811
+
+
+def per_class(sub, ctr):
+    acc = defaultdict(float)
+    for f in find(sub, "*counter_collection.csv"):
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                if row.get("Counter_Name") != ctr:
+                    continue
+                k = row.get("Kernel_Name", "?").split("(")[0]
+                k = k[5:] if k.startswith("void ") else k
+                for cls in sorted(LEG_CLASSES, key=len, reverse=True):
+                    if k.startswith(cls):
+                        acc[cls] += float(row["Counter_Value"])
+                        break
+    return acc
+
+
+cfgs = {}
+for leg in ("lanczos_ell", "gmres", "block", "gkl"):
+    jf, jw = out / f"leg_{leg}_fetch.json", out / f"leg_{leg}_write.json"
+    if not (jf.exists() and jw.exists()):
+        continue
+    try:
+        sweeps_f = json.loads([l for l in jf.read_text().splitlines() if l.startswith("{")][-1])["sweeps"]
+        sweeps_w = json.loads([l for l in jw.read_text().splitlines() if l.startswith("{")][-1])["sweeps"]
+    except Exception as e:
+        print("leg", leg, "no JSON line:", e)
+        continue
+    fe, wr = per_class(f"pmc_fetch_{leg}", "FETCH_SIZE"), per_class(f"pmc_write_{leg}", "WRITE_SIZE")
+    cfgs[leg] = {cls: round((2 * fe.get(cls, 0.0) / sweeps_f + wr.get(cls, 0.0) / sweeps_w) * 1024) for cls in set(fe) | set(wr)}
+    cfgs[leg]["_sweeps_profiled"] = sweeps_f
+    for f in find(f"trace_{leg}", "*kernel_stats.csv"):
+        (dst / f"{tag}_{leg}_kernel_stats.csv").write_text(f.read_text())
+if cfgs and "--no-traffic" not in sys.argv:
+    tc = {"_comment": "HBM bytes per SWEEP and kernel class of every entry of bench.py's `configs` block, from separate rocprofv3 --pmc FETCH_SIZE / "
+                      "WRITE_SIZE passes of `bench.py --only-leg <name>`: (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 correction of MI355X_MICROARCH.md) "
+                      "summed over the launches of the class, divided by the sweeps of the run",
+          "source_sha": kernel_source_sha(), "stamped_by": f"tools/profile_gpu.sh {tag}", "configs": cfgs}
+    (dst / "traffic_configs.json").write_text(json.dumps(tc, indent=1))
+    print("traffic_configs.json:", json.dumps(cfgs))
