@@ -71,8 +71,8 @@ static int stage_coef(kk_ctx c, const double* S, int lds, int m, int j0, int nb,
     return KK_OK;
 }
 // W[:, j] = beta W[:, j] + alpha V S[:, j]  (S host, m x q col-major lds); norms_host optional
-static int block_update_run(kk_ctx c, const double* V, int64_t ld, int m, double* W, int64_t ldw, int q, const double* S,
-                            int lds, double alpha, double beta, double* norms) {
+int block_update_run(kk_ctx c, const double* V, int64_t ld, int m, double* W, int64_t ldw, int q, const double* S,
+                     int lds, double alpha, double beta, double* norms) {
     if (q == 0) return KK_OK;
     KK_CHECK((int64_t)m * 16 + 64 <= KK_BLK_SCRATCH / 2, KK_ERR_UNSUPPORTED, "block_update: m=%d too large", m);
     double* nrm_dev = c->blk + KK_BLK_SCRATCH / 2;  // q doubles

@@ -21,6 +21,7 @@ static const double KK_EPS = std::numeric_limits<double>::epsilon();
 #define CHECK_COL(b, c) do { KK_CHECK((b) && (c) >= 0 && (c) < (b)->cap, KK_ERR_INVALID, "%s: column %d out of range", __func__, (c)); KK_TRY(norm_flush(b)); } while (0)
 #define CHECK_SAME(bx, by) KK_CHECK((bx)->ctx == (by)->ctx && (bx)->n == (by)->n && (bx)->ld == (by)->ld, KK_ERR_DIM, "%s: vector length mismatch (%lld vs %lld)", __func__, (long long)(bx)->n, (long long)(by)->n)
 #define CHECK_RANGE(b, c0, m) do { KK_CHECK((b) && (c0) >= 0 && (m) >= 0 && (c0) + (m) <= (b)->cap && (m) <= KK_MAX_M, KK_ERR_INVALID, "%s: column range [%d,%d) invalid (capacity %d, max %d per call)", __func__, (c0), (c0) + (m), (b) ? (b)->cap : 0, KK_MAX_M); KK_TRY(norm_flush(b)); } while (0)
+// (CHECK_RANGE: one kernel panel, m <= KK_MAX_M; CHECK_BLOCK: any number of columns -- the entry point goes panel by panel)
 #define CHECK_BLOCK(b, c0, p) do { KK_CHECK((b) && (c0) >= 0 && (p) >= 0 && (c0) + (p) <= (b)->cap, KK_ERR_INVALID, "%s: block [%d,%d) outside capacity %d", __func__, (c0), (c0) + (p), (b) ? (b)->cap : 0); KK_TRY(norm_flush(b)); } while (0)
 
 // ---- scalar read-backs (kk_context.hip): results of the finalize kernels travel through the pinned mirror of the
@@ -88,5 +89,8 @@ int fetch_wait(kk_ctx c);    // ... and wait for it (not for work enqueued after
 int final_sync(kk_ctx c);    // fetch_mark + speculative next-step apply (if requested) + fetch_wait
 
 // ---- block operations (kk_block.hip)
+// W[:, j] = beta W[:, j] + alpha V S[:, j], j < q (S on the host, m x q column-major with leading dimension lds; m <= KK_MAX_M)
+int block_update_run(kk_ctx c, const double* V, int64_t ld, int m, double* W, int64_t ldw, int q, const double* S, int lds,
+                     double alpha, double beta, double* norms);
 int block_inner_run(kk_ctx c, const double* X, int64_t ldx, int p, const double* Y, int64_t ldy, int q, int64_t ld,
                     double* M, int ldm);

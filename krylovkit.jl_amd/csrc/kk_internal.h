@@ -359,6 +359,7 @@ int kk_launch_mgs_step(kk_ctx ctx, double* w, int64_t ld, const double* q_prev, 
 int kk_launch_basistransform(kk_ctx ctx, double* V, int64_t ld, int m, int n, const double* U_dev);
 int kk_launch_givens(kk_ctx ctx, double* q1, double* q2, int64_t ld, double c, double s);
 int kk_launch_householder(kk_ctx ctx, double* V, int64_t ld, int m, const kk_coef* v, double beta);
+int kk_launch_householder_dev(kk_ctx ctx, double* V, int64_t ld, int m, const double* v_dev, double beta);
 int kk_launch_rank1(kk_ctx ctx, double* V, int64_t ld, int m, const double* y, const kk_coef* x, double alpha,
                     double beta);
 

@@ -124,6 +124,27 @@ __global__ __launch_bounds__(KK_TPB) void k_householder(double* __restrict__ V, 
     }
 }
 
+// the same with the reflector read from device memory: more than KK_MAX_M columns (the kernarg block holds 256 coefficients)
+__global__ __launch_bounds__(KK_TPB) void k_householder_dev(double* __restrict__ V, int64_t ld, int m, const double* __restrict__ hv,
+                                                            double beta, int64_t rpb) {
+    const int64_t r0 = (int64_t)blockIdx.x * rpb, r1 = imin(r0 + rpb, ld);
+    for (int64_t r = r0 + threadIdx.x * 2; r < r1; r += KK_SUB) {
+        d2 t{0.0, 0.0};
+        for (int j = 0; j < m; ++j) {
+            const d2 x = ld2(V + (int64_t)j * ld + r);
+            const double c = hv[j];
+            t.x = fma(x.x, c, t.x); t.y = fma(x.y, c, t.y);
+        }
+        t.x *= beta; t.y *= beta;
+        for (int j = 0; j < m; ++j) {
+            d2 x = ld2(V + (int64_t)j * ld + r);
+            const double c = hv[j];
+            x.x = fma(-t.x, c, x.x); x.y = fma(-t.y, c, x.y);
+            st2(V + (int64_t)j * ld + r, x);
+        }
+    }
+}
+
 // rank1update! (orthonormal.jl:210-275): V_j = beta*V_j + alpha * y * x[j]
 __global__ __launch_bounds__(KK_TPB) void k_rank1(double* __restrict__ V, int64_t ld, int m,
                                                   const double* __restrict__ y, kk_coef xc, double alpha, double beta,
@@ -199,6 +220,14 @@ int kk_launch_householder(kk_ctx ctx, double* V, int64_t ld, int m, const kk_coe
     kk_prof_scope ps(ctx, "k_householder");
     kk_part p = kk_partition(ctx, ld);
     hipLaunchKernelGGL(k_householder, dim3(p.nblk), dim3(KK_TPB), 0, ctx->stream, V, ld, m, *v, beta, p.rpb);
+    KK_HIP(hipGetLastError());
+    return KK_OK;
+}
+
+int kk_launch_householder_dev(kk_ctx ctx, double* V, int64_t ld, int m, const double* v_dev, double beta) {
+    kk_prof_scope ps(ctx, "k_householder");
+    kk_part p = kk_partition(ctx, ld);
+    hipLaunchKernelGGL(k_householder_dev, dim3(p.nblk), dim3(KK_TPB), 0, ctx->stream, V, ld, m, v_dev, beta, p.rpb);
     KK_HIP(hipGetLastError());
     return KK_OK;
 }

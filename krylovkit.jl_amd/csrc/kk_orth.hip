@@ -32,23 +32,53 @@ KK_API int kk_unproject(kk_basis by, int cy, kk_basis b, int c0, int m, const do
 }
 
 KK_API int kk_rank1update(kk_basis b, int c0, int m, kk_basis by, int cy, const double* x, double alpha, double beta) {
-    CHECK_RANGE(b, c0, m); CHECK_COL(by, cy); CHECK_SAME(b, by);
+    CHECK_BLOCK(b, c0, m); CHECK_COL(by, cy); CHECK_SAME(b, by);   // any m: column-local, so wider ranges simply go panel by panel
     KK_CHECK(x || m == 0, KK_ERR_INVALID, "null x");
     KK_CHECK(!(by == b && cy >= c0 && cy < c0 + m), KK_ERR_INVALID, "kk_rank1update: y aliases a basis column");
     if (m == 0) return KK_OK;
     gram_touch(b, c0);
-    kk_coef ch;
-    memset(&ch, 0, sizeof(ch));
-    for (int j = 0; j < m; ++j) ch.v[j] = x[j];
-    return kk_launch_rank1(b->ctx, b->col(c0), b->ld, m, by->col(cy), &ch, alpha, beta);
+    for (int j0 = 0; j0 < m; j0 += KK_MAX_M) {
+        const int mm = std::min(KK_MAX_M, m - j0);
+        kk_coef ch;
+        memset(&ch, 0, sizeof(ch));
+        for (int j = 0; j < mm; ++j) ch.v[j] = x[j0 + j];
+        KK_TRY(kk_launch_rank1(b->ctx, b->col(c0 + j0), b->ld, mm, by->col(cy), &ch, alpha, beta));
+    }
+    return KK_OK;
+}
+
+// basistransform!(b, U) (orthonormal.jl:291-354).  One kernel panel (m <= KK_MAX_M) is transformed in place by the MFMA
+// kernel.  A wider basis -- krylovdim > 256 is legal in the reference and the thick restarts of eigsolve / svdsolve hand
+// over the WHOLE basis (eigsolve/lanczos.jl:109) -- takes the rarely used wide route: the product is accumulated panel by
+// panel of input columns into a temporary n-column slab (multi-column update kernel, 16 outputs per launch) and copied back.
+static int basistransform_wide(kk_basis b, int c0, int m, int n, const double* U, int ldu) {
+    kk_ctx c = b->ctx;
+    double* tmp = nullptr;
+    KK_HIP(hipSetDevice(c->device));
+    const size_t bytes = (size_t)n * b->ld * sizeof(double);
+    hipError_t e = hipMalloc(&tmp, bytes);
+    if (e != hipSuccess) {
+        kk_set_error("kk_basistransform: m = %d > %d needs a temporary of %zu bytes: %s", m, KK_MAX_M, bytes, hipGetErrorString(e));
+        return KK_ERR_NOMEM;
+    }
+    int st = KK_OK;
+    for (int k0 = 0; k0 < m && st == KK_OK; k0 += KK_MAX_M) {
+        const int mk = std::min(KK_MAX_M, m - k0);
+        st = block_update_run(c, b->col(c0 + k0), b->ld, mk, tmp, b->ld, n, U + k0, ldu, 1.0, k0 == 0 ? 0.0 : 1.0, nullptr);
+    }
+    if (st == KK_OK && hipMemcpyAsync(b->col(c0), tmp, bytes, hipMemcpyDeviceToDevice, c->stream) != hipSuccess) st = KK_ERR_HIP;
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(tmp);
+    return st;
 }
 
 KK_API int kk_basistransform(kk_basis b, int c0, int m, int n, const double* U, int ldu) {
-    CHECK_RANGE(b, c0, m);
+    CHECK_BLOCK(b, c0, m);
     KK_CHECK(U && n >= 0 && n <= m && ldu >= m, KK_ERR_DIM, "kk_basistransform: U must be m x n with n <= m, ldu >= m");
     if (n == 0 || m == 0) return KK_OK;
     kk_ctx c = b->ctx;
     gram_touch(b, c0);
+    if (m > KK_MAX_M) return basistransform_wide(b, c0, m, n, U, ldu);
     // pack U (m x n, leading dimension m) into the pinned staging area, then into device scratch
     KK_TRY(stream_sync(c));
     double* hp = c->h_U;  // pinned KK_MAX_M x KK_MAX_M staging
@@ -66,10 +96,17 @@ KK_API int kk_givens_rmul(kk_basis b, int i1, int i2, double cc, double s) {
 }
 
 KK_API int kk_householder_rmul(kk_basis b, int c0, int m, const double* v, double beta) {
-    CHECK_RANGE(b, c0, m);
+    CHECK_BLOCK(b, c0, m);
     KK_CHECK(v || m == 0, KK_ERR_INVALID, "null v");
     if (m == 0 || beta == 0.0) return KK_OK;  // iszero(beta) && return b  (reflector.jl:147)
     gram_touch(b, c0);
+    if (m > KK_MAX_M) {   // the reflector does not fit the kernarg block: read it from device memory (same row-local kernel)
+        kk_ctx c = b->ctx;
+        KK_CHECK((size_t)m <= (size_t)(2 * KK_MAX_M + 8) * KK_MAX_BLOCKS, KK_ERR_UNSUPPORTED, "kk_householder_rmul: m too large");
+        KK_TRY(stream_sync(c));   // the partial-sum scratch doubles as staging: nothing may still be reading it
+        KK_HIP(hipMemcpyAsync(c->partials, v, (size_t)m * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        return kk_launch_householder_dev(c, b->col(c0), b->ld, m, c->partials, beta);
+    }
     kk_coef ch;
     memset(&ch, 0, sizeof(ch));
     for (int j = 0; j < m; ++j) ch.v[j] = v[j];
