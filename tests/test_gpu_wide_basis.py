@@ -91,3 +91,56 @@ def test_arnoldi_and_gkl_beyond_the_panel_limit(kk, ko, ctx):
         assert np.max(np.abs(U.T @ U - np.eye(kq))) < 1e-11 and np.max(np.abs(Vv.T @ Vv - np.eye(kq))) < 1e-11, dev.name
         ekq = np.zeros(kq); ekq[-1] = 1
         assert np.max(np.abs(Ar @ Vv - U @ B - np.outer(gf.r.get(), ekq))) < 1e-10, dev.name
+
+
+def test_eigsolve_krylovdim_300_with_thick_restarts(kk, ko, ctx):
+    """the restarting drivers hand the WHOLE basis to basistransform! (eigsolve/lanczos.jl:109) -- with
+    krylovdim = 300 that is more than one kernel panel.  The run must restart at least once and agree with the oracle in
+    values AND in the restart / operation counts; kk_basistransform / kk_householder_rmul / kk_rank1update take m > 256."""
+    nx, ny = 64, 60
+    n = nx * ny
+    A = ko.laplacian_2d(nx, ny)                          # clustered low end: 300 steps do not converge 6 values to 1e-12
+    x0 = np.random.default_rng(2).random(n)
+    op = kk.SparseOperator(A, ctx, symmetric=True)
+    vals, vecs, info = kk.eigsolve(op, x0, 6, "SR", krylovdim=300, maxiter=6, tol=1e-12, orth=kk.ModifiedGramSchmidt2())
+    ovals, ovecs, oinfo = ko.eigsolve_lanczos(A, x0, 6, "SR", krylovdim=300, maxiter=6, tol=1e-12, orth=ko.MGS2)
+    assert info.numiter > 1, "the test is meant to restart"
+    assert (info.numiter, info.numops, info.converged) == (oinfo.numiter, oinfo.numops, oinfo.converged)
+    assert relerr(vals[:6], ovals[:6]) < 1e-9
+    expect = np.sort(ko.laplacian_2d_eigs(nx, ny))[:6]
+    for lam, v, nr in zip(vals[:6], vecs[:6], info.normres[:6]):
+        assert np.linalg.norm(A @ v - lam * v) <= max(10 * nr, 1e-9)
+    if info.converged >= 6:
+        assert relerr(vals[:6], expect) < 1e-9
+
+
+def test_wide_basis_restart_primitives(kk, ko, ctx):
+    """basistransform! (orthonormal.jl:291-354), rmul!(b, Householder) (dense/reflector.jl:143-154) and rank1update!
+    (orthonormal.jl:210-275) on 300 columns against NumPy"""
+    rng = np.random.default_rng(17)
+    n, m, keep = 3000, 300, 180
+    X = rng.standard_normal((n, m))
+    B = kk.DeviceBasis(n, m + 2, ctx)
+    for j in range(m):
+        B.upload(j, X[:, j])
+    B.length = m
+    U, _ = np.linalg.qr(rng.standard_normal((m, m)))
+    B.basistransform(U[:, :keep])
+    got = np.stack([B[j].get() for j in range(keep)], 1)
+    np.testing.assert_allclose(got, X @ U[:, :keep], rtol=0, atol=1e-11 * np.abs(X).max() * np.sqrt(m))
+    # Householder over all 300 columns
+    for j in range(m):
+        B.upload(j, X[:, j])
+    B.length = m
+    v = rng.standard_normal(m); v /= np.linalg.norm(v)
+    beta = 2.0
+    B.rmul_householder(beta, v, 0, m)
+    got = np.stack([B[j].get() for j in range(m)], 1)
+    np.testing.assert_allclose(got, X - beta * np.outer(X @ v, v), rtol=0, atol=1e-11 * np.abs(X).max() * np.sqrt(m))
+    # rank-1 update of 300 columns
+    y = rng.standard_normal(n)
+    xs = rng.standard_normal(m)
+    B[m].set(y)
+    B.rank1update(B[m], xs, 0, m, 0.7, 1.3)
+    got2 = np.stack([B[j].get() for j in range(m)], 1)
+    np.testing.assert_allclose(got2, 1.3 * got + 0.7 * np.outer(y, xs), rtol=0, atol=1e-11 * np.abs(got).max() * 10)

@@ -8,7 +8,6 @@ A  = ((A + A.T) * 0.5).tocsr()
 op = kk.SparseOperator(A, symmetric=True)
 x0 = np.random.default_rng(0).random(A.shape[0])
 vals, vecs, info = kk.eigsolve(op, x0, 4, "LM", kk.Lanczos(krylovdim=60, tol=1e-8, maxiter=30)); print(vals, info.converged)
-vals, vecs, info = kk.eigsolve(op, x0, 4, "LR", kk.Arnoldi(krylovdim=60, tol=1e-8, maxiter=30)); print(vals, info.converged)
 x, info = kk.linsolve(op, x0, None, kk.GMRES(krylovdim=40, tol=1e-8), 12.0, 1.0); print(info.converged, np.linalg.norm(12*x + A@x - x0))
 x, info = kk.linsolve(op, x0, None, kk.BiCGStab(tol=1e-8), 12.0, 1.0); print(info.converged, np.linalg.norm(12*x + A@x - x0))
 w, info = kk.exponentiate(op, -0.5, x0, kk.Lanczos(krylovdim=30, tol=1e-10)); print(info.converged, np.linalg.norm(w))
