@@ -163,6 +163,14 @@ KK_API int kk_ctx_set_option(kk_ctx c, const char* key, double value) {
     } else if (!strcmp(key, "mgs_persist")) {
         c->mgs_persist = value != 0;
         c->persist_skip = 0;
+    } else if (!strcmp(key, "mgs_panel")) {
+        c->mgs_panel = value != 0;
+    } else if (!strcmp(key, "panel_width")) {
+        KK_CHECK(value == 0 || value == 1 || value == 2 || value == 3, KK_ERR_INVALID, "panel_width must be 0 (by vector length), 1, 2 or 3");
+        c->panel_width = (int)value;
+    } else if (!strcmp(key, "panel_min_rows")) {
+        KK_CHECK(value >= 0, KK_ERR_INVALID, "panel_min_rows must be >= 0");
+        c->panel_min_rows = (int64_t)value;
     } else if (!strcmp(key, "persist_fault")) {
         c->persist_fault = (int)value;   // test hook: the next `value` persistent launches behave like a grid-barrier timeout
     } else if (!strcmp(key, "persist_threads")) {
@@ -248,6 +256,10 @@ KK_API int kk_ctx_get_option(kk_ctx c, const char* key, double* value) {
     else if (!strcmp(key, "persist_skip")) *value = c->persist_skip;
     else if (!strcmp(key, "persist_capacity_rows")) *value = (double)kk_mgs_persist_capacity(c);
     else if (!strcmp(key, "fold_scale")) *value = c->fold_scale;
+    else if (!strcmp(key, "mgs_panel")) *value = c->mgs_panel;
+    else if (!strcmp(key, "panel_width")) *value = c->panel_width;
+    else if (!strcmp(key, "panel_min_rows")) *value = (double)c->panel_min_rows;
+    else if (!strcmp(key, "panel_capacity_rows")) *value = (double)kk_mgs_panel_capacity(c);
     else if (!strcmp(key, "persist_nt")) *value = c->persist_nt;
     else if (!strcmp(key, "persist_lds")) *value = c->persist_lds;
     else if (!strcmp(key, "persist_min_rows")) *value = (double)c->persist_min_rows;

@@ -145,6 +145,9 @@ struct kk_ctx_s {
     int64_t persist_min_rows = 4000000;   // auto mode: below this the per-vector grid reduction (~3 us) outweighs the saved basis traffic
     int keep_mb = 160;           // MB of trailing basis columns a project pass leaves cache-allocated for the unproject
                                  // pass that follows (the Infinity Cache holds 256 MB); 0 = all loads non-temporal
+    int mgs_panel = 1;           // MGS sweeps of vectors of <= 16 grid-rows (4.19 M rows) through the persistent PANEL kernel (kk_kernels_panel.hip)
+    int panel_width = 0;         // basis vectors per grid reduction of that kernel: 0 = by vector length (3 / 2 / 1), else min(value, by length); mgs_mode 0 forces 1
+    int64_t panel_min_rows = 400000;   // auto mode: below this an expand! is launch-bound and the low-sync pair (3 small launches) beats one reduction per panel
     int mgs_persist = 1;         // strict MGS sweeps through the persistent register-resident kernel when the vector fits
     int persist_threads = 512;   // threads per block (= per CU) of that kernel: 1024 (<= 40 doubles of w per thread) or 512 (<= 80)
     int persist_nt = 1;          // second read of a basis vector (served by the Infinity Cache) with non-temporal loads
@@ -429,9 +432,18 @@ int kk_launch_lsmr_u(kk_ctx ctx, const double* av, double* ah, double* u, int64_
 int kk_launch_lsmr_hx(kk_ctx ctx, double* h, double* hbar, double* x, const double* v, int64_t ld, double c1, double c2,
                       double c3);
 bool kk_mgs_persist_eligible(kk_ctx ctx, int64_t ld, int m, int nsweeps);
-// does an MGS-family sweep over vectors of leading dimension ld run in the low-synchronisation form?  (option "mgs_mode")
+bool kk_mgs_panel_eligible(kk_ctx ctx, int64_t ld);
+int64_t kk_mgs_panel_capacity(kk_ctx ctx);
+int kk_mgs_panel_width(kk_ctx ctx, int64_t ld, bool strict);
+int kk_launch_mgs_panel(kk_ctx ctx, const double* V, int64_t ld, int m, int nsweeps, double* w, const double* carry_q,
+                        const double* carry_s, double* out_s, int out_stride, double* nrm_out3, bool normalize_w, bool strict);
+// does an MGS-family sweep over vectors of leading dimension ld run in the low-synchronisation (projection-based) form?
+// (option "mgs_mode").  auto: the persistent kernels wherever they are the faster route -- the panel kernel for vectors of
+// panel_min_rows .. 4.19 M rows, the register-resident strict kernel from persist_min_rows rows up to its capacity -- and the
+// projection pair otherwise (tiny vectors: launch-bound; vectors beyond the register file; row-sharded contexts).
 static inline bool kk_mgs_lowsync(kk_ctx ctx, int64_t ld, int m) {
     if (ctx->mgs_mode != 2) return ctx->mgs_mode == 1;
+    if (ld >= ctx->panel_min_rows && kk_mgs_panel_eligible(ctx, ld)) return false;
     return !(ld >= ctx->persist_min_rows && kk_mgs_persist_eligible(ctx, ld, m, 2));
 }
 int kk_launch_mgs_persist(kk_ctx ctx, const double* V, int64_t ld, int m, int nsweeps, double* w, const double* carry_q,

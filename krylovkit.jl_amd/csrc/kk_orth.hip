@@ -228,15 +228,20 @@ int pass_mgs_strict(kk_ctx c, const double* V, int64_t ld, int m, double* w, int
 int pass_mgs_strict_sweeps(kk_ctx c, const double* V, int64_t ld, int m, int nsweeps, double* w, const int64_t* ws_s,
                            bool want_norm, int slot, const double* carry_q, const double* carry_s) {
     c->persist_norm_done = false;
-    if (m > 0 && kk_mgs_persist_eligible(c, ld, m, nsweeps)) {
+    const bool panel = m > 0 && kk_mgs_panel_eligible(c, ld);   // short vectors: P basis vectors per grid reduction (P = 1 in strict mode)
+    if (panel || (m > 0 && kk_mgs_persist_eligible(c, ld, m, nsweeps))) {
         // both sweeps' coefficient areas must be addressable as out_s + sweep * stride
         const int stride = nsweeps > 1 ? (int)(ws_s[1] - ws_s[0]) : KK_MAX_M;
         if (c->persist_skip > 0) {
             --c->persist_skip;   // recovering from a grid-barrier timeout: this sweep takes the launch-per-vector route (same order)
         } else if (stride >= m) {
             const bool normalize = c->persist_norm_req && want_norm;
-            KK_TRY(kk_launch_mgs_persist(c, V, ld, m, nsweeps, w, carry_q, carry_s, WSP(c, ws_s[0]), stride,
-                                         want_norm ? SCP(c, SC_NRM2) : nullptr, normalize));
+            if (panel)
+                KK_TRY(kk_launch_mgs_panel(c, V, ld, m, nsweeps, w, carry_q, carry_s, WSP(c, ws_s[0]), stride,
+                                           want_norm ? SCP(c, SC_NRM2) : nullptr, normalize, c->mgs_mode == 0));
+            else
+                KK_TRY(kk_launch_mgs_persist(c, V, ld, m, nsweeps, w, carry_q, carry_s, WSP(c, ws_s[0]), stride,
+                                             want_norm ? SCP(c, SC_NRM2) : nullptr, normalize));
             c->persist_pending = true;
             c->persist_slot = slot;
             c->persist_norm_done = normalize;

@@ -20,6 +20,7 @@ def relerr(a, b):
 def sctx(kk):
     c = kk.Context(0)
     c.set_option("mgs_mode", 0)          # strict order: the persistent kernel runs at every size
+    c.set_option("mgs_panel", 0)         # these tests are about k_mgs_persist (the panel kernel has its own: tests/test_gpu_panel.py)
     if c.get_option("mgs_persist") == 0:
         pytest.skip("no cooperative launch on this device: the persistent route is off")
     yield c
