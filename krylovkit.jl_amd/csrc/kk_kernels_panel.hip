@@ -92,6 +92,9 @@ __device__ __forceinline__ bool panel_grid_sum(const double (&acc)[NVAL], double
     int good = 1;
     for (int b0 = 0; b0 < G; b0 += 32 * NW) {
         for (;;) {
+            // compiler barrier: the buffer-load builtin is a plain read to LLVM -- without it the granule loads are hoisted
+            // out of the spin loop as loop invariants and the wave polls registers (found the hard way: every launch timed out)
+            asm volatile("" ::: "memory");
             const int errv = __hip_atomic_load(err, RLX_AGENT);
             v4u t[4];
 #pragma unroll

@@ -70,6 +70,8 @@ __device__ __forceinline__ bool grid_sum(double acc, int step, unsigned ebase, c
         double total = 0;
         int good = 1;
         for (;;) {
+            asm volatile("" ::: "memory");   // compiler barrier: the granule loads below must be re-issued by every pass (the
+                                             // buffer-load builtin is a plain read to LLVM and may otherwise be hoisted out of the spin loop)
             bool ok = true;
             double x = 0;
             // (the error flag travels with the first batch instead of costing a failed pass a round trip of its own)
