@@ -253,13 +253,15 @@ __global__ __launch_bounds__(KK_PANEL_PT) void k_mgs_panel(const double* __restr
     // commit (see k_mgs_persist): every block writes its rows back or -- flag raised by a block that timed out -- none does
     if (__hip_atomic_load(err, RLX_AGENT)) return;
     if (blockIdx.x == 0 && threadIdx.x == 0) { ok_out[0] = token; ok_out[1] = scale ? 1.0 : inv; }   // SC_PERSIST_OK, SC_XS
+    // scale in place FIRST, store afterwards, nothing in between: a VALU write to the data registers of a 16-byte buffer store
+    // in the instruction after it can reach the store (hipcc inserts the wait state only for stores WITHOUT an SGPR offset;
+    // with one, gfx950 still picked up the NEXT row's product in lanes 12-15 of every row of 16 -- one launch in ~100)
     const double f = scale ? inv : 1.0;
 #pragma unroll
-    for (int j = 0; j < NV; ++j) {
-        d2 o = wr[j];
-        o.x *= f; o.y *= f;
-        pstore(rw, voff, (unsigned)j * sbytes, o);
-    }
+    for (int j = 0; j < NV; ++j) { wr[j].x *= f; wr[j].y *= f; }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) pstore(rw, voff, (unsigned)j * sbytes, wr[j]);
 }
 
 // ---- launcher ------------------------------------------------------------------------------

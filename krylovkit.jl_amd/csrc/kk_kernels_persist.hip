@@ -287,13 +287,16 @@ __global__ __launch_bounds__(PT) void k_mgs_persist(const double* __restrict__ V
     // `normalize`: scale!!(w, 1/|w|) of the NEXT expand! (factorizations/lanczos.jl:257, arnoldi.jl:209; orthonormalize!!
     // orthonormal.jl:522-527) folded into the write-back -- the same product w[i] * (1/|w|) k_scal forms, so the
     // stored vector has the bits of the separate pass, which is no longer needed (16 N bytes and one launch per expand!)
+    // Scale in place FIRST, store afterwards, nothing in between.  (A VALU write to the data registers of a 16-byte buffer
+    // store in the instruction right behind it can still reach the store: hipcc inserts the wait state only for stores
+    // without an SGPR offset; with one, gfx950 picked up the NEXT grid-row's product in lanes 12-15 of every row of 16,
+    // about one launch in a hundred -- found with the same commit in kk_kernels_panel.hip.)
     const double f = scale ? inv : 1.0;   // (x * 1.0 is x, bit for bit)
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        d2 o = wr[i];
-        o.x *= f; o.y *= f;
-        bstore(rw, voff, (unsigned)i * sbytes, o);
-    }
+    for (int i = 0; i < NV; ++i) { wr[i].x *= f; wr[i].y *= f; }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) bstore(rw, voff, (unsigned)i * sbytes, wr[i]);
 }
 
 // ---- launcher ------------------------------------------------------------------------------

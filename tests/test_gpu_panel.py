@@ -65,6 +65,7 @@ def test_non_orthonormal_basis_gets_the_exact_mgs_coefficients(kk, ko, pctx, wid
     X[:, 1] += 0.8 * X[:, 0]
     X[:, 2] += 0.5 * X[:, 1] - 0.3 * X[:, 0]
     X[:, 5] += 0.9 * X[:, 4]
+    X /= np.linalg.norm(X, axis=0)          # unit vectors, far from orthogonal
     w = rng.standard_normal(n) + X @ rng.standard_normal(m)
     B = kk.DeviceBasis(n, m + 2, pctx)
     for j in range(m):
