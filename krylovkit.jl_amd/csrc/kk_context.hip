@@ -178,6 +178,8 @@ KK_API int kk_ctx_set_option(kk_ctx c, const char* key, double value) {
         c->persist_threads = (int)value;
     } else if (!strcmp(key, "persist_nt")) {
         c->persist_nt = value != 0;
+    } else if (!strcmp(key, "persist_sync")) {
+        c->persist_sync = value != 0;
     } else if (!strcmp(key, "persist_min_rows")) {
         KK_CHECK(value >= 0, KK_ERR_INVALID, "persist_min_rows must be >= 0");
         c->persist_min_rows = (int64_t)value;
@@ -262,6 +264,7 @@ KK_API int kk_ctx_get_option(kk_ctx c, const char* key, double* value) {
     else if (!strcmp(key, "panel_capacity_rows")) *value = (double)kk_mgs_panel_capacity(c);
     else if (!strcmp(key, "persist_nt")) *value = c->persist_nt;
     else if (!strcmp(key, "persist_lds")) *value = c->persist_lds;
+    else if (!strcmp(key, "persist_sync")) *value = c->persist_sync;
     else if (!strcmp(key, "persist_min_rows")) *value = (double)c->persist_min_rows;
     else if (!strcmp(key, "speculate")) *value = c->speculate;
     else if (!strcmp(key, "spmv_dia")) *value = c->spmv_dia;

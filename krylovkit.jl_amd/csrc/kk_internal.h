@@ -151,6 +151,7 @@ struct kk_ctx_s {
     int mgs_persist = 1;         // strict MGS sweeps through the persistent register-resident kernel when the vector fits
     int persist_threads = 512;   // threads per block (= per CU) of that kernel: 1024 (<= 40 doubles of w per thread) or 512 (<= 80)
     int persist_nt = 1;          // second read of a basis vector (served by the Infinity Cache) with non-temporal loads
+    int persist_sync = 0;        // granule layout of that kernel's grid reduction: 0 = one 128-byte line per block (lowest latency on an idle chip), 1 = packed (16 bytes per block: 8 x less sweep traffic)
     int persist_lds = 2;         // park grid-rows of the current basis vector on chip between its two uses: 1 = as many as fit the LDS,
                                  // 2 = those plus KK_PERSIST_NR more in spare registers (512-thread blocks), 0 = none (second read from memory)
     void* d_sync = nullptr;      // device: hand-off granules + error flag of the in-kernel grid reduction (KK_SYNC_BYTES)

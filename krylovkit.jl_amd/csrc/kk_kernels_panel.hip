@@ -16,10 +16,9 @@
 //     k_lowsync_solve restricted to the panel, with Gram entries of the vectors as they ARE (no bookkeeping, no
 //     orthonormality assumption).  Between panels the order is strictly sequential.  P = 1 is the reference's strict order,
 //     bit for bit the operations of k_mgs_persist (option mgs_mode = 0 forces it);
-//   * the reduction itself: every block publishes its P (P + 1) / 2 partials as 16-byte tagged granules side by side on its
-//     own 128-byte line (one coalesced sc1 store), every WAVE of every block sweeps the lines of 32 blocks (eight granule
-//     slots of eight lines per load instruction) and the per-wave sums are combined through LDS in a fixed order -- all
-//     blocks obtain the same bits.  Workgroup barriers are raw s_barrier (+ lgkmcnt(0)): a __syncthreads() would make hipcc
+//   * the reduction itself: every block publishes its P (P + 1) / 2 partials as 16-byte tagged granules (write-through
+//     stores), wave v of every block sweeps the partials of value v (packed: 4 KB per value) and sums them in a fixed
+//     order -- all blocks obtain the same bits.  Workgroup barriers are raw s_barrier (+ lgkmcnt(0)): a __syncthreads() would make hipcc
 //     drain the panel loads in flight (vmcnt(0)) before every barrier, i.e. stop the stream for every reduction.
 //     The sweep loads queue behind the wave's own panel loads (returns are in order), which costs nothing: by the time a
 //     panel has landed every block has long published.
@@ -62,78 +61,79 @@ __device__ __forceinline__ void fnma2(d2& x, double s, const d2& q) {
 
 // Sum of NVAL per-thread values over all threads of all blocks; tot[v] holds the same bits in every thread of every block.
 // smA / smB: 64 doubles of LDS each.  Returns false on a timeout (flag raised).
+// Layout of a granule set: value-major and PACKED, granule (v, block) at ((v * G + block) * 16) bytes -- the G partials of one
+// value are 4 KB of contiguous memory.  Wave v (< NVAL) of every block sweeps value v: 4 sc1 loads per lane, the summation
+// order of k_mgs_persist (lane l: blocks l, l + 64, ..; then across the lanes).  Packed, not one line per block as in the
+// register-resident kernel: there the reduction is on the critical path and the own-line layout is the lower-LATENCY one
+// (tools/grid_reduce_variants.hip); here the latency hides behind the panel in flight and what counts is the fabric TRAFFIC
+// of the sweeps -- every block reads every partial, 256 x 256 requests per reduction, which with one line per block was a
+// quarter of the bytes of a 2M-row panel (measured: 8.0 us per vector at 4M rows against 4.8 of stream).
 template <int NVAL>
 __device__ __forceinline__ bool panel_grid_sum(const double (&acc)[NVAL], double (&tot)[NVAL], unsigned epoch, int set, char* __restrict__ sync,
                                                int* __restrict__ err, double* smA, double* smB) {
     const int G = gridDim.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int NW = KK_PANEL_PT / 64;
+    static_assert(NVAL <= NW, "one sweeping wave per value");
 #pragma unroll
     for (int v = 0; v < NVAL; ++v) {
         const double t = wave_sum(acc[v]);
         if (lane == 0) smA[wave * 8 + v] = t;
     }
     lds_barrier();
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(sync, 0, 2 * G * KK_SYNC_LINE, 0x00020000);
-    const unsigned set_off = (unsigned)set * (unsigned)G * KK_SYNC_LINE;
-    if (threadIdx.x < NVAL) {   // one granule per value, side by side on this block's line: one coalesced write-through store
+    const unsigned set_bytes = (unsigned)G * 16u * 8u;   // room for 8 values per set
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(sync, 0, 2 * (int)set_bytes, 0x00020000);
+    const unsigned set_off = (unsigned)set * set_bytes;
+    if (threadIdx.x < NVAL) {   // thread v publishes the block's partial of value v
         double b = 0;
 #pragma unroll
         for (int k = 0; k < NW; ++k) b += smA[k * 8 + threadIdx.x];   // fixed order
         const unsigned long long bits = (unsigned long long)__double_as_longlong(b);
         v4u t;
         t.x = epoch; t.y = (unsigned)(bits >> 32); t.z = (unsigned)bits; t.w = epoch;
-        __builtin_amdgcn_raw_buffer_store_b128(t, rs, set_off + blockIdx.x * KK_SYNC_LINE + threadIdx.x * 16u, 0, 16 /* sc1 */);
+        __builtin_amdgcn_raw_buffer_store_b128(t, rs, set_off + (threadIdx.x * (unsigned)G + blockIdx.x) * 16u, 0, 16 /* sc1 */);
     }
-    // every wave sweeps 32 blocks per round: lane = (block in group of 8) * 8 + granule slot
-    const int slot = lane & 7, bl = lane >> 3;
-    const long long t0 = wall_clock64();
-    double x = 0;
     int good = 1;
-    for (int b0 = 0; b0 < G; b0 += 32 * NW) {
+    if (wave < NVAL) {
+        const unsigned voff_v = set_off + (unsigned)wave * (unsigned)G * 16u;
+        const long long t0 = wall_clock64();
+        double total = 0;
         for (;;) {
             // compiler barrier: the buffer-load builtin is a plain read to LLVM -- without it the granule loads are hoisted
             // out of the spin loop as loop invariants and the wave polls registers (found the hard way: every launch timed out)
             asm volatile("" ::: "memory");
             const int errv = __hip_atomic_load(err, RLX_AGENT);
-            v4u t[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int b = b0 + wave * 32 + i * 8 + bl;
-                const int bb = b < G ? b : 0;
-                t[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, set_off + (unsigned)bb * KK_SYNC_LINE + (unsigned)slot * 16u, 0, 16 /* sc1 */);
-            }
             bool ok = true;
-            double y = 0;
+            double x = 0;
+            for (int b0 = 0; b0 < G; b0 += 256) {
+                v4u t[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int b = b0 + wave * 32 + i * 8 + bl;
-                if (b < G && slot < NVAL) {
-                    ok = ok && t[i].x == epoch && t[i].w == epoch;
-                    y += __longlong_as_double((long long)(((unsigned long long)t[i].y << 32) | t[i].z));
+                for (int i = 0; i < 4; ++i) {
+                    const int b = b0 + i * 64 + lane;
+                    const int bb = b < G ? b : 0;
+                    t[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff_v + (unsigned)bb * 16u, 0, 16 /* sc1 */);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (b0 + i * 64 + lane < G) {
+                        ok = ok && t[i].x == epoch && t[i].w == epoch;
+                        x += __longlong_as_double((long long)(((unsigned long long)t[i].y << 32) | t[i].z));
+                    }
                 }
             }
-            if (__all(ok)) { x += y; break; }
+            if (__all(ok)) { total = wave_sum(x); break; }
             __builtin_amdgcn_s_sleep(1);
             if (wall_clock64() - t0 > KK_PANEL_TIMEOUT_TICKS || errv) { good = 0; break; }
         }
-        if (!good) break;
+        if (lane == 0) {
+            smB[wave] = total;
+            if (!good) { __hip_atomic_store(err, 1, RLX_AGENT); smB[NW * 8] = 1.0; }
+        }
     }
-    // the 8 lanes that hold one slot: lanes slot, slot + 8, ... -> butterfly over bl (fixed order)
-    x += __shfl_xor(x, 8);
-    x += __shfl_xor(x, 16);
-    x += __shfl_xor(x, 32);
-    if (lane < 8) smB[wave * 8 + lane] = x;
-    if (lane == 0 && !good) { __hip_atomic_store(err, 1, RLX_AGENT); smB[NW * 8] = 1.0; }
     lds_barrier();
     const bool bad = smB[NW * 8] != 0.0;
 #pragma unroll
-    for (int v = 0; v < NVAL; ++v) {
-        double s = 0;
-#pragma unroll
-        for (int k = 0; k < NW; ++k) s += smB[k * 8 + v];
-        tot[v] = s;
-    }
+    for (int v = 0; v < NVAL; ++v) tot[v] = smB[v];
     return !bad;
 }
 

@@ -52,17 +52,17 @@ __device__ __forceinline__ double block_sum_w(double v, double* sm /* >= NW doub
 // launches.  Returns false on a timeout.
 template <int PT>
 __device__ __forceinline__ bool grid_sum(double acc, int step, unsigned ebase, char* __restrict__ sync, int* __restrict__ err,
-                                         double* sm, double* out) {
+                                         double* sm, double* out, unsigned gstride /* bytes between the granules of two blocks: 128 = own line, 16 = packed */) {
     const int G = gridDim.x;
     const double v = block_sum_w<PT / 64>(acc, sm);
     const unsigned epoch = ebase + (unsigned)step + 1u;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(sync, 0, 2 * G * KK_SYNC_LINE, 0x00020000);
-    const unsigned set_off = (unsigned)(step & 1) * (unsigned)G * KK_SYNC_LINE;   // one 128-byte line per block and set
+    const unsigned set_off = (unsigned)(step & 1) * (unsigned)G * KK_SYNC_LINE;   // (a set always spans G lines, whatever the stride)
     if (threadIdx.x == 0) {
         const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
         v4u t;
         t.x = epoch; t.y = (unsigned)(bits >> 32); t.z = (unsigned)bits; t.w = epoch;
-        __builtin_amdgcn_raw_buffer_store_b128(t, rs, set_off + blockIdx.x * KK_SYNC_LINE, 0, 16 /* sc1 */);
+        __builtin_amdgcn_raw_buffer_store_b128(t, rs, set_off + blockIdx.x * gstride, 0, 16 /* sc1 */);
     }
     if (threadIdx.x < 64) {   // wave 0 sweeps
         const int lane = threadIdx.x;
@@ -85,7 +85,7 @@ __device__ __forceinline__ bool grid_sum(double acc, int step, unsigned ebase, c
                 for (int i = 0; i < 4; ++i) {
                     const int b = b0 + i * 64 + lane;
                     const int bb = b < G ? b : 0;
-                    t[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, set_off + (unsigned)bb * KK_SYNC_LINE, 0, 16 /* sc1 */);
+                    t[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, set_off + (unsigned)bb * gstride, 0, 16 /* sc1 */);
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {   // summation order: b ascending per lane, then across the lanes (wave_sum)
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(PT) void k_mgs_persist(const double* __restrict__ V
                                                     double* __restrict__ w, const double* __restrict__ carry_q,
                                                     const double* __restrict__ carry_s, double* __restrict__ out_s,
                                                     int out_stride, double* __restrict__ nrm_out3,
-                                                    char* __restrict__ sync, int* __restrict__ err, int fault,
+                                                    char* __restrict__ sync, int* __restrict__ err, int fault, unsigned gstride,
                                                     unsigned ebase, int normalize, double* __restrict__ ok_out, double token) {
     __shared__ double sm[PT / 64];
     extern __shared__ d2 park[];   // NL * PT double2 (dynamic): the parked grid-rows of the current basis vector
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(PT) void k_mgs_persist(const double* __restrict__ V
             for (int u = 0; u < B; ++u) qpre[u] = bload(r2, voff, (unsigned)(u < NV ? u : 0) * sbytes, false);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (!grid_sum<PT>(a0 + a1, s, ebase, sync, err, sm, &total)) return;   // timeout: w in HBM is untouched
+        if (!grid_sum<PT>(a0 + a1, s, ebase, sync, err, sm, &total, gstride)) return;   // timeout: w in HBM is untouched
         if (blockIdx.x == 0 && threadIdx.x == 0) out_s[(s / m) * out_stride + (s % m)] = total;
         sp = total;
         qp = qn;
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(PT) void k_mgs_persist(const double* __restrict__ V
         double a0 = 0, a1 = 0, total;
         persist_step<NV, NL, NR, PT, B, NTPREV, true, true>(wr, qk, qpre, col_rsrc(qp, ld), col_rsrc(qp, ld), sp, sbytes, voff, lq, a0, a1);
         if (nrm_out3) {
-            if (!grid_sum<PT>(a0 + a1, nsteps, ebase, sync, err, sm, &total)) return;
+            if (!grid_sum<PT>(a0 + a1, nsteps, ebase, sync, err, sm, &total, gstride)) return;
             // every block holds the same bits of |w|^2: the normalised commit below needs no second exchange
             const double rt = sqrt(total);
             inv = 1.0 / rt;
@@ -374,11 +374,12 @@ int kk_launch_mgs_persist(kk_ctx ctx, const double* V, int64_t ld, int m, int ns
     int fault = 0;
     if (ctx->persist_fault > 0) { --ctx->persist_fault; fault = 1; }
     int normalize = (normalize_w && nrm_out3) ? 1 : 0;
+    unsigned gstride = ctx->persist_sync ? 16u : (unsigned)KK_SYNC_LINE;
     ctx->persist_token += 1.0;
     double token = ctx->persist_token;
     double* ok_out = ctx->ws + WS_SCAL + SC_PERSIST_OK;
     void* args[] = {(void*)&V, (void*)&ld, (void*)&m, (void*)&nsweeps, (void*)&w, (void*)&carry_q, (void*)&carry_s,
-                    (void*)&out_s, (void*)&out_stride, (void*)&nrm_out3, (void*)&sync, (void*)&err, (void*)&fault,
+                    (void*)&out_s, (void*)&out_stride, (void*)&nrm_out3, (void*)&sync, (void*)&err, (void*)&fault, (void*)&gstride,
                     (void*)&ebase, (void*)&normalize, (void*)&ok_out, (void*)&token};
     const bool nt = ctx->persist_nt != 0;
     kk_prof_scope ps(ctx, "k_mgs_persist");
