@@ -3,8 +3,9 @@
 // BASELINE.json: 2M rows; strong-scaling shards).  SURVEY.md 8(a) rows a6 / a8; reference order being restated:
 // src/orthonormal.jl:414-452 (MGS, MGS2), src/factorizations/arnoldi.jl:239-245, lanczos.jl:325-338.
 //
-//   * one block of 512 threads per CU (cooperative launch), the block's rows of the work vector w in registers for the
-//     whole launch (NV double2 per thread), exactly as in k_mgs_persist;
+//   * one block of 512 threads per CU (cooperative launch): seven DATA waves hold the block's rows of the work vector w in
+//     registers for the whole launch (NV double2 per thread, as in k_mgs_persist), wave 0 is the block's REDUCTION wave and
+//     owns no rows (see the last item);
 //   * the basis is taken P vectors at a time.  A panel is loaded ONCE into registers (P * NV double2 per thread) and serves
 //     both its inner products and its update; while it is being used the NEXT panel is already on its way into a second
 //     register set (ordinary buffer loads, consumed one loop iteration later), so the basis stream never stops for the
@@ -16,12 +17,16 @@
 //     k_lowsync_solve restricted to the panel, with Gram entries of the vectors as they ARE (no bookkeeping, no
 //     orthonormality assumption).  Between panels the order is strictly sequential.  P = 1 is the reference's strict order,
 //     bit for bit the operations of k_mgs_persist (option mgs_mode = 0 forces it);
-//   * the reduction itself: every block publishes its P (P + 1) / 2 partials as 16-byte tagged granules (write-through
-//     stores), wave v of every block sweeps the partials of value v (packed: 4 KB per value) and sums them in a fixed
-//     order -- all blocks obtain the same bits.  Workgroup barriers are raw s_barrier (+ lgkmcnt(0)): a __syncthreads() would make hipcc
-//     drain the panel loads in flight (vmcnt(0)) before every barrier, i.e. stop the stream for every reduction.
-//     The sweep loads queue behind the wave's own panel loads (returns are in order), which costs nothing: by the time a
-//     panel has landed every block has long published.
+//   * the reduction itself: the block's P (P + 1) / 2 partials are published as 16-byte tagged granules (write-through
+//     stores; value-major and packed, 4 KB per value) and swept with sc1 loads, summed in a fixed order -- all blocks obtain
+//     the same bits.  Publishing and sweeping is the job of WAVE 0 alone, which issues no panel loads: memory returns are in
+//     order per wave, so a sweep issued by a wave with a panel in flight completes only after that panel has landed, the
+//     update that frees the register set for the panel after next waits for it, and every panel is then requested into an
+//     EMPTY memory pipe -- latency + stream per panel instead of the stream alone (the first version of this kernel, all
+//     eight waves loading and sweeping: 7.5 us per vector at 4M rows against 4.8 of stream).  With the sweep in a wave of
+//     its own the data waves get the totals ~2.5 us after they published and have the next panel requested while the current
+//     one is still arriving.  Workgroup barriers are raw s_barrier (+ lgkmcnt(0)): a __syncthreads() would make hipcc drain
+//     the panel loads in flight (vmcnt(0)) before every barrier.
 #include "kk_internal.h"
 #include "kk_device.h"
 
@@ -59,44 +64,50 @@ __device__ __forceinline__ void fnma2(d2& x, double s, const d2& q) {
     asm("v_fma_f64 %0, -%1, %2, %0" : "+v"(x.y) : "v"(s), "v"(q.y));
 }
 
-// Sum of NVAL per-thread values over all threads of all blocks; tot[v] holds the same bits in every thread of every block.
-// smA / smB: 64 doubles of LDS each.  Returns false on a timeout (flag raised).
-// Layout of a granule set: value-major and PACKED, granule (v, block) at ((v * G + block) * 16) bytes -- the G partials of one
-// value are 4 KB of contiguous memory.  Wave v (< NVAL) of every block sweeps value v: 4 sc1 loads per lane, the summation
-// order of k_mgs_persist (lane l: blocks l, l + 64, ..; then across the lanes).  Packed, not one line per block as in the
-// register-resident kernel: there the reduction is on the critical path and the own-line layout is the lower-LATENCY one
-// (tools/grid_reduce_variants.hip); here the latency hides behind the panel in flight and what counts is the fabric TRAFFIC
-// of the sweeps -- every block reads every partial, 256 x 256 requests per reduction, which with one line per block was a
-// quarter of the bytes of a 2M-row panel (measured: 8.0 us per vector at 4M rows against 4.8 of stream).
+// ---- the block's two roles meet at two workgroup barriers per reduction: (1) partials of the data waves are in smA,
+// (2) totals (and the timeout flag) of the reduction wave are in smB.
+#define KK_PANEL_DW 7                       // data waves per block (waves 1..7); wave 0 reduces
+#define KK_PANEL_DT (KK_PANEL_DW * 64)      // data threads per block
+
+// data waves: hand the NVAL per-thread partials to the reduction wave, come back with the totals (same bits in every thread
+// of every block).  Returns false after a timeout anywhere on the chip.
 template <int NVAL>
-__device__ __forceinline__ bool panel_grid_sum(const double (&acc)[NVAL], double (&tot)[NVAL], unsigned epoch, int set, char* __restrict__ sync,
-                                               int* __restrict__ err, double* smA, double* smB) {
-    const int G = gridDim.x;
+__device__ __forceinline__ bool panel_reduce_data(const double (&acc)[NVAL], double (&tot)[NVAL], double* smA, const double* smB) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    constexpr int NW = KK_PANEL_PT / 64;
-    static_assert(NVAL <= NW, "one sweeping wave per value");
 #pragma unroll
     for (int v = 0; v < NVAL; ++v) {
         const double t = wave_sum(acc[v]);
         if (lane == 0) smA[wave * 8 + v] = t;
     }
-    lds_barrier();
+    lds_barrier();   // (1)
+    lds_barrier();   // (2)
+#pragma unroll
+    for (int v = 0; v < NVAL; ++v) tot[v] = smB[v];
+    return smB[8] == 0.0;
+}
+
+// reduction wave: one grid reduction of nval values.  Granule (v, block) of a set sits at ((v * G + block) * 16) bytes.
+__device__ __forceinline__ bool panel_reduce_sync(int nval, unsigned epoch, int set, char* __restrict__ sync, int* __restrict__ err, const double* smA,
+                                                  double* smB) {
+    const int G = gridDim.x;
+    const int lane = threadIdx.x;
+    lds_barrier();   // (1)
     const unsigned set_bytes = (unsigned)G * 16u * 8u;   // room for 8 values per set
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(sync, 0, 2 * (int)set_bytes, 0x00020000);
     const unsigned set_off = (unsigned)set * set_bytes;
-    if (threadIdx.x < NVAL) {   // thread v publishes the block's partial of value v
+    if (lane < nval) {   // lane v publishes the block's partial of value v
         double b = 0;
 #pragma unroll
-        for (int k = 0; k < NW; ++k) b += smA[k * 8 + threadIdx.x];   // fixed order
+        for (int k = 1; k <= KK_PANEL_DW; ++k) b += smA[k * 8 + lane];   // fixed order
         const unsigned long long bits = (unsigned long long)__double_as_longlong(b);
         v4u t;
         t.x = epoch; t.y = (unsigned)(bits >> 32); t.z = (unsigned)bits; t.w = epoch;
-        __builtin_amdgcn_raw_buffer_store_b128(t, rs, set_off + (threadIdx.x * (unsigned)G + blockIdx.x) * 16u, 0, 16 /* sc1 */);
+        __builtin_amdgcn_raw_buffer_store_b128(t, rs, set_off + ((unsigned)lane * (unsigned)G + blockIdx.x) * 16u, 0, 16 /* sc1 */);
     }
+    const long long t0 = wall_clock64();
     int good = 1;
-    if (wave < NVAL) {
-        const unsigned voff_v = set_off + (unsigned)wave * (unsigned)G * 16u;
-        const long long t0 = wall_clock64();
+    for (int v = 0; v < nval && good; ++v) {   // value after value: by the time value 0 is complete the others usually are too
+        const unsigned voff_v = set_off + (unsigned)v * (unsigned)G * 16u;
         double total = 0;
         for (;;) {
             // compiler barrier: the buffer-load builtin is a plain read to LLVM -- without it the granule loads are hoisted
@@ -114,7 +125,7 @@ __device__ __forceinline__ bool panel_grid_sum(const double (&acc)[NVAL], double
                     t[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff_v + (unsigned)bb * 16u, 0, 16 /* sc1 */);
                 }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < 4; ++i) {   // summation order: b ascending per lane, then across the lanes (wave_sum)
                     if (b0 + i * 64 + lane < G) {
                         ok = ok && t[i].x == epoch && t[i].w == epoch;
                         x += __longlong_as_double((long long)(((unsigned long long)t[i].y << 32) | t[i].z));
@@ -125,16 +136,11 @@ __device__ __forceinline__ bool panel_grid_sum(const double (&acc)[NVAL], double
             __builtin_amdgcn_s_sleep(1);
             if (wall_clock64() - t0 > KK_PANEL_TIMEOUT_TICKS || errv) { good = 0; break; }
         }
-        if (lane == 0) {
-            smB[wave] = total;
-            if (!good) { __hip_atomic_store(err, 1, RLX_AGENT); smB[NW * 8] = 1.0; }
-        }
+        if (lane == 0) smB[v] = total;
     }
-    lds_barrier();
-    const bool bad = smB[NW * 8] != 0.0;
-#pragma unroll
-    for (int v = 0; v < NVAL; ++v) tot[v] = smB[v];
-    return !bad;
+    if (lane == 0 && !good) { __hip_atomic_store(err, 1, RLX_AGENT); smB[8] = 1.0; }
+    lds_barrier();   // (2)
+    return good != 0;
 }
 
 // panel p = vectors (sweep-major sequence) s0 .. s0 + P - 1 of the nsteps = m * nsweeps vectors of the launch
@@ -152,8 +158,8 @@ __device__ __forceinline__ void panel_issue(d2 (&q)[P][NV], const double* __rest
 }
 
 template <int NV, int P>
-__device__ __forceinline__ bool panel_step(d2 (&wr)[NV], d2 (&cur)[P][NV], int s0, int nsteps, int m, int pidx, unsigned ebase, char* sync, int* err,
-                                           double* smA, double* smB, double* __restrict__ out_s, int out_stride) {
+__device__ __forceinline__ bool panel_step(d2 (&wr)[NV], d2 (&cur)[P][NV], int s0, int nsteps, int m, double* smA, const double* smB,
+                                           double* __restrict__ out_s, int out_stride) {
     constexpr int NVAL = P * (P + 1) / 2;
     double acc[NVAL], tot[NVAL];
 #pragma unroll
@@ -172,7 +178,7 @@ __device__ __forceinline__ bool panel_step(d2 (&wr)[NV], d2 (&cur)[P][NV], int s
             }
         }
     }
-    if (!panel_grid_sum<NVAL>(acc, tot, ebase + (unsigned)pidx + 1u, pidx & 1, sync, err, smA, smB)) return false;
+    if (!panel_reduce_data<NVAL>(acc, tot, smA, smB)) return false;
     // (I + L) s = d, L = strictly lower in-panel Gram block: exact forward substitution, the same bits in every thread
     double s[P];
 #pragma unroll
@@ -187,7 +193,7 @@ __device__ __forceinline__ bool panel_step(d2 (&wr)[NV], d2 (&cur)[P][NV], int s
 #pragma unroll
         for (int j = 0; j < NV; ++j) fnma2(wr[j], s[i], cur[i][j]);
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (blockIdx.x == 0 && threadIdx.x == 64) {
 #pragma unroll
         for (int i = 0; i < P; ++i) {
             const int sv = s0 + i;
@@ -206,16 +212,27 @@ __global__ __launch_bounds__(KK_PANEL_PT) void k_mgs_panel(const double* __restr
                                                            char* __restrict__ sync, int* __restrict__ err, int fault, unsigned ebase, int normalize,
                                                            double* __restrict__ ok_out, double token) {
     __shared__ double smA[64];
-    __shared__ double smB[72];
+    __shared__ double smB[16];
     if (fault && blockIdx.x == 0) {   // test hook (option "persist_fault"): block 0 behaves like a block whose spin ran out
         if (threadIdx.x == 0) __hip_atomic_store(err, 1, RLX_AGENT);
         return;
     }
-    if (threadIdx.x == 0) smB[(KK_PANEL_PT / 64) * 8] = 0.0;
-    const unsigned sbytes = gridDim.x * KK_PANEL_PT * 16u;                  // one grid-row in bytes
-    const unsigned voff = (blockIdx.x * KK_PANEL_PT + threadIdx.x) * 16u;   // this lane's byte offset inside a grid-row
     const int nsteps = m * nsweeps;
     const int npanels = (nsteps + P - 1) / P;
+    constexpr int NVAL = P * (P + 1) / 2;
+    if (threadIdx.x < 64) {
+        // ---------------- the reduction wave: no rows, no panel loads -- nothing queues in front of its sweeps
+        if (threadIdx.x == 0) smB[8] = 0.0;
+        lds_barrier();   // (0)
+        for (int p = 0; p < npanels; ++p)
+            if (!panel_reduce_sync(NVAL, ebase + (unsigned)p + 1u, p & 1, sync, err, smA, smB)) return;
+        if (nrm_out3) panel_reduce_sync(1, ebase + (unsigned)npanels + 1u, npanels & 1, sync, err, smA, smB);
+        return;
+    }
+    // ---------------- the data waves
+    const unsigned dt = threadIdx.x - 64;
+    const unsigned sbytes = gridDim.x * KK_PANEL_DT * 16u;               // one grid-row in bytes
+    const unsigned voff = (blockIdx.x * KK_PANEL_DT + dt) * 16u;         // this lane's byte offset inside a grid-row
     const __amdgpu_buffer_rsrc_t rw = pcol_rsrc(w, (int)(ld * 8));
     d2 wr[NV];
     d2 qa[P][NV], qb[P][NV];
@@ -230,13 +247,13 @@ __global__ __launch_bounds__(KK_PANEL_PT) void k_mgs_panel(const double* __restr
 #pragma unroll
         for (int j = 0; j < NV; ++j) fnma2(wr[j], cs, qb[0][j]);
     }
-    lds_barrier();   // (the timeout flag slot is initialised)
+    lds_barrier();   // (0) (the timeout flag slot is initialised)
     for (int p = 0; p < npanels; p += 2) {
         panel_issue<NV, P>(qb, V, ld, m, (p + 1) * P, nsteps, voff, sbytes);   // next panel in flight across this panel's reduction
-        if (!panel_step<NV, P>(wr, qa, p * P, nsteps, m, p, ebase, sync, err, smA, smB, out_s, out_stride)) return;   // timeout: w in HBM is untouched
+        if (!panel_step<NV, P>(wr, qa, p * P, nsteps, m, smA, smB, out_s, out_stride)) return;   // timeout: w in HBM is untouched
         if (p + 1 >= npanels) break;
         panel_issue<NV, P>(qa, V, ld, m, (p + 2) * P, nsteps, voff, sbytes);
-        if (!panel_step<NV, P>(wr, qb, (p + 1) * P, nsteps, m, p + 1, ebase, sync, err, smA, smB, out_s, out_stride)) return;
+        if (!panel_step<NV, P>(wr, qb, (p + 1) * P, nsteps, m, smA, smB, out_s, out_stride)) return;
     }
     double inv = 1.0;
     bool scale = false;
@@ -244,15 +261,15 @@ __global__ __launch_bounds__(KK_PANEL_PT) void k_mgs_panel(const double* __restr
         double acc[1] = {0.0}, tot[1];
 #pragma unroll
         for (int j = 0; j < NV; ++j) { acc[0] = fma(wr[j].x, wr[j].x, acc[0]); acc[0] = fma(wr[j].y, wr[j].y, acc[0]); }
-        if (!panel_grid_sum<1>(acc, tot, ebase + (unsigned)npanels + 1u, npanels & 1, sync, err, smA, smB)) return;
+        if (!panel_reduce_data<1>(acc, tot, smA, smB)) return;
         const double rt = sqrt(tot[0]);
         inv = 1.0 / rt;
         scale = normalize && rt > 0.0 && inv <= 1.79769313486231570815e308;
-        if (blockIdx.x == 0 && threadIdx.x == 0) { nrm_out3[0] = tot[0]; nrm_out3[1] = rt; nrm_out3[2] = inv; }
+        if (blockIdx.x == 0 && threadIdx.x == 64) { nrm_out3[0] = tot[0]; nrm_out3[1] = rt; nrm_out3[2] = inv; }
     }
     // commit (see k_mgs_persist): every block writes its rows back or -- flag raised by a block that timed out -- none does
     if (__hip_atomic_load(err, RLX_AGENT)) return;
-    if (blockIdx.x == 0 && threadIdx.x == 0) { ok_out[0] = token; ok_out[1] = scale ? 1.0 : inv; }   // SC_PERSIST_OK, SC_XS
+    if (blockIdx.x == 0 && threadIdx.x == 64) { ok_out[0] = token; ok_out[1] = scale ? 1.0 : inv; }   // SC_PERSIST_OK, SC_XS
     // scale in place FIRST, store afterwards, nothing in between: a VALU write to the data registers of a 16-byte buffer store
     // in the instruction after it can reach the store (hipcc inserts the wait state only for stores WITHOUT an SGPR offset;
     // with one, gfx950 still picked up the NEXT row's product in lanes 12-15 of every row of 16 -- one launch in ~100)
@@ -265,8 +282,8 @@ __global__ __launch_bounds__(KK_PANEL_PT) void k_mgs_panel(const double* __restr
 }
 
 // ---- launcher ------------------------------------------------------------------------------
-// vectors of at most 16 grid-rows (4.19 M rows on 256 CUs): w plus two panels fit the 256 registers of a 512-thread block
-int64_t kk_mgs_panel_capacity(kk_ctx ctx) { return (int64_t)ctx->num_cus * KK_PANEL_PT * 2 * 16; }
+// vectors of at most 16 grid-rows (3.67 M rows on 256 CUs): w plus two panels fit the 256 registers of a 512-thread block
+int64_t kk_mgs_panel_capacity(kk_ctx ctx) { return (int64_t)ctx->num_cus * KK_PANEL_DT * 2 * 16; }
 bool kk_mgs_panel_eligible(kk_ctx ctx, int64_t ld) {
     if (!ctx->mgs_panel || !ctx->mgs_persist || kk_sharded(ctx) || !ctx->d_sync) return false;
     if (ctx->num_cus > KK_SYNC_MAX_BLOCKS || ld * 8 >= ((int64_t)1 << 31)) return false;
@@ -283,14 +300,14 @@ static int launch_panel_inst(kk_ctx ctx, void** args) {
 // panel width by vector length: what two register-resident panels + w leave room for (4 NV (1 + 2 P) <= ~200 registers)
 int kk_mgs_panel_width(kk_ctx ctx, int64_t ld, bool strict) {
     if (strict) return 1;
-    const int nv = (int)((ld + (int64_t)ctx->num_cus * KK_PANEL_PT * 2 - 1) / ((int64_t)ctx->num_cus * KK_PANEL_PT * 2));
-    const int by_size = nv <= 4 ? 3 : (nv <= 8 ? 2 : 1);
+    const int nv = (int)((ld + (int64_t)ctx->num_cus * KK_PANEL_DT * 2 - 1) / ((int64_t)ctx->num_cus * KK_PANEL_DT * 2));
+    const int by_size = nv <= 4 ? 3 : (nv <= 9 ? 2 : 1);
     return ctx->panel_width > 0 ? std::min(ctx->panel_width, by_size) : by_size;
 }
 
 int kk_launch_mgs_panel(kk_ctx ctx, const double* V, int64_t ld, int m, int nsweeps, double* w, const double* carry_q,
                         const double* carry_s, double* out_s, int out_stride, double* nrm_out3, bool normalize_w, bool strict) {
-    const int nv = (int)((ld + (int64_t)ctx->num_cus * KK_PANEL_PT * 2 - 1) / ((int64_t)ctx->num_cus * KK_PANEL_PT * 2));
+    const int nv = (int)((ld + (int64_t)ctx->num_cus * KK_PANEL_DT * 2 - 1) / ((int64_t)ctx->num_cus * KK_PANEL_DT * 2));
     const int P = kk_mgs_panel_width(ctx, ld, strict);
     KK_HIP(hipSetDevice(ctx->device));
     char* sync = (char*)ctx->d_sync;
@@ -313,8 +330,7 @@ int kk_launch_mgs_panel(kk_ctx ctx, const double* V, int64_t ld, int m, int nswe
                     (void*)&ebase, (void*)&normalize, (void*)&ok_out, (void*)&token};
     kk_prof_scope ps(ctx, "k_mgs_panel");
     if (nv <= 4) return P >= 3 ? launch_panel_inst<4, 3>(ctx, args) : (P == 2 ? launch_panel_inst<4, 2>(ctx, args) : launch_panel_inst<4, 1>(ctx, args));
-    if (nv <= 8) return P >= 2 ? launch_panel_inst<8, 2>(ctx, args) : launch_panel_inst<8, 1>(ctx, args);
-    if (nv <= 12) return launch_panel_inst<12, 1>(ctx, args);
+    if (nv <= 9) return P >= 2 ? launch_panel_inst<9, 2>(ctx, args) : launch_panel_inst<9, 1>(ctx, args);
     if (nv <= 16) return launch_panel_inst<16, 1>(ctx, args);
     kk_set_error("kk_launch_mgs_panel: vector of %lld rows does not fit two register-resident panels", (long long)ld);
     return KK_ERR_UNSUPPORTED;

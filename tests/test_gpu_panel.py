@@ -27,8 +27,8 @@ def algs(kk, ko):
     return [(kk.ModifiedGramSchmidt(), ko.MGS), (kk.ModifiedGramSchmidt2(), ko.MGS2), (kk.ModifiedGramSchmidtIR(0.99), ko.MGSIR(0.99))]
 
 
-# vector lengths chosen to hit every instantiation on 256 CUs (grid-row = 262144 rows): NV = 4 / 8 / 12 / 16
-@pytest.mark.parametrize("n,m", [(777, 5), (300000, 7), (1200000, 5), (2500000, 4), (3900000, 3)])
+# vector lengths chosen to hit every instantiation on 256 CUs (grid-row = 229376 rows): NV = 4 / 9 / 16
+@pytest.mark.parametrize("n,m", [(777, 5), (900000, 7), (1200000, 5), (2500000, 4), (3600000, 3)])
 @pytest.mark.parametrize("mode,width", [(0, 0), (2, 0), (2, 3)])
 def test_orthogonalize_through_the_panel_kernel(kk, ko, pctx, n, m, mode, width):
     pctx.set_option("mgs_mode", mode)

@@ -11,7 +11,7 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT / "krylovkit.jl_amd"))
 import krylovkit_hip as kk  # noqa: E402
 
-rows = [int(a) for a in sys.argv[1:]] or [500_000, 1_000_000, 2_000_000, 4_000_000]
+rows = [int(a) for a in sys.argv[1:]] or [500_000, 1_000_000, 2_000_000, 3_600_000]
 ctx = kk.Context(0)
 for n in rows:
     for m in (16, 48):
