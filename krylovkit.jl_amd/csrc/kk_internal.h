@@ -142,12 +142,12 @@ struct kk_ctx_s {
     int blocks_per_cu = 4;       // 4 resident 256-thread blocks per CU (measured best on the 10M-row sweep)
     int mgs_mode = 2;            // MGS family: 0 strict (reference order), 1 low-synchronisation, 2 auto = strict through the persistent
                                  // kernel where that is the faster one (eligible and >= persist_min_rows rows), low-sync otherwise
-    int64_t persist_min_rows = 3600000;   // auto mode: below this the per-vector grid reduction outweighs the saved basis traffic (and the panel kernel, which holds up to 3.67 M rows, is the faster persistent route)
+    int64_t persist_min_rows = 3600000;   // auto mode: below this the per-vector grid reduction outweighs the saved basis traffic (and the panel kernel, which holds up to 4.19 M rows, is the faster persistent route)
     int keep_mb = 160;           // MB of trailing basis columns a project pass leaves cache-allocated for the unproject
                                  // pass that follows (the Infinity Cache holds 256 MB); 0 = all loads non-temporal
-    int mgs_panel = 1;           // MGS sweeps of vectors of <= 16 grid-rows (3.67 M rows) through the persistent PANEL kernel (kk_kernels_panel.hip)
+    int mgs_panel = 1;           // MGS sweeps of vectors of <= 16 grid-rows (4.19 M rows) through the persistent PANEL kernel (kk_kernels_panel.hip)
     int panel_width = 0;         // basis vectors per grid reduction of that kernel: 0 = by vector length (3 / 2 / 1), else min(value, by length); mgs_mode 0 forces 1
-    int64_t panel_min_rows = 400000;   // auto mode: below this an expand! is launch-bound and the low-sync pair (3 small launches) beats one reduction per panel
+    int64_t panel_min_rows = 1400000;  // auto mode: below this one grid reduction per panel (a fixed ~6 us) costs more than the second read of the basis by the projection pair (tools/panel_sweep_cost.py: 1 M rows 3.1 vs 2.6 us per vector, 2 M rows 3.6 vs 5.1)
     int mgs_persist = 1;         // strict MGS sweeps through the persistent register-resident kernel when the vector fits
     int persist_threads = 512;   // threads per block (= per CU) of that kernel: 1024 (<= 40 doubles of w per thread) or 512 (<= 80)
     int persist_nt = 1;          // second read of a basis vector (served by the Infinity Cache) with non-temporal loads
@@ -440,7 +440,7 @@ int kk_launch_mgs_panel(kk_ctx ctx, const double* V, int64_t ld, int m, int nswe
                         const double* carry_s, double* out_s, int out_stride, double* nrm_out3, bool normalize_w, bool strict);
 // does an MGS-family sweep over vectors of leading dimension ld run in the low-synchronisation (projection-based) form?
 // (option "mgs_mode").  auto: the persistent kernels wherever they are the faster route -- the panel kernel for vectors of
-// panel_min_rows .. 3.67 M rows, the register-resident strict kernel from persist_min_rows rows up to its capacity -- and the
+// panel_min_rows .. 4.19 M rows, the register-resident strict kernel from persist_min_rows rows up to its capacity -- and the
 // projection pair otherwise (tiny vectors: launch-bound; vectors beyond the register file; row-sharded contexts).
 static inline bool kk_mgs_lowsync(kk_ctx ctx, int64_t ld, int m) {
     if (ctx->mgs_mode != 2) return ctx->mgs_mode == 1;

@@ -3,9 +3,8 @@
 // BASELINE.json: 2M rows; strong-scaling shards).  SURVEY.md 8(a) rows a6 / a8; reference order being restated:
 // src/orthonormal.jl:414-452 (MGS, MGS2), src/factorizations/arnoldi.jl:239-245, lanczos.jl:325-338.
 //
-//   * one block of 512 threads per CU (cooperative launch): seven DATA waves hold the block's rows of the work vector w in
-//     registers for the whole launch (NV double2 per thread, as in k_mgs_persist), wave 0 is the block's REDUCTION wave and
-//     owns no rows (see the last item);
+//   * one block of 512 threads per CU (cooperative launch), the block's rows of the work vector w in registers for the
+//     whole launch (NV double2 per thread, as in k_mgs_persist);
 //   * the basis is taken P vectors at a time.  A panel is loaded ONCE into registers (P * NV double2 per thread) and serves
 //     both its inner products and its update; while it is being used the NEXT panel is already on its way into a second
 //     register set (ordinary buffer loads, consumed one loop iteration later), so the basis stream never stops for the
@@ -17,16 +16,25 @@
 //     k_lowsync_solve restricted to the panel, with Gram entries of the vectors as they ARE (no bookkeeping, no
 //     orthonormality assumption).  Between panels the order is strictly sequential.  P = 1 is the reference's strict order,
 //     bit for bit the operations of k_mgs_persist (option mgs_mode = 0 forces it);
-//   * the reduction itself: the block's P (P + 1) / 2 partials are published as 16-byte tagged granules (write-through
-//     stores; value-major and packed, 4 KB per value) and swept with sc1 loads, summed in a fixed order -- all blocks obtain
-//     the same bits.  Publishing and sweeping is the job of WAVE 0 alone, which issues no panel loads: memory returns are in
-//     order per wave, so a sweep issued by a wave with a panel in flight completes only after that panel has landed, the
-//     update that frees the register set for the panel after next waits for it, and every panel is then requested into an
-//     EMPTY memory pipe -- latency + stream per panel instead of the stream alone (the first version of this kernel, all
-//     eight waves loading and sweeping: 7.5 us per vector at 4M rows against 4.8 of stream).  With the sweep in a wave of
-//     its own the data waves get the totals ~2.5 us after they published and have the next panel requested while the current
-//     one is still arriving.  Workgroup barriers are raw s_barrier (+ lgkmcnt(0)): a __syncthreads() would make hipcc drain
-//     the panel loads in flight (vmcnt(0)) before every barrier.
+//   * the reduction itself: wave 0 publishes the block's P (P + 1) / 2 partials as 16-byte tagged granules (write-through
+//     stores; value-major and packed, 4 KB per value) and sweeps those of all blocks with sc1 loads, summed in a fixed order
+//     -- all blocks obtain the same bits.  What the first versions of this kernel taught (tools/panel_trace.hip):
+//       - a CU's memory instructions leave through ONE in-order queue.  A publication (or a sweep) issued behind the ~128 KB
+//         of loads of a panel reaches the fabric when most of them have been served, whichever wave issues it (a reduction
+//         wave without rows and without loads of its own changes nothing: KK_PANEL_DW = 7): the reduction then ADDS to the
+//         landing time of the panel.  Hence the order of a step: inner products -> barrier -> PUBLISH -> barrier -> request
+//         the next panel -> sweep (queued behind it, served when the panel has landed, by which time every block has long
+//         published: one pass) -> barrier -> update.  3.6 M rows: 6.8 -> 5.2 us per vector, equal to the kernel with the
+//         reductions compiled out;
+//       - a quarter of the next panel is requested BEFORE the inner products (KK_PANEL_EARLY): it keeps the memory pipe from
+//         running empty during the hand-off and costs the publication ~0.2 us;
+//       - non-temporal panel loads (every basis vector is read once): -8 %;
+//       - rows owned contiguously per block instead of strided over the grid; granules packed instead of one line per block
+//         (the sweeps of 256 blocks are fabric traffic, and their latency hides here);
+//       - workgroup barriers are raw s_barrier (+ lgkmcnt(0)): a __syncthreads() makes hipcc drain the panel loads in flight
+//         (vmcnt(0)) before every barrier.
+//     What remains per panel is one pipeline fill (~1.5 us) plus the hand-off: 3.6 us per vector at 2 M rows (P = 2) against
+//     5.1 for the projection pair and for k_mgs_persist, 2.4 for the bare stream.
 #include "kk_internal.h"
 #include "kk_device.h"
 
@@ -36,8 +44,12 @@
 
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
 
+#ifndef KK_PANEL_AUX
+#define KK_PANEL_AUX 2   // non-temporal: every basis vector is read once per sweep (7.2 vs 6.3 TB/s read ceiling, tools/hbm_peak.hip)
+#endif
+template <int AUX = 0>
 __device__ __forceinline__ d2 pload(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-    const v4u t = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    const v4u t = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, AUX);
     d2 o;
     o.x = __longlong_as_double((long long)(((unsigned long long)t.y << 32) | t.x));
     o.y = __longlong_as_double((long long)(((unsigned long long)t.w << 32) | t.z));
@@ -66,46 +78,47 @@ __device__ __forceinline__ void fnma2(d2& x, double s, const d2& q) {
 
 // ---- the block's two roles meet at two workgroup barriers per reduction: (1) partials of the data waves are in smA,
 // (2) totals (and the timeout flag) of the reduction wave are in smB.
-#define KK_PANEL_DW 7                       // data waves per block (waves 1..7); wave 0 reduces
+#ifdef KK_PANEL_TRACE   // tools/panel_trace.hip: wall-clock stamps of block 0 (one data wave, the reduction wave) per panel
+__device__ long long* g_panel_trace = nullptr;
+#define PTRACE(slot, p) do { if (g_panel_trace && blockIdx.x == 0 && (threadIdx.x == 64 || threadIdx.x == 0)) g_panel_trace[(p) * 16 + (slot)] = wall_clock64(); } while (0)
+#define PTRACE_SET(slot, p, v) do { if (g_panel_trace && blockIdx.x == 0 && threadIdx.x == 0) g_panel_trace[(p) * 16 + (slot)] = (v); } while (0)
+#else
+#define PTRACE(slot, p) do { } while (0)
+#define PTRACE_SET(slot, p, v) do { } while (0)
+#endif
+#ifndef KK_PANEL_DW
+#define KK_PANEL_DW 8                       // data waves per block: 8 = every wave holds rows and wave 0 reduces on the side; 7 = wave 0 reduces only
+#endif
+#define KK_PANEL_W0 (8 - KK_PANEL_DW)       // first data wave
 #define KK_PANEL_DT (KK_PANEL_DW * 64)      // data threads per block
+#define KK_PANEL_NVMID (KK_PANEL_DW == 8 ? 8 : 9)   // grid-rows of the middle instantiation: what a 2M-row vector (config 3) needs
 
-// data waves: hand the NVAL per-thread partials to the reduction wave, come back with the totals (same bits in every thread
-// of every block).  Returns false after a timeout anywhere on the chip.
-template <int NVAL>
-__device__ __forceinline__ bool panel_reduce_data(const double (&acc)[NVAL], double (&tot)[NVAL], double* smA, const double* smB) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int v = 0; v < NVAL; ++v) {
-        const double t = wave_sum(acc[v]);
-        if (lane == 0) smA[wave * 8 + v] = t;
-    }
-    lds_barrier();   // (1)
-    lds_barrier();   // (2)
-#pragma unroll
-    for (int v = 0; v < NVAL; ++v) tot[v] = smB[v];
-    return smB[8] == 0.0;
-}
-
-// reduction wave: one grid reduction of nval values.  Granule (v, block) of a set sits at ((v * G + block) * 16) bytes.
-__device__ __forceinline__ bool panel_reduce_sync(int nval, unsigned epoch, int set, char* __restrict__ sync, int* __restrict__ err, const double* smA,
-                                                  double* smB) {
+// wave 0, between barriers (1) and (1b): publish the block's partials.  Granule (v, block) of a set sits at ((v * G + block) * 16) bytes.
+__device__ __forceinline__ void panel_publish(int nval, unsigned epoch, int set, char* __restrict__ sync, const double* smA) {
     const int G = gridDim.x;
     const int lane = threadIdx.x;
-    lds_barrier();   // (1)
     const unsigned set_bytes = (unsigned)G * 16u * 8u;   // room for 8 values per set
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(sync, 0, 2 * (int)set_bytes, 0x00020000);
-    const unsigned set_off = (unsigned)set * set_bytes;
     if (lane < nval) {   // lane v publishes the block's partial of value v
         double b = 0;
 #pragma unroll
-        for (int k = 1; k <= KK_PANEL_DW; ++k) b += smA[k * 8 + lane];   // fixed order
+        for (int k = KK_PANEL_W0; k < 8; ++k) b += smA[k * 8 + lane];   // fixed order
         const unsigned long long bits = (unsigned long long)__double_as_longlong(b);
         v4u t;
         t.x = epoch; t.y = (unsigned)(bits >> 32); t.z = (unsigned)bits; t.w = epoch;
-        __builtin_amdgcn_raw_buffer_store_b128(t, rs, set_off + ((unsigned)lane * (unsigned)G + blockIdx.x) * 16u, 0, 16 /* sc1 */);
+        __builtin_amdgcn_raw_buffer_store_b128(t, rs, (unsigned)set * set_bytes + ((unsigned)lane * (unsigned)G + blockIdx.x) * 16u, 0, 16 /* sc1 */);
     }
+}
+// wave 0, between barriers (1b) and (2): sweep the partials of all blocks, totals to smB[0 .. nval), timeout flag to smB[8]
+__device__ __forceinline__ bool panel_sweep(int nval, unsigned epoch, int set, char* __restrict__ sync, int* __restrict__ err, double* smB, int pidx = 0) {
+    const int G = gridDim.x;
+    const int lane = threadIdx.x;
+    const unsigned set_bytes = (unsigned)G * 16u * 8u;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(sync, 0, 2 * (int)set_bytes, 0x00020000);
+    const unsigned set_off = (unsigned)set * set_bytes;
     const long long t0 = wall_clock64();
     int good = 1;
+    long long npass = 0;
     for (int v = 0; v < nval && good; ++v) {   // value after value: by the time value 0 is complete the others usually are too
         const unsigned voff_v = set_off + (unsigned)v * (unsigned)G * 16u;
         double total = 0;
@@ -113,6 +126,7 @@ __device__ __forceinline__ bool panel_reduce_sync(int nval, unsigned epoch, int 
             // compiler barrier: the buffer-load builtin is a plain read to LLVM -- without it the granule loads are hoisted
             // out of the spin loop as loop invariants and the wave polls registers (found the hard way: every launch timed out)
             asm volatile("" ::: "memory");
+            ++npass;
             const int errv = __hip_atomic_load(err, RLX_AGENT);
             bool ok = true;
             double x = 0;
@@ -139,29 +153,81 @@ __device__ __forceinline__ bool panel_reduce_sync(int nval, unsigned epoch, int 
         if (lane == 0) smB[v] = total;
     }
     if (lane == 0 && !good) { __hip_atomic_store(err, 1, RLX_AGENT); smB[8] = 1.0; }
-    lds_barrier();   // (2)
+    PTRACE(9, pidx);   // totals complete
+    PTRACE_SET(10, pidx, npass);
+    (void)npass;
     return good != 0;
+}
+// one whole reduction as seen by a wave 0 that holds no rows (KK_PANEL_DW = 7)
+__device__ __forceinline__ bool panel_reduce_sync(int nval, unsigned epoch, int set, char* __restrict__ sync, int* __restrict__ err, const double* smA,
+                                                  double* smB, int pidx = 0) {
+    lds_barrier();   // (1)
+    panel_publish(nval, epoch, set, sync, smA);
+    PTRACE(8, pidx);
+    lds_barrier();   // (1b)
+    const bool good = panel_sweep(nval, epoch, set, sync, err, smB, pidx);
+    lds_barrier();   // (2)
+    return good;
+}
+
+// data waves, first half: hand the NVAL per-thread partials to the reduction wave and wait until it has PUBLISHED the block's
+// partials -- only then may the next panel be requested: a CU's memory instructions leave through one in-order queue, and a
+// publication queued behind 126 KB of panel loads reaches the fabric when most of them have been served (measured: the whole
+// reduction then ADDS to the landing time of the panel instead of hiding behind it).
+template <int NVAL>
+__device__ __forceinline__ void panel_handoff(const double (&acc)[NVAL], double* smA, unsigned epoch, int set, char* __restrict__ sync, int pidx = 0) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    PTRACE(1, pidx);   // partial sums formed (the panel has landed)
+#ifdef KK_PANEL_NOSYNC   // tools/panel_trace.hip: the stream structure of the kernel without any reduction
+    return;
+#endif
+#pragma unroll
+    for (int v = 0; v < NVAL; ++v) {
+        const double t = wave_sum(acc[v]);
+        if (lane == 0) smA[wave * 8 + v] = t;
+    }
+    lds_barrier();   // (1)  partials in smA
+    PTRACE(2, pidx);
+    if (KK_PANEL_W0 == 0 && threadIdx.x < 64) panel_publish(NVAL, epoch, set, sync, smA);   // wave 0 also holds rows: it publishes before it requests
+    lds_barrier();   // (1b) published
+}
+// second half: the totals (same bits in every thread of every block).  Returns false after a timeout anywhere on the chip.
+template <int NVAL>
+__device__ __forceinline__ bool panel_totals(const double (&acc)[NVAL], double (&tot)[NVAL], double* smB, unsigned epoch, int set, char* __restrict__ sync,
+                                             int* __restrict__ err, int pidx = 0) {
+#ifdef KK_PANEL_NOSYNC
+#pragma unroll
+    for (int v = 0; v < NVAL; ++v) tot[v] = acc[v] * 1e-30;
+    return true;
+#endif
+    if (KK_PANEL_W0 == 0 && threadIdx.x < 64) panel_sweep(NVAL, epoch, set, sync, err, smB, pidx);   // (its sweep queues behind its own panel loads: fine)
+    lds_barrier();   // (2)
+    PTRACE(3, pidx);   // totals available
+#pragma unroll
+    for (int v = 0; v < NVAL; ++v) tot[v] = smB[v];
+    return smB[8] == 0.0;
 }
 
 // panel p = vectors (sweep-major sequence) s0 .. s0 + P - 1 of the nsteps = m * nsweeps vectors of the launch
-template <int NV, int P>
+// rows [J0, J1) of every vector of the panel
+template <int NV, int P, int J0 = 0, int J1 = NV>
 __device__ __forceinline__ void panel_issue(d2 (&q)[P][NV], const double* __restrict__ V, int64_t ld, int m, int s0, int nsteps, unsigned voff,
-                                            unsigned sbytes) {
+                                            unsigned sbytes, int64_t brow, int bbytes) {
 #pragma unroll
     for (int i = 0; i < P; ++i) {
         const int s = s0 + i;
         const bool valid = s < nsteps;
-        const __amdgpu_buffer_rsrc_t r = pcol_rsrc(V + (int64_t)((valid ? s : 0) % m) * ld, valid ? (int)(ld * 8) : 0);
+        const __amdgpu_buffer_rsrc_t r = pcol_rsrc(V + (int64_t)((valid ? s : 0) % m) * ld + brow, valid ? bbytes : 0);
 #pragma unroll
-        for (int j = 0; j < NV; ++j) q[i][j] = pload(r, voff, (unsigned)j * sbytes);
+        for (int j = J0; j < J1; ++j) q[i][j] = pload<KK_PANEL_AUX>(r, voff, (unsigned)j * sbytes);
     }
 }
 
+// step of panel `cur`, first half: partial inner products <q_i, w> and in-panel Gram entries, handed to the reduction wave
 template <int NV, int P>
-__device__ __forceinline__ bool panel_step(d2 (&wr)[NV], d2 (&cur)[P][NV], int s0, int nsteps, int m, double* smA, const double* smB,
-                                           double* __restrict__ out_s, int out_stride) {
+__device__ __forceinline__ void panel_dots(const d2 (&wr)[NV], const d2 (&cur)[P][NV], double (&acc)[P * (P + 1) / 2], double* smA, unsigned ebase, char* sync,
+                                           int pidx) {
     constexpr int NVAL = P * (P + 1) / 2;
-    double acc[NVAL], tot[NVAL];
 #pragma unroll
     for (int v = 0; v < NVAL; ++v) acc[v] = 0;
 #pragma unroll
@@ -178,7 +244,15 @@ __device__ __forceinline__ bool panel_step(d2 (&wr)[NV], d2 (&cur)[P][NV], int s
             }
         }
     }
-    if (!panel_reduce_data<NVAL>(acc, tot, smA, smB)) return false;
+    panel_handoff<NVAL>(acc, smA, ebase + (unsigned)pidx + 1u, pidx & 1, sync, pidx);
+}
+// second half: totals -> coefficients -> update of w
+template <int NV, int P>
+__device__ __forceinline__ bool panel_update(d2 (&wr)[NV], d2 (&cur)[P][NV], const double (&acc)[P * (P + 1) / 2], int s0, int nsteps, int m,
+                                             double* smB, double* __restrict__ out_s, int out_stride, unsigned ebase, char* sync, int* err, int pidx) {
+    constexpr int NVAL = P * (P + 1) / 2;
+    double tot[NVAL];
+    if (!panel_totals<NVAL>(acc, tot, smB, ebase + (unsigned)pidx + 1u, pidx & 1, sync, err, pidx)) return false;
     // (I + L) s = d, L = strictly lower in-panel Gram block: exact forward substitution, the same bits in every thread
     double s[P];
 #pragma unroll
@@ -193,13 +267,14 @@ __device__ __forceinline__ bool panel_step(d2 (&wr)[NV], d2 (&cur)[P][NV], int s
 #pragma unroll
         for (int j = 0; j < NV; ++j) fnma2(wr[j], s[i], cur[i][j]);
     }
-    if (blockIdx.x == 0 && threadIdx.x == 64) {
+    if (blockIdx.x == 0 && threadIdx.x == 64 * KK_PANEL_W0) {
 #pragma unroll
         for (int i = 0; i < P; ++i) {
             const int sv = s0 + i;
             if (sv < nsteps) out_s[(sv / m) * out_stride + (sv % m)] = s[i];
         }
     }
+    PTRACE(4, pidx);   // update done
     return true;
 }
 
@@ -220,27 +295,42 @@ __global__ __launch_bounds__(KK_PANEL_PT) void k_mgs_panel(const double* __restr
     const int nsteps = m * nsweeps;
     const int npanels = (nsteps + P - 1) / P;
     constexpr int NVAL = P * (P + 1) / 2;
-    if (threadIdx.x < 64) {
-        // ---------------- the reduction wave: no rows, no panel loads -- nothing queues in front of its sweeps
+    if (KK_PANEL_W0 == 0 && threadIdx.x == 0) smB[8] = 0.0;
+    if (KK_PANEL_W0 == 1 && threadIdx.x < 64) {
+        // ---------------- a reduction wave without rows
         if (threadIdx.x == 0) smB[8] = 0.0;
         lds_barrier();   // (0)
+#ifdef KK_PANEL_NOSYNC
+        return;
+#endif
         for (int p = 0; p < npanels; ++p)
-            if (!panel_reduce_sync(NVAL, ebase + (unsigned)p + 1u, p & 1, sync, err, smA, smB)) return;
+            if (!panel_reduce_sync(NVAL, ebase + (unsigned)p + 1u, p & 1, sync, err, smA, smB, p)) return;
         if (nrm_out3) panel_reduce_sync(1, ebase + (unsigned)npanels + 1u, npanels & 1, sync, err, smA, smB);
         return;
     }
     // ---------------- the data waves
-    const unsigned dt = threadIdx.x - 64;
-    const unsigned sbytes = gridDim.x * KK_PANEL_DT * 16u;               // one grid-row in bytes
-    const unsigned voff = (blockIdx.x * KK_PANEL_DT + dt) * 16u;         // this lane's byte offset inside a grid-row
-    const __amdgpu_buffer_rsrc_t rw = pcol_rsrc(w, (int)(ld * 8));
+    // Row ownership: block b holds the CONTIGUOUS rows [b * rpb, (b + 1) * rpb), rpb = nvr * 896 with nvr = ceil(ld / (G * 896))
+    // <= NV; thread t its double2 number r * 448 + t of them, r < NV.  Every stream goes through a descriptor of the BLOCK's
+    // slice of the column (base + b * rpb, as many bytes as the slice has inside the vector): rows r >= nvr and the tail of
+    // the last blocks read as zeros / are not written, with no mask anywhere.  (Contiguous per block, not strided over the
+    // grid as in k_mgs_persist: with 16 .. 32 loads per lane in flight a grid-strided thread touches 16 .. 32 windows 1.8 MB
+    // apart at once, and the same request stream then ran at 3.6 TB/s -- tools/panel_trace.hip, reductions compiled out.)
+    const unsigned dt = threadIdx.x - 64 * KK_PANEL_W0;
+    const int nvr = (int)((ld + (int64_t)gridDim.x * KK_PANEL_DT * 2 - 1) / ((int64_t)gridDim.x * KK_PANEL_DT * 2));
+    const int64_t rpb = (int64_t)nvr * KK_PANEL_DT * 2;
+    const int64_t brow = (int64_t)blockIdx.x * rpb;
+    const int64_t left = ld - brow;
+    const int bbytes = (int)((left < 0 ? 0 : (left < rpb ? left : rpb)) * 8);
+    const unsigned sbytes = KK_PANEL_DT * 16u;                           // one row of 448 double2 in bytes
+    const unsigned voff = dt * 16u;                                      // this lane's byte offset inside such a row
+    const __amdgpu_buffer_rsrc_t rw = pcol_rsrc(w + brow, bbytes);
     d2 wr[NV];
     d2 qa[P][NV], qb[P][NV];
-    panel_issue<NV, P>(qa, V, ld, m, 0, nsteps, voff, sbytes);   // first panel on its way before anything else
+    panel_issue<NV, P>(qa, V, ld, m, 0, nsteps, voff, sbytes, brow, bbytes);   // first panel on its way before anything else
 #pragma unroll
     for (int j = 0; j < NV; ++j) wr[j] = pload(rw, voff, (unsigned)j * sbytes);
     if (carry_q) {   // pending axpy of the caller (Lanczos: w -= alpha0 v): one extra read of that vector, through the idle second panel set
-        const __amdgpu_buffer_rsrc_t rc = pcol_rsrc(carry_q, (int)(ld * 8));
+        const __amdgpu_buffer_rsrc_t rc = pcol_rsrc(carry_q + brow, bbytes);
         const double cs = *carry_s;
 #pragma unroll
         for (int j = 0; j < NV; ++j) qb[0][j] = pload(rc, voff, (unsigned)j * sbytes);   // all loads first: one round trip, not NV
@@ -248,28 +338,41 @@ __global__ __launch_bounds__(KK_PANEL_PT) void k_mgs_panel(const double* __restr
         for (int j = 0; j < NV; ++j) fnma2(wr[j], cs, qb[0][j]);
     }
     lds_barrier();   // (0) (the timeout flag slot is initialised)
+#ifndef KK_PANEL_EARLY
+#define KK_PANEL_EARLY 4
+#endif
+    constexpr int EARLY = (NV * KK_PANEL_EARLY) / 16;   // rows of each vector of the next panel requested BEFORE this panel's partials are published
+    double acc[NVAL];
     for (int p = 0; p < npanels; p += 2) {
-        panel_issue<NV, P>(qb, V, ld, m, (p + 1) * P, nsteps, voff, sbytes);   // next panel in flight across this panel's reduction
-        if (!panel_step<NV, P>(wr, qa, p * P, nsteps, m, smA, smB, out_s, out_stride)) return;   // timeout: w in HBM is untouched
+        // per panel: inner products -> the block's partials are published -> request the NEXT panel -> totals -> update
+        panel_issue<NV, P, 0, EARLY>(qb, V, ld, m, (p + 1) * P, nsteps, voff, sbytes, brow, bbytes);   // head of the next panel: keeps the memory pipe primed
+        panel_dots<NV, P>(wr, qa, acc, smA, ebase, sync, p);
+        PTRACE(0, p);
+        panel_issue<NV, P, EARLY, NV>(qb, V, ld, m, (p + 1) * P, nsteps, voff, sbytes, brow, bbytes);   // the rest, in flight across this panel's reduction
+        if (!panel_update<NV, P>(wr, qa, acc, p * P, nsteps, m, smB, out_s, out_stride, ebase, sync, err, p)) return;   // timeout: w in HBM is untouched
         if (p + 1 >= npanels) break;
-        panel_issue<NV, P>(qa, V, ld, m, (p + 2) * P, nsteps, voff, sbytes);
-        if (!panel_step<NV, P>(wr, qb, (p + 1) * P, nsteps, m, smA, smB, out_s, out_stride)) return;
+        panel_issue<NV, P, 0, EARLY>(qa, V, ld, m, (p + 2) * P, nsteps, voff, sbytes, brow, bbytes);
+        panel_dots<NV, P>(wr, qb, acc, smA, ebase, sync, p + 1);
+        PTRACE(0, p + 1);
+        panel_issue<NV, P, EARLY, NV>(qa, V, ld, m, (p + 2) * P, nsteps, voff, sbytes, brow, bbytes);
+        if (!panel_update<NV, P>(wr, qb, acc, (p + 1) * P, nsteps, m, smB, out_s, out_stride, ebase, sync, err, p + 1)) return;
     }
     double inv = 1.0;
     bool scale = false;
     if (nrm_out3) {
-        double acc[1] = {0.0}, tot[1];
+        double an[1] = {0.0}, tot[1];
 #pragma unroll
-        for (int j = 0; j < NV; ++j) { acc[0] = fma(wr[j].x, wr[j].x, acc[0]); acc[0] = fma(wr[j].y, wr[j].y, acc[0]); }
-        if (!panel_reduce_data<1>(acc, tot, smA, smB)) return;
+        for (int j = 0; j < NV; ++j) { an[0] = fma(wr[j].x, wr[j].x, an[0]); an[0] = fma(wr[j].y, wr[j].y, an[0]); }
+        panel_handoff<1>(an, smA, ebase + (unsigned)npanels + 1u, npanels & 1, sync);
+        if (!panel_totals<1>(an, tot, smB, ebase + (unsigned)npanels + 1u, npanels & 1, sync, err)) return;
         const double rt = sqrt(tot[0]);
         inv = 1.0 / rt;
         scale = normalize && rt > 0.0 && inv <= 1.79769313486231570815e308;
-        if (blockIdx.x == 0 && threadIdx.x == 64) { nrm_out3[0] = tot[0]; nrm_out3[1] = rt; nrm_out3[2] = inv; }
+        if (blockIdx.x == 0 && threadIdx.x == 64 * KK_PANEL_W0) { nrm_out3[0] = tot[0]; nrm_out3[1] = rt; nrm_out3[2] = inv; }
     }
     // commit (see k_mgs_persist): every block writes its rows back or -- flag raised by a block that timed out -- none does
     if (__hip_atomic_load(err, RLX_AGENT)) return;
-    if (blockIdx.x == 0 && threadIdx.x == 64) { ok_out[0] = token; ok_out[1] = scale ? 1.0 : inv; }   // SC_PERSIST_OK, SC_XS
+    if (blockIdx.x == 0 && threadIdx.x == 64 * KK_PANEL_W0) { ok_out[0] = token; ok_out[1] = scale ? 1.0 : inv; }   // SC_PERSIST_OK, SC_XS
     // scale in place FIRST, store afterwards, nothing in between: a VALU write to the data registers of a 16-byte buffer store
     // in the instruction after it can reach the store (hipcc inserts the wait state only for stores WITHOUT an SGPR offset;
     // with one, gfx950 still picked up the NEXT row's product in lanes 12-15 of every row of 16 -- one launch in ~100)
@@ -282,7 +385,7 @@ __global__ __launch_bounds__(KK_PANEL_PT) void k_mgs_panel(const double* __restr
 }
 
 // ---- launcher ------------------------------------------------------------------------------
-// vectors of at most 16 grid-rows (3.67 M rows on 256 CUs): w plus two panels fit the 256 registers of a 512-thread block
+// vectors of at most 16 rows of 512 double2 per block (4.19 M rows on 256 CUs): w plus two panels fit the 256 registers of a 512-thread block
 int64_t kk_mgs_panel_capacity(kk_ctx ctx) { return (int64_t)ctx->num_cus * KK_PANEL_DT * 2 * 16; }
 bool kk_mgs_panel_eligible(kk_ctx ctx, int64_t ld) {
     if (!ctx->mgs_panel || !ctx->mgs_persist || kk_sharded(ctx) || !ctx->d_sync) return false;
@@ -301,7 +404,7 @@ static int launch_panel_inst(kk_ctx ctx, void** args) {
 int kk_mgs_panel_width(kk_ctx ctx, int64_t ld, bool strict) {
     if (strict) return 1;
     const int nv = (int)((ld + (int64_t)ctx->num_cus * KK_PANEL_DT * 2 - 1) / ((int64_t)ctx->num_cus * KK_PANEL_DT * 2));
-    const int by_size = nv <= 4 ? 3 : (nv <= 9 ? 2 : 1);
+    const int by_size = nv <= 4 ? 3 : (nv <= KK_PANEL_NVMID ? 2 : 1);
     return ctx->panel_width > 0 ? std::min(ctx->panel_width, by_size) : by_size;
 }
 
@@ -330,7 +433,7 @@ int kk_launch_mgs_panel(kk_ctx ctx, const double* V, int64_t ld, int m, int nswe
                     (void*)&ebase, (void*)&normalize, (void*)&ok_out, (void*)&token};
     kk_prof_scope ps(ctx, "k_mgs_panel");
     if (nv <= 4) return P >= 3 ? launch_panel_inst<4, 3>(ctx, args) : (P == 2 ? launch_panel_inst<4, 2>(ctx, args) : launch_panel_inst<4, 1>(ctx, args));
-    if (nv <= 9) return P >= 2 ? launch_panel_inst<9, 2>(ctx, args) : launch_panel_inst<9, 1>(ctx, args);
+    if (nv <= KK_PANEL_NVMID) return P >= 2 ? launch_panel_inst<KK_PANEL_NVMID, 2>(ctx, args) : launch_panel_inst<KK_PANEL_NVMID, 1>(ctx, args);
     if (nv <= 16) return launch_panel_inst<16, 1>(ctx, args);
     kk_set_error("kk_launch_mgs_panel: vector of %lld rows does not fit two register-resident panels", (long long)ld);
     return KK_ERR_UNSUPPORTED;
