@@ -160,7 +160,7 @@ def restorearnoldiform(U: np.ndarray, H: np.ndarray, f: np.ndarray, keep: int, o
 def _set_packed_hessenberg(fact, H: np.ndarray, K: int):
     """copy!(rayleighquotient(fact), H) (eigsolve/arnoldi.jl:443): write the K x K dense H back into the packed
     Hessenberg storage (dense/packedhessenberg.jl:32-48)."""
-    from .factorizations import packed_index
+    from krylovkit_hip.factorizations import packed_index
     for j in range(1, K + 1):
         for i in range(1, min(j + 1, K) + 1):
             fact.H[packed_index(i, j)] = float(H[i - 1, j - 1])
@@ -284,7 +284,7 @@ def _bischursolve(A, v0, w0, howmany: int, which: str, alg):
     their coupling M = W'V, the oblique corrections of the residuals and the K x K Schur algebra follow the reference
     (host LAPACK for the small matrices, kk_project / kk_unproject / kk_basistransform for everything N-long)."""
     import scipy.linalg as sla
-    from .core import FunctionOperator
+    from krylovkit_hip.core import FunctionOperator
     krylovdim, maxiter, tol = alg.krylovdim, alg.maxiter, alg.tol
     if howmany > krylovdim:
         raise ValueError(f"krylov dimension {krylovdim} too small to compute {howmany} eigenvalues")
@@ -386,7 +386,7 @@ def _bischursolve(A, v0, w0, howmany: int, which: str, alg):
 def bieigsolve(A, v0, w0, howmany: int = 1, which: str = "LM", alg=None, **kw):
     """bieigsolve(f, v0, w0, howmany, which, alg::BiArnoldi) (src/eigsolve/biarnoldi.jl:127-194): eigenvalues with right
     and left eigenvectors (W'V = I) of a general operator.  Returns (values, (vectorsV, vectorsW), (infoV, infoW))."""
-    from .algorithms import BiArnoldi
+    pass  # BiArnoldi is defined in this module
     alg = alg or BiArnoldi(**kw)
     (S, T), (Q, Z), (fV, fW), (rV, rW), (h, k), M, converged, numiter, numops = _bischursolve(A, v0, w0, howmany, which, alg)
     hm = howmany
@@ -427,7 +427,7 @@ def geneigsolve(AB, x0, howmany: int = 1, which: str = "SR", alg: Optional[Golub
     symmetric positive definite B, both device sparse operators.  The inner iteration is the Lanczos recurrence of
     A - rho B on the device basis (two SpMVs + the same orthogonalisation passes per step, golubye.jl:182-281); the
     projected K x K pencil is solved on the host (LAPACK sygvd through SciPy, as the reference does)."""
-    from .factorizations import Block, block_inner, lanczos_recurrence_unfused
+    from krylovkit_hip.factorizations import Block, block_inner, lanczos_recurrence_unfused
     alg = alg or GolubYe(**kw)
     if which in ("LI", "SI"):
         raise ValueError(f"Eigenvalue selector which = {which} invalid: real eigenvalues expected with Lanczos algorithm")
