@@ -54,6 +54,8 @@ static int ctx_allocate(kk_ctx c) {
     KK_HIP(hipEventCreate(&c->t1));
     KK_HIP(hipEventCreateWithFlags(&c->ev_fetch, hipEventDisableTiming));
     KK_HIP(hipEventCreateWithFlags(&c->ev_fetch2, hipEventDisableTiming));
+    KK_HIP(hipEventCreateWithFlags(&c->ev_la[0], hipEventDisableTiming));
+    KK_HIP(hipEventCreateWithFlags(&c->ev_la[1], hipEventDisableTiming));
     KK_HIP(hipMalloc(&c->d_sync, KK_SYNC_BYTES));
     KK_HIP(hipMemset(c->d_sync, 0, KK_SYNC_BYTES));
     KK_HIP(hipHostMalloc((void**)&c->h_sync, 64, hipHostMallocDefault));
@@ -116,6 +118,7 @@ KK_API int kk_ctx_destroy(kk_ctx c) {
     if (c->t1) (void)hipEventDestroy(c->t1);
     if (c->ev_fetch) (void)hipEventDestroy(c->ev_fetch);
     if (c->ev_fetch2) (void)hipEventDestroy(c->ev_fetch2);
+    for (int i = 0; i < 2; ++i) if (c->ev_la[i]) (void)hipEventDestroy(c->ev_la[i]);
     (void)hipFree(c->ws_own);
     (void)hipFree(c->partials);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
@@ -163,6 +166,8 @@ KK_API int kk_ctx_set_option(kk_ctx c, const char* key, double value) {
     } else if (!strcmp(key, "mgs_persist")) {
         c->mgs_persist = value != 0;
         c->persist_skip = 0;
+    } else if (!strcmp(key, "lookahead")) {
+        c->lookahead = value != 0;
     } else if (!strcmp(key, "mgs_panel")) {
         c->mgs_panel = value != 0;
     } else if (!strcmp(key, "panel_width")) {
@@ -259,6 +264,7 @@ KK_API int kk_ctx_get_option(kk_ctx c, const char* key, double* value) {
     else if (!strcmp(key, "persist_capacity_rows")) *value = (double)kk_mgs_persist_capacity(c);
     else if (!strcmp(key, "fold_scale")) *value = c->fold_scale;
     else if (!strcmp(key, "mgs_panel")) *value = c->mgs_panel;
+    else if (!strcmp(key, "lookahead")) *value = c->lookahead;
     else if (!strcmp(key, "panel_width")) *value = c->panel_width;
     else if (!strcmp(key, "panel_min_rows")) *value = (double)c->panel_min_rows;
     else if (!strcmp(key, "panel_capacity_rows")) *value = (double)kk_mgs_panel_capacity(c);

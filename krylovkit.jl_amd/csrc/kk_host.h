@@ -33,6 +33,7 @@ static inline const double* pin(kk_ctx c, int64_t off, int slot = 0) { return c-
 static inline void gram_touch(kk_basis b, int col) {
     if (col < b->gram_rows) b->gram_rows = col;
     b->spec_valid = false;
+    b->la_valid = false;
     kk_ctx c = b->ctx;   // cached Gram matrix of a residual block: gone as soon as a column at or below its end may have changed
     if (c->gw_valid && c->gw_basis == b->uid && col < c->gw_col + c->gw_p) c->gw_valid = false;
 }
@@ -76,6 +77,7 @@ int pass_mgs_strict(kk_ctx c, const double* V, int64_t ld, int m, double* w, int
 int pass_mgs_strict_sweeps(kk_ctx c, const double* V, int64_t ld, int m, int nsweeps, double* w, const int64_t* ws_s,
                            bool want_norm, int slot, const double* carry_q, const double* carry_s);
 int persist_check(kk_ctx c, bool* timed_out);
+int persist_check_at(kk_ctx c, int slot, double token, bool* timed_out);   // the same for a launch identified by (pinned slot, token)
 int gram_ensure(kk_basis b, int upto /* exclusive */);
 int gram_device(kk_basis b);   // device mirror of the host Gram rows (created on first use)
 int lowsync_project_dev(kk_basis b, int m, const double* w, const double* pre_vec, const double* pre_a,

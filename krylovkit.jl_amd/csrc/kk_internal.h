@@ -176,6 +176,8 @@ struct kk_ctx_s {
     int stage_slot = 0;             // next free coefficient staging slot (stage_coef)
     bool bicg_ahead = false;        // a BiCG half was enqueued by kk_bicgstab_full and not collected yet
     hipEvent_t ev_fetch = nullptr;  // marks the end of the scalar read-backs of an expand (host waits on this, not on the stream)
+    hipEvent_t ev_la[2] = {nullptr, nullptr};   // ... of a step whose sweep was enqueued one call ahead (pinned slots 2 and 3)
+    int lookahead = 1;              // Lanczos / Arnoldi expand! with a persistent MGS sweep: the NEXT step's apply AND sweep are enqueued before the host waits for this step's scalars
     int prof = 0;                // 0 off, 1 every kernel class, 2 only the basis-streaming classes (project/unproject)
     std::map<std::string, kk_prof_entry> prof_tab;
     std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> prof_pending;
@@ -198,6 +200,10 @@ struct kk_basis_s {
     const void* spec_op = nullptr;
     int spec_c0 = 0, spec_k = 0, spec_dot_mode = 0;
     double spec_beta = 0;
+    // the whole next step (apply + persistent sweep + read-back) enqueued one call ahead: valid only together with spec_valid
+    bool la_valid = false;
+    int la_k = 0, la_slot = 0;
+    double la_token = 0;
     // residual column left NORMALISED by a fused expand! (persistent kernel, w / |w| written at commit): logically the column
     // still holds r = norm_beta * stored; the next expand! of the same factorization takes it as its new basis vector without
     // the scale pass, every other access multiplies it back first (norm_flush)

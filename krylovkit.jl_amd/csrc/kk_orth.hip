@@ -269,13 +269,11 @@ int pass_mgs_strict_sweeps(kk_ctx c, const double* V, int64_t ld, int m, int nsw
 // for the next few sweeps and *timed_out tells the caller to repeat the sweep -- pass_mgs_strict_sweeps now takes the
 // launch-per-vector route.  Callers that enqueued dependent work behind the launch (a speculative next-step apply)
 // must cancel it first: it consumed scalars the failed launch never wrote.
-int persist_check(kk_ctx c, bool* timed_out) {
+int persist_check_at(kk_ctx c, int slot, double token, bool* timed_out) {
     *timed_out = false;
-    if (!c->persist_pending) return KK_OK;
-    c->persist_pending = false;
     // a launch that committed wrote its token next to the scalars of the sweep (same read-back); anything else -- the flag
     // was raised by a block whose spin ran out, blocks left without writing w back -- leaves the previous launch's token
-    if (pin(c, WS_SCAL + SC_PERSIST_OK, c->persist_slot)[0] != c->persist_token) {
+    if (pin(c, WS_SCAL + SC_PERSIST_OK, slot)[0] != token) {
         KK_HIP(hipMemsetAsync((char*)c->d_sync + KK_SYNC_ERR_OFFSET, 0, sizeof(int), c->stream));
         c->persist_norm_done = false;
         ++c->persist_timeouts;
@@ -291,6 +289,12 @@ int persist_check(kk_ctx c, bool* timed_out) {
         c->persist_backoff = 4;   // a clean launch: back to the short retry interval
     }
     return KK_OK;
+}
+int persist_check(kk_ctx c, bool* timed_out) {
+    *timed_out = false;
+    if (!c->persist_pending) return KK_OK;
+    c->persist_pending = false;
+    return persist_check_at(c, c->persist_slot, c->persist_token, timed_out);
 }
 // strict sweeps + the synchronisation that ends them, with the recovery above folded in (no speculation involved)
 static int strict_sweeps_synced(kk_ctx c, const double* V, int64_t ld, int m, int nsweeps, double* w, const int64_t* ws_s,
