@@ -559,7 +559,7 @@ def main():
             ms_ = range(2, Kg_ + 1)
             return dict(sweep=sweep_g, units=Kg_ - 1, kmult=3, keep=(opg, Vg, x0g, itg),
                         model={"k_project": float(sum((8 * m + 16) * Ng for m in ms_)), "k_unproj_proj": float(sum((8 * m + 16) * Ng for m in ms_)),
-                               "k_unproject": float(sum((8 * m + 16) * Ng for m in ms_)), "k_mgs_panel": float(sum((16 * m + 16) * Ng for m in ms_))   # two sweeps in one launch, every basis vector read once per sweep, w read and written once,
+                               "k_unproject": float(sum((8 * m + 16) * Ng for m in ms_)), "k_mgs_panel": float(sum((16 * m + 16) * Ng for m in ms_)),   # (two sweeps in one launch, every basis vector read once per sweep, w read and written once)
                                "k_spmv_dia": 24.0 * Ng * Kg_, "k_scal": 16.0 * Ng * Kg_},
                         alg=float(sum((144 + 32 * m) * Ng for m in ms_)),
                         meta={"metric": "arnoldi_iterations_per_second", "unit": "it/s",

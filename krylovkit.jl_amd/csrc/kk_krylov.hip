@@ -196,10 +196,12 @@ KK_API int kk_lanczos_expand(kk_op op, kk_basis b, int c0, int k, kk_orth_t orth
     const bool v_ready = b->norm_col == c0 + k && b->norm_beta == beta_old;
     if (!v_ready) KK_TRY(norm_flush(b));
     // the previous call may have enqueued this WHOLE step already (apply, sweep and read-back: la_enqueue below)
+    const bool strict_branch = orth == KK_MGS2 && !wide && !sh_fused && !(lowsync && c0 == 0);
     const bool la_hit = b->la_valid && b->spec_valid && c->spec_owner == b && b->spec_op == op && b->spec_c0 == c0 && b->spec_k == k &&
-                        b->la_k == k && b->spec_beta == beta_old && orth == KK_MGS2 && v_ready;
+                        b->la_k == k && b->spec_beta == beta_old && strict_branch && v_ready;
     const int la_slot = b->la_slot;
     const double la_token = b->la_token;
+    if (b->la_valid && !la_hit) b->spec_valid = false;   // a sweep enqueued ahead has consumed the speculative apply's output column: nothing to take over
     bool hit = la_hit;
     if (!la_hit) KK_TRY(spec_take(op, b, c0, k, cgs_order ? 1 : 2, beta_old, a0_slot, &hit));
     gram_touch(b, c0 + k);
@@ -345,6 +347,12 @@ KK_API int kk_lanczos_expand(kk_op op, kk_basis b, int c0, int k, kk_orth_t orth
             b->spec_valid = false;
             b->la_valid = false;
             KK_CHECK(attempt == 0, KK_ERR_HIP, "kk_lanczos_expand: the launch-per-vector MGS route reported a grid-barrier timeout (internal error)");
+            // (the step enqueued ahead has replaced alpha0 on the device by its own: put this step's back -- it came home with
+            // the read-back of the failed launch -- once the stream has run dry)
+            KK_TRY(stream_sync(c));
+            const double a0_host = pin(c, WS_SCAL + SC_ALPHA0, slot)[0];
+            KK_HIP(hipMemcpyAsync(SCP(c, SC_ALPHA0), &a0_host, sizeof(double), hipMemcpyHostToDevice, c->stream));
+            KK_TRY(stream_sync(c));
         }
         a = pin(c, WS_SCAL + SC_ALPHA0, slot)[0] + pin(c, WS_S, slot)[m - 1];
         bt = pin(c, WS_SCAL + SC_NRM2, slot)[1];
@@ -374,6 +382,7 @@ KK_API int kk_arnoldi_expand(kk_op op, kk_basis b, int c0, int k, kk_orth_t orth
     double* w = b->col(c0 + k + 1);
     const bool v_ready = b->norm_col == c0 + k && b->norm_beta == beta_old;   // see kk_lanczos_expand
     if (!v_ready) KK_TRY(norm_flush(b));
+    if (b->la_valid) { b->spec_valid = false; b->la_valid = false; }   // (a Lanczos step enqueued ahead on this slab: its apply column has been swept)
     bool hit = false;
     KK_TRY(spec_take(op, b, c0, k, 0, beta_old, SCP(c, SC_ALPHA0), &hit));
     gram_touch(b, c0 + k);

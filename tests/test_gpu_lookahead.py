@@ -1,0 +1,96 @@
+"""Run-ahead of a whole Lanczos step (csrc/kk_krylov.hip::la_enqueue): the apply AND the persistent sweep of step k+1 are
+enqueued before the host waits for the scalars of step k (factorizations/lanczos.jl:250-272 is called once per step by the
+reference's drivers; the GPU must not idle through that round trip).  Same kernels, operands and order as the call-by-call
+route, so everything must be bitwise the same; anything that touches the slab between two calls drops the run-ahead."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(params=["persist", "panel"])
+def lctx(kk, request):
+    c = kk.Context(0)
+    if c.get_option("mgs_persist") == 0:
+        pytest.skip("no cooperative launch on this device")
+    c.set_option("mgs_mode", 0)                      # strict order at every size
+    c.set_option("mgs_panel", 1 if request.param == "panel" else 0)
+    yield c
+    c.close()
+
+
+def run(kk, ctx, A, x0, steps, lookahead, capacity=None, poke=()):
+    ctx.set_option("lookahead", lookahead)
+    it = kk.LanczosIterator(kk.SparseOperator(A, ctx, symmetric=True), x0, kk.ModifiedGramSchmidt2(), capacity=capacity or steps + 3)
+    f = kk.initialize(it)
+    seen = {}
+    for i in range(steps):
+        f = kk.expand_(it, f)
+        if i in poke:
+            seen[i] = f.r.get().copy()
+    return f, seen
+
+
+def test_bitwise_equal_to_the_call_by_call_route(kk, ko, lctx):
+    nx, ny, steps = 52, 40, 28
+    n = nx * ny
+    A = ko.laplacian_2d(nx, ny, shift_diag=10 * np.linspace(0, 1, n) ** 2)
+    x0 = np.random.default_rng(3).random(n)
+    f1, _ = run(kk, lctx, A, x0, steps, 1)
+    a1, b1, V1 = np.array(f1.alphas), np.array(f1.betas), f1.V.to_numpy().copy()
+    f0, _ = run(kk, lctx, A, x0, steps, 0)
+    lctx.set_option("lookahead", 1)
+    assert np.array_equal(a1, np.array(f0.alphas)) and np.array_equal(b1, np.array(f0.betas))
+    assert np.array_equal(V1, f0.V.to_numpy())
+    oit = ko.LanczosIterator(A, x0.copy(), ko.MGS2)
+    of = ko.lanczos_initialize(oit)
+    for _ in range(steps):
+        of = ko.lanczos_expand(oit, of)
+    assert np.max(np.abs(a1 - of.alphas) / np.abs(of.alphas)) < 1e-10 and np.max(np.abs(b1 - of.betas) / np.abs(of.betas)) < 1e-10
+    assert np.max(np.abs(V1.T @ V1 - np.eye(V1.shape[1]))) < 1e-12
+
+
+def test_stops_at_the_end_of_the_slab_and_survives_interruptions(kk, ko, lctx):
+    """capacity = krylovdim + 2 (what the drivers allocate): the run-ahead must not enqueue a sweep beyond the last step;
+    reading residual(F) in the middle drops the step enqueued ahead and the run continues unharmed"""
+    nx, ny, steps = 40, 30, 18
+    n = nx * ny
+    A = ko.laplacian_2d(nx, ny, shift_diag=10 * np.linspace(0, 1, n) ** 2)
+    x0 = np.random.default_rng(5).random(n)
+    lctx.prof_reset(); lctx.prof_enable(1)
+    f, seen = run(kk, lctx, A, x0, steps, 1, capacity=steps + 3, poke={4, 5, 11})
+    lctx.prof_enable(0)
+    launches = lctx.prof_get("k_mgs_persist")[1] + lctx.prof_get("k_mgs_panel")[1]
+    assert steps <= launches <= steps + 3     # one per step, + one dropped run-ahead per interruption, none beyond the slab
+    oit = ko.LanczosIterator(A, x0.copy(), ko.MGS2)
+    of = ko.lanczos_initialize(oit)
+    for i in range(steps):
+        of = ko.lanczos_expand(oit, of)
+        if i in seen:
+            assert np.max(np.abs(seen[i] - of.r)) < 1e-10 * np.linalg.norm(of.r)
+    assert np.max(np.abs(np.array(f.alphas) - of.alphas) / np.abs(of.alphas)) < 1e-10
+    assert np.max(np.abs(np.array(f.betas) - of.betas) / np.abs(of.betas)) < 1e-10
+    V = f.V.to_numpy()
+    assert np.max(np.abs(V.T @ V - np.eye(V.shape[1]))) < 1e-12
+
+
+def test_timeout_of_a_step_enqueued_ahead_is_recovered(kk, ko, lctx):
+    nx, ny, steps = 44, 36, 20
+    n = nx * ny
+    A = ko.laplacian_2d(nx, ny, shift_diag=10 * np.linspace(0, 1, n) ** 2)
+    x0 = np.random.default_rng(7).random(n)
+    lctx.set_option("lookahead", 1)
+    it = kk.LanczosIterator(kk.SparseOperator(A, lctx, symmetric=True), x0, kk.ModifiedGramSchmidt2(), capacity=steps + 3)
+    f = kk.initialize(it)
+    oit = ko.LanczosIterator(A, x0.copy(), ko.MGS2)
+    of = ko.lanczos_initialize(oit)
+    for i in range(steps):
+        if i in (6, 13):
+            lctx.set_option("persist_fault", 1)    # the next persistent launch (a step enqueued ahead) behaves like a timed-out one
+        f = kk.expand_(it, f)
+        of = ko.lanczos_expand(oit, of)
+    assert lctx.get_option("persist_timeouts") == 2
+    assert np.max(np.abs(np.array(f.alphas) - of.alphas) / np.abs(of.alphas)) < 1e-10
+    assert np.max(np.abs(np.array(f.betas) - of.betas) / np.abs(of.betas)) < 1e-10
+    V = f.V.to_numpy()
+    assert np.max(np.abs(V.T @ V - np.eye(V.shape[1]))) < 1e-12

@@ -19,6 +19,7 @@ def sctx(kk):
     c = kk.Context(0)
     c.set_option("mgs_mode", 0)
     c.set_option("mgs_panel", 0)         # these tests are about k_mgs_persist (the panel kernel has its own: tests/test_gpu_panel.py)
+    c.set_option("lookahead", 0)         # call-by-call route: the launch counts below are those of one sweep per call (run-ahead: tests/test_gpu_lookahead.py)
     if c.get_option("mgs_persist") == 0:
         pytest.skip("no cooperative launch on this device: the persistent route is off anyway")
     yield c
