@@ -166,6 +166,8 @@ KK_API int kk_ctx_set_option(kk_ctx c, const char* key, double value) {
     } else if (!strcmp(key, "mgs_persist")) {
         c->mgs_persist = value != 0;
         c->persist_skip = 0;
+    } else if (!strcmp(key, "persist_coop")) {
+        c->persist_coop = value != 0;
     } else if (!strcmp(key, "lookahead")) {
         c->lookahead = value != 0;
     } else if (!strcmp(key, "mgs_panel")) {
@@ -265,6 +267,7 @@ KK_API int kk_ctx_get_option(kk_ctx c, const char* key, double* value) {
     else if (!strcmp(key, "fold_scale")) *value = c->fold_scale;
     else if (!strcmp(key, "mgs_panel")) *value = c->mgs_panel;
     else if (!strcmp(key, "lookahead")) *value = c->lookahead;
+    else if (!strcmp(key, "persist_coop")) *value = c->persist_coop;
     else if (!strcmp(key, "panel_width")) *value = c->panel_width;
     else if (!strcmp(key, "panel_min_rows")) *value = (double)c->panel_min_rows;
     else if (!strcmp(key, "panel_capacity_rows")) *value = (double)kk_mgs_panel_capacity(c);

@@ -149,6 +149,7 @@ struct kk_ctx_s {
     int panel_width = 0;         // basis vectors per grid reduction of that kernel: 0 = by vector length (3 / 2 / 1), else min(value, by length); mgs_mode 0 forces 1
     int64_t panel_min_rows = 1400000;  // auto mode: below this one grid reduction per panel (a fixed ~6 us) costs more than the second read of the basis by the projection pair (tools/panel_sweep_cost.py: 1 M rows 3.1 vs 2.6 us per vector, 2 M rows 3.6 vs 5.1)
     int mgs_persist = 1;         // strict MGS sweeps through the persistent register-resident kernel when the vector fits
+    int persist_coop = 0;        // launch the persistent kernels through hipLaunchCooperativeKernel (1) or as ordinary launches (0): see kk_launch_resident
     int persist_threads = 512;   // threads per block (= per CU) of that kernel: 1024 (<= 40 doubles of w per thread) or 512 (<= 80)
     int persist_nt = 1;          // second read of a basis vector (served by the Infinity Cache) with non-temporal loads
     int persist_sync = 0;        // granule layout of that kernel's grid reduction: 0 = one 128-byte line per block (lowest latency on an idle chip), 1 = packed (16 bytes per block: 8 x less sweep traffic)
@@ -170,7 +171,7 @@ struct kk_ctx_s {
     int fuse_passes = 1;         // fuse unproject(pass i) with project(pass i+1)
     int speculate = 1;           // enqueue the next expand's SpMV before syncing the host
     kk_basis spec_owner = nullptr;   // basis whose speculative result currently sits in SC_SPECA / its next column
-    struct { bool active = false; kk_op op = nullptr; kk_basis b = nullptr; int c0 = 0, k_next = 0; } spec_req;
+    struct { bool active = false; kk_op op = nullptr; kk_basis b = nullptr; int c0 = 0, k_next = 0, la_nsweeps = 0; } spec_req;
     hipEvent_t t0 = nullptr, t1 = nullptr;
     hipEvent_t ev_fetch2 = nullptr; // read-backs of a run-ahead BiCGStab half
     int stage_slot = 0;             // next free coefficient staging slot (stage_coef)
@@ -199,10 +200,11 @@ struct kk_basis_s {
     bool spec_valid = false;
     const void* spec_op = nullptr;
     int spec_c0 = 0, spec_k = 0, spec_dot_mode = 0;
+    const double* spec_dot_ptr = nullptr;   // device slot that received the speculative apply's inner product
     double spec_beta = 0;
     // the whole next step (apply + persistent sweep + read-back) enqueued one call ahead: valid only together with spec_valid
     bool la_valid = false;
-    int la_k = 0, la_slot = 0;
+    int la_k = 0, la_slot = 0, la_nsweeps = 0;
     double la_token = 0;
     // residual column left NORMALISED by a fused expand! (persistent kernel, w / |w| written at commit): logically the column
     // still holds r = norm_beta * stored; the next expand! of the same factorization takes it as its new basis vector without
@@ -439,6 +441,7 @@ int kk_launch_lsmr_u(kk_ctx ctx, const double* av, double* ah, double* u, int64_
 int kk_launch_lsmr_hx(kk_ctx ctx, double* h, double* hbar, double* x, const double* v, int64_t ld, double c1, double c2,
                       double c3);
 bool kk_mgs_persist_eligible(kk_ctx ctx, int64_t ld, int m, int nsweeps);
+int kk_launch_resident(kk_ctx ctx, const void* fn, int threads, void** args, size_t dyn_lds, const char* what);
 bool kk_mgs_panel_eligible(kk_ctx ctx, int64_t ld);
 int64_t kk_mgs_panel_capacity(kk_ctx ctx);
 int kk_mgs_panel_width(kk_ctx ctx, int64_t ld, bool strict);

@@ -395,9 +395,7 @@ bool kk_mgs_panel_eligible(kk_ctx ctx, int64_t ld) {
 
 template <int NV, int P>
 static int launch_panel_inst(kk_ctx ctx, void** args) {
-    hipError_t e = hipLaunchCooperativeKernel((const void*)k_mgs_panel<NV, P>, dim3(ctx->num_cus), dim3(KK_PANEL_PT), args, 0, ctx->stream);
-    if (e != hipSuccess) return kk_hip_fail(e, "hipLaunchCooperativeKernel(k_mgs_panel)", __FILE__, __LINE__);
-    return KK_OK;
+    return kk_launch_resident(ctx, (const void*)k_mgs_panel<NV, P>, KK_PANEL_PT, args, 0, "k_mgs_panel");
 }
 
 // panel width by vector length: what two register-resident panels + w leave room for (4 NV (1 + 2 P) <= ~200 registers)

@@ -89,7 +89,7 @@ KK_API int kk_arnoldi_initialize(kk_op op, kk_basis b, int c0, kk_orth_t orth, d
 // (alpha, beta), returns to the caller and re-enters.  r itself is NOT modified; the next expand
 // call normalises it in place (after this read) and skips its SpMV if (op, c0, k, beta) match.
 // Bit-identical to the non-speculative order: r*(1/beta) is formed with the same operands.
-static int speculate_next(kk_op op, kk_basis b, int c0, int k_next, int dot_mode, bool with_prev, double beta_host) {
+static int speculate_next(kk_op op, kk_basis b, int c0, int k_next, int dot_mode, bool with_prev, double beta_host, double* dot_out = nullptr) {
     kk_ctx c = b->ctx;
     b->spec_valid = false;
     if (!c->speculate || c0 + k_next + 2 > b->cap || k_next + 1 > KK_MAX_M) return KK_OK;
@@ -99,8 +99,11 @@ static int speculate_next(kk_op op, kk_basis b, int c0, int k_next, int dot_mode
     f.xscale_dev = c->persist_norm_done ? SCP(c, SC_XS) : SCP(c, SC_INVNRM);
     if (with_prev) { f.vprev = b->col(c0 + k_next - 1); f.bprev_dev = SCP(c, SC_NRM); }
     f.dot_mode = dot_mode;
-    f.dot_out = SCP(c, SC_SPECA);
+    // (where the speculative <v, w> lands: its own slot, or -- when the caller knows that every read-back of the current step
+    // is in the stream already -- directly the slot the next call's sweep reads: no device-to-device copy at the next call)
+    f.dot_out = dot_out ? dot_out : SCP(c, SC_SPECA);
     KK_TRY(kk_launch_spmv(c, op->A, b->col(c0 + k_next), b->col(c0 + k_next + 1), b->ld, f));
+    b->spec_dot_ptr = f.dot_out;
     b->spec_valid = true; b->spec_op = op; b->spec_c0 = c0; b->spec_k = k_next; b->spec_dot_mode = dot_mode;
     b->spec_beta = beta_host;
     c->spec_owner = b;
@@ -112,13 +115,14 @@ static int spec_take(kk_op op, kk_basis b, int c0, int k, int dot_mode, double b
     kk_ctx c = b->ctx;
     *hit = b->spec_valid && c->spec_owner == b && b->spec_op == op && b->spec_c0 == c0 && b->spec_k == k &&
            b->spec_dot_mode == dot_mode && b->spec_beta == beta_old;
-    if (*hit && dot_mode)
-        KK_HIP(hipMemcpyAsync(a0_slot, SCP(c, SC_SPECA), sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    if (*hit && dot_mode && b->spec_dot_ptr != a0_slot)
+        KK_HIP(hipMemcpyAsync(a0_slot, b->spec_dot_ptr, sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     return KK_OK;
 }
 // the last synchronisation of an expand: a pending speculation request (Arnoldi) is enqueued first
 // The host waits only for the read-backs queued so far (event), NOT for the speculative SpMV that
 // is enqueued behind them -- that one keeps the GPU busy during the host round trip.
+static int la_enqueue(kk_op op, kk_basis b, int c0, int j, int nsweeps, bool lanczos_carry);
 int fetch_mark(kk_ctx c) {
     KK_HIP(hipEventRecord(c->ev_fetch, c->stream));
     return KK_OK;
@@ -132,6 +136,8 @@ int final_sync(kk_ctx c) {
         c->spec_req.active = false;
         KK_TRY(fetch_mark(c));
         KK_TRY(speculate_next(c->spec_req.op, c->spec_req.b, c->spec_req.c0, c->spec_req.k_next, 0, false, 0.0));
+        if (c->spec_req.la_nsweeps > 0)   // Arnoldi with a persistent MGS / MGS2 sweep: the whole next step behind its apply (see la_enqueue)
+            KK_TRY(la_enqueue(c->spec_req.op, c->spec_req.b, c->spec_req.c0, c->spec_req.k_next, c->spec_req.la_nsweeps, false));
         return fetch_wait(c);
     }
     return stream_sync(c);
@@ -145,27 +151,27 @@ int final_sync(kk_ctx c) {
 // Same kernels, same operands, same order as the call-by-call route: bit-identical results.  Not enqueued when the step after
 // it would no longer fit the slab (c0 + j + 3 > capacity): with the usual capacity of krylovdim + 2 the run-ahead stops at the
 // last step of a Krylov cycle instead of wasting a sweep the caller will never ask for.
-static int la_enqueue(kk_op op, kk_basis b, int c0, int j) {
+static int la_enqueue(kk_op op, kk_basis b, int c0, int j, int nsweeps, bool lanczos_carry) {
     kk_ctx c = b->ctx;
     b->la_valid = false;
     const int m = j + 1;
     if (!c->lookahead || !c->fold_scale || !b->spec_valid || !c->persist_norm_done || kk_sharded(c) || c->persist_skip > 0) return KK_OK;
     if (m > KK_MAX_M || c0 + j + 3 > b->cap) return KK_OK;
-    if (!(kk_mgs_panel_eligible(c, b->ld) || kk_mgs_persist_eligible(c, b->ld, m, 1)) || kk_mgs_lowsync(c, b->ld, m)) return KK_OK;
+    if (!(kk_mgs_panel_eligible(c, b->ld) || kk_mgs_persist_eligible(c, b->ld, m, nsweeps)) || kk_mgs_lowsync(c, b->ld, m)) return KK_OK;
+    if (lanczos_carry && b->spec_dot_ptr != SCP(c, SC_ALPHA0)) return KK_OK;   // (alpha0 of step j must sit where the sweep reads it)
     const int slot = 2 + (j & 1);
-    const int64_t offs[1] = {WS_S};
-    // alpha0 of step j: from the speculative apply's slot to where the sweep (and the read-back) expect it
-    KK_HIP(hipMemcpyAsync(SCP(c, SC_ALPHA0), SCP(c, SC_SPECA), sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    const int64_t offs[2] = {WS_S, WS_G};
     c->persist_norm_req = true;
     const bool was_done = c->persist_norm_done;
-    const int st = pass_mgs_strict_sweeps(c, b->col(c0), b->ld, m, 1, b->col(c0 + j + 1), offs, true, slot, b->col(c0 + j), c->ws + WS_SCAL + SC_ALPHA0);
+    const int st = pass_mgs_strict_sweeps(c, b->col(c0), b->ld, m, nsweeps, b->col(c0 + j + 1), offs, true, slot,
+                                          lanczos_carry ? b->col(c0 + j) : nullptr, lanczos_carry ? c->ws + WS_SCAL + SC_ALPHA0 : nullptr);
     c->persist_norm_req = false;
     c->persist_norm_done = was_done;   // (describes the sweep of the CURRENT step until the caller has read it)
     KK_TRY(st);
     if (!c->persist_pending) return KK_OK;   // (took the launch-per-vector route: results are simply not used ahead)
     c->persist_pending = false;              // this launch is checked through (slot, token) by the next call
     KK_HIP(hipEventRecord(c->ev_la[slot & 1], c->stream));
-    b->la_valid = true; b->la_k = j; b->la_slot = slot; b->la_token = c->persist_token;
+    b->la_valid = true; b->la_k = j; b->la_slot = slot; b->la_token = c->persist_token; b->la_nsweeps = nsweeps;
     return KK_OK;
 }
 
@@ -198,7 +204,7 @@ KK_API int kk_lanczos_expand(kk_op op, kk_basis b, int c0, int k, kk_orth_t orth
     // the previous call may have enqueued this WHOLE step already (apply, sweep and read-back: la_enqueue below)
     const bool strict_branch = orth == KK_MGS2 && !wide && !sh_fused && !(lowsync && c0 == 0);
     const bool la_hit = b->la_valid && b->spec_valid && c->spec_owner == b && b->spec_op == op && b->spec_c0 == c0 && b->spec_k == k &&
-                        b->la_k == k && b->spec_beta == beta_old && strict_branch && v_ready;
+                        b->la_k == k && b->la_nsweeps == 1 && b->spec_beta == beta_old && strict_branch && v_ready;
     const int la_slot = b->la_slot;
     const double la_token = b->la_token;
     if (b->la_valid && !la_hit) b->spec_valid = false;   // a sweep enqueued ahead has consumed the speculative apply's output column: nothing to take over
@@ -331,8 +337,8 @@ KK_API int kk_lanczos_expand(kk_op op, kk_basis b, int c0, int k, kk_orth_t orth
                 slot = la_slot;
             }
             if (attempt == 0 && !kk_sharded(c)) {
-                KK_TRY(speculate_next(op, b, c0, k + 1, 2, true, 0.0));   // |w| and 1/|w| are on the device
-                KK_TRY(la_enqueue(op, b, c0, k + 1));                      // ... and, where it pays, the whole next step behind it
+                KK_TRY(speculate_next(op, b, c0, k + 1, 2, true, 0.0, SCP(c, SC_ALPHA0)));   // |w| and 1/|w| are on the device; alpha0 straight to its slot
+                KK_TRY(la_enqueue(op, b, c0, k + 1, 1, true));                                   // ... and, where it pays, the whole next step behind it
             }
             if (ahead) KK_HIP(hipEventSynchronize(c->ev_la[slot & 1]));
             else KK_TRY(fetch_wait(c));
@@ -382,24 +388,54 @@ KK_API int kk_arnoldi_expand(kk_op op, kk_basis b, int c0, int k, kk_orth_t orth
     double* w = b->col(c0 + k + 1);
     const bool v_ready = b->norm_col == c0 + k && b->norm_beta == beta_old;   // see kk_lanczos_expand
     if (!v_ready) KK_TRY(norm_flush(b));
-    if (b->la_valid) { b->spec_valid = false; b->la_valid = false; }   // (a Lanczos step enqueued ahead on this slab: its apply column has been swept)
-    bool hit = false;
-    KK_TRY(spec_take(op, b, c0, k, 0, beta_old, SCP(c, SC_ALPHA0), &hit));
+    const int la_sweeps = orth == KK_MGS ? 1 : (orth == KK_MGS2 ? 2 : 0);
+    const bool strict_route = la_sweeps > 0 && m <= KK_MAX_M && !kk_mgs_lowsync(c, b->ld, m) && !kk_sharded(c);
+    // the previous call may have enqueued this WHOLE step already (apply, sweeps and read-back: la_enqueue)
+    const bool la_hit = b->la_valid && b->spec_valid && c->spec_owner == b && b->spec_op == op && b->spec_c0 == c0 && b->spec_k == k &&
+                        b->spec_dot_mode == 0 && b->la_k == k && b->la_nsweeps == la_sweeps && b->spec_beta == beta_old && strict_route && v_ready;
+    const int la_slot = b->la_slot;
+    const double la_token = b->la_token;
+    if (b->la_valid && !la_hit) b->spec_valid = false;   // the sweep enqueued ahead has consumed the speculative apply's column
+    bool hit = la_hit;
+    if (!la_hit) KK_TRY(spec_take(op, b, c0, k, 0, beta_old, SCP(c, SC_ALPHA0), &hit));
     gram_touch(b, c0 + k);
-    c->persist_norm_done = false;
+    c->persist_norm_done = la_hit;
     if (v_ready) b->norm_col = -1;
     else KK_TRY(kk_launch_scal(c, v, b->ld, 1.0 / beta_old, nullptr));  // push!(V, scale(r, 1/beta))   arnoldi.jl:209
     if (!hit) {
         kk_spmv_fuse f;
         KK_TRY(kk_launch_spmv(c, op->A, v, w, b->ld, f));           // w = apply(operator, last(V))  :242
     }
+    if (la_hit) {
+        // this step is in the stream (or done): enqueue the NEXT one behind it, then collect
+        KK_TRY(speculate_next(op, b, c0, k + 1, 0, false, 0.0));
+        KK_TRY(la_enqueue(op, b, c0, k + 1, la_sweeps, false));
+        KK_HIP(hipEventSynchronize(c->ev_la[la_slot & 1]));
+        bool redo = false;
+        KK_TRY(persist_check_at(c, la_slot, la_token, &redo));
+        if (!redo) {
+            for (int j = 0; j < m; ++j) h[j] = pin(c, WS_S, la_slot)[j] + (la_sweeps > 1 ? pin(c, WS_G, la_slot)[j] : 0.0);
+            *beta = pin(c, WS_SCAL + SC_NRM2, la_slot)[1];
+            if (npasses) *npasses = la_sweeps;
+            if (b->spec_valid) b->spec_beta = *beta;
+            if (kk_persist_norm_applies(*beta)) { b->norm_col = c0 + k + 1; b->norm_beta = *beta; }
+            return KK_OK;
+        }
+        // grid-barrier timeout of the launch enqueued ahead: w = A v is untouched -- drop what was enqueued behind it and run
+        // this step's sweeps on the ordinary route (which now takes the launch-per-vector kernels)
+        b->spec_valid = false; b->la_valid = false;
+        KK_TRY(stream_sync(c));
+        c->persist_norm_done = false;
+    }
     // ask orth_run to enqueue the NEXT step's SpMV right before its final host sync (non-IR variants)
     c->spec_req.active = (orth != KK_CGSIR && orth != KK_MGSIR);
     c->spec_req.op = op; c->spec_req.b = b; c->spec_req.c0 = c0; c->spec_req.k_next = k + 1;
+    c->spec_req.la_nsweeps = strict_route ? la_sweeps : 0;
     c->persist_norm_req = c->fold_scale != 0 && (orth == KK_MGS || orth == KK_MGS2);   // one launch ends the step: it may store r / beta
     int st = orth_run(b, c0, m, w, orth, eta, h, beta, npasses, true);  // orthogonalize!! + norm      :243-244
     c->persist_norm_req = false;
     c->spec_req.active = false;
+    c->spec_req.la_nsweeps = 0;
     if (st == KK_OK && b->spec_valid) b->spec_beta = *beta;
     if (st == KK_OK && c->persist_norm_done && kk_persist_norm_applies(*beta)) { b->norm_col = c0 + k + 1; b->norm_beta = *beta; }
     return st;

@@ -94,3 +94,61 @@ def test_timeout_of_a_step_enqueued_ahead_is_recovered(kk, ko, lctx):
     assert np.max(np.abs(np.array(f.betas) - of.betas) / np.abs(of.betas)) < 1e-10
     V = f.V.to_numpy()
     assert np.max(np.abs(V.T @ V - np.eye(V.shape[1]))) < 1e-12
+
+
+@pytest.mark.parametrize("orth_name", ["mgs", "mgs2"])
+def test_arnoldi_run_ahead_bitwise_and_gmres_counts(kk, ko, lctx, orth_name):
+    """arnoldi.jl:199-245 with the next step's apply + sweeps enqueued ahead: same H bits as the call-by-call route, the
+    oracle's Hessenberg matrix, shrink! in the middle (drops the run-ahead), and linsolve(GMRES) with equal counts"""
+    dev = {"mgs": kk.ModifiedGramSchmidt(), "mgs2": kk.ModifiedGramSchmidt2()}[orth_name]
+    ref = {"mgs": ko.MGS, "mgs2": ko.MGS2}[orth_name]
+    C = ko.convection_diffusion_2d(48, 40)
+    x0 = np.random.default_rng(8).random(C.shape[0])
+    out = {}
+    for la in (1, 0):
+        lctx.set_option("lookahead", la)
+        it = kk.ArnoldiIterator(kk.SparseOperator(C, lctx), x0, dev, capacity=26)
+        f = kk.initialize(it)
+        for i in range(14):
+            f = kk.expand_(it, f)
+        f = kk.shrink_(f, 9)
+        for i in range(8):
+            f = kk.expand_(it, f)
+        out[la] = (np.array(f.H, dtype=float).copy(), f.V.to_numpy().copy(), f.r.get().copy())
+    lctx.set_option("lookahead", 1)
+    assert np.array_equal(out[1][0], out[0][0]) and np.array_equal(out[1][1], out[0][1])
+    oit = ko.ArnoldiIterator(C, x0.copy(), ref)
+    of = ko.arnoldi_initialize(oit)
+    for i in range(14):
+        of = ko.arnoldi_expand(oit, of)
+    of = ko.arnoldi_shrink(of, 9)
+    for i in range(8):
+        of = ko.arnoldi_expand(oit, of)
+    assert np.max(np.abs(out[1][0] - np.asarray(of.H))) < 1e-10 * np.max(np.abs(of.H))
+    assert np.max(np.abs(out[1][2] - of.r)) < 1e-10 * np.linalg.norm(of.r)
+    if orth_name == "mgs2":
+        b = np.random.default_rng(4).random(C.shape[0])
+        tol = 1e-10 * np.linalg.norm(b)
+        x, info = kk.linsolve(kk.SparseOperator(C, lctx), b, None, kk.GMRES(dev, 20, 25, tol), 0.1, 1.0)
+        xo, oinfo = ko.gmres(C, b, None, 0.1, 1.0, krylovdim=25, maxiter=20, tol=tol, orth=ref)
+        assert (info.converged, info.numiter, info.numops) == (oinfo.converged, oinfo.numiter, oinfo.numops)
+        assert np.linalg.norm(0.1 * x + C @ x - b) <= 1.01 * tol
+
+
+def test_arnoldi_timeout_of_a_step_enqueued_ahead(kk, ko, lctx):
+    C = ko.convection_diffusion_2d(40, 32)
+    x0 = np.random.default_rng(8).random(C.shape[0])
+    lctx.set_option("lookahead", 1)
+    it = kk.ArnoldiIterator(kk.SparseOperator(C, lctx), x0, kk.ModifiedGramSchmidt2(), capacity=22)
+    f = kk.initialize(it)
+    oit = ko.ArnoldiIterator(C, x0.copy(), ko.MGS2)
+    of = ko.arnoldi_initialize(oit)
+    for i in range(16):
+        if i in (5, 11):
+            lctx.set_option("persist_fault", 1)
+        f = kk.expand_(it, f)
+        of = ko.arnoldi_expand(oit, of)
+    assert lctx.get_option("persist_timeouts") == 2
+    assert np.max(np.abs(np.asarray(f.H) - np.asarray(of.H))) < 1e-10 * np.max(np.abs(of.H))
+    V = f.V.to_numpy()
+    assert np.max(np.abs(V.T @ V - np.eye(V.shape[1]))) < 1e-12

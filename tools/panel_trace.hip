@@ -9,6 +9,7 @@
 #include "../krylovkit.jl_amd/csrc/kk_kernels_panel.hip"
 void kk_set_error(const char* fmt, ...) { va_list a; va_start(a, fmt); vprintf(fmt, a); va_end(a); printf("\n"); }
 int kk_hip_fail(hipError_t e, const char* what, const char*, int line) { printf("HIP error %s: %s (line %d)\n", what, hipGetErrorString(e), line); return KK_ERR_HIP; }
+int kk_launch_resident(kk_ctx ctx, const void* fn, int threads, void** args, size_t dyn, const char*) { return hipLaunchCooperativeKernel(fn, dim3(ctx->num_cus), dim3(threads), args, dyn, ctx->stream) == hipSuccess ? KK_OK : KK_ERR_HIP; }
 void kk_prof_begin(kk_ctx, const char*) {}
 void kk_prof_end(kk_ctx) {}
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
