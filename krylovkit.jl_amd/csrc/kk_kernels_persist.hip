@@ -50,9 +50,9 @@ __device__ __forceinline__ double block_sum_w(double v, double* sm /* >= NW doub
 // step s; it cannot reach step s+2 before the slow one has published s+1, i.e. has finished that sweep.  Epochs are
 // unique over the life of the context (`ebase` advances from launch to launch), so the area is never cleared between
 // launches.  Returns false on a timeout.
+// first half: the block's partial, published (one write-through store by thread 0)
 template <int PT>
-__device__ __forceinline__ bool grid_sum(double acc, int step, unsigned ebase, char* __restrict__ sync, int* __restrict__ err,
-                                         double* sm, double* out, unsigned gstride /* bytes between the granules of two blocks: 128 = own line, 16 = packed */) {
+__device__ __forceinline__ void grid_publish(double acc, int step, unsigned ebase, char* __restrict__ sync, double* sm, unsigned gstride) {
     const int G = gridDim.x;
     const double v = block_sum_w<PT / 64>(acc, sm);
     const unsigned epoch = ebase + (unsigned)step + 1u;
@@ -64,6 +64,15 @@ __device__ __forceinline__ bool grid_sum(double acc, int step, unsigned ebase, c
         t.x = epoch; t.y = (unsigned)(bits >> 32); t.z = (unsigned)bits; t.w = epoch;
         __builtin_amdgcn_raw_buffer_store_b128(t, rs, set_off + blockIdx.x * gstride, 0, 16 /* sc1 */);
     }
+}
+// second half: wave 0 sweeps the partials of all blocks
+template <int PT>
+__device__ __forceinline__ bool grid_collect(int step, unsigned ebase, char* __restrict__ sync, int* __restrict__ err,
+                                             double* sm, double* out, unsigned gstride /* bytes between the granules of two blocks: 128 = own line, 16 = packed */) {
+    const int G = gridDim.x;
+    const unsigned epoch = ebase + (unsigned)step + 1u;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(sync, 0, 2 * G * KK_SYNC_LINE, 0x00020000);
+    const unsigned set_off = (unsigned)(step & 1) * (unsigned)G * KK_SYNC_LINE;
     if (threadIdx.x < 64) {   // wave 0 sweeps
         const int lane = threadIdx.x;
         const long long t0 = wall_clock64();
@@ -253,13 +262,25 @@ __global__ __launch_bounds__(PT) void k_mgs_persist(const double* __restrict__ V
         const double* qn = V + (int64_t)(s % m) * ld;
         double a0 = 0, a1 = 0, total;
         persist_step<NV, NL, NR, PT, B, NTPREV, false, true>(wr, qk, qpre, col_rsrc(qp, ld), col_rsrc(qn, ld), sp, sbytes, voff, lq, a0, a1);
-        {   // (the column after the last one wraps to column 0: a valid address, the values are not used)
-            const __amdgpu_buffer_rsrc_t r2 = col_rsrc(V + (int64_t)((s + 1) % m) * ld, ld);
+        // The first batch of the next vector goes out around the reduction: AFTER the block's partial has been
+        // published -- a CU's memory instructions leave through one in-order queue, and a publication behind 32 KB of loads
+        // reaches the fabric that much later (kk_kernels_panel.hip); the sweep then queues behind the batch, which is fine.
+        const __amdgpu_buffer_rsrc_t r2 = col_rsrc(V + (int64_t)((s + 1) % m) * ld, ld);   // (wraps to column 0 after the last one: a valid address, the values are not used)
+#ifndef KK_PERSIST_PUBFIRST
+#define KK_PERSIST_PUBFIRST 1
+#endif
+#if !KK_PERSIST_PUBFIRST
 #pragma unroll
-            for (int u = 0; u < B; ++u) qpre[u] = bload(r2, voff, (unsigned)(u < NV ? u : 0) * sbytes, false);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (!grid_sum<PT>(a0 + a1, s, ebase, sync, err, sm, &total, gstride)) return;   // timeout: w in HBM is untouched
+        for (int u = 0; u < B; ++u) qpre[u] = bload(r2, voff, (unsigned)(u < NV ? u : 0) * sbytes, false);
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        grid_publish<PT>(a0 + a1, s, ebase, sync, sm, gstride);
+#if KK_PERSIST_PUBFIRST
+#pragma unroll
+        for (int u = 0; u < B; ++u) qpre[u] = bload(r2, voff, (unsigned)(u < NV ? u : 0) * sbytes, false);
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        if (!grid_collect<PT>(s, ebase, sync, err, sm, &total, gstride)) return;   // timeout: w in HBM is untouched
         if (blockIdx.x == 0 && threadIdx.x == 0) out_s[(s / m) * out_stride + (s % m)] = total;
         sp = total;
         qp = qn;
@@ -270,7 +291,8 @@ __global__ __launch_bounds__(PT) void k_mgs_persist(const double* __restrict__ V
         double a0 = 0, a1 = 0, total;
         persist_step<NV, NL, NR, PT, B, NTPREV, true, true>(wr, qk, qpre, col_rsrc(qp, ld), col_rsrc(qp, ld), sp, sbytes, voff, lq, a0, a1);
         if (nrm_out3) {
-            if (!grid_sum<PT>(a0 + a1, nsteps, ebase, sync, err, sm, &total, gstride)) return;
+            grid_publish<PT>(a0 + a1, nsteps, ebase, sync, sm, gstride);
+            if (!grid_collect<PT>(nsteps, ebase, sync, err, sm, &total, gstride)) return;
             // every block holds the same bits of |w|^2: the normalised commit below needs no second exchange
             const double rt = sqrt(total);
             inv = 1.0 / rt;
