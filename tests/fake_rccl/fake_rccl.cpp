@@ -9,8 +9,12 @@
 // 8-GPU node ever sees it.  Semantics follow the NCCL API contract the library relies on:
 //   * collectives are matched by call order on every rank; send/recv pairs are matched per (source, destination) in
 //     FIFO order; operations inside ncclGroupStart/End are issued together and may be mutually dependent;
-//   * results are stream-ordered: here every call drains the stream, stages through host memory and is complete on
-//     return (stronger than the contract, never weaker);
+//   * results are stream-ordered.  Default mode: every call drains the stream, stages through host memory and is complete
+//     on return (stronger than the contract, never weaker).  KK_FAKE_RCCL_ASYNC=1: the call only ENQUEUES -- a copy of the
+//     send data into pinned staging, a host function on the caller's stream that waits KK_FAKE_RCCL_DELAY_US (default 300)
+//     and then does the exchange with the peers, a copy of the result to the receive buffer -- and returns at once, as RCCL
+//     does.  In that mode a host read of a "result" that is not behind a stream / event synchronisation, or a kernel on
+//     another stream that consumes it without an event, sees stale data: the class of bug the synchronous mode hides;
 //   * sum / max / min all-reduces combine the ranks in rank order 0..world-1 on every rank, so every rank receives
 //     bit-identical results (RCCL's ring / tree all-reduce gives the same guarantee).
 // Every wait is bounded (KK_FAKE_RCCL_TIMEOUT seconds, default 120): a missing peer produces ncclSystemError, not a hang.
@@ -266,6 +270,194 @@ ncclResult_t run_p2p(std::vector<p2p_op>& ops) {
 }
 }  // namespace
 
+namespace {
+// ---------------------------------------------------------------------------------------------------------------------
+// asynchronous mode (KK_FAKE_RCCL_ASYNC=1)
+// ---------------------------------------------------------------------------------------------------------------------
+bool async_mode() {
+    static bool a = [] { const char* e = getenv("KK_FAKE_RCCL_ASYNC"); return e && *e == '1' && !hostmem(); }();
+    return a;
+}
+long delay_us() {
+    static long d = [] { const char* e = getenv("KK_FAKE_RCCL_DELAY_US"); return e && *e ? atol(e) : 300L; }();
+    return d;
+}
+// pinned staging: a ring of slots, each reused only after the stream has passed the operation that used it last
+struct pin_slot { char* p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool used = false; };
+constexpr int kPinSlots = 64;
+pin_slot g_pin[kPinSlots];
+int g_pin_next = 0;
+char* pin_get(size_t bytes, int* idx) {
+    pin_slot& sl = g_pin[g_pin_next];
+    *idx = g_pin_next;
+    g_pin_next = (g_pin_next + 1) % kPinSlots;
+    if (!sl.ev && hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming) != hipSuccess) return nullptr;
+    if (sl.used && hipEventSynchronize(sl.ev) != hipSuccess) return nullptr;
+    if (sl.cap < bytes) {
+        if (sl.p) (void)hipHostFree(sl.p);
+        sl.cap = (bytes + 4095) / 4096 * 4096;
+        if (hipHostMalloc((void**)&sl.p, sl.cap, hipHostMallocDefault) != hipSuccess) { sl.p = nullptr; sl.cap = 0; return nullptr; }
+    }
+    sl.used = true;
+    return sl.p;
+}
+ncclResult_t pin_done(int idx, hipStream_t s) {
+    FK_HIP(hipEventRecord(g_pin[idx].ev, s));
+    return ncclSuccess;
+}
+
+struct seg { bool is_send; int peer; size_t bytes; size_t off; size_t done; };   // p2p segment inside the job's staging
+struct job {
+    int kind;   // 0 all-reduce, 1 all-gather, 2 reduce-scatter, 3 p2p batch
+    fake_comm* c;
+    char* sendh; char* recvh;
+    size_t count;   // elements (per rank for gather / scatter)
+    ncclDataType_t dt; ncclRedOp_t op;
+    std::vector<seg> segs;
+};
+void job_fail(fake_comm* c, const char* what) {
+    c->hdr()->aborted.store(1, std::memory_order_release);
+    fprintf(stderr, "fake_rccl(async): rank %d of %d: %s -- communicator aborted\n", c->rank, c->world, what);
+    fflush(stderr);
+}
+// the exchange itself, on host memory, run by the stream's host function
+void run_job(void* arg) {
+    job* j = (job*)arg;
+    fake_comm* c = j->c;
+    if (delay_us() > 0) usleep((useconds_t)delay_us());
+    const size_t es = dtype_size(j->dt);
+    if (j->kind == 0) {
+        const size_t per = c->slot_bytes / es;
+        for (size_t off = 0; off < j->count || (j->count == 0 && off == 0); off += per) {
+            const size_t n = j->count - off < per ? j->count - off : per;
+            if (n) memcpy(c->slot(c->rank), j->sendh + off * es, n * es);
+            if (c->barrier() != ncclSuccess) { job_fail(c, "all-reduce: a peer is missing"); break; }
+            char* out = j->recvh + off * es;
+            if (n) memcpy(out, c->slot(0), n * es);
+            for (int r = 1; r < c->world; ++r) (void)combine_any(out, c->slot(r), n, j->dt, j->op);
+            if (c->barrier() != ncclSuccess) { job_fail(c, "all-reduce: a peer is missing"); break; }
+            if (j->count == 0) break;
+        }
+    } else if (j->kind == 1) {
+        const size_t per = c->slot_bytes / es;
+        for (size_t off = 0; off < j->count || (j->count == 0 && off == 0); off += per) {
+            const size_t n = j->count - off < per ? j->count - off : per;
+            if (n) memcpy(c->slot(c->rank), j->sendh + off * es, n * es);
+            if (c->barrier() != ncclSuccess) { job_fail(c, "all-gather: a peer is missing"); break; }
+            for (int r = 0; r < c->world; ++r)
+                if (n) memcpy(j->recvh + ((size_t)r * j->count + off) * es, c->slot(r), n * es);
+            if (c->barrier() != ncclSuccess) { job_fail(c, "all-gather: a peer is missing"); break; }
+            if (j->count == 0) break;
+        }
+    } else if (j->kind == 2) {
+        const size_t per = c->slot_bytes / es / (size_t)c->world;
+        for (size_t off = 0; off < j->count || (j->count == 0 && off == 0); off += per) {
+            const size_t n = j->count - off < per ? j->count - off : per;
+            for (int q = 0; q < c->world; ++q)
+                if (n) memcpy(c->slot(c->rank) + (size_t)q * n * es, j->sendh + ((size_t)q * j->count + off) * es, n * es);
+            if (c->barrier() != ncclSuccess) { job_fail(c, "reduce-scatter: a peer is missing"); break; }
+            char* out = j->recvh + off * es;
+            if (n) memcpy(out, c->slot(0) + (size_t)c->rank * n * es, n * es);
+            for (int r = 1; r < c->world; ++r) (void)combine_any(out, c->slot(r) + (size_t)c->rank * n * es, n, j->dt, j->op);
+            if (c->barrier() != ncclSuccess) { job_fail(c, "reduce-scatter: a peer is missing"); break; }
+            if (j->count == 0) break;
+        }
+    } else {
+        // p2p batch: the progress loop of run_p2p on the staged segments (sends read sendh + off, receives fill recvh + off)
+        std::vector<seg>& ops = j->segs;
+        const double t0 = now_s();
+        size_t open = 0;
+        for (seg& o : ops) if (o.bytes) ++open;
+        int idle = 0;
+        while (open) {
+            bool progressed = false;
+            for (size_t i = 0; i < ops.size(); ++i) {
+                seg& o = ops[i];
+                if (o.done == o.bytes) continue;
+                bool first = true;
+                for (size_t k = 0; k < i && first; ++k)
+                    if (ops[k].is_send == o.is_send && ops[k].peer == o.peer && ops[k].done < ops[k].bytes) first = false;
+                if (!first) continue;
+                if (c->dead()) { open = 0; break; }
+                const size_t chunk = o.bytes - o.done < c->mbox_bytes ? o.bytes - o.done : c->mbox_bytes;
+                if (o.is_send) {
+                    mbox* m = c->mb(c->rank, o.peer);
+                    const uint64_t w = m->written.load(std::memory_order_relaxed);
+                    if (m->consumed.load(std::memory_order_acquire) != w) continue;
+                    memcpy(c->mb_data(c->rank, o.peer), j->sendh + o.off + o.done, chunk);
+                    m->chunk_bytes = chunk;
+                    m->written.store(w + 1, std::memory_order_release);
+                } else {
+                    mbox* m = c->mb(o.peer, c->rank);
+                    const uint64_t r = m->consumed.load(std::memory_order_relaxed);
+                    if (m->written.load(std::memory_order_acquire) == r) continue;
+                    if (m->chunk_bytes != chunk) { job_fail(c, "mismatched send / recv sizes"); open = 0; break; }
+                    memcpy(j->recvh + o.off + o.done, c->mb_data(o.peer, c->rank), chunk);
+                    m->consumed.store(r + 1, std::memory_order_release);
+                }
+                o.done += chunk;
+                progressed = true;
+                if (o.done == o.bytes) --open;
+            }
+            if (progressed) { idle = 0; continue; }
+            if (++idle > 200) {
+                sched_yield();
+                if ((idle & 1023) == 0 && now_s() - t0 > timeout_s()) { job_fail(c, "a send / recv never found its partner"); break; }
+            }
+        }
+    }
+    delete j;
+}
+// enqueue: stage the send data, the host function, the delivery of the result
+ncclResult_t enqueue_collective(int kind, const void* send, void* recv, size_t send_bytes, size_t recv_bytes, size_t count, ncclDataType_t dt,
+                                ncclRedOp_t op, fake_comm* c, hipStream_t s) {
+    int idx;
+    char* st = pin_get(send_bytes + recv_bytes + 64, &idx);
+    if (!st) return ncclUnhandledCudaError;
+    job* j = new job();
+    j->kind = kind; j->c = c; j->sendh = st; j->recvh = st + (send_bytes + 63) / 64 * 64; j->count = count; j->dt = dt; j->op = op;
+    if (send_bytes) FK_HIP(hipMemcpyAsync(j->sendh, send, send_bytes, hipMemcpyDeviceToHost, s));
+    FK_HIP(hipLaunchHostFunc(s, run_job, j));
+    if (recv_bytes) FK_HIP(hipMemcpyAsync(recv, j->recvh, recv_bytes, hipMemcpyHostToDevice, s));
+    return pin_done(idx, s);
+}
+ncclResult_t enqueue_p2p(std::vector<p2p_op>& ops) {
+    if (ops.empty()) return ncclSuccess;
+    size_t sb = 0, rb = 0;
+    for (p2p_op& o : ops) (o.is_send ? sb : rb) += (o.bytes + 63) / 64 * 64;
+    int idx;
+    char* st = pin_get(sb + rb + 64, &idx);
+    if (!st) return ncclUnhandledCudaError;
+    job* j = new job();
+    j->kind = 3; j->c = ops[0].comm; j->sendh = st; j->recvh = st + sb; j->count = 0; j->dt = ncclUint8; j->op = ncclSum;
+    hipStream_t s = ops[0].stream;
+    size_t so = 0, ro = 0;
+    for (p2p_op& o : ops) {
+        seg g{o.is_send, o.peer, o.bytes, o.is_send ? so : ro, 0};
+        if (o.is_send) {
+            if (o.bytes) FK_HIP(hipMemcpyAsync(j->sendh + so, o.dev, o.bytes, hipMemcpyDeviceToHost, s));
+            so += (o.bytes + 63) / 64 * 64;
+        } else {
+            ro += (o.bytes + 63) / 64 * 64;
+        }
+        j->segs.push_back(g);
+    }
+    std::vector<seg> recvs;
+    for (size_t i = 0; i < ops.size(); ++i)
+        if (!ops[i].is_send) recvs.push_back(j->segs[i]);
+    char* recvh = j->recvh;
+    FK_HIP(hipLaunchHostFunc(s, run_job, j));
+    size_t k = 0;
+    for (p2p_op& o : ops)
+        if (!o.is_send) {
+            if (o.bytes) FK_HIP(hipMemcpyAsync(o.dev, recvh + recvs[k].off, o.bytes, hipMemcpyHostToDevice, s));
+            ++k;
+        }
+    ops[0].comm->n_p2p++;
+    return pin_done(idx, s);
+}
+}  // namespace
+
 extern "C" {
 #define FK_EXPORT __attribute__((visibility("default")))
 
@@ -335,6 +527,7 @@ FK_EXPORT ncclResult_t ncclCommInitRank(ncclComm_t* out, int world, ncclUniqueId
 }
 FK_EXPORT ncclResult_t ncclCommDestroy(ncclComm_t c) {
     if (!c) return ncclInvalidArgument;
+    if (async_mode()) (void)hipDeviceSynchronize();   // (host functions still in a stream hold pointers into the mapping)
     c->hdr()->detached.fetch_add(1);
     munmap(c->base, c->total);
     delete c;
@@ -346,6 +539,7 @@ FK_EXPORT ncclResult_t ncclAllReduce(const void* send, void* recv, size_t count,
     if (!c || (count && (!send || !recv))) return ncclInvalidArgument;
     if (g_group_depth) return ncclInvalidUsage;   // collectives inside a group are not needed by libkrylov_hip
     if (tracing()) fprintf(stderr, "fake_rccl[%d]: allreduce %zu x dtype %d op %d\n", c->rank, count, (int)dt, (int)op);
+    if (async_mode()) { c->n_coll++; return enqueue_collective(0, send, recv, count * dtype_size(dt), count * dtype_size(dt), count, dt, op, c, s); }
     const size_t es = dtype_size(dt), per = c->slot_bytes / es;
     for (size_t off = 0; off < count || (count == 0 && off == 0); off += per) {
         const size_t n = count - off < per ? count - off : per;
@@ -365,6 +559,7 @@ FK_EXPORT ncclResult_t ncclAllGather(const void* send, void* recv, size_t sendco
     if (!c || (sendcount && (!send || !recv))) return ncclInvalidArgument;
     if (g_group_depth) return ncclInvalidUsage;
     if (tracing()) fprintf(stderr, "fake_rccl[%d]: allgather %zu x dtype %d\n", c->rank, sendcount, (int)dt);
+    if (async_mode()) { c->n_coll++; return enqueue_collective(1, send, recv, sendcount * dtype_size(dt), sendcount * dtype_size(dt) * c->world, sendcount, dt, ncclSum, c, s); }
     const size_t es = dtype_size(dt), per = c->slot_bytes / es;
     for (size_t off = 0; off < sendcount || (sendcount == 0 && off == 0); off += per) {
         const size_t n = sendcount - off < per ? sendcount - off : per;
@@ -388,6 +583,7 @@ FK_EXPORT ncclResult_t ncclReduceScatter(const void* send, void* recv, size_t re
     if (tracing()) fprintf(stderr, "fake_rccl[%d]: reducescatter %zu x dtype %d\n", c->rank, recvcount, (int)dt);
     const size_t es = dtype_size(dt), per = c->slot_bytes / es / (size_t)c->world;
     if (per == 0) return ncclInternalError;
+    if (async_mode()) { c->n_coll++; return enqueue_collective(2, send, recv, recvcount * es * c->world, recvcount * es, recvcount, dt, op, c, s); }
     for (size_t off = 0; off < recvcount || (recvcount == 0 && off == 0); off += per) {
         const size_t n = recvcount - off < per ? recvcount - off : per;
         // my contribution to every destination block, laid out [dest][n] in my slot
@@ -414,7 +610,7 @@ FK_EXPORT ncclResult_t ncclGroupEnd() {
     if (--g_group_depth > 0) return ncclSuccess;
     std::vector<p2p_op> ops;
     ops.swap(g_group_ops);
-    return run_p2p(ops);
+    return async_mode() ? enqueue_p2p(ops) : run_p2p(ops);
 }
 static ncclResult_t p2p(bool is_send, void* buf, size_t count, ncclDataType_t dt, int peer, ncclComm_t c, hipStream_t s) {
     if (!c || peer < 0 || peer >= c->world || (count && !buf)) return ncclInvalidArgument;
@@ -426,7 +622,7 @@ static ncclResult_t p2p(bool is_send, void* buf, size_t count, ncclDataType_t dt
     }
     std::vector<p2p_op> one;
     one.push_back(std::move(o));
-    return run_p2p(one);
+    return async_mode() ? enqueue_p2p(one) : run_p2p(one);
 }
 FK_EXPORT ncclResult_t ncclSend(const void* buf, size_t count, ncclDataType_t dt, int peer, ncclComm_t c, hipStream_t s) {
     return p2p(true, const_cast<void*>(buf), count, dt, peer, c, s);

@@ -30,8 +30,9 @@ def _env(tmp_path):
     return env
 
 
-def run_world(scenario, world, tmp_path, timeout=600):
+def run_world(scenario, world, tmp_path, timeout=600, extra_env=None):
     env = _env(tmp_path)
+    env.update(extra_env or {})
     procs = [subprocess.Popen([sys.executable, str(HERE / "world2_worker.py"), scenario, str(r), str(world), str(tmp_path)],
                               env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = []
@@ -98,6 +99,16 @@ def test_world2_collective_create_rejects_bad_input_on_all_ranks(tmp_path):
     """kk_csr_create_sharded agrees on the local validation status before its first data collective"""
     reps = run_world("bad_input", 2, tmp_path, timeout=200)
     assert reps[0]["status"] == reps[1]["status"] != 0
+
+
+@pytest.mark.parametrize("scenario,world", [("lanczos_grid", 2), ("lanczos_random", 3), ("gkl", 2), ("block", 2), ("solvers", 2), ("solvers2", 2)])
+def test_world_asynchronous_collectives(tmp_path, scenario, world):
+    """The same scenarios with the stand-in in its ASYNCHRONOUS mode (KK_FAKE_RCCL_ASYNC=1): every nccl* call only enqueues
+    -- staging copy, a host function on the stream that sleeps 300 us before it talks to the peers, delivery copy -- and
+    returns at once, as RCCL does.  A host read of a collective's result that is not behind a synchronisation, or a missing
+    stream dependency, now reads stale data and fails the oracle comparison inside the workers."""
+    reps = run_world(scenario, world, tmp_path, extra_env={"KK_FAKE_RCCL_ASYNC": "1", "KK_FAKE_RCCL_DELAY_US": "300"})
+    assert all(r["stats"]["allreduce"] > 0 for r in reps)
 
 
 @pytest.mark.parametrize("config,extra", [("lanczos", []), ("lanczos", ["--scaling", "strong"]), ("gkl", []), ("block", [])])
