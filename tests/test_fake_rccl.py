@@ -52,3 +52,24 @@ sys.exit(0 if lib.ncclCommInitRank(C.byref(comm), 2, uid, 0) == 2 else 1)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=60)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "only 1 of 2 ranks attached" in r.stderr
+
+
+@pytest.mark.gpu
+def test_fake_rccl_async_mode_really_is_asynchronous(tmp_path):
+    """KK_FAKE_RCCL_ASYNC=1 on cuda:0, two ranks, 0.4 s artificial delay: the call returns at once, the receive buffer still
+    holds its old contents when read through another stream, the bit-identical result is there after the stream sync"""
+    _build()
+    env = dict(os.environ, KK_FAKE_RCCL_ASYNC="1", KK_FAKE_RCCL_DELAY_US="400000", KK_FAKE_RCCL_TIMEOUT="60", KK_FAKE_RCCL_DIR=str(tmp_path))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = [subprocess.Popen([sys.executable, str(HERE / "fake_rccl_async_worker.py"), str(r), "2", str(tmp_path)],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=180)[0])
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"rank {r} OK" in o, o
