@@ -360,6 +360,9 @@ def main():
     ap.add_argument("--parity-seeds", type=int, default=3, help="start vectors of the full-size parity block (each costs one CPU sweep)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-strict-leg", action="store_true")
+    ap.add_argument("--no-sharded-leg", action="store_true",
+                    help="config lanczos, N = 1: skip the `sharded_world1` leg (the same sweep on a row-sharded context of world size 1 with real RCCL "
+                         "collectives issued: the like-for-like single-GPU base of the N > 1 lines)")
     ap.add_argument("--no-configs", action="store_true",
                     help="config lanczos, N = 1: skip the `configs` block (BASELINE.json configs[2..4] at full size + the general-format leg of configs[1])")
     ap.add_argument("--config-steps", type=int, default=3, help="timed sweeps per entry of the `configs` block")
@@ -850,6 +853,29 @@ def main():
                           "note": "bytes the kernels of one sweep really move (counter traffic per launch where profiles/traffic.json is current, the "
                                   "byte models of DESIGN.md section 3 otherwise) over the wall time of the sweep"}
 
+    # ---------------- `sharded_world1`: the sweep as every N > 1 rank runs it (row-sharded context, RCCL collectives issued by the
+    # library, low-synchronisation MGS2) on this ONE GPU, in a child process with KK_BENCH_FORCE_DIST=1
+    sharded_leg = None
+    if (args.config == "lanczos" and world == 1 and not use_dist and not args.no_sharded_leg and args.ny == NY
+            and not os.environ.get("KK_BENCH_FORCE_DIST")):
+        import subprocess
+        cmd = [sys.executable, str(Path(__file__).resolve()), "--gpus", "1", "--steps", "3", "--warmup", "1", "--orth", args.orth,
+               "--no-cpu-baseline", "--no-configs", "--no-strict-leg", "--no-sharded-leg"]
+        try:
+            r_ = subprocess.run(cmd, env=dict(os.environ, KK_BENCH_FORCE_DIST="1"), capture_output=True, text=True, timeout=300)
+            ln_ = [l for l in r_.stdout.splitlines() if l.startswith("{")]
+            if r_.returncode == 0 and ln_:
+                d_ = json.loads(ln_[-1])
+                sharded_leg = {"value": d_["value"], "unit": "it/s", "ms_per_step": d_["ms_per_step"], "collectives": d_.get("collectives"),
+                               "roofline": {k: d_["roofline"].get(k) for k in ("kernel", "achieved", "frac", "avg_launch_ms")} if d_.get("roofline") else None,
+                               "note": "world size 1 with the collectives forced: 2 ncclAllReduce + the (self-served) ghost exchange per iteration are really "
+                                       "issued; mgs_mode auto = the low-synchronisation form, as on every N > 1 rank.  Efficiency of an N-GPU weak-scaling "
+                                       "line = its value / (N x this value)"}
+            else:
+                sharded_leg = {"error": (r_.stderr or r_.stdout)[-400:]}
+        except Exception as e_:   # the leg must never cost the line
+            sharded_leg = {"error": repr(e_)[:400]}
+
     # ---------------- `configs` block: BASELINE.json configs[2..4] at full size + the general-format leg of configs[1], one GPU
     configs = None
     if args.config == "lanczos" and world == 1 and not use_dist and not args.no_configs and args.ny == NY:
@@ -890,6 +916,8 @@ def main():
             "algorithmic_equiv_frac_of_peak_per_gpu": round(alg_sweep * K / elapsed / 1e9 / (HBM_PEAK_GBPS * world), 4),
             "roofline": roofline,
         }
+        if sharded_leg:
+            out["sharded_world1"] = sharded_leg
         if configs:
             out["configs"] = configs
         if args.config != "block":
