@@ -18,6 +18,14 @@
 #include "kk_internal.h"
 #include "kk_device.h"
 
+// First read of a basis vector (as q_next): non-temporal for the grid-rows that will wait on chip (LDS / spare registers) and
+// are therefore never read again, cache-allocating only for the rows that ARE read a second time one step later.  With every
+// row allocated (round 3) a CU's 39 rows x 8 KB x 32 CUs = 10 MB per vector washed through each XCD's 4 MB L2 and the second
+// read went out to the fabric; with only the 12 re-read rows allocated (3 MB per XCD) the second read is an L2 hit:
+// 1084 -> 1244 it/s on the headline sweep (0: nothing non-temporal 1084, 2: everything 1087).
+#ifndef KK_PERSIST_NT_FIRST
+#define KK_PERSIST_NT_FIRST 1
+#endif
 #define KK_PERSIST_TIMEOUT_TICKS 300000000ll   // 3 s of the 100 MHz wall clock
 #define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
@@ -178,7 +186,9 @@ __device__ __forceinline__ void persist_step(d2 (&wr)[NV], d2 (&qk)[NR > 0 ? NR 
                 if (PREV_LDS && i0 + u < NL) p[u] = lq[(i0 + u) * PT];
                 else if (PREV_LDS && i0 + u < NL + NR) p[u] = qk[i0 + u - NL];
                 else p[u] = bload(rp, voff, (unsigned)(i0 + u) * sbytes, NTPREV);
-                if (!NORM) q[u] = (i0 == 0) ? qpre[u] : bload(rn, voff, (unsigned)(i0 + u) * sbytes, false);   // batch 0 was requested before the grid reduction
+                // first read of the next vector: rows that will wait on chip are never read again -> non-temporal for them
+                // (KK_PERSIST_NT_FIRST: 0 none, 1 the parked rows, 2 every row)
+                if (!NORM) q[u] = (i0 == 0) ? qpre[u] : bload(rn, voff, (unsigned)(i0 + u) * sbytes, KK_PERSIST_NT_FIRST == 2 || (KK_PERSIST_NT_FIRST == 1 && i0 + u < NL + NR));   // batch 0 was requested before the grid reduction
             }
         }
 #pragma unroll
@@ -271,13 +281,13 @@ __global__ __launch_bounds__(PT) void k_mgs_persist(const double* __restrict__ V
 #endif
 #if !KK_PERSIST_PUBFIRST
 #pragma unroll
-        for (int u = 0; u < B; ++u) qpre[u] = bload(r2, voff, (unsigned)(u < NV ? u : 0) * sbytes, false);
+        for (int u = 0; u < B; ++u) qpre[u] = bload(r2, voff, (unsigned)(u < NV ? u : 0) * sbytes, KK_PERSIST_NT_FIRST == 2 || (KK_PERSIST_NT_FIRST == 1 && u < NL + NR));
         __builtin_amdgcn_sched_barrier(0);
 #endif
         grid_publish<PT>(a0 + a1, s, ebase, sync, sm, gstride);
 #if KK_PERSIST_PUBFIRST
 #pragma unroll
-        for (int u = 0; u < B; ++u) qpre[u] = bload(r2, voff, (unsigned)(u < NV ? u : 0) * sbytes, false);
+        for (int u = 0; u < B; ++u) qpre[u] = bload(r2, voff, (unsigned)(u < NV ? u : 0) * sbytes, KK_PERSIST_NT_FIRST == 2 || (KK_PERSIST_NT_FIRST == 1 && u < NL + NR));
         __builtin_amdgcn_sched_barrier(0);
 #endif
         if (!grid_collect<PT>(s, ebase, sync, err, sm, &total, gstride)) return;   // timeout: w in HBM is untouched
