@@ -532,7 +532,7 @@ def main():
         """workload of one entry of the `configs` block -> dict(sweep, units, model bytes per sweep and class, algorithmic bytes
         per sweep, meta[, kmult, cleanup]); also what `--only-leg` runs under rocprofv3 for profiles/traffic_configs.json"""
         if name == "lanczos_ell":
-            reread_ = 12.0 / 39.0 if prob["n_local"] == NX * NY else 0.0
+            reread_ = 11.0 / 39.0 if prob["n_local"] == NX * NY else 0.0
             # configs[1] again with the operator applied the general way: ELL gather kernel on the SparseMatrixCSC's entries, no
             # stencil recognition (neither the value-free constant-coefficient form nor the stored diagonals)
             ctx.set_option("spmv_dia", 0)
@@ -739,7 +739,7 @@ def main():
                 ld_rows += 512
             rows = -(-ld_rows // (ncu * pt * 2))                                # grid-rows of double2 per thread
             lds_rows = min(rows, (160 * 1024 - 256) // (pt * 16)) if ctx.get_option("persist_lds") >= 1 else 0
-            reg_rows = min(rows - lds_rows, 8) if (ctx.get_option("persist_lds") >= 2 and pt == 512) else 0
+            reg_rows = min(rows - lds_rows, 9) if (ctx.get_option("persist_lds") >= 2 and pt == 512) else 0
             reread = (rows - lds_rows - reg_rows) / rows
             scale_n = n / launches_per_sweep                                   # sweeps in the timed region
             alg = sum((16 * m + 24) * n_local for m in range(2, KRYLOVDIM + 1)) * scale_n

@@ -386,7 +386,8 @@ static int launch_persist_inst(kk_ctx ctx, void** args) {
 // grid-rows of the current basis vector kept in spare registers on top of the LDS-parked ones: only where the work vector
 // leaves room (512 threads: 256 registers per lane, w takes 4 NV of them) -- KK_PERSIST_NR picks the count at build time
 #ifndef KK_PERSIST_NR
-#define KK_PERSIST_NR 8
+#define KK_PERSIST_NR 9   // (A/B on the headline sweep, B = 4: NR 0 / 4 / 6 / 8 / 9 -> 976 / 1094 / 1186 / 1240 / 1259 it/s: the rows that are NOT parked
+                         // must fit the XCD's L2 next to everything else -- 12 of them still do, 14 no longer)
 #endif
 
 template <int NV, int PT>
