@@ -532,13 +532,12 @@ def main():
         """workload of one entry of the `configs` block -> dict(sweep, units, model bytes per sweep and class, algorithmic bytes
         per sweep, meta[, kmult, cleanup]); also what `--only-leg` runs under rocprofv3 for profiles/traffic_configs.json"""
         if name == "lanczos_ell":
-            reread_ = 11.0 / 39.0 if prob["n_local"] == NX * NY else 0.0
             # configs[1] again with the operator applied the general way: ELL gather kernel on the SparseMatrixCSC's entries, no
             # stencil recognition (neither the value-free constant-coefficient form nor the stored diagonals)
             ctx.set_option("spmv_dia", 0)
             return dict(sweep=prob["sweep"], units=KRYLOVDIM - 1, cleanup=lambda: ctx.set_option("spmv_dia", 1),
                         model={"k_spmv_ell": 84.0 * prob["n_local"] * KRYLOVDIM, "k_scal": 16.0 * prob["n_local"] * 3,
-                               "k_mgs_persist": float(sum((8 * m * (1 + reread_) + 24) * prob["n_local"] for m in range(2, KRYLOVDIM + 1)))},
+                               "k_mgs_persist": float(sum((8 * m + 24) * prob["n_local"] for m in range(2, KRYLOVDIM + 1)))},
                         alg=algorithmic_bytes_sweep(prob["n_global"], KRYLOVDIM),
                         meta={"metric": "lanczos_iterations_per_second", "unit": "it/s",
                               "workload": "configs[1] with the library's stencil recognition OFF (option spmv_dia = 0): the general SparseMatrixCSC path, "
@@ -727,7 +726,7 @@ def main():
             # w -= s q, the pending "w -= alpha v" in front, |w| behind, w / |w| stored).  What the launch really moves: w read and
             # written once (it lives in registers in between), every basis vector once, plus the grid-rows of it that do not
             # fit on chip (LDS + spare registers) between the inner product and the update a second time:
-            #   model(m) = (8 m (1 + reread) + 24) N.       `frac` is PHYSICAL: counter traffic (stamped PMC pass) or this model
+            #   model(m) = (8 m + 24) N  (+ 8 m reread N when the second read misses the L2).  `frac` is PHYSICAL: counter traffic (stamped PMC pass) or this model
             # over the event-timed duration.  The contract figure of SURVEY 8(d), pass(m) = (16 m + 24) N -- every basis vector
             # read twice -- is what the projection-based kernels move and is carried as algorithmic_equiv_*; the least a strict
             # sweep with w on chip could move is (8 m + 16) N (min_bytes, frac_of_min).
@@ -743,14 +742,18 @@ def main():
             reread = (rows - lds_rows - reg_rows) / rows
             scale_n = n / launches_per_sweep                                   # sweeps in the timed region
             alg = sum((16 * m + 24) * n_local for m in range(2, KRYLOVDIM + 1)) * scale_n
-            model = sum((8 * m * (1 + reread) + 24) * n_local for m in range(2, KRYLOVDIM + 1)) * scale_n
+            # (round 4: the rows that are read a second time are the only ones the first read leaves cache-allocated -- 11 rows x 8 KB x
+            # 32 CUs = 2.8 MB per XCD -- so that second read is an L2 hit and does not reach the fabric: the model counts every
+            # basis vector once; the counters decide)
+            model = sum((8 * m + 24) * n_local for m in range(2, KRYLOVDIM + 1)) * scale_n
             least = sum((8 * m + 16) * n_local for m in range(2, KRYLOVDIM + 1)) * scale_n
             tj, traffic_note = stamped_traffic("traffic.json")
             per_launch = (tj or {}).get(dom)
             roofline = physical_roofline(dom, ms * 1e-3, n, None if per_launch is None else per_launch * n, model, alg, least, traffic_note)
             cap_rows = int(ctx.get_option("persist_capacity_rows"))
             roofline["on_chip_parking"] = {"grid_rows_per_thread": int(rows), "parked_in_lds": int(lds_rows), "parked_in_registers": int(reg_rows),
-                                           "second_read_fraction": round(reread, 4)}
+                                           "second_read_fraction": round(reread, 4),
+                                           "second_read_served_by": "the XCD's L2 (only these rows are cache-allocated by the first read; the parked rows are loaded non-temporally)"}
             roofline["persist"] = {"eligible": True, "rows": int(ld_rows), "capacity_rows": cap_rows, "rows_per_thread": int(2 * rows),
                                    "used_fraction_of_capacity": round(ld_rows / cap_rows, 4),
                                    "beyond_capacity": "a work vector longer than capacity_rows does not fit the register file of the chip: mgs_mode auto then runs the "
