@@ -33,6 +33,8 @@
 //         (the sweeps of 256 blocks are fabric traffic, and their latency hides here);
 //       - workgroup barriers are raw s_barrier (+ lgkmcnt(0)): a __syncthreads() makes hipcc drain the panel loads in flight
 //         (vmcnt(0)) before every barrier.
+//       - wider panels do not pay at 8 rows per thread: P = 3 (w + two panels = 224 registers of 256) 3.98 us per vector at 2 M
+//         rows against 3.70 for P = 2.
 //     What remains per panel is one pipeline fill (~1.5 us) plus the hand-off: 3.6 us per vector at 2 M rows (P = 2) against
 //     5.1 for the projection pair and for k_mgs_persist, 2.4 for the bare stream.
 #include "kk_internal.h"
