@@ -856,7 +856,21 @@ int kk_launch_blk_panel_correct(kk_ctx ctx, const double* P, int st, int kn, int
 }
 int kk_launch_blk_resid_gram(kk_ctx ctx, const double* P, const double* Pc, int st, int kn, int p, const double* GYY,
                              const double* nrm2, double* GW) {
-    hipLaunchKernelGGL(k_blk_resid_gram, dim3(1), dim3(KK_TPB), (size_t)2 * kn * st * sizeof(double), ctx->stream, P, Pc, st, kn, p, GYY, nrm2, GW);
+    // both panels in dynamic LDS: 2 kn st doubles (64 KB at kn = 256, st = 16) next to the static 16 x 17 tile -- beyond the
+    // 64 KB a kernel gets without asking.  The opt-in is a per-device attribute of the function
+    const size_t dyn = (size_t)2 * kn * st * sizeof(double);
+    if (dyn + 4096 > 160 * 1024) {
+        kk_set_error("kk_launch_blk_resid_gram: panels of %d x %d do not fit the LDS", kn, st);
+        return KK_ERR_UNSUPPORTED;
+    }
+    static bool configured[KK_MAX_DEVICES] = {};
+    const int dev = ctx->device;
+    if (dyn > 48 * 1024 && (dev < 0 || dev >= KK_MAX_DEVICES || !configured[dev])) {
+        KK_HIP(hipSetDevice(ctx->device));
+        KK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_blk_resid_gram), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+        if (dev >= 0 && dev < KK_MAX_DEVICES) configured[dev] = true;
+    }
+    hipLaunchKernelGGL(k_blk_resid_gram, dim3(1), dim3(KK_TPB), dyn, ctx->stream, P, Pc, st, kn, p, GYY, nrm2, GW);
     KK_HIP(hipGetLastError());
     return KK_OK;
 }
