@@ -201,7 +201,7 @@ def cfg2_cpu_reference():
 def test_config2_lanczos_10M_parity_more_start_vectors(kk, ctx, seed):
     """The headline parity figure (Ritz values of the 100 x 100 T, 1e-10 relative) is the rounding noise of the smallest Ritz
     value amplified by |T| / theta_min ~ 2e4: one start vector is thin evidence, so two more (the bench line carries the
-    maximum over its own three).  Low-sync MGS2 = the timed configuration."""
+    maximum over its own three).  MGS2 in the library's default mode = the timed configuration (strict order, persistent kernel)."""
     import cpu_ref_lib as cr
     from bench import laplacian_rows, NX, NY
     N, K = NX * NY, 100
@@ -256,6 +256,35 @@ def test_config2_lanczos_10M_parity_with_cpu_reference(kk, ctx, cfg2_cpu_referen
     assert np.max(np.abs(be_g - be_c) / np.abs(be_c)) <= 1e-10
     th_g, th_c = _tri_eigs(al_g, be_g), _tri_eigs(al_c, be_c)
     assert np.max(np.abs(th_g - th_c) / np.abs(th_c)) <= 1e-10
+    V.free(); x0b.free(); op.free()
+
+
+@pytest.mark.parametrize("ny,expect_persist", [(2600, True), (2650, False)])
+def test_lanczos_parity_on_both_sides_of_the_register_file_limit(kk, ctx, ny, expect_persist):
+    """The register-resident strict-MGS kernel holds work vectors of at most 10.48 M rows (`persist_capacity_rows`); the
+    headline vector uses 95 % of that.  4000 x 2600 = 10.4 M rows still runs it, 4000 x 2650 = 10.6 M rows takes the
+    low-synchronisation pair in auto mode (the line's `mgs2_lowsync` leg): both must match the CPU reference path
+    (lanczos.jl:250-338) to 1e-10 over 40 steps, and each must run the kernels it is supposed to."""
+    import cpu_ref_lib as cr
+    from bench import laplacian_rows, NX
+    N, K = NX * ny, 41
+    assert (N <= ctx.get_option("persist_capacity_rows")) == expect_persist
+    A = laplacian_rows(NX, ny, 0, ny)
+    op = kk.SparseOperator(A, ctx, symmetric=True, via_csc=True)
+    x0b = kk.DeviceBasis(N, 1, ctx)
+    x0b[0].rand_(17)
+    V = kk.DeviceBasis(N, K + 2, ctx)
+    it = kk.LanczosIterator(op, x0b[0], kk.ModifiedGramSchmidt2(), capacity=K + 2)
+    ctx.prof_reset(); ctx.prof_enable(1)
+    f = kk.initialize(it, V)
+    for _ in range(K - 1):
+        f = kk.expand_(it, f)
+    ctx.prof_enable(0)
+    assert (ctx.prof_get("k_mgs_persist")[1] > 0) == expect_persist and (ctx.prof_get("k_project")[1] > 0) == (not expect_persist)
+    al_g, be_g = np.array(f.alphas), np.array(f.betas)
+    al_c, be_c, _, _ = cr.run_lanczos(cr.load(), A, x0b[0].get(), K - 1, 3, nthreads=cr.usable_threads())
+    assert np.max(np.abs(al_g - al_c) / np.abs(al_c)) <= 1e-10 and np.max(np.abs(be_g - be_c) / np.abs(be_c)) <= 1e-10
+    assert _gram_offdiag_max(kk, f.V, K) < 1e-12
     V.free(); x0b.free(); op.free()
 
 
