@@ -224,6 +224,11 @@ KK_API int kk_ctx_set_option(kk_ctx c, const char* key, double value) {
     } else if (!strcmp(key, "gram2_chunk")) {
         KK_CHECK(value == 64 || value == 80 || value == 128, KK_ERR_INVALID, "gram2_chunk must be 64, 80 or 128");
         c->gram2_chunk = (int)value;
+    } else if (!strcmp(key, "gram2_pipe")) {
+        c->gram2_pipe = value != 0;
+    } else if (!strcmp(key, "gram2_bpc")) {
+        KK_CHECK(value >= 0 && value <= 8, KK_ERR_INVALID, "gram2_bpc must be in 0..8");
+        c->gram2_bpc = (int)value;
     } else if (!strcmp(key, "gram_bpc")) {
         KK_CHECK(value >= 2 && value <= 16, KK_ERR_INVALID, "gram_bpc must be in 2..16");
         c->gram_bpc = (int)value;
@@ -283,6 +288,8 @@ KK_API int kk_ctx_get_option(kk_ctx c, const char* key, double* value) {
     else if (!strcmp(key, "spmm_cols")) *value = c->spmm_cols;
     else if (!strcmp(key, "spmm_rpl")) *value = c->spmm_rpl;
     else if (!strcmp(key, "gram_bpc")) *value = c->gram_bpc;
+    else if (!strcmp(key, "gram2_pipe")) *value = c->gram2_pipe;
+    else if (!strcmp(key, "gram2_bpc")) *value = c->gram2_bpc;
     else if (!strcmp(key, "gram2_chunk")) *value = c->gram2_chunk;
     else if (!strcmp(key, "qr_skip_tol")) *value = c->qr_skip_tol;
     else if (!strcmp(key, "resid_gram")) *value = c->resid_gram;

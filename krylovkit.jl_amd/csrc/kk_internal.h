@@ -135,6 +135,8 @@ struct kk_ctx_s {
     double qr_skip_tol = 2e-14;  // async block step: skip the second CholQR2 back-substitution when |Q1'Q1 - I|_max <= this (0: never)
     double last_qr_dev = 0;      // |Q1'Q1 - I|_max of the last asynchronous block step (diagnostics)
     int gram2_chunk = 80;        // two-panel Gram kernel (one-pass block step): basis columns per launch (64, 80 or 128)
+    int gram2_pipe = 1;          // two-panel Gram kernel: software-pipelined form (k_block_gram2p), NG <= 5
+    int gram2_bpc = 0;           // its blocks per CU (0 = what the occupancy query reports)
     int gram_bpc = 8;            // Gram panel: blocks per CU of a one-group (p <= 16) launch; NG groups -> gram_bpc / NG, >= 2
     int block_fuse = 5;          // async block step, bit mask: 1 = CholQR2 round 2 fused (update + Gram in one pass), 2 = three-term
                                  // update folded into the re-orthogonalisation panel, 4 = one-pass projection against the whole basis

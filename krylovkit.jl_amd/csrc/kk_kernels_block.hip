@@ -175,6 +175,158 @@ __global__ __launch_bounds__(KK_TPB) void k_block_gram2(const double* __restrict
     }
 }
 
+// Software-pipelined form of k_block_gram2 (round 4).  The kernel above issues the loads of a 32-row chunk, waits, and then
+// feeds the matrix pipe for (16 NG + 8) x 64 cycles before it can request the next chunk: with two waves per SIMD (228 VGPRs)
+// memory time and MFMA time ADD (NG = 3 at 10M rows: 0.73 ms of stream + 0.46 ms of MFMA = the measured 1.19 ms).  Here every
+// wave keeps two chunks in registers (ping-pong, unified 512-register file at one or two waves per SIMD) and requests chunk
+// i+1 before the first MFMA of chunk i, so a single wave overlaps its own stream with its own matrix work.  Lanes whose column
+// lies outside the panel read a clamped (valid) column instead of zeros: an A-operand column only reaches its own row of the
+// C tile, a B-operand column only its own column, and the finalize kernels write i < p, j < q only.
+template <int NG>
+struct g2_chunk {
+    d2 x[NG][BG_T / 2];
+    d2 y[BG_T / 2], z[BG_T / 2];
+};
+typedef unsigned v4u_blk __attribute__((ext_vector_type(4)));
+#ifndef KK_G2P_AUX
+#define KK_G2P_AUX 0                // cache policy of the panel streams: plain (non-temporal = 2 measured slower: the two 64-byte halves of a line arrive in different instructions)
+#endif
+// 16-byte load through a buffer descriptor: the address is descriptor base + lane offset (32 bit) + scalar offset + an
+// immediate -- no 64-bit address registers per stream -- and, being an opaque intrinsic, it stays where it is written
+// relative to the compiler barrier that follows every request (a plain load of a `const __restrict__` argument is free to
+// sink to its first use, which is exactly what un-pipelines the loop: seen in the ISA of the first version)
+template <int IMM>
+__device__ __forceinline__ d2 g2_bload(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    const v4u_blk t = __builtin_amdgcn_raw_buffer_load_b128(r, voff + IMM, soff, KK_G2P_AUX);
+    d2 o;
+    o.x = __longlong_as_double((long long)(((unsigned long long)t.y << 32) | t.x));
+    o.y = __longlong_as_double((long long)(((unsigned long long)t.w << 32) | t.z));
+    return o;
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t g2_rsrc(const double* p, int64_t bytes) {
+    const unsigned long long a = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    const int nb = __builtin_amdgcn_readfirstlane((int)bytes);
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, nb, 0x00020000);
+}
+template <int NG>
+struct g2_streams {
+    __amdgpu_buffer_rsrc_t x[NG], y, z;
+    unsigned vx[NG], vy, vz;     // lane part of the byte offset: clamped column * ld * 8 + 16 kq
+};
+// GXL: the ride-along block Y2 is the LAST group of this X panel -- its tile is x[NG-1], nothing extra is read
+template <int NG, bool GXL>
+__device__ __forceinline__ void g2_request(g2_chunk<NG>& T, const g2_streams<NG>& S, unsigned soff) {
+    T.y[0] = g2_bload<0>(S.y, S.vy, soff); T.y[1] = g2_bload<64>(S.y, S.vy, soff);
+    T.y[2] = g2_bload<128>(S.y, S.vy, soff); T.y[3] = g2_bload<192>(S.y, S.vy, soff);
+    if (!GXL) {
+        T.z[0] = g2_bload<0>(S.z, S.vz, soff); T.z[1] = g2_bload<64>(S.z, S.vz, soff);
+        T.z[2] = g2_bload<128>(S.z, S.vz, soff); T.z[3] = g2_bload<192>(S.z, S.vz, soff);
+    }
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        T.x[g][0] = g2_bload<0>(S.x[g], S.vx[g], soff); T.x[g][1] = g2_bload<64>(S.x[g], S.vx[g], soff);
+        T.x[g][2] = g2_bload<128>(S.x[g], S.vx[g], soff); T.x[g][3] = g2_bload<192>(S.x[g], S.vx[g], soff);
+    }
+    asm volatile("" ::: "memory");
+}
+template <int NG, bool P3, bool GXL>
+__device__ __forceinline__ void g2_consume(const g2_chunk<NG>& T, v4d (&acc)[NG], v4d (&acc2)[NG], v4d& acc3) {
+    if (P3) {
+#pragma unroll
+        for (int t = 0; t < BG_T / 2; ++t) {
+            acc3 = __builtin_amdgcn_mfma_f64_16x16x4f64(T.y[t].x, T.y[t].x, acc3, 0, 0, 0);
+            acc3 = __builtin_amdgcn_mfma_f64_16x16x4f64(T.y[t].y, T.y[t].y, acc3, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+#pragma unroll
+        for (int t = 0; t < BG_T / 2; ++t) {
+            const d2 xv = T.x[g][t];
+            const d2 zv = GXL ? T.x[NG - 1][t] : T.z[t];
+            acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(xv.x, T.y[t].x, acc[g], 0, 0, 0);
+            acc2[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(xv.x, zv.x, acc2[g], 0, 0, 0);
+            acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(xv.y, T.y[t].y, acc[g], 0, 0, 0);
+            acc2[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(xv.y, zv.y, acc2[g], 0, 0, 0);
+        }
+    }
+    asm volatile("" ::: "memory");
+}
+// requires 16 * ldx * 8 < 2^31 (one descriptor spans a 16-column group); the launcher checks
+template <int NG, bool P3, bool GXL>
+__global__ __launch_bounds__(KK_TPB) void k_block_gram2p(const double* __restrict__ X, int64_t ldx, int p,
+                                                         const double* __restrict__ Y, int64_t ldy, int q,
+                                                         const double* __restrict__ Y2, int64_t ldy2, int q2, int64_t ld,
+                                                         int64_t rpb, double* __restrict__ part, double* __restrict__ part2,
+                                                         double* __restrict__ part3) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];  // [NG][4][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, kq = lane >> 4;
+    const int64_t r0 = (int64_t)blockIdx.x * rpb, r1 = imin(r0 + rpb, ld);
+    v4d acc[NG], acc2[NG], acc3 = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int g = 0; g < NG; ++g) { acc[g] = v4d{0.0, 0.0, 0.0, 0.0}; acc2[g] = v4d{0.0, 0.0, 0.0, 0.0}; }
+    // one descriptor per 16-column group, columns clamped into the panel (see above); rows beyond ld read as zero
+    g2_streams<NG> S;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int ncol = imin(16, p - g * 16) > 0 ? imin(16, p - g * 16) : 1;
+        const int g0 = imin(g * 16, p - 1);
+        S.x[g] = g2_rsrc(X + (int64_t)g0 * ldx, ((int64_t)(ncol - 1) * ldx + ld) * 8);
+        S.vx[g] = (unsigned)((int64_t)imin(c, ncol - 1) * ldx * 8) + kq * 16;
+    }
+    S.y = g2_rsrc(Y, ((int64_t)(q - 1) * ldy + ld) * 8);
+    S.vy = (unsigned)((int64_t)imin(c, q - 1) * ldy * 8) + kq * 16;
+    S.z = g2_rsrc(Y2, ((int64_t)(q2 - 1) * ldy2 + ld) * 8);
+    S.vz = (unsigned)((int64_t)imin(c, q2 - 1) * ldy2 * 8) + kq * 16;
+    // rpb and ld are multiples of KK_SUB = 512 rows = 4 chunks per wave: every wave has an even number of chunks, so the loop
+    // below is branch-free between a request and its use
+    const unsigned step = 4 * BG_CHUNK * 8;                       // bytes between two chunks of one wave
+    const int nch = (int)((r1 - r0) / (4 * BG_CHUNK));
+    unsigned so = (unsigned)__builtin_amdgcn_readfirstlane((int)((r0 + wave * BG_CHUNK) * 8));
+    g2_chunk<NG> A, B;
+    if (nch > 0) g2_request<NG, GXL>(A, S, so);
+    for (int i = 0; i < nch; i += 2) {
+        g2_request<NG, GXL>(B, S, so + step);
+        g2_consume<NG, P3, GXL>(A, acc, acc2, acc3);
+        g2_request<NG, GXL>(A, S, i + 2 < nch ? so + 2 * step : so);   // past the end: a harmless re-read
+        g2_consume<NG, P3, GXL>(B, acc, acc2, acc3);
+        so += 2 * step;
+    }
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int w = 0; w < 4; ++w) {
+            if (wave == w) {
+#pragma unroll
+                for (int g = 0; g < NG; ++g)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        double* a = &lds[(g * 4 + r) * 64 + lane];
+                        const double v = pass ? acc2[g][r] : acc[g][r];
+                        *a = (w == 0) ? v : (*a + v);
+                    }
+            }
+            __syncthreads();
+        }
+        double* dst = (pass ? part2 : part) + (int64_t)blockIdx.x * (NG * 256);
+        for (int e = tid; e < NG * 256; e += KK_TPB) dst[e] = lds[e];
+        __syncthreads();
+    }
+    if (P3) {
+        for (int w = 0; w < 4; ++w) {
+            if (wave == w) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    double* a = &lds[r * 64 + lane];
+                    *a = (w == 0) ? acc3[r] : (*a + acc3[r]);
+                }
+            }
+            __syncthreads();
+        }
+        part3[(int64_t)blockIdx.x * 256 + tid] = lds[tid];
+    }
+}
+
 // Gram panel against a tile that is COMPUTED on the fly instead of read:
 //     T(rows, q) = beta * Yin + alpha * Z(rows, nz) S(nz, q)            C = X' T
 //   * three-term update + re-orthogonalisation panel of block_lanczosrecurrence in one pass (blocklanczos.jl:253-260 then
@@ -987,24 +1139,49 @@ int kk_launch_block_gram2(kk_ctx ctx, const double* X, int64_t ldx, int p, const
     const int NG = ng <= 4 ? ng : (ng == 5 ? 5 : 8);   // 48-column chunks (kn = 96, 112) run three groups, not four with one empty
     int nblk;
     int64_t rpb;
-    // NG >= 5: two blocks per CU fit (VGPRs); the partial tiles double (+ one tile per block for Y'Y), which bounds the grid
-    gram_grid(ctx, ld, NG == 5 ? 8 : (NG == 3 ? 4 : NG), NG >= 5 ? 2 : (NG >= 3 ? 3 : 8), &nblk, &rpb);
-    if ((2 * (int64_t)NG + 1) * nblk * 256 > (int64_t)(2 * KK_MAX_M + 8) * KK_MAX_BLOCKS) { kk_set_error("kk_launch_block_gram2: partial buffer too small"); return KK_ERR_INVALID; }
-    const size_t shm = (size_t)NG * 256 * sizeof(double);
-    double* part = ctx->partials;
-    double* part2 = part + (int64_t)nblk * NG * 256;
-    double* part3 = C3_dev ? part2 + (int64_t)nblk * NG * 256 : nullptr;
     // ride-along block = a whole group of X?  (same leading dimension, starts on a 16-column boundary of this launch, 16 wide)
     int gx = -1;
     if (ldy2 == ldx && q2 == 16 && Y2 >= X) {
         const int64_t off = Y2 - X;
         if (off % ldx == 0 && (off / ldx) % 16 == 0 && off / ldx + 16 <= p) gx = (int)(off / ldx / 16);
     }
+    const size_t shm = (size_t)NG * 256 * sizeof(double);
+    // the pipelined kernel addresses every 16-column group through one 32-bit buffer descriptor
+    const int64_t lim = (int64_t)1 << 31;
+    const bool pipe = ctx->gram2_pipe && NG <= 5 && (15 * ldx + ld) * 8 < lim && ((int64_t)(q - 1) * ldy + ld) * 8 < lim &&
+                      ((int64_t)(q2 - 1) * ldy2 + ld) * 8 < lim && ld % KK_SUB == 0;
+    const bool gxl = pipe && gx == NG - 1 && p == NG * 16;   // the pipelined kernel aliases the ride-along tile only in the common last-group case
+    if (pipe) {
+        // the pipelined kernel runs as ONE resident wave of blocks: as many per CU as its register budget admits
+        // resident blocks per CU of the instantiation (one 256-thread block = one wave per SIMD; register counts of the
+        // gfx950 build: NG = 1: 92-136, 2: 144-184, 3: 196-236, 4: 244-292, 5: 300-344 of the 512 per SIMD lane)
+        const int o = NG == 1 ? 3 : (NG <= 3 ? 2 : (NG == 4 && gxl ? 2 : 1));
+        int bpc = ctx->gram2_bpc > 0 ? ctx->gram2_bpc : o;
+        const int64_t nsub = ld / KK_SUB;
+        int64_t maxb = (int64_t)bpc * ctx->num_cus;
+        if (maxb > KK_MAX_BLOCKS) maxb = KK_MAX_BLOCKS;
+        const int64_t spb = std::max<int64_t>(1, (nsub + maxb - 1) / maxb);
+        rpb = spb * KK_SUB;
+        nblk = (int)std::max<int64_t>(1, (nsub + spb - 1) / spb);
+    } else {
+        // NG >= 5: two blocks per CU fit (VGPRs); the partial tiles double (+ one tile per block for Y'Y), which bounds the grid
+        gram_grid(ctx, ld, NG == 5 ? 8 : (NG == 3 ? 4 : NG), NG >= 5 ? 2 : (NG >= 3 ? 3 : 8), &nblk, &rpb);
+    }
+    if ((2 * (int64_t)NG + 1) * nblk * 256 > (int64_t)(2 * KK_MAX_M + 8) * KK_MAX_BLOCKS) { kk_set_error("kk_launch_block_gram2: partial buffer too small"); return KK_ERR_INVALID; }
+    double* part = ctx->partials;
+    double* part2 = part + (int64_t)nblk * NG * 256;
+    double* part3 = C3_dev ? part2 + (int64_t)nblk * NG * 256 : nullptr;
     {
         kk_prof_scope ps(ctx, "k_block_gram");
         dim3 g(nblk), b(KK_TPB);
 #define BG2_ARGS X, ldx, p, Y, ldy, q, Y2, ldy2, q2, gx, ld, rpb, part, part2, part3
-        switch (NG) {
+#define G2P_ARGS X, ldx, p, Y, ldy, q, Y2, ldy2, q2, ld, rpb, part, part2, part3
+#define G2P_CASE(N) case N: if (part3) { if (gxl) hipLaunchKernelGGL((k_block_gram2p<N, true, true>), g, b, shm, ctx->stream, G2P_ARGS); \
+                                         else hipLaunchKernelGGL((k_block_gram2p<N, true, false>), g, b, shm, ctx->stream, G2P_ARGS); } \
+                            else { if (gxl) hipLaunchKernelGGL((k_block_gram2p<N, false, true>), g, b, shm, ctx->stream, G2P_ARGS); \
+                                   else hipLaunchKernelGGL((k_block_gram2p<N, false, false>), g, b, shm, ctx->stream, G2P_ARGS); } break;
+        if (pipe) switch (NG) { G2P_CASE(1) G2P_CASE(2) G2P_CASE(3) G2P_CASE(4) default: G2P_CASE(5) }
+        else switch (NG) {
             case 1: hipLaunchKernelGGL((k_block_gram2<1>), g, b, shm, ctx->stream, BG2_ARGS); break;
             case 2: hipLaunchKernelGGL((k_block_gram2<2>), g, b, shm, ctx->stream, BG2_ARGS); break;
             case 3: hipLaunchKernelGGL((k_block_gram2<3>), g, b, shm, ctx->stream, BG2_ARGS); break;
@@ -1012,6 +1189,8 @@ int kk_launch_block_gram2(kk_ctx ctx, const double* X, int64_t ldx, int p, const
             case 5: hipLaunchKernelGGL((k_block_gram2<5>), g, b, shm, ctx->stream, BG2_ARGS); break;
             default: hipLaunchKernelGGL((k_block_gram2<8>), g, b, shm, ctx->stream, BG2_ARGS); break;
         }
+#undef G2P_CASE
+#undef G2P_ARGS
 #undef BG2_ARGS
     }
     KK_HIP(hipGetLastError());

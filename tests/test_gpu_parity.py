@@ -1398,3 +1398,32 @@ def test_constant_coefficient_stencil_needs_neither_indices_nor_values(kk, ko, c
     for _ in range(25):
         of = ko.lanczos_expand(oit, of)
     assert relerr(runs[0][0], of.alphas) < 1e-10 and relerr(runs[0][1], of.betas) < 1e-10
+
+
+@pytest.mark.parametrize("bs", [3, 16])
+def test_blocklanczos_pipelined_two_panel_gram_kernel(kk, ko, ctx, bs):
+    """k_block_gram2p (software-pipelined form of the two-panel Gram kernel of the one-pass block step: buffer-descriptor
+    loads, clamped columns instead of zero fill, ride-along tile aliased to the last X group) against the plain kernel: same
+    H to rounding over enough steps to visit every instantiation (1..5 groups per launch, with and without the alias)."""
+    nx, ny = 64, 40
+    n = nx * ny
+    A = ko.laplacian_2d(nx, ny, shift_diag=10 * np.linspace(0, 1, n) ** 2)
+    rng = np.random.default_rng(90 + bs)
+    x0 = [rng.random(n) for _ in range(bs)]
+    steps = 7
+    ctx.set_option("block_async", 1)
+    ctx.set_option("block_fuse", 5)
+    Hs = {}
+    for pipe in (0, 1):
+        ctx.set_option("gram2_pipe", pipe)
+        it = kk.BlockLanczosIterator(kk.SparseOperator(A, ctx, symmetric=True), x0, (steps + 2) * bs)
+        f = it.initialize()
+        for _ in range(steps):
+            f = it.expand(f)
+            assert f.R_size == bs and not f.last_drift
+        k = len(f)
+        V = f.V.to_numpy()
+        assert np.max(np.abs(V.T @ V - np.eye(k))) < 1e-12
+        Hs[pipe] = f.H[:k, :k].copy()
+    ctx.set_option("gram2_pipe", 1)
+    assert np.max(np.abs(Hs[0] - Hs[1])) < 1e-12 * np.max(np.abs(Hs[0]))
