@@ -1,6 +1,7 @@
 // libkrylov_hip.so, C ABI part 6: block (multi-vector) operations and the BlockLanczos steps
 // (src/factorizations/blocklanczos.jl).
 #include "kk_host.h"
+#include <cstring>
 
 // ------------------------------------------------------------------------------------------
 // BlockLanczos (src/factorizations/blocklanczos.jl)
@@ -322,19 +323,30 @@ KK_API int kk_blocklanczos_initialize(kk_op op, kk_basis b, int c_x0, int bs0, i
     return KK_OK;
 }
 
+// settle a pending normalised commit: W = T R1 into the residual area (kk_host.h norm_flush calls this from every entry
+// point that lets a caller see or change the slab)
+int blk_commit_flush(kk_basis b) {
+    if (!b || !b->tc_valid) return KK_OK;
+    b->tc_valid = false;
+    if (b->ctx->tc_owner == b->uid) b->ctx->tc_owner = 0;
+    const int p = b->tc_p;
+    return block_update_run(b->ctx, b->col(b->tc_k), b->ld, p, b->col(b->tc_cr), b->ld, p, b->tc_R1, p, 1.0, 0.0, nullptr);
+}
+
 // device-side layout of the asynchronous block step inside the second half of the block scratch (doubles)
 #define AB_BASE (KK_BLK_SCRATCH / 2 + 64)
 #define AB_FLAG (AB_BASE)            // [4]   0 = fine, 1 / 2 = a CholQR2 safety test failed
 #define AB_NRM (AB_BASE + 4)         // [16]  squared column norms of the new residual block
 #define AB_B (AB_BASE + 20)          // [256] B = R2 R1, column-major ld 16
 #define AB_M (AB_BASE + 276)         // [256] M = X' A X, column-major ld 16
-#define AB_READBACK 532              // flag + norms + B + M travel to the host in ONE copy
-#define AB_G (AB_BASE + 532)         // [256] Gram panels of the two CholQR2 rounds
-#define AB_R1 (AB_BASE + 788)        // [256]
-#define AB_S1 (AB_BASE + 1044)       // [256] staged R1^-1
-#define AB_S2 (AB_BASE + 1300)       // [256] staged R2^-1
-#define AB_S3 (AB_BASE + 1556)       // [512] three-term panel [B' ; M]
-#define AB_P (AB_BASE + 2068)        // [3 * KK_MAX_M * 16] re-orthogonalisation panel V'(AX), row-major; the one-pass step appends
+#define AB_CF (AB_BASE + 532)        // [4]   commit flag of the step: 0 = the update wrote T = W R1^-1 (k_blk_commit_prep), else the plain block
+#define AB_R1 (AB_BASE + 536)        // [256] first CholQR2 factor: of this step (k_blk_chol1) until k_blk_chol2 has read it, then of the NEXT step's commit
+#define AB_READBACK 792              // flag + norms + B + M + commit flag + R1 travel to the host in ONE copy
+#define AB_G (AB_BASE + 792)         // [256] Gram panels of the two CholQR2 rounds
+#define AB_S1 (AB_BASE + 1048)       // [256] staged R1^-1
+#define AB_S2 (AB_BASE + 1304)       // [256] staged R2^-1
+#define AB_S3 (AB_BASE + 1560)       // [512] three-term panel [B' ; M]
+#define AB_P (AB_BASE + 2072)        // [3 * KK_MAX_M * 16] re-orthogonalisation panel V'(AX), row-major; the one-pass step appends
                                      // the ride-along Gram panel V'X and the corrected panel (kn * st doubles each)
 #define AB_GYY (AB_P + 3 * KK_MAX_M * 16)   // [256] (A X)'(A X), column-major ld 16 (one-pass step)
 #define AB_GW (AB_GYY + 256)                // [256] Gram matrix of the residual block left behind, column-major ld p
@@ -347,7 +359,7 @@ static_assert(AB_END <= KK_BLK_SCRATCH, "block scratch too small for the asynchr
 // ONE host synchronisation at the end returns B, M, the column norms and the safety flag.  The input block (c_r) and the
 // basis are not modified, so a raised flag (*fine = false) simply sends the caller to the synchronous route below.
 static int blocklanczos_expand_async(kk_op op, kk_basis b, int k, int p, int c_r, int c_rnext, double qr_tol, double* B,
-                                     int ldb, double* M, int ldm, double* norm_R, bool* fine, bool use_gw) {
+                                     int ldb, double* M, int ldm, double* norm_R, bool* fine, bool use_gw, bool take_tc, int* qr_state) {
     kk_ctx c = b->ctx;
     const int64_t ld = b->ld;
     const int st = kk_bu_stride(p);
@@ -355,19 +367,26 @@ static int blocklanczos_expand_async(kk_op op, kk_basis b, int k, int p, int c_r
     const int kn = k + p;
     KK_CHECK(kn <= KK_MAX_M, KK_ERR_UNSUPPORTED, "block step: %d basis vectors exceed the panel limit", kn);
     const bool onepass = (c->block_fuse & 4) != 0;
+    bool try_tc = false;
     if (onepass) {   // Gram rows of the basis columns [0, k): known from the previous steps, recomputed after a restart
         if (b->gram_c0 != 0) { b->gram_c0 = 0; b->gram_rows = 0; }
         KK_TRY(gram_device(b));
         if (b->gram_rows < k) KK_TRY(gram_ensure(b, k));
     }
     KK_HIP(hipMemsetAsync(D + AB_FLAG, 0, 4 * sizeof(double), c->stream));
+    if (!take_tc) c->tc_owner = 0;   // this step rewrites the scratch a pending commit of another slab would need
     // ---- block_qr! as CholQR2, out of place: residual block (c_r) -> new basis block (columns k..k+p-1)
-    if (use_gw) {   // the previous step left the Gram matrix of this very block behind (all-reduced already)
+    if (take_tc) {
+        // normalised commit of the previous step: columns k..k+p-1 hold T = W R1^-1 already, AB_R1 its factor and AB_G the
+        // (not yet all-reduced) Gram matrix T'T -- the first CholQR2 round costs nothing here
+    } else if (use_gw) {   // the previous step left the Gram matrix of this very block behind (all-reduced already)
         KK_HIP(hipMemcpyAsync(D + AB_G, D + AB_GW, (size_t)p * p * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     } else {
         KK_TRY(kk_launch_block_gram(c, b->col(c_r), ld, p, b->col(c_r), ld, p, ld, D + AB_G, p));
         KK_TRY(kk_allreduce(c, D + AB_G, (int64_t)p * p));
     }
+    if (take_tc) {
+    } else {
     KK_TRY(kk_launch_blk_chol1(c, D + AB_G, p, 1000.0 * qr_tol, D + AB_R1, D + AB_S1, st, D + AB_FLAG));
     if (c->block_fuse & 1) {   // Q1 = B R1^-1 written and G2 = Q1'Q1 accumulated in ONE pass over the block
         KK_TRY(kk_launch_block_gram_tile(c, nullptr, 0, p, nullptr, 0, b->col(c_r), ld, p, D + AB_S1, st, 1.0, 0.0, b->col(k), ld, p,
@@ -375,6 +394,7 @@ static int blocklanczos_expand_async(kk_op op, kk_basis b, int k, int p, int c_r
     } else {
         KK_TRY(kk_launch_block_update(c, b->col(c_r), ld, p, nullptr, b->col(k), ld, ld, p, D + AB_S1, 1.0, 0.0, nullptr));
         KK_TRY(kk_launch_block_gram(c, b->col(k), ld, p, b->col(k), ld, p, ld, D + AB_G, p));
+    }
     }
     KK_TRY(kk_allreduce(c, D + AB_G, (int64_t)p * p));
     KK_TRY(kk_launch_blk_chol2(c, D + AB_G, p, D + AB_R1, D + AB_B, 16, D + AB_S2, D + AB_S3, st, D + AB_FLAG));
@@ -409,7 +429,20 @@ static int blocklanczos_expand_async(kk_op op, kk_basis b, int k, int p, int c_r
         KK_TRY(kk_launch_blk_gram_rows(c, G2, st, k, p, b->d_gram, b->cap));
         KK_TRY(kk_launch_blk_panel_m(c, P, st, k, p, D + AB_M, 16));
         KK_TRY(kk_launch_blk_panel_correct(c, P, st, kn, p, b->d_gram, b->cap, Pc));
-        KK_TRY(kk_launch_block_update(c, b->col(0), ld, kn, AX, AX, ld, ld, p, Pc, -1.0, 1.0, D + AB_NRM));
+        // normalised commit: the next basis slot must be free (it is not on the last step before a restart) and the
+        // panels small enough for the update kernel's LDS
+        try_tc = c->block_commit && want_gw && kn + p <= std::min(c_r, c_rnext) && kn + p <= b->cap &&
+                 ((size_t)kn * st + 64 + st * st + 4 * 16 * 34) * sizeof(double) <= 64 * 1024;
+        if (try_tc) {
+            // first CholQR2 factor of the NEXT step from the predicted Gram matrix (AX)'(AX) - P'Pc, then the update writes
+            // T = W R1^-1 into columns kn.. and accumulates T'T (AB_G); the residual area keeps A X
+            KK_TRY(kk_launch_blk_resid_gram(c, P, Pc, st, kn, p, D + AB_GYY, nullptr, D + AB_GW));
+            KK_TRY(kk_launch_blk_commit_prep(c, D + AB_GW, D + AB_GYY, p, 1000.0 * qr_tol, 1e-3, D + AB_R1, D + AB_S1, st, D + AB_CF));
+            KK_TRY(kk_launch_block_update_commit(c, b->col(0), ld, kn, AX, AX, ld, b->col(kn), ld, p, Pc, D + AB_NRM, D + AB_CF, D + AB_S1,
+                                                 D + AB_G));
+        } else {
+            KK_TRY(kk_launch_block_update(c, b->col(0), ld, kn, AX, AX, ld, ld, p, Pc, -1.0, 1.0, D + AB_NRM));
+        }
         KK_TRY(kk_launch_blk_onepass_check(c, P, st, kn, p, D + AB_NRM, 0.1, D + AB_FLAG));
         if (want_gw) KK_TRY(kk_launch_blk_resid_gram(c, P, Pc, st, kn, p, D + AB_GYY, D + AB_NRM, D + AB_GW));
         KK_HIP(hipMemcpyAsync(c->h_blk + (G2 - D), G2, (size_t)kn * st * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -441,8 +474,15 @@ readback:
     const double* H = c->h_blk + AB_BASE;
     c->last_qr_dev = H[2];
     *fine = (H[0] == 0.0);
+    // where the block in columns k.. stands if this step has to be repeated: 0 = T (second round not applied), 1 = Q = T R2^-1
+    if (qr_state) *qr_state = (H[0] == 2.0 || H[1] != 0.0) ? 0 : 1;
     if (!*fine) return KK_OK;
-    if (onepass && c->resid_gram) {   // the residual block in c_rnext now has its Gram matrix in AB_GW
+    if (take_tc) c->block_commits++;
+    if (try_tc && H[AB_CF - AB_BASE] == 0.0) {   // committed: columns kn.. hold T, the residual area still holds A X
+        b->tc_valid = true; b->tc_k = kn; b->tc_cr = c_rnext; b->tc_p = p;
+        memcpy(b->tc_R1, H + (AB_R1 - AB_BASE), (size_t)p * p * sizeof(double));
+        c->tc_owner = b->uid;
+    } else if (onepass && c->resid_gram) {   // the residual block in c_rnext now has its Gram matrix in AB_GW
         c->gw_valid = true; c->gw_basis = b->uid; c->gw_col = c_rnext; c->gw_p = p;
     }
     if (onepass) {   // host mirror of the new Gram rows (strictly-lower storage), as the device kernel wrote them
@@ -465,6 +505,14 @@ readback:
 KK_API int kk_blocklanczos_expand(kk_op op, kk_basis b, int k, int bs_r, int c_r, int c_rnext, double qr_tol,
                                       int* bs_next, double* B, int ldb, double* M, int ldm, double* norm_R, int* is_drift) {
     KK_TRY(check_square_op(op, b));
+    // a pending normalised commit of exactly this residual block is consumed here; anything else settles it first (CHECK_*)
+    bool take_tc = false;
+    if (b && b->tc_valid) {
+        kk_ctx cc = b->ctx;
+        take_tc = cc->tc_owner == b->uid && b->tc_k == k && b->tc_cr == c_r && b->tc_p == bs_r && cc->block_mode == 1 && cc->block_async &&
+                  (cc->block_fuse & 4) && cc->block_commit && bs_r >= 2 && bs_r <= 16 && k + bs_r <= KK_MAX_M;
+        if (take_tc) b->tc_valid = false;
+    }
     CHECK_BLOCK(b, 0, k + bs_r); CHECK_BLOCK(b, c_r, bs_r); CHECK_BLOCK(b, c_rnext, bs_r);
     KK_CHECK(k >= bs_r && bs_r >= 1 && bs_next && B && M && norm_R && ldb >= bs_r && ldm >= bs_r, KK_ERR_INVALID,
              "kk_blocklanczos_expand: bad arguments");
@@ -481,12 +529,25 @@ KK_API int kk_blocklanczos_expand(kk_op op, kk_basis b, int k, int bs_r, int c_r
         if (kk_bu_stride(bs_r) > bs_r)   // pad columns of the row-major panels: zero once, the kernels write only the first bs_r
             KK_HIP(hipMemsetAsync(c->blk + AB_P, 0, (size_t)((c->block_fuse & 4) ? 3 : 1) * (k + bs_r) * kk_bu_stride(bs_r) * sizeof(double),
                                   c->stream));   // one-pass mode keeps three panels (P, G2, Pc) back to back
-        KK_TRY(blocklanczos_expand_async(op, b, k, bs_r, c_r, c_rnext, qr_tol, B, ldb, M, ldm, norm_R, &fine, use_gw));
+        int qr_state = 0;
+        KK_TRY(blocklanczos_expand_async(op, b, k, bs_r, c_r, c_rnext, qr_tol, B, ldb, M, ldm, norm_R, &fine, use_gw, take_tc, &qr_state));
         if (fine) {
             *bs_next = bs_r;
             if (is_drift) *is_drift = 0;
             return KK_OK;
         }   // else: a pivot came close to the rank / DGKS thresholds -- the faithful route decides (inputs untouched)
+        if (take_tc) {
+            // ... except that after a normalised commit the input block exists only as T (or Q = T R2^-1) in columns k..:
+            // W = T R1 = Q (R2 R1) goes back into its residual area first (B holds R2 R1 when the second round was applied)
+            std::vector<double> X((size_t)bs_r * bs_r);
+            for (int j = 0; j < bs_r; ++j)
+                for (int i = 0; i < bs_r; ++i) X[i + (size_t)bs_r * j] = qr_state ? c->h_blk[AB_B + i + 16 * j] : b->tc_R1[i + (size_t)bs_r * j];
+            KK_TRY(block_update_run(c, b->col(k), b->ld, bs_r, b->col(c_r), b->ld, bs_r, X.data(), bs_r, 1.0, 0.0, nullptr));
+            take_tc = false;
+        }
+    } else if (take_tc) {   // (cannot happen: take_tc implies the asynchronous route)
+        b->tc_valid = true;
+        KK_TRY(blk_commit_flush(b));
     }
     std::vector<int> good(bs_r);
     int ng = 0, drift = 0;

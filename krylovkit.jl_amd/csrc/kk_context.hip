@@ -215,6 +215,8 @@ KK_API int kk_ctx_set_option(kk_ctx c, const char* key, double value) {
     } else if (!strcmp(key, "spmm_rpl")) {
         KK_CHECK(value == 1 || value == 2, KK_ERR_INVALID, "spmm_rpl must be 1 or 2");
         c->spmm_rpl = (int)value;
+    } else if (!strcmp(key, "block_commit")) {
+        c->block_commit = value != 0;
     } else if (!strcmp(key, "resid_gram")) {
         c->resid_gram = value != 0;
         c->gw_valid = false;
@@ -293,6 +295,8 @@ KK_API int kk_ctx_get_option(kk_ctx c, const char* key, double* value) {
     else if (!strcmp(key, "gram2_chunk")) *value = c->gram2_chunk;
     else if (!strcmp(key, "qr_skip_tol")) *value = c->qr_skip_tol;
     else if (!strcmp(key, "resid_gram")) *value = c->resid_gram;
+    else if (!strcmp(key, "block_commit")) *value = c->block_commit;
+    else if (!strcmp(key, "block_commits")) *value = (double)c->block_commits;
     else if (!strcmp(key, "last_qr_dev")) *value = c->last_qr_dev;
     else if (!strcmp(key, "gram_nt")) *value = c->gram_nt;
     else {

@@ -41,8 +41,11 @@ static inline void gram_touch(kk_basis b, int col) {
 // kernel's commit, SURVEY a7: the scale!!(r, 1/beta) of factorizations/lanczos.jl:257 / arnoldi.jl:209 costs no pass of its
 // own) and notes (column, beta) on the slab.  The next expand! of the same factorization takes the column as its new basis
 // vector; anything else that looks at the slab first gets r = beta * column back (residual(F), shrink!, restarts).
+int blk_commit_flush(kk_basis b);   // kk_block.hip: W = T R1 into the residual area of a pending block commit
 static inline int norm_flush(kk_basis b) {
-    if (!b || b->norm_col < 0) return KK_OK;
+    if (!b) return KK_OK;
+    if (b->tc_valid) KK_TRY(blk_commit_flush(b));
+    if (b->norm_col < 0) return KK_OK;
     const int col = b->norm_col;
     b->norm_col = -1;
     gram_touch(b, col);   // (also drops a speculative apply formed from the normalised bits)

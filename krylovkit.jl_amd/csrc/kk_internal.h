@@ -132,6 +132,9 @@ struct kk_ctx_s {
     uint64_t gw_basis = 0;   // uid of the slab
     int gw_col = -1, gw_p = 0;
     int resid_gram = 1;          // use it (0: always run the Gram pass)
+    int block_commit = 1;        // one-pass block step: residual update writes T = W R1^-1 into the next basis slot (normalised commit)
+    uint64_t tc_owner = 0;       // uid of the slab whose pending commit (R1, G2 = T'T) sits in the block scratch; 0 = none
+    int64_t block_commits = 0;   // commits consumed by a following expand! (diagnostics)
     double qr_skip_tol = 2e-14;  // async block step: skip the second CholQR2 back-substitution when |Q1'Q1 - I|_max <= this (0: never)
     double last_qr_dev = 0;      // |Q1'Q1 - I|_max of the last asynchronous block step (diagnostics)
     int gram2_chunk = 80;        // two-panel Gram kernel (one-pass block step): basis columns per launch (64, 80 or 128)
@@ -213,6 +216,11 @@ struct kk_basis_s {
     // the scale pass, every other access multiplies it back first (norm_flush)
     int norm_col = -1;
     double norm_beta = 0;
+    // pending normalised commit of a residual BLOCK (one-pass BlockLanczos step): columns [tc_k, tc_k + tc_p) hold
+    // T = W R1^-1, the residual area at tc_cr still holds A X; W = T R1 is formed on demand (blk_commit_flush, kk_host.h)
+    bool tc_valid = false;
+    int tc_k = -1, tc_cr = -1, tc_p = 0;
+    double tc_R1[256];   // column-major, leading dimension tc_p
     inline double* col(int c) const { return d + (int64_t)c * ld; }
 };
 
@@ -391,6 +399,11 @@ int kk_launch_block_gram2(kk_ctx ctx, const double* X, int64_t ldx, int p, const
                           int64_t ldy2, int q2, int64_t ld, double* C_dev, int rs, double* C2_dev, int rs2, double* C3_dev = nullptr);
 int kk_launch_blk_resid_gram(kk_ctx ctx, const double* P, const double* Pc, int st, int kn, int p, const double* GYY,
                              const double* nrm2, double* GW);
+int kk_launch_blk_commit_prep(kk_ctx ctx, const double* GWE, const double* GYY, int p, double abs_min, double keep, double* R1, double* S1,
+                              int st, double* cflag);
+int kk_launch_block_update_commit(kk_ctx ctx, const double* V, int64_t ld, int m, const double* Win, double* Wout, int64_t ldw, double* Tout,
+                                  int64_t ldt, int nb, const double* S_dev, double* norms2_dev, const double* cflag_dev,
+                                  const double* S1_dev, double* G2_dev);
 int kk_launch_blk_gram_rows(kk_ctx ctx, const double* G2, int st, int k, int p, double* gram, int cap);
 int kk_launch_blk_panel_correct(kk_ctx ctx, const double* P, int st, int kn, int p, const double* gram, int cap, double* Pc);
 int kk_launch_blk_panel_m(kk_ctx ctx, const double* P, int st, int k, int p, double* M, int ldm);

@@ -602,9 +602,11 @@ __global__ __launch_bounds__(64) void k_blk_chol2(const double* __restrict__ G2,
     wave_sync();
     double dev = 0.0;
     for (int t = 0; t < 64; ++t) dev = fmax(dev, devs[t]);   // every lane: the same value
-    if (flag[0] != 0.0) return;   // first factor already failed
+    // every failure also raises flag[1]: the back-substitution that follows must not touch the block (after a normalised
+    // commit it is the only copy of the residual block, T = W R1^-1, and the step is repeated from it)
+    if (flag[0] != 0.0) { if (threadIdx.x == 0) flag[1] = 1.0; return; }   // first factor already failed
     if (threadIdx.x == 0) flag[2] = dev;   // |Q1'Q1 - I|_max of this step (diagnostics)
-    if (!(dev < 1e-3)) { if (threadIdx.x == 0) flag[0] = 2.0; return; }
+    if (!(dev < 1e-3)) { if (threadIdx.x == 0) { flag[0] = 2.0; flag[1] = 1.0; } return; }
     if (dev <= skip_tol) {
         // Q1 = W R1^-1 is orthonormal to skip_tol already (a well-conditioned block: cond(W)^2 eps): the second round would
         // be the identity up to that level.  B = R1, the back-substitution panel is the identity and flag[1] tells the
@@ -621,7 +623,7 @@ __global__ __launch_bounds__(64) void k_blk_chol2(const double* __restrict__ G2,
         return;
     }
     const bool ok = chol16(G2, p, R, 1e-2, 0.0);
-    if (!ok) { if (threadIdx.x == 0) flag[0] = 2.0; return; }
+    if (!ok) { if (threadIdx.x == 0) { flag[0] = 2.0; flag[1] = 1.0; } return; }
     triu_inv16(R, p, Ri);
     for (int e = threadIdx.x; e < p * p; e += 64) {   // B = R2 R1 (upper triangular)
         const int i = e % p, j = e / p;
@@ -716,7 +718,32 @@ __global__ __launch_bounds__(KK_TPB) void k_blk_resid_gram(const double* __restr
         for (int l = 0; l < kn; ++l) a = fma(ps[l * st + i], pcs[l * st + j], a);
     g[i][j] = (i < p && j < p) ? GYY[i + 16 * j] - a : 0.0;
     __syncthreads();
-    if (i < p && j < p) GW[i + p * j] = (i == j) ? nrm2[i] : 0.5 * (g[i][j] + g[j][i]);
+    if (i < p && j < p) GW[i + p * j] = (i == j) ? (nrm2 ? nrm2[i] : g[i][i]) : 0.5 * (g[i][j] + g[j][i]);
+}
+// Normalised commit of the residual block (round 4): the first CholQR2 factor of the NEXT step from the Gram matrix the
+// one-pass panel predicts (GWE = (AX)'(AX) - P'Pc, all entries estimated), formed BEFORE the residual update runs, so that
+// the update can write T = W R1^-1 straight into the next basis slot.  cflag[0] = 0: commit; anything else: the update
+// writes the plain residual block.  The commit needs the same pivot margins as k_blk_chol1 and, because every entry of GWE
+// carries eps |A x_j|^2, a residual column that kept at least `keep` of its squared norm in the projection.
+__global__ __launch_bounds__(64) void k_blk_commit_prep(const double* __restrict__ GWE, const double* __restrict__ GYY, int p, double abs_min,
+                                                        double keep, double* __restrict__ R1out, double* __restrict__ S1, int st,
+                                                        double* __restrict__ cflag) {
+    __shared__ double R[16][17], Ri[16][17];
+    __shared__ int bad;
+    if (threadIdx.x == 0) bad = 0;
+    wave_sync();
+    if ((int)threadIdx.x < p) {
+        const double gw = GWE[threadIdx.x + p * threadIdx.x], gy = GYY[threadIdx.x + 16 * threadIdx.x];
+        if (!(gw > keep * gy) || !(gw < 1e300)) bad = 1;
+    }
+    wave_sync();
+    if (bad) { if (threadIdx.x == 0) cflag[0] = 2.0; return; }
+    const bool ok = chol16(GWE, p, R, 1e-5, abs_min);
+    if (!ok) { if (threadIdx.x == 0) cflag[0] = 1.0; return; }
+    triu_inv16(R, p, Ri);
+    for (int e = threadIdx.x; e < p * st; e += 64) { const int i = e / st, j = e % st; S1[e] = j < p ? Ri[i][j] : 0.0; }
+    for (int e = threadIdx.x; e < p * p; e += 64) R1out[e] = R[e % p][e / p];
+    if (threadIdx.x == 0) cflag[0] = 0.0;
 }
 // rows p..2p-1 of the three-term panel: S3[p + i][j] = M[i][j]  (M col-major, ld ldm)
 __global__ __launch_bounds__(64) void k_blk_fill_m(const double* __restrict__ M, int ldm, int p, double* __restrict__ S3, int st) {
@@ -892,6 +919,140 @@ __global__ __launch_bounds__(KK_TPB, 4) void k_block_update_lds(const double* V,
 // Deep-prefetch variant: a ring of PF basis-column loads (16 B each) stays in flight per lane -- as many bytes in flight as
 // the single-vector unproject kernel keeps with its 32 x 2 tile -- at 2 blocks per CU (up to 256 registers per lane).
 // Same arithmetic, same summation order as k_block_update.
+// Residual update of the one-pass block step with the NORMALISED COMMIT (round 4, VERDICT round 3 item 5: "CholQR2
+// back-substitution fused into the residual update, one write of the 16-column block per step"):
+//     w = Win - V S  (as k_block_update_lds),  column norms of w,  and -- when the device flag allows --
+//     t = w R1^-1   written to the NEXT BASIS SLOT instead of w to the residual area,   G2 += t' t   (MFMA).
+// The next expand! then starts from T and G2: no Gram pass over the residual block, no Q1 = W R1^-1 pass (one read and one
+// write of the block saved per step).  t' t: the wave's 128 x 16 tile goes through a wave-private LDS slab in four
+// 32-row quarters (lanes 16q..16q+15 own quarter q) and comes back in the column-owner layout of the MFMA operands.
+#define BUC_LD 34     // row stride (doubles) of a slab column: 32 rows + 2 (16-byte aligned, column starts 4 banks apart)
+template <int NB>
+__global__ __launch_bounds__(KK_TPB, 4) void k_block_update_commit(const double* V, int64_t ld, int m, const double* Win, double* Wout,
+                                                                 int64_t ldw, double* Tout, int64_t ldt, int nb,
+                                                                 const double* __restrict__ S, int64_t rpb,
+                                                                 double* __restrict__ part_nrm, const double* __restrict__ cflag,
+                                                                 const double* __restrict__ S1, double* __restrict__ part_g) {
+    extern __shared__ __attribute__((aligned(16))) double ssm[];   // [m][NB] coefficients | [64] norm slots | [NB][NB] R1^-1 | 4 slabs [16][BUC_LD]
+    double* nsl = ssm + (size_t)m * NB;
+    double* s1 = nsl + 64;
+    double* slab_all = s1 + NB * NB;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    double* slab = slab_all + wave * (16 * BUC_LD);
+    const bool commit = (cflag[0] == 0.0);
+    for (int e = tid; e < m * NB; e += KK_TPB) ssm[e] = S[e];
+    if (tid < 64) nsl[tid] = 0.0;
+    for (int e = tid; e < NB * NB; e += KK_TPB) s1[e] = commit ? S1[e] : 0.0;
+    for (int e = tid; e < 4 * 16 * BUC_LD; e += KK_TPB) slab_all[e] = 0.0;    // columns >= NB stay zero
+    __syncthreads();
+    v4d gacc = v4d{0.0, 0.0, 0.0, 0.0};
+    const int cq = lane & 15, kq = lane >> 4;
+    const int64_t r0 = (int64_t)blockIdx.x * rpb, r1 = imin(r0 + rpb, ld);
+    for (int64_t r = r0 + tid * 2; r < r1; r += KK_SUB) {     // (r1 - r0) is a multiple of KK_SUB: every lane of a wave iterates alike
+        d2 acc[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[j] = d2{0.0, 0.0};
+        int c = 0;
+        d2 xn[4];
+        if (m >= 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) xn[u] = ld2s(V + (int64_t)u * ld + r);
+        }
+        for (; c + 4 <= m; c += 4) {
+            d2 x[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) x[u] = xn[u];
+            if (c + 8 <= m) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) xn[u] = ld2s(V + (int64_t)(c + 4 + u) * ld + r);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const d2* Sc = reinterpret_cast<const d2*>(ssm + (size_t)(c + u) * NB);
+#pragma unroll
+                for (int j2 = 0; j2 < NB / 2; ++j2) {
+                    const d2 sv = Sc[j2];
+                    acc[2 * j2].x = fma(sv.x, x[u].x, acc[2 * j2].x); acc[2 * j2].y = fma(sv.x, x[u].y, acc[2 * j2].y);
+                    acc[2 * j2 + 1].x = fma(sv.y, x[u].x, acc[2 * j2 + 1].x); acc[2 * j2 + 1].y = fma(sv.y, x[u].y, acc[2 * j2 + 1].y);
+                }
+            }
+        }
+        for (; c < m; ++c) {
+            const d2 x = ld2(V + (int64_t)c * ld + r);
+            const d2* Sc = reinterpret_cast<const d2*>(ssm + (size_t)c * NB);
+#pragma unroll
+            for (int j2 = 0; j2 < NB / 2; ++j2) {
+                const d2 sv = Sc[j2];
+                acc[2 * j2].x = fma(sv.x, x.x, acc[2 * j2].x); acc[2 * j2].y = fma(sv.x, x.y, acc[2 * j2].y);
+                acc[2 * j2 + 1].x = fma(sv.y, x.x, acc[2 * j2 + 1].x); acc[2 * j2 + 1].y = fma(sv.y, x.y, acc[2 * j2 + 1].y);
+            }
+        }
+        // w = Win - V S  (same operation order as k_block_update_lds with alpha = -1, beta = 1), squared column norms
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            if (j < nb) {
+                const d2 wi = ld2(Win + (int64_t)j * ldw + r);
+                acc[j].x = fma(1.0, wi.x, -acc[j].x); acc[j].y = fma(1.0, wi.y, -acc[j].y);
+                const double t = wave_sum(fma(acc[j].x, acc[j].x, acc[j].y * acc[j].y));
+                if (lane == 0) nsl[j * 4 + wave] += t;
+            } else {
+                acc[j] = d2{0.0, 0.0};
+            }
+        }
+        if (!commit) {     // uniform for the launch
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+                if (j < nb) st2(Wout + (int64_t)j * ldw + r, acc[j]);
+            continue;
+        }
+        // t = w R1^-1 in place, last column first (t_j needs w_0 .. w_j only; R1^-1 is upper triangular, row-major in LDS)
+#pragma unroll
+        for (int j = NB - 1; j >= 0; --j) {
+            double tx = 0.0, ty = 0.0;
+#pragma unroll
+            for (int i = 0; i <= j; ++i) {
+                const double sij = s1[i * NB + j];
+                tx = fma(acc[i].x, sij, tx); ty = fma(acc[i].y, sij, ty);
+            }
+            acc[j].x = tx; acc[j].y = ty;
+            if (j < nb) st2(Tout + (int64_t)j * ldt + r, acc[j]);
+            __builtin_amdgcn_sched_barrier(0);      // keep the R1^-1 reads of one column together (else all 136 are hoisted: spills)
+        }
+        // G2 += t' t: quarter q of the wave's 128 rows is owned by lanes 16q .. 16q+15 (two rows each)
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            if (kq == q4) {
+#pragma unroll
+                for (int j = 0; j < NB; ++j) *reinterpret_cast<d2*>(slab + j * BUC_LD + 2 * cq) = acc[j];
+            }
+            wave_sync();
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const d2 v = *reinterpret_cast<const d2*>(slab + cq * BUC_LD + kq * 8 + 2 * u);
+                gacc = __builtin_amdgcn_mfma_f64_16x16x4f64(v.x, v.x, gacc, 0, 0, 0);
+                gacc = __builtin_amdgcn_mfma_f64_16x16x4f64(v.y, v.y, gacc, 0, 0, 0);
+            }
+            wave_sync();
+        }
+    }
+    __syncthreads();
+    if (tid < nb) part_nrm[(int64_t)tid * KK_MAX_BLOCKS + blockIdx.x] = (nsl[tid * 4] + nsl[tid * 4 + 1]) + (nsl[tid * 4 + 2] + nsl[tid * 4 + 3]);
+    if (commit) {      // the four waves' tiles in a fixed order, one 256-double partial tile per block (layout of k_block_gram)
+        double* red = slab_all;   // all slabs are idle now (the barrier above)
+        for (int w = 0; w < 4; ++w) {
+            if (wave == w) {
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    double* a = &red[rr * 64 + lane];
+                    *a = (w == 0) ? gacc[rr] : (*a + gacc[rr]);
+                }
+            }
+            __syncthreads();
+        }
+        part_g[(int64_t)blockIdx.x * 256 + tid] = red[tid];
+    }
+}
+
 template <int NB, bool BZERO, int PF>
 __global__ __launch_bounds__(KK_TPB, 2) void k_block_update_pf(const double* V, int64_t ld, int m, const double* Win,
                                                                double* Wout, int64_t ldw_in, int64_t ldw_out, int nb,
@@ -1196,6 +1357,47 @@ int kk_launch_block_gram2(kk_ctx ctx, const double* X, int64_t ldx, int p, const
     KK_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_finalize_gram3, dim3(2 * NG * 16 + (C3_dev ? 16 : 0)), dim3(KK_TPB), 0, ctx->stream, part, part2, part3, nblk, NG, p, q, q2,
                        C_dev, rs, C2_dev, rs2, C3_dev);
+    KK_HIP(hipGetLastError());
+    return KK_OK;
+}
+
+int kk_launch_blk_commit_prep(kk_ctx ctx, const double* GWE, const double* GYY, int p, double abs_min, double keep, double* R1, double* S1,
+                              int st, double* cflag) {
+    hipLaunchKernelGGL(k_blk_commit_prep, dim3(1), dim3(64), 0, ctx->stream, GWE, GYY, p, abs_min, keep, R1, S1, st, cflag);
+    KK_HIP(hipGetLastError());
+    return KK_OK;
+}
+// residual update of the one-pass block step with the normalised commit (k_block_update_commit): W = Win - V S with its
+// squared column norms (norms2_dev, all-reduced); cflag[0] == 0 on the device: T = W R1^-1 -> Tout and G2 = T'T -> G2_dev
+// (p x p column-major, NOT all-reduced: the consumer does that), else W -> Wout (may alias Win).
+int kk_launch_block_update_commit(kk_ctx ctx, const double* V, int64_t ld, int m, const double* Win, double* Wout, int64_t ldw, double* Tout,
+                                  int64_t ldt, int nb, const double* S_dev, double* norms2_dev, const double* cflag_dev,
+                                  const double* S1_dev, double* G2_dev) {
+    if (nb <= 0 || nb > 16) { kk_set_error("kk_launch_block_update_commit: nb=%d", nb); return KK_ERR_INVALID; }
+    const int NB = kk_bu_stride(nb);
+    kk_part p = kk_partition(ctx, ld);
+    if (ld % KK_SUB != 0 || (int64_t)p.nblk * 256 > (int64_t)(2 * KK_MAX_M + 8 - 16) * KK_MAX_BLOCKS) {
+        kk_set_error("kk_launch_block_update_commit: layout not supported"); return KK_ERR_UNSUPPORTED;
+    }
+    const size_t shm = ((size_t)m * NB + 64 + NB * NB + 4 * 16 * BUC_LD) * sizeof(double);
+    if (shm > 64 * 1024) { kk_set_error("kk_launch_block_update_commit: %d x %d panel does not fit", m, NB); return KK_ERR_UNSUPPORTED; }
+    double* part = ctx->partials;
+    double* part_g = ctx->partials + (int64_t)16 * KK_MAX_BLOCKS;
+    dim3 g(p.nblk), b(KK_TPB);
+    {
+        kk_prof_scope ps(ctx, "k_block_update");
+#define BUC_ARGS V, ld, m, Win, Wout, ldw, Tout, ldt, nb, S_dev, p.rpb, part, cflag_dev, S1_dev, part_g
+        if (NB == 4) hipLaunchKernelGGL((k_block_update_commit<4>), g, b, shm, ctx->stream, BUC_ARGS);
+        else if (NB == 8) hipLaunchKernelGGL((k_block_update_commit<8>), g, b, shm, ctx->stream, BUC_ARGS);
+        else hipLaunchKernelGGL((k_block_update_commit<16>), g, b, shm, ctx->stream, BUC_ARGS);
+#undef BUC_ARGS
+    }
+    KK_HIP(hipGetLastError());
+    KK_TRY(finalize_rows(ctx, part, p.nblk, nb, norms2_dev, nullptr));
+    KK_TRY(kk_allreduce(ctx, norms2_dev, nb));
+    // (when the flag said "no commit" the partial tiles were not written: the finalize then sums stale data into G2_dev,
+    //  which nobody reads -- the host learns the flag with the step's read-back)
+    hipLaunchKernelGGL(k_finalize_gram, dim3(16), dim3(KK_TPB), 0, ctx->stream, part_g, p.nblk, 1, nb, nb, G2_dev, 1, nb);
     KK_HIP(hipGetLastError());
     return KK_OK;
 }

@@ -795,10 +795,13 @@ def test_blocklanczos_async_step_matches_synchronous(kk, ko, ctx, bs):
     # round left the block orthonormal to 2e-14, which is the case here: last_qr_dev ~ 1e-15)
     # 5: as 3 but without the residual-block Gram matrix handed from step to step (resid_gram = 0: every step reads its
     # residual block once more for the first CholQR2 Gram pass)
+    # 6: as 3 with the normalised commit of the residual block (the library default: the update writes T = W R1^-1 into the
+    # next basis slot, the next step starts at the second CholQR2 round); 3, 4, 5 run with it switched off
     launches = {}
-    for mode in (1, 2, 3, 4, 5, 0):
+    for mode in (1, 2, 3, 4, 5, 6, 0):
         ctx.set_option("block_async", 1 if mode else 0)
-        ctx.set_option("block_fuse", {1: 3, 2: 0, 3: 5, 4: 5, 5: 5, 0: 0}[mode])
+        ctx.set_option("block_fuse", {1: 3, 2: 0, 3: 5, 4: 5, 5: 5, 6: 5, 0: 0}[mode])
+        ctx.set_option("block_commit", 1 if mode == 6 else 0)
         ctx.set_option("qr_skip_tol", 0.0 if mode == 4 else 2e-14)
         ctx.set_option("resid_gram", 0 if mode == 5 else 1)
         ctx.prof_reset(); ctx.prof_enable(1)
@@ -818,11 +821,13 @@ def test_blocklanczos_async_step_matches_synchronous(kk, ko, ctx, bs):
         Hs[mode] = H.copy()
         ctx.prof_enable(0)
         launches[mode] = ctx.prof_get("k_block_gram")[1]
-        if mode in (3, 4):
+        if mode in (3, 4, 6):
             assert 0 < ctx.get_option("last_qr_dev") < 2e-14    # the skip branch (3) / the full branch (4) were really taken
     ctx.set_option("qr_skip_tol", 2e-14)
     ctx.set_option("resid_gram", 1)
     assert launches[5] - launches[3] == steps - 1    # every step but the first started from the handed-over Gram matrix
+    assert launches[3] - launches[6] == steps - 1    # ... and, with the commit, without the Q1 = W R1^-1 pass either
+    ctx.set_option("block_commit", 1)
     ctx.set_option("block_async", 1)
     ctx.set_option("block_fuse", BLOCK_FUSE_DEFAULT)
     np.testing.assert_allclose(Hs[1], Hs[0], atol=1e-10)
@@ -830,6 +835,7 @@ def test_blocklanczos_async_step_matches_synchronous(kk, ko, ctx, bs):
     np.testing.assert_allclose(Hs[3], Hs[0], atol=1e-10)
     np.testing.assert_allclose(Hs[4], Hs[0], atol=1e-10)
     np.testing.assert_allclose(Hs[5], Hs[0], atol=1e-10)
+    np.testing.assert_allclose(Hs[6], Hs[0], atol=1e-10)
     oit = ko.BlockLanczosIterator(A, [x.copy() for x in x0], (steps + 1) * bs + bs)
     of = ko.blocklanczos_initialize(oit)
     for _ in range(steps):
