@@ -367,7 +367,12 @@ static int blocklanczos_expand_async(kk_op op, kk_basis b, int k, int p, int c_r
     const int kn = k + p;
     KK_CHECK(kn <= KK_MAX_M, KK_ERR_UNSUPPORTED, "block step: %d basis vectors exceed the panel limit", kn);
     const bool onepass = (c->block_fuse & 4) != 0;
-    bool try_tc = false;
+    // normalised commit (one-pass step): the next basis slot must be free (it is not on the last step before a restart) and
+    // the panels small enough for the update kernel's LDS.  A X is then formed IN that slot and updated in place (the
+    // read-modify-write of one 16-column area keeps the DRAM pages of the update's read and write streams together)
+    const int st0 = kk_bu_stride(p);
+    const bool try_tc = onepass && c->block_commit && c->resid_gram && kn + p <= std::min(c_r, c_rnext) && kn + p <= b->cap &&
+                        ((size_t)kn * st0 + 64 + st0 * st0 + 4 * 16 * 34) * sizeof(double) <= 64 * 1024;
     if (onepass) {   // Gram rows of the basis columns [0, k): known from the previous steps, recomputed after a restart
         if (b->gram_c0 != 0) { b->gram_c0 = 0; b->gram_rows = 0; }
         KK_TRY(gram_device(b));
@@ -401,7 +406,7 @@ static int blocklanczos_expand_async(kk_op op, kk_basis b, int k, int p, int c_r
     // Q = Q1 R2^-1 in place (row-local); not executed when k_blk_chol2 found Q1 orthonormal already (device flag)
     KK_TRY(kk_launch_block_update(c, b->col(k), ld, p, nullptr, b->col(k), ld, ld, p, D + AB_S2, 1.0, 0.0, nullptr, D + AB_FLAG + 1));
     // ---- block_lanczosrecurrence: AX = A X ; M = X' AX ; AX -= [Xprev X] [B' ; M]
-    double* AX = b->col(c_rnext);
+    double* AX = try_tc ? b->col(kn) : b->col(c_rnext);
     KK_TRY(kk_launch_spmm(c, op->A, b->col(k), ld, AX, ld, p));
     if (onepass) {
         // one pass: P = V'(A X) against the whole basis, AX -= V P.  Rows k-p .. k+p-1 of P are the three-term coefficients
@@ -429,16 +434,12 @@ static int blocklanczos_expand_async(kk_op op, kk_basis b, int k, int p, int c_r
         KK_TRY(kk_launch_blk_gram_rows(c, G2, st, k, p, b->d_gram, b->cap));
         KK_TRY(kk_launch_blk_panel_m(c, P, st, k, p, D + AB_M, 16));
         KK_TRY(kk_launch_blk_panel_correct(c, P, st, kn, p, b->d_gram, b->cap, Pc));
-        // normalised commit: the next basis slot must be free (it is not on the last step before a restart) and the
-        // panels small enough for the update kernel's LDS
-        try_tc = c->block_commit && want_gw && kn + p <= std::min(c_r, c_rnext) && kn + p <= b->cap &&
-                 ((size_t)kn * st + 64 + st * st + 4 * 16 * 34) * sizeof(double) <= 64 * 1024;
         if (try_tc) {
             // first CholQR2 factor of the NEXT step from the predicted Gram matrix (AX)'(AX) - P'Pc, then the update writes
             // T = W R1^-1 into columns kn.. and accumulates T'T (AB_G); the residual area keeps A X
             KK_TRY(kk_launch_blk_resid_gram(c, P, Pc, st, kn, p, D + AB_GYY, nullptr, D + AB_GW));
             KK_TRY(kk_launch_blk_commit_prep(c, D + AB_GW, D + AB_GYY, p, 1000.0 * qr_tol, 1e-3, D + AB_R1, D + AB_S1, st, D + AB_CF));
-            KK_TRY(kk_launch_block_update_commit(c, b->col(0), ld, kn, AX, AX, ld, b->col(kn), ld, p, Pc, D + AB_NRM, D + AB_CF, D + AB_S1,
+            KK_TRY(kk_launch_block_update_commit(c, b->col(0), ld, kn, AX, AX, ld, AX, ld, p, Pc, D + AB_NRM, D + AB_CF, D + AB_S1,
                                                  D + AB_G));
         } else {
             KK_TRY(kk_launch_block_update(c, b->col(0), ld, kn, AX, AX, ld, ld, p, Pc, -1.0, 1.0, D + AB_NRM));
@@ -478,7 +479,9 @@ readback:
     if (qr_state) *qr_state = (H[0] == 2.0 || H[1] != 0.0) ? 0 : 1;
     if (!*fine) return KK_OK;
     if (take_tc) c->block_commits++;
-    if (try_tc && H[AB_CF - AB_BASE] == 0.0) {   // committed: columns kn.. hold T, the residual area still holds A X
+    if (try_tc && H[AB_CF - AB_BASE] != 0.0)   // not committed (decided on the device): the plain block sits in the basis slot
+        KK_HIP(hipMemcpyAsync(b->col(c_rnext), b->col(kn), (size_t)p * ld * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    if (try_tc && H[AB_CF - AB_BASE] == 0.0) {   // committed: columns kn.. hold T, the residual area is not written at all
         b->tc_valid = true; b->tc_k = kn; b->tc_cr = c_rnext; b->tc_p = p;
         memcpy(b->tc_R1, H + (AB_R1 - AB_BASE), (size_t)p * p * sizeof(double));
         c->tc_owner = b->uid;
