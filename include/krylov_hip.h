@@ -92,12 +92,18 @@ typedef enum {
  * needs no scale pass (factorizations/lanczos.jl:257, arnoldi.jl:209); the slab remembers (column, beta) and ANY other
  * entry point that is handed the slab first multiplies the column back, so residual(F), shrink! and restarts see r as
  * before (to 1 ulp); kk_orthonormalize uses the same commit; 0 = every expand! runs its own scale pass; same alpha / beta
- * bits either way).  A grid-barrier timeout of the persistent kernel (GPU shared with another job) is recovered inside the
+ * bits either way), "block_commit" (default 1: the one-pass BlockLanczos step writes its residual block W as T = W R1^-1
+ * -- R1 = the first CholQR2 factor, from the Gram matrix the projection panel predicts -- straight into the next basis
+ * slot (columns k+bs .. k+2bs-1, which must lie below both residual areas) and does not write the residual area; the next
+ * kk_blocklanczos_expand of the same factorization starts at the second CholQR2 round (blocklanczos.jl:209-216), any other
+ * entry point that is handed the slab first forms W = T R1 in the residual area, so residual(F), shrink! and restarts see
+ * the block as before; "block_commits" counts the commits consumed; 0 = the residual block is always written).
+ * A grid-barrier timeout of the persistent kernel (GPU shared with another job) is recovered inside the
  * library on the launch-per-vector route in the same strict order; the persistent route is retried a few sweeps later
  * (kk_ctx_get_option: "persist_timeouts", "persist_skip"); "persist_capacity_rows" = rows of a work vector the register
  * file of the chip holds (longer vectors run the low-synchronisation form in auto mode).
  * Tuning knobs without semantic effect:
- * "gram_bpc", "gram2_chunk", "spmm_bpc", "spmm_cols", "spmm_rpl", "spmm_dia_lines", "bu_prefetch", "gram_nt", "persist_nt",
+ * "gram_bpc", "gram2_chunk", "gram2_pipe", "gram2_bpc", "spmm_bpc", "spmm_cols", "spmm_rpl", "spmm_dia_lines", "bu_prefetch", "gram_nt", "persist_nt",
  * "persist_lds", "persist_min_rows", "spmv_dia_pairs" (row pairs per lane of the diagonal SpMV: 0 = by size, 1 / 2 / 4).  Test hook: "persist_fault" (the next n persistent launches behave like a grid-barrier timeout). */
 
 /* Environment variables read by the library (all optional): KK_MGS_MODE, KK_BLOCK_MODE, KK_BLOCKS_PER_CU, KK_MGS_PERSIST,
