@@ -196,7 +196,7 @@ def kernel_source_sha() -> str:
     import hashlib
     h = hashlib.sha256()
     src = ROOT / "krylovkit.jl_amd" / "csrc"
-    for f in sorted(src.glob("*.hip")) + sorted(src.glob("*.h")):
+    for f in sorted(src.glob("*.hip")) + sorted(src.glob("*.h")) + [src.parent / "Makefile"]:   # (the Makefile carries per-file code-generation flags)
         h.update(f.read_bytes())
     return h.hexdigest()[:16]
 

@@ -431,9 +431,9 @@ static int blocklanczos_expand_async(kk_op op, kk_basis b, int k, int p, int c_r
                                          st, G2 + (int64_t)i0 * st, st, (want_gw && i0 == 0) ? D + AB_GYY : nullptr));
         KK_TRY(kk_allreduce(c, P, 2 * (int64_t)kn * st));
         if (want_gw) KK_TRY(kk_allreduce(c, D + AB_GYY, 256));
-        KK_TRY(kk_launch_blk_gram_rows(c, G2, st, k, p, b->d_gram, b->cap));
+        KK_TRY(kk_launch_blk_gram_rows(c, G2, st, k, p, b->d_gram, b->cap, b->d_gdiag));
         KK_TRY(kk_launch_blk_panel_m(c, P, st, k, p, D + AB_M, 16));
-        KK_TRY(kk_launch_blk_panel_correct(c, P, st, kn, p, b->d_gram, b->cap, Pc));
+        KK_TRY(kk_launch_blk_panel_correct(c, P, st, kn, p, b->d_gram, b->cap, Pc, b->d_gdiag));
         if (try_tc) {
             // first CholQR2 factor of the NEXT step from the predicted Gram matrix (AX)'(AX) - P'Pc, then the update writes
             // T = W R1^-1 into columns kn.. and accumulates T'T (AB_G); the residual area keeps A X

@@ -448,6 +448,7 @@ KK_API int kk_basis_free(kk_basis b) {
     if (!b) return KK_OK;
     (void)hipDeviceSynchronize();  // not the context's stream: finalizers may run after the context is gone
     (void)hipFree(b->d_gram);
+    (void)hipFree(b->d_gdiag);
     (void)hipFree(b->d);
     delete b;
     return KK_OK;

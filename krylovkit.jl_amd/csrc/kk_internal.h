@@ -201,6 +201,7 @@ struct kk_basis_s {
     int gram_c0 = 0;    // first column the Gram rows refer to
     int gram_rows = 0;  // rows [0, gram_rows) of the strictly-lower Gram matrix are valid
     double* d_gram = nullptr;  // device mirror of `gram` (same layout), valid for the same rows
+    double* d_gdiag = nullptr; // device only: |b_i|^2 - 1 where a block step measured it (0 elsewhere), rows as d_gram
     // speculative next-step SpMV (hides the host round trip between two expand! calls)
     bool spec_valid = false;
     const void* spec_op = nullptr;
@@ -404,8 +405,9 @@ int kk_launch_blk_commit_prep(kk_ctx ctx, const double* GWE, const double* GYY, 
 int kk_launch_block_update_commit(kk_ctx ctx, const double* V, int64_t ld, int m, const double* Win, double* Wout, int64_t ldw, double* Tout,
                                   int64_t ldt, int nb, const double* S_dev, double* norms2_dev, const double* cflag_dev,
                                   const double* S1_dev, double* G2_dev);
-int kk_launch_blk_gram_rows(kk_ctx ctx, const double* G2, int st, int k, int p, double* gram, int cap);
-int kk_launch_blk_panel_correct(kk_ctx ctx, const double* P, int st, int kn, int p, const double* gram, int cap, double* Pc);
+int kk_launch_blk_gram_rows(kk_ctx ctx, const double* G2, int st, int k, int p, double* gram, int cap, double* gdiag);
+int kk_launch_blk_panel_correct(kk_ctx ctx, const double* P, int st, int kn, int p, const double* gram, int cap, double* Pc,
+                                const double* gdiag);
 int kk_launch_blk_panel_m(kk_ctx ctx, const double* P, int st, int k, int p, double* M, int ldm);
 int kk_launch_blk_onepass_check(kk_ctx ctx, const double* P, int st, int kn, int p, const double* nrm2, double eta, double* flag);
 int kk_launch_block_gram_tile(kk_ctx ctx, const double* X, int64_t ldx, int p, const double* Yin, int64_t ldy, const double* Z,

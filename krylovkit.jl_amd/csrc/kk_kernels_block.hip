@@ -670,20 +670,27 @@ __global__ __launch_bounds__(KK_TPB) void k_blk_onepass_check(const double* __re
 }
 // Gram rows of the newest block from the ride-along panel G2[j][i] = <v_j, x_i> (row-major, stride st):
 //   gram[(k+i)*cap + j] = G2[j][i]  for j < k+i      (strictly-lower storage of kk_orth.hip, device mirror)
-__global__ __launch_bounds__(KK_TPB) void k_blk_gram_rows(const double* __restrict__ G2, int st, int k, int p, double* __restrict__ gram, int cap) {
+// gdiag (optional): |x_i|^2 - 1 of the newest block's vectors, the DIAGONAL of E = V'V - I, which the strictly-lower storage has no place for
+__global__ __launch_bounds__(KK_TPB) void k_blk_gram_rows(const double* __restrict__ G2, int st, int k, int p, double* __restrict__ gram, int cap,
+                                                          double* __restrict__ gdiag) {
     const int kn = k + p;
     for (int e = threadIdx.x + blockIdx.x * KK_TPB; e < kn * p; e += KK_TPB * gridDim.x) {
         const int j = e / p, i = e % p;
         if (j < k + i) gram[(int64_t)(k + i) * cap + j] = G2[(int64_t)j * st + i];
+        else if (j == k + i && gdiag) gdiag[k + i] = G2[(int64_t)j * st + i] - 1.0;
     }
 }
 // One-pass projection with a non-orthonormal basis to first order: the coefficients of the projector onto span(V) are
-// (V'V)^-1 V'y ~ (I - E) V'y, E = V'V - I (off-diagonal part, from the strictly-lower Gram rows):
-//   Pc[i][j] = P[i][j] - sum_{l != i} G(i, l) P[l][j]
+// (V'V)^-1 V'y ~ (I - E) V'y, E = V'V - I (off-diagonal part from the strictly-lower Gram rows, diagonal from gdiag):
+//   Pc[i][j] = P[i][j] - sum_{l != i} G(i, l) P[l][j] - (|v_i|^2 - 1) P[i][j]
+// (the diagonal matters since round 4: a block whose second CholQR2 round was skipped at |Q1'Q1 - I| <= 2e-14 carries that
+// much in its norms; left out, V'w keeps (|v_i|^2 - 1) P_i and the predicted Gram matrix of the residual block -- the normalised
+// commit factors it -- is off by P'DP, 1e-13 relative on config 5 instead of 1e-15)
 // Without it the error E of the basis re-enters every new block multiplied by |P| / |w| > 1 and grows geometrically (one
 // classical Gram-Schmidt pass is not enough); with it V'w = O(E^2 |P|) + the rounding of the panel itself.
 __global__ __launch_bounds__(KK_TPB) void k_blk_panel_correct(const double* __restrict__ P, int st, int kn, int p,
-                                                              const double* __restrict__ gram, int cap, double* __restrict__ Pc) {
+                                                              const double* __restrict__ gram, int cap, double* __restrict__ Pc,
+                                                              const double* __restrict__ gdiag) {
     extern __shared__ double psm[];   // P staged: kn * st (every block stages the whole panel and computes its 256 entries)
     for (int e = threadIdx.x; e < kn * st; e += KK_TPB) psm[e] = P[e];
     __syncthreads();
@@ -693,6 +700,7 @@ __global__ __launch_bounds__(KK_TPB) void k_blk_panel_correct(const double* __re
         if (j < p) {
             for (int l = 0; l < i; ++l) a = fma(gram[(int64_t)i * cap + l], psm[l * st + j], a);
             for (int l = i + 1; l < kn; ++l) a = fma(gram[(int64_t)l * cap + i], psm[l * st + j], a);
+            if (gdiag) a = fma(gdiag[i], psm[i * st + j], a);
         }
         Pc[e] = psm[e] - a;
     }
@@ -921,7 +929,7 @@ __global__ __launch_bounds__(KK_TPB, 4) void k_block_update_lds(const double* V,
 // Same arithmetic, same summation order as k_block_update.
 // Residual update of the one-pass block step with the NORMALISED COMMIT (round 4, VERDICT round 3 item 5: "CholQR2
 // back-substitution fused into the residual update, one write of the 16-column block per step"):
-//     w = Win - V S  (as k_block_update_lds),  column norms of w,  and -- when the device flag allows --
+//     w = Win - V S  (accumulated onto Win, column by column),  column norms of w,  and -- when the device flag allows --
 //     t = w R1^-1   written to the NEXT BASIS SLOT instead of w to the residual area,   G2 += t' t   (MFMA).
 // The next expand! then starts from T and G2: no Gram pass over the residual block, no Q1 = W R1^-1 pass (one read and one
 // write of the block saved per step).  t' t: the wave's 128 x 16 tile goes through a wave-private LDS slab in four
@@ -940,7 +948,7 @@ __global__ __launch_bounds__(KK_TPB, 4) void k_block_update_commit(const double*
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     double* slab = slab_all + wave * (16 * BUC_LD);
     const bool commit = (cflag[0] == 0.0);
-    for (int e = tid; e < m * NB; e += KK_TPB) ssm[e] = S[e];
+    for (int e = tid; e < m * NB; e += KK_TPB) ssm[e] = -S[e];     // w = Win - V S is accumulated ONTO Win (below)
     if (tid < 64) nsl[tid] = 0.0;
     for (int e = tid; e < NB * NB; e += KK_TPB) s1[e] = commit ? S1[e] : 0.0;
     for (int e = tid; e < 4 * 16 * BUC_LD; e += KK_TPB) slab_all[e] = 0.0;    // columns >= NB stay zero
@@ -949,9 +957,12 @@ __global__ __launch_bounds__(KK_TPB, 4) void k_block_update_commit(const double*
     const int cq = lane & 15, kq = lane >> 4;
     const int64_t r0 = (int64_t)blockIdx.x * rpb, r1 = imin(r0 + rpb, ld);
     for (int64_t r = r0 + tid * 2; r < r1; r += KK_SUB) {     // (r1 - r0) is a multiple of KK_SUB: every lane of a wave iterates alike
+        // the accumulators START as the rows of Win: its 16 loads travel with the first basis columns instead of standing,
+        // one after the other, between the main loop and the epilogue (every accumulator stays live for the R1^-1 product,
+        // so there is no register to hoist them into: measured 20 % of the kernel)
         d2 acc[NB];
 #pragma unroll
-        for (int j = 0; j < NB; ++j) acc[j] = d2{0.0, 0.0};
+        for (int j = 0; j < NB; ++j) acc[j] = (j < nb) ? ld2(Win + (int64_t)j * ldw + r) : d2{0.0, 0.0};
         int c = 0;
         d2 xn[4];
         if (m >= 4) {
@@ -987,16 +998,12 @@ __global__ __launch_bounds__(KK_TPB, 4) void k_block_update_commit(const double*
                 acc[2 * j2 + 1].x = fma(sv.y, x.x, acc[2 * j2 + 1].x); acc[2 * j2 + 1].y = fma(sv.y, x.y, acc[2 * j2 + 1].y);
             }
         }
-        // w = Win - V S  (same operation order as k_block_update_lds with alpha = -1, beta = 1), squared column norms
+        // acc = w = Win - V S; squared column norms
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             if (j < nb) {
-                const d2 wi = ld2(Win + (int64_t)j * ldw + r);
-                acc[j].x = fma(1.0, wi.x, -acc[j].x); acc[j].y = fma(1.0, wi.y, -acc[j].y);
                 const double t = wave_sum(fma(acc[j].x, acc[j].x, acc[j].y * acc[j].y));
                 if (lane == 0) nsl[j * 4 + wave] += t;
-            } else {
-                acc[j] = d2{0.0, 0.0};
             }
         }
         if (!commit) {     // uniform for the launch
@@ -1157,13 +1164,14 @@ int kk_launch_blk_onepass_check(kk_ctx ctx, const double* P, int st, int kn, int
     KK_HIP(hipGetLastError());
     return KK_OK;
 }
-int kk_launch_blk_gram_rows(kk_ctx ctx, const double* G2, int st, int k, int p, double* gram, int cap) {
-    hipLaunchKernelGGL(k_blk_gram_rows, dim3(4), dim3(KK_TPB), 0, ctx->stream, G2, st, k, p, gram, cap);
+int kk_launch_blk_gram_rows(kk_ctx ctx, const double* G2, int st, int k, int p, double* gram, int cap, double* gdiag) {
+    hipLaunchKernelGGL(k_blk_gram_rows, dim3(4), dim3(KK_TPB), 0, ctx->stream, G2, st, k, p, gram, cap, gdiag);
     KK_HIP(hipGetLastError());
     return KK_OK;
 }
-int kk_launch_blk_panel_correct(kk_ctx ctx, const double* P, int st, int kn, int p, const double* gram, int cap, double* Pc) {
-    hipLaunchKernelGGL(k_blk_panel_correct, dim3((kn * st + KK_TPB - 1) / KK_TPB), dim3(KK_TPB), (size_t)kn * st * sizeof(double), ctx->stream, P, st, kn, p, gram, cap, Pc);
+int kk_launch_blk_panel_correct(kk_ctx ctx, const double* P, int st, int kn, int p, const double* gram, int cap, double* Pc,
+                                const double* gdiag) {
+    hipLaunchKernelGGL(k_blk_panel_correct, dim3((kn * st + KK_TPB - 1) / KK_TPB), dim3(KK_TPB), (size_t)kn * st * sizeof(double), ctx->stream, P, st, kn, p, gram, cap, Pc, gdiag);
     KK_HIP(hipGetLastError());
     return KK_OK;
 }

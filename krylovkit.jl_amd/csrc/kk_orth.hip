@@ -122,6 +122,8 @@ int gram_device(kk_basis b) {
         KK_HIP(hipSetDevice(b->ctx->device));   // lazy allocation: must land on the context's device, not the thread's current one
         KK_HIP(hipMalloc(&b->d_gram, (size_t)b->cap * b->cap * sizeof(double)));
         KK_HIP(hipMemcpy(b->d_gram, b->gram.data(), (size_t)b->cap * b->cap * sizeof(double), hipMemcpyHostToDevice));
+        KK_HIP(hipMalloc(&b->d_gdiag, (size_t)b->cap * sizeof(double)));
+        KK_HIP(hipMemset(b->d_gdiag, 0, (size_t)b->cap * sizeof(double)));
     }
     return KK_OK;
 }
@@ -130,6 +132,8 @@ static int gram_upload_rows(kk_basis b, int lo, int hi) {
     // pageable source: the runtime stages it before returning, so the host vector may change afterwards
     KK_HIP(hipMemcpyAsync(b->d_gram + (size_t)lo * b->cap, b->gram.data() + (size_t)lo * b->cap,
                           (size_t)(hi - lo) * b->cap * sizeof(double), hipMemcpyHostToDevice, b->ctx->stream));
+    // rows recomputed from the slab (after a restart transformed it): their norms were not measured, take them as 1
+    if (b->d_gdiag) KK_HIP(hipMemsetAsync(b->d_gdiag + lo, 0, (size_t)(hi - lo) * sizeof(double), b->ctx->stream));
     return KK_OK;
 }
 static int gram_ensure_host(kk_basis b, int upto);
