@@ -956,6 +956,13 @@ __global__ __launch_bounds__(KK_TPB, 4) void k_block_update_commit(const double*
     v4d gacc = v4d{0.0, 0.0, 0.0, 0.0};
     const int cq = lane & 15, kq = lane >> 4;
     const int64_t r0 = (int64_t)blockIdx.x * rpb, r1 = imin(r0 + rpb, ld);
+    // the first four basis columns of a tile are requested during the LAST column group of the tile before it: the epilogue
+    // below (R1^-1 product, slab transposition, MFMAs) would otherwise leave this wave without a load in flight
+    d2 xn[4];
+    if (m >= 4 && r0 + tid * 2 < r1) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) xn[u] = ld2s(V + (int64_t)u * ld + r0 + tid * 2);
+    }
     for (int64_t r = r0 + tid * 2; r < r1; r += KK_SUB) {     // (r1 - r0) is a multiple of KK_SUB: every lane of a wave iterates alike
         // the accumulators START as the rows of Win: its 16 loads travel with the first basis columns instead of standing,
         // one after the other, between the main loop and the epilogue (every accumulator stays live for the R1^-1 product,
@@ -964,11 +971,6 @@ __global__ __launch_bounds__(KK_TPB, 4) void k_block_update_commit(const double*
 #pragma unroll
         for (int j = 0; j < NB; ++j) acc[j] = (j < nb) ? ld2(Win + (int64_t)j * ldw + r) : d2{0.0, 0.0};
         int c = 0;
-        d2 xn[4];
-        if (m >= 4) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) xn[u] = ld2s(V + (int64_t)u * ld + r);
-        }
         for (; c + 4 <= m; c += 4) {
             d2 x[4];
 #pragma unroll
@@ -976,6 +978,9 @@ __global__ __launch_bounds__(KK_TPB, 4) void k_block_update_commit(const double*
             if (c + 8 <= m) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) xn[u] = ld2s(V + (int64_t)(c + 4 + u) * ld + r);
+            } else if (r + KK_SUB < r1) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) xn[u] = ld2s(V + (int64_t)u * ld + r + KK_SUB);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
