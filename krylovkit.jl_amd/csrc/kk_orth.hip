@@ -133,7 +133,8 @@ static int gram_upload_rows(kk_basis b, int lo, int hi) {
     KK_HIP(hipMemcpyAsync(b->d_gram + (size_t)lo * b->cap, b->gram.data() + (size_t)lo * b->cap,
                           (size_t)(hi - lo) * b->cap * sizeof(double), hipMemcpyHostToDevice, b->ctx->stream));
     // rows recomputed from the slab (after a restart transformed it): their norms were not measured, take them as 1
-    if (b->d_gdiag) KK_HIP(hipMemsetAsync(b->d_gdiag + lo, 0, (size_t)(hi - lo) * sizeof(double), b->ctx->stream));
+    const int z0 = lo <= 1 ? 0 : lo;   // (row 0 has no strictly-lower entries and is never uploaded: its norm goes with row 1)
+    if (b->d_gdiag) KK_HIP(hipMemsetAsync(b->d_gdiag + z0, 0, (size_t)(hi - z0) * sizeof(double), b->ctx->stream));
     return KK_OK;
 }
 static int gram_ensure_host(kk_basis b, int upto);
