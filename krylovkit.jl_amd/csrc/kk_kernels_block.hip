@@ -188,20 +188,43 @@ struct g2_chunk {
     d2 y[BG_T / 2], z[BG_T / 2];
 };
 typedef unsigned v4u_blk __attribute__((ext_vector_type(4)));
-#ifndef KK_G2P_AUX
-#define KK_G2P_AUX 0                // cache policy of the panel streams: plain (non-temporal = 2 measured slower: the two 64-byte halves of a line arrive in different instructions)
+// Lane -> address map of the panel streams (tools/column_panel_read.hip, profiles/r04_column_panel_read.jsonl):
+//   0  the MFMA operand layout itself: lane (c = l & 15, kq = l >> 4) reads 16 B of column c, one instruction = 16 columns x
+//      64 B.  Ceiling 6.2 TB/s with plain loads; non-temporal loads are SLOWER (5.3: the two halves of a line arrive in
+//      different instructions);
+//   1  whole cache lines: lane (c8 = l & 7, h = l >> 3) reads 16 B of column c8 (c8 + 8 in the odd instructions), one
+//      instruction = 8 columns x 128 B, non-temporal: 6.7-6.8 TB/s.  The operand layout is restored in registers: lanes l and
+//      l ^ 8 exchange one of their two 16-byte values (8 DPP moves per pair of loads, row_ror:8 with a bank mask).
+#ifndef KK_G2P_LINE
+#define KK_G2P_LINE 1
 #endif
+#define KK_G2P_AUX (KK_G2P_LINE ? 2 : 0)
 // 16-byte load through a buffer descriptor: the address is descriptor base + lane offset (32 bit) + scalar offset + an
 // immediate -- no 64-bit address registers per stream -- and, being an opaque intrinsic, it stays where it is written
 // relative to the compiler barrier that follows every request (a plain load of a `const __restrict__` argument is free to
 // sink to its first use, which is exactly what un-pipelines the loop: seen in the ISA of the first version)
 template <int IMM>
-__device__ __forceinline__ d2 g2_bload(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-    const v4u_blk t = __builtin_amdgcn_raw_buffer_load_b128(r, voff + IMM, soff, KK_G2P_AUX);
+__device__ __forceinline__ v4u_blk g2_bload(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_amdgcn_raw_buffer_load_b128(r, voff + IMM, soff, KK_G2P_AUX);
+}
+__device__ __forceinline__ d2 g2_d2(v4u_blk t) {
     d2 o;
     o.x = __longlong_as_double((long long)(((unsigned long long)t.y << 32) | t.x));
     o.y = __longlong_as_double((long long)(((unsigned long long)t.w << 32) | t.z));
     return o;
+}
+// whole-line map: a = this lane's 16 B of column c8, b = of column c8 + 8, both at row pair h = l >> 3 of a 16-row group.
+// Lane l = c8 + 8 b3 + 16 kq must end up with column (l & 15) at the row pairs 2 kq and 2 kq + 1:
+//   first  = b3 ? partner's b : own a        second = b3 ? own b : partner's a        (partner = l ^ 8, same 16-lane row)
+__device__ __forceinline__ void g2_line_fix(v4u_blk a, v4u_blk b, d2& first, d2& second) {
+    v4u_blk f, s;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        f[e] = (unsigned)__builtin_amdgcn_update_dpp((int)a[e], (int)b[e], 0x128 /* row_ror:8 */, 0xF, 0xC /* lanes 8-15 of a row */, false);
+        s[e] = (unsigned)__builtin_amdgcn_update_dpp((int)b[e], (int)a[e], 0x128, 0xF, 0x3 /* lanes 0-7 */, false);
+    }
+    first = g2_d2(f);
+    second = g2_d2(s);
 }
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t g2_rsrc(const double* p, int64_t bytes) {
     const unsigned long long a = (unsigned long long)p;
@@ -212,22 +235,28 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t g2_rsrc(const double* p, int64
 template <int NG>
 struct g2_streams {
     __amdgpu_buffer_rsrc_t x[NG], y, z;
-    unsigned vx[NG], vy, vz;     // lane part of the byte offset: clamped column * ld * 8 + 16 kq
+    unsigned vx[NG], vy, vz;        // lane part of the byte offset: clamped column * ld * 8 + row part
+    unsigned vx2[NG], vy2, vz2;     // whole-line map: the same for the second column of the lane (c8 + 8)
 };
+// one 32-row tile of one 16-column stream -> four d2 per lane in the operand layout (t: rows 8t + 2kq .. in map 0; map 1: see g2_line_fix)
+__device__ __forceinline__ void g2_load_tile(d2 (&o)[BG_T / 2], __amdgpu_buffer_rsrc_t r, unsigned v, unsigned v2, unsigned soff) {
+#if KK_G2P_LINE
+    const v4u_blk a0 = g2_bload<0>(r, v, soff), b0 = g2_bload<0>(r, v2, soff);
+    const v4u_blk a1 = g2_bload<128>(r, v, soff), b1 = g2_bload<128>(r, v2, soff);
+    g2_line_fix(a0, b0, o[0], o[1]);
+    g2_line_fix(a1, b1, o[2], o[3]);
+#else
+    o[0] = g2_d2(g2_bload<0>(r, v, soff)); o[1] = g2_d2(g2_bload<64>(r, v, soff));
+    o[2] = g2_d2(g2_bload<128>(r, v, soff)); o[3] = g2_d2(g2_bload<192>(r, v, soff));
+#endif
+}
 // GXL: the ride-along block Y2 is the LAST group of this X panel -- its tile is x[NG-1], nothing extra is read
 template <int NG, bool GXL>
 __device__ __forceinline__ void g2_request(g2_chunk<NG>& T, const g2_streams<NG>& S, unsigned soff) {
-    T.y[0] = g2_bload<0>(S.y, S.vy, soff); T.y[1] = g2_bload<64>(S.y, S.vy, soff);
-    T.y[2] = g2_bload<128>(S.y, S.vy, soff); T.y[3] = g2_bload<192>(S.y, S.vy, soff);
-    if (!GXL) {
-        T.z[0] = g2_bload<0>(S.z, S.vz, soff); T.z[1] = g2_bload<64>(S.z, S.vz, soff);
-        T.z[2] = g2_bload<128>(S.z, S.vz, soff); T.z[3] = g2_bload<192>(S.z, S.vz, soff);
-    }
+    g2_load_tile(T.y, S.y, S.vy, S.vy2, soff);
+    if (!GXL) g2_load_tile(T.z, S.z, S.vz, S.vz2, soff);
 #pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        T.x[g][0] = g2_bload<0>(S.x[g], S.vx[g], soff); T.x[g][1] = g2_bload<64>(S.x[g], S.vx[g], soff);
-        T.x[g][2] = g2_bload<128>(S.x[g], S.vx[g], soff); T.x[g][3] = g2_bload<192>(S.x[g], S.vx[g], soff);
-    }
+    for (int g = 0; g < NG; ++g) g2_load_tile(T.x[g], S.x[g], S.vx[g], S.vx2[g], soff);
     asm volatile("" ::: "memory");
 }
 template <int NG, bool P3, bool GXL>
@@ -269,17 +298,28 @@ __global__ __launch_bounds__(KK_TPB) void k_block_gram2p(const double* __restric
     for (int g = 0; g < NG; ++g) { acc[g] = v4d{0.0, 0.0, 0.0, 0.0}; acc2[g] = v4d{0.0, 0.0, 0.0, 0.0}; }
     // one descriptor per 16-column group, columns clamped into the panel (see above); rows beyond ld read as zero
     g2_streams<NG> S;
+    (void)c; (void)kq;
+#if KK_G2P_LINE
+    const int c1 = lane & 7, c2 = c1 + 8;
+    const unsigned rowpart = (unsigned)(lane >> 3) * 16;
+#else
+    const int c1 = c, c2 = c;
+    const unsigned rowpart = (unsigned)kq * 16;
+#endif
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
         const int ncol = imin(16, p - g * 16) > 0 ? imin(16, p - g * 16) : 1;
         const int g0 = imin(g * 16, p - 1);
         S.x[g] = g2_rsrc(X + (int64_t)g0 * ldx, ((int64_t)(ncol - 1) * ldx + ld) * 8);
-        S.vx[g] = (unsigned)((int64_t)imin(c, ncol - 1) * ldx * 8) + kq * 16;
+        S.vx[g] = (unsigned)((int64_t)imin(c1, ncol - 1) * ldx * 8) + rowpart;
+        S.vx2[g] = (unsigned)((int64_t)imin(c2, ncol - 1) * ldx * 8) + rowpart;
     }
     S.y = g2_rsrc(Y, ((int64_t)(q - 1) * ldy + ld) * 8);
-    S.vy = (unsigned)((int64_t)imin(c, q - 1) * ldy * 8) + kq * 16;
+    S.vy = (unsigned)((int64_t)imin(c1, q - 1) * ldy * 8) + rowpart;
+    S.vy2 = (unsigned)((int64_t)imin(c2, q - 1) * ldy * 8) + rowpart;
     S.z = g2_rsrc(Y2, ((int64_t)(q2 - 1) * ldy2 + ld) * 8);
-    S.vz = (unsigned)((int64_t)imin(c, q2 - 1) * ldy2 * 8) + kq * 16;
+    S.vz = (unsigned)((int64_t)imin(c1, q2 - 1) * ldy2 * 8) + rowpart;
+    S.vz2 = (unsigned)((int64_t)imin(c2, q2 - 1) * ldy2 * 8) + rowpart;
     // rpb and ld are multiples of KK_SUB = 512 rows = 4 chunks per wave: every wave has an even number of chunks, so the loop
     // below is branch-free between a request and its use
     const unsigned step = 4 * BG_CHUNK * 8;                       // bytes between two chunks of one wave
