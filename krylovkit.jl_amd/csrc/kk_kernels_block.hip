@@ -887,6 +887,16 @@ __global__ __launch_bounds__(KK_TPB) void k_block_update(const double* V, int64_
 // (m x NB doubles, <= 17 KB) to LDS once and every lane reads the coefficients with broadcast ds_read_b128 (same address
 // in all lanes: conflict-free), NB/2 at a time; the column norms are reduced per iteration with wave sums instead of
 // per-thread LDS accumulators (32 KB less LDS per block).
+#ifndef KK_BUL_NT
+#define KK_BUL_NT 1     // non-temporal Win loads and W stores: -0.3 ... -0.8 % on the block step (same-box A/B)
+#endif
+#if KK_BUL_NT
+#define BUL_LD_WIN ld2s
+#define BUL_ST st2s
+#else
+#define BUL_LD_WIN ld2
+#define BUL_ST st2
+#endif
 template <int NB, bool BZERO>
 __global__ __launch_bounds__(KK_TPB, 4) void k_block_update_lds(const double* V, int64_t ld, int m, const double* Win,
                                                              double* Wout, int64_t ldw_in, int64_t ldw_out, int nb,
@@ -947,10 +957,10 @@ __global__ __launch_bounds__(KK_TPB, 4) void k_block_update_lds(const double* V,
             if (j < nb) {
                 d2 w{alpha * acc[j].x, alpha * acc[j].y};
                 if (!BZERO) {
-                    const d2 wi = ld2(Win + (int64_t)j * ldw_in + r);
+                    const d2 wi = BUL_LD_WIN(Win + (int64_t)j * ldw_in + r);
                     w.x = fma(beta, wi.x, w.x); w.y = fma(beta, wi.y, w.y);
                 }
-                st2(Wout + (int64_t)j * ldw_out + r, w);
+                BUL_ST(Wout + (int64_t)j * ldw_out + r, w);
                 if (part_nrm) {
                     const double t = wave_sum(fma(w.x, w.x, w.y * w.y));
                     if (lane == 0) nsl[j * 4 + wave] += t;
@@ -974,6 +984,16 @@ __global__ __launch_bounds__(KK_TPB, 4) void k_block_update_lds(const double* V,
 // The next expand! then starts from T and G2: no Gram pass over the residual block, no Q1 = W R1^-1 pass (one read and one
 // write of the block saved per step).  t' t: the wave's 128 x 16 tile goes through a wave-private LDS slab in four
 // 32-row quarters (lanes 16q..16q+15 own quarter q) and comes back in the column-owner layout of the MFMA operands.
+#ifndef KK_BUC_NT
+#define KK_BUC_NT 1     // non-temporal Win loads and T / W stores (every element moves once): block step -1.5 % in a same-box A/B
+#endif
+#if KK_BUC_NT
+#define BUC_LD_WIN ld2s
+#define BUC_ST st2s
+#else
+#define BUC_LD_WIN ld2
+#define BUC_ST st2
+#endif
 #define BUC_LD 34     // row stride (doubles) of a slab column: 32 rows + 2 (16-byte aligned, column starts 4 banks apart)
 template <int NB>
 __global__ __launch_bounds__(KK_TPB, 4) void k_block_update_commit(const double* V, int64_t ld, int m, const double* Win, double* Wout,
@@ -1009,7 +1029,7 @@ __global__ __launch_bounds__(KK_TPB, 4) void k_block_update_commit(const double*
         // so there is no register to hoist them into: measured 20 % of the kernel)
         d2 acc[NB];
 #pragma unroll
-        for (int j = 0; j < NB; ++j) acc[j] = (j < nb) ? ld2(Win + (int64_t)j * ldw + r) : d2{0.0, 0.0};
+        for (int j = 0; j < NB; ++j) acc[j] = (j < nb) ? BUC_LD_WIN(Win + (int64_t)j * ldw + r) : d2{0.0, 0.0};
         int c = 0;
         for (; c + 4 <= m; c += 4) {
             d2 x[4];
@@ -1054,7 +1074,7 @@ __global__ __launch_bounds__(KK_TPB, 4) void k_block_update_commit(const double*
         if (!commit) {     // uniform for the launch
 #pragma unroll
             for (int j = 0; j < NB; ++j)
-                if (j < nb) st2(Wout + (int64_t)j * ldw + r, acc[j]);
+                if (j < nb) BUC_ST(Wout + (int64_t)j * ldw + r, acc[j]);
             continue;
         }
         // t = w R1^-1 in place, last column first (t_j needs w_0 .. w_j only; R1^-1 is upper triangular, row-major in LDS)
@@ -1067,7 +1087,7 @@ __global__ __launch_bounds__(KK_TPB, 4) void k_block_update_commit(const double*
                 tx = fma(acc[i].x, sij, tx); ty = fma(acc[i].y, sij, ty);
             }
             acc[j].x = tx; acc[j].y = ty;
-            if (j < nb) st2(Tout + (int64_t)j * ldt + r, acc[j]);
+            if (j < nb) BUC_ST(Tout + (int64_t)j * ldt + r, acc[j]);
             __builtin_amdgcn_sched_barrier(0);      // keep the R1^-1 reads of one column together (else all 136 are hoisted: spills)
         }
         // G2 += t' t: quarter q of the wave's 128 rows is owned by lanes 16q .. 16q+15 (two rows each)
