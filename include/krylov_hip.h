@@ -103,6 +103,7 @@ typedef enum {
  * (kk_ctx_get_option: "persist_timeouts", "persist_skip"); "persist_capacity_rows" = rows of a work vector the register
  * file of the chip holds (longer vectors run the low-synchronisation form in auto mode).
  * Tuning knobs without semantic effect:
+ * "nt_store_rows" (results of sparse applies on at least this many rows are written with non-temporal stores, default 4e6),
  * "gram_bpc", "gram2_chunk", "gram2_pipe", "gram2_bpc", "spmm_bpc", "spmm_cols", "spmm_rpl", "spmm_dia_lines", "bu_prefetch", "gram_nt", "persist_nt",
  * "persist_lds", "persist_min_rows", "spmv_dia_pairs" (row pairs per lane of the diagonal SpMV: 0 = by size, 1 / 2 / 4).  Test hook: "persist_fault" (the next n persistent launches behave like a grid-barrier timeout). */
 

@@ -215,6 +215,9 @@ KK_API int kk_ctx_set_option(kk_ctx c, const char* key, double value) {
     } else if (!strcmp(key, "spmm_rpl")) {
         KK_CHECK(value == 1 || value == 2, KK_ERR_INVALID, "spmm_rpl must be 1 or 2");
         c->spmm_rpl = (int)value;
+    } else if (!strcmp(key, "nt_store_rows")) {
+        KK_CHECK(value >= 0, KK_ERR_INVALID, "nt_store_rows must be >= 0");
+        c->nt_store_rows = (int64_t)value;
     } else if (!strcmp(key, "block_commit")) {
         c->block_commit = value != 0;
     } else if (!strcmp(key, "resid_gram")) {
@@ -296,6 +299,7 @@ KK_API int kk_ctx_get_option(kk_ctx c, const char* key, double* value) {
     else if (!strcmp(key, "qr_skip_tol")) *value = c->qr_skip_tol;
     else if (!strcmp(key, "resid_gram")) *value = c->resid_gram;
     else if (!strcmp(key, "block_commit")) *value = c->block_commit;
+    else if (!strcmp(key, "nt_store_rows")) *value = (double)c->nt_store_rows;
     else if (!strcmp(key, "block_commits")) *value = (double)c->block_commits;
     else if (!strcmp(key, "last_qr_dev")) *value = c->last_qr_dev;
     else if (!strcmp(key, "gram_nt")) *value = c->gram_nt;

@@ -131,6 +131,7 @@ struct kk_ctx_s {
     bool gw_valid = false;
     uint64_t gw_basis = 0;   // uid of the slab
     int gw_col = -1, gw_p = 0;
+    int64_t nt_store_rows = 4000000;   // SpMV results of at least this many rows are written with non-temporal stores
     int resid_gram = 1;          // use it (0: always run the Gram pass)
     int block_commit = 1;        // one-pass block step: residual update writes T = W R1^-1 into the next basis slot (normalised commit)
     uint64_t tc_owner = 0;       // uid of the slab whose pending commit (R1, G2 = T'T) sits in the block scratch; 0 = none

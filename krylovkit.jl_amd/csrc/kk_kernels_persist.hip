@@ -143,11 +143,14 @@ __device__ __forceinline__ d2 bload(__amdgpu_buffer_rsrc_t r, unsigned voff, uns
     o.y = __longlong_as_double((long long)(((unsigned long long)t.w << 32) | t.z));
     return o;
 }
+#ifndef KK_PERSIST_ST_AUX
+#define KK_PERSIST_ST_AUX 2     // non-temporal commit store of the work vector (headline +0.75 % in a same-box A/B: the apply that follows runs faster)
+#endif
 __device__ __forceinline__ void bstore(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, d2 v) {
     const unsigned long long a = (unsigned long long)__double_as_longlong(v.x), b = (unsigned long long)__double_as_longlong(v.y);
     v4u t;
     t.x = (unsigned)a; t.y = (unsigned)(a >> 32); t.z = (unsigned)b; t.w = (unsigned)(b >> 32);
-    __builtin_amdgcn_raw_buffer_store_b128(t, r, voff, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(t, r, voff, soff, KK_PERSIST_ST_AUX);
 }
 // descriptor of one column.  The inputs are wave-uniform by construction; passing them through readfirstlane makes that
 // PROVABLE to the compiler (a loop-carried column pointer may otherwise be treated as divergent and every buffer access

@@ -2,6 +2,7 @@
 // on ELL for the block path.
 #include "kk_device.h"
 
+
 // ------------------------------------------------------------------------------------------
 // SpMV.  ELL (column-major, padded to `width`) with 2 rows per lane for regular matrices
 // (stencils); CSR with L lanes per row (L = 64 is row-per-wavefront) otherwise.
@@ -39,6 +40,9 @@ struct spmv_epi {
     const double* dvec;  // dot_mode 3: <dvec, y>
     int acc;             // column-tiled apply: 0 = whole matrix, 1 = first tile (y = raw sums), 2 = middle tile
                          // (y += raw sums), 3 = last tile (sum = y + raw, then the epilogue)
+    int nt_store;        // y is written with non-temporal stores: long vectors, whose next reader streams them anyway (the sweep
+                         // kernel that follows loses 1.4 % at 10M rows, same-box A/B: headline +1.1 %, general-format leg +1.1 %);
+                         // short vectors stay in the L2 for their reader
 };
 
 // gathered element of x; column indices >= n_local address the ghost buffer.  BRANCH-FREE (the address is selected, the
@@ -109,7 +113,7 @@ __global__ __launch_bounds__(KK_TPB) void k_spmv_ell(const int32_t* __restrict__
             if (e.dot_mode == 2) { dacc = fma(xv.x, out.x, dacc); dacc = fma(xv.y, out.y, dacc); }
             if (e.dot_mode == 3) { const d2 z = ld2(e.dvec + row); dacc = fma(z.x, out.x, dacc); dacc = fma(z.y, out.y, dacc); }
             if (e.want_nrm) { nacc = fma(out.x, out.x, nacc); nacc = fma(out.y, out.y, nacc); }
-            st2(y + row, out);
+            if (e.nt_store) st2s(y + row, out); else st2(y + row, out);
         }
     }
     if (e.dot_mode) {
@@ -215,7 +219,7 @@ __global__ __launch_bounds__(KK_TPB) void k_spmv_dia(const double* __restrict__ 
                 if (e.dot_mode == 2) { dacc = fma(xc.x, out.x, dacc); dacc = fma(xc.y, out.y, dacc); }
                 if (e.dot_mode == 3) { dacc = fma(zv[u].x, out.x, dacc); dacc = fma(zv[u].y, out.y, dacc); }
                 if (e.want_nrm) { nacc = fma(out.x, out.x, nacc); nacc = fma(out.y, out.y, nacc); }
-                st2(y + row, out);
+                if (e.nt_store) st2s(y + row, out); else st2(y + row, out);
             }
         }
     }
@@ -538,7 +542,7 @@ __device__ __forceinline__ double wave_from_right(double v) {   // lane l receiv
     hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
     return __hiloint2double(hi, lo);
 }
-template <int NB, int PTS, bool CONST>
+template <int NB, int PTS, bool CONST, bool NTY>
 __global__ __launch_bounds__(KK_TPB) void k_spmm_dia(const double* __restrict__ dval, int64_t dld, int64_t D, int64_t nrows,
                                                      const double* __restrict__ X, int64_t ldx, double* __restrict__ Y,
                                                      int64_t ldy, int nb, int strips, int lines, int64_t Tlo, int64_t T,
@@ -599,7 +603,10 @@ __global__ __launch_bounds__(KK_TPB) void k_spmm_dia(const double* __restrict__ 
                     a = fma(d[7], xp[j], a);
                     a = fma(d[8], wave_from_right(xp[j]), a);
                 }
-                if (st) Y[(int64_t)j * ldy + r] = a;
+                // (non-temporal for long blocks: the Gram pass that follows reads A X non-temporally and runs 9 % faster -- block
+                //  step -3 % in a same-box A/B; non-temporal LOADS of X make this kernel slower.  A template parameter: as a
+                //  run-time branch hipcc merges the two stores into one plain store)
+                if (st) { if (NTY) __builtin_nontemporal_store(a, Y + (int64_t)j * ldy + r); else Y[(int64_t)j * ldy + r] = a; }
             }
         }
 #pragma unroll
@@ -674,6 +681,7 @@ int kk_launch_spmv(kk_ctx ctx, const kk_sparse_dev& M, const double* x, double* 
     e.ghost = M.ghost;
     e.dvec = f.dot_vec;
     e.acc = 0;
+    e.nt_store = (M.nrows >= ctx->nt_store_rows) ? 1 : 0;
     double* pd = part_row(ctx, PART_SCAL_A);
     double* pn = part_row(ctx, PART_SCAL_B);
     int nblk = 0;
@@ -797,15 +805,17 @@ int kk_launch_spmm(kk_ctx ctx, const kk_sparse_dev& M, const double* X, int64_t 
             double* y = Y + (int64_t)j0 * ldy;
             kk_prof_scope ps(ctx, "k_spmm_dia");
 #define DIA_ARGS M.dia_val, M.dia_ld, M.dia_D, M.nrows, x, ldx, y, ldy, n, strips, lines, Tlo, T, row_lo, row_hi, cst
-#define DIA_CASE(NBT) \
-            if (cc) { if (M.dia_pts == 5) hipLaunchKernelGGL((k_spmm_dia<NBT, 5, true>), g, b, 0, ctx->stream, DIA_ARGS); \
-                      else hipLaunchKernelGGL((k_spmm_dia<NBT, 9, true>), g, b, 0, ctx->stream, DIA_ARGS); } \
-            else { if (M.dia_pts == 5) hipLaunchKernelGGL((k_spmm_dia<NBT, 5, false>), g, b, 0, ctx->stream, DIA_ARGS); \
-                   else hipLaunchKernelGGL((k_spmm_dia<NBT, 9, false>), g, b, 0, ctx->stream, DIA_ARGS); }
+#define DIA_CASE2(NBT, NTY) \
+            if (cc) { if (M.dia_pts == 5) hipLaunchKernelGGL((k_spmm_dia<NBT, 5, true, NTY>), g, b, 0, ctx->stream, DIA_ARGS); \
+                      else hipLaunchKernelGGL((k_spmm_dia<NBT, 9, true, NTY>), g, b, 0, ctx->stream, DIA_ARGS); } \
+            else { if (M.dia_pts == 5) hipLaunchKernelGGL((k_spmm_dia<NBT, 5, false, NTY>), g, b, 0, ctx->stream, DIA_ARGS); \
+                   else hipLaunchKernelGGL((k_spmm_dia<NBT, 9, false, NTY>), g, b, 0, ctx->stream, DIA_ARGS); }
+#define DIA_CASE(NBT) if (M.nrows >= ctx->nt_store_rows) { DIA_CASE2(NBT, true) } else { DIA_CASE2(NBT, false) }
             if (n > 8) { DIA_CASE(16) }
             else if (n > 4) { DIA_CASE(8) }
             else { DIA_CASE(4) }
 #undef DIA_CASE
+#undef DIA_CASE2
 #undef DIA_ARGS
             j0 += n;
         }
