@@ -329,6 +329,10 @@ int blk_commit_flush(kk_basis b) {
     if (!b || !b->tc_valid) return KK_OK;
     b->tc_valid = false;
     if (b->ctx->tc_owner == b->uid) b->ctx->tc_owner = 0;
+    // not consumed.  Once is normal (a restart looks at the block); twice in a row means the caller looks after every step:
+    // pause the commits, longer each time, until one is consumed again
+    if (b->tc_streak >= 1) b->tc_skip = 2 << std::min(b->tc_streak, 5);
+    ++b->tc_streak;
     const int p = b->tc_p;
     return block_update_run(b->ctx, b->col(b->tc_k), b->ld, p, b->col(b->tc_cr), b->ld, p, b->tc_R1, p, 1.0, 0.0, nullptr);
 }
@@ -371,7 +375,9 @@ static int blocklanczos_expand_async(kk_op op, kk_basis b, int k, int p, int c_r
     // the panels small enough for the update kernel's LDS.  A X is then formed IN that slot and updated in place (the
     // read-modify-write of one 16-column area keeps the DRAM pages of the update's read and write streams together)
     const int st0 = kk_bu_stride(p);
-    const bool try_tc = onepass && c->block_commit && c->resid_gram && kn + p <= std::min(c_r, c_rnext) && kn + p <= b->cap &&
+    const bool tc_pause = b->tc_skip > 0;
+    if (tc_pause) --b->tc_skip;
+    const bool try_tc = !tc_pause && onepass && c->block_commit && c->resid_gram && kn + p <= std::min(c_r, c_rnext) && kn + p <= b->cap &&
                         ((size_t)kn * st0 + 64 + st0 * st0 + 4 * 16 * 34) * sizeof(double) <= 64 * 1024;
     if (onepass) {   // Gram rows of the basis columns [0, k): known from the previous steps, recomputed after a restart
         if (b->gram_c0 != 0) { b->gram_c0 = 0; b->gram_rows = 0; }
@@ -478,7 +484,7 @@ readback:
     // where the block in columns k.. stands if this step has to be repeated: 0 = T (second round not applied), 1 = Q = T R2^-1
     if (qr_state) *qr_state = (H[0] == 2.0 || H[1] != 0.0) ? 0 : 1;
     if (!*fine) return KK_OK;
-    if (take_tc) c->block_commits++;
+    if (take_tc) { c->block_commits++; b->tc_streak = 0; }
     if (try_tc && H[AB_CF - AB_BASE] != 0.0)   // not committed (decided on the device): the plain block sits in the basis slot
         KK_HIP(hipMemcpyAsync(b->col(c_rnext), b->col(kn), (size_t)p * ld * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     if (try_tc && H[AB_CF - AB_BASE] == 0.0) {   // committed: columns kn.. hold T, the residual area is not written at all

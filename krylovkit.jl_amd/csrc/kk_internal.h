@@ -222,6 +222,8 @@ struct kk_basis_s {
     // T = W R1^-1, the residual area at tc_cr still holds A X; W = T R1 is formed on demand (blk_commit_flush, kk_host.h)
     bool tc_valid = false;
     int tc_k = -1, tc_cr = -1, tc_p = 0;
+    int tc_skip = 0, tc_streak = 0;   // steps that shall NOT commit / commits settled in a row without one being consumed: a caller that
+                                      // looks at the residual block after every step turns each commit into an extra pass
     double tc_R1[256];   // column-major, leading dimension tc_p
     inline double* col(int c) const { return d + (int64_t)c * ld; }
 };

@@ -63,8 +63,10 @@ def test_looking_at_the_residual_block_settles_the_commit(kk, ko, ctx):
     A, n = problem(ko)
     rng = np.random.default_rng(41)
     x0 = [rng.random(n) for _ in range(4)]
-    a = run(kk, ctx, A, x0, 5, commit=1, look=True)
-    b = run(kk, ctx, A, x0, 5, commit=0, look=True)
+    # 12 steps: after two settled commits in a row the library pauses committing (2 << streak steps), so this also runs the
+    # plain step in between and the re-armed commit afterwards
+    a = run(kk, ctx, A, x0, 12, commit=1, look=True)
+    b = run(kk, ctx, A, x0, 12, commit=0, look=True)
     ctx.set_option("block_commit", 1)
     assert a["commits"] == 0                 # every commit was flushed before the next expand! could take it
     assert np.max(np.abs(a["H"] - b["H"])) < 1e-11 * np.max(np.abs(b["H"]))
