@@ -387,25 +387,23 @@ static int blocklanczos_expand_async(kk_op op, kk_basis b, int k, int p, int c_r
     KK_HIP(hipMemsetAsync(D + AB_FLAG, 0, 4 * sizeof(double), c->stream));
     if (!take_tc) c->tc_owner = 0;   // this step rewrites the scratch a pending commit of another slab would need
     // ---- block_qr! as CholQR2, out of place: residual block (c_r) -> new basis block (columns k..k+p-1)
-    if (take_tc) {
-        // normalised commit of the previous step: columns k..k+p-1 hold T = W R1^-1 already, AB_R1 its factor and AB_G the
-        // (not yet all-reduced) Gram matrix T'T -- the first CholQR2 round costs nothing here
-    } else if (use_gw) {   // the previous step left the Gram matrix of this very block behind (all-reduced already)
-        KK_HIP(hipMemcpyAsync(D + AB_G, D + AB_GW, (size_t)p * p * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-    } else {
-        KK_TRY(kk_launch_block_gram(c, b->col(c_r), ld, p, b->col(c_r), ld, p, ld, D + AB_G, p));
-        KK_TRY(kk_allreduce(c, D + AB_G, (int64_t)p * p));
-    }
-    if (take_tc) {
-    } else {
-    KK_TRY(kk_launch_blk_chol1(c, D + AB_G, p, 1000.0 * qr_tol, D + AB_R1, D + AB_S1, st, D + AB_FLAG));
-    if (c->block_fuse & 1) {   // Q1 = B R1^-1 written and G2 = Q1'Q1 accumulated in ONE pass over the block
-        KK_TRY(kk_launch_block_gram_tile(c, nullptr, 0, p, nullptr, 0, b->col(c_r), ld, p, D + AB_S1, st, 1.0, 0.0, b->col(k), ld, p,
-                                         ld, D + AB_G, 1, p));
-    } else {
-        KK_TRY(kk_launch_block_update(c, b->col(c_r), ld, p, nullptr, b->col(k), ld, ld, p, D + AB_S1, 1.0, 0.0, nullptr));
-        KK_TRY(kk_launch_block_gram(c, b->col(k), ld, p, b->col(k), ld, p, ld, D + AB_G, p));
-    }
+    // (after a normalised commit of the previous step columns k..k+p-1 hold T = W R1^-1 already, AB_R1 its factor and AB_G the
+    //  not yet all-reduced Gram matrix T'T: the first CholQR2 round costs nothing)
+    if (!take_tc) {
+        if (use_gw) {   // the previous step left the Gram matrix of this very block behind (all-reduced already)
+            KK_HIP(hipMemcpyAsync(D + AB_G, D + AB_GW, (size_t)p * p * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        } else {
+            KK_TRY(kk_launch_block_gram(c, b->col(c_r), ld, p, b->col(c_r), ld, p, ld, D + AB_G, p));
+            KK_TRY(kk_allreduce(c, D + AB_G, (int64_t)p * p));
+        }
+        KK_TRY(kk_launch_blk_chol1(c, D + AB_G, p, 1000.0 * qr_tol, D + AB_R1, D + AB_S1, st, D + AB_FLAG));
+        if (c->block_fuse & 1) {   // Q1 = B R1^-1 written and G2 = Q1'Q1 accumulated in ONE pass over the block
+            KK_TRY(kk_launch_block_gram_tile(c, nullptr, 0, p, nullptr, 0, b->col(c_r), ld, p, D + AB_S1, st, 1.0, 0.0, b->col(k), ld, p,
+                                             ld, D + AB_G, 1, p));
+        } else {
+            KK_TRY(kk_launch_block_update(c, b->col(c_r), ld, p, nullptr, b->col(k), ld, ld, p, D + AB_S1, 1.0, 0.0, nullptr));
+            KK_TRY(kk_launch_block_gram(c, b->col(k), ld, p, b->col(k), ld, p, ld, D + AB_G, p));
+        }
     }
     KK_TRY(kk_allreduce(c, D + AB_G, (int64_t)p * p));
     KK_TRY(kk_launch_blk_chol2(c, D + AB_G, p, D + AB_R1, D + AB_B, 16, D + AB_S2, D + AB_S3, st, D + AB_FLAG));
