@@ -64,18 +64,24 @@ typedef enum {
 } kk_orth_t;
 
 /* How the MGS family is executed on the device (kk_ctx_set_option("mgs_mode", v)):
- *   0 = strict:   sequential as in src/orthonormal.jl:417-421, one basis vector after the other: a persistent
- *                 cooperative kernel that keeps w in registers for the whole sweep and parks the current basis vector on
- *                 chip (LDS + spare registers) between its two uses, so that HBM sees ~1.3 reads per basis vector
- *                 (10.5 N bytes / vector at N = 10^7; options "mgs_persist", default 1, "persist_threads" 512 / 1024,
- *                 "persist_lds" 0 / 1 / 2); when w does not fit the register file of the chip, or the context is
- *                 row-sharded, one fused axpy+dot kernel per vector (32 N bytes).
+ *   0 = strict:   sequential as in src/orthonormal.jl:417-421, one basis vector after the other: a persistent kernel
+ *                 (one block per CU, an ordinary launch; "persist_coop" 1 = cooperative launch) that keeps w in registers
+ *                 for the whole sweep and parks the current basis vector on chip (LDS + spare registers; the remaining rows
+ *                 are re-read from the L2) between its two uses, so that HBM sees one read per basis vector (8 N bytes /
+ *                 vector at N = 10^7; options "mgs_persist", default 1, "persist_threads" 512 / 1024, "persist_lds"
+ *                 0 / 1 / 2); when w does not fit the register file of the chip ("persist_capacity_rows"), or the context
+ *                 is row-sharded, one fused axpy+dot kernel per vector (32 N bytes).
  *   1 = lowsync:  algebraically identical MGS coefficients from ONE projection pass plus a
  *                 triangular solve (on the device) with the strictly-lower Gram matrix of the
  *                 basis, maintained incrementally (16 N bytes / vector).
- *   2 = auto:     (default) strict through the persistent kernel wherever that is the faster of the two -- the work vector
- *                 fits the chip, the context is not row-sharded and the vectors have >= "persist_min_rows" (4e6) rows, so
- *                 that the saved basis traffic outweighs one grid reduction per vector -- and lowsync otherwise. */
+ *   2 = auto:     (default) by vector length on an unsharded context: the persistent PANEL kernel ("mgs_panel", default 1:
+ *                 w in registers, "panel_width" = 2-3 basis vectors per grid reduction with the exact in-panel triangular
+ *                 correction, every basis vector read once) from "panel_min_rows" (1.4e6) rows up to its capacity
+ *                 ("panel_capacity_rows", 4.19e6 on 256 CUs), the strict persistent kernel from "persist_min_rows" (3.6e6)
+ *                 rows up to "persist_capacity_rows" (10.48e6), lowsync otherwise (shorter and longer vectors, row-sharded
+ *                 contexts).  "lookahead" (default 1): a fused Lanczos / Arnoldi expand! whose sweep runs through a
+ *                 persistent kernel enqueues the NEXT step's apply, sweep and read-back before the host waits for the
+ *                 current one (bit-identical results; dropped if anything touches the slab in between). */
 /* Other kk_ctx_set_option keys: "blocks_per_cu" (grid of the streaming kernels, default 4), "block_mode" (0 strict
  * block QR / re-orthogonalisation, 1 MFMA panels + CholQR2, default), "fuse_passes", "speculate" (next-step SpMV
  * enqueued before the host reads alpha/beta), "keep_mb" (MB of trailing basis columns a project pass leaves
