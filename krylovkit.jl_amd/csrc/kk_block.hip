@@ -518,13 +518,19 @@ KK_API int kk_blocklanczos_expand(kk_op op, kk_basis b, int k, int bs_r, int c_r
         kk_ctx cc = b->ctx;
         take_tc = cc->tc_owner == b->uid && b->tc_k == k && b->tc_cr == c_r && b->tc_p == bs_r && cc->block_mode == 1 && cc->block_async &&
                   (cc->block_fuse & 4) && cc->block_commit && bs_r >= 2 && bs_r <= 16 && k + bs_r <= KK_MAX_M;
-        if (take_tc) b->tc_valid = false;
     }
-    CHECK_BLOCK(b, 0, k + bs_r); CHECK_BLOCK(b, c_r, bs_r); CHECK_BLOCK(b, c_rnext, bs_r);
+    // argument validation FIRST, without side effects: an early error return must leave a pending commit pending (ADVICE r4 --
+    // with the flag cleared before the checks a rejected call lost the commit: the residual area still held A X and nothing
+    // formed W = T R1 afterwards)
+    KK_CHECK(b && k >= 0 && bs_r >= 0 && k + bs_r <= b->cap && c_r >= 0 && c_r + bs_r <= b->cap && c_rnext >= 0 && c_rnext + bs_r <= b->cap,
+             KK_ERR_INVALID, "kk_blocklanczos_expand: block [%d,%d), [%d,%d) or [%d,%d) outside capacity %d", 0, k + bs_r, c_r, c_r + bs_r,
+             c_rnext, c_rnext + bs_r, b ? b->cap : 0);
     KK_CHECK(k >= bs_r && bs_r >= 1 && bs_next && B && M && norm_R && ldb >= bs_r && ldm >= bs_r, KK_ERR_INVALID,
              "kk_blocklanczos_expand: bad arguments");
     KK_CHECK(c_r >= k + bs_r && c_rnext >= k + bs_r && (c_rnext + bs_r <= c_r || c_r + bs_r <= c_rnext), KK_ERR_INVALID,
              "kk_blocklanczos_expand: residual blocks must lie beyond column k+bs_r and not overlap");
+    if (take_tc) b->tc_valid = false;   // consumed by this call (every check has passed)
+    KK_TRY(norm_flush(b));              // anything else that is pending on the slab is settled first
     kk_ctx c = b->ctx;
     // cached Gram matrix of the incoming residual block (read before gram_touch, which drops it): only this very block,
     // untouched since the step that produced it

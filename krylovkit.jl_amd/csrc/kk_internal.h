@@ -165,7 +165,8 @@ struct kk_ctx_s {
     int* h_sync = nullptr;       // pinned: read-back of the error flag
     bool persist_pending = false;  // a persistent launch has not been checked for a barrier timeout yet
     int persist_slot = 0;          // pinned slot its scalars (and completion token) were fetched into
-    double persist_token = 0;      // token of the last launch (a launch that committed wrote it to SC_PERSIST_OK)
+    double persist_token = 0;      // token COUNTER: the last launch enqueued (a launch that committed wrote its token to SC_PERSIST_OK)
+    double persist_check_token = 0;  // token of the launch `persist_pending` refers to (a run-ahead launch behind it has its own: la_token)
     unsigned persist_epoch = 0;    // epochs handed out so far: tags of the grid reductions are unique over the life of the context
     bool persist_norm_req = false; // the caller of the sweep wants w / |w| stored (expand!'s scale of the next step, orthonormalize!!)
     bool persist_norm_done = false;  // ... and the last sweep went through a launch that was asked to do so

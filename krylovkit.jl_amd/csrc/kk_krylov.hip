@@ -163,15 +163,25 @@ static int la_enqueue(kk_op op, kk_basis b, int c0, int j, int nsweeps, bool lan
     const int64_t offs[2] = {WS_S, WS_G};
     c->persist_norm_req = true;
     const bool was_done = c->persist_norm_done;
+    // The CURRENT step's launch may still be waiting for its check (persist_pending, slot 0, its token): the nested sweep below
+    // must not take its place -- the caller's persist_check has to look at THAT launch (with the bookkeeping
+    // overwritten here a barrier timeout of the first launch of a run-ahead chain went unnoticed).  The launch enqueued ahead
+    // is identified by (la_slot, la_token) and checked by the next call.
+    const bool cur_pending = c->persist_pending;
+    const int cur_slot = c->persist_slot;
+    const double cur_token = c->persist_check_token;
+    c->persist_pending = false;
     const int st = pass_mgs_strict_sweeps(c, b->col(c0), b->ld, m, nsweeps, b->col(c0 + j + 1), offs, true, slot,
                                           lanczos_carry ? b->col(c0 + j) : nullptr, lanczos_carry ? c->ws + WS_SCAL + SC_ALPHA0 : nullptr);
+    const bool ahead_persistent = c->persist_pending;
+    const double ahead_token = c->persist_check_token;
+    c->persist_pending = cur_pending; c->persist_slot = cur_slot; c->persist_check_token = cur_token;
     c->persist_norm_req = false;
     c->persist_norm_done = was_done;   // (describes the sweep of the CURRENT step until the caller has read it)
     KK_TRY(st);
-    if (!c->persist_pending) return KK_OK;   // (took the launch-per-vector route: results are simply not used ahead)
-    c->persist_pending = false;              // this launch is checked through (slot, token) by the next call
+    if (!ahead_persistent) return KK_OK;   // (took the launch-per-vector route: results are simply not used ahead)
     KK_HIP(hipEventRecord(c->ev_la[slot & 1], c->stream));
-    b->la_valid = true; b->la_k = j; b->la_slot = slot; b->la_token = c->persist_token; b->la_nsweeps = nsweeps;
+    b->la_valid = true; b->la_k = j; b->la_slot = slot; b->la_token = ahead_token; b->la_nsweeps = nsweeps;
     return KK_OK;
 }
 

@@ -249,6 +249,7 @@ int pass_mgs_strict_sweeps(kk_ctx c, const double* V, int64_t ld, int m, int nsw
                                              want_norm ? SCP(c, SC_NRM2) : nullptr, normalize));
             c->persist_pending = true;
             c->persist_slot = slot;
+            c->persist_check_token = c->persist_token;
             c->persist_norm_done = normalize;
             // ONE read-back from the first coefficient area through the named scalars (alpha0, |w|^2, |w|, 1/|w|, ... and the
             // completion token of the launch): a D2H copy costs ~4.5 us on the stream whatever its size, and the areas in
@@ -299,7 +300,7 @@ int persist_check(kk_ctx c, bool* timed_out) {
     *timed_out = false;
     if (!c->persist_pending) return KK_OK;
     c->persist_pending = false;
-    return persist_check_at(c, c->persist_slot, c->persist_token, timed_out);
+    return persist_check_at(c, c->persist_slot, c->persist_check_token, timed_out);
 }
 // strict sweeps + the synchronisation that ends them, with the recovery above folded in (no speculation involved)
 static int strict_sweeps_synced(kk_ctx c, const double* V, int64_t ld, int m, int nsweeps, double* w, const int64_t* ws_s,

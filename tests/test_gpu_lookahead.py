@@ -152,3 +152,49 @@ def test_arnoldi_timeout_of_a_step_enqueued_ahead(kk, ko, lctx):
     assert np.max(np.abs(np.asarray(f.H) - np.asarray(of.H))) < 1e-10 * np.max(np.abs(of.H))
     V = f.V.to_numpy()
     assert np.max(np.abs(V.T @ V - np.eye(V.shape[1]))) < 1e-12
+
+
+@pytest.mark.parametrize("case", ["lanczos", "arnoldi_mgs", "arnoldi_mgs2"])
+@pytest.mark.parametrize("fault_steps", [(0,), (0, 9), (3,)])
+def test_timeout_of_the_first_launch_of_a_run_ahead_chain(kk, ko, lctx, case, fault_steps):
+    """the launch of the CURRENT step times out while the step enqueued behind it goes out -- the
+    first expand! after initialize (fault at 0), the first one after an interruption that dropped the chain (residual read
+    at step 8 -> fault at 9) and, for comparison, a launch in the middle of a chain (3: that one was enqueued ahead).  The
+    nested sweep of la_enqueue used to overwrite (slot, token) of the current launch and clear its pending check: the
+    timeout went unnoticed and stale alpha / beta came back with an unorthogonalised column marked as a basis vector."""
+    steps = 16
+    lctx.set_option("lookahead", 1)
+    if case == "lanczos":
+        A = ko.laplacian_2d(44, 36, shift_diag=10 * np.linspace(0, 1, 44 * 36) ** 2)
+        x0 = np.random.default_rng(11).random(A.shape[0])
+        it = kk.LanczosIterator(kk.SparseOperator(A, lctx, symmetric=True), x0, kk.ModifiedGramSchmidt2(), capacity=steps + 3)
+        oit = ko.LanczosIterator(A, x0.copy(), ko.MGS2)
+        of = ko.lanczos_initialize(oit)
+        oexp = ko.lanczos_expand
+    else:
+        dev, ref = (kk.ModifiedGramSchmidt(), ko.MGS) if case == "arnoldi_mgs" else (kk.ModifiedGramSchmidt2(), ko.MGS2)
+        A = ko.convection_diffusion_2d(40, 32)
+        x0 = np.random.default_rng(12).random(A.shape[0])
+        it = kk.ArnoldiIterator(kk.SparseOperator(A, lctx), x0, dev, capacity=steps + 3)
+        oit = ko.ArnoldiIterator(A, x0.copy(), ref)
+        of = ko.arnoldi_initialize(oit)
+        oexp = ko.arnoldi_expand
+    f = kk.initialize(it)
+    t0 = lctx.get_option("persist_timeouts")
+    for i in range(steps):
+        if i in fault_steps:
+            lctx.set_option("persist_fault", 1)
+        f = kk.expand_(it, f)
+        of = oexp(oit, of)
+        if i == 8:
+            r = f.r.get()     # drops the run-ahead: step 9 starts a new chain
+            assert np.max(np.abs(r - of.r)) < 1e-10 * np.linalg.norm(of.r)
+    assert lctx.get_option("persist_timeouts") - t0 == len(fault_steps)
+    if case == "lanczos":
+        assert np.max(np.abs(np.array(f.alphas) - of.alphas) / np.abs(of.alphas)) < 1e-10
+        assert np.max(np.abs(np.array(f.betas) - of.betas) / np.abs(of.betas)) < 1e-10
+    else:
+        assert np.max(np.abs(np.asarray(f.H) - np.asarray(of.H))) < 1e-10 * np.max(np.abs(of.H))
+        assert abs(f.normres - of.normres) < 1e-10 * abs(of.normres)
+    V = f.V.to_numpy()
+    assert np.max(np.abs(V.T @ V - np.eye(V.shape[1]))) < 1e-12
