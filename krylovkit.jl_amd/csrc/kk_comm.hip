@@ -10,6 +10,7 @@
 #include "kk_host.h"
 #include <dlfcn.h>
 #include <mutex>
+#include <unistd.h>
 #include <rccl/rccl.h>
 
 namespace {
@@ -94,6 +95,112 @@ KK_API int kk_comm_get_unique_id(void* id128) {
     return KK_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// cross-rank in-kernel reduction (kk_xsync.h): every rank allocates a small sync area in fine-grained device memory,
+// the ranks exchange its IPC handle through the communicator and map each other's area.  The feature is switched on only
+// when EVERY rank succeeded (agreed by an all-reduce of the local status): the sequence of collectives issued here is the
+// same on every rank whatever happens locally.
+// ------------------------------------------------------------------------------------------
+namespace {
+struct xs_record {            // what a rank tells the others (13 x 8 bytes)
+    int64_t ok, pid, dev, ptr;
+    char handle[72];          // hipIpcMemHandle_t (64 bytes) + padding to a multiple of 8
+};
+static_assert(sizeof(hipIpcMemHandle_t) <= 72 && sizeof(xs_record) % 8 == 0, "xs_record layout");
+}
+static void xs_release(kk_ctx c) {
+    kk_comm_s* k = c->comm;
+    if (!k) return;
+    for (int r = 0; r < KK_XS_MAX_RANKS; ++r) {
+        if (k->xs_peer[r] && k->xs_peer[r] != (void*)k->xs_mine && k->xs_opened[r]) (void)hipIpcCloseMemHandle(k->xs_peer[r]);
+        k->xs_peer[r] = nullptr; k->xs_opened[r] = false;
+    }
+    if (k->xs_table) (void)hipFree(k->xs_table);
+    if (k->xs_mine) (void)hipFree(k->xs_mine);
+    k->xs_table = nullptr; k->xs_mine = nullptr; k->xs_active = false;
+}
+static int xs_setup(kk_ctx c) {
+    kk_comm_s* k = c->comm;
+    const char* env = getenv("KK_XSYNC");
+    int local_ok = (k->world <= KK_XS_MAX_RANKS && !(env && atoi(env) == 0)) ? 1 : 0;
+    xs_record mine;
+    memset(&mine, 0, sizeof(mine));
+    if (local_ok) {
+        if (hipExtMallocWithFlags((void**)&k->xs_mine, KK_XS_BYTES, hipDeviceMallocFinegrained) != hipSuccess) { (void)hipGetLastError(); k->xs_mine = nullptr; local_ok = 0; }
+    }
+    if (local_ok && hipMemset(k->xs_mine, 0, KK_XS_BYTES) != hipSuccess) local_ok = 0;
+    if (local_ok && k->world > 1) {
+        hipIpcMemHandle_t h;
+        if (hipIpcGetMemHandle(&h, k->xs_mine) != hipSuccess) { (void)hipGetLastError(); local_ok = 0; }
+        else memcpy(mine.handle, &h, sizeof(h));
+    }
+    mine.ok = local_ok; mine.pid = (int64_t)getpid(); mine.dev = c->device; mine.ptr = (int64_t)(uintptr_t)k->xs_mine;
+    // all-gather of the records (a world-1 communicator copies): staged in the block scratch, which nothing uses right now
+    const int64_t nw = sizeof(xs_record) / 8;
+    int64_t* d_send = (int64_t*)c->blk;
+    int64_t* d_recv = d_send + 64;
+    KK_HIP(hipMemcpyAsync(d_send, &mine, sizeof(mine), hipMemcpyHostToDevice, c->stream));
+    KK_HIP(hipStreamSynchronize(c->stream));
+    KK_TRY(kk_comm_allgather_i64(c, d_send, d_recv, nw));
+    std::vector<xs_record> all((size_t)k->world);
+    KK_HIP(hipMemcpyAsync(all.data(), d_recv, sizeof(xs_record) * (size_t)k->world, hipMemcpyDeviceToHost, c->stream));
+    KK_HIP(hipStreamSynchronize(c->stream));
+    int status = KK_OK;
+    for (int r = 0; r < k->world && local_ok; ++r) if (!all[r].ok) local_ok = 0;
+    for (int r = 0; r < k->world && local_ok; ++r) {
+        if (r == k->rank) { k->xs_peer[r] = k->xs_mine; continue; }
+        if (all[r].pid == mine.pid) {   // another context of this process (one thread per GPU): same address space, no IPC mapping
+            if ((int)all[r].dev != c->device) {
+                hipError_t e = hipDeviceEnablePeerAccess((int)all[r].dev, 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) local_ok = 0;
+                (void)hipGetLastError();
+            }
+            k->xs_peer[r] = (void*)(uintptr_t)all[r].ptr;
+            continue;
+        }
+        hipIpcMemHandle_t h;
+        memcpy(&h, all[r].handle, sizeof(h));
+        void* p = nullptr;
+        if (hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); local_ok = 0; }
+        else { k->xs_peer[r] = p; k->xs_opened[r] = true; }
+    }
+    if (local_ok) {
+        unsigned long long tab[KK_XS_MAX_RANKS] = {};
+        for (int r = 0; r < k->world; ++r) tab[r] = (unsigned long long)(uintptr_t)k->xs_peer[r];
+        if (hipMalloc((void**)&k->xs_table, sizeof(tab)) != hipSuccess || hipMemcpy(k->xs_table, tab, sizeof(tab), hipMemcpyHostToDevice) != hipSuccess) local_ok = 0;
+    }
+    int worst = KK_OK;
+    status = kk_comm_agree_status(c, local_ok ? KK_OK : KK_ERR_UNSUPPORTED, &worst);
+    if (status != KK_OK || worst != KK_OK) { xs_release(c); return status; }   // (not an error of kk_comm_init: the RCCL route serves)
+    // hand-shake through the mapped areas (every rank is here: the all-reduce above has just completed on all of them)
+    kk_xs_dev a;
+    a.table = k->xs_table; a.mine = k->xs_mine; a.tag0 = 1u; a.launch = 1u; a.rank = k->rank; a.world = k->world;
+    int* d_out = (int*)(d_send + 512);
+    KK_HIP(hipMemsetAsync(d_out, 0, sizeof(int), c->stream));
+    KK_TRY(kk_launch_xs_selftest(c, a, d_out));
+    int h_out = 0;
+    KK_HIP(hipMemcpyAsync(&h_out, d_out, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    KK_HIP(hipStreamSynchronize(c->stream));
+    k->xs_red = 4; k->xs_launch = 1;
+    status = kk_comm_agree_status(c, h_out == 1 ? KK_OK : KK_ERR_UNSUPPORTED, &worst);
+    if (status != KK_OK || worst != KK_OK) { xs_release(c); return status; }
+    k->xs_active = true;
+    return KK_OK;
+}
+kk_xs_dev kk_xs_launch_args(kk_ctx ctx, unsigned nred) {
+    kk_xs_dev a;
+    if (!kk_sharded(ctx) || !kk_xs_on(ctx)) return a;
+    kk_comm_s* k = ctx->comm;
+    a.table = k->xs_table; a.mine = k->xs_mine;
+    a.tag0 = k->xs_red + 1u;
+    k->xs_red += nred;
+    if (++k->xs_launch == 0) ++k->xs_launch;   // (0 is the "no abort" value of the error word)
+    a.launch = k->xs_launch;
+    a.rank = k->rank; a.world = k->world;
+    ++k->n_xs_launches;
+    return a;
+}
+
 KK_API int kk_comm_init(kk_ctx c, const void* id128, int rank, int world, int flags) {
     KK_CHECK(c && id128, KK_ERR_INVALID, "kk_comm_init: null arg");
     KK_CHECK(world >= 1 && rank >= 0 && rank < world, KK_ERR_INVALID, "kk_comm_init: rank %d of %d", rank, world);
@@ -111,6 +218,10 @@ KK_API int kk_comm_init(kk_ctx c, const void* id128, int rank, int world, int fl
     k->active = world > 1 || (flags & KK_COMM_FORCE_COLLECTIVES) != 0;
     c->comm = k;
     c->spec_owner = nullptr;   // a speculative apply enqueued before the switch carries an un-sharded alpha
+    if (k->active) {           // in-kernel sum over the ranks for the persistent MGS kernels (falls back to the RCCL routes when unavailable)
+        const int st = xs_setup(c);
+        if (st != KK_OK) { (void)kk_comm_destroy(c); return st; }
+    }
     return KK_OK;
 }
 
@@ -120,6 +231,7 @@ KK_API int kk_comm_destroy(kk_ctx c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     ncclComm_t comm = (ncclComm_t)c->comm->nccl;
+    xs_release(c);
     delete c->comm;
     c->comm = nullptr;
     c->spec_owner = nullptr;

@@ -85,6 +85,7 @@ KK_API int kk_ctx_create(int device, kk_ctx* out) {
     kk_ctx c = new kk_ctx_s();
     c->device = device;
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    c->dev_cus = c->num_cus;
     const int st = ctx_allocate(c);
     if (st != KK_OK) {   // release whatever was created before the failing call
         const std::string msg = kk_last_error();
@@ -103,6 +104,8 @@ KK_API int kk_ctx_create(int device, kk_ctx* out) {
     if (env && (atoi(env) == 512 || atoi(env) == 1024)) c->persist_threads = atoi(env);
     env = getenv("KK_PERSIST_NT");
     if (env) c->persist_nt = atoi(env) != 0;
+    env = getenv("KK_NUM_CUS");   // a process confined to part of the chip (HSA_CU_MASK, a partition mode) says how many CUs it owns
+    if (env && atoi(env) >= 1 && atoi(env) <= c->dev_cus) c->num_cus = atoi(env);
     *out = c;
     return KK_OK;
 }
@@ -168,6 +171,14 @@ KK_API int kk_ctx_set_option(kk_ctx c, const char* key, double value) {
         c->persist_skip = 0;
     } else if (!strcmp(key, "persist_coop")) {
         c->persist_coop = value != 0;
+    } else if (!strcmp(key, "num_cus")) {
+        // CUs this context may count on (a GPU shared between ranks / jobs: HSA_CU_MASK, CU-masked streams): the persistent
+        // kernels launch one block per CU and need all of them resident at once
+        KK_CHECK(value >= 1 && value <= c->dev_cus, KK_ERR_INVALID, "num_cus must be in 1..%d", c->dev_cus);
+        KK_HIP(hipStreamSynchronize(c->stream));
+        c->num_cus = (int)value;
+    } else if (!strcmp(key, "xsync")) {
+        c->xsync = value != 0;   // (must be set to the same value on every rank)
     } else if (!strcmp(key, "lookahead")) {
         c->lookahead = value != 0;
     } else if (!strcmp(key, "mgs_panel")) {
@@ -262,6 +273,10 @@ KK_API int kk_ctx_get_option(kk_ctx c, const char* key, double* value) {
     if (!strcmp(key, "blocks_per_cu")) *value = c->blocks_per_cu;
     else if (!strcmp(key, "mgs_mode")) *value = c->mgs_mode;
     else if (!strcmp(key, "num_cus")) *value = c->num_cus;
+    else if (!strcmp(key, "device_cus")) *value = c->dev_cus;
+    else if (!strcmp(key, "xsync")) *value = c->xsync;
+    else if (!strcmp(key, "xsync_active")) *value = kk_xs_on(c) ? 1 : 0;
+    else if (!strcmp(key, "xsync_launches")) *value = c->comm ? (double)c->comm->n_xs_launches : 0.0;
     else if (!strcmp(key, "block_mode")) *value = c->block_mode;
     else if (!strcmp(key, "block_async")) *value = c->block_async;
     else if (!strcmp(key, "block_fuse")) *value = c->block_fuse;

@@ -85,6 +85,23 @@ int kk_hip_fail(hipError_t e, const char* what, const char* file, int line);
         if (_s != KK_OK) return _s; \
     } while (0)
 
+// ---- cross-rank in-kernel reduction ("xsync", kk_comm.hip / kk_xsync.h): the persistent MGS kernels of a row-sharded run sum
+// their grid-wide inner products over the ranks THEMSELVES -- block 0 of every rank stores its rank's partial as a tagged
+// 16-byte granule into every peer's sync area (fine-grained device memory, mapped through hipIpcOpenMemHandle: stores travel
+// over xGMI), every block polls its OWN rank's area and adds the W partials in rank order (same bits on all ranks).
+#define KK_XS_MAX_RANKS 8        // one node
+#define KK_XS_MAX_VALS 8         // values per reduction (panel kernel: P (P + 1) / 2 <= 6)
+#define KK_XS_SET_BYTES (KK_XS_MAX_VALS * KK_XS_MAX_RANKS * 16)   // granule (value v, rank r) of a set at (v * 8 + r) * 16
+#define KK_XS_ERR_OFFSET (2 * KK_XS_SET_BYTES)                    // id of the launch a peer gave up in (0 = none)
+#define KK_XS_BYTES 4096
+struct kk_xs_dev {               // by value in the kernarg segment of the persistent kernels; world == 0: single-rank launch
+    const unsigned long long* table = nullptr;   // device: base address of every rank's area as mapped into THIS process
+    char* mine = nullptr;        // this rank's area
+    unsigned tag0 = 0;           // tag of the launch's first reduction (tags count reductions over the life of the communicator: set = tag & 1)
+    unsigned launch = 0;         // id of the launch (same on all ranks)
+    int rank = 0, world = 0;
+};
+
 struct kk_prof_entry {
     double ms = 0;
     int64_t launches = 0;
@@ -96,13 +113,23 @@ struct kk_comm_s {
     int rank = 0, world = 1;
     bool active = false;    // collectives are issued: world > 1, or forced at world 1 (plumbing tests on a 1-GPU box)
     int64_t n_allreduce = 0, n_p2p = 0, n_gather = 0;   // statistics (kk_comm_stats)
+    // cross-rank in-kernel reduction (set up by kk_comm_init when every rank could map every peer's area)
+    bool xs_active = false;
+    char* xs_mine = nullptr;                    // fine-grained device memory, KK_XS_BYTES
+    void* xs_peer[KK_XS_MAX_RANKS] = {};        // rank r's area in this process (xs_peer[rank] == xs_mine)
+    bool xs_opened[KK_XS_MAX_RANKS] = {};       // ... mapped by hipIpcOpenMemHandle (to be closed)
+    unsigned long long* xs_table = nullptr;     // device copy of xs_peer
+    unsigned xs_red = 0;                        // reductions issued so far (identical on all ranks: SPMD call sequence)
+    unsigned xs_launch = 0;                     // launches issued so far
+    int64_t n_xs_launches = 0;                  // statistics
 };
 
 struct kk_ctx_s {
     int device = 0;
     kk_comm_s* comm = nullptr;   // set by kk_comm_init: every reduction of the library is summed over the ranks
     bool ar_suspend = false;     // fused sharded steps collect several local partials and all-reduce them at once
-    int num_cus = 256;
+    int num_cus = 256;           // blocks of a persistent launch / partition unit of the streaming kernels (option "num_cus": fewer than the device has when the GPU is shared)
+    int dev_cus = 256;           // what the device reports
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     double* ws = nullptr;        // device scalar workspace [WS_TOTAL] (ws_own unless the caller supplied one)
@@ -154,6 +181,7 @@ struct kk_ctx_s {
     int mgs_panel = 1;           // MGS sweeps of vectors of <= 16 grid-rows (4.19 M rows) through the persistent PANEL kernel (kk_kernels_panel.hip)
     int panel_width = 0;         // basis vectors per grid reduction of that kernel: 0 = by vector length (3 / 2 / 1), else min(value, by length); mgs_mode 0 forces 1
     int64_t panel_min_rows = 1400000;  // auto mode: below this one grid reduction per panel (a fixed ~6 us) costs more than the second read of the basis by the projection pair (tools/panel_sweep_cost.py: 1 M rows 3.1 vs 2.6 us per vector, 2 M rows 3.6 vs 5.1)
+    int xsync = 1;               // row-sharded context: persistent kernels with the in-kernel cross-rank reduction where the communicator offers it (0: RCCL all-reduce per inner-product batch, low-sync route)
     int mgs_persist = 1;         // strict MGS sweeps through the persistent register-resident kernel when the vector fits
     int persist_coop = 0;        // launch the persistent kernels through hipLaunchCooperativeKernel (1) or as ordinary launches (0): see kk_launch_resident
     int persist_threads = 512;   // threads per block (= per CU) of that kernel: 1024 (<= 40 doubles of w per thread) or 512 (<= 80)
@@ -431,6 +459,13 @@ int kk_comm_allreduce_sum(kk_ctx ctx, double* dev_ptr, int64_t count);
 static inline bool kk_sharded(kk_ctx ctx) {
     return !ctx->ar_suspend && ((ctx->comm && ctx->comm->active) || ctx->allreduce);
 }
+// the persistent kernels of this (row-sharded) context reduce over the ranks inside the launch
+static inline bool kk_xs_on(kk_ctx ctx) {
+    return ctx->xsync && !ctx->allreduce && ctx->comm && ctx->comm->active && ctx->comm->xs_active;
+}
+// fills the kernel argument of one persistent launch with `nred` grid reductions (all zero on a single-rank context)
+kk_xs_dev kk_xs_launch_args(kk_ctx ctx, unsigned nred);
+int kk_launch_xs_selftest(kk_ctx ctx, const kk_xs_dev& xs, int* out_dev);   // 4 reductions; *out_dev = 1 on success
 struct kk_ar_suspend {   // RAII: local partials only inside the scope
     kk_ctx c; bool prev;
     explicit kk_ar_suspend(kk_ctx ctx) : c(ctx), prev(ctx->ar_suspend) { c->ar_suspend = true; }

@@ -39,6 +39,7 @@
 //     5.1 for the projection pair and for k_mgs_persist, 2.4 for the bare stream.
 #include "kk_internal.h"
 #include "kk_device.h"
+#include "kk_xsync.h"
 
 #define KK_PANEL_TIMEOUT_TICKS 300000000ll   // 3 s of the 100 MHz wall clock
 #define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
@@ -112,7 +113,8 @@ __device__ __forceinline__ void panel_publish(int nval, unsigned epoch, int set,
     }
 }
 // wave 0, between barriers (1b) and (2): sweep the partials of all blocks, totals to smB[0 .. nval), timeout flag to smB[8]
-__device__ __forceinline__ bool panel_sweep(int nval, unsigned epoch, int set, char* __restrict__ sync, int* __restrict__ err, double* smB, int pidx = 0) {
+__device__ __forceinline__ bool panel_sweep(int nval, unsigned epoch, int set, char* __restrict__ sync, int* __restrict__ err, double* smB, const kk_xs_dev& xs,
+                                            unsigned xred /* index of this reduction within the launch */, int pidx = 0) {
     const int G = gridDim.x;
     const int lane = threadIdx.x;
     const unsigned set_bytes = (unsigned)G * 16u * 8u;
@@ -121,6 +123,7 @@ __device__ __forceinline__ bool panel_sweep(int nval, unsigned epoch, int set, c
     const long long t0 = wall_clock64();
     int good = 1;
     long long npass = 0;
+    double mine = 0;   // lane v: this rank's partial of value v (row-sharded context)
     for (int v = 0; v < nval && good; ++v) {   // value after value: by the time value 0 is complete the others usually are too
         const unsigned voff_v = set_off + (unsigned)v * (unsigned)G * 16u;
         double total = 0;
@@ -152,7 +155,14 @@ __device__ __forceinline__ bool panel_sweep(int nval, unsigned epoch, int set, c
             __builtin_amdgcn_s_sleep(1);
             if (wall_clock64() - t0 > KK_PANEL_TIMEOUT_TICKS || errv) { good = 0; break; }
         }
-        if (lane == 0) smB[v] = total;
+        if (xs.world > 0) { if (lane == v) mine = total; }
+        else if (lane == 0) smB[v] = total;
+    }
+    if (xs.world > 0) {   // level 2: the sum over the ranks (kk_xsync.h); lanes v * 8 .. v * 8 + 7 receive the total of value v
+        double t2 = 0;
+        if (good && !xs_allreduce(xs, xred, nval, mine, err, KK_PANEL_TIMEOUT_TICKS, t2)) good = 0;
+        if (good && (lane & 7) == 0 && (lane >> 3) < nval) smB[lane >> 3] = t2;
+        if (!good && lane == 0) xs_abort(xs);
     }
     if (lane == 0 && !good) { __hip_atomic_store(err, 1, RLX_AGENT); smB[8] = 1.0; }
     PTRACE(9, pidx);   // totals complete
@@ -162,12 +172,12 @@ __device__ __forceinline__ bool panel_sweep(int nval, unsigned epoch, int set, c
 }
 // one whole reduction as seen by a wave 0 that holds no rows (KK_PANEL_DW = 7)
 __device__ __forceinline__ bool panel_reduce_sync(int nval, unsigned epoch, int set, char* __restrict__ sync, int* __restrict__ err, const double* smA,
-                                                  double* smB, int pidx = 0) {
+                                                  double* smB, const kk_xs_dev& xs, unsigned xred, int pidx = 0) {
     lds_barrier();   // (1)
     panel_publish(nval, epoch, set, sync, smA);
     PTRACE(8, pidx);
     lds_barrier();   // (1b)
-    const bool good = panel_sweep(nval, epoch, set, sync, err, smB, pidx);
+    const bool good = panel_sweep(nval, epoch, set, sync, err, smB, xs, xred, pidx);
     lds_barrier();   // (2)
     return good;
 }
@@ -196,13 +206,13 @@ __device__ __forceinline__ void panel_handoff(const double (&acc)[NVAL], double*
 // second half: the totals (same bits in every thread of every block).  Returns false after a timeout anywhere on the chip.
 template <int NVAL>
 __device__ __forceinline__ bool panel_totals(const double (&acc)[NVAL], double (&tot)[NVAL], double* smB, unsigned epoch, int set, char* __restrict__ sync,
-                                             int* __restrict__ err, int pidx = 0) {
+                                             int* __restrict__ err, const kk_xs_dev& xs, unsigned xred, int pidx = 0) {
 #ifdef KK_PANEL_NOSYNC
 #pragma unroll
     for (int v = 0; v < NVAL; ++v) tot[v] = acc[v] * 1e-30;
     return true;
 #endif
-    if (KK_PANEL_W0 == 0 && threadIdx.x < 64) panel_sweep(NVAL, epoch, set, sync, err, smB, pidx);   // (its sweep queues behind its own panel loads: fine)
+    if (KK_PANEL_W0 == 0 && threadIdx.x < 64) panel_sweep(NVAL, epoch, set, sync, err, smB, xs, xred, pidx);   // (its sweep queues behind its own panel loads: fine)
     lds_barrier();   // (2)
     PTRACE(3, pidx);   // totals available
 #pragma unroll
@@ -251,10 +261,10 @@ __device__ __forceinline__ void panel_dots(const d2 (&wr)[NV], const d2 (&cur)[P
 // second half: totals -> coefficients -> update of w
 template <int NV, int P>
 __device__ __forceinline__ bool panel_update(d2 (&wr)[NV], d2 (&cur)[P][NV], const double (&acc)[P * (P + 1) / 2], int s0, int nsteps, int m,
-                                             double* smB, double* __restrict__ out_s, int out_stride, unsigned ebase, char* sync, int* err, int pidx) {
+                                             double* smB, double* __restrict__ out_s, int out_stride, unsigned ebase, char* sync, int* err, const kk_xs_dev& xs, int pidx) {
     constexpr int NVAL = P * (P + 1) / 2;
     double tot[NVAL];
-    if (!panel_totals<NVAL>(acc, tot, smB, ebase + (unsigned)pidx + 1u, pidx & 1, sync, err, pidx)) return false;
+    if (!panel_totals<NVAL>(acc, tot, smB, ebase + (unsigned)pidx + 1u, pidx & 1, sync, err, xs, (unsigned)pidx, pidx)) return false;
     // (I + L) s = d, L = strictly lower in-panel Gram block: exact forward substitution, the same bits in every thread
     double s[P];
 #pragma unroll
@@ -287,11 +297,11 @@ __global__ __launch_bounds__(KK_PANEL_PT) void k_mgs_panel(const double* __restr
                                                            const double* __restrict__ carry_q, const double* __restrict__ carry_s,
                                                            double* __restrict__ out_s, int out_stride, double* __restrict__ nrm_out3,
                                                            char* __restrict__ sync, int* __restrict__ err, int fault, unsigned ebase, int normalize,
-                                                           double* __restrict__ ok_out, double token) {
+                                                           double* __restrict__ ok_out, double token, kk_xs_dev xs) {
     __shared__ double smA[64];
     __shared__ double smB[16];
     if (fault && blockIdx.x == 0) {   // test hook (option "persist_fault"): block 0 behaves like a block whose spin ran out
-        if (threadIdx.x == 0) __hip_atomic_store(err, 1, RLX_AGENT);
+        if (threadIdx.x == 0) { __hip_atomic_store(err, 1, RLX_AGENT); xs_abort(xs); }
         return;
     }
     const int nsteps = m * nsweeps;
@@ -306,8 +316,8 @@ __global__ __launch_bounds__(KK_PANEL_PT) void k_mgs_panel(const double* __restr
         return;
 #endif
         for (int p = 0; p < npanels; ++p)
-            if (!panel_reduce_sync(NVAL, ebase + (unsigned)p + 1u, p & 1, sync, err, smA, smB, p)) return;
-        if (nrm_out3) panel_reduce_sync(1, ebase + (unsigned)npanels + 1u, npanels & 1, sync, err, smA, smB);
+            if (!panel_reduce_sync(NVAL, ebase + (unsigned)p + 1u, p & 1, sync, err, smA, smB, xs, (unsigned)p, p)) return;
+        if (nrm_out3) panel_reduce_sync(1, ebase + (unsigned)npanels + 1u, npanels & 1, sync, err, smA, smB, xs, (unsigned)npanels);
         return;
     }
     // ---------------- the data waves
@@ -351,13 +361,13 @@ __global__ __launch_bounds__(KK_PANEL_PT) void k_mgs_panel(const double* __restr
         panel_dots<NV, P>(wr, qa, acc, smA, ebase, sync, p);
         PTRACE(0, p);
         panel_issue<NV, P, EARLY, NV>(qb, V, ld, m, (p + 1) * P, nsteps, voff, sbytes, brow, bbytes);   // the rest, in flight across this panel's reduction
-        if (!panel_update<NV, P>(wr, qa, acc, p * P, nsteps, m, smB, out_s, out_stride, ebase, sync, err, p)) return;   // timeout: w in HBM is untouched
+        if (!panel_update<NV, P>(wr, qa, acc, p * P, nsteps, m, smB, out_s, out_stride, ebase, sync, err, xs, p)) return;   // timeout: w in HBM is untouched
         if (p + 1 >= npanels) break;
         panel_issue<NV, P, 0, EARLY>(qa, V, ld, m, (p + 2) * P, nsteps, voff, sbytes, brow, bbytes);
         panel_dots<NV, P>(wr, qb, acc, smA, ebase, sync, p + 1);
         PTRACE(0, p + 1);
         panel_issue<NV, P, EARLY, NV>(qa, V, ld, m, (p + 2) * P, nsteps, voff, sbytes, brow, bbytes);
-        if (!panel_update<NV, P>(wr, qb, acc, (p + 1) * P, nsteps, m, smB, out_s, out_stride, ebase, sync, err, p + 1)) return;
+        if (!panel_update<NV, P>(wr, qb, acc, (p + 1) * P, nsteps, m, smB, out_s, out_stride, ebase, sync, err, xs, p + 1)) return;
     }
     double inv = 1.0;
     bool scale = false;
@@ -366,7 +376,7 @@ __global__ __launch_bounds__(KK_PANEL_PT) void k_mgs_panel(const double* __restr
 #pragma unroll
         for (int j = 0; j < NV; ++j) { an[0] = fma(wr[j].x, wr[j].x, an[0]); an[0] = fma(wr[j].y, wr[j].y, an[0]); }
         panel_handoff<1>(an, smA, ebase + (unsigned)npanels + 1u, npanels & 1, sync);
-        if (!panel_totals<1>(an, tot, smB, ebase + (unsigned)npanels + 1u, npanels & 1, sync, err)) return;
+        if (!panel_totals<1>(an, tot, smB, ebase + (unsigned)npanels + 1u, npanels & 1, sync, err, xs, (unsigned)npanels)) return;
         const double rt = sqrt(tot[0]);
         inv = 1.0 / rt;
         scale = normalize && rt > 0.0 && inv <= 1.79769313486231570815e308;
@@ -390,7 +400,7 @@ __global__ __launch_bounds__(KK_PANEL_PT) void k_mgs_panel(const double* __restr
 // vectors of at most 16 rows of 512 double2 per block (4.19 M rows on 256 CUs): w plus two panels fit the 256 registers of a 512-thread block
 int64_t kk_mgs_panel_capacity(kk_ctx ctx) { return (int64_t)ctx->num_cus * KK_PANEL_DT * 2 * 16; }
 bool kk_mgs_panel_eligible(kk_ctx ctx, int64_t ld) {
-    if (!ctx->mgs_panel || !ctx->mgs_persist || kk_sharded(ctx) || !ctx->d_sync) return false;
+    if (!ctx->mgs_panel || !ctx->mgs_persist || (kk_sharded(ctx) && !kk_xs_on(ctx)) || !ctx->d_sync) return false;
     if (ctx->num_cus > KK_SYNC_MAX_BLOCKS || ld * 8 >= ((int64_t)1 << 31)) return false;
     return ld <= kk_mgs_panel_capacity(ctx);
 }
@@ -428,9 +438,10 @@ int kk_launch_mgs_panel(kk_ctx ctx, const double* V, int64_t ld, int m, int nswe
     ctx->persist_token += 1.0;
     double token = ctx->persist_token;
     double* ok_out = ctx->ws + WS_SCAL + SC_PERSIST_OK;
+    kk_xs_dev xs = kk_xs_launch_args(ctx, (unsigned)((m * nsweeps + P - 1) / P) + (nrm_out3 ? 1u : 0u));   // cross-rank reductions of this launch (row-sharded context)
     void* args[] = {(void*)&V, (void*)&ld, (void*)&m, (void*)&nsweeps, (void*)&w, (void*)&carry_q, (void*)&carry_s,
                     (void*)&out_s, (void*)&out_stride, (void*)&nrm_out3, (void*)&sync, (void*)&err, (void*)&fault,
-                    (void*)&ebase, (void*)&normalize, (void*)&ok_out, (void*)&token};
+                    (void*)&ebase, (void*)&normalize, (void*)&ok_out, (void*)&token, (void*)&xs};
     kk_prof_scope ps(ctx, "k_mgs_panel");
     if (nv <= 4) return P >= 3 ? launch_panel_inst<4, 3>(ctx, args) : (P == 2 ? launch_panel_inst<4, 2>(ctx, args) : launch_panel_inst<4, 1>(ctx, args));
     if (nv <= KK_PANEL_NVMID) return P >= 2 ? launch_panel_inst<KK_PANEL_NVMID, 2>(ctx, args) : launch_panel_inst<KK_PANEL_NVMID, 1>(ctx, args);

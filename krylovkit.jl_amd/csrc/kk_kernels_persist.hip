@@ -17,6 +17,7 @@
 //     flag is raised, no block writes w back (HBM still holds the input) and the host reports the failure.
 #include "kk_internal.h"
 #include "kk_device.h"
+#include "kk_xsync.h"
 
 // First read of a basis vector (as q_next): non-temporal for the grid-rows that will wait on chip (LDS / spare registers) and
 // are therefore never read again, cache-allocating only for the rows that ARE read a second time one step later.  With every
@@ -76,7 +77,8 @@ __device__ __forceinline__ void grid_publish(double acc, int step, unsigned ebas
 // second half: wave 0 sweeps the partials of all blocks
 template <int PT>
 __device__ __forceinline__ bool grid_collect(int step, unsigned ebase, char* __restrict__ sync, int* __restrict__ err,
-                                             double* sm, double* out, unsigned gstride /* bytes between the granules of two blocks: 128 = own line, 16 = packed */) {
+                                             double* sm, double* out, unsigned gstride /* bytes between the granules of two blocks: 128 = own line, 16 = packed */,
+                                             const kk_xs_dev& xs /* row-sharded context: the sum over the ranks follows (kk_xsync.h) */) {
     const int G = gridDim.x;
     const unsigned epoch = ebase + (unsigned)step + 1u;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(sync, 0, 2 * G * KK_SYNC_LINE, 0x00020000);
@@ -115,6 +117,12 @@ __device__ __forceinline__ bool grid_collect(int step, unsigned ebase, char* __r
             if (__all(ok)) { total = wave_sum(x); break; }
             __builtin_amdgcn_s_sleep(1);
             if (wall_clock64() - t0 > KK_PERSIST_TIMEOUT_TICKS || errv) { good = 0; break; }
+        }
+        if (xs.world > 0) {   // level 2: every block of this rank holds the same bits of the rank's partial -- now the sum over the ranks
+            double t2 = 0;
+            if (good && !xs_allreduce(xs, (unsigned)step, 1, total, err, KK_PERSIST_TIMEOUT_TICKS, t2)) good = 0;
+            total = t2;   // (lane 0: value 0)
+            if (!good && lane == 0) xs_abort(xs);   // whatever went wrong on this chip, the peers must not wait for it
         }
         if (lane == 0) {
             if (!good) __hip_atomic_store(err, 1, RLX_AGENT);
@@ -222,11 +230,11 @@ __global__ __launch_bounds__(PT) void k_mgs_persist(const double* __restrict__ V
                                                     const double* __restrict__ carry_s, double* __restrict__ out_s,
                                                     int out_stride, double* __restrict__ nrm_out3,
                                                     char* __restrict__ sync, int* __restrict__ err, int fault, unsigned gstride,
-                                                    unsigned ebase, int normalize, double* __restrict__ ok_out, double token) {
+                                                    unsigned ebase, int normalize, double* __restrict__ ok_out, double token, kk_xs_dev xs) {
     __shared__ double sm[PT / 64];
     extern __shared__ d2 park[];   // NL * PT double2 (dynamic): the parked grid-rows of the current basis vector
     if (fault && blockIdx.x == 0) {   // test hook (option "persist_fault"): block 0 behaves like a block whose spin ran out
-        if (threadIdx.x == 0) __hip_atomic_store(err, 1, RLX_AGENT);
+        if (threadIdx.x == 0) { __hip_atomic_store(err, 1, RLX_AGENT); xs_abort(xs); }
         return;
     }
 #ifndef KK_PERSIST_B512
@@ -293,7 +301,7 @@ __global__ __launch_bounds__(PT) void k_mgs_persist(const double* __restrict__ V
         for (int u = 0; u < B; ++u) qpre[u] = bload(r2, voff, (unsigned)(u < NV ? u : 0) * sbytes, KK_PERSIST_NT_FIRST == 2 || (KK_PERSIST_NT_FIRST == 1 && u < NL + NR));
         __builtin_amdgcn_sched_barrier(0);
 #endif
-        if (!grid_collect<PT>(s, ebase, sync, err, sm, &total, gstride)) return;   // timeout: w in HBM is untouched
+        if (!grid_collect<PT>(s, ebase, sync, err, sm, &total, gstride, xs)) return;   // timeout: w in HBM is untouched
         if (blockIdx.x == 0 && threadIdx.x == 0) out_s[(s / m) * out_stride + (s % m)] = total;
         sp = total;
         qp = qn;
@@ -305,7 +313,7 @@ __global__ __launch_bounds__(PT) void k_mgs_persist(const double* __restrict__ V
         persist_step<NV, NL, NR, PT, B, NTPREV, true, true>(wr, qk, qpre, col_rsrc(qp, ld), col_rsrc(qp, ld), sp, sbytes, voff, lq, a0, a1);
         if (nrm_out3) {
             grid_publish<PT>(a0 + a1, nsteps, ebase, sync, sm, gstride);
-            if (!grid_collect<PT>(nsteps, ebase, sync, err, sm, &total, gstride)) return;
+            if (!grid_collect<PT>(nsteps, ebase, sync, err, sm, &total, gstride, xs)) return;
             // every block holds the same bits of |w|^2: the normalised commit below needs no second exchange
             const double rt = sqrt(total);
             inv = 1.0 / rt;
@@ -355,14 +363,15 @@ int kk_launch_resident(kk_ctx ctx, const void* fn, int threads, void** args, siz
 }
 
 // Eligible when the vector fits the register file of the chip (NV <= 20 double2 per thread at 1024 threads per CU, 40 at
-// 512), the blocks fit the synchronisation area and the context is not row-sharded (a sharded sweep needs one all-reduce
-// per vector, which cannot be issued from inside a kernel).
+// 512) and the blocks fit the synchronisation area.  On a row-sharded context the sum over the ranks must be available
+// INSIDE the launch (kk_xs_on: every rank has every peer's sync area mapped, kk_comm_init) -- an RCCL all-reduce per vector
+// cannot be issued from a kernel; without it the sharded sweep takes the low-synchronisation route.
 int64_t kk_mgs_persist_capacity(kk_ctx ctx) {   // rows of a work vector the register file of the chip can hold
     const int pt = ctx->persist_threads;
     return (int64_t)ctx->num_cus * pt * 2 * (pt == 1024 ? 20 : 40);
 }
 bool kk_mgs_persist_eligible(kk_ctx ctx, int64_t ld, int m, int nsweeps) {
-    if (!ctx->mgs_persist || kk_sharded(ctx) || !ctx->d_sync) return false;
+    if (!ctx->mgs_persist || (kk_sharded(ctx) && !kk_xs_on(ctx)) || !ctx->d_sync) return false;
     if (ctx->num_cus > KK_SYNC_MAX_BLOCKS || ld * 8 >= ((int64_t)1 << 31)) return false;
     return ld <= kk_mgs_persist_capacity(ctx);
 }
@@ -430,9 +439,10 @@ int kk_launch_mgs_persist(kk_ctx ctx, const double* V, int64_t ld, int m, int ns
     ctx->persist_token += 1.0;
     double token = ctx->persist_token;
     double* ok_out = ctx->ws + WS_SCAL + SC_PERSIST_OK;
+    kk_xs_dev xs = kk_xs_launch_args(ctx, (unsigned)(m * nsweeps) + (nrm_out3 ? 1u : 0u));   // one cross-rank reduction per grid reduction (row-sharded context)
     void* args[] = {(void*)&V, (void*)&ld, (void*)&m, (void*)&nsweeps, (void*)&w, (void*)&carry_q, (void*)&carry_s,
                     (void*)&out_s, (void*)&out_stride, (void*)&nrm_out3, (void*)&sync, (void*)&err, (void*)&fault, (void*)&gstride,
-                    (void*)&ebase, (void*)&normalize, (void*)&ok_out, (void*)&token};
+                    (void*)&ebase, (void*)&normalize, (void*)&ok_out, (void*)&token, (void*)&xs};
     const bool nt = ctx->persist_nt != 0;
     kk_prof_scope ps(ctx, "k_mgs_persist");
     if (pt == 1024) {
@@ -450,4 +460,25 @@ int kk_launch_mgs_persist(kk_ctx ctx, const double* V, int64_t ld, int m, int ns
     }
     kk_set_error("kk_launch_mgs_persist: vector of %lld rows does not fit the register file", (long long)ld);
     return KK_ERR_UNSUPPORTED;
+}
+
+// ---- hand-shake of the cross-rank sync areas (kk_comm_init): every rank pushes a known value into every peer's area and waits
+// for all of them, four times (both granule sets, twice) -- the mapping, the visibility of system-scope stores across the
+// fabric and the tag protocol are exercised once with a short timeout BEFORE the persistent kernels rely on them.
+// out[0] = 1 when every round produced sum_r (r + 1) * round, else 0.
+__global__ __launch_bounds__(64) void k_xs_selftest(kk_xs_dev xs, int* __restrict__ err, long long timeout_ticks, int* __restrict__ out) {
+    int ok = 1;
+    for (unsigned round = 0; round < 4 && ok; ++round) {
+        double total = 0;
+        const double mine = (double)((xs.rank + 1) * (int)(round + 1));
+        if (!xs_allreduce(xs, round, 1, mine, err, timeout_ticks, total)) ok = 0;
+        else if (readlane_d(total, 0) != (double)(xs.world * (xs.world + 1) / 2 * (int)(round + 1))) ok = 0;
+    }
+    if (threadIdx.x == 0) out[0] = ok;
+}
+int kk_launch_xs_selftest(kk_ctx ctx, const kk_xs_dev& xs, int* out_dev) {
+    int* err = (int*)((char*)ctx->d_sync + KK_SYNC_ERR_OFFSET);
+    hipLaunchKernelGGL(k_xs_selftest, dim3(1), dim3(64), 0, ctx->stream, xs, err, 200000000ll /* 2 s */, out_dev);
+    KK_HIP(hipGetLastError());
+    return KK_OK;
 }

@@ -155,7 +155,7 @@ static int la_enqueue(kk_op op, kk_basis b, int c0, int j, int nsweeps, bool lan
     kk_ctx c = b->ctx;
     b->la_valid = false;
     const int m = j + 1;
-    if (!c->lookahead || !c->fold_scale || !b->spec_valid || !c->persist_norm_done || kk_sharded(c) || c->persist_skip > 0) return KK_OK;
+    if (!c->lookahead || !c->fold_scale || !b->spec_valid || !c->persist_norm_done || (kk_sharded(c) && !kk_xs_on(c)) || c->persist_skip > 0) return KK_OK;
     if (m > KK_MAX_M || c0 + j + 3 > b->cap) return KK_OK;
     if (!(kk_mgs_panel_eligible(c, b->ld) || kk_mgs_persist_eligible(c, b->ld, m, nsweeps)) || kk_mgs_lowsync(c, b->ld, m)) return KK_OK;
     if (lanczos_carry && b->spec_dot_ptr != SCP(c, SC_ALPHA0)) return KK_OK;   // (alpha0 of step j must sit where the sweep reads it)
@@ -346,7 +346,7 @@ KK_API int kk_lanczos_expand(kk_op op, kk_basis b, int c0, int k, kk_orth_t orth
             } else {
                 slot = la_slot;
             }
-            if (attempt == 0 && !kk_sharded(c)) {
+            if (attempt == 0 && (!kk_sharded(c) || kk_xs_on(c))) {   // (row-sharded: only when the sweep reduces over the ranks inside its launch)
                 KK_TRY(speculate_next(op, b, c0, k + 1, 2, true, 0.0, SCP(c, SC_ALPHA0)));   // |w| and 1/|w| are on the device; alpha0 straight to its slot
                 KK_TRY(la_enqueue(op, b, c0, k + 1, 1, true));                                   // ... and, where it pays, the whole next step behind it
             }
@@ -399,7 +399,7 @@ KK_API int kk_arnoldi_expand(kk_op op, kk_basis b, int c0, int k, kk_orth_t orth
     const bool v_ready = b->norm_col == c0 + k && b->norm_beta == beta_old;   // see kk_lanczos_expand
     if (!v_ready) KK_TRY(norm_flush(b));
     const int la_sweeps = orth == KK_MGS ? 1 : (orth == KK_MGS2 ? 2 : 0);
-    const bool strict_route = la_sweeps > 0 && m <= KK_MAX_M && !kk_mgs_lowsync(c, b->ld, m) && !kk_sharded(c);
+    const bool strict_route = la_sweeps > 0 && m <= KK_MAX_M && !kk_mgs_lowsync(c, b->ld, m) && (!kk_sharded(c) || kk_xs_on(c));
     // the previous call may have enqueued this WHOLE step already (apply, sweeps and read-back: la_enqueue)
     const bool la_hit = b->la_valid && b->spec_valid && c->spec_owner == b && b->spec_op == op && b->spec_c0 == c0 && b->spec_k == k &&
                         b->spec_dot_mode == 0 && b->la_k == k && b->la_nsweeps == la_sweeps && b->spec_beta == beta_old && strict_route && v_ready;

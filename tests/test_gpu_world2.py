@@ -30,8 +30,20 @@ def _env(tmp_path):
     return env
 
 
+def device_cus():
+    import krylovkit_hip as kk
+    c = kk.Context(0)
+    try:
+        return int(c.get_option("device_cus"))
+    finally:
+        c.close()
+
+
 def run_world(scenario, world, tmp_path, timeout=600, extra_env=None):
     env = _env(tmp_path)
+    # every rank owns its share of the CUs: the persistent kernels (one block per CU, all resident at once) of all ranks then
+    # fit the one GPU side by side -- what HSA_CU_MASK / a partition mode would enforce, here by block count alone
+    env["KK_NUM_CUS"] = str(device_cus() // world)
     env.update(extra_env or {})
     procs = [subprocess.Popen([sys.executable, str(HERE / "world2_worker.py"), scenario, str(r), str(world), str(tmp_path)],
                               env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
@@ -101,7 +113,37 @@ def test_world2_collective_create_rejects_bad_input_on_all_ranks(tmp_path):
     assert reps[0]["status"] == reps[1]["status"] != 0
 
 
-@pytest.mark.parametrize("scenario,world", [("lanczos_grid", 2), ("lanczos_random", 3), ("gkl", 2), ("block", 2), ("solvers", 2), ("solvers2", 2)])
+@pytest.mark.parametrize("world", [2, 3])
+def test_world_persistent_kernels_reduce_over_the_ranks_in_kernel(tmp_path, world):
+    """k_mgs_persist / k_mgs_panel on a row-sharded context -- two-level grid reduction, tagged granules
+    stored into the peers' IPC-mapped sync areas, RCCL only for the ghost exchange and alpha0.  Lanczos MGS2, Arnoldi MGS / MGS2
+    against the oracle at 1e-10, strict and panel order, run-ahead on and off, bit-identical scalars on every rank"""
+    reps = run_world("xsync", world, tmp_path)
+    keys = [k for k in reps[0] if "." in k and isinstance(reps[0][k], list)]
+    assert len(keys) == 12
+    for k in keys:
+        assert all(r[k] == reps[0][k] for r in reps), k        # ranks_agree_bitwise
+
+
+def test_world2_persistent_kernels_recover_when_one_rank_loses_a_launch(tmp_path):
+    """a barrier timeout on ONE rank (test hook): the abort word stops the peers' spins, nobody commits, every rank repeats the
+    sweep on the launch-per-vector route (RCCL all-reduces) and the persistent route resumes after the back-off"""
+    reps = run_world("xsync_fault", 2, tmp_path)
+    keys = [k for k in reps[0] if "." in k and isinstance(reps[0][k], list)]
+    for k in keys:
+        assert reps[0][k] == reps[1][k], k
+
+
+def test_world2_persistent_kernels_full_size_shards(tmp_path):
+    """2 x 5 M rows (config-2 shape, k_mgs_persist) and 2 x 1 M rows (config-3 shape, k_mgs_panel) with default options:
+    the auto mode takes the persistent kernels on the sharded context, alpha / beta / H against the CPU twin at 1e-10"""
+    reps = run_world("xsync_full", 2, tmp_path, timeout=1500)
+    for k in ("full.lanczos", "full.gmres"):
+        assert reps[0][k] == reps[1][k], k
+    print({k: [r[k] for r in reps] for k in ("full.lanczos.ms_per_step", "full.gmres.ms_per_step")})
+
+
+@pytest.mark.parametrize("scenario,world", [("lanczos_grid", 2), ("lanczos_random", 3), ("gkl", 2), ("block", 2), ("solvers", 2), ("solvers2", 2), ("xsync", 2)])
 def test_world_asynchronous_collectives(tmp_path, scenario, world):
     """The same scenarios with the stand-in in its ASYNCHRONOUS mode (KK_FAKE_RCCL_ASYNC=1): every nccl* call only enqueues
     -- staging copy, a host function on the stream that sleeps 300 us before it talks to the peers, delivery copy -- and

@@ -319,6 +319,137 @@ elif scenario == "solvers2":
     assert einfo.converged == 1 and (einfo.numiter, einfo.numops) == (eoinfo.numiter, eoinfo.numops)
     assert np.linalg.norm(wg - wo) <= 1e-9 * np.linalg.norm(wo)
     report["exponentiate"] = [einfo.numiter, einfo.numops]
+elif scenario in ("xsync", "xsync_fault"):
+    # The persistent MGS kernels on a row-sharded context: the sum over the ranks happens INSIDE the launch -- block 0 of a rank
+    # stores the rank's partial into every peer's IPC-mapped sync area, every block adds the W partials in rank order
+    # (csrc/kk_xsync.h; reference order src/orthonormal.jl:414-439, factorizations/lanczos.jl:325-338, arnoldi.jl:239-245).
+    # Every rank owns num_cus = device / world CUs (KK_NUM_CUS): the launches of all ranks are resident side by side.
+    assert ctx.get_option("xsync_active") == 1, "kk_comm_init did not establish the cross-rank sync areas"
+    assert ctx.get_option("num_cus") <= ctx.get_option("device_cus") // world
+    nx, ny = 70, 64 * world
+    n = nx * ny
+    A = ko.laplacian_2d(nx, ny, shift_diag=10 * np.linspace(0, 1, n) ** 2)
+    Cd = ko.convection_diffusion_2d(nx, ny)
+    x0 = np.random.default_rng(3).random(n)
+    part = kd.Partition.even(n, world, rank, align=nx)
+    lo, hi = part.lo, part.hi
+    opA = kd.NativeShardedOperator(A[lo:hi], part, ctx, symmetric=True)
+    opC = kd.NativeShardedOperator(Cd[lo:hi], part, ctx)
+    steps = 24
+    fault_at = {7, 15} if scenario == "xsync_fault" else set()
+    for route, lookahead in (("persist", 1), ("panel", 1), ("panel_p", 1), ("persist", 0)):
+        ctx.set_option("mgs_mode", 2 if route == "panel_p" else 0)      # panel_p: panels of 2-3 vectors per reduction (auto mode), else the strict order
+        ctx.set_option("mgs_panel", 0 if route == "persist" else 1)
+        ctx.set_option("panel_min_rows", 0); ctx.set_option("persist_min_rows", 0)
+        ctx.set_option("lookahead", lookahead)
+        for case in ("lanczos", "arnoldi_mgs", "arnoldi_mgs2"):
+            x1 = ctx.get_option("xsync_launches"); t1 = ctx.get_option("persist_timeouts")
+            ctx.prof_reset(); ctx.prof_enable(1)
+            if case == "lanczos":
+                it = kk.LanczosIterator(opA, x0[lo:hi], kk.ModifiedGramSchmidt2(), capacity=steps + 3)
+            else:
+                it = kk.ArnoldiIterator(opC, x0[lo:hi], kk.ModifiedGramSchmidt() if case == "arnoldi_mgs" else kk.ModifiedGramSchmidt2(), capacity=steps + 3)
+            f = kk.initialize(it)
+            s0 = comm.stats()
+            for i in range(steps):
+                if i in fault_at and rank == (i % world):
+                    ctx.set_option("persist_fault", 1)     # ONE rank loses a launch: its peers must give up with it (abort word), all repeat the sweep
+                f = kk.expand_(it, f)
+            s1 = comm.stats()
+            ctx.prof_enable(0)
+            launches = ctx.prof_get("k_mgs_persist")[1] + ctx.prof_get("k_mgs_panel")[1]
+            assert launches > 0 and ctx.get_option("xsync_launches") - x1 == launches, (route, case, launches)
+            assert (ctx.prof_get("k_mgs_persist")[1] > 0) == (route == "persist"), (route, case)
+            if fault_at:
+                assert ctx.get_option("persist_timeouts") - t1 >= len(fault_at), (route, case, ctx.get_option("persist_timeouts") - t1)
+            else:
+                assert ctx.get_option("persist_timeouts") == t1, (route, case)
+                if case == "lanczos":   # the only all-reduce left per expand! is alpha0 of the apply (speculative applies included)
+                    assert (s1["allreduce"] - s0["allreduce"]) <= steps + 2, (route, s0, s1)
+            # the oracle on the global problem, after the device run (a rank busy on the CPU would let its peers' kernels wait)
+            if case == "lanczos":
+                oit = ko.LanczosIterator(A, x0.copy(), ko.MGS2); of = ko.lanczos_initialize(oit)
+                for _ in range(steps):
+                    of = ko.lanczos_expand(oit, of)
+                ea, eb = relerr(f.alphas, of.alphas), relerr(f.betas, of.betas)
+                assert ea < 1e-10 and eb < 1e-10, (route, case, ea, eb)
+                bits = [float(a).hex() for a in f.alphas] + [float(b).hex() for b in f.betas]
+            else:
+                oit = ko.ArnoldiIterator(Cd, x0.copy(), ko.MGS if case == "arnoldi_mgs" else ko.MGS2); of = ko.arnoldi_initialize(oit)
+                for _ in range(steps):
+                    of = ko.arnoldi_expand(oit, of)
+                H = np.asarray(f.H, dtype=float)
+                ea = float(np.max(np.abs(H - np.asarray(of.H))) / np.max(np.abs(of.H)))
+                eb = abs(f.normres - of.normres) / abs(of.normres)
+                assert ea < 1e-10 and eb < 1e-10, (route, case, ea, eb)
+                bits = [float(h).hex() for h in H.ravel()] + [float(f.normres).hex()]
+            V = gather_rows(f"V_{route}{lookahead}_{case}", f.V.to_numpy())
+            assert np.max(np.abs(V.T @ V - np.eye(V.shape[1]))) < 1e-12, (route, case)
+            report[f"{route}{lookahead}.{case}"] = bits      # compared rank against rank by the test: bit-identical scalars
+    # orthonormalize!! through the same kernels: global coefficients and norm, the stored vector normalised
+    ctx.set_option("mgs_mode", 0); ctx.set_option("mgs_panel", 1)
+    rng = np.random.default_rng(5)
+    m = 9
+    Q, _ = np.linalg.qr(rng.standard_normal((n, m)))
+    w = rng.standard_normal(n)
+    B = kk.DeviceBasis(hi - lo, m + 2, ctx)
+    for j in range(m):
+        B.upload(j, Q[lo:hi, j])
+    B.length = m
+    x, nrm, _ = B.orthogonalize(B[m].set(w[lo:hi]), kk.ModifiedGramSchmidt2())
+    wo, xo = ko.orthogonalize(w.copy(), [Q[:, j].copy() for j in range(m)], ko.MGS2)
+    np.testing.assert_allclose(x, xo, rtol=0, atol=1e-12 * np.linalg.norm(w))
+    assert abs(nrm - np.linalg.norm(wo)) < 1e-12 * np.linalg.norm(w)
+    np.testing.assert_allclose(B[m].get(), wo[lo:hi], rtol=0, atol=1e-12 * np.linalg.norm(w))
+    ctx.set_option("mgs_mode", 2); ctx.set_option("lookahead", 1)
+elif scenario == "xsync_full":
+    # config-2 shape at world x 5 M rows and config-3 shape at world x 1 M rows: the sizes where the persistent kernels ARE the
+    # route of the auto mode (k_mgs_persist from 3.6 M rows per rank, k_mgs_panel for 1.4 .. 4.19 M) -- default options
+    sys.path.insert(0, str(HERE))
+    import cpu_ref_lib
+    ref = cpu_ref_lib.load()
+    assert ctx.get_option("xsync_active") == 1
+    for shape, steps in (("lanczos", 20), ("gmres", 20)):
+        nx = 2500 if shape == "lanczos" else 1000
+        ny = (2000 if shape == "lanczos" else 1000) * world
+        n = nx * ny
+        A = ko.laplacian_2d(nx, ny) if shape == "lanczos" else ko.convection_diffusion_2d(nx, ny)
+        x0 = np.random.default_rng(3).random(n)
+        part = kd.Partition.even(n, world, rank, align=nx)
+        lo, hi = part.lo, part.hi
+        op = kd.NativeShardedOperator(A[lo:hi], part, ctx, symmetric=(shape == "lanczos"))
+        ctx.prof_reset(); ctx.prof_enable(1)
+        t1 = ctx.get_option("persist_timeouts")
+        if shape == "lanczos":
+            it = kk.LanczosIterator(op, x0[lo:hi], kk.ModifiedGramSchmidt2(), capacity=steps + 3)
+        else:
+            it = kk.ArnoldiIterator(op, x0[lo:hi], kk.ModifiedGramSchmidt2(), capacity=steps + 3)
+        f = kk.initialize(it)
+        t0 = time.time()
+        for i in range(steps):
+            f = kk.expand_(it, f)
+        ctx.sync()
+        dt = time.time() - t0
+        ctx.prof_enable(0)
+        kern = "k_mgs_persist" if shape == "lanczos" else "k_mgs_panel"
+        assert ctx.prof_get(kern)[1] >= steps - 1, (shape, ctx.prof_get("k_mgs_persist"), ctx.prof_get("k_mgs_panel"))
+        assert ctx.get_option("persist_timeouts") == t1, shape
+        comm.barrier()
+        if shape == "lanczos":
+            a_ref, b_ref = cpu_ref_lib.run_lanczos(ref, A, x0, steps, 3, nthreads=max(2, cpu_ref_lib.usable_threads() // world))[:2]   # 3 = MGS2
+            ea, eb = relerr(f.alphas, a_ref), relerr(f.betas, b_ref)
+            assert ea < 1e-10 and eb < 1e-10, (shape, ea, eb)
+            report[f"full.{shape}"] = [float(a).hex() for a in f.alphas] + [float(b).hex() for b in f.betas]
+        else:
+            oit = ko.ArnoldiIterator(A, x0.copy(), ko.MGS2); of = ko.arnoldi_initialize(oit)
+            for _ in range(steps):
+                of = ko.arnoldi_expand(oit, of)
+            H = np.asarray(f.H, dtype=float)
+            ea = float(np.max(np.abs(H - np.asarray(of.H))) / np.max(np.abs(of.H)))
+            assert ea < 1e-10, (shape, ea)
+            report[f"full.{shape}"] = [float(h).hex() for h in H.ravel()]
+        report[f"full.{shape}.ms_per_step"] = 1e3 * dt / steps
+        del it, f, op
 elif scenario == "bad_input":
     # a collective create call with bad input on ONE rank: every rank must come back with an error (nobody left waiting)
     import ctypes as C
