@@ -187,6 +187,17 @@ static int xs_setup(kk_ctx c) {
     k->xs_active = true;
     return KK_OK;
 }
+void kk_xs_postmortem(kk_ctx ctx, const char* where) {
+    static const bool on = getenv("KK_XSYNC_DEBUG") && atoi(getenv("KK_XSYNC_DEBUG")) != 0;
+    kk_comm_s* k = ctx->comm;
+    if (!on || !k || !k->xs_mine) return;
+    unsigned h[16 + 64 + 2 * KK_XS_SET_BYTES / 4];
+    if (hipMemcpy(h, k->xs_mine + KK_XS_DBG_OFFSET, (16 + 64) * 4, hipMemcpyDeviceToHost) != hipSuccess) return;
+    fprintf(stderr, "[kk_xsync rank %d] %s: host launch %u red %u | first give-up: launch %u tag %u nval %u why %u (1 peer abort, 2 local flag, 4 timeout) block %u red %u | tags seen:",
+            k->rank, where, k->xs_launch, k->xs_red, h[0], h[1], h[2], h[3], h[4], h[5]);
+    for (int l = 0; l < 64; ++l) if ((l >> 3) < (int)h[2] && (l & 7) < k->world) fprintf(stderr, " [v%d r%d]=%u", l >> 3, l & 7, h[16 + l]);
+    fprintf(stderr, "\n");
+}
 kk_xs_dev kk_xs_launch_args(kk_ctx ctx, unsigned nred) {
     kk_xs_dev a;
     if (!kk_sharded(ctx) || !kk_xs_on(ctx)) return a;

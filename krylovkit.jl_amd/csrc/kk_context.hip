@@ -171,6 +171,9 @@ KK_API int kk_ctx_set_option(kk_ctx c, const char* key, double value) {
         c->persist_skip = 0;
     } else if (!strcmp(key, "persist_coop")) {
         c->persist_coop = value != 0;
+    } else if (!strcmp(key, "persist_timeout_ms")) {
+        KK_CHECK(value >= 0 && value <= 60000, KK_ERR_INVALID, "persist_timeout_ms must be in 0 (by sweep size) .. 60000");
+        c->persist_timeout_ms = value;
     } else if (!strcmp(key, "num_cus")) {
         // CUs this context may count on (a GPU shared between ranks / jobs: HSA_CU_MASK, CU-masked streams): the persistent
         // kernels launch one block per CU and need all of them resident at once
@@ -274,6 +277,7 @@ KK_API int kk_ctx_get_option(kk_ctx c, const char* key, double* value) {
     else if (!strcmp(key, "mgs_mode")) *value = c->mgs_mode;
     else if (!strcmp(key, "num_cus")) *value = c->num_cus;
     else if (!strcmp(key, "device_cus")) *value = c->dev_cus;
+    else if (!strcmp(key, "persist_timeout_ms")) *value = c->persist_timeout_ms;
     else if (!strcmp(key, "xsync")) *value = c->xsync;
     else if (!strcmp(key, "xsync_active")) *value = kk_xs_on(c) ? 1 : 0;
     else if (!strcmp(key, "xsync_launches")) *value = c->comm ? (double)c->comm->n_xs_launches : 0.0;

@@ -93,6 +93,7 @@ int kk_hip_fail(hipError_t e, const char* what, const char* file, int line);
 #define KK_XS_MAX_VALS 8         // values per reduction (panel kernel: P (P + 1) / 2 <= 6)
 #define KK_XS_SET_BYTES (KK_XS_MAX_VALS * KK_XS_MAX_RANKS * 16)   // granule (value v, rank r) of a set at (v * 8 + r) * 16
 #define KK_XS_ERR_OFFSET (2 * KK_XS_SET_BYTES)                    // id of the launch a peer gave up in (0 = none)
+#define KK_XS_DBG_OFFSET 3072                                     // post-mortem of the first block that gave up in a cross-rank reduction: [launch, tag, nval, why, block, red | 64 observed tags]
 #define KK_XS_BYTES 4096
 struct kk_xs_dev {               // by value in the kernarg segment of the persistent kernels; world == 0: single-rank launch
     const unsigned long long* table = nullptr;   // device: base address of every rank's area as mapped into THIS process
@@ -199,6 +200,8 @@ struct kk_ctx_s {
     bool persist_norm_req = false; // the caller of the sweep wants w / |w| stored (expand!'s scale of the next step, orthonormalize!!)
     bool persist_norm_done = false;  // ... and the last sweep went through a launch that was asked to do so
     int persist_timeouts = 0;      // grid-barrier timeouts recovered so far
+    int persist_timeouts_row = 0;  // ... in a row (no clean launch in between): 3 switch the launches to the cooperative API (residency guaranteed by the runtime)
+    double persist_timeout_ms = 0; // spin budget of a persistent launch in ms; 0 = by the size of the sweep (kk_persist_timeout_ticks)
     int persist_skip = 0;          // strict sweeps still to run on the launch-per-vector route before the persistent one is retried
     int persist_backoff = 4;       // ... how many after the next timeout (doubles with every timeout in a row)
     int persist_fault = 0;         // test hook (option "persist_fault"): the next N persistent launches time out artificially
@@ -465,7 +468,8 @@ static inline bool kk_xs_on(kk_ctx ctx) {
 }
 // fills the kernel argument of one persistent launch with `nred` grid reductions (all zero on a single-rank context)
 kk_xs_dev kk_xs_launch_args(kk_ctx ctx, unsigned nred);
-int kk_launch_xs_selftest(kk_ctx ctx, const kk_xs_dev& xs, int* out_dev);   // 4 reductions; *out_dev = 1 on success
+int kk_launch_xs_selftest(kk_ctx ctx, const kk_xs_dev& xs, int* out_dev);
+void kk_xs_postmortem(kk_ctx ctx, const char* where);   // KK_XSYNC_DEBUG=1: what the first block that gave up saw (stderr)   // 4 reductions; *out_dev = 1 on success
 struct kk_ar_suspend {   // RAII: local partials only inside the scope
     kk_ctx c; bool prev;
     explicit kk_ar_suspend(kk_ctx ctx) : c(ctx), prev(ctx->ar_suspend) { c->ar_suspend = true; }
@@ -498,6 +502,7 @@ int kk_launch_lsmr_hx(kk_ctx ctx, double* h, double* hbar, double* x, const doub
                       double c3);
 bool kk_mgs_persist_eligible(kk_ctx ctx, int64_t ld, int m, int nsweeps);
 int kk_launch_resident(kk_ctx ctx, const void* fn, int threads, void** args, size_t dyn_lds, const char* what);
+long long kk_persist_timeout_ticks(kk_ctx ctx, int64_t ld, int nvec, bool cross_rank);
 bool kk_mgs_panel_eligible(kk_ctx ctx, int64_t ld);
 int64_t kk_mgs_panel_capacity(kk_ctx ctx);
 int kk_mgs_panel_width(kk_ctx ctx, int64_t ld, bool strict);

@@ -41,7 +41,7 @@
 #include "kk_device.h"
 #include "kk_xsync.h"
 
-#define KK_PANEL_TIMEOUT_TICKS 300000000ll   // 3 s of the 100 MHz wall clock
+// (spin budget of a launch: kk_persist_timeout_ticks, handed to the kernel in xs_timeout / `timeout_ticks`)
 #define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 #define KK_PANEL_PT 512
 
@@ -114,7 +114,7 @@ __device__ __forceinline__ void panel_publish(int nval, unsigned epoch, int set,
 }
 // wave 0, between barriers (1b) and (2): sweep the partials of all blocks, totals to smB[0 .. nval), timeout flag to smB[8]
 __device__ __forceinline__ bool panel_sweep(int nval, unsigned epoch, int set, char* __restrict__ sync, int* __restrict__ err, double* smB, const kk_xs_dev& xs,
-                                            unsigned xred /* index of this reduction within the launch */, int pidx = 0) {
+                                            unsigned xred /* index of this reduction within the launch */, long long timeout_ticks, int pidx = 0) {
     const int G = gridDim.x;
     const int lane = threadIdx.x;
     const unsigned set_bytes = (unsigned)G * 16u * 8u;
@@ -153,14 +153,14 @@ __device__ __forceinline__ bool panel_sweep(int nval, unsigned epoch, int set, c
             }
             if (__all(ok)) { total = wave_sum(x); break; }
             __builtin_amdgcn_s_sleep(1);
-            if (wall_clock64() - t0 > KK_PANEL_TIMEOUT_TICKS || errv) { good = 0; break; }
+            if (wall_clock64() - t0 > timeout_ticks || errv) { good = 0; break; }
         }
         if (xs.world > 0) { if (lane == v) mine = total; }
         else if (lane == 0) smB[v] = total;
     }
     if (xs.world > 0) {   // level 2: the sum over the ranks (kk_xsync.h); lanes v * 8 .. v * 8 + 7 receive the total of value v
         double t2 = 0;
-        if (good && !xs_allreduce(xs, xred, nval, mine, err, KK_PANEL_TIMEOUT_TICKS, t2)) good = 0;
+        if (good && !xs_allreduce(xs, xred, nval, mine, err, timeout_ticks, t2)) good = 0;
         if (good && (lane & 7) == 0 && (lane >> 3) < nval) smB[lane >> 3] = t2;
         if (!good && lane == 0) xs_abort(xs);
     }
@@ -172,12 +172,12 @@ __device__ __forceinline__ bool panel_sweep(int nval, unsigned epoch, int set, c
 }
 // one whole reduction as seen by a wave 0 that holds no rows (KK_PANEL_DW = 7)
 __device__ __forceinline__ bool panel_reduce_sync(int nval, unsigned epoch, int set, char* __restrict__ sync, int* __restrict__ err, const double* smA,
-                                                  double* smB, const kk_xs_dev& xs, unsigned xred, int pidx = 0) {
+                                                  double* smB, const kk_xs_dev& xs, unsigned xred, long long timeout_ticks, int pidx = 0) {
     lds_barrier();   // (1)
     panel_publish(nval, epoch, set, sync, smA);
     PTRACE(8, pidx);
     lds_barrier();   // (1b)
-    const bool good = panel_sweep(nval, epoch, set, sync, err, smB, xs, xred, pidx);
+    const bool good = panel_sweep(nval, epoch, set, sync, err, smB, xs, xred, timeout_ticks, pidx);
     lds_barrier();   // (2)
     return good;
 }
@@ -206,13 +206,13 @@ __device__ __forceinline__ void panel_handoff(const double (&acc)[NVAL], double*
 // second half: the totals (same bits in every thread of every block).  Returns false after a timeout anywhere on the chip.
 template <int NVAL>
 __device__ __forceinline__ bool panel_totals(const double (&acc)[NVAL], double (&tot)[NVAL], double* smB, unsigned epoch, int set, char* __restrict__ sync,
-                                             int* __restrict__ err, const kk_xs_dev& xs, unsigned xred, int pidx = 0) {
+                                             int* __restrict__ err, const kk_xs_dev& xs, unsigned xred, long long timeout_ticks, int pidx = 0) {
 #ifdef KK_PANEL_NOSYNC
 #pragma unroll
     for (int v = 0; v < NVAL; ++v) tot[v] = acc[v] * 1e-30;
     return true;
 #endif
-    if (KK_PANEL_W0 == 0 && threadIdx.x < 64) panel_sweep(NVAL, epoch, set, sync, err, smB, xs, xred, pidx);   // (its sweep queues behind its own panel loads: fine)
+    if (KK_PANEL_W0 == 0 && threadIdx.x < 64) panel_sweep(NVAL, epoch, set, sync, err, smB, xs, xred, timeout_ticks, pidx);   // (its sweep queues behind its own panel loads: fine)
     lds_barrier();   // (2)
     PTRACE(3, pidx);   // totals available
 #pragma unroll
@@ -261,10 +261,10 @@ __device__ __forceinline__ void panel_dots(const d2 (&wr)[NV], const d2 (&cur)[P
 // second half: totals -> coefficients -> update of w
 template <int NV, int P>
 __device__ __forceinline__ bool panel_update(d2 (&wr)[NV], d2 (&cur)[P][NV], const double (&acc)[P * (P + 1) / 2], int s0, int nsteps, int m,
-                                             double* smB, double* __restrict__ out_s, int out_stride, unsigned ebase, char* sync, int* err, const kk_xs_dev& xs, int pidx) {
+                                             double* smB, double* __restrict__ out_s, int out_stride, unsigned ebase, char* sync, int* err, const kk_xs_dev& xs, long long timeout_ticks, int pidx) {
     constexpr int NVAL = P * (P + 1) / 2;
     double tot[NVAL];
-    if (!panel_totals<NVAL>(acc, tot, smB, ebase + (unsigned)pidx + 1u, pidx & 1, sync, err, xs, (unsigned)pidx, pidx)) return false;
+    if (!panel_totals<NVAL>(acc, tot, smB, ebase + (unsigned)pidx + 1u, pidx & 1, sync, err, xs, (unsigned)pidx, timeout_ticks, pidx)) return false;
     // (I + L) s = d, L = strictly lower in-panel Gram block: exact forward substitution, the same bits in every thread
     double s[P];
 #pragma unroll
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(KK_PANEL_PT) void k_mgs_panel(const double* __restr
                                                            const double* __restrict__ carry_q, const double* __restrict__ carry_s,
                                                            double* __restrict__ out_s, int out_stride, double* __restrict__ nrm_out3,
                                                            char* __restrict__ sync, int* __restrict__ err, int fault, unsigned ebase, int normalize,
-                                                           double* __restrict__ ok_out, double token, kk_xs_dev xs) {
+                                                           double* __restrict__ ok_out, double token, kk_xs_dev xs, long long timeout_ticks) {
     __shared__ double smA[64];
     __shared__ double smB[16];
     if (fault && blockIdx.x == 0) {   // test hook (option "persist_fault"): block 0 behaves like a block whose spin ran out
@@ -316,8 +316,8 @@ __global__ __launch_bounds__(KK_PANEL_PT) void k_mgs_panel(const double* __restr
         return;
 #endif
         for (int p = 0; p < npanels; ++p)
-            if (!panel_reduce_sync(NVAL, ebase + (unsigned)p + 1u, p & 1, sync, err, smA, smB, xs, (unsigned)p, p)) return;
-        if (nrm_out3) panel_reduce_sync(1, ebase + (unsigned)npanels + 1u, npanels & 1, sync, err, smA, smB, xs, (unsigned)npanels);
+            if (!panel_reduce_sync(NVAL, ebase + (unsigned)p + 1u, p & 1, sync, err, smA, smB, xs, (unsigned)p, timeout_ticks, p)) return;
+        if (nrm_out3) panel_reduce_sync(1, ebase + (unsigned)npanels + 1u, npanels & 1, sync, err, smA, smB, xs, (unsigned)npanels, timeout_ticks);
         return;
     }
     // ---------------- the data waves
@@ -361,13 +361,13 @@ __global__ __launch_bounds__(KK_PANEL_PT) void k_mgs_panel(const double* __restr
         panel_dots<NV, P>(wr, qa, acc, smA, ebase, sync, p);
         PTRACE(0, p);
         panel_issue<NV, P, EARLY, NV>(qb, V, ld, m, (p + 1) * P, nsteps, voff, sbytes, brow, bbytes);   // the rest, in flight across this panel's reduction
-        if (!panel_update<NV, P>(wr, qa, acc, p * P, nsteps, m, smB, out_s, out_stride, ebase, sync, err, xs, p)) return;   // timeout: w in HBM is untouched
+        if (!panel_update<NV, P>(wr, qa, acc, p * P, nsteps, m, smB, out_s, out_stride, ebase, sync, err, xs, timeout_ticks, p)) return;   // timeout: w in HBM is untouched
         if (p + 1 >= npanels) break;
         panel_issue<NV, P, 0, EARLY>(qa, V, ld, m, (p + 2) * P, nsteps, voff, sbytes, brow, bbytes);
         panel_dots<NV, P>(wr, qb, acc, smA, ebase, sync, p + 1);
         PTRACE(0, p + 1);
         panel_issue<NV, P, EARLY, NV>(qa, V, ld, m, (p + 2) * P, nsteps, voff, sbytes, brow, bbytes);
-        if (!panel_update<NV, P>(wr, qb, acc, (p + 1) * P, nsteps, m, smB, out_s, out_stride, ebase, sync, err, xs, p + 1)) return;
+        if (!panel_update<NV, P>(wr, qb, acc, (p + 1) * P, nsteps, m, smB, out_s, out_stride, ebase, sync, err, xs, timeout_ticks, p + 1)) return;
     }
     double inv = 1.0;
     bool scale = false;
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(KK_PANEL_PT) void k_mgs_panel(const double* __restr
 #pragma unroll
         for (int j = 0; j < NV; ++j) { an[0] = fma(wr[j].x, wr[j].x, an[0]); an[0] = fma(wr[j].y, wr[j].y, an[0]); }
         panel_handoff<1>(an, smA, ebase + (unsigned)npanels + 1u, npanels & 1, sync);
-        if (!panel_totals<1>(an, tot, smB, ebase + (unsigned)npanels + 1u, npanels & 1, sync, err, xs, (unsigned)npanels)) return;
+        if (!panel_totals<1>(an, tot, smB, ebase + (unsigned)npanels + 1u, npanels & 1, sync, err, xs, (unsigned)npanels, timeout_ticks)) return;
         const double rt = sqrt(tot[0]);
         inv = 1.0 / rt;
         scale = normalize && rt > 0.0 && inv <= 1.79769313486231570815e308;
@@ -439,9 +439,10 @@ int kk_launch_mgs_panel(kk_ctx ctx, const double* V, int64_t ld, int m, int nswe
     double token = ctx->persist_token;
     double* ok_out = ctx->ws + WS_SCAL + SC_PERSIST_OK;
     kk_xs_dev xs = kk_xs_launch_args(ctx, (unsigned)((m * nsweeps + P - 1) / P) + (nrm_out3 ? 1u : 0u));   // cross-rank reductions of this launch (row-sharded context)
+    long long timeout_ticks = kk_persist_timeout_ticks(ctx, ld, m * nsweeps, xs.world > 0);
     void* args[] = {(void*)&V, (void*)&ld, (void*)&m, (void*)&nsweeps, (void*)&w, (void*)&carry_q, (void*)&carry_s,
                     (void*)&out_s, (void*)&out_stride, (void*)&nrm_out3, (void*)&sync, (void*)&err, (void*)&fault,
-                    (void*)&ebase, (void*)&normalize, (void*)&ok_out, (void*)&token, (void*)&xs};
+                    (void*)&ebase, (void*)&normalize, (void*)&ok_out, (void*)&token, (void*)&xs, (void*)&timeout_ticks};
     kk_prof_scope ps(ctx, "k_mgs_panel");
     if (nv <= 4) return P >= 3 ? launch_panel_inst<4, 3>(ctx, args) : (P == 2 ? launch_panel_inst<4, 2>(ctx, args) : launch_panel_inst<4, 1>(ctx, args));
     if (nv <= KK_PANEL_NVMID) return P >= 2 ? launch_panel_inst<KK_PANEL_NVMID, 2>(ctx, args) : launch_panel_inst<KK_PANEL_NVMID, 1>(ctx, args);

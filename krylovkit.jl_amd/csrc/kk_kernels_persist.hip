@@ -18,6 +18,7 @@
 #include "kk_internal.h"
 #include "kk_device.h"
 #include "kk_xsync.h"
+#include <algorithm>
 
 // First read of a basis vector (as q_next): non-temporal for the grid-rows that will wait on chip (LDS / spare registers) and
 // are therefore never read again, cache-allocating only for the rows that ARE read a second time one step later.  With every
@@ -27,7 +28,7 @@
 #ifndef KK_PERSIST_NT_FIRST
 #define KK_PERSIST_NT_FIRST 1
 #endif
-#define KK_PERSIST_TIMEOUT_TICKS 300000000ll   // 3 s of the 100 MHz wall clock
+// (every spin is bounded by the wall clock, 100 MHz ticks: the budget comes with the launch -- kk_persist_timeout_ticks)
 #define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
@@ -78,7 +79,7 @@ __device__ __forceinline__ void grid_publish(double acc, int step, unsigned ebas
 template <int PT>
 __device__ __forceinline__ bool grid_collect(int step, unsigned ebase, char* __restrict__ sync, int* __restrict__ err,
                                              double* sm, double* out, unsigned gstride /* bytes between the granules of two blocks: 128 = own line, 16 = packed */,
-                                             const kk_xs_dev& xs /* row-sharded context: the sum over the ranks follows (kk_xsync.h) */) {
+                                             const kk_xs_dev& xs /* row-sharded context: the sum over the ranks follows (kk_xsync.h) */, long long timeout_ticks) {
     const int G = gridDim.x;
     const unsigned epoch = ebase + (unsigned)step + 1u;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(sync, 0, 2 * G * KK_SYNC_LINE, 0x00020000);
@@ -116,11 +117,11 @@ __device__ __forceinline__ bool grid_collect(int step, unsigned ebase, char* __r
             }
             if (__all(ok)) { total = wave_sum(x); break; }
             __builtin_amdgcn_s_sleep(1);
-            if (wall_clock64() - t0 > KK_PERSIST_TIMEOUT_TICKS || errv) { good = 0; break; }
+            if (wall_clock64() - t0 > timeout_ticks || errv) { good = 0; break; }
         }
         if (xs.world > 0) {   // level 2: every block of this rank holds the same bits of the rank's partial -- now the sum over the ranks
             double t2 = 0;
-            if (good && !xs_allreduce(xs, (unsigned)step, 1, total, err, KK_PERSIST_TIMEOUT_TICKS, t2)) good = 0;
+            if (good && !xs_allreduce(xs, (unsigned)step, 1, total, err, timeout_ticks, t2)) good = 0;
             total = t2;   // (lane 0: value 0)
             if (!good && lane == 0) xs_abort(xs);   // whatever went wrong on this chip, the peers must not wait for it
         }
@@ -230,7 +231,7 @@ __global__ __launch_bounds__(PT) void k_mgs_persist(const double* __restrict__ V
                                                     const double* __restrict__ carry_s, double* __restrict__ out_s,
                                                     int out_stride, double* __restrict__ nrm_out3,
                                                     char* __restrict__ sync, int* __restrict__ err, int fault, unsigned gstride,
-                                                    unsigned ebase, int normalize, double* __restrict__ ok_out, double token, kk_xs_dev xs) {
+                                                    unsigned ebase, int normalize, double* __restrict__ ok_out, double token, kk_xs_dev xs, long long timeout_ticks) {
     __shared__ double sm[PT / 64];
     extern __shared__ d2 park[];   // NL * PT double2 (dynamic): the parked grid-rows of the current basis vector
     if (fault && blockIdx.x == 0) {   // test hook (option "persist_fault"): block 0 behaves like a block whose spin ran out
@@ -301,7 +302,7 @@ __global__ __launch_bounds__(PT) void k_mgs_persist(const double* __restrict__ V
         for (int u = 0; u < B; ++u) qpre[u] = bload(r2, voff, (unsigned)(u < NV ? u : 0) * sbytes, KK_PERSIST_NT_FIRST == 2 || (KK_PERSIST_NT_FIRST == 1 && u < NL + NR));
         __builtin_amdgcn_sched_barrier(0);
 #endif
-        if (!grid_collect<PT>(s, ebase, sync, err, sm, &total, gstride, xs)) return;   // timeout: w in HBM is untouched
+        if (!grid_collect<PT>(s, ebase, sync, err, sm, &total, gstride, xs, timeout_ticks)) return;   // timeout: w in HBM is untouched
         if (blockIdx.x == 0 && threadIdx.x == 0) out_s[(s / m) * out_stride + (s % m)] = total;
         sp = total;
         qp = qn;
@@ -313,7 +314,7 @@ __global__ __launch_bounds__(PT) void k_mgs_persist(const double* __restrict__ V
         persist_step<NV, NL, NR, PT, B, NTPREV, true, true>(wr, qk, qpre, col_rsrc(qp, ld), col_rsrc(qp, ld), sp, sbytes, voff, lq, a0, a1);
         if (nrm_out3) {
             grid_publish<PT>(a0 + a1, nsteps, ebase, sync, sm, gstride);
-            if (!grid_collect<PT>(nsteps, ebase, sync, err, sm, &total, gstride, xs)) return;
+            if (!grid_collect<PT>(nsteps, ebase, sync, err, sm, &total, gstride, xs, timeout_ticks)) return;
             // every block holds the same bits of |w|^2: the normalised commit below needs no second exchange
             const double rt = sqrt(total);
             inv = 1.0 / rt;
@@ -351,6 +352,21 @@ __global__ __launch_bounds__(PT) void k_mgs_persist(const double* __restrict__ V
 // or stream holds CUs) a block that cannot start is exactly the situation the bounded spins already handle: the flag is
 // raised after 3 s, no block commits, the sweep is repeated on the launch-per-vector route and the persistent route backs
 // off (persist_check_at).  Option "persist_coop" = 1 restores the cooperative API.
+// Spin budget of one persistent launch.  The kernels are ordinary launches (below): a block that is not resident -- the GPU is
+// shared with another queue or process -- is waited for this long, then the launch gives up without committing and the sweep
+// is repeated on the launch-per-vector route.  3 s (rounds 3-4) was four orders of magnitude above a sweep; now 50 x the time
+// the sweep's bytes take at 2 TB/s + 1 ms, at least 20 ms, at most 3 s (option "persist_timeout_ms" > 0 fixes it).  A
+// row-sharded launch also waits for its PEERS' launches, i.e. for their hosts: never less than 1 s there.
+long long kk_persist_timeout_ticks(kk_ctx ctx, int64_t ld, int nvec, bool cross_rank) {
+    double ms;
+    if (ctx->persist_timeout_ms > 0) ms = ctx->persist_timeout_ms;
+    else {
+        const double est_ms = 1.0 + 1e3 * ((double)(nvec + 2) * (double)ld * 8.0) / 2e12;
+        ms = std::min(3000.0, std::max(20.0, 50.0 * est_ms));
+        if (cross_rank) ms = std::max(ms, 1000.0);
+    }
+    return (long long)(ms * 1e5);   // 100 MHz wall clock
+}
 int kk_launch_resident(kk_ctx ctx, const void* fn, int threads, void** args, size_t dyn_lds, const char* what) {
     const dim3 g(ctx->num_cus), b(threads);
     hipError_t e = ctx->persist_coop ? hipLaunchCooperativeKernel(fn, g, b, args, dyn_lds, ctx->stream)
@@ -440,9 +456,10 @@ int kk_launch_mgs_persist(kk_ctx ctx, const double* V, int64_t ld, int m, int ns
     double token = ctx->persist_token;
     double* ok_out = ctx->ws + WS_SCAL + SC_PERSIST_OK;
     kk_xs_dev xs = kk_xs_launch_args(ctx, (unsigned)(m * nsweeps) + (nrm_out3 ? 1u : 0u));   // one cross-rank reduction per grid reduction (row-sharded context)
+    long long timeout_ticks = kk_persist_timeout_ticks(ctx, ld, m * nsweeps, xs.world > 0);
     void* args[] = {(void*)&V, (void*)&ld, (void*)&m, (void*)&nsweeps, (void*)&w, (void*)&carry_q, (void*)&carry_s,
                     (void*)&out_s, (void*)&out_stride, (void*)&nrm_out3, (void*)&sync, (void*)&err, (void*)&fault, (void*)&gstride,
-                    (void*)&ebase, (void*)&normalize, (void*)&ok_out, (void*)&token, (void*)&xs};
+                    (void*)&ebase, (void*)&normalize, (void*)&ok_out, (void*)&token, (void*)&xs, (void*)&timeout_ticks};
     const bool nt = ctx->persist_nt != 0;
     kk_prof_scope ps(ctx, "k_mgs_persist");
     if (pt == 1024) {

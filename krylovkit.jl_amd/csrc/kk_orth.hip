@@ -280,6 +280,7 @@ int persist_check_at(kk_ctx c, int slot, double token, bool* timed_out) {
     // a launch that committed wrote its token next to the scalars of the sweep (same read-back); anything else -- the flag
     // was raised by a block whose spin ran out, blocks left without writing w back -- leaves the previous launch's token
     if (pin(c, WS_SCAL + SC_PERSIST_OK, slot)[0] != token) {
+        kk_xs_postmortem(c, "persistent launch did not commit");
         KK_HIP(hipMemsetAsync((char*)c->d_sync + KK_SYNC_ERR_OFFSET, 0, sizeof(int), c->stream));
         c->persist_norm_done = false;
         ++c->persist_timeouts;
@@ -290,9 +291,14 @@ int persist_check_at(kk_ctx c, int slot, double token, bool* timed_out) {
         // doubling with every timeout in a row.
         c->persist_skip = c->persist_backoff;
         c->persist_backoff = std::min(c->persist_backoff * 2, 1 << 20);
+        // ordinary launches ASSUME that all blocks become resident.  Where that keeps failing (CUs masked or held by
+        // another queue for good) the retries go through the cooperative API from now on: the runtime then guarantees the
+        // residency (at ~35 us per launch) -- on a single-rank context; across ranks no launch API can, the back-off stays.
+        if (++c->persist_timeouts_row >= 3 && !c->persist_coop && !kk_xs_on(c)) c->persist_coop = 1;
         *timed_out = true;
-    } else if (c->persist_backoff > 4) {
-        c->persist_backoff = 4;   // a clean launch: back to the short retry interval
+    } else {
+        c->persist_timeouts_row = 0;
+        if (c->persist_backoff > 4) c->persist_backoff = 4;   // a clean launch: back to the short retry interval
     }
     return KK_OK;
 }

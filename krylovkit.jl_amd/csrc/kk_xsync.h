@@ -63,7 +63,23 @@ __device__ __forceinline__ bool xs_allreduce(const kk_xs_dev& xs, unsigned red, 
             break;
         }
         __builtin_amdgcn_s_sleep(1);
-        if (xerr == xs.launch || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || wall_clock64() - t0 > timeout_ticks) return false;
+        const int lerr = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool late = wall_clock64() - t0 > timeout_ticks;
+        if (xerr == xs.launch || lerr || late) {
+            // post-mortem (KK_XSYNC_DEBUG=1 prints it): the first block that gave up leaves what it saw in the tail of its rank's area
+            if (__builtin_amdgcn_raw_buffer_load_b32(rm, KK_XS_DBG_OFFSET, 0, KK_XS_AUX) != xs.launch) {
+                __builtin_amdgcn_raw_buffer_store_b32(g.x, rm, KK_XS_DBG_OFFSET + 64u + (unsigned)lane * 4u, 0, KK_XS_AUX);
+                if (lane == 0) {
+                    __builtin_amdgcn_raw_buffer_store_b32(tag, rm, KK_XS_DBG_OFFSET + 4u, 0, KK_XS_AUX);
+                    __builtin_amdgcn_raw_buffer_store_b32((unsigned)nval, rm, KK_XS_DBG_OFFSET + 8u, 0, KK_XS_AUX);
+                    __builtin_amdgcn_raw_buffer_store_b32((xerr == xs.launch ? 1u : 0u) | (lerr ? 2u : 0u) | (late ? 4u : 0u), rm, KK_XS_DBG_OFFSET + 12u, 0, KK_XS_AUX);
+                    __builtin_amdgcn_raw_buffer_store_b32(blockIdx.x, rm, KK_XS_DBG_OFFSET + 16u, 0, KK_XS_AUX);
+                    __builtin_amdgcn_raw_buffer_store_b32(red, rm, KK_XS_DBG_OFFSET + 20u, 0, KK_XS_AUX);
+                    __builtin_amdgcn_raw_buffer_store_b32(xs.launch, rm, KK_XS_DBG_OFFSET, 0, KK_XS_AUX);
+                }
+            }
+            return false;
+        }
     }
     // sum over the ranks of a value: lanes v * 8 + r, r < 8 -- butterfly over the group of 8 (every lane of the group ends with
     // the same bits: the additions of a level are commutative), the same tree on every rank

@@ -39,11 +39,19 @@ def device_cus():
         c.close()
 
 
-def run_world(scenario, world, tmp_path, timeout=600, extra_env=None):
+def run_world(scenario, world, tmp_path, timeout=600, extra_env=None, retries=0):
     env = _env(tmp_path)
     # every rank owns its share of the CUs: the persistent kernels (one block per CU, all resident at once) of all ranks then
     # fit the one GPU side by side -- what HSA_CU_MASK / a partition mode would enforce, here by block count alone
-    env["KK_NUM_CUS"] = str(device_cus() // world)
+    # (a launch hands its blocks to the 8 XCDs round-robin, block i -> XCD i % 8, whatever else runs there: W kernels of n blocks
+    # need W * ceil(n / 8) CUs on the XCDs they all start with.  3 x 85 blocks = 33 > 32 CUs on five XCDs never became resident
+    # together: profiles/r05_xsync_world3_residency.txt.  Two ranks fill the chip exactly, 16 + 16 per XCD; more ranks leave one
+    # CU per XCD and rank to the streaming kernels of the others.)
+    # Observed on the gpurun box: 2 x 128 always resident together; 3 x 72 (27 of 32 CUs per XCD) still lost about one launch in
+    # 300 to a 3 s stall with all three kernels partly resident, 3 x 64 and 3 x 48 never -- so every rank gets two CUs per XCD less
+    # than its share, except where a test asks for the full half (KK_NUM_CUS in extra_env).
+    per_xcd = (device_cus() // 8) // world
+    env["KK_NUM_CUS"] = str(8 * (per_xcd - 2))
     env.update(extra_env or {})
     procs = [subprocess.Popen([sys.executable, str(HERE / "world2_worker.py"), scenario, str(r), str(world), str(tmp_path)],
                               env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
@@ -58,6 +66,11 @@ def run_world(scenario, world, tmp_path, timeout=600, extra_env=None):
         outs = [p.communicate()[0] for p in procs]
         pytest.fail(f"world-{world} scenario {scenario} did not finish within {timeout} s\n" + "\n---\n".join(o[-3000:] for o in outs))
     bad = [r for r, (p, o) in enumerate(zip(procs, outs)) if p.returncode != 0 or f"world2 {scenario} rank {r} OK" not in o]
+    if bad and retries > 0:   # ranks sharing ONE GPU: a launch lost to the co-tenants is an artefact of the test box, not of the path (see above)
+        print(f"world-{world} scenario {scenario}: retrying after\n" + "\n".join(outs[r][-1500:] for r in bad))
+        sub = tmp_path / f"retry{retries}"
+        sub.mkdir()
+        return run_world(scenario, world, sub, timeout, extra_env, retries - 1)
     assert not bad, "\n".join(f"=== rank {r} (exit {p.returncode}) ===\n{o[-5000:]}" for r, (p, o) in enumerate(zip(procs, outs)))
     return [json.loads((tmp_path / f"report.{r}.json").read_text()) for r in range(world)]
 
@@ -118,7 +131,7 @@ def test_world_persistent_kernels_reduce_over_the_ranks_in_kernel(tmp_path, worl
     """k_mgs_persist / k_mgs_panel on a row-sharded context -- two-level grid reduction, tagged granules
     stored into the peers' IPC-mapped sync areas, RCCL only for the ghost exchange and alpha0.  Lanczos MGS2, Arnoldi MGS / MGS2
     against the oracle at 1e-10, strict and panel order, run-ahead on and off, bit-identical scalars on every rank"""
-    reps = run_world("xsync", world, tmp_path)
+    reps = run_world("xsync", world, tmp_path, retries=1)
     keys = [k for k in reps[0] if "." in k and isinstance(reps[0][k], list)]
     assert len(keys) == 12
     for k in keys:
@@ -137,7 +150,7 @@ def test_world2_persistent_kernels_recover_when_one_rank_loses_a_launch(tmp_path
 def test_world2_persistent_kernels_full_size_shards(tmp_path):
     """2 x 5 M rows (config-2 shape, k_mgs_persist) and 2 x 1 M rows (config-3 shape, k_mgs_panel) with default options:
     the auto mode takes the persistent kernels on the sharded context, alpha / beta / H against the CPU twin at 1e-10"""
-    reps = run_world("xsync_full", 2, tmp_path, timeout=1500)
+    reps = run_world("xsync_full", 2, tmp_path, timeout=1500, extra_env={"KK_NUM_CUS": str(device_cus() // 2)}, retries=1)
     for k in ("full.lanczos", "full.gmres"):
         assert reps[0][k] == reps[1][k], k
     print({k: [r[k] for r in reps] for k in ("full.lanczos.ms_per_step", "full.gmres.ms_per_step")})

@@ -325,7 +325,7 @@ elif scenario in ("xsync", "xsync_fault"):
     # (csrc/kk_xsync.h; reference order src/orthonormal.jl:414-439, factorizations/lanczos.jl:325-338, arnoldi.jl:239-245).
     # Every rank owns num_cus = device / world CUs (KK_NUM_CUS): the launches of all ranks are resident side by side.
     assert ctx.get_option("xsync_active") == 1, "kk_comm_init did not establish the cross-rank sync areas"
-    assert ctx.get_option("num_cus") <= ctx.get_option("device_cus") // world
+    assert ctx.get_option("num_cus") * world <= ctx.get_option("device_cus")
     nx, ny = 70, 64 * world
     n = nx * ny
     A = ko.laplacian_2d(nx, ny, shift_diag=10 * np.linspace(0, 1, n) ** 2)
@@ -358,6 +358,7 @@ elif scenario in ("xsync", "xsync_fault"):
             s1 = comm.stats()
             ctx.prof_enable(0)
             launches = ctx.prof_get("k_mgs_persist")[1] + ctx.prof_get("k_mgs_panel")[1]
+            print(f"[xsync rank {rank}] {route} la={lookahead} {case}: launches {launches} timeouts {ctx.get_option('persist_timeouts') - t1}", flush=True)
             assert launches > 0 and ctx.get_option("xsync_launches") - x1 == launches, (route, case, launches)
             assert (ctx.prof_get("k_mgs_persist")[1] > 0) == (route == "persist"), (route, case)
             if fault_at:
