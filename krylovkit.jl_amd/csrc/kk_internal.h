@@ -514,8 +514,11 @@ int kk_launch_mgs_panel(kk_ctx ctx, const double* V, int64_t ld, int m, int nswe
 // projection pair otherwise (tiny vectors: launch-bound; vectors beyond the register file; row-sharded contexts).
 static inline bool kk_mgs_lowsync(kk_ctx ctx, int64_t ld, int m) {
     if (ctx->mgs_mode != 2) return ctx->mgs_mode == 1;
-    if (ld >= ctx->panel_min_rows && kk_mgs_panel_eligible(ctx, ld)) return false;
-    return !(ld >= ctx->persist_min_rows && kk_mgs_persist_eligible(ctx, ld, m, 2));
+    // (the thresholds were measured on the whole chip: what decides is the length of a CU's share of the vector, so a context
+    // that owns fewer CUs -- option "num_cus" -- scales them down with it)
+    const double share = (double)ctx->num_cus / 256.0;
+    if ((double)ld >= share * (double)ctx->panel_min_rows && kk_mgs_panel_eligible(ctx, ld)) return false;
+    return !((double)ld >= share * (double)ctx->persist_min_rows && kk_mgs_persist_eligible(ctx, ld, m, 2));
 }
 int kk_launch_mgs_persist(kk_ctx ctx, const double* V, int64_t ld, int m, int nsweeps, double* w, const double* carry_q,
                           const double* carry_s, double* out_s, int out_stride, double* nrm_out3, bool normalize_w);
