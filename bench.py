@@ -216,6 +216,22 @@ def stamped_traffic(fname: str):
     return tj, f"PMC passes of {tj.get('stamped_by', 'tools/profile_gpu.sh')} on the same kernel sources (sha {tj.get('source_sha')})"
 
 
+def read_ceiling():
+    """the box's own attainable HBM read rate, measured now (tools/hbm_peak.hip --json, ~1 s in a child process before anything
+    of the bench is resident): best non-temporal and best plain 16-byte read stream over 2 GiB.  None when the tool is not
+    built (build() of __graft_entry__.py compiles it)."""
+    import subprocess
+    exe = ROOT / "tools" / "bin" / "hbm_peak"
+    if not exe.exists():
+        return None
+    try:
+        r = subprocess.run([str(exe), "--json"], capture_output=True, text=True, timeout=60)
+        ln = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        return json.loads(ln[-1]) if r.returncode == 0 and ln else None
+    except Exception:
+        return None
+
+
 def physical_roofline(kernel: str, seconds: float, launches: int, traffic_bytes, model_bytes, alg_bytes, min_bytes=None, note=None):
     """roofline object of one kernel class over a timed region: `achieved` = bytes the kernel really moved (counter traffic
     when a stamped PMC pass exists, the byte model of DESIGN.md otherwise) / its event-timed duration; `frac` = achieved /
@@ -259,6 +275,7 @@ def convdiff_rows(nx: int, ny: int, px: float = 0.5, py: float = 0.25) -> sp.csr
     return sp.csr_matrix((vv, (rows, cc)), shape=(n, n))
 
 
+LEG_ROUNDS = 3
 LEG_CLASSES = ("k_project", "k_unproject", "k_unproj_proj", "k_mgs_persist", "k_mgs_panel", "k_mgs_step", "k_spmv_ell", "k_spmv_dia", "k_spmv_sell",
                "k_spmv_csr", "k_scal", "k_dot", "k_axpby", "k_block_gram", "k_block_update", "k_spmm_dia", "k_spmm_ell")
 
@@ -269,14 +286,14 @@ def run_leg(ctx, name: str, sweep, units_per_sweep: int, K: int, model_bytes_per
     when there is one, the byte model otherwise)."""
     sweep()
     ctx.sync()
-    dt = None
-    for _round in range(2):                  # the rate: K sweeps with no event anywhere; the faster of two rounds (host-synchronisation-heavy
-        t0 = time.perf_counter()             # steps -- GKL: four host round trips per expand! -- jitter with whatever else the box is doing)
-        for _ in range(K):
+    rounds = []
+    for _round in range(LEG_ROUNDS):         # the rate: K sweeps with no event anywhere, LEG_ROUNDS times over; the MEDIAN round is reported, the
+        t0 = time.perf_counter()             # fastest and the slowest next to it (host-synchronisation-heavy steps -- GKL: four host round trips
+        for _ in range(K):                   # per expand! -- jitter with whatever else the box is doing; rounds 3-4 reported the best of two)
             fact = sweep()
         ctx.sync()
-        d_ = time.perf_counter() - t0
-        dt = d_ if dt is None else min(dt, d_)
+        rounds.append(time.perf_counter() - t0)
+    dt = sorted(rounds)[len(rounds) // 2]
     ctx.prof_reset(); ctx.prof_enable(1)     # the same K sweeps once more, every kernel class bracketed by HIP events
     for _ in range(K):
         sweep()
@@ -305,6 +322,8 @@ def run_leg(ctx, name: str, sweep, units_per_sweep: int, K: int, model_bytes_per
         roof = physical_roofline(dom, ms * 1e-3, n, None if tb is None else tb * K, None if mb is None else mb * K, None, note=note)
     kernel_ms = sum(v[0] for v in classes.values()) / K
     out = {"value": round(units_per_sweep * K / dt, 2), "ms_per_step": round(dt / K * 1e3, 3), "steps": K,
+           "rate_is": f"median of {LEG_ROUNDS} rounds of {K} sweeps", "value_min": round(units_per_sweep * K / max(rounds), 2),
+           "value_max": round(units_per_sweep * K / min(rounds), 2),
            "kernel_ms_per_sweep": round(kernel_ms, 3),
            "algorithmic_equiv_frac": round(alg_bytes_per_sweep * K / dt / 1e9 / HBM_PEAK_GBPS, 4),
            "roofline": roof, "kernels": table}
@@ -312,15 +331,16 @@ def run_leg(ctx, name: str, sweep, units_per_sweep: int, K: int, model_bytes_per
     return out, fact
 
 
-def self_launch(args) -> int:
-    """`python bench.py --gpus N` from a plain shell: run N ranks under torch.distributed.run on this node."""
+def self_launch(args, script=None) -> int:
+    """`python bench.py --gpus N` from a plain shell: run N ranks under torch.distributed.run on this node.  (`script`: the
+    CPU test of this launcher, tests/bench_checker.py, re-launches itself through the same code.)"""
     import socket
     import subprocess
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(script or __file__).resolve())] + sys.argv[1:]
     env = dict(os.environ, KK_BENCH_SPAWNED="1")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     return subprocess.call(cmd, env=env)
@@ -373,8 +393,6 @@ def main():
                     help="run nothing but the sweeps of ONE entry of the `configs` block (tools/profile_gpu.sh: counter passes per configuration)")
     ap.add_argument("--ny", type=int, default=NY, help="grid rows per GPU (default 2500 -> 10M rows per GPU)")
     ap.add_argument("--deadline", type=float, default=900.0, help="multi-rank runs only: abort if the whole run takes longer (seconds)")
-    ap.add_argument("--backend", default="hip", choices=["hip", "checker"],
-                    help="checker: NumPy stand-in of the device engine, CPU test of the launcher / rendezvous only (never a measurement)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -386,8 +404,6 @@ def main():
         raise SystemExit(self_launch(args))     # plain `python bench.py --gpus N`: become the launcher
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.backend == "checker":
-        return main_checker(args, rank, world)
     if world > 1:
         # A multi-rank run that stops making progress (a rank died, a collective never completes) must not sit on the GPU
         # box until an outer limit kills it: every rank gives itself a deadline and leaves with a message instead.
@@ -401,6 +417,8 @@ def main():
         wd = threading.Timer(args.deadline, _deadline)
         wd.daemon = True
         wd.start()
+
+    ceiling = read_ceiling() if (world == 1 and not os.environ.get("KK_BENCH_FORCE_DIST") and not args.only_leg) else None
 
     import krylovkit_hip as kk
     from krylovkit_hip import dist as kd
@@ -645,12 +663,13 @@ def main():
         sweep()
     barrier(); sync()
     ctx.prof_enable(0)
-    breakdown = {}
+    breakdown, breakdown_launches = {}, {}
     for name in ("k_project", "k_unproject", "k_unproj_proj", "k_spmv_ell", "k_spmv_dia", "k_spmv_sell", "k_spmv_csr", "k_scal", "k_mgs_step", "k_dot",
                  "k_axpby", "k_block_gram", "k_block_update", "k_spmm_ell", "k_spmm_dia", "k_mgs_persist", "nccl_allreduce", "nccl_p2p", "nccl_gather"):
         ms, n = ctx.prof_get(name)
         if n:
             breakdown[name] = round(ms, 3)
+            breakdown_launches[name] = int(n)
     # timed region: K sweeps; only the basis-streaming kernels (the dominant ones) carry HIP events
     ctx.prof_reset()
     ctx.prof_enable(0 if os.environ.get("KK_BENCH_NOPROF") else (1 if args.config == "block" else 2))   # block step: ms-scale kernels, every class
@@ -859,8 +878,25 @@ def main():
                           "note": "bytes the kernels of one sweep really move (counter traffic per launch where profiles/traffic.json is current, the "
                                   "byte models of DESIGN.md section 3 otherwise) over the wall time of the sweep"}
 
-    # ---------------- `sharded_world1`: the sweep as every N > 1 rank runs it (row-sharded context, RCCL collectives issued by the
-    # library, low-synchronisation MGS2) on this ONE GPU, in a child process with KK_BENCH_FORCE_DIST=1
+    # ---------------- the second-largest item of the sweep: the sparse apply (its own line and a target)
+    second_kernel = None
+    if args.config == "lanczos" and world == 1 and not use_dist and roofline:
+        fmt = prob["keep"][0].info()["format"]
+        cls = "k_spmv_dia" if "DIA" in fmt and ctx.get_option("spmv_dia") else "k_spmv_ell"
+        if cls in breakdown:
+            tj, note2 = stamped_traffic("traffic.json")
+            model_b = ({"ELL+DIA const": 24.0, "ELL+DIA": 64.0}.get(fmt, 84.0) if cls == "k_spmv_dia" else 84.0) * float(n_local)
+            pmc_b = (tj or {}).get(cls)
+            b_ = pmc_b if pmc_b is not None else model_b
+            ms_launch = breakdown[cls] / breakdown_launches[cls]      # from the event-profiled warm-up sweep
+            second_kernel = {"kernel": cls, "format": fmt, "avg_launch_ms": round(ms_launch, 5), "bytes_per_launch": round(b_),
+                             "bytes_source": "pmc" if pmc_b is not None else "model", "achieved": round(b_ / (ms_launch * 1e-3) / 1e9, 1),
+                             "frac": round(b_ / (ms_launch * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "target_frac": 0.75,
+                             "launches_per_sweep": breakdown_launches[cls], "ms_per_sweep": round(breakdown[cls], 3)}
+
+    # ---------------- `sharded_world1`: the sweep as every N > 1 rank runs it (row-sharded context: RCCL collectives issued by the
+    # library, the persistent kernel's inner products summed over the ranks inside the launch -- kk_xsync.h, here through the
+    # rank's own sync area) on this ONE GPU, in a child process with KK_BENCH_FORCE_DIST=1
     sharded_leg = None
     if (args.config == "lanczos" and world == 1 and not use_dist and not args.no_sharded_leg and args.ny == NY
             and not os.environ.get("KK_BENCH_FORCE_DIST")):
@@ -874,9 +910,11 @@ def main():
                 d_ = json.loads(ln_[-1])
                 sharded_leg = {"value": d_["value"], "unit": "it/s", "ms_per_step": d_["ms_per_step"], "collectives": d_.get("collectives"),
                                "roofline": {k: d_["roofline"].get(k) for k in ("kernel", "achieved", "frac", "avg_launch_ms")} if d_.get("roofline") else None,
-                               "note": "world size 1 with the collectives forced: 2 ncclAllReduce + the (self-served) ghost exchange per iteration are really "
-                                       "issued; mgs_mode auto = the low-synchronisation form, as on every N > 1 rank.  Efficiency of an N-GPU weak-scaling "
-                                       "line = its value / (N x this value)"}
+                               "xsync": d_.get("xsync"),
+                               "note": "world size 1 with the collectives forced: the ncclAllReduce of alpha0 + the (self-served) ghost exchange per "
+                                       "iteration are really issued, and the persistent strict-MGS kernel runs its cross-rank reduction (one tagged granule "
+                                       "per basis vector stored into, and polled from, the rank's own IPC-shareable sync area) as on every N > 1 rank.  "
+                                       "Efficiency of an N-GPU weak-scaling line = its value / (N x this value)"}
             else:
                 sharded_leg = {"error": (r_.stderr or r_.stdout)[-400:]}
         except Exception as e_:   # the leg must never cost the line
@@ -922,6 +960,15 @@ def main():
             "algorithmic_equiv_frac_of_peak_per_gpu": round(alg_sweep * K / elapsed / 1e9 / (HBM_PEAK_GBPS * world), 4),
             "roofline": roofline,
         }
+        if ceiling and roofline and roofline.get("achieved"):
+            # against what THIS box's memory system delivers to a pure read stream right now (the kernels read non-temporally)
+            roofline["attainable_read_GBps"] = ceiling["nt_read_GBps"]
+            roofline["frac_of_attainable"] = round(roofline["achieved"] / ceiling["nt_read_GBps"], 4)
+            out["hbm_read_ceiling"] = ceiling
+        if second_kernel:
+            roofline["second_kernel"] = second_kernel
+            if ceiling and second_kernel.get("achieved"):
+                second_kernel["frac_of_attainable"] = round(second_kernel["achieved"] / ceiling["nt_read_GBps"], 4)
         if sharded_leg:
             out["sharded_world1"] = sharded_leg
         if configs:
@@ -929,10 +976,11 @@ def main():
         if args.config != "block":
             out["last_alpha"], out["last_beta"] = fact.alphas[-1], fact.betas[-1]
         if world > 1 and args.config == "lanczos":
-            out["scaling_note"] = ("rows are sharded: every inner product needs an all-reduce, which the persistent strict-MGS kernel of the N = 1 line "
-                                   "cannot issue from inside a launch, so mgs_mode auto runs the low-synchronisation form here (2 all-reduces per iteration, "
-                                   "basis read twice).  The like-for-like single-GPU rate for efficiency accounting is the N = 1 line's `mgs2_lowsync` leg, "
-                                   "not its headline value")
+            out["scaling_note"] = ("rows are sharded: the persistent strict-MGS kernel sums its inner products over the ranks inside the launch (tagged "
+                                   "granules stored into the peers' IPC-mapped sync areas over xGMI, csrc/kk_xsync.h) when kk_comm_init could map every "
+                                   "peer -- see `xsync`; otherwise mgs_mode auto falls back to the low-synchronisation form (2 RCCL all-reduces per "
+                                   "iteration, basis read twice).  The like-for-like single-GPU rate for efficiency accounting is the N = 1 line's "
+                                   "`sharded_world1` leg")
         if unbracketed:
             out["without_event_bracketing"] = unbracketed
         if other_leg:
@@ -942,6 +990,8 @@ def main():
         if lowsync_leg:
             out["mgs2_lowsync"] = lowsync_leg
         if comm:
+            out["xsync"] = {"active": bool(ctx.get_option("xsync_active")), "persistent_launches_with_cross_rank_reduction": int(ctx.get_option("xsync_launches")),
+                            "num_cus": int(ctx.get_option("num_cus"))}
             info = comm.info()
             per = {k: (stats1[k] - stats0[k]) / (K * sweep_its) for k in stats1}
             out["collectives"] = {"library": "RCCL inside libkrylov_hip (kk_comm_init)", "rccl_version": info["rccl_version"],
@@ -988,48 +1038,6 @@ def main():
         pass
     if rank == 0:
         print(line, flush=True)   # the ONE JSON line, last thing on stdout (RCCL prints its banner on stdout too)
-
-
-def main_checker(args, rank: int, world: int):
-    """CPU-only exercise of the launcher: rendezvous (gloo), row partition, ghost exchange and the two all-reduces of a
-    sharded Lanczos sweep with the NumPy checker backend of the test-suite.  Prints a line marked data = "checker";
-    it is NOT a measurement (tests/test_bench_launcher.py)."""
-    import torch.distributed as dist
-    sys.path.insert(0, str(ROOT / "tests"))
-    sys.path.insert(0, str(ROOT / "oracle"))
-    from dist_checker_backend import CheckerBackend
-    import splitphase_dist as kd          # test-side exerciser of the split-phase C entry points (tests/splitphase_dist.py)
-    import krylovkit_hip as kk
-
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("gloo", rank=rank, world_size=world)
-    be = CheckerBackend()
-    nx, nyl, kd_ = 32, max(4, min(args.ny, 16)), 12
-    part = kd.Partition.even(nx * nyl * world, world, rank, align=nx)
-    A = laplacian_rows(nx, nyl * world, rank * nyl, (rank + 1) * nyl)
-    dop = kd.DistSparseOperator(A, part, be)
-    x0 = np.random.default_rng(3 + rank).random(nx * nyl)
-    it = kd.DistLanczosIterator(dop, x0, kk.Orthogonalizer(args.orth), capacity=kd_ + 2)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        f = it.initialize()
-        for _ in range(kd_ - 1):
-            f = it.expand(f)
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        dist.barrier()
-        dist.destroy_process_group()
-    if rank == 0:
-        print(json.dumps({"metric": "lanczos_iterations_per_second", "value": round((kd_ - 1) * args.steps * world / elapsed, 3),
-                          "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "data": "checker",
-                          "higher_is_better": True, "scaling": "weak", "last_alpha": f.alphas[-1], "last_beta": f.betas[-1],
-                          "config": {"workload": f"launcher self-test: {nx}x{nyl * world} Laplacian, NumPy checker backend, gloo"}}), flush=True)
 
 
 if __name__ == "__main__":

@@ -4,7 +4,7 @@
     `DistLanczosIterator` / `DistGKLIterator` keep their communication buffers in torch tensors and call
     torch.distributed between the library's half-steps.  With the NumPy `CheckerBackend` (tests/dist_checker_backend.py)
     they run under gloo with world_size 2 on a box without a GPU and check the row partition, the ghost plan and the
-    all-reduce placement of a sharded step (tests/test_dist_gloo.py, `bench.py --backend checker`);
+    all-reduce placement of a sharded step (tests/test_dist_gloo.py, tests/bench_checker.py);
   * the hooks (kk_ctx_set_allreduce, kk_op_set_halo_hook, kk_ctx_set_workspace): `ShardedContext` / `ShardedOperator`
     (tests/test_gpu_sharded_hooks.py: two logical ranks as two threads on one GPU).
 
