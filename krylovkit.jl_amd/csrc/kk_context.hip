@@ -215,6 +215,8 @@ KK_API int kk_ctx_set_option(kk_ctx c, const char* key, double value) {
         c->spmv_dia = value != 0;
     } else if (!strcmp(key, "spmv_dia_const")) {
         c->spmv_dia_const = value != 0;
+    } else if (!strcmp(key, "spmv_dia_aligned")) {
+        c->spmv_dia_aligned = value != 0;
     } else if (!strcmp(key, "spmv_dia_pairs")) {
         KK_CHECK(value == 0 || value == 1 || value == 2 || value == 4, KK_ERR_INVALID, "spmv_dia_pairs must be 0 (by size), 1, 2 or 4");
         c->spmv_dia_pairs = (int)value;
@@ -277,6 +279,7 @@ KK_API int kk_ctx_get_option(kk_ctx c, const char* key, double* value) {
     else if (!strcmp(key, "mgs_mode")) *value = c->mgs_mode;
     else if (!strcmp(key, "num_cus")) *value = c->num_cus;
     else if (!strcmp(key, "device_cus")) *value = c->dev_cus;
+    else if (!strcmp(key, "norm_commits_consumed")) *value = (double)c->norm_commits_consumed;
     else if (!strcmp(key, "persist_timeout_ms")) *value = c->persist_timeout_ms;
     else if (!strcmp(key, "xsync")) *value = c->xsync;
     else if (!strcmp(key, "xsync_active")) *value = kk_xs_on(c) ? 1 : 0;
@@ -307,6 +310,7 @@ KK_API int kk_ctx_get_option(kk_ctx c, const char* key, double* value) {
     else if (!strcmp(key, "speculate")) *value = c->speculate;
     else if (!strcmp(key, "spmv_dia")) *value = c->spmv_dia;
     else if (!strcmp(key, "spmv_dia_const")) *value = c->spmv_dia_const;
+    else if (!strcmp(key, "spmv_dia_aligned")) *value = c->spmv_dia_aligned;
     else if (!strcmp(key, "spmm_dia")) *value = c->spmm_dia;
     else if (!strcmp(key, "spmm_dia_lines")) *value = c->spmm_dia_lines;
     else if (!strcmp(key, "spmm_cols")) *value = c->spmm_cols;
@@ -493,6 +497,7 @@ KK_API int kk_basis_invalidate_gram(kk_basis b) {
     return KK_OK;
 }
 KK_API int kk_basis_upload(kk_basis b, int col, const double* host) {
+    norm_discard(b, col);   // (overwritten as a whole)
     CHECK_COL(b, col);
     KK_CHECK(host, KK_ERR_INVALID, "null host pointer");
     gram_touch(b, col);
@@ -506,6 +511,7 @@ KK_API int kk_basis_download(kk_basis b, int col, double* host) {
     return stream_sync(b->ctx);
 }
 KK_API int kk_basis_upload_device(kk_basis b, int col, const void* dptr) {
+    norm_discard(b, col);
     CHECK_COL(b, col);
     gram_touch(b, col);
     KK_HIP(hipMemcpyAsync(b->col(col), dptr, b->n * sizeof(double), hipMemcpyDeviceToDevice, b->ctx->stream));
@@ -546,23 +552,49 @@ KK_API int kk_vec_axpby(kk_basis by, int cy, kk_basis bx, int cx, double a, doub
     gram_touch(by, cy);
     return kk_launch_axpby(by->ctx, by->col(cy), bx->col(cx), by->ld, a, b, nullptr, 1.0, 0);
 }
+// A residual column left NORMALISED by a fused expand! (norm_col: the slab holds r * (1 / beta), logically r) meets the one
+// operation that asks for exactly those bits -- scale!!(r, 1 / beta) of a thick restart (eigsolve/lanczos.jl:111,
+// svdsolve.jl:249, arnoldi restarts): the commit is CONSUMED instead of being undone (norm_flush forms (r / beta) * beta, 1-2 ulp
+// off r, and costs a pass) and redone.  `a` must be the very double the host forms as 1 / beta.
+static inline bool norm_commit_matches(kk_basis b, int col, double a) {
+    return b && b->norm_col == col && col >= 0 && col < b->cap && a == 1.0 / b->norm_beta;
+}
 KK_API int kk_vec_scal(kk_basis bx, int cx, double a) {
+    if (norm_commit_matches(bx, cx, a)) {          // in place: the column already IS scale!!(r, 1 / beta) -- no pass at all
+        if (bx->tc_valid) KK_TRY(blk_commit_flush(bx));
+        bx->norm_col = -1;
+        gram_touch(bx, cx);                        // (drops a step enqueued ahead: it took the column for the next basis vector of the OLD factorization)
+        ++bx->ctx->norm_commits_consumed;
+        return KK_OK;
+    }
     CHECK_COL(bx, cx);
     gram_touch(bx, cx);
     return kk_launch_scal(bx->ctx, bx->col(cx), bx->ld, a, nullptr);
 }
 KK_API int kk_vec_copy_scal(kk_basis by, int cy, kk_basis bx, int cx, double a) {
+    if (norm_commit_matches(bx, cx, a) && by && cy >= 0 && cy < by->cap && !(by == bx && cy == cx) && by->ctx == bx->ctx && by->n == bx->n &&
+        by->ld == bx->ld) {
+        // y = scale!!(r, 1 / beta) from the stored bits: one copy (x * 1.0 is x), the source stays as it is -- normalised, logically r
+        if (by != bx) KK_TRY(norm_flush(by));
+        else if (by->tc_valid) KK_TRY(blk_commit_flush(by));
+        gram_touch(by, cy);
+        ++bx->ctx->norm_commits_consumed;
+        return kk_launch_copy_scal(by->ctx, by->col(cy), bx->col(cx), by->ld, 1.0);
+    }
+    if (!(by == bx && cy == cx)) norm_discard(by, cy);   // the destination is overwritten as a whole: no point in settling it first
     CHECK_COL(bx, cx); CHECK_COL(by, cy); CHECK_SAME(bx, by);
     gram_touch(by, cy);
     return kk_launch_copy_scal(by->ctx, by->col(cy), bx->col(cx), by->ld, a);
 }
 KK_API int kk_vec_zero(kk_basis bx, int cx) {
+    norm_discard(bx, cx);
     CHECK_COL(bx, cx);
     gram_touch(bx, cx);
     KK_HIP(hipMemsetAsync(bx->col(cx), 0, bx->ld * sizeof(double), bx->ctx->stream));
     return KK_OK;
 }
 KK_API int kk_vec_fill_random(kk_basis bx, int cx, uint64_t seed) {
+    norm_discard(bx, cx);
     CHECK_COL(bx, cx);
     gram_touch(bx, cx);
     return kk_launch_fill_random(bx->ctx, bx->col(cx), bx->n, seed);

@@ -16,13 +16,16 @@ static const double KK_EPS = std::numeric_limits<double>::epsilon();
 #define WSP(c, off) ((c)->ws + (off))
 #define SCP(c, slot) ((c)->ws + WS_SCAL + (slot))
 
-// ---- argument checks (status + message, never an exception across the C boundary).  Every check of a basis argument also
-// settles a pending normalised residual (norm_flush below): only the expand! that consumes it looks at the flag itself.
-#define CHECK_COL(b, c) do { KK_CHECK((b) && (c) >= 0 && (c) < (b)->cap, KK_ERR_INVALID, "%s: column %d out of range", __func__, (c)); KK_TRY(norm_flush(b)); } while (0)
+// ---- argument checks (status + message, never an exception across the C boundary).  A check of a basis argument also
+// settles a pending normalised residual WHEN THE CHECKED COLUMNS INCLUDE IT (norm_flush_range below; a pending block commit is
+// settled by every check): only the expand! that consumes it -- and scale!!(r, 1 / beta) of a restart, kk_vec_scal /
+// kk_vec_copy_scal -- look at the flag themselves.  An entry point that touches a column declares it through one of these
+// macros; the fused L3 steps and kk_basis_info (raw pointer) call norm_flush for the whole slab.
+#define CHECK_COL(b, c) do { KK_CHECK((b) && (c) >= 0 && (c) < (b)->cap, KK_ERR_INVALID, "%s: column %d out of range", __func__, (c)); KK_TRY(norm_flush_range(b, (c), 1)); } while (0)
 #define CHECK_SAME(bx, by) KK_CHECK((bx)->ctx == (by)->ctx && (bx)->n == (by)->n && (bx)->ld == (by)->ld, KK_ERR_DIM, "%s: vector length mismatch (%lld vs %lld)", __func__, (long long)(bx)->n, (long long)(by)->n)
-#define CHECK_RANGE(b, c0, m) do { KK_CHECK((b) && (c0) >= 0 && (m) >= 0 && (c0) + (m) <= (b)->cap && (m) <= KK_MAX_M, KK_ERR_INVALID, "%s: column range [%d,%d) invalid (capacity %d, max %d per call)", __func__, (c0), (c0) + (m), (b) ? (b)->cap : 0, KK_MAX_M); KK_TRY(norm_flush(b)); } while (0)
+#define CHECK_RANGE(b, c0, m) do { KK_CHECK((b) && (c0) >= 0 && (m) >= 0 && (c0) + (m) <= (b)->cap && (m) <= KK_MAX_M, KK_ERR_INVALID, "%s: column range [%d,%d) invalid (capacity %d, max %d per call)", __func__, (c0), (c0) + (m), (b) ? (b)->cap : 0, KK_MAX_M); KK_TRY(norm_flush_range(b, (c0), (m))); } while (0)
 // (CHECK_RANGE: one kernel panel, m <= KK_MAX_M; CHECK_BLOCK: any number of columns -- the entry point goes panel by panel)
-#define CHECK_BLOCK(b, c0, p) do { KK_CHECK((b) && (c0) >= 0 && (p) >= 0 && (c0) + (p) <= (b)->cap, KK_ERR_INVALID, "%s: block [%d,%d) outside capacity %d", __func__, (c0), (c0) + (p), (b) ? (b)->cap : 0); KK_TRY(norm_flush(b)); } while (0)
+#define CHECK_BLOCK(b, c0, p) do { KK_CHECK((b) && (c0) >= 0 && (p) >= 0 && (c0) + (p) <= (b)->cap, KK_ERR_INVALID, "%s: block [%d,%d) outside capacity %d", __func__, (c0), (c0) + (p), (b) ? (b)->cap : 0); KK_TRY(norm_flush_range(b, (c0), (p))); } while (0)
 
 // ---- scalar read-backs (kk_context.hip): results of the finalize kernels travel through the pinned mirror of the
 // scalar workspace; `slot` selects one of its 4 copies
@@ -50,6 +53,19 @@ static inline int norm_flush(kk_basis b) {
     b->norm_col = -1;
     gram_touch(b, col);   // (also drops a speculative apply formed from the normalised bits)
     return kk_launch_scal(b->ctx, b->col(col), b->ld, b->norm_beta, nullptr);
+}
+
+// ... only when the column range [c0, c0 + m) contains the normalised column: the thick restart transforms the basis columns
+// [0, krylovdim) and THEN asks for scale!!(r, 1 / beta) (eigsolve/lanczos.jl:109-111) -- the transform must leave the commit alone
+static inline int norm_flush_range(kk_basis b, int c0, int m) {
+    if (!b) return KK_OK;
+    if (b->tc_valid) KK_TRY(blk_commit_flush(b));
+    if (b->norm_col >= c0 && b->norm_col < c0 + m) return norm_flush(b);
+    return KK_OK;
+}
+// the column is about to be OVERWRITTEN as a whole (upload, zero, fill, copy into it): a pending normalisation of it is moot
+static inline void norm_discard(kk_basis b, int col) {
+    if (b && col >= 0 && b->norm_col == col) { b->norm_col = -1; gram_touch(b, col); }
 }
 
 // ---- sparse operators (kk_sparse.hip)

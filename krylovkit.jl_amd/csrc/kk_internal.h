@@ -148,6 +148,7 @@ struct kk_ctx_s {
     int spmm_rpl = 2;            // SpMM on ELL: rows per lane (1 or 2)
     int spmv_dia = 1;            // single-column apply of a detected grid stencil: diagonal kernel (0: ELL gather kernel)
     int spmv_dia_pairs = 0;      // row pairs per lane of k_spmv_dia: 0 = by size, or 1 / 2 / 4 (4: value-free form only)
+    int spmv_dia_aligned = 1;    // ... 5-point stencils with an even line length: far neighbours as aligned 16-byte pairs, +-1 neighbours by lane shift (0: the 8-byte loads of rounds 2-4)
     int spmv_dia_const = 1;      // ... value-free kernel when the stencil has constant coefficients (0: always stream the diagonals)
     int spmm_dia = 1;            // multi-column apply of a detected grid stencil: sweeping diagonal kernel (0: ELL gather kernel)
     int spmm_dia_lines = 16;     // ... grid lines per wave sweep
@@ -205,6 +206,7 @@ struct kk_ctx_s {
     int persist_skip = 0;          // strict sweeps still to run on the launch-per-vector route before the persistent one is retried
     int persist_backoff = 4;       // ... how many after the next timeout (doubles with every timeout in a row)
     int persist_fault = 0;         // test hook (option "persist_fault"): the next N persistent launches time out artificially
+    int64_t norm_commits_consumed = 0;   // normalised residual columns taken over by scale!!(r, 1 / beta) of a restart without a pass (diagnostics)
     int fold_scale = 1;          // persistent kernel stores r / |r| at its commit when an expand! ends with it (no scale pass in the next step)
     int fuse_passes = 1;         // fuse unproject(pass i) with project(pass i+1)
     int speculate = 1;           // enqueue the next expand's SpMV before syncing the host

@@ -144,7 +144,23 @@ __device__ __forceinline__ d2 dia_pair(const double* __restrict__ x, int64_t idx
 // CONST: constant-coefficient stencil (kk_sparse_dev::dia_const) -- the coefficient of slot q is cst.c[q] wherever the
 // neighbour sits on the same grid line, 0 where a +-1 shift would wrap to the next line; no diagonal is read at all.
 struct dia_cst { double c[9]; int64_t phase, D; };
-template <int PTS, int U, bool CONST>   // U row pairs per lane: a block covers U consecutive 512-row chunks, all their loads in flight together
+// ALIGNED (5-point stencils with an EVEN far offset D, vectors below 4 GB): the load count per row pair drops from eight (two
+// 16-byte + six 8-byte) to four 16-byte ones --
+//   * x[row +- D], x[row + 1 +- D] are ONE aligned pair each (row and D even);
+//   * x[row - 1] and x[row + 2] are the neighbouring lanes' centre pairs: a DPP wave shift instead of a load; only lane 0 /
+//     lane 63 of a wave fetch theirs, through a buffer descriptor whose out-of-range offsets switch the other 63 lanes' loads off
+//     in the address unit (no branch: a load inside a branch is waited for at its end, see dia_pair).
+// 8-byte accesses run at 0.54-0.70 of the 16-byte rate (MI355X_MICROARCH.md): the value-free apply of config 2 moved 24 N bytes
+// at 5.0 TB/s with them (r4, 0.63 of peak).  Same operands in the same order: bit-identical results.
+typedef unsigned dia_v2u __attribute__((ext_vector_type(2)));
+template <int CTRL>
+__device__ __forceinline__ double dia_wave_shift(double v) {   // 0x138: lane i takes lane i - 1; 0x130: lane i takes lane i + 1 (edge lane keeps its own)
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <int PTS, int U, bool CONST, bool ALIGNED = false>   // U row pairs per lane: a block covers U consecutive 512-row chunks, all their loads in flight together
 __global__ __launch_bounds__(KK_TPB) void k_spmv_dia(const double* __restrict__ dval, int64_t dld, dia_offs offs, int64_t nrows,
                                                      const double* __restrict__ x, double* __restrict__ y, spmv_epi e,
                                                      int nb_logical, double* __restrict__ part_dot,
@@ -164,14 +180,32 @@ __global__ __launch_bounds__(KK_TPB) void k_spmv_dia(const double* __restrict__ 
         const int64_t row0 = row_base + ((int64_t)lb * U * KK_TPB + threadIdx.x) * 2;
         // ---- phase 1: every load of this iteration (a lane whose rows lie beyond row_end loads row 0 and stores nothing)
         d2 xv[U][PTS], dv[U][CONST ? 1 : PTS], pv[U], zv[U];
+        double el[U], er[U];   // ALIGNED: x[row - 1] of lane 0, x[row + 2] of lane 63
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t row = row0 + (int64_t)u * 2 * KK_TPB;
-            const int64_t rl = row < row_end ? row : 0;      // dia_ld, ld are even and >= nrows: the pair (rl, rl + 1) is inside the arrays
+            // dia_ld, ld are even and >= nrows: the pair (rl, rl + 1) is inside the arrays.  (ALIGNED: clamped by the operator, not by
+            // row_end -- a lane beyond the end of a row-sharded interior still holds what its left neighbour needs)
+            const int64_t rl = ALIGNED ? (row < nrows ? row : 0) : (row < row_end ? row : 0);
             xv[u][QC] = ld2(x + rl);                         // centre pair: aligned (row is even); pad rows hold zeros
+            if (ALIGNED) {
+                const int lane = threadIdx.x & 63;
+                const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)(nrows * 8), 0x00020000);
+                const dia_v2u l2 = __builtin_amdgcn_raw_buffer_load_b64(rx, (lane == 0 && rl >= 1) ? (unsigned)((rl - 1) * 8) : 0xfffffff0u, 0, 0);
+                const dia_v2u r2 = __builtin_amdgcn_raw_buffer_load_b64(rx, (lane == 63 && rl + 2 < nrows) ? (unsigned)((rl + 2) * 8) : 0xfffffff0u, 0, 0);
+                el[u] = __hiloint2double((int)l2.y, (int)l2.x);
+                er[u] = __hiloint2double((int)r2.y, (int)r2.x);
+#pragma unroll
+                for (int q = 0; q < PTS; q += PTS - 1) {     // the two far slots (PTS == 5: q = 0 and 4)
+                    const int64_t idx = rl + offs.o[q];
+                    const bool ok = (unsigned long long)idx < (unsigned long long)nrows;
+                    const d2 pr = ld2(x + (ok ? idx : 0));
+                    xv[u][q] = d2{ok ? pr.x : 0.0, (ok && idx + 1 < nrows) ? pr.y : 0.0};
+                }
+            }
 #pragma unroll
             for (int q = 0; q < PTS; ++q) {
-                if (q == QC) continue;
+                if (q == QC || ALIGNED) continue;
                 // the +-1 neighbours inside the line share one element with the centre pair: one new load each
                 if (q == QC - 1) { const bool ok = rl >= 1; const double a = x[ok ? rl - 1 : 0]; xv[u][q] = d2{ok ? a : 0.0, 0.0}; }
                 else if (q == QC + 1) { const bool ok = rl + 2 < nrows; const double b = x[ok ? rl + 2 : 0]; xv[u][q] = d2{0.0, ok ? b : 0.0}; }
@@ -188,6 +222,13 @@ __global__ __launch_bounds__(KK_TPB) void k_spmv_dia(const double* __restrict__ 
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t row = row0 + (int64_t)u * 2 * KK_TPB;
+            if (ALIGNED) {   // the +-1 neighbours inside the line: the centre pairs of the lanes next door
+                const int lane = threadIdx.x & 63;
+                const int64_t rl = row < nrows ? row : 0;
+                const double fl = dia_wave_shift<0x138>(xv[u][QC].y), fr = dia_wave_shift<0x130>(xv[u][QC].x);
+                xv[u][QC - 1].x = lane == 0 ? el[u] : fl;                                     // (lane 0 with rl == 0: the switched-off load returned 0)
+                xv[u][QC + 1].y = lane == 63 ? er[u] : (rl + 2 < nrows ? fr : 0.0);
+            }
             xv[u][QC - 1].y = xv[u][QC].x;                   // x[row] is the right element of the "-1" pair ...
             xv[u][QC + 1].x = xv[u][QC].y;                   // ... and x[row + 1] the left element of the "+1" pair
             if (row + 1 >= nrows) { xv[u][QC + 1].x = 0.0; } // (row + 1 outside the operator: the old range test gave 0; the pad row holds 0 anyway)
@@ -647,7 +688,15 @@ static void launch_spmv_dia_rows(kk_ctx ctx, const kk_sparse_dev& M, const doubl
     for (int q = 0; q < 9; ++q) cst.c[q] = M.dia_c[q];
     cst.phase = M.dia_phase; cst.D = D;
 #define SPMV_DIA_ARGS dim3(nblk), dim3(KK_TPB), 0, ctx->stream, M.dia_val, M.dia_ld, of, M.nrows, x, y, e, nb_logical, pd + *nblk_io, pn + *nblk_io, r0, r1, cst
-    if (M.dia_pts == 5) {
+    // 16-byte far loads + lane-shift neighbours (see k_spmv_dia): 5-point stencil, even grid-line length, byte offsets within 32 bits
+    const bool al = ctx->spmv_dia_aligned && M.dia_pts == 5 && (D & 1) == 0 && M.nrows * 8 < ((int64_t)1 << 31) && (r0 & 1) == 0;
+    if (al) {
+        if (cc) {
+            if (U == 4) hipLaunchKernelGGL((k_spmv_dia<5, 4, true, true>), SPMV_DIA_ARGS);
+            else if (U == 2) hipLaunchKernelGGL((k_spmv_dia<5, 2, true, true>), SPMV_DIA_ARGS);
+            else hipLaunchKernelGGL((k_spmv_dia<5, 1, true, true>), SPMV_DIA_ARGS);
+        } else { if (U == 2) hipLaunchKernelGGL((k_spmv_dia<5, 2, false, true>), SPMV_DIA_ARGS); else hipLaunchKernelGGL((k_spmv_dia<5, 1, false, true>), SPMV_DIA_ARGS); }
+    } else if (M.dia_pts == 5) {
         if (cc) {
             if (U == 4) hipLaunchKernelGGL((k_spmv_dia<5, 4, true>), SPMV_DIA_ARGS);
             else if (U == 2) hipLaunchKernelGGL((k_spmv_dia<5, 2, true>), SPMV_DIA_ARGS);

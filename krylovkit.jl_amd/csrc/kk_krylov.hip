@@ -210,7 +210,10 @@ KK_API int kk_lanczos_expand(kk_op op, kk_basis b, int c0, int k, kk_orth_t orth
     // the previous expand! of this factorization may have left r already normalised (persistent kernel): then the column IS
     // the new basis vector; any other pending normalised column is settled first
     const bool v_ready = b->norm_col == c0 + k && b->norm_beta == beta_old;
-    if (!v_ready) KK_TRY(norm_flush(b));
+    if (!v_ready) {
+        norm_discard(b, c0 + k + 1);                    // (w is overwritten as a whole by the apply)
+        KK_TRY(norm_flush_range(b, c0, k + 2));         // a normalised column among the ones this step reads; one beyond them (the dead
+    }                                                   // residual of the factorization a restart shrank) stays as it is until somebody looks
     // the previous call may have enqueued this WHOLE step already (apply, sweep and read-back: la_enqueue below)
     const bool strict_branch = orth == KK_MGS2 && !wide && !sh_fused && !(lowsync && c0 == 0);
     const bool la_hit = b->la_valid && b->spec_valid && c->spec_owner == b && b->spec_op == op && b->spec_c0 == c0 && b->spec_k == k &&
@@ -397,7 +400,10 @@ KK_API int kk_arnoldi_expand(kk_op op, kk_basis b, int c0, int k, kk_orth_t orth
     double* v = b->col(c0 + k);
     double* w = b->col(c0 + k + 1);
     const bool v_ready = b->norm_col == c0 + k && b->norm_beta == beta_old;   // see kk_lanczos_expand
-    if (!v_ready) KK_TRY(norm_flush(b));
+    if (!v_ready) {
+        norm_discard(b, c0 + k + 1);
+        KK_TRY(norm_flush_range(b, c0, k + 2));
+    }
     const int la_sweeps = orth == KK_MGS ? 1 : (orth == KK_MGS2 ? 2 : 0);
     const bool strict_route = la_sweeps > 0 && m <= KK_MAX_M && !kk_mgs_lowsync(c, b->ld, m) && (!kk_sharded(c) || kk_xs_on(c));
     // the previous call may have enqueued this WHOLE step already (apply, sweeps and read-back: la_enqueue)

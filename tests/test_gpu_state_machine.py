@@ -1,0 +1,220 @@
+"""Randomised interleavings of the C entry points against the oracle, with every piece of DEFERRED STATE of the slab switched
+on: the normalised residual column of the persistent kernels' commit (fold_scale -> norm_col), the speculative next apply
+(speculate -> spec_valid), the whole step enqueued ahead (lookahead -> la_valid), the cached Gram rows of the
+low-synchronisation form, and -- block factorizations -- the normalised block commit (block_commit -> tc_valid) with the cached
+Gram matrix of the residual block.  Each feature has its own tests; what none of them does is drive ARBITRARY sequences of
+entry points through all of them at once.  hypothesis draws the sequence; after every operation
+the device result is compared with the oracle's state (src/factorizations/lanczos.jl:250-291, arnoldi.jl:199-260,
+blocklanczos.jl:197-353, src/orthonormal.jl:378-452, eigsolve/lanczos.jl:109-114 for the restart's scale!!(r, 1 / beta))."""
+import ctypes as C
+
+import numpy as np
+import pytest
+from hypothesis import HealthCheck, given, settings
+from hypothesis import strategies as st
+
+pytestmark = pytest.mark.gpu
+
+OPS = ["expand", "expand", "expand", "read_r", "norm_r", "read_v", "raw_ptr", "toggle_lookahead", "toggle_fold", "toggle_speculate",
+       "project_r", "orth_extra", "shrink", "restart_scale", "scale_r_inplace_roundtrip", "sync", "dot_rv", "reupload_v"]
+
+
+def _relerr(a, b):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300))) if a.size else 0.0
+
+
+@settings(max_examples=30, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
+@given(data=st.data())
+def test_random_interleavings_of_krylov_entry_points(kk, ko, data):
+    kind = data.draw(st.sampled_from(["lanczos", "arnoldi_mgs", "arnoldi_mgs2"]), label="kind")
+    route = data.draw(st.sampled_from(["persist", "panel", "panel_p", "lowsync", "launch_per_vector"]), label="route")
+    ops = data.draw(st.lists(st.sampled_from(OPS), min_size=10, max_size=26), label="ops")
+    picks = data.draw(st.lists(st.integers(0, 10 ** 6), min_size=len(ops), max_size=len(ops)), label="picks")
+    c = kk.Context(0)
+    try:
+        if c.get_option("mgs_persist") == 0:
+            pytest.skip("persistent route off on this device")
+        c.set_option("mgs_mode", {"persist": 0, "panel": 0, "panel_p": 2, "lowsync": 1, "launch_per_vector": 0}[route])
+        c.set_option("mgs_panel", 0 if route == "persist" else 1)
+        c.set_option("mgs_persist", 0 if route == "launch_per_vector" else 1)
+        c.set_option("panel_min_rows", 0); c.set_option("persist_min_rows", 0)
+        opt = {"lookahead": data.draw(st.integers(0, 1), label="lookahead"), "fold_scale": data.draw(st.integers(0, 1), label="fold_scale"),
+               "speculate": data.draw(st.integers(0, 1), label="speculate")}
+        for k_, v_ in opt.items():
+            c.set_option(k_, v_)
+        nx, ny = 36, 30
+        n = nx * ny
+        rng = np.random.default_rng(7)
+        x0 = rng.random(n)
+        max_k = 18
+        cap = max_k + 6          # columns max_k + 2 .. cap - 1 are spare
+        if kind == "lanczos":
+            A = ko.laplacian_2d(nx, ny, shift_diag=10 * np.linspace(0, 1, n) ** 2)
+            dev, ref = kk.ModifiedGramSchmidt2(), ko.MGS2
+            it = kk.LanczosIterator(kk.SparseOperator(A, c, symmetric=True), x0, dev, capacity=cap)
+            oit = ko.LanczosIterator(A, x0.copy(), ref); of = ko.lanczos_initialize(oit)
+            oexp, oshrink = ko.lanczos_expand, ko.lanczos_shrink
+        else:
+            A = ko.convection_diffusion_2d(nx, ny)
+            dev, ref = (kk.ModifiedGramSchmidt(), ko.MGS) if kind == "arnoldi_mgs" else (kk.ModifiedGramSchmidt2(), ko.MGS2)
+            it = kk.ArnoldiIterator(kk.SparseOperator(A, c), x0, dev, capacity=cap)
+            oit = ko.ArnoldiIterator(A, x0.copy(), ref); of = ko.arnoldi_initialize(oit)
+            oexp, oshrink = ko.arnoldi_expand, ko.arnoldi_shrink
+        f = kk.initialize(it)
+        spare = cap - 1
+
+        def check_scalars(where):
+            if kind == "lanczos":
+                assert _relerr(f.alphas, of.alphas) < 1e-10 and _relerr(f.betas, of.betas) < 1e-10, (where, list(zip(ops, picks)))
+            else:
+                H, Ho = np.asarray(f.H, float), np.asarray(of.H, float)
+                assert H.shape == Ho.shape and np.max(np.abs(H - Ho)) < 1e-10 * max(1.0, np.max(np.abs(Ho))), (where, list(zip(ops, picks)))
+            assert abs(f.normres - of.normres) < 1e-10 * max(abs(of.normres), 1e-300), where
+
+        for i, (op_, pk) in enumerate(zip(ops, picks)):
+            k = len(f)
+            V = f.V
+            oV = of.V if isinstance(of.V, list) else list(np.asarray(of.V).T)
+            rn = np.linalg.norm(of.r)
+            if op_ == "expand":
+                if k >= max_k:
+                    continue
+                f = kk.expand_(it, f); of = oexp(oit, of)
+                check_scalars(f"expand at op {i}")
+            elif op_ == "read_r":
+                assert np.max(np.abs(f.r.get() - of.r)) < 1e-10 * rn, (i, "read_r")
+            elif op_ == "norm_r":
+                assert abs(f.r.norm() - rn) < 1e-10 * rn, (i, "norm_r")
+            elif op_ == "dot_rv":
+                j = pk % k
+                assert abs(f.r.inner(V[j]) - float(of.r @ oV[j])) < 1e-10 * rn, (i, "dot_rv")
+            elif op_ == "read_v":
+                j = pk % k
+                assert np.max(np.abs(V[j].get() - oV[j])) < 1e-9, (i, "read_v", j)
+            elif op_ == "reupload_v":                      # a mutation of a basis column that changes nothing (same bits back): drops cached state only
+                j = pk % k
+                V.upload(j, V[j].get())
+            elif op_ == "raw_ptr":
+                n_, ld_, cap_, dp = C.c_int64(), C.c_int64(), C.c_int(), C.c_void_p()
+                from krylovkit_hip._lib import check
+                check(c._lib.kk_basis_info(V.handle, C.byref(n_), C.byref(ld_), C.byref(cap_), C.byref(dp)))
+                assert dp.value
+            elif op_.startswith("toggle_"):
+                key = {"toggle_lookahead": "lookahead", "toggle_fold": "fold_scale", "toggle_speculate": "speculate"}[op_]
+                opt[key] ^= 1
+                c.set_option(key, opt[key])
+            elif op_ == "project_r":
+                s = V.project(f.r, 0, k)
+                so = np.array([float(q @ of.r) for q in oV[:k]])
+                assert np.max(np.abs(np.asarray(s) - so)) < 1e-10 * rn, (i, "project_r")
+            elif op_ == "orth_extra":
+                w = np.random.default_rng(pk).standard_normal(n)
+                x, nrm, _ = V.orthogonalize(V[spare].set(w), dev, 0, k)
+                wo, xo = ko.orthogonalize(w.copy(), [q.copy() for q in oV[:k]], ref)
+                np.testing.assert_allclose(x, xo, rtol=0, atol=1e-10 * np.linalg.norm(w))
+                assert abs(nrm - np.linalg.norm(wo)) < 1e-10 * np.linalg.norm(w)
+            elif op_ == "shrink":
+                if k < 4:
+                    continue
+                kn = 2 + pk % (k - 2)
+                f = kk.shrink_(f, kn); of = oshrink(of, kn)
+                check_scalars(f"shrink at op {i}")
+                assert np.max(np.abs(f.r.get() - of.r)) < 1e-9 * np.linalg.norm(of.r)
+            elif op_ == "restart_scale":                   # B[spare] = scale!!(r, 1 / beta): eigsolve/lanczos.jl:111 (the commit is consumed, r stays r)
+                out = V[spare - 1].scale_from_(f.r, 1.0 / f.normres).get()
+                assert np.max(np.abs(out - of.r / of.normres)) < 1e-10, (i, "restart_scale")
+                assert np.max(np.abs(f.r.get() - of.r)) < 1e-10 * rn, (i, "restart_scale: r afterwards")
+            elif op_ == "scale_r_inplace_roundtrip":       # scale!!(r, 1 / beta) in place (consumed without a pass), then back: r within a few ulp
+                f.r.scale_(1.0 / f.normres)
+                assert abs(f.r.norm() - 1.0) < 1e-12, (i, "in-place scale")
+                f.r.scale_(f.normres)
+                assert np.max(np.abs(f.r.get() - of.r)) < 1e-10 * rn
+            elif op_ == "sync":
+                c.sync()
+        check_scalars("end")
+        Vn = f.V.to_numpy(len(f))
+        assert np.max(np.abs(Vn.T @ Vn - np.eye(Vn.shape[1]))) < 1e-11
+        assert c.get_option("persist_timeouts") == 0
+    finally:
+        c.close()
+
+
+BLOCK_OPS = ["expand", "expand", "read_resid", "read_basis", "norm_resid", "toggle_commit", "toggle_resid_gram", "raw_ptr", "sync", "project_resid"]
+
+
+@settings(max_examples=12, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
+@given(data=st.data())
+def test_random_interleavings_of_block_entry_points(kk, ko, data):
+    """BlockLanczos with the normalised block commit and the cached residual Gram matrix on, interrupted at random by reads
+    of the residual block (settles the commit), of basis columns, by option changes and raw-pointer accesses"""
+    ops = data.draw(st.lists(st.sampled_from(BLOCK_OPS), min_size=6, max_size=16), label="ops")
+    picks = data.draw(st.lists(st.integers(0, 10 ** 6), min_size=len(ops), max_size=len(ops)), label="picks")
+    bs = data.draw(st.sampled_from([4, 8, 16]), label="bs")
+    c = kk.Context(0)
+    try:
+        nx, ny = 40, 36
+        n = nx * ny
+        A = ko.laplacian_2d(nx, ny, shift_diag=10 * np.linspace(0, 1, n) ** 2)
+        rng = np.random.default_rng(11)
+        xb = [rng.random(n) for _ in range(bs)]
+        max_steps = 5
+        kdim = bs * (max_steps + 2)
+        bit = kk.BlockLanczosIterator(kk.SparseOperator(A, c, symmetric=True), [x.copy() for x in xb], kdim)
+        bf = bit.initialize()
+        obit = ko.BlockLanczosIterator(A, [x.copy() for x in xb], kdim)
+        obf = ko.blocklanczos_initialize(obit)
+        opt = {"block_commit": 1, "resid_gram": 1}
+        nexp = 0
+
+        def resid():
+            blk = bf.residual()
+            return np.stack([blk[j].get() for j in range(len(blk))], axis=1)
+
+        def check_H(where):
+            k = len(bf)
+            assert k == len(obf), where
+            ev, evo = np.linalg.eigvalsh(bf.H[:k, :k]), np.linalg.eigvalsh(obf.H[:k, :k])
+            assert np.max(np.abs(ev - evo)) < 1e-10 * np.max(np.abs(evo)), (where, list(zip(ops, picks)))
+
+        for i, (op_, pk) in enumerate(zip(ops, picks)):
+            if op_ == "expand":
+                if nexp >= max_steps:
+                    continue
+                bf = bit.expand(bf); obf = ko.blocklanczos_expand(obit, obf); nexp += 1
+                check_H(f"expand at op {i}")
+            elif op_ == "read_resid":
+                R = resid()
+                Ro = np.stack(obf.R, axis=1) if isinstance(obf.R, list) else np.asarray(obf.R)
+                assert R.shape == Ro.shape
+                # (the block is defined up to the orthogonal factor the QR of the previous step chose: compare the Gram matrices)
+                assert np.max(np.abs(R.T @ R - Ro.T @ Ro)) < 1e-8 * max(1.0, np.max(np.abs(Ro.T @ Ro))), (i, "read_resid")
+            elif op_ == "norm_resid":
+                R = resid()
+                Ro = np.stack(obf.R, axis=1) if isinstance(obf.R, list) else np.asarray(obf.R)
+                assert abs(np.linalg.norm(R) - np.linalg.norm(Ro)) < 1e-9 * max(1.0, np.linalg.norm(Ro))
+            elif op_ == "project_resid":
+                R = resid()
+                k = len(bf)
+                Vn = bf.V.to_numpy(k)
+                assert np.max(np.abs(Vn.T @ R)) < 1e-9 * max(1.0, np.linalg.norm(R)), (i, "project_resid")
+            elif op_ == "read_basis":
+                k = len(bf)
+                Vn = bf.V.to_numpy(k)
+                assert np.max(np.abs(Vn.T @ Vn - np.eye(k))) < 1e-11, (i, "read_basis")
+            elif op_ == "toggle_commit":
+                opt["block_commit"] ^= 1; c.set_option("block_commit", opt["block_commit"])
+            elif op_ == "toggle_resid_gram":
+                opt["resid_gram"] ^= 1; c.set_option("resid_gram", opt["resid_gram"])
+            elif op_ == "raw_ptr":
+                n_, ld_, cap_, dp = C.c_int64(), C.c_int64(), C.c_int(), C.c_void_p()
+                from krylovkit_hip._lib import check
+                check(c._lib.kk_basis_info(bf.V.handle, C.byref(n_), C.byref(ld_), C.byref(cap_), C.byref(dp)))
+            elif op_ == "sync":
+                c.sync()
+        check_H("end")
+        k = len(bf)
+        Vn = bf.V.to_numpy(k)
+        assert np.max(np.abs(Vn.T @ Vn - np.eye(k))) < 1e-11
+    finally:
+        c.close()
