@@ -186,6 +186,8 @@ KK_API int kk_ctx_set_option(kk_ctx c, const char* key, double value) {
         c->lookahead = value != 0;
     } else if (!strcmp(key, "mgs_panel")) {
         c->mgs_panel = value != 0;
+    } else if (!strcmp(key, "panel_lag")) {
+        c->panel_lag = value != 0;
     } else if (!strcmp(key, "panel_width")) {
         KK_CHECK(value == 0 || value == 1 || value == 2 || value == 3, KK_ERR_INVALID, "panel_width must be 0 (by vector length), 1, 2 or 3");
         c->panel_width = (int)value;
@@ -279,6 +281,7 @@ KK_API int kk_ctx_get_option(kk_ctx c, const char* key, double* value) {
     else if (!strcmp(key, "mgs_mode")) *value = c->mgs_mode;
     else if (!strcmp(key, "num_cus")) *value = c->num_cus;
     else if (!strcmp(key, "device_cus")) *value = c->dev_cus;
+    else if (!strcmp(key, "panel_lag")) *value = c->panel_lag;
     else if (!strcmp(key, "norm_commits_consumed")) *value = (double)c->norm_commits_consumed;
     else if (!strcmp(key, "persist_timeout_ms")) *value = c->persist_timeout_ms;
     else if (!strcmp(key, "xsync")) *value = c->xsync;

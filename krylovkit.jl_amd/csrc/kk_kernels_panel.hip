@@ -396,6 +396,230 @@ __global__ __launch_bounds__(KK_PANEL_PT) void k_mgs_panel(const double* __restr
     for (int j = 0; j < NV; ++j) pstore(rw, voff, (unsigned)j * sbytes, wr[j]);
 }
 
+// ==========================================================================================================================
+// Cross-panel LAG-1 form.  In k_mgs_panel the inner products of panel p + 1 wait for the update of panel p,
+// which waits for the grid reduction of panel p: one reduction (+ one refill of the memory pipe, because the registers of panel
+// p are not free for panel p + 2 before that) is exposed per panel -- 3.6 us per vector at 2 M rows against 2.4 us for the
+// bare stream.  Here the reduction of panel p is taken OFF the critical path:
+//   * the values of reduction R_p are formed from the work vector as it is BEFORE the update of panel p - 1:
+//         d~_p = Q_p' w_(p-1),   C_p = Q_p' Q_(p-1)   (P x P, both panels are in registers anyway),   G_p = strictly lower Q_p' Q_p
+//     and the MGS coefficients follow exactly:   rhs = d~_p - C_p s_(p-1)  ( = Q_p' (w_(p-1) - Q_(p-1) s_(p-1)) ),
+//     s_p = (I + L_p)^-1 rhs -- the algebra of the in-panel correction applied between two panels; no orthonormality assumed;
+//   * iteration p of the data waves:  partial sums of R_p -> hand-off;  totals of R_(p-1) (published one iteration ago) ->
+//     s_(p-1) -> w -= Q_(p-1) s_(p-1);  the registers of Q_(p-1) take the loads of Q_(p+2).  THREE register-resident panels:
+//     one being used up, one landed, one in flight -- the basis stream never waits for a reduction or a register;
+//   * the reductions belong to wave 0, which holds NO rows (7 data waves of 64 lanes): its sweep of R_p spins while the data
+//     waves stream, and -- having no panel loads of its own -- its granule loads are not queued behind any (in-order vmcnt).
+//     Per panel the kernel costs max(stream of P vectors, one grid reduction).
+// Same interface, epochs, granule sets, cross-rank level and commit as k_mgs_panel.  Not the reference's association of the
+// operations (like panels of P > 1): auto mode only; mgs_mode 0 keeps the strict kernel.
+// ==========================================================================================================================
+#define KK_LAG_DT 448   // data threads per block (waves 1..7)
+__device__ __forceinline__ void lag_publish(int nval, unsigned epoch, int set, char* __restrict__ sync, const double* smA) {
+    const int G = gridDim.x;
+    const int lane = threadIdx.x;
+    const unsigned set_bytes = (unsigned)G * 16u * 8u;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(sync, 0, 2 * (int)set_bytes, 0x00020000);
+    if (lane < nval) {
+        double b = 0;
+#pragma unroll
+        for (int k = 1; k < 8; ++k) b += smA[k * 8 + lane];   // data waves 1..7, fixed order
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(b);
+        v4u t;
+        t.x = epoch; t.y = (unsigned)(bits >> 32); t.z = (unsigned)bits; t.w = epoch;
+        __builtin_amdgcn_raw_buffer_store_b128(t, rs, (unsigned)set * set_bytes + ((unsigned)lane * (unsigned)G + blockIdx.x) * 16u, 0, 16 /* sc1 */);
+    }
+}
+// data waves, iteration p: partial sums of R_p from the landed panel `cur` (= Q_p), the panel before it `prev` (= Q_(p-1), zeros for
+// p = 0) and the work vector as it stands -> smA
+template <int NV, int P>
+__device__ __forceinline__ void lag_partials(const d2 (&wr)[NV], const d2 (&cur)[P][NV], const d2 (&prev)[P][NV], double* smA) {
+    constexpr int NVAL = P + P * P + P * (P - 1) / 2;
+    double acc[NVAL];
+#pragma unroll
+    for (int v = 0; v < NVAL; ++v) acc[v] = 0;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            acc[i] = fma(cur[i][j].x, wr[j].x, acc[i]);
+            acc[i] = fma(cur[i][j].y, wr[j].y, acc[i]);
+#pragma unroll
+            for (int k = 0; k < P; ++k) {
+                acc[P + i * P + k] = fma(cur[i][j].x, prev[k][j].x, acc[P + i * P + k]);
+                acc[P + i * P + k] = fma(cur[i][j].y, prev[k][j].y, acc[P + i * P + k]);
+            }
+#pragma unroll
+            for (int k = 0; k < i; ++k) {
+                const int g = P + P * P + i * (i - 1) / 2 + k;
+                acc[g] = fma(cur[i][j].x, cur[k][j].x, acc[g]);
+                acc[g] = fma(cur[i][j].y, cur[k][j].y, acc[g]);
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int v = 0; v < NVAL; ++v) {
+        const double t = wave_sum(acc[v]);
+        if (lane == 0) smA[wave * 8 + v] = t;
+    }
+}
+// data waves: totals of R_q (q = the panel held in `pan`) -> coefficients (sp: in = s_(q-1), out = s_q) -> w -= pan s_q
+template <int NV, int P>
+__device__ __forceinline__ void lag_update(d2 (&wr)[NV], const d2 (&pan)[P][NV], const double* tot, double (&sp)[P], int s0, int nsteps, int m,
+                                           double* __restrict__ out_s, int out_stride) {
+    double s[P];
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        double t = tot[i];
+#pragma unroll
+        for (int k = 0; k < P; ++k) t = fma(-tot[P + i * P + k], sp[k], t);              // - C s_(q-1)
+#pragma unroll
+        for (int k = 0; k < i; ++k) t = fma(-tot[P + P * P + i * (i - 1) / 2 + k], s[k], t);   // forward substitution inside the panel
+        s[i] = t;
+    }
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) fnma2(wr[j], s[i], pan[i][j]);
+        sp[i] = s[i];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 64) {
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            const int sv = s0 + i;
+            if (sv < nsteps) out_s[(sv / m) * out_stride + (sv % m)] = s[i];
+        }
+    }
+}
+
+template <int NV, int P>
+__global__ __launch_bounds__(KK_PANEL_PT) void k_mgs_panel_lag(const double* __restrict__ V, int64_t ld, int m, int nsweeps, double* __restrict__ w,
+                                                               const double* __restrict__ carry_q, const double* __restrict__ carry_s,
+                                                               double* __restrict__ out_s, int out_stride, double* __restrict__ nrm_out3,
+                                                               char* __restrict__ sync, int* __restrict__ err, int fault, unsigned ebase, int normalize,
+                                                               double* __restrict__ ok_out, double token, kk_xs_dev xs, long long timeout_ticks) {
+    constexpr int NVAL = P + P * P + P * (P - 1) / 2;
+    static_assert(NVAL <= 8, "one reduction carries at most 8 values");
+    __shared__ double smA[64];   // [wave][8] partial sums of the data waves
+    __shared__ double smB[32];   // [set][16]: totals of a reduction, [8] = failure flag
+    if (fault && blockIdx.x == 0) {
+        if (threadIdx.x == 0) { __hip_atomic_store(err, 1, RLX_AGENT); xs_abort(xs); }
+        return;
+    }
+    const int nsteps = m * nsweeps;
+    const int npanels = (nsteps + P - 1) / P;
+    if (threadIdx.x < 64) {
+        // ---------------- the reduction wave
+        if (threadIdx.x == 0) { smB[8] = 0.0; smB[24] = 0.0; }
+        lds_barrier();   // (0)
+        for (int p = 0; p < npanels; ++p) {
+            lds_barrier();   // (1_p) partial sums of R_p are in smA
+            lag_publish(NVAL, ebase + (unsigned)p + 1u, p & 1, sync, smA);
+            lds_barrier();   // (2_p) smA may be overwritten; the totals of R_(p-1) (swept before (1_p)) are in smB[(p-1) & 1]
+            if (!panel_sweep(NVAL, ebase + (unsigned)p + 1u, p & 1, sync, err, smB + (p & 1) * 16, xs, (unsigned)p, timeout_ticks, p)) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the flag is in LDS: the data waves see it behind their next barrier pair
+                return;                                               // (a wave that has ended no longer counts in s_barrier)
+            }
+        }
+        lds_barrier();   // (2_npanels) totals of the last panel
+        if (nrm_out3) {
+            lds_barrier();   // (1_n) partial of |w|^2
+            lag_publish(1, ebase + (unsigned)npanels + 1u, npanels & 1, sync, smA);
+            panel_sweep(1, ebase + (unsigned)npanels + 1u, npanels & 1, sync, err, smB + (npanels & 1) * 16, xs, (unsigned)npanels, timeout_ticks);
+            lds_barrier();   // (2_n)
+        }
+        return;
+    }
+    // ---------------- the data waves: rows owned contiguously per block, as in k_mgs_panel, 448 double2 per grid-row
+    const unsigned dt = threadIdx.x - 64;
+    const int nvr = (int)((ld + (int64_t)gridDim.x * KK_LAG_DT * 2 - 1) / ((int64_t)gridDim.x * KK_LAG_DT * 2));
+    const int64_t rpb = (int64_t)nvr * KK_LAG_DT * 2;
+    const int64_t brow = (int64_t)blockIdx.x * rpb;
+    const int64_t left = ld - brow;
+    const int bbytes = (int)((left < 0 ? 0 : (left < rpb ? left : rpb)) * 8);
+    const unsigned sbytes = KK_LAG_DT * 16u;
+    const unsigned voff = dt * 16u;
+    const __amdgpu_buffer_rsrc_t rw = pcol_rsrc(w + brow, bbytes);
+    d2 wr[NV];
+    d2 q0[P][NV], q1[P][NV], q2[P][NV];   // panels p = 0, 1, 2 (mod 3)
+    panel_issue<NV, P>(q0, V, ld, m, 0, nsteps, voff, sbytes, brow, bbytes);
+    panel_issue<NV, P>(q1, V, ld, m, P, nsteps, voff, sbytes, brow, bbytes);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) wr[j] = pload(rw, voff, (unsigned)j * sbytes);
+    if (carry_q) {   // pending axpy of the caller (Lanczos: w -= alpha0 v), through the set that is idle until panel 2 is requested
+        const __amdgpu_buffer_rsrc_t rc = pcol_rsrc(carry_q + brow, bbytes);
+        const double cs = *carry_s;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) q2[0][j] = pload(rc, voff, (unsigned)j * sbytes);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) fnma2(wr[j], cs, q2[0][j]);
+    }
+#pragma unroll
+    for (int i = 0; i < P; ++i)
+#pragma unroll
+        for (int j = 0; j < NV; ++j) q2[i][j] = d2{0.0, 0.0};   // "panel -1": C_0 = 0
+    lds_barrier();   // (0)
+    double sp[P];
+#pragma unroll
+    for (int i = 0; i < P; ++i) sp[i] = 0.0;
+    // one iteration: cur = Q_p (landed), prev = Q_(p-1) (updates w now, then takes the loads of Q_(p+2)), the third set is in flight
+#define LAG_STEP(cur, prev, p)                                                                                                           \
+    do {                                                                                                                                 \
+        lag_partials<NV, P>(wr, cur, prev, smA);                                                                                         \
+        lds_barrier(); /* (1_p) */                                                                                                       \
+        lds_barrier(); /* (2_p) */                                                                                                       \
+        if ((p) > 0) {                                                                                                                   \
+            const double* tot = smB + (((p) - 1) & 1) * 16;                                                                              \
+            if (tot[8] != 0.0) return; /* timeout somewhere on the chip (or on a peer): w in HBM is untouched */                        \
+            lag_update<NV, P>(wr, prev, tot, sp, ((p) - 1) * P, nsteps, m, out_s, out_stride);                                           \
+        }                                                                                                                                \
+        panel_issue<NV, P>(prev, V, ld, m, ((p) + 2) * P, nsteps, voff, sbytes, brow, bbytes);                                           \
+    } while (0)
+    int p = 0;
+    for (;;) {
+        LAG_STEP(q0, q2, p); if (++p >= npanels) break;
+        LAG_STEP(q1, q0, p); if (++p >= npanels) break;
+        LAG_STEP(q2, q1, p); if (++p >= npanels) break;
+    }
+#undef LAG_STEP
+    lds_barrier();   // (2_npanels)
+    {
+        const double* tot = smB + ((npanels - 1) & 1) * 16;
+        if (tot[8] != 0.0) return;
+        const int last = (npanels - 1) % 3;   // uniform: the set that holds the last panel
+        if (last == 0) lag_update<NV, P>(wr, q0, tot, sp, (npanels - 1) * P, nsteps, m, out_s, out_stride);
+        else if (last == 1) lag_update<NV, P>(wr, q1, tot, sp, (npanels - 1) * P, nsteps, m, out_s, out_stride);
+        else lag_update<NV, P>(wr, q2, tot, sp, (npanels - 1) * P, nsteps, m, out_s, out_stride);
+    }
+    double inv = 1.0;
+    bool scale = false;
+    if (nrm_out3) {
+        double an = 0.0;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) { an = fma(wr[j].x, wr[j].x, an); an = fma(wr[j].y, wr[j].y, an); }
+        const double t = wave_sum(an);
+        if ((threadIdx.x & 63) == 0) smA[(threadIdx.x >> 6) * 8] = t;
+        lds_barrier();   // (1_n)
+        lds_barrier();   // (2_n)
+        const double* tot = smB + (npanels & 1) * 16;
+        if (tot[8] != 0.0) return;
+        const double rt = sqrt(tot[0]);
+        inv = 1.0 / rt;
+        scale = normalize && rt > 0.0 && inv <= 1.79769313486231570815e308;
+        if (blockIdx.x == 0 && threadIdx.x == 64) { nrm_out3[0] = tot[0]; nrm_out3[1] = rt; nrm_out3[2] = inv; }
+    }
+    // commit (see k_mgs_persist / k_mgs_panel)
+    if (__hip_atomic_load(err, RLX_AGENT)) return;
+    if (blockIdx.x == 0 && threadIdx.x == 64) { ok_out[0] = token; ok_out[1] = scale ? 1.0 : inv; }
+    const double f = scale ? inv : 1.0;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) { wr[j].x *= f; wr[j].y *= f; }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) pstore(rw, voff, (unsigned)j * sbytes, wr[j]);
+}
+
 // ---- launcher ------------------------------------------------------------------------------
 // vectors of at most 16 rows of 512 double2 per block (4.19 M rows on 256 CUs): w plus two panels fit the 256 registers of a 512-thread block
 int64_t kk_mgs_panel_capacity(kk_ctx ctx) { return (int64_t)ctx->num_cus * KK_PANEL_DT * 2 * 16; }
@@ -410,6 +634,11 @@ static int launch_panel_inst(kk_ctx ctx, void** args) {
     return kk_launch_resident(ctx, (const void*)k_mgs_panel<NV, P>, KK_PANEL_PT, args, 0, "k_mgs_panel");
 }
 
+template <int NV, int P>
+static int launch_panel_lag_inst(kk_ctx ctx, void** args) {
+    return kk_launch_resident(ctx, (const void*)k_mgs_panel_lag<NV, P>, KK_PANEL_PT, args, 0, "k_mgs_panel_lag");
+}
+
 // panel width by vector length: what two register-resident panels + w leave room for (4 NV (1 + 2 P) <= ~200 registers)
 int kk_mgs_panel_width(kk_ctx ctx, int64_t ld, bool strict) {
     if (strict) return 1;
@@ -421,7 +650,11 @@ int kk_mgs_panel_width(kk_ctx ctx, int64_t ld, bool strict) {
 int kk_launch_mgs_panel(kk_ctx ctx, const double* V, int64_t ld, int m, int nsweeps, double* w, const double* carry_q,
                         const double* carry_s, double* out_s, int out_stride, double* nrm_out3, bool normalize_w, bool strict) {
     const int nv = (int)((ld + (int64_t)ctx->num_cus * KK_PANEL_DT * 2 - 1) / ((int64_t)ctx->num_cus * KK_PANEL_DT * 2));
-    const int P = kk_mgs_panel_width(ctx, ld, strict);
+    // the lag-1 kernel (three register-resident panels, 448 double2 per grid-row): vectors of <= 12 such rows per block, i.e.
+    // 2.75 M rows on 256 CUs; beyond that (and in the strict order) the kernel above
+    const int nvl = (int)((ld + (int64_t)ctx->num_cus * KK_LAG_DT * 2 - 1) / ((int64_t)ctx->num_cus * KK_LAG_DT * 2));
+    const bool lag = !strict && ctx->panel_lag && nvl <= 12;
+    const int P = lag ? (nvl <= 6 ? std::min(2, ctx->panel_width > 0 ? ctx->panel_width : 2) : 1) : kk_mgs_panel_width(ctx, ld, strict);
     KK_HIP(hipSetDevice(ctx->device));
     char* sync = (char*)ctx->d_sync;
     int* err = (int*)((char*)ctx->d_sync + KK_SYNC_ERR_OFFSET);
@@ -444,6 +677,12 @@ int kk_launch_mgs_panel(kk_ctx ctx, const double* V, int64_t ld, int m, int nswe
                     (void*)&out_s, (void*)&out_stride, (void*)&nrm_out3, (void*)&sync, (void*)&err, (void*)&fault,
                     (void*)&ebase, (void*)&normalize, (void*)&ok_out, (void*)&token, (void*)&xs, (void*)&timeout_ticks};
     kk_prof_scope ps(ctx, "k_mgs_panel");
+    if (lag) {
+        if (nvl <= 4) return P >= 2 ? launch_panel_lag_inst<4, 2>(ctx, args) : launch_panel_lag_inst<4, 1>(ctx, args);
+        if (nvl <= 6) return P >= 2 ? launch_panel_lag_inst<6, 2>(ctx, args) : launch_panel_lag_inst<9, 1>(ctx, args);
+        if (nvl <= 9) return launch_panel_lag_inst<9, 1>(ctx, args);
+        return launch_panel_lag_inst<12, 1>(ctx, args);
+    }
     if (nv <= 4) return P >= 3 ? launch_panel_inst<4, 3>(ctx, args) : (P == 2 ? launch_panel_inst<4, 2>(ctx, args) : launch_panel_inst<4, 1>(ctx, args));
     if (nv <= KK_PANEL_NVMID) return P >= 2 ? launch_panel_inst<KK_PANEL_NVMID, 2>(ctx, args) : launch_panel_inst<KK_PANEL_NVMID, 1>(ctx, args);
     if (nv <= 16) return launch_panel_inst<16, 1>(ctx, args);

@@ -13,12 +13,16 @@ def relerr(a, b):
     return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300)))
 
 
-@pytest.fixture()
-def pctx(kk):
+@pytest.fixture(params=["lag1", "in_panel"])
+def pctx(kk, request):
+    """outside the strict order the sweeps go through the cross-panel lag-1 kernel (k_mgs_panel_lag: three register-resident panels,
+    reductions off the critical path; vectors of <= 2.75 M rows) or -- option panel_lag = 0, and beyond that length -- through
+    k_mgs_panel with its in-panel correction only: both against the oracle"""
     c = kk.Context(0)
     if c.get_option("mgs_persist") == 0:
         pytest.skip("no cooperative launch on this device: the persistent routes are off")
     c.set_option("panel_min_rows", 0)     # auto mode takes the panel kernel at every size it can hold
+    c.set_option("panel_lag", 1 if request.param == "lag1" else 0)
     yield c
     c.close()
 
@@ -27,8 +31,9 @@ def algs(kk, ko):
     return [(kk.ModifiedGramSchmidt(), ko.MGS), (kk.ModifiedGramSchmidt2(), ko.MGS2), (kk.ModifiedGramSchmidtIR(0.99), ko.MGSIR(0.99))]
 
 
-# vector lengths chosen to hit every instantiation on 256 CUs (grid-row = 229376 rows): NV = 4 / 9 / 16
-@pytest.mark.parametrize("n,m", [(777, 5), (900000, 7), (1200000, 5), (2500000, 4), (3600000, 3)])
+# vector lengths chosen to hit every instantiation on 256 CUs (k_mgs_panel, grid-row = 262144 rows: NV = 4 / 8 / 16; k_mgs_panel_lag,
+# grid-row = 229376 rows: NV = 4 / 6 / 9 / 12, beyond 2.75 M rows the former)
+@pytest.mark.parametrize("n,m", [(777, 5), (900000, 7), (1200000, 5), (1900000, 4), (2500000, 4), (3600000, 3)])
 @pytest.mark.parametrize("mode,width", [(0, 0), (2, 0), (2, 3)])
 def test_orthogonalize_through_the_panel_kernel(kk, ko, pctx, n, m, mode, width):
     pctx.set_option("mgs_mode", mode)
