@@ -181,7 +181,10 @@ struct kk_ctx_s {
     int keep_mb = 160;           // MB of trailing basis columns a project pass leaves cache-allocated for the unproject
                                  // pass that follows (the Infinity Cache holds 256 MB); 0 = all loads non-temporal
     int mgs_panel = 1;           // MGS sweeps of vectors of <= 16 grid-rows (4.19 M rows) through the persistent PANEL kernel (kk_kernels_panel.hip)
-    int panel_lag = 1;           // panel sweeps outside the strict order: cross-panel lag-1 kernel (k_mgs_panel_lag: reductions off the critical path) where the vector fits three register-resident panels
+    int panel_lag = 0;           // panel sweeps outside the strict order through the cross-panel lag-1 kernel (k_mgs_panel_lag) where the vector fits three
+                                 // register-resident panels of two vectors.  OFF by default: measured SLOWER than k_mgs_panel at every length it can hold
+                                 // (profiles/r05_panel_lag_ab.jsonl: 4289 vs 5552 it/s on a 1 M-row GMRES(60) cycle) -- the reduction chain of its wave 0
+                                 // (publish -> sweep -> publish) is as long as the reduction it was meant to hide; kept, tested, as the record of the experiment
     int panel_width = 0;         // basis vectors per grid reduction of that kernel: 0 = by vector length (3 / 2 / 1), else min(value, by length); mgs_mode 0 forces 1
     int64_t panel_min_rows = 1400000;  // auto mode: below this one grid reduction per panel (a fixed ~6 us) costs more than the second read of the basis by the projection pair (tools/panel_sweep_cost.py: 1 M rows 3.1 vs 2.6 us per vector, 2 M rows 3.6 vs 5.1)
     int xsync = 1;               // row-sharded context: persistent kernels with the in-kernel cross-rank reduction where the communicator offers it (0: RCCL all-reduce per inner-product batch, low-sync route)

@@ -413,6 +413,16 @@ __global__ __launch_bounds__(KK_PANEL_PT) void k_mgs_panel(const double* __restr
 //     Per panel the kernel costs max(stream of P vectors, one grid reduction).
 // Same interface, epochs, granule sets, cross-rank level and commit as k_mgs_panel.  Not the reference's association of the
 // operations (like panels of P > 1): auto mode only; mgs_mode 0 keeps the strict kernel.
+//
+// MEASURED (round 5, profiles/r05_panel_lag_ab.jsonl, Arnoldi MGS2 cycle of 60 on the convection-diffusion operator): slower
+// than k_mgs_panel at every length -- 0.25 M rows 4738 vs 5932 it/s, 1 M 4289 vs 5552, 1.8 M 3520 vs 4787; with ONE vector per
+// reduction (the only width whose three panels fit the registers at 2 M rows) 3926 vs 4594.  What bounds it is the chain of wave
+// 0 -- publish R_p, sweep R_p (2-3 passes of ~1 us under a streaming chip), barrier, publish R_(p+1) -- about 6-7 us per
+// reduction, as long as the reduction k_mgs_panel exposes; and it holds two vectors per reduction where k_mgs_panel holds three
+// at <= 4 grid-rows.  The lag buys nothing while the reduction itself, not its position, is the cost.  Option "panel_lag" = 1
+// selects it (default 0); tests/test_gpu_panel.py runs both.
+// ==========================================================================================================================
+// (kept compiled and tested: exact algebra, same interface)
 // ==========================================================================================================================
 #define KK_LAG_DT 448   // data threads per block (waves 1..7)
 __device__ __forceinline__ void lag_publish(int nval, unsigned epoch, int set, char* __restrict__ sync, const double* smA) {
@@ -650,11 +660,14 @@ int kk_mgs_panel_width(kk_ctx ctx, int64_t ld, bool strict) {
 int kk_launch_mgs_panel(kk_ctx ctx, const double* V, int64_t ld, int m, int nsweeps, double* w, const double* carry_q,
                         const double* carry_s, double* out_s, int out_stride, double* nrm_out3, bool normalize_w, bool strict) {
     const int nv = (int)((ld + (int64_t)ctx->num_cus * KK_PANEL_DT * 2 - 1) / ((int64_t)ctx->num_cus * KK_PANEL_DT * 2));
-    // the lag-1 kernel (three register-resident panels, 448 double2 per grid-row): vectors of <= 12 such rows per block, i.e.
-    // 2.75 M rows on 256 CUs; beyond that (and in the strict order) the kernel above
+    // the lag-1 kernel (three register-resident panels of two vectors, 448 double2 per grid-row): vectors of <= 8 such rows per
+    // block, i.e. 1.83 M rows on 256 CUs; beyond that (and in the strict order) the kernel above
     const int nvl = (int)((ld + (int64_t)ctx->num_cus * KK_LAG_DT * 2 - 1) / ((int64_t)ctx->num_cus * KK_LAG_DT * 2));
-    const bool lag = !strict && ctx->panel_lag && nvl <= 12;
-    const int P = lag ? (nvl <= 6 ? std::min(2, ctx->panel_width > 0 ? ctx->panel_width : 2) : 1) : kk_mgs_panel_width(ctx, ld, strict);
+    // (two vectors per reduction or not at all: with ONE vector per reduction the lag-1 form is bound by the latency of the
+    // reduction chain of wave 0 -- publish, sweep, publish -- at ~3.6 us per vector, slower than k_mgs_panel's 3.0 at 2 M rows,
+    // profiles/r05_panel_lag_ab.jsonl; three panels of two vectors fit the registers up to 8 grid-rows = 1.83 M rows on 256 CUs)
+    const bool lag = !strict && ctx->panel_lag && nvl <= 8 && (ctx->panel_width == 0 || ctx->panel_width >= 2);
+    const int P = lag ? 2 : kk_mgs_panel_width(ctx, ld, strict);
     KK_HIP(hipSetDevice(ctx->device));
     char* sync = (char*)ctx->d_sync;
     int* err = (int*)((char*)ctx->d_sync + KK_SYNC_ERR_OFFSET);
@@ -678,10 +691,9 @@ int kk_launch_mgs_panel(kk_ctx ctx, const double* V, int64_t ld, int m, int nswe
                     (void*)&ebase, (void*)&normalize, (void*)&ok_out, (void*)&token, (void*)&xs, (void*)&timeout_ticks};
     kk_prof_scope ps(ctx, "k_mgs_panel");
     if (lag) {
-        if (nvl <= 4) return P >= 2 ? launch_panel_lag_inst<4, 2>(ctx, args) : launch_panel_lag_inst<4, 1>(ctx, args);
-        if (nvl <= 6) return P >= 2 ? launch_panel_lag_inst<6, 2>(ctx, args) : launch_panel_lag_inst<9, 1>(ctx, args);
-        if (nvl <= 9) return launch_panel_lag_inst<9, 1>(ctx, args);
-        return launch_panel_lag_inst<12, 1>(ctx, args);
+        if (nvl <= 4) return launch_panel_lag_inst<4, 2>(ctx, args);
+        if (nvl <= 6) return launch_panel_lag_inst<6, 2>(ctx, args);
+        return launch_panel_lag_inst<8, 2>(ctx, args);
     }
     if (nv <= 4) return P >= 3 ? launch_panel_inst<4, 3>(ctx, args) : (P == 2 ? launch_panel_inst<4, 2>(ctx, args) : launch_panel_inst<4, 1>(ctx, args));
     if (nv <= KK_PANEL_NVMID) return P >= 2 ? launch_panel_inst<KK_PANEL_NVMID, 2>(ctx, args) : launch_panel_inst<KK_PANEL_NVMID, 1>(ctx, args);

@@ -11,7 +11,8 @@ sys.path.insert(0, str(ROOT))
 import krylovkit_hip as kk  # noqa: E402
 from bench import convdiff_rows  # noqa: E402
 
-nx, ny, K = 2000, 1000, 60
+import os
+nx, ny, K = int(os.environ.get("KK_AB_NX", 2000)), int(os.environ.get("KK_AB_NY", 1000)), 60
 N = nx * ny
 ctx = kk.default_context()
 op = kk.SparseOperator(convdiff_rows(nx, ny), ctx)
@@ -41,6 +42,6 @@ for rnd in range(2):
             f = sweep()
         ctx.sync()
         dt = (time.perf_counter() - t0) / 10
-        print(json.dumps({"variant": var, "round": rnd, "it_per_s": round((K - 1) / dt, 1), "ms_per_cycle": round(dt * 1e3, 3)}), flush=True)
+        print(json.dumps({"rows": N, "variant": var, "round": rnd, "it_per_s": round((K - 1) / dt, 1), "ms_per_cycle": round(dt * 1e3, 3)}), flush=True)
         for k, v in defaults.items():
             ctx.set_option(k, v)
