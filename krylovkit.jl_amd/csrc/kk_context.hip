@@ -260,6 +260,8 @@ KK_API int kk_ctx_set_option(kk_ctx c, const char* key, double value) {
         c->block_fuse = (int)value;
     } else if (!strcmp(key, "block_async")) {
         c->block_async = value != 0;
+    } else if (!strcmp(key, "bu_mfma")) {
+        c->bu_mfma = (int)value;
     } else if (!strcmp(key, "bu_prefetch")) {
         KK_CHECK(value == 0 || value == 1 || value == 8 || value == 16 || value == 24, KK_ERR_INVALID, "bu_prefetch must be 0, 1, 8, 16 or 24");
         c->bu_prefetch = (int)value;
@@ -281,6 +283,7 @@ KK_API int kk_ctx_get_option(kk_ctx c, const char* key, double* value) {
     else if (!strcmp(key, "mgs_mode")) *value = c->mgs_mode;
     else if (!strcmp(key, "num_cus")) *value = c->num_cus;
     else if (!strcmp(key, "device_cus")) *value = c->dev_cus;
+    else if (!strcmp(key, "bu_mfma")) *value = c->bu_mfma;
     else if (!strcmp(key, "panel_lag")) *value = c->panel_lag;
     else if (!strcmp(key, "norm_commits_consumed")) *value = (double)c->norm_commits_consumed;
     else if (!strcmp(key, "persist_timeout_ms")) *value = c->persist_timeout_ms;

@@ -153,6 +153,7 @@ struct kk_ctx_s {
     int spmm_dia = 1;            // multi-column apply of a detected grid stencil: sweeping diagonal kernel (0: ELL gather kernel)
     int spmm_dia_lines = 16;     // ... grid lines per wave sweep
     int spmm_cols = 16;          // SpMM on ELL: right-hand sides per launch (16, 8 or 4)
+    int bu_mfma = 0;             // block update W = beta W + alpha V S through the MFMA kernel (k_block_update_mfma: transposed product, 16-byte operand loads)
     int bu_prefetch = 1;         // block update kernel: 1 = coefficient panel in LDS (default), 0 = scalar-load kernel of round 1, 8/16/24 = deep-prefetch experiments
     int gram_nt = 0;             // Gram panel: non-temporal loads for the X stream
     // Gram matrix of the residual block the last asynchronous one-pass block step left behind (device, AB_GW), valid while

@@ -974,6 +974,107 @@ __global__ __launch_bounds__(KK_TPB, 4) void k_block_update_lds(const double* V,
     }
 }
 
+// MFMA form of the block update ("W -= V P on v_mfma_f64_16x16x4_f64").  The product is taken TRANSPOSED,
+// W^T (16 x rows) += P^T (16 x m) V^T (m x rows), so that every operand sits where the data already is:
+//   * B operand = V^T: lane (i = lane % 16, k = lane / 16) supplies V[row, column 4q + k] -- ONE 16-byte load per lane covers the
+//     two rows 2i, 2i + 1 of a 32-row tile (.x -> the even-row accumulator, .y -> the odd-row one): 16 lanes x 16 B = 256
+//     contiguous bytes of one basis column, four columns per load instruction, no 8-byte access, no re-layout;
+//   * A operand = P^T: lane supplies P[4q + k][n = i], one double per four MFMAs (two tiles x even / odd), read from an LDS
+//     copy of the panel laid out in fragment order (conflict-free 512-byte wave reads; no broadcast traffic: the VALU kernel
+//     issues eight 16-byte broadcast reads per basis column and lane);
+//   * D = W^T: lane holds the residual columns n = lane / 16 + 4 r, r < 4, of its row pair -- the Win loads and W stores are
+//     again 256 contiguous bytes per column.
+// gfx950's f64 matrix rate equals its vector rate: the gain is not flops but instruction issue -- per 32 rows x 4 columns one
+// load, one LDS read and two MFMAs instead of one load, eight LDS reads and 32 FMAs.  The summation over the basis columns runs
+// in the order q = 0, 1, ... with four columns per MFMA: not the bit pattern of the VALU kernel (parity bar: 1e-10 on H).
+template <bool BZERO, int TR /* 32-row tiles per wave iteration */, int PF /* column groups of loads in flight */, int MINB = 2>
+__global__ __launch_bounds__(KK_TPB, MINB) void k_block_update_mfma(const double* V, int64_t ld, int m, const double* Win, double* Wout, int64_t ldw_in,
+                                                                int64_t ldw_out, int nb, const double* __restrict__ S, int sstride, double alpha, double beta,
+                                                                int64_t rpb, double* __restrict__ part_nrm, const double* __restrict__ skip) {
+    if (skip && *skip != 0.0) return;
+    extern __shared__ __attribute__((aligned(16))) double ssm[];   // [MQ][64] coefficient fragments, then [16][4] norm slots
+    const int MQ = (m + 3) >> 2;
+    double* nsl = ssm + (size_t)MQ * 64;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    for (int e = tid; e < MQ * 64; e += KK_TPB) {
+        const int k = 4 * (e >> 6) + ((e & 63) >> 4), n = e & 15;
+        ssm[e] = (k < m && n < sstride) ? S[(size_t)k * sstride + n] : 0.0;
+    }
+    if (tid < 64) nsl[tid] = 0.0;
+    __syncthreads();
+    const int li = lane & 15, lk = lane >> 4;
+    const int64_t r0 = (int64_t)blockIdx.x * rpb, r1 = imin(r0 + rpb, ld);
+    double nacc[4] = {0.0, 0.0, 0.0, 0.0};   // squared norms of columns lk + 4 r over this lane's rows
+    // a wave owns TR consecutive 32-row tiles per iteration; rpb is a multiple of 512 = 4 waves x 128 rows
+    for (int64_t rt = r0 + (int64_t)wave * (32 * TR); rt < r1; rt += 4 * 32 * TR) {
+        v4d acc[TR][2];
+#pragma unroll
+        for (int t = 0; t < TR; ++t) { acc[t][0] = v4d{0.0, 0.0, 0.0, 0.0}; acc[t][1] = v4d{0.0, 0.0, 0.0, 0.0}; }
+        const int64_t rbase = rt + 2 * li;
+        d2 x[PF][TR];
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int c = 4 * u + lk;
+            const double* col = V + (int64_t)(c < m ? c : m - 1) * ld + rbase;
+#pragma unroll
+            for (int t = 0; t < TR; ++t) x[u][t] = ld2s(col + 32 * t);
+        }
+        for (int q0 = 0; q0 < MQ; q0 += PF) {
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int q = q0 + u;
+                if (q < MQ) {   // uniform
+                    const double a = ssm[q * 64 + lane];
+                    d2 xc[TR];
+#pragma unroll
+                    for (int t = 0; t < TR; ++t) xc[t] = x[u][t];
+                    const int qn = q + PF;
+                    if (qn < MQ) {
+                        const int c = 4 * qn + lk;
+                        const double* col = V + (int64_t)(c < m ? c : m - 1) * ld + rbase;
+#pragma unroll
+                        for (int t = 0; t < TR; ++t) x[u][t] = ld2s(col + 32 * t);
+                    }
+#pragma unroll
+                    for (int t = 0; t < TR; ++t) {
+                        acc[t][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, xc[t].x, acc[t][0], 0, 0, 0);
+                        acc[t][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, xc[t].y, acc[t][1], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        // epilogue: w = beta Win + alpha (V S), columns n = lk + 4 r of the row pairs (2 li, 2 li + 1) of every tile
+        // (accumulator element r of lane l is D[l / 16 + 4 r][l % 16]: the layout k_finalize_gram decodes)
+#pragma unroll
+        for (int t = 0; t < TR; ++t) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = lk + 4 * r;
+                if (n < nb) {
+                    d2 w{alpha * acc[t][0][r], alpha * acc[t][1][r]};
+                    if (!BZERO) {
+                        const d2 wi = BUL_LD_WIN(Win + (int64_t)n * ldw_in + rbase + 32 * t);
+                        w.x = fma(beta, wi.x, w.x); w.y = fma(beta, wi.y, w.y);
+                    }
+                    BUL_ST(Wout + (int64_t)n * ldw_out + rbase + 32 * t, w);
+                    nacc[r] = fma(w.x, w.x, fma(w.y, w.y, nacc[r]));
+                }
+            }
+        }
+    }
+    if (part_nrm) {
+        // column lk + 4 r: sum over the 16 lanes of the group (row reduction inside a DPP row), then over the waves
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            double v = nacc[r];
+            v += dpp_mov<0xB1>(v); v += dpp_mov<0x4E>(v); v += dpp_mov<0x141>(v); v += dpp_mov<0x140>(v);
+            if (li == 0) nsl[(lk + 4 * r) * 4 + wave] = v;
+        }
+        __syncthreads();
+        if (tid < nb) part_nrm[(int64_t)tid * KK_MAX_BLOCKS + blockIdx.x] = (nsl[tid * 4] + nsl[tid * 4 + 1]) + (nsl[tid * 4 + 2] + nsl[tid * 4 + 3]);
+    }
+}
+
 // Deep-prefetch variant: a ring of PF basis-column loads (16 B each) stays in flight per lane -- as many bytes in flight as
 // the single-vector unproject kernel keeps with its 32 x 2 tile -- at 2 blocks per CU (up to 256 registers per lane).
 // Same arithmetic, same summation order as k_block_update.
@@ -1497,7 +1598,24 @@ int kk_launch_block_update(kk_ctx ctx, const double* V, int64_t ld, int m, const
 #define BU_LDS(NBT) \
         if (bz) hipLaunchKernelGGL((k_block_update_lds<NBT, true>), g, b, shm, ctx->stream, V, ld, m, Win, Wout, ldw_in, ldw_out, nb, S_dev, alpha, beta, p.rpb, part, skip_dev); \
         else hipLaunchKernelGGL((k_block_update_lds<NBT, false>), g, b, shm, ctx->stream, V, ld, m, Win, Wout, ldw_in, ldw_out, nb, S_dev, alpha, beta, p.rpb, part, skip_dev);
-        if (ctx->bu_prefetch == 1 && m * kk_bu_stride(nb) <= 8192) { if (nb <= 4) { BU_LDS(4) } else if (nb <= 8) { BU_LDS(8) } else { BU_LDS(16) } }
+        if (ctx->bu_mfma && m >= 4 && ((size_t)((m + 3) / 4) * 64 + 64) * sizeof(double) <= 60 * 1024) {
+            // MFMA form (any nb <= 16: the panel stride is that of the VALU kernels)
+            const size_t shm2 = ((size_t)((m + 3) / 4) * 64 + 64) * sizeof(double);
+            const int sst = kk_bu_stride(nb);
+#define BU_MFMA(TRV, PFV, MB) \
+            if (bz) hipLaunchKernelGGL((k_block_update_mfma<true, TRV, PFV, MB>), g, b, shm2, ctx->stream, V, ld, m, Win, Wout, ldw_in, ldw_out, nb, S_dev, sst, alpha, beta, p.rpb, part, skip_dev); \
+            else hipLaunchKernelGGL((k_block_update_mfma<false, TRV, PFV, MB>), g, b, shm2, ctx->stream, V, ld, m, Win, Wout, ldw_in, ldw_out, nb, S_dev, sst, alpha, beta, p.rpb, part, skip_dev);
+            switch (ctx->bu_mfma) {   // tile shapes (tools/bu_mfma_check.py)
+                case 2: { BU_MFMA(2, 8, 2) } break;
+                case 3: { BU_MFMA(4, 4, 2) } break;
+                case 4: { BU_MFMA(1, 8, 4) } break;
+                case 5: { BU_MFMA(2, 4, 4) } break;
+                case 6: { BU_MFMA(1, 16, 2) } break;
+                default: { BU_MFMA(2, 4, 2) } break;
+            }
+#undef BU_MFMA
+        }
+        else if (ctx->bu_prefetch == 1 && m * kk_bu_stride(nb) <= 8192) { if (nb <= 4) { BU_LDS(4) } else if (nb <= 8) { BU_LDS(8) } else { BU_LDS(16) } }
         else if (nb > 8 && ctx->bu_prefetch == 16) { BU_PF(16, 16) }
         else if (nb > 8 && ctx->bu_prefetch == 8) { BU_PF(16, 8) }
         else if (nb > 8 && ctx->bu_prefetch == 24) { BU_PF(16, 24) }

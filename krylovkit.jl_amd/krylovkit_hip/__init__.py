@@ -19,6 +19,7 @@ from .linsolve import linsolve, linsolve_bicgstab, linsolve_cg
 from .lssolve import lssolve
 
 from .matrixfun import expintegrator, exponentiate
+from .scope import BiArnoldi, GolubYe, OutOfScopeError, bieigsolve, eigsolve_arnoldi, geneigsolve, schursolve   # import-compatible stubs (out of scope, see scope.py)
 
 _lib.load()  # fail at import time if libkrylov_hip.so is missing
 

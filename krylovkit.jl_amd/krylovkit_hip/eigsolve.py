@@ -27,8 +27,10 @@ def eigsolve(A, x0, howmany: int = 1, which: str = "LM", alg: Optional[Lanczos] 
     A: SparseOperator or scipy.sparse matrix (must be symmetric).  Returns
     (values, vectors, ConvergenceInfo); vectors are numpy arrays unless return_device."""
     if isinstance(alg, Arnoldi):
-        raise TypeError("eigsolve with alg::Arnoldi (src/eigsolve/arnoldi.jl) is outside this package's scope (SURVEY section 2); "
-                        "the Arnoldi FACTORIZATION (expand!) is what linsolve(GMRES) / exponentiate use")
+        from .scope import OutOfScopeError
+        raise OutOfScopeError("eigsolve with alg::Arnoldi (src/eigsolve/arnoldi.jl) is outside this package's scope (SURVEY section 2); "
+                              "the Arnoldi FACTORIZATION (expand!) is what linsolve(GMRES) / exponentiate use.  Host transliteration with "
+                              "the tests: tests/hostmirror_extras.py::eigsolve_arnoldi")
     alg = alg or Lanczos(**kw)
     krylovdim, maxiter = alg.krylovdim, alg.maxiter
     if howmany > krylovdim:

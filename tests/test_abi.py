@@ -78,3 +78,18 @@ def test_host_dense_helpers(kk):
     assert list(dense.sortperm(np.array([-3.0, 1.0, 2.0]), "SR")) == [0, 1, 2]
     from krylovkit_hip.factorizations import packed_index
     assert [packed_index(i, j) for j in (1, 2, 3) for i in range(1, min(j + 1, 3) + 1)] == list(range(8))
+
+
+def test_out_of_scope_drivers_stay_importable_and_say_so():
+    """eigsolve(alg=Arnoldi), schursolve, bieigsolve, geneigsolve, BiArnoldi, GolubYe are outside SURVEY section 2's
+    scope; the names stay importable from the package (round-2 callers), a call raises OutOfScopeError (a NotImplementedError)
+    that names tests/hostmirror_extras.py -- and README / INTEGRATION state the reduction"""
+    import krylovkit_hip as kk
+    for call in (lambda: kk.schursolve(None, None), lambda: kk.bieigsolve(None, None, None), lambda: kk.geneigsolve(None, None),
+                 lambda: kk.eigsolve_arnoldi(None, None), lambda: kk.BiArnoldi(), lambda: kk.GolubYe(),
+                 lambda: kk.eigsolve(None, None, 1, "LM", kk.Arnoldi())):
+        with pytest.raises(kk.OutOfScopeError) as e:
+            call()
+        assert isinstance(e.value, NotImplementedError) and "hostmirror_extras" in str(e.value)
+    root = Path(__file__).resolve().parent.parent
+    assert "## Scope" in (root / "README.md").read_text() and "does not cover" in (root / "INTEGRATION.md").read_text()

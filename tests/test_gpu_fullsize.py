@@ -315,7 +315,12 @@ def test_config3_gmres_2M_parity_with_cpu_reference(kk, ctx):
     lib = cr.load()
     xc, ic, tc = cr.run_gmres(lib, A, b, None, 0.0, 1.0, 60, 2, tol, 3, nthreads=cr.usable_threads())
     tr = []
+    ctx.prof_reset(); ctx.prof_enable(1)
     x, info = kk.linsolve(kk.SparseOperator(A, ctx), b, None, kk.GMRES(kk.ModifiedGramSchmidt2(), 2, 60, tol), trace=tr)
+    ctx.prof_enable(0)
+    # which kernel this parity figure belongs to: the default route of a 2M-row MGS2 sweep is the persistent
+    # PANEL kernel with two vectors per grid reduction -- exact algebra, NOT the reference's association of the operations
+    assert ctx.prof_get("k_mgs_panel")[1] >= 2 * 59 and ctx.prof_get("k_project")[1] == 0 and ctx.prof_get("k_mgs_persist")[1] == 0
     assert (info.converged, info.numiter, info.numops) == (ic["converged"], ic["numiter"], ic["numops"])
     tg = np.array([t[2] for t in tr])
     assert len(tg) == len(tc) == 120
@@ -348,7 +353,11 @@ def test_config3b_gmres_2M_converges_with_equal_iteration_count(kk, ctx):
         xc, ic, tc = cr.run_gmres(lib, A, b, None, a0, 1.0, 60, 20, tol, orth_code, nthreads=cr.usable_threads())
         assert ic["converged"] == 1 and 3 <= ic["numiter"] <= 8, ic
         tr = []
+        ctx.prof_reset(); ctx.prof_enable(1)
         x, info = kk.linsolve(kk.SparseOperator(A, ctx), b, None, kk.GMRES(orth, 20, 60, tol), a0, 1.0, trace=tr)
+        ctx.prof_enable(0)
+        if orth_code == 3:    # MGS2: every sweep through k_mgs_panel (two vectors per reduction), none through the projection pair
+            assert ctx.prof_get("k_mgs_panel")[1] >= len(tc) - info.numiter and ctx.prof_get("k_project")[1] == 0
         assert (info.converged, info.numiter, info.numops) == (ic["converged"], ic["numiter"], ic["numops"]), (info, ic)
         tg = np.array([t[2] for t in tr])
         assert len(tg) == len(tc)

@@ -51,6 +51,22 @@ if "FETCH_SIZE" in res and "WRITE_SIZE" in res and "--no-traffic" not in sys.arg
             nf = sum(v["dispatches"] for v in f)
             nw = sum(v["dispatches"] for v in w)
             traffic[short] = round((2 * sum(v["sum"] for v in f) / nf + sum(v["sum"] for v in w) / nw) * 1024)
+    # average duration per launch of the same classes from the kernel-trace pass (rocprofv3 --kernel-trace --stats of the same
+    # command): what bench.py quotes for SHORT kernels, whose HIP-event brackets in the stream also contain the launch gaps
+    avg_us = {}
+    for f in find("trace", "*kernel_stats.csv"):
+        with open(f) as fh:
+            agg = defaultdict(lambda: [0, 0.0])
+            for row in csv.DictReader(fh):
+                nm = row["Name"]
+                nm = nm[5:] if nm.startswith("void ") else nm
+                for short in ("k_project", "k_unproject", "k_spmv_ell", "k_spmv_dia", "k_scal", "k_mgs_step", "k_mgs_persist", "k_unproj_proj", "k_mgs_panel"):
+                    if nm.startswith(short + "<") or nm.startswith(short + "("):
+                        agg[short][0] += int(row["Calls"]); agg[short][1] += float(row["TotalDurationNs"])
+            for k_, (n_, t_) in agg.items():
+                if n_:
+                    avg_us[k_] = round(t_ / n_ / 1e3, 3)
+    traffic["rocprof_avg_us"] = avg_us
     (dst / "traffic.json").write_text(json.dumps(traffic, indent=1))
     print("traffic.json:", traffic)
 
