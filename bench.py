@@ -391,6 +391,8 @@ def main():
     ap.add_argument("--config-steps", type=int, default=3, help="timed sweeps per entry of the `configs` block")
     ap.add_argument("--only-leg", default=None, choices=["lanczos_ell", "gmres", "block", "gkl"],
                     help="run nothing but the sweeps of ONE entry of the `configs` block (tools/profile_gpu.sh: counter passes per configuration)")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
+                    help="kk_ctx_set_option before the workload is built (A/B runs; every override is reported in the line as `options_overridden`)")
     ap.add_argument("--ny", type=int, default=NY, help="grid rows per GPU (default 2500 -> 10M rows per GPU)")
     ap.add_argument("--deadline", type=float, default=900.0, help="multi-rank runs only: abort if the whole run takes longer (seconds)")
     args = ap.parse_args()
@@ -442,6 +444,11 @@ def main():
             kd.NativeComm.single(ctx, force_collectives=True)
     MODE = {"strict": 0, "lowsync": 1, "auto": 2}
     ctx.set_option("mgs_mode", MODE[args.mgs_mode])
+    overridden = {}
+    for kv in args.opt:
+        k_, v_ = kv.split("=", 1)
+        ctx.set_option(k_, float(v_))
+        overridden[k_] = float(v_)
     sync = ctx.sync
     barrier = dist.barrier if world > 1 else (lambda: None)
 
@@ -966,6 +973,8 @@ def main():
             "algorithmic_equiv_frac_of_peak_per_gpu": round(alg_sweep * K / elapsed / 1e9 / (HBM_PEAK_GBPS * world), 4),
             "roofline": roofline,
         }
+        if overridden:
+            out["options_overridden"] = overridden      # NOT the library defaults: an A/B line, not a headline
         if ceiling and roofline and roofline.get("achieved"):
             # against what THIS box's memory system delivers to a pure read stream right now (the kernels read non-temporally)
             roofline["attainable_read_GBps"] = ceiling["nt_read_GBps"]

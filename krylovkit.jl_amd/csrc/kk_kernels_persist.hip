@@ -76,7 +76,8 @@ __device__ __forceinline__ void grid_publish(double acc, int step, unsigned ebas
     }
 }
 // second half: wave 0 sweeps the partials of all blocks
-template <int PT>
+template <int PT, bool XS /* compiled with the cross-rank level: the single-rank instantiation carries none of it (its live ranges cost the
+                           register-starved <40, 19, 9, 512> kernel 15 more spill slots and 1.5 % of the headline sweep) */>
 __device__ __forceinline__ bool grid_collect(int step, unsigned ebase, char* __restrict__ sync, int* __restrict__ err,
                                              double* sm, double* out, unsigned gstride /* bytes between the granules of two blocks: 128 = own line, 16 = packed */,
                                              const kk_xs_dev& xs /* row-sharded context: the sum over the ranks follows (kk_xsync.h) */, long long timeout_ticks) {
@@ -119,7 +120,7 @@ __device__ __forceinline__ bool grid_collect(int step, unsigned ebase, char* __r
             __builtin_amdgcn_s_sleep(1);
             if (wall_clock64() - t0 > timeout_ticks || errv) { good = 0; break; }
         }
-        if (xs.world > 0) {   // level 2: every block of this rank holds the same bits of the rank's partial -- now the sum over the ranks
+        if (XS && xs.world > 0) {   // level 2: every block of this rank holds the same bits of the rank's partial -- now the sum over the ranks
             double t2 = 0;
             if (good && !xs_allreduce(xs, (unsigned)step, 1, total, err, timeout_ticks, t2)) good = 0;
             total = t2;   // (lane 0: value 0)
@@ -225,7 +226,7 @@ __device__ __forceinline__ void persist_step(d2 (&wr)[NV], d2 (&qk)[NR > 0 ? NR 
 // Every step has the same shape -- pending axpy with (q_prev, s_prev), then the inner product with q_next -- so that the
 // work vector stays in ONE register set through the loop; a step with nothing pending (the first one without a carry)
 // runs the axpy with s_prev = 0 against a column of V.
-template <int NV, int NL, int NR, int PT, bool NTPREV>
+template <int NV, int NL, int NR, int PT, bool NTPREV, bool XS = false>
 __global__ __launch_bounds__(PT) void k_mgs_persist(const double* __restrict__ V, int64_t ld, int m, int nsweeps,
                                                     double* __restrict__ w, const double* __restrict__ carry_q,
                                                     const double* __restrict__ carry_s, double* __restrict__ out_s,
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(PT) void k_mgs_persist(const double* __restrict__ V
     __shared__ double sm[PT / 64];
     extern __shared__ d2 park[];   // NL * PT double2 (dynamic): the parked grid-rows of the current basis vector
     if (fault && blockIdx.x == 0) {   // test hook (option "persist_fault"): block 0 behaves like a block whose spin ran out
-        if (threadIdx.x == 0) { __hip_atomic_store(err, 1, RLX_AGENT); xs_abort(xs); }
+        if (threadIdx.x == 0) { __hip_atomic_store(err, 1, RLX_AGENT); if (XS) xs_abort(xs); }
         return;
     }
 #ifndef KK_PERSIST_B512
@@ -302,7 +303,7 @@ __global__ __launch_bounds__(PT) void k_mgs_persist(const double* __restrict__ V
         for (int u = 0; u < B; ++u) qpre[u] = bload(r2, voff, (unsigned)(u < NV ? u : 0) * sbytes, KK_PERSIST_NT_FIRST == 2 || (KK_PERSIST_NT_FIRST == 1 && u < NL + NR));
         __builtin_amdgcn_sched_barrier(0);
 #endif
-        if (!grid_collect<PT>(s, ebase, sync, err, sm, &total, gstride, xs, timeout_ticks)) return;   // timeout: w in HBM is untouched
+        if (!grid_collect<PT, XS>(s, ebase, sync, err, sm, &total, gstride, xs, timeout_ticks)) return;   // timeout: w in HBM is untouched
         if (blockIdx.x == 0 && threadIdx.x == 0) out_s[(s / m) * out_stride + (s % m)] = total;
         sp = total;
         qp = qn;
@@ -314,7 +315,7 @@ __global__ __launch_bounds__(PT) void k_mgs_persist(const double* __restrict__ V
         persist_step<NV, NL, NR, PT, B, NTPREV, true, true>(wr, qk, qpre, col_rsrc(qp, ld), col_rsrc(qp, ld), sp, sbytes, voff, lq, a0, a1);
         if (nrm_out3) {
             grid_publish<PT>(a0 + a1, nsteps, ebase, sync, sm, gstride);
-            if (!grid_collect<PT>(nsteps, ebase, sync, err, sm, &total, gstride, xs, timeout_ticks)) return;
+            if (!grid_collect<PT, XS>(nsteps, ebase, sync, err, sm, &total, gstride, xs, timeout_ticks)) return;
             // every block holds the same bits of |w|^2: the normalised commit below needs no second exchange
             const double rt = sqrt(total);
             inv = 1.0 / rt;
@@ -396,9 +397,15 @@ bool kk_mgs_persist_eligible(kk_ctx ctx, int64_t ld, int m, int nsweeps) {
 template <int NV, int PT>
 struct persist_park { static constexpr int full = (160 * 1024 - 256) / (PT * 16); static constexpr int n = NV < full ? NV : full; };
 
+template <int NV, int NL, int NR, int PT, bool NT, bool XS>
+static int launch_persist_inst2(kk_ctx ctx, void** args);
 template <int NV, int NL, int NR, int PT, bool NT>
-static int launch_persist_inst(kk_ctx ctx, void** args) {
-    const void* fn = (const void*)k_mgs_persist<NV, NL, NR, PT, NT>;
+static int launch_persist_inst(kk_ctx ctx, void** args, bool xs_on) {
+    return xs_on ? launch_persist_inst2<NV, NL, NR, PT, NT, true>(ctx, args) : launch_persist_inst2<NV, NL, NR, PT, NT, false>(ctx, args);
+}
+template <int NV, int NL, int NR, int PT, bool NT, bool XS>
+static int launch_persist_inst2(kk_ctx ctx, void** args) {
+    const void* fn = (const void*)k_mgs_persist<NV, NL, NR, PT, NT, XS>;
     const size_t dyn = (size_t)NL * PT * sizeof(double) * 2;
     // the opt-in to more than 64 KB of dynamic LDS is a per-DEVICE attribute of the function: one call per instantiation and
     // device (a process may drive contexts on several GPUs), made with the context's device current
@@ -419,14 +426,14 @@ static int launch_persist_inst(kk_ctx ctx, void** args) {
 #endif
 
 template <int NV, int PT>
-static int launch_persist(kk_ctx ctx, void** args, bool ntprev) {
+static int launch_persist(kk_ctx ctx, void** args, bool ntprev, bool xs_on) {
     constexpr int NL = persist_park<NV, PT>::n;
     // (256-thread blocks -- one wave per SIMD with the whole 512-register file -- were tried: w then takes 320 registers per
     // lane and 39 + 12 of 77 grid-rows can be parked, no more than the 27 of 39 here: the on-chip capacity is what it is)
     constexpr int NR = (PT == 512 && NV - NL > 0) ? (NV - NL < KK_PERSIST_NR ? NV - NL : KK_PERSIST_NR) : 0;
-    if (ctx->persist_lds == 2) return ntprev ? launch_persist_inst<NV, NL, NR, PT, true>(ctx, args) : launch_persist_inst<NV, NL, NR, PT, false>(ctx, args);
-    if (ctx->persist_lds) return ntprev ? launch_persist_inst<NV, NL, 0, PT, true>(ctx, args) : launch_persist_inst<NV, NL, 0, PT, false>(ctx, args);
-    return ntprev ? launch_persist_inst<NV, 0, 0, PT, true>(ctx, args) : launch_persist_inst<NV, 0, 0, PT, false>(ctx, args);
+    if (ctx->persist_lds == 2) return ntprev ? launch_persist_inst<NV, NL, NR, PT, true>(ctx, args, xs_on) : launch_persist_inst<NV, NL, NR, PT, false>(ctx, args, xs_on);
+    if (ctx->persist_lds) return ntprev ? launch_persist_inst<NV, NL, 0, PT, true>(ctx, args, xs_on) : launch_persist_inst<NV, NL, 0, PT, false>(ctx, args, xs_on);
+    return ntprev ? launch_persist_inst<NV, 0, 0, PT, true>(ctx, args, xs_on) : launch_persist_inst<NV, 0, 0, PT, false>(ctx, args, xs_on);
 }
 
 // `normalize`: store w / |w| instead of w (needs nrm_out3; a zero norm leaves w unscaled -- kk_persist_norm_applies is the
@@ -463,17 +470,17 @@ int kk_launch_mgs_persist(kk_ctx ctx, const double* V, int64_t ld, int m, int ns
     const bool nt = ctx->persist_nt != 0;
     kk_prof_scope ps(ctx, "k_mgs_persist");
     if (pt == 1024) {
-        if (nv <= 4) return launch_persist<4, 1024>(ctx, args, nt);
-        if (nv <= 8) return launch_persist<8, 1024>(ctx, args, nt);
-        if (nv <= 12) return launch_persist<12, 1024>(ctx, args, nt);
-        if (nv <= 16) return launch_persist<16, 1024>(ctx, args, nt);
-        if (nv <= 20) return launch_persist<20, 1024>(ctx, args, nt);
+        if (nv <= 4) return launch_persist<4, 1024>(ctx, args, nt, xs.world > 0);
+        if (nv <= 8) return launch_persist<8, 1024>(ctx, args, nt, xs.world > 0);
+        if (nv <= 12) return launch_persist<12, 1024>(ctx, args, nt, xs.world > 0);
+        if (nv <= 16) return launch_persist<16, 1024>(ctx, args, nt, xs.world > 0);
+        if (nv <= 20) return launch_persist<20, 1024>(ctx, args, nt, xs.world > 0);
     } else {
-        if (nv <= 8) return launch_persist<8, 512>(ctx, args, nt);
-        if (nv <= 16) return launch_persist<16, 512>(ctx, args, nt);
-        if (nv <= 24) return launch_persist<24, 512>(ctx, args, nt);
-        if (nv <= 32) return launch_persist<32, 512>(ctx, args, nt);
-        if (nv <= 40) return launch_persist<40, 512>(ctx, args, nt);
+        if (nv <= 8) return launch_persist<8, 512>(ctx, args, nt, xs.world > 0);
+        if (nv <= 16) return launch_persist<16, 512>(ctx, args, nt, xs.world > 0);
+        if (nv <= 24) return launch_persist<24, 512>(ctx, args, nt, xs.world > 0);
+        if (nv <= 32) return launch_persist<32, 512>(ctx, args, nt, xs.world > 0);
+        if (nv <= 40) return launch_persist<40, 512>(ctx, args, nt, xs.world > 0);
     }
     kk_set_error("kk_launch_mgs_persist: vector of %lld rows does not fit the register file", (long long)ld);
     return KK_ERR_UNSUPPORTED;
