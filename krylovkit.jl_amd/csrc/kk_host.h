@@ -45,8 +45,21 @@ static inline void gram_touch(kk_basis b, int col) {
 // own) and notes (column, beta) on the slab.  The next expand! of the same factorization takes the column as its new basis
 // vector; anything else that looks at the slab first gets r = beta * column back (residual(F), shrink!, restarts).
 int blk_commit_flush(kk_basis b);   // kk_block.hip: W = T R1 into the residual area of a pending block commit
+// Work enqueued AHEAD for one factorization (the speculative apply, a whole step) leaves state in the context's shared scalar
+// workspace that the owner's NEXT call relies on: alpha0 of the apply, |w| / 1 / |w| of the step in flight.  Any entry point
+// that is handed ANOTHER slab of the same context may launch kernels that write those scalars (a second factorization stepping
+// in turns, an un-fused FunctionOperator run, a solver): the owner's run-ahead is dropped -- its next call redoes the apply and the
+// step from the slab, which is intact (round 5: two interleaved Lanczos runs on one context returned the other run's beta).
+// (the owner is only ever COMPARED, never dereferenced -- its slab may have been freed: a generation counter of the context carries the
+//  verdict, the owner recorded the generation it speculated in and finds it moved on)
+static inline void ctx_foreign_touch(kk_basis b) {
+    if (!b) return;
+    kk_ctx c = b->ctx;
+    if (c->spec_owner != b) ++c->foreign_gen;
+}
 static inline int norm_flush(kk_basis b) {
     if (!b) return KK_OK;
+    ctx_foreign_touch(b);
     if (b->tc_valid) KK_TRY(blk_commit_flush(b));
     if (b->norm_col < 0) return KK_OK;
     const int col = b->norm_col;
@@ -59,6 +72,7 @@ static inline int norm_flush(kk_basis b) {
 // [0, krylovdim) and THEN asks for scale!!(r, 1 / beta) (eigsolve/lanczos.jl:109-111) -- the transform must leave the commit alone
 static inline int norm_flush_range(kk_basis b, int c0, int m) {
     if (!b) return KK_OK;
+    ctx_foreign_touch(b);
     if (b->tc_valid) KK_TRY(blk_commit_flush(b));
     if (b->norm_col >= c0 && b->norm_col < c0 + m) return norm_flush(b);
     return KK_OK;
@@ -100,7 +114,7 @@ int persist_check_at(kk_ctx c, int slot, double token, bool* timed_out);   // th
 int gram_ensure(kk_basis b, int upto /* exclusive */);
 int gram_device(kk_basis b);   // device mirror of the host Gram rows (created on first use)
 int lowsync_project_dev(kk_basis b, int m, const double* w, const double* pre_vec, const double* pre_a,
-                        const double* a0_dev, int64_t ws_coef, int64_t ws_s, bool* rode);
+                        const double* a0_dev, int64_t ws_coef, int64_t ws_s, bool* rode, int rows_in_stream = 0);
 void lowsync_commit_row(kk_basis b, int m, const double* g_host);
 
 // ---- Krylov steps (kk_krylov.hip)

@@ -216,6 +216,7 @@ struct kk_ctx_s {
     int fuse_passes = 1;         // fuse unproject(pass i) with project(pass i+1)
     int speculate = 1;           // enqueue the next expand's SpMV before syncing the host
     kk_basis spec_owner = nullptr;   // basis whose speculative result currently sits in SC_SPECA / its next column
+    uint64_t foreign_gen = 0;        // bumped by every entry point that is handed a slab other than spec_owner's (ctx_foreign_touch)
     struct { bool active = false; kk_op op = nullptr; kk_basis b = nullptr; int c0 = 0, k_next = 0, la_nsweeps = 0; } spec_req;
     hipEvent_t t0 = nullptr, t1 = nullptr;
     hipEvent_t ev_fetch2 = nullptr; // read-backs of a run-ahead BiCGStab half
@@ -244,6 +245,7 @@ struct kk_basis_s {
     double* d_gdiag = nullptr; // device only: |b_i|^2 - 1 where a block step measured it (0 elsewhere), rows as d_gram
     // speculative next-step SpMV (hides the host round trip between two expand! calls)
     bool spec_valid = false;
+    uint64_t spec_gen = 0;       // ctx->foreign_gen when the speculative apply (and what was enqueued behind it) went out
     const void* spec_op = nullptr;
     int spec_c0 = 0, spec_k = 0, spec_dot_mode = 0;
     const double* spec_dot_ptr = nullptr;   // device slot that received the speculative apply's inner product
@@ -252,6 +254,9 @@ struct kk_basis_s {
     bool la_valid = false;
     int la_k = 0, la_slot = 0, la_nsweeps = 0;
     double la_token = 0;
+    int la_kind = 0;          // 0: persistent sweep (la_token), 1: projection-based Lanczos step (CGS2 / low-sync MGS2: la_orth, la_rode)
+    int la_orth = 0;
+    bool la_rode = false;
     // residual column left NORMALISED by a fused expand! (persistent kernel, w / |w| written at commit): logically the column
     // still holds r = norm_beta * stored; the next expand! of the same factorization takes it as its new basis vector without
     // the scale pass, every other access multiplies it back first (norm_flush)

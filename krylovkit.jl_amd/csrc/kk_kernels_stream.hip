@@ -82,7 +82,10 @@ __global__ __launch_bounds__(KK_TPB) void k_axpby(double* __restrict__ y, const 
 
 __global__ __launch_bounds__(KK_TPB) void k_scal(double* __restrict__ x, int64_t ld, int64_t rpb, double a,
                                                  const double* __restrict__ a_dev, int rsqrt_mode) {
-    if (a_dev) a = rsqrt_mode ? 1.0 / sqrt(*a_dev) : *a_dev;
+    if (a_dev) a = rsqrt_mode == 1 ? 1.0 / sqrt(*a_dev) : *a_dev;
+    // mode 2: *a_dev is 1 / |w| of a step whose norm the host has not seen yet (run-ahead): a zero or overflowing norm leaves the
+    // vector as it is -- the test kk_persist_norm_applies makes on the host's copy when it arrives
+    if (rsqrt_mode == 2 && !(a > 0.0 && a <= 1.79769313486231570815e308)) a = 1.0;
     const int64_t r0 = (int64_t)blockIdx.x * rpb, r1 = imin(r0 + rpb, ld);
     for (int64_t r = r0 + threadIdx.x * 2; r < r1; r += KK_SUB) {
         d2 v = ld2(x + r);

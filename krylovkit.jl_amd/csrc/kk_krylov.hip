@@ -11,6 +11,7 @@ int check_square_op(kk_op op, kk_basis b) {
     const int64_t in = op->A.n_ghost > 0 ? op->A.n_local : op->ncols;
     KK_CHECK(op->nrows == b->n && in == b->n, KK_ERR_DIM, "operator is %lldx%lld but vectors have %lld rows",
              (long long)op->nrows, (long long)op->ncols, (long long)b->n);
+    ctx_foreign_touch(b);   // (a step of ANOTHER factorization of this context: that one's run-ahead state in the shared scalars is void)
     return KK_OK;
 }
 
@@ -107,13 +108,14 @@ static int speculate_next(kk_op op, kk_basis b, int c0, int k_next, int dot_mode
     b->spec_valid = true; b->spec_op = op; b->spec_c0 = c0; b->spec_k = k_next; b->spec_dot_mode = dot_mode;
     b->spec_beta = beta_host;
     c->spec_owner = b;
+    b->spec_gen = c->foreign_gen;
     return KK_OK;
 }
 // true if the previous expand on this basis already enqueued exactly this step's SpMV; moves the
 // speculative alpha into the regular slot
 static int spec_take(kk_op op, kk_basis b, int c0, int k, int dot_mode, double beta_old, double* a0_slot, bool* hit) {
     kk_ctx c = b->ctx;
-    *hit = b->spec_valid && c->spec_owner == b && b->spec_op == op && b->spec_c0 == c0 && b->spec_k == k &&
+    *hit = b->spec_valid && c->spec_owner == b && b->spec_gen == c->foreign_gen && b->spec_op == op && b->spec_c0 == c0 && b->spec_k == k &&
            b->spec_dot_mode == dot_mode && b->spec_beta == beta_old;
     if (*hit && dot_mode && b->spec_dot_ptr != a0_slot)
         KK_HIP(hipMemcpyAsync(a0_slot, b->spec_dot_ptr, sizeof(double), hipMemcpyDeviceToDevice, c->stream));
@@ -185,6 +187,58 @@ static int la_enqueue(kk_op op, kk_basis b, int c0, int j, int nsweeps, bool lan
     return KK_OK;
 }
 
+// The projection-based Lanczos step (CGS2, or MGS2 in its low-synchronisation form; lanczos.jl:318-322 / 329-336) for basis size
+// m = k + 1, enqueued WITHOUT any host data: w = col(c0 + k + 1) holds A v - beta v_prev (the apply is in the stream), alpha0 sits in
+// SC_ALPHA0, v = col(c0 + k) is normalised.  Coefficients, [Gram row,] scalars are fetched into pinned slot `slot`.
+static int lanczos_proj_enqueue(kk_basis b, int c0, int k, kk_orth_t orth, int slot, int rows_in_stream, bool* rode) {
+    kk_ctx c = b->ctx;
+    const int m = k + 1;
+    const int64_t ld = b->ld;
+    double* V = b->col(c0);
+    double* v = b->col(c0 + k);
+    double* w = b->col(c0 + k + 1);
+    const double* a0_dev = c->ws + WS_SCAL + SC_ALPHA0;
+    *rode = false;
+    if (orth == KK_CGS2) {
+        // one projection pass with "w -= alpha0 v" folded in (read V twice in total):
+        //   s = V'(w - alpha0 v) ; w <- w - V (s + alpha0 e_m) ; beta = |w|
+        KK_TRY(kk_launch_project(c, V, ld, m, w, v, a0_dev, nullptr, WSP(c, WS_S), WSP(c, WS_G)));
+        KK_TRY(kk_launch_unproject(c, V, ld, m, w, w, nullptr, c->ws + WS_S, -1.0, 1.0, m - 1, a0_dev, SCP(c, SC_NRM2)));
+        // ONE read-back for coefficients and scalars: a D2H copy costs ~4.5 us on the stream whatever its size, and the
+        // workspace areas in between travel along for free (WS_S .. WS_SCAL+4 = 10 KB)
+        return ws_fetch_async(c, WS_S, WS_SCAL + 4 - WS_S, slot);
+    }
+    // low-sync MGS2: project (Gram row riding along) -> triangular solve ON THE DEVICE (alpha0 folded into the last
+    // coefficient) -> update
+    KK_TRY(lowsync_project_dev(b, m, w, v, a0_dev, a0_dev, WS_X, WS_Y, rode, rows_in_stream));
+    KK_TRY(kk_launch_unproject(c, V, ld, m, w, w, nullptr, WSP(c, WS_X), -1.0, 1.0, -1, nullptr, SCP(c, SC_NRM2)));
+    // ONE read-back (Gram row, last MGS coefficient, scalars): WS_G .. WS_SCAL+4 = 8 KB
+    if (*rode) return ws_fetch_async(c, WS_G, WS_SCAL + 4 - WS_G, slot);
+    return ws_fetch_async(c, WS_Y + m - 1, WS_SCAL + 4 - (WS_Y + m - 1), slot);
+}
+// Run-ahead of that step (VERDICT r4 item 5 for the route the SHORT vectors take: below ~1.4 M rows the auto mode runs the projection
+// pair, and an expand! there was bound by the host round trip between two calls): once the speculative apply of step j is in the
+// stream, the scale of its new basis vector (by the device's 1 / beta, guarded like the persistent kernels' commit), its projection
+// step and its read-back are enqueued as well, BEFORE the host waits for the scalars of step j - 1.  Same kernels, operands and
+// order as call by call: bit-identical.  The column the scale touched is noted as normalised (norm_col) once beta is known, so any
+// other access settles it exactly as after a persistent sweep.
+static int la_enqueue_proj(kk_op op, kk_basis b, int c0, int j, kk_orth_t orth) {
+    kk_ctx c = b->ctx;
+    b->la_valid = false;
+    const int m = j + 1;
+    if (!c->lookahead || !c->fold_scale || !b->spec_valid || kk_sharded(c)) return KK_OK;
+    if (m > KK_MAX_M || c0 + j + 3 > b->cap || b->spec_dot_ptr != SCP(c, SC_ALPHA0)) return KK_OK;
+    if (orth == KK_MGS2 && c0 != 0) return KK_OK;
+    const int slot = 2 + (j & 1);
+    // v_j = r / beta in place, beta still on the device only
+    KK_TRY(kk_launch_scal(c, b->col(c0 + j), b->ld, 0.0, SCP(c, SC_INVNRM), 2));
+    bool rode = false;
+    KK_TRY(lanczos_proj_enqueue(b, c0, j, orth, slot, orth == KK_MGS2 ? j : 0, &rode));   // (Gram row j - 1 is being produced by the step in front)
+    KK_HIP(hipEventRecord(c->ev_la[slot & 1], c->stream));
+    b->la_valid = true; b->la_k = j; b->la_slot = slot; b->la_nsweeps = 0; b->la_kind = 1; b->la_orth = (int)orth; b->la_rode = rode;
+    return KK_OK;
+}
+
 KK_API int kk_lanczos_expand(kk_op op, kk_basis b, int c0, int k, kk_orth_t orth, double eta, double beta_old,
                                  double* alpha, double* beta, int* npasses) {
     KK_TRY(check_square_op(op, b));
@@ -216,13 +270,18 @@ KK_API int kk_lanczos_expand(kk_op op, kk_basis b, int c0, int k, kk_orth_t orth
     }                                                   // residual of the factorization a restart shrank) stays as it is until somebody looks
     // the previous call may have enqueued this WHOLE step already (apply, sweep and read-back: la_enqueue below)
     const bool strict_branch = orth == KK_MGS2 && !wide && !sh_fused && !(lowsync && c0 == 0);
-    const bool la_hit = b->la_valid && b->spec_valid && c->spec_owner == b && b->spec_op == op && b->spec_c0 == c0 && b->spec_k == k &&
-                        b->la_k == k && b->la_nsweeps == 1 && b->spec_beta == beta_old && strict_branch && v_ready;
+    const bool proj_branch = !wide && !sh_fused && (orth == KK_CGS2 || (orth == KK_MGS2 && lowsync && c0 == 0));
+    const bool la_same = b->la_valid && b->spec_valid && c->spec_owner == b && b->spec_gen == c->foreign_gen && b->spec_op == op && b->spec_c0 == c0 && b->spec_k == k &&
+                         b->la_k == k && b->spec_beta == beta_old && v_ready;
+    const bool la_hit = la_same && b->la_kind == 0 && b->la_nsweeps == 1 && strict_branch;
+    const bool la_proj_hit = la_same && b->la_kind == 1 && b->la_orth == (int)orth && proj_branch && !kk_sharded(c);
     const int la_slot = b->la_slot;
     const double la_token = b->la_token;
-    if (b->la_valid && !la_hit) b->spec_valid = false;   // a sweep enqueued ahead has consumed the speculative apply's output column: nothing to take over
-    bool hit = la_hit;
-    if (!la_hit) KK_TRY(spec_take(op, b, c0, k, cgs_order ? 1 : 2, beta_old, a0_slot, &hit));
+    if (b->la_valid && !la_hit && !la_proj_hit) b->spec_valid = false;   // a sweep enqueued ahead has consumed the speculative apply's output column: nothing to take over
+    const int la_proj_slot = b->la_slot;
+    const bool la_proj_rode = b->la_rode;
+    bool hit = la_hit || la_proj_hit;
+    if (!hit) KK_TRY(spec_take(op, b, c0, k, cgs_order ? 1 : 2, beta_old, a0_slot, &hit));
     gram_touch(b, c0 + k);
     int passes = 0;
     c->persist_norm_done = la_hit;   // (a step enqueued ahead always asked for the normalised commit)
@@ -302,36 +361,34 @@ KK_API int kk_lanczos_expand(kk_op op, kk_basis b, int c0, int k, kk_orth_t orth
         if (ls) lowsync_commit_row(b, m, pin(c, WS_SHBUF + 1 + m, 0));
         passes = 1;
     } else if (orth == KK_CGS2 || (orth == KK_MGS2 && lowsync && c0 == 0)) {
-        // one projection pass with "w -= alpha0 v" folded in (read V twice in total):
-        //   s = V'(w - alpha0 v) ; w <- w - V (s + alpha0 e_m) ; beta = |w|     lanczos.jl:318-322 / 329-336
-        if (orth == KK_CGS2) {
-            KK_TRY(kk_launch_project(c, V, ld, m, w, v, a0_dev, nullptr, WSP(c, WS_S), WSP(c, WS_G)));
-            KK_TRY(kk_launch_unproject(c, V, ld, m, w, w, nullptr, c->ws + WS_S, -1.0, 1.0, m - 1, a0_dev,
-                                       SCP(c, SC_NRM2)));
-            // ONE read-back for coefficients and scalars: a D2H copy costs ~4.5 us on the stream whatever its size, and the
-            // workspace areas in between travel along for free (WS_S .. WS_SCAL+4 = 10 KB)
-            KK_TRY(ws_fetch_async(c, WS_S, WS_SCAL + 4 - WS_S, 0));
-            KK_TRY(fetch_mark(c));
-            KK_TRY(speculate_next(op, b, c0, k + 1, 1, true, 0.0));
-            KK_TRY(fetch_wait(c));
-            a = pin(c, WS_SCAL + SC_ALPHA0)[0] + pin(c, WS_S)[m - 1];
+        // projection-based step (lanczos_proj_enqueue): s = V'(w - alpha0 v) [exact triangular solve for MGS2], w <- w - V (s + alpha0 e_m),
+        // beta = |w|; one host synchronisation.  With the run-ahead (la_enqueue_proj) this call finds its step in the stream already.
+        const int dm = cgs_order ? 1 : 2;
+        int slot = 0;
+        bool rode = false;
+        if (la_proj_hit) {
+            slot = la_proj_slot;
+            rode = la_proj_rode;
         } else {
-            // low-sync MGS2: project (Gram row riding along) -> triangular solve ON THE DEVICE (alpha0 folded
-            // into the last coefficient) -> update; one host synchronisation, as for CGS2
-            bool rode = false;
-            KK_TRY(lowsync_project_dev(b, m, w, v, a0_dev, a0_dev, WS_X, WS_Y, &rode));
-            KK_TRY(kk_launch_unproject(c, V, ld, m, w, w, nullptr, WSP(c, WS_X), -1.0, 1.0, -1, nullptr, SCP(c, SC_NRM2)));
-            // ONE read-back (Gram row, last MGS coefficient, scalars): WS_G .. WS_SCAL+4 = 8 KB, see above
-            if (rode) KK_TRY(ws_fetch_async(c, WS_G, WS_SCAL + 4 - WS_G, 0));
-            else KK_TRY(ws_fetch_async(c, WS_Y + m - 1, WS_SCAL + 4 - (WS_Y + m - 1), 0));
+            KK_TRY(lanczos_proj_enqueue(b, c0, k, orth, 0, 0, &rode));
             KK_TRY(fetch_mark(c));
-            KK_TRY(speculate_next(op, b, c0, k + 1, 2, true, 0.0));
-            KK_TRY(fetch_wait(c));
-            a = pin(c, WS_SCAL + SC_ALPHA0)[0] + pin(c, WS_Y)[m - 1];
-            if (rode) lowsync_commit_row(b, m, pin(c, WS_G, 0));
         }
-        bt = pin(c, WS_SCAL + SC_NRM)[0];
+        // the NEXT step: its apply (|w| and 1 / |w| are on the device; alpha0 straight to its slot: every read-back of this step is in the
+        // stream) and, where the run-ahead applies, its scale + projection step + read-back
+        KK_TRY(speculate_next(op, b, c0, k + 1, dm, true, 0.0, kk_sharded(c) ? nullptr : SCP(c, SC_ALPHA0)));
+        KK_TRY(la_enqueue_proj(op, b, c0, k + 1, orth));
+        if (la_proj_hit) KK_HIP(hipEventSynchronize(c->ev_la[slot & 1]));
+        else KK_TRY(fetch_wait(c));
+        const int64_t off_last = orth == KK_CGS2 ? WS_S : WS_Y;
+        a = pin(c, WS_SCAL + SC_ALPHA0, slot)[0] + pin(c, off_last, slot)[m - 1];
+        if (rode) lowsync_commit_row(b, m, pin(c, WS_G, slot));
+        bt = pin(c, WS_SCAL + SC_NRM, slot)[0];
         passes = 1;
+        // the step enqueued ahead has scaled the new residual column in place: logically it still holds r = bt * column
+        if (b->la_valid && b->la_kind == 1) {
+            if (kk_persist_norm_applies(bt)) { b->norm_col = c0 + k + 1; b->norm_beta = bt; }
+            else { b->la_valid = false; b->spec_valid = false; }   // (zero / overflowing norm: the kernel left the column alone; the step behind it is void)
+        }
     } else if (orth == KK_MGS2) {
         // strict: w -= alpha0 v fused with the first dot of the sweep   lanczos.jl:329-334
         const int64_t offs[1] = {WS_S};
@@ -407,7 +464,7 @@ KK_API int kk_arnoldi_expand(kk_op op, kk_basis b, int c0, int k, kk_orth_t orth
     const int la_sweeps = orth == KK_MGS ? 1 : (orth == KK_MGS2 ? 2 : 0);
     const bool strict_route = la_sweeps > 0 && m <= KK_MAX_M && !kk_mgs_lowsync(c, b->ld, m) && (!kk_sharded(c) || kk_xs_on(c));
     // the previous call may have enqueued this WHOLE step already (apply, sweeps and read-back: la_enqueue)
-    const bool la_hit = b->la_valid && b->spec_valid && c->spec_owner == b && b->spec_op == op && b->spec_c0 == c0 && b->spec_k == k &&
+    const bool la_hit = b->la_valid && b->spec_valid && c->spec_owner == b && b->spec_gen == c->foreign_gen && b->spec_op == op && b->spec_c0 == c0 && b->spec_k == k &&
                         b->spec_dot_mode == 0 && b->la_k == k && b->la_nsweeps == la_sweeps && b->spec_beta == beta_old && strict_route && v_ready;
     const int la_slot = b->la_slot;
     const double la_token = b->la_token;

@@ -353,12 +353,15 @@ static int lowsync_project(kk_basis b, int c0, int m, const double* w, const dou
 // ws[ws_coef..], plain s in ws[ws_s..].  No host synchronisation.  If *rode, the caller must fetch
 // ws[WS_G .. WS_G+m-1) with its final read-back and hand it to lowsync_commit_row().
 int lowsync_project_dev(kk_basis b, int m, const double* w, const double* pre_vec, const double* pre_a,
-                               const double* a0_dev, int64_t ws_coef, int64_t ws_s, bool* rode) {
+                               const double* a0_dev, int64_t ws_coef, int64_t ws_s, bool* rode, int rows_in_stream) {
     kk_ctx c = b->ctx;
     const int newest = m - 1;
-    if (b->gram_rows < newest) KK_TRY(gram_ensure(b, newest));  // only after the basis was transformed (restart)
+    // rows_in_stream (run-ahead of a whole step): Gram rows below this index are valid ON THE DEVICE -- the solve kernels of the steps in
+    // the stream store them -- although the host mirror has not received them yet; they arrive with those steps' read-backs
+    const int have = std::max(b->gram_rows, rows_in_stream);
+    if (have < newest) KK_TRY(gram_ensure(b, newest));  // only after the basis was transformed (restart)
     if (b->gram_rows < 1) b->gram_rows = 1;
-    const bool ride = (b->gram_rows == newest && newest > 0);
+    const bool ride = (std::max(b->gram_rows, rows_in_stream) == newest && newest > 0);
     KK_TRY(gram_device(b));
     KK_TRY(kk_launch_project(c, b->col(0), b->ld, m, w, pre_vec, pre_a, ride ? b->col(newest) : nullptr, WSP(c, WS_S),
                              WSP(c, WS_G)));

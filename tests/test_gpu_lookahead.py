@@ -198,3 +198,90 @@ def test_timeout_of_the_first_launch_of_a_run_ahead_chain(kk, ko, lctx, case, fa
         assert abs(f.normres - of.normres) < 1e-10 * abs(of.normres)
     V = f.V.to_numpy()
     assert np.max(np.abs(V.T @ V - np.eye(V.shape[1]))) < 1e-12
+
+
+@pytest.mark.parametrize("route", ["cgs2", "mgs2_lowsync"])
+def test_projection_route_run_ahead_is_bitwise_the_call_by_call_route(kk, ko, route):
+    """la_enqueue_proj (round 5): the projection-based Lanczos step -- CGS2, and MGS2 in its low-synchronisation form, the routes of
+    vectors too short for the persistent kernels -- enqueued one call ahead: scale of the new basis vector by the device's 1 / beta,
+    projection (+ triangular solve), update, read-back.  Bit-identical to lookahead = 0, the oracle's trajectory, interruptions
+    (residual read, shrink!) drop the step enqueued ahead and settle the column it had scaled."""
+    c = kk.Context(0)
+    try:
+        c.set_option("mgs_mode", 1)
+        dev, ref = (kk.ClassicalGramSchmidt2(), ko.CGS2) if route == "cgs2" else (kk.ModifiedGramSchmidt2(), ko.MGS2)
+        nx, ny, steps = 52, 40, 28
+        n = nx * ny
+        A = ko.laplacian_2d(nx, ny, shift_diag=10 * np.linspace(0, 1, n) ** 2)
+        x0 = np.random.default_rng(3).random(n)
+        out = {}
+        for interrupted in (False, True):
+            for la in (1, 0):
+                c.set_option("lookahead", la)
+                c.prof_reset(); c.prof_enable(1)
+                it = kk.LanczosIterator(kk.SparseOperator(A, c, symmetric=True), x0, dev, capacity=steps + 3)
+                f = kk.initialize(it)
+                r9 = None
+                for i in range(steps):
+                    f = kk.expand_(it, f)
+                    if interrupted and i == 9:
+                        r9 = f.r.get().copy()          # settles the scaled column, drops the step enqueued ahead
+                    if i == 17:
+                        f = kk.shrink_(f, 12)
+                c.prof_enable(0)
+                out[(interrupted, la)] = (np.array(f.alphas), np.array(f.betas), f.V.to_numpy().copy(), r9, c.prof_get("k_scal")[1])
+        c.set_option("lookahead", 1)
+        # undisturbed: every bit equal (same kernels, operands and order), and the scale passes are the run-ahead's own launches
+        assert np.array_equal(out[(False, 1)][0], out[(False, 0)][0]) and np.array_equal(out[(False, 1)][1], out[(False, 0)][1])
+        assert np.array_equal(out[(False, 1)][2], out[(False, 0)][2])
+        # reading r at step 9 un-scales and re-scales the column on the run-ahead route only: agreement to rounding from there on
+        a1, a0 = out[(True, 1)], out[(True, 0)]
+        assert np.max(np.abs(a1[0] - a0[0]) / np.abs(a0[0])) < 1e-13 and np.max(np.abs(a1[1] - a0[1]) / np.abs(a0[1])) < 1e-13
+        assert np.max(np.abs(a1[2] - a0[2])) < 1e-12 and np.max(np.abs(a1[3] - a0[3])) < 1e-13 * np.linalg.norm(a0[3])
+        out = {1: out[(True, 1)], 0: out[(True, 0)]}
+        oit = ko.LanczosIterator(A, x0.copy(), ref)
+        of = ko.lanczos_initialize(oit)
+        for i in range(steps):
+            of = ko.lanczos_expand(oit, of)
+            if i == 17:
+                of = ko.lanczos_shrink(of, 12)
+        assert np.max(np.abs(out[1][0] - of.alphas) / np.abs(of.alphas)) < 1e-10 and np.max(np.abs(out[1][1] - of.betas) / np.abs(of.betas)) < 1e-10
+        V1 = out[1][2]
+        assert np.max(np.abs(V1.T @ V1 - np.eye(V1.shape[1]))) < 1e-12
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("route", ["persist", "panel", "mgs2_lowsync", "cgs2"])
+def test_two_factorizations_taking_turns_on_one_context(kk, ko, route):
+    """Work enqueued ahead for one factorization leaves state in the context's SHARED scalar workspace (alpha0 of the speculative apply,
+    |w| and 1 / |w| of the step in flight) that its next call relies on; a second factorization stepping in turns on the same context
+    overwrites it.  The library notices (any entry point handed another slab bumps the context's generation, csrc/kk_host.h::
+    ctx_foreign_touch) and each call redoes its apply and step from the slab: both trajectories must be the oracle's.  (Found in
+    round 5 by tests/test_gpu_parity.py::test_function_operator once the projection route ran ahead: the interleaved run returned the
+    other run's beta.)"""
+    c = kk.Context(0)
+    try:
+        c.set_option("mgs_mode", {"persist": 0, "panel": 0, "mgs2_lowsync": 1, "cgs2": 1}[route])
+        c.set_option("mgs_panel", 1 if route == "panel" else 0)
+        dev, ref = (kk.ClassicalGramSchmidt2(), ko.CGS2) if route == "cgs2" else (kk.ModifiedGramSchmidt2(), ko.MGS2)
+        nx, ny, steps = 44, 36, 18
+        n = nx * ny
+        A = ko.laplacian_2d(nx, ny, shift_diag=10 * np.linspace(0, 1, n) ** 2)
+        op = kk.SparseOperator(A, c, symmetric=True)
+        xs = [np.random.default_rng(s).random(n) for s in (3, 4)]
+        its = [kk.LanczosIterator(op, x, dev, capacity=steps + 3) for x in xs]
+        fs = [kk.initialize(it) for it in its]
+        for _ in range(steps):
+            fs = [kk.expand_(it, f) for it, f in zip(its, fs)]
+        for x, f in zip(xs, fs):
+            oit = ko.LanczosIterator(A, x.copy(), ref)
+            of = ko.lanczos_initialize(oit)
+            for _ in range(steps):
+                of = ko.lanczos_expand(oit, of)
+            assert np.max(np.abs(np.array(f.alphas) - of.alphas) / np.abs(of.alphas)) < 1e-10
+            assert np.max(np.abs(np.array(f.betas) - of.betas) / np.abs(of.betas)) < 1e-10
+            V = f.V.to_numpy()
+            assert np.max(np.abs(V.T @ V - np.eye(V.shape[1]))) < 1e-12
+    finally:
+        c.close()
