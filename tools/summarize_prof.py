@@ -15,8 +15,11 @@ def find(sub, pat):
 
 
 # 1. kernel stats
-for f in find("trace", "*kernel_stats.csv"):
-    (dst / f"{tag}_kernel_stats.csv").write_text(f.read_text())
+# (rocprofv3 follows child processes -- bench.py's read-ceiling probe tools/bin/hbm_peak -- and writes one file per process: the bench's
+#  own is the big one)
+ks = find("trace", "*kernel_stats.csv")
+if ks:
+    (dst / f"{tag}_kernel_stats.csv").write_text(max(ks, key=lambda f: f.stat().st_size).read_text())
 # 2. PMC: sum counter per kernel name, average per dispatch
 res = {}
 for sub, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
