@@ -183,7 +183,7 @@ static int la_enqueue(kk_op op, kk_basis b, int c0, int j, int nsweeps, bool lan
     KK_TRY(st);
     if (!ahead_persistent) return KK_OK;   // (took the launch-per-vector route: results are simply not used ahead)
     KK_HIP(hipEventRecord(c->ev_la[slot & 1], c->stream));
-    b->la_valid = true; b->la_k = j; b->la_slot = slot; b->la_token = ahead_token; b->la_nsweeps = nsweeps;
+    b->la_valid = true; b->la_k = j; b->la_slot = slot; b->la_token = ahead_token; b->la_nsweeps = nsweeps; b->la_kind = 0;
     return KK_OK;
 }
 
@@ -465,7 +465,7 @@ KK_API int kk_arnoldi_expand(kk_op op, kk_basis b, int c0, int k, kk_orth_t orth
     const bool strict_route = la_sweeps > 0 && m <= KK_MAX_M && !kk_mgs_lowsync(c, b->ld, m) && (!kk_sharded(c) || kk_xs_on(c));
     // the previous call may have enqueued this WHOLE step already (apply, sweeps and read-back: la_enqueue)
     const bool la_hit = b->la_valid && b->spec_valid && c->spec_owner == b && b->spec_gen == c->foreign_gen && b->spec_op == op && b->spec_c0 == c0 && b->spec_k == k &&
-                        b->spec_dot_mode == 0 && b->la_k == k && b->la_nsweeps == la_sweeps && b->spec_beta == beta_old && strict_route && v_ready;
+                        b->spec_dot_mode == 0 && b->la_kind == 0 && b->la_k == k && b->la_nsweeps == la_sweeps && b->spec_beta == beta_old && strict_route && v_ready;
     const int la_slot = b->la_slot;
     const double la_token = b->la_token;
     if (b->la_valid && !la_hit) b->spec_valid = false;   // the sweep enqueued ahead has consumed the speculative apply's column

@@ -285,3 +285,45 @@ def test_two_factorizations_taking_turns_on_one_context(kk, ko, route):
             assert np.max(np.abs(V.T @ V - np.eye(V.shape[1]))) < 1e-12
     finally:
         c.close()
+
+
+def test_switching_routes_on_one_slab_does_not_repeat_every_step(kk, ko):
+    """the two kinds of run-ahead share the slab's bookkeeping: after steps on the projection route (kind 1) the persistent route's
+    run-ahead (kind 0) must be RECOGNISED by the next call -- found by bench.py's general-format leg, which ran after the
+    `mgs2_lowsync` leg on the same slab: every step was enqueued ahead, not recognised, and executed again (569 instead of 1106 it/s)"""
+    c = kk.Context(0)
+    try:
+        if c.get_option("mgs_persist") == 0:
+            pytest.skip("persistent route off on this device")
+        c.set_option("mgs_panel", 0)
+        nx, ny = 44, 36
+        n = nx * ny
+        A = ko.laplacian_2d(nx, ny, shift_diag=10 * np.linspace(0, 1, n) ** 2)
+        x0 = np.random.default_rng(3).random(n)
+        it = kk.LanczosIterator(kk.SparseOperator(A, c, symmetric=True), x0, kk.ModifiedGramSchmidt2(), capacity=40)
+        f = kk.initialize(it)
+        c.set_option("mgs_mode", 1)
+        for _ in range(8):
+            f = kk.expand_(it, f)
+        c.set_option("mgs_mode", 0)
+        f = kk.expand_(it, f)                       # the switch itself may cost one repeated step
+        c.prof_reset(); c.prof_enable(1)
+        for _ in range(10):
+            f = kk.expand_(it, f)
+        c.prof_enable(0)
+        assert c.prof_get("k_mgs_persist")[1] == 10, c.prof_get("k_mgs_persist")     # one launch per step: each found the one enqueued for it
+        c.set_option("mgs_mode", 1)
+        f = kk.expand_(it, f)
+        c.prof_reset(); c.prof_enable(1)
+        for _ in range(8):
+            f = kk.expand_(it, f)
+        c.prof_enable(0)
+        assert c.prof_get("k_project")[1] == 8 and c.prof_get("k_mgs_persist")[1] == 0, (c.prof_get("k_project"), c.prof_get("k_mgs_persist"))
+        oit = ko.LanczosIterator(A, x0.copy(), ko.MGS2)
+        of = ko.lanczos_initialize(oit)
+        for _ in range(28):
+            of = ko.lanczos_expand(oit, of)
+        assert np.max(np.abs(np.array(f.alphas) - of.alphas) / np.abs(of.alphas)) < 1e-10
+        assert np.max(np.abs(np.array(f.betas) - of.betas) / np.abs(of.betas)) < 1e-10
+    finally:
+        c.close()

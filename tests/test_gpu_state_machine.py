@@ -16,7 +16,7 @@ from hypothesis import strategies as st
 pytestmark = pytest.mark.gpu
 
 OPS = ["expand", "expand", "expand", "read_r", "norm_r", "read_v", "raw_ptr", "toggle_lookahead", "toggle_fold", "toggle_speculate",
-       "project_r", "orth_extra", "shrink", "restart_scale", "scale_r_inplace_roundtrip", "sync", "dot_rv", "reupload_v"]
+       "project_r", "orth_extra", "shrink", "restart_scale", "scale_r_inplace_roundtrip", "sync", "dot_rv", "reupload_v", "switch_route"]
 
 
 def _relerr(a, b):
@@ -63,6 +63,7 @@ def test_random_interleavings_of_krylov_entry_points(kk, ko, data):
             oexp, oshrink = ko.arnoldi_expand, ko.arnoldi_shrink
         f = kk.initialize(it)
         spare = cap - 1
+        cur_mode = 1 if route == "lowsync" else 0
 
         def check_scalars(where):
             if kind == "lanczos":
@@ -130,6 +131,9 @@ def test_random_interleavings_of_krylov_entry_points(kk, ko, data):
                 assert abs(f.r.norm() - 1.0) < 1e-12, (i, "in-place scale")
                 f.r.scale_(f.normres)
                 assert np.max(np.abs(f.r.get() - of.r)) < 1e-10 * rn
+            elif op_ == "switch_route":                    # strict order <-> low-synchronisation form on the SAME slab (two kinds of run-ahead, Gram rows)
+                cur_mode = 1 - cur_mode if route != "launch_per_vector" else cur_mode
+                c.set_option("mgs_mode", cur_mode)
             elif op_ == "sync":
                 c.sync()
         check_scalars("end")
