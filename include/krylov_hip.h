@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define KK_VERSION 300 /* 0.3.0: mgs_mode auto is the default, no limit on the basis size, constant-coefficient stencils */
+#define KK_VERSION 301 /* 0.3.1: same 92 entry points; persistent MGS kernels on row-sharded contexts (xsync), run-ahead of the projection route, commit consumed by scale!!(r, 1/beta) (0.3.0: mgs_mode auto is the default, no limit on the basis size, constant-coefficient stencils) */
 
 /* status codes */
 #define KK_OK 0
@@ -78,10 +78,27 @@ typedef enum {
  *                 w in registers, "panel_width" = 2-3 basis vectors per grid reduction with the exact in-panel triangular
  *                 correction, every basis vector read once) from "panel_min_rows" (1.4e6) rows up to its capacity
  *                 ("panel_capacity_rows", 4.19e6 on 256 CUs), the strict persistent kernel from "persist_min_rows" (3.6e6)
- *                 rows up to "persist_capacity_rows" (10.48e6), lowsync otherwise (shorter and longer vectors, row-sharded
- *                 contexts).  "lookahead" (default 1): a fused Lanczos / Arnoldi expand! whose sweep runs through a
- *                 persistent kernel enqueues the NEXT step's apply, sweep and read-back before the host waits for the
- *                 current one (bit-identical results; dropped if anything touches the slab in between). */
+ *                 rows up to "persist_capacity_rows" (10.48e6), lowsync otherwise (shorter and longer vectors; row-sharded
+ *                 contexts whose ranks could not map each other's sync areas, see "xsync").  The length thresholds scale with
+ *                 "num_cus" / 256.  "lookahead" (default 1): a fused Lanczos / Arnoldi expand! whose sweep runs through a
+ *                 persistent kernel -- and, since 0.3.1, a Lanczos expand! on the projection route (CGS2, lowsync MGS2) --
+ *                 enqueues the NEXT step's apply, scale, sweep / projection step and read-back before the host waits for the
+ *                 current one (bit-identical results; dropped if anything touches the slab, or another slab of the context is
+ *                 handed to any entry point, in between).
+ * Row-sharded contexts (kk_comm_init): "xsync" (default 1; must be the same on every rank): the persistent kernels of the MGS
+ * family sum their grid-wide inner products over the RANKS inside the launch -- block 0 of a rank stores the rank's partial as
+ * a tagged 16-byte granule into every peer's sync area (4 KB of fine-grained device memory per rank, exchanged by
+ * hipIpcGetMemHandle / hipIpcOpenMemHandle inside kk_comm_init and checked there by a hand-shake kernel), every block adds the
+ * W partials in rank order (bit-identical on all ranks) -- so that a sharded sweep runs in the reference's sequential order
+ * with every basis vector read once, RCCL serving the ghost exchange and alpha0 only; kk_ctx_get_option "xsync_active" tells
+ * whether the communicator offers it (<= 8 ranks, every peer mapped), "xsync_launches" counts such launches.  "num_cus"
+ * (default: what the device reports, "device_cus"): CUs this context may count on -- blocks of a persistent launch, one per CU,
+ * all resident at once; ranks or jobs that share a GPU must set it (one launch hands its blocks to the 8 XCDs round-robin:
+ * W launches of n blocks need W * ceil(n / 8) CUs per XCD).  "persist_timeout_ms" (default 0 = 50 x the time the sweep's bytes
+ * take at 2 TB/s + 1 ms, within [20 ms, 3 s]; >= 1 s on a sharded context): how long a persistent launch waits for a block that
+ * is not resident (or a peer that does not answer) before it gives up WITHOUT committing; the sweep is then repeated on the
+ * launch-per-vector route, the persistent route backs off, and three timeouts in a row move the launches of a single-rank
+ * context to hipLaunchCooperativeKernel ("persist_coop" reads 1 from then on). */
 /* Other kk_ctx_set_option keys: "blocks_per_cu" (grid of the streaming kernels, default 4), "block_mode" (0 strict
  * block QR / re-orthogonalisation, 1 MFMA panels + CholQR2, default), "fuse_passes", "speculate" (next-step SpMV
  * enqueued before the host reads alpha/beta), "keep_mb" (MB of trailing basis columns a project pass leaves
@@ -95,10 +112,12 @@ typedef enum {
  * one value each is applied from its 5 / 9 coefficients, no indices and no values read; default 1, bit-identical to 0),
  * "fold_scale" (default 1: a Lanczos / Arnoldi expand! whose sweep ran through the persistent kernel stores the residual
  * already NORMALISED -- the kernel holds |w| before it writes w back -- so that the next expand! of the same factorization
- * needs no scale pass (factorizations/lanczos.jl:257, arnoldi.jl:209); the slab remembers (column, beta) and ANY other
- * entry point that is handed the slab first multiplies the column back, so residual(F), shrink! and restarts see r as
- * before (to 1 ulp); kk_orthonormalize uses the same commit; 0 = every expand! runs its own scale pass; same alpha / beta
- * bits either way), "block_commit" (default 1: the one-pass BlockLanczos step writes its residual block W as T = W R1^-1
+ * needs no scale pass (factorizations/lanczos.jl:257, arnoldi.jl:209); the slab remembers (column, beta) and any other
+ * entry point that is handed THAT COLUMN first multiplies it back, so residual(F) and shrink! see r as before (to 1 ulp) --
+ * except kk_vec_scal(r, 1 / beta) / kk_vec_copy_scal(dst, r, 1 / beta), the scale!!(r, 1 / beta) of a thick restart
+ * (eigsolve/lanczos.jl:111), which CONSUME the commit: no pass in place, one plain copy out of place, the reference's bits
+ * ("norm_commits_consumed" counts them); kk_orthonormalize uses the same commit; 0 = every expand! runs its own scale pass;
+ * same alpha / beta bits either way), "block_commit" (default 1: the one-pass BlockLanczos step writes its residual block W as T = W R1^-1
  * -- R1 = the first CholQR2 factor, from the Gram matrix the projection panel predicts -- straight into the next basis
  * slot (columns k+bs .. k+2bs-1, which must lie below both residual areas) and does not write the residual area; the next
  * kk_blocklanczos_expand of the same factorization starts at the second CholQR2 round (blocklanczos.jl:209-216), any other
@@ -111,10 +130,17 @@ typedef enum {
  * Tuning knobs without semantic effect:
  * "nt_store_rows" (results of sparse applies on at least this many rows are written with non-temporal stores, default 4e6),
  * "gram_bpc", "gram2_chunk", "gram2_pipe", "gram2_bpc", "spmm_bpc", "spmm_cols", "spmm_rpl", "spmm_dia_lines", "bu_prefetch", "gram_nt", "persist_nt",
- * "persist_lds", "persist_min_rows", "spmv_dia_pairs" (row pairs per lane of the diagonal SpMV: 0 = by size, 1 / 2 / 4).  Test hook: "persist_fault" (the next n persistent launches behave like a grid-barrier timeout). */
+ * "persist_lds", "persist_min_rows", "spmv_dia_pairs" (row pairs per lane of the diagonal SpMV: 0 = by size, 1 / 2 / 4),
+ * "spmv_dia_aligned" (default 1: 5-point stencils with an even line length load their far neighbours as aligned 16-byte pairs
+ * and take the +-1 neighbours from the lanes next door; bit-identical to 0), "panel_lag" (default 0; 1 = panel sweeps outside the
+ * strict order through the cross-panel lag-1 kernel -- exact algebra, measured slower at every length, kept as the record),
+ * "bu_mfma" (default 0; 1..6 = block update through the MFMA kernel in one of six tile shapes -- bit-identical to the default
+ * kernel, not faster).  Test hook: "persist_fault" (the next n persistent launches behave like a grid-barrier timeout). */
 
 /* Environment variables read by the library (all optional): KK_MGS_MODE, KK_BLOCK_MODE, KK_BLOCKS_PER_CU, KK_MGS_PERSIST,
- * KK_PERSIST_THREADS, KK_PERSIST_NT (defaults of the options of the same name, read at kk_ctx_create); KK_SPMV_FORMAT = ell |
+ * KK_PERSIST_THREADS, KK_PERSIST_NT, KK_NUM_CUS (defaults of the options of the same name, read at kk_ctx_create); KK_XSYNC = 0 (no
+ * cross-rank sync areas: kk_comm_init leaves the RCCL routes in charge; same on every rank); KK_XSYNC_DEBUG = 1 (post-mortem of a
+ * persistent launch that did not commit, on stderr); KK_SPMV_FORMAT = ell |
  * sell | csr, KK_SPMV_TILE_COLS and KK_SELLW_ROUNDS = 1 | 2 | 4 | 8 (force a device format / the column-tile width / the
  * sorting window of the tiled format in units of 256 rows, default 4, at operator creation); KK_NO_DIA (no
  * grid-stencil diagonals); KK_BASISTRANSFORM_LDS (LDS-tile basistransform instead of the MFMA kernel); KK_RCCL_LIB (path of
