@@ -641,6 +641,18 @@ function init_comm!(ctx::HipContext, id::Vector{UInt8}, rank::Integer, world::In
     return ctx
 end
 destroy_comm!(ctx::HipContext) = (chk(ccall((:kk_comm_destroy, lib), Cint, (Ptr{Cvoid},), ctx.h)); ctx)
+# Options of a context (include/krylov_hip.h lists them; none changes a call sequence or the layout contract).  Two matter to a
+# multi-GPU run: after `init_comm!` the persistent MGS kernels sum their inner products over the ranks inside the launch whenever
+# every rank could map every peer's sync area -- `xsync_active(ctx)` tells; and ranks or jobs that SHARE a GPU must say how many CUs
+# are theirs: `set_option!(ctx, "num_cus", n)` (one block per CU of every rank has to be resident at the same time).
+set_option!(ctx::HipContext, key::AbstractString, value::Real) =
+    (chk(ccall((:kk_ctx_set_option, lib), Cint, (Ptr{Cvoid}, Cstring, Float64), ctx.h, key, Float64(value))); ctx)
+function get_option(ctx::HipContext, key::AbstractString)
+    v = Ref{Float64}()
+    chk(ccall((:kk_ctx_get_option, lib), Cint, (Ptr{Cvoid}, Cstring, Ref{Float64}), ctx.h, key, v))
+    return v[]
+end
+xsync_active(ctx::HipContext) = get_option(ctx, "xsync_active") == 1
 comm_barrier(ctx::HipContext) = (chk(ccall((:kk_comm_barrier, lib), Cint, (Ptr{Cvoid},), ctx.h)); nothing)
 """
     sharded_operator(ctx, Arows, row_offsets; symmetric)

@@ -189,3 +189,24 @@ def test_world2_bench_end_to_end(tmp_path, config, extra):
         assert per["gather"] >= 2.0
     else:
         assert per["p2p_groups"] >= 1.0 and per["allreduce"] > 0
+
+
+def test_world2_bench_weak_scaling_runs_the_persistent_kernel_across_the_ranks(tmp_path):
+    """`python bench.py --gpus 2` at a shard size the persistent strict-MGS kernel takes (4.4 M rows per rank on 112 CUs each): the line
+    says so (`xsync.active`, launches counted), the all-reduces per iteration drop from 2.05 to ~1.06 (alpha0 only), the scalars agree
+    bitwise between the ranks -- the N > 1 line the driver's scaling run would produce, over the stand-in on one GPU"""
+    env = _env(tmp_path)
+    env["KK_BENCH_SPAWNED"] = ""
+    per_xcd = (device_cus() // 8) // 2
+    env["KK_NUM_CUS"] = str(8 * (per_xcd - 2))
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--config", "lanczos", "--ny", "1100",
+           "--deadline", "800", "--no-other-scaling-leg", "--no-strict-leg"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-6000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["scaling"] == "weak"
+    assert line["xsync"]["active"] is True and line["xsync"]["persistent_launches_with_cross_rank_reduction"] >= 99
+    coll = line["collectives"]
+    assert coll["ranks"] == 2 and coll["ranks_agree_bitwise"] is True
+    assert 1.0 <= coll["per_iteration"]["allreduce"] <= 1.2 and coll["per_iteration"]["p2p_groups"] >= 1.0
+    assert line["roofline"]["kernel"] == "k_mgs_persist"
