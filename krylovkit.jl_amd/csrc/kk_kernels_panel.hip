@@ -170,6 +170,68 @@ __device__ __forceinline__ bool panel_sweep(int nval, unsigned epoch, int set, c
     (void)npass;
     return good != 0;
 }
+// The same sweep with the VALUES SPREAD OVER THE WAVES (round 5): wave v sweeps value v, all at once.  panel_sweep takes the values one
+// after the other -- each a round trip of its own to the L2 (~1 us while the chip streams), and only the first hides behind the landing
+// of the next panel: with three values (two vectors per reduction) two round trips per panel were exposed, 6.0 us per panel against
+// 5.4 for the same traffic with a one-value reduction (tools/sstore_publish.hip).  Same granules, same summation order per value (blocks
+// ascending per lane, wave_sum): the totals have the bits of panel_sweep.  Called by ALL waves between barriers (1b) and (2); smB[0 .. 8)
+// totals, [8] failure flag, [9 .. 16) the rank's partials on a row-sharded context, where wave 0 runs the cross-rank level behind one more
+// barrier.
+template <int NVAL>
+__device__ __forceinline__ void panel_sweep_par(unsigned epoch, int set, char* __restrict__ sync, int* __restrict__ err, double* smB, const kk_xs_dev& xs,
+                                                unsigned xred, long long timeout_ticks) {
+    static_assert(NVAL <= 7, "one wave per value, seven slots for the rank's partials");
+    const int G = gridDim.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (wave < NVAL) {
+        const unsigned set_bytes = (unsigned)G * 16u * 8u;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(sync, 0, 2 * (int)set_bytes, 0x00020000);
+        const unsigned voff_v = (unsigned)set * set_bytes + (unsigned)wave * (unsigned)G * 16u;
+        const long long t0 = wall_clock64();
+        int good = 1;
+        double total = 0;
+        for (;;) {
+            asm volatile("" ::: "memory");   // (the granule loads must be re-issued by every pass: see panel_sweep)
+            const int errv = __hip_atomic_load(err, RLX_AGENT);
+            bool ok = true;
+            double x = 0;
+            for (int b0 = 0; b0 < G; b0 += 256) {
+                v4u t[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int b = b0 + i * 64 + lane;
+                    const int bb = b < G ? b : 0;
+                    t[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff_v + (unsigned)bb * 16u, 0, 16 /* sc1 */);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (b0 + i * 64 + lane < G) {
+                        ok = ok && t[i].x == epoch && t[i].w == epoch;
+                        x += __longlong_as_double((long long)(((unsigned long long)t[i].y << 32) | t[i].z));
+                    }
+                }
+            }
+            if (__all(ok)) { total = wave_sum(x); break; }
+            __builtin_amdgcn_s_sleep(1);
+            if (wall_clock64() - t0 > timeout_ticks || errv) { good = 0; break; }
+        }
+        if (lane == 0) {
+            if (!good) { __hip_atomic_store(err, 1, RLX_AGENT); smB[8] = 1.0; }
+            smB[xs.world > 0 ? 9 + wave : wave] = total;
+        }
+    }
+    if (xs.world > 0) {   // (uniform) level 2: the sum over the ranks, by wave 0, from the rank's partials the waves left in smB[9 ..]
+        lds_barrier();
+        if (wave == 0) {
+            bool good = smB[8] == 0.0;
+            const double mine = lane < NVAL ? smB[9 + lane] : 0.0;
+            double t2 = 0;
+            if (good && !xs_allreduce(xs, xred, NVAL, mine, err, timeout_ticks, t2)) good = false;
+            if (good && (lane & 7) == 0 && (lane >> 3) < NVAL) smB[lane >> 3] = t2;
+            if (!good && lane == 0) { xs_abort(xs); __hip_atomic_store(err, 1, RLX_AGENT); smB[8] = 1.0; }
+        }
+    }
+}
 // one whole reduction as seen by a wave 0 that holds no rows (KK_PANEL_DW = 7)
 __device__ __forceinline__ bool panel_reduce_sync(int nval, unsigned epoch, int set, char* __restrict__ sync, int* __restrict__ err, const double* smA,
                                                   double* smB, const kk_xs_dev& xs, unsigned xred, long long timeout_ticks, int pidx = 0) {
@@ -212,7 +274,11 @@ __device__ __forceinline__ bool panel_totals(const double (&acc)[NVAL], double (
     for (int v = 0; v < NVAL; ++v) tot[v] = acc[v] * 1e-30;
     return true;
 #endif
-    if (KK_PANEL_W0 == 0 && threadIdx.x < 64) panel_sweep(NVAL, epoch, set, sync, err, smB, xs, xred, timeout_ticks, pidx);   // (its sweep queues behind its own panel loads: fine)
+#ifndef KK_PANEL_SWEEP_SERIAL
+    if (KK_PANEL_W0 == 0) panel_sweep_par<NVAL>(epoch, set, sync, err, smB, xs, xred, timeout_ticks);   // wave v sweeps value v (its loads queue behind its own panel loads: fine)
+#else
+    if (KK_PANEL_W0 == 0 && threadIdx.x < 64) panel_sweep(NVAL, epoch, set, sync, err, smB, xs, xred, timeout_ticks, pidx);   // round-4 form: wave 0 takes the values one after the other
+#endif
     lds_barrier();   // (2)
     PTRACE(3, pidx);   // totals available
 #pragma unroll
