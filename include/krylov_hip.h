@@ -76,7 +76,7 @@ typedef enum {
  *                 basis, maintained incrementally (16 N bytes / vector).
  *   2 = auto:     (default) by vector length on an unsharded context: the persistent PANEL kernel ("mgs_panel", default 1:
  *                 w in registers, "panel_width" = 2-3 basis vectors per grid reduction with the exact in-panel triangular
- *                 correction, every basis vector read once) from "panel_min_rows" (1.4e6) rows up to its capacity
+ *                 correction, every basis vector read once) from "panel_min_rows" (2.5e5) rows up to its capacity
  *                 ("panel_capacity_rows", 4.19e6 on 256 CUs), the strict persistent kernel from "persist_min_rows" (3.6e6)
  *                 rows up to "persist_capacity_rows" (10.48e6), lowsync otherwise (shorter and longer vectors; row-sharded
  *                 contexts whose ranks could not map each other's sync areas, see "xsync").  The length thresholds scale with

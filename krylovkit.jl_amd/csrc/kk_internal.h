@@ -187,7 +187,10 @@ struct kk_ctx_s {
                                  // (profiles/r05_panel_lag_ab.jsonl: 4289 vs 5552 it/s on a 1 M-row GMRES(60) cycle) -- the reduction chain of its wave 0
                                  // (publish -> sweep -> publish) is as long as the reduction it was meant to hide; kept, tested, as the record of the experiment
     int panel_width = 0;         // basis vectors per grid reduction of that kernel: 0 = by vector length (3 / 2 / 1), else min(value, by length); mgs_mode 0 forces 1
-    int64_t panel_min_rows = 1400000;  // auto mode: below this one grid reduction per panel (a fixed ~6 us) costs more than the second read of the basis by the projection pair (tools/panel_sweep_cost.py: 1 M rows 3.1 vs 2.6 us per vector, 2 M rows 3.6 vs 5.1)
+    int64_t panel_min_rows = 250000;   // auto mode: below this the projection pair (two launch-bound passes) is the faster route.  Round 4: 1.4 M rows (one grid
+                                       // reduction per panel cost ~6 us); since the values of a reduction are swept by as many waves at once (round 5) the panel
+                                       // kernel wins from ~0.2 M rows: Arnoldi MGS2 cycle of 60, 128 k rows 11.7 vs 13.1 k it/s (projection pair ahead), 250 k 12.3 vs
+                                       // 11.6, 500 k 11.1 vs 8.0, 1 M 8.3 vs 5.5 (profiles/r05_panel_sweep_par.jsonl)
     int xsync = 1;               // row-sharded context: persistent kernels with the in-kernel cross-rank reduction where the communicator offers it (0: RCCL all-reduce per inner-product batch, low-sync route)
     int mgs_persist = 1;         // strict MGS sweeps through the persistent register-resident kernel when the vector fits
     int persist_coop = 0;        // launch the persistent kernels through hipLaunchCooperativeKernel (1) or as ordinary launches (0): see kk_launch_resident
