@@ -102,8 +102,9 @@ KK_API int kk_comm_get_unique_id(void* id128) {
 // same on every rank whatever happens locally.
 // ------------------------------------------------------------------------------------------
 namespace {
-struct xs_record {            // what a rank tells the others (13 x 8 bytes)
+struct xs_record {            // what a rank tells the others (14 x 8 bytes)
     int64_t ok, pid, dev, ptr;
+    int64_t bus;              // hash of the PCI bus id of the rank's device: ranks that SHARE a GPU find each other by it
     char handle[72];          // hipIpcMemHandle_t (64 bytes) + padding to a multiple of 8
 };
 static_assert(sizeof(hipIpcMemHandle_t) <= 72 && sizeof(xs_record) % 8 == 0, "xs_record layout");
@@ -135,6 +136,13 @@ static int xs_setup(kk_ctx c) {
         else memcpy(mine.handle, &h, sizeof(h));
     }
     mine.ok = local_ok; mine.pid = (int64_t)getpid(); mine.dev = c->device; mine.ptr = (int64_t)(uintptr_t)k->xs_mine;
+    {
+        char bus[64] = {0};
+        if (hipDeviceGetPCIBusId(bus, sizeof(bus), c->device) != hipSuccess) { (void)hipGetLastError(); snprintf(bus, sizeof(bus), "dev%d-pid%d", c->device, (int)getpid()); }
+        uint64_t h = 1469598103934665603ull;
+        for (const char* q = bus; *q; ++q) h = (h ^ (uint64_t)(unsigned char)*q) * 1099511628211ull;
+        mine.bus = (int64_t)(h & 0x7fffffffffffffffull);
+    }
     // all-gather of the records (a world-1 communicator copies): staged in the block scratch, which nothing uses right now
     const int64_t nw = sizeof(xs_record) / 8;
     int64_t* d_send = (int64_t*)c->blk;
@@ -146,6 +154,19 @@ static int xs_setup(kk_ctx c) {
     KK_HIP(hipMemcpyAsync(all.data(), d_recv, sizeof(xs_record) * (size_t)k->world, hipMemcpyDeviceToHost, c->stream));
     KK_HIP(hipStreamSynchronize(c->stream));
     int status = KK_OK;
+    // Ranks that share ONE GPU (tests; a node with fewer GPUs than ranks): the persistent kernels launch one block per CU and need
+    // the blocks of ALL ranks resident at once.  A launch deals its blocks to the 8 XCDs round-robin, so W kernels of n blocks need
+    // W * ceil(n / 8) CUs per XCD (profiles/r05_xsync_world3_residency.txt): unless the caller has set "num_cus" itself, every rank
+    // takes its share of each XCD, less two CUs per XCD for the streaming kernels of the others.
+    {
+        int n_share = 0;
+        for (int r = 0; r < k->world; ++r) n_share += (all[r].bus == mine.bus);
+        if (n_share > 1 && c->num_cus == c->dev_cus) {
+            const int per_xcd = (c->dev_cus / 8) / n_share;
+            c->num_cus = 8 * std::max(1, per_xcd - 2);
+        }
+        k->xs_share = n_share;
+    }
     for (int r = 0; r < k->world && local_ok; ++r) if (!all[r].ok) local_ok = 0;
     for (int r = 0; r < k->world && local_ok; ++r) {
         if (r == k->rank) { k->xs_peer[r] = k->xs_mine; continue; }

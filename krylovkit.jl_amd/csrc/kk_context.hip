@@ -290,6 +290,7 @@ KK_API int kk_ctx_get_option(kk_ctx c, const char* key, double* value) {
     else if (!strcmp(key, "xsync")) *value = c->xsync;
     else if (!strcmp(key, "xsync_active")) *value = kk_xs_on(c) ? 1 : 0;
     else if (!strcmp(key, "xsync_launches")) *value = c->comm ? (double)c->comm->n_xs_launches : 0.0;
+    else if (!strcmp(key, "ranks_on_this_gpu")) *value = c->comm ? c->comm->xs_share : 1;
     else if (!strcmp(key, "block_mode")) *value = c->block_mode;
     else if (!strcmp(key, "block_async")) *value = c->block_async;
     else if (!strcmp(key, "block_fuse")) *value = c->block_fuse;

@@ -123,6 +123,7 @@ struct kk_comm_s {
     unsigned xs_red = 0;                        // reductions issued so far (identical on all ranks: SPMD call sequence)
     unsigned xs_launch = 0;                     // launches issued so far
     int64_t n_xs_launches = 0;                  // statistics
+    int xs_share = 1;                           // ranks of this communicator on this rank's GPU (> 1: num_cus was cut to the rank's share)
 };
 
 struct kk_ctx_s {

@@ -325,7 +325,7 @@ elif scenario in ("xsync", "xsync_fault"):
     # (csrc/kk_xsync.h; reference order src/orthonormal.jl:414-439, factorizations/lanczos.jl:325-338, arnoldi.jl:239-245).
     # Every rank owns num_cus = device / world CUs (KK_NUM_CUS): the launches of all ranks are resident side by side.
     assert ctx.get_option("xsync_active") == 1, "kk_comm_init did not establish the cross-rank sync areas"
-    assert ctx.get_option("num_cus") * world <= ctx.get_option("device_cus")
+    assert ctx.get_option("num_cus") * world <= ctx.get_option("device_cus") and ctx.get_option("ranks_on_this_gpu") == world   # (found by kk_comm_init)
     nx, ny = 70, 64 * world
     n = nx * ny
     A = ko.laplacian_2d(nx, ny, shift_diag=10 * np.linspace(0, 1, n) ** 2)
