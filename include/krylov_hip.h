@@ -93,8 +93,9 @@ typedef enum {
  * with every basis vector read once, RCCL serving the ghost exchange and alpha0 only; kk_ctx_get_option "xsync_active" tells
  * whether the communicator offers it (<= 8 ranks, every peer mapped), "xsync_launches" counts such launches.  "num_cus"
  * (default: what the device reports, "device_cus"): CUs this context may count on -- blocks of a persistent launch, one per CU,
- * all resident at once; ranks or jobs that share a GPU must set it (one launch hands its blocks to the 8 XCDs round-robin:
- * W launches of n blocks need W * ceil(n / 8) CUs per XCD).  "persist_timeout_ms" (default 0 = 50 x the time the sweep's bytes
+ * all resident at once; jobs that share a GPU must set it (one launch hands its blocks to the 8 XCDs round-robin: W launches of
+ * n blocks need W * ceil(n / 8) CUs per XCD); RANKS of one communicator that share a GPU are recognised by kk_comm_init (PCI bus
+ * id; "ranks_on_this_gpu") and get 8 * (CUs per XCD / ranks - 2) unless the option was set explicitly.  "persist_timeout_ms" (default 0 = 50 x the time the sweep's bytes
  * take at 2 TB/s + 1 ms, within [20 ms, 3 s]; >= 1 s on a sharded context): how long a persistent launch waits for a block that
  * is not resident (or a peer that does not answer) before it gives up WITHOUT committing; the sweep is then repeated on the
  * launch-per-vector route, the persistent route backs off, and three timeouts in a row move the launches of a single-rank
