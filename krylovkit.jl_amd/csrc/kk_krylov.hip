@@ -633,10 +633,9 @@ KK_API int kk_gkl_expand(kk_op op, kk_basis bu, kk_basis bv, int k, kk_orth_t or
         KK_TRY(orth_run(bv, 0, k, v, KK_MGS, eta, tmp.data(), &nn, nullptr, true));
         a = nn;
         pv = 1;
-        // publish alpha / 1/alpha on the device for the next kernels
-        double hv[3] = {a * a, a, 1.0 / a};
-        KK_HIP(hipMemcpyAsync(c->ws + WS_SCAL + SC_NRM2, hv, sizeof(hv), hipMemcpyHostToDevice, c->stream));
-        KK_TRY(stream_sync(c));
+        // alpha and 1 / alpha are on the device already: every route of the sweep ends with the norm triple {|v|^2, |v|, 1 / |v|} in
+        // SC_NRM2 -- the same sqrt and the same division the host would repeat (rounds 1-4 copied them back up and waited: one host
+        // round trip of the four per expand!)
     } else if (orth == KK_CGSIR || orth == KK_MGSIR) {  // gkl.jl:353-360 / 380-389
         KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2, 2, 0));
         KK_TRY(stream_sync(c));
