@@ -853,8 +853,8 @@ def main():
         if other == 0:
             # strict MGS2 as the reference codes it: (176 + 16 m) N algorithmic bytes per expand as well
             leg["note"] = ("mgs_mode=0: the reference's sequential order (src/orthonormal.jl:414-439), one basis vector after the other; "
-                           + ("row-sharded: one fused axpy+dot kernel and one all-reduce per basis vector (32 N bytes per vector; the "
-                              "persistent kernel cannot issue collectives)" if use_dist else
+                           + ("row-sharded: the persistent kernel with its in-kernel cross-rank reduction where the communicator offers it (`xsync`), "
+                              "else one fused axpy+dot kernel and one all-reduce per basis vector (32 N bytes per vector)" if use_dist else
                               "persistent cooperative kernel, w resident in registers"))
             strict = leg
         else:
