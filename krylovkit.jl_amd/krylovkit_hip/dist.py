@@ -2,7 +2,9 @@
 
 kk_comm_init gives a context its own RCCL communicator: from then on every entry point of libkrylov_hip works on
 row-sharded vectors and issues its collectives itself on the context stream -- ncclAllReduce at every finalize site
-(kk_lanczos_expand with CGS2 / low-sync MGS2: exactly two per step, 2m+1 and 1 doubles), ONE grouped ncclSend / ncclRecv
+(kk_lanczos_expand with CGS2 / low-sync MGS2: exactly two per step, 2m+1 and 1 doubles; with the persistent MGS kernels, which since
+0.3.1 sum their inner products over the ranks INSIDE the launch through IPC-mapped sync areas -- csrc/kk_xsync.h, set up by kk_comm_init,
+`ctx.get_option("xsync_active")` -- only the one of alpha0), ONE grouped ncclSend / ncclRecv
 of the ghost entries before a sparse apply (NativeShardedOperator; one group for all <= 16 columns of a block apply),
 ncclAllGather / ncclReduceScatter for the rectangular map of the sharded GKL (NativeShardedRectOperator).  Every N-vector
 (basis, w, r) is split into contiguous row blocks; axpy / scal / unproject / basistransform / Givens are purely local.
