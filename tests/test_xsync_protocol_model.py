@@ -85,3 +85,63 @@ def test_parity_by_step_inside_the_launch_is_not():
     assert failures > 0, "the broken rule was never caught: the model does not explore enough interleavings"
     # ... while even-length launches hide the defect (every launch starts on set 0 after ending on set 1)
     assert all(simulate(2, [4, 2, 6], seed=t, parity_follows_tag=False)[0] for t in range(100))
+
+
+def simulate_blocks(world, blocks, nred, seed, level1=True, max_events=400000):
+    """The same protocol with the BLOCKS of a rank made explicit: block 0 of a rank pushes, every block polls on its own.  With
+    `level1` the push of reduction t waits until every block of the rank has arrived at t (the single-chip reduction in front of every
+    cross-rank one: block 0 cannot know the rank's partial earlier); without it block 0 pushes as soon as it is done with t - 1 itself."""
+    rng = random.Random(seed)
+    area = [[[(0, None)] * world for _ in range(2)] for _ in range(world)]
+    inflight = []
+    pos = [[1] * blocks for _ in range(world)]      # the reduction (= tag) block b of rank r works on
+    pushed = [0] * world                            # last tag rank r has pushed
+    for _ in range(max_events):
+        if all(p > nred for row in pos for p in row) and not inflight:
+            return True, "done"
+        moves = [("deliver", i, 0) for i in range(len(inflight))]
+        for r in range(world):
+            for b in range(blocks):
+                if pos[r][b] <= nred:
+                    moves.append(("block", r, b))
+        kind, r, b = rng.choice(moves)
+        if kind == "deliver":
+            dst, st, slot, tg, val = inflight.pop(r)
+            area[dst][st][slot] = (tg, val)
+            continue
+        tg = pos[r][b]
+        st = tg & 1
+        if b == 0 and pushed[r] < tg:
+            if level1 and any(p < tg for p in pos[r]):
+                continue                             # level 1 of this step is not complete: a block of the rank is still in reduction tg - 1
+            for dst in range(world):
+                inflight.append((dst, st, r, tg, (r, tg)))
+            pushed[r] = tg
+            continue
+        got = area[r][st]
+        if all(g[0] == tg for g in got):
+            if any(g[1] != (q, tg) for q, g in enumerate(got)):
+                return False, f"block {b} of rank {r} read a foreign partial in reduction {tg}"
+            pos[r][b] += 1
+        elif any(g[0] > tg for g in got):
+            return False, f"block {b} of rank {r} waits for reduction {tg} but a slot holds {max(g[0] for g in got)}: overwritten before it was read"
+    return False, "event budget exhausted (livelock)"
+
+
+@pytest.mark.parametrize("world,blocks", [(2, 3), (3, 4)])
+def test_every_block_of_a_slow_rank_has_read_before_a_slot_is_reused(world, blocks):
+    """two sets suffice although only block 0 publishes and EVERY block reads: the single-chip reduction in front of each cross-rank one
+    is what keeps a rank's block 0 from running ahead of its own blocks"""
+    for trial in range(150):
+        ok, why = simulate_blocks(world, blocks, nred=9, seed=7000 * world + trial)
+        assert ok, (world, blocks, trial, why)
+
+
+def test_without_the_single_chip_level_in_front_it_is_not():
+    failures = 0
+    for trial in range(300):
+        ok, why = simulate_blocks(2, 3, nred=9, seed=trial, level1=False)
+        if not ok:
+            failures += 1
+            assert "overwritten before it was read" in why or "livelock" in why, why
+    assert failures > 0, "the model never caught a block-0 that runs ahead of its rank's other blocks"
