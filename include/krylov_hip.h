@@ -136,7 +136,9 @@ typedef enum {
  * and take the +-1 neighbours from the lanes next door; bit-identical to 0), "panel_lag" (default 0; 1 = panel sweeps outside the
  * strict order through the cross-panel lag-1 kernel -- exact algebra, measured slower at every length, kept as the record),
  * "bu_mfma" (default 0; 1..6 = block update through the MFMA kernel in one of six tile shapes -- bit-identical to the default
- * kernel, not faster).  Test hook: "persist_fault" (the next n persistent launches behave like a grid-barrier timeout). */
+ * kernel, not faster).  Test hooks: "persist_fault" (the next n persistent launches behave like a grid-barrier timeout),
+ * "persist_fault_late" (cross-rank contexts: in the next n k_mgs_persist launches this rank gives up at the last reduction,
+ * its partial already published). */
 
 /* Environment variables read by the library (all optional): KK_MGS_MODE, KK_BLOCK_MODE, KK_BLOCKS_PER_CU, KK_MGS_PERSIST,
  * KK_PERSIST_THREADS, KK_PERSIST_NT, KK_NUM_CUS (defaults of the options of the same name, read at kk_ctx_create); KK_XSYNC = 0 (no

@@ -196,6 +196,8 @@ KK_API int kk_ctx_set_option(kk_ctx c, const char* key, double value) {
         c->panel_min_rows = (int64_t)value;
     } else if (!strcmp(key, "persist_fault")) {
         c->persist_fault = (int)value;   // test hook: the next `value` persistent launches behave like a grid-barrier timeout
+    } else if (!strcmp(key, "persist_fault_late")) {
+        c->persist_fault_late = (int)value;   // test hook (cross-rank contexts): ... give up at the last reduction, partial already published
     } else if (!strcmp(key, "persist_threads")) {
         KK_CHECK(value == 512 || value == 1024, KK_ERR_INVALID, "persist_threads must be 512 or 1024");
         c->persist_threads = (int)value;

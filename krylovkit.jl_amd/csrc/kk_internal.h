@@ -215,6 +215,8 @@ struct kk_ctx_s {
     int persist_skip = 0;          // strict sweeps still to run on the launch-per-vector route before the persistent one is retried
     int persist_backoff = 4;       // ... how many after the next timeout (doubles with every timeout in a row)
     int persist_fault = 0;         // test hook (option "persist_fault"): the next N persistent launches time out artificially
+    int persist_fault_late = 0;    // test hook (option "persist_fault_late"): in the next N k_mgs_persist launches of a cross-rank context this rank publishes
+                                   // its partial of the LAST reduction and then declares the launch lost (a peer that arrives after this rank's patience ran out)
     int64_t norm_commits_consumed = 0;   // normalised residual columns taken over by scale!!(r, 1 / beta) of a restart without a pass (diagnostics)
     int fold_scale = 1;          // persistent kernel stores r / |r| at its commit when an expand! ends with it (no scale pass in the next step)
     int fuse_passes = 1;         // fuse unproject(pass i) with project(pass i+1)

@@ -366,7 +366,7 @@ __global__ __launch_bounds__(KK_PANEL_PT) void k_mgs_panel(const double* __restr
                                                            double* __restrict__ ok_out, double token, kk_xs_dev xs, long long timeout_ticks) {
     __shared__ double smA[64];
     __shared__ double smB[16];
-    if (fault && blockIdx.x == 0) {   // test hook (option "persist_fault"): block 0 behaves like a block whose spin ran out
+    if (fault == 1 && blockIdx.x == 0) {   // test hook (option "persist_fault"): block 0 behaves like a block whose spin ran out
         if (threadIdx.x == 0) { __hip_atomic_store(err, 1, RLX_AGENT); xs_abort(xs); }
         return;
     }
@@ -448,8 +448,9 @@ __global__ __launch_bounds__(KK_PANEL_PT) void k_mgs_panel(const double* __restr
         scale = normalize && rt > 0.0 && inv <= 1.79769313486231570815e308;
         if (blockIdx.x == 0 && threadIdx.x == 64 * KK_PANEL_W0) { nrm_out3[0] = tot[0]; nrm_out3[1] = rt; nrm_out3[2] = inv; }
     }
-    // commit (see k_mgs_persist): every block writes its rows back or -- flag raised by a block that timed out -- none does
+    // commit (see k_mgs_persist): every block writes its rows back or -- flag raised by a block that timed out, abort word of a peer -- none does
     if (__hip_atomic_load(err, RLX_AGENT)) return;
+    if (xs.world > 0 && xs_aborted(xs)) return;
     if (blockIdx.x == 0 && threadIdx.x == 64 * KK_PANEL_W0) { ok_out[0] = token; ok_out[1] = scale ? 1.0 : inv; }   // SC_PERSIST_OK, SC_XS
     // scale in place FIRST, store afterwards, nothing in between: a VALU write to the data registers of a 16-byte buffer store
     // in the instruction after it can reach the store (hipcc inserts the wait state only for stores WITHOUT an SGPR offset;
@@ -687,6 +688,7 @@ __global__ __launch_bounds__(KK_PANEL_PT) void k_mgs_panel_lag(const double* __r
     }
     // commit (see k_mgs_persist / k_mgs_panel)
     if (__hip_atomic_load(err, RLX_AGENT)) return;
+    if (xs.world > 0 && xs_aborted(xs)) return;
     if (blockIdx.x == 0 && threadIdx.x == 64) { ok_out[0] = token; ok_out[1] = scale ? 1.0 : inv; }
     const double f = scale ? inv : 1.0;
 #pragma unroll

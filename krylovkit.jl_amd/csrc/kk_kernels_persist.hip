@@ -80,7 +80,8 @@ template <int PT, bool XS /* compiled with the cross-rank level: the single-rank
                            register-starved <40, 19, 9, 512> kernel 15 more spill slots and 1.5 % of the headline sweep) */>
 __device__ __forceinline__ bool grid_collect(int step, unsigned ebase, char* __restrict__ sync, int* __restrict__ err,
                                              double* sm, double* out, unsigned gstride /* bytes between the granules of two blocks: 128 = own line, 16 = packed */,
-                                             const kk_xs_dev& xs /* row-sharded context: the sum over the ranks follows (kk_xsync.h) */, long long timeout_ticks) {
+                                             const kk_xs_dev& xs /* row-sharded context: the sum over the ranks follows (kk_xsync.h) */, long long timeout_ticks,
+                                             bool give_up_late = false /* test hook: this rank publishes its partial of THIS reduction and then declares the launch lost */) {
     const int G = gridDim.x;
     const unsigned epoch = ebase + (unsigned)step + 1u;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(sync, 0, 2 * G * KK_SYNC_LINE, 0x00020000);
@@ -122,6 +123,10 @@ __device__ __forceinline__ bool grid_collect(int step, unsigned ebase, char* __r
         }
         if (XS && xs.world > 0) {   // level 2: every block of this rank holds the same bits of the rank's partial -- now the sum over the ranks
             double t2 = 0;
+            if (good && give_up_late) {   // what a rank looks like to its peers when ITS wait for one of them ran out a moment before that peer arrived
+                if (blockIdx.x == 0) xs_publish(xs, (unsigned)step, 1, total);
+                good = 0;
+            }
             if (good && !xs_allreduce(xs, (unsigned)step, 1, total, err, timeout_ticks, t2)) good = 0;
             total = t2;   // (lane 0: value 0)
             if (!good && lane == 0) xs_abort(xs);   // whatever went wrong on this chip, the peers must not wait for it
@@ -235,7 +240,7 @@ __global__ __launch_bounds__(PT) void k_mgs_persist(const double* __restrict__ V
                                                     unsigned ebase, int normalize, double* __restrict__ ok_out, double token, kk_xs_dev xs, long long timeout_ticks) {
     __shared__ double sm[PT / 64];
     extern __shared__ d2 park[];   // NL * PT double2 (dynamic): the parked grid-rows of the current basis vector
-    if (fault && blockIdx.x == 0) {   // test hook (option "persist_fault"): block 0 behaves like a block whose spin ran out
+    if (fault == 1 && blockIdx.x == 0) {   // test hook (option "persist_fault"): block 0 behaves like a block whose spin ran out
         if (threadIdx.x == 0) { __hip_atomic_store(err, 1, RLX_AGENT); if (XS) xs_abort(xs); }
         return;
     }
@@ -315,7 +320,7 @@ __global__ __launch_bounds__(PT) void k_mgs_persist(const double* __restrict__ V
         persist_step<NV, NL, NR, PT, B, NTPREV, true, true>(wr, qk, qpre, col_rsrc(qp, ld), col_rsrc(qp, ld), sp, sbytes, voff, lq, a0, a1);
         if (nrm_out3) {
             grid_publish<PT>(a0 + a1, nsteps, ebase, sync, sm, gstride);
-            if (!grid_collect<PT, XS>(nsteps, ebase, sync, err, sm, &total, gstride, xs, timeout_ticks)) return;
+            if (!grid_collect<PT, XS>(nsteps, ebase, sync, err, sm, &total, gstride, xs, timeout_ticks, XS && fault == 2 /* option "persist_fault_late" */)) return;
             // every block holds the same bits of |w|^2: the normalised commit below needs no second exchange
             const double rt = sqrt(total);
             inv = 1.0 / rt;
@@ -327,7 +332,10 @@ __global__ __launch_bounds__(PT) void k_mgs_persist(const double* __restrict__ V
     // here, so that either every block writes its rows of w back or (up to the microsecond around a 3 s timeout) none does
     // and HBM still holds the input -- the host then repeats the sweep on the launch-per-vector route (persist_check).
     // The completion token travels with the scalars of the sweep (one read-back instead of a second one for the flag).
+    // Across ranks the abort word plays the part of the flag: a rank that arrives late passes the last reduction on the partials its peers
+    // left before they gave up on it (kk_xsync.h).
     if (__hip_atomic_load(err, RLX_AGENT)) return;
+    if (XS && xs.world > 0 && xs_aborted(xs)) return;
     if (blockIdx.x == 0 && threadIdx.x == 0) { ok_out[0] = token; ok_out[1] = scale ? 1.0 : inv; }   // SC_PERSIST_OK, SC_XS
     // `normalize`: scale!!(w, 1/|w|) of the NEXT expand! (factorizations/lanczos.jl:257, arnoldi.jl:209; orthonormalize!!
     // orthonormal.jl:522-527) folded into the write-back -- the same product w[i] * (1/|w|) k_scal forms, so the
@@ -463,6 +471,7 @@ int kk_launch_mgs_persist(kk_ctx ctx, const double* V, int64_t ld, int m, int ns
     double token = ctx->persist_token;
     double* ok_out = ctx->ws + WS_SCAL + SC_PERSIST_OK;
     kk_xs_dev xs = kk_xs_launch_args(ctx, (unsigned)(m * nsweeps) + (nrm_out3 ? 1u : 0u));   // one cross-rank reduction per grid reduction (row-sharded context)
+    if (!fault && ctx->persist_fault_late > 0 && xs.world > 0 && nrm_out3) { --ctx->persist_fault_late; fault = 2; }
     long long timeout_ticks = kk_persist_timeout_ticks(ctx, ld, m * nsweeps, xs.world > 0);
     void* args[] = {(void*)&V, (void*)&ld, (void*)&m, (void*)&nsweeps, (void*)&w, (void*)&carry_q, (void*)&carry_s,
                     (void*)&out_s, (void*)&out_stride, (void*)&nrm_out3, (void*)&sync, (void*)&err, (void*)&fault, (void*)&gstride,

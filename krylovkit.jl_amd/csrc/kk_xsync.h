@@ -11,11 +11,16 @@
 // Tags count the reductions of the communicator's life (identical on all ranks: SPMD call sequence), the set is tag & 1:
 // a fast rank may publish reduction t + 1 while a slow one still reads t; it cannot reach t + 2 before the slow one has
 // published t + 1, i.e. has finished reading t -- across launches too, which is why the parity follows the tag and not the
-// step of the launch.  A slot always holds the tag of the last write (tag - 2 or older): wrap-around of the 32-bit tag is
+// step of the launch.  ("Finished reading" holds for ALL blocks of the slow rank, not only for the publishing block 0: a cross-rank
+// reduction follows the level-1 reduction of its step, which block 0 cannot complete before every block of its rank has published
+// its level-1 partial, i.e. has left the poll of reduction t.)  A slot always holds the tag of the last write (tag - 2 or older): wrap-around of the 32-bit tag is
 // harmless, the area is zeroed once at creation (first tags 1, 2).
 // A rank that gives up (barrier timeout on its chip, test hook) stores the id of the launch into the error word of every
 // peer's area: the peers stop spinning at once, nobody commits, every rank repeats the sweep on the launch-per-vector route
 // (whose all-reduces then re-align the ranks).  Launch ids are unique, so the word is never cleared.
+// A LATE rank finds the partials of the others in its area although they have given up waiting for it: a reduction therefore only
+// succeeds while the abort word is clean, and the kernels ask once more (xs_aborted) before they commit -- otherwise the late rank
+// would commit the sweep its peers are repeating, and the ranks' collectives would no longer pair up.
 #pragma once
 #include "kk_internal.h"
 #include "kk_device.h"
@@ -32,6 +37,23 @@ __device__ __forceinline__ void xs_abort(const kk_xs_dev& xs) {
     for (int r = 0; r < xs.world; ++r)
         __builtin_amdgcn_raw_buffer_store_b32(xs.launch, xs_rsrc(xs.table[r]), KK_XS_ERR_OFFSET, 0, KK_XS_AUX);
 }
+// has a rank (this one included) declared launch `xs.launch` lost?
+__device__ __forceinline__ bool xs_aborted(const kk_xs_dev& xs) {
+    return __builtin_amdgcn_raw_buffer_load_b32(xs_rsrc((unsigned long long)xs.mine), KK_XS_ERR_OFFSET, 0, KK_XS_AUX) == xs.launch;
+}
+// block 0, wave 0: the rank's partial of value v (lane v < nval) into slot (v, my rank) of every rank's area
+__device__ __forceinline__ void xs_publish(const kk_xs_dev& xs, unsigned red, int nval, double local) {
+    const int lane = threadIdx.x & 63;
+    const unsigned tag = xs.tag0 + red;
+    const unsigned set_off = (tag & 1u) * (unsigned)KK_XS_SET_BYTES;
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(local);
+    xs_v4u t;
+    t.x = tag; t.y = (unsigned)(bits >> 32); t.z = (unsigned)bits; t.w = tag;
+    for (int r = 0; r < xs.world; ++r) {   // uniform loop: one store instruction per rank, lanes v < nval active
+        const __amdgpu_buffer_rsrc_t rp = xs_rsrc(xs.table[r]);
+        if (lane < nval) __builtin_amdgcn_raw_buffer_store_b128(t, rp, set_off + (unsigned)(lane * KK_XS_MAX_RANKS + xs.rank) * 16u, 0, KK_XS_AUX);
+    }
+}
 // Called by wave 0 (all 64 lanes) of every block once the rank's partials are known.  `local`: lane v < nval holds the rank's
 // partial of value v (same bits in every block).  On success lane v * 8 .. v * 8 + 7 hold the total of value v; returns false
 // after a timeout, a raised local flag or a peer's abort (the caller raises the local flag and leaves without committing).
@@ -40,15 +62,7 @@ __device__ __forceinline__ bool xs_allreduce(const kk_xs_dev& xs, unsigned red, 
     const int lane = threadIdx.x & 63;
     const unsigned tag = xs.tag0 + red;
     const unsigned set_off = (tag & 1u) * (unsigned)KK_XS_SET_BYTES;
-    if (blockIdx.x == 0) {
-        const unsigned long long bits = (unsigned long long)__double_as_longlong(local);
-        xs_v4u t;
-        t.x = tag; t.y = (unsigned)(bits >> 32); t.z = (unsigned)bits; t.w = tag;
-        for (int r = 0; r < xs.world; ++r) {   // uniform loop: one store instruction per rank, lanes v < nval active
-            const __amdgpu_buffer_rsrc_t rp = xs_rsrc(xs.table[r]);
-            if (lane < nval) __builtin_amdgcn_raw_buffer_store_b128(t, rp, set_off + (unsigned)(lane * KK_XS_MAX_RANKS + xs.rank) * 16u, 0, KK_XS_AUX);
-        }
-    }
+    if (blockIdx.x == 0) xs_publish(xs, red, nval, local);
     const __amdgpu_buffer_rsrc_t rm = xs_rsrc((unsigned long long)xs.mine);
     const bool active = (lane >> 3) < nval && (lane & 7) < xs.world;
     const long long t0 = wall_clock64();
@@ -58,7 +72,7 @@ __device__ __forceinline__ bool xs_allreduce(const kk_xs_dev& xs, unsigned red, 
         const xs_v4u g = __builtin_amdgcn_raw_buffer_load_b128(rm, set_off + (unsigned)lane * 16u, 0, KK_XS_AUX);
         const unsigned xerr = __builtin_amdgcn_raw_buffer_load_b32(rm, KK_XS_ERR_OFFSET, 0, KK_XS_AUX);
         const bool ok = !active || (g.x == tag && g.w == tag);
-        if (__all(ok)) {
+        if (__all(ok) && xerr != xs.launch) {
             x = active ? __longlong_as_double((long long)(((unsigned long long)g.y << 32) | g.z)) : 0.0;
             break;
         }

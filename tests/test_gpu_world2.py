@@ -147,6 +147,20 @@ def test_world2_persistent_kernels_recover_when_one_rank_loses_a_launch(tmp_path
         assert reps[0][k] == reps[1][k], k
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_persistent_kernels_do_not_commit_what_a_peer_gave_up_on(tmp_path, world):
+    """one rank declares a launch lost at its LAST cross-rank reduction, its own partial already out (test hook "persist_fault_late"):
+    the peers find all partials in their areas -- as a rank does that arrives after the others' patience ran out -- and must leave
+    without committing too: every rank counts the timeout (asserted in the workers), every rank repeats the sweep, the scalars stay
+    bit-identical across ranks and within 1e-10 of the oracle.  (A peer that committed would skip the all-reduces of the repeated
+    sweep: the run would hang and this test time out.)"""
+    reps = run_world("xsync_late", world, tmp_path, timeout=300, retries=1)
+    keys = [k for k in reps[0] if "." in k and isinstance(reps[0][k], list)]
+    assert len(keys) == 6
+    for k in keys:
+        assert all(r[k] == reps[0][k] for r in reps), k
+
+
 def test_world2_persistent_kernels_full_size_shards(tmp_path):
     """2 x 5 M rows (config-2 shape, k_mgs_persist) and 2 x 1 M rows (config-3 shape, k_mgs_panel) with default options:
     the auto mode takes the persistent kernels on the sharded context, alpha / beta / H against the CPU twin at 1e-10"""

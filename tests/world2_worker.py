@@ -319,7 +319,7 @@ elif scenario == "solvers2":
     assert einfo.converged == 1 and (einfo.numiter, einfo.numops) == (eoinfo.numiter, eoinfo.numops)
     assert np.linalg.norm(wg - wo) <= 1e-9 * np.linalg.norm(wo)
     report["exponentiate"] = [einfo.numiter, einfo.numops]
-elif scenario in ("xsync", "xsync_fault"):
+elif scenario in ("xsync", "xsync_fault", "xsync_late"):
     # The persistent MGS kernels on a row-sharded context: the sum over the ranks happens INSIDE the launch -- block 0 of a rank
     # stores the rank's partial into every peer's IPC-mapped sync area, every block adds the W partials in rank order
     # (csrc/kk_xsync.h; reference order src/orthonormal.jl:414-439, factorizations/lanczos.jl:325-338, arnoldi.jl:239-245).
@@ -336,8 +336,12 @@ elif scenario in ("xsync", "xsync_fault"):
     opA = kd.NativeShardedOperator(A[lo:hi], part, ctx, symmetric=True)
     opC = kd.NativeShardedOperator(Cd[lo:hi], part, ctx)
     steps = 24
-    fault_at = {7, 15} if scenario == "xsync_fault" else set()
-    for route, lookahead in (("persist", 1), ("panel", 1), ("panel_p", 1), ("persist", 0)):
+    fault_at = {7, 15} if scenario != "xsync" else set()
+    # xsync_late: the faulting rank gives up at the LAST reduction of its launch with its partial already published -- to its peers it
+    # looks like a rank whose wait ran out a moment before they arrived: they find every partial in their area and must NOT commit
+    # (abort word re-read before the commit), or the ranks' collectives stop pairing up.  k_mgs_persist carries the hook.
+    routes = (("persist", 1), ("persist", 0)) if scenario == "xsync_late" else (("persist", 1), ("panel", 1), ("panel_p", 1), ("persist", 0))
+    for route, lookahead in routes:
         ctx.set_option("mgs_mode", 2 if route == "panel_p" else 0)      # panel_p: panels of 2-3 vectors per reduction (auto mode), else the strict order
         ctx.set_option("mgs_panel", 0 if route == "persist" else 1)
         ctx.set_option("panel_min_rows", 0); ctx.set_option("persist_min_rows", 0)
@@ -353,7 +357,7 @@ elif scenario in ("xsync", "xsync_fault"):
             s0 = comm.stats()
             for i in range(steps):
                 if i in fault_at and rank == (i % world):
-                    ctx.set_option("persist_fault", 1)     # ONE rank loses a launch: its peers must give up with it (abort word), all repeat the sweep
+                    ctx.set_option("persist_fault_late" if scenario == "xsync_late" else "persist_fault", 1)     # ONE rank loses a launch: its peers must give up with it (abort word), all repeat the sweep
                 f = kk.expand_(it, f)
             s1 = comm.stats()
             ctx.prof_enable(0)
