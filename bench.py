@@ -598,7 +598,7 @@ def main():
         if name == "block":
             gb = build_block(NY)     # configs[4]: BlockLanczos bs = 16, 10M rows
             return dict(sweep=gb["sweep"], units=gb["sweep_its"], keep=gb,
-                        model={"k_block_update": (sum(8 * kn + 256 for kn in range(2 * gb["bs"], gb["Kb"] + gb["bs"] + 1, gb["bs"])) + 256) * float(gb["n_local"])},
+                        model={"k_block_update": (sum(8 * kn + 256 for kn in range(2 * gb["bs"], gb["Kb"] + gb["bs"] + 1, gb["bs"])) + 2 * 256) * float(gb["n_local"])},   # (+ the two 16 -> 16 column back-substitutions that really run: below)
                         alg=gb["alg_sweep"], meta={"metric": "block_lanczos_steps_per_second", "unit": "block steps/s (bs=16, 10M rows)", "workload": gb["workload"]})
         if name == "gkl":
             gg = build_gkl(NY)       # configs[3]: svdsolve(GKL) 5M x 1M sparse random (one GPU holds the whole map)
@@ -814,8 +814,10 @@ def main():
     if args.config == "block":
         # the two basis-streaming classes of the block step.  k_block_update_lds: W <- W - V P with the whole basis (kn = 32 ..
         # 112 columns after the push) streamed once and the 16-column residual block read and written: (8 kn + 256) N bytes per
-        # launch, + one 16 -> 16 column launch in initialize (256 N); launches skipped on the device (second CholQR2
-        # back-substitution, a few microseconds each) are in the launch count but carry no bytes.  k_block_gram: counters only.
+        # launch, + TWO 16 -> 16 column launches per sweep that run in full (256 N each: the second CholQR2 round of the start block
+        # in initialize and of the first residual block, which no commit has normalised yet -- 485 us each in profiles/r05_block_kernel_stats.csv;
+        # rounds 3-4 counted one); the other second-round back-substitutions are skipped on the device (5 us each): in the launch count,
+        # no bytes.  k_block_gram: counters only.
         tj, note = stamped_traffic("traffic_configs.json")
         tcfg = (tj or {}).get("configs", {}).get("block", {}) if tj else {}
         per_class = {}
@@ -823,7 +825,7 @@ def main():
             ms, n = ctx.prof_get(cls)
             if n:
                 per_class[cls] = (ms, n)
-        model = {"k_block_update": (sum(8 * kn + 256 for kn in range(2 * bs, Kb + bs + 1, bs)) + 256) * float(n_local)}
+        model = {"k_block_update": (sum(8 * kn + 256 for kn in range(2 * bs, Kb + bs + 1, bs)) + 2 * 256) * float(n_local)}
         if per_class:
             dom = max(per_class, key=lambda c_: per_class[c_][0])
             ms, n = per_class[dom]
