@@ -229,6 +229,9 @@ KK_API int kk_ctx_set_option(kk_ctx c, const char* key, double value) {
     } else if (!strcmp(key, "spmm_dia_lines")) {
         KK_CHECK(value >= 2 && value <= 4096, KK_ERR_INVALID, "spmm_dia_lines must be in 2..4096");
         c->spmm_dia_lines = (int)value;
+    } else if (!strcmp(key, "spmm_dia_al")) {
+        KK_CHECK(value == 0 || value == 2 || value == 4, KK_ERR_INVALID, "spmm_dia_al must be 0, 2 or 4");
+        c->spmm_dia_al = (int)value;
     } else if (!strcmp(key, "spmm_cols")) {
         KK_CHECK(value == 4 || value == 8 || value == 16, KK_ERR_INVALID, "spmm_cols must be 4, 8 or 16");
         c->spmm_cols = (int)value;
@@ -288,6 +291,7 @@ KK_API int kk_ctx_get_option(kk_ctx c, const char* key, double* value) {
     else if (!strcmp(key, "bu_mfma")) *value = c->bu_mfma;
     else if (!strcmp(key, "panel_lag")) *value = c->panel_lag;
     else if (!strcmp(key, "norm_commits_consumed")) *value = (double)c->norm_commits_consumed;
+    else if (!strcmp(key, "spmm_dia_al_launches")) *value = (double)c->spmm_dia_al_launches;
     else if (!strcmp(key, "persist_timeout_ms")) *value = c->persist_timeout_ms;
     else if (!strcmp(key, "xsync")) *value = c->xsync;
     else if (!strcmp(key, "xsync_active")) *value = kk_xs_on(c) ? 1 : 0;
@@ -322,6 +326,7 @@ KK_API int kk_ctx_get_option(kk_ctx c, const char* key, double* value) {
     else if (!strcmp(key, "spmv_dia_aligned")) *value = c->spmv_dia_aligned;
     else if (!strcmp(key, "spmm_dia")) *value = c->spmm_dia;
     else if (!strcmp(key, "spmm_dia_lines")) *value = c->spmm_dia_lines;
+    else if (!strcmp(key, "spmm_dia_al")) *value = c->spmm_dia_al;
     else if (!strcmp(key, "spmm_cols")) *value = c->spmm_cols;
     else if (!strcmp(key, "spmm_rpl")) *value = c->spmm_rpl;
     else if (!strcmp(key, "gram_bpc")) *value = c->gram_bpc;

@@ -153,6 +153,7 @@ struct kk_ctx_s {
     int spmv_dia_const = 1;      // ... value-free kernel when the stencil has constant coefficients (0: always stream the diagonals)
     int spmm_dia = 1;            // multi-column apply of a detected grid stencil: sweeping diagonal kernel (0: ELL gather kernel)
     int spmm_dia_lines = 16;     // ... grid lines per wave sweep
+    int spmm_dia_al = 0;         // ... aligned 16-byte form (k_spmm_dia_al): columns per wave (2 / 4), 0 = the 8-byte form
     int spmm_cols = 16;          // SpMM on ELL: right-hand sides per launch (16, 8 or 4)
     int bu_mfma = 0;             // block update W = beta W + alpha V S through the MFMA kernel (k_block_update_mfma: transposed product, 16-byte operand loads)
     int bu_prefetch = 1;         // block update kernel: 1 = coefficient panel in LDS (default), 0 = scalar-load kernel of round 1, 8/16/24 = deep-prefetch experiments
@@ -217,6 +218,7 @@ struct kk_ctx_s {
     int persist_fault = 0;         // test hook (option "persist_fault"): the next N persistent launches time out artificially
     int persist_fault_late = 0;    // test hook (option "persist_fault_late"): in the next N k_mgs_persist launches of a cross-rank context this rank publishes
                                    // its partial of the LAST reduction and then declares the launch lost (a peer that arrives after this rank's patience ran out)
+    int64_t spmm_dia_al_launches = 0;    // launches of the aligned sweeping SpMM (diagnostics: "spmm_dia_al_launches")
     int64_t norm_commits_consumed = 0;   // normalised residual columns taken over by scale!!(r, 1 / beta) of a restart without a pass (diagnostics)
     int fold_scale = 1;          // persistent kernel stores r / |r| at its commit when an expand! ends with it (no scale pass in the next step)
     int fuse_passes = 1;         // fuse unproject(pass i) with project(pass i+1)

@@ -655,6 +655,100 @@ __global__ __launch_bounds__(KK_TPB) void k_spmm_dia(const double* __restrict__ 
     }
 }
 
+// The same sweep with ALIGNED 16-byte window loads and the next line in flight while the current one is multiplied (5-point stencil,
+// constant coefficients, EVEN line length, lines starting at phase 0, vectors below 2 GB).  k_spmm_dia moves 8 bytes per lane and load
+// (62 of 64 lanes, strips that start 8 bytes before a 16-byte boundary), waits for the line it has just requested, and carries 16
+// columns x 3 lines in registers: 4.2 TB/s on the 10M-row block step where the read+write stream kernels reach 5.6-5.8.  Here
+//   * a lane owns the positions 2l, 2l + 1 of its wave's 128-wide strip: ONE 16-byte load per column and line, one 16-byte store;
+//   * the +-1 neighbours are the lanes next door (DPP wave shifts of the centre pair); only lane 0 / lane 63 fetch theirs -- one 8-byte
+//     buffer load per column and line whose out-of-range offset switches the other 62 lanes off in the address unit (no branch);
+//   * a wave carries NBW (2 / 4) of the block's columns (blockIdx.y = column group: the columns are independent and the value-free
+//     stencil has no per-row data to share between them) through a FOUR-line window: line t + 2 is requested before line t is
+//     multiplied, and the window rotates by renaming (the loop is unrolled four times) instead of by register moves.
+// Same operands in the same order as k_spmm_dia: bit-identical results.
+template <int NBW> struct dia_line { d2 v[NBW]; double e[NBW]; };
+template <int CTRL>
+__device__ __forceinline__ double dia_wave_shift_old(double old, double v) {   // 0x138: lane i takes lane i - 1, lane 0 takes `old`; 0x130: lane i takes lane i + 1, lane 63 `old`
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <int NBW, bool NTY>
+__global__ __launch_bounds__(KK_TPB, (NBW <= 2 ? 6 : 3)) void k_spmm_dia_al(int64_t D, int64_t nrows, const double* __restrict__ X, int64_t ldx, double* __restrict__ Y,
+                                                        int64_t ldy, int nb, int strips, int lines, int64_t Tlo, int64_t T, int64_t row_lo,
+                                                        int64_t row_hi, dia_cst cst) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wv = (int64_t)blockIdx.x * (KK_TPB / 64) + (threadIdx.x >> 6);
+    const int strip = (int)(wv % strips);
+    const int64_t t0 = Tlo + (wv / strips) * lines;
+    if (t0 >= T) return;
+    const int64_t t1 = imin(t0 + lines, T);
+    const int j0 = (int)blockIdx.y * NBW;
+    const int64_t p0 = (int64_t)strip * 128, p = p0 + 2 * lane;          // position of the lane's pair inside the grid line
+    const bool own = p < D;                                              // (D even: a pair is inside the line or outside)
+    const int64_t pe = lane == 0 ? p0 - 1 : p0 + 128;                    // lane 0: left neighbour of the strip, lane 63: right neighbour
+    const bool eown = (lane == 0 && strip > 0) || (lane == 63 && pe < D);
+    __amdgpu_buffer_rsrc_t rx[NBW], ry[NBW];
+#pragma unroll
+    for (int j = 0; j < NBW; ++j) {   // (the launcher sends whole groups of NBW columns here)
+        rx[j] = __builtin_amdgcn_make_buffer_rsrc((void*)(X + (int64_t)(j0 + j) * ldx), 0, (int)(nrows * 8), 0x00020000);
+        ry[j] = __builtin_amdgcn_make_buffer_rsrc((void*)(Y + (int64_t)(j0 + j) * ldy), 0, (int)(nrows * 8), 0x00020000);
+    }
+    const unsigned off_none = 0xfffffff0u;
+    typedef unsigned v4u_ __attribute__((ext_vector_type(4)));
+    // line t of the window: the pairs two lines ahead of the line being multiplied, the strip's edge elements (needed when the line is
+    // the CENTRE of the window) one line ahead.  Lines outside the operator read as zero (a negative 32-bit offset wraps beyond the records)
+    auto fetch_pairs = [&](dia_line<NBW>& L, int64_t t) {
+        const unsigned vo = (t <= t1 && own) ? (unsigned)((t * D + p) * 8) : off_none;
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) {
+            const v4u_ q = __builtin_amdgcn_raw_buffer_load_b128(rx[j], vo, 0, 0);
+            L.v[j] = d2{__hiloint2double((int)q.y, (int)q.x), __hiloint2double((int)q.w, (int)q.z)};
+        }
+    };
+    auto fetch_edges = [&](dia_line<NBW>& L, int64_t t) {
+        const unsigned eo = (t < t1 && eown) ? (unsigned)((t * D + pe) * 8) : off_none;
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) {
+            const dia_v2u q2 = __builtin_amdgcn_raw_buffer_load_b64(rx[j], eo, 0, 0);
+            L.e[j] = __hiloint2double((int)q2.y, (int)q2.x);
+        }
+    };
+    // coefficients of the lane's two positions: the -1 entry does not exist at position 0, the +1 entry not at position D - 1
+    const double cS = cst.c[0], cW0 = p == 0 ? 0.0 : cst.c[1], cW1 = cst.c[1], cC = cst.c[2], cE0 = cst.c[3], cE1 = (p + 2 == D) ? 0.0 : cst.c[3], cN = cst.c[4];
+    auto line = [&](const dia_line<NBW>& Lm, const dia_line<NBW>& L0, const dia_line<NBW>& Lp, int64_t t) {
+        const int64_t r = t * D + p;
+        // (row_lo, row_hi even: both rows of the pair or none; a store that is not due is switched off by its offset, like the loads)
+        const unsigned so = (own && r >= row_lo && r < row_hi) ? (unsigned)(r * 8) : off_none;
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) {
+            const double left = dia_wave_shift_old<0x138>(L0.e[j], L0.v[j].y), right = dia_wave_shift_old<0x130>(L0.e[j], L0.v[j].x);
+            double ax = cS * Lm.v[j].x;
+            ax = fma(cW0, left, ax);
+            ax = fma(cC, L0.v[j].x, ax);
+            ax = fma(cE0, L0.v[j].y, ax);
+            ax = fma(cN, Lp.v[j].x, ax);
+            double ay = cS * Lm.v[j].y;
+            ay = fma(cW1, L0.v[j].x, ay);
+            ay = fma(cC, L0.v[j].y, ay);
+            ay = fma(cE1, right, ay);
+            ay = fma(cN, Lp.v[j].y, ay);
+            v4u_ q;
+            q.x = (unsigned)__double2loint(ax); q.y = (unsigned)__double2hiint(ax); q.z = (unsigned)__double2loint(ay); q.w = (unsigned)__double2hiint(ay);
+            // (non-temporal for long blocks: see k_spmm_dia)
+            if (NTY) __builtin_amdgcn_raw_buffer_store_b128(q, ry[j], so, 0, 2); else __builtin_amdgcn_raw_buffer_store_b128(q, ry[j], so, 0, 0);
+        }
+    };
+    dia_line<NBW> A, B, C, E;
+    fetch_pairs(A, t0 - 1); fetch_pairs(B, t0); fetch_edges(B, t0); fetch_pairs(C, t0 + 1);
+    for (int64_t t = t0;;) {
+        fetch_pairs(E, t + 2); fetch_edges(C, t + 1); line(A, B, C, t); if (++t >= t1) break;
+        fetch_pairs(A, t + 2); fetch_edges(E, t + 1); line(B, C, E, t); if (++t >= t1) break;
+        fetch_pairs(B, t + 2); fetch_edges(A, t + 1); line(C, E, A, t); if (++t >= t1) break;
+        fetch_pairs(C, t + 2); fetch_edges(B, t + 1); line(E, A, B, t); if (++t >= t1) break;
+    }
+}
+
 // ranged launches: rows [r0, r1) of an ELL / diagonal operator; partial sums go to pd / pn + *nblk_io, *nblk_io advances
 static void launch_spmv_ell_rows(kk_ctx ctx, const kk_sparse_dev& M, const double* x, double* y, const spmv_epi& e, int64_t r0,
                                  int64_t r1, double* pd, double* pn, int* nblk_io, int max_blocks) {
@@ -846,7 +940,28 @@ int kk_launch_spmm(kk_ctx ctx, const kk_sparse_dev& M, const double* X, int64_t 
         const int lines = ctx->spmm_dia_lines;
         const int64_t waves = (int64_t)strips * ((T - Tlo + lines - 1) / lines);
         dim3 g((unsigned)((waves + KK_TPB / 64 - 1) / (KK_TPB / 64))), b(KK_TPB);
-        int j0 = 0;
+        // aligned form (k_spmm_dia_al): one launch for all columns, NBW of them per wave
+        const int nbw = ctx->spmm_dia_al;
+        int j_first = 0;
+        if ((nbw == 2 || nbw == 4) && cc && M.dia_pts == 5 && M.dia_D % 2 == 0 && M.dia_phase == 0 && M.nrows * 8 < (int64_t)2000000000 && ldx % 2 == 0 &&
+            ldy % 2 == 0 && ((uintptr_t)X & 15) == 0 && ((uintptr_t)Y & 15) == 0 && row_lo % 2 == 0 && row_hi % 2 == 0) {
+            const int strips2 = (int)((M.dia_D + 127) / 128);
+            const int lines2 = ctx->spmm_dia_lines;
+            const int64_t waves2 = (int64_t)strips2 * ((T - Tlo + lines2 - 1) / lines2);
+            const int nfull = nb / nbw * nbw;   // whole groups of nbw columns; the others go through the 8-byte form below
+            dim3 g2((unsigned)((waves2 + KK_TPB / 64 - 1) / (KK_TPB / 64)), (unsigned)(nfull / nbw)), b2(KK_TPB);
+            kk_prof_scope ps(ctx, "k_spmm_dia");
+#define DIA_AL(NBWT, NTY) hipLaunchKernelGGL((k_spmm_dia_al<NBWT, NTY>), g2, b2, 0, ctx->stream, M.dia_D, M.nrows, X, ldx, Y, ldy, nfull, strips2, lines2, Tlo, T, row_lo, row_hi, cst)
+            const bool nty = M.nrows >= ctx->nt_store_rows;
+            if (nfull > 0) {
+                ++ctx->spmm_dia_al_launches;
+                if (nbw == 4) { if (nty) DIA_AL(4, true); else DIA_AL(4, false); }
+                else { if (nty) DIA_AL(2, true); else DIA_AL(2, false); }
+            }
+#undef DIA_AL
+            j_first = nfull;
+        }
+        int j0 = j_first;
         while (j0 < nb) {
             const int rem = nb - j0;
             const int n = std::min(rem > 8 ? std::min(rem, 16) : rem, ctx->spmm_cols);

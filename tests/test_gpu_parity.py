@@ -690,6 +690,48 @@ def test_block_apply_grid_stencil_sweep(kk, ko, ctx, nine):
     np.testing.assert_allclose(np.stack([S.download(4 + j) for j in range(4)], 1), R @ X, rtol=1e-12, atol=1e-12)
 
 
+def test_block_apply_constant_stencil_aligned_sweep(kk, ko, ctx):
+    """the aligned form of the sweeping multi-column apply (k_spmm_dia_al: 16-byte window loads, +-1 neighbours from the lanes next
+    door, next line in flight, 2 / 4 columns per wave) against SciPy and BITWISE against the 8-byte form, for value-free 5-point
+    stencils with four different off-diagonal coefficients (a slot mix-up cannot hide), line lengths around the 128-position strip,
+    block widths with and without a remainder group, sweeps of 2 / 5 / 16 lines per wave; an odd line length falls back silently"""
+    from krylovkit_hip._lib import check
+    rng = np.random.default_rng(29)
+    al_default = ctx.get_option("spmm_dia_al")
+    try:
+        for nx, ny in ((64, 70), (128, 40), (130, 33), (254, 21), (256, 19), (1000, 12), (62, 50), (65, 40)):
+            A = ko.convection_diffusion_2d(nx, ny) if nx != 128 else ko.laplacian_2d(nx, ny)
+            n = A.shape[0]
+            op = kk.SparseOperator(A, ctx)
+            assert "const" in op.info()["format"], op.info()
+            for nb in (16, 4, 5, 3, 9):
+                X = rng.standard_normal((n, nb))
+                S = kk.DeviceBasis(n, 2 * nb, ctx)
+                for j in range(nb):
+                    S.upload(j, X[:, j])
+                ref = None
+                for al, lines in ((0, 16), (4, 16), (2, 16), (4, 2), (2, 5)):
+                    ctx.set_option("spmm_dia_al", al); ctx.set_option("spmm_dia_lines", lines)
+                    for j in range(nb):
+                        S[nb + j].rand_(5 + j)          # (stale output must not pass for output)
+                    l0 = ctx.get_option("spmm_dia_al_launches")
+                    ctx.prof_reset(); ctx.prof_enable(1)
+                    check(S._lib.kk_block_apply(op.handle, S.handle, 0, S.handle, nb, nb))
+                    ctx.prof_enable(0)
+                    assert ctx.prof_get("k_spmm_dia")[1] > 0
+                    took = ctx.get_option("spmm_dia_al_launches") - l0
+                    assert took == (1 if (al and nx % 2 == 0 and nb >= al) else 0), (nx, nb, al, took)
+                    Y = np.stack([S.download(nb + j) for j in range(nb)], 1)
+                    if ref is None:
+                        ref = Y
+                        np.testing.assert_allclose(Y, A @ X, rtol=1e-13, atol=1e-13)
+                    else:
+                        assert np.array_equal(Y, ref), (nx, ny, nb, al, lines, float(np.max(np.abs(Y - ref))))
+                S.free()
+    finally:
+        ctx.set_option("spmm_dia_al", al_default); ctx.set_option("spmm_dia_lines", 16)
+
+
 def test_grid_stencil_single_vector_apply_and_fused_epilogues(kk, ko, ctx):
     """The diagonal SpMV of detected grid stencils (k_spmv_dia) against SciPy, the affine form, and -- through the fused
     Lanczos / CG epilogues (inner products, v_prev term, norms, speculative scaled apply) -- against the oracle; every case also
