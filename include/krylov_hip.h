@@ -132,6 +132,9 @@ typedef enum {
  * "nt_store_rows" (results of sparse applies on at least this many rows are written with non-temporal stores, default 4e6),
  * "gram_bpc", "gram2_chunk", "gram2_pipe", "gram2_bpc", "spmm_bpc", "spmm_cols", "spmm_rpl", "spmm_dia_lines", "bu_prefetch", "gram_nt", "persist_nt",
  * "persist_lds", "persist_min_rows", "spmv_dia_pairs" (row pairs per lane of the diagonal SpMV: 0 = by size, 1 / 2 / 4),
+ * "spmm_dia_al" (default 2: the sweeping multi-column apply of a value-free 5-point stencil with an even line length runs in its
+ * aligned 16-byte form, 2 or 4 columns per wave; 0 = the 8-byte form; bit-identical), "spmm_dia_al_lines" (default 4: grid lines per
+ * wave sweep of that form),
  * "spmv_dia_aligned" (default 1: 5-point stencils with an even line length load their far neighbours as aligned 16-byte pairs
  * and take the +-1 neighbours from the lanes next door; bit-identical to 0), "panel_lag" (default 0; 1 = panel sweeps outside the
  * strict order through the cross-panel lag-1 kernel -- exact algebra, measured slower at every length, kept as the record),

@@ -229,6 +229,9 @@ KK_API int kk_ctx_set_option(kk_ctx c, const char* key, double value) {
     } else if (!strcmp(key, "spmm_dia_lines")) {
         KK_CHECK(value >= 2 && value <= 4096, KK_ERR_INVALID, "spmm_dia_lines must be in 2..4096");
         c->spmm_dia_lines = (int)value;
+    } else if (!strcmp(key, "spmm_dia_al_lines")) {
+        KK_CHECK(value >= 1 && value <= 4096, KK_ERR_INVALID, "spmm_dia_al_lines must be in 1..4096");
+        c->spmm_dia_al_lines = (int)value;
     } else if (!strcmp(key, "spmm_dia_al")) {
         KK_CHECK(value == 0 || value == 2 || value == 4, KK_ERR_INVALID, "spmm_dia_al must be 0, 2 or 4");
         c->spmm_dia_al = (int)value;
@@ -327,6 +330,7 @@ KK_API int kk_ctx_get_option(kk_ctx c, const char* key, double* value) {
     else if (!strcmp(key, "spmm_dia")) *value = c->spmm_dia;
     else if (!strcmp(key, "spmm_dia_lines")) *value = c->spmm_dia_lines;
     else if (!strcmp(key, "spmm_dia_al")) *value = c->spmm_dia_al;
+    else if (!strcmp(key, "spmm_dia_al_lines")) *value = c->spmm_dia_al_lines;
     else if (!strcmp(key, "spmm_cols")) *value = c->spmm_cols;
     else if (!strcmp(key, "spmm_rpl")) *value = c->spmm_rpl;
     else if (!strcmp(key, "gram_bpc")) *value = c->gram_bpc;

@@ -153,7 +153,8 @@ struct kk_ctx_s {
     int spmv_dia_const = 1;      // ... value-free kernel when the stencil has constant coefficients (0: always stream the diagonals)
     int spmm_dia = 1;            // multi-column apply of a detected grid stencil: sweeping diagonal kernel (0: ELL gather kernel)
     int spmm_dia_lines = 16;     // ... grid lines per wave sweep
-    int spmm_dia_al = 0;         // ... aligned 16-byte form (k_spmm_dia_al): columns per wave (2 / 4), 0 = the 8-byte form
+    int spmm_dia_al = 2;         // ... aligned 16-byte form (k_spmm_dia_al): columns per wave (2 / 4), 0 = the 8-byte form
+    int spmm_dia_al_lines = 4;   // ... and its grid lines per wave sweep (short sweeps win: tools/spmm_dia_ab.py, profiles/r05_spmm_dia_ab.jsonl)
     int spmm_cols = 16;          // SpMM on ELL: right-hand sides per launch (16, 8 or 4)
     int bu_mfma = 0;             // block update W = beta W + alpha V S through the MFMA kernel (k_block_update_mfma: transposed product, 16-byte operand loads)
     int bu_prefetch = 1;         // block update kernel: 1 = coefficient panel in LDS (default), 0 = scalar-load kernel of round 1, 8/16/24 = deep-prefetch experiments

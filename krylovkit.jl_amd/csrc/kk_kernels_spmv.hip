@@ -946,7 +946,7 @@ int kk_launch_spmm(kk_ctx ctx, const kk_sparse_dev& M, const double* X, int64_t 
         if ((nbw == 2 || nbw == 4) && cc && M.dia_pts == 5 && M.dia_D % 2 == 0 && M.dia_phase == 0 && M.nrows * 8 < (int64_t)2000000000 && ldx % 2 == 0 &&
             ldy % 2 == 0 && ((uintptr_t)X & 15) == 0 && ((uintptr_t)Y & 15) == 0 && row_lo % 2 == 0 && row_hi % 2 == 0) {
             const int strips2 = (int)((M.dia_D + 127) / 128);
-            const int lines2 = ctx->spmm_dia_lines;
+            const int lines2 = ctx->spmm_dia_al_lines;
             const int64_t waves2 = (int64_t)strips2 * ((T - Tlo + lines2 - 1) / lines2);
             const int nfull = nb / nbw * nbw;   // whole groups of nbw columns; the others go through the 8-byte form below
             dim3 g2((unsigned)((waves2 + KK_TPB / 64 - 1) / (KK_TPB / 64)), (unsigned)(nfull / nbw)), b2(KK_TPB);

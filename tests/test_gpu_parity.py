@@ -694,12 +694,12 @@ def test_block_apply_constant_stencil_aligned_sweep(kk, ko, ctx):
     """the aligned form of the sweeping multi-column apply (k_spmm_dia_al: 16-byte window loads, +-1 neighbours from the lanes next
     door, next line in flight, 2 / 4 columns per wave) against SciPy and BITWISE against the 8-byte form, for value-free 5-point
     stencils with four different off-diagonal coefficients (a slot mix-up cannot hide), line lengths around the 128-position strip,
-    block widths with and without a remainder group, sweeps of 2 / 5 / 16 lines per wave; an odd line length falls back silently"""
+    block widths with and without a remainder group, sweeps of 1 / 4 / 5 / 16 lines per wave; an odd line length falls back silently"""
     from krylovkit_hip._lib import check
     rng = np.random.default_rng(29)
     al_default = ctx.get_option("spmm_dia_al")
     try:
-        for nx, ny in ((64, 70), (128, 40), (130, 33), (254, 21), (256, 19), (1000, 12), (62, 50), (65, 40)):
+        for nx, ny in ((64, 70), (128, 40), (130, 33), (254, 21), (256, 19), (1000, 12), (66, 80), (65, 80)):
             A = ko.convection_diffusion_2d(nx, ny) if nx != 128 else ko.laplacian_2d(nx, ny)
             n = A.shape[0]
             op = kk.SparseOperator(A, ctx)
@@ -710,8 +710,8 @@ def test_block_apply_constant_stencil_aligned_sweep(kk, ko, ctx):
                 for j in range(nb):
                     S.upload(j, X[:, j])
                 ref = None
-                for al, lines in ((0, 16), (4, 16), (2, 16), (4, 2), (2, 5)):
-                    ctx.set_option("spmm_dia_al", al); ctx.set_option("spmm_dia_lines", lines)
+                for al, lines in ((0, 16), (4, 16), (2, 4), (4, 1), (2, 5)):
+                    ctx.set_option("spmm_dia_al", al); ctx.set_option("spmm_dia_al_lines", lines)
                     for j in range(nb):
                         S[nb + j].rand_(5 + j)          # (stale output must not pass for output)
                     l0 = ctx.get_option("spmm_dia_al_launches")
@@ -729,7 +729,7 @@ def test_block_apply_constant_stencil_aligned_sweep(kk, ko, ctx):
                         assert np.array_equal(Y, ref), (nx, ny, nb, al, lines, float(np.max(np.abs(Y - ref))))
                 S.free()
     finally:
-        ctx.set_option("spmm_dia_al", al_default); ctx.set_option("spmm_dia_lines", 16)
+        ctx.set_option("spmm_dia_al", al_default); ctx.set_option("spmm_dia_al_lines", 4)
 
 
 def test_grid_stencil_single_vector_apply_and_fused_epilogues(kk, ko, ctx):

@@ -37,8 +37,8 @@ def run(reps=20):
 
 ref = None
 for rnd in range(2):
-    for al, lines in ((0, 16), (4, 16), (4, 32), (4, 64), (4, 8), (2, 16), (2, 32), (2, 64)):
-        ctx.set_option("spmm_dia_al", al); ctx.set_option("spmm_dia_lines", lines)
+    for al, lines in ((0, 16), (0, 4), (4, 16), (4, 8), (4, 4), (4, 2), (2, 16), (2, 8), (2, 4), (2, 2), (2, 1)):
+        ctx.set_option("spmm_dia_al", al); ctx.set_option("spmm_dia_al_lines" if al else "spmm_dia_lines", lines)
         dt = min(run() for _ in range(3))
         chk = [S.download(nb + j)[::997].copy() for j in (0, nb - 1)]
         if ref is None:
