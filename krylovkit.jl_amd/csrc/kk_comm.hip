@@ -102,9 +102,10 @@ KK_API int kk_comm_get_unique_id(void* id128) {
 // same on every rank whatever happens locally.
 // ------------------------------------------------------------------------------------------
 namespace {
-struct xs_record {            // what a rank tells the others (14 x 8 bytes)
+struct xs_record {            // what a rank tells the others (16 x 8 bytes)
     int64_t ok, pid, dev, ptr;
     int64_t bus;              // hash of the PCI bus id of the rank's device: ranks that SHARE a GPU find each other by it
+    int64_t cus, dev_cus, xcds;   // CUs the rank's context counts on ("num_cus"), CUs and XCDs of its device
     char handle[72];          // hipIpcMemHandle_t (64 bytes) + padding to a multiple of 8
 };
 static_assert(sizeof(hipIpcMemHandle_t) <= 72 && sizeof(xs_record) % 8 == 0, "xs_record layout");
@@ -119,6 +120,7 @@ static void xs_release(kk_ctx c) {
     if (k->xs_table) (void)hipFree(k->xs_table);
     if (k->xs_mine) (void)hipFree(k->xs_mine);
     k->xs_table = nullptr; k->xs_mine = nullptr; k->xs_active = false;
+    if (k->cus_before > 0) { c->num_cus = k->cus_before; k->cus_before = 0; }   // (the cut belongs to the cross-rank launches: single-rank work gets the chip back)
 }
 static int xs_setup(kk_ctx c) {
     kk_comm_s* k = c->comm;
@@ -136,6 +138,7 @@ static int xs_setup(kk_ctx c) {
         else memcpy(mine.handle, &h, sizeof(h));
     }
     mine.ok = local_ok; mine.pid = (int64_t)getpid(); mine.dev = c->device; mine.ptr = (int64_t)(uintptr_t)k->xs_mine;
+    mine.cus = c->num_cus; mine.dev_cus = c->dev_cus; mine.xcds = c->dev_xcds;
     {
         char bus[64] = {0};
         if (hipDeviceGetPCIBusId(bus, sizeof(bus), c->device) != hipSuccess) { (void)hipGetLastError(); snprintf(bus, sizeof(bus), "dev%d-pid%d", c->device, (int)getpid()); }
@@ -155,17 +158,28 @@ static int xs_setup(kk_ctx c) {
     KK_HIP(hipStreamSynchronize(c->stream));
     int status = KK_OK;
     // Ranks that share ONE GPU (tests; a node with fewer GPUs than ranks): the persistent kernels launch one block per CU and need
-    // the blocks of ALL ranks resident at once.  A launch deals its blocks to the 8 XCDs round-robin, so W kernels of n blocks need
-    // W * ceil(n / 8) CUs per XCD (profiles/r05_xsync_world3_residency.txt): unless the caller has set "num_cus" itself, every rank
-    // takes its share of each XCD, less two CUs per XCD for the streaming kernels of the others.
+    // the blocks of ALL ranks resident at once.  A launch deals its blocks to the XCDs round-robin, so W kernels of n blocks need
+    // W * ceil(n / XCDs) CUs per XCD (profiles/r05_xsync_world3_residency.txt): unless the caller has set "num_cus" itself, every rank
+    // takes its share of each XCD, less two CUs per XCD for the streaming kernels of the others.  And ALL ranks of the communicator
+    // launch the SAME number of blocks, the minimum over the ranks: the route of a sweep and the panel width of k_mgs_panel follow
+    // from (vector length, CUs), and every rank must arrive at the same ones -- the vector length is agreed per slab
+    // (route_agree, kk_host.h).  Every rank derives the same numbers from the same records; they are APPLIED further down, once the
+    // feature is known to be on (and taken back by xs_release).
+    int cus_agreed = c->num_cus;
     {
         int n_share = 0;
         for (int r = 0; r < k->world; ++r) n_share += (all[r].bus == mine.bus);
-        if (n_share > 1 && c->num_cus == c->dev_cus) {
-            const int per_xcd = (c->dev_cus / 8) / n_share;
-            c->num_cus = 8 * std::max(1, per_xcd - 2);
-        }
         k->xs_share = n_share;
+        cus_agreed = 1 << 30;
+        for (int r = 0; r < k->world; ++r) {
+            int share_r = 0;
+            for (int q = 0; q < k->world; ++q) share_r += (all[q].bus == all[r].bus);
+            int cus_r = (int)all[r].cus;
+            const int xcds_r = all[r].xcds > 0 ? (int)all[r].xcds : 8;
+            if (share_r > 1 && all[r].cus == all[r].dev_cus) cus_r = xcds_r * std::max(1, (int)(all[r].dev_cus / xcds_r) / share_r - 2);
+            cus_agreed = std::min(cus_agreed, cus_r);
+        }
+        if (cus_agreed < 1 || cus_agreed > c->dev_cus) cus_agreed = c->num_cus;
     }
     for (int r = 0; r < k->world && local_ok; ++r) if (!all[r].ok) local_ok = 0;
     for (int r = 0; r < k->world && local_ok; ++r) {
@@ -205,7 +219,40 @@ static int xs_setup(kk_ctx c) {
     k->xs_red = 4; k->xs_launch = 1;
     status = kk_comm_agree_status(c, h_out == 1 ? KK_OK : KK_ERR_UNSUPPORTED, &worst);
     if (status != KK_OK || worst != KK_OK) { xs_release(c); return status; }
+    // What the two ways of summing over the ranks COST on this machine, measured here and now: XS_NRED
+    // in-kernel reductions back to back (one round trip through every peer's area each) and XS_NAR RCCL all-reduces of 8 doubles
+    // back to back on the context stream.  The slowest rank's figures are the communicator's (all-reduce max): the rule that
+    // picks the route of a sweep (kk_xs_pays, kk_internal.h) reads the same numbers on every rank.
+    {
+        const int XS_NRED = 65, XS_NAR = 20;
+        a.tag0 = k->xs_red + 1u; a.launch = ++k->xs_launch;
+        k->xs_red += (unsigned)XS_NRED;
+        long long* d_t = (long long*)(d_send + 520);
+        KK_HIP(hipMemsetAsync(d_t, 0, 2 * sizeof(long long), c->stream));
+        KK_TRY(kk_launch_xs_timing(c, a, XS_NRED, d_t));
+        long long h_t[2] = {0, 0};
+        KK_HIP(hipMemcpyAsync(h_t, d_t, sizeof(h_t), hipMemcpyDeviceToHost, c->stream));
+        KK_HIP(hipStreamSynchronize(c->stream));
+        double* d_ar = (double*)(d_send + 528);
+        KK_HIP(hipMemsetAsync(d_ar, 0, 8 * sizeof(double), c->stream));
+        KK_TRY(kk_comm_allreduce_sum(c, d_ar, 8));   // (warm-up: the first collective of a communicator sets up its channels)
+        KK_HIP(hipEventRecord(c->t0, c->stream));
+        for (int i = 0; i < XS_NAR; ++i) KK_TRY(kk_comm_allreduce_sum(c, d_ar, 8));
+        KK_HIP(hipEventRecord(c->t1, c->stream));
+        KK_HIP(hipEventSynchronize(c->t1));
+        float ms = 0;
+        KK_HIP(hipEventElapsedTime(&ms, c->t0, c->t1));
+        k->n_allreduce -= XS_NAR + 1;   // (set-up traffic: not part of the caller's statistics)
+        double fig[3] = {h_t[0] == 1 ? 0.0 : 1.0, (double)h_t[1] * 0.01 / (XS_NRED - 1), 1e3 * (double)ms / XS_NAR};   // failed?, us per in-kernel reduction, us per all-reduce
+        KK_HIP(hipMemcpyAsync(d_ar, fig, sizeof(fig), hipMemcpyHostToDevice, c->stream));
+        KK_NCCL(g_rccl.AllReduce(d_ar, d_ar, 3, ncclDouble, ncclMax, (ncclComm_t)k->nccl, c->stream));
+        KK_HIP(hipMemcpyAsync(fig, d_ar, sizeof(fig), hipMemcpyDeviceToHost, c->stream));
+        KK_HIP(hipStreamSynchronize(c->stream));
+        if (fig[0] != 0.0) { xs_release(c); return KK_OK; }   // a rank's timing launch gave up: the RCCL routes serve
+        k->xs_hop_us = fig[1]; k->ar_us = fig[2];
+    }
     k->xs_active = true;
+    if (cus_agreed != c->num_cus) { k->cus_before = c->num_cus; c->num_cus = cus_agreed; }
     return KK_OK;
 }
 void kk_xs_postmortem(kk_ctx ctx, const char* where) {
@@ -224,6 +271,10 @@ kk_xs_dev kk_xs_launch_args(kk_ctx ctx, unsigned nred) {
     if (!kk_sharded(ctx) || !kk_xs_on(ctx)) return a;
     kk_comm_s* k = ctx->comm;
     a.table = k->xs_table; a.mine = k->xs_mine;
+    if (k->xs_clear_word) {   // first persistent launch after a recovery: every store of the lost launch's id has landed (kk_xsync.h)
+        k->xs_clear_word = false;
+        (void)hipMemsetAsync(k->xs_mine + KK_XS_ERR_OFFSET, 0, sizeof(unsigned), ctx->stream);
+    }
     a.tag0 = k->xs_red + 1u;
     k->xs_red += nred;
     if (++k->xs_launch == 0) ++k->xs_launch;   // (0 is the "no abort" value of the error word)
@@ -246,7 +297,8 @@ KK_API int kk_comm_init(kk_ctx c, const void* id128, int rank, int world, int fl
     ncclComm_t comm = nullptr;
     KK_NCCL(g_rccl.CommInitRank(&comm, world, id, rank));
     kk_comm_s* k = new kk_comm_s();
-    k->nccl = comm; k->rank = rank; k->world = world;
+    static uint64_t next_uid = 0;
+    k->nccl = comm; k->rank = rank; k->world = world; k->uid = ++next_uid;
     k->active = world > 1 || (flags & KK_COMM_FORCE_COLLECTIVES) != 0;
     c->comm = k;
     c->spec_owner = nullptr;   // a speculative apply enqueued before the switch carries an un-sharded alpha
@@ -308,6 +360,18 @@ KK_API int kk_comm_allreduce(kk_ctx c, void* dev_ptr, int64_t count, int op) {
     const ncclRedOp_t ro = op == 0 ? ncclSum : (op == 1 ? ncclMax : ncclMin);
     KK_NCCL(g_rccl.AllReduce(dev_ptr, dev_ptr, (size_t)count, ncclDouble, ro, (ncclComm_t)k->nccl, c->stream));
     ++k->n_allreduce;
+    return KK_OK;
+}
+
+// *v = max over the ranks, on the host when the call returns (route_agree, kk_host.h)
+int kk_comm_allreduce_max_host(kk_ctx c, double* v) {
+    kk_comm_s* k = c->comm;
+    if (!k || !k->active) return KK_OK;
+    double* t = SCP(c, SC_TMP2);
+    KK_HIP(hipMemcpyAsync(t, v, sizeof(double), hipMemcpyHostToDevice, c->stream));
+    KK_NCCL(g_rccl.AllReduce(t, t, 1, ncclDouble, ncclMax, (ncclComm_t)k->nccl, c->stream));
+    KK_HIP(hipMemcpyAsync(v, t, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    KK_HIP(hipStreamSynchronize(c->stream));
     return KK_OK;
 }
 

@@ -86,6 +86,11 @@ KK_API int kk_ctx_create(int device, kk_ctx* out) {
     c->device = device;
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     c->dev_cus = c->num_cus;
+    {
+        int xcds = 0;
+        if (hipDeviceGetAttribute(&xcds, hipDeviceAttributeNumberOfXccs, device) != hipSuccess) (void)hipGetLastError();
+        c->dev_xcds = (xcds >= 1 && c->dev_cus % xcds == 0) ? xcds : 8;
+    }
     const int st = ctx_allocate(c);
     if (st != KK_OK) {   // release whatever was created before the failing call
         const std::string msg = kk_last_error();
@@ -180,8 +185,9 @@ KK_API int kk_ctx_set_option(kk_ctx c, const char* key, double value) {
         KK_CHECK(value >= 1 && value <= c->dev_cus, KK_ERR_INVALID, "num_cus must be in 1..%d", c->dev_cus);
         KK_HIP(hipStreamSynchronize(c->stream));
         c->num_cus = (int)value;
+        if (c->comm) c->comm->cus_before = 0;   // (the caller's figure from now on -- to be set alike on every rank of a cross-rank communicator)
     } else if (!strcmp(key, "xsync")) {
-        c->xsync = value != 0;   // (must be set to the same value on every rank)
+        c->xsync = value >= 2 ? 2 : (value != 0 ? 1 : 0);   // 0 off, 1 where it pays (kk_xs_pays: the hand-shake's own timings decide), 2 always; must be set to the same value on every rank
     } else if (!strcmp(key, "lookahead")) {
         c->lookahead = value != 0;
     } else if (!strcmp(key, "mgs_panel")) {
@@ -300,6 +306,9 @@ KK_API int kk_ctx_get_option(kk_ctx c, const char* key, double* value) {
     else if (!strcmp(key, "xsync_active")) *value = kk_xs_on(c) ? 1 : 0;
     else if (!strcmp(key, "xsync_launches")) *value = c->comm ? (double)c->comm->n_xs_launches : 0.0;
     else if (!strcmp(key, "ranks_on_this_gpu")) *value = c->comm ? c->comm->xs_share : 1;
+    else if (!strcmp(key, "xsync_hop_us")) *value = c->comm ? c->comm->xs_hop_us : 0.0;           // one in-kernel cross-rank reduction, measured by kk_comm_init
+    else if (!strcmp(key, "comm_allreduce_us")) *value = c->comm ? c->comm->ar_us : 0.0;         // one small RCCL all-reduce on the stream, measured by kk_comm_init
+    else if (!strcmp(key, "device_xcds")) *value = c->dev_xcds;
     else if (!strcmp(key, "block_mode")) *value = c->block_mode;
     else if (!strcmp(key, "block_async")) *value = c->block_async;
     else if (!strcmp(key, "block_fuse")) *value = c->block_fuse;
@@ -515,20 +524,24 @@ KK_API int kk_basis_invalidate_gram(kk_basis b) {
     return KK_OK;
 }
 KK_API int kk_basis_upload(kk_basis b, int col, const double* host) {
+    CHECK_COL_BOUNDS(b, col);   // (validation first: a rejected call must leave the slab's deferred state as it was -- ADVICE r5)
+    KK_CHECK(host, KK_ERR_INVALID, "null host pointer");
     norm_discard(b, col);   // (overwritten as a whole)
     CHECK_COL(b, col);
-    KK_CHECK(host, KK_ERR_INVALID, "null host pointer");
     gram_touch(b, col);
     KK_HIP(hipMemcpyAsync(b->col(col), host, b->n * sizeof(double), hipMemcpyHostToDevice, b->ctx->stream));
     return stream_sync(b->ctx);
 }
 KK_API int kk_basis_download(kk_basis b, int col, double* host) {
-    CHECK_COL(b, col);
+    CHECK_COL_BOUNDS(b, col);
     KK_CHECK(host, KK_ERR_INVALID, "null host pointer");
+    CHECK_COL_RO(b, col);
     KK_HIP(hipMemcpyAsync(host, b->col(col), b->n * sizeof(double), hipMemcpyDeviceToHost, b->ctx->stream));
     return stream_sync(b->ctx);
 }
 KK_API int kk_basis_upload_device(kk_basis b, int col, const void* dptr) {
+    CHECK_COL_BOUNDS(b, col);
+    KK_CHECK(dptr, KK_ERR_INVALID, "null device pointer");
     norm_discard(b, col);
     CHECK_COL(b, col);
     gram_touch(b, col);
@@ -536,7 +549,9 @@ KK_API int kk_basis_upload_device(kk_basis b, int col, const void* dptr) {
     return KK_OK;
 }
 KK_API int kk_basis_download_device(kk_basis b, int col, void* dptr) {
-    CHECK_COL(b, col);
+    CHECK_COL_BOUNDS(b, col);
+    KK_CHECK(dptr, KK_ERR_INVALID, "null device pointer");
+    CHECK_COL_RO(b, col);
     KK_HIP(hipMemcpyAsync(dptr, b->col(col), b->n * sizeof(double), hipMemcpyDeviceToDevice, b->ctx->stream));
     return KK_OK;
 }
@@ -599,12 +614,14 @@ KK_API int kk_vec_copy_scal(kk_basis by, int cy, kk_basis bx, int cx, double a) 
         ++bx->ctx->norm_commits_consumed;
         return kk_launch_copy_scal(by->ctx, by->col(cy), bx->col(cx), by->ld, 1.0);
     }
+    CHECK_COL_BOUNDS(bx, cx); CHECK_COL_BOUNDS(by, cy); CHECK_SAME(bx, by);   // (validation before any side effect)
     if (!(by == bx && cy == cx)) norm_discard(by, cy);   // the destination is overwritten as a whole: no point in settling it first
-    CHECK_COL(bx, cx); CHECK_COL(by, cy); CHECK_SAME(bx, by);
+    CHECK_COL(bx, cx); CHECK_COL(by, cy);
     gram_touch(by, cy);
     return kk_launch_copy_scal(by->ctx, by->col(cy), bx->col(cx), by->ld, a);
 }
 KK_API int kk_vec_zero(kk_basis bx, int cx) {
+    CHECK_COL_BOUNDS(bx, cx);
     norm_discard(bx, cx);
     CHECK_COL(bx, cx);
     gram_touch(bx, cx);
@@ -612,6 +629,7 @@ KK_API int kk_vec_zero(kk_basis bx, int cx) {
     return KK_OK;
 }
 KK_API int kk_vec_fill_random(kk_basis bx, int cx, uint64_t seed) {
+    CHECK_COL_BOUNDS(bx, cx);
     norm_discard(bx, cx);
     CHECK_COL(bx, cx);
     gram_touch(bx, cx);

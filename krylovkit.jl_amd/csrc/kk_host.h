@@ -21,11 +21,18 @@ static const double KK_EPS = std::numeric_limits<double>::epsilon();
 // settled by every check): only the expand! that consumes it -- and scale!!(r, 1 / beta) of a restart, kk_vec_scal /
 // kk_vec_copy_scal -- look at the flag themselves.  An entry point that touches a column declares it through one of these
 // macros; the fused L3 steps and kk_basis_info (raw pointer) call norm_flush for the whole slab.
-#define CHECK_COL(b, c) do { KK_CHECK((b) && (c) >= 0 && (c) < (b)->cap, KK_ERR_INVALID, "%s: column %d out of range", __func__, (c)); KK_TRY(norm_flush_range(b, (c), 1)); } while (0)
+// Every PUBLIC entry point other than the expand! steps also voids what was enqueued AHEAD for the context's running factorization
+// (ctx_public_touch: the speculative apply, a whole step): its kernels may write the shared device scalars the step in flight
+// still has to read -- kk_vec_nrm2 on a basis column of the owner slab overwrites |w| and 1 / |w| -- and the owner's
+// next expand! then simply redoes the apply and the sweep from the slab.  CHECK_COL_RO: entry points that launch no kernel
+// writing the scalar workspace (downloads, gathers) leave the run-ahead alone.
+#define CHECK_COL_BOUNDS(b, c) KK_CHECK((b) && (c) >= 0 && (c) < (b)->cap, KK_ERR_INVALID, "%s: column %d out of range", __func__, (c))
+#define CHECK_COL_RO(b, c) do { CHECK_COL_BOUNDS(b, c); KK_TRY(norm_flush_range(b, (c), 1)); } while (0)
+#define CHECK_COL(b, c) do { CHECK_COL_RO(b, c); ctx_public_touch(b); } while (0)
 #define CHECK_SAME(bx, by) KK_CHECK((bx)->ctx == (by)->ctx && (bx)->n == (by)->n && (bx)->ld == (by)->ld, KK_ERR_DIM, "%s: vector length mismatch (%lld vs %lld)", __func__, (long long)(bx)->n, (long long)(by)->n)
-#define CHECK_RANGE(b, c0, m) do { KK_CHECK((b) && (c0) >= 0 && (m) >= 0 && (c0) + (m) <= (b)->cap && (m) <= KK_MAX_M, KK_ERR_INVALID, "%s: column range [%d,%d) invalid (capacity %d, max %d per call)", __func__, (c0), (c0) + (m), (b) ? (b)->cap : 0, KK_MAX_M); KK_TRY(norm_flush_range(b, (c0), (m))); } while (0)
+#define CHECK_RANGE(b, c0, m) do { KK_CHECK((b) && (c0) >= 0 && (m) >= 0 && (c0) + (m) <= (b)->cap && (m) <= KK_MAX_M, KK_ERR_INVALID, "%s: column range [%d,%d) invalid (capacity %d, max %d per call)", __func__, (c0), (c0) + (m), (b) ? (b)->cap : 0, KK_MAX_M); KK_TRY(norm_flush_range(b, (c0), (m))); ctx_public_touch(b); } while (0)
 // (CHECK_RANGE: one kernel panel, m <= KK_MAX_M; CHECK_BLOCK: any number of columns -- the entry point goes panel by panel)
-#define CHECK_BLOCK(b, c0, p) do { KK_CHECK((b) && (c0) >= 0 && (p) >= 0 && (c0) + (p) <= (b)->cap, KK_ERR_INVALID, "%s: block [%d,%d) outside capacity %d", __func__, (c0), (c0) + (p), (b) ? (b)->cap : 0); KK_TRY(norm_flush_range(b, (c0), (p))); } while (0)
+#define CHECK_BLOCK(b, c0, p) do { KK_CHECK((b) && (c0) >= 0 && (p) >= 0 && (c0) + (p) <= (b)->cap, KK_ERR_INVALID, "%s: block [%d,%d) outside capacity %d", __func__, (c0), (c0) + (p), (b) ? (b)->cap : 0); KK_TRY(norm_flush_range(b, (c0), (p))); ctx_public_touch(b); } while (0)
 
 // ---- scalar read-backs (kk_context.hip): results of the finalize kernels travel through the pinned mirror of the
 // scalar workspace; `slot` selects one of its 4 copies
@@ -57,6 +64,7 @@ static inline void ctx_foreign_touch(kk_basis b) {
     kk_ctx c = b->ctx;
     if (c->spec_owner != b) ++c->foreign_gen;
 }
+static inline void ctx_public_touch(kk_basis b) { ++b->ctx->foreign_gen; }
 static inline int norm_flush(kk_basis b) {
     if (!b) return KK_OK;
     ctx_foreign_touch(b);
@@ -80,6 +88,25 @@ static inline int norm_flush_range(kk_basis b, int c0, int m) {
 // the column is about to be OVERWRITTEN as a whole (upload, zero, fill, copy into it): a pending normalisation of it is moot
 static inline void norm_discard(kk_basis b, int col) {
     if (b && col >= 0 && b->norm_col == col) { b->norm_col = -1; gram_touch(b, col); }
+}
+
+// Cross-rank (xsync) context: the route of a sweep -- persistent kernel or low-synchronisation pair, and the panel width -- must come
+// out THE SAME on every rank, or one rank spins in a launch its peer never made.  The inputs that differ between ranks
+// are the shard length (Partition.even hands out different n_local) and the CU count (agreed by kk_comm_init): the longest shard
+// of a slab is agreed ONCE per slab and communicator -- one all-reduce (max) at the first sweep, which every rank reaches in the
+// same call (SPMD) -- and every decision of the entry point at hand is taken with it (kk_dec_ld).
+int kk_comm_allreduce_max_host(kk_ctx c, double* v);   // kk_comm.hip: *v = max over the ranks (blocking)
+static inline int route_agree(kk_basis b) {
+    kk_ctx c = b->ctx;
+    if (!kk_xs_on(c)) { c->dec_ld_local = -1; return KK_OK; }
+    if (b->ld_agreed_comm != c->comm->uid) {
+        double v = (double)b->ld;
+        KK_TRY(kk_comm_allreduce_max_host(c, &v));
+        b->ld_agreed = (int64_t)v;
+        b->ld_agreed_comm = c->comm->uid;
+    }
+    c->dec_ld_local = b->ld; c->dec_ld = b->ld_agreed;
+    return KK_OK;
 }
 
 // ---- sparse operators (kk_sparse.hip)

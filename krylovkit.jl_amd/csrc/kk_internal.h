@@ -6,6 +6,7 @@
 #include <string>
 #include <vector>
 #include <map>
+#include <algorithm>
 #include "../../include/krylov_hip.h"
 
 #define KK_MAX_M 256          // max basis vectors touched by one project/unproject call
@@ -111,6 +112,7 @@ struct kk_prof_entry {
 // RCCL communicator of a row-sharded run (kk_comm.hip); the library dlopens librccl at kk_comm_init
 struct kk_comm_s {
     void* nccl = nullptr;   // ncclComm_t
+    uint64_t uid = 0;       // unique over the life of the process (what a slab's agreed length refers to)
     int rank = 0, world = 1;
     bool active = false;    // collectives are issued: world > 1, or forced at world 1 (plumbing tests on a 1-GPU box)
     int64_t n_allreduce = 0, n_p2p = 0, n_gather = 0;   // statistics (kk_comm_stats)
@@ -124,14 +126,22 @@ struct kk_comm_s {
     unsigned xs_launch = 0;                     // launches issued so far
     int64_t n_xs_launches = 0;                  // statistics
     int xs_share = 1;                           // ranks of this communicator on this rank's GPU (> 1: num_cus was cut to the rank's share)
+    int cus_before = 0;                         // "num_cus" of the context before the communicator set it to the value ALL ranks launch with (0: untouched); restored by xs_release
+    bool xs_clear_word = false;                 // a lost launch left its id in this rank's abort word: cleared before the next persistent launch
+    double xs_hop_us = 0;                       // one in-kernel cross-rank reduction, measured by the hand-shake (slowest rank)
+    double ar_us = 0;                           // one RCCL all-reduce of 8 doubles on the context stream, measured by the hand-shake (slowest rank)
 };
 
 struct kk_ctx_s {
     int device = 0;
     kk_comm_s* comm = nullptr;   // set by kk_comm_init: every reduction of the library is summed over the ranks
+    // route decisions of a cross-rank (xsync) context use the LONGEST shard of the slab at hand, agreed once per slab
+    // (route_agree, kk_host.h): local leading dimension the agreement below belongs to, and the agreed one
+    int64_t dec_ld_local = -1, dec_ld = -1;
     bool ar_suspend = false;     // fused sharded steps collect several local partials and all-reduce them at once
     int num_cus = 256;           // blocks of a persistent launch / partition unit of the streaming kernels (option "num_cus": fewer than the device has when the GPU is shared)
     int dev_cus = 256;           // what the device reports
+    int dev_xcds = 8;            // ... and its XCDs (a launch deals its blocks to them round-robin)
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     double* ws = nullptr;        // device scalar workspace [WS_TOTAL] (ws_own unless the caller supplied one)
@@ -245,6 +255,8 @@ struct kk_basis_s {
     uint64_t uid = 0;   // unique over the life of the process (a freed slab's address may be reused)
     int64_t n = 0, ld = 0;
     int cap = 0;
+    int64_t ld_agreed = 0;      // max of ld over the ranks of communicator `ld_agreed_comm` (0: not agreed yet)
+    uint64_t ld_agreed_comm = 0;
     double* d = nullptr;
     // Gram bookkeeping for mgs_mode=1: gram[i*cap + j] = <b_i, b_j> for j < i < gram_rows
     std::vector<double> gram;
@@ -487,9 +499,28 @@ static inline bool kk_sharded(kk_ctx ctx) {
 static inline bool kk_xs_on(kk_ctx ctx) {
     return ctx->xsync && !ctx->allreduce && ctx->comm && ctx->comm->active && ctx->comm->xs_active;
 }
+// the vector length the ROUTE of a sweep is decided with: on a cross-rank context the longest shard of the slab (same on every rank)
+static inline int64_t kk_dec_ld(kk_ctx ctx, int64_t ld) {
+    return (kk_xs_on(ctx) && ctx->dec_ld_local == ld && ctx->dec_ld >= ld) ? ctx->dec_ld : ld;
+}
+// Does the in-kernel sum over the ranks PAY for a sweep of `nvec` vector-steps with `nred` grid reductions?
+// Against the low-synchronisation route (one more RCCL all-reduce per step: 2.05 instead of 1.06) a persistent launch pays one
+// cross-rank round trip per grid reduction and gains what it gains on ONE chip: nothing at the single-chip threshold `ld_min`,
+// `t_sync_us` per vector-step for every further multiple of it (the saved basis traffic grows with the rows, the exposed
+// reduction does not).  Both prices were measured by this communicator's hand-shake (kk_comm_init; the slowest rank's figures,
+// identical on all ranks):   take the in-kernel route  iff  nred x hop  <=  all-reduce + nvec x t_sync x (ld / ld_min - 1).
+// Option "xsync" = 2 skips the rule (tests; A/B runs), 0 switches the in-kernel route off.
+static inline bool kk_xs_pays(kk_ctx ctx, int64_t ld, int nvec, int nred, double ld_min, double t_sync_us) {
+    if (!kk_xs_on(ctx)) return true;   // (not a cross-rank launch: nothing to weigh)
+    if (ctx->xsync >= 2 || ld_min <= 0.0) return true;
+    const kk_comm_s* k = ctx->comm;
+    const double gain = k->ar_us + (double)nvec * t_sync_us * std::max(0.0, (double)ld / ld_min - 1.0);
+    return (double)nred * k->xs_hop_us <= gain;
+}
 // fills the kernel argument of one persistent launch with `nred` grid reductions (all zero on a single-rank context)
 kk_xs_dev kk_xs_launch_args(kk_ctx ctx, unsigned nred);
 int kk_launch_xs_selftest(kk_ctx ctx, const kk_xs_dev& xs, int* out_dev);
+int kk_launch_xs_timing(kk_ctx ctx, const kk_xs_dev& xs, int nred, long long* out_dev);   // out[0] = ok, out[1] = 100 MHz ticks of reductions 1 .. nred - 1
 void kk_xs_postmortem(kk_ctx ctx, const char* where);   // KK_XSYNC_DEBUG=1: what the first block that gave up saw (stderr)   // 4 reductions; *out_dev = 1 on success
 struct kk_ar_suspend {   // RAII: local partials only inside the scope
     kk_ctx c; bool prev;
@@ -533,13 +564,20 @@ int kk_launch_mgs_panel(kk_ctx ctx, const double* V, int64_t ld, int m, int nswe
 // (option "mgs_mode").  auto: the persistent kernels wherever they are the faster route -- the panel kernel for vectors of
 // panel_min_rows .. 4.19 M rows, the register-resident strict kernel from persist_min_rows rows up to its capacity -- and the
 // projection pair otherwise (tiny vectors: launch-bound; vectors beyond the register file; row-sharded contexts).
-static inline bool kk_mgs_lowsync(kk_ctx ctx, int64_t ld, int m) {
+static inline bool kk_mgs_lowsync(kk_ctx ctx, int64_t ld_local, int m) {
     if (ctx->mgs_mode != 2) return ctx->mgs_mode == 1;
     // (the thresholds were measured on the whole chip: what decides is the length of a CU's share of the vector, so a context
-    // that owns fewer CUs -- option "num_cus" -- scales them down with it)
+    // that owns fewer CUs -- option "num_cus" -- scales them down with it.  Cross-rank context: the longest shard decides, and
+    // the in-kernel reduction has to pay for its round trips -- kk_xs_pays)
+    const int64_t ld = kk_dec_ld(ctx, ld_local);
     const double share = (double)ctx->num_cus / 256.0;
-    if ((double)ld >= share * (double)ctx->panel_min_rows && kk_mgs_panel_eligible(ctx, ld)) return false;
-    return !((double)ld >= share * (double)ctx->persist_min_rows && kk_mgs_persist_eligible(ctx, ld, m, 2));
+    if ((double)ld >= share * (double)ctx->panel_min_rows && kk_mgs_panel_eligible(ctx, ld_local)) {
+        const int P = kk_mgs_panel_width(ctx, ld_local, false);
+        if (kk_xs_pays(ctx, ld, 2 * m, (2 * m + P - 1) / P + 1, share * (double)ctx->panel_min_rows, 5.4 / P)) return false;
+    }
+    if ((double)ld >= share * (double)ctx->persist_min_rows && kk_mgs_persist_eligible(ctx, ld_local, m, 2))
+        return !kk_xs_pays(ctx, ld, 2 * m, 2 * m + 1, share * (double)ctx->persist_min_rows, 2.6);
+    return true;
 }
 int kk_launch_mgs_persist(kk_ctx ctx, const double* V, int64_t ld, int m, int nsweeps, double* w, const double* carry_q,
                           const double* carry_s, double* out_s, int out_stride, double* nrm_out3, bool normalize_w);

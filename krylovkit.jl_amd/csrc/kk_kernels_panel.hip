@@ -122,6 +122,7 @@ __device__ __forceinline__ bool panel_sweep(int nval, unsigned epoch, int set, c
     const unsigned set_off = (unsigned)set * set_bytes;
     const long long t0 = wall_clock64();
     int good = 1;
+    bool origin = false;   // the failure (if any) is this wave's own timeout, not an observed flag / abort
     long long npass = 0;
     double mine = 0;   // lane v: this rank's partial of value v (row-sharded context)
     for (int v = 0; v < nval && good; ++v) {   // value after value: by the time value 0 is complete the others usually are too
@@ -153,16 +154,16 @@ __device__ __forceinline__ bool panel_sweep(int nval, unsigned epoch, int set, c
             }
             if (__all(ok)) { total = wave_sum(x); break; }
             __builtin_amdgcn_s_sleep(1);
-            if (wall_clock64() - t0 > timeout_ticks || errv) { good = 0; break; }
+            if (wall_clock64() - t0 > timeout_ticks || errv) { good = 0; origin = !errv; break; }
         }
         if (xs.world > 0) { if (lane == v) mine = total; }
         else if (lane == 0) smB[v] = total;
     }
     if (xs.world > 0) {   // level 2: the sum over the ranks (kk_xsync.h); lanes v * 8 .. v * 8 + 7 receive the total of value v
         double t2 = 0;
-        if (good && !xs_allreduce(xs, xred, nval, mine, err, timeout_ticks, t2)) good = 0;
+        if (good && !xs_allreduce(xs, xred, nval, mine, err, timeout_ticks, t2, &origin)) good = 0;
         if (good && (lane & 7) == 0 && (lane >> 3) < nval) smB[lane >> 3] = t2;
-        if (!good && lane == 0) xs_abort(xs);
+        if (!good && origin && lane == 0) xs_abort(xs);   // (only the wave whose OWN wait ran out tells the peers: kk_xsync.h)
     }
     if (lane == 0 && !good) { __hip_atomic_store(err, 1, RLX_AGENT); smB[8] = 1.0; }
     PTRACE(9, pidx);   // totals complete
@@ -213,10 +214,12 @@ __device__ __forceinline__ void panel_sweep_par(unsigned epoch, int set, char* _
             }
             if (__all(ok)) { total = wave_sum(x); break; }
             __builtin_amdgcn_s_sleep(1);
-            if (wall_clock64() - t0 > timeout_ticks || errv) { good = 0; break; }
+            if (wall_clock64() - t0 > timeout_ticks || errv) { good = errv ? -1 : 0; break; }
         }
         if (lane == 0) {
-            if (!good) { __hip_atomic_store(err, 1, RLX_AGENT); smB[8] = 1.0; }
+            // failure flag: 1.0 observed (local flag already raised), 2.0 this block's own wait ran out (originator: tells the peers below);
+            // several waves may fail at once -- the larger value stays (positive doubles order like their bit patterns)
+            if (good <= 0) { __hip_atomic_store(err, 1, RLX_AGENT); atomicMax((unsigned long long*)&smB[8], (unsigned long long)__double_as_longlong(good == 0 ? 2.0 : 1.0)); }
             smB[xs.world > 0 ? 9 + wave : wave] = total;
         }
     }
@@ -224,11 +227,12 @@ __device__ __forceinline__ void panel_sweep_par(unsigned epoch, int set, char* _
         lds_barrier();
         if (wave == 0) {
             bool good = smB[8] == 0.0;
+            bool origin = smB[8] == 2.0;
             const double mine = lane < NVAL ? smB[9 + lane] : 0.0;
             double t2 = 0;
-            if (good && !xs_allreduce(xs, xred, NVAL, mine, err, timeout_ticks, t2)) good = false;
+            if (good && !xs_allreduce(xs, xred, NVAL, mine, err, timeout_ticks, t2, &origin)) good = false;
             if (good && (lane & 7) == 0 && (lane >> 3) < NVAL) smB[lane >> 3] = t2;
-            if (!good && lane == 0) { xs_abort(xs); __hip_atomic_store(err, 1, RLX_AGENT); smB[8] = 1.0; }
+            if (!good && lane == 0) { if (origin) xs_abort(xs); __hip_atomic_store(err, 1, RLX_AGENT); smB[8] = 1.0; }
         }
     }
 }
@@ -701,8 +705,9 @@ __global__ __launch_bounds__(KK_PANEL_PT) void k_mgs_panel_lag(const double* __r
 // ---- launcher ------------------------------------------------------------------------------
 // vectors of at most 16 rows of 512 double2 per block (4.19 M rows on 256 CUs): w plus two panels fit the 256 registers of a 512-thread block
 int64_t kk_mgs_panel_capacity(kk_ctx ctx) { return (int64_t)ctx->num_cus * KK_PANEL_DT * 2 * 16; }
-bool kk_mgs_panel_eligible(kk_ctx ctx, int64_t ld) {
+bool kk_mgs_panel_eligible(kk_ctx ctx, int64_t ld_local) {
     if (!ctx->mgs_panel || !ctx->mgs_persist || (kk_sharded(ctx) && !kk_xs_on(ctx)) || !ctx->d_sync) return false;
+    const int64_t ld = kk_dec_ld(ctx, ld_local);   // cross-rank context: the longest shard of the slab must fit (same answer on every rank)
     if (ctx->num_cus > KK_SYNC_MAX_BLOCKS || ld * 8 >= ((int64_t)1 << 31)) return false;
     return ld <= kk_mgs_panel_capacity(ctx);
 }
@@ -718,8 +723,9 @@ static int launch_panel_lag_inst(kk_ctx ctx, void** args) {
 }
 
 // panel width by vector length: what two register-resident panels + w leave room for (4 NV (1 + 2 P) <= ~200 registers)
-int kk_mgs_panel_width(kk_ctx ctx, int64_t ld, bool strict) {
+int kk_mgs_panel_width(kk_ctx ctx, int64_t ld_local, bool strict) {
     if (strict) return 1;
+    const int64_t ld = kk_dec_ld(ctx, ld_local);   // (every rank of a cross-rank context must sweep panels of the same width: ADVICE r5)
     const int nv = (int)((ld + (int64_t)ctx->num_cus * KK_PANEL_DT * 2 - 1) / ((int64_t)ctx->num_cus * KK_PANEL_DT * 2));
     const int by_size = nv <= 4 ? 3 : (nv <= KK_PANEL_NVMID ? 2 : 1);
     return ctx->panel_width > 0 ? std::min(ctx->panel_width, by_size) : by_size;
@@ -727,10 +733,13 @@ int kk_mgs_panel_width(kk_ctx ctx, int64_t ld, bool strict) {
 
 int kk_launch_mgs_panel(kk_ctx ctx, const double* V, int64_t ld, int m, int nsweeps, double* w, const double* carry_q,
                         const double* carry_s, double* out_s, int out_stride, double* nrm_out3, bool normalize_w, bool strict) {
-    const int nv = (int)((ld + (int64_t)ctx->num_cus * KK_PANEL_DT * 2 - 1) / ((int64_t)ctx->num_cus * KK_PANEL_DT * 2));
+    // (the register tile is chosen for the longest shard of the slab: the kernel itself works out from its own ld how many of the
+    // NV rows per lane exist locally -- the rest read as zeros)
+    const int64_t ld_dec = kk_dec_ld(ctx, ld);
+    const int nv = (int)((ld_dec + (int64_t)ctx->num_cus * KK_PANEL_DT * 2 - 1) / ((int64_t)ctx->num_cus * KK_PANEL_DT * 2));
     // the lag-1 kernel (three register-resident panels of two vectors, 448 double2 per grid-row): vectors of <= 8 such rows per
     // block, i.e. 1.83 M rows on 256 CUs; beyond that (and in the strict order) the kernel above
-    const int nvl = (int)((ld + (int64_t)ctx->num_cus * KK_LAG_DT * 2 - 1) / ((int64_t)ctx->num_cus * KK_LAG_DT * 2));
+    const int nvl = (int)((ld_dec + (int64_t)ctx->num_cus * KK_LAG_DT * 2 - 1) / ((int64_t)ctx->num_cus * KK_LAG_DT * 2));
     // (two vectors per reduction or not at all: with ONE vector per reduction the lag-1 form is bound by the latency of the
     // reduction chain of wave 0 -- publish, sweep, publish -- at ~3.6 us per vector, slower than k_mgs_panel's 3.0 at 2 M rows,
     // profiles/r05_panel_lag_ab.jsonl; three panels of two vectors fit the registers up to 8 grid-rows = 1.83 M rows on 256 CUs)

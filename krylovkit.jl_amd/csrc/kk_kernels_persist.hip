@@ -91,6 +91,7 @@ __device__ __forceinline__ bool grid_collect(int step, unsigned ebase, char* __r
         const long long t0 = wall_clock64();
         double total = 0;
         int good = 1;
+        bool origin = false;   // the failure (if any) is this wave's own timeout / the test hook, not an observed flag or a peer's abort
         for (;;) {
             asm volatile("" ::: "memory");   // compiler barrier: the granule loads below must be re-issued by every pass (the
                                              // buffer-load builtin is a plain read to LLVM and may otherwise be hoisted out of the spin loop)
@@ -119,17 +120,18 @@ __device__ __forceinline__ bool grid_collect(int step, unsigned ebase, char* __r
             }
             if (__all(ok)) { total = wave_sum(x); break; }
             __builtin_amdgcn_s_sleep(1);
-            if (wall_clock64() - t0 > timeout_ticks || errv) { good = 0; break; }
+            if (wall_clock64() - t0 > timeout_ticks || errv) { good = 0; origin = !errv; break; }
         }
         if (XS && xs.world > 0) {   // level 2: every block of this rank holds the same bits of the rank's partial -- now the sum over the ranks
             double t2 = 0;
             if (good && give_up_late) {   // what a rank looks like to its peers when ITS wait for one of them ran out a moment before that peer arrived
                 if (blockIdx.x == 0) xs_publish(xs, (unsigned)step, 1, total);
-                good = 0;
+                good = 0; origin = true;
             }
-            if (good && !xs_allreduce(xs, (unsigned)step, 1, total, err, timeout_ticks, t2)) good = 0;
+            if (good && !xs_allreduce(xs, (unsigned)step, 1, total, err, timeout_ticks, t2, &origin)) good = 0;
             total = t2;   // (lane 0: value 0)
-            if (!good && lane == 0) xs_abort(xs);   // whatever went wrong on this chip, the peers must not wait for it
+            if (!good && origin && lane == 0) xs_abort(xs);   // this chip's own wait ran out: the peers must not wait for it (a block that only OBSERVED the
+                                                              // local flag or a peer's abort writes nothing -- kk_xsync.h)
         }
         if (lane == 0) {
             if (!good) __hip_atomic_store(err, 1, RLX_AGENT);
@@ -395,8 +397,9 @@ int64_t kk_mgs_persist_capacity(kk_ctx ctx) {   // rows of a work vector the reg
     const int pt = ctx->persist_threads;
     return (int64_t)ctx->num_cus * pt * 2 * (pt == 1024 ? 20 : 40);
 }
-bool kk_mgs_persist_eligible(kk_ctx ctx, int64_t ld, int m, int nsweeps) {
+bool kk_mgs_persist_eligible(kk_ctx ctx, int64_t ld_local, int m, int nsweeps) {
     if (!ctx->mgs_persist || (kk_sharded(ctx) && !kk_xs_on(ctx)) || !ctx->d_sync) return false;
+    const int64_t ld = kk_dec_ld(ctx, ld_local);   // cross-rank context: the longest shard of the slab must fit (same answer on every rank)
     if (ctx->num_cus > KK_SYNC_MAX_BLOCKS || ld * 8 >= ((int64_t)1 << 31)) return false;
     return ld <= kk_mgs_persist_capacity(ctx);
 }
@@ -508,6 +511,29 @@ __global__ __launch_bounds__(64) void k_xs_selftest(kk_xs_dev xs, int* __restric
         else if (readlane_d(total, 0) != (double)(xs.world * (xs.world + 1) / 2 * (int)(round + 1))) ok = 0;
     }
     if (threadIdx.x == 0) out[0] = ok;
+}
+// ---- the price of one cross-rank reduction, measured by the hand-shake itself: `nred` reductions back to
+// back from ONE wave per rank -- the first aligns the ranks, the 100 MHz wall clock brackets the rest.  out[0] = 1 on success,
+// out[1] = ticks of reductions 1 .. nred - 1.  What a persistent launch pays per basis vector ON TOP of its single-chip
+// reduction is this round trip: store into every peer's area over the fabric, poll of the own area.
+__global__ __launch_bounds__(64) void k_xs_timing(kk_xs_dev xs, int* __restrict__ err, long long timeout_ticks, int nred, long long* __restrict__ out) {
+    int ok = 1;
+    long long t0 = 0;
+    double v = (double)(xs.rank + 1);
+    for (int r = 0; r < nred && ok; ++r) {
+        double total = 0;
+        if (!xs_allreduce(xs, (unsigned)r, 1, v, err, timeout_ticks, total)) ok = 0;
+        v = readlane_d(total, 0) * 0.5;   // (the next partial depends on this total: no reduction can be issued ahead)
+        if (r == 0) t0 = wall_clock64();
+    }
+    const long long t1 = wall_clock64();
+    if (threadIdx.x == 0) { out[0] = ok; out[1] = t1 - t0; }
+}
+int kk_launch_xs_timing(kk_ctx ctx, const kk_xs_dev& xs, int nred, long long* out_dev) {
+    int* err = (int*)((char*)ctx->d_sync + KK_SYNC_ERR_OFFSET);
+    hipLaunchKernelGGL(k_xs_timing, dim3(1), dim3(64), 0, ctx->stream, xs, err, 200000000ll /* 2 s */, nred, out_dev);
+    KK_HIP(hipGetLastError());
+    return KK_OK;
 }
 int kk_launch_xs_selftest(kk_ctx ctx, const kk_xs_dev& xs, int* out_dev) {
     int* err = (int*)((char*)ctx->d_sync + KK_SYNC_ERR_OFFSET);

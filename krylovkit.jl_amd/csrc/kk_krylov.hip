@@ -247,6 +247,7 @@ KK_API int kk_lanczos_expand(kk_op op, kk_basis b, int c0, int k, kk_orth_t orth
     KK_CHECK(alpha && beta, KK_ERR_INVALID, "null output");
     KK_CHECK(beta_old != 0.0, KK_ERR_ZERO_NORM, "kk_lanczos_expand: residual norm is zero");
     kk_ctx c = b->ctx;
+    KK_TRY(route_agree(b));
     const int64_t ld = b->ld;
     const int m = k + 1;                  // basis size after the push
     double* V = b->col(c0);
@@ -453,6 +454,7 @@ KK_API int kk_arnoldi_expand(kk_op op, kk_basis b, int c0, int k, kk_orth_t orth
     KK_CHECK(h && beta, KK_ERR_INVALID, "null output");
     KK_CHECK(beta_old != 0.0, KK_ERR_ZERO_NORM, "kk_arnoldi_expand: residual norm is zero");
     kk_ctx c = b->ctx;
+    KK_TRY(route_agree(b));
     const int m = k + 1;
     double* v = b->col(c0 + k);
     double* w = b->col(c0 + k + 1);

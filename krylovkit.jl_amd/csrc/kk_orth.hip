@@ -284,6 +284,7 @@ int persist_check_at(kk_ctx c, int slot, double token, bool* timed_out) {
         KK_HIP(hipMemsetAsync((char*)c->d_sync + KK_SYNC_ERR_OFFSET, 0, sizeof(int), c->stream));
         c->persist_norm_done = false;
         ++c->persist_timeouts;
+        if (c->comm && c->comm->xs_active) c->comm->xs_clear_word = true;   // (the lost launch's id sits in this rank's abort word: kk_xs_launch_args clears it)
         // the route is NOT switched off for good -- a transient timeout (GPU shared with another job) used to move
         // an auto-mode context from the reference's strict order to the low-sync form for the rest of its life, silently
         // changing the rounding of every later sweep.  The sweep that failed is repeated on the launch-per-vector route
@@ -475,6 +476,7 @@ int orth_run(kk_basis b, int c0, int m, double* w, kk_orth_t alg, double eta, do
     const int64_t ld = b->ld;
     int passes = 0;
     double nn = 0;
+    KK_TRY(route_agree(b));   // (cross-rank context: the route of the sweeps below is decided with the longest shard of this slab)
     if (m > KK_MAX_M) return orth_run_wide(b, c0, m, w, alg, eta, x, nrm, npasses, want_norm);
     if (m == 0) {
         if (want_norm || alg == KK_CGSIR || alg == KK_MGSIR) {

@@ -797,7 +797,7 @@ KK_API int kk_spmv_affine_dot(kk_op op, kk_basis bx, int cx, kk_basis by, int cy
     return KK_OK;
 }
 KK_API int kk_gather(kk_basis bx, int cx, const int64_t* device_idx, int64_t count, void* device_out) {
-    CHECK_COL(bx, cx);
+    CHECK_COL_RO(bx, cx);
     return kk_launch_gather(bx->ctx, bx->col(cx), device_idx, count, (double*)device_out);
 }
 

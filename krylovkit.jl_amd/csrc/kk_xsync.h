@@ -17,7 +17,14 @@
 // harmless, the area is zeroed once at creation (first tags 1, 2).
 // A rank that gives up (barrier timeout on its chip, test hook) stores the id of the launch into the error word of every
 // peer's area: the peers stop spinning at once, nobody commits, every rank repeats the sweep on the launch-per-vector route
-// (whose all-reduces then re-align the ranks).  Launch ids are unique, so the word is never cleared.
+// (whose all-reduces then re-align the ranks).  Launch ids only grow and the word is compared MONOTONICALLY (word != 0 and
+// word - launch >= 0 in 32-bit wrap-around arithmetic): with run-ahead the launch behind a lost one is already in the stream, and
+// should anything of it reach a peer's word, a peer still inside the lost launch must read that as an abort of ITS launch too
+// (ADVICE r5).  Only the ORIGINATOR of a give-up writes the word -- the block whose own wait ran out, a test hook -- never a block
+// that merely observed the local flag or a peer's abort: a run-ahead launch that starts with the flag of its predecessor still
+// raised leaves at its first reduction without touching anybody's word.  The host clears its own word before the first persistent
+// launch that follows a recovery (kk_xs_launch_args; every peer's store for the lost launch is complete by then: the all-reduces
+// of the repeated sweep lie in between), so a stale id cannot outlive 2^31 launches and turn into a false abort.
 // A LATE rank finds the partials of the others in its area although they have given up waiting for it: a reduction therefore only
 // succeeds while the abort word is clean, and the kernels ask once more (xs_aborted) before they commit -- otherwise the late rank
 // would commit the sweep its peers are repeating, and the ranks' collectives would no longer pair up.
@@ -38,8 +45,9 @@ __device__ __forceinline__ void xs_abort(const kk_xs_dev& xs) {
         __builtin_amdgcn_raw_buffer_store_b32(xs.launch, xs_rsrc(xs.table[r]), KK_XS_ERR_OFFSET, 0, KK_XS_AUX);
 }
 // has a rank (this one included) declared launch `xs.launch` lost?
+__device__ __forceinline__ bool xs_word_hits(unsigned word, unsigned launch) { return word != 0u && (int)(word - launch) >= 0; }
 __device__ __forceinline__ bool xs_aborted(const kk_xs_dev& xs) {
-    return __builtin_amdgcn_raw_buffer_load_b32(xs_rsrc((unsigned long long)xs.mine), KK_XS_ERR_OFFSET, 0, KK_XS_AUX) == xs.launch;
+    return xs_word_hits(__builtin_amdgcn_raw_buffer_load_b32(xs_rsrc((unsigned long long)xs.mine), KK_XS_ERR_OFFSET, 0, KK_XS_AUX), xs.launch);
 }
 // block 0, wave 0: the rank's partial of value v (lane v < nval) into slot (v, my rank) of every rank's area
 __device__ __forceinline__ void xs_publish(const kk_xs_dev& xs, unsigned red, int nval, double local) {
@@ -57,8 +65,9 @@ __device__ __forceinline__ void xs_publish(const kk_xs_dev& xs, unsigned red, in
 // Called by wave 0 (all 64 lanes) of every block once the rank's partials are known.  `local`: lane v < nval holds the rank's
 // partial of value v (same bits in every block).  On success lane v * 8 .. v * 8 + 7 hold the total of value v; returns false
 // after a timeout, a raised local flag or a peer's abort (the caller raises the local flag and leaves without committing).
+// *originator (optional): the failure is THIS wave's own timeout -- only then does the caller tell the peers (xs_abort).
 __device__ __forceinline__ bool xs_allreduce(const kk_xs_dev& xs, unsigned red, int nval, double local, const int* __restrict__ err, long long timeout_ticks,
-                                             double& total) {
+                                             double& total, bool* originator = nullptr) {
     const int lane = threadIdx.x & 63;
     const unsigned tag = xs.tag0 + red;
     const unsigned set_off = (tag & 1u) * (unsigned)KK_XS_SET_BYTES;
@@ -72,21 +81,23 @@ __device__ __forceinline__ bool xs_allreduce(const kk_xs_dev& xs, unsigned red, 
         const xs_v4u g = __builtin_amdgcn_raw_buffer_load_b128(rm, set_off + (unsigned)lane * 16u, 0, KK_XS_AUX);
         const unsigned xerr = __builtin_amdgcn_raw_buffer_load_b32(rm, KK_XS_ERR_OFFSET, 0, KK_XS_AUX);
         const bool ok = !active || (g.x == tag && g.w == tag);
-        if (__all(ok) && xerr != xs.launch) {
+        const bool hit = xs_word_hits(xerr, xs.launch);
+        if (__all(ok) && !hit) {
             x = active ? __longlong_as_double((long long)(((unsigned long long)g.y << 32) | g.z)) : 0.0;
             break;
         }
         __builtin_amdgcn_s_sleep(1);
         const int lerr = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const bool late = wall_clock64() - t0 > timeout_ticks;
-        if (xerr == xs.launch || lerr || late) {
+        if (hit || lerr || late) {
+            if (originator) *originator = !hit && !lerr;
             // post-mortem (KK_XSYNC_DEBUG=1 prints it): the first block that gave up leaves what it saw in the tail of its rank's area
             if (__builtin_amdgcn_raw_buffer_load_b32(rm, KK_XS_DBG_OFFSET, 0, KK_XS_AUX) != xs.launch) {
                 __builtin_amdgcn_raw_buffer_store_b32(g.x, rm, KK_XS_DBG_OFFSET + 64u + (unsigned)lane * 4u, 0, KK_XS_AUX);
                 if (lane == 0) {
                     __builtin_amdgcn_raw_buffer_store_b32(tag, rm, KK_XS_DBG_OFFSET + 4u, 0, KK_XS_AUX);
                     __builtin_amdgcn_raw_buffer_store_b32((unsigned)nval, rm, KK_XS_DBG_OFFSET + 8u, 0, KK_XS_AUX);
-                    __builtin_amdgcn_raw_buffer_store_b32((xerr == xs.launch ? 1u : 0u) | (lerr ? 2u : 0u) | (late ? 4u : 0u), rm, KK_XS_DBG_OFFSET + 12u, 0, KK_XS_AUX);
+                    __builtin_amdgcn_raw_buffer_store_b32((hit ? 1u : 0u) | (lerr ? 2u : 0u) | (late ? 4u : 0u), rm, KK_XS_DBG_OFFSET + 12u, 0, KK_XS_AUX);
                     __builtin_amdgcn_raw_buffer_store_b32(blockIdx.x, rm, KK_XS_DBG_OFFSET + 16u, 0, KK_XS_AUX);
                     __builtin_amdgcn_raw_buffer_store_b32(red, rm, KK_XS_DBG_OFFSET + 20u, 0, KK_XS_AUX);
                     __builtin_amdgcn_raw_buffer_store_b32(xs.launch, rm, KK_XS_DBG_OFFSET, 0, KK_XS_AUX);
