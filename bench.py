@@ -232,6 +232,37 @@ def read_ceiling():
         return None
 
 
+def read_gather_ceiling(table_doubles: int = 393216):
+    """the box's own RANDOM-GATHER rate for an L2-resident table with a value stream (tools/gather_rate.hip --json, the column tile of the
+    tiled SELL format as the table): the ceiling of config 4's apply, which issues one L2 request per stored entry (DESIGN section 3,
+    profiles/r03_gather_rate_ceiling.json).  None when the tool is not built."""
+    import subprocess
+    exe = ROOT / "tools" / "bin" / "gather_rate"
+    if not exe.exists():
+        return None
+    try:
+        r = subprocess.run([str(exe), "--json", str(table_doubles)], capture_output=True, text=True, timeout=120)
+        ln = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        return json.loads(ln[-1]) if r.returncode == 0 and ln else None
+    except Exception:
+        return None
+
+
+def gather_roofline(leg: dict, nnz: int, applies_per_sweep: int, ceiling):
+    """config 4: next to the HBM fraction (which the gather-bound apply can never move) the fraction of the box's gather ceiling"""
+    roof = leg.get("roofline") or {}
+    k = (leg.get("kernels") or {}).get("k_spmv_sell")
+    if not roof or not k or not k.get("ms_per_sweep"):
+        return
+    ach = nnz * applies_per_sweep / (k["ms_per_sweep"] * 1e-3) / 1e9
+    roof["achieved_Ggathers_per_s"] = round(ach, 1)
+    if ceiling and ceiling.get("Ggathers_per_s"):
+        roof["gather_ceiling_Ggathers_per_s"] = ceiling["Ggathers_per_s"]
+        roof["frac_of_gather_ceiling"] = round(ach / ceiling["Ggathers_per_s"], 4)
+        roof["gather_ceiling"] = {k_: ceiling[k_] for k_ in ("table_bytes", "in_flight", "grid", "value_stream") if k_ in ceiling}
+    roof["bound_is"] = "gather rate (one L2 request per stored entry), not HBM: `frac` cannot approach 1; `frac_of_gather_ceiling` is the figure to read"
+
+
 def physical_roofline(kernel: str, seconds: float, launches: int, traffic_bytes, model_bytes, alg_bytes, min_bytes=None, note=None):
     """roofline object of one kernel class over a timed region: `achieved` = bytes the kernel really moved (counter traffic
     when a stamped PMC pass exists, the byte model of DESIGN.md otherwise) / its event-timed duration; `frac` = achieved /
@@ -421,6 +452,8 @@ def main():
         wd.start()
 
     ceiling = read_ceiling() if (world == 1 and not os.environ.get("KK_BENCH_FORCE_DIST") and not args.only_leg) else None
+    gather_ceiling = read_gather_ceiling() if (world == 1 and not os.environ.get("KK_BENCH_FORCE_DIST") and
+                                               (args.config == "gkl" or args.only_leg == "gkl" or (args.config == "lanczos" and not args.no_configs and not args.only_leg and args.ny == NY))) else None
 
     import krylovkit_hip as kk
     from krylovkit_hip import dist as kd
@@ -951,6 +984,8 @@ def main():
                 t6 = min(spec["keep"]["expands_only"]() for _ in range(3))
                 leg["ms_per_block_step"] = round(t6 / spec["units"] * 1e3, 3)
                 leg["block_step_algorithmic_equiv_frac"] = round(spec["alg"] / t6 / 1e9 / HBM_PEAK_GBPS, 4)
+            if name == "gkl":
+                gather_roofline(leg, spec["keep"]["nnz"], spec["units"] * 2 + 2, gather_ceiling)
             configs[key] = leg
             del spec
 

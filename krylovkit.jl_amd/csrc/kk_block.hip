@@ -170,12 +170,13 @@ static int block_qr_strict(kk_basis b, int c_in, int p, int c_out, double tol, d
 // beta_j > 1e-5 |b_j|), in which case the reference's block_qr! keeps every column and does not
 // drift; otherwise the faithful column-by-column path below runs on the untouched input.
 static int block_qr_run(kk_basis b, int c_in, int p, int c_out, double tol, double* R, int ldr, int* good_idx, int* ngood,
-                        int* is_drift) {
+                        int* is_drift, const double* G_known = nullptr /* B'B (p x p, column-major) when the caller has it already */) {
     kk_ctx c = b->ctx;
     if (c->block_mode == 1 && c_out != c_in && p <= 64 && p >= 2) {
         const int64_t ld = b->ld;
         std::vector<double> G((size_t)p * p), R1, R2, Ri;
-        KK_TRY(block_inner_run(c, b->col(c_in), ld, p, b->col(c_in), ld, p, ld, G.data(), p));
+        if (G_known) G.assign(G_known, G_known + (size_t)p * p);
+        else KK_TRY(block_inner_run(c, b->col(c_in), ld, p, b->col(c_in), ld, p, ld, G.data(), p));
         if (chol_upper_safe(G, p, R1, 1e-5, 1000.0 * tol)) {
             triu_inverse(R1, p, Ri);
             // Q1 = B * R1^-1 (out of place)
@@ -298,18 +299,26 @@ KK_API int kk_blocklanczos_initialize(kk_op op, kk_basis b, int c_x0, int bs0, i
     std::vector<double> G((size_t)bs0 * bs0), R((size_t)bs0 * bs0);
     std::vector<int> good(bs0);
     double n2 = 0;
-    for (int j = 0; j < bs0; ++j) {
-        KK_TRY(kk_launch_nrm2(c, b->col(c_x0 + j), b->ld, SCP(c, SC_NRM2)));
-        KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2, 1, 0));
-        KK_TRY(stream_sync(c));
-        n2 += pin(c, WS_SCAL + SC_NRM2)[0];
+    if (c->block_mode == 1 && bs0 >= 2 && bs0 <= 64) {
+        // |X0|_F^2 = trace(X0' X0): ONE Gram launch and one host round trip instead of bs0 of each (the 16 k_dot +
+        // 16 synchronisations of a bs = 16 initialize).  The figure only decides whether the start block vanishes.
+        KK_TRY(block_inner_run(c, b->col(c_x0), b->ld, bs0, b->col(c_x0), b->ld, bs0, b->ld, G.data(), bs0));
+        for (int j = 0; j < bs0; ++j) n2 += G[j + (size_t)bs0 * j];
+    } else {
+        for (int j = 0; j < bs0; ++j) {
+            KK_TRY(kk_launch_nrm2(c, b->col(c_x0 + j), b->ld, SCP(c, SC_NRM2)));
+            KK_TRY(ws_fetch_async(c, WS_SCAL + SC_NRM2, 1, 0));
+            KK_TRY(stream_sync(c));
+            n2 += pin(c, WS_SCAL + SC_NRM2)[0];
+        }
     }
     if (n2 == 0.0) {
         kk_set_error("initial vector should not have norm zero");
         return KK_ERR_ZERO_NORM;
     }
     int ng = 0, drift = 0;
-    KK_TRY(block_qr_run(b, c_x0, bs0, 0, qr_tol, R.data(), bs0, good.data(), &ng, &drift));  // X1 = block_qr!(X0)[good]  :175-177
+    const bool have_G = c->block_mode == 1 && bs0 >= 2 && bs0 <= 64;
+    KK_TRY(block_qr_run(b, c_x0, bs0, 0, qr_tol, R.data(), bs0, good.data(), &ng, &drift, have_G ? G.data() : nullptr));  // X1 = block_qr!(X0)[good]  :175-177
     KK_CHECK(ng >= 1, KK_ERR_ZERO_NORM, "kk_blocklanczos_initialize: start block has numerical rank 0");
     // AX1 = A X1 ; M1 = block_inner(X1, AX1) ; AX1[j] -= X1[i] M1[i,j]   :181-192
     KK_TRY(kk_launch_spmm(c, op->A, b->col(0), b->ld, b->col(c_r), b->ld, ng));

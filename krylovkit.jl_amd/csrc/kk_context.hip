@@ -227,6 +227,12 @@ KK_API int kk_ctx_set_option(kk_ctx c, const char* key, double value) {
         c->spmv_dia_const = value != 0;
     } else if (!strcmp(key, "spmv_dia_aligned")) {
         c->spmv_dia_aligned = value != 0;
+    } else if (!strcmp(key, "spmv_dia_sw")) {
+        KK_CHECK(value == 0 || value == 1 || value == 2, KK_ERR_INVALID, "spmv_dia_sw must be 0 (k_spmv_dia), 1 or 2 (strips per wave of k_spmv_dia_sw)");
+        c->spmv_dia_sw = (int)value;
+    } else if (!strcmp(key, "spmv_dia_sw_lines")) {
+        KK_CHECK(value == 0 || (value >= 2 && value <= 4096), KK_ERR_INVALID, "spmv_dia_sw_lines must be 0 (by size) or in 2..4096");
+        c->spmv_dia_sw_lines = (int)value;
     } else if (!strcmp(key, "spmv_dia_pairs")) {
         KK_CHECK(value == 0 || value == 1 || value == 2 || value == 4, KK_ERR_INVALID, "spmv_dia_pairs must be 0 (by size), 1, 2 or 4");
         c->spmv_dia_pairs = (int)value;
@@ -336,6 +342,9 @@ KK_API int kk_ctx_get_option(kk_ctx c, const char* key, double* value) {
     else if (!strcmp(key, "spmv_dia")) *value = c->spmv_dia;
     else if (!strcmp(key, "spmv_dia_const")) *value = c->spmv_dia_const;
     else if (!strcmp(key, "spmv_dia_aligned")) *value = c->spmv_dia_aligned;
+    else if (!strcmp(key, "spmv_dia_sw")) *value = c->spmv_dia_sw;
+    else if (!strcmp(key, "spmv_dia_sw_lines")) *value = c->spmv_dia_sw_lines;
+    else if (!strcmp(key, "spmv_dia_sw_launches")) *value = (double)c->spmv_dia_sw_launches;
     else if (!strcmp(key, "spmm_dia")) *value = c->spmm_dia;
     else if (!strcmp(key, "spmm_dia_lines")) *value = c->spmm_dia_lines;
     else if (!strcmp(key, "spmm_dia_al")) *value = c->spmm_dia_al;
@@ -615,6 +624,9 @@ KK_API int kk_vec_copy_scal(kk_basis by, int cy, kk_basis bx, int cx, double a) 
         return kk_launch_copy_scal(by->ctx, by->col(cy), bx->col(cx), by->ld, 1.0);
     }
     CHECK_COL_BOUNDS(bx, cx); CHECK_COL_BOUNDS(by, cy); CHECK_SAME(bx, by);   // (validation before any side effect)
+    // x = 1 * x in place: nothing to do (a start block handed over as columns of the slab it already lives in, blocklanczos.jl:159-166
+    // -- the bench's 16 start vectors used to cost 16 read + write passes per sweep here)
+    if (by == bx && cy == cx && a == 1.0) { CHECK_COL_RO(bx, cx); return KK_OK; }
     if (!(by == bx && cy == cx)) norm_discard(by, cy);   // the destination is overwritten as a whole: no point in settling it first
     CHECK_COL(bx, cx); CHECK_COL(by, cy);
     gram_touch(by, cy);

@@ -161,6 +161,9 @@ struct kk_ctx_s {
     int spmv_dia_pairs = 0;      // row pairs per lane of k_spmv_dia: 0 = by size, or 1 / 2 / 4 (4: value-free form only)
     int spmv_dia_aligned = 1;    // ... 5-point stencils with an even line length: far neighbours as aligned 16-byte pairs, +-1 neighbours by lane shift (0: the 8-byte loads of rounds 2-4)
     int spmv_dia_const = 1;      // ... value-free kernel when the stencil has constant coefficients (0: always stream the diagonals)
+    int spmv_dia_sw = 1;         // ... value-free 5-point stencils with an even line length: the SWEEPING kernel (k_spmv_dia_sw), strips per wave (1 / 2); 0 = k_spmv_dia
+    int spmv_dia_sw_lines = 0;   // ... its grid lines per wave sweep (0: by operator size)
+    int64_t spmv_dia_sw_launches = 0;   // launches of the sweeping single-vector apply (diagnostics: "spmv_dia_sw_launches")
     int spmm_dia = 1;            // multi-column apply of a detected grid stencil: sweeping diagonal kernel (0: ELL gather kernel)
     int spmm_dia_lines = 16;     // ... grid lines per wave sweep
     int spmm_dia_al = 2;         // ... aligned 16-byte form (k_spmm_dia_al): columns per wave (2 / 4), 0 = the 8-byte form

@@ -749,6 +749,140 @@ __global__ __launch_bounds__(KK_TPB, (NBW <= 2 ? 6 : 3)) void k_spmm_dia_al(int6
     }
 }
 
+// The SINGLE-VECTOR apply of a value-free 5-point stencil as a sweep (reference: src/apply.jl:1, the call sites
+// factorizations/lanczos.jl:306-310 and arnoldi.jl:242).  k_spmv_dia<5, U, true, true> covers 512-row chunks and fetches the far neighbours
+// of every chunk as loads of their own: three 16-byte x loads per row pair, two of them for lines some other block has requested a moment
+// before -- cheap in HBM bytes, not in L2 requests (0.67 of peak at 10 M rows, 0.39 in the launch-bound 2 M-row applies).  Here, as in
+// k_spmm_dia_al, a wave walks `lines` grid lines of its strip through a FOUR-line window that rotates by renaming:
+//   * a lane owns positions 2l, 2l + 1 of a 128-wide strip: per line ONE 16-byte load of x (line t + 2 requested before line t is
+//     multiplied), one of v_prev (requested with it: two lines ahead), one 16-byte store of y;
+//   * the +-1 neighbours come from the lanes next door (DPP wave shifts); lanes 0 / 63 fetch the strip's edge elements through a
+//     descriptor whose out-of-range offset switches the other 62 lanes off;
+//   * a wave carries NS strips side by side (independent streams: more loads in flight per wave), a block 4 NS of them;
+//   * the fused epilogues of k_spmv_dia -- scale by the device scalar, a0 x, -beta v_prev, the alpha dot in CGS or MGS order, |y|^2,
+//     non-temporal store -- run on the line in registers.
+// Blocks are dealt to the XCDs round-robin, so the (strip chunk, line group) grid is laid out in VIRTUAL COLUMNS: NV = nbl x bands of them
+// (nbl chunks per line, the lines split into `bands` so that NV is a multiple of 8); block lb works on column lb % NV -- always the same
+// XCD -- and steps DOWN the lines from launch row to launch row: the line group below, whose first halo line is this group's last line,
+// belongs to the block NV places later on the same XCD (resident at the same time: the halo is an L2 hit), while the nbl blocks of one
+// line group read a contiguous stretch of HBM.
+// y: same operands in the same order as k_spmv_dia -- bit-identical; the inner products are summed in a different order (within rounding).
+template <int NS> struct sw_line { d2 v[NS]; double e[NS]; d2 pv[NS]; };
+template <int NS, bool NTY, bool VPREV>
+__global__ __launch_bounds__(KK_TPB) void k_spmv_dia_sw(int64_t D, int64_t nrows, const double* __restrict__ x, double* __restrict__ y, spmv_epi e, dia_cst cst,
+                                                        int nbl, int NV, int gpb, int lines, int64_t Tlo, int64_t T, int64_t row_lo, int64_t row_hi,
+                                                        double* __restrict__ part_dot, double* __restrict__ part_nrm) {
+    __shared__ double sm[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int vc = (int)(blockIdx.x % (unsigned)NV);
+    const int band = vc / nbl, sc = vc % nbl;
+    const int crows = (int)(gridDim.x / (unsigned)NV);
+    double dacc = 0, nacc = 0;
+    const double xs = e.xs_dev ? *e.xs_dev : 1.0;
+    const double bp = VPREV ? (e.bprev_dev ? *e.bprev_dev : e.bprev) : 0.0;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)(nrows * 8), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, (int)(nrows * 8), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)(VPREV ? e.vprev : x), 0, (int)(nrows * 8), 0x00020000);
+    const unsigned off_none = 0xfffffff0u;
+    typedef unsigned v4u_ __attribute__((ext_vector_type(4)));
+    int64_t p[NS], pe[NS];
+    bool own[NS], eown[NS];
+    double cW0[NS], cE1[NS];
+    bool any = false;
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        const int64_t strip = ((int64_t)sc * (KK_TPB / 64) + wave) * NS + j;
+        const int64_t p0 = strip * 128;
+        p[j] = p0 + 2 * lane;
+        own[j] = p[j] < D;                                   // (D even: a pair is inside the line or outside)
+        pe[j] = lane == 0 ? p0 - 1 : p0 + 128;               // lane 0: left neighbour of the strip, lane 63: right neighbour
+        eown[j] = (lane == 0 && strip > 0 && p0 < D) || (lane == 63 && pe[j] < D);
+        cW0[j] = p[j] == 0 ? 0.0 : cst.c[1];                 // the -1 entry does not exist at position 0 ...
+        cE1[j] = p[j] + 2 == D ? 0.0 : cst.c[3];             // ... the +1 entry not at position D - 1
+        any = any || p0 < D;
+    }
+    const double cS = cst.c[0], cW1 = cst.c[1], cC = cst.c[2], cE0 = cst.c[3], cN = cst.c[4];
+    if (any) {   // (wave-uniform: a wave whose strips all lie beyond the line only joins the reductions below)
+        for (int c = (int)(blockIdx.x / (unsigned)NV); c < gpb; c += crows) {
+            const int64_t t0 = Tlo + ((int64_t)band * gpb + c) * lines;
+            if (t0 >= T) break;
+            const int64_t t1 = imin(t0 + lines, T);
+            // line t of the window: the x pairs (and the v_prev pairs of the lines that are multiplied) two lines ahead, the strip's edge
+            // elements one line ahead.  Lines outside the operator read as zero (a negative 32-bit offset wraps beyond the records)
+            auto fetch_pairs = [&](sw_line<NS>& L, int64_t t) {
+#pragma unroll
+                for (int j = 0; j < NS; ++j) {
+                    const unsigned vo = (t <= t1 && own[j]) ? (unsigned)((t * D + p[j]) * 8) : off_none;
+                    const v4u_ q = __builtin_amdgcn_raw_buffer_load_b128(rx, vo, 0, 0);
+                    L.v[j] = d2{__hiloint2double((int)q.y, (int)q.x), __hiloint2double((int)q.w, (int)q.z)};
+                    if (VPREV) {
+                        const unsigned po = (t >= t0 && t < t1 && own[j]) ? (unsigned)((t * D + p[j]) * 8) : off_none;
+                        const v4u_ q2 = __builtin_amdgcn_raw_buffer_load_b128(rp, po, 0, 0);
+                        L.pv[j] = d2{__hiloint2double((int)q2.y, (int)q2.x), __hiloint2double((int)q2.w, (int)q2.z)};
+                    }
+                }
+            };
+            auto fetch_edges = [&](sw_line<NS>& L, int64_t t) {
+#pragma unroll
+                for (int j = 0; j < NS; ++j) {
+                    const unsigned eo = (t < t1 && eown[j]) ? (unsigned)((t * D + pe[j]) * 8) : off_none;
+                    const dia_v2u q2 = __builtin_amdgcn_raw_buffer_load_b64(rx, eo, 0, 0);
+                    L.e[j] = __hiloint2double((int)q2.y, (int)q2.x);
+                }
+            };
+            auto line = [&](const sw_line<NS>& Lm, const sw_line<NS>& L0, const sw_line<NS>& Lp, int64_t t) {
+#pragma unroll
+                for (int j = 0; j < NS; ++j) {
+                    const int64_t r = t * D + p[j];
+                    // (row_lo, row_hi even: both rows of the pair or none; a store that is not due is switched off by its offset, like the loads)
+                    const bool due = own[j] && r >= row_lo && r < row_hi;
+                    const unsigned so = due ? (unsigned)(r * 8) : off_none;
+                    const double left = dia_wave_shift_old<0x138>(L0.e[j], L0.v[j].y), right = dia_wave_shift_old<0x130>(L0.e[j], L0.v[j].x);
+                    double s0 = cS * Lm.v[j].x;
+                    s0 = fma(cW0[j], left, s0);
+                    s0 = fma(cC, L0.v[j].x, s0);
+                    s0 = fma(cE0, L0.v[j].y, s0);
+                    s0 = fma(cN, Lp.v[j].x, s0);
+                    double s1 = cS * Lm.v[j].y;
+                    s1 = fma(cW1, L0.v[j].x, s1);
+                    s1 = fma(cC, L0.v[j].y, s1);
+                    s1 = fma(cE1[j], right, s1);
+                    s1 = fma(cN, Lp.v[j].y, s1);
+                    // the epilogue of k_spmv_dia, operation by operation
+                    const double u0 = s0 * xs, u1 = s1 * xs;
+                    d2 out{e.a1 * u0, e.a1 * u1};
+                    const d2 xc{L0.v[j].x * xs, L0.v[j].y * xs};
+                    if (e.a0 != 0.0) { out.x = fma(e.a0, xc.x, out.x); out.y = fma(e.a0, xc.y, out.y); }
+                    if (e.dot_mode == 1 && due) { dacc = fma(xc.x, out.x, dacc); dacc = fma(xc.y, out.y, dacc); }
+                    if (VPREV) { out.x = fma(-bp, L0.pv[j].x, out.x); out.y = fma(-bp, L0.pv[j].y, out.y); }
+                    if (r + 1 >= nrows) out.y = 0.0;   // odd nrows: keep the pad row zero
+                    if (e.dot_mode == 2 && due) { dacc = fma(xc.x, out.x, dacc); dacc = fma(xc.y, out.y, dacc); }
+                    if (e.want_nrm && due) { nacc = fma(out.x, out.x, nacc); nacc = fma(out.y, out.y, nacc); }
+                    v4u_ q;
+                    q.x = (unsigned)__double2loint(out.x); q.y = (unsigned)__double2hiint(out.x); q.z = (unsigned)__double2loint(out.y); q.w = (unsigned)__double2hiint(out.y);
+                    if (NTY) __builtin_amdgcn_raw_buffer_store_b128(q, ry, so, 0, 2); else __builtin_amdgcn_raw_buffer_store_b128(q, ry, so, 0, 0);
+                }
+            };
+            sw_line<NS> A, B, C, E;
+            fetch_pairs(A, t0 - 1); fetch_pairs(B, t0); fetch_edges(B, t0); fetch_pairs(C, t0 + 1);
+            for (int64_t t = t0;;) {
+                fetch_pairs(E, t + 2); fetch_edges(C, t + 1); line(A, B, C, t); if (++t >= t1) break;
+                fetch_pairs(A, t + 2); fetch_edges(E, t + 1); line(B, C, E, t); if (++t >= t1) break;
+                fetch_pairs(B, t + 2); fetch_edges(A, t + 1); line(C, E, A, t); if (++t >= t1) break;
+                fetch_pairs(C, t + 2); fetch_edges(B, t + 1); line(E, A, B, t); if (++t >= t1) break;
+            }
+        }
+    }
+    if (e.dot_mode) {
+        double t = block_sum(dacc, sm);
+        if (threadIdx.x == 0) part_dot[blockIdx.x] = t;
+    }
+    if (e.want_nrm) {
+        double t = block_sum(nacc, sm);
+        if (threadIdx.x == 0) part_nrm[blockIdx.x] = t;
+    }
+}
+
 // ranged launches: rows [r0, r1) of an ELL / diagonal operator; partial sums go to pd / pn + *nblk_io, *nblk_io advances
 static void launch_spmv_ell_rows(kk_ctx ctx, const kk_sparse_dev& M, const double* x, double* y, const spmv_epi& e, int64_t r0,
                                  int64_t r1, double* pd, double* pn, int* nblk_io, int max_blocks) {
@@ -784,6 +918,36 @@ static void launch_spmv_dia_rows(kk_ctx ctx, const kk_sparse_dev& M, const doubl
 #define SPMV_DIA_ARGS dim3(nblk), dim3(KK_TPB), 0, ctx->stream, M.dia_val, M.dia_ld, of, M.nrows, x, y, e, nb_logical, pd + *nblk_io, pn + *nblk_io, r0, r1, cst
     // 16-byte far loads + lane-shift neighbours (see k_spmv_dia): 5-point stencil, even grid-line length, byte offsets within 32 bits
     const bool al = ctx->spmv_dia_aligned && M.dia_pts == 5 && (D & 1) == 0 && M.nrows * 8 < ((int64_t)1 << 31) && (r0 & 1) == 0;
+    // the sweeping form (k_spmv_dia_sw): value-free 5-point stencil whose lines start at phase 0, 16-byte aligned vectors, an even row range
+    const int ns = ctx->spmv_dia_sw;
+    const bool aligned16 = (((uintptr_t)x | (uintptr_t)y | (uintptr_t)(e.vprev ? e.vprev : x)) & 15) == 0;
+    // (a line so long that one launch row of blocks would not fit the partial-sum rows stays with k_spmv_dia: 4096 blocks x 512 positions)
+    if ((ns == 1 || ns == 2) && al && cc && M.dia_phase == 0 && e.dot_mode != 3 && e.acc == 0 && aligned16 && (r1 & 1) == 0 && M.nrows * 8 < (int64_t)2000000000 &&
+        (D + (KK_TPB / 64) * ns * 128 - 1) / ((KK_TPB / 64) * ns * 128) * 8 <= max_blocks) {
+        const int64_t Tlo = r0 / D, T = (r1 + D - 1) / D;
+        // lines per sweep: 0 = by size -- short operators are launch-bound (few waves, each paying the window fill): longer sweeps there
+        const int lines = ctx->spmv_dia_sw_lines > 0 ? ctx->spmv_dia_sw_lines : (r1 - r0 >= 6000000 ? 8 : 16);
+        const int wpb = (KK_TPB / 64) * ns * 128;                       // positions of a line one block covers
+        const int nbl = (int)((D + wpb - 1) / wpb);                     // blocks per line group
+        int g8 = nbl, b8 = 8;
+        while (b8) { const int t_ = g8 % b8; g8 = b8; b8 = t_; }       // gcd(nbl, 8)
+        int bands = 8 / g8;
+        const int64_t ngroups = (T - Tlo + lines - 1) / lines;
+        while (bands > 1 && ngroups < 4 * bands) bands >>= 1;           // (too few line groups to split: some XCDs idle rather than empty bands)
+        const int NV = nbl * bands;
+        const int gpb = (int)((ngroups + bands - 1) / bands);
+        const int crows = std::max(1, std::min(gpb, max_blocks / NV));
+        const int nblk_sw = crows * NV;
+        ++ctx->spmv_dia_sw_launches;
+#define SW_ARGS dim3(nblk_sw), dim3(KK_TPB), 0, ctx->stream, D, M.nrows, x, y, e, cst, nbl, NV, gpb, lines, Tlo, T, r0, r1, pd + *nblk_io, pn + *nblk_io
+#define SW_CASE(NSV) do { if (e.nt_store) { if (e.vprev) hipLaunchKernelGGL((k_spmv_dia_sw<NSV, true, true>), SW_ARGS); else hipLaunchKernelGGL((k_spmv_dia_sw<NSV, true, false>), SW_ARGS); } \
+                          else { if (e.vprev) hipLaunchKernelGGL((k_spmv_dia_sw<NSV, false, true>), SW_ARGS); else hipLaunchKernelGGL((k_spmv_dia_sw<NSV, false, false>), SW_ARGS); } } while (0)
+        if (ns == 2) SW_CASE(2); else SW_CASE(1);
+#undef SW_CASE
+#undef SW_ARGS
+        *nblk_io += nblk_sw;
+        return;
+    }
     if (al) {
         if (cc) {
             if (U == 4) hipLaunchKernelGGL((k_spmv_dia<5, 4, true, true>), SPMV_DIA_ARGS);

