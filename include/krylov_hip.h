@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define KK_VERSION 301 /* 0.3.1: same 92 entry points; persistent MGS kernels on row-sharded contexts (xsync), run-ahead of the projection route, commit consumed by scale!!(r, 1/beta) (0.3.0: mgs_mode auto is the default, no limit on the basis size, constant-coefficient stencils) */
+#define KK_VERSION 302 /* 0.3.2: same 92 entry points; sweeping single-vector stencil apply (spmv_dia_sw), cross-rank route chosen from the hand-shake's own timings ("xsync" 0 / 1 / 2, "xsync_hop_us", "comm_allreduce_us"), route decisions of a cross-rank context rank-invariant, every entry point other than expand! voids the run-ahead, BlockLanczos initialize ends in the normalised commit.  0.3.1: same 92 entry points; persistent MGS kernels on row-sharded contexts (xsync), run-ahead of the projection route, commit consumed by scale!!(r, 1/beta) (0.3.0: mgs_mode auto is the default, no limit on the basis size, constant-coefficient stencils) */
 
 /* status codes */
 #define KK_OK 0
@@ -85,7 +85,19 @@ typedef enum {
  *                 enqueues the NEXT step's apply, scale, sweep / projection step and read-back before the host waits for the
  *                 current one (bit-identical results; dropped if anything touches the slab, or another slab of the context is
  *                 handed to any entry point, in between).
- * Row-sharded contexts (kk_comm_init): "xsync" (default 1; must be the same on every rank): the persistent kernels of the MGS
+ *                 Since 0.3.2 EVERY entry point other than the expand! steps themselves (and the plain downloads / gathers, which write
+ *                 no device scalar) voids what was enqueued ahead, also on the slab that owns it: a norm or inner product of a basis
+ *                 column overwrites the shared device scalars the step in flight reads.  The next expand! redoes apply and sweep.
+ * Row-sharded contexts (kk_comm_init): "xsync" (default 1 = where it pays, 2 = always, 0 = never; must be the same on every rank):
+ * kk_comm_init times 64 in-kernel reductions over the ranks and 20 small RCCL all-reduces ("xsync_hop_us", "comm_allreduce_us": the
+ * slowest rank's figures, identical on all ranks) and a sweep takes the in-kernel route iff
+ *     reductions x xsync_hop_us  <=  comm_allreduce_us + vector_steps x t_sync x (rows / threshold_rows - 1)
+ * (t_sync = the basis traffic the kernel saves per vector AT its threshold: 2.6 us for the register-resident kernel, 0.4 us for the panel kernel; threshold_rows = the single-chip
+ * thresholds "persist_min_rows" / "panel_min_rows" scaled by the CU share): what the cross-rank round trips cost against the one RCCL
+ * all-reduce per step the low-synchronisation route needs on top and the single-chip gain of the persistent kernel.  Route, panel
+ * width and register tile are decided from the LONGEST shard of the slab (one all-reduce per slab and communicator at its first
+ * sweep) and from a CU count all ranks share (the minimum; restored at kk_comm_destroy): every rank arrives at the same launch.
+ * "xsync": the persistent kernels of the MGS
  * family sum their grid-wide inner products over the RANKS inside the launch -- block 0 of a rank stores the rank's partial as
  * a tagged 16-byte granule into every peer's sync area (4 KB of fine-grained device memory per rank, exchanged by
  * hipIpcGetMemHandle / hipIpcOpenMemHandle inside kk_comm_init and checked there by a hand-shake kernel), every block adds the
@@ -135,6 +147,11 @@ typedef enum {
  * "spmm_dia_al" (default 2: the sweeping multi-column apply of a value-free 5-point stencil with an even line length runs in its
  * aligned 16-byte form, 2 or 4 columns per wave; 0 = the 8-byte form; bit-identical), "spmm_dia_al_lines" (default 4: grid lines per
  * wave sweep of that form),
+ * "spmv_dia_sw" (default 1: the single-vector apply of a value-free 5-point stencil with an even line length whose lines start at
+ * phase 0 runs as a SWEEP -- k_spmv_dia_sw: a wave walks the grid lines of its 128-wide strips through a four-line register window,
+ * one 16-byte x load, one v_prev load and one store per line and lane, the fused epilogues on the line in registers; 1 / 2 = strips per
+ * wave, 0 = k_spmv_dia; y bit-identical, inner products to rounding; "spmv_dia_sw_launches" counts), "spmv_dia_sw_lines" (0 = by
+ * operator size, else grid lines per wave sweep),
  * "spmv_dia_aligned" (default 1: 5-point stencils with an even line length load their far neighbours as aligned 16-byte pairs
  * and take the +-1 neighbours from the lanes next door; bit-identical to 0), "panel_lag" (default 0; 1 = panel sweeps outside the
  * strict order through the cross-panel lag-1 kernel -- exact algebra, measured slower at every length, kept as the record),

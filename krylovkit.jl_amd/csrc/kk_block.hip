@@ -286,6 +286,81 @@ KK_API int kk_block_qr(kk_basis b, int c_in, int p, int c_out, double tol, doubl
     return block_qr_run(b, c_in, p, c_out, tol, R, ldr, good_idx, ngood, is_drift);
 }
 
+// device-side layout of the asynchronous block step inside the second half of the block scratch (doubles)
+#define AB_BASE (KK_BLK_SCRATCH / 2 + 64)
+#define AB_FLAG (AB_BASE)            // [4]   0 = fine, 1 / 2 = a CholQR2 safety test failed
+#define AB_NRM (AB_BASE + 4)         // [16]  squared column norms of the new residual block
+#define AB_B (AB_BASE + 20)          // [256] B = R2 R1, column-major ld 16
+#define AB_M (AB_BASE + 276)         // [256] M = X' A X, column-major ld 16
+#define AB_CF (AB_BASE + 532)        // [4]   commit flag of the step: 0 = the update wrote T = W R1^-1 (k_blk_commit_prep), else the plain block
+#define AB_R1 (AB_BASE + 536)        // [256] first CholQR2 factor: of this step (k_blk_chol1) until k_blk_chol2 has read it, then of the NEXT step's commit
+#define AB_READBACK 792              // flag + norms + B + M + commit flag + R1 travel to the host in ONE copy
+#define AB_G (AB_BASE + 792)         // [256] Gram panels of the two CholQR2 rounds
+#define AB_S1 (AB_BASE + 1048)       // [256] staged R1^-1
+#define AB_S2 (AB_BASE + 1304)       // [256] staged R2^-1
+#define AB_S3 (AB_BASE + 1560)       // [512] three-term panel [B' ; M]
+#define AB_P (AB_BASE + 2072)        // [3 * KK_MAX_M * 16] re-orthogonalisation panel V'(AX), row-major; the one-pass step appends
+                                     // the ride-along Gram panel V'X and the corrected panel (kn * st doubles each)
+#define AB_GYY (AB_P + 3 * KK_MAX_M * 16)   // [256] (A X)'(A X), column-major ld 16 (one-pass step)
+#define AB_GW (AB_GYY + 256)                // [256] Gram matrix of the residual block left behind, column-major ld p
+#define AB_END (AB_GW + 256)
+static_assert(AB_END <= KK_BLK_SCRATCH, "block scratch too small for the asynchronous block step");
+
+// The one-pass recurrence of a block step, enqueued without a host round trip (used by expand! for k >= p and by initialize for
+// k = 0, where the panel has no three-term rows and P = X1'(A X1) IS M1 -- blocklanczos.jl:181-192):
+//   AX = A X (X = columns k .. k+p-1)  ->  P = V'(AX) against the whole basis [0, kn), Gram rows of the new block riding along
+//   ->  Pc = (I - E) P  ->  W = AX - V Pc, written as the plain block, or (try_tc) as T = W R1^-1 into the next basis slot kn ..
+// Leaves M in AB_M, the squared column norms in AB_NRM, the commit flag in AB_CF, R1 in AB_R1, T'T in AB_G, the residual Gram
+// matrix in AB_GW, the safety flag in AB_FLAG, and copies the ride-along Gram panel to the pinned mirror.
+static int onepass_enqueue(kk_op op, kk_basis b, int k, int p, int c_rnext, double qr_tol, bool try_tc) {
+    kk_ctx c = b->ctx;
+    const int64_t ld = b->ld;
+    const int st = kk_bu_stride(p);
+    double* D = c->blk;
+    const int kn = k + p;
+    double* AX = try_tc ? b->col(kn) : b->col(c_rnext);
+    KK_TRY(kk_launch_spmm(c, op->A, b->col(k), ld, AX, ld, p));
+    // one pass: P = V'(A X) against the whole basis, AX -= V P.  Rows k-p .. k+p-1 of P are the three-term coefficients
+    // [B' ; M] (blocklanczos.jl:253-260), the other rows the re-orthogonalisation (:277-284); the reference subtracts the
+    // three-term part first and projects the remainder once more ("twice is enough").  A single classical pass is NOT:
+    // the orthogonality error E = V'V - I re-enters as E P and grows geometrically.  Here E is known -- the Gram rows of
+    // every new block ride along in the panel kernel -- and the coefficients are corrected to first order,
+    // P <- (I - E) P (k_blk_panel_correct), which leaves V'w = O(E^2 |P|) like the second pass does.  What remains is the
+    // rounding of the panel itself, eps |A x_j| instead of eps |w_j|: a column that loses more than a factor 10 of its
+    // norm raises flag 3 and the step is repeated on the two-pass route.  Saves the M panel, and one read + one write
+    // of [Xprev X AX] per step.
+    double* P = D + AB_P;
+    double* G2 = P + (int64_t)kn * st;
+    double* Pc = G2 + (int64_t)kn * st;
+    // two accumulator sets: 80 basis columns per launch keep the kernel at two waves per SIMD (128 columns: one)
+    const int chunk = c->gram2_chunk;
+    const int nch = (kn + chunk - 1) / chunk;
+    const int per = ((kn + nch - 1) / nch + 15) / 16 * 16;   // balanced chunks, whole 16-column groups
+    const bool want_gw = c->resid_gram != 0;
+    for (int i0 = 0; i0 < kn; i0 += per)
+        KK_TRY(kk_launch_block_gram2(c, b->col(i0), ld, std::min(per, kn - i0), AX, ld, p, b->col(k), ld, p, ld, P + (int64_t)i0 * st,
+                                     st, G2 + (int64_t)i0 * st, st, (want_gw && i0 == 0) ? D + AB_GYY : nullptr));
+    KK_TRY(kk_allreduce(c, P, 2 * (int64_t)kn * st));
+    if (want_gw) KK_TRY(kk_allreduce(c, D + AB_GYY, 256));
+    KK_TRY(kk_launch_blk_gram_rows(c, G2, st, k, p, b->d_gram, b->cap, b->d_gdiag));
+    KK_TRY(kk_launch_blk_panel_m(c, P, st, k, p, D + AB_M, 16));
+    KK_TRY(kk_launch_blk_panel_correct(c, P, st, kn, p, b->d_gram, b->cap, Pc, b->d_gdiag));
+    if (try_tc) {
+        // first CholQR2 factor of the NEXT step from the predicted Gram matrix (AX)'(AX) - P'Pc, then the update writes
+        // T = W R1^-1 into columns kn.. and accumulates T'T (AB_G); the residual area keeps A X
+        KK_TRY(kk_launch_blk_resid_gram(c, P, Pc, st, kn, p, D + AB_GYY, nullptr, D + AB_GW));
+        KK_TRY(kk_launch_blk_commit_prep(c, D + AB_GW, D + AB_GYY, p, 1000.0 * qr_tol, 1e-3, D + AB_R1, D + AB_S1, st, D + AB_CF));
+        KK_TRY(kk_launch_block_update_commit(c, b->col(0), ld, kn, AX, AX, ld, AX, ld, p, Pc, D + AB_NRM, D + AB_CF, D + AB_S1,
+                                             D + AB_G));
+    } else {
+        KK_TRY(kk_launch_block_update(c, b->col(0), ld, kn, AX, AX, ld, ld, p, Pc, -1.0, 1.0, D + AB_NRM));
+    }
+    KK_TRY(kk_launch_blk_onepass_check(c, P, st, kn, p, D + AB_NRM, 0.1, D + AB_FLAG));
+    if (want_gw) KK_TRY(kk_launch_blk_resid_gram(c, P, Pc, st, kn, p, D + AB_GYY, D + AB_NRM, D + AB_GW));
+    KK_HIP(hipMemcpyAsync(c->h_blk + (G2 - D), G2, (size_t)kn * st * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    return KK_OK;
+}
+
 KK_API int kk_blocklanczos_initialize(kk_op op, kk_basis b, int c_x0, int bs0, int c_r, double qr_tol, int* bs,
                                           double* M1, int ldm, double* norm_R) {
     KK_TRY(check_square_op(op, b));
@@ -320,6 +395,53 @@ KK_API int kk_blocklanczos_initialize(kk_op op, kk_basis b, int c_x0, int bs0, i
     const bool have_G = c->block_mode == 1 && bs0 >= 2 && bs0 <= 64;
     KK_TRY(block_qr_run(b, c_x0, bs0, 0, qr_tol, R.data(), bs0, good.data(), &ng, &drift, have_G ? G.data() : nullptr));  // X1 = block_qr!(X0)[good]  :175-177
     KK_CHECK(ng >= 1, KK_ERR_ZERO_NORM, "kk_blocklanczos_initialize: start block has numerical rank 0");
+    // Round 6: the recurrence of initialize in the ONE-PASS form of the block steps, ending in the same normalised
+    // commit -- AX1 formed in the next basis slot, P = X1'(A X1) (= M1, with the Gram rows of X1 riding along), the residual written as
+    // T = W R1^-1 with T'T accumulated.  The first expand! then finds its first CholQR2 round done, as every later one does: no Gram pass
+    // over the residual block, no Q1 = W R1^-1 pass (0.8 ms of the 10 M-row sweep), and initialize itself loses the separate
+    // block_inner / update pair.  Same conditions as the commit of a block step; anything else -- and a raised safety flag -- takes the
+    // synchronous route below on the untouched X1.
+    {
+        const int p = ng, st = kk_bu_stride(ng), kn = ng;
+        const bool can = c->block_mode == 1 && c->block_async && (c->block_fuse & 4) && c->block_commit && c->resid_gram && ng == bs0 && ng >= 2 &&
+                         ng <= 16 && !drift && b->tc_skip == 0 && !b->tc_valid && 2 * ng <= c_r && 2 * ng <= c_x0 && 2 * ng <= b->cap &&
+                         ((size_t)kn * st + 64 + st * st + 4 * 16 * 34) * sizeof(double) <= 64 * 1024;
+        if (can) {
+            double* D = c->blk;
+            b->gram_c0 = 0; b->gram_rows = 0;
+            KK_TRY(gram_device(b));
+            if (st > p) KK_HIP(hipMemsetAsync(D + AB_P, 0, (size_t)3 * kn * st * sizeof(double), c->stream));   // pad columns of the row-major panels
+            KK_HIP(hipMemsetAsync(D + AB_FLAG, 0, 4 * sizeof(double), c->stream));
+            c->tc_owner = 0;
+            c->gw_valid = false;
+            KK_TRY(onepass_enqueue(op, b, 0, p, c_r, qr_tol, true));
+            KK_HIP(hipMemcpyAsync(c->h_blk + AB_BASE, D + AB_BASE, AB_READBACK * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            KK_TRY(stream_sync(c));
+            const double* H = c->h_blk + AB_BASE;
+            if (H[0] == 0.0) {
+                if (H[AB_CF - AB_BASE] != 0.0) {   // not committed (decided on the device): the plain residual block sits in the basis slot
+                    KK_HIP(hipMemcpyAsync(b->col(c_r), b->col(kn), (size_t)p * b->ld * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+                    c->gw_valid = true; c->gw_basis = b->uid; c->gw_col = c_r; c->gw_p = p;
+                } else {                           // committed: columns kn .. hold T, the residual area is formed on demand (blk_commit_flush)
+                    b->tc_valid = true; b->tc_k = kn; b->tc_cr = c_r; b->tc_p = p;
+                    memcpy(b->tc_R1, H + (AB_R1 - AB_BASE), (size_t)p * p * sizeof(double));
+                    c->tc_owner = b->uid;
+                }
+                const double* G2h = c->h_blk + AB_P + (int64_t)kn * st;   // host mirror of the Gram rows of X1
+                for (int i = 0; i < p; ++i)
+                    for (int j = 0; j < i; ++j) b->gram[(size_t)i * b->cap + j] = G2h[(size_t)j * st + i];
+                b->gram_rows = kn;
+                for (int j = 0; j < p; ++j)
+                    for (int i = 0; i < p; ++i) M1[i + (size_t)ldm * j] = H[276 + i + 16 * j];
+                double f2 = 0;
+                for (int j = 0; j < p; ++j) f2 += H[4 + j];
+                *norm_R = std::sqrt(f2);
+                *bs = ng;
+                return KK_OK;
+            }
+            b->gram_rows = 0;   // (flag raised: the panel of this attempt is not the basis' Gram record)
+        }
+    }
     // AX1 = A X1 ; M1 = block_inner(X1, AX1) ; AX1[j] -= X1[i] M1[i,j]   :181-192
     KK_TRY(kk_launch_spmm(c, op->A, b->col(0), b->ld, b->col(c_r), b->ld, ng));
     KK_TRY(block_inner_run(c, b->col(0), b->ld, ng, b->col(c_r), b->ld, ng, b->ld, M1, ldm));
@@ -345,26 +467,6 @@ int blk_commit_flush(kk_basis b) {
     const int p = b->tc_p;
     return block_update_run(b->ctx, b->col(b->tc_k), b->ld, p, b->col(b->tc_cr), b->ld, p, b->tc_R1, p, 1.0, 0.0, nullptr);
 }
-
-// device-side layout of the asynchronous block step inside the second half of the block scratch (doubles)
-#define AB_BASE (KK_BLK_SCRATCH / 2 + 64)
-#define AB_FLAG (AB_BASE)            // [4]   0 = fine, 1 / 2 = a CholQR2 safety test failed
-#define AB_NRM (AB_BASE + 4)         // [16]  squared column norms of the new residual block
-#define AB_B (AB_BASE + 20)          // [256] B = R2 R1, column-major ld 16
-#define AB_M (AB_BASE + 276)         // [256] M = X' A X, column-major ld 16
-#define AB_CF (AB_BASE + 532)        // [4]   commit flag of the step: 0 = the update wrote T = W R1^-1 (k_blk_commit_prep), else the plain block
-#define AB_R1 (AB_BASE + 536)        // [256] first CholQR2 factor: of this step (k_blk_chol1) until k_blk_chol2 has read it, then of the NEXT step's commit
-#define AB_READBACK 792              // flag + norms + B + M + commit flag + R1 travel to the host in ONE copy
-#define AB_G (AB_BASE + 792)         // [256] Gram panels of the two CholQR2 rounds
-#define AB_S1 (AB_BASE + 1048)       // [256] staged R1^-1
-#define AB_S2 (AB_BASE + 1304)       // [256] staged R2^-1
-#define AB_S3 (AB_BASE + 1560)       // [512] three-term panel [B' ; M]
-#define AB_P (AB_BASE + 2072)        // [3 * KK_MAX_M * 16] re-orthogonalisation panel V'(AX), row-major; the one-pass step appends
-                                     // the ride-along Gram panel V'X and the corrected panel (kn * st doubles each)
-#define AB_GYY (AB_P + 3 * KK_MAX_M * 16)   // [256] (A X)'(A X), column-major ld 16 (one-pass step)
-#define AB_GW (AB_GYY + 256)                // [256] Gram matrix of the residual block left behind, column-major ld p
-#define AB_END (AB_GW + 256)
-static_assert(AB_END <= KK_BLK_SCRATCH, "block scratch too small for the asynchronous block step");
 
 // expand!(::BlockLanczosIterator) without a host round trip between its kernels (panel mode, 2 <= block size <= 16, no rank
 // drop, no DGKS drift): CholQR2 of the residual block with both Cholesky factorisations, the triangular inverses and
@@ -419,49 +521,11 @@ static int blocklanczos_expand_async(kk_op op, kk_basis b, int k, int p, int c_r
     // Q = Q1 R2^-1 in place (row-local); not executed when k_blk_chol2 found Q1 orthonormal already (device flag)
     KK_TRY(kk_launch_block_update(c, b->col(k), ld, p, nullptr, b->col(k), ld, ld, p, D + AB_S2, 1.0, 0.0, nullptr, D + AB_FLAG + 1));
     // ---- block_lanczosrecurrence: AX = A X ; M = X' AX ; AX -= [Xprev X] [B' ; M]
-    double* AX = try_tc ? b->col(kn) : b->col(c_rnext);
-    KK_TRY(kk_launch_spmm(c, op->A, b->col(k), ld, AX, ld, p));
     if (onepass) {
-        // one pass: P = V'(A X) against the whole basis, AX -= V P.  Rows k-p .. k+p-1 of P are the three-term coefficients
-        // [B' ; M] (blocklanczos.jl:253-260), the other rows the re-orthogonalisation (:277-284); the reference subtracts the
-        // three-term part first and projects the remainder once more ("twice is enough").  A single classical pass is NOT:
-        // the orthogonality error E = V'V - I re-enters as E P and grows geometrically.  Here E is known -- the Gram rows of
-        // every new block ride along in the panel kernel -- and the coefficients are corrected to first order,
-        // P <- (I - E) P (k_blk_panel_correct), which leaves V'w = O(E^2 |P|) like the second pass does.  What remains is the
-        // rounding of the panel itself, eps |A x_j| instead of eps |w_j|: a column that loses more than a factor 10 of its
-        // norm raises flag 3 and the step is repeated on the two-pass route.  Saves the M panel, and one read + one write
-        // of [Xprev X AX] per step.
-        double* P = D + AB_P;
-        double* G2 = P + (int64_t)kn * st;
-        double* Pc = G2 + (int64_t)kn * st;
-        // two accumulator sets: 80 basis columns per launch keep the kernel at two waves per SIMD (128 columns: one)
-        const int chunk = c->gram2_chunk;
-        const int nch = (kn + chunk - 1) / chunk;
-        const int per = ((kn + nch - 1) / nch + 15) / 16 * 16;   // balanced chunks, whole 16-column groups
-        const bool want_gw = c->resid_gram != 0;
-        for (int i0 = 0; i0 < kn; i0 += per)
-            KK_TRY(kk_launch_block_gram2(c, b->col(i0), ld, std::min(per, kn - i0), AX, ld, p, b->col(k), ld, p, ld, P + (int64_t)i0 * st,
-                                         st, G2 + (int64_t)i0 * st, st, (want_gw && i0 == 0) ? D + AB_GYY : nullptr));
-        KK_TRY(kk_allreduce(c, P, 2 * (int64_t)kn * st));
-        if (want_gw) KK_TRY(kk_allreduce(c, D + AB_GYY, 256));
-        KK_TRY(kk_launch_blk_gram_rows(c, G2, st, k, p, b->d_gram, b->cap, b->d_gdiag));
-        KK_TRY(kk_launch_blk_panel_m(c, P, st, k, p, D + AB_M, 16));
-        KK_TRY(kk_launch_blk_panel_correct(c, P, st, kn, p, b->d_gram, b->cap, Pc, b->d_gdiag));
-        if (try_tc) {
-            // first CholQR2 factor of the NEXT step from the predicted Gram matrix (AX)'(AX) - P'Pc, then the update writes
-            // T = W R1^-1 into columns kn.. and accumulates T'T (AB_G); the residual area keeps A X
-            KK_TRY(kk_launch_blk_resid_gram(c, P, Pc, st, kn, p, D + AB_GYY, nullptr, D + AB_GW));
-            KK_TRY(kk_launch_blk_commit_prep(c, D + AB_GW, D + AB_GYY, p, 1000.0 * qr_tol, 1e-3, D + AB_R1, D + AB_S1, st, D + AB_CF));
-            KK_TRY(kk_launch_block_update_commit(c, b->col(0), ld, kn, AX, AX, ld, AX, ld, p, Pc, D + AB_NRM, D + AB_CF, D + AB_S1,
-                                                 D + AB_G));
-        } else {
-            KK_TRY(kk_launch_block_update(c, b->col(0), ld, kn, AX, AX, ld, ld, p, Pc, -1.0, 1.0, D + AB_NRM));
-        }
-        KK_TRY(kk_launch_blk_onepass_check(c, P, st, kn, p, D + AB_NRM, 0.1, D + AB_FLAG));
-        if (want_gw) KK_TRY(kk_launch_blk_resid_gram(c, P, Pc, st, kn, p, D + AB_GYY, D + AB_NRM, D + AB_GW));
-        KK_HIP(hipMemcpyAsync(c->h_blk + (G2 - D), G2, (size_t)kn * st * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        goto readback;
-    }
+        KK_TRY(onepass_enqueue(op, b, k, p, c_rnext, qr_tol, try_tc));
+    } else {
+    double* AX = b->col(c_rnext);
+    KK_TRY(kk_launch_spmm(c, op->A, b->col(k), ld, AX, ld, p));
     KK_TRY(kk_launch_block_gram(c, b->col(k), ld, p, AX, ld, p, ld, D + AB_M, 16));
     KK_TRY(kk_allreduce(c, D + AB_M, 256));
     KK_TRY(kk_launch_blk_fill_m(c, D + AB_M, 16, p, D + AB_S3, st));
@@ -481,7 +545,7 @@ static int blocklanczos_expand_async(kk_op op, kk_basis b, int k, int p, int c_r
         KK_TRY(kk_allreduce(c, D + AB_P, (int64_t)kn * st));
     }
     KK_TRY(kk_launch_block_update(c, b->col(0), ld, kn, AX, AX, ld, ld, p, D + AB_P, -1.0, 1.0, D + AB_NRM));
-readback:
+    }
     // ---- the one read-back
     KK_HIP(hipMemcpyAsync(c->h_blk + AB_BASE, D + AB_BASE, AB_READBACK * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     KK_TRY(stream_sync(c));

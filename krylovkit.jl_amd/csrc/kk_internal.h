@@ -510,7 +510,8 @@ static inline int64_t kk_dec_ld(kk_ctx ctx, int64_t ld) {
 // Against the low-synchronisation route (one more RCCL all-reduce per step: 2.05 instead of 1.06) a persistent launch pays one
 // cross-rank round trip per grid reduction and gains what it gains on ONE chip: nothing at the single-chip threshold `ld_min`,
 // `t_sync_us` per vector-step for every further multiple of it (the saved basis traffic grows with the rows, the exposed
-// reduction does not).  Both prices were measured by this communicator's hand-shake (kk_comm_init; the slowest rank's figures,
+// reduction does not; t_sync_us = the traffic saved per vector AT the threshold: 3.9 B/row x 3.6 M rows = 2.6 us for the
+// register-resident kernel, 8 B/row x 250 k rows = 0.4 us for the panel kernel).  Both prices were measured by this communicator's hand-shake (kk_comm_init; the slowest rank's figures,
 // identical on all ranks):   take the in-kernel route  iff  nred x hop  <=  all-reduce + nvec x t_sync x (ld / ld_min - 1).
 // Option "xsync" = 2 skips the rule (tests; A/B runs), 0 switches the in-kernel route off.
 static inline bool kk_xs_pays(kk_ctx ctx, int64_t ld, int nvec, int nred, double ld_min, double t_sync_us) {
@@ -576,7 +577,9 @@ static inline bool kk_mgs_lowsync(kk_ctx ctx, int64_t ld_local, int m) {
     const double share = (double)ctx->num_cus / 256.0;
     if ((double)ld >= share * (double)ctx->panel_min_rows && kk_mgs_panel_eligible(ctx, ld_local)) {
         const int P = kk_mgs_panel_width(ctx, ld_local, false);
-        if (kk_xs_pays(ctx, ld, 2 * m, (2 * m + P - 1) / P + 1, share * (double)ctx->panel_min_rows, 5.4 / P)) return false;
+        // (gain per vector-step and multiple of the threshold = the basis traffic the panel kernel saves AT the threshold: 8 bytes per row x
+        //  250 k rows at ~5 TB/s = 0.4 us -- profiles/r05_panel_sweep_par.jsonl: 0.58 us per vector-step ahead at 500 k rows, 1.0 at 1 M)
+        if (kk_xs_pays(ctx, ld, 2 * m, (2 * m + P - 1) / P + 1, share * (double)ctx->panel_min_rows, 0.4)) return false;
     }
     if ((double)ld >= share * (double)ctx->persist_min_rows && kk_mgs_persist_eligible(ctx, ld_local, m, 2))
         return !kk_xs_pays(ctx, ld, 2 * m, 2 * m + 1, share * (double)ctx->persist_min_rows, 2.6);

@@ -925,8 +925,10 @@ static void launch_spmv_dia_rows(kk_ctx ctx, const kk_sparse_dev& M, const doubl
     if ((ns == 1 || ns == 2) && al && cc && M.dia_phase == 0 && e.dot_mode != 3 && e.acc == 0 && aligned16 && (r1 & 1) == 0 && M.nrows * 8 < (int64_t)2000000000 &&
         (D + (KK_TPB / 64) * ns * 128 - 1) / ((KK_TPB / 64) * ns * 128) * 8 <= max_blocks) {
         const int64_t Tlo = r0 / D, T = (r1 + D - 1) / D;
-        // lines per sweep: 0 = by size -- short operators are launch-bound (few waves, each paying the window fill): longer sweeps there
-        const int lines = ctx->spmv_dia_sw_lines > 0 ? ctx->spmv_dia_sw_lines : (r1 - r0 >= 6000000 ? 8 : 16);
+        // lines per sweep: 0 = the measured best
+        // (tools/spmv_dia_sw_sweep.py, profiles/r06_spmv_dia_sw_sweep.jsonl: 2 .. 4 lines are the fastest at 2 M and at 10 M rows -- short sweeps keep
+        //  many waves in flight and the halo lines are L2 hits; 16 and more lose: fewer, longer waves)
+        const int lines = ctx->spmv_dia_sw_lines > 0 ? ctx->spmv_dia_sw_lines : 4;
         const int wpb = (KK_TPB / 64) * ns * 128;                       // positions of a line one block covers
         const int nbl = (int)((D + wpb - 1) / wpb);                     // blocks per line group
         int g8 = nbl, b8 = 8;

@@ -28,7 +28,7 @@ def test_header_symbols_exported(kk):
 
 def test_version_and_error_string(kk):
     lib = kk._lib.load()
-    assert lib.kk_version() == 301
+    assert lib.kk_version() == 302
     assert isinstance(lib.kk_last_error(), bytes)
 
 

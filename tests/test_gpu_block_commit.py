@@ -45,7 +45,7 @@ def test_commit_path_gives_the_same_factorization(kk, ko, ctx, bs):
     a = run(kk, ctx, A, x0, steps, commit=1)
     b = run(kk, ctx, A, x0, steps, commit=0)
     ctx.set_option("block_commit", 1)
-    assert a["commits"] == steps - 1 and b["commits"] == 0          # every step but the first consumed a commit
+    assert a["commits"] == steps and b["commits"] == 0              # every step consumed a commit (the first one that of initialize: round 6)
     k = a["k"]
     E = np.zeros((k, bs)); E[k - bs:, :] = np.eye(bs)
     for r in (a, b):
@@ -68,7 +68,7 @@ def test_looking_at_the_residual_block_settles_the_commit(kk, ko, ctx):
     a = run(kk, ctx, A, x0, 12, commit=1, look=True)
     b = run(kk, ctx, A, x0, 12, commit=0, look=True)
     ctx.set_option("block_commit", 1)
-    assert a["commits"] == 0                 # every commit was flushed before the next expand! could take it
+    assert a["commits"] == 1                 # every commit of a STEP was flushed before the next expand! could take it (initialize's own was consumed)
     assert np.max(np.abs(a["H"] - b["H"])) < 1e-11 * np.max(np.abs(b["H"]))
     assert np.max(np.abs(a["R"] - b["R"])) < 1e-10 * np.max(np.abs(b["R"]))
 

@@ -340,7 +340,7 @@ elif scenario in ("xsync", "xsync_fault", "xsync_late"):
     opC = kd.NativeShardedOperator(Cd[lo:hi], part, ctx)
     import os
     steps = int(os.environ.get("KK_W2_STEPS", "24"))      # (the 8-rank rehearsal on ONE GPU runs a shorter factorization: eight processes share the chip's queues)
-    fault_at = ({7, 15} if steps >= 20 else {3, steps - 2}) if scenario != "xsync" else set()
+    fault_at = ({7, 15} if steps >= 20 else {3}) if scenario != "xsync" else set()   # (short run: one fault -- the back-off after it outlasts the factorization)
     # xsync_late: the faulting rank gives up at the LAST reduction of its launch with its partial already published -- to its peers it
     # looks like a rank whose wait ran out a moment before they arrived: they find every partial in their area and must NOT commit
     # (abort word re-read before the commit), or the ranks' collectives stop pairing up.  k_mgs_persist carries the hook.
