@@ -46,6 +46,7 @@ static int ctx_allocate(kk_ctx c) {
     c->ws = c->ws_own;
     KK_HIP(hipMalloc(&c->partials, (size_t)(2 * KK_MAX_M + 8) * KK_MAX_BLOCKS * sizeof(double)));
     KK_HIP(hipHostMalloc(&c->h_pin, 4 * WS_TOTAL * sizeof(double), hipHostMallocDefault));
+    memset(c->h_pin, 0, 4 * WS_TOTAL * sizeof(double));   // (the one-launch step's completion tokens are compared against these slots)
     KK_HIP(hipHostMalloc(&c->h_U, (size_t)KK_MAX_M * KK_MAX_M * sizeof(double), hipHostMallocDefault));
     KK_HIP(hipMalloc(&c->blk_own, (size_t)KK_BLK_SCRATCH * sizeof(double)));
     c->blk = c->blk_own;
@@ -58,6 +59,8 @@ static int ctx_allocate(kk_ctx c) {
     KK_HIP(hipEventCreateWithFlags(&c->ev_la[1], hipEventDisableTiming));
     KK_HIP(hipMalloc(&c->d_sync, KK_SYNC_BYTES));
     KK_HIP(hipMemset(c->d_sync, 0, KK_SYNC_BYTES));
+    KK_HIP(hipMalloc(&c->d_fsync, KK_FS_SYNC_BYTES + 64));
+    KK_HIP(hipMemset(c->d_fsync, 0, KK_FS_SYNC_BYTES + 64));
     KK_HIP(hipHostMalloc((void**)&c->h_sync, 64, hipHostMallocDefault));
     c->h_sync[0] = 0;
     int coop = 0;
@@ -133,6 +136,7 @@ KK_API int kk_ctx_destroy(kk_ctx c) {
     if (c->h_U) (void)hipHostFree(c->h_U);
     (void)hipFree(c->blk_own);
     (void)hipFree(c->d_sync);
+    (void)hipFree(c->d_fsync);
     if (c->h_sync) (void)hipHostFree(c->h_sync);
     if (c->h_blk) (void)hipHostFree(c->h_blk);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -227,6 +231,16 @@ KK_API int kk_ctx_set_option(kk_ctx c, const char* key, double value) {
         c->spmv_dia_const = value != 0;
     } else if (!strcmp(key, "spmv_dia_aligned")) {
         c->spmv_dia_aligned = value != 0;
+    } else if (!strcmp(key, "fused_step")) {
+        c->fused_step = value != 0;
+    } else if (!strcmp(key, "fused_step_max_rows")) {
+        KK_CHECK(value >= 0, KK_ERR_INVALID, "fused_step_max_rows must be >= 0");
+        c->fused_step_max_rows = (int64_t)value;
+    } else if (!strcmp(key, "fstep_blocks")) {
+        KK_CHECK(value >= 8 && value <= KK_FS_MAX_BLOCKS, KK_ERR_INVALID, "fstep_blocks must be in 8..%d", KK_FS_MAX_BLOCKS);
+        c->fstep_blocks = (int)value;
+    } else if (!strcmp(key, "fstep_fault")) {
+        c->fstep_fault = (int)value;
     } else if (!strcmp(key, "spmv_dia_sw")) {
         KK_CHECK(value == 0 || value == 1 || value == 2, KK_ERR_INVALID, "spmv_dia_sw must be 0 (k_spmv_dia), 1 or 2 (strips per wave of k_spmv_dia_sw)");
         c->spmv_dia_sw = (int)value;
@@ -342,6 +356,11 @@ KK_API int kk_ctx_get_option(kk_ctx c, const char* key, double* value) {
     else if (!strcmp(key, "spmv_dia")) *value = c->spmv_dia;
     else if (!strcmp(key, "spmv_dia_const")) *value = c->spmv_dia_const;
     else if (!strcmp(key, "spmv_dia_aligned")) *value = c->spmv_dia_aligned;
+    else if (!strcmp(key, "fused_step")) *value = c->fused_step;
+    else if (!strcmp(key, "fused_step_max_rows")) *value = (double)c->fused_step_max_rows;
+    else if (!strcmp(key, "fstep_blocks")) *value = c->fstep_blocks;
+    else if (!strcmp(key, "fstep_launches")) *value = (double)c->fstep_launches;
+    else if (!strcmp(key, "fstep_failures")) *value = (double)c->fstep_failures;
     else if (!strcmp(key, "spmv_dia_sw")) *value = c->spmv_dia_sw;
     else if (!strcmp(key, "spmv_dia_sw_lines")) *value = c->spmv_dia_sw_lines;
     else if (!strcmp(key, "spmv_dia_sw_launches")) *value = (double)c->spmv_dia_sw_launches;

@@ -19,6 +19,11 @@
 #define KK_SYNC_MAX_BLOCKS 1024
 #define KK_SYNC_ERR_OFFSET (2 * KK_SYNC_MAX_BLOCKS * KK_SYNC_LINE)
 #define KK_SYNC_BYTES (KK_SYNC_ERR_OFFSET + 64)
+// one-launch Lanczos step of short vectors (kk_kernels_fstep.hip): at most KK_FS_MAX_M basis vectors, at most KK_FS_MAX_BLOCKS blocks of 256 threads
+// x up to 8 row pairs (64 blocks, the default: 262 144 rows); granule area = (2 m + 1 values + the norm) x blocks x 16 bytes, error flag behind it
+#define KK_FS_MAX_M 128
+#define KK_FS_MAX_BLOCKS 128
+#define KK_FS_SYNC_BYTES ((2 * KK_FS_MAX_M + 2) * KK_FS_MAX_BLOCKS * 16)
 #define KK_MAX_DEVICES 64     // per-device bookkeeping of function attributes
 #define KK_TPB 256            // threads per block of every streaming kernel (4 waves)
 #define KK_SUB 512            // rows covered by one block sub-step: 256 threads x 2 rows (16 B/lane)
@@ -234,6 +239,15 @@ struct kk_ctx_s {
                                    // its partial of the LAST reduction and then declares the launch lost (a peer that arrives after this rank's patience ran out)
     int64_t spmm_dia_al_launches = 0;    // launches of the aligned sweeping SpMM (diagnostics: "spmm_dia_al_launches")
     int64_t norm_commits_consumed = 0;   // normalised residual columns taken over by scale!!(r, 1 / beta) of a restart without a pass (diagnostics)
+    // ---- whole Lanczos step of a short vector in one launch (kk_kernels_fstep.hip; option "fused_step")
+    int fused_step = 1;              // CGS2 / low-sync MGS2 Lanczos steps of vectors of at most fused_step_max_rows rows (single rank, ELL-format operator, <= 128 basis vectors)
+    int64_t fused_step_max_rows = 250000;   // ... above this the panel kernel / the projection pair are the faster routes (0.25 M rows = panel_min_rows)
+    int fstep_blocks = 64;           // blocks of a launch at most (<= KK_FS_MAX_BLOCKS; option "fstep_blocks")
+    void* d_fsync = nullptr;         // granule area + error flag (KK_FS_SYNC_BYTES + 64)
+    unsigned fs_epoch = 0;           // tags of its grid reductions: unique over the life of the context (two per launch)
+    double fs_token = 0;             // token counter: a launch that committed stores its token into the pinned host slot
+    int fstep_fault = 0;             // test hook (option "fstep_fault"): the next N launches give up at once
+    int64_t fstep_launches = 0, fstep_failures = 0;   // diagnostics; a failure (launch that did not commit) switches the route off for the context
     int fold_scale = 1;          // persistent kernel stores r / |r| at its commit when an expand! ends with it (no scale pass in the next step)
     int fuse_passes = 1;         // fuse unproject(pass i) with project(pass i+1)
     int speculate = 1;           // enqueue the next expand's SpMV before syncing the host
@@ -278,7 +292,7 @@ struct kk_basis_s {
     bool la_valid = false;
     int la_k = 0, la_slot = 0, la_nsweeps = 0;
     double la_token = 0;
-    int la_kind = 0;          // 0: persistent sweep (la_token), 1: projection-based Lanczos step (CGS2 / low-sync MGS2: la_orth, la_rode)
+    int la_kind = 0;          // 0: persistent sweep (la_token), 1: projection-based Lanczos step (CGS2 / low-sync MGS2: la_orth, la_rode), 2: one-launch step (k_lanczos_fstep: la_token = its token)
     int la_orth = 0;
     bool la_rode = false;
     // residual column left NORMALISED by a fused expand! (persistent kernel, w / |w| written at commit): logically the column
@@ -591,6 +605,10 @@ int64_t kk_mgs_persist_capacity(kk_ctx ctx);
 // the kernel's own test for the normalised commit, on the host's copy of |w|
 static inline bool kk_persist_norm_applies(double nrm) { return nrm > 0.0 && 1.0 / nrm <= 1.79769313486231570815e308; }
 int kk_launch_lanczos_coef(kk_ctx ctx, const double* buf, double* L, int cap, int m, int lowsync, double* coef_out, double* res);
+// one fused Lanczos step on columns [0, m) of V (v = column m - 1, normalised; v_prev = column m - 2), result column m; kk_kernels_fstep.hip
+int kk_launch_lanczos_fstep(kk_ctx ctx, const kk_sparse_dev& M, double* V, int64_t ld, int m, bool lowsync, bool cgs_order, const double* bprev_dev,
+                            double bprev, double* L, int cap, double* host_out, double token, bool normalize);
+int64_t kk_fstep_capacity_rows(kk_ctx ctx);
 int kk_launch_norm_scalars(kk_ctx ctx, const double* nrm2, double* sc, double* res2);
 int kk_launch_lowsync_solve(kk_ctx ctx, const double* p, const double* g_ride, double* L, int cap, int m, int newest,
                             const double* a0_dev, double* coef_out, double* s_out);

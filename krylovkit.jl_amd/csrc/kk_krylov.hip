@@ -1,6 +1,8 @@
 // libkrylov_hip.so, C ABI part 5: the fused L3 steps -- initialize / expand! of Lanczos, Arnoldi and GKL with the
 // speculative next-step apply (src/factorizations/{lanczos,arnoldi,gkl}.jl).
 #include "kk_host.h"
+#include <atomic>
+#include <chrono>
 
 // ------------------------------------------------------------------------------------------
 // L3 fused expand! steps
@@ -239,6 +241,47 @@ static int la_enqueue_proj(kk_op op, kk_basis b, int c0, int j, kk_orth_t orth) 
     return KK_OK;
 }
 
+// ---- the whole step in one launch (short vectors: kk_kernels_fstep.hip).  Single-rank context, operator in the ELL format without
+// ghost columns, factorization starting at column 0, at most KK_FS_MAX_M basis vectors, CGS2 or MGS2 in its low-synchronisation form.
+static bool fstep_ok(kk_ctx c, kk_op op, kk_basis b, int c0, int k, kk_orth_t orth, bool lowsync) {
+    if (!c->fused_step || !c->d_fsync || kk_sharded(c) || c->allreduce || (c->comm && c->comm->active)) return false;
+    if (c0 != 0 || k < 1 || k + 1 > KK_FS_MAX_M) return false;
+    if (!(orth == KK_CGS2 || (orth == KK_MGS2 && lowsync))) return false;
+    const kk_sparse_dev& M = op->A;
+    if (M.format != 0 || M.n_ghost != 0 || M.halo || M.plan) return false;
+    return b->n <= c->fused_step_max_rows && b->n <= kk_fstep_capacity_rows(c) && b->ld * 8 < ((int64_t)1 << 31);
+}
+static inline double* fstep_slot(kk_ctx c, int slot) { return c->h_pin + (int64_t)slot * WS_TOTAL + WS_USER; }   // (WS_USER: unused on single-rank contexts)
+// enqueue the step for basis size m = k + 1 (v = column k, normalised IN THE STREAM); the kernel reads beta of the step in front from
+// the device (bprev_dev) or takes the host's value
+static int fstep_enqueue(kk_op op, kk_basis b, int k, kk_orth_t orth, const double* bprev_dev, double bprev, int rows_in_stream, int slot, double* token_out) {
+    kk_ctx c = b->ctx;
+    const int m = k + 1;
+    const bool ls = orth == KK_MGS2;
+    if (ls) {   // Gram rows of the basis columns below the newest one (lowsync_project_dev): known, on their way in the stream, or recomputed (restart)
+        const int newest = m - 1;
+        if (std::max(b->gram_rows, rows_in_stream) < newest) KK_TRY(gram_ensure(b, newest));
+        if (b->gram_rows < 1) b->gram_rows = 1;
+        KK_TRY(gram_device(b));
+    }
+    c->fs_token += 1.0;
+    *token_out = c->fs_token;
+    return kk_launch_lanczos_fstep(c, op->A, b->col(0), b->ld, m, ls, orth == KK_CGS2, bprev_dev, bprev, ls ? b->d_gram : nullptr, b->cap, fstep_slot(c, slot),
+                                   c->fs_token, c->fold_scale != 0);
+}
+// wait for the token of a launch in its pinned slot (the kernel's LAST store): a spin on host memory -- no copy, no event
+static bool fstep_wait(kk_ctx c, int slot, double token) {
+    const volatile double* h = fstep_slot(c, slot);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (long it = 0;; ++it) {
+        if (h[0] == token) { std::atomic_thread_fence(std::memory_order_acquire); return true; }
+        if ((it & 1023) == 1023 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 0.25) break;
+    }
+    (void)hipStreamSynchronize(c->stream);   // (a launch that is merely late has arrived now; one that gave up never will)
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return h[0] == token;
+}
+
 KK_API int kk_lanczos_expand(kk_op op, kk_basis b, int c0, int k, kk_orth_t orth, double eta, double beta_old,
                                  double* alpha, double* beta, int* npasses) {
     KK_TRY(check_square_op(op, b));
@@ -274,22 +317,24 @@ KK_API int kk_lanczos_expand(kk_op op, kk_basis b, int c0, int k, kk_orth_t orth
     const bool proj_branch = !wide && !sh_fused && (orth == KK_CGS2 || (orth == KK_MGS2 && lowsync && c0 == 0));
     const bool la_same = b->la_valid && b->spec_valid && c->spec_owner == b && b->spec_gen == c->foreign_gen && b->spec_op == op && b->spec_c0 == c0 && b->spec_k == k &&
                          b->la_k == k && b->spec_beta == beta_old && v_ready;
+    const bool fs_route = proj_branch && fstep_ok(c, op, b, c0, k, orth, lowsync);   // the whole step in one launch (short vectors)
     const bool la_hit = la_same && b->la_kind == 0 && b->la_nsweeps == 1 && strict_branch;
-    const bool la_proj_hit = la_same && b->la_kind == 1 && b->la_orth == (int)orth && proj_branch && !kk_sharded(c);
+    const bool la_proj_hit = la_same && b->la_kind == 1 && b->la_orth == (int)orth && proj_branch && !kk_sharded(c) && !fs_route;
+    const bool la_fs_hit = la_same && b->la_kind == 2 && b->la_orth == (int)orth && fs_route;
     const int la_slot = b->la_slot;
     const double la_token = b->la_token;
-    if (b->la_valid && !la_hit && !la_proj_hit) b->spec_valid = false;   // a sweep enqueued ahead has consumed the speculative apply's output column: nothing to take over
+    if (b->la_valid && !la_hit && !la_proj_hit && !la_fs_hit) b->spec_valid = false;   // a sweep enqueued ahead has consumed the speculative apply's output column: nothing to take over
     const int la_proj_slot = b->la_slot;
     const bool la_proj_rode = b->la_rode;
-    bool hit = la_hit || la_proj_hit;
-    if (!hit) KK_TRY(spec_take(op, b, c0, k, cgs_order ? 1 : 2, beta_old, a0_slot, &hit));
+    bool hit = la_hit || la_proj_hit || la_fs_hit;
+    if (!hit && !fs_route) KK_TRY(spec_take(op, b, c0, k, cgs_order ? 1 : 2, beta_old, a0_slot, &hit));
     gram_touch(b, c0 + k);
     int passes = 0;
     c->persist_norm_done = la_hit;   // (a step enqueued ahead always asked for the normalised commit)
     // V = push!(V, scale!!(r, 1/beta_old))   lanczos.jl:257
     if (v_ready) b->norm_col = -1;
     else KK_TRY(kk_launch_scal(c, v, ld, 1.0 / beta_old, nullptr));
-    if (!hit) {
+    if (!hit && !fs_route) {
         // w = A v - beta_old v_prev with the fused alpha dot   lanczos.jl:297-299 / 306-308
         kk_spmv_fuse f;
         f.vprev = vprev; f.bprev = beta_old;
@@ -361,6 +406,39 @@ KK_API int kk_lanczos_expand(kk_op op, kk_basis b, int c0, int k, kk_orth_t orth
         bt = pin(c, WS_SCAL + SC_NRM)[0];
         if (ls) lowsync_commit_row(b, m, pin(c, WS_SHBUF + 1 + m, 0));
         passes = 1;
+    } else if (fs_route) {
+        // ONE launch per step (k_lanczos_fstep): apply, both grid reductions, the small solve, the update and the normalised commit; the scalars
+        // arrive in a pinned slot the host polls.  The NEXT step's launch goes out before the host looks at this one's token.
+        const int m1 = k + 1;
+        int slot = 2 + (k & 1);
+        double token = 0;
+        if (la_fs_hit) { slot = la_slot; token = la_token; }
+        else KK_TRY(fstep_enqueue(op, b, k, orth, nullptr, beta_old, 0, slot, &token));
+        b->spec_valid = false; b->la_valid = false;
+        if (c->lookahead && c->fold_scale && c0 + k + 3 <= b->cap && m1 + 1 <= KK_FS_MAX_M) {
+            double tk = 0;
+            KK_TRY(fstep_enqueue(op, b, k + 1, orth, SCP(c, SC_NRM), 0.0, m1, 2 + ((k + 1) & 1), &tk));   // (beta of THIS step: on the device when that launch starts)
+            b->spec_valid = true; b->spec_op = op; b->spec_c0 = c0; b->spec_k = k + 1; b->spec_dot_mode = -1; b->spec_beta = 0.0; b->spec_dot_ptr = nullptr;
+            c->spec_owner = b; b->spec_gen = c->foreign_gen;
+            b->la_valid = true; b->la_k = k + 1; b->la_slot = 2 + ((k + 1) & 1); b->la_token = tk; b->la_nsweeps = 0; b->la_kind = 2; b->la_orth = (int)orth; b->la_rode = false;
+        }
+        if (!fstep_wait(c, slot, token)) {
+            // the launch gave up (a block that never became resident: GPU shared with another job).  Column k holds v = r / beta_old, nothing else of
+            // the factorization was touched: the route is switched off for this context and the step runs again on the ordinary one
+            KK_HIP(hipMemsetAsync((char*)c->d_fsync + KK_FS_SYNC_BYTES, 0, sizeof(int), c->stream));
+            ++c->fstep_failures;
+            c->fused_step = 0;
+            b->spec_valid = false; b->la_valid = false;
+            b->norm_col = c0 + k; b->norm_beta = beta_old;   // (v is normalised in place already: the repeated call must not scale it again)
+            return kk_lanczos_expand(op, b, c0, k, orth, eta, beta_old, alpha, beta, npasses);
+        }
+        const double* h = fstep_slot(c, slot);
+        a = h[1] + h[2];
+        bt = h[4];
+        if (orth == KK_MGS2) lowsync_commit_row(b, m1, h + 8);
+        passes = 1;
+        if (h[6] != 0.0 && kk_persist_norm_applies(bt)) { b->norm_col = c0 + k + 1; b->norm_beta = bt; }
+        else { b->la_valid = false; b->spec_valid = false; }   // (zero / overflowing norm: the column holds w itself, the step enqueued behind it is void)
     } else if (orth == KK_CGS2 || (orth == KK_MGS2 && lowsync && c0 == 0)) {
         // projection-based step (lanczos_proj_enqueue): s = V'(w - alpha0 v) [exact triangular solve for MGS2], w <- w - V (s + alpha0 e_m),
         // beta = |w|; one host synchronisation.  With the run-ahead (la_enqueue_proj) this call finds its step in the stream already.

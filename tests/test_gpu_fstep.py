@@ -1,0 +1,143 @@
+"""The whole Lanczos expand! of a short vector in ONE launch (csrc/kk_kernels_fstep.hip): apply, the grid reduction of
+[alpha0 | V'w | V'v], the (low-sync) solve, the update, the norm and the normalised commit in one kernel, the scalars delivered through a
+pinned slot the host polls, the next step's launch enqueued before the host looks.  Reference recurrences: src/factorizations/lanczos.jl
+:297-322 (ClassicalGramSchmidt2) and :325-336 (ModifiedGramSchmidt2), expand! :250-291; the oracle restates them (oracle/krylov_oracle.py).
+Not bitwise equal to the projection pair (another summation order of the inner products): equal to rounding, 1e-10 against the oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def relerr(a, b):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300)))
+
+
+def run(kk, c, A, x0, dev, steps, fused, lookahead=1, sym=True):
+    c.set_option("fused_step", fused); c.set_option("lookahead", lookahead)
+    l0 = c.get_option("fstep_launches")
+    it = kk.LanczosIterator(kk.SparseOperator(A, c, symmetric=sym), x0, dev, capacity=steps + 3)
+    f = kk.initialize(it)
+    for _ in range(steps):
+        f = kk.expand_(it, f)
+    return f, int(c.get_option("fstep_launches") - l0)
+
+
+@pytest.mark.parametrize("shape", [(36, 30), (131, 77), (512, 200), (498, 500)])
+@pytest.mark.parametrize("orth", ["mgs2", "cgs2"])
+def test_one_launch_step_against_oracle_and_projection_pair(kk, ko, shape, orth):
+    """1 080 .. 250 000 rows (1, 2, 4 and 8 row pairs per thread), odd and even row counts: alpha / beta within 1e-10 of the oracle and 1e-12 of the
+    projection pair, V orthonormal, one launch per step (+ the one enqueued ahead), lookahead on and off bit-identical (same kernel either way)"""
+    nx, ny = shape
+    n = nx * ny
+    A = ko.laplacian_2d(nx, ny, shift_diag=10 * np.linspace(0, 1, n) ** 2)
+    x0 = np.random.default_rng(3).random(n)
+    dev, ref = (kk.ModifiedGramSchmidt2(), ko.MGS2) if orth == "mgs2" else (kk.ClassicalGramSchmidt2(), ko.CGS2)
+    steps = 24
+    c = kk.Context(0)
+    try:
+        assert c.get_option("fused_step") == 1 and n <= c.get_option("fused_step_max_rows")       # the DEFAULT route at these sizes (auto mode)
+        f1, n1 = run(kk, c, A, x0, dev, steps, 1, 1)
+        f2, n2 = run(kk, c, A, x0, dev, steps, 1, 0)
+        f0, n0 = run(kk, c, A, x0, dev, steps, 0, 1)
+        assert n0 == 0 and n2 == steps and steps <= n1 <= steps + 1, (n0, n1, n2)
+        assert np.array_equal(f1.alphas, f2.alphas) and np.array_equal(f1.betas, f2.betas)
+        assert relerr(f1.alphas, f0.alphas) < 1e-12 and relerr(f1.betas, f0.betas) < 1e-12
+        oit = ko.LanczosIterator(A, x0.copy(), ref); of = ko.lanczos_initialize(oit)
+        for _ in range(steps):
+            of = ko.lanczos_expand(oit, of)
+        assert relerr(f1.alphas, of.alphas) < 1e-10 and relerr(f1.betas, of.betas) < 1e-10
+        V = f1.V.to_numpy()
+        assert np.max(np.abs(V.T @ V - np.eye(V.shape[1]))) < 1e-12
+        r = f1.r.get()
+        assert abs(np.linalg.norm(r) - f1.normres) < 1e-12 * f1.normres and np.max(np.abs(V.T @ r)) < 1e-11 * f1.normres
+        assert c.get_option("fstep_failures") == 0
+    finally:
+        c.close()
+
+
+def test_general_sparsity_and_nonsymmetric_values(kk, ko):
+    """any operator in the ELL format: a random symmetric pattern (no stencil structure), 20 entries per row"""
+    import scipy.sparse as sp
+    n = 30_000
+    rng = np.random.default_rng(8)
+    R = sp.random(n, n, density=10 / n, random_state=rng, format="csr")
+    A = (R + R.T + sp.diags(np.linspace(1, 30, n))).tocsr()
+    x0 = rng.random(n)
+    c = kk.Context(0)
+    try:
+        op = kk.SparseOperator(A, c, symmetric=True)
+        if not op.info()["format"].startswith("ELL"):
+            pytest.skip("operator did not get the ELL format")
+        f1, n1 = run(kk, c, A, x0, kk.ModifiedGramSchmidt2(), 20, 1)
+        assert n1 >= 20
+        oit = ko.LanczosIterator(A, x0.copy(), ko.MGS2); of = ko.lanczos_initialize(oit)
+        for _ in range(20):
+            of = ko.lanczos_expand(oit, of)
+        assert relerr(f1.alphas, of.alphas) < 1e-10 and relerr(f1.betas, of.betas) < 1e-10
+    finally:
+        c.close()
+
+
+def test_eigsolve_with_restarts_runs_on_the_one_launch_step(kk, ko):
+    """thick restarts (eigsolve/lanczos.jl:33-120): shrink!, basistransform!, the restart's scale!!(r, 1 / beta) between cycles of one-launch
+    steps -- numiter / numops and the eigenvalues of the oracle"""
+    nx, ny = 60, 50
+    n = nx * ny
+    A = ko.laplacian_2d(nx, ny)
+    x0 = np.random.default_rng(5).random(n)
+    c = kk.Context(0)
+    try:
+        l0 = c.get_option("fstep_launches")
+        vals, vecs, info = kk.eigsolve(kk.SparseOperator(A, c, symmetric=True), x0, 3, "SR", krylovdim=20, maxiter=60, tol=1e-10, orth=kk.ModifiedGramSchmidt2())
+        ovals, ovecs, oinfo = ko.eigsolve_lanczos(A, x0.copy(), 3, "SR", krylovdim=20, maxiter=60, tol=1e-10, orth=ko.MGS2)
+        assert c.get_option("fstep_launches") - l0 > 20
+        assert info.converged >= 3 and (info.numiter, info.numops) == (oinfo.numiter, oinfo.numops)
+        np.testing.assert_allclose(vals[:3], ovals[:3], rtol=1e-10)
+    finally:
+        c.close()
+
+
+def test_launch_that_gives_up_is_repeated_on_the_ordinary_route(kk, ko):
+    """test hook "fstep_fault": a launch whose block 0 leaves at once never stores its token -- the host notices, switches the route off for
+    the context ("fstep_failures", "fused_step" -> 0) and repeats the step on the projection pair; same factorization"""
+    nx, ny = 70, 64
+    n = nx * ny
+    A = ko.laplacian_2d(nx, ny, shift_diag=10 * np.linspace(0, 1, n) ** 2)
+    x0 = np.random.default_rng(3).random(n)
+    c = kk.Context(0)
+    try:
+        c.set_option("persist_timeout_ms", 20)
+        it = kk.LanczosIterator(kk.SparseOperator(A, c, symmetric=True), x0, kk.ModifiedGramSchmidt2(), capacity=30)
+        f = kk.initialize(it)
+        for i in range(20):
+            if i == 7:
+                c.set_option("fstep_fault", 1)
+            f = kk.expand_(it, f)
+        assert c.get_option("fstep_failures") == 1 and c.get_option("fused_step") == 0
+        oit = ko.LanczosIterator(A, x0.copy(), ko.MGS2); of = ko.lanczos_initialize(oit)
+        for _ in range(20):
+            of = ko.lanczos_expand(oit, of)
+        assert relerr(f.alphas, of.alphas) < 1e-10 and relerr(f.betas, of.betas) < 1e-10
+        V = f.V.to_numpy()
+        assert np.max(np.abs(V.T @ V - np.eye(V.shape[1]))) < 1e-12
+    finally:
+        c.close()
+
+
+def test_routes_outside_its_scope_are_unchanged(kk, ko):
+    """strict MGS2 (mgs_mode 0), more rows than fused_step_max_rows, a factorization that does not start at column 0: not this route"""
+    nx, ny = 70, 64
+    n = nx * ny
+    A = ko.laplacian_2d(nx, ny)
+    x0 = np.random.default_rng(3).random(n)
+    c = kk.Context(0)
+    try:
+        c.set_option("mgs_mode", 0)
+        _, n_strict = run(kk, c, A, x0, kk.ModifiedGramSchmidt2(), 6, 1)
+        c.set_option("mgs_mode", 2); c.set_option("fused_step_max_rows", 1000)
+        _, n_long = run(kk, c, A, x0, kk.ModifiedGramSchmidt2(), 6, 1)
+        assert n_strict == 0 and n_long == 0
+    finally:
+        c.close()

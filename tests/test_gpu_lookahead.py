@@ -209,6 +209,7 @@ def test_projection_route_run_ahead_is_bitwise_the_call_by_call_route(kk, ko, ro
     c = kk.Context(0)
     try:
         c.set_option("mgs_mode", 1)
+        c.set_option("fused_step", 0)     # (round 6: vectors this short take the one-launch step by default -- tests/test_gpu_fstep.py; this test is about the projection pair)
         dev, ref = (kk.ClassicalGramSchmidt2(), ko.CGS2) if route == "cgs2" else (kk.ModifiedGramSchmidt2(), ko.MGS2)
         nx, ny, steps = 52, 40, 28
         n = nx * ny
@@ -296,6 +297,7 @@ def test_switching_routes_on_one_slab_does_not_repeat_every_step(kk, ko):
         if c.get_option("mgs_persist") == 0:
             pytest.skip("persistent route off on this device")
         c.set_option("mgs_panel", 0)
+        c.set_option("fused_step", 0)     # (the low-sync leg of this test is the projection pair, not the one-launch step of round 6)
         nx, ny = 44, 36
         n = nx * ny
         A = ko.laplacian_2d(nx, ny, shift_diag=10 * np.linspace(0, 1, n) ** 2)

@@ -25,7 +25,9 @@ for nx, ny in [(32, 32), (100, 100), (320, 320), (1000, 1000), (2000, 2000)]:
     op = kk.SparseOperator(A, ctx, symmetric=True)
     x0 = np.random.default_rng(3).random(N)
     row = {"rows": N}
-    for oname, orth, ocode in [("mgs2", kk.ModifiedGramSchmidt2(), 3), ("cgs2", kk.ClassicalGramSchmidt2(), 2)]:
+    for oname, orth, ocode, fused in [("mgs2", kk.ModifiedGramSchmidt2(), 3, 1), ("cgs2", kk.ClassicalGramSchmidt2(), 2, 1),
+                                      ("mgs2_projection_pair", kk.ModifiedGramSchmidt2(), 3, 0), ("cgs2_projection_pair", kk.ClassicalGramSchmidt2(), 2, 0)]:
+        ctx.set_option("fused_step", fused)     # round 6: the one-launch step is the default below 250 k rows; the projection pair of rounds 1-5 next to it
         it = kk.LanczosIterator(op, x0, orth, capacity=K + 2)
         f = kk.initialize(it)
         V = f.V
@@ -40,6 +42,8 @@ for nx, ny in [(32, 32), (100, 100), (320, 320), (1000, 1000), (2000, 2000)]:
             ctx.sync()
             best = min(best, time.perf_counter() - t0)
         row[f"gpu_{oname}_us_per_expand"] = round(best / (K - 1) * 1e6, 1)
+    row["fstep_launches"] = int(ctx.get_option("fstep_launches"))
+    ctx.set_option("fused_step", 1)
     for nt in (1, cpu_ref_lib.usable_threads()):
         best = 1e9
         for rep in range(3):

@@ -64,7 +64,8 @@ if "FETCH_SIZE" in res and "WRITE_SIZE" in res and "--no-traffic" not in sys.arg
                 nm = row["Name"]
                 nm = nm[5:] if nm.startswith("void ") else nm
                 for short in ("k_project", "k_unproject", "k_spmv_ell", "k_spmv_dia", "k_scal", "k_mgs_step", "k_mgs_persist", "k_unproj_proj", "k_mgs_panel"):
-                    if nm.startswith(short + "<") or nm.startswith(short + "("):
+                    # (k_spmv_dia_sw is the sweeping form of the same class: bench.py brackets both as "k_spmv_dia")
+                    if nm.startswith(short + "<") or nm.startswith(short + "(") or (short == "k_spmv_dia" and nm.startswith("k_spmv_dia_sw<")):
                         agg[short][0] += int(row["Calls"]); agg[short][1] += float(row["TotalDurationNs"])
             for k_, (n_, t_) in agg.items():
                 if n_:
