@@ -239,6 +239,9 @@ KK_API int kk_ctx_set_option(kk_ctx c, const char* key, double value) {
     } else if (!strcmp(key, "fstep_blocks")) {
         KK_CHECK(value >= 8 && value <= KK_FS_MAX_BLOCKS, KK_ERR_INVALID, "fstep_blocks must be in 8..%d", KK_FS_MAX_BLOCKS);
         c->fstep_blocks = (int)value;
+    } else if (!strcmp(key, "fstep_threads")) {
+        KK_CHECK(value == 256 || value == 1024, KK_ERR_INVALID, "fstep_threads must be 256 or 1024");
+        c->fstep_threads = (int)value;
     } else if (!strcmp(key, "fstep_fault")) {
         c->fstep_fault = (int)value;
     } else if (!strcmp(key, "spmv_dia_sw")) {
@@ -359,6 +362,7 @@ KK_API int kk_ctx_get_option(kk_ctx c, const char* key, double* value) {
     else if (!strcmp(key, "fused_step")) *value = c->fused_step;
     else if (!strcmp(key, "fused_step_max_rows")) *value = (double)c->fused_step_max_rows;
     else if (!strcmp(key, "fstep_blocks")) *value = c->fstep_blocks;
+    else if (!strcmp(key, "fstep_threads")) *value = c->fstep_threads;
     else if (!strcmp(key, "fstep_launches")) *value = (double)c->fstep_launches;
     else if (!strcmp(key, "fstep_failures")) *value = (double)c->fstep_failures;
     else if (!strcmp(key, "spmv_dia_sw")) *value = c->spmv_dia_sw;

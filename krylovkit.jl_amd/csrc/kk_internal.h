@@ -241,8 +241,10 @@ struct kk_ctx_s {
     int64_t norm_commits_consumed = 0;   // normalised residual columns taken over by scale!!(r, 1 / beta) of a restart without a pass (diagnostics)
     // ---- whole Lanczos step of a short vector in one launch (kk_kernels_fstep.hip; option "fused_step")
     int fused_step = 1;              // CGS2 / low-sync MGS2 Lanczos steps of vectors of at most fused_step_max_rows rows (single rank, ELL-format operator, <= 128 basis vectors)
-    int64_t fused_step_max_rows = 250000;   // ... above this the panel kernel / the projection pair are the faster routes (0.25 M rows = panel_min_rows)
-    int fstep_blocks = 64;           // blocks of a launch at most (<= KK_FS_MAX_BLOCKS; option "fstep_blocks")
+    int64_t fused_step_max_rows = 131072;   // ... above this the projection pair / the panel kernel are the faster routes (tools/fstep_probe.py, profiles/r06_fstep_probe.jsonl:
+                                            // 15 vs 30 us per step at 1 k rows, 17 vs 30 at 10 k, 26 vs 34 at 102 k; 34 vs 38 (MGS2) but 38 vs 32 (CGS2) at 200 k)
+    int fstep_blocks = 128;          // blocks of a launch at most (<= KK_FS_MAX_BLOCKS; option "fstep_blocks")
+    int fstep_threads = 256;         // threads per block: 256 (1024 measured slower at every length: kept as the record)
     void* d_fsync = nullptr;         // granule area + error flag (KK_FS_SYNC_BYTES + 64)
     unsigned fs_epoch = 0;           // tags of its grid reductions: unique over the life of the context (two per launch)
     double fs_token = 0;             // token counter: a launch that committed stores its token into the pinned host slot

@@ -24,7 +24,6 @@
 #include "kk_internal.h"
 #include "kk_device.h"
 
-#define KK_FS_TPB 256
 #define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 typedef unsigned fs_v4u __attribute__((ext_vector_type(4)));
 
@@ -64,17 +63,18 @@ __device__ __forceinline__ void fs_host_store(double* p, double x) {   // system
     __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// NP row pairs per thread; LOWSYNC: MGS2 in its low-synchronisation form (triangular solve with the Gram rows), else CGS2
-template <int NP, bool LOWSYNC>
-__global__ __launch_bounds__(KK_FS_TPB) void k_lanczos_fstep(const int32_t* __restrict__ ecol, const double* __restrict__ eval, int64_t ell_ld, int width,
+// TPB threads per block (256; 1024 exists behind option "fstep_threads" and is slower), NP row pairs per thread, JB = 4 columns of V per batch of
+// loads; LOWSYNC: MGS2 in its low-synchronisation form, else CGS2
+template <int TPB, int NP, bool LOWSYNC>
+__global__ __launch_bounds__(TPB) void k_lanczos_fstep(const int32_t* __restrict__ ecol, const double* __restrict__ eval, int64_t ell_ld, int width,
                                                             int64_t nrows, double* __restrict__ V, int64_t ld, int m, const double* __restrict__ bprev_dev,
                                                             double bprev, int cgs_order, double* __restrict__ L, int cap, char* __restrict__ sync,
                                                             int* __restrict__ err, unsigned epoch, long long timeout_ticks, double* __restrict__ ws_scal,
                                                             double* __restrict__ host_out, double token, int normalize, int fault) {
-    __shared__ double wsum[KK_FS_TPB / 64][2 * KK_FS_MAX_M + 2];   // per-wave partials of the 2 m + 1 values
+    __shared__ double wsum[TPB / 64][2 * KK_FS_MAX_M + 2];   // per-wave partials of the 2 m + 1 values
     __shared__ double tot[2 * KK_FS_MAX_M + 2];                    // totals; later rhs / coefficients in tot[1 .. m]
     __shared__ double part4[(2 * KK_FS_MAX_M + 2) * 4];            // quarter sums of the grid reduction
-    __shared__ double red[KK_FS_TPB / 64];
+    __shared__ double red[TPB / 64];
     __shared__ int bad;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int G = gridDim.x;
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(KK_FS_TPB) void k_lanczos_fstep(const int32_t* __re
     double a0p = 0;
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-        const int64_t row = (((int64_t)blockIdx.x * NP + i) * KK_FS_TPB + tid) * 2;
+        const int64_t row = (((int64_t)blockIdx.x * NP + i) * TPB + tid) * 2;
         wr[i] = d2{0.0, 0.0}; vr[i] = d2{0.0, 0.0};
         if (row < nrows) {   // ell_ld is even and >= nrows; pad entries have val 0, col 0
             double s0 = 0, s1 = 0;
@@ -131,19 +131,21 @@ __global__ __launch_bounds__(KK_FS_TPB) void k_lanczos_fstep(const int32_t* __re
         if (lane == 0) wsum[wave][0] = t;
     }
     // ---- p_j = <V_j, w>, g_j = <V_j, v> on this block's rows, four columns at a time
-    for (int j0 = 0; j0 < m; j0 += 4) {
-        d2 q[4][NP];
+    constexpr int JB = 4;   // (16 / NP columns per batch were tried: the short factorizations this kernel serves pay for the clamped loads -- 15.2 -> 20.0 us per step at 1 k rows)
+    for (int j0 = 0; j0 < m; j0 += JB) {
+        d2 q[JB][NP];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < JB; ++u) {
             const int j = j0 + u < m ? j0 + u : m - 1;
 #pragma unroll
             for (int i = 0; i < NP; ++i) {
-                const int64_t row = (((int64_t)blockIdx.x * NP + i) * KK_FS_TPB + tid) * 2;
+                const int64_t row = (((int64_t)blockIdx.x * NP + i) * TPB + tid) * 2;
                 q[u][i] = row < ld ? ld2(V + (int64_t)j * ld + row) : d2{0.0, 0.0};   // (rows nrows .. ld - 1 of every column are zero)
             }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < JB; ++u) {
+            if (j0 + u >= m) break;   // (uniform)
             double pp = 0, gg = 0;
 #pragma unroll
             for (int i = 0; i < NP; ++i) {
@@ -156,16 +158,16 @@ __global__ __launch_bounds__(KK_FS_TPB) void k_lanczos_fstep(const int32_t* __re
     }
     __syncthreads();
     // ---- grid reduction 1: 2 m + 1 values.  Granule of (value t, block b) at (t * G + b) * 16
-    for (int t = tid; t < nval; t += KK_FS_TPB) {
+    for (int t = tid; t < nval; t += TPB) {
         double s = 0;
 #pragma unroll
-        for (int wv = 0; wv < KK_FS_TPB / 64; ++wv) s += wsum[wv][t];   // fixed order
+        for (int wv = 0; wv < TPB / 64; ++wv) s += wsum[wv][t];   // fixed order
         fs_publish(rs, (unsigned)((t * G + (int)blockIdx.x) * 16), epoch, s);
     }
     // four threads per value, each the granules of a quarter of the blocks (<= 32: one or two batches of loads); the quarters are added in a fixed order
     const long long t0 = wall_clock64();
     const int gq = (G + 3) >> 2;
-    for (int idx = tid; idx < nval * 4; idx += KK_FS_TPB) {
+    for (int idx = tid; idx < nval * 4; idx += TPB) {
         const int t = idx >> 2, qd = idx & 3;
         const int b_lo = qd * gq, b_hi = b_lo + gq < G ? b_lo + gq : G;
         double x = 0;
@@ -174,18 +176,18 @@ __global__ __launch_bounds__(KK_FS_TPB) void k_lanczos_fstep(const int32_t* __re
     }
     __syncthreads();
     if (bad) { if (tid == 0) __hip_atomic_store(err, 1, RLX_AGENT); return; }
-    for (int t = tid; t < nval; t += KK_FS_TPB) tot[t] = ((part4[4 * t] + part4[4 * t + 1]) + part4[4 * t + 2]) + part4[4 * t + 3];
+    for (int t = tid; t < nval; t += TPB) tot[t] = ((part4[4 * t] + part4[4 * t + 1]) + part4[4 * t + 2]) + part4[4 * t + 3];
     __syncthreads();
     // ---- coefficients (the algebra of k_lanczos_coef): rhs = p - alpha0 g ; low-sync: (I + L) s = rhs with row m - 1 of L = g
     const double a0 = tot[0];
     double* rhs = tot + 1;            // rhs[i] overwrites p[i]
     const double* g = tot + 1 + m;
-    for (int i = tid; i < m; i += KK_FS_TPB) rhs[i] = fma(-a0, g[i], rhs[i]);
+    for (int i = tid; i < m; i += TPB) rhs[i] = fma(-a0, g[i], rhs[i]);
     if (LOWSYNC && blockIdx.x == 0)
-        for (int i = tid; i < m - 1; i += KK_FS_TPB) L[(int64_t)(m - 1) * cap + i] = g[i];   // the new Gram row (device mirror; the host's copy travels below)
+        for (int i = tid; i < m - 1; i += TPB) L[(int64_t)(m - 1) * cap + i] = g[i];   // the new Gram row (device mirror; the host's copy travels below)
     __syncthreads();
     if (LOWSYNC) {
-        // column-oriented forward substitution; thread i owns row i (m <= KK_FS_MAX_M <= KK_FS_TPB)
+        // column-oriented forward substitution; thread i owns row i (m <= KK_FS_MAX_M <= TPB)
         const int i = tid;
         const bool act = i < m;
         const double* lrow = (i == m - 1) ? g : L + (int64_t)(act ? i : 0) * cap;
@@ -213,21 +215,21 @@ __global__ __launch_bounds__(KK_FS_TPB) void k_lanczos_fstep(const int32_t* __re
     if (tid == 0) rhs[m - 1] = s_last + a0;   // alpha0 folded into the last coefficient: w -= V (s + alpha0 e_m)
     __syncthreads();
     // ---- phase 2: w -= V coef on this block's rows, |w|^2 partial
-    for (int j0 = 0; j0 < m; j0 += 4) {
-        d2 q[4][NP];
-        double cf[4];
+    for (int j0 = 0; j0 < m; j0 += JB) {
+        d2 q[JB][NP];
+        double cf[JB];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < JB; ++u) {
             const int j = j0 + u < m ? j0 + u : m - 1;
             cf[u] = j0 + u < m ? rhs[j] : 0.0;
 #pragma unroll
             for (int i = 0; i < NP; ++i) {
-                const int64_t row = (((int64_t)blockIdx.x * NP + i) * KK_FS_TPB + tid) * 2;
+                const int64_t row = (((int64_t)blockIdx.x * NP + i) * TPB + tid) * 2;
                 q[u][i] = row < ld ? ld2(V + (int64_t)j * ld + row) : d2{0.0, 0.0};
             }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < JB; ++u) {
 #pragma unroll
             for (int i = 0; i < NP; ++i) { wr[i].x = fma(-cf[u], q[u][i].x, wr[i].x); wr[i].y = fma(-cf[u], q[u][i].y, wr[i].y); }
         }
@@ -243,7 +245,7 @@ __global__ __launch_bounds__(KK_FS_TPB) void k_lanczos_fstep(const int32_t* __re
     if (tid == 0) {
         double s = 0;
 #pragma unroll
-        for (int wv = 0; wv < KK_FS_TPB / 64; ++wv) s += red[wv];
+        for (int wv = 0; wv < TPB / 64; ++wv) s += red[wv];
         fs_publish(rs, noff + blockIdx.x * 16u, epoch + 1u, s);
     }
     __syncthreads();   // (red[] read above by thread 0 before it is reused)
@@ -278,7 +280,7 @@ __global__ __launch_bounds__(KK_FS_TPB) void k_lanczos_fstep(const int32_t* __re
     // ---- commit: column m <- w (normalised), scalars to the device workspace and -- block 0 -- to the pinned host slot
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-        const int64_t row = (((int64_t)blockIdx.x * NP + i) * KK_FS_TPB + tid) * 2;
+        const int64_t row = (((int64_t)blockIdx.x * NP + i) * TPB + tid) * 2;
         if (row < nrows) st2(wout + row, d2{wr[i].x * f, wr[i].y * f});
     }
     if (blockIdx.x == 0) {
@@ -287,7 +289,7 @@ __global__ __launch_bounds__(KK_FS_TPB) void k_lanczos_fstep(const int32_t* __re
         }
         // host slot: [0] token (written LAST), [1] alpha0, [2] last coefficient before the fold, [3 .. 5] |w|^2, |w|, 1 / |w|, [6] stored normalised?,
         // [8 .. 8 + m) the Gram row g = V'v.  System-scope stores; the token follows a system-scope fence.
-        for (int i = tid; i < m; i += KK_FS_TPB) fs_host_store(host_out + 8 + i, g[i]);
+        for (int i = tid; i < m; i += TPB) fs_host_store(host_out + 8 + i, g[i]);
         if (tid == 0) {
             fs_host_store(host_out + 1, a0);
             fs_host_store(host_out + 2, s_last);
@@ -305,17 +307,17 @@ __global__ __launch_bounds__(KK_FS_TPB) void k_lanczos_fstep(const int32_t* __re
 }
 
 // ---- launcher --------------------------------------------------------------------------------------------------------
-int64_t kk_fstep_capacity_rows(kk_ctx ctx) { return (int64_t)std::max(1, std::min(std::min(KK_FS_MAX_BLOCKS, ctx->fstep_blocks), ctx->num_cus)) * 8 * KK_FS_TPB * 2; }
+int64_t kk_fstep_capacity_rows(kk_ctx ctx) { return (int64_t)std::max(1, std::min(std::min(KK_FS_MAX_BLOCKS, ctx->fstep_blocks), ctx->num_cus)) * 8 * 256 * 2; }
 
-template <int NP>
+template <int TPB, int NP>
 static void fstep_launch(bool lowsync, int G, hipStream_t s, const kk_sparse_dev& M, double* V, int64_t ld, int m, const double* bprev_dev, double bprev,
                          int cgs_order, double* L, int cap, char* sync, int* err, unsigned epoch, long long ticks, double* ws_scal, double* host_out,
                          double token, int normalize, int fault) {
     if (lowsync)
-        hipLaunchKernelGGL((k_lanczos_fstep<NP, true>), dim3(G), dim3(KK_FS_TPB), 0, s, M.ell_col, M.ell_val, M.ell_ld, M.width, M.nrows, V, ld, m, bprev_dev, bprev,
+        hipLaunchKernelGGL((k_lanczos_fstep<TPB, NP, true>), dim3(G), dim3(TPB), 0, s, M.ell_col, M.ell_val, M.ell_ld, M.width, M.nrows, V, ld, m, bprev_dev, bprev,
                            cgs_order, L, cap, sync, err, epoch, ticks, ws_scal, host_out, token, normalize, fault);
     else
-        hipLaunchKernelGGL((k_lanczos_fstep<NP, false>), dim3(G), dim3(KK_FS_TPB), 0, s, M.ell_col, M.ell_val, M.ell_ld, M.width, M.nrows, V, ld, m, bprev_dev, bprev,
+        hipLaunchKernelGGL((k_lanczos_fstep<TPB, NP, false>), dim3(G), dim3(TPB), 0, s, M.ell_col, M.ell_val, M.ell_ld, M.width, M.nrows, V, ld, m, bprev_dev, bprev,
                            cgs_order, L, cap, sync, err, epoch, ticks, ws_scal, host_out, token, normalize, fault);
 }
 
@@ -324,14 +326,17 @@ int kk_launch_lanczos_fstep(kk_ctx ctx, const kk_sparse_dev& M, double* V, int64
                             double bprev, double* L, int cap, double* host_out, double token, bool normalize) {
     KK_CHECK(ctx->d_fsync && m >= 2 && m <= KK_FS_MAX_M && M.format == 0 && M.nrows <= kk_fstep_capacity_rows(ctx), KK_ERR_UNSUPPORTED,
              "kk_launch_lanczos_fstep: not eligible (m = %d, %lld rows)", m, (long long)M.nrows);
-    const int64_t chunks = (M.nrows + KK_FS_TPB * 2 - 1) / (KK_FS_TPB * 2);
-    // as many blocks as the chip offers CUs (all resident at once: the grid reductions need every block), at most KK_FS_MAX_BLOCKS
-    // (option "fstep_blocks": fewer blocks = cheaper reductions, more blocks = more CUs on the data phases; multiples of the XCD count)
+    // as many blocks as the chip offers CUs (all resident at once: the grid reductions need every block), at most "fstep_blocks".  256-thread
+    // blocks while one row pair per thread covers the vector (<= 512 x blocks rows), else 1024-thread blocks with 1 / 2 / 4 pairs per thread
     const int gmax = std::max(1, std::min(std::min(KK_FS_MAX_BLOCKS, ctx->fstep_blocks), ctx->num_cus));
+    // (1024-thread blocks -- four waves per SIMD -- were measured SLOWER at every length, 34.7 vs 20.0 us at 1 k rows, 44.1 vs 26.2 at 1e5: sixteen
+    //  waves per block make the block-level steps of the two reductions and the solve's barriers that much longer; kept behind option "fstep_threads")
+    const int tpb = ctx->fstep_threads == 1024 ? 1024 : 256;
+    const int64_t chunks = (M.nrows + tpb * 2 - 1) / (tpb * 2);
     const int np_need = (int)((chunks + gmax - 1) / gmax);
     const int NP = np_need <= 1 ? 1 : (np_need <= 2 ? 2 : (np_need <= 4 ? 4 : 8));
     const int G = (int)((chunks + NP - 1) / NP);
-    KK_CHECK(G >= 1 && G <= gmax && np_need <= 8, KK_ERR_UNSUPPORTED, "kk_launch_lanczos_fstep: %lld rows do not fit %d blocks", (long long)M.nrows, gmax);
+    KK_CHECK(G >= 1 && G <= gmax && np_need <= (tpb == 256 ? 8 : 4), KK_ERR_UNSUPPORTED, "kk_launch_lanczos_fstep: %lld rows do not fit %d blocks", (long long)M.nrows, gmax);
     KK_HIP(hipSetDevice(ctx->device));
     if (ctx->fs_epoch > 0xffffffffu - 8u) {   // tags are unique over the life of the context: re-zero the area before the 32-bit counter wraps
         KK_HIP(hipMemsetAsync(ctx->d_fsync, 0, KK_FS_SYNC_BYTES, ctx->stream));
@@ -346,12 +351,22 @@ int kk_launch_lanczos_fstep(kk_ctx ctx, const kk_sparse_dev& M, double* V, int64
     kk_prof_scope ps(ctx, "k_lanczos_fstep");
     double* ws_scal = ctx->ws + WS_SCAL;
     const int nrm = normalize ? 1 : 0, cg = cgs_order ? 1 : 0;
-    switch (NP) {
-        case 1: fstep_launch<1>(lowsync, G, ctx->stream, M, V, ld, m, bprev_dev, bprev, cg, L, cap, (char*)ctx->d_fsync, err, epoch, ticks, ws_scal, host_out, token, nrm, fault); break;
-        case 2: fstep_launch<2>(lowsync, G, ctx->stream, M, V, ld, m, bprev_dev, bprev, cg, L, cap, (char*)ctx->d_fsync, err, epoch, ticks, ws_scal, host_out, token, nrm, fault); break;
-        case 4: fstep_launch<4>(lowsync, G, ctx->stream, M, V, ld, m, bprev_dev, bprev, cg, L, cap, (char*)ctx->d_fsync, err, epoch, ticks, ws_scal, host_out, token, nrm, fault); break;
-        default: fstep_launch<8>(lowsync, G, ctx->stream, M, V, ld, m, bprev_dev, bprev, cg, L, cap, (char*)ctx->d_fsync, err, epoch, ticks, ws_scal, host_out, token, nrm, fault); break;
+#define FS_ARGS lowsync, G, ctx->stream, M, V, ld, m, bprev_dev, bprev, cg, L, cap, (char*)ctx->d_fsync, err, epoch, ticks, ws_scal, host_out, token, nrm, fault
+    if (tpb == 256) {
+        switch (NP) {
+            case 1: fstep_launch<256, 1>(FS_ARGS); break;
+            case 2: fstep_launch<256, 2>(FS_ARGS); break;
+            case 4: fstep_launch<256, 4>(FS_ARGS); break;
+            default: fstep_launch<256, 8>(FS_ARGS); break;
+        }
+    } else {
+        switch (NP) {
+            case 1: fstep_launch<1024, 1>(FS_ARGS); break;
+            case 2: fstep_launch<1024, 2>(FS_ARGS); break;
+            default: fstep_launch<1024, 4>(FS_ARGS); break;
+        }
     }
+#undef FS_ARGS
     KK_HIP(hipGetLastError());
     ++ctx->fstep_launches;
     return KK_OK;

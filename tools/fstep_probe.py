@@ -24,6 +24,7 @@ for N in sizes:
     op = kk.SparseOperator(A, ctx, symmetric=True)
     x0 = np.random.default_rng(3).random(N)
     row = {"rows": N}
+    ctx.set_option("fused_step_max_rows", 600000)   # (measure the kernel beyond its default range too)
     for oname, orth in (("mgs2", kk.ModifiedGramSchmidt2()), ("cgs2", kk.ClassicalGramSchmidt2())):
         for fused in (1, 0):
             ctx.set_option("fused_step", fused)
@@ -51,10 +52,10 @@ for N in sizes:
                 row[f"{oname}_kernel_bracket_us"] = round(ms / max(n, 1) * 1e3, 2)
     ctx.set_option("fused_step", 1)
     # blocks per launch (option "fstep_blocks"): fewer = cheaper reductions, more = more CUs on the data phases
-    for blocks in (16, 32, 64, 96, 128):
-        if N > blocks * 8 * 512:
+    for threads, blocks in ((256, 32), (256, 64), (256, 128), (1024, 32), (1024, 64), (1024, 128)):
+        if N > blocks * (8 * 512 if threads == 256 else 4 * 2048):
             continue
-        ctx.set_option("fstep_blocks", blocks)
+        ctx.set_option("fstep_blocks", blocks); ctx.set_option("fstep_threads", threads)
         it = kk.LanczosIterator(op, x0, kk.ModifiedGramSchmidt2(), capacity=K + 2)
         f = kk.initialize(it); V = f.V
         best = 1e9
@@ -67,6 +68,6 @@ for N in sizes:
             _ = f.normres
             ctx.sync()
             best = min(best, time.perf_counter() - t0)
-        row[f"mgs2_one_launch_us_blocks{blocks}"] = round(best / (K - 1) * 1e6, 1)
-    ctx.set_option("fstep_blocks", 64)
+        row[f"mgs2_one_launch_us_t{threads}_b{blocks}"] = round(best / (K - 1) * 1e6, 1)
+    ctx.set_option("fstep_blocks", 128); ctx.set_option("fstep_threads", 256)
     print(json.dumps(row), flush=True)
