@@ -345,6 +345,9 @@ elif scenario in ("xsync", "xsync_fault", "xsync_late"):
     # looks like a rank whose wait ran out a moment before they arrived: they find every partial in their area and must NOT commit
     # (abort word re-read before the commit), or the ranks' collectives stop pairing up.  k_mgs_persist carries the hook.
     routes = (("persist", 1), ("persist", 0)) if scenario == "xsync_late" else (("persist", 1), ("panel", 1), ("panel_p", 1), ("persist", 0))
+    if os.environ.get("KK_W2_ROUTES"):   # (the 8-rank rehearsal: a subset -- every route costs ~25 s there, the processes time-share the chip)
+        keep = os.environ["KK_W2_ROUTES"].split(",")
+        routes = tuple(r for r in routes if f"{r[0]}{r[1]}" in keep)
     for route, lookahead in routes:
         ctx.set_option("mgs_mode", 2 if route == "panel_p" else 0)      # panel_p: panels of 2-3 vectors per reduction (auto mode), else the strict order
         ctx.set_option("mgs_panel", 0 if route == "persist" else 1)
