@@ -236,6 +236,9 @@ KK_API int kk_ctx_set_option(kk_ctx c, const char* key, double value) {
     } else if (!strcmp(key, "fused_step_max_rows")) {
         KK_CHECK(value >= 0, KK_ERR_INVALID, "fused_step_max_rows must be >= 0");
         c->fused_step_max_rows = (int64_t)value;
+    } else if (!strcmp(key, "fused_step_m_limit")) {
+        KK_CHECK(value >= -1 && value <= KK_FS_MAX_M, KK_ERR_INVALID, "fused_step_m_limit must be -1 (none), 0 (by vector length) or 1..%d", KK_FS_MAX_M);
+        c->fused_step_m_limit = (int)value;
     } else if (!strcmp(key, "fstep_blocks")) {
         KK_CHECK(value >= 8 && value <= KK_FS_MAX_BLOCKS, KK_ERR_INVALID, "fstep_blocks must be in 8..%d", KK_FS_MAX_BLOCKS);
         c->fstep_blocks = (int)value;
@@ -361,6 +364,7 @@ KK_API int kk_ctx_get_option(kk_ctx c, const char* key, double* value) {
     else if (!strcmp(key, "spmv_dia_aligned")) *value = c->spmv_dia_aligned;
     else if (!strcmp(key, "fused_step")) *value = c->fused_step;
     else if (!strcmp(key, "fused_step_max_rows")) *value = (double)c->fused_step_max_rows;
+    else if (!strcmp(key, "fused_step_m_limit")) *value = c->fused_step_m_limit;
     else if (!strcmp(key, "fstep_blocks")) *value = c->fstep_blocks;
     else if (!strcmp(key, "fstep_threads")) *value = c->fstep_threads;
     else if (!strcmp(key, "fstep_launches")) *value = (double)c->fstep_launches;

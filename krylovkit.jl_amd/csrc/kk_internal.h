@@ -245,6 +245,7 @@ struct kk_ctx_s {
                                             // 15 vs 30 us per step at 1 k rows, 17 vs 30 at 10 k, 26 vs 34 at 102 k; 34 vs 38 (MGS2) but 38 vs 32 (CGS2) at 200 k)
     int fstep_blocks = 128;          // blocks of a launch at most (<= KK_FS_MAX_BLOCKS; option "fstep_blocks")
     int fstep_threads = 256;         // threads per block: 256 (1024 measured slower at every length: kept as the record)
+    int fused_step_m_limit = 0;      // basis vectors up to which a step takes the one launch: 0 = by vector length (96 - 64 n / 1e5, at least 16), > 0 = fixed, -1 = no limit but KK_FS_MAX_M
     void* d_fsync = nullptr;         // granule area + error flag (KK_FS_SYNC_BYTES + 64)
     unsigned fs_epoch = 0;           // tags of its grid reductions: unique over the life of the context (two per launch)
     double fs_token = 0;             // token counter: a launch that committed stores its token into the pinned host slot

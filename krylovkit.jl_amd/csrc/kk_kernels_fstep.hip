@@ -130,10 +130,11 @@ __global__ __launch_bounds__(TPB) void k_lanczos_fstep(const int32_t* __restrict
         const double t = wave_sum(a0p);
         if (lane == 0) wsum[wave][0] = t;
     }
-    // ---- p_j = <V_j, w>, g_j = <V_j, v> on this block's rows, four columns at a time
+    // ---- p_j = <V_j, w>, g_j = <V_j, v> on this block's rows, four columns at a time; the NEXT batch of columns is requested before the
+    // current one is reduced (two register sets: with one, every batch cost a full L2 round trip -- 0.8 us per basis vector at 1e5 rows)
     constexpr int JB = 4;   // (16 / NP columns per batch were tried: the short factorizations this kernel serves pay for the clamped loads -- 15.2 -> 20.0 us per step at 1 k rows)
-    for (int j0 = 0; j0 < m; j0 += JB) {
-        d2 q[JB][NP];
+    constexpr bool PIPE = NP <= 4;
+    auto vload = [&](d2 (&q)[JB][NP], int j0) {
 #pragma unroll
         for (int u = 0; u < JB; ++u) {
             const int j = j0 + u < m ? j0 + u : m - 1;
@@ -143,6 +144,8 @@ __global__ __launch_bounds__(TPB) void k_lanczos_fstep(const int32_t* __restrict
                 q[u][i] = row < ld ? ld2(V + (int64_t)j * ld + row) : d2{0.0, 0.0};   // (rows nrows .. ld - 1 of every column are zero)
             }
         }
+    };
+    auto vdots = [&](const d2 (&q)[JB][NP], int j0) {
 #pragma unroll
         for (int u = 0; u < JB; ++u) {
             if (j0 + u >= m) break;   // (uniform)
@@ -153,7 +156,22 @@ __global__ __launch_bounds__(TPB) void k_lanczos_fstep(const int32_t* __restrict
                 gg = fma(q[u][i].x, vr[i].x, gg); gg = fma(q[u][i].y, vr[i].y, gg);
             }
             pp = wave_sum(pp); gg = wave_sum(gg);
-            if (lane == 0 && j0 + u < m) { wsum[wave][1 + j0 + u] = pp; wsum[wave][1 + m + j0 + u] = gg; }
+            if (lane == 0) { wsum[wave][1 + j0 + u] = pp; wsum[wave][1 + m + j0 + u] = gg; }
+        }
+    };
+    {
+        d2 qa[JB][NP], qb[PIPE ? JB : 1][PIPE ? NP : 1];
+        vload(qa, 0);
+        for (int j0 = 0; j0 < m; j0 += (PIPE ? 2 : 1) * JB) {
+            if constexpr (PIPE) {
+                if (j0 + JB < m) vload(qb, j0 + JB);
+                vdots(qa, j0);
+                if (j0 + 2 * JB < m) vload(qa, j0 + 2 * JB);
+                if (j0 + JB < m) vdots(qb, j0 + JB);
+            } else {
+                vdots(qa, j0);
+                if (j0 + JB < m) vload(qa, j0 + JB);
+            }
         }
     }
     __syncthreads();
@@ -214,24 +232,28 @@ __global__ __launch_bounds__(TPB) void k_lanczos_fstep(const int32_t* __restrict
     __syncthreads();
     if (tid == 0) rhs[m - 1] = s_last + a0;   // alpha0 folded into the last coefficient: w -= V (s + alpha0 e_m)
     __syncthreads();
-    // ---- phase 2: w -= V coef on this block's rows, |w|^2 partial
-    for (int j0 = 0; j0 < m; j0 += JB) {
-        d2 q[JB][NP];
-        double cf[JB];
+    // ---- phase 2: w -= V coef on this block's rows (column order 0 .. m - 1, pipelined like the first pass), |w|^2 partial
+    auto vaxpy = [&](const d2 (&q)[JB][NP], int j0) {
 #pragma unroll
         for (int u = 0; u < JB; ++u) {
-            const int j = j0 + u < m ? j0 + u : m - 1;
-            cf[u] = j0 + u < m ? rhs[j] : 0.0;
+            const double cf = j0 + u < m ? rhs[j0 + u] : 0.0;
 #pragma unroll
-            for (int i = 0; i < NP; ++i) {
-                const int64_t row = (((int64_t)blockIdx.x * NP + i) * TPB + tid) * 2;
-                q[u][i] = row < ld ? ld2(V + (int64_t)j * ld + row) : d2{0.0, 0.0};
-            }
+            for (int i = 0; i < NP; ++i) { wr[i].x = fma(-cf, q[u][i].x, wr[i].x); wr[i].y = fma(-cf, q[u][i].y, wr[i].y); }
         }
-#pragma unroll
-        for (int u = 0; u < JB; ++u) {
-#pragma unroll
-            for (int i = 0; i < NP; ++i) { wr[i].x = fma(-cf[u], q[u][i].x, wr[i].x); wr[i].y = fma(-cf[u], q[u][i].y, wr[i].y); }
+    };
+    {
+        d2 qa[JB][NP], qb[PIPE ? JB : 1][PIPE ? NP : 1];
+        vload(qa, 0);
+        for (int j0 = 0; j0 < m; j0 += (PIPE ? 2 : 1) * JB) {
+            if constexpr (PIPE) {
+                if (j0 + JB < m) vload(qb, j0 + JB);
+                vaxpy(qa, j0);
+                if (j0 + 2 * JB < m) vload(qa, j0 + 2 * JB);
+                if (j0 + JB < m) vaxpy(qb, j0 + JB);
+            } else {
+                vaxpy(qa, j0);
+                if (j0 + JB < m) vload(qa, j0 + JB);
+            }
         }
     }
     double an = 0;

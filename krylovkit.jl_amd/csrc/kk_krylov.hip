@@ -246,6 +246,15 @@ static int la_enqueue_proj(kk_op op, kk_basis b, int c0, int j, kk_orth_t orth) 
 static bool fstep_ok(kk_ctx c, kk_op op, kk_basis b, int c0, int k, kk_orth_t orth, bool lowsync) {
     if (!c->fused_step || !c->d_fsync || kk_sharded(c) || c->allreduce || (c->comm && c->comm->active)) return false;
     if (c0 != 0 || k < 1 || k + 1 > KK_FS_MAX_M) return false;
+    // The one launch wins while the basis is SHORT as well: its fixed cost is ~8-15 us against ~28 us of the projection pair's ten stream
+    // operations, but every basis vector costs it 0.3-0.8 us (two wave reductions per column, a granule per value and block, a row of the
+    // solve) against 0.05-0.4 us in the pair, whose passes use the whole chip.  Measured cross-over (tools/fstep_probe.py, krylovdim 30 and
+    // 100, profiles/r06_fstep_probe.jsonl): m ~ 80-107 at 1 k rows, ~60 at 40 k, 27-35 at 102 k.  Beyond it the step takes the ordinary route
+    // (same slab state: the Gram rows and the normalised column are kept by both).
+    if (c->fused_step_m_limit >= 0) {
+        const double lim = c->fused_step_m_limit > 0 ? (double)c->fused_step_m_limit : std::max(16.0, 96.0 - 64.0 * (double)b->n / 1.0e5);
+        if ((double)(k + 1) > lim) return false;
+    }
     if (!(orth == KK_CGS2 || (orth == KK_MGS2 && lowsync))) return false;
     const kk_sparse_dev& M = op->A;
     if (M.format != 0 || M.n_ghost != 0 || M.halo || M.plan) return false;
@@ -415,7 +424,7 @@ KK_API int kk_lanczos_expand(kk_op op, kk_basis b, int c0, int k, kk_orth_t orth
         if (la_fs_hit) { slot = la_slot; token = la_token; }
         else KK_TRY(fstep_enqueue(op, b, k, orth, nullptr, beta_old, 0, slot, &token));
         b->spec_valid = false; b->la_valid = false;
-        if (c->lookahead && c->fold_scale && c0 + k + 3 <= b->cap && m1 + 1 <= KK_FS_MAX_M) {
+        if (c->lookahead && c->fold_scale && c0 + k + 3 <= b->cap && fstep_ok(c, op, b, c0, k + 1, orth, lowsync)) {
             double tk = 0;
             KK_TRY(fstep_enqueue(op, b, k + 1, orth, SCP(c, SC_NRM), 0.0, m1, 2 + ((k + 1) & 1), &tk));   // (beta of THIS step: on the device when that launch starts)
             b->spec_valid = true; b->spec_op = op; b->spec_c0 = c0; b->spec_k = k + 1; b->spec_dot_mode = -1; b->spec_beta = 0.0; b->spec_dot_ptr = nullptr;

@@ -38,8 +38,9 @@ def test_one_launch_step_against_oracle_and_projection_pair(kk, ko, shape, orth)
     c = kk.Context(0)
     try:
         assert c.get_option("fused_step") == 1
-        if n > c.get_option("fused_step_max_rows"):       # (the default route up to 131 072 rows; the kernel itself holds up to 524 288)
+        if n > c.get_option("fused_step_max_rows"):       # (the default route up to 131 072 rows; the kernel itself holds up to 262 144)
             c.set_option("fused_step_max_rows", 249500)
+        c.set_option("fused_step_m_limit", -1)            # (by default long bases switch to the projection pair: test_switch_at_the_basis_length_limit)
         f1, n1 = run(kk, c, A, x0, dev, steps, 1, 1)
         f2, n2 = run(kk, c, A, x0, dev, steps, 1, 0)
         f0, n0 = run(kk, c, A, x0, dev, steps, 0, 1)
@@ -124,6 +125,32 @@ def test_launch_that_gives_up_is_repeated_on_the_ordinary_route(kk, ko):
         assert relerr(f.alphas, of.alphas) < 1e-10 and relerr(f.betas, of.betas) < 1e-10
         V = f.V.to_numpy()
         assert np.max(np.abs(V.T @ V - np.eye(V.shape[1]))) < 1e-12
+    finally:
+        c.close()
+
+
+def test_switch_at_the_basis_length_limit(kk, ko):
+    """by default the one launch serves the SHORT bases (m <= 96 - 64 n / 1e5, at least 16) and the projection pair the steps beyond: the
+    switch happens inside a factorization, on the same slab state (Gram rows, normalised residual column), with no repeated step"""
+    nx, ny = 250, 240            # 60 000 rows: limit 57.6 -> steps with m = k + 1 <= 57 take the one launch
+    n = nx * ny
+    A = ko.laplacian_2d(nx, ny, shift_diag=10 * np.linspace(0, 1, n) ** 2)
+    x0 = np.random.default_rng(3).random(n)
+    steps = 70
+    c = kk.Context(0)
+    try:
+        for dev, ref in ((kk.ModifiedGramSchmidt2(), ko.MGS2), (kk.ClassicalGramSchmidt2(), ko.CGS2)):
+            c.prof_reset(); c.prof_enable(1)
+            f, nl = run(kk, c, A, x0, dev, steps, 1)
+            c.prof_enable(0)
+            assert 56 <= nl <= 57, nl                                     # k = 1 .. 56 (m = 2 .. 57)
+            assert c.prof_get("k_project")[1] == steps - 56, c.prof_get("k_project")   # ... and one projection step each for the rest: none repeated
+            oit = ko.LanczosIterator(A, x0.copy(), ref); of = ko.lanczos_initialize(oit)
+            for _ in range(steps):
+                of = ko.lanczos_expand(oit, of)
+            assert relerr(f.alphas, of.alphas) < 1e-10 and relerr(f.betas, of.betas) < 1e-10
+            V = f.V.to_numpy()
+            assert np.max(np.abs(V.T @ V - np.eye(V.shape[1]))) < 1e-12
     finally:
         c.close()
 

@@ -15,15 +15,15 @@ import krylovkit_hip as kk  # noqa: E402
 from bench import laplacian_rows  # noqa: E402
 
 ctx = kk.default_context()
-K = 30
 sizes = [int(a) for a in sys.argv[1:]] or [1024, 10000, 102400, 200000, 249000]
-for N in sizes:
+import itertools
+for N, K in itertools.product(sizes, (30, 100)):
     nx = int(round(N ** 0.5)); ny = N // nx
     N = nx * ny
     A = laplacian_rows(nx, ny, 0, ny)
     op = kk.SparseOperator(A, ctx, symmetric=True)
     x0 = np.random.default_rng(3).random(N)
-    row = {"rows": N}
+    row = {"rows": N, "krylovdim": K}
     ctx.set_option("fused_step_max_rows", 600000)   # (measure the kernel beyond its default range too)
     for oname, orth in (("mgs2", kk.ModifiedGramSchmidt2()), ("cgs2", kk.ClassicalGramSchmidt2())):
         for fused in (1, 0):
@@ -51,23 +51,4 @@ for N in sizes:
                 ms, n = ctx.prof_get("k_lanczos_fstep")
                 row[f"{oname}_kernel_bracket_us"] = round(ms / max(n, 1) * 1e3, 2)
     ctx.set_option("fused_step", 1)
-    # blocks per launch (option "fstep_blocks"): fewer = cheaper reductions, more = more CUs on the data phases
-    for threads, blocks in ((256, 32), (256, 64), (256, 128), (1024, 32), (1024, 64), (1024, 128)):
-        if N > blocks * (8 * 512 if threads == 256 else 4 * 2048):
-            continue
-        ctx.set_option("fstep_blocks", blocks); ctx.set_option("fstep_threads", threads)
-        it = kk.LanczosIterator(op, x0, kk.ModifiedGramSchmidt2(), capacity=K + 2)
-        f = kk.initialize(it); V = f.V
-        best = 1e9
-        for rep in range(6):
-            f = kk.initialize(it, V)
-            ctx.sync()
-            t0 = time.perf_counter()
-            for _ in range(K - 1):
-                f = kk.expand_(it, f)
-            _ = f.normres
-            ctx.sync()
-            best = min(best, time.perf_counter() - t0)
-        row[f"mgs2_one_launch_us_t{threads}_b{blocks}"] = round(best / (K - 1) * 1e6, 1)
-    ctx.set_option("fstep_blocks", 128); ctx.set_option("fstep_threads", 256)
     print(json.dumps(row), flush=True)
