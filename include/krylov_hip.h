@@ -92,7 +92,7 @@ typedef enum {
  * kk_comm_init times 64 in-kernel reductions over the ranks and 20 small RCCL all-reduces ("xsync_hop_us", "comm_allreduce_us": the
  * slowest rank's figures, identical on all ranks) and a sweep takes the in-kernel route iff
  *     reductions x xsync_hop_us  <=  comm_allreduce_us + vector_steps x t_sync x (rows / threshold_rows - 1)
- * (t_sync = the basis traffic the kernel saves per vector AT its threshold: 2.6 us for the register-resident kernel, 0.4 us for the panel kernel; threshold_rows = the single-chip
+ * (t_sync = the measured gain per vector-step and multiple of the threshold: 6 us for the register-resident kernel, 0.4 us for the panel kernel; threshold_rows = the single-chip
  * thresholds "persist_min_rows" / "panel_min_rows" scaled by the CU share): what the cross-rank round trips cost against the one RCCL
  * all-reduce per step the low-synchronisation route needs on top and the single-chip gain of the persistent kernel.  Route, panel
  * width and register tile are decided from the LONGEST shard of the slab (one all-reduce per slab and communicator at its first

@@ -23,7 +23,8 @@
 // x up to 8 row pairs (64 blocks, the default: 262 144 rows); granule area = (2 m + 1 values + the norm) x blocks x 16 bytes, error flag behind it
 #define KK_FS_MAX_M 128
 #define KK_FS_MAX_BLOCKS 128
-#define KK_FS_SYNC_BYTES ((2 * KK_FS_MAX_M + 2) * KK_FS_MAX_BLOCKS * 16)
+#define KK_FS_SET_BYTES ((2 * KK_FS_MAX_M + 2) * KK_FS_MAX_BLOCKS * 16)   // one granule set; two sets: the two passes of an Arnoldi CGS2 / MGS2 step alternate
+#define KK_FS_SYNC_BYTES (2 * KK_FS_SET_BYTES)
 #define KK_MAX_DEVICES 64     // per-device bookkeeping of function attributes
 #define KK_TPB 256            // threads per block of every streaming kernel (4 waves)
 #define KK_SUB 512            // rows covered by one block sub-step: 256 threads x 2 rows (16 B/lane)
@@ -527,8 +528,9 @@ static inline int64_t kk_dec_ld(kk_ctx ctx, int64_t ld) {
 // Against the low-synchronisation route (one more RCCL all-reduce per step: 2.05 instead of 1.06) a persistent launch pays one
 // cross-rank round trip per grid reduction and gains what it gains on ONE chip: nothing at the single-chip threshold `ld_min`,
 // `t_sync_us` per vector-step for every further multiple of it (the saved basis traffic grows with the rows, the exposed
-// reduction does not; t_sync_us = the traffic saved per vector AT the threshold: 3.9 B/row x 3.6 M rows = 2.6 us for the
-// register-resident kernel, 8 B/row x 250 k rows = 0.4 us for the panel kernel).  Both prices were measured by this communicator's hand-shake (kk_comm_init; the slowest rank's figures,
+// reduction does not; t_sync_us = the measured gain per vector-step and multiple: 6 us for the register-resident kernel -- 786 vs
+// 1359 us per iteration at 2.78 x its threshold --, 0.4 us for the panel kernel -- 8 B/row x 250 k rows of saved traffic; 0.58 us per
+// vector-step ahead at 2 x, 1.0 at 4 x its threshold).  Both prices were measured by this communicator's hand-shake (kk_comm_init; the slowest rank's figures,
 // identical on all ranks):   take the in-kernel route  iff  nred x hop  <=  all-reduce + nvec x t_sync x (ld / ld_min - 1).
 // Option "xsync" = 2 skips the rule (tests; A/B runs), 0 switches the in-kernel route off.
 static inline bool kk_xs_pays(kk_ctx ctx, int64_t ld, int nvec, int nred, double ld_min, double t_sync_us) {
@@ -599,7 +601,9 @@ static inline bool kk_mgs_lowsync(kk_ctx ctx, int64_t ld_local, int m) {
         if (kk_xs_pays(ctx, ld, 2 * m, (2 * m + P - 1) / P + 1, share * (double)ctx->panel_min_rows, 0.4)) return false;
     }
     if ((double)ld >= share * (double)ctx->persist_min_rows && kk_mgs_persist_eligible(ctx, ld_local, m, 2))
-        return !kk_xs_pays(ctx, ld, 2 * m, 2 * m + 1, share * (double)ctx->persist_min_rows, 2.6);
+        // (gain per vector-step and multiple of the threshold, calibrated on the measured step times: at 10 M rows = 2.78 x the threshold the strict
+        //  persistent sweep takes 786 us per iteration, the low-sync pair 1359 us -- 11 us per vector-step over 1.78 multiples = 6 us)
+        return !kk_xs_pays(ctx, ld, 2 * m, 2 * m + 1, share * (double)ctx->persist_min_rows, 6.0);
     return true;
 }
 int kk_launch_mgs_persist(kk_ctx ctx, const double* V, int64_t ld, int m, int nsweeps, double* w, const double* carry_q,
@@ -609,8 +613,9 @@ int64_t kk_mgs_persist_capacity(kk_ctx ctx);
 static inline bool kk_persist_norm_applies(double nrm) { return nrm > 0.0 && 1.0 / nrm <= 1.79769313486231570815e308; }
 int kk_launch_lanczos_coef(kk_ctx ctx, const double* buf, double* L, int cap, int m, int lowsync, double* coef_out, double* res);
 // one fused Lanczos step on columns [0, m) of V (v = column m - 1, normalised; v_prev = column m - 2), result column m; kk_kernels_fstep.hip
+// (arnoldi: w = A v without the three-term part, npass = 1 / 2 orthogonalisation passes, the column of H at host_out + 8 + KK_FS_MAX_M)
 int kk_launch_lanczos_fstep(kk_ctx ctx, const kk_sparse_dev& M, double* V, int64_t ld, int m, bool lowsync, bool cgs_order, const double* bprev_dev,
-                            double bprev, double* L, int cap, double* host_out, double token, bool normalize);
+                            double bprev, double* L, int cap, double* host_out, double token, bool normalize, bool arnoldi = false, int npass = 1);
 int64_t kk_fstep_capacity_rows(kk_ctx ctx);
 int kk_launch_norm_scalars(kk_ctx ctx, const double* nrm2, double* sc, double* res2);
 int kk_launch_lowsync_solve(kk_ctx ctx, const double* p, const double* g_ride, double* L, int cap, int m, int newest,

@@ -70,19 +70,20 @@ __global__ __launch_bounds__(TPB) void k_lanczos_fstep(const int32_t* __restrict
                                                             int64_t nrows, double* __restrict__ V, int64_t ld, int m, const double* __restrict__ bprev_dev,
                                                             double bprev, int cgs_order, double* __restrict__ L, int cap, char* __restrict__ sync,
                                                             int* __restrict__ err, unsigned epoch, long long timeout_ticks, double* __restrict__ ws_scal,
-                                                            double* __restrict__ host_out, double token, int normalize, int fault) {
+                                                            double* __restrict__ host_out, double token, int normalize, int fault, int arnoldi, int npass) {
     __shared__ double wsum[TPB / 64][2 * KK_FS_MAX_M + 2];   // per-wave partials of the 2 m + 1 values
     __shared__ double tot[2 * KK_FS_MAX_M + 2];                    // totals; later rhs / coefficients in tot[1 .. m]
     __shared__ double part4[(2 * KK_FS_MAX_M + 2) * 4];            // quarter sums of the grid reduction
+    __shared__ double gsave[KK_FS_MAX_M];                          // the new Gram row g = V'v (first pass)
+    __shared__ double hsum[KK_FS_MAX_M];                           // sum of the passes' coefficients (Arnoldi: the column of H)
     __shared__ double red[TPB / 64];
     __shared__ int bad;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int G = gridDim.x;
-    const int nval = 2 * m + 1;
     const double* v = V + (int64_t)(m - 1) * ld;
-    const double* vprev = V + (int64_t)(m - 2) * ld;
+    const double* vprev = V + (int64_t)(m >= 2 ? m - 2 : 0) * ld;
     double* wout = V + (int64_t)m * ld;
-    const double bp = bprev_dev ? *bprev_dev : bprev;
+    const double bp = arnoldi ? 0.0 : (bprev_dev ? *bprev_dev : bprev);
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(sync, 0, KK_FS_SYNC_BYTES, 0x00020000);
     if (tid == 0) bad = 0;
     if (fault && blockIdx.x == 0) {   // test hook: block 0 behaves like a block whose wait ran out
@@ -117,12 +118,14 @@ __global__ __launch_bounds__(TPB) void k_lanczos_fstep(const int32_t* __restrict
                 s1 = fma(a.y, v[cc.y], s1);
             }
             const d2 xv = ld2(v + row);
-            const d2 pv = ld2(vprev + row);
             d2 out{s0, s1};
-            if (cgs_order) { a0p = fma(xv.x, out.x, a0p); a0p = fma(xv.y, out.y, a0p); }      // <v, A v>        lanczos.jl:298
-            out.x = fma(-bp, pv.x, out.x); out.y = fma(-bp, pv.y, out.y);
+            if (!arnoldi) {
+                const d2 pv = ld2(vprev + row);
+                if (cgs_order) { a0p = fma(xv.x, out.x, a0p); a0p = fma(xv.y, out.y, a0p); }      // <v, A v>        lanczos.jl:298
+                out.x = fma(-bp, pv.x, out.x); out.y = fma(-bp, pv.y, out.y);
+            }
             if (row + 1 >= nrows) out.y = 0.0;   // odd nrows: keep the pad row zero
-            if (!cgs_order) { a0p = fma(xv.x, out.x, a0p); a0p = fma(xv.y, out.y, a0p); }     // <v, w>          lanczos.jl:308
+            if (!arnoldi && !cgs_order) { a0p = fma(xv.x, out.x, a0p); a0p = fma(xv.y, out.y, a0p); }     // <v, w>          lanczos.jl:308
             wr[i] = out; vr[i] = xv;
         }
     }
@@ -130,8 +133,9 @@ __global__ __launch_bounds__(TPB) void k_lanczos_fstep(const int32_t* __restrict
         const double t = wave_sum(a0p);
         if (lane == 0) wsum[wave][0] = t;
     }
-    // ---- p_j = <V_j, w>, g_j = <V_j, v> on this block's rows, four columns at a time; the NEXT batch of columns is requested before the
-    // current one is reduced (two register sets: with one, every batch cost a full L2 round trip -- 0.8 us per basis vector at 1e5 rows)
+    // ---- the orthogonalisation passes (one: Lanczos, Arnoldi with CGS / MGS; two: Arnoldi with CGS2 / MGS2).  Per pass: p_j = <V_j, w> (first pass also
+    // g_j = <V_j, v>, the new Gram row) on this block's rows, four columns at a time with the NEXT batch requested before the current one is reduced;
+    // ONE grid reduction; the small solve, redundantly in every block; w -= V s.
     constexpr int JB = 4;   // (16 / NP columns per batch were tried: the short factorizations this kernel serves pay for the clamped loads -- 15.2 -> 20.0 us per step at 1 k rows)
     constexpr bool PIPE = NP <= 4;
     auto vload = [&](d2 (&q)[JB][NP], int j0) {
@@ -145,116 +149,131 @@ __global__ __launch_bounds__(TPB) void k_lanczos_fstep(const int32_t* __restrict
             }
         }
     };
-    auto vdots = [&](const d2 (&q)[JB][NP], int j0) {
-#pragma unroll
-        for (int u = 0; u < JB; ++u) {
-            if (j0 + u >= m) break;   // (uniform)
-            double pp = 0, gg = 0;
-#pragma unroll
-            for (int i = 0; i < NP; ++i) {
-                pp = fma(q[u][i].x, wr[i].x, pp); pp = fma(q[u][i].y, wr[i].y, pp);
-                gg = fma(q[u][i].x, vr[i].x, gg); gg = fma(q[u][i].y, vr[i].y, gg);
-            }
-            pp = wave_sum(pp); gg = wave_sum(gg);
-            if (lane == 0) { wsum[wave][1 + j0 + u] = pp; wsum[wave][1 + m + j0 + u] = gg; }
-        }
-    };
-    {
-        d2 qa[JB][NP], qb[PIPE ? JB : 1][PIPE ? NP : 1];
-        vload(qa, 0);
-        for (int j0 = 0; j0 < m; j0 += (PIPE ? 2 : 1) * JB) {
-            if constexpr (PIPE) {
-                if (j0 + JB < m) vload(qb, j0 + JB);
-                vdots(qa, j0);
-                if (j0 + 2 * JB < m) vload(qa, j0 + 2 * JB);
-                if (j0 + JB < m) vdots(qb, j0 + JB);
-            } else {
-                vdots(qa, j0);
-                if (j0 + JB < m) vload(qa, j0 + JB);
-            }
-        }
-    }
-    __syncthreads();
-    // ---- grid reduction 1: 2 m + 1 values.  Granule of (value t, block b) at (t * G + b) * 16
-    for (int t = tid; t < nval; t += TPB) {
-        double s = 0;
-#pragma unroll
-        for (int wv = 0; wv < TPB / 64; ++wv) s += wsum[wv][t];   // fixed order
-        fs_publish(rs, (unsigned)((t * G + (int)blockIdx.x) * 16), epoch, s);
-    }
-    // four threads per value, each the granules of a quarter of the blocks (<= 32: one or two batches of loads); the quarters are added in a fixed order
-    const long long t0 = wall_clock64();
-    const int gq = (G + 3) >> 2;
-    for (int idx = tid; idx < nval * 4; idx += TPB) {
-        const int t = idx >> 2, qd = idx & 3;
-        const int b_lo = qd * gq, b_hi = b_lo + gq < G ? b_lo + gq : G;
-        double x = 0;
-        if (b_lo < b_hi && !fs_collect(rs, (unsigned)(t * G * 16), b_lo, b_hi, epoch, err, t0, timeout_ticks, x)) bad = 1;
-        part4[idx] = x;
-    }
-    __syncthreads();
-    if (bad) { if (tid == 0) __hip_atomic_store(err, 1, RLX_AGENT); return; }
-    for (int t = tid; t < nval; t += TPB) tot[t] = ((part4[4 * t] + part4[4 * t + 1]) + part4[4 * t + 2]) + part4[4 * t + 3];
-    __syncthreads();
-    // ---- coefficients (the algebra of k_lanczos_coef): rhs = p - alpha0 g ; low-sync: (I + L) s = rhs with row m - 1 of L = g
-    const double a0 = tot[0];
     double* rhs = tot + 1;            // rhs[i] overwrites p[i]
-    const double* g = tot + 1 + m;
-    for (int i = tid; i < m; i += TPB) rhs[i] = fma(-a0, g[i], rhs[i]);
-    if (LOWSYNC && blockIdx.x == 0)
-        for (int i = tid; i < m - 1; i += TPB) L[(int64_t)(m - 1) * cap + i] = g[i];   // the new Gram row (device mirror; the host's copy travels below)
-    __syncthreads();
-    if (LOWSYNC) {
-        // column-oriented forward substitution; thread i owns row i (m <= KK_FS_MAX_M <= TPB)
-        const int i = tid;
-        const bool act = i < m;
-        const double* lrow = (i == m - 1) ? g : L + (int64_t)(act ? i : 0) * cap;
-        constexpr int AH = 8;     // entries of the row requested ahead of their use (L2 latency off the dependent chain)
-        double la[AH];
+    for (int i = tid; i < m; i += TPB) hsum[i] = 0.0;
+    double a0 = 0.0, s_last = 0.0;
+    for (int pass = 0; pass < npass; ++pass) {
+        const bool first = pass == 0;
+        const int nval = first ? 2 * m + 1 : m + 1;       // [alpha0 (Lanczos) | p | g (first pass)]
+        auto vdots = [&](const d2 (&q)[JB][NP], int j0) {
 #pragma unroll
-        for (int u = 0; u < AH; ++u) la[u] = (act && u < i) ? lrow[u] : 0.0;
-        for (int j0 = 0; j0 < m - 1; j0 += AH) {
+            for (int u = 0; u < JB; ++u) {
+                if (j0 + u >= m) break;   // (uniform)
+                double pp = 0, gg = 0;
 #pragma unroll
-            for (int u = 0; u < AH; ++u) {
-                const int j = j0 + u;
-                if (j < m - 1) {   // uniform
-                    const double lij = la[u];
-                    const int jn = j + AH;
-                    la[u] = (act && jn < i) ? lrow[jn] : 0.0;
-                    const double sj = rhs[j];
-                    if (i > j && act) rhs[i] = fma(-lij, sj, rhs[i]);
-                    __syncthreads();
+                for (int i = 0; i < NP; ++i) {
+                    pp = fma(q[u][i].x, wr[i].x, pp); pp = fma(q[u][i].y, wr[i].y, pp);
+                    gg = fma(q[u][i].x, vr[i].x, gg); gg = fma(q[u][i].y, vr[i].y, gg);
+                }
+                pp = wave_sum(pp);
+                if (first) gg = wave_sum(gg);
+                if (lane == 0) { wsum[wave][1 + j0 + u] = pp; if (first) wsum[wave][1 + m + j0 + u] = gg; }
+            }
+        };
+        {
+            d2 qa[JB][NP], qb[PIPE ? JB : 1][PIPE ? NP : 1];
+            vload(qa, 0);
+            for (int j0 = 0; j0 < m; j0 += (PIPE ? 2 : 1) * JB) {
+                if constexpr (PIPE) {
+                    if (j0 + JB < m) vload(qb, j0 + JB);
+                    vdots(qa, j0);
+                    if (j0 + 2 * JB < m) vload(qa, j0 + 2 * JB);
+                    if (j0 + JB < m) vdots(qb, j0 + JB);
+                } else {
+                    vdots(qa, j0);
+                    if (j0 + JB < m) vload(qa, j0 + JB);
                 }
             }
         }
-    }
-    const double s_last = rhs[m - 1];
-    __syncthreads();
-    if (tid == 0) rhs[m - 1] = s_last + a0;   // alpha0 folded into the last coefficient: w -= V (s + alpha0 e_m)
-    __syncthreads();
-    // ---- phase 2: w -= V coef on this block's rows (column order 0 .. m - 1, pipelined like the first pass), |w|^2 partial
-    auto vaxpy = [&](const d2 (&q)[JB][NP], int j0) {
+        __syncthreads();
+        // ---- grid reduction of the pass: granule of (value t, block b) at (t * G + b) * 16 of set pass & 1 (a fast block may publish the second pass
+        // while a slow one still polls the first: different sets), tag epoch + pass
+        const unsigned set_off = (unsigned)(pass & 1) * (unsigned)KK_FS_SET_BYTES;
+        for (int t = tid; t < nval; t += TPB) {
+            double sv = 0;
 #pragma unroll
-        for (int u = 0; u < JB; ++u) {
-            const double cf = j0 + u < m ? rhs[j0 + u] : 0.0;
-#pragma unroll
-            for (int i = 0; i < NP; ++i) { wr[i].x = fma(-cf, q[u][i].x, wr[i].x); wr[i].y = fma(-cf, q[u][i].y, wr[i].y); }
+            for (int wv = 0; wv < TPB / 64; ++wv) sv += wsum[wv][t];   // fixed order
+            fs_publish(rs, set_off + (unsigned)((t * G + (int)blockIdx.x) * 16), epoch + (unsigned)pass, sv);
         }
-    };
-    {
-        d2 qa[JB][NP], qb[PIPE ? JB : 1][PIPE ? NP : 1];
-        vload(qa, 0);
-        for (int j0 = 0; j0 < m; j0 += (PIPE ? 2 : 1) * JB) {
-            if constexpr (PIPE) {
-                if (j0 + JB < m) vload(qb, j0 + JB);
-                vaxpy(qa, j0);
-                if (j0 + 2 * JB < m) vload(qa, j0 + 2 * JB);
-                if (j0 + JB < m) vaxpy(qb, j0 + JB);
-            } else {
-                vaxpy(qa, j0);
-                if (j0 + JB < m) vload(qa, j0 + JB);
+        // four threads per value, each the granules of a quarter of the blocks (<= 32: one or two batches of loads); the quarters are added in a fixed order
+        const long long t0 = wall_clock64();
+        const int gq = (G + 3) >> 2;
+        for (int idx = tid; idx < nval * 4; idx += TPB) {
+            const int t = idx >> 2, qd = idx & 3;
+            const int b_lo = qd * gq, b_hi = b_lo + gq < G ? b_lo + gq : G;
+            double x = 0;
+            if (b_lo < b_hi && !fs_collect(rs, set_off + (unsigned)(t * G * 16), b_lo, b_hi, epoch + (unsigned)pass, err, t0, timeout_ticks, x)) bad = 1;
+            part4[idx] = x;
+        }
+        __syncthreads();
+        if (bad) { if (tid == 0) __hip_atomic_store(err, 1, RLX_AGENT); return; }
+        for (int t = tid; t < nval; t += TPB) tot[t] = ((part4[4 * t] + part4[4 * t + 1]) + part4[4 * t + 2]) + part4[4 * t + 3];
+        __syncthreads();
+        // ---- coefficients (the algebra of k_lanczos_coef): rhs = p - alpha0 g ; low-sync: (I + L) s = rhs with row m - 1 of L = g
+        if (first) {
+            a0 = arnoldi ? 0.0 : tot[0];
+            for (int i = tid; i < m; i += TPB) gsave[i] = tot[1 + m + i];     // the Gram row: kept for the second pass' solve and for the host
+        }
+        __syncthreads();
+        const double* g = gsave;
+        if (first && !arnoldi) for (int i = tid; i < m; i += TPB) rhs[i] = fma(-a0, g[i], rhs[i]);
+        if (LOWSYNC && first && blockIdx.x == 0)
+            for (int i = tid; i < m - 1; i += TPB) L[(int64_t)(m - 1) * cap + i] = g[i];   // the new Gram row (device mirror; the host's copy travels below)
+        __syncthreads();
+        if (LOWSYNC) {
+            // column-oriented forward substitution; thread i owns row i (m <= KK_FS_MAX_M <= TPB)
+            const int i = tid;
+            const bool act = i < m;
+            const double* lrow = (i == m - 1) ? g : L + (int64_t)(act ? i : 0) * cap;
+            constexpr int AH = 8;     // entries of the row requested ahead of their use (L2 latency off the dependent chain)
+            double la[AH];
+#pragma unroll
+            for (int u = 0; u < AH; ++u) la[u] = (act && u < i) ? lrow[u] : 0.0;
+            for (int j0 = 0; j0 < m - 1; j0 += AH) {
+#pragma unroll
+                for (int u = 0; u < AH; ++u) {
+                    const int j = j0 + u;
+                    if (j < m - 1) {   // uniform
+                        const double lij = la[u];
+                        const int jn = j + AH;
+                        la[u] = (act && jn < i) ? lrow[jn] : 0.0;
+                        const double sj = rhs[j];
+                        if (i > j && act) rhs[i] = fma(-lij, sj, rhs[i]);
+                        __syncthreads();
+                    }
+                }
             }
         }
+        for (int i = tid; i < m; i += TPB) hsum[i] += rhs[i];     // Arnoldi: h = s (+ s2)
+        if (first) s_last = rhs[m - 1];
+        __syncthreads();
+        if (first && !arnoldi && tid == 0) rhs[m - 1] = s_last + a0;   // Lanczos: alpha0 folded into the last coefficient: w -= V (s + alpha0 e_m)
+        __syncthreads();
+        // ---- w -= V coef on this block's rows (column order 0 .. m - 1, pipelined like the dots)
+        auto vaxpy = [&](const d2 (&q)[JB][NP], int j0) {
+#pragma unroll
+            for (int u = 0; u < JB; ++u) {
+                const double cf = j0 + u < m ? rhs[j0 + u] : 0.0;
+#pragma unroll
+                for (int i = 0; i < NP; ++i) { wr[i].x = fma(-cf, q[u][i].x, wr[i].x); wr[i].y = fma(-cf, q[u][i].y, wr[i].y); }
+            }
+        };
+        {
+            d2 qa[JB][NP], qb[PIPE ? JB : 1][PIPE ? NP : 1];
+            vload(qa, 0);
+            for (int j0 = 0; j0 < m; j0 += (PIPE ? 2 : 1) * JB) {
+                if constexpr (PIPE) {
+                    if (j0 + JB < m) vload(qb, j0 + JB);
+                    vaxpy(qa, j0);
+                    if (j0 + 2 * JB < m) vload(qa, j0 + 2 * JB);
+                    if (j0 + JB < m) vaxpy(qb, j0 + JB);
+                } else {
+                    vaxpy(qa, j0);
+                    if (j0 + JB < m) vload(qa, j0 + JB);
+                }
+            }
+        }
+        __syncthreads();   // (rhs / tot are rewritten by the next pass' reduction)
     }
     double an = 0;
 #pragma unroll
@@ -263,12 +282,13 @@ __global__ __launch_bounds__(TPB) void k_lanczos_fstep(const int32_t* __restrict
     if (lane == 0) red[wave] = an;
     __syncthreads();
     // ---- grid reduction 2: |w|^2 (value slot nval_max of the area, its own epoch)
-    const unsigned noff = (unsigned)((2 * KK_FS_MAX_M + 1) * KK_FS_MAX_BLOCKS * 16);
+    const unsigned noff = (unsigned)((2 * KK_FS_MAX_M + 1) * KK_FS_MAX_BLOCKS * 16);   // (last value slot of set 0)
+    const unsigned nepoch = epoch + (unsigned)npass;
     if (tid == 0) {
         double s = 0;
 #pragma unroll
         for (int wv = 0; wv < TPB / 64; ++wv) s += red[wv];
-        fs_publish(rs, noff + blockIdx.x * 16u, epoch + 1u, s);
+        fs_publish(rs, noff + blockIdx.x * 16u, nepoch, s);
     }
     __syncthreads();   // (red[] read above by thread 0 before it is reused)
     if (wave == 0) {   // lane l: the granules of blocks l and l + 64 (G <= 128); the lanes' values are added by wave_sum: same order in every block
@@ -280,7 +300,7 @@ __global__ __launch_bounds__(TPB) void k_lanczos_fstep(const int32_t* __restrict
             const int errv = __hip_atomic_load(err, RLX_AGENT);
             const fs_v4u ta = __builtin_amdgcn_raw_buffer_load_b128(rs, noff + (unsigned)((lane < G ? lane : 0) * 16), 0, 16 /* sc1 */);
             const fs_v4u tb = __builtin_amdgcn_raw_buffer_load_b128(rs, noff + (unsigned)((lane + 64 < G ? lane + 64 : 0) * 16), 0, 16 /* sc1 */);
-            const bool ok = (lane >= G || (ta.x == epoch + 1u && ta.w == epoch + 1u)) && (lane + 64 >= G || (tb.x == epoch + 1u && tb.w == epoch + 1u));
+            const bool ok = (lane >= G || (ta.x == nepoch && ta.w == nepoch)) && (lane + 64 >= G || (tb.x == nepoch && tb.w == nepoch));
             if (__all(ok)) {
                 x = lane < G ? __longlong_as_double((long long)(((unsigned long long)ta.y << 32) | ta.z)) : 0.0;
                 if (lane + 64 < G) x += __longlong_as_double((long long)(((unsigned long long)tb.y << 32) | tb.z));
@@ -311,7 +331,7 @@ __global__ __launch_bounds__(TPB) void k_lanczos_fstep(const int32_t* __restrict
         }
         // host slot: [0] token (written LAST), [1] alpha0, [2] last coefficient before the fold, [3 .. 5] |w|^2, |w|, 1 / |w|, [6] stored normalised?,
         // [8 .. 8 + m) the Gram row g = V'v.  System-scope stores; the token follows a system-scope fence.
-        for (int i = tid; i < m; i += TPB) fs_host_store(host_out + 8 + i, g[i]);
+        for (int i = tid; i < m; i += TPB) { fs_host_store(host_out + 8 + i, gsave[i]); fs_host_store(host_out + 8 + KK_FS_MAX_M + i, hsum[i]); }
         if (tid == 0) {
             fs_host_store(host_out + 1, a0);
             fs_host_store(host_out + 2, s_last);
@@ -334,19 +354,19 @@ int64_t kk_fstep_capacity_rows(kk_ctx ctx) { return (int64_t)std::max(1, std::mi
 template <int TPB, int NP>
 static void fstep_launch(bool lowsync, int G, hipStream_t s, const kk_sparse_dev& M, double* V, int64_t ld, int m, const double* bprev_dev, double bprev,
                          int cgs_order, double* L, int cap, char* sync, int* err, unsigned epoch, long long ticks, double* ws_scal, double* host_out,
-                         double token, int normalize, int fault) {
+                         double token, int normalize, int fault, int arnoldi, int npass) {
     if (lowsync)
         hipLaunchKernelGGL((k_lanczos_fstep<TPB, NP, true>), dim3(G), dim3(TPB), 0, s, M.ell_col, M.ell_val, M.ell_ld, M.width, M.nrows, V, ld, m, bprev_dev, bprev,
-                           cgs_order, L, cap, sync, err, epoch, ticks, ws_scal, host_out, token, normalize, fault);
+                           cgs_order, L, cap, sync, err, epoch, ticks, ws_scal, host_out, token, normalize, fault, arnoldi, npass);
     else
         hipLaunchKernelGGL((k_lanczos_fstep<TPB, NP, false>), dim3(G), dim3(TPB), 0, s, M.ell_col, M.ell_val, M.ell_ld, M.width, M.nrows, V, ld, m, bprev_dev, bprev,
-                           cgs_order, L, cap, sync, err, epoch, ticks, ws_scal, host_out, token, normalize, fault);
+                           cgs_order, L, cap, sync, err, epoch, ticks, ws_scal, host_out, token, normalize, fault, arnoldi, npass);
 }
 
 // one fused Lanczos step on columns [0, m) of V (v = column m - 1, normalised), result in column m; scalars to ws + WS_SCAL and to host_out
 int kk_launch_lanczos_fstep(kk_ctx ctx, const kk_sparse_dev& M, double* V, int64_t ld, int m, bool lowsync, bool cgs_order, const double* bprev_dev,
-                            double bprev, double* L, int cap, double* host_out, double token, bool normalize) {
-    KK_CHECK(ctx->d_fsync && m >= 2 && m <= KK_FS_MAX_M && M.format == 0 && M.nrows <= kk_fstep_capacity_rows(ctx), KK_ERR_UNSUPPORTED,
+                            double bprev, double* L, int cap, double* host_out, double token, bool normalize, bool arnoldi, int npass) {
+    KK_CHECK(ctx->d_fsync && m >= 2 && m <= KK_FS_MAX_M && npass >= 1 && npass <= 2 && M.format == 0 && M.nrows <= kk_fstep_capacity_rows(ctx), KK_ERR_UNSUPPORTED,
              "kk_launch_lanczos_fstep: not eligible (m = %d, %lld rows)", m, (long long)M.nrows);
     // as many blocks as the chip offers CUs (all resident at once: the grid reductions need every block), at most "fstep_blocks".  256-thread
     // blocks while one row pair per thread covers the vector (<= 512 x blocks rows), else 1024-thread blocks with 1 / 2 / 4 pairs per thread
@@ -364,8 +384,8 @@ int kk_launch_lanczos_fstep(kk_ctx ctx, const kk_sparse_dev& M, double* V, int64
         KK_HIP(hipMemsetAsync(ctx->d_fsync, 0, KK_FS_SYNC_BYTES, ctx->stream));
         ctx->fs_epoch = 0;
     }
-    ctx->fs_epoch += 2;
-    const unsigned epoch = ctx->fs_epoch;
+    const unsigned epoch = ctx->fs_epoch + 1u;   // tags epoch .. epoch + npass (passes, then the norm)
+    ctx->fs_epoch += 4;
     int fault = 0;
     if (ctx->fstep_fault > 0) { --ctx->fstep_fault; fault = 1; }
     int* err = (int*)((char*)ctx->d_fsync + KK_FS_SYNC_BYTES);
@@ -373,7 +393,7 @@ int kk_launch_lanczos_fstep(kk_ctx ctx, const kk_sparse_dev& M, double* V, int64
     kk_prof_scope ps(ctx, "k_lanczos_fstep");
     double* ws_scal = ctx->ws + WS_SCAL;
     const int nrm = normalize ? 1 : 0, cg = cgs_order ? 1 : 0;
-#define FS_ARGS lowsync, G, ctx->stream, M, V, ld, m, bprev_dev, bprev, cg, L, cap, (char*)ctx->d_fsync, err, epoch, ticks, ws_scal, host_out, token, nrm, fault
+#define FS_ARGS lowsync, G, ctx->stream, M, V, ld, m, bprev_dev, bprev, cg, L, cap, (char*)ctx->d_fsync, err, epoch, ticks, ws_scal, host_out, token, nrm, fault, arnoldi ? 1 : 0, npass
     if (tpb == 256) {
         switch (NP) {
             case 1: fstep_launch<256, 1>(FS_ARGS); break;

@@ -243,7 +243,17 @@ static int la_enqueue_proj(kk_op op, kk_basis b, int c0, int j, kk_orth_t orth) 
 
 // ---- the whole step in one launch (short vectors: kk_kernels_fstep.hip).  Single-rank context, operator in the ELL format without
 // ghost columns, factorization starting at column 0, at most KK_FS_MAX_M basis vectors, CGS2 or MGS2 in its low-synchronisation form.
+static bool fstep_ok_common(kk_ctx c, kk_op op, kk_basis b, int c0, int k);
 static bool fstep_ok(kk_ctx c, kk_op op, kk_basis b, int c0, int k, kk_orth_t orth, bool lowsync) {
+    if (!(orth == KK_CGS2 || (orth == KK_MGS2 && lowsync))) return false;
+    return fstep_ok_common(c, op, b, c0, k);
+}
+// Arnoldi: the same launch without the three-term part, one (CGS, MGS) or two (CGS2, MGS2) orthogonalisation passes; MGS family in its low-sync form
+static bool fstep_ok_arnoldi(kk_ctx c, kk_op op, kk_basis b, int c0, int k, kk_orth_t orth, bool lowsync) {
+    if (!(orth == KK_CGS || orth == KK_CGS2 || ((orth == KK_MGS || orth == KK_MGS2) && lowsync))) return false;
+    return fstep_ok_common(c, op, b, c0, k);
+}
+static bool fstep_ok_common(kk_ctx c, kk_op op, kk_basis b, int c0, int k) {
     if (!c->fused_step || !c->d_fsync || kk_sharded(c) || c->allreduce || (c->comm && c->comm->active)) return false;
     if (c0 != 0 || k < 1 || k + 1 > KK_FS_MAX_M) return false;
     // The one launch wins while the basis is SHORT as well: its fixed cost is ~8-15 us against ~28 us of the projection pair's ten stream
@@ -255,7 +265,6 @@ static bool fstep_ok(kk_ctx c, kk_op op, kk_basis b, int c0, int k, kk_orth_t or
         const double lim = c->fused_step_m_limit > 0 ? (double)c->fused_step_m_limit : std::max(16.0, 96.0 - 64.0 * (double)b->n / 1.0e5);
         if ((double)(k + 1) > lim) return false;
     }
-    if (!(orth == KK_CGS2 || (orth == KK_MGS2 && lowsync))) return false;
     const kk_sparse_dev& M = op->A;
     if (M.format != 0 || M.n_ghost != 0 || M.halo || M.plan) return false;
     return b->n <= c->fused_step_max_rows && b->n <= kk_fstep_capacity_rows(c) && b->ld * 8 < ((int64_t)1 << 31);
@@ -263,10 +272,12 @@ static bool fstep_ok(kk_ctx c, kk_op op, kk_basis b, int c0, int k, kk_orth_t or
 static inline double* fstep_slot(kk_ctx c, int slot) { return c->h_pin + (int64_t)slot * WS_TOTAL + WS_USER; }   // (WS_USER: unused on single-rank contexts)
 // enqueue the step for basis size m = k + 1 (v = column k, normalised IN THE STREAM); the kernel reads beta of the step in front from
 // the device (bprev_dev) or takes the host's value
-static int fstep_enqueue(kk_op op, kk_basis b, int k, kk_orth_t orth, const double* bprev_dev, double bprev, int rows_in_stream, int slot, double* token_out) {
+static int fstep_enqueue(kk_op op, kk_basis b, int k, kk_orth_t orth, const double* bprev_dev, double bprev, int rows_in_stream, int slot, double* token_out,
+                         bool arnoldi = false) {
     kk_ctx c = b->ctx;
     const int m = k + 1;
-    const bool ls = orth == KK_MGS2;
+    const bool ls = orth == KK_MGS2 || orth == KK_MGS;
+    const int npass = arnoldi && (orth == KK_CGS2 || orth == KK_MGS2) ? 2 : 1;
     if (ls) {   // Gram rows of the basis columns below the newest one (lowsync_project_dev): known, on their way in the stream, or recomputed (restart)
         const int newest = m - 1;
         if (std::max(b->gram_rows, rows_in_stream) < newest) KK_TRY(gram_ensure(b, newest));
@@ -276,7 +287,7 @@ static int fstep_enqueue(kk_op op, kk_basis b, int k, kk_orth_t orth, const doub
     c->fs_token += 1.0;
     *token_out = c->fs_token;
     return kk_launch_lanczos_fstep(c, op->A, b->col(0), b->ld, m, ls, orth == KK_CGS2, bprev_dev, bprev, ls ? b->d_gram : nullptr, b->cap, fstep_slot(c, slot),
-                                   c->fs_token, c->fold_scale != 0);
+                                   c->fs_token, c->fold_scale != 0, arnoldi, npass);
 }
 // wait for the token of a launch in its pinned slot (the kernel's LAST store): a spin on host memory -- no copy, no event
 static bool fstep_wait(kk_ctx c, int slot, double token) {
@@ -557,13 +568,49 @@ KK_API int kk_arnoldi_expand(kk_op op, kk_basis b, int c0, int k, kk_orth_t orth
                         b->spec_dot_mode == 0 && b->la_kind == 0 && b->la_k == k && b->la_nsweeps == la_sweeps && b->spec_beta == beta_old && strict_route && v_ready;
     const int la_slot = b->la_slot;
     const double la_token = b->la_token;
-    if (b->la_valid && !la_hit) b->spec_valid = false;   // the sweep enqueued ahead has consumed the speculative apply's column
-    bool hit = la_hit;
-    if (!la_hit) KK_TRY(spec_take(op, b, c0, k, 0, beta_old, SCP(c, SC_ALPHA0), &hit));
+    // the whole step in one launch (short vectors and short bases: kk_kernels_fstep.hip; round 6)
+    const bool fs_route = m <= KK_MAX_M && fstep_ok_arnoldi(c, op, b, c0, k, orth, la_sweeps > 0 && kk_mgs_lowsync(c, b->ld, m));
+    const bool la_fs_hit = b->la_valid && b->spec_valid && c->spec_owner == b && b->spec_gen == c->foreign_gen && b->spec_op == op && b->spec_c0 == c0 && b->spec_k == k &&
+                           b->la_kind == 2 && b->la_orth == 100 + (int)orth && b->la_k == k && b->spec_beta == beta_old && v_ready && fs_route;
+    if (b->la_valid && !la_hit && !la_fs_hit) b->spec_valid = false;   // the sweep enqueued ahead has consumed the speculative apply's column
+    bool hit = la_hit || la_fs_hit;
+    if (!hit && !fs_route) KK_TRY(spec_take(op, b, c0, k, 0, beta_old, SCP(c, SC_ALPHA0), &hit));
     gram_touch(b, c0 + k);
     c->persist_norm_done = la_hit;
     if (v_ready) b->norm_col = -1;
     else KK_TRY(kk_launch_scal(c, v, b->ld, 1.0 / beta_old, nullptr));  // push!(V, scale(r, 1/beta))   arnoldi.jl:209
+    if (fs_route) {
+        // w = A v, one or two orthogonalisation passes, the norm and the normalised commit in ONE launch; column of H and beta through the pinned slot
+        int slot = 2 + (k & 1);
+        double token = 0;
+        if (la_fs_hit) { slot = la_slot; token = la_token; }
+        else KK_TRY(fstep_enqueue(op, b, k, orth, nullptr, 0.0, 0, slot, &token, true));
+        b->spec_valid = false; b->la_valid = false;
+        if (c->lookahead && c->fold_scale && c0 + k + 3 <= b->cap && fstep_ok_arnoldi(c, op, b, c0, k + 1, orth, la_sweeps > 0 && kk_mgs_lowsync(c, b->ld, m + 1))) {
+            double tk = 0;
+            KK_TRY(fstep_enqueue(op, b, k + 1, orth, nullptr, 0.0, m, 2 + ((k + 1) & 1), &tk, true));
+            b->spec_valid = true; b->spec_op = op; b->spec_c0 = c0; b->spec_k = k + 1; b->spec_dot_mode = -1; b->spec_beta = 0.0; b->spec_dot_ptr = nullptr;
+            c->spec_owner = b; b->spec_gen = c->foreign_gen;
+            b->la_valid = true; b->la_k = k + 1; b->la_slot = 2 + ((k + 1) & 1); b->la_token = tk; b->la_nsweeps = 0; b->la_kind = 2; b->la_orth = 100 + (int)orth; b->la_rode = false;
+        }
+        if (!fstep_wait(c, slot, token)) {   // the launch gave up: route off for this context, the step again on the ordinary one (see kk_lanczos_expand)
+            KK_HIP(hipMemsetAsync((char*)c->d_fsync + KK_FS_SYNC_BYTES, 0, sizeof(int), c->stream));
+            ++c->fstep_failures;
+            c->fused_step = 0;
+            b->spec_valid = false; b->la_valid = false;
+            b->norm_col = c0 + k; b->norm_beta = beta_old;
+            return kk_arnoldi_expand(op, b, c0, k, orth, eta, beta_old, h, beta, npasses);
+        }
+        const double* hs = fstep_slot(c, slot);
+        for (int j = 0; j < m; ++j) h[j] = hs[8 + KK_FS_MAX_M + j];
+        *beta = hs[4];
+        if (orth == KK_MGS || orth == KK_MGS2) lowsync_commit_row(b, m, hs + 8);
+        if (npasses) *npasses = (orth == KK_CGS2 || orth == KK_MGS2) ? 2 : 1;
+        if (hs[6] != 0.0 && kk_persist_norm_applies(*beta)) { b->norm_col = c0 + k + 1; b->norm_beta = *beta; }
+        else { b->la_valid = false; b->spec_valid = false; }
+        if (b->spec_valid) b->spec_beta = *beta;
+        return KK_OK;
+    }
     if (!hit) {
         kk_spmv_fuse f;
         KK_TRY(kk_launch_spmv(c, op->A, v, w, b->ld, f));           // w = apply(operator, last(V))  :242

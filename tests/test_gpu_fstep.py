@@ -60,9 +60,75 @@ def test_one_launch_step_against_oracle_and_projection_pair(kk, ko, shape, orth)
         c.close()
 
 
-def test_general_sparsity_and_nonsymmetric_values(kk, ko):
+@pytest.mark.parametrize("shape", [(36, 30), (300, 200)])
+@pytest.mark.parametrize("orth", ["cgs", "mgs", "cgs2", "mgs2"])
+def test_one_launch_arnoldi_step(kk, ko, shape, orth):
+    """arnoldirecurrence!! + orthogonalize!! (src/factorizations/arnoldi.jl:199-245, orthonormal.jl:378-452) in one launch: w = A v, one (CGS, MGS) or
+    two (CGS2, MGS2) passes -- MGS family in the library's low-synchronisation form --, norm, normalised commit; H and beta through the pinned slot.
+    H within 1e-10 of the oracle and 1e-12 of the ordinary route, V orthonormal, lookahead on / off bit-identical"""
+    nx, ny = shape
+    n = nx * ny
+    A = ko.convection_diffusion_2d(nx, ny)
+    x0 = np.random.default_rng(3).random(n)
+    dev, ref = {"cgs": (kk.ClassicalGramSchmidt(), ko.CGS), "mgs": (kk.ModifiedGramSchmidt(), ko.MGS), "cgs2": (kk.ClassicalGramSchmidt2(), ko.CGS2),
+                "mgs2": (kk.ModifiedGramSchmidt2(), ko.MGS2)}[orth]
+    steps = 20
+    c = kk.Context(0)
+    try:
+        def arnoldi(fused, la):
+            c.set_option("fused_step", fused); c.set_option("lookahead", la)
+            l0 = c.get_option("fstep_launches")
+            it = kk.ArnoldiIterator(kk.SparseOperator(A, c), x0, dev, capacity=steps + 3)
+            f = kk.initialize(it)
+            for _ in range(steps):
+                f = kk.expand_(it, f)
+            return f, int(c.get_option("fstep_launches") - l0)
+        f1, n1 = arnoldi(1, 1)
+        f2, n2 = arnoldi(1, 0)
+        f0, n0 = arnoldi(0, 1)
+        assert n0 == 0 and n2 == steps and steps <= n1 <= steps + 1, (n0, n1, n2)
+        H1, H2, H0 = (np.asarray(f.H, float) for f in (f1, f2, f0))
+        assert np.array_equal(H1, H2) and f1.normres == f2.normres
+        tol_pair = 1e-12 if dev.is_reorth else 1e-8          # (one-pass orthogonalisers: the two routes differ by their loss of orthogonality)
+        assert np.max(np.abs(H1 - H0)) < tol_pair * np.max(np.abs(H0))
+        oit = ko.ArnoldiIterator(A, x0.copy(), ref); of = ko.arnoldi_initialize(oit)
+        for _ in range(steps):
+            of = ko.arnoldi_expand(oit, of)
+        Ho = np.asarray(of.H, float)
+        tol = 1e-10 if dev.is_reorth else 1e-6
+        assert np.max(np.abs(H1 - Ho)) < tol * np.max(np.abs(Ho)) and abs(f1.normres - of.normres) < tol * abs(of.normres)
+        if dev.is_reorth:
+            V = f1.V.to_numpy()
+            assert np.max(np.abs(V.T @ V - np.eye(V.shape[1]))) < 1e-12
+        assert c.get_option("fstep_failures") == 0
+    finally:
+        c.close()
+
+
+def test_gmres_on_the_one_launch_step(kk, ko):
+    """linsolve(GMRES) with restarts (linsolve/gmres.jl:55-140) on a short vector: every Arnoldi step one launch; iteration / operation counts of the
+    oracle, the same solution"""
+    nx, ny = 60, 50
+    n = nx * ny
+    A = ko.convection_diffusion_2d(nx, ny)
+    b = np.random.default_rng(4).random(n)
+    c = kk.Context(0)
+    try:
+        l0 = c.get_option("fstep_launches")
+        tol = 1e-10 * np.linalg.norm(b)
+        x, info = kk.linsolve(kk.SparseOperator(A, c), b, None, kk.GMRES(kk.ModifiedGramSchmidt2(), 40, 20, tol))
+        xo, oinfo = ko.gmres(A, b, None, krylovdim=20, maxiter=40, tol=tol, orth=ko.MGS2)
+        assert c.get_option("fstep_launches") - l0 > 20
+        assert info.converged == 1 and (info.numiter, info.numops) == (oinfo.numiter, oinfo.numops)
+        assert np.linalg.norm(x - xo) < 1e-8 * np.linalg.norm(xo) and np.linalg.norm(A @ x - b) <= 1.01 * tol
+    finally:
+        c.close()
+
+
+def test_general_sparsity_and_nonsymmetric_values(kk, ko, monkeypatch):
     """any operator in the ELL format: a random symmetric pattern (no stencil structure), 20 entries per row"""
     import scipy.sparse as sp
+    monkeypatch.setenv("KK_SPMV_FORMAT", "ell")
     n = 30_000
     rng = np.random.default_rng(8)
     R = sp.random(n, n, density=10 / n, random_state=rng, format="csr")
