@@ -147,6 +147,15 @@ typedef enum {
  * "spmm_dia_al" (default 2: the sweeping multi-column apply of a value-free 5-point stencil with an even line length runs in its
  * aligned 16-byte form, 2 or 4 columns per wave; 0 = the 8-byte form; bit-identical), "spmm_dia_al_lines" (default 4: grid lines per
  * wave sweep of that form),
+ * "fused_step" (default 1: a Lanczos expand! with CGS2 / low-sync MGS2, or an Arnoldi expand! with CGS / CGS2 / low-sync MGS / MGS2, on a SHORT
+ * vector -- single-rank context, operator in the ELL format, factorization starting at column 0, at most "fused_step_max_rows" rows
+ * (default 131072) and "fused_step_m_limit" basis vectors (default 0 = by vector length: 96 - 64 n / 1e5, at least 16; -1 = no limit but 128)
+ * -- runs as ONE kernel launch: apply, the grid reductions, the small solve, the update(s), the norm and the normalised commit, with the
+ * scalars delivered through a pinned host slot the call polls (no copy, no event) and the next step's launch enqueued before the host looks:
+ * 15 instead of 31 us per expand! at 1e3-1e4 rows, 27 instead of 34 at 1e5.  Equal to the ordinary route to rounding (another summation
+ * order of the inner products).  A launch that cannot complete (a block that never becomes resident on a shared GPU) is noticed by the
+ * host, the step repeated on the ordinary route and the option switched off for the context ("fstep_failures"; "fstep_launches" counts);
+ * 0 = the projection pair of rounds 1-5), "fstep_blocks" (blocks per launch at most, default 128), test hook "fstep_fault",
  * "spmv_dia_sw" (default 1: the single-vector apply of a value-free 5-point stencil with an even line length whose lines start at
  * phase 0 runs as a SWEEP -- k_spmv_dia_sw: a wave walks the grid lines of its 128-wide strips through a four-line register window,
  * one 16-byte x load, one v_prev load and one store per line and lane, the fused epilogues on the line in registers; 1 / 2 = strips per

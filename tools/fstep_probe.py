@@ -50,5 +50,23 @@ for N, K in itertools.product(sizes, (30, 100)):
                 ctx.sync(); ctx.prof_enable(0)
                 ms, n = ctx.prof_get("k_lanczos_fstep")
                 row[f"{oname}_kernel_bracket_us"] = round(ms / max(n, 1) * 1e3, 2)
+    # Arnoldi MGS2 (the GMRES step): two passes per step
+    from bench import convdiff_rows
+    opa = kk.SparseOperator(convdiff_rows(nx, ny), ctx)
+    for fused in (1, 0):
+        ctx.set_option("fused_step", fused)
+        ita = kk.ArnoldiIterator(opa, x0, kk.ModifiedGramSchmidt2(), capacity=K + 2)
+        fa = kk.initialize(ita); Va = fa.V
+        best = 1e9
+        for rep in range(4):
+            fa = kk.initialize(ita, Va)
+            ctx.sync()
+            t0 = time.perf_counter()
+            for _ in range(K - 1):
+                fa = kk.expand_(ita, fa)
+            _ = fa.normres
+            ctx.sync()
+            best = min(best, time.perf_counter() - t0)
+        row[f"arnoldi_mgs2_{'one_launch' if fused else 'ordinary'}_us"] = round(best / (K - 1) * 1e6, 1)
     ctx.set_option("fused_step", 1)
     print(json.dumps(row), flush=True)
