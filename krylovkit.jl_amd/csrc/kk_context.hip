@@ -243,7 +243,7 @@ KK_API int kk_ctx_set_option(kk_ctx c, const char* key, double value) {
         KK_CHECK(value >= 8 && value <= KK_FS_MAX_BLOCKS, KK_ERR_INVALID, "fstep_blocks must be in 8..%d", KK_FS_MAX_BLOCKS);
         c->fstep_blocks = (int)value;
     } else if (!strcmp(key, "fstep_threads")) {
-        KK_CHECK(value == 256 || value == 1024, KK_ERR_INVALID, "fstep_threads must be 256 or 1024");
+        KK_CHECK(value == 256 || value == 512 || value == 1024, KK_ERR_INVALID, "fstep_threads must be 256, 512 or 1024");
         c->fstep_threads = (int)value;
     } else if (!strcmp(key, "fstep_fault")) {
         c->fstep_fault = (int)value;

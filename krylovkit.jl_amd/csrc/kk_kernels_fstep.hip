@@ -145,7 +145,11 @@ __global__ __launch_bounds__(TPB) void k_lanczos_fstep(const int32_t* __restrict
 #pragma unroll
             for (int i = 0; i < NP; ++i) {
                 const int64_t row = (((int64_t)blockIdx.x * NP + i) * TPB + tid) * 2;
+#if defined(KK_FS_EXP) && (KK_FS_EXP & 2)       // (timing experiment 2: without the loads of V)
+                q[u][i] = d2{(double)j, (double)row};
+#else
                 q[u][i] = row < ld ? ld2(V + (int64_t)j * ld + row) : d2{0.0, 0.0};   // (rows nrows .. ld - 1 of every column are zero)
+#endif
             }
         }
     };
@@ -165,8 +169,10 @@ __global__ __launch_bounds__(TPB) void k_lanczos_fstep(const int32_t* __restrict
                     pp = fma(q[u][i].x, wr[i].x, pp); pp = fma(q[u][i].y, wr[i].y, pp);
                     gg = fma(q[u][i].x, vr[i].x, gg); gg = fma(q[u][i].y, vr[i].y, gg);
                 }
+#if !(defined(KK_FS_EXP) && (KK_FS_EXP & 1))   // (timing experiment 1: without the wave reductions -- tools/fstep_where.sh; never defined in the product build)
                 pp = wave_sum(pp);
                 if (first) gg = wave_sum(gg);
+#endif
                 if (lane == 0) { wsum[wave][1 + j0 + u] = pp; if (first) wsum[wave][1 + m + j0 + u] = gg; }
             }
         };
@@ -202,12 +208,19 @@ __global__ __launch_bounds__(TPB) void k_lanczos_fstep(const int32_t* __restrict
             const int t = idx >> 2, qd = idx & 3;
             const int b_lo = qd * gq, b_hi = b_lo + gq < G ? b_lo + gq : G;
             double x = 0;
+#if defined(KK_FS_EXP) && (KK_FS_EXP & 4)       // (timing experiment 4: without waiting for the other blocks)
+            x = 1e-3;
+#else
             if (b_lo < b_hi && !fs_collect(rs, set_off + (unsigned)(t * G * 16), b_lo, b_hi, epoch + (unsigned)pass, err, t0, timeout_ticks, x)) bad = 1;
+#endif
             part4[idx] = x;
         }
         __syncthreads();
         if (bad) { if (tid == 0) __hip_atomic_store(err, 1, RLX_AGENT); return; }
         for (int t = tid; t < nval; t += TPB) tot[t] = ((part4[4 * t] + part4[4 * t + 1]) + part4[4 * t + 2]) + part4[4 * t + 3];
+#if defined(KK_FS_EXP) && (KK_FS_EXP & 8)       // (timing experiment 8: keep the numbers finite when 1 / 2 are on)
+        for (int t = tid; t < nval; t += TPB) tot[t] = 1e-3;
+#endif
         __syncthreads();
         // ---- coefficients (the algebra of k_lanczos_coef): rhs = p - alpha0 g ; low-sync: (I + L) s = rhs with row m - 1 of L = g
         if (first) {
@@ -373,12 +386,12 @@ int kk_launch_lanczos_fstep(kk_ctx ctx, const kk_sparse_dev& M, double* V, int64
     const int gmax = std::max(1, std::min(std::min(KK_FS_MAX_BLOCKS, ctx->fstep_blocks), ctx->num_cus));
     // (1024-thread blocks -- four waves per SIMD -- were measured SLOWER at every length, 34.7 vs 20.0 us at 1 k rows, 44.1 vs 26.2 at 1e5: sixteen
     //  waves per block make the block-level steps of the two reductions and the solve's barriers that much longer; kept behind option "fstep_threads")
-    const int tpb = ctx->fstep_threads == 1024 ? 1024 : 256;
+    const int tpb = ctx->fstep_threads == 1024 ? 1024 : (ctx->fstep_threads == 512 ? 512 : 256);
     const int64_t chunks = (M.nrows + tpb * 2 - 1) / (tpb * 2);
     const int np_need = (int)((chunks + gmax - 1) / gmax);
     const int NP = np_need <= 1 ? 1 : (np_need <= 2 ? 2 : (np_need <= 4 ? 4 : 8));
     const int G = (int)((chunks + NP - 1) / NP);
-    KK_CHECK(G >= 1 && G <= gmax && np_need <= (tpb == 256 ? 8 : 4), KK_ERR_UNSUPPORTED, "kk_launch_lanczos_fstep: %lld rows do not fit %d blocks", (long long)M.nrows, gmax);
+    KK_CHECK(G >= 1 && G <= gmax && np_need <= (tpb == 1024 ? 4 : 8), KK_ERR_UNSUPPORTED, "kk_launch_lanczos_fstep: %lld rows do not fit %d blocks", (long long)M.nrows, gmax);
     KK_HIP(hipSetDevice(ctx->device));
     if (ctx->fs_epoch > 0xffffffffu - 8u) {   // tags are unique over the life of the context: re-zero the area before the 32-bit counter wraps
         KK_HIP(hipMemsetAsync(ctx->d_fsync, 0, KK_FS_SYNC_BYTES, ctx->stream));
@@ -400,6 +413,13 @@ int kk_launch_lanczos_fstep(kk_ctx ctx, const kk_sparse_dev& M, double* V, int64
             case 2: fstep_launch<256, 2>(FS_ARGS); break;
             case 4: fstep_launch<256, 4>(FS_ARGS); break;
             default: fstep_launch<256, 8>(FS_ARGS); break;
+        }
+    } else if (tpb == 512) {
+        switch (NP) {
+            case 1: fstep_launch<512, 1>(FS_ARGS); break;
+            case 2: fstep_launch<512, 2>(FS_ARGS); break;
+            case 4: fstep_launch<512, 4>(FS_ARGS); break;
+            default: fstep_launch<512, 8>(FS_ARGS); break;
         }
     } else {
         switch (NP) {
