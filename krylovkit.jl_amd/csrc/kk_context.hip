@@ -231,6 +231,8 @@ KK_API int kk_ctx_set_option(kk_ctx c, const char* key, double value) {
         c->spmv_dia_const = value != 0;
     } else if (!strcmp(key, "spmv_dia_aligned")) {
         c->spmv_dia_aligned = value != 0;
+    } else if (!strcmp(key, "panel_apply")) {
+        c->panel_apply = value != 0;
     } else if (!strcmp(key, "fused_step")) {
         c->fused_step = value != 0;
     } else if (!strcmp(key, "fused_step_max_rows")) {
@@ -362,6 +364,8 @@ KK_API int kk_ctx_get_option(kk_ctx c, const char* key, double* value) {
     else if (!strcmp(key, "spmv_dia")) *value = c->spmv_dia;
     else if (!strcmp(key, "spmv_dia_const")) *value = c->spmv_dia_const;
     else if (!strcmp(key, "spmv_dia_aligned")) *value = c->spmv_dia_aligned;
+    else if (!strcmp(key, "panel_apply")) *value = c->panel_apply;
+    else if (!strcmp(key, "panel_apply_launches")) *value = (double)c->panel_apply_launches;
     else if (!strcmp(key, "fused_step")) *value = c->fused_step;
     else if (!strcmp(key, "fused_step_max_rows")) *value = (double)c->fused_step_max_rows;
     else if (!strcmp(key, "fused_step_m_limit")) *value = c->fused_step_m_limit;

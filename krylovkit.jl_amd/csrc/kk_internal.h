@@ -138,6 +138,17 @@ struct kk_comm_s {
     double ar_us = 0;                           // one RCCL all-reduce of 8 doubles on the context stream, measured by the hand-shake (slowest rank)
 };
 
+// constant-coefficient grid stencil as the kernels take it: coefficient of diagonal q, position of row 0 inside its grid line, line length
+struct dia_cst { double c[9]; int64_t phase, D; };
+// A sparse apply that the NEXT persistent sweep launch performs itself (round 6: k_mgs_panel<.., APPLY> forms w = (A x) * xs in its registers instead of
+// loading a w that a separate launch has just written): set by the run-ahead of an Arnoldi step, consumed by pass_mgs_strict_sweeps
+struct kk_sweep_apply {
+    bool on = false;
+    const struct kk_sparse_dev* M = nullptr;
+    const double* x = nullptr;
+    const double* xs_dev = nullptr;
+};
+
 struct kk_ctx_s {
     int device = 0;
     kk_comm_s* comm = nullptr;   // set by kk_comm_init: every reduction of the library is summed over the ranks
@@ -213,6 +224,9 @@ struct kk_ctx_s {
                                        // reduction per panel cost ~6 us); since the values of a reduction are swept by as many waves at once (round 5) the panel
                                        // kernel wins from ~0.2 M rows: Arnoldi MGS2 cycle of 60, 128 k rows 11.7 vs 13.1 k it/s (projection pair ahead), 250 k 12.3 vs
                                        // 11.6, 500 k 11.1 vs 8.0, 1 M 8.3 vs 5.5 (profiles/r05_panel_sweep_par.jsonl)
+    int panel_apply = 1;         // Arnoldi steps enqueued ahead on the panel kernel, value-free 5-point stencil (even line length, phase 0): the kernel forms w = A v itself
+    kk_sweep_apply sweep_apply;  // ... the pending request (see kk_sweep_apply)
+    int64_t panel_apply_launches = 0;   // diagnostics
     int xsync = 1;               // row-sharded context: persistent kernels with the in-kernel cross-rank reduction where the communicator offers it (0: RCCL all-reduce per inner-product batch, low-sync route)
     int mgs_persist = 1;         // strict MGS sweeps through the persistent register-resident kernel when the vector fits
     int persist_coop = 0;        // launch the persistent kernels through hipLaunchCooperativeKernel (1) or as ordinary launches (0): see kk_launch_resident
@@ -582,7 +596,9 @@ bool kk_mgs_panel_eligible(kk_ctx ctx, int64_t ld);
 int64_t kk_mgs_panel_capacity(kk_ctx ctx);
 int kk_mgs_panel_width(kk_ctx ctx, int64_t ld, bool strict);
 int kk_launch_mgs_panel(kk_ctx ctx, const double* V, int64_t ld, int m, int nsweeps, double* w, const double* carry_q,
-                        const double* carry_s, double* out_s, int out_stride, double* nrm_out3, bool normalize_w, bool strict);
+                        const double* carry_s, double* out_s, int out_stride, double* nrm_out3, bool normalize_w, bool strict,
+                        const kk_sweep_apply* apply = nullptr);
+bool kk_sweep_apply_ok(kk_ctx ctx, const kk_sparse_dev& M, int64_t ld);   // can the panel kernel apply this operator itself?
 // does an MGS-family sweep over vectors of leading dimension ld run in the low-synchronisation (projection-based) form?
 // (option "mgs_mode").  auto: the persistent kernels wherever they are the faster route -- the panel kernel for vectors of
 // panel_min_rows .. 4.19 M rows, the register-resident strict kernel from persist_min_rows rows up to its capacity -- and the

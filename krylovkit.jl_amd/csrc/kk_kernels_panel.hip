@@ -362,12 +362,16 @@ __device__ __forceinline__ bool panel_update(d2 (&wr)[NV], d2 (&cur)[P][NV], con
 
 // nsweeps MGS sweeps of w against V[:, 0:m) (+ an optional pending axpy w -= *carry_s * carry_q in front, + the squared
 // norm of the result, + the normalised commit): the interface of k_mgs_persist.
-template <int NV, int P>
+// APPLY (round 6): the work vector is not loaded but FORMED -- w = (A x) * xs for a value-free 5-point grid stencil (even line length D, lines
+// starting at phase 0), the operator of BASELINE config 3: the Arnoldi step's separate apply launch, its 16 N bytes of store and this kernel's 16 N
+// bytes of load go (arnoldi.jl:242 + orthonormal.jl:414-439 in one launch).  Same products in the same order as k_spmv_dia<5, U, true>: same bits.
+struct panel_apply_args { const double* x; const double* xs_dev; int64_t nrows; dia_cst cst; };
+template <int NV, int P, bool APPLY = false>
 __global__ __launch_bounds__(KK_PANEL_PT) void k_mgs_panel(const double* __restrict__ V, int64_t ld, int m, int nsweeps, double* __restrict__ w,
                                                            const double* __restrict__ carry_q, const double* __restrict__ carry_s,
                                                            double* __restrict__ out_s, int out_stride, double* __restrict__ nrm_out3,
                                                            char* __restrict__ sync, int* __restrict__ err, int fault, unsigned ebase, int normalize,
-                                                           double* __restrict__ ok_out, double token, kk_xs_dev xs, long long timeout_ticks) {
+                                                           double* __restrict__ ok_out, double token, kk_xs_dev xs, long long timeout_ticks, panel_apply_args ap) {
     __shared__ double smA[64];
     __shared__ double smB[16];
     if (fault == 1 && blockIdx.x == 0) {   // test hook (option "persist_fault"): block 0 behaves like a block whose spin ran out
@@ -409,8 +413,48 @@ __global__ __launch_bounds__(KK_PANEL_PT) void k_mgs_panel(const double* __restr
     d2 wr[NV];
     d2 qa[P][NV], qb[P][NV];
     panel_issue<NV, P>(qa, V, ld, m, 0, nsteps, voff, sbytes, brow, bbytes);   // first panel on its way before anything else
+    if (APPLY) {
+        // w = (A x) * xs on this thread's row pairs: centre pair, the two far pairs (aligned: row and D are even) and the two single neighbours,
+        // all loads of all pairs first (branch-free: an index outside the operator reads x[0] and is replaced by 0), then the products in the
+        // slot order -D, -1, 0, +1, +D of k_spmv_dia
+        const double* __restrict__ x = ap.x;
+        const int64_t nr = ap.nrows, D = ap.cst.D;
+        const double xsv = ap.xs_dev ? *ap.xs_dev : 1.0;
+        const double c0 = ap.cst.c[0], c1 = ap.cst.c[1], c2 = ap.cst.c[2], c3 = ap.cst.c[3], c4 = ap.cst.c[4];
+        d2 xc[NV], xm[NV], xp[NV];
+        double xl[NV], xr[NV];
 #pragma unroll
-    for (int j = 0; j < NV; ++j) wr[j] = pload(rw, voff, (unsigned)j * sbytes);
+        for (int j = 0; j < NV; ++j) {
+            const int64_t row = brow + ((int64_t)j * KK_PANEL_DT + dt) * 2;
+            const bool in = j < nvr && row < nr;
+            const int64_t rc = in ? row : 0;
+            const bool okm = in && rc >= D, okp = in && rc + D < nr, okl = in && rc >= 1, okr = in && rc + 2 < nr;
+            xc[j] = ld2(x + rc);
+            const d2 a = ld2(x + (okm ? rc - D : 0)), b = ld2(x + (okp ? rc + D : 0));
+            const double l = x[okl ? rc - 1 : 0], r = x[okr ? rc + 2 : 0];
+            xm[j] = d2{okm ? a.x : 0.0, okm ? a.y : 0.0};
+            xp[j] = d2{okp ? b.x : 0.0, (okp && rc + D + 1 < nr) ? b.y : 0.0};
+            xl[j] = okl ? l : 0.0; xr[j] = okr ? r : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int64_t row = brow + ((int64_t)j * KK_PANEL_DT + dt) * 2;
+            const bool in = j < nvr && row < nr;
+            const int64_t i0 = (int64_t)((unsigned)(in ? row : 0) % (unsigned)D);   // position of the pair's first row inside its grid line (rows, D < 2^31)
+            const double cw0 = i0 == 0 ? 0.0 : c1, ce1 = i0 + 2 == D ? 0.0 : c3;     // no -1 entry at position 0, no +1 entry at position D - 1
+            double s0 = 0.0, s1 = 0.0;
+            s0 = fma(c0, xm[j].x, s0); s1 = fma(c0, xm[j].y, s1);
+            s0 = fma(cw0, xl[j], s0);  s1 = fma(c1, xc[j].x, s1);
+            s0 = fma(c2, xc[j].x, s0); s1 = fma(c2, xc[j].y, s1);
+            s0 = fma(c3, xc[j].y, s0); s1 = fma(ce1, xr[j], s1);
+            s0 = fma(c4, xp[j].x, s0); s1 = fma(c4, xp[j].y, s1);
+            const double t0 = s0 * xsv, t1 = s1 * xsv;
+            wr[j] = in ? d2{1.0 * t0, (row + 1 >= nr) ? 0.0 : 1.0 * t1} : d2{0.0, 0.0};
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) wr[j] = pload(rw, voff, (unsigned)j * sbytes);
+    }
     if (carry_q) {   // pending axpy of the caller (Lanczos: w -= alpha0 v): one extra read of that vector, through the idle second panel set
         const __amdgpu_buffer_rsrc_t rc = pcol_rsrc(carry_q + brow, bbytes);
         const double cs = *carry_s;
@@ -713,8 +757,17 @@ bool kk_mgs_panel_eligible(kk_ctx ctx, int64_t ld_local) {
 }
 
 template <int NV, int P>
-static int launch_panel_inst(kk_ctx ctx, void** args) {
-    return kk_launch_resident(ctx, (const void*)k_mgs_panel<NV, P>, KK_PANEL_PT, args, 0, "k_mgs_panel");
+static int launch_panel_inst(kk_ctx ctx, void** args, bool apply = false) {
+    if (apply) return kk_launch_resident(ctx, (const void*)k_mgs_panel<NV, P, true>, KK_PANEL_PT, args, 0, "k_mgs_panel");
+    return kk_launch_resident(ctx, (const void*)k_mgs_panel<NV, P, false>, KK_PANEL_PT, args, 0, "k_mgs_panel");
+}
+// the panel kernel can apply the operator itself: value-free 5-point stencil with an even line length whose lines start at phase 0, no ghost columns
+bool kk_sweep_apply_ok(kk_ctx ctx, const kk_sparse_dev& M, int64_t ld) {
+    return ctx->panel_apply && ctx->spmv_dia && ctx->spmv_dia_const && !kk_sharded(ctx) && !ctx->allreduce && M.format == 0 && M.dia_D > 0 && M.dia_const && M.dia_pts == 5 &&
+           (M.dia_D & 1) == 0 && M.dia_phase == 0 && M.n_ghost == 0 && !M.halo && !M.plan && M.nrows * 8 < ((int64_t)1 << 31) && M.dia_D < ((int64_t)1 << 31) &&
+           kk_mgs_panel_eligible(ctx, ld) &&
+           // (vectors of at most KK_PANEL_NVMID grid-rows per block: the 16-row instantiation has no registers left for the apply's operands)
+           (kk_dec_ld(ctx, ld) + (int64_t)ctx->num_cus * KK_PANEL_DT * 2 - 1) / ((int64_t)ctx->num_cus * KK_PANEL_DT * 2) <= KK_PANEL_NVMID;
 }
 
 template <int NV, int P>
@@ -732,7 +785,8 @@ int kk_mgs_panel_width(kk_ctx ctx, int64_t ld_local, bool strict) {
 }
 
 int kk_launch_mgs_panel(kk_ctx ctx, const double* V, int64_t ld, int m, int nsweeps, double* w, const double* carry_q,
-                        const double* carry_s, double* out_s, int out_stride, double* nrm_out3, bool normalize_w, bool strict) {
+                        const double* carry_s, double* out_s, int out_stride, double* nrm_out3, bool normalize_w, bool strict,
+                        const kk_sweep_apply* apply) {
     // (the register tile is chosen for the longest shard of the slab: the kernel itself works out from its own ld how many of the
     // NV rows per lane exist locally -- the rest read as zeros)
     const int64_t ld_dec = kk_dec_ld(ctx, ld);
@@ -763,18 +817,27 @@ int kk_launch_mgs_panel(kk_ctx ctx, const double* V, int64_t ld, int m, int nswe
     double* ok_out = ctx->ws + WS_SCAL + SC_PERSIST_OK;
     kk_xs_dev xs = kk_xs_launch_args(ctx, (unsigned)((m * nsweeps + P - 1) / P) + (nrm_out3 ? 1u : 0u));   // cross-rank reductions of this launch (row-sharded context)
     long long timeout_ticks = kk_persist_timeout_ticks(ctx, ld, m * nsweeps, xs.world > 0);
+    panel_apply_args ap = panel_apply_args();
+    const bool do_apply = apply && apply->on && !lag && !carry_q && nv <= KK_PANEL_NVMID;
+    KK_CHECK(!(apply && apply->on) || do_apply, KK_ERR_UNSUPPORTED, "kk_launch_mgs_panel: the requested in-kernel apply is not available for this launch (internal error)");
+    if (do_apply) {
+        ap.x = apply->x; ap.xs_dev = apply->xs_dev; ap.nrows = apply->M->nrows;
+        for (int q = 0; q < 9; ++q) ap.cst.c[q] = apply->M->dia_c[q];
+        ap.cst.phase = apply->M->dia_phase; ap.cst.D = apply->M->dia_D;
+        ++ctx->panel_apply_launches;
+    }
     void* args[] = {(void*)&V, (void*)&ld, (void*)&m, (void*)&nsweeps, (void*)&w, (void*)&carry_q, (void*)&carry_s,
                     (void*)&out_s, (void*)&out_stride, (void*)&nrm_out3, (void*)&sync, (void*)&err, (void*)&fault,
-                    (void*)&ebase, (void*)&normalize, (void*)&ok_out, (void*)&token, (void*)&xs, (void*)&timeout_ticks};
+                    (void*)&ebase, (void*)&normalize, (void*)&ok_out, (void*)&token, (void*)&xs, (void*)&timeout_ticks, (void*)&ap};
     kk_prof_scope ps(ctx, "k_mgs_panel");
     if (lag) {
         if (nvl <= 4) return launch_panel_lag_inst<4, 2>(ctx, args);
         if (nvl <= 6) return launch_panel_lag_inst<6, 2>(ctx, args);
         return launch_panel_lag_inst<8, 2>(ctx, args);
     }
-    if (nv <= 4) return P >= 3 ? launch_panel_inst<4, 3>(ctx, args) : (P == 2 ? launch_panel_inst<4, 2>(ctx, args) : launch_panel_inst<4, 1>(ctx, args));
-    if (nv <= KK_PANEL_NVMID) return P >= 2 ? launch_panel_inst<KK_PANEL_NVMID, 2>(ctx, args) : launch_panel_inst<KK_PANEL_NVMID, 1>(ctx, args);
-    if (nv <= 16) return launch_panel_inst<16, 1>(ctx, args);
+    if (nv <= 4) return P >= 3 ? launch_panel_inst<4, 3>(ctx, args, do_apply) : (P == 2 ? launch_panel_inst<4, 2>(ctx, args, do_apply) : launch_panel_inst<4, 1>(ctx, args, do_apply));
+    if (nv <= KK_PANEL_NVMID) return P >= 2 ? launch_panel_inst<KK_PANEL_NVMID, 2>(ctx, args, do_apply) : launch_panel_inst<KK_PANEL_NVMID, 1>(ctx, args, do_apply);
+    if (nv <= 16) return launch_panel_inst<16, 1>(ctx, args, false);
     kk_set_error("kk_launch_mgs_panel: vector of %lld rows does not fit two register-resident panels", (long long)ld);
     return KK_ERR_UNSUPPORTED;
 }

@@ -143,7 +143,7 @@ __device__ __forceinline__ d2 dia_pair(const double* __restrict__ x, int64_t idx
 }
 // CONST: constant-coefficient stencil (kk_sparse_dev::dia_const) -- the coefficient of slot q is cst.c[q] wherever the
 // neighbour sits on the same grid line, 0 where a +-1 shift would wrap to the next line; no diagonal is read at all.
-struct dia_cst { double c[9]; int64_t phase, D; };
+// (struct dia_cst {c[9], phase, D}: kk_internal.h -- shared with the sweep kernels that apply the stencil themselves)
 // ALIGNED (5-point stencils with an EVEN far offset D, vectors below 4 GB): the load count per row pair drops from eight (two
 // 16-byte + six 8-byte) to four 16-byte ones --
 //   * x[row +- D], x[row + 1 +- D] are ONE aligned pair each (row and D even);

@@ -92,10 +92,21 @@ KK_API int kk_arnoldi_initialize(kk_op op, kk_basis b, int c0, kk_orth_t orth, d
 // (alpha, beta), returns to the caller and re-enters.  r itself is NOT modified; the next expand
 // call normalises it in place (after this read) and skips its SpMV if (op, c0, k, beta) match.
 // Bit-identical to the non-speculative order: r*(1/beta) is formed with the same operands.
-static int speculate_next(kk_op op, kk_basis b, int c0, int k_next, int dot_mode, bool with_prev, double beta_host, double* dot_out = nullptr) {
+static int speculate_next(kk_op op, kk_basis b, int c0, int k_next, int dot_mode, bool with_prev, double beta_host, double* dot_out = nullptr,
+                          bool inside_sweep = false /* the sweep launch that follows forms A v itself (c->sweep_apply): nothing is launched here */) {
     kk_ctx c = b->ctx;
     b->spec_valid = false;
     if (!c->speculate || c0 + k_next + 2 > b->cap || k_next + 1 > KK_MAX_M) return KK_OK;
+    if (inside_sweep) {
+        c->sweep_apply.on = true; c->sweep_apply.M = &op->A; c->sweep_apply.x = b->col(c0 + k_next);
+        c->sweep_apply.xs_dev = c->persist_norm_done ? SCP(c, SC_XS) : SCP(c, SC_INVNRM);
+        b->spec_dot_ptr = nullptr;
+        b->spec_valid = true; b->spec_op = op; b->spec_c0 = c0; b->spec_k = k_next; b->spec_dot_mode = dot_mode;
+        b->spec_beta = beta_host;
+        c->spec_owner = b;
+        b->spec_gen = c->foreign_gen;
+        return KK_OK;
+    }
     kk_spmv_fuse f;
     // a sweep that went through a normalising persistent launch left r / |r| in the column (or r itself when the norm was
     // zero): the kernel wrote the factor that is still to be applied -- 1 or 1/|r| -- to SC_XS
@@ -127,6 +138,17 @@ static int spec_take(kk_op op, kk_basis b, int c0, int k, int dot_mode, double b
 // The host waits only for the read-backs queued so far (event), NOT for the speculative SpMV that
 // is enqueued behind them -- that one keeps the GPU busy during the host round trip.
 static int la_enqueue(kk_op op, kk_basis b, int c0, int j, int nsweeps, bool lanczos_carry);
+// the run-ahead of an Arnoldi step (la_enqueue below) will go through the panel kernel, which can apply this operator itself: same conditions as
+// la_enqueue's own + kk_sweep_apply_ok
+static bool la_apply_inside(kk_op op, kk_basis b, int c0, int j, int nsweeps) {
+    kk_ctx c = b->ctx;
+    const int m = j + 1;
+    if (!c->lookahead || !c->fold_scale || !c->speculate || !c->persist_norm_done || kk_sharded(c) || c->persist_skip > 0) return false;
+    if (m > KK_MAX_M || c0 + j + 3 > b->cap || c0 + j + 2 > b->cap) return false;
+    if (!kk_mgs_panel_eligible(c, b->ld) || kk_mgs_lowsync(c, b->ld, m)) return false;
+    const int stride = nsweeps > 1 ? (int)(WS_G - WS_S) : KK_MAX_M;
+    return stride >= m && kk_sweep_apply_ok(c, op->A, b->ld);
+}
 int fetch_mark(kk_ctx c) {
     KK_HIP(hipEventRecord(c->ev_fetch, c->stream));
     return KK_OK;
@@ -139,9 +161,14 @@ int final_sync(kk_ctx c) {
     if (c->spec_req.active) {
         c->spec_req.active = false;
         KK_TRY(fetch_mark(c));
-        KK_TRY(speculate_next(c->spec_req.op, c->spec_req.b, c->spec_req.c0, c->spec_req.k_next, 0, false, 0.0));
+        const bool inside = c->spec_req.la_nsweeps > 0 && la_apply_inside(c->spec_req.op, c->spec_req.b, c->spec_req.c0, c->spec_req.k_next, c->spec_req.la_nsweeps);
+        KK_TRY(speculate_next(c->spec_req.op, c->spec_req.b, c->spec_req.c0, c->spec_req.k_next, 0, false, 0.0, nullptr, inside));
         if (c->spec_req.la_nsweeps > 0)   // Arnoldi with a persistent MGS / MGS2 sweep: the whole next step behind its apply (see la_enqueue)
             KK_TRY(la_enqueue(c->spec_req.op, c->spec_req.b, c->spec_req.c0, c->spec_req.k_next, c->spec_req.la_nsweeps, false));
+        if (c->sweep_apply.on) {   // (la_enqueue declined after all: the apply goes out as its own launch -- nobody is left to consume the request)
+            c->sweep_apply.on = false;
+            KK_TRY(speculate_next(c->spec_req.op, c->spec_req.b, c->spec_req.c0, c->spec_req.k_next, 0, false, 0.0));
+        }
         return fetch_wait(c);
     }
     return stream_sync(c);
@@ -617,8 +644,12 @@ KK_API int kk_arnoldi_expand(kk_op op, kk_basis b, int c0, int k, kk_orth_t orth
     }
     if (la_hit) {
         // this step is in the stream (or done): enqueue the NEXT one behind it, then collect
-        KK_TRY(speculate_next(op, b, c0, k + 1, 0, false, 0.0));
+        KK_TRY(speculate_next(op, b, c0, k + 1, 0, false, 0.0, nullptr, la_apply_inside(op, b, c0, k + 1, la_sweeps)));
         KK_TRY(la_enqueue(op, b, c0, k + 1, la_sweeps, false));
+        if (c->sweep_apply.on) {   // (la_enqueue declined after all: the apply as its own launch)
+            c->sweep_apply.on = false;
+            KK_TRY(speculate_next(op, b, c0, k + 1, 0, false, 0.0));
+        }
         KK_HIP(hipEventSynchronize(c->ev_la[la_slot & 1]));
         bool redo = false;
         KK_TRY(persist_check_at(c, la_slot, la_token, &redo));

@@ -234,6 +234,20 @@ int pass_mgs_strict_sweeps(kk_ctx c, const double* V, int64_t ld, int m, int nsw
                            bool want_norm, int slot, const double* carry_q, const double* carry_s) {
     c->persist_norm_done = false;
     const bool panel = m > 0 && kk_mgs_panel_eligible(c, ld);   // short vectors: P basis vectors per grid reduction (P = 1 in strict mode)
+    // a pending "apply inside the sweep launch" request (run-ahead of an Arnoldi step, kk_krylov.hip): honoured by the panel kernel; on any other
+    // route the apply goes out as the separate launch it would have been
+    kk_sweep_apply ap = c->sweep_apply;
+    c->sweep_apply.on = false;
+    {
+        const int stride0 = nsweeps > 1 ? (int)(ws_s[1] - ws_s[0]) : KK_MAX_M;
+        const bool fused = ap.on && panel && c->persist_skip == 0 && stride0 >= m && !carry_q && !c->panel_lag && kk_sweep_apply_ok(c, *ap.M, ld);
+        if (ap.on && !fused) {
+            kk_spmv_fuse f;
+            f.xscale_dev = ap.xs_dev;
+            KK_TRY(kk_launch_spmv(c, *ap.M, ap.x, w, ld, f));
+            ap.on = false;
+        }
+    }
     if (panel || (m > 0 && kk_mgs_persist_eligible(c, ld, m, nsweeps))) {
         // both sweeps' coefficient areas must be addressable as out_s + sweep * stride
         const int stride = nsweeps > 1 ? (int)(ws_s[1] - ws_s[0]) : KK_MAX_M;
@@ -243,7 +257,7 @@ int pass_mgs_strict_sweeps(kk_ctx c, const double* V, int64_t ld, int m, int nsw
             const bool normalize = c->persist_norm_req && want_norm;
             if (panel)
                 KK_TRY(kk_launch_mgs_panel(c, V, ld, m, nsweeps, w, carry_q, carry_s, WSP(c, ws_s[0]), stride,
-                                           want_norm ? SCP(c, SC_NRM2) : nullptr, normalize, c->mgs_mode == 0));
+                                           want_norm ? SCP(c, SC_NRM2) : nullptr, normalize, c->mgs_mode == 0, ap.on ? &ap : nullptr));
             else
                 KK_TRY(kk_launch_mgs_persist(c, V, ld, m, nsweeps, w, carry_q, carry_s, WSP(c, ws_s[0]), stride,
                                              want_norm ? SCP(c, SC_NRM2) : nullptr, normalize));

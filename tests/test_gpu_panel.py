@@ -178,3 +178,49 @@ def test_bitwise_reproducible_and_identical_on_every_block(kk, pctx):
         outs.append((x.copy(), nrm, B[m].get().copy()))
     for o in outs[1:]:
         assert np.array_equal(o[0], outs[0][0]) and o[1] == outs[0][1] and np.array_equal(o[2], outs[0][2])
+
+
+@pytest.mark.parametrize("shape", [(2000, 160), (1000, 700), (130, 2400), (4000, 500)])
+@pytest.mark.parametrize("orth_name", ["mgs", "mgs2"])
+def test_panel_kernel_applies_the_stencil_itself(kk, ko, shape, orth_name):
+    """k_mgs_panel<.., APPLY> (round 6): the run-ahead of an Arnoldi step on a value-free 5-point stencil (even line length: BASELINE config 3's operator)
+    forms w = A v inside the sweep launch -- no separate apply, no store and re-load of w.  Same products in the same order as k_spmv_dia: every entry of
+    H and every basis vector BIT-identical to panel_apply = 0; the apply launches disappear from the steps that ran ahead (arnoldi.jl:242,
+    orthonormal.jl:414-439)"""
+    nx, ny = shape
+    n = nx * ny
+    A = ko.convection_diffusion_2d(nx, ny)
+    x0 = np.random.default_rng(3).random(n)
+    dev, ref = (kk.ModifiedGramSchmidt(), ko.MGS) if orth_name == "mgs" else (kk.ModifiedGramSchmidt2(), ko.MGS2)
+    steps = 14
+    c = kk.Context(0)
+    try:
+        if c.get_option("mgs_persist") == 0:
+            pytest.skip("persistent routes off on this device")
+        c.set_option("panel_min_rows", 0); c.set_option("fused_step", 0)
+        out = {}
+        for pa in (1, 0):
+            c.set_option("panel_apply", pa)
+            l0 = c.get_option("panel_apply_launches")
+            c.prof_reset(); c.prof_enable(1)
+            it = kk.ArnoldiIterator(kk.SparseOperator(A, c), x0, dev, capacity=steps + 3)
+            f = kk.initialize(it)
+            for _ in range(steps):
+                f = kk.expand_(it, f)
+            c.prof_enable(0)
+            out[pa] = (np.asarray(f.H, float).copy(), f.normres, f.V.to_numpy().copy(), int(c.get_option("panel_apply_launches") - l0), c.prof_get("k_spmv_dia")[1],
+                       c.prof_get("k_mgs_panel")[1])
+        c.set_option("panel_apply", 1)
+        assert out[1][3] >= steps - 2 and out[0][3] == 0, (out[1][3], out[0][3])         # every step that ran ahead applied the operator inside its sweep launch
+        assert out[1][4] <= out[0][4] - (steps - 2), (out[1][4], out[0][4])               # ... and those apply launches are gone
+        assert out[1][5] == out[0][5]
+        assert np.array_equal(out[1][0], out[0][0]) and out[1][1] == out[0][1] and np.array_equal(out[1][2], out[0][2])
+        oit = ko.ArnoldiIterator(A, x0.copy(), ref); of = ko.arnoldi_initialize(oit)
+        for _ in range(steps):
+            of = ko.arnoldi_expand(oit, of)
+        Ho = np.asarray(of.H, float)
+        tol = 1e-10 if orth_name == "mgs2" else 1e-7
+        assert np.max(np.abs(out[1][0] - Ho)) < tol * np.max(np.abs(Ho))
+        assert c.get_option("persist_timeouts") == 0
+    finally:
+        c.close()
