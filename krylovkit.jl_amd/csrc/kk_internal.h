@@ -226,6 +226,7 @@ struct kk_ctx_s {
                                        // 11.6, 500 k 11.1 vs 8.0, 1 M 8.3 vs 5.5 (profiles/r05_panel_sweep_par.jsonl)
     int panel_apply = 1;         // Arnoldi steps enqueued ahead on the panel kernel, value-free 5-point stencil (even line length, phase 0): the kernel forms w = A v itself
     kk_sweep_apply sweep_apply;  // ... the pending request (see kk_sweep_apply)
+    bool sweep_apply_fused = false;   // ... the last pass_mgs_strict_sweeps honoured one inside its launch (the work vector was never written by an apply of its own)
     int64_t panel_apply_launches = 0;   // diagnostics
     int xsync = 1;               // row-sharded context: persistent kernels with the in-kernel cross-rank reduction where the communicator offers it (0: RCCL all-reduce per inner-product batch, low-sync route)
     int mgs_persist = 1;         // strict MGS sweeps through the persistent register-resident kernel when the vector fits
@@ -313,6 +314,7 @@ struct kk_basis_s {
     int la_kind = 0;          // 0: persistent sweep (la_token), 1: projection-based Lanczos step (CGS2 / low-sync MGS2: la_orth, la_rode), 2: one-launch step (k_lanczos_fstep: la_token = its token)
     int la_orth = 0;
     bool la_rode = false;
+    bool la_inside = false;   // the launch enqueued ahead formed A v itself (k_mgs_panel<.., APPLY>): if it is lost, the apply has to be repeated too
     // residual column left NORMALISED by a fused expand! (persistent kernel, w / |w| written at commit): logically the column
     // still holds r = norm_beta * stored; the next expand! of the same factorization takes it as its new basis vector without
     // the scale pass, every other access multiplies it back first (norm_flush)

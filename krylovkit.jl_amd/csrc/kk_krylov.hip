@@ -213,6 +213,7 @@ static int la_enqueue(kk_op op, kk_basis b, int c0, int j, int nsweeps, bool lan
     if (!ahead_persistent) return KK_OK;   // (took the launch-per-vector route: results are simply not used ahead)
     KK_HIP(hipEventRecord(c->ev_la[slot & 1], c->stream));
     b->la_valid = true; b->la_k = j; b->la_slot = slot; b->la_token = ahead_token; b->la_nsweeps = nsweeps; b->la_kind = 0;
+    b->la_inside = c->sweep_apply_fused;
     return KK_OK;
 }
 
@@ -666,6 +667,10 @@ KK_API int kk_arnoldi_expand(kk_op op, kk_basis b, int c0, int k, kk_orth_t orth
         b->spec_valid = false; b->la_valid = false;
         KK_TRY(stream_sync(c));
         c->persist_norm_done = false;
+        if (b->la_inside) {   // ... unless the lost launch was to form A v itself (k_mgs_panel<.., APPLY>): then nothing has written w yet
+            kk_spmv_fuse f;
+            KK_TRY(kk_launch_spmv(c, op->A, v, w, b->ld, f));
+        }
     }
     // ask orth_run to enqueue the NEXT step's SpMV right before its final host sync (non-IR variants)
     c->spec_req.active = (orth != KK_CGSIR && orth != KK_MGSIR);

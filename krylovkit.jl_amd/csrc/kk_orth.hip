@@ -238,6 +238,7 @@ int pass_mgs_strict_sweeps(kk_ctx c, const double* V, int64_t ld, int m, int nsw
     // route the apply goes out as the separate launch it would have been
     kk_sweep_apply ap = c->sweep_apply;
     c->sweep_apply.on = false;
+    c->sweep_apply_fused = false;
     {
         const int stride0 = nsweeps > 1 ? (int)(ws_s[1] - ws_s[0]) : KK_MAX_M;
         const bool fused = ap.on && panel && c->persist_skip == 0 && stride0 >= m && !carry_q && !c->panel_lag && kk_sweep_apply_ok(c, *ap.M, ld);
@@ -255,10 +256,11 @@ int pass_mgs_strict_sweeps(kk_ctx c, const double* V, int64_t ld, int m, int nsw
             --c->persist_skip;   // recovering from a grid-barrier timeout: this sweep takes the launch-per-vector route (same order)
         } else if (stride >= m) {
             const bool normalize = c->persist_norm_req && want_norm;
-            if (panel)
+            if (panel) {
                 KK_TRY(kk_launch_mgs_panel(c, V, ld, m, nsweeps, w, carry_q, carry_s, WSP(c, ws_s[0]), stride,
                                            want_norm ? SCP(c, SC_NRM2) : nullptr, normalize, c->mgs_mode == 0, ap.on ? &ap : nullptr));
-            else
+                c->sweep_apply_fused = ap.on;
+            } else
                 KK_TRY(kk_launch_mgs_persist(c, V, ld, m, nsweeps, w, carry_q, carry_s, WSP(c, ws_s[0]), stride,
                                              want_norm ? SCP(c, SC_NRM2) : nullptr, normalize));
             c->persist_pending = true;

@@ -224,3 +224,29 @@ def test_panel_kernel_applies_the_stencil_itself(kk, ko, shape, orth_name):
         assert c.get_option("persist_timeouts") == 0
     finally:
         c.close()
+
+
+def test_lost_launch_that_was_to_apply_the_stencil_itself_is_repeated_with_its_apply(kk, ko):
+    """a run-ahead launch of k_mgs_panel<.., APPLY> that gives up (test hook) has written nothing -- not even w = A v, which no other launch formed:
+    the recovery has to repeat the apply as well as the sweeps (kk_arnoldi_expand, `la_inside`)"""
+    nx, ny = 600, 500
+    A = ko.convection_diffusion_2d(nx, ny)
+    x0 = np.random.default_rng(8).random(nx * ny)
+    c = kk.Context(0)
+    try:
+        if c.get_option("mgs_persist") == 0:
+            pytest.skip("persistent routes off on this device")
+        c.set_option("panel_min_rows", 0); c.set_option("fused_step", 0); c.set_option("persist_timeout_ms", 20)
+        it = kk.ArnoldiIterator(kk.SparseOperator(A, c), x0, kk.ModifiedGramSchmidt2(), capacity=22)
+        f = kk.initialize(it)
+        oit = ko.ArnoldiIterator(A, x0.copy(), ko.MGS2); of = ko.arnoldi_initialize(oit)
+        for i in range(16):
+            if i in (5, 11):
+                c.set_option("persist_fault", 1)     # the NEXT persistent launch -- the one enqueued ahead during this call -- gives up
+            f = kk.expand_(it, f); of = ko.arnoldi_expand(oit, of)
+        assert c.get_option("persist_timeouts") == 2 and c.get_option("panel_apply_launches") >= 8
+        assert np.max(np.abs(np.asarray(f.H) - np.asarray(of.H))) < 1e-10 * np.max(np.abs(of.H))
+        V = f.V.to_numpy()
+        assert np.max(np.abs(V.T @ V - np.eye(V.shape[1]))) < 1e-12
+    finally:
+        c.close()
