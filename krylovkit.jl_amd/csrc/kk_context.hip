@@ -231,6 +231,8 @@ KK_API int kk_ctx_set_option(kk_ctx c, const char* key, double value) {
         c->spmv_dia_const = value != 0;
     } else if (!strcmp(key, "spmv_dia_aligned")) {
         c->spmv_dia_aligned = value != 0;
+    } else if (!strcmp(key, "persist_apply")) {
+        c->persist_apply = value != 0;
     } else if (!strcmp(key, "panel_apply")) {
         c->panel_apply = value != 0;
     } else if (!strcmp(key, "fused_step")) {
@@ -364,6 +366,8 @@ KK_API int kk_ctx_get_option(kk_ctx c, const char* key, double* value) {
     else if (!strcmp(key, "spmv_dia")) *value = c->spmv_dia;
     else if (!strcmp(key, "spmv_dia_const")) *value = c->spmv_dia_const;
     else if (!strcmp(key, "spmv_dia_aligned")) *value = c->spmv_dia_aligned;
+    else if (!strcmp(key, "persist_apply")) *value = c->persist_apply;
+    else if (!strcmp(key, "persist_apply_launches")) *value = (double)c->persist_apply_launches;
     else if (!strcmp(key, "panel_apply")) *value = c->panel_apply;
     else if (!strcmp(key, "panel_apply_launches")) *value = (double)c->panel_apply_launches;
     else if (!strcmp(key, "fused_step")) *value = c->fused_step;

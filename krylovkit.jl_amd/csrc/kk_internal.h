@@ -138,6 +138,22 @@ struct kk_comm_s {
     double ar_us = 0;                           // one RCCL all-reduce of 8 doubles on the context stream, measured by the hand-shake (slowest rank)
 };
 
+// epilogue / fusion description of an SpMV launch
+struct kk_spmv_fuse {
+    double a1 = 1.0;                 // y = a1*(A x)*xscale + a0*x - bprev*vprev
+    double a0 = 0.0;
+    const double* xscale_dev = nullptr;  // optional device scalar multiplying x (e.g. 1/alpha)
+    const double* vprev = nullptr;   // optional vector subtracted with weight bprev
+    double bprev = 0.0;
+    const double* bprev_dev = nullptr;   // if set: weight = *bprev_dev (device scalar)
+    int dot_mode = 0;                // 0 none, 1 = <x, A x> before subtracting vprev (CGS order,
+                                     // lanczos.jl:298), 2 = <x, y> after (MGS order, lanczos.jl:308),
+                                     // 3 = <dot_vec, y> (BiCGStab <r_shadow, A p>)
+    const double* dot_vec = nullptr; // third vector of dot_mode 3
+    double* dot_out = nullptr;       // device scalar receiving the dot (required when dot_mode != 0)
+    double* nrm_out = nullptr;       // optional: device triple receiving |y|^2, sqrt, 1/sqrt
+};
+
 // constant-coefficient grid stencil as the kernels take it: coefficient of diagonal q, position of row 0 inside its grid line, line length
 struct dia_cst { double c[9]; int64_t phase, D; };
 // A sparse apply that the NEXT persistent sweep launch performs itself (round 6: k_mgs_panel<.., APPLY> forms w = (A x) * xs in its registers instead of
@@ -146,7 +162,7 @@ struct kk_sweep_apply {
     bool on = false;
     const struct kk_sparse_dev* M = nullptr;
     const double* x = nullptr;
-    const double* xs_dev = nullptr;
+    kk_spmv_fuse f;   // the apply as the separate launch would have run it (scale, - beta v_prev, alpha dot): what the sweep kernel does instead -- or, on a route that cannot, kk_launch_spmv
 };
 
 struct kk_ctx_s {
@@ -224,6 +240,12 @@ struct kk_ctx_s {
                                        // reduction per panel cost ~6 us); since the values of a reduction are swept by as many waves at once (round 5) the panel
                                        // kernel wins from ~0.2 M rows: Arnoldi MGS2 cycle of 60, 128 k rows 11.7 vs 13.1 k it/s (projection pair ahead), 250 k 12.3 vs
                                        // 11.6, 500 k 11.1 vs 8.0, 1 M 8.3 vs 5.5 (profiles/r05_panel_sweep_par.jsonl)
+    int persist_apply = 0;       // Lanczos steps on the register-resident strict kernel, value-free 5-point stencil: the kernel forms w = A v - beta v_prev and the alpha dot itself.
+                                 // OFF by default: measured SLOWER on the headline sweep -- 1140-1158 vs 1281-1283 it/s, the launch grows from 0.718 to 0.858 ms
+                                 // (profiles/r06_persist_apply_ab.txt): with the grid-strided row ownership of this kernel the ten batches of apply loads are ten
+                                 // exposed memory round trips at the head of every launch, and the instantiation spills 17 registers (2 without); the same idea
+                                 // on the panel kernel, whose blocks own contiguous rows, is a gain (panel_apply).  Kept, tested, as the record of the experiment
+    int64_t persist_apply_launches = 0;   // diagnostics
     int panel_apply = 1;         // Arnoldi steps enqueued ahead on the panel kernel, value-free 5-point stencil (even line length, phase 0): the kernel forms w = A v itself
     kk_sweep_apply sweep_apply;  // ... the pending request (see kk_sweep_apply)
     bool sweep_apply_fused = false;   // ... the last pass_mgs_strict_sweeps honoured one inside its launch (the work vector was never written by an apply of its own)
@@ -447,22 +469,6 @@ struct kk_coef {
     double v[KK_MAX_M];
 };
 
-// epilogue / fusion description of an SpMV launch
-struct kk_spmv_fuse {
-    double a1 = 1.0;                 // y = a1*(A x)*xscale + a0*x - bprev*vprev
-    double a0 = 0.0;
-    const double* xscale_dev = nullptr;  // optional device scalar multiplying x (e.g. 1/alpha)
-    const double* vprev = nullptr;   // optional vector subtracted with weight bprev
-    double bprev = 0.0;
-    const double* bprev_dev = nullptr;   // if set: weight = *bprev_dev (device scalar)
-    int dot_mode = 0;                // 0 none, 1 = <x, A x> before subtracting vprev (CGS order,
-                                     // lanczos.jl:298), 2 = <x, y> after (MGS order, lanczos.jl:308),
-                                     // 3 = <dot_vec, y> (BiCGStab <r_shadow, A p>)
-    const double* dot_vec = nullptr; // third vector of dot_mode 3
-    double* dot_out = nullptr;       // device scalar receiving the dot (required when dot_mode != 0)
-    double* nrm_out = nullptr;       // optional: device triple receiving |y|^2, sqrt, 1/sqrt
-};
-
 int kk_launch_spmv(kk_ctx ctx, const kk_sparse_dev& M, const double* x, double* y, int64_t ld_y_rows,
                    const kk_spmv_fuse& f);
 int kk_launch_dot(kk_ctx ctx, const double* x, const double* y, int64_t ld, double* out);
@@ -625,7 +631,8 @@ static inline bool kk_mgs_lowsync(kk_ctx ctx, int64_t ld_local, int m) {
     return true;
 }
 int kk_launch_mgs_persist(kk_ctx ctx, const double* V, int64_t ld, int m, int nsweeps, double* w, const double* carry_q,
-                          const double* carry_s, double* out_s, int out_stride, double* nrm_out3, bool normalize_w);
+                          const double* carry_s, double* out_s, int out_stride, double* nrm_out3, bool normalize_w, const kk_sweep_apply* apply = nullptr);
+bool kk_sweep_apply_ok_persist(kk_ctx ctx, const kk_sparse_dev& M, int64_t ld, int m);   // can k_mgs_persist form w = A v - beta v_prev (+ the alpha dot) itself?
 int64_t kk_mgs_persist_capacity(kk_ctx ctx);
 // the kernel's own test for the normalised commit, on the host's copy of |w|
 static inline bool kk_persist_norm_applies(double nrm) { return nrm > 0.0 && 1.0 / nrm <= 1.79769313486231570815e308; }

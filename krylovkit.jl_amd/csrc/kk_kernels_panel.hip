@@ -821,7 +821,7 @@ int kk_launch_mgs_panel(kk_ctx ctx, const double* V, int64_t ld, int m, int nswe
     const bool do_apply = apply && apply->on && !lag && !carry_q && nv <= KK_PANEL_NVMID;
     KK_CHECK(!(apply && apply->on) || do_apply, KK_ERR_UNSUPPORTED, "kk_launch_mgs_panel: the requested in-kernel apply is not available for this launch (internal error)");
     if (do_apply) {
-        ap.x = apply->x; ap.xs_dev = apply->xs_dev; ap.nrows = apply->M->nrows;
+        ap.x = apply->x; ap.xs_dev = apply->f.xscale_dev; ap.nrows = apply->M->nrows;
         for (int q = 0; q < 9; ++q) ap.cst.c[q] = apply->M->dia_c[q];
         ap.cst.phase = apply->M->dia_phase; ap.cst.D = apply->M->dia_D;
         ++ctx->panel_apply_launches;

@@ -233,13 +233,20 @@ __device__ __forceinline__ void persist_step(d2 (&wr)[NV], d2 (&qk)[NR > 0 ? NR 
 // Every step has the same shape -- pending axpy with (q_prev, s_prev), then the inner product with q_next -- so that the
 // work vector stays in ONE register set through the loop; a step with nothing pending (the first one without a carry)
 // runs the axpy with s_prev = 0 against a column of V.
-template <int NV, int NL, int NR, int PT, bool NTPREV, bool XS = false>
+// APPLY (round 6): the work vector is not loaded but FORMED -- the Lanczos step's w = (A v) * xs - beta v_prev for a value-free 5-point grid stencil
+// (even line length, lines starting at phase 0: BASELINE config 2's operator) with alpha0 = <v, w> summed by one more grid reduction (index -1, the
+// other granule set than step 0's) and handed to the sweep as its pending coefficient: the apply launch, its 8 N bytes of store, this kernel's 8 N
+// bytes of load and the launch gap between the two go (lanczos.jl:306-310 + orthonormal.jl:414-439 in one launch).  w has the bits of
+// k_spmv_dia / k_spmv_dia_sw; alpha0 is summed in another order (to rounding).
+struct persist_apply_args { const double* x; const double* vprev; const double* xs_dev; const double* bprev_dev; double bprev; double* alpha_out; int64_t nrows; dia_cst cst; };
+template <int NV, int NL, int NR, int PT, bool NTPREV, bool XS = false, bool APPLY = false>
 __global__ __launch_bounds__(PT) void k_mgs_persist(const double* __restrict__ V, int64_t ld, int m, int nsweeps,
                                                     double* __restrict__ w, const double* __restrict__ carry_q,
                                                     const double* __restrict__ carry_s, double* __restrict__ out_s,
                                                     int out_stride, double* __restrict__ nrm_out3,
                                                     char* __restrict__ sync, int* __restrict__ err, int fault, unsigned gstride,
-                                                    unsigned ebase, int normalize, double* __restrict__ ok_out, double token, kk_xs_dev xs, long long timeout_ticks) {
+                                                    unsigned ebase, int normalize, double* __restrict__ ok_out, double token, kk_xs_dev xs, long long timeout_ticks,
+                                                    persist_apply_args ap) {
     __shared__ double sm[PT / 64];
     extern __shared__ d2 park[];   // NL * PT double2 (dynamic): the parked grid-rows of the current basis vector
     if (fault == 1 && blockIdx.x == 0) {   // test hook (option "persist_fault"): block 0 behaves like a block whose spin ran out
@@ -255,10 +262,75 @@ __global__ __launch_bounds__(PT) void k_mgs_persist(const double* __restrict__ V
     d2* lq = park + threadIdx.x;
     const __amdgpu_buffer_rsrc_t rw = col_rsrc(w, ld);
     d2 wr[NV];
-#pragma unroll
-    for (int i = 0; i < NV; ++i) wr[i] = bload(rw, voff, (unsigned)i * sbytes, false);
     const double* qp = carry_q ? carry_q : V;   // nothing pending: s_prev = 0 against a (finite) basis column
-    double sp = carry_q ? *carry_s : 0.0;
+    double sp = 0.0;
+    if (APPLY) {
+        // grid-row i of this thread: rows i * srows + r0, r0 = (block * PT + thread) * 2 (the ownership of the loads this replaces); four grid-rows at a
+        // time: centre pair, the two far pairs (aligned: rows and D are even), the two single neighbours, the v_prev pair -- all loads first
+        // (branch-free: an index outside the operator reads x[0] and is replaced by 0), then the products in the slot order -D, -1, 0, +1, +D
+        const double* __restrict__ x = ap.x;
+        const double* __restrict__ vp = ap.vprev;
+        const int64_t nr = ap.nrows, D = ap.cst.D;
+        const int64_t srows = (int64_t)gridDim.x * PT * 2, r0 = ((int64_t)blockIdx.x * PT + threadIdx.x) * 2;
+        const double xsv = ap.xs_dev ? *ap.xs_dev : 1.0;
+        const double bp = ap.bprev_dev ? *ap.bprev_dev : ap.bprev;
+        const double c0 = ap.cst.c[0], c1 = ap.cst.c[1], c2 = ap.cst.c[2], c3 = ap.cst.c[3], c4 = ap.cst.c[4];
+        double dacc = 0.0;
+#pragma unroll
+        for (int i0 = 0; i0 < NV; i0 += 4) {
+            d2 xc[4], xm[4], xq[4], pv[4];
+            double xl[4], xr[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (i0 + u < NV) {
+                    const int64_t row = (int64_t)(i0 + u) * srows + r0;
+                    const bool in = row < nr;
+                    const int64_t rc = in ? row : 0;
+                    const bool okm = in && rc >= D, okp = in && rc + D < nr, okl = in && rc >= 1, okr = in && rc + 2 < nr;
+                    xc[u] = ld2(x + rc);
+                    pv[u] = ld2s(vp + rc);
+                    const d2 a = ld2(x + (okm ? rc - D : 0)), b = ld2(x + (okp ? rc + D : 0));
+                    const double l = x[okl ? rc - 1 : 0], r = x[okr ? rc + 2 : 0];
+                    xm[u] = d2{okm ? a.x : 0.0, okm ? a.y : 0.0};
+                    xq[u] = d2{okp ? b.x : 0.0, (okp && rc + D + 1 < nr) ? b.y : 0.0};
+                    xl[u] = okl ? l : 0.0; xr[u] = okr ? r : 0.0;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (i0 + u < NV) {
+                    const int64_t row = (int64_t)(i0 + u) * srows + r0;
+                    const bool in = row < nr;
+                    const int64_t i0l = (int64_t)((unsigned)(in ? row : 0) % (unsigned)D);   // position of the pair's first row inside its grid line
+                    const double cw0 = i0l == 0 ? 0.0 : c1, ce1 = i0l + 2 == D ? 0.0 : c3;   // no -1 entry at position 0, no +1 entry at position D - 1
+                    double s0 = 0.0, s1 = 0.0;
+                    s0 = fma(c0, xm[u].x, s0); s1 = fma(c0, xm[u].y, s1);
+                    s0 = fma(cw0, xl[u], s0);  s1 = fma(c1, xc[u].x, s1);
+                    s0 = fma(c2, xc[u].x, s0); s1 = fma(c2, xc[u].y, s1);
+                    s0 = fma(c3, xc[u].y, s0); s1 = fma(ce1, xr[u], s1);
+                    s0 = fma(c4, xq[u].x, s0); s1 = fma(c4, xq[u].y, s1);
+                    const double t0 = s0 * xsv, t1 = s1 * xsv;
+                    d2 out{1.0 * t0, 1.0 * t1};
+                    const d2 xs2{xc[u].x * xsv, xc[u].y * xsv};
+                    out.x = fma(-bp, pv[u].x, out.x); out.y = fma(-bp, pv[u].y, out.y);
+                    if (row + 1 >= nr) out.y = 0.0;
+                    if (!in) out = d2{0.0, 0.0};
+                    dacc = fma(xs2.x, out.x, dacc); dacc = fma(xs2.y, out.y, dacc);   // alpha0 = <v, w> after the three-term part (lanczos.jl:308)
+                    wr[i0 + u] = out;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        double a0tot;
+        grid_publish<PT>(dacc, -1, ebase, sync, sm, gstride);
+        if (!grid_collect<PT, false>(-1, ebase, sync, err, sm, &a0tot, gstride, xs, timeout_ticks)) return;
+        if (blockIdx.x == 0 && threadIdx.x == 0) ap.alpha_out[0] = a0tot;
+        sp = a0tot;
+    } else {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) wr[i] = bload(rw, voff, (unsigned)i * sbytes, false);
+        sp = carry_q ? *carry_s : 0.0;
+    }
     const int nsteps = m * nsweeps;
     d2 qk[NR > 0 ? NR : 1];   // NR more grid-rows of the current basis vector parked in spare registers
     if (NL + NR > 0) {   // park the first q_prev (the carried vector, or the dummy that goes with s_prev = 0): every step then has ONE shape
@@ -408,15 +480,20 @@ bool kk_mgs_persist_eligible(kk_ctx ctx, int64_t ld_local, int m, int nsweeps) {
 template <int NV, int PT>
 struct persist_park { static constexpr int full = (160 * 1024 - 256) / (PT * 16); static constexpr int n = NV < full ? NV : full; };
 
-template <int NV, int NL, int NR, int PT, bool NT, bool XS>
+template <int NV, int NL, int NR, int PT, bool NT, bool XS, bool APPLY = false>
 static int launch_persist_inst2(kk_ctx ctx, void** args);
 template <int NV, int NL, int NR, int PT, bool NT>
-static int launch_persist_inst(kk_ctx ctx, void** args, bool xs_on) {
+static int launch_persist_inst(kk_ctx ctx, void** args, bool xs_on, bool apply = false) {
+    if (apply) {   // (the in-kernel apply exists for the default shape only: 512 threads, parked rows in LDS + registers, non-temporal second read, one rank)
+        if constexpr (PT == 512 && NT && NR > 0) return launch_persist_inst2<NV, NL, NR, PT, NT, false, true>(ctx, args);
+        kk_set_error("k_mgs_persist: in-kernel apply requested for an instantiation that has none (internal error)");
+        return KK_ERR_UNSUPPORTED;
+    }
     return xs_on ? launch_persist_inst2<NV, NL, NR, PT, NT, true>(ctx, args) : launch_persist_inst2<NV, NL, NR, PT, NT, false>(ctx, args);
 }
-template <int NV, int NL, int NR, int PT, bool NT, bool XS>
+template <int NV, int NL, int NR, int PT, bool NT, bool XS, bool APPLY>
 static int launch_persist_inst2(kk_ctx ctx, void** args) {
-    const void* fn = (const void*)k_mgs_persist<NV, NL, NR, PT, NT, XS>;
+    const void* fn = (const void*)k_mgs_persist<NV, NL, NR, PT, NT, XS, APPLY>;
     const size_t dyn = (size_t)NL * PT * sizeof(double) * 2;
     // the opt-in to more than 64 KB of dynamic LDS is a per-DEVICE attribute of the function: one call per instantiation and
     // device (a process may drive contexts on several GPUs), made with the context's device current
@@ -437,12 +514,12 @@ static int launch_persist_inst2(kk_ctx ctx, void** args) {
 #endif
 
 template <int NV, int PT>
-static int launch_persist(kk_ctx ctx, void** args, bool ntprev, bool xs_on) {
+static int launch_persist(kk_ctx ctx, void** args, bool ntprev, bool xs_on, bool apply = false) {
     constexpr int NL = persist_park<NV, PT>::n;
     // (256-thread blocks -- one wave per SIMD with the whole 512-register file -- were tried: w then takes 320 registers per
     // lane and 39 + 12 of 77 grid-rows can be parked, no more than the 27 of 39 here: the on-chip capacity is what it is)
     constexpr int NR = (PT == 512 && NV - NL > 0) ? (NV - NL < KK_PERSIST_NR ? NV - NL : KK_PERSIST_NR) : 0;
-    if (ctx->persist_lds == 2) return ntprev ? launch_persist_inst<NV, NL, NR, PT, true>(ctx, args, xs_on) : launch_persist_inst<NV, NL, NR, PT, false>(ctx, args, xs_on);
+    if (ctx->persist_lds == 2) return ntprev ? launch_persist_inst<NV, NL, NR, PT, true>(ctx, args, xs_on, apply) : launch_persist_inst<NV, NL, NR, PT, false>(ctx, args, xs_on);
     if (ctx->persist_lds) return ntprev ? launch_persist_inst<NV, NL, 0, PT, true>(ctx, args, xs_on) : launch_persist_inst<NV, NL, 0, PT, false>(ctx, args, xs_on);
     return ntprev ? launch_persist_inst<NV, 0, 0, PT, true>(ctx, args, xs_on) : launch_persist_inst<NV, 0, 0, PT, false>(ctx, args, xs_on);
 }
@@ -450,8 +527,18 @@ static int launch_persist(kk_ctx ctx, void** args, bool ntprev, bool xs_on) {
 // `normalize`: store w / |w| instead of w (needs nrm_out3; a zero norm leaves w unscaled -- kk_persist_norm_applies is the
 // host's copy of the kernel's test).  The completion token lands in the scalar workspace (SC_PERSIST_OK) and is checked by
 // persist_check after the read-back of the sweep's scalars.
+// k_mgs_persist can form the Lanczos step's w itself: value-free 5-point stencil with an even line length whose lines start at phase 0, no ghost
+// columns, one rank, the default kernel shape (512 threads, rows parked in LDS and registers, non-temporal second read), the vector on the strict kernel
+bool kk_sweep_apply_ok_persist(kk_ctx ctx, const kk_sparse_dev& M, int64_t ld, int m) {
+    return ctx->persist_apply && ctx->spmv_dia && ctx->spmv_dia_const && !kk_sharded(ctx) && !ctx->allreduce && !(ctx->comm && ctx->comm->active) && M.format == 0 &&
+           M.dia_D > 0 && M.dia_const && M.dia_pts == 5 && (M.dia_D & 1) == 0 && M.dia_phase == 0 && M.n_ghost == 0 && !M.halo && !M.plan &&
+           M.nrows * 8 < ((int64_t)1 << 31) && M.dia_D < ((int64_t)1 << 31) && ctx->persist_threads == 512 && ctx->persist_lds == 2 && ctx->persist_nt &&
+           !kk_mgs_panel_eligible(ctx, ld) && kk_mgs_persist_eligible(ctx, ld, m, 1) &&
+           (ld + (int64_t)ctx->num_cus * 512 * 2 - 1) / ((int64_t)ctx->num_cus * 512 * 2) > 24;   // (NV 32 / 40: the instantiations with rows parked in registers -- what 6 M rows and more take)
+}
+
 int kk_launch_mgs_persist(kk_ctx ctx, const double* V, int64_t ld, int m, int nsweeps, double* w, const double* carry_q,
-                          const double* carry_s, double* out_s, int out_stride, double* nrm_out3, bool normalize_w) {
+                          const double* carry_s, double* out_s, int out_stride, double* nrm_out3, bool normalize_w, const kk_sweep_apply* apply) {
     const int pt = ctx->persist_threads;
     const int nv = (int)((ld + (int64_t)ctx->num_cus * pt * 2 - 1) / ((int64_t)ctx->num_cus * pt * 2));
     KK_HIP(hipSetDevice(ctx->device));   // the attribute call and the cooperative launch act on the CURRENT device
@@ -460,16 +547,26 @@ int kk_launch_mgs_persist(kk_ctx ctx, const double* V, int64_t ld, int m, int ns
     // epochs: nsteps + 1 reductions, tags ebase + 1 .. ebase + nsteps + 1; unique over the life of the context, so that the
     // granule area never needs clearing (it is zeroed at creation and when the 32-bit epoch counter is about to wrap)
     const unsigned need = (unsigned)(m * nsweeps) + 2u;
-    if (ctx->persist_epoch > 0xffffffffu - need - 1u) {
+    if (ctx->persist_epoch > 0xffffffffu - need - 2u) {
         KK_HIP(hipMemsetAsync(sync, 0, (size_t)KK_SYNC_ERR_OFFSET, ctx->stream));
         ctx->persist_epoch = 0;
     }
-    unsigned ebase = ctx->persist_epoch;
-    ctx->persist_epoch += need;
+    const bool do_apply = apply && apply->on;
+    // (in-kernel apply: one more reduction, index -1 = tag ebase + 0, which must not be 0 -- the tag of the zeroed area: the launch's tags start one later)
+    unsigned ebase = ctx->persist_epoch + (do_apply ? 1u : 0u);
+    ctx->persist_epoch += need + (do_apply ? 1u : 0u);
     int fault = 0;
     if (ctx->persist_fault > 0) { --ctx->persist_fault; fault = 1; }
     int normalize = (normalize_w && nrm_out3) ? 1 : 0;
     unsigned gstride = ctx->persist_sync ? 16u : (unsigned)KK_SYNC_LINE;
+    persist_apply_args ap = persist_apply_args();
+    if (do_apply) {
+        ap.x = apply->x; ap.vprev = apply->f.vprev; ap.xs_dev = apply->f.xscale_dev; ap.bprev_dev = apply->f.bprev_dev; ap.bprev = apply->f.bprev;
+        ap.alpha_out = apply->f.dot_out; ap.nrows = apply->M->nrows;
+        for (int q = 0; q < 9; ++q) ap.cst.c[q] = apply->M->dia_c[q];
+        ap.cst.phase = apply->M->dia_phase; ap.cst.D = apply->M->dia_D;
+        ++ctx->persist_apply_launches;
+    }
     ctx->persist_token += 1.0;
     double token = ctx->persist_token;
     double* ok_out = ctx->ws + WS_SCAL + SC_PERSIST_OK;
@@ -478,7 +575,7 @@ int kk_launch_mgs_persist(kk_ctx ctx, const double* V, int64_t ld, int m, int ns
     long long timeout_ticks = kk_persist_timeout_ticks(ctx, ld, m * nsweeps, xs.world > 0);
     void* args[] = {(void*)&V, (void*)&ld, (void*)&m, (void*)&nsweeps, (void*)&w, (void*)&carry_q, (void*)&carry_s,
                     (void*)&out_s, (void*)&out_stride, (void*)&nrm_out3, (void*)&sync, (void*)&err, (void*)&fault, (void*)&gstride,
-                    (void*)&ebase, (void*)&normalize, (void*)&ok_out, (void*)&token, (void*)&xs, (void*)&timeout_ticks};
+                    (void*)&ebase, (void*)&normalize, (void*)&ok_out, (void*)&token, (void*)&xs, (void*)&timeout_ticks, (void*)&ap};
     const bool nt = ctx->persist_nt != 0;
     kk_prof_scope ps(ctx, "k_mgs_persist");
     if (pt == 1024) {
@@ -491,8 +588,8 @@ int kk_launch_mgs_persist(kk_ctx ctx, const double* V, int64_t ld, int m, int ns
         if (nv <= 8) return launch_persist<8, 512>(ctx, args, nt, xs.world > 0);
         if (nv <= 16) return launch_persist<16, 512>(ctx, args, nt, xs.world > 0);
         if (nv <= 24) return launch_persist<24, 512>(ctx, args, nt, xs.world > 0);
-        if (nv <= 32) return launch_persist<32, 512>(ctx, args, nt, xs.world > 0);
-        if (nv <= 40) return launch_persist<40, 512>(ctx, args, nt, xs.world > 0);
+        if (nv <= 32) return launch_persist<32, 512>(ctx, args, nt, xs.world > 0, do_apply);
+        if (nv <= 40) return launch_persist<40, 512>(ctx, args, nt, xs.world > 0, do_apply);
     }
     kk_set_error("kk_launch_mgs_persist: vector of %lld rows does not fit the register file", (long long)ld);
     return KK_ERR_UNSUPPORTED;

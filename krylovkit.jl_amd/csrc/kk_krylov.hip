@@ -98,9 +98,13 @@ static int speculate_next(kk_op op, kk_basis b, int c0, int k_next, int dot_mode
     b->spec_valid = false;
     if (!c->speculate || c0 + k_next + 2 > b->cap || k_next + 1 > KK_MAX_M) return KK_OK;
     if (inside_sweep) {
-        c->sweep_apply.on = true; c->sweep_apply.M = &op->A; c->sweep_apply.x = b->col(c0 + k_next);
-        c->sweep_apply.xs_dev = c->persist_norm_done ? SCP(c, SC_XS) : SCP(c, SC_INVNRM);
-        b->spec_dot_ptr = nullptr;
+        kk_spmv_fuse fi;
+        fi.xscale_dev = c->persist_norm_done ? SCP(c, SC_XS) : SCP(c, SC_INVNRM);
+        if (with_prev) { fi.vprev = b->col(c0 + k_next - 1); fi.bprev_dev = SCP(c, SC_NRM); }
+        fi.dot_mode = dot_mode;
+        fi.dot_out = dot_out ? dot_out : SCP(c, SC_SPECA);
+        c->sweep_apply.on = true; c->sweep_apply.M = &op->A; c->sweep_apply.x = b->col(c0 + k_next); c->sweep_apply.f = fi;
+        b->spec_dot_ptr = fi.dot_mode ? fi.dot_out : nullptr;
         b->spec_valid = true; b->spec_op = op; b->spec_c0 = c0; b->spec_k = k_next; b->spec_dot_mode = dot_mode;
         b->spec_beta = beta_host;
         c->spec_owner = b;
@@ -148,6 +152,15 @@ static bool la_apply_inside(kk_op op, kk_basis b, int c0, int j, int nsweeps) {
     if (!kk_mgs_panel_eligible(c, b->ld) || kk_mgs_lowsync(c, b->ld, m)) return false;
     const int stride = nsweeps > 1 ? (int)(WS_G - WS_S) : KK_MAX_M;
     return stride >= m && kk_sweep_apply_ok(c, op->A, b->ld);
+}
+// ... and of a Lanczos step through k_mgs_persist, which can form w = A v - beta v_prev and alpha0 itself (kk_sweep_apply_ok_persist)
+static bool la_apply_inside_lanczos(kk_op op, kk_basis b, int c0, int j) {
+    kk_ctx c = b->ctx;
+    const int m = j + 1;
+    if (!c->lookahead || !c->fold_scale || !c->speculate || !c->persist_norm_done || kk_sharded(c) || c->persist_skip > 0) return false;
+    if (m > KK_MAX_M || c0 + j + 3 > b->cap) return false;
+    if (kk_mgs_lowsync(c, b->ld, m)) return false;
+    return kk_sweep_apply_ok_persist(c, op->A, b->ld, m);
 }
 int fetch_mark(kk_ctx c) {
     KK_HIP(hipEventRecord(c->ev_fetch, c->stream));
@@ -382,15 +395,20 @@ KK_API int kk_lanczos_expand(kk_op op, kk_basis b, int c0, int k, kk_orth_t orth
     // V = push!(V, scale!!(r, 1/beta_old))   lanczos.jl:257
     if (v_ready) b->norm_col = -1;
     else KK_TRY(kk_launch_scal(c, v, ld, 1.0 / beta_old, nullptr));
-    if (!hit && !fs_route) {
+    // (strict MGS2 on the register-resident kernel, value-free stencil: the sweep launch forms w and alpha0 itself -- k_mgs_persist<.., APPLY>;
+    //  pass_mgs_strict_sweeps sends the apply out as its own launch on any route that cannot)
+    const bool apply_inside = !hit && !fs_route && strict_branch && a0_slot == SCP(c, SC_ALPHA0) && c->persist_skip == 0 && kk_sweep_apply_ok_persist(c, op->A, ld, m);
+    kk_spmv_fuse f_step;
+    f_step.vprev = vprev; f_step.bprev = beta_old;
+    f_step.dot_mode = cgs_order ? 1 : 2;
+    f_step.dot_out = a0_slot;
+    if (apply_inside) {
+        c->sweep_apply.on = true; c->sweep_apply.M = &op->A; c->sweep_apply.x = v; c->sweep_apply.f = f_step;
+    } else if (!hit && !fs_route) {
         // w = A v - beta_old v_prev with the fused alpha dot   lanczos.jl:297-299 / 306-308
-        kk_spmv_fuse f;
-        f.vprev = vprev; f.bprev = beta_old;
-        f.dot_mode = cgs_order ? 1 : 2;
-        f.dot_out = a0_slot;
         const bool prev_suspend = c->ar_suspend;
         if (sh_fused) c->ar_suspend = true;
-        const int st = kk_launch_spmv(c, op->A, v, w, ld, f);
+        const int st = kk_launch_spmv(c, op->A, v, w, ld, f_step);
         c->ar_suspend = prev_suspend;
         KK_TRY(st);
     }  // else: the previous expand already enqueued exactly this SpMV (speculate_next)
@@ -520,6 +538,7 @@ KK_API int kk_lanczos_expand(kk_op op, kk_basis b, int c0, int k, kk_orth_t orth
         // strict: w -= alpha0 v fused with the first dot of the sweep   lanczos.jl:329-334
         const int64_t offs[1] = {WS_S};
         int slot = 0;
+        bool inside_lost = la_hit && b->la_inside;   // the launch in question (this call's, or the one enqueued ahead) formed w and alpha0 itself
         for (int attempt = 0;; ++attempt) {
             const bool ahead = la_hit && attempt == 0;   // this step's sweep and read-back are in the stream already
             if (!ahead) {
@@ -527,6 +546,7 @@ KK_API int kk_lanczos_expand(kk_op op, kk_basis b, int c0, int k, kk_orth_t orth
                 const int st_sw = pass_mgs_strict_sweeps(c, V, ld, m, 1, w, offs, true, 0, v, a0_dev);
                 c->persist_norm_req = false;
                 KK_TRY(st_sw);
+                if (attempt == 0) inside_lost = c->sweep_apply_fused;   // (the launch was to form w and alpha0 itself: if it is lost, so are they)
                 if (!c->persist_pending) KK_TRY(ws_fetch_async(c, WS_SCAL, 1, 0));   // (the persistent route fetched the scalars already)
                 KK_TRY(fetch_mark(c));
                 slot = 0;
@@ -534,8 +554,13 @@ KK_API int kk_lanczos_expand(kk_op op, kk_basis b, int c0, int k, kk_orth_t orth
                 slot = la_slot;
             }
             if (attempt == 0 && (!kk_sharded(c) || kk_xs_on(c))) {   // (row-sharded: only when the sweep reduces over the ranks inside its launch)
-                KK_TRY(speculate_next(op, b, c0, k + 1, 2, true, 0.0, SCP(c, SC_ALPHA0)));   // |w| and 1/|w| are on the device; alpha0 straight to its slot
+                const bool inside = la_apply_inside_lanczos(op, b, c0, k + 1);
+                KK_TRY(speculate_next(op, b, c0, k + 1, 2, true, 0.0, SCP(c, SC_ALPHA0), inside));   // |w| and 1/|w| are on the device; alpha0 straight to its slot
                 KK_TRY(la_enqueue(op, b, c0, k + 1, 1, true));                                   // ... and, where it pays, the whole next step behind it
+                if (c->sweep_apply.on) {   // (la_enqueue declined after all: the apply as its own launch)
+                    c->sweep_apply.on = false;
+                    KK_TRY(speculate_next(op, b, c0, k + 1, 2, true, 0.0, SCP(c, SC_ALPHA0)));
+                }
             }
             if (ahead) KK_HIP(hipEventSynchronize(c->ev_la[slot & 1]));
             else KK_TRY(fetch_wait(c));
@@ -553,9 +578,15 @@ KK_API int kk_lanczos_expand(kk_op op, kk_basis b, int c0, int k, kk_orth_t orth
             // (the step enqueued ahead has replaced alpha0 on the device by its own: put this step's back -- it came home with
             // the read-back of the failed launch -- once the stream has run dry)
             KK_TRY(stream_sync(c));
-            const double a0_host = pin(c, WS_SCAL + SC_ALPHA0, slot)[0];
-            KK_HIP(hipMemcpyAsync(SCP(c, SC_ALPHA0), &a0_host, sizeof(double), hipMemcpyHostToDevice, c->stream));
-            KK_TRY(stream_sync(c));
+            if (inside_lost) {
+                // ... unless the lost launch was to form them itself (k_mgs_persist<.., APPLY>): then neither w nor alpha0 exists -- the repeated sweep is
+                // handed the apply again and, on the launch-per-vector route it takes now, sends it out as a launch of its own
+                c->sweep_apply.on = true; c->sweep_apply.M = &op->A; c->sweep_apply.x = v; c->sweep_apply.f = f_step;
+            } else {
+                const double a0_host = pin(c, WS_SCAL + SC_ALPHA0, slot)[0];
+                KK_HIP(hipMemcpyAsync(SCP(c, SC_ALPHA0), &a0_host, sizeof(double), hipMemcpyHostToDevice, c->stream));
+                KK_TRY(stream_sync(c));
+            }
         }
         a = pin(c, WS_SCAL + SC_ALPHA0, slot)[0] + pin(c, WS_S, slot)[m - 1];
         bt = pin(c, WS_SCAL + SC_NRM2, slot)[1];

@@ -241,11 +241,13 @@ int pass_mgs_strict_sweeps(kk_ctx c, const double* V, int64_t ld, int m, int nsw
     c->sweep_apply_fused = false;
     {
         const int stride0 = nsweeps > 1 ? (int)(ws_s[1] - ws_s[0]) : KK_MAX_M;
-        const bool fused = ap.on && panel && c->persist_skip == 0 && stride0 >= m && !carry_q && !c->panel_lag && kk_sweep_apply_ok(c, *ap.M, ld);
+        const bool plain = !ap.f.vprev && ap.f.dot_mode == 0 && !ap.f.nrm_out && ap.f.a0 == 0.0 && ap.f.a1 == 1.0;
+        const bool lanczos = ap.f.vprev && ap.f.dot_mode == 2 && !ap.f.nrm_out && ap.f.a0 == 0.0 && ap.f.a1 == 1.0 && carry_q == ap.x && ap.f.dot_out == carry_s && nsweeps == 1;
+        const bool fused = ap.on && c->persist_skip == 0 && stride0 >= m &&
+                           ((panel && plain && !carry_q && !c->panel_lag && kk_sweep_apply_ok(c, *ap.M, ld)) ||
+                            (!panel && lanczos && kk_sweep_apply_ok_persist(c, *ap.M, ld, m)));
         if (ap.on && !fused) {
-            kk_spmv_fuse f;
-            f.xscale_dev = ap.xs_dev;
-            KK_TRY(kk_launch_spmv(c, *ap.M, ap.x, w, ld, f));
+            KK_TRY(kk_launch_spmv(c, *ap.M, ap.x, w, ld, ap.f));
             ap.on = false;
         }
     }
@@ -260,9 +262,11 @@ int pass_mgs_strict_sweeps(kk_ctx c, const double* V, int64_t ld, int m, int nsw
                 KK_TRY(kk_launch_mgs_panel(c, V, ld, m, nsweeps, w, carry_q, carry_s, WSP(c, ws_s[0]), stride,
                                            want_norm ? SCP(c, SC_NRM2) : nullptr, normalize, c->mgs_mode == 0, ap.on ? &ap : nullptr));
                 c->sweep_apply_fused = ap.on;
-            } else
+            } else {
                 KK_TRY(kk_launch_mgs_persist(c, V, ld, m, nsweeps, w, carry_q, carry_s, WSP(c, ws_s[0]), stride,
-                                             want_norm ? SCP(c, SC_NRM2) : nullptr, normalize));
+                                             want_norm ? SCP(c, SC_NRM2) : nullptr, normalize, ap.on ? &ap : nullptr));
+                c->sweep_apply_fused = ap.on;
+            }
             c->persist_pending = true;
             c->persist_slot = slot;
             c->persist_check_token = c->persist_token;

@@ -439,3 +439,38 @@ def test_config5_blocklanczos_10M_parity_with_cpu_reference(kk, ctx, block_mode)
     # diagonal blocks M_j and sub-diagonal blocks B_j, entry by entry
     assert np.max(np.abs(Hg - Hc)) <= 1e-9 * scale, np.max(np.abs(Hg - Hc)) / scale
     assert abs(nR_g - out["norm_R"]) <= 1e-9 * out["norm_R"]
+
+
+def test_config2_lanczos_10M_apply_inside_the_persistent_kernel(kk, ctx):
+    """k_mgs_persist<.., APPLY> (round 6): at BASELINE config 2's size the strict MGS2 Lanczos step forms w = A v - beta v_prev and alpha0 = <v, w>
+    INSIDE the sweep launch (value-free stencil) -- no apply launch, no store and re-load of w.  Same w bits; alpha0 summed in another order: the
+    factorization equals the one with persist_apply = 0 to rounding.  And a launch that gives up (test hook) takes its apply with it: the
+    recovery repeats both (factorizations/lanczos.jl:250-336)"""
+    from bench import laplacian_rows, NX, NY
+    N, steps = NX * NY, 16
+    op = kk.SparseOperator(laplacian_rows(NX, NY, 0, NY), ctx, symmetric=True, via_csc=True)
+    V = kk.DeviceBasis(N, steps + 4, ctx)
+    x0 = kk.DeviceBasis(N, 1, ctx)
+    x0[0].rand_(3)
+    it = kk.LanczosIterator(op, x0[0], kk.ModifiedGramSchmidt2(), capacity=steps + 3)
+    out = {}
+    for mode in ("inside", "separate", "inside_fault"):
+        ctx.set_option("persist_apply", 0 if mode == "separate" else 1)
+        l0, t0 = ctx.get_option("persist_apply_launches"), ctx.get_option("persist_timeouts")
+        ctx.prof_reset(); ctx.prof_enable(1)
+        f = kk.initialize(it, V)
+        for i in range(steps):
+            if mode == "inside_fault" and i in (4, 9):
+                ctx.set_option("persist_fault", 1)
+            f = kk.expand_(it, f)
+        ctx.prof_enable(0)
+        out[mode] = (np.array(f.alphas), np.array(f.betas), int(ctx.get_option("persist_apply_launches") - l0), ctx.prof_get("k_spmv_dia")[1],
+                     int(ctx.get_option("persist_timeouts") - t0), _gram_offdiag_max(kk, V, steps))
+    ctx.set_option("persist_apply", 1)
+    a, s, ft = out["inside"], out["separate"], out["inside_fault"]
+    assert a[2] >= steps - 1 and s[2] == 0, (a[2], s[2])                         # every step's sweep launch applied the operator itself ...
+    assert a[3] <= s[3] - (steps - 1), (a[3], s[3])                              # ... and the apply launches are gone (initialize keeps its own)
+    rel = lambda x, y: float(np.max(np.abs(x - y) / np.abs(y)))
+    assert rel(a[0], s[0]) < 1e-12 and rel(a[1], s[1]) < 1e-12
+    assert ft[4] == 2 and rel(ft[0], s[0]) < 1e-12 and rel(ft[1], s[1]) < 1e-12  # two lost launches, each repeated WITH its apply
+    assert max(a[5], s[5], ft[5]) < 1e-12
