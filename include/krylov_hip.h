@@ -147,6 +147,9 @@ typedef enum {
  * "spmm_dia_al" (default 2: the sweeping multi-column apply of a value-free 5-point stencil with an even line length runs in its
  * aligned 16-byte form, 2 or 4 columns per wave; 0 = the 8-byte form; bit-identical), "spmm_dia_al_lines" (default 4: grid lines per
  * wave sweep of that form),
+ * "panel_apply" (default 1: the run-ahead of an Arnoldi step on the panel kernel hands the sparse apply of a value-free 5-point stencil with an even
+ * line length to the sweep launch itself -- one launch per step, w never stored and re-loaded; bit-identical to 0; "panel_apply_launches" counts),
+ * "persist_apply" (default 0: the same for the Lanczos step on the register-resident strict kernel -- exact, measured 11 % slower, kept as the record),
  * "fused_step" (default 1: a Lanczos expand! with CGS2 / low-sync MGS2, or an Arnoldi expand! with CGS / CGS2 / low-sync MGS / MGS2, on a SHORT
  * vector -- single-rank context, operator in the ELL format, factorization starting at column 0, at most "fused_step_max_rows" rows
  * (default 131072) and "fused_step_m_limit" basis vectors (default 0 = by vector length: 96 - 64 n / 1e5, at least 16; -1 = no limit but 128)
