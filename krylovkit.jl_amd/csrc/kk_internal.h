@@ -617,7 +617,7 @@ static inline bool kk_mgs_lowsync(kk_ctx ctx, int64_t ld_local, int m) {
     // that owns fewer CUs -- option "num_cus" -- scales them down with it.  Cross-rank context: the longest shard decides, and
     // the in-kernel reduction has to pay for its round trips -- kk_xs_pays)
     const int64_t ld = kk_dec_ld(ctx, ld_local);
-    const double share = (double)ctx->num_cus / 256.0;
+    const double share = (double)ctx->num_cus / (double)(ctx->dev_cus > 0 ? ctx->dev_cus : 256);   // (the thresholds were measured on the whole chip)
     if ((double)ld >= share * (double)ctx->panel_min_rows && kk_mgs_panel_eligible(ctx, ld_local)) {
         const int P = kk_mgs_panel_width(ctx, ld_local, false);
         // (gain per vector-step and multiple of the threshold = the basis traffic the panel kernel saves AT the threshold: 8 bytes per row x

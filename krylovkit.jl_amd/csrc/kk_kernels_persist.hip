@@ -622,8 +622,12 @@ __global__ __launch_bounds__(64) void k_xs_timing(kk_xs_dev xs, int* __restrict_
         if (!xs_allreduce(xs, (unsigned)r, 1, v, err, timeout_ticks, total)) ok = 0;
         v = readlane_d(total, 0) * 0.5;   // (the next partial depends on this total: no reduction can be issued ahead)
         if (r == 0) t0 = wall_clock64();
+        // a fabric on which a reduction takes milliseconds is not one to spin on: give the whole measurement 0.25 s (3.8 ms per reduction), then
+        // report failure -- kk_comm_init leaves the RCCL routes in charge (first contact with a real node must cost seconds at most, never minutes)
+        else if (wall_clock64() - t0 > 25000000ll) ok = 0;
     }
     const long long t1 = wall_clock64();
+    if (!ok && threadIdx.x == 0) xs_abort(xs);   // (a rank that stops measuring tells the others: they leave at once instead of waiting for its next partial)
     if (threadIdx.x == 0) { out[0] = ok; out[1] = t1 - t0; }
 }
 int kk_launch_xs_timing(kk_ctx ctx, const kk_xs_dev& xs, int nred, long long* out_dev) {
