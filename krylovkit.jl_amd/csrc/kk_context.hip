@@ -558,6 +558,8 @@ KK_API int kk_basis_info(kk_basis b, int64_t* n, int64_t* ld, int* capacity, voi
     if (capacity) *capacity = b->cap;
     if (dptr) {
         KK_TRY(norm_flush(b));   // whoever takes the raw pointer sees the residual itself, not its normalised form
+        ctx_public_touch(b);     // ... and may write through it: whatever was enqueued ahead for the slab is void
+        gram_touch(b, 0);
         *dptr = b->d;
     }
     return KK_OK;
